@@ -1,0 +1,643 @@
+/* evstore_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference's algorithms for the embedding
+ * lookup / EvLFU cache / interaction hot path.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library, and only as the checker.  The product path
+ * (ev-store-dlrm_amd/) never links, imports or falls back to it.
+ *
+ * Parity status: PINNED.  Every function here is checked in
+ * tests/test_oracle_golden.py against vectors produced by running the
+ * reference itself (tests/golden/make_golden.py imports the reference's
+ * Python; oracle/ref/ref_codec_dump.cpp links the reference's C++ decoders).
+ *
+ * Each function cites the reference file:line it restates (paths relative to
+ * /root/reference).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MAX_TABLES 64
+#define ORC_NBUCKET_MAX 65 /* buckets 0..n_tables */
+
+/* ------------------------------------------------------------------------ */
+/* a10: codecs, bytes -> fp32                                                */
+/* ------------------------------------------------------------------------ */
+
+/* mixed_precs_caching/evlfu_8.cpp:370-378  f = ((float)u / 254) * 2 - 1, all fp32 */
+void orc_decode_u8(const uint8_t *in, int64_t n, float *out) {
+    for (int64_t i = 0; i < n; i++) {
+        float v = (float)in[i];
+        v = v / 254;
+        v = v * 2;
+        out[i] = v - 1;
+    }
+}
+
+/* mixed_precs_caching/evlfu_4.hpp:46 (table), evlfu_4.cpp:319-341 (high nibble first).
+ * Index 15 is out of bounds in the reference; the encoder never emits it
+ * (script/reduce_precision.py:163).  It decodes to NaN here so a test can see it. */
+static const float k_u4_lut[16] = {1.0f, 0.8f, 0.6f, 0.4f, 0.0625f, 0.00390625f, 0.0000153f, 0.0f,
+                                   -0.0000153f, -0.00390625f, -0.0625f, -0.4f, -0.6f, -0.8f, -1.0f,
+                                   NAN};
+const float *orc_u4_lut(void) { return k_u4_lut; }
+
+void orc_decode_u4(const uint8_t *in, int64_t nbytes, float *out) {
+    for (int64_t i = 0; i < nbytes; i++) {
+        int lo = in[i] % 16;
+        int hi = (in[i] - lo) / 16;
+        out[2 * i + 0] = k_u4_lut[hi];
+        out[2 * i + 1] = k_u4_lut[lo];
+    }
+}
+
+/* mixed_precs_caching/evlfu_16.cpp:332-356.  The arithmetic mixes float and
+ * double exactly as the C++ does: (float)v * 0.00002 is a double product. */
+void orc_decode_u16(const uint16_t *in, int64_t n, float *out) {
+    for (int64_t i = 0; i < n; i++) {
+        uint16_t value = in[i];
+        if (value > 65000) {
+            float diff = ((float)(value - 65000)) / 100;
+            if (value % 2 == 1)
+                out[i] = (float)(-1 * (0.65 + diff));
+            else
+                out[i] = (float)(0.65 + diff);
+        } else {
+            out[i] = (float)((((float)value) * 0.00002) - 0.65);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* a11: encoders, value -> code (script/reduce_precision.py)                 */
+/* ------------------------------------------------------------------------ */
+
+/* script/reduce_precision.py:270  round(((x + 1)/2) * 254), Python round = half-to-even */
+int64_t orc_encode_u8(double x) { return (int64_t)nearbyint(((x + 1) / 2) * 254); }
+
+/* script/reduce_precision.py:26-51 convert_ev_float_to_ushort (int() truncates toward zero) */
+int64_t orc_encode_u16(double value) {
+    if (value < -0.65) {
+        int64_t leftover = (int64_t)(-100 * (0.65 + value));
+        if (leftover % 2 == 0) leftover += 1;
+        return 65000 + leftover;
+    } else if (value > 0.65) {
+        int64_t leftover = (int64_t)(100 * (value - 0.65));
+        if (leftover % 2 == 1) leftover -= 1;
+        return 65000 + leftover;
+    }
+    return (int64_t)((value + 0.65) / 1.3 * 65000);
+}
+
+/* script/reduce_precision.py:140-172 convert_to_4bit_int_posit */
+int64_t orc_encode_u4(double v) {
+    static const double pos[7] = {0.8, 0.6, 0.4, 0.25, 0.015, 0.00025, 0};
+    static const double neg[7] = {-1, -0.8, -0.6, -0.4, -0.25, -0.015, -0.00025};
+    if (v == 0) return 7;
+    if (v > 0) {
+        int code = 0;
+        for (int i = 0; i < 7; i++) {
+            if (v >= pos[i]) return code;
+            code++;
+        }
+        return -1;
+    }
+    if (v >= neg[6]) return 8;
+    int code = 15;
+    for (int i = 0; i < 7; i++) {
+        if (v < neg[i]) return code;
+        code--;
+    }
+    return -1;
+}
+
+void orc_encode_u8_arr(const double *x, int64_t n, int64_t *out) { for (int64_t i = 0; i < n; i++) out[i] = orc_encode_u8(x[i]); }
+void orc_encode_u16_arr(const double *x, int64_t n, int64_t *out) { for (int64_t i = 0; i < n; i++) out[i] = orc_encode_u16(x[i]); }
+void orc_encode_u4_arr(const double *x, int64_t n, int64_t *out) { for (int64_t i = 0; i < n; i++) out[i] = orc_encode_u4(x[i]); }
+
+/* ------------------------------------------------------------------------ */
+/* a1: EmbeddingBag(mode="sum") for one table                                */
+/* dlrm_s_pytorch.py:407-461 (per-table loop), :276 (nn.EmbeddingBag sum).   */
+/* offsets hold bag STARTS only; the last bag runs to nnz.  per-row weights   */
+/* (v_W_l[k].gather(0, idx), :426) multiply each row before the add.          */
+/* Summation order: index order, fp32, multiply and add not fused.           */
+/* codec: 32 (fp32 rows), 16, 8, 4 -- rows decoded then summed (a9/a10).      */
+/* returns 0, or -1 on an out-of-range index / malformed offsets.            */
+/* ------------------------------------------------------------------------ */
+static void decode_row(const void *W, int codec, int d, int64_t row, float *tmp) {
+    switch (codec) {
+    case 32: memcpy(tmp, (const float *)W + row * d, sizeof(float) * (size_t)d); break;
+    case 16: orc_decode_u16((const uint16_t *)W + row * d, d, tmp); break;
+    case 8: orc_decode_u8((const uint8_t *)W + row * d, d, tmp); break;
+    case 4: orc_decode_u4((const uint8_t *)W + row * (d / 2), d / 2, tmp); break;
+    }
+}
+
+int orc_embedding_bag_sum(const void *W, int codec, int64_t n_rows, int d, const int64_t *idx,
+                          int64_t nnz, const int64_t *off, int64_t B, const float *row_weights,
+                          float *out /* B*d */) {
+    float tmp[1024];
+    if (d > 1024) return -2;
+    for (int64_t b = 0; b < B; b++) {
+        int64_t s = off[b], e = (b + 1 < B) ? off[b + 1] : nnz;
+        if (s < 0 || e < s || e > nnz) return -1;
+        float *o = out + b * d;
+        for (int c = 0; c < d; c++) o[c] = 0.0f;
+        for (int64_t j = s; j < e; j++) {
+            int64_t r = idx[j];
+            if (r < 0 || r >= n_rows) return -1;
+            decode_row(W, codec, d, r, tmp);
+            if (row_weights) {
+                float w = row_weights[r];
+                for (int c = 0; c < d; c++) {
+                    float p = tmp[c] * w;
+                    o[c] = o[c] + p;
+                }
+            } else {
+                for (int c = 0; c < d; c++) o[c] = o[c] + tmp[c];
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* a3: interact_features, arch_interaction_op="dot"                          */
+/* dlrm_s_pytorch.py:483-516: T=(B,F,d); Z=T.T^T; keep (i,j) with j<i        */
+/* (j<=i when arch_interaction_itself) in row-major order; R=[x | Zflat].    */
+/* Dot products are accumulated in double and rounded once: a rounding-       */
+/* order-free reference; compare with rtol 1e-5 (BASELINE.json north_star).  */
+/* ------------------------------------------------------------------------ */
+void orc_interact_dot(const float *T, int64_t B, int F, int d, int itself, float *R) {
+    int off = itself ? 1 : 0;
+    int64_t P = 0;
+    for (int i = 0; i < F; i++) P += i + off;
+    for (int64_t b = 0; b < B; b++) {
+        const float *t = T + b * (int64_t)F * d;
+        float *r = R + b * (d + P);
+        for (int c = 0; c < d; c++) r[c] = t[c];
+        int64_t p = d;
+        for (int i = 0; i < F; i++)
+            for (int j = 0; j < i + off; j++) {
+                double acc = 0;
+                for (int c = 0; c < d; c++) acc += (double)t[i * d + c] * (double)t[j * d + c];
+                r[p++] = (float)acc;
+            }
+    }
+}
+
+/* fp32 k-ordered fused chain: what v_mfma_f32_16x16x4_f32 computes when fed
+ * k in natural order (MI355X guide, "FP32-input MFMA" numerics). Kept for
+ * bounding the GPU kernel's rounding against the double version above. */
+void orc_interact_dot_f32chain(const float *T, int64_t B, int F, int d, int itself, float *R) {
+    int off = itself ? 1 : 0;
+    int64_t P = 0;
+    for (int i = 0; i < F; i++) P += i + off;
+    for (int64_t b = 0; b < B; b++) {
+        const float *t = T + b * (int64_t)F * d;
+        float *r = R + b * (d + P);
+        for (int c = 0; c < d; c++) r[c] = t[c];
+        int64_t p = d;
+        for (int i = 0; i < F; i++)
+            for (int j = 0; j < i + off; j++) {
+                float acc = 0;
+                for (int c = 0; c < d; c++) acc = fmaf(t[i * d + c], t[j * d + c], acc);
+                r[p++] = acc;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* key -> entry hash map shared by the three policies                        */
+/* keys: (table_id_1based << 32) | row  -- the reference's "T-R" strings      */
+/* (cache_algo/EvLFU_C1.py:108) carry exactly this pair.                      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t *keys; /* 0 = empty */
+    int32_t *vals;
+    uint64_t mask;
+    int64_t count;
+} orc_map;
+
+static uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+static void map_init(orc_map *m, int64_t cap) {
+    uint64_t n = 16;
+    while ((int64_t)n < cap * 2 + 8) n <<= 1;
+    m->keys = (uint64_t *)calloc(n, sizeof(uint64_t));
+    m->vals = (int32_t *)malloc(n * sizeof(int32_t));
+    m->mask = n - 1;
+    m->count = 0;
+}
+static void map_free(orc_map *m) { free(m->keys); free(m->vals); }
+static int32_t map_get(const orc_map *m, uint64_t key) {
+    uint64_t i = mix64(key) & m->mask;
+    while (m->keys[i]) {
+        if (m->keys[i] == key) return m->vals[i];
+        i = (i + 1) & m->mask;
+    }
+    return -1;
+}
+static void map_put(orc_map *m, uint64_t key, int32_t v) {
+    uint64_t i = mix64(key) & m->mask;
+    while (m->keys[i] && m->keys[i] != key) i = (i + 1) & m->mask;
+    if (!m->keys[i]) m->count++;
+    m->keys[i] = key;
+    m->vals[i] = v;
+}
+static void map_del(orc_map *m, uint64_t key) { /* linear probing, backward-shift delete */
+    uint64_t i = mix64(key) & m->mask;
+    while (m->keys[i] && m->keys[i] != key) i = (i + 1) & m->mask;
+    if (!m->keys[i]) return;
+    m->count--;
+    uint64_t j = i;
+    for (;;) {
+        j = (j + 1) & m->mask;
+        if (!m->keys[j]) break;
+        uint64_t h = mix64(m->keys[j]) & m->mask;
+        /* can entry j move into hole i?  yes iff h is cyclically outside (i, j] */
+        int between = (i <= j) ? (h > i && h <= j) : (h > i || h <= j);
+        if (!between) {
+            m->keys[i] = m->keys[j];
+            m->vals[i] = m->vals[j];
+            i = j;
+        }
+    }
+    m->keys[i] = 0;
+}
+
+/* intrusive FIFO lists over entry indices (append tail / pop head / unlink) */
+typedef struct { int32_t head, tail; int64_t len; } orc_list;
+static void list_init(orc_list *l) { l->head = l->tail = -1; l->len = 0; }
+static void list_append(orc_list *l, int32_t *prev, int32_t *next, int32_t e) {
+    prev[e] = l->tail; next[e] = -1;
+    if (l->tail >= 0) next[l->tail] = e; else l->head = e;
+    l->tail = e; l->len++;
+}
+static void list_unlink(orc_list *l, int32_t *prev, int32_t *next, int32_t e) {
+    if (prev[e] >= 0) next[prev[e]] = next[e]; else l->head = next[e];
+    if (next[e] >= 0) prev[next[e]] = prev[e]; else l->tail = prev[e];
+    l->len--;
+}
+
+/* miss source: in-memory tables (fp32, row-major, dim floats per row) = what
+ * emb_storage/file_read.py:27-33 returns for (tableId,rowId). */
+typedef struct {
+    int n_tables, dim;
+    const float *tables[ORC_MAX_TABLES];
+} orc_store;
+
+static void store_fetch(const orc_store *s, int table1, int64_t row, float *out) {
+    memcpy(out, s->tables[table1 - 1] + row * s->dim, sizeof(float) * (size_t)s->dim);
+}
+
+/* ------------------------------------------------------------------------ */
+/* a6: EvLFU  (cache_algo/EvLFU_C1.py:21-166)                                */
+/*   flush_rate / perfect_item_cap: 0.3 / 0.95 in Python (:18-19) and in     */
+/*   mixed_precs_caching (evlfu_8.hpp:50-51); 0.4 / 1.0 in the Cython build  */
+/*   (cache_algo/EvLFU_C1_Cython/EvLFU.cpp:12-13).                           */
+/*   flush_extra: Python flushes int(rate*cap)+1 keys (:40); the C++ flushes */
+/*   int(rate*cap) (evlfu_8.cpp:256).                                        */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int64_t cap;
+    int n_tables, dim;
+    int min_c1;
+    int64_t n_perfect, max_perfect;
+    double flush_rate;
+    int flush_extra;
+    int64_t n_flush, n_evict;
+    orc_map map;
+    uint64_t *ekey;
+    int32_t *eagg, *prev, *next;
+    int32_t *free_stack;
+    int64_t n_free;
+    float *vals;
+    orc_list lists[ORC_NBUCKET_MAX];
+    orc_store store;
+} orc_evlfu;
+
+orc_evlfu *orc_evlfu_new(int64_t cap, int n_tables, int dim, double flush_rate,
+                         double perfect_item_cap, int flush_extra) {
+    if (n_tables > ORC_MAX_TABLES || cap < 1) return NULL;
+    orc_evlfu *c = (orc_evlfu *)calloc(1, sizeof(orc_evlfu));
+    c->cap = cap; c->n_tables = n_tables; c->dim = dim; c->min_c1 = 0;
+    c->flush_rate = flush_rate; c->flush_extra = flush_extra;
+    c->max_perfect = (int64_t)(cap * perfect_item_cap); /* EvLFU_C1.py:30 int(cap*0.95) */
+    map_init(&c->map, cap);
+    c->ekey = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+    c->eagg = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->prev = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->next = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->free_stack = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->vals = (float *)malloc(sizeof(float) * cap * dim);
+    for (int64_t i = 0; i < cap; i++) c->free_stack[i] = (int32_t)(cap - 1 - i);
+    c->n_free = cap;
+    for (int b = 0; b <= n_tables; b++) list_init(&c->lists[b]);
+    c->store.n_tables = n_tables; c->store.dim = dim;
+    return c;
+}
+void orc_evlfu_free(orc_evlfu *c) {
+    if (!c) return;
+    map_free(&c->map);
+    free(c->ekey); free(c->eagg); free(c->prev); free(c->next); free(c->free_stack); free(c->vals);
+    free(c);
+}
+void orc_evlfu_set_tables(orc_evlfu *c, const float *const *tables) {
+    for (int k = 0; k < c->n_tables; k++) c->store.tables[k] = tables[k];
+}
+
+static void evlfu_drop(orc_evlfu *c, int32_t e) { /* vals_C1.pop(key) */
+    map_del(&c->map, c->ekey[e]);
+    c->free_stack[c->n_free++] = e;
+}
+
+/* EvLFU_C1.py:32-63 set(key, value, agg_hit) */
+static int evlfu_set(orc_evlfu *c, uint64_t key, const float *value, int agg_hit) {
+    int top = c->n_tables;
+    if (c->n_perfect >= c->max_perfect) { /* :36-44 flush the oldest of bucket 26 */
+        int64_t n = (int64_t)(c->flush_rate * c->cap) + c->flush_extra;
+        for (int64_t i = 0; i < n; i++) {
+            int32_t e = c->lists[top].head;
+            if (e < 0) return -1; /* Python would raise IndexError on pop(0) */
+            list_unlink(&c->lists[top], c->prev, c->next, e);
+            evlfu_drop(c, e);
+        }
+        c->n_perfect = c->lists[top].len;
+        c->n_flush++;
+    } else if (c->map.count >= c->cap) { /* :47-56 evict FIFO-oldest of lowest non-empty bucket */
+        while (c->lists[c->min_c1].len == 0) {
+            c->min_c1 += 1;
+            if (c->min_c1 > top) c->min_c1 = 1;
+        }
+        int32_t e = c->lists[c->min_c1].head;
+        list_unlink(&c->lists[c->min_c1], c->prev, c->next, e);
+        evlfu_drop(c, e);
+        c->n_evict++;
+    }
+    if (c->n_free <= 0) return -2;
+    int32_t existing = map_get(&c->map, key);
+    int32_t e;
+    if (existing >= 0) {
+        /* vals_C1[key] = ... overwrites; lists_C1 would then hold the key twice.
+         * Cannot happen through request(): a present key takes the hit branch. */
+        return -3;
+    }
+    e = c->free_stack[--c->n_free];
+    c->ekey[e] = key; c->eagg[e] = agg_hit;
+    memcpy(c->vals + (int64_t)e * c->dim, value, sizeof(float) * (size_t)c->dim);
+    map_put(&c->map, key, e);
+    list_append(&c->lists[agg_hit], c->prev, c->next, e);
+    if (agg_hit < c->min_c1) c->min_c1 = agg_hit; /* :62-63 */
+    return 0;
+}
+
+/* EvLFU_C1.py:97-166 request_to_ev_lfu.  rows: n_tables int32 (0-based row ids,
+ * table = position).  hit_out: n_tables bytes.  out: n_tables*dim floats.
+ * approx_thres > 0 enables the approximate mode (:122-125,:142-152).
+ * returns agg_hit, or < 0 on an internal error. */
+int orc_evlfu_request(orc_evlfu *c, const int32_t *rows, uint8_t *hit_out, float *out,
+                      int approx_thres) {
+    int T = c->n_tables, dim = c->dim;
+    int agg_hit = 0;
+    uint64_t keys[ORC_MAX_TABLES];
+    uint8_t hit[ORC_MAX_TABLES];
+    for (int i = 0; i < T; i++) { /* :105-120 probe */
+        keys[i] = ((uint64_t)(i + 1) << 32) | (uint32_t)rows[i];
+        hit[i] = map_get(&c->map, keys[i]) >= 0;
+        agg_hit += hit[i];
+    }
+    int pick_random = (approx_thres > 0 && agg_hit >= approx_thres);
+    float miss_vals[ORC_MAX_TABLES][256];
+    if (dim > 256) return -9;
+    if (!pick_random) /* :128 fetch all missing at once */
+        for (int i = 0; i < T; i++)
+            if (!hit[i]) store_fetch(&c->store, i + 1, rows[i], miss_vals[i]);
+    const float *last_val = NULL; /* random_ev_value: last hit's vector (:141) */
+    for (int i = 0; i < T; i++) { /* :135-161 update */
+        float *o = out + (int64_t)i * dim;
+        if (hit[i]) {
+            int32_t e = map_get(&c->map, keys[i]); /* update() -> update_agg_hit (:65-78) */
+            if (e >= 0) {
+                if (c->eagg[e] < agg_hit) {
+                    list_unlink(&c->lists[c->eagg[e]], c->prev, c->next, e);
+                    list_append(&c->lists[agg_hit], c->prev, c->next, e);
+                    c->eagg[e] = agg_hit;
+                }
+                memcpy(o, c->vals + (int64_t)e * dim, sizeof(float) * (size_t)dim);
+            } else { /* :90-94 kicked out while inserting a previous key: re-fetch + set */
+                float tmp[256];
+                store_fetch(&c->store, i + 1, rows[i], tmp);
+                int rc = evlfu_set(c, keys[i], tmp, agg_hit);
+                if (rc) return rc - 10;
+                memcpy(o, tmp, sizeof(float) * (size_t)dim);
+            }
+            last_val = o;
+        } else if (pick_random) { /* :142-152 miss served from the previous hit, reported as hit */
+            if (last_val) memcpy(o, last_val, sizeof(float) * (size_t)dim);
+            else memset(o, 0, sizeof(float) * (size_t)dim); /* reference: 36 random.uniform draws */
+            hit[i] = 1;
+        } else {
+            /* update(key, ..., missing_value): a duplicate key inserted earlier in this same
+             * request is found by update_agg_hit and returned without a second insert */
+            int32_t e = map_get(&c->map, keys[i]);
+            if (e >= 0) {
+                if (c->eagg[e] < agg_hit) {
+                    list_unlink(&c->lists[c->eagg[e]], c->prev, c->next, e);
+                    list_append(&c->lists[agg_hit], c->prev, c->next, e);
+                    c->eagg[e] = agg_hit;
+                }
+                memcpy(o, c->vals + (int64_t)e * dim, sizeof(float) * (size_t)dim);
+            } else {
+                int rc = evlfu_set(c, keys[i], miss_vals[i], agg_hit);
+                if (rc) return rc - 20;
+                memcpy(o, miss_vals[i], sizeof(float) * (size_t)dim);
+            }
+        }
+    }
+    if (agg_hit == T) c->n_perfect = c->lists[T].len; /* :163-165 */
+    if (hit_out) memcpy(hit_out, hit, (size_t)T);
+    return agg_hit;
+}
+
+/* state dump: triples (bucket, table1, row) in bucket order then FIFO order */
+int64_t orc_evlfu_dump(const orc_evlfu *c, int64_t *out, int64_t max_triples) {
+    int64_t n = 0;
+    for (int b = 0; b <= c->n_tables; b++)
+        for (int32_t e = c->lists[b].head; e >= 0; e = c->next[e]) {
+            if (n < max_triples) {
+                out[3 * n + 0] = b;
+                out[3 * n + 1] = (int64_t)(c->ekey[e] >> 32);
+                out[3 * n + 2] = (int64_t)(c->ekey[e] & 0xffffffffu);
+            }
+            n++;
+        }
+    return n;
+}
+/* [min_C1, n_perfect, len(vals), n_flush, n_evict] */
+void orc_evlfu_state(const orc_evlfu *c, int64_t *out5) {
+    out5[0] = c->min_c1; out5[1] = c->n_perfect; out5[2] = c->map.count; out5[3] = c->n_flush;
+    out5[4] = c->n_evict;
+}
+
+/* ------------------------------------------------------------------------ */
+/* a7: LRU  (cache_algo/LRU.py:14-64): per key, in table order: hit -> move  */
+/* to MRU end; miss -> fetch, evict LRU head if len >= cap, insert at end.   */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int64_t cap; int n_tables, dim;
+    orc_map map; uint64_t *ekey; int32_t *prev, *next, *free_stack; int64_t n_free;
+    float *vals; orc_list order; orc_store store;
+} orc_lru;
+
+orc_lru *orc_lru_new(int64_t cap, int n_tables, int dim) {
+    if (n_tables > ORC_MAX_TABLES || cap < 1) return NULL;
+    orc_lru *c = (orc_lru *)calloc(1, sizeof(orc_lru));
+    c->cap = cap; c->n_tables = n_tables; c->dim = dim;
+    map_init(&c->map, cap);
+    c->ekey = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+    c->prev = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->next = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->free_stack = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->vals = (float *)malloc(sizeof(float) * cap * dim);
+    for (int64_t i = 0; i < cap; i++) c->free_stack[i] = (int32_t)(cap - 1 - i);
+    c->n_free = cap; list_init(&c->order);
+    c->store.n_tables = n_tables; c->store.dim = dim;
+    return c;
+}
+void orc_lru_free(orc_lru *c) {
+    if (!c) return;
+    map_free(&c->map); free(c->ekey); free(c->prev); free(c->next); free(c->free_stack); free(c->vals); free(c);
+}
+void orc_lru_set_tables(orc_lru *c, const float *const *tables) {
+    for (int k = 0; k < c->n_tables; k++) c->store.tables[k] = tables[k];
+}
+int orc_lru_request(orc_lru *c, const int32_t *rows, uint8_t *hit_out, float *out) {
+    int agg = 0;
+    for (int i = 0; i < c->n_tables; i++) {
+        uint64_t key = ((uint64_t)(i + 1) << 32) | (uint32_t)rows[i];
+        float *o = out + (int64_t)i * c->dim;
+        int32_t e = map_get(&c->map, key);
+        if (e >= 0) { /* LRU.py:24-28 */
+            list_unlink(&c->order, c->prev, c->next, e);
+            list_append(&c->order, c->prev, c->next, e);
+            memcpy(o, c->vals + (int64_t)e * c->dim, sizeof(float) * (size_t)c->dim);
+            hit_out[i] = 1; agg++;
+        } else { /* :30-34 -> set() :14-20 */
+            store_fetch(&c->store, i + 1, rows[i], o);
+            if (c->map.count >= c->cap) {
+                int32_t v = c->order.head;
+                list_unlink(&c->order, c->prev, c->next, v);
+                map_del(&c->map, c->ekey[v]);
+                c->free_stack[c->n_free++] = v;
+            }
+            e = c->free_stack[--c->n_free];
+            c->ekey[e] = key;
+            memcpy(c->vals + (int64_t)e * c->dim, o, sizeof(float) * (size_t)c->dim);
+            map_put(&c->map, key, e);
+            list_append(&c->order, c->prev, c->next, e);
+            hit_out[i] = 0;
+        }
+    }
+    return agg;
+}
+int64_t orc_lru_dump(const orc_lru *c, int64_t *out, int64_t max_pairs) {
+    int64_t n = 0;
+    for (int32_t e = c->order.head; e >= 0; e = c->next[e]) {
+        if (n < max_pairs) { out[2 * n] = (int64_t)(c->ekey[e] >> 32); out[2 * n + 1] = (int64_t)(c->ekey[e] & 0xffffffffu); }
+        n++;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* a7: LFU  (cache_algo/LFU.py:12-95): FIFO within a frequency; a hit moves  */
+/* the key from freq f to f+1; a miss evicts the head of least_freq's list.   */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int64_t cap; int n_tables, dim; int64_t least_freq;
+    orc_map map; uint64_t *ekey; int64_t *efreq; int32_t *prev, *next, *free_stack; int64_t n_free;
+    float *vals; orc_list *freq_lists; int64_t n_freq_lists; orc_store store;
+} orc_lfu;
+
+static void lfu_grow(orc_lfu *c, int64_t f) {
+    if (f < c->n_freq_lists) return;
+    int64_t n = c->n_freq_lists ? c->n_freq_lists : 16;
+    while (n <= f) n *= 2;
+    c->freq_lists = (orc_list *)realloc(c->freq_lists, sizeof(orc_list) * n);
+    for (int64_t i = c->n_freq_lists; i < n; i++) list_init(&c->freq_lists[i]);
+    c->n_freq_lists = n;
+}
+orc_lfu *orc_lfu_new(int64_t cap, int n_tables, int dim) {
+    if (n_tables > ORC_MAX_TABLES || cap < 1) return NULL;
+    orc_lfu *c = (orc_lfu *)calloc(1, sizeof(orc_lfu));
+    c->cap = cap; c->n_tables = n_tables; c->dim = dim; c->least_freq = 1;
+    map_init(&c->map, cap);
+    c->ekey = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+    c->efreq = (int64_t *)malloc(sizeof(int64_t) * cap);
+    c->prev = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->next = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->free_stack = (int32_t *)malloc(sizeof(int32_t) * cap);
+    c->vals = (float *)malloc(sizeof(float) * cap * dim);
+    for (int64_t i = 0; i < cap; i++) c->free_stack[i] = (int32_t)(cap - 1 - i);
+    c->n_free = cap; lfu_grow(c, 2);
+    c->store.n_tables = n_tables; c->store.dim = dim;
+    return c;
+}
+void orc_lfu_free(orc_lfu *c) {
+    if (!c) return;
+    map_free(&c->map); free(c->ekey); free(c->efreq); free(c->prev); free(c->next);
+    free(c->free_stack); free(c->vals); free(c->freq_lists); free(c);
+}
+void orc_lfu_set_tables(orc_lfu *c, const float *const *tables) {
+    for (int k = 0; k < c->n_tables; k++) c->store.tables[k] = tables[k];
+}
+int orc_lfu_request(orc_lfu *c, const int32_t *rows, uint8_t *hit_out, float *out) {
+    int agg = 0;
+    for (int i = 0; i < c->n_tables; i++) {
+        uint64_t key = ((uint64_t)(i + 1) << 32) | (uint32_t)rows[i];
+        float *o = out + (int64_t)i * c->dim;
+        int32_t e = map_get(&c->map, key);
+        if (e >= 0) { /* LFU.py:53-60 -> _update :19-34 */
+            int64_t f = c->efreq[e];
+            list_unlink(&c->freq_lists[f], c->prev, c->next, e);
+            if (c->freq_lists[c->least_freq].len == 0) c->least_freq += 1;
+            c->efreq[e] = f + 1;
+            lfu_grow(c, f + 1);
+            list_append(&c->freq_lists[f + 1], c->prev, c->next, e);
+            memcpy(o, c->vals + (int64_t)e * c->dim, sizeof(float) * (size_t)c->dim);
+            hit_out[i] = 1; agg++;
+        } else { /* :61-65 -> set() :36-51 */
+            store_fetch(&c->store, i + 1, rows[i], o);
+            if (c->map.count >= c->cap) {
+                int32_t v = c->freq_lists[c->least_freq].head;
+                if (v < 0) return -1;
+                list_unlink(&c->freq_lists[c->least_freq], c->prev, c->next, v);
+                map_del(&c->map, c->ekey[v]);
+                c->free_stack[c->n_free++] = v;
+            }
+            e = c->free_stack[--c->n_free];
+            c->ekey[e] = key; c->efreq[e] = 1;
+            memcpy(c->vals + (int64_t)e * c->dim, o, sizeof(float) * (size_t)c->dim);
+            map_put(&c->map, key, e);
+            list_append(&c->freq_lists[1], c->prev, c->next, e);
+            c->least_freq = 1;
+            hit_out[i] = 0;
+        }
+    }
+    return agg;
+}
+int64_t orc_lfu_dump(const orc_lfu *c, int64_t *out, int64_t max_triples) {
+    int64_t n = 0;
+    for (int64_t f = 1; f < c->n_freq_lists; f++)
+        for (int32_t e = c->freq_lists[f].head; e >= 0; e = c->next[e]) {
+            if (n < max_triples) { out[3 * n] = f; out[3 * n + 1] = (int64_t)(c->ekey[e] >> 32); out[3 * n + 2] = (int64_t)(c->ekey[e] & 0xffffffffu); }
+            n++;
+        }
+    return n;
+}

@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference).  Nothing from the
+reference travels: this script records inputs and the reference's outputs as
+plain numpy arrays (.npz).  Re-run with:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is pinned:
+  * dlrm_s_pytorch.DLRM_Net.apply_emb / interact_features  (dlrm_s_pytorch.py:407, :483)
+  * dlrm_data_pytorch.generate_dist_input_batch            (dlrm_data_pytorch.py:1011)
+  * cache_algo/EvLFU_C1.py, LRU.py, LFU.py hit traces       (EvLFU_C1.py:97, LRU.py:38, LFU.py:69)
+  * emb_storage/file_read.py + mmap_file_read.py row reads  (file_read.py:27, mmap_file_read.py:32)
+  * script/reduce_precision.py encoders                     (reduce_precision.py:26,:140,:270)
+"""
+import os
+import sys
+import types
+import struct
+import tempfile
+import hashlib
+import random
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    import torch  # noqa: F401
+
+    class _SW:  # torch.utils.tensorboard.SummaryWriter stand-in (dlrm_s_pytorch.py:101)
+        def __init__(self, *a, **k):
+            pass
+
+    _stub("torch.utils.tensorboard", SummaryWriter=_SW)
+    _stub("pyrocksdb")   # storage_rocksdb.py:1 (third-party, absent)
+    _stub("EvLFU")       # storage_manager.py:18 (cython .so is cpython-36 only)
+    for p in (REF, os.path.join(REF, "script"), os.path.join(REF, "emb_storage"),
+              os.path.join(REF, "cache_algo")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    cwd = os.getcwd()
+    os.chdir(REF)  # EvLFU_C1.py appends the relative path 'emb_storage'
+    try:
+        import dlrm_s_pytorch as D
+        import dlrm_data_pytorch as DP
+        import storage_manager as SM
+        import file_read as FR
+        import mmap_file_read as MFR
+        import EvLFU_C1, LRU, LFU
+    finally:
+        os.chdir(cwd)
+    return D, DP, SM, FR, MFR, EvLFU_C1, LRU, LFU
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# --------------------------------------------------------------------------
+# a1/a3: apply_emb + interact_features
+# --------------------------------------------------------------------------
+def gen_dlrm_case(D, DP, name, ln_emb, m_spa, B, n_idx, seed, itself=False,
+                  weighted=False, criteo_layout=False, store_tables=True):
+    import torch
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    ln_emb = np.asarray(ln_emb)
+    T = len(ln_emb)
+    m_den = 13
+    ln_bot = np.array([m_den, 32, m_spa])
+    F = T + 1
+    n_int = (F * (F + 1)) // 2 if itself else (F * (F - 1)) // 2
+    ln_top = np.array([n_int + m_spa, 16, 1])
+    # data first, then the model: same RNG draw order as run() (dlrm_s_pytorch.py:1178 then :1326)
+    if criteo_layout:
+        # collate_wrapper_criteo_offset (dlrm_data_pytorch.py:397-410): one index per (table, sample)
+        X = torch.tensor(np.random.rand(B, m_den).astype(np.float32))
+        lS_i = torch.stack([torch.tensor(np.random.randint(0, n, size=B), dtype=torch.long)
+                            for n in ln_emb])
+        lS_o = torch.stack([torch.tensor(range(B)) for _ in range(T)])
+    else:
+        X, lS_o_l, lS_i = DP.generate_dist_input_batch(
+            m_den, ln_emb, B, n_idx, False, "uniform", 0, 1, -1, 1)
+        lS_o = torch.stack(lS_o_l)  # collate_wrapper_random_offset (dlrm_data_pytorch.py:791)
+    dlrm = D.DLRM_Net(
+        m_spa, ln_emb, ln_bot, ln_top,
+        arch_interaction_op="dot", arch_interaction_itself=itself,
+        sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, ndevices=-1,
+        weighted_pooling=("fixed" if weighted else None))
+    if weighted:
+        # reference initialises v_W_l to ones (dlrm_s_pytorch.py:293); use non-trivial
+        # per-row weights so the gather of weights is actually exercised
+        for k in range(T):
+            dlrm.v_W_l[k] = torch.tensor(
+                np.random.uniform(0.5, 1.5, size=int(ln_emb[k])).astype(np.float32))
+    with torch.no_grad():
+        x = dlrm.apply_mlp(X, dlrm.bot_l)
+        ly = dlrm.apply_emb(lS_o, lS_i, dlrm.emb_l, dlrm.v_W_l)
+        R = dlrm.interact_features(x, ly)
+        Z = dlrm.apply_mlp(R, dlrm.top_l)
+    out = {
+        "ln_emb": ln_emb.astype(np.int64), "m_spa": np.int64(m_spa), "B": np.int64(B),
+        "itself": np.int64(itself), "seed": np.int64(seed),
+        "X": X.numpy(), "x": x.numpy(), "R": R.numpy(), "Z": Z.numpy(),
+        "lS_o": lS_o.numpy().astype(np.int64),
+        "ly": np.stack([v.numpy() for v in ly]),
+    }
+    if criteo_layout:
+        out["lS_i_stacked"] = lS_i.numpy().astype(np.int64)
+    else:
+        out["lS_i_cat"] = np.concatenate([v.numpy() for v in lS_i]).astype(np.int64)
+        out["lS_i_nnz"] = np.array([v.numel() for v in lS_i], dtype=np.int64)
+    tables = [e.weight.detach().numpy() for e in dlrm.emb_l]
+    out["tables_sha256"] = np.array([sha(t) for t in tables])
+    if store_tables:
+        out["tables_cat"] = np.concatenate([t.reshape(-1) for t in tables])
+    if weighted:
+        out["vW_cat"] = np.concatenate([w.numpy() for w in dlrm.v_W_l])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+# --------------------------------------------------------------------------
+# a6/a7/a13: cache policies over the file/mmap readers
+# --------------------------------------------------------------------------
+KAGGLE_LN = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593,
+             3194, 27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+
+
+def make_bin_tables(root, n_rows, seed):
+    """Write ev-table-{1..26}.bin fp32 LE raw (script/convert_ev_to_binary.py:58-69)."""
+    rs = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "binary"), exist_ok=True)
+    tabs = []
+    for k, n in enumerate(n_rows):
+        w = rs.uniform(-np.sqrt(1.0 / n), np.sqrt(1.0 / n), size=(n, 36)).astype(np.float32)
+        w.tofile(os.path.join(root, "binary", "ev-table-%d.bin" % (k + 1)))
+        tabs.append(w)
+    return tabs
+
+
+def zipf_stream(n_rows, n_req, seed, alpha=1.2, n_hot=40, p_hot=0.35, distinct_hot=False):
+    """Request stream: Zipf per table + a set of hot whole requests that repeat
+    (whole-request repeats are what drives keys into bucket 26 and triggers flush)."""
+    rs = np.random.RandomState(seed)
+    perms = [rs.permutation(n) for n in n_rows]
+    def one():
+        return [int(perms[k][min(rs.zipf(alpha) - 1, n - 1)]) for k, n in enumerate(n_rows)]
+    hot = [one() for _ in range(n_hot)]
+    if distinct_hot:  # no key shared between hot requests (tables must have >= n_hot rows)
+        hot = [[int(perms[k][j]) for k in range(len(n_rows))] for j in range(n_hot)]
+    reqs = []
+    if distinct_hot:  # cold start: each hot request twice -> all its keys reach bucket 26
+        for h in hot:
+            reqs += [h, h]
+    for _ in range(n_req - len(reqs)):
+        if rs.rand() < p_hot:
+            reqs.append(hot[rs.randint(n_hot)])
+        else:
+            reqs.append(one())
+    return np.asarray(reqs, dtype=np.int32)
+
+
+FLUSH_CAPS = (79, 80, 82)
+
+
+def reset_evlfu(E):
+    E.cap_C1 = -1; E.min_C1 = 0; E.vals_C1 = dict(); E.lists_C1 = dict()
+    E.n_perfect_item_C1 = 0; E.max_perfect_item_C1 = 0
+
+
+def reset_lru(L):
+    import collections
+    L.cap = -1; L.LRUCache = collections.OrderedDict()
+
+
+def reset_lfu(L):
+    L.cap = -1; L.least_freq = 1; L.node_for_freq.clear(); L.node_for_key.clear()
+
+
+def key_to_pair(key):
+    t, r = key.split("-")
+    return (int(t), int(r))
+
+
+def gen_cache_traces(SM, FR, MFR, EvLFU_C1, LRU, LFU):
+    import io, contextlib
+    n_rows = [min(n, 600) for n in KAGGLE_LN]
+    tmp = tempfile.mkdtemp(prefix="evs_golden_")
+    tabs = make_bin_tables(tmp, n_rows, seed=7)
+    reqs_main = zipf_stream(n_rows, 1500, seed=11)
+    # few hot whole-requests, repeated often: bucket 26 fills past 0.95*cap -> flush path
+    reqs_flush = zipf_stream(n_rows, 1200, seed=13, n_hot=3, p_hot=0.7, distinct_hot=True)
+    out = {"n_rows": np.asarray(n_rows, np.int64), "table_seed": np.int64(7),
+           "requests": reqs_main, "requests_flush": reqs_flush}
+
+    # a13: file and mmap readers return the same 36 floats as the table rows
+    with contextlib.redirect_stdout(io.StringIO()):
+        FR.open_files_as_binary(tmp)
+        MFR.open_files_as_binary(tmp)
+    probe = [(1, 0), (3, 599), (9, 2), (26, 17), (12, 333)]
+    rows_f = np.array([FR.get(t, r) for t, r in probe], dtype=np.float32)
+    rows_m = np.array([MFR.get(t, r) for t, r in probe], dtype=np.float32)
+    for (t, r), a, b in zip(probe, rows_f, rows_m):
+        assert np.array_equal(a, tabs[t - 1][r]) and np.array_equal(b, tabs[t - 1][r])
+    out["reader_probe"] = np.asarray(probe, np.int64)
+    out["reader_rows"] = rows_f
+
+    SM.storage_type = SM.EmbStorage.FILEPY
+    for algo, mod, reset, req_fn in (
+            ("evlfu", EvLFU_C1, reset_evlfu, "request_to_ev_lfu"),
+            ("lru", LRU, reset_lru, "request_to_lru"),
+            ("lfu", LFU, reset_lfu, "request_to_lfu")):
+        for cap in (64, 300, 768, 2000) + FLUSH_CAPS:
+            reqs = reqs_flush if cap in FLUSH_CAPS else reqs_main
+            reset(mod)
+            random.seed(0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                mod.init(cap)
+            hits = np.zeros((len(reqs), 26), dtype=np.bool_)
+            nflush = 0
+            for i, rq in enumerate(reqs):
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    h, vals = getattr(mod, req_fn)([int(v) for v in rq], False)
+                nflush += buf.getvalue().count("flushing!")
+                hits[i] = h
+                for k in range(26):  # values are always the true rows (bit-exact pass-through)
+                    v = vals[k].detach().numpy().reshape(-1)
+                    assert np.array_equal(v, tabs[k][rq[k]]), (algo, cap, i, k)
+            tag = "%s_cap%d" % (algo, cap)
+            out[tag + "_hits"] = np.packbits(hits, axis=1)
+            if algo == "evlfu":
+                buckets = []
+                for b in range(27):
+                    for key in mod.lists_C1[b]:
+                        buckets.append((b,) + key_to_pair(key))
+                out[tag + "_final_buckets"] = np.asarray(buckets, np.int64).reshape(-1, 3)
+                out[tag + "_state"] = np.asarray(
+                    [mod.min_C1, mod.n_perfect_item_C1, len(mod.vals_C1), nflush], np.int64)
+            elif algo == "lru":
+                out[tag + "_final_order"] = np.asarray(
+                    [key_to_pair(k) for k in mod.LRUCache.keys()], np.int64).reshape(-1, 2)
+            else:
+                fin = []
+                for f, lst in enumerate(mod.node_for_freq):
+                    if f == 0:
+                        continue
+                    for key in lst:
+                        fin.append((f,) + key_to_pair(key))
+                out[tag + "_final_freq"] = np.asarray(fin, np.int64).reshape(-1, 3)
+            print(tag, "hits", int(hits.sum()), "perfect", int(hits.all(1).sum()),
+                  "flushes", nflush)
+
+    # approximate-embedding mode (EvLFU_C1.py:122-125,142-152): misses turned into hits
+    reset_evlfu(EvLFU_C1)
+    random.seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        EvLFU_C1.init(768)
+    reqs = reqs_main
+    hits = np.zeros((len(reqs), 26), dtype=np.bool_)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for i, rq in enumerate(reqs):
+            h, _ = EvLFU_C1.request_to_ev_lfu([int(v) for v in rq], False, 20)
+            hits[i] = h
+    out["evlfu_cap768_approx20_hits"] = np.packbits(hits, axis=1)
+    buckets = []
+    for b in range(27):
+        for key in EvLFU_C1.lists_C1[b]:
+            buckets.append((b,) + key_to_pair(key))
+    out["evlfu_cap768_approx20_final_buckets"] = np.asarray(buckets, np.int64).reshape(-1, 3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        FR.close(); MFR.close()
+    np.savez_compressed(os.path.join(HERE, "cache_traces.npz"), **out)
+    print("wrote cache_traces")
+
+
+# --------------------------------------------------------------------------
+# a11: encoders (script/reduce_precision.py) on a fixed grid of values
+# --------------------------------------------------------------------------
+def gen_encoder_vectors():
+    sys.argv = ["reduce_precision.py"]
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_reduce_precision", os.path.join(REF, "script", "reduce_precision.py"))
+    src = open(os.path.join(REF, "script", "reduce_precision.py")).read()
+    # import only the function definitions (the file's tail is an argparse main)
+    head = src.split("if __name__")[0]
+    ns = {}
+    exec(compile(head, "reduce_precision_head", "exec"), ns)
+    rs = np.random.RandomState(3)
+    vals = np.concatenate([
+        np.linspace(-1.0, 1.0, 4001),
+        rs.uniform(-1, 1, 3000),
+        rs.uniform(-0.02, 0.02, 3000),
+        np.array([0.0, 1.0, -1.0, 0.65, -0.65, 0.6500001, -0.6500001, 0.25, -0.25, 0.8, -0.8,
+                  0.015, -0.015, 0.00025, -0.00025, 1e-9, -1e-9]),
+    ]).astype(np.float32).astype(np.float64)
+    u16 = np.array([ns["convert_ev_float_to_ushort"](float(v)) for v in vals], np.int64)
+    u4 = np.array([ns["convert_to_4bit_int_posit"](float(v)) for v in vals], np.int64)
+    u8 = np.array([round(((float(v) + 1) / 2) * 254) for v in vals], np.int64)  # reduce_precision.py:270
+    dec4 = np.array([ns["convert_from_4bit_int_posit"](int(c)) for c in range(15)], np.float64)
+    np.savez_compressed(os.path.join(HERE, "encoders.npz"), values=vals, u16=u16, u8=u8, u4=u4,
+                        u4_decode_table=dec4)
+    print("wrote encoders", len(vals))
+
+
+# --------------------------------------------------------------------------
+# a10: decode tables from the COMPILED reference C++ (oracle/_ref/ref_codec_dump)
+# --------------------------------------------------------------------------
+def gen_codec_tables():
+    import subprocess
+    orc = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle")
+    subprocess.check_call(["make", "-s", "-C", orc, "ref"])
+    tmp = tempfile.mkdtemp(prefix="evs_codec_")
+    outp = os.path.join(tmp, "codec_tables.bin")
+    subprocess.check_call([os.path.join(orc, "_ref", "ref_codec_dump"), outp],
+                          stdout=subprocess.DEVNULL)
+    t = np.fromfile(outp, np.float32)
+    assert t.size == 256 + 512 + 65536
+    np.savez_compressed(os.path.join(HERE, "codec_tables.npz"), u8=t[:256],
+                        u4=t[256:768].reshape(256, 2), u16=t[768:])
+    print("wrote codec_tables")
+
+
+def main():
+    D, DP, SM, FR, MFR, EvLFU_C1, LRU, LFU = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "codec":
+        gen_codec_tables()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cache":
+        gen_cache_traces(SM, FR, MFR, EvLFU_C1, LRU, LFU)
+        return
+    # cfg1 exactly: 8 x 10000 x 16, B=128, <=10 idx/lookup (BASELINE.json configs[0]); tables by sha only
+    gen_dlrm_case(D, DP, "dlrm_cfg1", [10000] * 8, 16, 128, 10, seed=123, store_tables=False)
+    # ragged small case with stored tables, tiny tables, bags 1..10
+    gen_dlrm_case(D, DP, "dlrm_ragged_small", [1000, 37, 3, 500, 64, 2, 129, 4096], 16, 33, 10,
+                  seed=5)
+    # Kaggle-shaped: 26 tables (row counts clipped), d=36, one index per bag
+    gen_dlrm_case(D, DP, "dlrm_kaggle_small", [min(n, 500) for n in KAGGLE_LN], 36, 64, 1,
+                  seed=9, criteo_layout=True)
+    # weighted pooling + interaction including the diagonal
+    gen_dlrm_case(D, DP, "dlrm_weighted_itself", [300, 5, 77, 1024], 32, 17, 6, seed=21,
+                  itself=True, weighted=True)
+    # d=64 / d=128 geometry (Terabyte-shaped scripts use 64 / 128)
+    gen_dlrm_case(D, DP, "dlrm_d64", [200, 3000, 11], 64, 20, 4, seed=31)
+    gen_dlrm_case(D, DP, "dlrm_d128", [150, 9], 128, 9, 3, seed=33)
+    gen_cache_traces(SM, FR, MFR, EvLFU_C1, LRU, LFU)
+    gen_encoder_vectors()
+    gen_codec_tables()
+
+
+if __name__ == "__main__":
+    main()
