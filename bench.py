@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- Criteo-Kaggle-shaped 26-table DLRM inference lookups/sec on MI355X.
+
+Workload (BASELINE.json configs[1]): 26 tables with the Kaggle row counts
+(sum 33 762 577 rows), d=36 fp32, all resident in HBM, no cache tier; one
+index per (table, sample) as the Criteo collate produces; synthetic uniform
+indices; tables drawn U(-sqrt(1/n), sqrt(1/n)) like create_emb.
+
+A step = the hot path over one batch: apply_emb (ONE fused gather launch for
+the 26 tables, writing the (B,27,36) interaction tile) + interact_features
+(one MFMA launch) -> R (B,387).  Inputs are resident in HBM before the timed
+region.  value = 26 * B * steps / time  (whole job, all ranks).
+
+N > 1 (one process per GPU, torch.distributed/RCCL): tables are sharded over
+ranks, every rank pools its tables for the FULL global batch (N * B), one
+all_to_all_single hands each rank all tables for its B-sample slice
+(dlrm_s_pytorch.py:529-586 distributed_forward), then interaction on the local
+slice.  Per-GPU gather work is constant in N -> "scaling": "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+KAGGLE_LN = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593,
+             3194, 27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+HBM_PEAK_GBPS = 8000.0  # MI355X datasheet HBM3E bandwidth (MI355X_MICROARCH.md: 8.0 TB/s spec)
+
+
+def make_tables(ln_emb, d, seed=0, device="cuda"):
+    """Synthetic tables, U(-sqrt(1/n), sqrt(1/n)) fp32 (dlrm_s_pytorch.py:279-283), made on the GPU."""
+    import evstore_dlrm_amd as E
+    g = torch.Generator(device=device).manual_seed(seed)
+    ws = []
+    for n in ln_emb:
+        a = float(np.sqrt(1.0 / n))
+        ws.append(torch.empty((n, d), dtype=torch.float32, device=device).uniform_(-a, a, generator=g))
+    return E.EVTables(ws, d, 32)
+
+
+def make_batches(ln_emb, B, n_batches, seed, device, dist="uniform", alpha=1.05):
+    """Criteo layout: lS_i (T,B) int64, lS_o (T,B) = arange(B) (dlrm_data_pytorch.py:397-410)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = []
+    off = torch.arange(B, device=device, dtype=torch.int64).repeat(len(ln_emb), 1).contiguous()
+    for _ in range(n_batches):
+        rows = []
+        for n in ln_emb:
+            if dist == "uniform":
+                rows.append(torch.randint(0, n, (B,), device=device, generator=g, dtype=torch.int64))
+            else:  # zipf-like skew through a fixed multiplicative scramble
+                u = torch.rand((B,), device=device, generator=g, dtype=torch.float64)
+                r = torch.clamp((u ** (-1.0 / (alpha - 1.0 + 1e-9))).to(torch.int64) - 1, max=n - 1)
+                rows.append((r * 2654435761 % n).to(torch.int64))
+        out.append((off, torch.stack(rows).contiguous()))
+    return out
+
+
+def cpu_baseline(ev, ln_emb, d, seconds=12.0):
+    """The reference's CPU path (per-table nn.EmbeddingBag loop + cat/bmm/tril gather,
+    dlrm_s_pytorch.py:407-461,:483-516) restated in oracle/dlrm_cpu.py, timed on the host cores."""
+    from oracle import dlrm_cpu
+    B = 2048
+    tables = [ev.fp32_view(k).cpu() for k in range(len(ln_emb))]
+    model = dlrm_cpu.CpuHotPath(tables)
+    g = torch.Generator().manual_seed(1)
+    batches = []
+    for _ in range(4):
+        lS_i = torch.stack([torch.randint(0, n, (B,), generator=g) for n in ln_emb])
+        lS_o = torch.arange(B).repeat(len(ln_emb), 1)
+        batches.append((lS_o, lS_i, torch.rand(B, d, generator=g)))
+    model.step(*batches[0])  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        model.step(*batches[n % len(batches)])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": len(ln_emb) * B * n / dt, "unit": "lookups/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d batches of B=%d over the same 26 Kaggle-shaped fp32 tables (copied from HBM), "
+                      "torch %s CPU EmbeddingBag+bmm loop, %.1f s" % (n, B, torch.__version__, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=16384, help="samples per GPU per step")
+    ap.add_argument("--dim", type=int, default=36)
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import evstore_dlrm_amd as E
+    E._lib.lib()  # fail loudly if the HIP library is missing
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        from evstore_dlrm_amd import sharded
+        result = sharded.bench_sharded(args, KAGGLE_LN, rank, world, dev)
+        if rank == 0:
+            print(json.dumps(result))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    B, d, T = args.batch, args.dim, len(KAGGLE_LN)
+    F = T + 1
+    ev = make_tables(KAGGLE_LN, d, seed=0, device=dev)
+    batches = make_batches(KAGGLE_LN, B, 8, seed=1, device=dev, dist=args.dist)
+    xs = [torch.rand((B, d), device=dev) for _ in range(2)]
+    tile = torch.empty((B, F, d), device=dev, dtype=torch.float32)
+
+    def step(i):
+        lS_o, lS_i = batches[i % len(batches)]
+        x = xs[i % len(xs)]
+        ly = E.apply_emb(lS_o, lS_i, ev, None, out=tile)
+        return E.interact_features(x, ly)
+
+    for i in range(args.warmup):
+        step(i)
+    E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps; event pairs bracket each gather launch ------------
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        lS_o, lS_i = batches[i % len(batches)]
+        ev0[i].record()
+        ly = E.apply_emb(lS_o, lS_i, ev, None, out=tile)
+        ev1[i].record()
+        R = E.interact_features(xs[i % len(xs)], ly)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    # ---- per-batch latency (sync per step), outside the throughput region ------------------
+    lat = []
+    for i in range(min(args.steps, 200)):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(i)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    # back-to-back gather launches only (cross-check of the event-pair number)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(args.steps):
+        lS_o, lS_i = batches[i % len(batches)]
+        E.apply_emb(lS_o, lS_i, ev, None, out=tile)
+    e1.record()
+    torch.cuda.synchronize()
+    gather_b2b_ms = e0.elapsed_time(e1) / args.steps
+
+    lookups = T * B
+    # algorithmic bytes per lookup: row 4d + index 8 + offset 8 read, 4d written
+    bytes_per_lookup = 4 * d + 8 + 8 + 4 * d
+    gather_bytes = lookups * bytes_per_lookup
+    achieved = gather_bytes / (gather_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = "gather_B%d_d%d_%s" % (B, d, args.dist)
+            traffic = tj.get(key)
+        except Exception:
+            traffic = None
+    result = {
+        "metric": "inference lookups/sec, Criteo-Kaggle 26-table DLRM (apply_emb + interact_features)",
+        "value": lookups * args.steps / dt, "unit": "lookups/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Criteo-Kaggle 26 tables (33.76M rows) x d=%d fp32 all in HBM, "
+                               "no cache tier, 1 index/bag, %s indices" % (d, args.dist),
+                   "batch_per_gpu": B, "global_batch": B, "tables": T, "dim": d, "parallelism": "single"},
+        "p50_batch_latency_ms": float(np.percentile(lat, 50)), "p95_batch_latency_ms": float(np.percentile(lat, 95)),
+        "roofline": {"bound": "hbm", "kernel": "embedding_bag_sum_kernel<32,9,4>", "achieved": achieved,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "bytes_per_launch": gather_bytes, "avg_launch_ms": gather_ms,
+                     "avg_launch_ms_back_to_back": gather_b2b_ms},
+    }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(ev, KAGGLE_LN, d, args.cpu_seconds)
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

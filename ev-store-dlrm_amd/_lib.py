@@ -1,0 +1,72 @@
+"""ctypes binding of libevstore_hip.so (include/evstore_hip.h).
+
+The HIP library is the product: there is NO CPU fallback.  If the shared
+object is missing or cannot be loaded, every op raises (loudly).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libevstore_hip.so")
+_lib = None
+
+EVS_OK, EVS_EINVAL, EVS_EHIP, EVS_EINDEX, EVS_ENOMEM, EVS_ESTATE, EVS_EIO = 0, -1, -2, -3, -4, -5, -6
+
+
+class EvsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libevstore_hip: %s (code %d)" % (msg, code))
+        self.code = code
+
+
+def build(force=False, verbose=False):
+    """Compile libevstore_hip.so for gfx950 with hipcc (works without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if force:
+        subprocess.check_call(cmd + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("build did not produce " + LIB_PATH)
+
+
+_vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
+_pp = C.POINTER(C.c_void_p)
+_i64p = C.POINTER(C.c_int64)
+
+_PROTOS = {
+    "evs_abi_version": (_int, []),
+    "evs_last_error": (C.c_char_p, []),
+    "evs_embedding_bag_sum": (_int, [_int, _i64, _int, _int, _pp, _i64p, _pp, _pp, _i64p, _pp, _vp, _i64, _i64, _vp]),
+    "evs_embedding_bag_sum_stacked": (_int, [_int, _i64, _int, _int, _pp, _i64p, _vp, _i64, _i64, _vp, _i64, _pp,
+                                             _vp, _i64, _i64, _vp]),
+    "evs_check_index_errors": (_int, [_vp]),
+    "evs_interact_dot": (_int, [_i64, _int, _int, _pp, _i64p, _int, _vp, _vp]),
+    "evs_interact_cat": (_int, [_i64, _int, _int, _pp, _i64p, _vp, _vp]),
+}
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libevstore_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C ev-store-dlrm_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)  # AttributeError = ABI mismatch, fail loudly
+            fn.restype, fn.argtypes = res, args
+        if L.evs_abi_version() != 1:
+            raise RuntimeError("libevstore_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EvsError(rc, lib().evs_last_error().decode("utf-8", "replace"))

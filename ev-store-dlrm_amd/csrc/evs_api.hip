@@ -1,0 +1,41 @@
+// Library-wide state of libevstore_hip.so: error strings, the sticky index-error flag.
+#include "evs_common.h"
+
+#include <mutex>
+
+namespace evs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int *index_error_flag() {
+    // one flag per device, allocated on first use and never freed (process lifetime)
+    static std::mutex mu;
+    static int *flags[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        set_error("hipGetDevice failed (no usable GPU?)");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!flags[dev]) {
+        int *p = nullptr;
+        if (hipMalloc(&p, sizeof(int)) != hipSuccess || hipMemset(p, 0, sizeof(int)) != hipSuccess) {
+            set_error("hipMalloc of the index-error flag failed");
+            return nullptr;
+        }
+        flags[dev] = p;
+    }
+    return flags[dev];
+}
+
+}  // namespace evs
+
+extern "C" int evs_abi_version(void) { return EVS_ABI_VERSION; }
+extern "C" const char *evs_last_error(void) { return evs::g_err; }

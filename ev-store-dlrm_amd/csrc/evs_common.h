@@ -1,0 +1,89 @@
+// Internal helpers shared by the kernels of libevstore_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/evstore_hip.h"
+
+namespace evs {
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kNumXcd = 8;       // MI355X: 8 XCDs, blocks are dealt round-robin over them
+constexpr int kNumCu = 256;
+
+void set_error(const char *fmt, ...);
+
+#define EVS_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            evs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return EVS_EHIP;                                                             \
+        }                                                                                \
+    } while (0)
+
+#define EVS_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            evs::set_error(__VA_ARGS__);       \
+            return EVS_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+// sticky device-side flag for out-of-range indices (one per process)
+int *index_error_flag();
+
+// ---- codecs: bit-exact device restatements of the reference decoders ----------------
+// 8-bit: mixed_precs_caching/evlfu_8.cpp:370-378, all fp32, division kept as a division
+__device__ __forceinline__ float dec_u8(unsigned v) {
+    float f = (float)v;
+    f = __fdiv_rn(f, 254.0f);
+    f = __fmul_rn(f, 2.0f);
+    return __fsub_rn(f, 1.0f);
+}
+// 16-bit: mixed_precs_caching/evlfu_16.cpp:332-356 -- the reference mixes float and
+// double ((float)v * 0.00002 is a double product), so this does too.
+__device__ __forceinline__ float dec_u16(unsigned v) {
+    if (v > 65000u) {
+        float diff = __fdiv_rn((float)(int)(v - 65000u), 100.0f);
+        double m = __dadd_rn(0.65, (double)diff);
+        return (v & 1u) ? (float)(-m) : (float)m;
+    }
+    return (float)__dsub_rn(__dmul_rn((double)(float)v, 0.00002), 0.65);
+}
+// 4-bit look-up table (mixed_precs_caching/evlfu_4.hpp:46); entry 15 is out of bounds in
+// the reference and never emitted by its encoder: it decodes to NaN here.
+__device__ __constant__ const float kU4Lut[16] = {
+    1.0f, 0.8f, 0.6f, 0.4f, 0.0625f, 0.00390625f, 0.0000153f, 0.0f,
+    -0.0000153f, -0.00390625f, -0.0625f, -0.4f, -0.6f, -0.8f, -1.0f, __builtin_nanf("")};
+
+// XCD-aware split of `n_items` (ordered so that neighbours share data, e.g. table-major)
+// over the grid: blocks b and b+8 share an XCD (and its 4 MiB L2), so XCD x owns the
+// contiguous item range [x*n/8, (x+1)*n/8) and its blocks stride through it.
+struct XcdRange {
+    int64_t begin, end, stride, first;
+};
+__device__ __forceinline__ XcdRange xcd_range(int64_t n_items, int units_per_block, int unit_in_block) {
+    const int nb = gridDim.x;
+    const int bid = blockIdx.x;
+    XcdRange r;
+    if (nb % kNumXcd == 0) {
+        const int xcd = bid % kNumXcd, local = bid / kNumXcd, per = nb / kNumXcd;
+        r.begin = n_items * xcd / kNumXcd;
+        r.end = n_items * (xcd + 1) / kNumXcd;
+        r.stride = (int64_t)per * units_per_block;
+        r.first = r.begin + (int64_t)local * units_per_block + unit_in_block;
+    } else {
+        r.begin = 0;
+        r.end = n_items;
+        r.stride = (int64_t)nb * units_per_block;
+        r.first = (int64_t)bid * units_per_block + unit_in_block;
+    }
+    return r;
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace evs

@@ -1,0 +1,363 @@
+// Fused multi-table EmbeddingBag(sum) gather for gfx950 (MI355X).
+//
+// Replaces the per-table Python loop of DLRM_Net.apply_emb (reference
+// dlrm_s_pytorch.py:407-461: T separate nn.EmbeddingBag launches) by ONE launch
+// over all T tables.  HBM-bound random-row gather; design notes:
+//   * a "lane group" of LPR = d/4 lanes owns one bag; each lane carries 4
+//     consecutive elements of the pooled row, so an fp32 row is read as
+//     LPR x 16-byte loads (global_load_dwordx4) and written as LPR x 16-byte
+//     stores; u16 / u8 / u4 rows are read as 8 / 4 / 2-byte pieces and decoded
+//     in registers (decode-on-load, fp32 accumulate).
+//   * every lane group works on UNROLL bags at once so that UNROLL independent
+//     row fetches are in flight per lane (bag size 1 -- Criteo -- is a pure
+//     gather: latency is hidden by memory-level parallelism, not by the loop).
+//   * work items are ordered table-major and split over the 8 XCDs in
+//     contiguous ranges (evs_common.h:xcd_range) so that each XCD's 4 MiB L2
+//     caches hot rows of ~T/8 tables instead of all T.
+//   * summation order is the index order, fp32, multiply and add unfused
+//     (library is built with -ffp-contract=off) -> bit-exact with the oracle.
+#include "evs_common.h"
+
+namespace evs {
+
+struct GatherArgs {
+    const void *table[EVS_MAX_TABLES_PER_LAUNCH];
+    const int64_t *indices[EVS_MAX_TABLES_PER_LAUNCH];
+    const int64_t *offsets[EVS_MAX_TABLES_PER_LAUNCH];
+    const float *row_w[EVS_MAX_TABLES_PER_LAUNCH];
+    int64_t n_rows[EVS_MAX_TABLES_PER_LAUNCH];
+    int64_t nnz[EVS_MAX_TABLES_PER_LAUNCH];
+    float *out;
+    int64_t out_tstride, out_bstride;
+    int64_t B;
+    int64_t chunks_per_table;  // ceil(B / bags-per-wave-item)
+    int T;
+    int d;
+    int *err;
+};
+
+template <int CODEC>
+struct RowPiece;  // 4 consecutive elements of a row -> float4
+
+template <>
+struct RowPiece<32> {
+    static constexpr int kBytes = 16;
+    __device__ static __forceinline__ float4 load(const void *row, int piece) {
+        return reinterpret_cast<const float4 *>(row)[piece];
+    }
+};
+template <>
+struct RowPiece<16> {
+    static constexpr int kBytes = 8;
+    __device__ static __forceinline__ float4 load(const void *row, int piece) {
+        uint2 v = reinterpret_cast<const uint2 *>(row)[piece];  // 4 native-endian ushorts
+        return make_float4(dec_u16(v.x & 0xffffu), dec_u16(v.x >> 16), dec_u16(v.y & 0xffffu),
+                           dec_u16(v.y >> 16));
+    }
+};
+template <>
+struct RowPiece<8> {
+    static constexpr int kBytes = 4;
+    __device__ static __forceinline__ float4 load(const void *row, int piece) {
+        unsigned v = reinterpret_cast<const unsigned *>(row)[piece];
+        return make_float4(dec_u8(v & 0xffu), dec_u8((v >> 8) & 0xffu), dec_u8((v >> 16) & 0xffu),
+                           dec_u8(v >> 24));
+    }
+};
+template <>
+struct RowPiece<4> {
+    static constexpr int kBytes = 2;
+    __device__ static __forceinline__ float4 load(const void *row, int piece) {
+        unsigned v = reinterpret_cast<const unsigned short *>(row)[piece];  // byte0 | byte1<<8
+        // element 2j is the HIGH nibble of byte j (script/reduce_precision.py:321)
+        return make_float4(kU4Lut[(v >> 4) & 15u], kU4Lut[v & 15u], kU4Lut[(v >> 12) & 15u],
+                           kU4Lut[(v >> 8) & 15u]);
+    }
+};
+
+// LPR = lanes per row (d = 4*LPR).  LPR_T > 0: compile-time, LPR_T == 0: runtime (args.d/4).
+template <int CODEC, int LPR_T, int UNROLL>
+__global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs args) {
+    const int LPR = LPR_T > 0 ? LPR_T : args.d / 4;
+    const int RPW = kWave / LPR;  // bags per wave per unroll slot
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int slot = lane / LPR;
+    const int piece = lane - slot * LPR;
+    const bool lane_on = slot < RPW;
+    const int64_t B = args.B;
+    const int64_t row_bytes = (int64_t)LPR * RowPiece<CODEC>::kBytes;
+    const int bags_per_item = RPW * UNROLL;
+
+    const int64_t n_items = (int64_t)args.T * args.chunks_per_table;
+    const XcdRange xr = xcd_range(n_items, 4, wave);
+    bool bad = false;
+
+    for (int64_t item = xr.first; item < xr.end; item += xr.stride) {
+        // wave-uniform table id -> per-table descriptors come from scalar loads
+        const int t = __builtin_amdgcn_readfirstlane((int)(item / args.chunks_per_table));
+        const int64_t chunk = item - (int64_t)t * args.chunks_per_table;
+        const int64_t b0 = chunk * bags_per_item;
+        const char *__restrict__ W = reinterpret_cast<const char *>(args.table[t]);
+        const int64_t *__restrict__ idx = args.indices[t];
+        const int64_t *__restrict__ off = args.offsets[t];
+        const float *__restrict__ rw = args.row_w[t];
+        const int64_t n_rows = args.n_rows[t];
+        const int64_t nnz = args.nnz[t];
+
+        int64_t s[UNROLL], len[UNROLL];
+        int64_t maxlen = 0;
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t b = b0 + (int64_t)u * RPW + slot;
+            s[u] = 0;
+            len[u] = 0;
+            if (lane_on && b < B) {
+                const int64_t st = off[b];
+                const int64_t en = (b + 1 < B) ? off[b + 1] : nnz;
+                if (st >= 0 && en >= st && en <= nnz) {
+                    s[u] = st;
+                    len[u] = en - st;
+                } else {
+                    bad = true;
+                }
+            }
+            maxlen = len[u] > maxlen ? len[u] : maxlen;
+        }
+        // wave-wide max bag length (all lanes must run the same trip count)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int64_t o = __shfl_xor(maxlen, m, kWave);
+            maxlen = o > maxlen ? o : maxlen;
+        }
+
+        float4 acc[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        for (int64_t j = 0; j < maxlen; j++) {
+            int64_t r[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                r[u] = -1;
+                if (j < len[u]) {
+                    const int64_t v = idx[s[u] + j];
+                    if (v >= 0 && v < n_rows) r[u] = v; else bad = true;
+                }
+            }
+            float4 v[UNROLL];
+            float w[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                w[u] = 1.0f;
+                if (r[u] >= 0) {
+                    v[u] = RowPiece<CODEC>::load(W + r[u] * row_bytes, piece);
+                    if (rw) w[u] = rw[r[u]];
+                }
+            }
+            if (rw) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    if (r[u] >= 0) {
+                        acc[u].x = __fadd_rn(acc[u].x, __fmul_rn(v[u].x, w[u]));
+                        acc[u].y = __fadd_rn(acc[u].y, __fmul_rn(v[u].y, w[u]));
+                        acc[u].z = __fadd_rn(acc[u].z, __fmul_rn(v[u].z, w[u]));
+                        acc[u].w = __fadd_rn(acc[u].w, __fmul_rn(v[u].w, w[u]));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    if (r[u] >= 0) {
+                        acc[u].x = __fadd_rn(acc[u].x, v[u].x);
+                        acc[u].y = __fadd_rn(acc[u].y, v[u].y);
+                        acc[u].z = __fadd_rn(acc[u].z, v[u].z);
+                        acc[u].w = __fadd_rn(acc[u].w, v[u].w);
+                    }
+                }
+            }
+        }
+
+        float *__restrict__ out = args.out + (int64_t)t * args.out_tstride + (int64_t)piece * 4;
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t b = b0 + (int64_t)u * RPW + slot;
+            if (lane_on && b < B) *reinterpret_cast<float4 *>(out + b * args.out_bstride) = acc[u];
+        }
+    }
+    if (bad) atomicOr(args.err, 1);
+}
+
+// any d (not a multiple of 4, or > 256): one element per lane, one bag per wave iteration.
+template <int CODEC>
+__global__ void __launch_bounds__(256) embedding_bag_sum_scalar_kernel(const GatherArgs args) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int d = args.d;
+    const int64_t n_items = (int64_t)args.T * args.B;
+    const XcdRange xr = xcd_range(n_items, 4, wave);
+    bool bad = false;
+    for (int64_t item = xr.first; item < xr.end; item += xr.stride) {
+        const int t = __builtin_amdgcn_readfirstlane((int)(item / args.B));
+        const int64_t b = item - (int64_t)t * args.B;
+        const int64_t nnz = args.nnz[t];
+        int64_t st = args.offsets[t][b];
+        int64_t en = (b + 1 < args.B) ? args.offsets[t][b + 1] : nnz;
+        if (!(st >= 0 && en >= st && en <= nnz)) { bad = true; en = st = 0; }
+        const unsigned char *W = reinterpret_cast<const unsigned char *>(args.table[t]);
+        const float *rw = args.row_w[t];
+        float *out = args.out + (int64_t)t * args.out_tstride + b * args.out_bstride;
+        for (int c = lane; c < d; c += kWave) {
+            float acc = 0.f;
+            for (int64_t j = st; j < en; j++) {
+                const int64_t r = args.indices[t][j];
+                if (r < 0 || r >= args.n_rows[t]) { bad = true; continue; }
+                float v;
+                if (CODEC == 32) v = reinterpret_cast<const float *>(W)[r * d + c];
+                else if (CODEC == 16) v = dec_u16(reinterpret_cast<const unsigned short *>(W)[r * d + c]);
+                else if (CODEC == 8) v = dec_u8(W[r * d + c]);
+                else {
+                    const unsigned byte = W[r * (d / 2) + c / 2];
+                    v = kU4Lut[(c & 1) ? (byte & 15u) : (byte >> 4)];
+                }
+                if (rw) v = __fmul_rn(v, rw[r]);
+                acc = __fadd_rn(acc, v);
+            }
+            out[c] = acc;
+        }
+    }
+    if (bad) atomicOr(args.err, 1);
+}
+
+template <int CODEC, int LPR_T, int UNROLL>
+static void launch_vec(const GatherArgs &a, int lpr, hipStream_t stream) {
+    GatherArgs args = a;
+    const int rpw = kWave / lpr;
+    const int bags_per_item = rpw * UNROLL;
+    args.chunks_per_table = (a.B + bags_per_item - 1) / bags_per_item;
+    const int64_t n_items = (int64_t)a.T * args.chunks_per_table;
+    int64_t blocks = (n_items + 3) / 4;
+    const int64_t cap = (int64_t)kNumCu * 8;  // 8 blocks of 256 threads per CU
+    if (blocks > cap) blocks = cap;
+    blocks = round_up((int)blocks, kNumXcd);
+    hipLaunchKernelGGL((embedding_bag_sum_kernel<CODEC, LPR_T, UNROLL>), dim3((unsigned)blocks), dim3(256), 0,
+                       stream, args);
+}
+
+template <int CODEC>
+static void launch_codec(const GatherArgs &a, bool vec_ok, hipStream_t stream) {
+    const int d = a.d;
+    if (vec_ok && d % 4 == 0 && d <= 256) {
+        const int lpr = d / 4;
+        switch (lpr) {
+        case 4: launch_vec<CODEC, 4, 4>(a, lpr, stream); return;    // d = 16
+        case 8: launch_vec<CODEC, 8, 4>(a, lpr, stream); return;    // d = 32
+        case 9: launch_vec<CODEC, 9, 4>(a, lpr, stream); return;    // d = 36 (every EVStore script)
+        case 16: launch_vec<CODEC, 16, 4>(a, lpr, stream); return;  // d = 64
+        case 32: launch_vec<CODEC, 32, 4>(a, lpr, stream); return;  // d = 128
+        default: launch_vec<CODEC, 0, 4>(a, lpr, stream); return;
+        }
+    }
+    GatherArgs args = a;
+    args.chunks_per_table = 0;
+    int64_t blocks = ((int64_t)a.T * a.B + 3) / 4;
+    const int64_t cap = (int64_t)kNumCu * 8;
+    if (blocks > cap) blocks = cap;
+    blocks = round_up((int)blocks, kNumXcd);
+    hipLaunchKernelGGL((embedding_bag_sum_scalar_kernel<CODEC>), dim3((unsigned)blocks), dim3(256), 0, stream, args);
+}
+
+}  // namespace evs
+
+extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const void *const *tables,
+                                     const int64_t *n_rows, const int64_t *const *indices,
+                                     const int64_t *const *offsets, const int64_t *nnz,
+                                     const float *const *row_weights, float *out,
+                                     int64_t out_table_stride, int64_t out_bag_stride, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(T >= 0 && B >= 0 && d > 0, "evs_embedding_bag_sum: bad shape T=%d B=%lld d=%d", T, (long long)B, d);
+    EVS_REQUIRE(codec == 32 || codec == 16 || codec == 8 || codec == 4, "evs_embedding_bag_sum: codec %d", codec);
+    EVS_REQUIRE(codec != 4 || d % 2 == 0, "evs_embedding_bag_sum: 4-bit rows need an even d (got %d)", d);
+    if (T == 0 || B == 0) return EVS_OK;
+    EVS_REQUIRE(tables && n_rows && indices && offsets && nnz && out, "evs_embedding_bag_sum: NULL argument");
+    int *err = index_error_flag();
+    if (!err) return EVS_EHIP;
+    bool vec_ok = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && out_table_stride % 4 == 0 &&
+                  out_bag_stride % 4 == 0;
+    for (int k = 0; k < T; k++) {
+        EVS_REQUIRE(n_rows[k] >= 0 && nnz[k] >= 0, "evs_embedding_bag_sum: table %d has negative size", k);
+        EVS_REQUIRE(tables[k] || n_rows[k] == 0, "evs_embedding_bag_sum: table %d is NULL", k);
+        EVS_REQUIRE(offsets[k], "evs_embedding_bag_sum: offsets[%d] is NULL", k);
+        EVS_REQUIRE(indices[k] || nnz[k] == 0, "evs_embedding_bag_sum: indices[%d] is NULL", k);
+        if (reinterpret_cast<uintptr_t>(tables[k]) % 16 != 0) vec_ok = false;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int k0 = 0; k0 < T; k0 += EVS_MAX_TABLES_PER_LAUNCH) {
+        const int n = (T - k0 < EVS_MAX_TABLES_PER_LAUNCH) ? T - k0 : EVS_MAX_TABLES_PER_LAUNCH;
+        GatherArgs a;
+        for (int k = 0; k < EVS_MAX_TABLES_PER_LAUNCH; k++) {
+            const bool on = k < n;
+            a.table[k] = on ? tables[k0 + k] : nullptr;
+            a.indices[k] = on ? indices[k0 + k] : nullptr;
+            a.offsets[k] = on ? offsets[k0 + k] : nullptr;
+            a.row_w[k] = (on && row_weights) ? row_weights[k0 + k] : nullptr;
+            a.n_rows[k] = on ? n_rows[k0 + k] : 0;
+            a.nnz[k] = on ? nnz[k0 + k] : 0;
+        }
+        a.out = out + (int64_t)k0 * out_table_stride;
+        a.out_tstride = out_table_stride;
+        a.out_bstride = out_bag_stride;
+        a.B = B;
+        a.T = n;
+        a.d = d;
+        a.err = err;
+        a.chunks_per_table = 0;
+        switch (codec) {
+        case 32: launch_codec<32>(a, vec_ok, st); break;
+        case 16: launch_codec<16>(a, vec_ok, st); break;
+        case 8: launch_codec<8>(a, vec_ok, st); break;
+        default: launch_codec<4>(a, vec_ok, st); break;
+        }
+        EVS_HIP_CHECK(hipGetLastError());
+    }
+    return EVS_OK;
+}
+
+extern "C" int evs_embedding_bag_sum_stacked(int T, int64_t B, int d, int codec, const void *const *tables,
+                                             const int64_t *n_rows, const int64_t *indices_base,
+                                             int64_t indices_row_stride, int64_t nnz_per_table,
+                                             const int64_t *offsets_base, int64_t offsets_row_stride,
+                                             const float *const *row_weights, float *out,
+                                             int64_t out_table_stride, int64_t out_bag_stride, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(T >= 0 && T <= 4096, "evs_embedding_bag_sum_stacked: bad T=%d", T);
+    if (T == 0 || B == 0) return EVS_OK;
+    EVS_REQUIRE(indices_base && offsets_base, "evs_embedding_bag_sum_stacked: NULL argument");
+    const int64_t *idx[4096];
+    const int64_t *off[4096];
+    int64_t nnz[4096];
+    for (int k = 0; k < T; k++) {
+        idx[k] = indices_base + (int64_t)k * indices_row_stride;
+        off[k] = offsets_base + (int64_t)k * offsets_row_stride;
+        nnz[k] = nnz_per_table;
+    }
+    return evs_embedding_bag_sum(T, B, d, codec, tables, n_rows, idx, off, nnz, row_weights, out,
+                                 out_table_stride, out_bag_stride, stream);
+}
+
+extern "C" int evs_check_index_errors(void *stream) {
+    using namespace evs;
+    int *err = index_error_flag();
+    if (!err) return EVS_EHIP;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int h = 0;
+    EVS_HIP_CHECK(hipMemcpyAsync(&h, err, sizeof(int), hipMemcpyDeviceToHost, st));
+    EVS_HIP_CHECK(hipStreamSynchronize(st));
+    if (h) {
+        EVS_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(int), st));
+        set_error("embedding index out of range (or malformed offsets) in a previous launch");
+        return EVS_EINDEX;
+    }
+    return EVS_OK;
+}

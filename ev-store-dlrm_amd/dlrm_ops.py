@@ -1,0 +1,183 @@
+"""Host-side mirror of the reference's hot-path operators.
+
+Same names, argument meaning and return conventions as the reference so the
+existing inference loop can call them unchanged:
+
+  apply_emb(lS_o, lS_i, emb_l, v_W_l)      -- DLRM_Net.apply_emb       (dlrm_s_pytorch.py:407-461)
+  interact_features(x, ly, ...)            -- DLRM_Net.interact_features (dlrm_s_pytorch.py:483-516)
+
+PyTorch is used for device memory and streams only; the arithmetic is in
+libevstore_hip.so (csrc/evs_gather.hip, csrc/evs_interact.hip).
+"""
+import ctypes as C
+import sys
+
+import torch
+
+from . import _lib
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class EVTables:
+    """The embedding tables of one model resident in HBM ("emb_l" for the HIP path).
+
+    Each table is kept exactly in the reference's on-disk byte layout
+    (ev-table-{k}.bin: row r at byte r*d*bits/8; script/convert_ev_to_binary.py:31-69),
+    so a .bin file is loaded into HBM verbatim and fp32 / 16 / 8 / 4-bit tables share
+    one gather kernel that decodes on load.
+    """
+
+    def __init__(self, raw_tables, d, codec=32):
+        assert codec in (32, 16, 8, 4)
+        self.d, self.codec = int(d), int(codec)
+        self.row_bytes = self.d * self.codec // 8
+        self.raw = []
+        for t in raw_tables:
+            assert t.is_cuda, "EVTables live in HBM: move the tensors to the GPU first"
+            t = t.contiguous()
+            if t.dtype != torch.uint8:
+                t = t.view(torch.uint8)
+            t = t.reshape(-1, self.row_bytes)
+            self.raw.append(t)
+        self.device = self.raw[0].device if self.raw else torch.device("cuda")
+        self.n_rows = [int(t.shape[0]) for t in self.raw]
+        T = len(self.raw)
+        self._tables_c = (C.c_void_p * T)(*[t.data_ptr() for t in self.raw])
+        self._n_rows_c = (C.c_int64 * T)(*self.n_rows)
+
+    # ---- constructors -------------------------------------------------------------
+    @classmethod
+    def from_fp32(cls, weights, device="cuda"):
+        """weights: list of (n_k, d) fp32 tensors/arrays, or nn.EmbeddingBag modules."""
+        ws = []
+        for w in weights:
+            if hasattr(w, "weight"):
+                w = w.weight.data
+            w = torch.as_tensor(w, dtype=torch.float32).to(device)
+            ws.append(w)
+        return cls(ws, ws[0].shape[1], 32)
+
+    @classmethod
+    def from_bin_dir(cls, ev_path, n_tables=26, d=36, codec=32, device="cuda"):
+        """Load ev-table-{1..n}.bin (the reference's storage format) straight into HBM."""
+        import numpy as np
+        import os
+        raws = []
+        for k in range(n_tables):
+            p = os.path.join(ev_path, "ev-table-%d.bin" % (k + 1))
+            a = np.fromfile(p, dtype=np.uint8)
+            if a.size % (d * codec // 8):
+                raise _lib.EvsError(_lib.EVS_EIO, "%s: size is not a multiple of the row size" % p)
+            raws.append(torch.from_numpy(a).to(device))
+        return cls(raws, d, codec)
+
+    def __len__(self):
+        return len(self.raw)
+
+    def fp32_view(self, k):
+        assert self.codec == 32
+        return self.raw[k].view(torch.float32).reshape(self.n_rows[k], self.d)
+
+
+def _as_evtables(emb_l):
+    if isinstance(emb_l, EVTables):
+        return emb_l
+    cached = getattr(emb_l, "_evs_tables", None)
+    if cached is not None:
+        return cached
+    ev = EVTables.from_fp32(list(emb_l), device=next(iter(emb_l)).weight.device
+                            if hasattr(next(iter(emb_l)), "weight") else "cuda")
+    try:
+        emb_l._evs_tables = ev
+    except Exception:
+        pass
+    return ev
+
+
+def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False):
+    """Drop-in for DLRM_Net.apply_emb (dlrm_s_pytorch.py:407-461).
+
+    lS_o: (T,B) int64 tensor or list of T (B,) tensors -- bag START offsets.
+    lS_i: (T,B) int64 tensor (Criteo collate) or list of T 1-D int64 tensors.
+    emb_l: EVTables (or a list / ModuleList of nn.EmbeddingBag, converted once).
+    v_W_l: None or list with None / per-ROW weight vectors (weighted pooling).
+    Returns a list of T (B,d) fp32 tensors in table order; they are views of one
+    (T,B,d) buffer, or of `out` = the (B,F,d) interaction tile (slot 0 is left for x).
+    One HIP launch for all tables.
+    """
+    ev = _as_evtables(emb_l)
+    T, d = len(ev), ev.d
+    dev = ev.device
+    L = _lib.lib()
+    stacked_o = torch.is_tensor(lS_o)
+    stacked_i = torch.is_tensor(lS_i)
+    B = int(lS_o.shape[1]) if stacked_o else int(lS_o[0].shape[0])
+    if out is None:
+        buf = torch.empty((T, B, d), dtype=torch.float32, device=dev)
+        base, tstride, bstride = buf, B * d, d
+        ly = [buf[k] for k in range(T)]
+    else:  # (B, F, d) tile: table k -> out[:, k+1, :]
+        assert out.shape == (B, T + 1, d) and out.is_contiguous() and out.dtype == torch.float32
+        base, tstride, bstride = out[:, 1:, :], d, (T + 1) * d
+        ly = [out[:, k + 1, :] for k in range(T)]
+    rw_c = None
+    if v_W_l is not None and any(w is not None for w in v_W_l):
+        keep = [None if w is None else w.detach().to(dev, torch.float32).contiguous() for w in v_W_l]
+        rw_c = (C.c_void_p * T)(*[None if w is None else w.data_ptr() for w in keep])
+    out_ptr = C.c_void_p(base.data_ptr() if out is None else out.data_ptr() + 4 * d)
+    stream = _stream_ptr(dev)
+    if stacked_i and stacked_o:
+        assert lS_i.dtype == torch.int64 and lS_o.dtype == torch.int64
+        assert lS_i.is_cuda and lS_o.is_cuda, "indices/offsets must already be on the GPU (dlrm_wrap does this)"
+        assert lS_i.stride(1) == 1 and lS_o.stride(1) == 1
+        rc = L.evs_embedding_bag_sum_stacked(
+            T, B, d, ev.codec, ev._tables_c, ev._n_rows_c,
+            C.c_void_p(lS_i.data_ptr()), lS_i.stride(0), int(lS_i.shape[1]),
+            C.c_void_p(lS_o.data_ptr()), lS_o.stride(0), rw_c, out_ptr, tstride, bstride, stream)
+    else:
+        li = [lS_i[k] for k in range(T)]
+        lo = [lS_o[k] for k in range(T)]
+        for t in li + lo:
+            assert t.dtype == torch.int64 and t.is_cuda and (t.numel() == 0 or t.stride(0) == 1)
+        idx_c = (C.c_void_p * T)(*[t.data_ptr() for t in li])
+        off_c = (C.c_void_p * T)(*[t.data_ptr() for t in lo])
+        nnz_c = (C.c_int64 * T)(*[int(t.numel()) for t in li])
+        rc = L.evs_embedding_bag_sum(T, B, d, ev.codec, ev._tables_c, ev._n_rows_c, idx_c, off_c, nnz_c, rw_c,
+                                     out_ptr, tstride, bstride, stream)
+    _lib.check(rc)
+    if check_indices:
+        _lib.check(L.evs_check_index_errors(stream))
+    return ly
+
+
+def interact_features(x, ly, arch_interaction_op="dot", arch_interaction_itself=False):
+    """Drop-in for DLRM_Net.interact_features (dlrm_s_pytorch.py:483-516).
+
+    x: (B,d) fp32, ly: list of (B,d) fp32 (any row stride; e.g. views of the (B,F,d) tile).
+    Returns R: (B, d + F(F-1)/2) for "dot" (F(F+1)/2 with arch_interaction_itself),
+    (B, F*d) for "cat".  Unsupported op -> sys.exit like the reference (:509-514).
+    """
+    if arch_interaction_op not in ("dot", "cat"):
+        sys.exit("ERROR: --arch-interaction-op=" + arch_interaction_op + " is not supported")
+    feats = [x] + list(ly)
+    B, d = x.shape
+    F = len(feats)
+    dev = x.device
+    for f in feats:
+        assert f.is_cuda and f.dtype == torch.float32 and f.shape == (B, d) and (d == 1 or f.stride(1) == 1)
+    ptrs = (C.c_void_p * F)(*[f.data_ptr() for f in feats])
+    strides = (C.c_int64 * F)(*[int(f.stride(0)) if B > 1 else d for f in feats])
+    L = _lib.lib()
+    if arch_interaction_op == "dot":
+        P = F * (F + 1) // 2 if arch_interaction_itself else F * (F - 1) // 2
+        R = torch.empty((B, d + P), dtype=torch.float32, device=dev)
+        rc = L.evs_interact_dot(B, F, d, ptrs, strides, int(bool(arch_interaction_itself)),
+                                C.c_void_p(R.data_ptr()), _stream_ptr(dev))
+    else:
+        R = torch.empty((B, F * d), dtype=torch.float32, device=dev)
+        rc = L.evs_interact_cat(B, F, d, ptrs, strides, C.c_void_p(R.data_ptr()), _stream_ptr(dev))
+    _lib.check(rc)
+    return R

@@ -1,0 +1,12 @@
+"""Import shim: `import evstore_dlrm_amd` loads the package in ./ev-store-dlrm_amd/
+(a hyphen cannot appear in a Python module name)."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ev-store-dlrm_amd")
+_spec = importlib.util.spec_from_file_location(
+    "evstore_dlrm_amd", os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["evstore_dlrm_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,120 @@
+/* evstore_hip.h -- C ABI of libevstore_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the DLRM embedding-lookup + EvLFU cache + feature
+ * interaction hot path of ucare-uchicago/ev-store-dlrm.  Plain pointers and
+ * sizes only; every pointer marked "device" is HBM memory of the current HIP
+ * device, every `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  All entry points return 0 on success and a negative EVS_E* code
+ * on failure; evs_last_error() returns a thread-local message.
+ *
+ * Each group cites the reference interface it replaces (paths relative to the
+ * reference tree).
+ */
+#ifndef EVSTORE_HIP_H
+#define EVSTORE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVS_ABI_VERSION 1
+#define EVS_API __attribute__((visibility("default")))
+
+/* error codes */
+#define EVS_OK 0
+#define EVS_EINVAL (-1)    /* bad argument (shape, alignment, unsupported codec ...) */
+#define EVS_EHIP (-2)      /* a HIP runtime call failed */
+#define EVS_EINDEX (-3)    /* an index was out of range (see evs_check_index_errors) */
+#define EVS_ENOMEM (-4)
+#define EVS_ESTATE (-5)    /* call sequence error (e.g. cache not initialised) */
+#define EVS_EIO (-6)       /* table file missing / short read */
+
+/* row codecs = the reference's on-disk precisions (SURVEY 8(b) on-disk contracts):
+ * 32: raw little-endian fp32                    (script/convert_ev_to_binary.py:58-69)
+ * 16: custom ushort affine code                 (mixed_precs_caching/evlfu_16.cpp:332-356)
+ *  8: uint8 affine  f=((float)u/254)*2-1        (mixed_precs_caching/evlfu_8.cpp:370-378)
+ *  4: 15-entry LUT, two codes per byte, hi first (mixed_precs_caching/evlfu_4.cpp:319-341) */
+#define EVS_CODEC_F32 32
+#define EVS_CODEC_U16 16
+#define EVS_CODEC_U8 8
+#define EVS_CODEC_U4 4
+
+#define EVS_MAX_TABLES_PER_LAUNCH 32
+#define EVS_MAX_FEATURES 32
+
+EVS_API int evs_abi_version(void);
+EVS_API const char *evs_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * a1: DLRM_Net.apply_emb  (dlrm_s_pytorch.py:407-461)
+ *     = T x nn.EmbeddingBag(n_k, d, mode="sum") (dlrm_s_pytorch.py:276) in ONE launch.
+ *
+ * For every table k and bag b:  out[k][b][:] = sum_{j in bag} decode(W_k[idx_k[j]]) (* w_k[idx_k[j]])
+ * bag b of table k = indices[k][ offsets[k][b] .. offsets[k][b+1] ) and the last bag
+ * runs to nnz[k] (start offsets only, exactly nn.EmbeddingBag's convention).
+ * Summation is in index order, fp32, multiply and add unfused (bit-exact with
+ * oracle/evstore_oracle.c:orc_embedding_bag_sum).
+ *
+ * The four pointer arrays and n_rows/nnz are HOST arrays of length T whose
+ * elements are device pointers / sizes.  tables[k]: rows of d elements in the
+ * given codec, row-major, row r at byte r*d*codec/8 -- i.e. the bytes of the
+ * reference's ev-table-{k+1}.bin, 16-byte aligned.  row_weights may be NULL, or
+ * hold NULL entries: row_weights[k] is the per-ROW weight vector v_W_l[k]
+ * (dlrm_s_pytorch.py:426 gathers it with the indices).
+ * Output element (k,b,c) is written to out[k*out_table_stride + b*out_bag_stride + c];
+ * strides are in floats and must be multiples of 4, out 16-byte aligned.
+ *   list-of-(B,d) layout:    table_stride = B*d, bag_stride = d
+ *   (B,F,d) interaction tile: out = T + d,  table_stride = d, bag_stride = F*d
+ * Out-of-range indices contribute nothing and raise a sticky device flag read
+ * by evs_check_index_errors() (nn.EmbeddingBag raises; a kernel cannot).
+ * ------------------------------------------------------------------------- */
+EVS_API int evs_embedding_bag_sum(int T, int64_t B, int d, int codec,
+                          const void *const *tables, const int64_t *n_rows,
+                          const int64_t *const *indices, const int64_t *const *offsets,
+                          const int64_t *nnz, const float *const *row_weights,
+                          float *out, int64_t out_table_stride, int64_t out_bag_stride,
+                          void *stream);
+
+/* Same operation for the stacked layout of the Criteo collate
+ * (dlrm_data_pytorch.py:397-410: lS_i and lS_o are (T,B) int64 tensors, one row per
+ * table): indices[k] = indices_base + k*indices_row_stride (B entries each, i.e.
+ * nnz[k] = nnz_per_table), offsets[k] = offsets_base + k*offsets_row_stride.
+ * Strides in elements.  Saves the caller from building four T-long pointer arrays
+ * per batch. */
+EVS_API int evs_embedding_bag_sum_stacked(int T, int64_t B, int d, int codec,
+                          const void *const *tables, const int64_t *n_rows,
+                          const int64_t *indices_base, int64_t indices_row_stride,
+                          int64_t nnz_per_table,
+                          const int64_t *offsets_base, int64_t offsets_row_stride,
+                          const float *const *row_weights,
+                          float *out, int64_t out_table_stride, int64_t out_bag_stride,
+                          void *stream);
+
+/* Synchronises `stream`, returns EVS_EINDEX if any launch since the last call saw
+ * an out-of-range index (and clears the flag), else 0. */
+EVS_API int evs_check_index_errors(void *stream);
+
+/* ---------------------------------------------------------------------------
+ * a3: DLRM_Net.interact_features, arch_interaction_op="dot"
+ *     (dlrm_s_pytorch.py:483-516)
+ *
+ * feats: HOST array of F device pointers; feature f of sample b is the d
+ * floats at feats[f] + b*feat_strides[f]  (feats[0] = x, feats[1..] = ly).
+ * R: device (B, d + P) row-major, P = F(F-1)/2 (itself=0) or F(F+1)/2 (itself=1):
+ *   R[b] = [ x[b] | Z[b][i][j] for i in 0..F-1 for j in 0..i-1(+itself) ],  Z = T.T^T
+ * fp32 in, fp32 accumulate on the matrix cores (v_mfma_f32_16x16x4_f32).
+ * Requires F <= 32, d % 4 == 0, d <= 256.
+ * ------------------------------------------------------------------------- */
+EVS_API int evs_interact_dot(int64_t B, int F, int d, const float *const *feats,
+                     const int64_t *feat_strides, int itself, float *R, void *stream);
+
+/* "cat" interaction (dlrm_s_pytorch.py:506-508): R[b] = [x[b] | ly_0[b] | ...], (B, F*d). */
+EVS_API int evs_interact_cat(int64_t B, int F, int d, const float *const *feats,
+                     const int64_t *feat_strides, float *R, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVSTORE_HIP_H */

@@ -1,0 +1,46 @@
+"""TEST INFRASTRUCTURE -- the reference's CPU path restated with the same torch CPU ops.
+
+Same per-table loop and the same ATen operators as DLRM_Net.apply_emb
+(dlrm_s_pytorch.py:407-461: nn.EmbeddingBag(mode="sum") per table) and
+DLRM_Net.interact_features (dlrm_s_pytorch.py:483-516: cat, bmm, index gather, cat).
+Used only as bench.py's cpu_baseline ("port") and by tests; checked against the
+golden vectors in tests/test_oracle_golden.py::test_cpu_port_matches_golden.
+"""
+import torch
+import torch.nn as nn
+
+
+class CpuHotPath:
+    def __init__(self, tables, arch_interaction_itself=False):
+        self.emb_l = nn.ModuleList()
+        for w in tables:
+            n, m = w.shape
+            e = nn.EmbeddingBag(n, m, mode="sum", sparse=True)  # dlrm_s_pytorch.py:276
+            e.weight.data = w
+            self.emb_l.append(e)
+        self.v_W_l = [None] * len(tables)
+        self.itself = arch_interaction_itself
+
+    def apply_emb(self, lS_o, lS_i):
+        ly = []
+        for k, sparse_index_group_batch in enumerate(lS_i):
+            sparse_offset_group_batch = lS_o[k]
+            w = self.v_W_l[k]
+            psw = w.gather(0, sparse_index_group_batch) if w is not None else None
+            ly.append(self.emb_l[k](sparse_index_group_batch, sparse_offset_group_batch, per_sample_weights=psw))
+        return ly
+
+    def interact_features(self, x, ly):
+        (batch_size, d) = x.shape
+        T = torch.cat([x] + ly, dim=1).view((batch_size, -1, d))
+        Z = torch.bmm(T, torch.transpose(T, 1, 2))
+        _, ni, nj = Z.shape
+        offset = 1 if self.itself else 0
+        li = torch.tensor([i for i in range(ni) for j in range(i + offset)])
+        lj = torch.tensor([j for i in range(nj) for j in range(i + offset)])
+        Zflat = Z[:, li, lj]
+        return torch.cat([x] + [Zflat], dim=1)
+
+    @torch.no_grad()
+    def step(self, lS_o, lS_i, x):
+        return self.interact_features(x, self.apply_emb(lS_o, lS_i))

@@ -1,0 +1,210 @@
+"""GPU parity: the HIP path (through the C ABI) vs the oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_indices, split_tables, split_weights
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # BASELINE.json north_star tolerance for fp32 pooled outputs
+
+
+@pytest.fixture(scope="module")
+def E():
+    import evstore_dlrm_amd as E
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    E._lib.lib()  # must load: no fallback
+    return E
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(a)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _run_case(E, g, tabs, stacked):
+    lS_o, lS_i = split_indices(g)
+    vW = split_weights(g)
+    ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    if stacked:
+        o, i = _dev(lS_o), _dev(np.stack(lS_i))
+    else:
+        o, i = [_dev(r) for r in lS_o], [_dev(r) for r in lS_i]
+    w = None if vW is None else [_dev(v) for v in vW]
+    ly = E.apply_emb(o, i, ev, w, check_indices=True)
+    return ly
+
+
+@pytest.mark.parametrize("name", ["dlrm_ragged_small", "dlrm_kaggle_small", "dlrm_weighted_itself", "dlrm_d64",
+                                  "dlrm_d128"])
+def test_apply_emb_and_interact_vs_golden_and_oracle(E, orc, name):
+    g = load_golden(name)
+    tabs = split_tables(g)
+    lS_o, lS_i = split_indices(g)
+    ly = _run_case(E, g, tabs, stacked=("lS_i_stacked" in g.files))
+    got = torch.stack(ly).cpu().numpy()
+    # (1) golden = the reference's own output
+    np.testing.assert_allclose(got, g["ly"], rtol=RTOL, atol=1e-7)
+    # (2) oracle: same summation order -> bit-exact
+    want = np.stack(orc.apply_emb(lS_o, lS_i, tabs, split_weights(g)))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # interaction on the reference's x
+    x = _dev(g["x"])
+    R = E.interact_features(x, ly, "dot", bool(g["itself"])).cpu().numpy()
+    assert R.shape == g["R"].shape
+    np.testing.assert_allclose(R, g["R"], rtol=RTOL, atol=2e-6)
+    Ro = orc.interact_features(g["x"], list(got), bool(g["itself"]))
+    np.testing.assert_allclose(R, Ro, rtol=RTOL, atol=2e-6)
+    assert np.array_equal(R[:, :g["x"].shape[1]], g["x"])  # x passthrough is a copy
+
+
+def test_cfg1_full(E, orc):
+    """BASELINE.json configs[0]: 8 x 10000 x 16, B=128, <=10 indices per bag."""
+    from test_oracle_golden import _tables_cfg1
+    g = load_golden("dlrm_cfg1")
+    tabs = _tables_cfg1(g)
+    ly = _run_case(E, g, tabs, stacked=False)
+    got = torch.stack(ly).cpu().numpy()
+    np.testing.assert_allclose(got, g["ly"], rtol=RTOL, atol=1e-7)
+    R = E.interact_features(_dev(g["x"]), ly).cpu().numpy()
+    np.testing.assert_allclose(R, g["R"], rtol=RTOL, atol=2e-6)
+
+
+def test_fused_tile_layout(E, orc):
+    """apply_emb writing straight into the (B,F,d) interaction tile."""
+    g = load_golden("dlrm_kaggle_small")
+    tabs = split_tables(g)
+    lS_o, lS_i = split_indices(g)
+    ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    B, T, d = 64, 26, 36
+    tile = torch.zeros((B, T + 1, d), device="cuda")
+    tile[:, 0, :] = _dev(g["x"])
+    ly = E.apply_emb(_dev(lS_o), _dev(np.stack(lS_i)), ev, None, out=tile)
+    assert ly[3].data_ptr() == tile[:, 4, :].data_ptr()
+    np.testing.assert_array_equal(tile[:, 1:, :].permute(1, 0, 2).cpu().numpy(), g["ly"])
+    R = E.interact_features(tile[:, 0, :], ly).cpu().numpy()
+    np.testing.assert_allclose(R, g["R"], rtol=RTOL, atol=2e-6)
+
+
+@pytest.mark.parametrize("codec", [16, 8, 4])
+@pytest.mark.parametrize("d", [36, 16])
+def test_codec_tiers_bit_exact(E, orc, codec, d):
+    """decode-on-load gather for the reference's 16/8/4-bit row formats (a9/a10)."""
+    rs = np.random.RandomState(codec * 100 + d)
+    n_rows = [1000, 3, 77, 5000]
+    T, B = len(n_rows), 200
+    raws = [orc.encode_table(rs.uniform(-1, 1, size=(n, d)).astype(np.float32), codec) for n in n_rows]
+    lens = rs.randint(0, 5, size=(T, B))
+    lS_i = [rs.randint(0, n_rows[k], size=lens[k].sum()).astype(np.int64) for k in range(T)]
+    lS_o = [np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64) for k in range(T)]
+    ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, codec)
+    ly = E.apply_emb([_dev(o) for o in lS_o], [_dev(i) for i in lS_i], ev, None, check_indices=True)
+    got = torch.stack(ly).cpu().numpy()
+    want = np.stack(orc.apply_emb(lS_o, lS_i, raws, None, codec, d))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_exhaustive_decode_tables_on_gpu(E, orc):
+    """every u8 / u16 code and every valid packed-u4 byte through the gather kernel
+    == the compiled reference's decode tables (tests/golden/codec_tables.npz)."""
+    t = load_golden("codec_tables")
+    # u16: a table with 65536/4 rows of d=4
+    raw = np.arange(65536, dtype=np.uint16).view(np.uint8).reshape(-1, 8)
+    ev = E.EVTables([torch.from_numpy(raw).cuda()], 4, 16)
+    n = raw.shape[0]
+    idx = torch.arange(n, device="cuda").reshape(1, n)
+    out = E.apply_emb(idx.clone(), idx, ev)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(out.view(np.uint32), t["u16"].view(np.uint32))
+    raw = np.arange(256, dtype=np.uint8).reshape(-1, 4)
+    ev = E.EVTables([torch.from_numpy(raw).cuda()], 4, 8)
+    idx = torch.arange(64, device="cuda").reshape(1, 64)
+    out = E.apply_emb(idx.clone(), idx, ev)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(out.view(np.uint32), t["u8"].view(np.uint32))
+    raw = np.arange(256, dtype=np.uint8).reshape(-1, 2)  # d=4 -> 2 bytes per row
+    ev = E.EVTables([torch.from_numpy(raw).cuda()], 4, 4)
+    idx = torch.arange(128, device="cuda").reshape(1, 128)
+    out = E.apply_emb(idx.clone(), idx, ev)[0].cpu().numpy().reshape(256, 2)
+    ok = ~np.isnan(t["u4"])
+    assert np.array_equal(out[ok].view(np.uint32), t["u4"][ok].view(np.uint32))
+
+
+def test_edge_cases(E, orc):
+    rs = np.random.RandomState(1)
+    W = rs.randn(50, 16).astype(np.float32)
+    ev = E.EVTables.from_fp32([torch.from_numpy(W)])
+    # empty bags, a long bag, trailing empty bag
+    idx = np.array([3, 3, 3, 7, 49, 0] + list(range(50)) * 3, np.int64)
+    off = np.array([0, 0, 3, 6, 6, len(idx)], np.int64)
+    ly = E.apply_emb([_dev(off)], [_dev(idx)], ev, None, check_indices=True)[0].cpu().numpy()
+    want = orc.embedding_bag_sum(W, idx, off)
+    assert np.array_equal(ly.view(np.uint32), want.view(np.uint32))
+    assert not ly[0].any() and not ly[3].any() and not ly[5].any()
+    # B = 1 (the EVStore scripts' batch size)
+    ly = E.apply_emb([_dev(np.array([0]))], [_dev(np.array([5]))], ev)[0].cpu().numpy()
+    assert np.array_equal(ly[0], W[5])
+    # out-of-range index is reported, not silently gathered
+    E.apply_emb([_dev(np.array([0]))], [_dev(np.array([50]))], ev)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    E._lib.check(E._lib.lib().evs_check_index_errors(None))  # flag cleared
+
+
+def test_odd_dim_falls_to_scalar_kernel(E, orc):
+    rs = np.random.RandomState(2)
+    W = rs.randn(40, 10).astype(np.float32)  # d=10: not a multiple of 4
+    ev = E.EVTables.from_fp32([torch.from_numpy(W)])
+    idx = rs.randint(0, 40, size=30).astype(np.int64)
+    off = np.arange(0, 30, 3).astype(np.int64)
+    ly = E.apply_emb([_dev(off)], [_dev(idx)], ev)[0].cpu().numpy()
+    want = orc.embedding_bag_sum(W, idx, off)
+    assert np.array_equal(ly.view(np.uint32), want.view(np.uint32))
+    x = torch.randn(10, 10, device="cuda")
+    R = E.interact_features(x, [torch.from_numpy(ly).cuda()]).cpu().numpy()
+    Ro = orc.interact_features(x.cpu().numpy(), [ly])
+    np.testing.assert_allclose(R, Ro, rtol=RTOL, atol=2e-6)
+
+
+def test_interact_cat_and_unsupported(E):
+    x = torch.randn(5, 8, device="cuda")
+    ly = [torch.randn(5, 8, device="cuda") for _ in range(3)]
+    R = E.interact_features(x, ly, "cat")
+    assert torch.equal(R, torch.cat([x] + ly, dim=1))
+    with pytest.raises(SystemExit):
+        E.interact_features(x, ly, "sum")
+
+
+def test_full_size_kaggle_properties(E):
+    """BASELINE configs[1] at full size: properties that need no CPU reference.
+    bag=1 -> every pooled row equals the addressed table row (exact copy);
+    linearity: pooling [i, j] == row i + row j."""
+    from bench import KAGGLE_LN, make_tables
+    ev = make_tables(KAGGLE_LN, 36, seed=0)
+    B = 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
+    idx = torch.stack([torch.randint(0, n, (B,), device="cuda", generator=g) for n in KAGGLE_LN])
+    off = torch.arange(B, device="cuda").repeat(26, 1)
+    ly = E.apply_emb(off, idx, ev, check_indices=True)
+    for k in (0, 2, 8, 11, 20, 25):
+        assert torch.equal(ly[k], ev.fp32_view(k)[idx[k]])
+    # pairs
+    off2 = (torch.arange(B // 2, device="cuda") * 2).repeat(26, 1)
+    ly2 = E.apply_emb(off2, idx, ev)
+    for k in (2, 15):
+        rows = ev.fp32_view(k)[idx[k]]
+        assert torch.equal(ly2[k], rows[0::2] + rows[1::2])
+    x = torch.randn(B, 36, device="cuda")
+    R = E.interact_features(x, ly)
+    T = torch.stack([x] + ly, dim=1)
+    Z = torch.bmm(T, T.transpose(1, 2))
+    li, lj = torch.tril_indices(27, 27, offset=-1, device="cuda")
+    ref = torch.cat([x, Z[:, li, lj]], dim=1)
+    torch.testing.assert_close(R, ref, rtol=1e-5, atol=1e-5)

@@ -184,3 +184,16 @@ def test_reader_rows(tmp_path):
     for (tb, r), want in zip(t["reader_probe"], t["reader_rows"]):
         got = orc.read_row(str(tmp_path), int(tb), int(r))
         np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["dlrm_ragged_small", "dlrm_kaggle_small", "dlrm_d64"])
+def test_cpu_port_matches_golden(name):
+    """oracle/dlrm_cpu.py (bench.py's cpu_baseline) reproduces the reference's outputs exactly."""
+    import torch
+    from oracle import dlrm_cpu
+    g = load_golden(name)
+    tabs = [torch.from_numpy(t) for t in split_tables(g)]
+    lS_o, lS_i = split_indices(g)
+    m = dlrm_cpu.CpuHotPath(tabs)
+    R = m.step([torch.from_numpy(o) for o in lS_o], [torch.from_numpy(i) for i in lS_i], torch.from_numpy(g["x"]))
+    np.testing.assert_array_equal(R.numpy(), g["R"])
