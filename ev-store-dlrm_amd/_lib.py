@@ -34,6 +34,12 @@ _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
 _pp = C.POINTER(C.c_void_p)
 _i64p = C.POINTER(C.c_int64)
 
+class EvsFeature(C.Structure):
+    """struct evs_feature (include/evstore_hip.h)"""
+    _fields_ = [("src", C.c_void_p), ("stride", C.c_int64), ("indices", C.c_void_p), ("offsets", C.c_void_p),
+                ("nnz", C.c_int64), ("n_rows", C.c_int64), ("row_weights", C.c_void_p)]
+
+
 _PROTOS = {
     "evs_abi_version": (_int, []),
     "evs_last_error": (C.c_char_p, []),
@@ -42,6 +48,10 @@ _PROTOS = {
                                              _vp, _i64, _i64, _vp]),
     "evs_check_index_errors": (_int, [_vp]),
     "evs_interact_dot": (_int, [_i64, _int, _int, _pp, _i64p, _int, _vp, _vp]),
+    "evs_fused_dim_supported": (_int, [_int]),
+    "evs_emb_interact_dot": (_int, [_i64, _int, _int, _int, C.POINTER(EvsFeature), _int, _vp, _vp]),
+    "evs_emb_interact_dot_stacked": (_int, [_i64, _int, _int, _int, _pp, _i64p, _vp, _i64, _vp, _i64, _i64, _vp, _i64,
+                                            _pp, _int, _vp, _vp]),
     "evs_interact_cat": (_int, [_i64, _int, _int, _pp, _i64p, _vp, _vp]),
 }
 

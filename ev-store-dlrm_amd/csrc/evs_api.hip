@@ -35,6 +35,26 @@ int *index_error_flag() {
     return flags[dev];
 }
 
+const void *zero_page() {
+    static std::mutex mu;
+    static void *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        set_error("hipGetDevice failed (no usable GPU?)");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pages[dev]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, 4096) != hipSuccess || hipMemset(p, 0, 4096) != hipSuccess) {
+            set_error("hipMalloc of the zero page failed");
+            return nullptr;
+        }
+        pages[dev] = p;
+    }
+    return pages[dev];
+}
+
 }  // namespace evs
 
 extern "C" int evs_abi_version(void) { return EVS_ABI_VERSION; }

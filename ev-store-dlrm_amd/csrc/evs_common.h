@@ -32,8 +32,10 @@ void set_error(const char *fmt, ...);
         }                                      \
     } while (0)
 
-// sticky device-side flag for out-of-range indices (one per process)
+// sticky device-side flag for out-of-range indices (one per device)
 int *index_error_flag();
+// 4 KiB of zeros in HBM (one per device): the "row" read by lanes that have nothing to fetch
+const void *zero_page();
 
 // ---- codecs: bit-exact device restatements of the reference decoders ----------------
 // 8-bit: mixed_precs_caching/evlfu_8.cpp:370-378, all fp32, division kept as a division

@@ -1,0 +1,503 @@
+// Fused embedding gather + pooling + pairwise-dot interaction on the gfx950 matrix cores.
+//
+// One kernel computes, per sample b,
+//     R[b] = [ x[b] | Z[b][i][j], j<i ],   Z[b] = T[b].T[b]^T,   T[b] = [x[b]; V_0[b]; ...; V_{F-2}[b]]
+// where every row of T[b] is either a DENSE feature (x from the bottom MLP, or pooled
+// vectors that arrived over the all-to-all) or an INDIRECT feature: the sum-pooled bag
+// of table rows that DLRM_Net.apply_emb would have produced
+//     V_k[b] = sum_{j in bag(b)} decode(W_k[idx_k[j]]) (* w_k[idx_k[j]])
+// (reference: dlrm_s_pytorch.py:407-461 apply_emb, :483-516 interact_features,
+//  :588-601 sequential_forward calls them back to back).
+// With all features dense this IS interact_features; with indirect features the
+// (B,F,d) intermediate -- 2 x 3.7 KB of HBM traffic per sample at F=27, d=36 --
+// never exists.
+//
+// Mapping (one wavefront per sample, NS samples in flight per wave):
+//   Z for F <= 32 is a 2x2 grid of 16x16 tiles; only (0,0), (1,0), (1,1) are computed,
+//   each as a chain of v_mfma_f32_16x16x4_f32 (exact fp32).  The MFMA sums over k in
+//   groups of 4 "k-slots" q = lane>>4; the order of k is free as long as A and B agree,
+//   so a row is cut into 16-byte CHUNKS of 4 elements and k-slot q owns chunks
+//   [q*CPQ, (q+1)*CPQ), CPQ = ceil(d/16): lane (r = lane&15, q) fetches its rows' chunks
+//   with aligned 16-byte loads (global_load_dwordx4) -- every byte of a row is fetched by
+//   exactly one lane -- and MFMA step (c,e) multiplies element e of chunk q*CPQ+c across
+//   the four q.  d=36: 9 chunks, CPQ=3, slot q=3 carries zeros (12 steps instead of 9;
+//   the kernel is HBM-bound, MFMA has >2x headroom).
+//   C/D layout: lane holds Z[i = 4*(lane>>4)+v][j = lane&15] -> row-major strict lower
+//   triangle at R[b][d + i(i-1)/2 + j].
+#include "evs_common.h"
+
+namespace evs {
+
+struct FusedArgs {
+    const void *src[EVS_MAX_FEATURES];        // dense: fp32 rows; indirect: table bytes
+    int64_t stride[EVS_MAX_FEATURES];         // dense: floats between samples
+    const int64_t *indices[EVS_MAX_FEATURES]; // NULL => dense
+    const int64_t *offsets[EVS_MAX_FEATURES];
+    int64_t nnz[EVS_MAX_FEATURES];
+    int64_t n_rows[EVS_MAX_FEATURES];
+    const float *row_w[EVS_MAX_FEATURES];
+    float *R;
+    int64_t B;
+    int F, d, itself, P;
+    int *err;
+    const int64_t *dummy_i64;  // any readable int64 (lanes with nothing to fetch read it)
+    const float *dummy_f32;
+    const void *zeros;         // >= 1 KiB of zero bytes (idle lanes / empty bags read rows from it)
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CODEC>
+__device__ __forceinline__ float4 load_chunk(const char *row, int chunk) {
+    if constexpr (CODEC == 32) {
+        return reinterpret_cast<const float4 *>(row)[chunk];
+    } else if constexpr (CODEC == 16) {
+        const uint2 v = reinterpret_cast<const uint2 *>(row)[chunk];
+        return make_float4(dec_u16(v.x & 0xffffu), dec_u16(v.x >> 16), dec_u16(v.y & 0xffffu), dec_u16(v.y >> 16));
+    } else if constexpr (CODEC == 8) {
+        const unsigned v = reinterpret_cast<const unsigned *>(row)[chunk];
+        return make_float4(dec_u8(v & 0xffu), dec_u8((v >> 8) & 0xffu), dec_u8((v >> 16) & 0xffu), dec_u8(v >> 24));
+    } else {
+        const unsigned v = reinterpret_cast<const unsigned short *>(row)[chunk];
+        return make_float4(kU4Lut[(v >> 4) & 15u], kU4Lut[v & 15u], kU4Lut[(v >> 12) & 15u], kU4Lut[(v >> 8) & 15u]);
+    }
+}
+
+// per-lane view of one row of T (one feature)
+struct LaneFeat {
+    const char *src;      // row base + this lane's k-slot byte offset folded in
+    const int64_t *idx;   // indirect only
+    const int64_t *off;   // indirect only
+    const float *rw;      // WEIGHTED only
+    unsigned scale;       // dense: row stride in BYTES; indirect: bytes per table row (0 for idle lanes)
+    int rem_delta;        // byte distance from this lane's own chunks to the shared remainder chunks
+    int nnz;              // API guarantees < 2^31
+    unsigned n_rows;      // API guarantees < 2^31
+    bool indirect;
+};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Software pipeline over the samples a wave owns (sample n of the wave is b = wave_id + n*waves):
+//   iteration k:  issue row loads of sample k+1   (its first index arrived during iteration k-1)
+//                 issue index loads of sample k+2 (its offsets arrived during iteration k-1)
+//                 issue offset loads of sample k+3
+//                 consume sample k: finish its bags, the MFMA chains, write R[b]
+// so the three dependent fetches (offset -> index -> row) of later samples are in flight
+// under the MFMA/store phase of the current one.  All loads are unconditional: lanes with
+// nothing to fetch (idle rows of the 16x16 tiles, empty bags) read a zero-filled buffer, so
+// there is no select after the load and the vmcnt accounting stays static.  Stores go through
+// a buffer resource sized to ONE output row: lanes whose (i,j) is outside the strict lower
+// triangle carry an out-of-range offset and the hardware drops them -- no exec masking.
+//
+// k-slot assignment: a row has n_chunks = 4*CQ + REM 16-byte chunks.  Slot q owns chunks
+// [q*CQ, (q+1)*CQ); the REM trailing chunks are fetched by all four slots (same cache line)
+// and slot q uses element q of each.  d=36: CQ=2, REM=1 -> 9 MFMA steps per tile, no padding.
+template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT>
+__global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs args) {
+    constexpr int NR = NT;        // rows of T per lane: r16 and (NT==2) r16+16
+    constexpr int NC = CQ + REM;  // float4 chunks held per lane per row
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int F = args.F, itself = args.itself;
+    constexpr int d = 4 * (4 * CQ + REM);
+    const int out_row = d + args.P;
+    const int64_t B = args.B;
+    constexpr int kChunkBytes = CODEC / 2;  // 4 elements of CODEC bits
+    constexpr int row_bytes = (4 * CQ + REM) * kChunkBytes;
+
+    const FusedArgs *ka = (const FusedArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    LaneFeat lf[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const int f = r16 + 16 * rr;
+        lf[rr].src = reinterpret_cast<const char *>(args.zeros);  // idle lanes read zeros
+        lf[rr].idx = nullptr; lf[rr].off = nullptr; lf[rr].rw = nullptr;
+        lf[rr].scale = 0; lf[rr].nnz = 0; lf[rr].n_rows = 0; lf[rr].indirect = false;
+        lf[rr].rem_delta = 4 * CQ * 16 - q * CQ * 16;
+        if (f < F) {
+            lf[rr].idx = ka->indices[f];
+            lf[rr].indirect = HAS_INDIRECT && lf[rr].idx != nullptr;
+            const int cb = lf[rr].indirect ? kChunkBytes : 16;
+            lf[rr].src = reinterpret_cast<const char *>(ka->src[f]) + q * CQ * cb;
+            lf[rr].rem_delta = 4 * CQ * cb - q * CQ * cb;
+            lf[rr].off = ka->offsets[f];
+            if constexpr (WEIGHTED) lf[rr].rw = ka->row_w[f];
+            lf[rr].scale = lf[rr].indirect ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4);
+            lf[rr].nnz = (int)ka->nnz[f];
+            lf[rr].n_rows = (unsigned)ka->n_rows[f];
+        }
+    }
+    const char *zeros_l = reinterpret_cast<const char *>(args.zeros);
+
+    // store offsets (bytes inside one output row); out-of-range = dropped by the buffer unit
+    constexpr int kOob = 0x7ffffff0;
+    int zo00[4], zo10[4], zo11[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const int i = 4 * q + v;
+        zo00[v] = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : kOob;
+        const int gi = 16 + i;
+        const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+        zo10[v] = (NT == 2 && gi < F) ? 4 * (d + base + r16) : kOob;
+        zo11[v] = (NT == 2 && gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : kOob;
+    }
+
+    // wave-uniform bookkeeping in SGPRs
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t waves_total = (int64_t)gridDim.x * 4;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave_in_block;
+    if (wave_id >= B) return;
+    const int n_samples = (int)((B - wave_id + waves_total - 1) / waves_total);
+    bool bad = false;
+
+    // ---- pipeline state -------------------------------------------------------------
+    int64_t off0[NR], off1[NR];        // raw offsets in flight
+    int64_t idx_raw[NR];               // raw first index in flight
+    int st2[NR], len2[NR];             // bag start/length of the sample whose index is in flight
+    int st1[NR], len1[NR];             // ... of the sample whose rows are in flight
+    int st0[NR], len0[NR];             // ... of the sample being consumed
+    bool first1[NR], first0[NR];       // first bag element valid (CODEC != 32 only: select after decode)
+    float w1[NR], w0[NR];              // per-row weight of the first element (WEIGHTED)
+    float4 a_next[NR][NC], a_cur[NR][NC];
+
+    auto sample_b = [&](int n) -> int64_t {
+        const int64_t b = wave_id + (int64_t)n * waves_total;
+        return b < B ? b : B - 1;  // past-the-end pipeline slots re-read the last sample
+    };
+    auto issue_off = [&](int n) {
+        if constexpr (HAS_INDIRECT) {
+            const int64_t b = sample_b(n);
+            const int64_t b1 = (b + 1 < B) ? b + 1 : b;
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                const int64_t *op = lf[rr].indirect ? lf[rr].off : args.dummy_i64;
+                off0[rr] = op[lf[rr].indirect ? b : 0];
+                off1[rr] = op[lf[rr].indirect ? b1 : 0];
+            }
+        }
+    };
+    auto issue_idx = [&](int n) {  // consumes off0/off1 -> st2/len2, issues the first-index load
+        if constexpr (HAS_INDIRECT) {
+            const int64_t b = sample_b(n);
+            const bool last = !(b + 1 < B);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                st2[rr] = 0;
+                len2[rr] = 0;
+                if (lf[rr].indirect) {
+                    const int64_t s0 = off0[rr];
+                    const int64_t e0 = last ? (int64_t)lf[rr].nnz : off1[rr];
+                    if (s0 >= 0 && e0 >= s0 && e0 <= (int64_t)lf[rr].nnz) { st2[rr] = (int)s0; len2[rr] = (int)(e0 - s0); }
+                    else bad = true;
+                }
+                const int64_t *ip = (len2[rr] > 0) ? lf[rr].idx + st2[rr] : args.dummy_i64;
+                idx_raw[rr] = *ip;
+            }
+        }
+    };
+    auto issue_rows = [&](int n) {  // consumes idx_raw (sample n), issues its chunk loads into a_next
+        const int64_t b = sample_b(n);
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            unsigned mult = (unsigned)b;  // dense: sample number (B < 2^31 is checked on the host)
+            bool ok = true;
+            if constexpr (HAS_INDIRECT) {
+                if (lf[rr].indirect) {
+                    ok = len2[rr] > 0;
+                    if (ok && (uint64_t)idx_raw[rr] >= (uint64_t)lf[rr].n_rows) { ok = false; bad = true; }
+                    mult = ok ? (unsigned)idx_raw[rr] : 0u;
+                }
+                st1[rr] = st2[rr];
+                len1[rr] = len2[rr];
+            }
+            first1[rr] = ok;
+            // one v_mad_u64_u32: base + u32*u32
+            const char *row = lf[rr].src + (uint64_t)mult * (uint64_t)lf[rr].scale;
+            int rem_delta = lf[rr].rem_delta;
+            if constexpr (HAS_INDIRECT && CODEC == 32) {
+                if (!ok) { row = zeros_l; rem_delta = 0; }  // empty bag / bad index: read zeros
+            }
+            if constexpr (CODEC == 32 || !HAS_INDIRECT) {
+#pragma unroll
+                for (int c = 0; c < CQ; c++) a_next[rr][c] = reinterpret_cast<const float4 *>(row)[c];
+#pragma unroll
+                for (int m = 0; m < REM; m++) a_next[rr][CQ + m] = reinterpret_cast<const float4 *>(row + rem_delta)[m];
+            } else {
+                if (lf[rr].indirect) {
+#pragma unroll
+                    for (int c = 0; c < CQ; c++) a_next[rr][c] = load_chunk<CODEC>(row, c);
+#pragma unroll
+                    for (int m = 0; m < REM; m++) a_next[rr][CQ + m] = load_chunk<CODEC>(row + rem_delta, m);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CQ; c++) a_next[rr][c] = reinterpret_cast<const float4 *>(row)[c];
+#pragma unroll
+                    for (int m = 0; m < REM; m++) a_next[rr][CQ + m] = reinterpret_cast<const float4 *>(row + rem_delta)[m];
+                }
+            }
+            w1[rr] = 1.0f;
+            if constexpr (WEIGHTED) {
+                const bool has_w = lf[rr].indirect && lf[rr].rw;
+                const float *wp = has_w ? lf[rr].rw + mult : args.dummy_f32;
+                w1[rr] = *wp;
+                if (!has_w) w1[rr] = 1.0f;
+            }
+        }
+    };
+
+    // ---- prologue ---------------------------------------------------------------------
+    issue_off(0);
+    issue_idx(0);
+    issue_off(1);
+    issue_rows(0);
+    issue_idx(1);
+    issue_off(2);
+
+    const float *x_base = reinterpret_cast<const float *>(args.src[0]);
+    const int64_t x_stride = args.stride[0];
+
+    for (int k = 0; k < n_samples; k++) {
+        // rotate: rows of sample k are (being) loaded into a_next -> a_cur
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) a_cur[rr][c] = a_next[rr][c];
+            st0[rr] = st1[rr]; len0[rr] = len1[rr]; first0[rr] = first1[rr]; w0[rr] = w1[rr];
+        }
+        issue_rows(k + 1);
+        issue_idx(k + 2);
+        issue_off(k + 3);
+
+        // ---- consume sample k --------------------------------------------------------
+        const int64_t b = wave_id + (int64_t)k * waves_total;  // wave-uniform
+        // x passthrough: re-read x[b] (L1/L2 hit) with one lane per element, one store
+        float xv[(d + 63) / 64];
+#pragma unroll
+        for (int h = 0; h < (d + 63) / 64; h++) {
+            const int e = lane + 64 * h;
+            xv[h] = x_base[b * x_stride + (e < d ? e : 0)];
+        }
+        float4 a[NR][NC];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float4 t = a_cur[rr][c];
+                if constexpr (HAS_INDIRECT && CODEC != 32) {
+                    if (lf[rr].indirect && !first0[rr]) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if constexpr (WEIGHTED) {
+                    t.x = __fmul_rn(t.x, w0[rr]); t.y = __fmul_rn(t.y, w0[rr]);
+                    t.z = __fmul_rn(t.z, w0[rr]); t.w = __fmul_rn(t.w, w0[rr]);
+                }
+                a[rr][c] = t;
+            }
+        if constexpr (HAS_INDIRECT) {
+            // bags longer than one index: remaining elements, in index order (not pipelined)
+            bool more = false;
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) more |= len0[rr] > 1;
+            if (__any(more)) {
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) {
+                    for (int j = 1; j < len0[rr]; j++) {
+                        const int64_t r = lf[rr].idx[st0[rr] + j];
+                        if ((uint64_t)r >= (uint64_t)lf[rr].n_rows) { bad = true; continue; }
+                        const char *row = lf[rr].src + (uint64_t)(unsigned)r * (uint64_t)lf[rr].scale;
+                        float w = 1.0f;
+                        if constexpr (WEIGHTED) { if (lf[rr].rw) w = lf[rr].rw[r]; }
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            float4 t = c < CQ ? load_chunk<CODEC>(row, c) : load_chunk<CODEC>(row + lf[rr].rem_delta, c - CQ);
+                            if constexpr (WEIGHTED) {
+                                t.x = __fmul_rn(t.x, w); t.y = __fmul_rn(t.y, w);
+                                t.z = __fmul_rn(t.z, w); t.w = __fmul_rn(t.w, w);
+                            }
+                            a[rr][c].x = __fadd_rn(a[rr][c].x, t.x); a[rr][c].y = __fadd_rn(a[rr][c].y, t.y);
+                            a[rr][c].z = __fadd_rn(a[rr][c].z, t.z); a[rr][c].w = __fadd_rn(a[rr][c].w, t.w);
+                        }
+                    }
+                }
+            }
+        }
+
+        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float e0[4] = {a[0][c].x, a[0][c].y, a[0][c].z, a[0][c].w};
+            const float e1[4] = {a[NR - 1][c].x, a[NR - 1][c].y, a[NR - 1][c].z, a[NR - 1][c].w};
+            if (c < CQ) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[e], e0[e], c00, 0, 0, 0);
+                    if constexpr (NT == 2) {
+                        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e0[e], c10, 0, 0, 0);
+                        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e1[e], c11, 0, 0, 0);
+                    }
+                }
+            } else {  // shared remainder chunk: k-slot q contributes its element q
+                const float s0 = q == 0 ? e0[0] : q == 1 ? e0[1] : q == 2 ? e0[2] : e0[3];
+                const float s1 = q == 0 ? e1[0] : q == 1 ? e1[1] : q == 2 ? e1[2] : e1[3];
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, s0, c00, 0, 0, 0);
+                if constexpr (NT == 2) {
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s0, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s1, c11, 0, 0, 0);
+                }
+            }
+        }
+        // one buffer resource per output row: base = R + b*out_row (SGPRs), bounds = one row
+        float *Rb = args.R + b * (int64_t)out_row;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, out_row * 4, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < (d + 63) / 64; h++) {
+            const int e = lane + 64 * h;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv[h]), rs, e < d ? 4 * e : kOob, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c00[v]), rs, zo00[v], 0, 0);
+            if constexpr (NT == 2) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c10[v]), rs, zo10[v], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c11[v]), rs, zo11[v], 0, 0);
+            }
+        }
+    }
+    if (bad) atomicOr(args.err, 1);
+}
+
+template <int CODEC, int CQ, int REM, bool WEIGHTED, bool HAS_INDIRECT>
+static void launch_nt(const FusedArgs &a, hipStream_t st) {
+    // persistent grid: exactly the resident waves, each walking its samples through the pipeline
+    static int per_cu[2] = {0, 0};
+    const int nt = a.F <= 16 ? 0 : 1;
+    if (!per_cu[nt]) {
+        int n = 0;
+        hipError_t e = nt ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                                &n, emb_interact_dot_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT>, 256, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                                &n, emb_interact_dot_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT>, 256, 0);
+        per_cu[nt] = (e == hipSuccess && n > 0) ? n : 2;
+    }
+    int64_t blocks = (a.B + 3) / 4;
+    const int64_t cap = (int64_t)kNumCu * per_cu[nt];
+    if (blocks > cap) blocks = cap;
+    if (nt == 0)
+        hipLaunchKernelGGL((emb_interact_dot_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT>), dim3((unsigned)blocks),
+                           dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((emb_interact_dot_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT>), dim3((unsigned)blocks),
+                           dim3(256), 0, st, a);
+}
+
+template <int CODEC, bool WEIGHTED, bool HAS_INDIRECT>
+static bool launch_cpq(const FusedArgs &a, hipStream_t st) {
+    switch (a.d) {
+    case 16: launch_nt<CODEC, 1, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
+    case 32: launch_nt<CODEC, 2, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
+    case 36: launch_nt<CODEC, 2, 1, WEIGHTED, HAS_INDIRECT>(a, st); return true;  // every EVStore script
+    case 48: launch_nt<CODEC, 3, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
+    case 64: launch_nt<CODEC, 4, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
+    case 128: launch_nt<CODEC, 8, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
+    default: return false;
+    }
+}
+
+}  // namespace evs
+
+extern "C" int evs_fused_dim_supported(int d) {
+    return d == 16 || d == 32 || d == 36 || d == 48 || d == 64 || d == 128;
+}
+
+extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const evs_feature *feats, int itself,
+                                    float *R, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(B >= 0 && B < (1ll << 31) && F >= 1 && F <= EVS_MAX_FEATURES && evs_fused_dim_supported(d),
+                "evs_emb_interact_dot: unsupported shape B=%lld F=%d d=%d (need F<=32, d in {16,32,36,48,64,128})",
+                (long long)B, F, d);
+    EVS_REQUIRE(codec == 32 || codec == 16 || codec == 8 || codec == 4, "evs_emb_interact_dot: codec %d", codec);
+    if (B == 0) return EVS_OK;
+    EVS_REQUIRE(feats && R, "evs_emb_interact_dot: NULL argument");
+    EVS_REQUIRE(feats[0].indices == nullptr, "evs_emb_interact_dot: feature 0 (x) must be dense");
+    FusedArgs a;
+    for (int f = 0; f < EVS_MAX_FEATURES; f++) {
+        const bool on = f < F;
+        a.src[f] = on ? feats[f].src : nullptr;
+        a.stride[f] = on ? feats[f].stride : 0;
+        a.indices[f] = on ? feats[f].indices : nullptr;
+        a.offsets[f] = on ? feats[f].offsets : nullptr;
+        a.nnz[f] = on ? feats[f].nnz : 0;
+        a.n_rows[f] = on ? feats[f].n_rows : 0;
+        a.row_w[f] = on ? feats[f].row_weights : nullptr;
+        if (!on) continue;
+        EVS_REQUIRE(feats[f].src || (feats[f].indices && feats[f].n_rows == 0), "evs_emb_interact_dot: feats[%d].src is NULL", f);
+        EVS_REQUIRE(reinterpret_cast<uintptr_t>(feats[f].src) % 16 == 0, "evs_emb_interact_dot: feats[%d].src must be 16-byte aligned", f);
+        if (feats[f].indices) {
+            EVS_REQUIRE(feats[f].offsets, "evs_emb_interact_dot: feats[%d].offsets is NULL", f);
+            EVS_REQUIRE(feats[f].nnz >= 0 && feats[f].n_rows >= 0 && feats[f].nnz < (1ll << 31) && feats[f].n_rows < (1ll << 31),
+                        "evs_emb_interact_dot: feats[%d]: nnz and n_rows must be in [0, 2^31)", f);
+        } else {
+            EVS_REQUIRE(feats[f].stride % 4 == 0 && feats[f].stride >= 0 && feats[f].stride < (1ll << 31),
+                        "evs_emb_interact_dot: dense feats[%d].stride must be a multiple of 4 in [0, 2^31)", f);
+        }
+    }
+    a.R = R; a.B = B; a.F = F; a.d = d; a.itself = itself ? 1 : 0;
+    a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    a.err = index_error_flag();
+    if (!a.err) return EVS_EHIP;
+    a.zeros = zero_page();
+    if (!a.zeros) return EVS_EHIP;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    bool weighted = false, indirect = false;
+    a.dummy_i64 = nullptr;
+    a.dummy_f32 = reinterpret_cast<const float *>(feats[0].src);
+    for (int f = 0; f < F; f++) {
+        if (!feats[f].indices) continue;
+        indirect = true;
+        weighted |= feats[f].row_weights != nullptr;
+        if (!a.dummy_i64) a.dummy_i64 = feats[f].offsets;  // B >= 1 entries, always readable
+        if (feats[f].n_rows == 0 || !feats[f].src) a.src[f] = a.zeros;  // never dereferenced for a valid row
+    }
+    EVS_REQUIRE(!weighted || codec == 32, "evs_emb_interact_dot: weighted pooling is only built for fp32 tables");
+    bool ok;
+    if (!indirect) {
+        ok = launch_cpq<32, false, false>(a, st);
+    } else {
+        switch (codec) {
+        case 32: ok = weighted ? launch_cpq<32, true, true>(a, st) : launch_cpq<32, false, true>(a, st); break;
+        case 16: ok = launch_cpq<16, false, true>(a, st); break;
+        case 8: ok = launch_cpq<8, false, true>(a, st); break;
+        default: ok = launch_cpq<4, false, true>(a, st); break;
+        }
+    }
+    EVS_REQUIRE(ok, "evs_emb_interact_dot: no kernel for d=%d", d);
+    (void)weighted;
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
+}
+
+extern "C" int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec, const void *const *tables,
+                                            const int64_t *n_rows, const float *x, int64_t x_stride,
+                                            const int64_t *indices_base, int64_t indices_row_stride,
+                                            int64_t nnz_per_table, const int64_t *offsets_base,
+                                            int64_t offsets_row_stride, const float *const *row_weights, int itself,
+                                            float *R, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(T >= 0 && T + 1 <= EVS_MAX_FEATURES, "evs_emb_interact_dot_stacked: T=%d (need T+1 <= %d)", T,
+                EVS_MAX_FEATURES);
+    EVS_REQUIRE(B == 0 || (tables && n_rows && x && indices_base && offsets_base),
+                "evs_emb_interact_dot_stacked: NULL argument");
+    evs_feature ft[EVS_MAX_FEATURES];
+    ft[0].src = x; ft[0].stride = x_stride; ft[0].indices = nullptr; ft[0].offsets = nullptr;
+    ft[0].nnz = 0; ft[0].n_rows = 0; ft[0].row_weights = nullptr;
+    for (int k = 0; k < T; k++) {
+        evs_feature &f = ft[k + 1];
+        f.src = tables[k]; f.stride = 0;
+        f.indices = indices_base + (int64_t)k * indices_row_stride;
+        f.offsets = offsets_base + (int64_t)k * offsets_row_stride;
+        f.nnz = nnz_per_table; f.n_rows = n_rows[k];
+        f.row_weights = row_weights ? row_weights[k] : nullptr;
+    }
+    return evs_emb_interact_dot(B, T + 1, d, codec, ft, itself, R, stream);
+}

@@ -1,4 +1,5 @@
-// interact_features ("dot") on the gfx950 matrix cores.
+// interact_features: entry point, generic fallback and the "cat" variant.
+// The matrix-core "dot" kernel lives in evs_fused.hip (dense features = plain interaction).
 //
 // Replaces dlrm_s_pytorch.py:483-516: cat -> bmm(T, T^T) -> strict-lower-triangle
 // gather (index tensors rebuilt on the host every call) -> cat, by ONE kernel that
@@ -27,83 +28,6 @@ struct InteractArgs {
     int64_t B;
     int F, d, itself, P;
 };
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int KS>
-__device__ __forceinline__ void load_piece(const float *__restrict__ p, float (&v)[KS]) {
-    if constexpr (KS % 4 == 0) {
-#pragma unroll
-        for (int i = 0; i < KS / 4; i++) {
-            const float4 q = reinterpret_cast<const float4 *>(p)[i];
-            v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < KS; i++) v[i] = p[i];
-    }
-}
-
-// NT = 1: F <= 16 (one tile); NT = 2: F <= 32 (tiles (0,0), (1,0), (1,1)).
-template <int KS, int NT>
-__global__ void __launch_bounds__(256) interact_dot_kernel(const InteractArgs args) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int r16 = lane & 15;  // row inside a 16-row tile (A operand) = column (B operand)
-    const int q = lane >> 4;    // k-slot 0..3
-    const int F = args.F, d = KS * 4, itself = args.itself;
-    const int64_t out_row = (int64_t)d + args.P;
-
-    // per-lane feature pointers: dynamic index into the kernarg struct (read-only memory)
-    const InteractArgs *ka = (const InteractArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    const float *p0 = nullptr, *p1 = nullptr;
-    int64_t s0 = 0, s1 = 0;
-    if (r16 < F) { p0 = ka->feat[r16] + q * KS; s0 = ka->stride[r16]; }
-    if (NT == 2 && r16 + 16 < F) { p1 = ka->feat[r16 + 16] + q * KS; s1 = ka->stride[r16 + 16]; }
-
-    const int64_t waves_total = (int64_t)gridDim.x * (blockDim.x / kWave);
-    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-
-    for (int64_t b = wave_id; b < args.B; b += waves_total) {
-        float a0[KS], a1[KS];
-#pragma unroll
-        for (int i = 0; i < KS; i++) { a0[i] = 0.f; a1[i] = 0.f; }
-        if (p0) load_piece<KS>(p0 + b * s0, a0);
-        if (NT == 2 && p1) load_piece<KS>(p1 + b * s1, a1);
-
-        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
-            c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], a0[s], c00, 0, 0, 0);
-            if (NT == 2) {
-                c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], a0[s], c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], a1[s], c11, 0, 0, 0);
-            }
-        }
-
-        float *__restrict__ R = args.R + b * out_row;
-        // x passthrough: feature 0 lives in the four lanes with r16 == 0
-        if (r16 == 0) {
-#pragma unroll
-            for (int i = 0; i < KS; i++) R[q * KS + i] = a0[i];
-        }
-        // C/D layout of 16x16 tiles: row i = 4*(lane>>4) + v, col j = lane & 15
-        float *__restrict__ Z = R + d;
-        const int j0 = r16;
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int i = 4 * q + v;
-            if (i < F && j0 < i + itself) Z[(i * (i - 1 + 2 * itself)) / 2 + j0] = c00[v];
-            if (NT == 2) {
-                const int gi = 16 + i;
-                if (gi < F) {
-                    const int base = (gi * (gi - 1 + 2 * itself)) / 2;
-                    Z[base + j0] = c10[v];                                            // cols 0..15 < gi
-                    if (16 + j0 < gi + itself) Z[base + 16 + j0] = c11[v];            // cols 16..31
-                }
-            }
-        }
-    }
-}
 
 // Generic fallback (F > 32 or d % 4 != 0 or d > 256): one (sample, pair) per thread.
 __global__ void __launch_bounds__(256) interact_dot_generic_kernel(const float *const *feat,
@@ -135,17 +59,6 @@ __global__ void __launch_bounds__(256) interact_cat_kernel(const InteractArgs ar
     }
 }
 
-template <int KS>
-static void launch_ks(const InteractArgs &a, hipStream_t st) {
-    int64_t blocks = (a.B + 3) / 4;
-    const int64_t cap = (int64_t)kNumCu * 8;
-    if (blocks > cap) blocks = cap;
-    if (a.F <= 16)
-        hipLaunchKernelGGL((interact_dot_kernel<KS, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((interact_dot_kernel<KS, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-}
-
 static int fill_args(InteractArgs &a, int64_t B, int F, int d, const float *const *feats,
                      const int64_t *feat_strides, int itself, float *R) {
     for (int f = 0; f < EVS_MAX_FEATURES; f++) {
@@ -167,29 +80,19 @@ extern "C" int evs_interact_dot(int64_t B, int F, int d, const float *const *fea
     EVS_REQUIRE(feats && feat_strides && R, "evs_interact_dot: NULL argument");
     itself = itself ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    bool mfma_ok = F <= EVS_MAX_FEATURES && d % 4 == 0 && d <= 256;
+    // matrix-core path = the fused kernel with every feature dense (evs_fused.hip)
+    bool mfma_ok = F <= EVS_MAX_FEATURES && evs_fused_dim_supported(d) && B < (1ll << 31);
     for (int f = 0; f < F && mfma_ok; f++) {
         EVS_REQUIRE(feats[f], "evs_interact_dot: feats[%d] is NULL", f);
-        const int ks = d / 4;
-        // lanes read KS-float pieces: float4 loads need 16-byte aligned pieces
-        if (ks % 4 == 0 && (reinterpret_cast<uintptr_t>(feats[f]) % 16 != 0 || feat_strides[f] % 4 != 0))
-            mfma_ok = false;
+        if (reinterpret_cast<uintptr_t>(feats[f]) % 16 != 0 || feat_strides[f] % 4 != 0) mfma_ok = false;
     }
     if (mfma_ok) {
-        InteractArgs a;
-        fill_args(a, B, F, d, feats, feat_strides, itself, R);
-        switch (d / 4) {
-        case 4: launch_ks<4>(a, st); break;    // d = 16
-        case 8: launch_ks<8>(a, st); break;    // d = 32
-        case 9: launch_ks<9>(a, st); break;    // d = 36
-        case 16: launch_ks<16>(a, st); break;  // d = 64
-        case 32: launch_ks<32>(a, st); break;  // d = 128
-        default: mfma_ok = false; break;
+        evs_feature ft[EVS_MAX_FEATURES];
+        for (int f = 0; f < F; f++) {
+            ft[f].src = feats[f]; ft[f].stride = feat_strides[f]; ft[f].indices = nullptr; ft[f].offsets = nullptr;
+            ft[f].nnz = 0; ft[f].n_rows = 0; ft[f].row_weights = nullptr;
         }
-        if (mfma_ok) {
-            EVS_HIP_CHECK(hipGetLastError());
-            return EVS_OK;
-        }
+        return evs_emb_interact_dot(B, F, d, 32, ft, itself, R, stream);
     }
     // generic path: pointer tables go through a small device buffer
     const int P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;

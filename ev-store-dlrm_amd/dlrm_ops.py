@@ -18,7 +18,15 @@ from . import _lib
 
 
 def _stream_ptr(device):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _row_weights_c(ev, v_W_l):
+    """ctypes array of per-row weight pointers (or None); tensors kept alive by the returned list."""
+    if v_W_l is None or all(w is None for w in v_W_l):
+        return None, None
+    keep = [None if w is None else w.detach().to(ev.device, torch.float32).contiguous() for w in v_W_l]
+    return (C.c_void_p * len(keep))(*[None if w is None else w.data_ptr() for w in keep]), keep
 
 
 class EVTables:
@@ -117,17 +125,13 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False):
     B = int(lS_o.shape[1]) if stacked_o else int(lS_o[0].shape[0])
     if out is None:
         buf = torch.empty((T, B, d), dtype=torch.float32, device=dev)
-        base, tstride, bstride = buf, B * d, d
-        ly = [buf[k] for k in range(T)]
+        out_ptr, tstride, bstride = buf.data_ptr(), B * d, d
+        ly = list(buf.unbind(0))
     else:  # (B, F, d) tile: table k -> out[:, k+1, :]
         assert out.shape == (B, T + 1, d) and out.is_contiguous() and out.dtype == torch.float32
-        base, tstride, bstride = out[:, 1:, :], d, (T + 1) * d
-        ly = [out[:, k + 1, :] for k in range(T)]
-    rw_c = None
-    if v_W_l is not None and any(w is not None for w in v_W_l):
-        keep = [None if w is None else w.detach().to(dev, torch.float32).contiguous() for w in v_W_l]
-        rw_c = (C.c_void_p * T)(*[None if w is None else w.data_ptr() for w in keep])
-    out_ptr = C.c_void_p(base.data_ptr() if out is None else out.data_ptr() + 4 * d)
+        out_ptr, tstride, bstride = out.data_ptr() + 4 * d, d, (T + 1) * d
+        ly = list(out.unbind(1)[1:])
+    rw_c, _keep = _row_weights_c(ev, v_W_l)
     stream = _stream_ptr(dev)
     if stacked_i and stacked_o:
         assert lS_i.dtype == torch.int64 and lS_o.dtype == torch.int64
@@ -135,8 +139,8 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False):
         assert lS_i.stride(1) == 1 and lS_o.stride(1) == 1
         rc = L.evs_embedding_bag_sum_stacked(
             T, B, d, ev.codec, ev._tables_c, ev._n_rows_c,
-            C.c_void_p(lS_i.data_ptr()), lS_i.stride(0), int(lS_i.shape[1]),
-            C.c_void_p(lS_o.data_ptr()), lS_o.stride(0), rw_c, out_ptr, tstride, bstride, stream)
+            lS_i.data_ptr(), lS_i.stride(0), int(lS_i.shape[1]),
+            lS_o.data_ptr(), lS_o.stride(0), rw_c, out_ptr, tstride, bstride, stream)
     else:
         li = [lS_i[k] for k in range(T)]
         lo = [lS_o[k] for k in range(T)]
@@ -175,9 +179,69 @@ def interact_features(x, ly, arch_interaction_op="dot", arch_interaction_itself=
         P = F * (F + 1) // 2 if arch_interaction_itself else F * (F - 1) // 2
         R = torch.empty((B, d + P), dtype=torch.float32, device=dev)
         rc = L.evs_interact_dot(B, F, d, ptrs, strides, int(bool(arch_interaction_itself)),
-                                C.c_void_p(R.data_ptr()), _stream_ptr(dev))
+                                R.data_ptr(), _stream_ptr(dev))
     else:
         R = torch.empty((B, F * d), dtype=torch.float32, device=dev)
-        rc = L.evs_interact_cat(B, F, d, ptrs, strides, C.c_void_p(R.data_ptr()), _stream_ptr(dev))
+        rc = L.evs_interact_cat(B, F, d, ptrs, strides, R.data_ptr(), _stream_ptr(dev))
     _lib.check(rc)
+    return R
+
+
+def fused_supported(F, d):
+    """Shapes the fused gather+interaction kernel is built for (csrc/evs_fused.hip)."""
+    return F <= 32 and d in (16, 32, 36, 48, 64, 128)
+
+
+def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself=False, check_indices=False,
+                       out=None):
+    """R = interact_features(x, apply_emb(lS_o, lS_i, emb_l, v_W_l)) in ONE kernel.
+
+    The apply_emb -> interact_features pair of DLRM_Net.sequential_forward
+    (dlrm_s_pytorch.py:596-601) without the (B,F,d) intermediate: table rows are
+    gathered, pooled and fed to the matrix cores in registers.  Same arguments as
+    apply_emb plus x; same result as the two-call path (pooled sums bit-identical,
+    dot products fp32 MFMA chains).  "dot" interaction only.
+    """
+    ev = _as_evtables(emb_l)
+    T, d = len(ev), ev.d
+    F = T + 1
+    B = int(x.shape[0])
+    dev = ev.device
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, d) and x.stride(1) == 1
+    if not fused_supported(F, d):
+        return interact_features(x, apply_emb(lS_o, lS_i, ev, v_W_l), "dot", arch_interaction_itself)
+    P = F * (F + 1) // 2 if arch_interaction_itself else F * (F - 1) // 2
+    R = out if out is not None else torch.empty((B, d + P), dtype=torch.float32, device=dev)
+    assert R.shape == (B, d + P) and R.is_contiguous() and R.dtype == torch.float32
+    L = _lib.lib()
+    stream = _stream_ptr(dev)
+    if torch.is_tensor(lS_i) and torch.is_tensor(lS_o):  # stacked (T,B) Criteo layout: one call, no lists
+        assert lS_i.dtype == torch.int64 and lS_o.dtype == torch.int64 and lS_i.is_cuda and lS_o.is_cuda
+        assert lS_i.stride(1) == 1 and lS_o.stride(1) == 1 and lS_o.shape[1] == B
+        rw_c, _keep = _row_weights_c(ev, v_W_l)
+        _lib.check(L.evs_emb_interact_dot_stacked(
+            B, T, d, ev.codec, ev._tables_c, ev._n_rows_c, x.data_ptr(), int(x.stride(0)) if B > 1 else d,
+            lS_i.data_ptr(), lS_i.stride(0), int(lS_i.shape[1]), lS_o.data_ptr(), lS_o.stride(0), rw_c,
+            int(bool(arch_interaction_itself)), R.data_ptr(), stream))
+        if check_indices:
+            _lib.check(L.evs_check_index_errors(stream))
+        return R
+    feats = (_lib.EvsFeature * F)()
+    feats[0].src, feats[0].stride = x.data_ptr(), (int(x.stride(0)) if B > 1 else d)
+    keep = []
+    for k in range(T):
+        i, o = lS_i[k], lS_o[k]
+        assert i.dtype == torch.int64 and o.dtype == torch.int64 and i.is_cuda and o.is_cuda
+        assert (i.numel() == 0 or i.stride(0) == 1) and o.stride(0) == 1 and o.numel() == B
+        f = feats[k + 1]
+        f.src, f.indices, f.offsets = ev.raw[k].data_ptr(), i.data_ptr(), o.data_ptr()
+        f.nnz, f.n_rows = int(i.numel()), ev.n_rows[k]
+        if v_W_l is not None and v_W_l[k] is not None:
+            w = v_W_l[k].detach().to(dev, torch.float32).contiguous()
+            keep.append(w)
+            f.row_weights = w.data_ptr()
+    _lib.check(L.evs_emb_interact_dot(B, F, d, ev.codec, feats, int(bool(arch_interaction_itself)),
+                                      R.data_ptr(), stream))
+    if check_indices:
+        _lib.check(L.evs_check_index_errors(stream))
     return R

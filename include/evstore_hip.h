@@ -110,6 +110,50 @@ EVS_API int evs_check_index_errors(void *stream);
 EVS_API int evs_interact_dot(int64_t B, int F, int d, const float *const *feats,
                      const int64_t *feat_strides, int itself, float *R, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * a4: the apply_emb -> interact_features pair of DLRM_Net.sequential_forward
+ *     (dlrm_s_pytorch.py:588-601) as ONE kernel: R = interact_features(x, apply_emb(...)).
+ *
+ * Every row of the per-sample matrix T[b] (F x d) is described by an evs_feature:
+ *   dense    (indices == NULL): the d floats at (const float*)src + b*stride
+ *                               -- x, or pooled vectors received from the all-to-all;
+ *   indirect (indices != NULL): the sum-pooled bag b of table `src` (row-major rows of d
+ *                               elements in `codec`), exactly evs_embedding_bag_sum's
+ *                               definition for one table (offsets = B bag starts, the
+ *                               last bag runs to nnz; row_weights = per-ROW weights or NULL).
+ * feats: HOST array of F entries, feats[0] must be dense (x).  All indirect features
+ * share `codec`.  Output as evs_interact_dot.  Requires F <= 32, B < 2^31,
+ * evs_fused_dim_supported(d), src 16-byte aligned, dense strides % 4 == 0.
+ * The (B,F,d) intermediate is never written.  Pooled sums round exactly as in
+ * evs_embedding_bag_sum; dot products are fp32 MFMA chains (rtol 1e-5 vs the oracle).
+ * ------------------------------------------------------------------------- */
+typedef struct evs_feature {
+    const void *src;
+    int64_t stride;
+    const int64_t *indices;
+    const int64_t *offsets;
+    int64_t nnz;
+    int64_t n_rows;
+    const float *row_weights;
+} evs_feature;
+
+/* 1 if the fused kernel is built for this embedding dimension (16,32,36,48,64,128). */
+EVS_API int evs_fused_dim_supported(int d);
+
+EVS_API int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const evs_feature *feats,
+                                 int itself, float *R, void *stream);
+
+/* Stacked-layout form (Criteo collate: indices and offsets are (T,B) int64 tensors, see
+ * evs_embedding_bag_sum_stacked): feature 0 = x (B,d) with row stride x_stride floats,
+ * feature k+1 = bag-sum over tables[k].  F = T + 1. */
+EVS_API int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec,
+                                 const void *const *tables, const int64_t *n_rows,
+                                 const float *x, int64_t x_stride,
+                                 const int64_t *indices_base, int64_t indices_row_stride,
+                                 int64_t nnz_per_table,
+                                 const int64_t *offsets_base, int64_t offsets_row_stride,
+                                 const float *const *row_weights, int itself, float *R, void *stream);
+
 /* "cat" interaction (dlrm_s_pytorch.py:506-508): R[b] = [x[b] | ly_0[b] | ...], (B, F*d). */
 EVS_API int evs_interact_cat(int64_t B, int F, int d, const float *const *feats,
                      const int64_t *feat_strides, float *R, void *stream);

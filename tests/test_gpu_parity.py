@@ -208,3 +208,44 @@ def test_full_size_kaggle_properties(E):
     li, lj = torch.tril_indices(27, 27, offset=-1, device="cuda")
     ref = torch.cat([x, Z[:, li, lj]], dim=1)
     torch.testing.assert_close(R, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["dlrm_ragged_small", "dlrm_kaggle_small", "dlrm_weighted_itself", "dlrm_d64",
+                                  "dlrm_d128", "dlrm_cfg1"])
+def test_fused_gather_interact_vs_golden(E, orc, name):
+    """apply_emb_interact == interact_features(x, apply_emb(...)) (one kernel, no intermediate)."""
+    g = load_golden(name)
+    if name == "dlrm_cfg1":
+        from test_oracle_golden import _tables_cfg1
+        tabs = _tables_cfg1(g)
+    else:
+        tabs = split_tables(g)
+    lS_o, lS_i = split_indices(g)
+    vW = split_weights(g)
+    ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    w = None if vW is None else [_dev(v) for v in vW]
+    x = _dev(g["x"])
+    o, i = [_dev(r) for r in lS_o], [_dev(r) for r in lS_i]
+    R = E.apply_emb_interact(x, o, i, ev, w, bool(g["itself"]), check_indices=True)
+    np.testing.assert_allclose(R.cpu().numpy(), g["R"], rtol=RTOL, atol=2e-6)
+    # identical to the two-kernel path bit for bit (same pooled sums, same MFMA chain)
+    R2 = E.interact_features(x, E.apply_emb(o, i, ev, w), "dot", bool(g["itself"]))
+    assert torch.equal(R, R2)
+
+
+@pytest.mark.parametrize("codec", [16, 8, 4])
+def test_fused_codec_tiers(E, orc, codec):
+    d = 36
+    rs = np.random.RandomState(codec)
+    n_rows = [700, 3, 41]
+    T, B = len(n_rows), 97
+    raws = [orc.encode_table(rs.uniform(-1, 1, size=(n, d)).astype(np.float32), codec) for n in n_rows]
+    lens = rs.randint(0, 4, size=(T, B))
+    lS_i = [rs.randint(0, n_rows[k], size=lens[k].sum()).astype(np.int64) for k in range(T)]
+    lS_o = [np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64) for k in range(T)]
+    ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, codec)
+    x = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    R = E.apply_emb_interact(_dev(x), [_dev(o) for o in lS_o], [_dev(i) for i in lS_i], ev, check_indices=True)
+    ly = orc.apply_emb(lS_o, lS_i, raws, None, codec, d)
+    Ro = orc.interact_features(x, ly)
+    np.testing.assert_allclose(R.cpu().numpy(), Ro, rtol=RTOL, atol=2e-6)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Developer micro-benchmark: per-kernel timings of the hot path on one GPU.
+usage: python tools/kbench.py [--batch 16384] [--layouts tile,table] [--iters 200]"""
+import argparse
+import os
+import sys
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import evstore_dlrm_amd as E  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(5):
+        fn(0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, nargs="+", default=[16384])
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--dim", type=int, default=36)
+    ap.add_argument("--dist", default="uniform")
+    ap.add_argument("--fused-only", action="store_true")
+    a = ap.parse_args()
+    d = a.dim
+    ev = bench.make_tables(bench.KAGGLE_LN, d)
+    T = 26
+    for B in a.batch:
+        batches = bench.make_batches(bench.KAGGLE_LN, B, 8, 1, "cuda", a.dist)
+        x = torch.rand(B, d, device="cuda")
+        tile = torch.empty(B, T + 1, d, device="cuda")
+        g_tile = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None, out=tile), a.iters)
+        ly_tile = E.apply_emb(batches[0][0], batches[0][1], ev, None, out=tile)
+        i_tile = timeit(lambda i: E.interact_features(x, ly_tile), a.iters)
+        g_tab = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None), a.iters)
+        ly_tab = E.apply_emb(batches[0][0], batches[0][1], ev, None)
+        i_tab = timeit(lambda i: E.interact_features(x, ly_tab), a.iters)
+        f_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev), a.iters)
+        fb = B * (26 * (4 * d + 16) + 4 * d + 4 * (d + 351)) / 1e3
+        print("B=%6d  fused gather+interact %7.1f us (%5.0f GB/s algorithmic, %.2f G lookups/s)" % (B, f_us, fb / f_us, 26 * B / f_us / 1e3))
+        if a.fused_only:
+            continue
+        gb = T * B * (8 * d + 16) / 1e3  # KB... bytes/1e3
+        ib = B * (4 * 27 * d + 4 * (d + 351)) / 1e3
+        print("B=%6d  gather tile %7.1f us (%5.0f GB/s)  table %7.1f us (%5.0f GB/s) | interact tile %7.1f us (%5.0f GB/s)  table %7.1f us (%5.0f GB/s)"
+              % (B, g_tile, gb / g_tile, g_tab, gb / g_tab, i_tile, ib / i_tile, i_tab, ib / i_tab), flush=True)
+
+
+if __name__ == "__main__":
+    main()
