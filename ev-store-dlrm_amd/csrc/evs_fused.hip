@@ -113,16 +113,17 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
     for (int rr = 0; rr < NR; rr++) {
         const int f = r16 + 16 * rr;
         lf[rr].src = reinterpret_cast<const char *>(args.zeros);  // idle lanes read zeros
-        lf[rr].idx = nullptr; lf[rr].off = nullptr; lf[rr].rw = nullptr;
+        lf[rr].idx = args.dummy_i64; lf[rr].off = args.dummy_i64; lf[rr].rw = nullptr;
         lf[rr].scale = 0; lf[rr].nnz = 0; lf[rr].n_rows = 0; lf[rr].indirect = false;
         lf[rr].rem_delta = 4 * CQ * 16 - q * CQ * 16;
         if (f < F) {
-            lf[rr].idx = ka->indices[f];
-            lf[rr].indirect = HAS_INDIRECT && lf[rr].idx != nullptr;
+            const int64_t *ip = ka->indices[f];
+            lf[rr].indirect = HAS_INDIRECT && ip != nullptr;
+            lf[rr].idx = lf[rr].indirect ? ip : args.dummy_i64;
             const int cb = lf[rr].indirect ? kChunkBytes : 16;
             lf[rr].src = reinterpret_cast<const char *>(ka->src[f]) + q * CQ * cb;
             lf[rr].rem_delta = 4 * CQ * cb - q * CQ * cb;
-            lf[rr].off = ka->offsets[f];
+            lf[rr].off = lf[rr].indirect ? ka->offsets[f] : args.dummy_i64;
             if constexpr (WEIGHTED) lf[rr].rw = ka->row_w[f];
             lf[rr].scale = lf[rr].indirect ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4);
             lf[rr].nnz = (int)ka->nnz[f];
@@ -152,15 +153,17 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
     const int n_samples = (int)((B - wave_id + waves_total - 1) / waves_total);
     bool bad = false;
 
-    // ---- pipeline state -------------------------------------------------------------
+    // ---- pipeline state (branch-free: every decision below is a select) ----------------
+    struct Stage {                     // one sample whose rows are in flight / being consumed
+        float4 a[NR][NC];
+        int st[NR], len[NR];
+        bool first[NR];                // first bag element valid
+        float w[NR];                   // per-row weight of the first element (WEIGHTED)
+    };
     int64_t off0[NR], off1[NR];        // raw offsets in flight
     int64_t idx_raw[NR];               // raw first index in flight
     int st2[NR], len2[NR];             // bag start/length of the sample whose index is in flight
-    int st1[NR], len1[NR];             // ... of the sample whose rows are in flight
-    int st0[NR], len0[NR];             // ... of the sample being consumed
-    bool first1[NR], first0[NR];       // first bag element valid (CODEC != 32 only: select after decode)
-    float w1[NR], w0[NR];              // per-row weight of the first element (WEIGHTED)
-    float4 a_next[NR][NC], a_cur[NR][NC];
+    Stage sA, sB;
 
     auto sample_b = [&](int n) -> int64_t {
         const int64_t b = wave_id + (int64_t)n * waves_total;
@@ -171,10 +174,9 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
             const int64_t b = sample_b(n);
             const int64_t b1 = (b + 1 < B) ? b + 1 : b;
 #pragma unroll
-            for (int rr = 0; rr < NR; rr++) {
-                const int64_t *op = lf[rr].indirect ? lf[rr].off : args.dummy_i64;
-                off0[rr] = op[lf[rr].indirect ? b : 0];
-                off1[rr] = op[lf[rr].indirect ? b1 : 0];
+            for (int rr = 0; rr < NR; rr++) {  // dense/idle lanes read a dummy offsets array
+                off0[rr] = lf[rr].off[b];
+                off1[rr] = lf[rr].off[b1];
             }
         }
     };
@@ -184,93 +186,74 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
             const bool last = !(b + 1 < B);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {
-                st2[rr] = 0;
-                len2[rr] = 0;
-                if (lf[rr].indirect) {
-                    const int64_t s0 = off0[rr];
-                    const int64_t e0 = last ? (int64_t)lf[rr].nnz : off1[rr];
-                    if (s0 >= 0 && e0 >= s0 && e0 <= (int64_t)lf[rr].nnz) { st2[rr] = (int)s0; len2[rr] = (int)(e0 - s0); }
-                    else bad = true;
-                }
+                const int64_t nnz = (int64_t)lf[rr].nnz;
+                const int64_t s0 = off0[rr];
+                const int64_t e0 = last ? nnz : off1[rr];
+                const bool valid = (s0 >= 0) & (e0 >= s0) & (e0 <= nnz);
+                bad |= lf[rr].indirect & !valid;
+                const bool use = lf[rr].indirect & valid;
+                st2[rr] = use ? (int)s0 : 0;
+                len2[rr] = use ? (int)(e0 - s0) : 0;
                 const int64_t *ip = (len2[rr] > 0) ? lf[rr].idx + st2[rr] : args.dummy_i64;
                 idx_raw[rr] = *ip;
             }
         }
     };
-    auto issue_rows = [&](int n) {  // consumes idx_raw (sample n), issues its chunk loads into a_next
+    auto issue_rows = [&](int n, Stage &S) {  // consumes idx_raw (sample n), issues its chunk loads
         const int64_t b = sample_b(n);
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) {
             unsigned mult = (unsigned)b;  // dense: sample number (B < 2^31 is checked on the host)
             bool ok = true;
             if constexpr (HAS_INDIRECT) {
-                if (lf[rr].indirect) {
-                    ok = len2[rr] > 0;
-                    if (ok && (uint64_t)idx_raw[rr] >= (uint64_t)lf[rr].n_rows) { ok = false; bad = true; }
-                    mult = ok ? (unsigned)idx_raw[rr] : 0u;
-                }
-                st1[rr] = st2[rr];
-                len1[rr] = len2[rr];
+                const bool in_range = (uint64_t)idx_raw[rr] < (uint64_t)lf[rr].n_rows;
+                const bool has = len2[rr] > 0;
+                bad |= lf[rr].indirect & has & !in_range;
+                ok = !lf[rr].indirect | (has & in_range);
+                mult = lf[rr].indirect ? (ok ? (unsigned)idx_raw[rr] : 0u) : mult;
+                S.st[rr] = st2[rr];
+                S.len[rr] = len2[rr];
             }
-            first1[rr] = ok;
+            S.first[rr] = ok;
             // one v_mad_u64_u32: base + u32*u32
             const char *row = lf[rr].src + (uint64_t)mult * (uint64_t)lf[rr].scale;
             int rem_delta = lf[rr].rem_delta;
-            if constexpr (HAS_INDIRECT && CODEC == 32) {
-                if (!ok) { row = zeros_l; rem_delta = 0; }  // empty bag / bad index: read zeros
+            if constexpr (HAS_INDIRECT && CODEC == 32) {  // empty bag / bad index: read zeros
+                row = ok ? row : zeros_l;
+                rem_delta = ok ? rem_delta : 0;
             }
             if constexpr (CODEC == 32 || !HAS_INDIRECT) {
 #pragma unroll
-                for (int c = 0; c < CQ; c++) a_next[rr][c] = reinterpret_cast<const float4 *>(row)[c];
+                for (int c = 0; c < CQ; c++) S.a[rr][c] = reinterpret_cast<const float4 *>(row)[c];
 #pragma unroll
-                for (int m = 0; m < REM; m++) a_next[rr][CQ + m] = reinterpret_cast<const float4 *>(row + rem_delta)[m];
+                for (int m = 0; m < REM; m++) S.a[rr][CQ + m] = reinterpret_cast<const float4 *>(row + rem_delta)[m];
             } else {
                 if (lf[rr].indirect) {
 #pragma unroll
-                    for (int c = 0; c < CQ; c++) a_next[rr][c] = load_chunk<CODEC>(row, c);
+                    for (int c = 0; c < CQ; c++) S.a[rr][c] = load_chunk<CODEC>(row, c);
 #pragma unroll
-                    for (int m = 0; m < REM; m++) a_next[rr][CQ + m] = load_chunk<CODEC>(row + rem_delta, m);
+                    for (int m = 0; m < REM; m++) S.a[rr][CQ + m] = load_chunk<CODEC>(row + rem_delta, m);
                 } else {
 #pragma unroll
-                    for (int c = 0; c < CQ; c++) a_next[rr][c] = reinterpret_cast<const float4 *>(row)[c];
+                    for (int c = 0; c < CQ; c++) S.a[rr][c] = reinterpret_cast<const float4 *>(row)[c];
 #pragma unroll
-                    for (int m = 0; m < REM; m++) a_next[rr][CQ + m] = reinterpret_cast<const float4 *>(row + rem_delta)[m];
+                    for (int m = 0; m < REM; m++) S.a[rr][CQ + m] = reinterpret_cast<const float4 *>(row + rem_delta)[m];
                 }
             }
-            w1[rr] = 1.0f;
+            S.w[rr] = 1.0f;
             if constexpr (WEIGHTED) {
                 const bool has_w = lf[rr].indirect && lf[rr].rw;
                 const float *wp = has_w ? lf[rr].rw + mult : args.dummy_f32;
-                w1[rr] = *wp;
-                if (!has_w) w1[rr] = 1.0f;
+                const float wv = *wp;
+                S.w[rr] = has_w ? wv : 1.0f;
             }
         }
     };
 
-    // ---- prologue ---------------------------------------------------------------------
-    issue_off(0);
-    issue_idx(0);
-    issue_off(1);
-    issue_rows(0);
-    issue_idx(1);
-    issue_off(2);
-
     const float *x_base = reinterpret_cast<const float *>(args.src[0]);
     const int64_t x_stride = args.stride[0];
 
-    for (int k = 0; k < n_samples; k++) {
-        // rotate: rows of sample k are (being) loaded into a_next -> a_cur
-#pragma unroll
-        for (int rr = 0; rr < NR; rr++) {
-#pragma unroll
-            for (int c = 0; c < NC; c++) a_cur[rr][c] = a_next[rr][c];
-            st0[rr] = st1[rr]; len0[rr] = len1[rr]; first0[rr] = first1[rr]; w0[rr] = w1[rr];
-        }
-        issue_rows(k + 1);
-        issue_idx(k + 2);
-        issue_off(k + 3);
-
-        // ---- consume sample k --------------------------------------------------------
+    auto consume = [&](int k, Stage &S) {
         const int64_t b = wave_id + (int64_t)k * waves_total;  // wave-uniform
         // x passthrough: re-read x[b] (L1/L2 hit) with one lane per element, one store
         float xv[(d + 63) / 64];
@@ -279,31 +262,28 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
             const int e = lane + 64 * h;
             xv[h] = x_base[b * x_stride + (e < d ? e : 0)];
         }
-        float4 a[NR][NC];
 #pragma unroll
         for (int rr = 0; rr < NR; rr++)
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                float4 t = a_cur[rr][c];
                 if constexpr (HAS_INDIRECT && CODEC != 32) {
-                    if (lf[rr].indirect && !first0[rr]) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!S.first[rr]) S.a[rr][c] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 if constexpr (WEIGHTED) {
-                    t.x = __fmul_rn(t.x, w0[rr]); t.y = __fmul_rn(t.y, w0[rr]);
-                    t.z = __fmul_rn(t.z, w0[rr]); t.w = __fmul_rn(t.w, w0[rr]);
+                    S.a[rr][c].x = __fmul_rn(S.a[rr][c].x, S.w[rr]); S.a[rr][c].y = __fmul_rn(S.a[rr][c].y, S.w[rr]);
+                    S.a[rr][c].z = __fmul_rn(S.a[rr][c].z, S.w[rr]); S.a[rr][c].w = __fmul_rn(S.a[rr][c].w, S.w[rr]);
                 }
-                a[rr][c] = t;
             }
         if constexpr (HAS_INDIRECT) {
             // bags longer than one index: remaining elements, in index order (not pipelined)
             bool more = false;
 #pragma unroll
-            for (int rr = 0; rr < NR; rr++) more |= len0[rr] > 1;
+            for (int rr = 0; rr < NR; rr++) more |= S.len[rr] > 1;
             if (__any(more)) {
 #pragma unroll
                 for (int rr = 0; rr < NR; rr++) {
-                    for (int j = 1; j < len0[rr]; j++) {
-                        const int64_t r = lf[rr].idx[st0[rr] + j];
+                    for (int j = 1; j < S.len[rr]; j++) {
+                        const int64_t r = lf[rr].idx[S.st[rr] + j];
                         if ((uint64_t)r >= (uint64_t)lf[rr].n_rows) { bad = true; continue; }
                         const char *row = lf[rr].src + (uint64_t)(unsigned)r * (uint64_t)lf[rr].scale;
                         float w = 1.0f;
@@ -315,8 +295,8 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
                                 t.x = __fmul_rn(t.x, w); t.y = __fmul_rn(t.y, w);
                                 t.z = __fmul_rn(t.z, w); t.w = __fmul_rn(t.w, w);
                             }
-                            a[rr][c].x = __fadd_rn(a[rr][c].x, t.x); a[rr][c].y = __fadd_rn(a[rr][c].y, t.y);
-                            a[rr][c].z = __fadd_rn(a[rr][c].z, t.z); a[rr][c].w = __fadd_rn(a[rr][c].w, t.w);
+                            S.a[rr][c].x = __fadd_rn(S.a[rr][c].x, t.x); S.a[rr][c].y = __fadd_rn(S.a[rr][c].y, t.y);
+                            S.a[rr][c].z = __fadd_rn(S.a[rr][c].z, t.z); S.a[rr][c].w = __fadd_rn(S.a[rr][c].w, t.w);
                         }
                     }
                 }
@@ -326,8 +306,8 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
         f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            const float e0[4] = {a[0][c].x, a[0][c].y, a[0][c].z, a[0][c].w};
-            const float e1[4] = {a[NR - 1][c].x, a[NR - 1][c].y, a[NR - 1][c].z, a[NR - 1][c].w};
+            const float e0[4] = {S.a[0][c].x, S.a[0][c].y, S.a[0][c].z, S.a[0][c].w};
+            const float e1[4] = {S.a[NR - 1][c].x, S.a[NR - 1][c].y, S.a[NR - 1][c].z, S.a[NR - 1][c].w};
             if (c < CQ) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -363,6 +343,27 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c11[v]), rs, zo11[v], 0, 0);
             }
         }
+    };
+
+    // ---- prologue ---------------------------------------------------------------------
+    issue_off(0);
+    issue_idx(0);
+    issue_off(1);
+    issue_rows(0, sA);
+    issue_idx(1);
+    issue_off(2);
+
+    // ---- steady state, unrolled by two so the row buffers ping-pong without copies ----
+    for (int k = 0; k < n_samples; k += 2) {
+        issue_rows(k + 1, sB);
+        issue_idx(k + 2);
+        issue_off(k + 3);
+        consume(k, sA);
+        if (k + 1 >= n_samples) break;
+        issue_rows(k + 2, sA);
+        issue_idx(k + 3);
+        issue_off(k + 4);
+        consume(k + 1, sB);
     }
     if (bad) atomicOr(args.err, 1);
 }
