@@ -6,10 +6,11 @@ Workload (BASELINE.json configs[1]): 26 tables with the Kaggle row counts
 index per (table, sample) as the Criteo collate produces; synthetic uniform
 indices; tables drawn U(-sqrt(1/n), sqrt(1/n)) like create_emb.
 
-A step = the hot path over one batch: apply_emb (ONE fused gather launch for
-the 26 tables, writing the (B,27,36) interaction tile) + interact_features
-(one MFMA launch) -> R (B,387).  Inputs are resident in HBM before the timed
-region.  value = 26 * B * steps / time  (whole job, all ranks).
+A step = the hot path over one batch: R = interact_features(x, apply_emb(...))
+-> (B,387), as ONE launch of the fused gather+pool+interaction kernel
+(csrc/evs_fused.hip); the same work through the two-call plugin surface is
+timed beside it ("two_call_path").  Inputs are resident in HBM before the
+timed region.  value = 26 * B * steps / time  (whole job, all ranks).
 
 N > 1 (one process per GPU, torch.distributed/RCCL): tables are sharded over
 ranks, every rank pools its tables for the FULL global batch (N * B), one
@@ -126,36 +127,35 @@ def main():
 
     B, d, T = args.batch, args.dim, len(KAGGLE_LN)
     F = T + 1
+    P = F * (F - 1) // 2
     ev = make_tables(KAGGLE_LN, d, seed=0, device=dev)
     batches = make_batches(KAGGLE_LN, B, 8, seed=1, device=dev, dist=args.dist)
     xs = [torch.rand((B, d), device=dev) for _ in range(2)]
-    tile = torch.empty((B, F, d), device=dev, dtype=torch.float32)
+    Rbuf = [torch.empty((B, d + P), device=dev, dtype=torch.float32) for _ in range(2)]
 
     def step(i):
+        # the hot path: R = interact_features(x, apply_emb(lS_o, lS_i, emb_l, v_W_l)); one fused launch
         lS_o, lS_i = batches[i % len(batches)]
-        x = xs[i % len(xs)]
-        ly = E.apply_emb(lS_o, lS_i, ev, None, out=tile)
-        return E.interact_features(x, ly)
+        return E.apply_emb_interact(xs[i % 2], lS_o, lS_i, ev, None, out=Rbuf[i % 2])
 
     for i in range(args.warmup):
         step(i)
     E._lib.check(E._lib.lib().evs_check_index_errors(None))
     torch.cuda.synchronize()
 
-    # ---- timed region: exactly K steps; event pairs bracket each gather launch ------------
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # ---- timed region: exactly K steps, nothing but the launches between the two syncs ----
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    e0.record()
     for i in range(args.steps):
-        lS_o, lS_i = batches[i % len(batches)]
-        ev0[i].record()
-        ly = E.apply_emb(lS_o, lS_i, ev, None, out=tile)
-        ev1[i].record()
-        R = E.interact_features(xs[i % len(xs)], ly)
+        step(i)
+    e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    # the timed region holds only this kernel, back to back on one stream: events over the region
+    # divided by the launches = average launch duration (incl. launch gaps when the host is slower)
+    kernel_ms = e0.elapsed_time(e1) / args.steps
 
     # ---- per-batch latency (sync per step), outside the throughput region ------------------
     lat = []
@@ -165,29 +165,36 @@ def main():
         step(i)
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t1) * 1e3)
-    # back-to-back gather launches only (cross-check of the event-pair number)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(args.steps):
+
+    # ---- the same work through the two-call plugin surface (apply_emb, then interact_features) ----
+    tile = torch.empty((B, F, d), device=dev, dtype=torch.float32)
+
+    def step2(i):
         lS_o, lS_i = batches[i % len(batches)]
-        E.apply_emb(lS_o, lS_i, ev, None, out=tile)
-    e1.record()
+        ly = E.apply_emb(lS_o, lS_i, ev, None)
+        return E.interact_features(xs[i % 2], ly)
+
+    for i in range(5):
+        step2(i)
     torch.cuda.synchronize()
-    gather_b2b_ms = e0.elapsed_time(e1) / args.steps
+    t2 = time.perf_counter()
+    for i in range(args.steps):
+        step2(i)
+    torch.cuda.synchronize()
+    dt2 = time.perf_counter() - t2
 
     lookups = T * B
-    # algorithmic bytes per lookup: row 4d + index 8 + offset 8 read, 4d written
-    bytes_per_lookup = 4 * d + 8 + 8 + 4 * d
-    gather_bytes = lookups * bytes_per_lookup
-    achieved = gather_bytes / (gather_ms * 1e-3) / 1e9
+    # algorithmic bytes per sample of the fused kernel (gather read side + interaction
+    # write side; the (B,F,d) intermediate does not exist): per lookup 4d row + 8 index + 8 offset,
+    # per sample 4d for x and 4(d+P) for R
+    bytes_per_sample = T * (4 * d + 16) + 4 * d + 4 * (d + P)
+    kernel_bytes = B * bytes_per_sample
+    achieved = kernel_bytes / (kernel_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            key = "gather_B%d_d%d_%s" % (B, d, args.dist)
-            traffic = tj.get(key)
+            traffic = json.load(open(tpath)).get("fused_B%d_d%d_%s" % (B, d, args.dist))
         except Exception:
             traffic = None
     result = {
@@ -196,13 +203,16 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: Criteo-Kaggle 26 tables (33.76M rows) x d=%d fp32 all in HBM, "
-                               "no cache tier, 1 index/bag, %s indices" % (d, args.dist),
+                               "no cache tier, 1 index/bag, %s indices; step = R=interact_features(x, apply_emb(...))"
+                               % (d, args.dist),
                    "batch_per_gpu": B, "global_batch": B, "tables": T, "dim": d, "parallelism": "single"},
         "p50_batch_latency_ms": float(np.percentile(lat, 50)), "p95_batch_latency_ms": float(np.percentile(lat, 95)),
-        "roofline": {"bound": "hbm", "kernel": "embedding_bag_sum_kernel<32,9,4>", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "emb_interact_dot_kernel<32,2,1,2,false,true>", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "bytes_per_launch": gather_bytes, "avg_launch_ms": gather_ms,
-                     "avg_launch_ms_back_to_back": gather_b2b_ms},
+                     "bytes_per_launch": kernel_bytes, "avg_launch_ms": kernel_ms},
+        "two_call_path": {"value": lookups * args.steps / dt2, "unit": "lookups/s",
+                          "ms_per_step": dt2 / args.steps * 1e3,
+                          "note": "apply_emb (fused 26-table gather) then interact_features, (T,B,d) intermediate in HBM"},
     }
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ev, KAGGLE_LN, d, args.cpu_seconds)

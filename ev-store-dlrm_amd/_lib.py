@@ -37,7 +37,7 @@ _i64p = C.POINTER(C.c_int64)
 class EvsFeature(C.Structure):
     """struct evs_feature (include/evstore_hip.h)"""
     _fields_ = [("src", C.c_void_p), ("stride", C.c_int64), ("indices", C.c_void_p), ("offsets", C.c_void_p),
-                ("nnz", C.c_int64), ("n_rows", C.c_int64), ("row_weights", C.c_void_p)]
+                ("nnz", C.c_int64), ("n_rows", C.c_int64), ("row_weights", C.c_void_p), ("offsets_len", C.c_int64)]
 
 
 _PROTOS = {

@@ -35,6 +35,7 @@ struct FusedArgs {
     const int64_t *offsets[EVS_MAX_FEATURES];
     int64_t nnz[EVS_MAX_FEATURES];
     int64_t n_rows[EVS_MAX_FEATURES];
+    int64_t off_len[EVS_MAX_FEATURES];
     const float *row_w[EVS_MAX_FEATURES];
     float *R;
     int64_t B;
@@ -73,6 +74,7 @@ struct LaneFeat {
     int rem_delta;        // byte distance from this lane's own chunks to the shared remainder chunks
     int nnz;              // API guarantees < 2^31
     unsigned n_rows;      // API guarantees < 2^31
+    int off_len;          // readable offsets entries (>= B)
     bool indirect;
 };
 
@@ -115,6 +117,7 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
         lf[rr].src = reinterpret_cast<const char *>(args.zeros);  // idle lanes read zeros
         lf[rr].idx = args.dummy_i64; lf[rr].off = args.dummy_i64; lf[rr].rw = nullptr;
         lf[rr].scale = 0; lf[rr].nnz = 0; lf[rr].n_rows = 0; lf[rr].indirect = false;
+        lf[rr].off_len = (int)B;
         lf[rr].rem_delta = 4 * CQ * 16 - q * CQ * 16;
         if (f < F) {
             const int64_t *ip = ka->indices[f];
@@ -128,6 +131,7 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
             lf[rr].scale = lf[rr].indirect ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4);
             lf[rr].nnz = (int)ka->nnz[f];
             lf[rr].n_rows = (unsigned)ka->n_rows[f];
+            lf[rr].off_len = lf[rr].indirect ? (int)ka->off_len[f] : (int)B;
         }
     }
     const char *zeros_l = reinterpret_cast<const char *>(args.zeros);
@@ -171,24 +175,22 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
     };
     auto issue_off = [&](int n) {
         if constexpr (HAS_INDIRECT) {
-            const int64_t b = sample_b(n);
-            const int64_t b1 = (b + 1 < B) ? b + 1 : b;
+            const int b = (int)sample_b(n);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {  // dense/idle lanes read a dummy offsets array
                 off0[rr] = lf[rr].off[b];
-                off1[rr] = lf[rr].off[b1];
+                off1[rr] = lf[rr].off[(b + 1 < lf[rr].off_len) ? b + 1 : b];
             }
         }
     };
     auto issue_idx = [&](int n) {  // consumes off0/off1 -> st2/len2, issues the first-index load
         if constexpr (HAS_INDIRECT) {
-            const int64_t b = sample_b(n);
-            const bool last = !(b + 1 < B);
+            const int b = (int)sample_b(n);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {
                 const int64_t nnz = (int64_t)lf[rr].nnz;
                 const int64_t s0 = off0[rr];
-                const int64_t e0 = last ? nnz : off1[rr];
+                const int64_t e0 = (b + 1 < lf[rr].off_len) ? off1[rr] : nnz;
                 const bool valid = (s0 >= 0) & (e0 >= s0) & (e0 <= nnz);
                 bad |= lf[rr].indirect & !valid;
                 const bool use = lf[rr].indirect & valid;
@@ -431,11 +433,14 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
         a.nnz[f] = on ? feats[f].nnz : 0;
         a.n_rows[f] = on ? feats[f].n_rows : 0;
         a.row_w[f] = on ? feats[f].row_weights : nullptr;
+        a.off_len[f] = on ? (feats[f].offsets_len > 0 ? feats[f].offsets_len : B) : B;
         if (!on) continue;
         EVS_REQUIRE(feats[f].src || (feats[f].indices && feats[f].n_rows == 0), "evs_emb_interact_dot: feats[%d].src is NULL", f);
         EVS_REQUIRE(reinterpret_cast<uintptr_t>(feats[f].src) % 16 == 0, "evs_emb_interact_dot: feats[%d].src must be 16-byte aligned", f);
         if (feats[f].indices) {
             EVS_REQUIRE(feats[f].offsets, "evs_emb_interact_dot: feats[%d].offsets is NULL", f);
+            EVS_REQUIRE(feats[f].offsets_len == 0 || (feats[f].offsets_len >= B && feats[f].offsets_len < (1ll << 31)),
+                        "evs_emb_interact_dot: feats[%d].offsets_len must be 0 or in [B, 2^31)", f);
             EVS_REQUIRE(feats[f].nnz >= 0 && feats[f].n_rows >= 0 && feats[f].nnz < (1ll << 31) && feats[f].n_rows < (1ll << 31),
                         "evs_emb_interact_dot: feats[%d]: nnz and n_rows must be in [0, 2^31)", f);
         } else {
@@ -491,7 +496,7 @@ extern "C" int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec, 
                 "evs_emb_interact_dot_stacked: NULL argument");
     evs_feature ft[EVS_MAX_FEATURES];
     ft[0].src = x; ft[0].stride = x_stride; ft[0].indices = nullptr; ft[0].offsets = nullptr;
-    ft[0].nnz = 0; ft[0].n_rows = 0; ft[0].row_weights = nullptr;
+    ft[0].nnz = 0; ft[0].n_rows = 0; ft[0].row_weights = nullptr; ft[0].offsets_len = 0;
     for (int k = 0; k < T; k++) {
         evs_feature &f = ft[k + 1];
         f.src = tables[k]; f.stride = 0;
@@ -499,6 +504,7 @@ extern "C" int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec, 
         f.offsets = offsets_base + (int64_t)k * offsets_row_stride;
         f.nnz = nnz_per_table; f.n_rows = n_rows[k];
         f.row_weights = row_weights ? row_weights[k] : nullptr;
+        f.offsets_len = 0;
     }
     return evs_emb_interact_dot(B, T + 1, d, codec, ft, itself, R, stream);
 }

@@ -90,7 +90,7 @@ extern "C" int evs_interact_dot(int64_t B, int F, int d, const float *const *fea
         evs_feature ft[EVS_MAX_FEATURES];
         for (int f = 0; f < F; f++) {
             ft[f].src = feats[f]; ft[f].stride = feat_strides[f]; ft[f].indices = nullptr; ft[f].offsets = nullptr;
-            ft[f].nnz = 0; ft[f].n_rows = 0; ft[f].row_weights = nullptr;
+            ft[f].nnz = 0; ft[f].n_rows = 0; ft[f].row_weights = nullptr; ft[f].offsets_len = 0;
         }
         return evs_emb_interact_dot(B, F, d, 32, ft, itself, R, stream);
     }

@@ -1,0 +1,285 @@
+"""Table-sharded embedding lookup across the GPUs of one node (one process per GPU).
+
+Reference behaviour (dlrm_s_pytorch.py:529-586 distributed_forward +
+extend_distributed.py:389-465): tables are split over ranks, every rank pools ITS tables
+for the FULL batch, one all-to-all turns "local tables x full batch" into "all tables x
+local batch", interaction runs on the local batch slice.
+
+MI355X-native re-design (same results, fewer bytes on xGMI and in HBM):
+  * the gather kernel writes pooled vectors straight into the all-to-all send layout
+    (B_global, T_own, d) -- no torch.cat;
+  * ONE all_to_all_single over RCCL/xGMI (point-to-point links: each peer pair has its
+    own link, so the exchange is one hop);
+  * the receive blocks are consumed IN PLACE by the fused interaction kernel through
+    per-feature (pointer, stride) pairs -- no split/view/cat, and any table placement
+    (not only contiguous slices) keeps the reference's feature order;
+  * placement policies: "count" (the reference's contiguous split, get_my_slice),
+    "rows" (balance by row count, BASELINE.json north_star), and "rows+replicate":
+    tables below `replicate_max_rows` are replicated on every rank and looked up
+    locally inside the fused kernel for the local batch slice only, so their pooled
+    vectors never cross xGMI (Kaggle: 21 of 26 tables, 82 MB; 5/26 of the bytes remain).
+The compute backend is injectable so the distributed plumbing is testable on CPU (gloo)
+with the oracle standing in for the HIP kernels (tests/test_sharded_gloo.py).
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .dlrm_ops import EVTables, _stream_ptr
+
+
+# ----------------------------------------------------------------------------- placement
+def plan_placement(ln_emb, world, policy="rows+replicate", replicate_max_rows=1_000_000):
+    """-> owner[t] in {0..world-1} or -1 (replicated on every rank)."""
+    T = len(ln_emb)
+    owner = [0] * T
+    if policy == "count":  # extend_distributed.get_my_slice: contiguous by table count
+        k, m = divmod(T, world)
+        t = 0
+        for r in range(world):
+            n = k + (1 if r < m else 0)
+            for _ in range(n):
+                owner[t] = r
+                t += 1
+        return owner
+    if policy not in ("rows", "rows+replicate"):
+        raise ValueError("unknown placement policy %r" % policy)
+    shard = list(range(T))
+    if policy == "rows+replicate":
+        shard = [t for t in range(T) if ln_emb[t] > replicate_max_rows]
+        for t in range(T):
+            if ln_emb[t] <= replicate_max_rows:
+                owner[t] = -1
+    load = [0] * world
+    for t in sorted(shard, key=lambda t: (-ln_emb[t], t)):  # LPT greedy on row counts
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[t] = r
+        load[r] += ln_emb[t]
+    return owner
+
+
+# ----------------------------------------------------------------------------- backends
+class HipBackend:
+    """libevstore_hip.so kernels (the product path)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._cache = {}
+
+    def make_tables(self, weights, d):
+        return EVTables([w.to(self.device) for w in weights], d, 32)
+
+    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d):
+        """pooled[b][j][:] for the j-th owned table, written into send (B, n_own, d)."""
+        B = int(send.shape[0])
+        n = len(table_ids_local)
+        if n == 0 or B == 0:
+            return
+        key = ("g", tuple(t.data_ptr() for t in lS_i_rows), tuple(t.data_ptr() for t in lS_o_rows), send.data_ptr())
+        ent = self._cache.get(key)
+        if ent is None:
+            ent = ((C.c_void_p * n)(*[ev.raw[k].data_ptr() for k in table_ids_local]),
+                   (C.c_int64 * n)(*[ev.n_rows[k] for k in table_ids_local]),
+                   (C.c_void_p * n)(*[t.data_ptr() for t in lS_i_rows]),
+                   (C.c_void_p * n)(*[t.data_ptr() for t in lS_o_rows]),
+                   (C.c_int64 * n)(*[int(t.numel()) for t in lS_i_rows]))
+            if len(self._cache) > 64:
+                self._cache.clear()
+            self._cache[key] = ent
+        L = _lib.lib()
+        _lib.check(L.evs_embedding_bag_sum(n, B, d, ev.codec, ent[0], ent[1], ent[2], ent[3], ent[4], None,
+                                           send.data_ptr(), d, n_own * d, _stream_ptr(self.device)))
+
+    def interact_mixed(self, x, specs, ev, d, itself, out=None):
+        """specs[t]: ("dense", tensor(B,d) view) | ("indirect", local_table_id, idx, off, nnz, off_len)."""
+        B = int(x.shape[0])
+        F = len(specs) + 1
+        P = F * (F + 1) // 2 if itself else F * (F - 1) // 2
+        R = out if out is not None else torch.empty((B, d + P), dtype=torch.float32, device=self.device)
+        key = ("f", x.data_ptr(), R.data_ptr()) + tuple(
+            (s[1].data_ptr(),) if s[0] == "dense" else (s[1], s[2].data_ptr(), s[3].data_ptr()) for s in specs)
+        feats = self._cache.get(key)
+        if feats is None:
+            feats = (_lib.EvsFeature * F)()
+            feats[0].src, feats[0].stride = x.data_ptr(), int(x.stride(0)) if B > 1 else d
+            for t, s in enumerate(specs):
+                f = feats[t + 1]
+                if s[0] == "dense":
+                    v = s[1]
+                    f.src, f.stride = v.data_ptr(), int(v.stride(0)) if B > 1 else d
+                else:
+                    _, k, idx, off, nnz, off_len = s
+                    f.src, f.indices, f.offsets = ev.raw[k].data_ptr(), idx.data_ptr(), off.data_ptr()
+                    f.nnz, f.n_rows, f.offsets_len = int(nnz), ev.n_rows[k], int(off_len)
+            if len(self._cache) > 64:
+                self._cache.clear()
+            self._cache[key] = feats
+        _lib.check(_lib.lib().evs_emb_interact_dot(B, F, d, ev.codec if ev is not None else 32, feats,
+                                                   int(bool(itself)), R.data_ptr(), _stream_ptr(self.device)))
+        return R
+
+
+# ----------------------------------------------------------------------------- the sharded op
+class ShardedEmbeddingInteract:
+    """apply_emb + all-to-all + interact_features for one rank.
+
+    local_weights: dict {global table id -> (n,d) fp32 tensor} for the tables this rank
+    holds (owned + replicated).  Every rank must use the same ln_emb / policy.
+    """
+
+    def __init__(self, ln_emb, d, rank, world, local_weights, backend, policy="rows+replicate",
+                 replicate_max_rows=1_000_000, group=None, itself=False):
+        self.ln_emb, self.d, self.rank, self.world = list(ln_emb), int(d), rank, world
+        self.group, self.itself, self.backend = group, itself, backend
+        self.owner = plan_placement(ln_emb, world, policy, replicate_max_rows)
+        self.own = [[t for t in range(len(ln_emb)) if self.owner[t] == r] for r in range(world)]
+        self.my_own = self.own[rank]
+        self.replicated = [t for t in range(len(ln_emb)) if self.owner[t] == -1]
+        held = self.my_own + self.replicated
+        assert sorted(local_weights.keys()) == sorted(held), "rank %d must hold tables %s" % (rank, held)
+        self.local_id = {t: i for i, t in enumerate(held)}
+        self.ev = backend.make_tables([local_weights[t] for t in held], d)
+        self._bufs = {}
+
+    def tables_held(self):
+        return self.my_own + self.replicated
+
+    # a2a element counts for a global batch of Bg samples
+    def _splits(self, Bg):
+        assert Bg % self.world == 0, "batch_size %d can not split across %d ranks evenly" % (Bg, self.world)
+        Bl = Bg // self.world
+        in_splits = [Bl * len(self.my_own) * self.d] * self.world
+        out_splits = [Bl * len(self.own[p]) * self.d for p in range(self.world)]
+        return Bl, in_splits, out_splits
+
+    def _buffers(self, Bg, slot, like):
+        key = (Bg, slot)
+        if key not in self._bufs:
+            Bl, _, out_splits = self._splits(Bg)
+            send = like.new_empty((Bg, max(len(self.my_own), 0), self.d), dtype=torch.float32)
+            recv = like.new_empty((sum(out_splits),), dtype=torch.float32)
+            self._bufs[key] = (send, recv)
+        return self._bufs[key]
+
+    def pool(self, lS_o, lS_i, slot=0):
+        """Pool the owned tables for the full batch into the send layout (B_global, T_own, d)."""
+        Bg = int(lS_o[0].shape[0])
+        like = lS_o[0].new_empty((0,), dtype=torch.float32)
+        send, recv = self._buffers(Bg, slot, like)
+        ids = [self.local_id[t] for t in self.my_own]
+        self.backend.bag_sum_into(self.ev, ids, [lS_o[t] for t in self.my_own], [lS_i[t] for t in self.my_own],
+                                  send, len(self.my_own), self.d)
+        return send, recv
+
+    def start(self, lS_o, lS_i, slot=0):
+        """pool() + launch the all-to-all (async)."""
+        Bg = int(lS_o[0].shape[0])
+        Bl, in_splits, out_splits = self._splits(Bg)
+        send, recv = self.pool(lS_o, lS_i, slot)
+        work = None
+        if self.world > 1:
+            work = dist.all_to_all_single(recv, send.view(-1), out_splits, in_splits, group=self.group, async_op=True)
+        else:
+            recv.copy_(send.view(-1))
+        return (work, recv, Bg, Bl, out_splits)
+
+    def finish(self, handle, x_local, lS_o, lS_i, out=None):
+        """Wait for the exchange, then R = interact_features(x_local, ly) on this rank's batch slice."""
+        work, recv, Bg, Bl, out_splits = handle
+        if work is not None:
+            work.wait()
+        b0 = self.rank * Bl
+        T = len(self.ln_emb)
+        specs = [None] * T
+        pos = 0
+        for p in range(self.world):
+            n = len(self.own[p])
+            if n:
+                block = recv[pos:pos + out_splits[p]].view(Bl, n, self.d)
+                for j, t in enumerate(self.own[p]):
+                    specs[t] = ("dense", block[:, j, :])
+            pos += out_splits[p]
+        for t in self.replicated:  # looked up locally, only for this rank's samples
+            off = lS_o[t]
+            specs[t] = ("indirect", self.local_id[t], lS_i[t], off[b0:], int(lS_i[t].numel()), Bg - b0)
+        return self.backend.interact_mixed(x_local, specs, self.ev, self.d, self.itself, out=out)
+
+    def forward(self, x_local, lS_o, lS_i):
+        """lS_o/lS_i: per-table offsets/indices of the FULL batch (every rank sees all of them,
+        dlrm_s_pytorch.py:543-545); x_local: this rank's (B/world, d) dense features."""
+        return self.finish(self.start(lS_o, lS_i), x_local, lS_o, lS_i)
+
+
+# ----------------------------------------------------------------------------- bench (N > 1)
+def bench_sharded(args, ln_emb, rank, world, dev):
+    """Weak scaling: global batch = world * args.batch; every rank times the same K steps."""
+    from bench import HBM_PEAK_GBPS  # noqa: F401  (kept for symmetry of the report)
+    d = args.dim
+    T = len(ln_emb)
+    Bl = args.batch
+    Bg = Bl * world
+    backend = HipBackend(dev)
+    policy = getattr(args, "placement", "rows+replicate")
+    owner = plan_placement(ln_emb, world, policy)
+    held = [t for t in range(T) if owner[t] in (rank, -1)]
+    g = torch.Generator(device=dev)
+    weights = {}
+    for t in held:  # same values on every rank that holds table t
+        g.manual_seed(1000 + t)
+        a = float(np.sqrt(1.0 / ln_emb[t]))
+        weights[t] = torch.empty((ln_emb[t], d), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
+    op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy)
+    # every rank generates the same full-batch indices (same seed), as the reference feeds them
+    g.manual_seed(7)
+    nb = 4
+    batches = []
+    off = torch.arange(Bg, device=dev, dtype=torch.int64)
+    for _ in range(nb):
+        lS_i = [torch.randint(0, n, (Bg,), device=dev, generator=g, dtype=torch.int64) for n in ln_emb]
+        batches.append(([off] * T, lS_i))
+    x = torch.rand((Bl, d), device=dev)
+    F = T + 1
+    P = F * (F - 1) // 2
+    outs = [torch.empty((Bl, d + P), device=dev) for _ in range(2)]
+
+    def run(steps):
+        # two-deep software pipeline: exchange of batch i+1 overlaps the interaction of batch i
+        h = op.start(*batches[0], slot=0)
+        for i in range(steps):
+            nxt = None
+            if i + 1 < steps:
+                nxt = op.start(*batches[(i + 1) % nb], slot=(i + 1) % 2)
+            lS_o, lS_i = batches[i % nb]
+            op.finish(h, x, lS_o, lS_i, out=outs[i % 2])
+            h = nxt
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    lookups = T * Bg
+    a2a_bytes = 4 * d * Bl * sum(1 for t in range(T) if owner[t] >= 0) * (world - 1)
+    return {
+        "metric": "inference lookups/sec, Criteo-Kaggle 26-table DLRM (apply_emb + interact_features)",
+        "value": lookups * args.steps / dt, "unit": "lookups/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Criteo-Kaggle 26 tables x d=%d fp32 sharded over %d GPUs (%s), one all_to_all_single "
+                               "of pooled vectors per batch over RCCL/xGMI, uniform indices" % (d, world, policy),
+                   "batch_per_gpu": Bl, "global_batch": Bg, "tables": T, "dim": d,
+                   "parallelism": "table-sharded x%d + a2a" % world,
+                   "owner": owner, "a2a_bytes_per_step_all_links": a2a_bytes},
+        "roofline": None, "cpu_baseline": None,
+    }

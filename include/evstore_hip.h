@@ -135,6 +135,9 @@ typedef struct evs_feature {
     int64_t nnz;
     int64_t n_rows;
     const float *row_weights;
+    int64_t offsets_len;   /* readable entries of `offsets` (>= B); 0 means B.  A batch SLICE of a longer
+                              offsets array passes offsets+b0 and offsets_len = B_total-b0: the slice's last
+                              bag then ends at offsets[B] instead of nnz. */
 } evs_feature;
 
 /* 1 if the fused kernel is built for this embedding dimension (16,32,36,48,64,128). */

@@ -249,3 +249,36 @@ def test_fused_codec_tiers(E, orc, codec):
     ly = orc.apply_emb(lS_o, lS_i, raws, None, codec, d)
     Ro = orc.interact_features(x, ly)
     np.testing.assert_allclose(R.cpu().numpy(), Ro, rtol=RTOL, atol=2e-6)
+
+
+def test_sharded_hip_backend_two_virtual_ranks(E, orc):
+    """The sharded op with the HIP backend: two 'ranks' on one GPU, the all-to-all done by hand
+    (block copies) -- validates send layout, receive-block feature pointers and the batch-slice
+    lookup of replicated tables against the fused single-rank result."""
+    from evstore_dlrm_amd import sharded
+    rs = np.random.RandomState(11)
+    ln = [700, 5, 90000, 33, 41000, 12]
+    d, world, Bl = 36, 2, 48
+    Bg = world * Bl
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    lens = rs.randint(0, 4, size=(len(ln), Bg))
+    lS_i = [torch.from_numpy(rs.randint(0, ln[k], size=lens[k].sum()).astype(np.int64)).cuda() for k in range(len(ln))]
+    lS_o = [torch.from_numpy(np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64)).cuda()
+            for k in range(len(ln))]
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(Bg, d)).astype(np.float32)).cuda()
+    ev_all = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    want = E.apply_emb_interact(x, lS_o, lS_i, ev_all)
+    for policy in ("count", "rows", "rows+replicate"):
+        ops = []
+        for r in range(world):
+            owner = sharded.plan_placement(ln, world, policy, replicate_max_rows=1000)
+            held = {t: torch.from_numpy(tabs[t]) for t in range(len(ln)) if owner[t] in (r, -1)}
+            ops.append(sharded.ShardedEmbeddingInteract(ln, d, r, world, held, sharded.HipBackend(torch.device("cuda")),
+                                                        policy=policy, replicate_max_rows=1000))
+        sends = [op.pool(lS_o, lS_i)[0] for op in ops]
+        torch.cuda.synchronize()
+        for r, op in enumerate(ops):
+            _, _, out_splits = op._splits(Bg)
+            recv = torch.cat([sends[p][r * Bl:(r + 1) * Bl].reshape(-1) for p in range(world)])
+            R = op.finish((None, recv, Bg, Bl, out_splits), x[r * Bl:(r + 1) * Bl], lS_o, lS_i)
+            assert torch.equal(R, want[r * Bl:(r + 1) * Bl]), (policy, r)

@@ -1,0 +1,127 @@
+"""CPU / gloo, world_size 2 and 3: the table-sharded path (placement, all-to-all splits, receive-block
+feature pointers, batch-slice lookups of replicated tables) against the single-process oracle.
+The oracle stands in for the HIP kernels through the backend hook of ShardedEmbeddingInteract."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as orc
+
+LN = [50, 3, 4000, 17, 2500, 9, 1200]
+D = 16
+
+
+class OracleBackend:
+    """test-only stand-in for HipBackend (same methods, numpy/oracle arithmetic)."""
+
+    def make_tables(self, weights, d):
+        return [np.ascontiguousarray(w.numpy()) for w in weights]
+
+    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d):
+        for j, k in enumerate(table_ids_local):
+            pooled = orc.embedding_bag_sum(ev[k], lS_i_rows[j].numpy(), lS_o_rows[j].numpy())
+            send[:, j, :] = torch.from_numpy(pooled)
+
+    def interact_mixed(self, x, specs, ev, d, itself, out=None):
+        B = x.shape[0]
+        ly = []
+        for s in specs:
+            if s[0] == "dense":
+                ly.append(s[1].numpy().copy())
+            else:
+                _, k, idx, off, nnz, off_len = s
+                off = off.numpy()
+                assert off_len == off.shape[0]
+                # slice semantics of evs_feature.offsets_len: bag b ends at off[b+1] while it exists
+                ends = np.concatenate([off[1:], [nnz]])[:B]
+                starts = off[:B]
+                rows = np.zeros((B, d), np.float32)
+                for b in range(B):
+                    rows[b] = orc.embedding_bag_sum(ev[k], idx.numpy()[starts[b]:ends[b]], np.array([0]))[0] \
+                        if ends[b] > starts[b] else 0
+                ly.append(rows)
+        return torch.from_numpy(orc.interact_features(x.numpy(), ly, itself))
+
+
+def _data(seed, Bg):
+    rs = np.random.RandomState(seed)
+    tabs = [rs.uniform(-1, 1, size=(n, D)).astype(np.float32) for n in LN]
+    lens = rs.randint(0, 4, size=(len(LN), Bg))
+    lS_i = [rs.randint(0, LN[k], size=lens[k].sum()).astype(np.int64) for k in range(len(LN))]
+    lS_o = [np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64) for k in range(len(LN))]
+    x = rs.uniform(-1, 1, size=(Bg, D)).astype(np.float32)
+    return tabs, lS_o, lS_i, x
+
+
+def _worker(rank, world, port, policy, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import evstore_dlrm_amd as E
+        from evstore_dlrm_amd import sharded
+        Bg = 6 * world
+        tabs, lS_o, lS_i, x = _data(3, Bg)
+        owner = sharded.plan_placement(LN, world, policy, replicate_max_rows=100)
+        held = {t: torch.from_numpy(tabs[t]) for t in range(len(LN)) if owner[t] in (rank, -1)}
+        op = sharded.ShardedEmbeddingInteract(LN, D, rank, world, held, OracleBackend(), policy=policy,
+                                              replicate_max_rows=100)
+        Bl = Bg // world
+        R = op.forward(torch.from_numpy(x[rank * Bl:(rank + 1) * Bl]), [torch.from_numpy(o) for o in lS_o],
+                       [torch.from_numpy(i) for i in lS_i])
+        ly = orc.apply_emb(lS_o, lS_i, tabs)
+        want = orc.interact_features(x, ly)[rank * Bl:(rank + 1) * Bl]
+        ok = np.allclose(R.numpy(), want, rtol=1e-6, atol=1e-6)
+        q.put((rank, bool(ok), owner))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,policy", [(2, "count"), (2, "rows"), (2, "rows+replicate"), (3, "rows+replicate")])
+def test_sharded_forward_matches_single_process(world, policy):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, policy, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    owner = res[0][2]
+    if policy == "rows+replicate":
+        assert all((o == -1) == (LN[t] <= 100) for t, o in enumerate(owner))
+
+
+def test_placement_policies():
+    from evstore_dlrm_amd import sharded
+    from bench import KAGGLE_LN
+    # the reference's contiguous split: 26 tables over 8 ranks -> 4,4,3,3,3,3,3,3
+    own = sharded.plan_placement(KAGGLE_LN, 8, "count")
+    assert [own.count(r) for r in range(8)] == [4, 4, 3, 3, 3, 3, 3, 3] and own == sorted(own)
+    rows = sharded.plan_placement(KAGGLE_LN, 8, "rows")
+    load = [sum(n for n, o in zip(KAGGLE_LN, rows) if o == r) for r in range(8)]
+    assert max(load) == 10131227  # one giant table alone on a rank: row balance != work balance
+    rep = sharded.plan_placement(KAGGLE_LN, 8, "rows+replicate")
+    assert sum(1 for o in rep if o >= 0) == 5 and sum(KAGGLE_LN[t] for t, o in enumerate(rep) if o == -1) < 600000
+
+
+def test_ext_dist_helpers_match_reference_semantics():
+    from evstore_dlrm_amd import extend_distributed as ext
+    assert ext.get_my_slice(26, 0, 8) == slice(0, 4, 1) and ext.get_my_slice(26, 7, 8) == slice(23, 26, 1)
+    assert ext.get_split_lengths(26, 1, 8) == (4, [4, 4, 3, 3, 3, 3, 3, 3])
+    assert ext.get_split_lengths(16, 3, 8) == (2, None)
