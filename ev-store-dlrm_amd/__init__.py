@@ -7,5 +7,6 @@ repository root (the directory name carries a hyphen).
 from . import _lib
 from ._lib import EvsError, build
 from .dlrm_ops import EVTables, apply_emb, apply_emb_interact, interact_features
+from .gpu_cache import GpuCache
 
-__all__ = ["EvsError", "build", "EVTables", "apply_emb", "apply_emb_interact", "interact_features"]
+__all__ = ["EvsError", "build", "GpuCache", "EVTables", "apply_emb", "apply_emb_interact", "interact_features"]

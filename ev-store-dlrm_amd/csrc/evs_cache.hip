@@ -1,0 +1,588 @@
+// GPU-resident EvLFU / LRU / LFU embedding cache ("C1") for gfx950.
+//
+// Reference semantics (cited per function below):
+//   cache_algo/EvLFU_C1.py:21-166        EvLFU policy (set / update_agg_hit / update / request_to_ev_lfu)
+//   cache_algo/LRU.py:14-64, LFU.py:12-95 baseline policies
+//   mixed_precs_caching/evlfu_8.cpp:252-321,798-868   the C++ single-tier variant (flush constants differ)
+//   cache_algo/EvLFU_C1_Cython/EvLFU.cpp:70-232       the Cython variant (0.4 / 1.0 constants)
+//
+// Data layout in HBM (everything the policy touches lives on the device):
+//   keys[nslot] u64     open-address hash, linear probing, key = (table_1based << 32) | row, 0 = empty
+//   slot_entry[nslot]   entry id of the key in that slot
+//   ekey/eagg/prev/next[cap]  entry records; prev/next thread the per-priority FIFO lists
+//   arena[cap * row_bytes]    the cached rows, in the table's own codec (fp32 / u16 / u8 / u4 bytes)
+//   State                     list heads/tails/lengths, min_C1, n_perfect, free stack pointer, counters
+//
+// Two request paths:
+//   * evlfu_exact_kernel -- ONE wavefront replays requests strictly in order, so the hit
+//     trace, the eviction order and the final state are bit-for-bit the reference's
+//     (parity gate at batch 1; any B works, B requests cost B serial policy steps).
+//     Lane i owns table i: all T keys of a request are probed at once, agg_hit is
+//     popcount(ballot(hit)); list surgery is done by lane 0 in table order; rows move with
+//     all lanes (arena -> out for hits, backing store -> out and -> arena for inserts).
+//   * cache_probe_gather_kernel (batched, snapshot semantics) -- see the section below.
+#include "evs_common.h"
+
+#include <mutex>
+#include <vector>
+
+namespace evs {
+
+constexpr int kMaxTables = 64;      // one lane per table
+constexpr int kMaxBuckets = 65;     // EvLFU priorities 0..n_tables
+constexpr unsigned long long kEmpty = 0ull;
+
+enum Policy { kEvLFU = 0, kLRU = 1, kLFU = 2 };
+
+struct CacheState {
+    int cap, n_tables, dim, codec, row_bytes, policy;
+    unsigned long long nslot_mask;
+    int min_c1, n_perfect, max_perfect, flush_n, perfect_mode;
+    int count;   // live entries
+    int n_free;  // free-stack depth
+    long long n_flush, n_evict, n_requests, n_perfect_hits, n_hits;
+    int head[kMaxBuckets], tail[kMaxBuckets], len[kMaxBuckets];
+    // LFU: lists by frequency live in lfu_head/lfu_tail/lfu_len arrays (device), least_freq here
+    long long least_freq;
+    int error;   // sticky: 1 = flush on an empty bucket (Python would raise), 2 = internal inconsistency
+};
+
+struct CacheArrays {
+    unsigned long long *keys;
+    int *slot_entry;
+    unsigned long long *ekey;
+    int *eagg;        // EvLFU: priority bucket; LFU: unused (efreq used); LRU: 0
+    long long *efreq; // LFU frequency
+    int *prev, *next;
+    int *free_stack;
+    unsigned char *arena;
+    int *lfu_head, *lfu_tail, *lfu_len;  // LFU only, indexed by frequency (< lfu_max_freq)
+    long long lfu_max_freq;
+};
+
+struct CacheArgs {
+    CacheState *st;
+    CacheArrays a;
+    const unsigned char *backing[kMaxTables];
+    long long backing_rows[kMaxTables];
+    const int *requests;   // (B, T) int32 row ids
+    float *out;            // (B, T, d) fp32, decoded
+    unsigned char *hit;    // (B, T)
+    long long B;
+    int approx_thres;
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+// agent-scope accesses: the probing lanes must see what lane 0 wrote in the previous request
+template <typename T>
+__device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ int map_find(const CacheArrays &a, unsigned long long mask, unsigned long long key) {
+    unsigned long long i = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long k = ld(&a.keys[i]);
+        if (k == key) return ld(&a.slot_entry[i]);
+        if (k == kEmpty) return -1;
+        i = (i + 1) & mask;
+    }
+}
+__device__ void map_put(const CacheArrays &a, unsigned long long mask, unsigned long long key, int e) {
+    unsigned long long i = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long k = ld(&a.keys[i]);
+        if (k == kEmpty || k == key) break;
+        i = (i + 1) & mask;
+    }
+    st(&a.slot_entry[i], e);
+    st(&a.keys[i], key);
+}
+// linear-probing delete with backward shift (no tombstones: the table never degrades)
+__device__ void map_del(const CacheArrays &a, unsigned long long mask, unsigned long long key) {
+    unsigned long long i = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long k = ld(&a.keys[i]);
+        if (k == key) break;
+        if (k == kEmpty) return;
+        i = (i + 1) & mask;
+    }
+    unsigned long long j = i;
+    for (;;) {
+        j = (j + 1) & mask;
+        const unsigned long long kj = ld(&a.keys[j]);
+        if (kj == kEmpty) break;
+        const unsigned long long h = mix64(kj) & mask;
+        const bool between = (i <= j) ? (h > i && h <= j) : (h > i || h <= j);
+        if (!between) {
+            st(&a.slot_entry[i], ld(&a.slot_entry[j]));
+            st(&a.keys[i], kj);
+            i = j;
+        }
+    }
+    st(&a.keys[i], kEmpty);
+}
+
+// intrusive FIFO lists (append tail / pop head / unlink) over entry ids
+struct ListRef { int *head, *tail, *len; };
+__device__ __forceinline__ void list_append(const CacheArrays &a, ListRef l, int e) {
+    const int t = *l.tail;
+    st(&a.prev[e], t);
+    st(&a.next[e], -1);
+    if (t >= 0) st(&a.next[t], e); else *l.head = e;
+    *l.tail = e;
+    *l.len += 1;
+}
+__device__ __forceinline__ void list_unlink(const CacheArrays &a, ListRef l, int e) {
+    const int p = ld(&a.prev[e]), n = ld(&a.next[e]);
+    if (p >= 0) st(&a.next[p], n); else *l.head = n;
+    if (n >= 0) st(&a.prev[n], p); else *l.tail = p;
+    *l.len -= 1;
+}
+
+__device__ __forceinline__ float decode_elem(const unsigned char *row, int codec, int c) {
+    if (codec == 32) return reinterpret_cast<const float *>(row)[c];
+    if (codec == 16) return dec_u16(reinterpret_cast<const unsigned short *>(row)[c]);
+    if (codec == 8) return dec_u8(row[c]);
+    const unsigned b = row[c >> 1];
+    return kU4Lut[(c & 1) ? (b & 15u) : (b >> 4)];
+}
+
+// shared (LDS) mirror of the hot part of CacheState: only lane 0 mutates it
+struct Hot {
+    int min_c1, n_perfect, count, n_free;
+    long long n_flush, n_evict, least_freq;
+    int head[kMaxBuckets], tail[kMaxBuckets], len[kMaxBuckets];
+    int error;
+};
+
+__device__ __forceinline__ ListRef bucket(Hot &h, int b) { return ListRef{&h.head[b], &h.tail[b], &h.len[b]}; }
+__device__ __forceinline__ ListRef lfu_list(const CacheArrays &a, long long f) {
+    return ListRef{&a.lfu_head[f], &a.lfu_tail[f], &a.lfu_len[f]};
+}
+
+__device__ void drop_entry(const CacheArrays &a, Hot &h, unsigned long long mask, int e) {
+    map_del(a, mask, ld(&a.ekey[e]));
+    st(&a.ekey[e], kEmpty);
+    a.free_stack[h.n_free++] = e;
+    h.count--;
+}
+
+// EvLFU_C1.py:32-63 set(key, value, agg_hit); returns the entry id (row is copied later)
+__device__ int evlfu_set(const CacheState &cs, const CacheArrays &a, Hot &h, unsigned long long mask,
+                         unsigned long long key, int agg_hit) {
+    const int top = cs.n_tables;
+    if (h.n_perfect >= cs.max_perfect) {  // :36-44 flush the oldest of the top bucket
+        for (int i = 0; i < cs.flush_n; i++) {
+            const int e = h.head[top];
+            if (e < 0) { if (cs.perfect_mode == 0) h.error = 1; break; }  // Python: IndexError; C++: loop guard
+            list_unlink(a, bucket(h, top), e);
+            drop_entry(a, h, mask, e);
+        }
+        // Python recounts (:43); the C++/Cython variants subtract int(rate*cap) (evlfu_8.cpp:270, EvLFU.cpp:86)
+        h.n_perfect = (cs.perfect_mode == 0) ? h.len[top] : h.n_perfect - (cs.flush_n - (cs.perfect_mode == 1 ? 1 : 0));
+        h.n_flush++;
+    } else if (h.count >= cs.cap) {       // :47-56 evict the FIFO-oldest key of the lowest non-empty bucket
+        while (h.len[h.min_c1] == 0) {
+            h.min_c1++;
+            if (h.min_c1 > top) h.min_c1 = 1;
+        }
+        const int e = h.head[h.min_c1];
+        list_unlink(a, bucket(h, h.min_c1), e);
+        drop_entry(a, h, mask, e);
+        h.n_evict++;
+    }
+    if (h.n_free <= 0) { h.error = 2; return -1; }
+    const int e = a.free_stack[--h.n_free];
+    st(&a.ekey[e], key);
+    st(&a.eagg[e], agg_hit);
+    map_put(a, mask, key, e);
+    list_append(a, bucket(h, agg_hit), e);
+    h.count++;
+    if (agg_hit < h.min_c1) h.min_c1 = agg_hit;  // :62-63
+    return e;
+}
+
+// One wavefront, requests strictly in order.
+__global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
+    __shared__ Hot h;
+    __shared__ int s_src[kMaxTables];    // >=0: arena entry to read the row from; -1: backing store; -2: copy of table s_from
+    __shared__ int s_fill[kMaxTables];   // >=0: arena entry to fill from the backing row after the request
+    __shared__ int s_from[kMaxTables];   // approximate mode: table whose vector is reused
+    const int lane = threadIdx.x;
+    CacheState *gs = args.st;
+    const CacheArrays a = args.a;
+    const CacheState cs = *gs;           // immutable config fields are read from this copy
+    const unsigned long long mask = cs.nslot_mask;
+    const int T = cs.n_tables, d = cs.dim, rb = cs.row_bytes;
+    if (lane == 0) {
+        h.min_c1 = cs.min_c1; h.n_perfect = cs.n_perfect; h.count = cs.count; h.n_free = cs.n_free;
+        h.n_flush = cs.n_flush; h.n_evict = cs.n_evict; h.least_freq = cs.least_freq; h.error = cs.error;
+    }
+    for (int b = lane; b < kMaxBuckets; b += 64) { h.head[b] = cs.head[b]; h.tail[b] = cs.tail[b]; h.len[b] = cs.len[b]; }
+    __syncthreads();
+    long long n_hits = 0, n_perfect_hits = 0;
+
+    for (long long rq = 0; rq < args.B; rq++) {
+        const int row = lane < T ? args.requests[rq * T + lane] : 0;
+        const unsigned long long key = ((unsigned long long)(lane + 1) << 32) | (unsigned)row;
+        const bool row_ok = lane < T && row >= 0 && row < args.backing_rows[lane < T ? lane : 0];
+        if (lane < T) { s_src[lane] = -1; s_fill[lane] = -1; s_from[lane] = -1; }
+
+        if (cs.policy == kEvLFU) {
+            // ---- probe all T keys at once; agg_hit = popcount(ballot)  (EvLFU_C1.py:105-120) ----
+            int e = (lane < T && row_ok) ? map_find(a, mask, key) : -1;
+            const unsigned long long hit_mask = __ballot(e >= 0);
+            const int agg_hit = __popcll(hit_mask);
+            const bool pick_random = args.approx_thres > 0 && agg_hit >= args.approx_thres;  // :122-125
+            bool my_hit = e >= 0;
+            // ---- policy update, table order, one lane (EvLFU_C1.py:135-161) ----
+            int last_hit_table = -1;
+            for (int i = 0; i < T; i++) {
+                const int ei = __shfl(e, i);
+                const unsigned long long ki = __shfl(key, i);
+                const bool oki = __shfl((int)row_ok, i) != 0;
+                const bool hiti = (hit_mask >> i) & 1ull;
+                int src = -1, fill = -1, from = -1;
+                if (lane == 0 && oki) {
+                    if (hiti) {
+                        // update() -> update_agg_hit (:65-78); the entry may have been evicted by an
+                        // earlier insert of this same request (:90-94): then re-fetch and set()
+                        const bool alive = ld(&a.ekey[ei]) == ki;
+                        if (alive) {
+                            const int old = ld(&a.eagg[ei]);
+                            if (old < agg_hit) {
+                                list_unlink(a, bucket(h, old), ei);
+                                list_append(a, bucket(h, agg_hit), ei);
+                                st(&a.eagg[ei], agg_hit);
+                            }
+                            src = ei;
+                        } else {
+                            fill = evlfu_set(cs, a, h, mask, ki, agg_hit);
+                        }
+                        last_hit_table = i;
+                    } else if (pick_random) {  // :142-152: the miss reuses the previous hit's vector
+                        from = last_hit_table;
+                        src = -2;
+                    } else {
+                        fill = evlfu_set(cs, a, h, mask, ki, agg_hit);
+                    }
+                    s_src[i] = src; s_fill[i] = fill; s_from[i] = from;
+                }
+            }
+            if (lane == 0 && agg_hit == T) h.n_perfect = h.len[T];  // :163-165
+            if (pick_random) my_hit = lane < T;                       // misses are reported as hits (:152)
+            if (lane < T) args.hit[rq * T + lane] = my_hit ? 1 : 0;
+            int nh = __popcll(__ballot(my_hit && lane < T));
+            n_hits += nh;
+            n_perfect_hits += (nh == T);
+        } else if (cs.policy == kLRU) {
+            // LRU.py:38-64: key by key; hit -> move to MRU end (:24-28); miss -> evict LRU head if full (:14-20)
+            int nh = 0;
+            for (int i = 0; i < T; i++) {
+                const unsigned long long ki = __shfl(key, i);
+                const bool oki = __shfl((int)row_ok, i) != 0;
+                int hit_i = 0;
+                if (lane == 0 && oki) {
+                    const int ei = map_find(a, mask, ki);
+                    if (ei >= 0) {
+                        list_unlink(a, bucket(h, 0), ei);
+                        list_append(a, bucket(h, 0), ei);
+                        s_src[i] = ei;
+                        hit_i = 1;
+                    } else {
+                        if (h.count >= cs.cap) {
+                            const int v = h.head[0];
+                            list_unlink(a, bucket(h, 0), v);
+                            drop_entry(a, h, mask, v);
+                            h.n_evict++;
+                        }
+                        const int en = a.free_stack[--h.n_free];
+                        st(&a.ekey[en], ki);
+                        map_put(a, mask, ki, en);
+                        list_append(a, bucket(h, 0), en);
+                        h.count++;
+                        s_fill[i] = en;
+                    }
+                }
+                hit_i = __shfl(hit_i, 0);
+                if (lane == i) args.hit[rq * T + i] = (unsigned char)hit_i;
+                nh += hit_i;
+                // the fill must land before a later key of this request can evict/reuse the entry:
+                // rows are moved after the loop from the BACKING store for every miss, so order is moot
+            }
+            n_hits += nh;
+            n_perfect_hits += (nh == T);
+        } else {
+            // LFU.py:69-95: FIFO inside a frequency; hit moves f -> f+1 (:19-34); miss evicts head of least_freq (:36-51)
+            int nh = 0;
+            for (int i = 0; i < T; i++) {
+                const unsigned long long ki = __shfl(key, i);
+                const bool oki = __shfl((int)row_ok, i) != 0;
+                int hit_i = 0;
+                if (lane == 0 && oki) {
+                    const int ei = map_find(a, mask, ki);
+                    if (ei >= 0) {
+                        const long long f = a.efreq[ei];
+                        list_unlink(a, lfu_list(a, f), ei);
+                        if (a.lfu_len[h.least_freq] == 0) h.least_freq += 1;
+                        if (f + 1 >= a.lfu_max_freq) { h.error = 3; }
+                        else {
+                            a.efreq[ei] = f + 1;
+                            list_append(a, lfu_list(a, f + 1), ei);
+                        }
+                        s_src[i] = ei;
+                        hit_i = 1;
+                    } else {
+                        if (h.count >= cs.cap) {
+                            const int v = a.lfu_head[h.least_freq];
+                            if (v < 0) { h.error = 2; }
+                            else {
+                                list_unlink(a, lfu_list(a, h.least_freq), v);
+                                drop_entry(a, h, mask, v);
+                                h.n_evict++;
+                            }
+                        }
+                        const int en = a.free_stack[--h.n_free];
+                        st(&a.ekey[en], ki);
+                        a.efreq[en] = 1;
+                        map_put(a, mask, ki, en);
+                        list_append(a, lfu_list(a, 1), en);
+                        h.count++;
+                        h.least_freq = 1;
+                        s_fill[i] = en;
+                    }
+                }
+                hit_i = __shfl(hit_i, 0);
+                if (lane == i) args.hit[rq * T + i] = (unsigned char)hit_i;
+                nh += hit_i;
+            }
+            n_hits += nh;
+            n_perfect_hits += (nh == T);
+        }
+        __syncthreads();
+
+        // ---- rows: hits from the arena, misses from the backing store; then fill inserted entries ----
+        float *out = args.out + rq * (long long)T * d;
+        for (int i = 0; i < T; i++) {
+            int src = s_src[i];
+            int tsrc = i;
+            if (src == -2) {  // approximate mode: vector of the previous hit (or zeros when there was none)
+                tsrc = s_from[i];
+                if (tsrc < 0) { for (int c = lane; c < d; c += 64) out[i * d + c] = 0.f; continue; }
+                src = s_src[tsrc];
+            }
+            const int rrow = args.requests[rq * T + tsrc];
+            const bool ok = rrow >= 0 && rrow < args.backing_rows[tsrc];
+            const unsigned char *rowp = nullptr;
+            if (src >= 0) rowp = a.arena + (long long)src * rb;
+            else if (ok) rowp = args.backing[tsrc] + (long long)rrow * rb;
+            for (int c = lane; c < d; c += 64) out[i * d + c] = rowp ? decode_elem(rowp, cs.codec, c) : 0.f;
+        }
+        __syncthreads();
+        for (int i = 0; i < T; i++) {
+            const int fe = s_fill[i];
+            if (fe < 0) continue;
+            // the entry may already have been evicted again by a later key of this request
+            const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)args.requests[rq * T + i];
+            if (ld(&a.ekey[fe]) != ki) continue;
+            const unsigned char *rowp = args.backing[i] + (long long)args.requests[rq * T + i] * rb;
+            unsigned char *dst = a.arena + (long long)fe * rb;
+            for (int c = lane; c < rb; c += 64) dst[c] = rowp[c];
+        }
+        __threadfence();
+        __syncthreads();
+    }
+
+    if (lane == 0) {
+        gs->min_c1 = h.min_c1; gs->n_perfect = h.n_perfect; gs->count = h.count; gs->n_free = h.n_free;
+        gs->n_flush = h.n_flush; gs->n_evict = h.n_evict; gs->least_freq = h.least_freq; gs->error = h.error;
+        gs->n_requests = cs.n_requests + args.B;
+        gs->n_hits = cs.n_hits + n_hits;
+        gs->n_perfect_hits = cs.n_perfect_hits + n_perfect_hits;
+    }
+    for (int b = lane; b < kMaxBuckets; b += 64) { gs->head[b] = h.head[b]; gs->tail[b] = h.tail[b]; gs->len[b] = h.len[b]; }
+}
+
+}  // namespace evs
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct evs_cache {
+    evs::CacheState host;      // configuration mirror
+    evs::CacheState *st = nullptr;
+    evs::CacheArrays a{};
+    long long nslot = 0;
+    const unsigned char *backing[evs::kMaxTables] = {nullptr};
+    long long backing_rows[evs::kMaxTables] = {0};
+    bool has_backing = false;
+};
+
+extern "C" int evs_cache_destroy(evs_cache *c) {
+    if (!c) return EVS_OK;
+    void *ptrs[] = {c->st, c->a.keys, c->a.slot_entry, c->a.ekey, c->a.eagg, c->a.efreq, c->a.prev, c->a.next,
+                    c->a.free_stack, c->a.arena, c->a.lfu_head, c->a.lfu_tail, c->a.lfu_len};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete c;
+    return EVS_OK;
+}
+
+extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, int n_tables, int dim, int codec,
+                                double flush_rate, double perfect_item_cap, int flush_extra, int perfect_mode) {
+    using namespace evs;
+    EVS_REQUIRE(out, "evs_cache_create: NULL out");
+    EVS_REQUIRE(policy >= 0 && policy <= 2, "evs_cache_create: policy %d", policy);
+    EVS_REQUIRE(capacity >= 1 && capacity < (1ll << 30), "evs_cache_create: capacity %lld", (long long)capacity);
+    EVS_REQUIRE(n_tables >= 1 && n_tables <= kMaxTables, "evs_cache_create: n_tables %d (max %d)", n_tables, kMaxTables);
+    EVS_REQUIRE(codec == 32 || codec == 16 || codec == 8 || codec == 4, "evs_cache_create: codec %d", codec);
+    EVS_REQUIRE(dim >= 1 && (codec != 4 || dim % 2 == 0), "evs_cache_create: dim %d", dim);
+    evs_cache *c = new evs_cache();
+    CacheState &h = c->host;
+    h = CacheState{};
+    h.cap = (int)capacity; h.n_tables = n_tables; h.dim = dim; h.codec = codec; h.row_bytes = dim * codec / 8;
+    h.policy = policy;
+    long long nslot = 16;
+    while (nslot < capacity * 2 + 8) nslot <<= 1;
+    c->nslot = nslot;
+    h.nslot_mask = (unsigned long long)(nslot - 1);
+    h.min_c1 = 0; h.n_perfect = 0;
+    h.max_perfect = (int)(capacity * perfect_item_cap);          // EvLFU_C1.py:30
+    h.flush_n = (int)(flush_rate * capacity) + (flush_extra ? 1 : 0);  // :40 (+1) / evlfu_8.cpp:256 (+0)
+    h.perfect_mode = perfect_mode;
+    h.n_free = (int)capacity; h.least_freq = 1;
+    for (int b = 0; b < kMaxBuckets; b++) { h.head[b] = -1; h.tail[b] = -1; h.len[b] = 0; }
+#define EVS_ALLOC(ptr, bytes)                                                                     \
+    do {                                                                                          \
+        if (hipMalloc(reinterpret_cast<void **>(&(ptr)), (bytes)) != hipSuccess) {                \
+            set_error("evs_cache_create: hipMalloc(%lld bytes) failed", (long long)(bytes));      \
+            evs_cache_destroy(c);                                                                 \
+            return EVS_ENOMEM;                                                                    \
+        }                                                                                         \
+    } while (0)
+    EVS_ALLOC(c->st, sizeof(CacheState));
+    EVS_ALLOC(c->a.keys, nslot * 8);
+    EVS_ALLOC(c->a.slot_entry, nslot * 4);
+    EVS_ALLOC(c->a.ekey, capacity * 8);
+    EVS_ALLOC(c->a.eagg, capacity * 4);
+    EVS_ALLOC(c->a.efreq, capacity * 8);
+    EVS_ALLOC(c->a.prev, capacity * 4);
+    EVS_ALLOC(c->a.next, capacity * 4);
+    EVS_ALLOC(c->a.free_stack, capacity * 4);
+    EVS_ALLOC(c->a.arena, capacity * (long long)h.row_bytes);
+    c->a.lfu_max_freq = policy == kLFU ? (1ll << 22) : 1;
+    EVS_ALLOC(c->a.lfu_head, c->a.lfu_max_freq * 4);
+    EVS_ALLOC(c->a.lfu_tail, c->a.lfu_max_freq * 4);
+    EVS_ALLOC(c->a.lfu_len, c->a.lfu_max_freq * 4);
+#undef EVS_ALLOC
+    EVS_HIP_CHECK(hipMemset(c->a.keys, 0, nslot * 8));
+    EVS_HIP_CHECK(hipMemset(c->a.ekey, 0, capacity * 8));
+    EVS_HIP_CHECK(hipMemset(c->a.lfu_head, 0xff, c->a.lfu_max_freq * 4));
+    EVS_HIP_CHECK(hipMemset(c->a.lfu_tail, 0xff, c->a.lfu_max_freq * 4));
+    EVS_HIP_CHECK(hipMemset(c->a.lfu_len, 0, c->a.lfu_max_freq * 4));
+    std::vector<int> fs(capacity);
+    for (int64_t i = 0; i < capacity; i++) fs[i] = (int)(capacity - 1 - i);  // pops hand out 0,1,2,...
+    EVS_HIP_CHECK(hipMemcpy(c->a.free_stack, fs.data(), capacity * 4, hipMemcpyHostToDevice));
+    EVS_HIP_CHECK(hipMemcpy(c->st, &h, sizeof h, hipMemcpyHostToDevice));
+    *out = c;
+    return EVS_OK;
+}
+
+extern "C" int evs_cache_set_backing(evs_cache *c, const void *const *tables, const int64_t *n_rows) {
+    using namespace evs;
+    EVS_REQUIRE(c && tables && n_rows, "evs_cache_set_backing: NULL argument");
+    for (int k = 0; k < c->host.n_tables; k++) {
+        EVS_REQUIRE(tables[k] || n_rows[k] == 0, "evs_cache_set_backing: table %d is NULL", k);
+        c->backing[k] = reinterpret_cast<const unsigned char *>(tables[k]);
+        c->backing_rows[k] = n_rows[k];
+    }
+    c->has_backing = true;
+    return EVS_OK;
+}
+
+extern "C" int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
+                                 int approx_thres, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(c, "evs_cache_request: NULL cache");
+    if (!c->has_backing) { set_error("evs_cache_request: call evs_cache_set_backing first"); return EVS_ESTATE; }
+    if (B == 0) return EVS_OK;
+    EVS_REQUIRE(B > 0 && rows && out && hit, "evs_cache_request: NULL argument");
+    CacheArgs args;
+    args.st = c->st; args.a = c->a;
+    for (int k = 0; k < kMaxTables; k++) { args.backing[k] = c->backing[k]; args.backing_rows[k] = c->backing_rows[k]; }
+    args.requests = rows; args.out = out; args.hit = hit; args.B = B; args.approx_thres = approx_thres;
+    hipLaunchKernelGGL(cache_exact_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), args);
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
+}
+
+// out8: [min_C1, n_perfect, size, n_flush, n_evict, n_requests, n_perfect_hits, n_hits]; returns the sticky error
+extern "C" int evs_cache_stats(evs_cache *c, int64_t *out8, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(c && out8, "evs_cache_stats: NULL argument");
+    CacheState h;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    EVS_HIP_CHECK(hipMemcpyAsync(&h, c->st, sizeof h, hipMemcpyDeviceToHost, st));
+    EVS_HIP_CHECK(hipStreamSynchronize(st));
+    out8[0] = h.min_c1; out8[1] = h.n_perfect; out8[2] = h.count; out8[3] = h.n_flush; out8[4] = h.n_evict;
+    out8[5] = h.n_requests; out8[6] = h.n_perfect_hits; out8[7] = h.n_hits;
+    if (h.error) {
+        set_error("cache policy error %d (1: flush popped an empty bucket, 2: internal, 3: LFU frequency overflow)", h.error);
+        return EVS_ESTATE;
+    }
+    return EVS_OK;
+}
+
+extern "C" int evs_cache_reset_counters(evs_cache *c, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(c, "evs_cache_reset_counters: NULL cache");
+    CacheState h;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    EVS_HIP_CHECK(hipMemcpyAsync(&h, c->st, sizeof h, hipMemcpyDeviceToHost, st));
+    EVS_HIP_CHECK(hipStreamSynchronize(st));
+    h.n_requests = 0; h.n_perfect_hits = 0; h.n_hits = 0;
+    EVS_HIP_CHECK(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, st));
+    EVS_HIP_CHECK(hipStreamSynchronize(st));
+    return EVS_OK;
+}
+
+// Resident keys in list order: triples (bucket|freq|0, table_1based, row); returns the count (may exceed max).
+extern "C" int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream) {
+    using namespace evs;
+    if (!c) return EVS_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipStreamSynchronize(st) != hipSuccess) return EVS_EHIP;
+    CacheState h;
+    const int64_t cap = c->host.cap;
+    std::vector<unsigned long long> ekey(cap);
+    std::vector<int> next(cap);
+    if (hipMemcpy(&h, c->st, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+    if (hipMemcpy(ekey.data(), c->a.ekey, cap * 8, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+    if (hipMemcpy(next.data(), c->a.next, cap * 4, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+    int64_t n = 0;
+    auto walk = [&](int head, int64_t tag) {
+        for (int e = head; e >= 0; e = next[e]) {
+            if (n < max_triples && triples) {
+                triples[3 * n] = tag;
+                triples[3 * n + 1] = (int64_t)(ekey[e] >> 32);
+                triples[3 * n + 2] = (int64_t)(ekey[e] & 0xffffffffull);
+            }
+            n++;
+            if (n > cap + 1) return;  // corrupted list guard
+        }
+    };
+    if (c->host.policy == kLFU) {
+        const int64_t F = c->a.lfu_max_freq;
+        std::vector<int> heads(F);
+        if (hipMemcpy(heads.data(), c->a.lfu_head, F * 4, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+        for (int64_t f = 1; f < F && n < h.count; f++) walk(heads[f], f);
+    } else {
+        for (int b = 0; b <= c->host.n_tables; b++) walk(h.head[b], b);
+    }
+    return n;
+}

@@ -1,0 +1,80 @@
+"""GPU-resident cache tier (EvLFU / LRU / LFU) -- Python handle over the C ABI (evs_cache_*).
+
+Reference policies: cache_algo/EvLFU_C1.py, LRU.py, LFU.py; C++/Cython EvLFU variants differ
+only in three constants (see include/evstore_hip.h).  All state (hash table, priority lists,
+row arena) lives in HBM; this class only owns device buffers and marshals pointers.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+POLICY = {"evlfu": 0, "lru": 1, "lfu": 2}
+# (flush_rate, perfect_item_cap, flush_extra, perfect_mode)
+EVLFU_VARIANTS = {"python": (0.3, 0.95, 1, 0), "cpp": (0.3, 0.95, 0, 2), "cython": (0.4, 1.0, 1, 1)}
+
+
+class GpuCache:
+    def __init__(self, policy, capacity, n_tables=26, dim=36, codec=32, variant="python", device="cuda"):
+        self.policy, self.capacity, self.n_tables, self.dim, self.codec = policy, int(capacity), n_tables, dim, codec
+        self.device = torch.device(device)
+        fr, pc, ex, pm = EVLFU_VARIANTS[variant]
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().evs_cache_create(C.byref(h), POLICY[policy], self.capacity, n_tables, dim, codec,
+                                                   fr, pc, ex, pm))
+        self._h = h
+        self._backing = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().evs_cache_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_backing(self, tables):
+        """tables: EVTables, or a list of uint8/float tensors (HBM or pinned host memory) in the cache's codec."""
+        raws = tables.raw if hasattr(tables, "raw") else list(tables)
+        assert len(raws) == self.n_tables
+        rb = self.dim * self.codec // 8
+        n_rows = [int(t.numel() * t.element_size() // rb) for t in raws]
+        self._backing = raws  # keep alive
+        ptrs = (C.c_void_p * self.n_tables)(*[t.data_ptr() for t in raws])
+        rows = (C.c_int64 * self.n_tables)(*n_rows)
+        _lib.check(_lib.lib().evs_cache_set_backing(self._h, ptrs, rows))
+
+    def request(self, rows, approx_thres=-1, out=None, hit=None):
+        """rows: (B, n_tables) int32 device tensor.  Requests are replayed strictly in order.
+        Returns (hit (B,T) uint8, out (B,T,dim) fp32), both on the device."""
+        assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
+        B = int(rows.shape[0])
+        if out is None:
+            out = torch.empty((B, self.n_tables, self.dim), dtype=torch.float32, device=self.device)
+        if hit is None:
+            hit = torch.empty((B, self.n_tables), dtype=torch.uint8, device=self.device)
+        _lib.check(_lib.lib().evs_cache_request(self._h, B, rows.data_ptr(), out.data_ptr(), hit.data_ptr(),
+                                                int(approx_thres), torch.cuda.current_stream(self.device).cuda_stream))
+        return hit, out
+
+    def stats(self):
+        s = (C.c_int64 * 8)()
+        _lib.check(_lib.lib().evs_cache_stats(self._h, s, torch.cuda.current_stream(self.device).cuda_stream))
+        keys = ("min_c1", "n_perfect", "size", "n_flush", "n_evict", "n_requests", "n_perfect_hits", "n_hits")
+        return dict(zip(keys, [int(v) for v in s]))
+
+    def reset_counters(self):
+        _lib.check(_lib.lib().evs_cache_reset_counters(self._h, torch.cuda.current_stream(self.device).cuda_stream))
+
+    def dump(self):
+        """Resident keys in list order: rows of (bucket | frequency | 0, table_1based, row)."""
+        import numpy as np
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        n = _lib.lib().evs_cache_dump(self._h, None, 0, st)
+        if n < 0:
+            _lib.check(int(n))
+        out = np.zeros((max(n, 1), 3), np.int64)
+        _lib.lib().evs_cache_dump(self._h, out.ctypes.data, n, st)
+        return out[:n]

@@ -161,6 +161,41 @@ EVS_API int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec,
 EVS_API int evs_interact_cat(int64_t B, int F, int d, const float *const *feats,
                      const int64_t *feat_strides, float *R, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * a6/a7/a8: the cache tier, GPU resident.
+ *   EvLFU: cache_algo/EvLFU_C1.py:21-166 (init/set/update_agg_hit/update/request_to_ev_lfu)
+ *   LRU:   cache_algo/LRU.py:14-64        LFU: cache_algo/LFU.py:12-95
+ * policy: 0 EvLFU, 1 LRU, 2 LFU.  capacity in ENTRIES (--cache-size).  n_tables keys per
+ * request (<= 64), table = position, key = (table_1based, row).
+ * EvLFU constants: (flush_rate, perfect_item_cap, flush_extra, perfect_mode) =
+ *   (0.3, 0.95, 1, 0) cache_algo/EvLFU_C1.py:18-19,:40,:43
+ *   (0.3, 0.95, 0, 2) mixed_precs_caching/evlfu_8.hpp:50-51, evlfu_8.cpp:256-270
+ *   (0.4, 1.0, 1, 1)  cache_algo/EvLFU_C1_Cython/EvLFU.cpp:12-13,:80-86
+ * Rows are cached in the table's codec (arena bytes = capacity * dim*codec/8) and
+ * decoded to fp32 on output.  The hash table, priority lists and arena live in HBM.
+ * ------------------------------------------------------------------------- */
+typedef struct evs_cache evs_cache;
+EVS_API int evs_cache_create(evs_cache **out, int policy, int64_t capacity, int n_tables, int dim, int codec,
+                             double flush_rate, double perfect_item_cap, int flush_extra, int perfect_mode);
+EVS_API int evs_cache_destroy(evs_cache *c);
+/* Miss path: tables[k] is DEVICE-ACCESSIBLE memory holding table k in the cache's codec
+ * (HBM, or pinned host memory mapped into the device = the host-mmap miss tier);
+ * HOST arrays of n_tables entries. */
+EVS_API int evs_cache_set_backing(evs_cache *c, const void *const *tables, const int64_t *n_rows);
+/* B requests replayed strictly in order (exact reference semantics; B=1 is the reference's
+ * request_to_ev_lfu / request_to_lru / request_to_lfu).  rows: device (B, n_tables) int32;
+ * out: device (B, n_tables, dim) fp32; hit: device (B, n_tables) bytes (0/1).
+ * approx_thres > 0: EvLFU approximate mode (EvLFU_C1.py:122-125,:142-152). */
+EVS_API int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
+                              int approx_thres, void *stream);
+/* out8 (host): [min_C1, n_perfect, size, n_flush, n_evict, n_requests, n_perfect_hits, n_hits].
+ * Synchronises the stream.  Returns EVS_ESTATE if the policy hit an inconsistency. */
+EVS_API int evs_cache_stats(evs_cache *c, int64_t *out8, void *stream);
+EVS_API int evs_cache_reset_counters(evs_cache *c, void *stream);
+/* Resident keys in list order as (bucket | frequency | 0, table_1based, row) triples (host);
+ * returns the number of resident keys (or a negative error). */
+EVS_API int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -311,6 +311,9 @@ typedef struct {
     int64_t n_perfect, max_perfect;
     double flush_rate;
     int flush_extra;
+    int perfect_mode; /* after a flush: 0 = recount len(bucket top) (EvLFU_C1.py:43); 1 = subtract int(rate*cap)
+                         with n+1 keys flushed (EvLFU_C1_Cython/EvLFU.cpp:80-86); 2 = subtract int(rate*cap), n keys
+                         flushed, stop silently at the end of the bucket (evlfu_8.cpp:256-270) */
     int64_t n_flush, n_evict;
     orc_map map;
     uint64_t *ekey;
@@ -323,11 +326,11 @@ typedef struct {
 } orc_evlfu;
 
 orc_evlfu *orc_evlfu_new(int64_t cap, int n_tables, int dim, double flush_rate,
-                         double perfect_item_cap, int flush_extra) {
+                         double perfect_item_cap, int flush_extra, int perfect_mode) {
     if (n_tables > ORC_MAX_TABLES || cap < 1) return NULL;
     orc_evlfu *c = (orc_evlfu *)calloc(1, sizeof(orc_evlfu));
     c->cap = cap; c->n_tables = n_tables; c->dim = dim; c->min_c1 = 0;
-    c->flush_rate = flush_rate; c->flush_extra = flush_extra;
+    c->flush_rate = flush_rate; c->flush_extra = flush_extra; c->perfect_mode = perfect_mode;
     c->max_perfect = (int64_t)(cap * perfect_item_cap); /* EvLFU_C1.py:30 int(cap*0.95) */
     map_init(&c->map, cap);
     c->ekey = (uint64_t *)malloc(sizeof(uint64_t) * cap);
@@ -364,11 +367,15 @@ static int evlfu_set(orc_evlfu *c, uint64_t key, const float *value, int agg_hit
         int64_t n = (int64_t)(c->flush_rate * c->cap) + c->flush_extra;
         for (int64_t i = 0; i < n; i++) {
             int32_t e = c->lists[top].head;
-            if (e < 0) return -1; /* Python would raise IndexError on pop(0) */
+            if (e < 0) {
+                if (c->perfect_mode == 0) return -1; /* Python would raise IndexError on pop(0) */
+                break;
+            }
             list_unlink(&c->lists[top], c->prev, c->next, e);
             evlfu_drop(c, e);
         }
-        c->n_perfect = c->lists[top].len;
+        if (c->perfect_mode == 0) c->n_perfect = c->lists[top].len;
+        else c->n_perfect -= (int64_t)(c->flush_rate * c->cap);
         c->n_flush++;
     } else if (c->map.count >= c->cap) { /* :47-56 evict FIFO-oldest of lowest non-empty bucket */
         while (c->lists[c->min_c1].len == 0) {

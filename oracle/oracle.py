@@ -47,7 +47,7 @@ def lib():
         for nm in ("orc_encode_u8_arr", "orc_encode_u16_arr", "orc_encode_u4_arr"):
             getattr(L, nm).argtypes = [C.POINTER(C.c_double), C.c_int64, _i64p]
         L.orc_evlfu_new.restype = C.c_void_p
-        L.orc_evlfu_new.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.orc_evlfu_new.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
         L.orc_evlfu_free.argtypes = [C.c_void_p]
         L.orc_evlfu_set_tables.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.orc_evlfu_request.restype = C.c_int
@@ -187,14 +187,18 @@ class _Policy:
             pass
 
 
+# (flush_rate, perfect_item_cap, flush_extra, perfect_mode) of the three EvLFU builds in the reference
+EVLFU_VARIANTS = {"python": (0.3, 0.95, 1, 0), "cpp": (0.3, 0.95, 0, 2), "cython": (0.4, 1.0, 1, 1)}
+
+
 class EvLFU(_Policy):
     """cache_algo/EvLFU_C1.py. variant='python' (0.3/0.95, flush n+1), 'cpp' (0.3/0.95, flush n;
     mixed_precs_caching/evlfu_8.cpp:252-300), 'cython' (0.4/1.0; EvLFU_C1_Cython/EvLFU.cpp:12-13)."""
     _prefix = "evlfu"
 
     def __init__(self, cap, tables, dim=36, variant="python"):
-        fr, pc, ex = {"python": (0.3, 0.95, 1), "cpp": (0.3, 0.95, 0), "cython": (0.4, 1.0, 1)}[variant]
-        h = lib().orc_evlfu_new(cap, len(tables), dim, fr, pc, ex)
+        fr, pc, ex, pm = EVLFU_VARIANTS[variant]
+        h = lib().orc_evlfu_new(cap, len(tables), dim, fr, pc, ex, pm)
         super().__init__(h, tables, len(tables), dim)
 
     def request(self, rows, approx_thres=-1):

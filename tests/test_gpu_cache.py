@@ -1,0 +1,158 @@
+"""GPU parity of the cache tier (csrc/evs_cache.hip) against the golden traces recorded from the
+reference's Python policies and against the oracle (bit-exact: hit flags, returned rows, final
+list order, counters)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import evstore_dlrm_amd as E
+    assert torch.cuda.is_available()
+    E._lib.lib()
+    return E
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _tables(orc, t):
+    return orc.kaggle_tables([int(n) for n in t["n_rows"]], int(t["table_seed"]))
+
+
+def _unpack(packed, n):
+    return np.unpackbits(packed, axis=1)[:, :26].astype(bool)[:n]
+
+
+def _run(E, policy, cap, tabs, reqs, chunk, approx=-1, variant="python", codec=32, raws=None):
+    c = E.GpuCache(policy, cap, 26, 36, codec, variant)
+    dev = [torch.from_numpy(np.ascontiguousarray(t)).cuda() for t in (raws if raws is not None else tabs)]
+    c.set_backing(dev)
+    hits, outs = [], []
+    r = torch.from_numpy(np.ascontiguousarray(reqs, dtype=np.int32)).cuda()
+    for s in range(0, len(reqs), chunk):
+        h, o = c.request(r[s:s + chunk].contiguous(), approx)
+        hits.append(h.cpu().numpy().astype(bool))
+        outs.append(o.cpu().numpy())
+    return c, np.concatenate(hits), np.concatenate(outs)
+
+
+@pytest.mark.parametrize("cap,chunk", [(64, 1), (300, 7), (768, 1500), (2000, 64), (79, 1), (80, 33), (82, 1200)])
+def test_evlfu_trace_matches_reference(E, orc, cap, chunk):
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    reqs = t["requests_flush"] if cap in (79, 80, 82) else t["requests"]
+    c, hits, outs = _run(E, "evlfu", cap, tabs, reqs, chunk)
+    want = _unpack(t["evlfu_cap%d_hits" % cap], len(reqs))
+    assert np.array_equal(hits, want)
+    for k in range(26):  # rows are the table rows, bit for bit, hit or miss
+        assert np.array_equal(outs[:, k, :], tabs[k][reqs[:, k]])
+    np.testing.assert_array_equal(c.dump(), t["evlfu_cap%d_final_buckets" % cap])
+    st = c.stats()
+    assert [st["min_c1"], st["n_perfect"], st["size"], st["n_flush"]] == list(t["evlfu_cap%d_state" % cap])
+    assert st["n_requests"] == len(reqs) and st["n_hits"] == int(want.sum())
+    assert st["n_perfect_hits"] == int(want.all(1).sum())
+
+
+def test_evlfu_approx_mode(E, orc):
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    c, hits, outs = _run(E, "evlfu", 768, tabs, t["requests"], 50, approx=20)
+    assert np.array_equal(hits, _unpack(t["evlfu_cap768_approx20_hits"], len(t["requests"])))
+    np.testing.assert_array_equal(c.dump(), t["evlfu_cap768_approx20_final_buckets"])
+
+
+@pytest.mark.parametrize("cap,chunk", [(64, 1), (768, 100), (80, 1200)])
+def test_lru_trace(E, orc, cap, chunk):
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    reqs = t["requests_flush"] if cap == 80 else t["requests"]
+    c, hits, outs = _run(E, "lru", cap, tabs, reqs, chunk)
+    assert np.array_equal(hits, _unpack(t["lru_cap%d_hits" % cap], len(reqs)))
+    assert np.array_equal(outs[:, 5, :], tabs[5][reqs[:, 5]])
+    np.testing.assert_array_equal(c.dump()[:, 1:], t["lru_cap%d_final_order" % cap])
+
+
+@pytest.mark.parametrize("cap,chunk", [(64, 1), (768, 100), (80, 1200)])
+def test_lfu_trace(E, orc, cap, chunk):
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    reqs = t["requests_flush"] if cap == 80 else t["requests"]
+    c, hits, outs = _run(E, "lfu", cap, tabs, reqs, chunk)
+    assert np.array_equal(hits, _unpack(t["lfu_cap%d_hits" % cap], len(reqs)))
+    assert np.array_equal(outs[:, 11, :], tabs[11][reqs[:, 11]])
+    np.testing.assert_array_equal(c.dump(), t["lfu_cap%d_final_freq" % cap])
+
+
+@pytest.mark.parametrize("variant", ["cpp", "cython"])
+def test_evlfu_variants_vs_oracle(E, orc, variant):
+    """mixed_precs_caching (0.3/0.95, n flushed) and Cython (0.4/1.0) constants: oracle vs GPU."""
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    reqs = t["requests_flush"]
+    o = orc.EvLFU(80, tabs, variant=variant)
+    want = np.stack([o.request(rq)[0].copy() for rq in reqs])
+    c, hits, _ = _run(E, "evlfu", 80, tabs, reqs, 97, variant=variant)
+    assert np.array_equal(hits, want)
+    np.testing.assert_array_equal(c.dump(), o.dump())
+
+
+@pytest.mark.parametrize("codec", [8, 4, 16])
+def test_cache_over_reduced_precision_rows(E, orc, codec):
+    """a cache tier holding 8/4/16-bit rows (the reference's C2 precisions) decodes on output."""
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    raws = [orc.encode_table(np.clip(w * 8, -1, 1), codec) for w in tabs]
+    reqs = t["requests"][:400]
+    c, hits, outs = _run(E, "evlfu", 300, tabs, reqs, 40, codec=codec, raws=raws)
+    assert np.array_equal(hits, _unpack(t["evlfu_cap300_hits"], 1500)[:400])  # policy is precision-agnostic
+    for k in (0, 2, 8, 25):
+        want = orc.decode(raws[k][reqs[:, k]], codec, 36)
+        assert np.array_equal(outs[:, k, :].view(np.uint32), want.view(np.uint32))
+
+
+def test_plugin_surface_evstore(E, orc, tmp_path):
+    """apply_emb_evstore + cache module + storage manager, as dlrm_s_pytorch_C1.py drives them."""
+    from evstore_dlrm_amd import evstore_ops
+    from evstore_dlrm_amd.cache_algo import EvLFU_C1
+    from evstore_dlrm_amd.emb_storage import storage_manager as sm
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    (tmp_path / "binary").mkdir()
+    for k, w in enumerate(tabs):
+        w.tofile(tmp_path / "binary" / ("ev-table-%d.bin" % (k + 1)))
+    # the reference's file / mmap readers
+    for st in (sm.EmbStorage.FILEPY, sm.EmbStorage.MMAPFILEPY):
+        sm.storage_type = st
+        sm.load_ev_table_into_emb_stor(str(tmp_path))
+        for (tb, r), want in zip(t["reader_probe"], t["reader_rows"]):
+            assert np.array_equal(np.asarray(sm.get_val_from_storage(int(tb), int(r)), np.float32), want)
+        sm.close_any_db_conn()
+    for st in (sm.EmbStorage.HBM, sm.EmbStorage.PINNED):
+        sm.storage_type = st
+        sm.load_ev_table_into_emb_stor(str(tmp_path))
+        EvLFU_C1.init(768)
+        evstore_ops.cache_algo = "evlfu"
+        evstore_ops.perfect_hit = 0
+        want = _unpack(t["evlfu_cap768_hits"], 1500)
+        n = 300
+        for i in range(n):
+            lS_i = torch.from_numpy(t["requests"][i].astype(np.int64)).reshape(26, 1)
+            ly = evstore_ops.apply_emb_evstore(None, lS_i, None, None, use_gpu=False, use_emb_cache=True)
+            assert len(ly) == 26 and ly[0].shape == (1, 36) and ly[0].requires_grad
+            if i % 37 == 0:
+                for k in range(26):
+                    assert np.array_equal(ly[k].detach().numpy()[0], tabs[k][t["requests"][i][k]])
+        assert evstore_ops.perfect_hit == int(want[:n].all(1).sum())
+        assert EvLFU_C1.stats()["n_hits"] == int(want[:n].sum())
+        _, ly = sm.request_to_emb_storage([int(v) for v in t["requests"][0]])
+        assert np.array_equal(ly[3].detach().numpy()[0], tabs[3][t["requests"][0][3]])
+        sm.close_any_db_conn()
