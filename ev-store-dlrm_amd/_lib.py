@@ -59,6 +59,15 @@ _PROTOS = {
     "evs_cache_stats": (_int, [_vp, _i64p, _vp]),
     "evs_cache_reset_counters": (_int, [_vp, _vp]),
     "evs_cache_dump": (_i64, [_vp, _vp, _i64, _vp]),
+    "evs_manager_configure": (_int, [_int, _int, _int, _i64, C.c_char_p, C.c_char_p, _int]),
+    "evs_manager_perfect_hit": (C.c_longlong, []),
+    "ev_lookup": (C.POINTER(C.c_float), [C.POINTER(C.c_int)]),
+    "get_ev_values": (C.POINTER(C.c_float), [C.POINTER(C.c_int)]),
+    "print_perfect_hit": (None, []),
+    "ev_lookup_based_on_list_keys": (_int, [C.POINTER(C.c_int)]),
+    "test_arr": (None, [C.POINTER(C.c_int)]),
+    "init_global_vars": (None, []),
+    "start_server_threads": (None, []),
     "evs_interact_cat": (_int, [_i64, _int, _int, _pp, _i64p, _vp, _vp]),
 }
 

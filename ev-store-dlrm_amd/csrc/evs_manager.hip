@@ -1,0 +1,200 @@
+// Cache manager: the reference's C ABI (mixed_precs_caching/cache_manager.cpp) on top of the
+// GPU cache tier.  What ctypes binds in cache_algo/cpp_socket_client.py:69-83 keeps working:
+//   float* ev_lookup(int*)                 cache_manager.cpp:231-237
+//   float* get_ev_values(int*)             :257-259
+//   void   print_perfect_hit()             :262-290
+//   int    ev_lookup_based_on_list_keys()  :239-253 (dead in the reference: prints and exit(-1))
+//   void   test_arr(int*)                  :154-168
+//   init_global_vars / start_server_threads :410-445 (epoll socket server: out of scope)
+// The reference is configured by editing #defines and recompiling (cache_manager.cpp:13-20);
+// here the same five knobs are runtime arguments of evs_manager_configure() or environment
+// variables read on the first ev_lookup (so a zero-argument dlopen + ev_lookup still works).
+#include "evs_common.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace evs {
+
+constexpr int kEvDim = 36;     // EV_DIMENSION (cache_manager.hpp:30)
+constexpr int kEvTables = 26;  // N_EV_TABLE   (cache_manager.hpp:31)
+
+struct Manager {
+    bool ready = false;
+    int n_layer = 1, main_prec = 32, secondary_prec = 4, backing_kind = 0;
+    long long total_size = 75425;
+    std::string proportion = "", root = "";
+    evs_cache *c1 = nullptr;
+    void *tables[kEvTables] = {nullptr};
+    long long rows[kEvTables] = {0};
+    int *d_rows = nullptr, *h_rows = nullptr;
+    float *d_out = nullptr, *h_out = nullptr;
+    unsigned char *d_hit = nullptr, *h_hit = nullptr;
+    long long perfect_hit = 0;
+    hipStream_t stream = nullptr;
+};
+static Manager g_mgr;
+static float g_emb_weights_in_1d_floats[kEvTables * kEvDim];  // cache_manager.hpp:51 (library-owned, static)
+
+static const char *precision_dir(int bits) {
+    // evlfu_32.hpp:61, evlfu_16.hpp:64, evlfu_8.hpp:58, evlfu_4.hpp:61
+    switch (bits) {
+    case 32: return "ev-table/binary/";
+    case 16: return "ev-table-16/binary/";
+    case 8: return "ev-table-8/binary/";
+    default: return "ev-table-4/binary/";
+    }
+}
+
+static int load_tables(Manager &m) {
+    const long long rb = (long long)kEvDim * m.main_prec / 8;
+    for (int k = 0; k < kEvTables; k++) {
+        const std::string path = m.root + "/" + precision_dir(m.main_prec) + "ev-table-" + std::to_string(k + 1) + ".bin";
+        FILE *fp = fopen(path.c_str(), "rb");
+        if (!fp) {  // evlfu_32.cpp:45-48 exits; the 8/4-bit tiers silently keep NULL and crash later
+            set_error("ERROR: Failed to load_ev_tables() when opening %s", path.c_str());
+            return EVS_EIO;
+        }
+        fseek(fp, 0, SEEK_END);
+        const long long bytes = ftell(fp);
+        fseek(fp, 0, SEEK_SET);
+        if (bytes % rb) { fclose(fp); set_error("%s: not a whole number of %lld-byte rows", path.c_str(), rb); return EVS_EIO; }
+        void *host = nullptr;
+        if (hipHostMalloc(&host, bytes > 0 ? bytes : 16, hipHostMallocDefault) != hipSuccess) { fclose(fp); return EVS_ENOMEM; }
+        const size_t got = bytes ? fread(host, 1, bytes, fp) : 0;
+        fclose(fp);
+        if ((long long)got != bytes) { (void)hipHostFree(host); set_error("%s: short read", path.c_str()); return EVS_EIO; }
+        if (m.backing_kind == 0) {  // HBM-resident tables
+            void *dev = nullptr;
+            if (hipMalloc(&dev, bytes > 0 ? bytes : 16) != hipSuccess) { (void)hipHostFree(host); return EVS_ENOMEM; }
+            if (hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return EVS_EHIP;
+            (void)hipHostFree(host);
+            m.tables[k] = dev;
+        } else {                    // pinned host memory, read by the GPU on a miss
+            m.tables[k] = host;
+        }
+        m.rows[k] = bytes / rb;
+    }
+    return EVS_OK;
+}
+
+static int ensure_ready() {
+    Manager &m = g_mgr;
+    if (m.ready) return EVS_OK;
+    if (m.root.empty()) {
+        const char *e;
+        if ((e = getenv("EVS_N_CACHING_LAYER"))) m.n_layer = atoi(e);
+        if ((e = getenv("EVS_MAIN_PRECISION"))) m.main_prec = atoi(e);
+        if ((e = getenv("EVS_SECONDARY_PRECISION"))) m.secondary_prec = atoi(e);
+        if ((e = getenv("EVS_TOTAL_SIZE"))) m.total_size = atoll(e);
+        if ((e = getenv("EVS_SIZE_PROPORTION"))) m.proportion = e;
+        if ((e = getenv("EVS_BACKING"))) m.backing_kind = (strcmp(e, "pinned") == 0) ? 1 : 0;
+        if ((e = getenv("EVS_EV_TABLE_ROOT"))) m.root = e;
+        if (m.root.empty()) {
+            set_error("cache manager is not configured: call evs_manager_configure() or set EVS_EV_TABLE_ROOT");
+            return EVS_ESTATE;
+        }
+    }
+    if (m.n_layer != 1) {
+        // cache_manager.cpp:213-217 prints and exit(-1)s on an unknown layer count; C1+C2(+aprx) is not built yet
+        set_error("ERROR: cache_manager N_CACHING_LAYER=%d is not built in this round (single tier only)", m.n_layer);
+        return EVS_ESTATE;
+    }
+    if (!(m.main_prec == 32 || m.main_prec == 16 || m.main_prec == 8 || m.main_prec == 4)) {
+        set_error("ERROR: MAIN_PRECISION %d", m.main_prec);
+        return EVS_EINVAL;
+    }
+    int rc = load_tables(m);
+    if (rc) return rc;
+    // sizes are in fp32-row equivalents: cache_manager.cpp:46-53, evlfu_8.cpp:92 (capacity * 4 for 8-bit rows)
+    const long long cap = m.total_size * (32 / m.main_prec);
+    // mixed_precs_caching constants: 0.3 / 0.95, n keys flushed, n_perfect -= n (evlfu_8.hpp:50-51, evlfu_8.cpp:256-270)
+    rc = evs_cache_create(&m.c1, 0, cap, kEvTables, kEvDim, m.main_prec, 0.3, 0.95, 0, 2);
+    if (rc) return rc;
+    long long rows64[kEvTables];
+    for (int k = 0; k < kEvTables; k++) rows64[k] = m.rows[k];
+    rc = evs_cache_set_backing(m.c1, m.tables, (const int64_t *)rows64);
+    if (rc) return rc;
+    EVS_HIP_CHECK(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+    EVS_HIP_CHECK(hipMalloc(&m.d_rows, kEvTables * 4));
+    EVS_HIP_CHECK(hipMalloc(&m.d_out, kEvTables * kEvDim * 4));
+    EVS_HIP_CHECK(hipMalloc(&m.d_hit, kEvTables));
+    EVS_HIP_CHECK(hipHostMalloc(&m.h_rows, kEvTables * 4, hipHostMallocDefault));
+    EVS_HIP_CHECK(hipHostMalloc(&m.h_out, kEvTables * kEvDim * 4, hipHostMallocDefault));
+    EVS_HIP_CHECK(hipHostMalloc(&m.h_hit, kEvTables, hipHostMallocDefault));
+    m.ready = true;
+    return EVS_OK;
+}
+
+}  // namespace evs
+
+extern "C" int evs_manager_configure(int n_caching_layer, int main_precision, int secondary_precision,
+                                     int64_t total_size, const char *size_proportion, const char *ev_table_root,
+                                     int backing) {
+    using namespace evs;
+    EVS_REQUIRE(!g_mgr.ready, "evs_manager_configure: the cache manager is already initialised");
+    EVS_REQUIRE(ev_table_root && *ev_table_root, "evs_manager_configure: ev_table_root is empty");
+    EVS_REQUIRE(total_size > 0, "evs_manager_configure: TOTAL_SIZE %lld", (long long)total_size);
+    g_mgr.n_layer = n_caching_layer; g_mgr.main_prec = main_precision; g_mgr.secondary_prec = secondary_precision;
+    g_mgr.total_size = total_size; g_mgr.proportion = size_proportion ? size_proportion : "";
+    g_mgr.root = ev_table_root; g_mgr.backing_kind = backing;
+    return ensure_ready();
+}
+
+// cache_manager.cpp:231-237.  Reads N_EV_TABLE int32 row ids (table = position), returns the
+// library-owned static float[26*36] (valid until the next call; single caller thread).
+// On a configuration error the reference prints and exit(-1)s; this returns NULL after printing.
+extern "C" float *ev_lookup(int *arr) {
+    using namespace evs;
+    if (ensure_ready() != EVS_OK) {
+        printf("%s\n", evs_last_error());
+        return nullptr;
+    }
+    Manager &m = g_mgr;
+    memcpy(m.h_rows, arr, kEvTables * sizeof(int));
+    if (hipMemcpyAsync(m.d_rows, m.h_rows, kEvTables * 4, hipMemcpyHostToDevice, m.stream) != hipSuccess) return nullptr;
+    if (evs_cache_request(m.c1, 1, m.d_rows, m.d_out, m.d_hit, -1, m.stream) != EVS_OK) {
+        printf("%s\n", evs_last_error());
+        return nullptr;
+    }
+    (void)hipMemcpyAsync(m.h_out, m.d_out, kEvTables * kEvDim * 4, hipMemcpyDeviceToHost, m.stream);
+    (void)hipMemcpyAsync(m.h_hit, m.d_hit, kEvTables, hipMemcpyDeviceToHost, m.stream);
+    if (hipStreamSynchronize(m.stream) != hipSuccess) return nullptr;
+    memcpy(g_emb_weights_in_1d_floats, m.h_out, sizeof g_emb_weights_in_1d_floats);
+    bool perfect = true;
+    for (int k = 0; k < kEvTables; k++) perfect &= m.h_hit[k] != 0;
+    m.perfect_hit += perfect ? 1 : 0;  // perfectHit += request_to_ev_lfu(...) (cache_manager.cpp:179)
+    return g_emb_weights_in_1d_floats;
+}
+
+extern "C" float *get_ev_values(int *) { return evs::g_emb_weights_in_1d_floats; }  // cache_manager.cpp:257-259
+
+extern "C" void print_perfect_hit() {  // cache_manager.cpp:262-290: prints, then resets the counter
+    using namespace evs;
+    printf("\n[epoll worker] C1_PRECISION    = %d\n", g_mgr.main_prec);
+    printf("[epoll worker] TOTAL_SIZE      = %lld\n", g_mgr.total_size);
+    printf("[epoll worker] Perfect hit     = %lld\n", g_mgr.perfect_hit);
+    fflush(stdout);
+    g_mgr.perfect_hit = 0;
+}
+
+extern "C" long long evs_manager_perfect_hit() { return evs::g_mgr.perfect_hit; }
+
+extern "C" int ev_lookup_based_on_list_keys(int *) {  // cache_manager.cpp:239-243: dead in the reference
+    printf("ERROR: This ev_lookup_based_on_list_keys() is outdated, better to use ev_lookup() instead!\n");
+    return -1;  // the reference exit(-1)s here; the symbol is kept, not the behaviour
+}
+
+extern "C" void test_arr(int *arr) {  // cache_manager.cpp:154-168
+    for (int i = 0; i < 5; i++) printf("key %d, ", arr[i]);
+    printf("\n");
+    for (int i = 0; i < 5; i++) printf("vec %d, ", arr[i]);
+    printf("\n");
+}
+
+// cache_manager.cpp:410-445 start an epoll TCP server on :8080.  Networking is out of scope of
+// this build; the symbols exist so a binding that resolves them still loads.
+extern "C" void init_global_vars() { printf("INFO: the socket transport is not part of libevstore_hip (use ev_lookup)\n"); }
+extern "C" void start_server_threads() { printf("INFO: the socket transport is not part of libevstore_hip (use ev_lookup)\n"); }

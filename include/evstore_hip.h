@@ -196,6 +196,33 @@ EVS_API int evs_cache_reset_counters(evs_cache *c, void *stream);
  * returns the number of resident keys (or a negative error). */
 EVS_API int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * a14: the reference's cache-manager C ABI (mixed_precs_caching/cache_manager.cpp), bound by
+ * cache_algo/cpp_socket_client.py:69-83 through ctypes.  Same names, same signatures.
+ *   ev_lookup: reads 26 int32 row ids (0-based; table = position), returns a pointer to the
+ *   library-owned static float[26*36], table-major, valid until the next call; not re-entrant;
+ *   side effect perfect-hit counter += (all 26 hit).  NULL (after printing) on a configuration error
+ *   (the reference prints and exit(-1)s).
+ * Configuration: the reference's five compile-time knobs (cache_manager.cpp:13-20) at run time.
+ *   n_caching_layer 1 (C1 only; 2/3 are not built this round), main_precision 32|16|8|4,
+ *   total_size in fp32-row equivalents (capacity = total_size * 32/main_precision entries),
+ *   ev_table_root = directory holding ev-table/binary, ev-table-16/binary, ev-table-8/binary,
+ *   ev-table-4/binary (evlfu_*.hpp EV_TABLE_PATH), backing 0 = tables in HBM, 1 = pinned host.
+ *   Without a call, ev_lookup reads EVS_N_CACHING_LAYER, EVS_MAIN_PRECISION, EVS_TOTAL_SIZE,
+ *   EVS_EV_TABLE_ROOT, EVS_BACKING from the environment on first use.
+ * ------------------------------------------------------------------------- */
+EVS_API int evs_manager_configure(int n_caching_layer, int main_precision, int secondary_precision,
+                                  int64_t total_size, const char *size_proportion, const char *ev_table_root,
+                                  int backing);
+EVS_API long long evs_manager_perfect_hit(void);
+EVS_API float *ev_lookup(int *arr);                      /* cache_manager.cpp:231 */
+EVS_API float *get_ev_values(int *arr);                  /* cache_manager.cpp:257 */
+EVS_API void print_perfect_hit(void);                    /* cache_manager.cpp:262 */
+EVS_API int ev_lookup_based_on_list_keys(int *arr);      /* cache_manager.cpp:239 (dead in the reference) */
+EVS_API void test_arr(int *arr);                         /* cache_manager.cpp:154 */
+EVS_API void init_global_vars(void);                     /* cache_manager.cpp:410 (socket server: not built) */
+EVS_API void start_server_threads(void);                 /* cache_manager.cpp:419 (socket server: not built) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,29 @@ def test_plugin_surface_evstore(E, orc, tmp_path):
         _, ly = sm.request_to_emb_storage([int(v) for v in t["requests"][0]])
         assert np.array_equal(ly[3].detach().numpy()[0], tabs[3][t["requests"][0][3]])
         sm.close_any_db_conn()
+
+
+@pytest.mark.parametrize("prec", [8, 32])
+def test_reference_cabi_ev_lookup(E, orc, tmp_path, prec):
+    """ev_lookup / get_ev_values / print_perfect_hit through ctypes, as cpp_socket_client.py binds them."""
+    import json
+    import os
+    import subprocess
+    import sys
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    sub = {32: "ev-table", 16: "ev-table-16", 8: "ev-table-8", 4: "ev-table-4"}[prec]
+    (tmp_path / sub / "binary").mkdir(parents=True)
+    for k, w in enumerate(tabs):
+        orc.encode_table(np.clip(w * 8, -1, 1), prec).tofile(tmp_path / sub / "binary" / ("ev-table-%d.bin" % (k + 1)))
+    np.save(tmp_path / "reqs.npy", t["requests"][:250])
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ev_lookup_child.py")
+    out = subprocess.run([sys.executable, child, str(tmp_path), str(prec), "100"], capture_output=True, text=True,
+                         timeout=300)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(line[0][7:])
+    assert r["ok"] and r["same_buf"] and r["rc_dead"] == -1
+    # ev_lookup was called once more after the loop (same_buf probe): counter >= the oracle's count
+    assert r["perfect_oracle"] <= r["counter"] <= r["perfect_oracle"] + 1 and r["after_print"] == 0
+    assert "Perfect hit" in out.stdout
