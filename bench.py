@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--dim", type=int, default=36)
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--placement", default="rows+replicate", choices=["count", "rows", "rows+replicate"],
+                    help="table placement for --gpus > 1 (sharded.plan_placement)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one process")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -114,9 +117,11 @@ def main():
     import evstore_dlrm_amd as E
     E._lib.lib()  # fail loudly if the HIP library is missing
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from evstore_dlrm_amd import sharded
         result = sharded.bench_sharded(args, KAGGLE_LN, rank, world, dev)
         if rank == 0:

@@ -408,6 +408,176 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
     for (int b = lane; b < kMaxBuckets; b += 64) { gs->head[b] = h.head[b]; gs->tail[b] = h.tail[b]; gs->len[b] = h.len[b]; }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// a9: two-tier request, C1 (main precision) + C2 (secondary precision)
+// mixed_precs_caching/evlfu_8.cpp:669-796 request_to_c1_c2 with evlfu_4.cpp phase_1 / phase_2
+// as the C2 half.  One wavefront, requests in order; both tiers use the exact EvLFU machinery
+// above.  Eviction victims are FIFO-oldest (the C++ takes unordered_set::begin()); a C1 hit whose
+// entry was evicted earlier in the same request is served from storage (the C++ dereferences a
+// dangling pointer there, evlfu_8.cpp:521-522).
+// ------------------------------------------------------------------------------------------
+struct TierArgs {
+    CacheState *st;
+    CacheArrays a;
+    const unsigned char *backing[kMaxTables];
+    long long backing_rows[kMaxTables];
+};
+struct C1C2Args {
+    TierArgs t1, t2;
+    const int *requests;
+    float *out;
+    unsigned char *tier_out;  // (B,T): 1 = C1 hit, 2 = served by a C2 hit, 0 = miss
+    long long B;
+    int threshold;            // high_agghit_threshold (evlfu_8.hpp:70)
+};
+
+__device__ void hot_load(Hot &h, const CacheState &cs, int lane) {
+    if (lane == 0) {
+        h.min_c1 = cs.min_c1; h.n_perfect = cs.n_perfect; h.count = cs.count; h.n_free = cs.n_free;
+        h.n_flush = cs.n_flush; h.n_evict = cs.n_evict; h.least_freq = cs.least_freq; h.error = cs.error;
+    }
+    for (int b = lane; b < kMaxBuckets; b += 64) { h.head[b] = cs.head[b]; h.tail[b] = cs.tail[b]; h.len[b] = cs.len[b]; }
+}
+__device__ void hot_store(const Hot &h, CacheState *gs, int lane) {
+    if (lane == 0) {
+        gs->min_c1 = h.min_c1; gs->n_perfect = h.n_perfect; gs->count = h.count; gs->n_free = h.n_free;
+        gs->n_flush = h.n_flush; gs->n_evict = h.n_evict; gs->least_freq = h.least_freq; gs->error = h.error;
+    }
+    for (int b = lane; b < kMaxBuckets; b += 64) { gs->head[b] = h.head[b]; gs->tail[b] = h.tail[b]; gs->len[b] = h.len[b]; }
+}
+__device__ __forceinline__ void touch(const CacheArrays &a, Hot &h, int e, int agg) {  // update_agg_hit
+    const int old = ld(&a.eagg[e]);
+    if (old < agg) {
+        list_unlink(a, bucket(h, old), e);
+        list_append(a, bucket(h, agg), e);
+        st(&a.eagg[e], agg);
+    }
+}
+
+__global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
+    __shared__ Hot h1, h2;
+    // per key: which tier's row to output (1/2), from its arena entry (>=0) or its backing store (-1);
+    // and the entry to fill afterwards per tier
+    __shared__ int s_tier[kMaxTables], s_src[kMaxTables], s_fill1[kMaxTables], s_fill2[kMaxTables];
+    const int lane = threadIdx.x;
+    const CacheState cs1 = *args.t1.st, cs2 = *args.t2.st;
+    const CacheArrays a1 = args.t1.a, a2 = args.t2.a;
+    const unsigned long long m1 = cs1.nslot_mask, m2 = cs2.nslot_mask;
+    const int T = cs1.n_tables, d = cs1.dim;
+    hot_load(h1, cs1, lane);
+    hot_load(h2, cs2, lane);
+    __syncthreads();
+    long long n_perfect_req = 0, n_hits = 0;
+
+    for (long long rq = 0; rq < args.B; rq++) {
+        const int row = lane < T ? args.requests[rq * T + lane] : 0;
+        const unsigned long long key = ((unsigned long long)(lane + 1) << 32) | (unsigned)row;
+        const bool ok = lane < T && row >= 0 && row < args.t1.backing_rows[lane < T ? lane : 0] &&
+                        row < args.t2.backing_rows[lane < T ? lane : 0];
+        const int e2 = ok ? map_find(a2, m2, key) : -1;  // evlfu_4.cpp phase_1_find_keys_in_cache
+        const int e1 = ok ? map_find(a1, m1, key) : -1;
+        const unsigned long long okm = __ballot(ok);
+        const unsigned long long hit2 = __ballot(e2 >= 0), hit1 = __ballot(e1 >= 0);
+        int agg = __popcll(hit2) + __popcll(hit1 & ~hit2);  // c1_c2_agg_hit (evlfu_8.cpp:688-703)
+        unsigned long long upd2 = ~hit1 & hit2 & okm;        // C1 miss, C2 hit: C2 serves and updates
+        unsigned long long ins2 = ~hit1 & ~hit2 & okm;       // double miss: C2 inserts (Cond 259) ...
+        unsigned long long job1 = 0;
+        bool update_c2 = true;
+        if (h1.count >= cs1.cap) {                           // :721-738 C1 full
+            if (agg < args.threshold) {                      // ... unless C1 takes the odd ones
+                const unsigned long long odd = 0xAAAAAAAAAAAAAAAAull;
+                job1 = ~hit2 & odd & okm;
+                ins2 &= ~odd;
+            }
+        } else {                                             // :739-751 C1 not full: all C1 misses go to C1
+            job1 = ~hit1 & okm;
+            update_c2 = false;
+            agg = __popcll(hit1);
+        }
+        if (lane < T) {
+            s_tier[lane] = 0; s_src[lane] = -1; s_fill1[lane] = -1; s_fill2[lane] = -1;
+            args.tier_out[rq * T + lane] = (hit1 >> lane) & 1 ? 1 : ((hit2 >> lane) & 1 ? 2 : 0);
+        }
+        __syncthreads();
+        for (int i = 0; i < T; i++) {  // C2 first (phase 2), updates before inserts (evlfu_4.cpp:374-400)
+            const int e2i = __shfl(e2, i);
+            if (lane == 0 && update_c2 && ((upd2 >> i) & 1)) {
+                touch(a2, h2, e2i, agg);
+                s_tier[i] = 2; s_src[i] = e2i;
+            }
+        }
+        for (int i = 0; i < T; i++) {
+            const unsigned long long ki = __shfl(key, i);
+            if (lane == 0 && update_c2 && ((ins2 >> i) & 1)) {
+                s_fill2[i] = evlfu_set(cs2, a2, h2, m2, ki, agg);
+                s_tier[i] = 2; s_src[i] = -1;
+            }
+        }
+        if (lane == 0 && update_c2 && agg == T) h2.n_perfect = h2.len[T];
+        for (int i = 0; i < T; i++) {  // C1 loop (evlfu_8.cpp:769-785)
+            const int e1i = __shfl(e1, i);
+            const unsigned long long ki = __shfl(key, i);
+            if (lane == 0) {
+                if ((hit1 >> i) & 1) {
+                    s_tier[i] = 1;
+                    if (ld(&a1.ekey[e1i]) == ki) { touch(a1, h1, e1i, agg); s_src[i] = e1i; }
+                    else s_src[i] = -1;  // evicted earlier in this request
+                } else if ((job1 >> i) & 1) {
+                    if ((ok ? 1 : 1) && !((hit1 >> i) & 1)) {
+                        s_fill1[i] = evlfu_set(cs1, a1, h1, m1, ki, agg);
+                        s_tier[i] = 1; s_src[i] = -1;
+                    }
+                }
+            }
+        }
+        if (lane == 0 && agg == T) h1.n_perfect = h1.len[T];
+        n_perfect_req += (agg == T);
+        n_hits += __popcll((hit1 | hit2) & okm);
+        __syncthreads();
+
+        float *out = args.out + rq * (long long)T * d;
+        for (int i = 0; i < T; i++) {
+            const int tier = s_tier[i], src = s_src[i];
+            const int rrow = args.requests[rq * T + i];
+            const unsigned char *rowp = nullptr;
+            int codec = cs1.codec;
+            if (tier == 1) rowp = src >= 0 ? a1.arena + (long long)src * cs1.row_bytes
+                                           : args.t1.backing[i] + (long long)rrow * cs1.row_bytes;
+            else if (tier == 2) {
+                codec = cs2.codec;
+                rowp = src >= 0 ? a2.arena + (long long)src * cs2.row_bytes
+                                : args.t2.backing[i] + (long long)rrow * cs2.row_bytes;
+            }
+            for (int c = lane; c < d; c += 64) out[i * d + c] = rowp ? decode_elem(rowp, codec, c) : 0.f;
+        }
+        __syncthreads();
+        for (int i = 0; i < T; i++) {
+            const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)args.requests[rq * T + i];
+            const int f1 = s_fill1[i], f2 = s_fill2[i];
+            if (f1 >= 0 && ld(&a1.ekey[f1]) == ki) {
+                const unsigned char *rowp = args.t1.backing[i] + (long long)args.requests[rq * T + i] * cs1.row_bytes;
+                unsigned char *dst = a1.arena + (long long)f1 * cs1.row_bytes;
+                for (int c = lane; c < cs1.row_bytes; c += 64) dst[c] = rowp[c];
+            }
+            if (f2 >= 0 && ld(&a2.ekey[f2]) == ki) {
+                const unsigned char *rowp = args.t2.backing[i] + (long long)args.requests[rq * T + i] * cs2.row_bytes;
+                unsigned char *dst = a2.arena + (long long)f2 * cs2.row_bytes;
+                for (int c = lane; c < cs2.row_bytes; c += 64) dst[c] = rowp[c];
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    hot_store(h1, args.t1.st, lane);
+    hot_store(h2, args.t2.st, lane);
+    if (lane == 0) {
+        args.t1.st->n_requests = cs1.n_requests + args.B;
+        args.t1.st->n_perfect_hits = cs1.n_perfect_hits + n_perfect_req;
+        args.t1.st->n_hits = cs1.n_hits + n_hits;
+    }
+}
+
 }  // namespace evs
 
 // ------------------------------------------------------------------------------------------
@@ -585,4 +755,27 @@ extern "C" int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_tr
         for (int b = 0; b <= c->host.n_tables; b++) walk(h.head[b], b);
     }
     return n;
+}
+
+extern "C" int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
+                                      uint8_t *tier, int high_agghit_threshold, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(c1 && c2, "evs_cache_request_c1c2: NULL cache");
+    EVS_REQUIRE(c1->host.policy == kEvLFU && c2->host.policy == kEvLFU, "evs_cache_request_c1c2: both tiers must be EvLFU");
+    EVS_REQUIRE(c1->host.n_tables == c2->host.n_tables && c1->host.dim == c2->host.dim,
+                "evs_cache_request_c1c2: the tiers disagree on n_tables/dim");
+    if (!c1->has_backing || !c2->has_backing) { set_error("evs_cache_request_c1c2: set the backing tables of both tiers first"); return EVS_ESTATE; }
+    if (B == 0) return EVS_OK;
+    EVS_REQUIRE(B > 0 && rows && out && tier, "evs_cache_request_c1c2: NULL argument");
+    C1C2Args args;
+    evs_cache *cs[2] = {c1, c2};
+    TierArgs *ts[2] = {&args.t1, &args.t2};
+    for (int t = 0; t < 2; t++) {
+        ts[t]->st = cs[t]->st; ts[t]->a = cs[t]->a;
+        for (int k = 0; k < kMaxTables; k++) { ts[t]->backing[k] = cs[t]->backing[k]; ts[t]->backing_rows[k] = cs[t]->backing_rows[k]; }
+    }
+    args.requests = rows; args.out = out; args.tier_out = tier; args.B = B; args.threshold = high_agghit_threshold;
+    hipLaunchKernelGGL(cache_c1c2_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), args);
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
 }

@@ -78,3 +78,17 @@ class GpuCache:
         out = np.zeros((max(n, 1), 3), np.int64)
         _lib.lib().evs_cache_dump(self._h, out.ctypes.data, n, st)
         return out[:n]
+
+
+def request_c1c2(c1, c2, rows, threshold=23, out=None, tier=None):
+    """Two-tier request (mixed_precs_caching/evlfu_8.cpp:669-796): c1 = main-precision GpuCache, c2 =
+    secondary-precision GpuCache (both variant="cpp").  Returns (tier (B,T) uint8, out (B,T,dim) fp32)."""
+    assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
+    B = int(rows.shape[0])
+    if out is None:
+        out = torch.empty((B, c1.n_tables, c1.dim), dtype=torch.float32, device=c1.device)
+    if tier is None:
+        tier = torch.empty((B, c1.n_tables), dtype=torch.uint8, device=c1.device)
+    _lib.check(_lib.lib().evs_cache_request_c1c2(c1._h, c2._h, B, rows.data_ptr(), out.data_ptr(), tier.data_ptr(),
+                                                 int(threshold), torch.cuda.current_stream(c1.device).cuda_stream))
+    return tier, out

@@ -188,6 +188,16 @@ EVS_API int evs_cache_set_backing(evs_cache *c, const void *const *tables, const
  * approx_thres > 0: EvLFU approximate mode (EvLFU_C1.py:122-125,:142-152). */
 EVS_API int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
                               int approx_thres, void *stream);
+/* a9: two-tier request, mixed_precs_caching/evlfu_8.cpp:669-796 (request_to_c1_c2): C1 = main
+ * precision tier, C2 = secondary precision tier, both EvLFU caches created with the
+ * mixed_precs_caching constants (0.3, 0.95, 0, 2), each with its own backing tables in its own
+ * codec.  tier (device, (B,n_tables) bytes): 1 = C1 hit, 2 = C2 hit, 0 = miss.  When C1 is full and
+ * the combined agg_hit < high_agghit_threshold (23, evlfu_8.hpp:70) double misses with odd table
+ * index go to C1, even ones to C2; at or above the threshold all go to C2; while C1 is not full
+ * every C1 miss goes to C1 and C2 is left untouched.  Victims are FIFO-oldest (the C++ evicts in
+ * unordered_set order); perfect requests are counted in c1's n_perfect_hits. */
+EVS_API int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
+                                   uint8_t *tier, int high_agghit_threshold, void *stream);
 /* out8 (host): [min_C1, n_perfect, size, n_flush, n_evict, n_requests, n_perfect_hits, n_hits].
  * Synchronises the stream.  Returns EVS_ESTATE if the policy hit an inconsistency. */
 EVS_API int evs_cache_stats(evs_cache *c, int64_t *out8, void *stream);

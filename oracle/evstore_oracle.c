@@ -648,3 +648,100 @@ int64_t orc_lfu_dump(const orc_lfu *c, int64_t *out, int64_t max_triples) {
         }
     return n;
 }
+
+/* ------------------------------------------------------------------------ */
+/* a9: two-tier request, C1 (main precision) + C2 (secondary precision)      */
+/* mixed_precs_caching/evlfu_8.cpp:669-796 request_to_c1_c2, with            */
+/* evlfu_4.cpp:374-425 phase_1 / phase_2 as the C2 half.                     */
+/* Both tiers are orc_evlfu objects built with the "cpp" constants; their     */
+/* tables hold the rows already decoded at that tier's precision.             */
+/* Deviations from the C++ (documented in DESIGN.md): eviction victims are    */
+/* FIFO-oldest (the C++ takes unordered_set::begin(), not reproducible), and  */
+/* a C1 hit whose entry was evicted earlier in the same request is served     */
+/* from storage instead of through the dangling pointer (evlfu_8.cpp:521-522).*/
+/* tier_out[i]: 1 = C1 hit, 2 = C2 hit (served by C2), 0 = miss.              */
+/* returns 1 for a perfect request (all keys in C1 or C2), 0 otherwise.       */
+/* ------------------------------------------------------------------------ */
+static void evlfu_touch(orc_evlfu *c, int32_t e, int agg_hit) { /* update_agg_hit, evlfu_8.cpp:303-321 */
+    if (c->eagg[e] < agg_hit) {
+        list_unlink(&c->lists[c->eagg[e]], c->prev, c->next, e);
+        list_append(&c->lists[agg_hit], c->prev, c->next, e);
+        c->eagg[e] = agg_hit;
+    }
+}
+
+int orc_c1c2_request(orc_evlfu *c1, orc_evlfu *c2, const int32_t *rows, uint8_t *tier_out, float *out,
+                     int high_agghit_threshold) {
+    const int T = c1->n_tables, dim = c1->dim;
+    uint64_t keys[ORC_MAX_TABLES];
+    int hit1[ORC_MAX_TABLES], hit2[ORC_MAX_TABLES], upd2[ORC_MAX_TABLES], ins2[ORC_MAX_TABLES], job1[ORC_MAX_TABLES];
+    int c2_agg = 0, c1_agg = 0, agg;
+    float tmp[256];
+    for (int i = 0; i < T; i++) {
+        keys[i] = ((uint64_t)(i + 1) << 32) | (uint32_t)rows[i];
+        hit2[i] = map_get(&c2->map, keys[i]) >= 0; /* evlfu_4.cpp phase_1_find_keys_in_cache */
+        c2_agg += hit2[i];
+    }
+    agg = c2_agg;
+    for (int i = 0; i < T; i++) { /* evlfu_8.cpp:690-712 */
+        hit1[i] = map_get(&c1->map, keys[i]) >= 0;
+        upd2[i] = 1; ins2[i] = 0; job1[i] = 0;
+        if (hit1[i]) {
+            c1_agg++;
+            upd2[i] = 0;
+            if (!hit2[i]) agg++;
+        } else if (!hit2[i]) {
+            ins2[i] = 1;
+            upd2[i] = 0;
+        }
+    }
+    int should_update_c2 = 1;
+    if (c1->map.count >= c1->cap) { /* :721-738 C1 full: below the threshold C1 takes the odd double-misses */
+        if (agg < high_agghit_threshold)
+            for (int i = 0; i < T; i++)
+                if (!hit2[i]) {
+                    upd2[i] = 0;
+                    if (i % 2 == 1) { job1[i] = 1; ins2[i] = 0; }
+                }
+    } else { /* :739-751 C1 not full: everything C1 misses goes to C1, C2 is left alone */
+        for (int i = 0; i < T; i++) if (!hit1[i]) job1[i] = 1;
+        should_update_c2 = 0;
+        agg = c1_agg;
+    }
+    for (int i = 0; i < T; i++) tier_out[i] = hit1[i] ? 1 : (hit2[i] ? 2 : 0);
+    if (should_update_c2) { /* evlfu_4.cpp phase_2_get_and_insert_missing_values */
+        for (int i = 0; i < T; i++)
+            if (upd2[i]) {
+                int32_t e = map_get(&c2->map, keys[i]);
+                evlfu_touch(c2, e, agg);
+                memcpy(out + (int64_t)i * dim, c2->vals + (int64_t)e * dim, sizeof(float) * (size_t)dim);
+            }
+        for (int i = 0; i < T; i++)
+            if (ins2[i]) {
+                store_fetch(&c2->store, i + 1, rows[i], tmp);
+                int rc = evlfu_set(c2, keys[i], tmp, agg);
+                if (rc) return rc - 30;
+                memcpy(out + (int64_t)i * dim, tmp, sizeof(float) * (size_t)dim);
+            }
+        if (agg == T) c2->n_perfect = c2->lists[T].len;
+    }
+    for (int i = 0; i < T; i++) { /* evlfu_8.cpp:769-785 */
+        float *o = out + (int64_t)i * dim;
+        if (hit1[i]) {
+            int32_t e = map_get(&c1->map, keys[i]);
+            if (e >= 0) {
+                evlfu_touch(c1, e, agg);
+                memcpy(o, c1->vals + (int64_t)e * dim, sizeof(float) * (size_t)dim);
+            } else { /* evicted earlier in this request: the C++ reads a dangling pointer here */
+                store_fetch(&c1->store, i + 1, rows[i], o);
+            }
+        } else if (job1[i]) {
+            store_fetch(&c1->store, i + 1, rows[i], tmp);
+            int rc = evlfu_set(c1, keys[i], tmp, agg);
+            if (rc) return rc - 40;
+            memcpy(o, tmp, sizeof(float) * (size_t)dim);
+        }
+    }
+    if (agg == T) { c1->n_perfect = c1->lists[T].len; return 1; }
+    return 0;
+}

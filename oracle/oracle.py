@@ -55,6 +55,8 @@ def lib():
         L.orc_evlfu_dump.restype = C.c_int64
         L.orc_evlfu_dump.argtypes = [C.c_void_p, _i64p, C.c_int64]
         L.orc_evlfu_state.argtypes = [C.c_void_p, _i64p]
+        L.orc_c1c2_request.restype = C.c_int
+        L.orc_c1c2_request.argtypes = [C.c_void_p, C.c_void_p, _i32p, _u8p, _f32p, C.c_int]
         for p in ("lru", "lfu"):
             getattr(L, "orc_%s_new" % p).restype = C.c_void_p
             getattr(L, "orc_%s_new" % p).argtypes = [C.c_int64, C.c_int, C.c_int]
@@ -275,3 +277,24 @@ def kaggle_tables(n_rows, seed, d=36):
     rs = np.random.RandomState(seed)
     return [rs.uniform(-np.sqrt(1.0 / n), np.sqrt(1.0 / n), size=(n, d)).astype(np.float32)
             for n in n_rows]
+
+
+class C1C2:
+    """Two-tier request (mixed_precs_caching/evlfu_8.cpp:669-796).  tables_c1 / tables_c2: the rows
+    decoded at each tier's precision (fp32 arrays)."""
+
+    def __init__(self, cap_c1, cap_c2, tables_c1, tables_c2, dim=36, threshold=23):
+        self.c1 = EvLFU(cap_c1, tables_c1, dim, "cpp")
+        self.c2 = EvLFU(cap_c2, tables_c2, dim, "cpp")
+        self.T, self.dim, self.threshold = len(tables_c1), dim, threshold
+        self._rows = np.zeros(self.T, np.int32)
+        self._tier = np.zeros(self.T, np.uint8)
+        self._out = np.zeros((self.T, dim), np.float32)
+
+    def request(self, rows):
+        self._rows[:] = rows
+        rc = lib().orc_c1c2_request(self.c1._h, self.c2._h, _p(self._rows, _i32p), _p(self._tier, _u8p),
+                                    _p(self._out, _f32p), self.threshold)
+        if rc < 0:
+            raise RuntimeError("orc_c1c2_request rc=%d" % rc)
+        return self._tier.copy(), self._out, rc

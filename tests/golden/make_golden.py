@@ -336,7 +336,80 @@ def gen_codec_tables():
     print("wrote codec_tables")
 
 
+# --------------------------------------------------------------------------
+# a9: C1/C2 routing of the COMPILED reference cache manager (oracle/_ref/libcachemanager_ref.so,
+# the as-shipped configuration: N_CACHING_LAYER 3, 8-bit C1 + 4-bit C2, TOTAL_SIZE 75425, "48-48-4")
+# --------------------------------------------------------------------------
+C1C2_ROWS = 12000
+C1C2_SEED = 5
+
+
+def c1c2_tables(orc):
+    """Synthetic tables for the two-tier fixture: (raw8, raw4, alt-keys) per table, one RandomState stream."""
+    rs = np.random.RandomState(C1C2_SEED)
+    out = []
+    for k in range(26):
+        w = rs.uniform(-1, 1, size=(C1C2_ROWS, 36)).astype(np.float32)
+        alt = (rs.randint(0, C1C2_ROWS, size=C1C2_ROWS) * 100 + (k + 1)).astype('>u4')
+        out.append((orc.encode_table(w, 8), orc.encode_table(w, 4), alt))
+    return rs, out
+
+
+def gen_c1c2():
+    """Runs in a child process (the reference spawns threads that never join)."""
+    import subprocess
+    code = r"""
+import os, sys, ctypes, tempfile, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import oracle as orc
+import make_golden as G
+root = tempfile.mkdtemp(prefix='evs_c1c2_')
+base = root + '/stored_model/criteo_kaggle_all_mmap/epoch-00/'
+alt = root + '/stored_model/criteo_kaggle_all/alternative-keys/1000n-euclid003-newrank/binary/'
+for d in (base + 'ev-table-8/binary', base + 'ev-table-4/binary', alt):
+    os.makedirs(d)
+rs, tabs = G.c1c2_tables(orc)
+for k, (r8, r4, a) in enumerate(tabs):
+    r8.tofile(base + 'ev-table-8/binary/ev-table-%%d.bin' %% (k + 1))
+    r4.tofile(base + 'ev-table-4/binary/ev-table-%%d.bin' %% (k + 1))
+    a.tofile(alt + 'ev-table-%%d.bin' %% (k + 1))
+os.environ['EVS_REF_ROOT'] = root
+L = ctypes.CDLL(%r)
+L.ev_lookup.argtypes = [ctypes.POINTER(ctypes.c_int)]
+L.ev_lookup.restype = ctypes.POINTER(ctypes.c_float)
+dec8 = [orc.decode(t[0], 8, 36) for t in tabs]
+dec4 = [orc.decode(t[1], 4, 36) for t in tabs]
+N, nreq = G.C1C2_ROWS, 11000
+reqs = np.zeros((nreq, 26), np.int32)
+for i in range(nreq):
+    fresh = (i + rs.randint(0, 2, 26)) %% N
+    back = rs.randint(0, max(1, min(i, N)), 26)
+    reqs[i] = np.where(rs.rand(26) < 0.9, fresh, back)
+    if i > 60 and rs.rand() < 0.25:
+        reqs[i] = reqs[i - 1 - rs.randint(50)]
+        reqs[i] = np.where(rs.rand(26) < 0.08, rs.randint(0, N, 26), reqs[i])
+served = np.zeros((nreq, 26), np.uint8)
+for i in range(nreq):
+    p = L.ev_lookup((ctypes.c_int * 26)(*[int(v) for v in reqs[i]]))
+    out = np.ctypeslib.as_array(p, shape=(26, 36)).copy()
+    for k in range(26):
+        r = reqs[i, k]
+        served[i, k] = 8 if np.array_equal(out[k], dec8[k][r]) else (4 if np.array_equal(out[k], dec4[k][r]) else 0)
+np.savez_compressed(%r, requests=reqs, served_bits=served, n_rows=np.int64(N), seed=np.int64(G.C1C2_SEED),
+                    cap_c1=np.int64((48 * 75425 // 100) * 4), cap_c2=np.int64((48 * 75425 // 100) * 8))
+print('c1c2: served 8bit', int((served == 8).sum()), '4bit', int((served == 4).sum()), 'other', int((served == 0).sum()))
+sys.stdout.flush(); os._exit(0)
+""" % (os.path.dirname(os.path.dirname(HERE)), HERE,
+       os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "libcachemanager_ref.so"),
+       os.path.join(HERE, "c1c2_ref.npz"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800)
+    print([l for l in out.stdout.splitlines() if l.startswith("c1c2")], out.stderr[-500:])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "c1c2":
+        gen_c1c2()
+        return
     D, DP, SM, FR, MFR, EvLFU_C1, LRU, LFU = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "codec":
         gen_codec_tables()
@@ -361,6 +434,7 @@ def main():
     gen_cache_traces(SM, FR, MFR, EvLFU_C1, LRU, LFU)
     gen_encoder_vectors()
     gen_codec_tables()
+    gen_c1c2()
 
 
 if __name__ == "__main__":

@@ -182,3 +182,44 @@ def test_reference_cabi_ev_lookup(E, orc, tmp_path, prec):
     # ev_lookup was called once more after the loop (same_buf probe): counter >= the oracle's count
     assert r["perfect_oracle"] <= r["counter"] <= r["perfect_oracle"] + 1 and r["after_print"] == 0
     assert "Perfect hit" in out.stdout
+
+
+def test_two_tier_c1c2_vs_oracle(E, orc):
+    """a9: request_to_c1_c2 on the GPU == the oracle restatement (itself pinned to the compiled
+    reference in tests/test_oracle_golden.py): serving tier, values, both tiers' final state."""
+    from evstore_dlrm_amd import gpu_cache
+    rs = np.random.RandomState(3)
+    n_rows = [400] * 26
+    ws = [rs.uniform(-1, 1, size=(n, 36)).astype(np.float32) for n in n_rows]
+    raw8 = [orc.encode_table(w, 8) for w in ws]
+    raw4 = [orc.encode_table(w, 4) for w in ws]
+    dec8 = [orc.decode(r, 8, 36) for r in raw8]
+    dec4 = [orc.decode(r, 4, 36) for r in raw4]
+    cap1, cap2 = 600, 1200
+    reqs = np.zeros((900, 26), np.int32)
+    for i in range(len(reqs)):
+        reqs[i] = rs.randint(0, 400, 26)
+        if i > 20 and rs.rand() < 0.4:
+            reqs[i] = reqs[i - 1 - rs.randint(15)]
+            reqs[i] = np.where(rs.rand(26) < 0.07, rs.randint(0, 400, 26), reqs[i])
+    o = orc.C1C2(cap1, cap2, dec8, dec4)
+    want_tier, want_out, perfect = [], [], 0
+    for rq in reqs:
+        t, out, p = o.request(rq)
+        want_tier.append(t.copy()); want_out.append(out.copy()); perfect += p
+    c1 = E.GpuCache("evlfu", cap1, 26, 36, 8, "cpp")
+    c2 = E.GpuCache("evlfu", cap2, 26, 36, 4, "cpp")
+    c1.set_backing([torch.from_numpy(r).cuda() for r in raw8])
+    c2.set_backing([torch.from_numpy(r).cuda() for r in raw4])
+    r = torch.from_numpy(reqs).cuda()
+    tiers, outs = [], []
+    for s in range(0, len(reqs), 111):
+        t, out = gpu_cache.request_c1c2(c1, c2, r[s:s + 111].contiguous())
+        tiers.append(t.cpu().numpy()); outs.append(out.cpu().numpy())
+    tiers, outs = np.concatenate(tiers), np.concatenate(outs)
+    assert np.array_equal(tiers, np.stack(want_tier))
+    assert np.array_equal(outs.view(np.uint32), np.stack(want_out).view(np.uint32))
+    np.testing.assert_array_equal(c1.dump(), o.c1.dump())
+    np.testing.assert_array_equal(c2.dump(), o.c2.dump())
+    assert c1.stats()["n_perfect_hits"] == perfect
+    assert (tiers == 2).sum() > 100 and (tiers == 1).sum() > 100  # both tiers actually serve
