@@ -26,13 +26,12 @@ struct Manager {
     int n_layer = 1, main_prec = 32, secondary_prec = 4, backing_kind = 0;
     long long total_size = 75425;
     std::string proportion = "", root = "";
-    evs_cache *c1 = nullptr;
-    void *tables[kEvTables] = {nullptr};
-    long long rows[kEvTables] = {0};
+    evs_cache *c1 = nullptr, *c2 = nullptr;
+    void *tables[kEvTables] = {nullptr}, *tables2[kEvTables] = {nullptr};
+    long long rows[kEvTables] = {0}, rows2[kEvTables] = {0};
     int *d_rows = nullptr, *h_rows = nullptr;
     float *d_out = nullptr, *h_out = nullptr;
     unsigned char *d_hit = nullptr, *h_hit = nullptr;
-    long long perfect_hit = 0;
     hipStream_t stream = nullptr;
 };
 static Manager g_mgr;
@@ -48,10 +47,10 @@ static const char *precision_dir(int bits) {
     }
 }
 
-static int load_tables(Manager &m) {
-    const long long rb = (long long)kEvDim * m.main_prec / 8;
+static int load_tables(Manager &m, int prec, void **tables, long long *rows) {
+    const long long rb = (long long)kEvDim * prec / 8;
     for (int k = 0; k < kEvTables; k++) {
-        const std::string path = m.root + "/" + precision_dir(m.main_prec) + "ev-table-" + std::to_string(k + 1) + ".bin";
+        const std::string path = m.root + "/" + precision_dir(prec) + "ev-table-" + std::to_string(k + 1) + ".bin";
         FILE *fp = fopen(path.c_str(), "rb");
         if (!fp) {  // evlfu_32.cpp:45-48 exits; the 8/4-bit tiers silently keep NULL and crash later
             set_error("ERROR: Failed to load_ev_tables() when opening %s", path.c_str());
@@ -71,11 +70,11 @@ static int load_tables(Manager &m) {
             if (hipMalloc(&dev, bytes > 0 ? bytes : 16) != hipSuccess) { (void)hipHostFree(host); return EVS_ENOMEM; }
             if (hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return EVS_EHIP;
             (void)hipHostFree(host);
-            m.tables[k] = dev;
+            tables[k] = dev;
         } else {                    // pinned host memory, read by the GPU on a miss
-            m.tables[k] = host;
+            tables[k] = host;
         }
-        m.rows[k] = bytes / rb;
+        rows[k] = bytes / rb;
     }
     return EVS_OK;
 }
@@ -97,19 +96,25 @@ static int ensure_ready() {
             return EVS_ESTATE;
         }
     }
-    if (m.n_layer != 1) {
-        // cache_manager.cpp:213-217 prints and exit(-1)s on an unknown layer count; C1+C2(+aprx) is not built yet
-        set_error("ERROR: cache_manager N_CACHING_LAYER=%d is not built in this round (single tier only)", m.n_layer);
+    if (m.n_layer != 1 && m.n_layer != 2) {
+        // cache_manager.cpp:213-217 prints and exit(-1)s on an unknown layer count; the alt-key tier (3) is not built
+        set_error("ERROR: cache_manager N_CACHING_LAYER=%d is not built in this round (1 or 2 tiers)", m.n_layer);
         return EVS_ESTATE;
+    }
+    if (m.n_layer == 2 && !(m.secondary_prec == 16 || m.secondary_prec == 8 || m.secondary_prec == 4) ) {
+        set_error("ERROR: Secondary precision (%d) is NOT recognized!", m.secondary_prec);  // evlfu_8.cpp:147
+        return EVS_EINVAL;
     }
     if (!(m.main_prec == 32 || m.main_prec == 16 || m.main_prec == 8 || m.main_prec == 4)) {
         set_error("ERROR: MAIN_PRECISION %d", m.main_prec);
         return EVS_EINVAL;
     }
-    int rc = load_tables(m);
+    int rc = load_tables(m, m.main_prec, m.tables, m.rows);
     if (rc) return rc;
-    // sizes are in fp32-row equivalents: cache_manager.cpp:46-53, evlfu_8.cpp:92 (capacity * 4 for 8-bit rows)
-    const long long cap = m.total_size * (32 / m.main_prec);
+    // sizes are in fp32-row equivalents: cache_manager.cpp:46-53, evlfu_8.cpp:86-92 (x4 for 8-bit rows, x8 for 4-bit);
+    // two tiers without a proportion string split TOTAL_SIZE evenly (evlfu_8.cpp:86-88, cache_manager.cpp:36-38)
+    const long long share = m.n_layer == 2 ? m.total_size / 2 : m.total_size;
+    const long long cap = share * (32 / m.main_prec);
     // mixed_precs_caching constants: 0.3 / 0.95, n keys flushed, n_perfect -= n (evlfu_8.hpp:50-51, evlfu_8.cpp:256-270)
     rc = evs_cache_create(&m.c1, 0, cap, kEvTables, kEvDim, m.main_prec, 0.3, 0.95, 0, 2);
     if (rc) return rc;
@@ -117,6 +122,15 @@ static int ensure_ready() {
     for (int k = 0; k < kEvTables; k++) rows64[k] = m.rows[k];
     rc = evs_cache_set_backing(m.c1, m.tables, (const int64_t *)rows64);
     if (rc) return rc;
+    if (m.n_layer == 2) {
+        rc = load_tables(m, m.secondary_prec, m.tables2, m.rows2);
+        if (rc) return rc;
+        rc = evs_cache_create(&m.c2, 0, share * (32 / m.secondary_prec), kEvTables, kEvDim, m.secondary_prec, 0.3, 0.95, 0, 2);
+        if (rc) return rc;
+        for (int k = 0; k < kEvTables; k++) rows64[k] = m.rows2[k];
+        rc = evs_cache_set_backing(m.c2, m.tables2, (const int64_t *)rows64);
+        if (rc) return rc;
+    }
     EVS_HIP_CHECK(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     EVS_HIP_CHECK(hipMalloc(&m.d_rows, kEvTables * 4));
     EVS_HIP_CHECK(hipMalloc(&m.d_out, kEvTables * kEvDim * 4));
@@ -155,32 +169,38 @@ extern "C" float *ev_lookup(int *arr) {
     Manager &m = g_mgr;
     memcpy(m.h_rows, arr, kEvTables * sizeof(int));
     if (hipMemcpyAsync(m.d_rows, m.h_rows, kEvTables * 4, hipMemcpyHostToDevice, m.stream) != hipSuccess) return nullptr;
-    if (evs_cache_request(m.c1, 1, m.d_rows, m.d_out, m.d_hit, -1, m.stream) != EVS_OK) {
+    const int rc = m.c2 ? evs_cache_request_c1c2(m.c1, m.c2, 1, m.d_rows, m.d_out, m.d_hit, 23 /* evlfu_8.hpp:70 */, m.stream)
+                        : evs_cache_request(m.c1, 1, m.d_rows, m.d_out, m.d_hit, -1, m.stream);
+    if (rc != EVS_OK) {
         printf("%s\n", evs_last_error());
         return nullptr;
     }
     (void)hipMemcpyAsync(m.h_out, m.d_out, kEvTables * kEvDim * 4, hipMemcpyDeviceToHost, m.stream);
-    (void)hipMemcpyAsync(m.h_hit, m.d_hit, kEvTables, hipMemcpyDeviceToHost, m.stream);
     if (hipStreamSynchronize(m.stream) != hipSuccess) return nullptr;
     memcpy(g_emb_weights_in_1d_floats, m.h_out, sizeof g_emb_weights_in_1d_floats);
-    bool perfect = true;
-    for (int k = 0; k < kEvTables; k++) perfect &= m.h_hit[k] != 0;
-    m.perfect_hit += perfect ? 1 : 0;  // perfectHit += request_to_ev_lfu(...) (cache_manager.cpp:179)
+    // perfectHit += request_to_*(...) (cache_manager.cpp:179-207): counted on the device (n_perfect_hits)
     return g_emb_weights_in_1d_floats;
 }
 
 extern "C" float *get_ev_values(int *) { return evs::g_emb_weights_in_1d_floats; }  // cache_manager.cpp:257-259
 
+extern "C" long long evs_manager_perfect_hit() {
+    using namespace evs;
+    if (!g_mgr.ready) return 0;
+    int64_t s8[8] = {0};
+    if (evs_cache_stats(g_mgr.c1, s8, g_mgr.stream) != EVS_OK) printf("%s\n", evs_last_error());
+    return s8[6];
+}
+
 extern "C" void print_perfect_hit() {  // cache_manager.cpp:262-290: prints, then resets the counter
     using namespace evs;
     printf("\n[epoll worker] C1_PRECISION    = %d\n", g_mgr.main_prec);
+    if (g_mgr.n_layer == 2) printf("[epoll worker] C2_PRECISION    = %d\n", g_mgr.secondary_prec);
     printf("[epoll worker] TOTAL_SIZE      = %lld\n", g_mgr.total_size);
-    printf("[epoll worker] Perfect hit     = %lld\n", g_mgr.perfect_hit);
+    printf("[epoll worker] Perfect hit     = %lld\n", evs_manager_perfect_hit());
     fflush(stdout);
-    g_mgr.perfect_hit = 0;
+    if (g_mgr.ready) (void)evs_cache_reset_counters(g_mgr.c1, g_mgr.stream);
 }
-
-extern "C" long long evs_manager_perfect_hit() { return evs::g_mgr.perfect_hit; }
 
 extern "C" int ev_lookup_based_on_list_keys(int *) {  // cache_manager.cpp:239-243: dead in the reference
     printf("ERROR: This ev_lookup_based_on_list_keys() is outdated, better to use ev_lookup() instead!\n");

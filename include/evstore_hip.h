@@ -214,8 +214,10 @@ EVS_API int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_tripl
  *   side effect perfect-hit counter += (all 26 hit).  NULL (after printing) on a configuration error
  *   (the reference prints and exit(-1)s).
  * Configuration: the reference's five compile-time knobs (cache_manager.cpp:13-20) at run time.
- *   n_caching_layer 1 (C1 only; 2/3 are not built this round), main_precision 32|16|8|4,
- *   total_size in fp32-row equivalents (capacity = total_size * 32/main_precision entries),
+ *   n_caching_layer 1 (C1) or 2 (C1 + C2 = request_to_c1_c2; 3 = alt-key tier, not built this round),
+ *   main_precision 32|16|8|4, secondary_precision 16|8|4,
+ *   total_size in fp32-row equivalents (one tier: capacity = total_size * 32/main_precision entries;
+ *   two tiers: total_size/2 each, i.e. (total/2)*32/main and (total/2)*32/secondary entries),
  *   ev_table_root = directory holding ev-table/binary, ev-table-16/binary, ev-table-8/binary,
  *   ev-table-4/binary (evlfu_*.hpp EV_TABLE_PATH), backing 0 = tables in HBM, 1 = pinned host.
  *   Without a call, ev_lookup reads EVS_N_CACHING_LAYER, EVS_MAIN_PRECISION, EVS_TOTAL_SIZE,

@@ -8,6 +8,7 @@ import sys
 import numpy as np
 
 root, prec, total = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+layers = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc  # noqa: E402
 from evstore_dlrm_amd.cache_algo import cpp_socket_client as cli  # noqa: E402
@@ -20,15 +21,26 @@ os.environ["EVS_EV_TABLE_ROOT"] = root            # zero-argument path: configur
 os.environ["EVS_MAIN_PRECISION"] = str(prec)
 os.environ["EVS_TOTAL_SIZE"] = str(total)
 os.environ["EVS_BACKING"] = "pinned"
+os.environ["EVS_N_CACHING_LAYER"] = str(layers)
+os.environ["EVS_SECONDARY_PRECISION"] = "4"
 cli.init_ctypes_lib()
 fp32_tabs = [orc.decode(r, prec, 36) for r in raws]
-o = orc.EvLFU(total * (32 // prec), fp32_tabs, variant="cpp")
+if layers == 2:
+    raws4 = [np.fromfile(os.path.join(root, "ev-table-4", "binary", "ev-table-%d.bin" % (k + 1)), np.uint8).reshape(-1, 18)
+             for k in range(26)]
+    o = orc.C1C2((total // 2) * (32 // prec), (total // 2) * 8, fp32_tabs, [orc.decode(r, 4, 36) for r in raws4])
+else:
+    o = orc.EvLFU(total * (32 // prec), fp32_tabs, variant="cpp")
 perfect = 0
 ok = True
 for i, rq in enumerate(reqs):
     ly = cli.request_to_cpp_cache([int(v) for v in rq])
-    hit, vals = o.request(rq)
-    perfect += int(hit.all())
+    if layers == 2:
+        _, vals, p = o.request(rq)
+        perfect += p
+    else:
+        hit, vals = o.request(rq)
+        perfect += int(hit.all())
     got = np.stack([t.numpy()[0] for t in ly])
     if not np.array_equal(got.view(np.uint32), vals.view(np.uint32)):
         ok = False

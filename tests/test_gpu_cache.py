@@ -158,8 +158,8 @@ def test_plugin_surface_evstore(E, orc, tmp_path):
         sm.close_any_db_conn()
 
 
-@pytest.mark.parametrize("prec", [8, 32])
-def test_reference_cabi_ev_lookup(E, orc, tmp_path, prec):
+@pytest.mark.parametrize("prec,layers", [(8, 1), (32, 1), (8, 2)])
+def test_reference_cabi_ev_lookup(E, orc, tmp_path, prec, layers):
     """ev_lookup / get_ev_values / print_perfect_hit through ctypes, as cpp_socket_client.py binds them."""
     import json
     import os
@@ -171,10 +171,14 @@ def test_reference_cabi_ev_lookup(E, orc, tmp_path, prec):
     (tmp_path / sub / "binary").mkdir(parents=True)
     for k, w in enumerate(tabs):
         orc.encode_table(np.clip(w * 8, -1, 1), prec).tofile(tmp_path / sub / "binary" / ("ev-table-%d.bin" % (k + 1)))
+    if layers == 2:
+        (tmp_path / "ev-table-4" / "binary").mkdir(parents=True)
+        for k, w in enumerate(tabs):
+            orc.encode_table(np.clip(w * 8, -1, 1), 4).tofile(tmp_path / "ev-table-4" / "binary" / ("ev-table-%d.bin" % (k + 1)))
     np.save(tmp_path / "reqs.npy", t["requests"][:250])
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ev_lookup_child.py")
-    out = subprocess.run([sys.executable, child, str(tmp_path), str(prec), "100"], capture_output=True, text=True,
-                         timeout=300)
+    out = subprocess.run([sys.executable, child, str(tmp_path), str(prec), "100", str(layers)], capture_output=True,
+                         text=True, timeout=300)
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
     assert line, out.stdout[-2000:] + out.stderr[-2000:]
     r = json.loads(line[0][7:])
