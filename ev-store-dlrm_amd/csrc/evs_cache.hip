@@ -578,6 +578,251 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Batched path (throughput): snapshot semantics.
+//
+// EvLFU is defined request by request; replaying a 16 384-request batch through one wavefront
+// would take milliseconds.  The batched path keeps what the policy is FOR and relaxes what only a
+// sequential machine can give:
+//   * every key of the batch is probed against the table as it was when the batch started
+//     (64 keys per wave step, one lane per key; agg_hit of a request = popcount of its lanes'
+//     ballot) and its row is served at once -- arena row for a hit, backing row for a miss:
+//     values are always exactly the table rows;
+//   * hits raise their entry's priority to max(old, agg_hit) with atomicMax (monotone, like
+//     update_agg_hit); misses are de-duplicated through the hash itself (CAS on the slot) and
+//     inserted with priority = max agg_hit over the requests that missed them;
+//   * room is made by evicting the lowest priorities first (a histogram of the 27 priorities gives
+//     the cut; inside the cut priority the scan order decides, not strict FIFO), and the EvLFU flush
+//     (top priority holding >= 95 % of the capacity -> drop 30 % of it) is applied per batch.
+// Invariants (tests/test_gpu_cache.py): rows exact; no key twice; size <= capacity; the priority
+// histogram matches the entries; priorities never decrease while resident.  The hit rate tracks
+// the sequential oracle's within a few percent on Zipf streams.
+// The priority lists of the exact path are NOT maintained here: a cache object is used either
+// exactly (evs_cache_request) or batched (evs_cache_lookup_batch), never both.
+// ------------------------------------------------------------------------------------------
+constexpr unsigned long long kTomb = ~0ull;
+constexpr int kPending = -2;
+
+struct BatchState {
+    int n_miss, n_new, n_free, count, n_tomb;
+    int cnt[kMaxBuckets];
+    int pstar, rem, ticket, flush_t, ticket_t, do_rebuild, n_assign;
+    long long batch_id, n_hits, n_requests, n_perfect_hits, n_evict, n_flush;
+};
+
+struct BatchArgs {
+    BatchState *bs;
+    CacheArrays a;
+    int *eslot;            // hash slot of each entry
+    int *estamp;           // batch id of the last insert / promotion
+    int *slot_aux;         // pending priority of a slot being inserted
+    unsigned long long *miss_key; int *miss_agg;   // miss list (capacity max_batch * T)
+    int *new_slot;                                 // unique new keys (hash slots)
+    const unsigned char *backing[kMaxTables];
+    long long backing_rows[kMaxTables];
+    const int *requests; float *out; unsigned char *hit;
+    long long B;
+    unsigned long long mask;
+    int cap, T, d, codec, row_bytes, max_perfect, flush_n, nslot;
+};
+
+__device__ __forceinline__ int probe_ro(const CacheArrays &a, unsigned long long mask, unsigned long long key) {
+    unsigned long long i = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long k = a.keys[i];
+        if (k == key) return a.slot_entry[i];
+        if (k == kEmpty) return -1;
+        i = (i + 1) & mask;  // tombstones and other keys: keep walking
+    }
+}
+
+// K1: one 32-lane half-wave per request (T <= 32): probe, agg_hit by ballot, priority bump, miss list, rows.
+__global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const BatchArgs args) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+    const int T = args.T, d = args.d;
+    const long long req = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + half;
+    const bool req_on = req < args.B;
+    const bool key_on = req_on && hl < T;
+    int row = key_on ? args.requests[req * T + hl] : -1;
+    const bool ok = key_on && row >= 0 && row < args.backing_rows[hl < T ? hl : 0];
+    const unsigned long long key = ((unsigned long long)(hl + 1) << 32) | (unsigned)row;
+    int e = ok ? probe_ro(args.a, args.mask, key) : -1;
+    if (e == kPending) e = -1;
+    const unsigned long long hm = __ballot(e >= 0);
+    const unsigned hmask = (unsigned)(half ? (hm >> 32) : hm);
+    const int agg = __popc(hmask);
+    if (e >= 0) {
+        const int old = atomicMax(&args.a.eagg[e], agg);
+        if (old < agg) { atomicSub(&args.bs->cnt[old], 1); atomicAdd(&args.bs->cnt[agg], 1); args.estamp[e] = (int)args.bs->batch_id; }
+    } else if (ok) {
+        const int m = atomicAdd(&args.bs->n_miss, 1);
+        args.miss_key[m] = key; args.miss_agg[m] = agg;
+    }
+    if (key_on) args.hit[req * T + hl] = e >= 0 ? 1 : 0;
+    if (req_on && hl == 0) {
+        atomicAdd((unsigned long long *)&args.bs->n_hits, (unsigned long long)agg);
+        if (agg == T) atomicAdd((unsigned long long *)&args.bs->n_perfect_hits, 1ull);
+    }
+    // rows: source pointer per key, then the half-wave copies row after row
+    const unsigned char *src = nullptr;
+    if (e >= 0) src = args.a.arena + (long long)e * args.row_bytes;
+    else if (ok) src = args.backing[hl] + (long long)row * args.row_bytes;
+    float *out = args.out + req * (long long)T * d;
+    if (args.codec == 32 && (d & 3) == 0) {
+        const int lpr = d >> 2;                 // float4 lanes per row
+        const int rpp = 32 / lpr;               // rows per pass of the half-wave
+        for (int r0 = 0; r0 < T; r0 += rpp) {
+            const int rr = r0 + hl / lpr, piece = hl % lpr;
+            const int srcl = (rr < T ? rr : 0) + 32 * half;
+            const unsigned long long p = __shfl((unsigned long long)src, srcl);
+            if (req_on && hl < rpp * lpr && rr < T) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p) v = reinterpret_cast<const float4 *>(p)[piece];
+                reinterpret_cast<float4 *>(out + rr * d)[piece] = v;
+            }
+        }
+    } else {
+        for (int r = 0; r < T; r++) {
+            const unsigned long long p = __shfl((unsigned long long)src, r + 32 * half);
+            if (!req_on) continue;
+            for (int c = hl; c < d; c += 32)
+                out[r * d + c] = p ? decode_elem(reinterpret_cast<const unsigned char *>(p), args.codec, c) : 0.f;
+        }
+    }
+}
+
+// K2: de-duplicate the misses through the hash (first CAS on an empty slot wins), collect unique new keys.
+__global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs args) {
+    const int n = args.bs->n_miss;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < n; m += gridDim.x * blockDim.x) {
+        const unsigned long long key = args.miss_key[m];
+        const int agg = args.miss_agg[m];
+        unsigned long long i = mix64(key) & args.mask;
+        for (;;) {
+            unsigned long long k = args.a.keys[i];
+            if (k == kEmpty) {
+                const unsigned long long prev = atomicCAS(&args.a.keys[i], kEmpty, key);
+                if (prev == kEmpty) {  // this thread owns the new key
+                    args.a.slot_entry[i] = kPending;
+                    atomicMax(&args.slot_aux[i], agg);
+                    args.new_slot[atomicAdd(&args.bs->n_new, 1)] = (int)i;
+                    break;
+                }
+                k = prev;
+            }
+            if (k == key) { atomicMax(&args.slot_aux[i], agg); break; }  // duplicate miss of this batch
+            i = (i + 1) & args.mask;
+        }
+    }
+}
+
+// K3: one thread decides how many entries must go and where the priority cut is.
+__global__ void cache_batch_plan_kernel(const BatchArgs args) {
+    BatchState *b = args.bs;
+    const int T = args.T;
+    b->pstar = -1; b->rem = 0; b->ticket = 0; b->flush_t = 0; b->ticket_t = 0;
+    int cnt[kMaxBuckets];
+    for (int p = 0; p <= T; p++) cnt[p] = b->cnt[p];
+    if (cnt[T] >= args.max_perfect && b->n_new > 0) {  // EvLFU flush (EvLFU_C1.py:36-44), once per batch
+        b->flush_t = args.flush_n < cnt[T] ? args.flush_n : cnt[T];
+        cnt[T] -= b->flush_t;
+        b->n_flush++;
+    }
+    const int n_new = b->n_new < args.cap ? b->n_new : args.cap;
+    b->n_assign = n_new;
+    int need = n_new - (b->n_free + b->flush_t);
+    const int live = b->count - b->flush_t;
+    if (need > live) need = live;
+    if (need > 0) {
+        int acc = 0;
+        for (int p = 0; p <= T; p++) {
+            if (acc + cnt[p] >= need) { b->pstar = p; b->rem = need - acc; break; }
+            acc += cnt[p];
+        }
+        b->n_evict += need;
+    }
+    b->do_rebuild = (b->n_tomb + (need > 0 ? need : 0) + b->flush_t) > args.nslot / 4;
+}
+
+// K4: evict every entry below the cut, `rem` entries at the cut, `flush_t` entries of the top priority.
+__global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs args) {
+    BatchState *b = args.bs;
+    const int pstar = b->pstar, rem = b->rem, flush_t = b->flush_t, T = args.T;
+    if (pstar < 0 && flush_t == 0) return;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < args.cap; e += gridDim.x * blockDim.x) {
+        if (args.a.ekey[e] == kEmpty) continue;
+        const int p = args.a.eagg[e];
+        bool victim = false;
+        if (p == T && flush_t > 0 && atomicAdd(&b->ticket_t, 1) < flush_t) victim = true;
+        else if (pstar >= 0 && (p < pstar || (p == pstar && atomicAdd(&b->ticket, 1) < rem))) victim = true;
+        if (!victim) continue;
+        args.a.keys[args.eslot[e]] = kTomb;
+        args.a.ekey[e] = kEmpty;
+        atomicSub(&b->cnt[p], 1);
+        args.a.free_stack[atomicAdd(&b->n_free, 1)] = e;
+        atomicSub(&b->count, 1);
+        atomicAdd(&b->n_tomb, 1);
+    }
+}
+
+// K5: give every unique new key an entry and fill its arena row from the backing store.
+__global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs args) {
+    BatchState *b = args.bs;
+    const int n_new = b->n_new, n_assign = b->n_assign;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += gridDim.x * blockDim.x) {
+        const int slot = args.new_slot[i];
+        int e = -1;
+        if (i < n_assign) {
+            const int top = atomicSub(&b->n_free, 1);
+            if (top > 0) e = args.a.free_stack[top - 1]; else atomicAdd(&b->n_free, 1);
+        }
+        const int agg = args.slot_aux[slot];
+        args.slot_aux[slot] = 0;
+        if (e < 0) { args.a.keys[slot] = kTomb; atomicAdd(&b->n_tomb, 1); continue; }  // no room: forget the key
+        const unsigned long long key = args.a.keys[slot];
+        args.a.ekey[e] = key; args.a.eagg[e] = agg; args.eslot[e] = slot; args.estamp[e] = (int)b->batch_id;
+        args.a.slot_entry[slot] = e;
+        atomicAdd(&b->cnt[agg], 1);
+        atomicAdd(&b->count, 1);
+        const int t = (int)(key >> 32) - 1;
+        const unsigned char *srow = args.backing[t] + (long long)(unsigned)(key & 0xffffffffull) * args.row_bytes;
+        unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
+        if ((args.row_bytes & 15) == 0) {
+            for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c);
+        } else {
+            for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c];
+        }
+    }
+}
+
+// K6a/K6b: rebuild the hash without tombstones when they pile up (decided in K3).
+__global__ void __launch_bounds__(256) cache_batch_clear_kernel(const BatchArgs args) {
+    if (!args.bs->do_rebuild) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < args.nslot; i += (long long)gridDim.x * blockDim.x)
+        args.a.keys[i] = kEmpty;
+}
+__global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchArgs args) {
+    if (!args.bs->do_rebuild) return;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < args.cap; e += gridDim.x * blockDim.x) {
+        const unsigned long long key = args.a.ekey[e];
+        if (key == kEmpty) continue;
+        unsigned long long i = mix64(key) & args.mask;
+        for (;;) {
+            if (args.a.keys[i] == kEmpty && atomicCAS(&args.a.keys[i], kEmpty, key) == kEmpty) break;
+            i = (i + 1) & args.mask;
+        }
+        args.a.slot_entry[i] = e;
+        args.eslot[e] = (int)i;
+    }
+}
+__global__ void cache_batch_finish_kernel(const BatchArgs args) {
+    BatchState *b = args.bs;
+    if (b->do_rebuild) b->n_tomb = 0;
+    b->n_miss = 0; b->n_new = 0; b->batch_id++;
+    b->n_requests += args.B;
+}
+
 }  // namespace evs
 
 // ------------------------------------------------------------------------------------------
@@ -591,12 +836,19 @@ struct evs_cache {
     const unsigned char *backing[evs::kMaxTables] = {nullptr};
     long long backing_rows[evs::kMaxTables] = {0};
     bool has_backing = false;
+    // batched path
+    evs::BatchState *bs = nullptr;
+    int *eslot = nullptr, *estamp = nullptr, *slot_aux = nullptr, *miss_agg = nullptr, *new_slot = nullptr;
+    unsigned long long *miss_key = nullptr;
+    long long max_batch = 0;
+    int used = 0;  // 0 fresh, 1 exact path, 2 batched path
 };
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
     void *ptrs[] = {c->st, c->a.keys, c->a.slot_entry, c->a.ekey, c->a.eagg, c->a.efreq, c->a.prev, c->a.next,
-                    c->a.free_stack, c->a.arena, c->a.lfu_head, c->a.lfu_tail, c->a.lfu_len};
+                    c->a.free_stack, c->a.arena, c->a.lfu_head, c->a.lfu_tail, c->a.lfu_len,
+                    c->bs, c->eslot, c->estamp, c->slot_aux, c->miss_agg, c->new_slot, c->miss_key};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -686,6 +938,8 @@ extern "C" int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, f
     args.st = c->st; args.a = c->a;
     for (int k = 0; k < kMaxTables; k++) { args.backing[k] = c->backing[k]; args.backing_rows[k] = c->backing_rows[k]; }
     args.requests = rows; args.out = out; args.hit = hit; args.B = B; args.approx_thres = approx_thres;
+    if (c->used == 2) { set_error("evs_cache_request: this cache is used through the batched path"); return EVS_ESTATE; }
+    c->used = 1;
     hipLaunchKernelGGL(cache_exact_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), args);
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
@@ -778,4 +1032,92 @@ extern "C" int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, c
     hipLaunchKernelGGL(cache_c1c2_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), args);
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
+}
+
+// ---- batched path --------------------------------------------------------------------------
+extern "C" int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
+                                      void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(c, "evs_cache_lookup_batch: NULL cache");
+    EVS_REQUIRE(c->host.policy == kEvLFU, "evs_cache_lookup_batch: EvLFU only");
+    EVS_REQUIRE(c->host.n_tables <= 32, "evs_cache_lookup_batch: at most 32 tables");
+    if (!c->has_backing) { set_error("evs_cache_lookup_batch: call evs_cache_set_backing first"); return EVS_ESTATE; }
+    if (c->used == 1) { set_error("evs_cache_lookup_batch: this cache is used through the exact path"); return EVS_ESTATE; }
+    if (B == 0) return EVS_OK;
+    EVS_REQUIRE(B > 0 && rows && out && hit, "evs_cache_lookup_batch: NULL argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int T = c->host.n_tables;
+    const long long cap = c->host.cap;
+    if (!c->bs) {
+        BatchState h{};
+        h.n_free = (int)cap;
+        EVS_HIP_CHECK(hipMalloc(&c->bs, sizeof(BatchState)));
+        EVS_HIP_CHECK(hipMemcpy(c->bs, &h, sizeof h, hipMemcpyHostToDevice));
+        EVS_HIP_CHECK(hipMalloc(&c->eslot, cap * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->estamp, cap * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->slot_aux, c->nslot * 4));
+        EVS_HIP_CHECK(hipMemset(c->slot_aux, 0, c->nslot * 4));
+    }
+    if (B > c->max_batch) {
+        if (c->miss_key) { EVS_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(c->miss_key); (void)hipFree(c->miss_agg); (void)hipFree(c->new_slot); }
+        EVS_HIP_CHECK(hipMalloc(&c->miss_key, B * T * 8));
+        EVS_HIP_CHECK(hipMalloc(&c->miss_agg, B * T * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->new_slot, B * T * 4));
+        c->max_batch = B;
+    }
+    c->used = 2;
+    BatchArgs a;
+    a.bs = c->bs; a.a = c->a; a.eslot = c->eslot; a.estamp = c->estamp; a.slot_aux = c->slot_aux;
+    a.miss_key = c->miss_key; a.miss_agg = c->miss_agg; a.new_slot = c->new_slot;
+    for (int k = 0; k < kMaxTables; k++) { a.backing[k] = c->backing[k]; a.backing_rows[k] = c->backing_rows[k]; }
+    a.requests = rows; a.out = out; a.hit = hit; a.B = B; a.mask = c->host.nslot_mask;
+    a.cap = (int)cap; a.T = T; a.d = c->host.dim; a.codec = c->host.codec; a.row_bytes = c->host.row_bytes;
+    a.max_perfect = c->host.max_perfect; a.flush_n = c->host.flush_n; a.nslot = (int)c->nslot;
+    const int wide = kNumCu * 8;
+    const long long waves = (B + 1) / 2;
+    hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    long long nb = (B * T + 255) / 256; if (nb > wide) nb = wide;
+    hipLaunchKernelGGL(cache_batch_insert_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_plan_kernel, dim3(1), dim3(1), 0, st, a);
+    long long ne = (cap + 255) / 256; if (ne > wide) ne = wide;
+    hipLaunchKernelGGL(cache_batch_evict_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_assign_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_finish_kernel, dim3(1), dim3(1), 0, st, a);
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
+}
+
+// out8 (host): [size, n_free, n_tomb, n_flush, n_evict, n_requests, n_perfect_hits, n_hits]; hist: n_tables+1 priority counts
+extern "C" int evs_cache_batch_stats(evs_cache *c, int64_t *out8, int64_t *hist, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(c && out8 && c->bs, "evs_cache_batch_stats: the batched path has not been used");
+    BatchState h;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    EVS_HIP_CHECK(hipMemcpyAsync(&h, c->bs, sizeof h, hipMemcpyDeviceToHost, st));
+    EVS_HIP_CHECK(hipStreamSynchronize(st));
+    out8[0] = h.count; out8[1] = h.n_free; out8[2] = h.n_tomb; out8[3] = h.n_flush; out8[4] = h.n_evict;
+    out8[5] = h.n_requests; out8[6] = h.n_perfect_hits; out8[7] = h.n_hits;
+    if (hist) for (int p = 0; p <= c->host.n_tables; p++) hist[p] = h.cnt[p];
+    return EVS_OK;
+}
+
+// resident (priority, table_1based, row) triples, unordered (host); returns the count
+extern "C" int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream) {
+    using namespace evs;
+    if (!c || !c->bs) return EVS_EINVAL;
+    if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return EVS_EHIP;
+    const int64_t cap = c->host.cap;
+    std::vector<unsigned long long> ekey(cap);
+    std::vector<int> eagg(cap);
+    if (hipMemcpy(ekey.data(), c->a.ekey, cap * 8, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+    if (hipMemcpy(eagg.data(), c->a.eagg, cap * 4, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+    int64_t n = 0;
+    for (int64_t e = 0; e < cap; e++) {
+        if (!ekey[e]) continue;
+        if (n < max_triples && triples) { triples[3 * n] = eagg[e]; triples[3 * n + 1] = (int64_t)(ekey[e] >> 32); triples[3 * n + 2] = (int64_t)(ekey[e] & 0xffffffffull); }
+        n++;
+    }
+    return n;
 }

@@ -59,6 +59,37 @@ class GpuCache:
                                                 int(approx_thres), torch.cuda.current_stream(self.device).cuda_stream))
         return hit, out
 
+    def lookup_batch(self, rows, out=None, hit=None):
+        """Batched EvLFU lookup, snapshot semantics (see include/evstore_hip.h: evs_cache_lookup_batch)."""
+        assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
+        B = int(rows.shape[0])
+        if out is None:
+            out = torch.empty((B, self.n_tables, self.dim), dtype=torch.float32, device=self.device)
+        if hit is None:
+            hit = torch.empty((B, self.n_tables), dtype=torch.uint8, device=self.device)
+        _lib.check(_lib.lib().evs_cache_lookup_batch(self._h, B, rows.data_ptr(), out.data_ptr(), hit.data_ptr(),
+                                                     torch.cuda.current_stream(self.device).cuda_stream))
+        return hit, out
+
+    def batch_stats(self):
+        s = (C.c_int64 * 8)()
+        hist = (C.c_int64 * (self.n_tables + 1))()
+        _lib.check(_lib.lib().evs_cache_batch_stats(self._h, s, hist, torch.cuda.current_stream(self.device).cuda_stream))
+        keys = ("size", "n_free", "n_tomb", "n_flush", "n_evict", "n_requests", "n_perfect_hits", "n_hits")
+        d = dict(zip(keys, [int(v) for v in s]))
+        d["hist"] = [int(v) for v in hist]
+        return d
+
+    def batch_dump(self):
+        import numpy as np
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        n = _lib.lib().evs_cache_batch_dump(self._h, None, 0, st)
+        if n < 0:
+            _lib.check(int(n))
+        out = np.zeros((max(n, 1), 3), np.int64)
+        _lib.lib().evs_cache_batch_dump(self._h, out.ctypes.data, n, st)
+        return out[:n]
+
     def stats(self):
         s = (C.c_int64 * 8)()
         _lib.check(_lib.lib().evs_cache_stats(self._h, s, torch.cuda.current_stream(self.device).cuda_stream))

@@ -198,6 +198,20 @@ EVS_API int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, floa
  * unordered_set order); perfect requests are counted in c1's n_perfect_hits. */
 EVS_API int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
                                    uint8_t *tier, int high_agghit_threshold, void *stream);
+/* Batched EvLFU lookup with snapshot semantics (the throughput path; no reference counterpart --
+ * the reference is batch-1): all B requests are probed against the cache as it is when the call
+ * starts, rows are served at once (arena for hits, backing for misses: always exactly the table
+ * rows), then priorities are raised (atomicMax to agg_hit), the batch's unique misses are inserted
+ * and the lowest priorities are evicted to make room (+ the EvLFU flush rule per batch).
+ * Same argument layout as evs_cache_request.  A cache object is driven either by
+ * evs_cache_request (exact) or by evs_cache_lookup_batch, never both (EVS_ESTATE). */
+EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
+                                   void *stream);
+/* out8: [size, n_free, n_tombstones, n_flush, n_evict, n_requests, n_perfect_hits, n_hits];
+ * hist (may be NULL): n_tables+1 resident-entry counts per priority. */
+EVS_API int evs_cache_batch_stats(evs_cache *c, int64_t *out8, int64_t *hist, void *stream);
+/* resident (priority, table_1based, row) triples of the batched path, unordered; returns the count. */
+EVS_API int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream);
 /* out8 (host): [min_C1, n_perfect, size, n_flush, n_evict, n_requests, n_perfect_hits, n_hits].
  * Synchronises the stream.  Returns EVS_ESTATE if the policy hit an inconsistency. */
 EVS_API int evs_cache_stats(evs_cache *c, int64_t *out8, void *stream);

@@ -227,3 +227,82 @@ def test_two_tier_c1c2_vs_oracle(E, orc):
     np.testing.assert_array_equal(c2.dump(), o.c2.dump())
     assert c1.stats()["n_perfect_hits"] == perfect
     assert (tiers == 2).sum() > 100 and (tiers == 1).sum() > 100  # both tiers actually serve
+
+
+def _zipf_requests(n_rows, n_req, seed, alpha=1.15):
+    rs = np.random.RandomState(seed)
+    perms = [rs.permutation(n) for n in n_rows]
+    reqs = np.zeros((n_req, len(n_rows)), np.int32)
+    for k, n in enumerate(n_rows):
+        reqs[:, k] = perms[k][np.minimum(rs.zipf(alpha, n_req) - 1, n - 1)]
+    hot = reqs[rs.randint(0, n_req, 64)]
+    rep = rs.rand(n_req) < 0.3
+    reqs[rep] = hot[rs.randint(0, 64, rep.sum())]
+    return reqs
+
+
+@pytest.mark.parametrize("cap_frac,batch", [(0.10, 256), (0.02, 64), (0.5, 1024)])
+def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch):
+    """Batched (snapshot) EvLFU: rows exact, hit flags = residency at batch start, no duplicate keys,
+    size <= capacity, histogram consistent, priorities monotone; hit rate tracks the sequential oracle."""
+    n_rows = [3000, 40, 20000, 700, 5, 9000, 1500, 12, 26000, 300, 8000, 64, 2200, 17000, 3, 450, 5000, 90, 13000,
+              2, 7000, 30, 1000, 11000, 150, 4000]
+    tabs = orc.kaggle_tables(n_rows, 21)
+    cap = int(cap_frac * sum(n_rows))
+    reqs = _zipf_requests(n_rows, 4096, 2)
+    c = E.GpuCache("evlfu", cap, 26, 36, 32, "python")
+    c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
+    r = torch.from_numpy(reqs).cuda()
+    resident = {}
+    hits_total = 0
+    for s in range(0, len(reqs), batch):
+        rq = reqs[s:s + batch]
+        hit, out = c.lookup_batch(r[s:s + batch].contiguous())
+        hit, out = hit.cpu().numpy().astype(bool), out.cpu().numpy()
+        for k in range(26):
+            assert np.array_equal(out[:, k, :], tabs[k][rq[:, k]])
+        want_hit = np.array([[(k + 1, int(rq[b, k])) in resident for k in range(26)] for b in range(len(rq))])
+        assert np.array_equal(hit, want_hit)
+        hits_total += int(hit.sum())
+        d = c.batch_dump()
+        st = c.batch_stats()
+        keys = [(int(t), int(rw)) for _, t, rw in d]
+        assert len(set(keys)) == len(keys) and len(keys) == st["size"] <= cap
+        assert np.array_equal(np.bincount(d[:, 0], minlength=27), np.array(st["hist"]))
+        new_res = {(int(t), int(rw)): int(p) for p, t, rw in d}
+        for key, p in new_res.items():
+            if key in resident:
+                assert p >= resident[key]
+        # every key of the batch that could be kept is resident afterwards when there was room
+        if st["size"] < cap:
+            assert all((k + 1, int(rq[b, k])) in new_res for b in range(len(rq)) for k in range(26))
+        resident = new_res
+    st = c.batch_stats()
+    assert st["n_hits"] == hits_total and st["n_requests"] == len(reqs)
+    o = orc.EvLFU(cap, tabs)
+    seq_hits = sum(int(o.request(rq)[0].sum()) for rq in reqs)
+    rate_b, rate_s = hits_total / reqs.size, seq_hits / reqs.size
+    # the snapshot cannot hit keys first inserted inside the same batch: allow that much plus 5 points
+    first_seen_in_batch = 0
+    seen = set()
+    for s in range(0, len(reqs), batch):
+        local = set()
+        for rq in reqs[s:s + batch]:
+            for k in range(26):
+                key = (k, int(rq[k]))
+                if key in local and key not in seen:
+                    first_seen_in_batch += 1
+                local.add(key)
+        seen |= local
+    assert rate_b >= rate_s - first_seen_in_batch / reqs.size - 0.05, (rate_b, rate_s)
+    assert rate_b <= rate_s + 0.05, (rate_b, rate_s)
+
+
+def test_batched_and_exact_paths_do_not_mix(E, orc):
+    tabs = orc.kaggle_tables([50] * 26, 1)
+    c = E.GpuCache("evlfu", 100, 26, 36, 32)
+    c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
+    rows = torch.zeros((4, 26), dtype=torch.int32, device="cuda")
+    c.lookup_batch(rows)
+    with pytest.raises(E.EvsError):
+        c.request(rows)
