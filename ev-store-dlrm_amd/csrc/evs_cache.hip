@@ -25,6 +25,7 @@
 
 #include <mutex>
 #include <vector>
+#include <stdlib.h>
 
 namespace evs {
 
@@ -619,6 +620,8 @@ struct BatchArgs {
     int *slot_aux;         // pending priority of a slot being inserted
     unsigned long long *miss_key; int *miss_agg;   // miss list (capacity max_batch * T)
     int *new_slot;                                 // unique new keys (hash slots)
+    int *agg_out;                                  // per-request agg_hit
+    long long *row_ptrs;                           // (T,B) address of each key's row (arena / backing / 0)
     const unsigned char *backing[kMaxTables];
     long long backing_rows[kMaxTables];
     const int *requests; float *out; unsigned char *hit;
@@ -637,10 +640,36 @@ __device__ __forceinline__ int probe_ro(const CacheArrays &a, unsigned long long
     }
 }
 
-// K1: one 32-lane half-wave per request (T <= 32): probe, agg_hit by ballot, priority bump, miss list, rows.
+// One atomic per BLOCK instead of one per thread: every thread of the block calls this in uniform
+// control flow; threads with flag set get consecutive indices starting at the value the block
+// reserved from *counter (a 426k-way contended counter would cost milliseconds).
+__device__ __forceinline__ int block_reserve(int *counter, bool flag, int *s_tot /* >= 8 ints of LDS */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s_tot[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < nw; w++) { const int c = s_tot[w]; s_tot[w] = tot; tot += c; }
+        s_tot[nw] = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    return s_tot[nw] + s_tot[wave] + rank;
+}
+
+// K1: one 32-lane half-wave per request (T <= 32): probe, agg_hit by ballot, priority bump, miss record,
+// and the address of every key's row (table-major (T,B) pointer table consumed by the fused
+// interaction kernel in pointer mode, or by cache_rows_from_ptrs_kernel when the rows are wanted).
+// No global counters are touched per key: misses go to the fixed slot (request, table) of the miss
+// arrays, the per-request agg_hit goes to agg_out, priority-histogram moves are folded per block.
 __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const BatchArgs args) {
+    __shared__ int s_delta[kMaxBuckets];
+    for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
-    const int T = args.T, d = args.d;
+    const int T = args.T;
     const long long req = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + half;
     const bool req_on = req < args.B;
     const bool key_on = req_on && hl < T;
@@ -652,78 +681,114 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
     const unsigned long long hm = __ballot(e >= 0);
     const unsigned hmask = (unsigned)(half ? (hm >> 32) : hm);
     const int agg = __popc(hmask);
-    if (e >= 0) {
+    // monotone max like update_agg_hit; the plain read first keeps hot entries (thousands of requests of
+    // one batch hit the same few rows of the tiny tables) from serialising on one atomic address
+    if (e >= 0 && args.a.eagg[e] < agg) {
         const int old = atomicMax(&args.a.eagg[e], agg);
-        if (old < agg) { atomicSub(&args.bs->cnt[old], 1); atomicAdd(&args.bs->cnt[agg], 1); args.estamp[e] = (int)args.bs->batch_id; }
-    } else if (ok) {
-        const int m = atomicAdd(&args.bs->n_miss, 1);
-        args.miss_key[m] = key; args.miss_agg[m] = agg;
+        if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); args.estamp[e] = (int)args.bs->batch_id; }
     }
-    if (key_on) args.hit[req * T + hl] = e >= 0 ? 1 : 0;
-    if (req_on && hl == 0) {
-        atomicAdd((unsigned long long *)&args.bs->n_hits, (unsigned long long)agg);
-        if (agg == T) atomicAdd((unsigned long long *)&args.bs->n_perfect_hits, 1ull);
+    if (key_on) {
+        args.hit[req * T + hl] = e >= 0 ? 1 : 0;
+        args.miss_key[req * T + hl] = (ok && e < 0) ? key : kEmpty;
+        args.miss_agg[req * T + hl] = agg;
     }
-    // rows: source pointer per key, then the half-wave copies row after row
+    if (req_on && hl == 0) args.agg_out[req] = agg;
+    // where the row lives right now: arena for a hit, backing store for a miss, 0 for a bad row id
     const unsigned char *src = nullptr;
     if (e >= 0) src = args.a.arena + (long long)e * args.row_bytes;
     else if (ok) src = args.backing[hl] + (long long)row * args.row_bytes;
-    float *out = args.out + req * (long long)T * d;
-    if (args.codec == 32 && (d & 3) == 0) {
-        const int lpr = d >> 2;                 // float4 lanes per row
-        const int rpp = 32 / lpr;               // rows per pass of the half-wave
-        for (int r0 = 0; r0 < T; r0 += rpp) {
-            const int rr = r0 + hl / lpr, piece = hl % lpr;
-            const int srcl = (rr < T ? rr : 0) + 32 * half;
-            const unsigned long long p = __shfl((unsigned long long)src, srcl);
-            if (req_on && hl < rpp * lpr && rr < T) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p) v = reinterpret_cast<const float4 *>(p)[piece];
-                reinterpret_cast<float4 *>(out + rr * d)[piece] = v;
-            }
+    if (key_on) args.row_ptrs[(long long)hl * args.B + req] = (long long)src;
+    __syncthreads();
+    for (int i = threadIdx.x; i <= T; i += blockDim.x)
+        if (s_delta[i]) atomicAdd(&args.bs->cnt[i], s_delta[i]);
+}
+
+// rows (B,T,d) fp32 from the pointer table (only when the caller wants the pooled rows themselves)
+__global__ void __launch_bounds__(256) cache_rows_from_ptrs_kernel(const long long *row_ptrs, float *out, long long B,
+                                                                   int T, int d, int codec) {
+    if (codec == 32 && (d & 3) == 0) {
+        const int lpr = d >> 2;
+        const long long n = B * T * lpr;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const long long rowi = i / lpr;
+            const int piece = (int)(i - rowi * lpr);
+            const long long b = rowi / T;
+            const int t = (int)(rowi - b * T);
+            const long long p = row_ptrs[(long long)t * B + b];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p) v = reinterpret_cast<const float4 *>(p)[piece];
+            reinterpret_cast<float4 *>(out)[i] = v;
         }
     } else {
-        for (int r = 0; r < T; r++) {
-            const unsigned long long p = __shfl((unsigned long long)src, r + 32 * half);
-            if (!req_on) continue;
-            for (int c = hl; c < d; c += 32)
-                out[r * d + c] = p ? decode_elem(reinterpret_cast<const unsigned char *>(p), args.codec, c) : 0.f;
+        const long long n = B * T * d;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const long long rowi = i / d;
+            const int c = (int)(i - rowi * d);
+            const long long b = rowi / T;
+            const int t = (int)(rowi - b * T);
+            const long long p = row_ptrs[(long long)t * B + b];
+            out[i] = p ? decode_elem(reinterpret_cast<const unsigned char *>(p), codec, c) : 0.f;
         }
     }
+}
+__global__ void iota_kernel(long long *p, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = i;
 }
 
 // K2: de-duplicate the misses through the hash (first CAS on an empty slot wins), collect unique new keys.
 __global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs args) {
-    const int n = args.bs->n_miss;
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < n; m += gridDim.x * blockDim.x) {
-        const unsigned long long key = args.miss_key[m];
-        const int agg = args.miss_agg[m];
-        unsigned long long i = mix64(key) & args.mask;
-        for (;;) {
-            unsigned long long k = args.a.keys[i];
-            if (k == kEmpty) {
-                const unsigned long long prev = atomicCAS(&args.a.keys[i], kEmpty, key);
-                if (prev == kEmpty) {  // this thread owns the new key
-                    args.a.slot_entry[i] = kPending;
-                    atomicMax(&args.slot_aux[i], agg);
-                    args.new_slot[atomicAdd(&args.bs->n_new, 1)] = (int)i;
-                    break;
+    __shared__ int s_tot[8];
+    const long long n = args.B * args.T;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long iters = (n + stride - 1) / stride;
+    for (long long it = 0; it < iters; it++) {
+        const long long m = it * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const unsigned long long key = m < n ? args.miss_key[m] : kEmpty;
+        bool is_new = false;
+        int slot = -1;
+        if (key != kEmpty) {
+            const int agg = args.miss_agg[m];
+            unsigned long long i = mix64(key) & args.mask;
+            for (;;) {
+                unsigned long long k = args.a.keys[i];
+                if (k == kEmpty) {
+                    const unsigned long long prev = atomicCAS(&args.a.keys[i], kEmpty, key);
+                    if (prev == kEmpty) {  // this thread owns the new key
+                        args.a.slot_entry[i] = kPending;
+                        atomicMax(&args.slot_aux[i], agg);
+                        is_new = true; slot = (int)i;
+                        break;
+                    }
+                    k = prev;
                 }
-                k = prev;
+                if (k == key) { atomicMax(&args.slot_aux[i], agg); break; }  // duplicate miss of this batch
+                i = (i + 1) & args.mask;
             }
-            if (k == key) { atomicMax(&args.slot_aux[i], agg); break; }  // duplicate miss of this batch
-            i = (i + 1) & args.mask;
         }
+        const int idx = block_reserve(&args.bs->n_new, is_new, s_tot);
+        if (is_new) args.new_slot[idx] = slot;
     }
 }
 
-// K3: one thread decides how many entries must go and where the priority cut is.
-__global__ void cache_batch_plan_kernel(const BatchArgs args) {
+// K3: one block sums the per-request agg_hit and decides how many entries must go and where the cut is.
+__global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs args) {
+    __shared__ long long s_h[256], s_p[256];
     BatchState *b = args.bs;
     const int T = args.T;
+    long long h = 0, pf = 0;
+    for (long long r = threadIdx.x; r < args.B; r += blockDim.x) { const int a = args.agg_out[r]; h += a; pf += (a == T); }
+    s_h[threadIdx.x] = h; s_p[threadIdx.x] = pf;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { s_h[threadIdx.x] += s_h[threadIdx.x + w]; s_p[threadIdx.x] += s_p[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    __shared__ int cnt[kMaxBuckets];
+    if ((int)threadIdx.x <= T) cnt[threadIdx.x] = b->cnt[threadIdx.x];  // one parallel fetch, not T serial ones
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    b->n_hits += s_h[0]; b->n_perfect_hits += s_p[0];
     b->pstar = -1; b->rem = 0; b->ticket = 0; b->flush_t = 0; b->ticket_t = 0;
-    int cnt[kMaxBuckets];
-    for (int p = 0; p <= T; p++) cnt[p] = b->cnt[p];
     if (cnt[T] >= args.max_perfect && b->n_new > 0) {  // EvLFU flush (EvLFU_C1.py:36-44), once per batch
         b->flush_t = args.flush_n < cnt[T] ? args.flush_n : cnt[T];
         cnt[T] -= b->flush_t;
@@ -747,44 +812,64 @@ __global__ void cache_batch_plan_kernel(const BatchArgs args) {
 
 // K4: evict every entry below the cut, `rem` entries at the cut, `flush_t` entries of the top priority.
 __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs args) {
+    __shared__ int s_tot[8];
+    __shared__ int s_delta[kMaxBuckets];
     BatchState *b = args.bs;
     const int pstar = b->pstar, rem = b->rem, flush_t = b->flush_t, T = args.T;
-    if (pstar < 0 && flush_t == 0) return;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < args.cap; e += gridDim.x * blockDim.x) {
-        if (args.a.ekey[e] == kEmpty) continue;
-        const int p = args.a.eagg[e];
+    if (pstar < 0 && flush_t == 0) return;  // uniform: read before any thread changes it (nothing in this kernel does)
+    for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
+    __syncthreads();
+    const int stride = gridDim.x * blockDim.x;
+    const int iters = (args.cap + stride - 1) / stride;
+    for (int it = 0; it < iters; it++) {
+        const int e = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = e < args.cap && args.a.ekey[e] != kEmpty;
+        const int p = live ? args.a.eagg[e] : -1;
         bool victim = false;
-        if (p == T && flush_t > 0 && atomicAdd(&b->ticket_t, 1) < flush_t) victim = true;
-        else if (pstar >= 0 && (p < pstar || (p == pstar && atomicAdd(&b->ticket, 1) < rem))) victim = true;
-        if (!victim) continue;
-        args.a.keys[args.eslot[e]] = kTomb;
-        args.a.ekey[e] = kEmpty;
-        atomicSub(&b->cnt[p], 1);
-        args.a.free_stack[atomicAdd(&b->n_free, 1)] = e;
-        atomicSub(&b->count, 1);
-        atomicAdd(&b->n_tomb, 1);
+        // tickets are handed out per block: one atomic per block and pass, not one per entry
+        const bool want_t = live && p == T && flush_t > 0;
+        const int tk_t = block_reserve(&b->ticket_t, want_t, s_tot);
+        if (want_t && tk_t < flush_t) victim = true;
+        const bool want_c = live && !victim && pstar >= 0 && p == pstar;
+        const int tk_c = block_reserve(&b->ticket, want_c, s_tot);
+        if (want_c && tk_c < rem) victim = true;
+        if (live && !victim && pstar >= 0 && p < pstar) victim = true;
+        const int fi = block_reserve(&b->n_free, victim, s_tot);
+        if (victim) {
+            args.a.keys[args.eslot[e]] = kTomb;
+            args.a.ekey[e] = kEmpty;
+            atomicSub(&s_delta[p], 1);
+            args.a.free_stack[fi] = e;
+        }
     }
+    __syncthreads();
+    int gone = 0;
+    for (int i = threadIdx.x; i <= T; i += blockDim.x)
+        if (s_delta[i]) { atomicAdd(&b->cnt[i], s_delta[i]); gone -= s_delta[i]; }
+    if (gone) { atomicSub(&b->count, gone); atomicAdd(&b->n_tomb, gone); }
 }
 
 // K5: give every unique new key an entry and fill its arena row from the backing store.
+// The free stack holds n_free entries; new key i simply takes free_stack[n_free - 1 - i] (no atomics).
 __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs args) {
+    __shared__ int s_delta[kMaxBuckets];
     BatchState *b = args.bs;
-    const int n_new = b->n_new, n_assign = b->n_assign;
+    for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
+    __syncthreads();
+    const int n_new = b->n_new, n_free = b->n_free;
+    const int n_assign = b->n_assign < n_free ? b->n_assign : n_free;
+    int dropped = 0, added = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += gridDim.x * blockDim.x) {
         const int slot = args.new_slot[i];
-        int e = -1;
-        if (i < n_assign) {
-            const int top = atomicSub(&b->n_free, 1);
-            if (top > 0) e = args.a.free_stack[top - 1]; else atomicAdd(&b->n_free, 1);
-        }
         const int agg = args.slot_aux[slot];
         args.slot_aux[slot] = 0;
-        if (e < 0) { args.a.keys[slot] = kTomb; atomicAdd(&b->n_tomb, 1); continue; }  // no room: forget the key
+        if (i >= n_assign) { args.a.keys[slot] = kTomb; dropped++; continue; }  // no room: forget the key
+        const int e = args.a.free_stack[n_free - 1 - i];
         const unsigned long long key = args.a.keys[slot];
         args.a.ekey[e] = key; args.a.eagg[e] = agg; args.eslot[e] = slot; args.estamp[e] = (int)b->batch_id;
         args.a.slot_entry[slot] = e;
-        atomicAdd(&b->cnt[agg], 1);
-        atomicAdd(&b->count, 1);
+        atomicAdd(&s_delta[agg], 1);
+        added++;
         const int t = (int)(key >> 32) - 1;
         const unsigned char *srow = args.backing[t] + (long long)(unsigned)(key & 0xffffffffull) * args.row_bytes;
         unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
@@ -794,6 +879,11 @@ __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs
             for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c];
         }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= args.T; i += blockDim.x)
+        if (s_delta[i]) atomicAdd(&b->cnt[i], s_delta[i]);
+    if (dropped) atomicAdd(&b->n_tomb, dropped);
+    (void)added;
 }
 
 // K6a/K6b: rebuild the hash without tombstones when they pile up (decided in K3).
@@ -802,8 +892,18 @@ __global__ void __launch_bounds__(256) cache_batch_clear_kernel(const BatchArgs 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < args.nslot; i += (long long)gridDim.x * blockDim.x)
         args.a.keys[i] = kEmpty;
 }
+// ... and the end-of-batch bookkeeping (thread 0 of block 0)
 __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchArgs args) {
-    if (!args.bs->do_rebuild) return;
+    BatchState *b = args.bs;
+    const bool rebuild = b->do_rebuild != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int take = b->n_assign < b->n_free ? b->n_assign : b->n_free;
+        b->n_free -= take; b->count += take;
+        if (rebuild) b->n_tomb = 0;
+        b->n_miss = 0; b->n_new = 0; b->batch_id++;
+        b->n_requests += args.B;
+    }
+    if (!rebuild) return;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < args.cap; e += gridDim.x * blockDim.x) {
         const unsigned long long key = args.a.ekey[e];
         if (key == kEmpty) continue;
@@ -815,12 +915,6 @@ __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchAr
         args.a.slot_entry[i] = e;
         args.eslot[e] = (int)i;
     }
-}
-__global__ void cache_batch_finish_kernel(const BatchArgs args) {
-    BatchState *b = args.bs;
-    if (b->do_rebuild) b->n_tomb = 0;
-    b->n_miss = 0; b->n_new = 0; b->batch_id++;
-    b->n_requests += args.B;
 }
 
 }  // namespace evs
@@ -838,7 +932,8 @@ struct evs_cache {
     bool has_backing = false;
     // batched path
     evs::BatchState *bs = nullptr;
-    int *eslot = nullptr, *estamp = nullptr, *slot_aux = nullptr, *miss_agg = nullptr, *new_slot = nullptr;
+    int *eslot = nullptr, *estamp = nullptr, *slot_aux = nullptr, *miss_agg = nullptr, *new_slot = nullptr, *agg_out = nullptr;
+    long long *row_ptrs = nullptr, *iota = nullptr;
     unsigned long long *miss_key = nullptr;
     long long max_batch = 0;
     int used = 0;  // 0 fresh, 1 exact path, 2 batched path
@@ -848,7 +943,7 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
     void *ptrs[] = {c->st, c->a.keys, c->a.slot_entry, c->a.ekey, c->a.eagg, c->a.efreq, c->a.prev, c->a.next,
                     c->a.free_stack, c->a.arena, c->a.lfu_head, c->a.lfu_tail, c->a.lfu_len,
-                    c->bs, c->eslot, c->estamp, c->slot_aux, c->miss_agg, c->new_slot, c->miss_key};
+                    c->bs, c->eslot, c->estamp, c->slot_aux, c->miss_agg, c->new_slot, c->miss_key, c->agg_out, c->row_ptrs, c->iota};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -1035,8 +1130,8 @@ extern "C" int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, c
 }
 
 // ---- batched path --------------------------------------------------------------------------
-extern "C" int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
-                                      void *stream) {
+static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit, const float *x,
+                            int64_t x_stride, int itself, float *R, void *stream) {
     using namespace evs;
     EVS_REQUIRE(c, "evs_cache_lookup_batch: NULL cache");
     EVS_REQUIRE(c->host.policy == kEvLFU, "evs_cache_lookup_batch: EvLFU only");
@@ -1044,7 +1139,7 @@ extern "C" int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *ro
     if (!c->has_backing) { set_error("evs_cache_lookup_batch: call evs_cache_set_backing first"); return EVS_ESTATE; }
     if (c->used == 1) { set_error("evs_cache_lookup_batch: this cache is used through the exact path"); return EVS_ESTATE; }
     if (B == 0) return EVS_OK;
-    EVS_REQUIRE(B > 0 && rows && out && hit, "evs_cache_lookup_batch: NULL argument");
+    EVS_REQUIRE(B > 0 && B < (1ll << 31) / 32 && rows && hit, "evs_cache_lookup_batch: bad argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int T = c->host.n_tables;
     const long long cap = c->host.cap;
@@ -1059,16 +1154,25 @@ extern "C" int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *ro
         EVS_HIP_CHECK(hipMemset(c->slot_aux, 0, c->nslot * 4));
     }
     if (B > c->max_batch) {
-        if (c->miss_key) { EVS_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(c->miss_key); (void)hipFree(c->miss_agg); (void)hipFree(c->new_slot); }
+        if (c->miss_key) {
+            EVS_HIP_CHECK(hipStreamSynchronize(st));
+            void *old[] = {c->miss_key, c->miss_agg, c->new_slot, c->agg_out, c->row_ptrs, c->iota};
+            for (void *p : old) (void)hipFree(p);
+        }
         EVS_HIP_CHECK(hipMalloc(&c->miss_key, B * T * 8));
         EVS_HIP_CHECK(hipMalloc(&c->miss_agg, B * T * 4));
         EVS_HIP_CHECK(hipMalloc(&c->new_slot, B * T * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->agg_out, B * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->row_ptrs, B * T * 8));
+        EVS_HIP_CHECK(hipMalloc(&c->iota, B * 8));
+        hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(256), 0, st, c->iota, (long long)B);
         c->max_batch = B;
     }
     c->used = 2;
     BatchArgs a;
     a.bs = c->bs; a.a = c->a; a.eslot = c->eslot; a.estamp = c->estamp; a.slot_aux = c->slot_aux;
-    a.miss_key = c->miss_key; a.miss_agg = c->miss_agg; a.new_slot = c->new_slot;
+    a.miss_key = c->miss_key; a.miss_agg = c->miss_agg; a.new_slot = c->new_slot; a.agg_out = c->agg_out;
+    a.row_ptrs = c->row_ptrs;
     for (int k = 0; k < kMaxTables; k++) { a.backing[k] = c->backing[k]; a.backing_rows[k] = c->backing_rows[k]; }
     a.requests = rows; a.out = out; a.hit = hit; a.B = B; a.mask = c->host.nslot_mask;
     a.cap = (int)cap; a.T = T; a.d = c->host.dim; a.codec = c->host.codec; a.row_bytes = c->host.row_bytes;
@@ -1076,17 +1180,44 @@ extern "C" int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *ro
     const int wide = kNumCu * 8;
     const long long waves = (B + 1) / 2;
     hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    // consumers of the snapshot read the rows BEFORE the policy kernels move anything
+    if (out) {
+        long long nb = (B * T * (long long)c->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(cache_rows_from_ptrs_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->row_ptrs, out,
+                           (long long)B, T, c->host.dim, c->host.codec);
+    }
+    if (R) {
+        EVS_REQUIRE(c->host.codec == 32 && evs_fused_dim_supported(c->host.dim) && T + 1 <= EVS_MAX_FEATURES,
+                    "evs_cache_lookup_interact: needs an fp32 cache, a fused-kernel dimension and T <= 31");
+        const int rc = fused_interact_from_row_ptrs(B, T, c->host.dim, x, x_stride, (const int64_t *)c->row_ptrs,
+                                                    (const int64_t *)c->iota, itself, R, st);
+        if (rc) return rc;
+    }
     long long nb = (B * T + 255) / 256; if (nb > wide) nb = wide;
     hipLaunchKernelGGL(cache_batch_insert_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(cache_batch_plan_kernel, dim3(1), dim3(1), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_plan_kernel, dim3(1), dim3(256), 0, st, a);
     long long ne = (cap + 255) / 256; if (ne > wide) ne = wide;
     hipLaunchKernelGGL(cache_batch_evict_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cache_batch_assign_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(cache_batch_finish_kernel, dim3(1), dim3(1), 0, st, a);
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
+}
+
+extern "C" int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
+                                      void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(out || B == 0, "evs_cache_lookup_batch: NULL out");
+    return cache_batch_impl(c, B, rows, out, hit, nullptr, 0, 0, nullptr, stream);
+}
+
+extern "C" int evs_cache_lookup_interact(evs_cache *c, int64_t B, const int32_t *rows, const float *x, int64_t x_stride,
+                                         int itself, float *R, uint8_t *hit, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE((x && R) || B == 0, "evs_cache_lookup_interact: NULL x / R");
+    EVS_REQUIRE(x_stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0, "evs_cache_lookup_interact: x must be 16-byte aligned, stride % 4 == 0");
+    return cache_batch_impl(c, B, rows, nullptr, hit, x, x_stride, itself, R, stream);
 }
 
 // out8 (host): [size, n_free, n_tomb, n_flush, n_evict, n_requests, n_perfect_hits, n_hits]; hist: n_tables+1 priority counts

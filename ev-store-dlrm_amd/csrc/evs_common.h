@@ -86,6 +86,10 @@ __device__ __forceinline__ XcdRange xcd_range(int64_t n_items, int units_per_blo
     return r;
 }
 
+// evs_fused.hip: interaction over x + T features given as absolute fp32 row addresses (cache tier)
+int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_t x_stride, const int64_t *row_ptrs,
+                                 const int64_t *iota, int itself, float *R, hipStream_t st);
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 }  // namespace evs

@@ -75,6 +75,7 @@ struct LaneFeat {
     int nnz;              // API guarantees < 2^31
     unsigned n_rows;      // API guarantees < 2^31
     int off_len;          // readable offsets entries (>= B)
+    int lane_off;         // this lane's k-slot byte offset inside a row (PTRS mode adds it to the row address)
     bool indirect;
 };
 
@@ -95,7 +96,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // k-slot assignment: a row has n_chunks = 4*CQ + REM 16-byte chunks.  Slot q owns chunks
 // [q*CQ, (q+1)*CQ); the REM trailing chunks are fetched by all four slots (same cache line)
 // and slot q uses element q of each.  d=36: CQ=2, REM=1 -> 9 MFMA steps per tile, no padding.
-template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT>
+template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS>
 __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs args) {
     constexpr int NR = NT;        // rows of T per lane: r16 and (NT==2) r16+16
     constexpr int NC = CQ + REM;  // float4 chunks held per lane per row
@@ -119,11 +120,13 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
         lf[rr].scale = 0; lf[rr].nnz = 0; lf[rr].n_rows = 0; lf[rr].indirect = false;
         lf[rr].off_len = (int)B;
         lf[rr].rem_delta = 4 * CQ * 16 - q * CQ * 16;
+        lf[rr].lane_off = 0;
         if (f < F) {
             const int64_t *ip = ka->indices[f];
             lf[rr].indirect = HAS_INDIRECT && ip != nullptr;
             lf[rr].idx = lf[rr].indirect ? ip : args.dummy_i64;
             const int cb = lf[rr].indirect ? kChunkBytes : 16;
+            lf[rr].lane_off = q * CQ * cb;
             lf[rr].src = reinterpret_cast<const char *>(ka->src[f]) + q * CQ * cb;
             lf[rr].rem_delta = 4 * CQ * cb - q * CQ * cb;
             lf[rr].off = lf[rr].indirect ? ka->offsets[f] : args.dummy_i64;
@@ -208,9 +211,10 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
             unsigned mult = (unsigned)b;  // dense: sample number (B < 2^31 is checked on the host)
             bool ok = true;
             if constexpr (HAS_INDIRECT) {
-                const bool in_range = (uint64_t)idx_raw[rr] < (uint64_t)lf[rr].n_rows;
+                // PTRS: the "indices" are absolute row addresses (cache tier: arena or backing row); 0 = no row
+                const bool in_range = PTRS ? idx_raw[rr] != 0 : (uint64_t)idx_raw[rr] < (uint64_t)lf[rr].n_rows;
                 const bool has = len2[rr] > 0;
-                bad |= lf[rr].indirect & has & !in_range;
+                if constexpr (!PTRS) bad |= lf[rr].indirect & has & !in_range;
                 ok = !lf[rr].indirect | (has & in_range);
                 mult = lf[rr].indirect ? (ok ? (unsigned)idx_raw[rr] : 0u) : mult;
                 S.st[rr] = st2[rr];
@@ -219,6 +223,9 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
             S.first[rr] = ok;
             // one v_mad_u64_u32: base + u32*u32
             const char *row = lf[rr].src + (uint64_t)mult * (uint64_t)lf[rr].scale;
+            if constexpr (PTRS) {
+                if (lf[rr].indirect) row = reinterpret_cast<const char *>(idx_raw[rr]) + lf[rr].lane_off;
+            }
             int rem_delta = lf[rr].rem_delta;
             if constexpr (HAS_INDIRECT && CODEC == 32) {  // empty bag / bad index: read zeros
                 row = ok ? row : zeros_l;
@@ -370,7 +377,7 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
     if (bad) atomicOr(args.err, 1);
 }
 
-template <int CODEC, int CQ, int REM, bool WEIGHTED, bool HAS_INDIRECT>
+template <int CODEC, int CQ, int REM, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS>
 static void launch_nt(const FusedArgs &a, hipStream_t st) {
     // persistent grid: exactly the resident waves, each walking its samples through the pipeline
     static int per_cu[2] = {0, 0};
@@ -378,33 +385,61 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
     if (!per_cu[nt]) {
         int n = 0;
         hipError_t e = nt ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                &n, emb_interact_dot_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT>, 256, 0)
+                                &n, emb_interact_dot_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS>, 256, 0)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                &n, emb_interact_dot_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT>, 256, 0);
+                                &n, emb_interact_dot_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS>, 256, 0);
         per_cu[nt] = (e == hipSuccess && n > 0) ? n : 2;
     }
     int64_t blocks = (a.B + 3) / 4;
     const int64_t cap = (int64_t)kNumCu * per_cu[nt];
     if (blocks > cap) blocks = cap;
     if (nt == 0)
-        hipLaunchKernelGGL((emb_interact_dot_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL((emb_interact_dot_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS>), dim3((unsigned)blocks),
                            dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((emb_interact_dot_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL((emb_interact_dot_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS>), dim3((unsigned)blocks),
                            dim3(256), 0, st, a);
 }
 
-template <int CODEC, bool WEIGHTED, bool HAS_INDIRECT>
+template <int CODEC, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS = false>
 static bool launch_cpq(const FusedArgs &a, hipStream_t st) {
     switch (a.d) {
-    case 16: launch_nt<CODEC, 1, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
-    case 32: launch_nt<CODEC, 2, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
-    case 36: launch_nt<CODEC, 2, 1, WEIGHTED, HAS_INDIRECT>(a, st); return true;  // every EVStore script
-    case 48: launch_nt<CODEC, 3, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
-    case 64: launch_nt<CODEC, 4, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
-    case 128: launch_nt<CODEC, 8, 0, WEIGHTED, HAS_INDIRECT>(a, st); return true;
+    case 16: launch_nt<CODEC, 1, 0, WEIGHTED, HAS_INDIRECT, PTRS>(a, st); return true;
+    case 32: launch_nt<CODEC, 2, 0, WEIGHTED, HAS_INDIRECT, PTRS>(a, st); return true;
+    case 36: launch_nt<CODEC, 2, 1, WEIGHTED, HAS_INDIRECT, PTRS>(a, st); return true;  // every EVStore script
+    case 48: launch_nt<CODEC, 3, 0, WEIGHTED, HAS_INDIRECT, PTRS>(a, st); return true;
+    case 64: launch_nt<CODEC, 4, 0, WEIGHTED, HAS_INDIRECT, PTRS>(a, st); return true;
+    case 128: launch_nt<CODEC, 8, 0, WEIGHTED, HAS_INDIRECT, PTRS>(a, st); return true;
     default: return false;
     }
+}
+
+
+
+// Cache-tier consumer (evs_cache.hip): feature 0 = x, feature k+1 = the fp32 row at address
+// row_ptrs[k*B + b] (0 = no row -> zeros).  iota: device int64 array 0..B-1 (bag b = index b).
+int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_t x_stride,
+                                 const int64_t *row_ptrs, const int64_t *iota, int itself, float *R, hipStream_t st) {
+    FusedArgs a;
+    const int F = T + 1;
+    for (int f = 0; f < EVS_MAX_FEATURES; f++) {
+        a.src[f] = nullptr; a.stride[f] = 0; a.indices[f] = nullptr; a.offsets[f] = nullptr; a.nnz[f] = 0;
+        a.n_rows[f] = 0; a.row_w[f] = nullptr; a.off_len[f] = B;
+    }
+    a.zeros = zero_page();
+    a.err = index_error_flag();
+    if (!a.zeros || !a.err) return EVS_EHIP;
+    a.src[0] = x; a.stride[0] = x_stride;
+    for (int k = 0; k < T; k++) {
+        a.src[k + 1] = a.zeros; a.indices[k + 1] = row_ptrs + (int64_t)k * B; a.offsets[k + 1] = iota;
+        a.nnz[k + 1] = B; a.n_rows[k + 1] = 1;
+    }
+    a.R = R; a.B = B; a.F = F; a.d = d; a.itself = itself ? 1 : 0;
+    a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    a.dummy_i64 = iota; a.dummy_f32 = x;
+    if (!launch_cpq<32, false, true, true>(a, st)) { set_error("fused_interact_from_row_ptrs: no kernel for d=%d", d); return EVS_EINVAL; }
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
 }
 
 }  // namespace evs

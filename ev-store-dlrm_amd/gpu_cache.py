@@ -71,6 +71,23 @@ class GpuCache:
                                                      torch.cuda.current_stream(self.device).cuda_stream))
         return hit, out
 
+    def lookup_interact(self, rows, x, itself=False, out=None, hit=None):
+        """R = interact_features(x, cached rows of the B requests): probe + fused MFMA kernel reading the
+        rows through a pointer table (no (B,T,d) intermediate), then the batched policy update."""
+        assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
+        B = int(rows.shape[0])
+        F = self.n_tables + 1
+        P = F * (F + 1) // 2 if itself else F * (F - 1) // 2
+        if out is None:
+            out = torch.empty((B, self.dim + P), dtype=torch.float32, device=self.device)
+        if hit is None:
+            hit = torch.empty((B, self.n_tables), dtype=torch.uint8, device=self.device)
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, self.dim) and x.stride(1) == 1
+        _lib.check(_lib.lib().evs_cache_lookup_interact(
+            self._h, B, rows.data_ptr(), x.data_ptr(), int(x.stride(0)) if B > 1 else self.dim, int(bool(itself)),
+            out.data_ptr(), hit.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
+        return hit, out
+
     def batch_stats(self):
         s = (C.c_int64 * 8)()
         hist = (C.c_int64 * (self.n_tables + 1))()

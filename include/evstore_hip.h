@@ -207,6 +207,12 @@ EVS_API int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, cons
  * evs_cache_request (exact) or by evs_cache_lookup_batch, never both (EVS_ESTATE). */
 EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
                                    void *stream);
+/* The same lookup feeding the interaction directly: R = interact_features(x, [rows of the 26 keys])
+ * (B, d + F(F-1)/2) without materialising the rows -- the probe writes a table of row addresses
+ * (arena row for a hit, backing row for a miss) that the fused MFMA kernel consumes.  fp32 caches,
+ * dimensions supported by evs_fused_dim_supported. */
+EVS_API int evs_cache_lookup_interact(evs_cache *c, int64_t B, const int32_t *rows, const float *x, int64_t x_stride,
+                                      int itself, float *R, uint8_t *hit, void *stream);
 /* out8: [size, n_free, n_tombstones, n_flush, n_evict, n_requests, n_perfect_hits, n_hits];
  * hist (may be NULL): n_tables+1 resident-entry counts per priority. */
 EVS_API int evs_cache_batch_stats(evs_cache *c, int64_t *out8, int64_t *hist, void *stream);

@@ -306,3 +306,23 @@ def test_batched_and_exact_paths_do_not_mix(E, orc):
     c.lookup_batch(rows)
     with pytest.raises(E.EvsError):
         c.request(rows)
+
+
+def test_cache_lookup_interact_equals_rows_then_interact(E, orc):
+    """evs_cache_lookup_interact (pointer-table + fused MFMA kernel) == interact_features over the table rows."""
+    n_rows = [500, 7, 9000, 40, 2500, 3] + [100] * 20
+    tabs = orc.kaggle_tables(n_rows, 5)
+    dev = [torch.from_numpy(t).cuda() for t in tabs]
+    c = E.GpuCache("evlfu", 2000, 26, 36, 32)
+    c.set_backing(dev)
+    reqs = _zipf_requests(n_rows, 900, 4)
+    r = torch.from_numpy(reqs).cuda()
+    ev = E.EVTables(dev, 36, 32)
+    for s in range(0, 900, 300):
+        x = torch.rand(300, 36, device="cuda")
+        hit, R = c.lookup_interact(r[s:s + 300].contiguous(), x)
+        idx = r[s:s + 300].t().contiguous().to(torch.int64)
+        off = torch.arange(300, device="cuda").repeat(26, 1)
+        want = E.apply_emb_interact(x, off, idx, ev)
+        assert torch.equal(R, want)
+    assert c.batch_stats()["n_hits"] > 0
