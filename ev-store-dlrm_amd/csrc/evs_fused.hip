@@ -26,6 +26,8 @@
 //   triangle at R[b][d + i(i-1)/2 + j].
 #include "evs_common.h"
 
+#include <stdlib.h>
+
 namespace evs {
 
 struct FusedArgs {
@@ -377,8 +379,334 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
     if (bad) atomicOr(args.err, 1);
 }
 
+// ------------------------------------------------------------------------------------------
+// fp32 rows through LDS: the same computation, with the row fetch re-shaped for the memory pipe.
+//
+// In the kernel above each MFMA lane fetches ITS pieces of ITS rows: one wave-instruction touches
+// 16 different rows (and the same lines again for the next piece) -- "fragment-shaped" loads that
+// keep the texture addresser busy (SQ_WAIT_INST_ANY ~70 %, PMC in profiles/).  Here whole rows are
+// moved by LDS-DMA (global_load_lds_dwordx4: per-lane SOURCE address, lane-linear 1 KiB LDS
+// destination): d/4 consecutive lanes fetch one row as d*4 contiguous bytes, 64/(d/4) rows per
+// instruction (7 for d=36), every cache line requested exactly once; the MFMA operands then come
+// from LDS with ds_read_b128 (row stride 144 B: the 16 rows of a tile land on distinct banks).
+// Row addresses are computed in the MFMA mapping (lane = row) and handed to the DMA mapping
+// (lane = row piece) with one 64-bit shuffle per instruction.  The rows of sample k+1 are in
+// flight into the wave's LDS slot while the MFMAs and stores of sample k run; the row registers
+// are single-buffered (24 VGPRs instead of 48), so more waves fit per SIMD.
+// ------------------------------------------------------------------------------------------
+template <int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS>
+__global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_kernel(const FusedArgs args) {
+    constexpr int NR = NT;
+    constexpr int NC = CQ + REM;
+    constexpr int d = 4 * (4 * CQ + REM);
+    constexpr int LPRD = d / 4;             // DMA lanes per row (16 B each)
+    constexpr int RPI = 64 / LPRD;          // rows per DMA instruction
+    constexpr int NROWS = 16 * NT;
+    constexpr int NINSTR = (NROWS + RPI - 1) / RPI;
+    constexpr int row_bytes = d * 4;
+    __shared__ __attribute__((aligned(16))) char s_rows[4][NINSTR * 1024];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int F = args.F, itself = args.itself;
+    const int out_row = d + args.P;
+    const int64_t B = args.B;
+
+    const FusedArgs *ka = (const FusedArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    LaneFeat lf[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const int f = r16 + 16 * rr;
+        lf[rr].src = reinterpret_cast<const char *>(args.zeros);
+        lf[rr].idx = args.dummy_i64; lf[rr].off = args.dummy_i64; lf[rr].rw = nullptr;
+        lf[rr].scale = 0; lf[rr].nnz = 0; lf[rr].n_rows = 0; lf[rr].indirect = false;
+        lf[rr].off_len = (int)B; lf[rr].rem_delta = 0; lf[rr].lane_off = 0;
+        if (f < F) {
+            const int64_t *ip = ka->indices[f];
+            lf[rr].indirect = HAS_INDIRECT && ip != nullptr;
+            lf[rr].idx = lf[rr].indirect ? ip : args.dummy_i64;
+            lf[rr].src = reinterpret_cast<const char *>(ka->src[f]);
+            lf[rr].off = lf[rr].indirect ? ka->offsets[f] : args.dummy_i64;
+            if constexpr (WEIGHTED) lf[rr].rw = ka->row_w[f];
+            lf[rr].scale = lf[rr].indirect ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4);
+            lf[rr].nnz = (int)ka->nnz[f];
+            lf[rr].n_rows = (unsigned)ka->n_rows[f];
+            lf[rr].off_len = lf[rr].indirect ? (int)ka->off_len[f] : (int)B;
+        }
+    }
+    const char *zeros_l = reinterpret_cast<const char *>(args.zeros);
+
+    // DMA mapping of this lane: for instruction j it moves piece dma_piece of row j*RPI + lane/LPRD
+    const int dma_piece = lane % LPRD;
+    int dma_src[NINSTR];     // lane that holds the row address in the MFMA mapping, or -1
+#pragma unroll
+    for (int j = 0; j < NINSTR; j++) {
+        const int row = j * RPI + lane / LPRD;
+        dma_src[j] = (lane < RPI * LPRD && row < NROWS) ? (row & 15) + 16 * (row >> 4) : -1;
+    }
+    // LDS byte offset of this lane's operand chunks (row r16 + 16*rr): block + row-in-block + chunk
+    int lds_off[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const int row = r16 + 16 * rr;
+        lds_off[rr] = (row / RPI) * 1024 + (row % RPI) * row_bytes + q * CQ * 16;
+    }
+    constexpr int kRemOff = 4 * CQ * 16;  // from the row start
+
+    constexpr int kOob = 0x7ffffff0;
+    int zo00[4], zo10[4], zo11[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const int i = 4 * q + v;
+        zo00[v] = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : kOob;
+        const int gi = 16 + i;
+        const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+        zo10[v] = (NT == 2 && gi < F) ? 4 * (d + base + r16) : kOob;
+        zo11[v] = (NT == 2 && gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : kOob;
+    }
+
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    char *my_lds = s_rows[wave_in_block];
+    const int64_t waves_total = (int64_t)gridDim.x * 4;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave_in_block;
+    if (wave_id >= B) return;
+    const int n_samples = (int)((B - wave_id + waves_total - 1) / waves_total);
+    bool bad = false;
+
+    int64_t off0[NR], off1[NR];
+    int64_t idx_raw[NR];
+    int st2[NR], len2[NR];
+    int st1[NR], len1[NR];    // bag of the sample whose rows are in LDS / in flight
+    float w1[NR];
+
+    auto sample_b = [&](int n) -> int64_t {
+        const int64_t b = wave_id + (int64_t)n * waves_total;
+        return b < B ? b : B - 1;
+    };
+    auto issue_off = [&](int n) {
+        if constexpr (HAS_INDIRECT) {
+            const int b = (int)sample_b(n);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                off0[rr] = lf[rr].off[b];
+                off1[rr] = lf[rr].off[(b + 1 < lf[rr].off_len) ? b + 1 : b];
+            }
+        }
+    };
+    auto issue_idx = [&](int n) {
+        if constexpr (HAS_INDIRECT) {
+            const int b = (int)sample_b(n);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                const int64_t nnz = (int64_t)lf[rr].nnz;
+                const int64_t s0 = off0[rr];
+                const int64_t e0 = (b + 1 < lf[rr].off_len) ? off1[rr] : nnz;
+                const bool valid = (s0 >= 0) & (e0 >= s0) & (e0 <= nnz);
+                bad |= lf[rr].indirect & !valid;
+                const bool use = lf[rr].indirect & valid;
+                st2[rr] = use ? (int)s0 : 0;
+                len2[rr] = use ? (int)(e0 - s0) : 0;
+                const int64_t *ip = (len2[rr] > 0) ? lf[rr].idx + st2[rr] : args.dummy_i64;
+                idx_raw[rr] = *ip;
+            }
+        }
+    };
+    // row addresses of sample n in the MFMA mapping, then the DMA of all its rows into this wave's LDS slot
+    auto issue_rows = [&](int n) {
+        const int64_t b = sample_b(n);
+        const char *rowp[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            unsigned mult = (unsigned)b;
+            bool ok = true;
+            if constexpr (HAS_INDIRECT) {
+                const bool in_range = PTRS ? idx_raw[rr] != 0 : (uint64_t)idx_raw[rr] < (uint64_t)lf[rr].n_rows;
+                const bool has = len2[rr] > 0;
+                if constexpr (!PTRS) bad |= lf[rr].indirect & has & !in_range;
+                ok = !lf[rr].indirect | (has & in_range);
+                mult = lf[rr].indirect ? (ok ? (unsigned)idx_raw[rr] : 0u) : mult;
+                st1[rr] = st2[rr];
+                len1[rr] = len2[rr];
+            }
+            const char *row = lf[rr].src + (uint64_t)mult * (uint64_t)lf[rr].scale;
+            if constexpr (PTRS) {
+                if (lf[rr].indirect) row = reinterpret_cast<const char *>(idx_raw[rr]);
+            }
+            rowp[rr] = ok ? row : zeros_l;
+            w1[rr] = 1.0f;
+            if constexpr (WEIGHTED) {
+                const bool has_w = lf[rr].indirect && lf[rr].rw;
+                const float *wp = has_w ? lf[rr].rw + mult : args.dummy_f32;
+                const float wv = *wp;
+                w1[rr] = has_w ? wv : 1.0f;
+            }
+        }
+        // lanes of k-slot q publish the address of tile-row set q (rows 16q..16q+15)
+        unsigned long long pub = (unsigned long long)rowp[0];
+        if constexpr (NR == 2) pub = (q == 1) ? (unsigned long long)rowp[1] : pub;
+#pragma unroll
+        for (int j = 0; j < NINSTR; j++) {
+            const unsigned long long p = __shfl(pub, dma_src[j] < 0 ? 0 : dma_src[j]);
+            const char *g = dma_src[j] < 0 ? zeros_l : reinterpret_cast<const char *>(p) + dma_piece * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(my_lds + j * 1024), 16, 0, 0);
+        }
+    };
+
+    const float *x_base = reinterpret_cast<const float *>(args.src[0]);
+    const int64_t x_stride = args.stride[0];
+
+    // ---- prologue ---------------------------------------------------------------------
+    issue_off(0);
+    issue_idx(0);
+    issue_off(1);
+    issue_rows(0);
+    issue_idx(1);
+    issue_off(2);
+
+    for (int k = 0; k < n_samples; k++) {
+        const int64_t b = wave_id + (int64_t)k * waves_total;  // wave-uniform
+        // rows of sample k have landed once every outstanding vector-memory op has retired
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float4 a[NR][NC];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+            for (int c = 0; c < CQ; c++) a[rr][c] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] + c * 16);
+#pragma unroll
+            for (int m = 0; m < REM; m++)
+                a[rr][CQ + m] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] - q * CQ * 16 + kRemOff + m * 16);
+        }
+        int st0[NR], len0[NR];
+        float w0[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) { st0[rr] = HAS_INDIRECT ? st1[rr] : 0; len0[rr] = HAS_INDIRECT ? len1[rr] : 0; w0[rr] = w1[rr]; }
+        // the LDS slot is free again once the reads above have returned
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (k + 1 < n_samples) issue_rows(k + 1);
+        issue_idx(k + 2);
+        issue_off(k + 3);
+
+        float xv[(d + 63) / 64];
+#pragma unroll
+        for (int h = 0; h < (d + 63) / 64; h++) {
+            const int e = lane + 64 * h;
+            xv[h] = x_base[b * x_stride + (e < d ? e : 0)];
+        }
+        if constexpr (WEIGHTED) {
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    a[rr][c].x = __fmul_rn(a[rr][c].x, w0[rr]); a[rr][c].y = __fmul_rn(a[rr][c].y, w0[rr]);
+                    a[rr][c].z = __fmul_rn(a[rr][c].z, w0[rr]); a[rr][c].w = __fmul_rn(a[rr][c].w, w0[rr]);
+                }
+        }
+        if constexpr (HAS_INDIRECT && !PTRS) {
+            bool more = false;
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) more |= len0[rr] > 1;
+            if (__any(more)) {  // bags longer than one index: remaining elements, in index order
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) {
+                    for (int j = 1; j < len0[rr]; j++) {
+                        const int64_t r = lf[rr].idx[st0[rr] + j];
+                        if ((uint64_t)r >= (uint64_t)lf[rr].n_rows) { bad = true; continue; }
+                        const char *row = lf[rr].src + (uint64_t)(unsigned)r * (uint64_t)lf[rr].scale + q * CQ * 16;
+                        float w = 1.0f;
+                        if constexpr (WEIGHTED) { if (lf[rr].rw) w = lf[rr].rw[r]; }
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            float4 t = c < CQ ? reinterpret_cast<const float4 *>(row)[c]
+                                              : reinterpret_cast<const float4 *>(row - q * CQ * 16 + kRemOff)[c - CQ];
+                            if constexpr (WEIGHTED) {
+                                t.x = __fmul_rn(t.x, w); t.y = __fmul_rn(t.y, w);
+                                t.z = __fmul_rn(t.z, w); t.w = __fmul_rn(t.w, w);
+                            }
+                            a[rr][c].x = __fadd_rn(a[rr][c].x, t.x); a[rr][c].y = __fadd_rn(a[rr][c].y, t.y);
+                            a[rr][c].z = __fadd_rn(a[rr][c].z, t.z); a[rr][c].w = __fadd_rn(a[rr][c].w, t.w);
+                        }
+                    }
+                }
+            }
+        }
+
+        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float e0[4] = {a[0][c].x, a[0][c].y, a[0][c].z, a[0][c].w};
+            const float e1[4] = {a[NR - 1][c].x, a[NR - 1][c].y, a[NR - 1][c].z, a[NR - 1][c].w};
+            if (c < CQ) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[e], e0[e], c00, 0, 0, 0);
+                    if constexpr (NT == 2) {
+                        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e0[e], c10, 0, 0, 0);
+                        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e1[e], c11, 0, 0, 0);
+                    }
+                }
+            } else {
+                const float s0 = q == 0 ? e0[0] : q == 1 ? e0[1] : q == 2 ? e0[2] : e0[3];
+                const float s1 = q == 0 ? e1[0] : q == 1 ? e1[1] : q == 2 ? e1[2] : e1[3];
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, s0, c00, 0, 0, 0);
+                if constexpr (NT == 2) {
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s0, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s1, c11, 0, 0, 0);
+                }
+            }
+        }
+        float *Rb = args.R + b * (int64_t)out_row;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, out_row * 4, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < (d + 63) / 64; h++) {
+            const int e = lane + 64 * h;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv[h]), rs, e < d ? 4 * e : kOob, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c00[v]), rs, zo00[v], 0, 0);
+            if constexpr (NT == 2) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c10[v]), rs, zo10[v], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c11[v]), rs, zo11[v], 0, 0);
+            }
+        }
+    }
+    if (bad) atomicOr(args.err, 1);
+}
+
+static bool use_lds_rows() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_LDS"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 template <int CODEC, int CQ, int REM, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS>
 static void launch_nt(const FusedArgs &a, hipStream_t st) {
+    if constexpr (CODEC == 32 && (4 * CQ + REM) <= 32) {
+        if (use_lds_rows()) {
+            static int per_cu_l[2] = {0, 0};
+            const int ntl = a.F <= 16 ? 0 : 1;
+            if (!per_cu_l[ntl]) {
+                int n = 0;
+                hipError_t e = ntl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                                         &n, emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS>, 256, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                                         &n, emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS>, 256, 0);
+                per_cu_l[ntl] = (e == hipSuccess && n > 0) ? n : 2;
+            }
+            int64_t blocks = (a.B + 3) / 4;
+            const int64_t cap = (int64_t)kNumCu * per_cu_l[ntl];
+            if (blocks > cap) blocks = cap;
+            if (ntl == 0)
+                hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS>),
+                                   dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS>),
+                                   dim3((unsigned)blocks), dim3(256), 0, st, a);
+            return;
+        }
+    }
     // persistent grid: exactly the resident waves, each walking its samples through the pipeline
     static int per_cu[2] = {0, 0};
     const int nt = a.F <= 16 ? 0 : 1;
