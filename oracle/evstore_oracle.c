@@ -315,6 +315,7 @@ typedef struct {
                          with n+1 keys flushed (EvLFU_C1_Cython/EvLFU.cpp:80-86); 2 = subtract int(rate*cap), n keys
                          flushed, stop silently at the end of the bucket (evlfu_8.cpp:256-270) */
     int64_t n_flush, n_evict;
+    uint64_t last_evicted; /* key evicted (not flushed) by the latest evlfu_set, 0 if none */
     orc_map map;
     uint64_t *ekey;
     int32_t *eagg, *prev, *next;
@@ -363,6 +364,7 @@ static void evlfu_drop(orc_evlfu *c, int32_t e) { /* vals_C1.pop(key) */
 /* EvLFU_C1.py:32-63 set(key, value, agg_hit) */
 static int evlfu_set(orc_evlfu *c, uint64_t key, const float *value, int agg_hit) {
     int top = c->n_tables;
+    c->last_evicted = 0;
     if (c->n_perfect >= c->max_perfect) { /* :36-44 flush the oldest of bucket 26 */
         int64_t n = (int64_t)(c->flush_rate * c->cap) + c->flush_extra;
         for (int64_t i = 0; i < n; i++) {
@@ -384,6 +386,7 @@ static int evlfu_set(orc_evlfu *c, uint64_t key, const float *value, int agg_hit
         }
         int32_t e = c->lists[c->min_c1].head;
         list_unlink(&c->lists[c->min_c1], c->prev, c->next, e);
+        c->last_evicted = c->ekey[e];
         evlfu_drop(c, e);
         c->n_evict++;
     }
@@ -739,6 +742,212 @@ int orc_c1c2_request(orc_evlfu *c1, orc_evlfu *c2, const int32_t *rows, uint8_t 
             store_fetch(&c1->store, i + 1, rows[i], tmp);
             int rc = evlfu_set(c1, keys[i], tmp, agg);
             if (rc) return rc - 40;
+            memcpy(o, tmp, sizeof(float) * (size_t)dim);
+        }
+    }
+    if (agg == T) { c1->n_perfect = c1->lists[T].len; return 1; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* a12: the alt-key ("approximate embedding") tier, C3                       */
+/* mixed_precs_caching/aprx_embedding.cpp + evlfu_8.cpp:474-490,492-667.     */
+/* DETERMINISTIC RE-SPECIFICATION -- parity UNPINNED: the reference fills    */
+/* this tier from 5 asynchronous threads with no lock against the request    */
+/* thread (aprx_embedding.cpp:90 vs :345) and its batch-insert loops use      */
+/* uninitialised counters (:293,:298,:314,:319), so its observable behaviour  */
+/* depends on thread timing.  Here:                                           */
+/*   * keys EVICTED (not flushed) from C1 / C2 are queued (evlfu_8.cpp:284-287,*/
+/*     :617-620,:654-658); when IO_JOB_Q_SIZE=50 are pending the batch is      */
+/*     inserted at the START of the next request: n_erase = size+50-cap        */
+/*     second-chance evictions, then 50 x (push FIFO, map[key]={alt,false})    */
+/*     (aprx_embedding.cpp:308-324, :360-388);                                 */
+/*   * alt key of (table,row) = the 4-byte big-endian word r of the table's     */
+/*     alt-key file = alt_row*100 + alt_table (:243-251, :344-353);            */
+/*   * on a double miss, if map[key] exists and the alt row is resident in C1   */
+/*     or else C2, that row's vector is served (decoded at the precision of the */
+/*     tier it was found in -- the C++ decodes a 4-bit buffer as 8-bit, an      */
+/*     overread), the key's recency flag is set, the request's agg_hit counts   */
+/*     it as a hit, and neither tier inserts or updates anything for it.        */
+/* ------------------------------------------------------------------------ */
+#define ORC_APRX_BATCH 50
+typedef struct {
+    int64_t cap, count, n_hit;
+    orc_map map;          /* key -> entry */
+    uint64_t *ekey; uint32_t *ealt; uint8_t *eflag; int32_t *free_stack; int64_t n_free;
+    uint64_t *queue; int64_t qcap, qhead, qtail; /* FIFO of keys, may hold stale duplicates */
+    uint64_t pending[ORC_APRX_BATCH]; int n_pending; int batch_ready;
+    const uint32_t *alt_tables[ORC_MAX_TABLES];
+    int error;
+} orc_aprx;
+
+orc_aprx *orc_aprx_new(int64_t cap, const uint32_t *const *alt_tables, int n_tables) {
+    if (cap < ORC_APRX_BATCH) return NULL; /* aprx_embedding.cpp:33 assert(cap_C3 >= IO_JOB_Q_SIZE) */
+    orc_aprx *x = (orc_aprx *)calloc(1, sizeof(orc_aprx));
+    x->cap = cap;
+    map_init(&x->map, cap);
+    x->ekey = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+    x->ealt = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    x->eflag = (uint8_t *)malloc((size_t)cap);
+    x->free_stack = (int32_t *)malloc(sizeof(int32_t) * cap);
+    for (int64_t i = 0; i < cap; i++) x->free_stack[i] = (int32_t)(cap - 1 - i);
+    x->n_free = cap;
+    x->qcap = 4 * cap + 64;
+    x->queue = (uint64_t *)malloc(sizeof(uint64_t) * x->qcap);
+    for (int k = 0; k < n_tables; k++) x->alt_tables[k] = alt_tables[k];
+    return x;
+}
+void orc_aprx_free(orc_aprx *x) {
+    if (!x) return;
+    map_free(&x->map); free(x->ekey); free(x->ealt); free(x->eflag); free(x->free_stack); free(x->queue); free(x);
+}
+static void aprx_evict_one(orc_aprx *x) { /* recency_aware_eviction, aprx_embedding.cpp:360-388 */
+    while (x->qhead < x->qtail) {
+        uint64_t key = x->queue[x->qhead % x->qcap];
+        int32_t e = map_get(&x->map, key);
+        if (e >= 0) {
+            if (x->eflag[e]) { /* second chance */
+                x->eflag[e] = 0;
+                x->queue[x->qtail % x->qcap] = key; x->qtail++;
+                x->qhead++;
+            } else {
+                map_del(&x->map, key);
+                x->free_stack[x->n_free++] = e;
+                x->count--;
+                x->qhead++;
+                return;
+            }
+        } else {
+            x->qhead++; /* stale duplicate */
+        }
+    }
+}
+static void aprx_insert_batch(orc_aprx *x) { /* insert_altkey_batched_obj, aprx_embedding.cpp:308-324 */
+    int64_t n_erase = x->count + ORC_APRX_BATCH - x->cap;
+    for (int64_t i = 0; i < n_erase; i++) aprx_evict_one(x);
+    for (int i = 0; i < ORC_APRX_BATCH; i++) {
+        uint64_t key = x->pending[i];
+        int t = (int)(key >> 32) - 1;
+        uint32_t alt = x->alt_tables[t][(uint32_t)(key & 0xffffffffu)];
+        if (x->qtail - x->qhead >= x->qcap) { x->error = 1; return; }
+        x->queue[x->qtail % x->qcap] = key; x->qtail++;
+        int32_t e = map_get(&x->map, key);
+        if (e < 0) {
+            if (x->n_free <= 0) { x->error = 2; return; }
+            e = x->free_stack[--x->n_free];
+            x->ekey[e] = key;
+            map_put(&x->map, key, e);
+            x->count++;
+        }
+        x->ealt[e] = alt; x->eflag[e] = 0;
+    }
+    x->n_pending = 0; x->batch_ready = 0;
+}
+static void aprx_queue_key(orc_aprx *x, uint64_t key) {
+    if (!key) return;
+    if (x->n_pending < ORC_APRX_BATCH) x->pending[x->n_pending++] = key;
+    /* a 51st key before the batch is inserted cannot happen: the batch is inserted at the next request start
+       and one request evicts at most 2*T <= 128 keys -> keep the first 50, count the overflow as dropped */
+    if (x->n_pending == ORC_APRX_BATCH) x->batch_ready = 1;
+}
+void orc_aprx_state(const orc_aprx *x, int64_t *out4) { out4[0] = x->count; out4[1] = x->n_hit; out4[2] = x->n_pending; out4[3] = x->error; }
+
+/* request_to_c1_c2_c3 (evlfu_8.cpp:492-667).  tier_out: 1 C1 hit, 2 C2 hit, 3 alt-key hit, 0 miss. */
+int orc_c1c2c3_request(orc_evlfu *c1, orc_evlfu *c2, orc_aprx *c3, const int32_t *rows, uint8_t *tier_out, float *out,
+                       int high_agghit_threshold) {
+    const int T = c1->n_tables, dim = c1->dim;
+    uint64_t keys[ORC_MAX_TABLES];
+    int hit1[ORC_MAX_TABLES], hit2[ORC_MAX_TABLES], hit3[ORC_MAX_TABLES], upd2[ORC_MAX_TABLES], ins2[ORC_MAX_TABLES],
+        job1[ORC_MAX_TABLES], alt_tier[ORC_MAX_TABLES];
+    int32_t alt_e[ORC_MAX_TABLES];
+    int c2_agg = 0, c1_agg = 0, agg;
+    float tmp[256];
+    if (c3->batch_ready) aprx_insert_batch(c3);
+    for (int i = 0; i < T; i++) {
+        keys[i] = ((uint64_t)(i + 1) << 32) | (uint32_t)rows[i];
+        hit2[i] = map_get(&c2->map, keys[i]) >= 0;
+        c2_agg += hit2[i];
+    }
+    agg = c2_agg;
+    for (int i = 0; i < T; i++) {
+        hit1[i] = map_get(&c1->map, keys[i]) >= 0;
+        hit3[i] = 0; upd2[i] = 1; ins2[i] = 0; job1[i] = 0; alt_tier[i] = 0; alt_e[i] = -1;
+        if (hit1[i]) {
+            c1_agg++;
+            upd2[i] = 0;
+            if (!hit2[i]) agg++;
+        } else if (!hit2[i]) {
+            upd2[i] = 0;
+            int32_t e3 = map_get(&c3->map, keys[i]); /* find_approximate_ev, evlfu_8.cpp:474-490 */
+            if (e3 >= 0) {
+                uint32_t alt = c3->ealt[e3];
+                uint64_t akey = ((uint64_t)(alt % 100) << 32) | (uint32_t)(alt / 100);
+                int32_t ea = map_get(&c1->map, akey);
+                if (ea >= 0) { alt_tier[i] = 1; alt_e[i] = ea; }
+                else { ea = map_get(&c2->map, akey); if (ea >= 0) { alt_tier[i] = 2; alt_e[i] = ea; } }
+            }
+            if (alt_tier[i]) {
+                hit3[i] = 1;
+                c3->eflag[e3] = 1; /* set_recency_flag_c3 */
+                c3->n_hit++;
+                agg++;
+            } else {
+                ins2[i] = 1;
+            }
+        }
+    }
+    int should_update_c2 = 1;
+    if (c1->map.count >= c1->cap) {
+        if (agg < high_agghit_threshold)
+            for (int i = 0; i < T; i++)
+                if (!hit2[i]) {
+                    upd2[i] = 0;
+                    if (i % 2 == 1) { job1[i] = !(hit1[i] || hit3[i]); ins2[i] = 0; }
+                }
+    } else {
+        for (int i = 0; i < T; i++) if (!(hit1[i] || hit3[i])) job1[i] = 1;
+        should_update_c2 = 0;
+        agg = c1_agg;
+    }
+    for (int i = 0; i < T; i++) tier_out[i] = hit1[i] ? 1 : (hit2[i] ? 2 : (hit3[i] ? 3 : 0));
+    /* alt-key rows are read now: the request's own evictions cannot invalidate what it serves */
+    for (int i = 0; i < T; i++)
+        if (hit3[i]) {
+            const orc_evlfu *src = alt_tier[i] == 1 ? c1 : c2;
+            memcpy(out + (int64_t)i * dim, src->vals + (int64_t)alt_e[i] * dim, sizeof(float) * (size_t)dim);
+        }
+    if (should_update_c2) {
+        for (int i = 0; i < T; i++)
+            if (upd2[i] && hit2[i]) {
+                int32_t e = map_get(&c2->map, keys[i]);
+                evlfu_touch(c2, e, agg);
+                memcpy(out + (int64_t)i * dim, c2->vals + (int64_t)e * dim, sizeof(float) * (size_t)dim);
+            }
+        for (int i = 0; i < T; i++)
+            if (ins2[i]) {
+                store_fetch(&c2->store, i + 1, rows[i], tmp);
+                int rc = evlfu_set(c2, keys[i], tmp, agg);
+                if (rc) return rc - 30;
+                aprx_queue_key(c3, c2->last_evicted); /* evlfu_8.cpp:617-620 */
+                memcpy(out + (int64_t)i * dim, tmp, sizeof(float) * (size_t)dim);
+            }
+        if (agg == T) c2->n_perfect = c2->lists[T].len;
+    }
+    for (int i = 0; i < T; i++) {
+        float *o = out + (int64_t)i * dim;
+        if (hit1[i]) {
+            int32_t e = map_get(&c1->map, keys[i]);
+            if (e >= 0) {
+                evlfu_touch(c1, e, agg);
+                memcpy(o, c1->vals + (int64_t)e * dim, sizeof(float) * (size_t)dim);
+            } else {
+                store_fetch(&c1->store, i + 1, rows[i], o);
+            }
+        } else if (job1[i]) {
+            store_fetch(&c1->store, i + 1, rows[i], tmp);
+            int rc = evlfu_set(c1, keys[i], tmp, agg);
+            if (rc) return rc - 40;
+            aprx_queue_key(c3, c1->last_evicted); /* evlfu_8.cpp:654-658 */
             memcpy(o, tmp, sizeof(float) * (size_t)dim);
         }
     }

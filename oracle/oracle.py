@@ -57,6 +57,12 @@ def lib():
         L.orc_evlfu_state.argtypes = [C.c_void_p, _i64p]
         L.orc_c1c2_request.restype = C.c_int
         L.orc_c1c2_request.argtypes = [C.c_void_p, C.c_void_p, _i32p, _u8p, _f32p, C.c_int]
+        L.orc_aprx_new.restype = C.c_void_p
+        L.orc_aprx_new.argtypes = [C.c_int64, C.POINTER(C.c_void_p), C.c_int]
+        L.orc_aprx_free.argtypes = [C.c_void_p]
+        L.orc_aprx_state.argtypes = [C.c_void_p, _i64p]
+        L.orc_c1c2c3_request.restype = C.c_int
+        L.orc_c1c2c3_request.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _i32p, _u8p, _f32p, C.c_int]
         for p in ("lru", "lfu"):
             getattr(L, "orc_%s_new" % p).restype = C.c_void_p
             getattr(L, "orc_%s_new" % p).argtypes = [C.c_int64, C.c_int, C.c_int]
@@ -298,3 +304,27 @@ class C1C2:
         if rc < 0:
             raise RuntimeError("orc_c1c2_request rc=%d" % rc)
         return self._tier.copy(), self._out, rc
+
+
+class C1C2C3(C1C2):
+    """C1 + C2 + the alt-key tier (deterministic re-specification of evlfu_8.cpp:492-667; parity unpinned:
+    the reference's tier is asynchronous).  alt_tables: per table a uint32 array, alt_key[row] = alt_row*100 + alt_table."""
+
+    def __init__(self, cap_c1, cap_c2, cap_c3, tables_c1, tables_c2, alt_tables, dim=36, threshold=23):
+        super().__init__(cap_c1, cap_c2, tables_c1, tables_c2, dim, threshold)
+        self._alt = [np.ascontiguousarray(a, np.uint32) for a in alt_tables]
+        arr = (C.c_void_p * self.T)(*[a.ctypes.data for a in self._alt])
+        self.c3 = lib().orc_aprx_new(cap_c3, arr, self.T)
+
+    def request(self, rows):
+        self._rows[:] = rows
+        rc = lib().orc_c1c2c3_request(self.c1._h, self.c2._h, self.c3, _p(self._rows, _i32p), _p(self._tier, _u8p),
+                                      _p(self._out, _f32p), self.threshold)
+        if rc < 0:
+            raise RuntimeError("orc_c1c2c3_request rc=%d" % rc)
+        return self._tier.copy(), self._out, rc
+
+    def c3_state(self):
+        s = np.zeros(4, np.int64)
+        lib().orc_aprx_state(self.c3, _p(s, _i64p))
+        return dict(size=int(s[0]), n_hit=int(s[1]), n_pending=int(s[2]), error=int(s[3]))
