@@ -61,6 +61,11 @@ _PROTOS = {
     "evs_cache_lookup_interact": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
     "evs_cache_batch_stats": (_int, [_vp, _i64p, _i64p, _vp]),
     "evs_cache_batch_dump": (_i64, [_vp, _vp, _i64, _vp]),
+    "evs_aprx_create": (_int, [_pp, _i64, _int]),
+    "evs_aprx_destroy": (_int, [_vp]),
+    "evs_aprx_set_altkeys": (_int, [_vp, _pp, _i64p]),
+    "evs_aprx_stats": (_int, [_vp, _i64p, _vp]),
+    "evs_cache_request_c1c2c3": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "evs_cache_stats": (_int, [_vp, _i64p, _vp]),
     "evs_cache_reset_counters": (_int, [_vp, _vp]),
     "evs_cache_dump": (_i64, [_vp, _vp, _i64, _vp]),

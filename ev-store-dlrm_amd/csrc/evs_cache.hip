@@ -159,6 +159,7 @@ struct Hot {
     long long n_flush, n_evict, least_freq;
     int head[kMaxBuckets], tail[kMaxBuckets], len[kMaxBuckets];
     int error;
+    unsigned long long last_evicted;  // key evicted (not flushed) by the latest evlfu_set, 0 if none
 };
 
 __device__ __forceinline__ ListRef bucket(Hot &h, int b) { return ListRef{&h.head[b], &h.tail[b], &h.len[b]}; }
@@ -177,6 +178,7 @@ __device__ void drop_entry(const CacheArrays &a, Hot &h, unsigned long long mask
 __device__ int evlfu_set(const CacheState &cs, const CacheArrays &a, Hot &h, unsigned long long mask,
                          unsigned long long key, int agg_hit) {
     const int top = cs.n_tables;
+    h.last_evicted = 0;
     if (h.n_perfect >= cs.max_perfect) {  // :36-44 flush the oldest of the top bucket
         for (int i = 0; i < cs.flush_n; i++) {
             const int e = h.head[top];
@@ -194,6 +196,7 @@ __device__ int evlfu_set(const CacheState &cs, const CacheArrays &a, Hot &h, uns
         }
         const int e = h.head[h.min_c1];
         list_unlink(a, bucket(h, h.min_c1), e);
+        h.last_evicted = ld(&a.ekey[e]);
         drop_entry(a, h, mask, e);
         h.n_evict++;
     }
@@ -418,6 +421,112 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
 // entry was evicted earlier in the same request is served from storage (the C++ dereferences a
 // dangling pointer there, evlfu_8.cpp:521-522).
 // ------------------------------------------------------------------------------------------
+// ---- a12: alt-key ("approximate embedding") tier, C3 -- deterministic re-specification --------------
+// mixed_precs_caching/aprx_embedding.cpp (map key -> {alt_key, recency flag}, FIFO with second-chance
+// eviction, batches of 50 evicted keys) and evlfu_8.cpp:474-490,533-558 (lookup on a double miss).
+// The reference fills this tier from asynchronous threads; here a full batch is inserted at the start
+// of the next request (oracle/evstore_oracle.c:orc_c1c2c3_request is the same specification).
+constexpr int kAprxBatch = 50;   // IO_JOB_Q_SIZE (aprx_embedding.hpp:29)
+struct AprxState {
+    int cap, count, n_free, n_pending, batch_ready, error;
+    unsigned long long mask;
+    long long qcap, qhead, qtail, n_hit;
+    unsigned long long pending[kAprxBatch];
+};
+struct AprxArrays {
+    AprxState *st;
+    unsigned long long *keys; int *slot_entry;       // hash: key -> entry
+    unsigned long long *ekey; unsigned *ealt; unsigned char *eflag; int *free_stack;
+    unsigned long long *queue;
+    const unsigned *alt_tables[kMaxTables];           // alt_key[row] = alt_row*100 + alt_table (native endian)
+    long long alt_rows[kMaxTables];
+};
+__device__ int aprx_find(const AprxArrays &x, unsigned long long mask, unsigned long long key) {
+    unsigned long long i = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long k = ld(&x.keys[i]);
+        if (k == key) return ld(&x.slot_entry[i]);
+        if (k == kEmpty) return -1;
+        i = (i + 1) & mask;
+    }
+}
+__device__ void aprx_put(const AprxArrays &x, unsigned long long mask, unsigned long long key, int e) {
+    unsigned long long i = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long k = ld(&x.keys[i]);
+        if (k == kEmpty || k == key) break;
+        i = (i + 1) & mask;
+    }
+    st(&x.slot_entry[i], e);
+    st(&x.keys[i], key);
+}
+__device__ void aprx_del(const AprxArrays &x, unsigned long long mask, unsigned long long key) {
+    unsigned long long i = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long k = ld(&x.keys[i]);
+        if (k == key) break;
+        if (k == kEmpty) return;
+        i = (i + 1) & mask;
+    }
+    unsigned long long j = i;
+    for (;;) {
+        j = (j + 1) & mask;
+        const unsigned long long kj = ld(&x.keys[j]);
+        if (kj == kEmpty) break;
+        const unsigned long long h = mix64(kj) & mask;
+        const bool between = (i <= j) ? (h > i && h <= j) : (h > i || h <= j);
+        if (!between) { st(&x.slot_entry[i], ld(&x.slot_entry[j])); st(&x.keys[i], kj); i = j; }
+    }
+    st(&x.keys[i], kEmpty);
+}
+__device__ void aprx_evict_one(const AprxArrays &x, AprxState &s) {  // recency_aware_eviction (aprx_embedding.cpp:360-388)
+    while (s.qhead < s.qtail) {
+        const unsigned long long key = x.queue[s.qhead % s.qcap];
+        const int e = aprx_find(x, s.mask, key);
+        if (e >= 0) {
+            if (ld(&x.eflag[e])) {  // second chance
+                st(&x.eflag[e], (unsigned char)0);
+                x.queue[s.qtail % s.qcap] = key; s.qtail++;
+                s.qhead++;
+            } else {
+                aprx_del(x, s.mask, key);
+                x.free_stack[s.n_free++] = e;
+                s.count--; s.qhead++;
+                return;
+            }
+        } else {
+            s.qhead++;  // stale duplicate
+        }
+    }
+}
+__device__ void aprx_insert_batch(const AprxArrays &x, AprxState &s) {  // insert_altkey_batched_obj (:308-324)
+    const int n_erase = s.count + kAprxBatch - s.cap;
+    for (int i = 0; i < n_erase; i++) aprx_evict_one(x, s);
+    for (int i = 0; i < kAprxBatch; i++) {
+        const unsigned long long key = s.pending[i];
+        const int t = (int)(key >> 32) - 1;
+        const unsigned alt = x.alt_tables[t][(unsigned)(key & 0xffffffffull)];
+        if (s.qtail - s.qhead >= s.qcap) { s.error = 1; return; }
+        x.queue[s.qtail % s.qcap] = key; s.qtail++;
+        int e = aprx_find(x, s.mask, key);
+        if (e < 0) {
+            if (s.n_free <= 0) { s.error = 2; return; }
+            e = x.free_stack[--s.n_free];
+            st(&x.ekey[e], key);
+            aprx_put(x, s.mask, key, e);
+            s.count++;
+        }
+        st(&x.ealt[e], alt);
+        st(&x.eflag[e], (unsigned char)0);
+    }
+    s.n_pending = 0; s.batch_ready = 0;
+}
+__device__ __forceinline__ void aprx_queue_key(AprxState &s, unsigned long long key) {
+    if (!key) return;
+    if (s.n_pending < kAprxBatch) s.pending[s.n_pending++] = key;
+    if (s.n_pending == kAprxBatch) s.batch_ready = 1;
+}
+
 struct TierArgs {
     CacheState *st;
     CacheArrays a;
@@ -426,6 +535,7 @@ struct TierArgs {
 };
 struct C1C2Args {
     TierArgs t1, t2;
+    AprxArrays c3;            // c3.st == nullptr: no alt-key tier
     const int *requests;
     float *out;
     unsigned char *tier_out;  // (B,T): 1 = C1 hit, 2 = served by a C2 hit, 0 = miss
@@ -458,6 +568,9 @@ __device__ __forceinline__ void touch(const CacheArrays &a, Hot &h, int e, int a
 
 __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
     __shared__ Hot h1, h2;
+    __shared__ AprxState s3;
+    __shared__ int s_alt_e[kMaxTables], s_alt_tier[kMaxTables];
+    const bool has_c3 = args.c3.st != nullptr;
     // per key: which tier's row to output (1/2), from its arena entry (>=0) or its backing store (-1);
     // and the entry to fill afterwards per tier
     __shared__ int s_tier[kMaxTables], s_src[kMaxTables], s_fill1[kMaxTables], s_fill2[kMaxTables];
@@ -468,6 +581,7 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
     const int T = cs1.n_tables, d = cs1.dim;
     hot_load(h1, cs1, lane);
     hot_load(h2, cs2, lane);
+    if (has_c3 && lane == 0) s3 = *args.c3.st;
     __syncthreads();
     long long n_perfect_req = 0, n_hits = 0;
 
@@ -476,29 +590,48 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
         const unsigned long long key = ((unsigned long long)(lane + 1) << 32) | (unsigned)row;
         const bool ok = lane < T && row >= 0 && row < args.t1.backing_rows[lane < T ? lane : 0] &&
                         row < args.t2.backing_rows[lane < T ? lane : 0];
+        if (has_c3 && lane == 0 && s3.batch_ready) aprx_insert_batch(args.c3, s3);  // a full batch becomes visible here
+        __syncthreads();
         const int e2 = ok ? map_find(a2, m2, key) : -1;  // evlfu_4.cpp phase_1_find_keys_in_cache
         const int e1 = ok ? map_find(a1, m1, key) : -1;
         const unsigned long long okm = __ballot(ok);
         const unsigned long long hit2 = __ballot(e2 >= 0), hit1 = __ballot(e1 >= 0);
-        int agg = __popcll(hit2) + __popcll(hit1 & ~hit2);  // c1_c2_agg_hit (evlfu_8.cpp:688-703)
+        // alt-key probe for double misses (find_approximate_ev, evlfu_8.cpp:474-490): C1 first, then C2
+        int alt_e = -1, alt_tier = 0;
+        if (has_c3 && ok && e1 < 0 && e2 < 0) {
+            const int e3 = aprx_find(args.c3, s3.mask, key);
+            if (e3 >= 0) {
+                const unsigned alt = ld(&args.c3.ealt[e3]);
+                const unsigned long long akey = ((unsigned long long)(alt % 100u) << 32) | (alt / 100u);
+                int ea = map_find(a1, m1, akey);
+                if (ea >= 0) { alt_tier = 1; alt_e = ea; }
+                else { ea = map_find(a2, m2, akey); if (ea >= 0) { alt_tier = 2; alt_e = ea; } }
+                if (alt_tier) st(&args.c3.eflag[e3], (unsigned char)1);  // set_recency_flag_c3
+            }
+        }
+        const unsigned long long hit3 = __ballot(alt_tier != 0);
+        if (lane < T) { s_alt_e[lane] = alt_e; s_alt_tier[lane] = alt_tier; }
+        int agg = __popcll(hit2) + __popcll(hit1 & ~hit2) + __popcll(hit3);  // c1_c2_agg_hit (evlfu_8.cpp:513-546)
+        const unsigned long long hit1e = hit1 | hit3;        // c1_arr_record_hit is piggybacked for alt hits (:547)
         unsigned long long upd2 = ~hit1 & hit2 & okm;        // C1 miss, C2 hit: C2 serves and updates
-        unsigned long long ins2 = ~hit1 & ~hit2 & okm;       // double miss: C2 inserts (Cond 259) ...
+        unsigned long long ins2 = ~hit1 & ~hit2 & ~hit3 & okm;  // double miss without an alt row: C2 inserts (Cond 259) ...
         unsigned long long job1 = 0;
         bool update_c2 = true;
-        if (h1.count >= cs1.cap) {                           // :721-738 C1 full
+        if (h1.count >= cs1.cap) {                           // :570-586 C1 full
             if (agg < args.threshold) {                      // ... unless C1 takes the odd ones
                 const unsigned long long odd = 0xAAAAAAAAAAAAAAAAull;
-                job1 = ~hit2 & odd & okm;
+                job1 = ~hit2 & ~hit1e & odd & okm;
                 ins2 &= ~odd;
             }
-        } else {                                             // :739-751 C1 not full: all C1 misses go to C1
-            job1 = ~hit1 & okm;
+        } else {                                             // :587-601 C1 not full: all C1 misses go to C1
+            job1 = ~hit1e & okm;
             update_c2 = false;
             agg = __popcll(hit1);
         }
+        if (lane == 0 && has_c3) s3.n_hit += __popcll(hit3);
         if (lane < T) {
             s_tier[lane] = 0; s_src[lane] = -1; s_fill1[lane] = -1; s_fill2[lane] = -1;
-            args.tier_out[rq * T + lane] = (hit1 >> lane) & 1 ? 1 : ((hit2 >> lane) & 1 ? 2 : 0);
+            args.tier_out[rq * T + lane] = (hit1 >> lane) & 1 ? 1 : ((hit2 >> lane) & 1 ? 2 : ((hit3 >> lane) & 1 ? 3 : 0));
         }
         __syncthreads();
         for (int i = 0; i < T; i++) {  // C2 first (phase 2), updates before inserts (evlfu_4.cpp:374-400)
@@ -512,6 +645,7 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
             const unsigned long long ki = __shfl(key, i);
             if (lane == 0 && update_c2 && ((ins2 >> i) & 1)) {
                 s_fill2[i] = evlfu_set(cs2, a2, h2, m2, ki, agg);
+                if (has_c3) aprx_queue_key(s3, h2.last_evicted);  // evlfu_8.cpp:617-620
                 s_tier[i] = 2; s_src[i] = -1;
             }
         }
@@ -524,17 +658,19 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
                     s_tier[i] = 1;
                     if (ld(&a1.ekey[e1i]) == ki) { touch(a1, h1, e1i, agg); s_src[i] = e1i; }
                     else s_src[i] = -1;  // evicted earlier in this request
+                } else if ((hit3 >> i) & 1) {
+                    s_tier[i] = 2 + s_alt_tier[i];  // 3: alt row in C1's arena, 4: in C2's arena
+                    s_src[i] = s_alt_e[i];
                 } else if ((job1 >> i) & 1) {
-                    if ((ok ? 1 : 1) && !((hit1 >> i) & 1)) {
-                        s_fill1[i] = evlfu_set(cs1, a1, h1, m1, ki, agg);
-                        s_tier[i] = 1; s_src[i] = -1;
-                    }
+                    s_fill1[i] = evlfu_set(cs1, a1, h1, m1, ki, agg);
+                    if (has_c3) aprx_queue_key(s3, h1.last_evicted);  // evlfu_8.cpp:654-658
+                    s_tier[i] = 1; s_src[i] = -1;
                 }
             }
         }
         if (lane == 0 && agg == T) h1.n_perfect = h1.len[T];
         n_perfect_req += (agg == T);
-        n_hits += __popcll((hit1 | hit2) & okm);
+        n_hits += __popcll((hit1 | hit2 | hit3) & okm);
         __syncthreads();
 
         float *out = args.out + rq * (long long)T * d;
@@ -549,6 +685,11 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
                 codec = cs2.codec;
                 rowp = src >= 0 ? a2.arena + (long long)src * cs2.row_bytes
                                 : args.t2.backing[i] + (long long)rrow * cs2.row_bytes;
+            } else if (tier == 3) {  // alt-key hit: the ALT row, decoded at the precision of the tier holding it
+                rowp = a1.arena + (long long)src * cs1.row_bytes;
+            } else if (tier == 4) {
+                codec = cs2.codec;
+                rowp = a2.arena + (long long)src * cs2.row_bytes;
             }
             for (int c = lane; c < d; c += 64) out[i * d + c] = rowp ? decode_elem(rowp, codec, c) : 0.f;
         }
@@ -572,6 +713,7 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
     }
     hot_store(h1, args.t1.st, lane);
     hot_store(h2, args.t2.st, lane);
+    if (has_c3 && lane == 0) *args.c3.st = s3;
     if (lane == 0) {
         args.t1.st->n_requests = cs1.n_requests + args.B;
         args.t1.st->n_perfect_hits = cs1.n_perfect_hits + n_perfect_req;
@@ -922,6 +1064,7 @@ __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchAr
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+struct evs_aprx;
 struct evs_cache {
     evs::CacheState host;      // configuration mirror
     evs::CacheState *st = nullptr;
@@ -1106,27 +1249,12 @@ extern "C" int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_tr
     return n;
 }
 
+extern "C" int evs_cache_request_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows,
+                                        float *out, uint8_t *tier, int high_agghit_threshold, void *stream);
+
 extern "C" int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
                                       uint8_t *tier, int high_agghit_threshold, void *stream) {
-    using namespace evs;
-    EVS_REQUIRE(c1 && c2, "evs_cache_request_c1c2: NULL cache");
-    EVS_REQUIRE(c1->host.policy == kEvLFU && c2->host.policy == kEvLFU, "evs_cache_request_c1c2: both tiers must be EvLFU");
-    EVS_REQUIRE(c1->host.n_tables == c2->host.n_tables && c1->host.dim == c2->host.dim,
-                "evs_cache_request_c1c2: the tiers disagree on n_tables/dim");
-    if (!c1->has_backing || !c2->has_backing) { set_error("evs_cache_request_c1c2: set the backing tables of both tiers first"); return EVS_ESTATE; }
-    if (B == 0) return EVS_OK;
-    EVS_REQUIRE(B > 0 && rows && out && tier, "evs_cache_request_c1c2: NULL argument");
-    C1C2Args args;
-    evs_cache *cs[2] = {c1, c2};
-    TierArgs *ts[2] = {&args.t1, &args.t2};
-    for (int t = 0; t < 2; t++) {
-        ts[t]->st = cs[t]->st; ts[t]->a = cs[t]->a;
-        for (int k = 0; k < kMaxTables; k++) { ts[t]->backing[k] = cs[t]->backing[k]; ts[t]->backing_rows[k] = cs[t]->backing_rows[k]; }
-    }
-    args.requests = rows; args.out = out; args.tier_out = tier; args.B = B; args.threshold = high_agghit_threshold;
-    hipLaunchKernelGGL(cache_c1c2_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), args);
-    EVS_HIP_CHECK(hipGetLastError());
-    return EVS_OK;
+    return evs_cache_request_c1c2c3(c1, c2, nullptr, B, rows, out, tier, high_agghit_threshold, stream);
 }
 
 // ---- batched path --------------------------------------------------------------------------
@@ -1251,4 +1379,109 @@ extern "C" int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t 
         n++;
     }
     return n;
+}
+
+// ---- a12: alt-key tier object --------------------------------------------------------------------
+struct evs_aprx {
+    evs::AprxArrays x{};
+    long long nslot = 0, cap = 0;
+    int n_tables = 0;
+    bool has_alt = false;
+};
+
+extern "C" int evs_aprx_destroy(evs_aprx *p) {
+    if (!p) return EVS_OK;
+    void *ptrs[] = {p->x.st, p->x.keys, p->x.slot_entry, p->x.ekey, p->x.ealt, p->x.eflag, p->x.free_stack, p->x.queue};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    delete p;
+    return EVS_OK;
+}
+
+extern "C" int evs_aprx_create(evs_aprx **out, int64_t capacity, int n_tables) {
+    using namespace evs;
+    EVS_REQUIRE(out && capacity >= kAprxBatch && capacity < (1ll << 30) && n_tables >= 1 && n_tables <= kMaxTables,
+                "evs_aprx_create: capacity must be >= %d (aprx_embedding.cpp:33) and n_tables <= %d", kAprxBatch, kMaxTables);
+    evs_aprx *p = new evs_aprx();
+    p->cap = capacity; p->n_tables = n_tables;
+    long long nslot = 16;
+    while (nslot < capacity * 2 + 8) nslot <<= 1;
+    p->nslot = nslot;
+    AprxState h{};
+    h.cap = (int)capacity; h.n_free = (int)capacity; h.mask = (unsigned long long)(nslot - 1); h.qcap = 4 * capacity + 64;
+#define EVS_ALLOC(ptr, bytes)                                                                   \
+    do {                                                                                        \
+        if (hipMalloc(reinterpret_cast<void **>(&(ptr)), (bytes)) != hipSuccess) {              \
+            set_error("evs_aprx_create: hipMalloc(%lld bytes) failed", (long long)(bytes));     \
+            evs_aprx_destroy(p);                                                                \
+            return EVS_ENOMEM;                                                                  \
+        }                                                                                       \
+    } while (0)
+    EVS_ALLOC(p->x.st, sizeof(AprxState));
+    EVS_ALLOC(p->x.keys, nslot * 8);
+    EVS_ALLOC(p->x.slot_entry, nslot * 4);
+    EVS_ALLOC(p->x.ekey, capacity * 8);
+    EVS_ALLOC(p->x.ealt, capacity * 4);
+    EVS_ALLOC(p->x.eflag, capacity);
+    EVS_ALLOC(p->x.free_stack, capacity * 4);
+    EVS_ALLOC(p->x.queue, h.qcap * 8);
+#undef EVS_ALLOC
+    EVS_HIP_CHECK(hipMemset(p->x.keys, 0, nslot * 8));
+    std::vector<int> fs(capacity);
+    for (int64_t i = 0; i < capacity; i++) fs[i] = (int)(capacity - 1 - i);
+    EVS_HIP_CHECK(hipMemcpy(p->x.free_stack, fs.data(), capacity * 4, hipMemcpyHostToDevice));
+    EVS_HIP_CHECK(hipMemcpy(p->x.st, &h, sizeof h, hipMemcpyHostToDevice));
+    *out = p;
+    return EVS_OK;
+}
+
+extern "C" int evs_aprx_set_altkeys(evs_aprx *p, const uint32_t *const *alt_tables, const int64_t *n_rows) {
+    using namespace evs;
+    EVS_REQUIRE(p && alt_tables && n_rows, "evs_aprx_set_altkeys: NULL argument");
+    for (int k = 0; k < p->n_tables; k++) {
+        EVS_REQUIRE(alt_tables[k] || n_rows[k] == 0, "evs_aprx_set_altkeys: table %d is NULL", k);
+        p->x.alt_tables[k] = alt_tables[k];
+        p->x.alt_rows[k] = n_rows[k];
+    }
+    p->has_alt = true;
+    return EVS_OK;
+}
+
+// out4 (host): [size, n_hit, n_pending, error]
+extern "C" int evs_aprx_stats(evs_aprx *p, int64_t *out4, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(p && out4, "evs_aprx_stats: NULL argument");
+    AprxState h;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    EVS_HIP_CHECK(hipMemcpyAsync(&h, p->x.st, sizeof h, hipMemcpyDeviceToHost, st));
+    EVS_HIP_CHECK(hipStreamSynchronize(st));
+    out4[0] = h.count; out4[1] = h.n_hit; out4[2] = h.n_pending; out4[3] = h.error;
+    return EVS_OK;
+}
+
+extern "C" int evs_cache_request_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows,
+                                        float *out, uint8_t *tier, int high_agghit_threshold, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(c1 && c2, "evs_cache_request_c1c2c3: NULL cache");
+    EVS_REQUIRE(c1->host.policy == kEvLFU && c2->host.policy == kEvLFU, "evs_cache_request_c1c2c3: both tiers must be EvLFU");
+    EVS_REQUIRE(c1->host.n_tables == c2->host.n_tables && c1->host.dim == c2->host.dim,
+                "evs_cache_request_c1c2c3: the tiers disagree on n_tables/dim");
+    if (!c1->has_backing || !c2->has_backing) { set_error("evs_cache_request_c1c2c3: set the backing tables of both tiers first"); return EVS_ESTATE; }
+    if (c3 && !c3->has_alt) { set_error("evs_cache_request_c1c2c3: call evs_aprx_set_altkeys first"); return EVS_ESTATE; }
+    EVS_REQUIRE(!c3 || c3->n_tables == c1->host.n_tables, "evs_cache_request_c1c2c3: alt-key tier has a different n_tables");
+    if (B == 0) return EVS_OK;
+    EVS_REQUIRE(B > 0 && rows && out && tier, "evs_cache_request_c1c2c3: NULL argument");
+    if (c1->used == 2 || c2->used == 2) { set_error("evs_cache_request_c1c2c3: a tier is used through the batched path"); return EVS_ESTATE; }
+    c1->used = c2->used = 1;
+    C1C2Args args;
+    evs_cache *cs[2] = {c1, c2};
+    TierArgs *ts[2] = {&args.t1, &args.t2};
+    for (int t = 0; t < 2; t++) {
+        ts[t]->st = cs[t]->st; ts[t]->a = cs[t]->a;
+        for (int k = 0; k < kMaxTables; k++) { ts[t]->backing[k] = cs[t]->backing[k]; ts[t]->backing_rows[k] = cs[t]->backing_rows[k]; }
+    }
+    if (c3) args.c3 = c3->x; else { args.c3 = AprxArrays{}; args.c3.st = nullptr; }
+    args.requests = rows; args.out = out; args.tier_out = tier; args.B = B; args.threshold = high_agghit_threshold;
+    hipLaunchKernelGGL(cache_c1c2_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), args);
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
 }

@@ -140,3 +140,48 @@ def request_c1c2(c1, c2, rows, threshold=23, out=None, tier=None):
     _lib.check(_lib.lib().evs_cache_request_c1c2(c1._h, c2._h, B, rows.data_ptr(), out.data_ptr(), tier.data_ptr(),
                                                  int(threshold), torch.cuda.current_stream(c1.device).cuda_stream))
     return tier, out
+
+
+class GpuAltKeyTier:
+    """C3: key -> alt-key map with second-chance FIFO (deterministic re-specification of
+    mixed_precs_caching/aprx_embedding.cpp).  alt_tables: per table a device uint32 tensor (viewed as int32 is fine)
+    with alt_key[row] = alt_row*100 + alt_table_1based."""
+
+    def __init__(self, capacity, alt_tables, device="cuda"):
+        self.device = torch.device(device)
+        self.n_tables = len(alt_tables)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().evs_aprx_create(C.byref(h), int(capacity), self.n_tables))
+        self._h = h
+        self._alt = [t.contiguous() for t in alt_tables]
+        ptrs = (C.c_void_p * self.n_tables)(*[t.data_ptr() for t in self._alt])
+        rows = (C.c_int64 * self.n_tables)(*[int(t.numel()) for t in self._alt])
+        _lib.check(_lib.lib().evs_aprx_set_altkeys(self._h, ptrs, rows))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().evs_aprx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def stats(self):
+        s = (C.c_int64 * 4)()
+        _lib.check(_lib.lib().evs_aprx_stats(self._h, s, torch.cuda.current_stream(self.device).cuda_stream))
+        return dict(size=int(s[0]), n_hit=int(s[1]), n_pending=int(s[2]), error=int(s[3]))
+
+
+def request_c1c2c3(c1, c2, c3, rows, threshold=23, out=None, tier=None):
+    """request_to_c1_c2_c3 (evlfu_8.cpp:492-667): tier codes 1 C1 hit, 2 C2 hit, 3 alt-key hit, 0 miss."""
+    assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
+    B = int(rows.shape[0])
+    if out is None:
+        out = torch.empty((B, c1.n_tables, c1.dim), dtype=torch.float32, device=c1.device)
+    if tier is None:
+        tier = torch.empty((B, c1.n_tables), dtype=torch.uint8, device=c1.device)
+    _lib.check(_lib.lib().evs_cache_request_c1c2c3(c1._h, c2._h, c3._h if c3 is not None else None, B, rows.data_ptr(),
+                                                   out.data_ptr(), tier.data_ptr(), int(threshold),
+                                                   torch.cuda.current_stream(c1.device).cuda_stream))
+    return tier, out

@@ -218,6 +218,24 @@ EVS_API int evs_cache_lookup_interact(evs_cache *c, int64_t B, const int32_t *ro
 EVS_API int evs_cache_batch_stats(evs_cache *c, int64_t *out8, int64_t *hist, void *stream);
 /* resident (priority, table_1based, row) triples of the batched path, unordered; returns the count. */
 EVS_API int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream);
+/* a12: the alt-key ("approximate embedding") tier C3 -- mixed_precs_caching/aprx_embedding.cpp and
+ * evlfu_8.cpp:474-490,492-667 (request_to_c1_c2_c3).  DETERMINISTIC RE-SPECIFICATION, parity unpinned:
+ * the reference fills the tier from asynchronous threads racing the request thread.  Here keys evicted
+ * (not flushed) from C1/C2 are queued; when 50 (IO_JOB_Q_SIZE) are pending the batch is inserted at the
+ * start of the next request (second-chance FIFO eviction makes room).  On a double miss whose alt key is
+ * mapped and whose alt row is resident in C1 (else C2), that row's vector is served (tier code 3),
+ * decoded at the precision of the tier holding it; the key's recency flag is set; the request's agg_hit
+ * counts it; nothing is inserted for it.  alt_tables[k]: device-accessible uint32[n_rows[k]] with
+ * alt_key = alt_row*100 + alt_table_1based (the reference's alt-key files store this big-endian,
+ * script/convert_altkeys_to_binary.py:27-57; convert to native order when loading). */
+typedef struct evs_aprx evs_aprx;
+EVS_API int evs_aprx_create(evs_aprx **out, int64_t capacity, int n_tables);
+EVS_API int evs_aprx_destroy(evs_aprx *p);
+EVS_API int evs_aprx_set_altkeys(evs_aprx *p, const uint32_t *const *alt_tables, const int64_t *n_rows);
+EVS_API int evs_aprx_stats(evs_aprx *p, int64_t *out4 /* size, n_hit, n_pending, error */, void *stream);
+/* evs_cache_request_c1c2 with the alt-key tier (c3 may be NULL = plain two tiers). */
+EVS_API int evs_cache_request_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows,
+                                     float *out, uint8_t *tier, int high_agghit_threshold, void *stream);
 /* out8 (host): [min_C1, n_perfect, size, n_flush, n_evict, n_requests, n_perfect_hits, n_hits].
  * Synchronises the stream.  Returns EVS_ESTATE if the policy hit an inconsistency. */
 EVS_API int evs_cache_stats(evs_cache *c, int64_t *out8, void *stream);

@@ -326,3 +326,42 @@ def test_cache_lookup_interact_equals_rows_then_interact(E, orc):
         want = E.apply_emb_interact(x, off, idx, ev)
         assert torch.equal(R, want)
     assert c.batch_stats()["n_hits"] > 0
+
+
+def test_three_tier_c1c2c3_vs_oracle(E, orc):
+    """a12: request_to_c1_c2_c3 with the alt-key tier (deterministic re-specification) == the oracle:
+    tier codes (incl. 3 = alt-key hit), values, both tiers' final lists, C3 counters."""
+    from evstore_dlrm_amd import gpu_cache
+    rs = np.random.RandomState(8)
+    n = 300
+    ws = [rs.uniform(-1, 1, size=(n, 36)).astype(np.float32) for _ in range(26)]
+    raw8 = [orc.encode_table(w, 8) for w in ws]
+    raw4 = [orc.encode_table(w, 4) for w in ws]
+    dec8 = [orc.decode(r, 8, 36) for r in raw8]
+    dec4 = [orc.decode(r, 4, 36) for r in raw4]
+    alt = [(rs.randint(0, n, size=n) * 100 + (k + 1)).astype(np.uint32) for k in range(26)]
+    cap1, cap2, cap3 = 400, 800, 200
+    reqs = np.minimum(rs.zipf(1.3, size=(2500, 26)) - 1, n - 1).astype(np.int32)
+    o = orc.C1C2C3(cap1, cap2, cap3, dec8, dec4, alt)
+    want_tier, want_out = [], []
+    for rq in reqs:
+        t, out, _ = o.request(rq)
+        want_tier.append(t.copy()); want_out.append(out.copy())
+    c1 = E.GpuCache("evlfu", cap1, 26, 36, 8, "cpp")
+    c2 = E.GpuCache("evlfu", cap2, 26, 36, 4, "cpp")
+    c1.set_backing([torch.from_numpy(r).cuda() for r in raw8])
+    c2.set_backing([torch.from_numpy(r).cuda() for r in raw4])
+    c3 = gpu_cache.GpuAltKeyTier(cap3, [torch.from_numpy(a.view(np.int32)).cuda() for a in alt])
+    r = torch.from_numpy(reqs).cuda()
+    tiers, outs = [], []
+    for s in range(0, len(reqs), 173):
+        t, out = gpu_cache.request_c1c2c3(c1, c2, c3, r[s:s + 173].contiguous())
+        tiers.append(t.cpu().numpy()); outs.append(out.cpu().numpy())
+    tiers, outs = np.concatenate(tiers), np.concatenate(outs)
+    assert np.array_equal(tiers, np.stack(want_tier))
+    assert np.array_equal(outs.view(np.uint32), np.stack(want_out).view(np.uint32))
+    np.testing.assert_array_equal(c1.dump(), o.c1.dump())
+    np.testing.assert_array_equal(c2.dump(), o.c2.dump())
+    st, so = c3.stats(), o.c3_state()
+    assert st == so and st["n_hit"] > 50 and st["error"] == 0
+    assert (tiers == 3).sum() == st["n_hit"]
