@@ -71,6 +71,8 @@ _PROTOS = {
     "evs_cache_dump": (_i64, [_vp, _vp, _i64, _vp]),
     "evs_manager_configure": (_int, [_int, _int, _int, _i64, C.c_char_p, C.c_char_p, _int]),
     "evs_manager_perfect_hit": (C.c_longlong, []),
+    "evs_manager_set_altkey_dir": (_int, [C.c_char_p]),
+    "evs_manager_aprx_hit": (C.c_longlong, []),
     "ev_lookup": (C.POINTER(C.c_float), [C.POINTER(C.c_int)]),
     "get_ev_values": (C.POINTER(C.c_float), [C.POINTER(C.c_int)]),
     "print_perfect_hit": (None, []),

@@ -14,12 +14,14 @@ emb_weights_in_tensor = [None] * N_EVTable  # module-global list reused across c
 
 
 def init_ctypes_lib(ev_table_root=None, main_precision=32, total_size=75425, n_caching_layer=1,
-                    secondary_precision=4, size_proportion="", backing="hbm"):
+                    secondary_precision=4, size_proportion="", backing="hbm", altkey_dir=None):
     """Loads libevstore_hip.so.  With ev_table_root the manager is configured here; without it the
     library reads the EVS_* environment variables on the first lookup."""
     global cache_manager_cpp
     print("Initiating ctypes cache_manager_cpp library (libevstore_hip.so) ...")
     cache_manager_cpp = _lib.lib()
+    if altkey_dir is not None:
+        _lib.check(cache_manager_cpp.evs_manager_set_altkey_dir(str(altkey_dir).encode()))
     if ev_table_root is not None:
         _lib.check(cache_manager_cpp.evs_manager_configure(
             n_caching_layer, main_precision, secondary_precision, total_size, size_proportion.encode(),

@@ -27,6 +27,10 @@ struct Manager {
     long long total_size = 75425;
     std::string proportion = "", root = "";
     evs_cache *c1 = nullptr, *c2 = nullptr;
+    evs_aprx *c3 = nullptr;
+    std::string altkey_dir = "";
+    void *alt_tables[kEvTables] = {nullptr};
+    long long alt_rows[kEvTables] = {0};
     void *tables[kEvTables] = {nullptr}, *tables2[kEvTables] = {nullptr};
     long long rows[kEvTables] = {0}, rows2[kEvTables] = {0};
     int *d_rows = nullptr, *h_rows = nullptr;
@@ -91,17 +95,21 @@ static int ensure_ready() {
         if ((e = getenv("EVS_SIZE_PROPORTION"))) m.proportion = e;
         if ((e = getenv("EVS_BACKING"))) m.backing_kind = (strcmp(e, "pinned") == 0) ? 1 : 0;
         if ((e = getenv("EVS_EV_TABLE_ROOT"))) m.root = e;
+        if ((e = getenv("EVS_ALTKEY_DIR"))) m.altkey_dir = e;
         if (m.root.empty()) {
             set_error("cache manager is not configured: call evs_manager_configure() or set EVS_EV_TABLE_ROOT");
             return EVS_ESTATE;
         }
     }
-    if (m.n_layer != 1 && m.n_layer != 2) {
-        // cache_manager.cpp:213-217 prints and exit(-1)s on an unknown layer count; the alt-key tier (3) is not built
-        set_error("ERROR: cache_manager N_CACHING_LAYER=%d is not built in this round (1 or 2 tiers)", m.n_layer);
+    if (m.n_layer < 1 || m.n_layer > 3) {
+        set_error("ERROR: cache_manager.cpp N_CACHING_LAYER is NOT recognized!!");  // cache_manager.cpp:224-225
         return EVS_ESTATE;
     }
-    if (m.n_layer == 2 && !(m.secondary_prec == 16 || m.secondary_prec == 8 || m.secondary_prec == 4) ) {
+    if (m.n_layer == 3 && m.altkey_dir.empty()) {
+        set_error("N_CACHING_LAYER=3 needs the alt-key directory (evs_manager_set_altkey_dir or EVS_ALTKEY_DIR)");
+        return EVS_ESTATE;
+    }
+    if (m.n_layer >= 2 && !(m.secondary_prec == 16 || m.secondary_prec == 8 || m.secondary_prec == 4) ) {
         set_error("ERROR: Secondary precision (%d) is NOT recognized!", m.secondary_prec);  // evlfu_8.cpp:147
         return EVS_EINVAL;
     }
@@ -113,7 +121,19 @@ static int ensure_ready() {
     if (rc) return rc;
     // sizes are in fp32-row equivalents: cache_manager.cpp:46-53, evlfu_8.cpp:86-92 (x4 for 8-bit rows, x8 for 4-bit);
     // two tiers without a proportion string split TOTAL_SIZE evenly (evlfu_8.cpp:86-88, cache_manager.cpp:36-38)
-    const long long share = m.n_layer == 2 ? m.total_size / 2 : m.total_size;
+    // capacities (evlfu_8.cpp:63-92): "a-b-c" proportions when three tiers are on, else equal shares
+    long long share1 = m.total_size, share2 = 0, share3 = 0;
+    if (m.n_layer == 2) { share1 = share2 = m.total_size / 2; }
+    if (m.n_layer == 3) {
+        int p1 = 0, p2 = 0, p3 = 0;
+        if (!m.proportion.empty() && sscanf(m.proportion.c_str(), "%d-%d-%d", &p1, &p2, &p3) == 3) {
+            if (p1 + p2 + p3 != 100) { set_error("SIZE_PROPORTION must add up to 100"); return EVS_EINVAL; }  // :75 assert
+            share1 = p1 * m.total_size / 100; share2 = p2 * m.total_size / 100; share3 = p3 * m.total_size / 100;
+        } else {
+            share1 = share2 = share3 = m.total_size / 3;
+        }
+    }
+    const long long share = share1;
     const long long cap = share * (32 / m.main_prec);
     // mixed_precs_caching constants: 0.3 / 0.95, n keys flushed, n_perfect -= n (evlfu_8.hpp:50-51, evlfu_8.cpp:256-270)
     rc = evs_cache_create(&m.c1, 0, cap, kEvTables, kEvDim, m.main_prec, 0.3, 0.95, 0, 2);
@@ -122,13 +142,41 @@ static int ensure_ready() {
     for (int k = 0; k < kEvTables; k++) rows64[k] = m.rows[k];
     rc = evs_cache_set_backing(m.c1, m.tables, (const int64_t *)rows64);
     if (rc) return rc;
-    if (m.n_layer == 2) {
+    if (m.n_layer >= 2) {
         rc = load_tables(m, m.secondary_prec, m.tables2, m.rows2);
         if (rc) return rc;
-        rc = evs_cache_create(&m.c2, 0, share * (32 / m.secondary_prec), kEvTables, kEvDim, m.secondary_prec, 0.3, 0.95, 0, 2);
+        rc = evs_cache_create(&m.c2, 0, share2 * (32 / m.secondary_prec), kEvTables, kEvDim, m.secondary_prec, 0.3, 0.95, 0, 2);
         if (rc) return rc;
         for (int k = 0; k < kEvTables; k++) rows64[k] = m.rows2[k];
         rc = evs_cache_set_backing(m.c2, m.tables2, (const int64_t *)rows64);
+        if (rc) return rc;
+    }
+    if (m.n_layer == 3 && share3 * 36 >= 50) {  // capacity_c3 = share * 36 (one fp32 row = 36 alt keys, evlfu_8.cpp:80)
+        // alt-key files: 4-byte BIG-endian words, alt_row*100 + alt_table (script/convert_altkeys_to_binary.py:27-57)
+        for (int k = 0; k < kEvTables; k++) {
+            const std::string path = m.altkey_dir + "/ev-table-" + std::to_string(k + 1) + ".bin";
+            FILE *fp = fopen(path.c_str(), "rb");
+            if (!fp) { set_error("cannot open alt-key file %s", path.c_str()); return EVS_EIO; }
+            fseek(fp, 0, SEEK_END);
+            const long long bytes = ftell(fp);
+            fseek(fp, 0, SEEK_SET);
+            std::vector<unsigned char> buf(bytes > 0 ? bytes : 4);
+            const size_t got = bytes ? fread(buf.data(), 1, bytes, fp) : 0;
+            fclose(fp);
+            if ((long long)got != bytes || bytes % 4) { set_error("%s: bad size", path.c_str()); return EVS_EIO; }
+            std::vector<unsigned> native(bytes / 4 + 1);
+            for (long long r = 0; r < bytes / 4; r++)
+                native[r] = ((unsigned)buf[4 * r] << 24) | ((unsigned)buf[4 * r + 1] << 16) | ((unsigned)buf[4 * r + 2] << 8) | buf[4 * r + 3];
+            void *dev = nullptr;
+            EVS_HIP_CHECK(hipMalloc(&dev, bytes > 0 ? bytes : 4));
+            EVS_HIP_CHECK(hipMemcpy(dev, native.data(), bytes, hipMemcpyHostToDevice));
+            m.alt_tables[k] = dev; m.alt_rows[k] = bytes / 4;
+        }
+        rc = evs_aprx_create(&m.c3, share3 * 36, kEvTables);
+        if (rc) return rc;
+        long long ar[kEvTables];
+        for (int k = 0; k < kEvTables; k++) ar[k] = m.alt_rows[k];
+        rc = evs_aprx_set_altkeys(m.c3, (const uint32_t *const *)m.alt_tables, (const int64_t *)ar);
         if (rc) return rc;
     }
     EVS_HIP_CHECK(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
@@ -143,6 +191,21 @@ static int ensure_ready() {
 }
 
 }  // namespace evs
+
+extern "C" int evs_manager_set_altkey_dir(const char *dir) {
+    using namespace evs;
+    EVS_REQUIRE(!g_mgr.ready && dir, "evs_manager_set_altkey_dir: call before the first lookup");
+    g_mgr.altkey_dir = dir;
+    return EVS_OK;
+}
+
+extern "C" long long evs_manager_aprx_hit() {  // evlfu_8bit->aprx_ev_hit (cache_manager.cpp:279)
+    using namespace evs;
+    if (!g_mgr.ready || !g_mgr.c3) return 0;
+    int64_t s4[4] = {0};
+    (void)evs_aprx_stats(g_mgr.c3, s4, g_mgr.stream);
+    return s4[1];
+}
 
 extern "C" int evs_manager_configure(int n_caching_layer, int main_precision, int secondary_precision,
                                      int64_t total_size, const char *size_proportion, const char *ev_table_root,
@@ -169,7 +232,7 @@ extern "C" float *ev_lookup(int *arr) {
     Manager &m = g_mgr;
     memcpy(m.h_rows, arr, kEvTables * sizeof(int));
     if (hipMemcpyAsync(m.d_rows, m.h_rows, kEvTables * 4, hipMemcpyHostToDevice, m.stream) != hipSuccess) return nullptr;
-    const int rc = m.c2 ? evs_cache_request_c1c2(m.c1, m.c2, 1, m.d_rows, m.d_out, m.d_hit, 23 /* evlfu_8.hpp:70 */, m.stream)
+    const int rc = m.c2 ? evs_cache_request_c1c2c3(m.c1, m.c2, m.c3, 1, m.d_rows, m.d_out, m.d_hit, 23 /* evlfu_8.hpp:70 */, m.stream)
                         : evs_cache_request(m.c1, 1, m.d_rows, m.d_out, m.d_hit, -1, m.stream);
     if (rc != EVS_OK) {
         printf("%s\n", evs_last_error());
@@ -195,7 +258,12 @@ extern "C" long long evs_manager_perfect_hit() {
 extern "C" void print_perfect_hit() {  // cache_manager.cpp:262-290: prints, then resets the counter
     using namespace evs;
     printf("\n[epoll worker] C1_PRECISION    = %d\n", g_mgr.main_prec);
-    if (g_mgr.n_layer == 2) printf("[epoll worker] C2_PRECISION    = %d\n", g_mgr.secondary_prec);
+    if (g_mgr.n_layer >= 2) printf("[epoll worker] C2_PRECISION    = %d\n", g_mgr.secondary_prec);
+    if (g_mgr.n_layer == 3) {
+        printf("[epoll worker] C3 APRX_EV      = ACTIVE\n");
+        printf("[epoll worker] SIZE_PROPORTION = %s\n", g_mgr.proportion.c_str());
+        printf("[epoll worker] C3 Indiv-Hit    = %lld\n", evs_manager_aprx_hit());
+    }
     printf("[epoll worker] TOTAL_SIZE      = %lld\n", g_mgr.total_size);
     printf("[epoll worker] Perfect hit     = %lld\n", evs_manager_perfect_hit());
     fflush(stdout);

@@ -252,7 +252,8 @@ EVS_API int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_tripl
  *   side effect perfect-hit counter += (all 26 hit).  NULL (after printing) on a configuration error
  *   (the reference prints and exit(-1)s).
  * Configuration: the reference's five compile-time knobs (cache_manager.cpp:13-20) at run time.
- *   n_caching_layer 1 (C1) or 2 (C1 + C2 = request_to_c1_c2; 3 = alt-key tier, not built this round),
+ *   n_caching_layer 1 (C1), 2 (C1 + C2 = request_to_c1_c2) or 3 (+ the alt-key tier = request_to_c1_c2_c3;
+ *   needs evs_manager_set_altkey_dir / EVS_ALTKEY_DIR; sizes from size_proportion "a-b-c" as evlfu_8.cpp:63-92),
  *   main_precision 32|16|8|4, secondary_precision 16|8|4,
  *   total_size in fp32-row equivalents (one tier: capacity = total_size * 32/main_precision entries;
  *   two tiers: total_size/2 each, i.e. (total/2)*32/main and (total/2)*32/secondary entries),
@@ -264,7 +265,9 @@ EVS_API int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_tripl
 EVS_API int evs_manager_configure(int n_caching_layer, int main_precision, int secondary_precision,
                                   int64_t total_size, const char *size_proportion, const char *ev_table_root,
                                   int backing);
+EVS_API int evs_manager_set_altkey_dir(const char *dir);  /* n_caching_layer 3: directory of the alt-key ev-table-N.bin files */
 EVS_API long long evs_manager_perfect_hit(void);
+EVS_API long long evs_manager_aprx_hit(void);             /* evlfu_8bit->aprx_ev_hit (cache_manager.cpp:279) */
 EVS_API float *ev_lookup(int *arr);                      /* cache_manager.cpp:231 */
 EVS_API float *get_ev_values(int *arr);                  /* cache_manager.cpp:257 */
 EVS_API void print_perfect_hit(void);                    /* cache_manager.cpp:262 */

@@ -23,19 +23,27 @@ os.environ["EVS_TOTAL_SIZE"] = str(total)
 os.environ["EVS_BACKING"] = "pinned"
 os.environ["EVS_N_CACHING_LAYER"] = str(layers)
 os.environ["EVS_SECONDARY_PRECISION"] = "4"
+if layers == 3:
+    os.environ["EVS_ALTKEY_DIR"] = os.path.join(root, "altkeys")
+    os.environ["EVS_SIZE_PROPORTION"] = "40-40-20"
 cli.init_ctypes_lib()
 fp32_tabs = [orc.decode(r, prec, 36) for r in raws]
-if layers == 2:
+if layers >= 2:
     raws4 = [np.fromfile(os.path.join(root, "ev-table-4", "binary", "ev-table-%d.bin" % (k + 1)), np.uint8).reshape(-1, 18)
              for k in range(26)]
-    o = orc.C1C2((total // 2) * (32 // prec), (total // 2) * 8, fp32_tabs, [orc.decode(r, 4, 36) for r in raws4])
+    dec4 = [orc.decode(r, 4, 36) for r in raws4]
+    if layers == 3:
+        alt = [np.fromfile(os.path.join(root, "altkeys", "ev-table-%d.bin" % (k + 1)), ">u4").astype(np.uint32) for k in range(26)]
+        o = orc.C1C2C3((40 * total // 100) * (32 // prec), (40 * total // 100) * 8, (20 * total // 100) * 36, fp32_tabs, dec4, alt)
+    else:
+        o = orc.C1C2((total // 2) * (32 // prec), (total // 2) * 8, fp32_tabs, dec4)
 else:
     o = orc.EvLFU(total * (32 // prec), fp32_tabs, variant="cpp")
 perfect = 0
 ok = True
 for i, rq in enumerate(reqs):
     ly = cli.request_to_cpp_cache([int(v) for v in rq])
-    if layers == 2:
+    if layers >= 2:
         _, vals, p = o.request(rq)
         perfect += p
     else:
@@ -49,8 +57,9 @@ L = cli.cache_manager_cpp
 same_buf = ctypes.addressof(L.get_ev_values(None).contents) == ctypes.addressof(
     L.ev_lookup((ctypes.c_int * 26)(*[int(v) for v in reqs[0]])).contents)
 counter = int(L.evs_manager_perfect_hit())
+aprx = (int(L.evs_manager_aprx_hit()), o.c3_state()["n_hit"] if layers == 3 else 0)
 L.print_perfect_hit()
 after = int(L.evs_manager_perfect_hit())
 rc_dead = L.ev_lookup_based_on_list_keys((ctypes.c_int * 26)())
 print("RESULT " + json.dumps({"ok": ok, "perfect_oracle": perfect, "counter": counter, "after_print": after,
-                              "same_buf": same_buf, "rc_dead": rc_dead}))
+                              "same_buf": same_buf, "rc_dead": rc_dead, "aprx": aprx}))

@@ -158,7 +158,7 @@ def test_plugin_surface_evstore(E, orc, tmp_path):
         sm.close_any_db_conn()
 
 
-@pytest.mark.parametrize("prec,layers", [(8, 1), (32, 1), (8, 2)])
+@pytest.mark.parametrize("prec,layers", [(8, 1), (32, 1), (8, 2), (8, 3)])
 def test_reference_cabi_ev_lookup(E, orc, tmp_path, prec, layers):
     """ev_lookup / get_ev_values / print_perfect_hit through ctypes, as cpp_socket_client.py binds them."""
     import json
@@ -171,13 +171,18 @@ def test_reference_cabi_ev_lookup(E, orc, tmp_path, prec, layers):
     (tmp_path / sub / "binary").mkdir(parents=True)
     for k, w in enumerate(tabs):
         orc.encode_table(np.clip(w * 8, -1, 1), prec).tofile(tmp_path / sub / "binary" / ("ev-table-%d.bin" % (k + 1)))
-    if layers == 2:
+    if layers == 3:
+        (tmp_path / "altkeys").mkdir()
+        rs = np.random.RandomState(4)
+        for k, w in enumerate(tabs):
+            ((rs.randint(0, len(w), size=len(w)) * 100 + (k + 1)).astype(">u4")).tofile(tmp_path / "altkeys" / ("ev-table-%d.bin" % (k + 1)))
+    if layers >= 2:
         (tmp_path / "ev-table-4" / "binary").mkdir(parents=True)
         for k, w in enumerate(tabs):
             orc.encode_table(np.clip(w * 8, -1, 1), 4).tofile(tmp_path / "ev-table-4" / "binary" / ("ev-table-%d.bin" % (k + 1)))
-    np.save(tmp_path / "reqs.npy", t["requests"][:250])
+    np.save(tmp_path / "reqs.npy", t["requests"][:1200] if layers == 3 else t["requests"][:250])
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ev_lookup_child.py")
-    out = subprocess.run([sys.executable, child, str(tmp_path), str(prec), "100", str(layers)], capture_output=True,
+    out = subprocess.run([sys.executable, child, str(tmp_path), str(prec), "40" if layers == 3 else "100", str(layers)], capture_output=True,
                          text=True, timeout=300)
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
     assert line, out.stdout[-2000:] + out.stderr[-2000:]
@@ -186,6 +191,9 @@ def test_reference_cabi_ev_lookup(E, orc, tmp_path, prec, layers):
     # ev_lookup was called once more after the loop (same_buf probe): counter >= the oracle's count
     assert r["perfect_oracle"] <= r["counter"] <= r["perfect_oracle"] + 1 and r["after_print"] == 0
     assert "Perfect hit" in out.stdout
+    if layers == 3:
+        # the child's extra ev_lookup probe may add alt-key hits of its own
+        assert r["aprx"][1] <= r["aprx"][0] <= r["aprx"][1] + 26 and "C3 Indiv-Hit" in out.stdout
 
 
 def test_two_tier_c1c2_vs_oracle(E, orc):
