@@ -46,6 +46,7 @@ struct FusedArgs {
     const int64_t *dummy_i64;  // any readable int64 (lanes with nothing to fetch read it)
     const float *dummy_f32;
     const void *zeros;         // >= 1 KiB of zero bytes (idle lanes / empty bags read rows from it)
+    int bag1;                  // every indirect feature: one index per bag, no offsets array
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -394,7 +395,9 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
 // flight into the wave's LDS slot while the MFMAs and stores of sample k run; the row registers
 // are single-buffered (24 VGPRs instead of 48), so more waves fit per SIMD.
 // ------------------------------------------------------------------------------------------
-template <int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS>
+// BAG1: every indirect feature has exactly one index per bag and no offsets array (the Criteo collate,
+// dlrm_data_pytorch.py:407-408: offsets = arange) -- the offsets stage of the pipeline disappears.
+template <int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1>
 __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_kernel(const FusedArgs args) {
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
@@ -485,7 +488,7 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_k
         return b < B ? b : B - 1;
     };
     auto issue_off = [&](int n) {
-        if constexpr (HAS_INDIRECT) {
+        if constexpr (HAS_INDIRECT && !BAG1) {
             const int b = (int)sample_b(n);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {
@@ -495,7 +498,15 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_k
         }
     };
     auto issue_idx = [&](int n) {
-        if constexpr (HAS_INDIRECT) {
+        if constexpr (HAS_INDIRECT && BAG1) {
+            const int b = (int)sample_b(n);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                st2[rr] = b;
+                len2[rr] = lf[rr].indirect ? 1 : 0;
+                idx_raw[rr] = lf[rr].idx[lf[rr].indirect ? b : 0];
+            }
+        } else if constexpr (HAS_INDIRECT) {
             const int b = (int)sample_b(n);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {
@@ -603,7 +614,7 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_k
                     a[rr][c].z = __fmul_rn(a[rr][c].z, w0[rr]); a[rr][c].w = __fmul_rn(a[rr][c].w, w0[rr]);
                 }
         }
-        if constexpr (HAS_INDIRECT && !PTRS) {
+        if constexpr (HAS_INDIRECT && !PTRS && !BAG1) {
             bool more = false;
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) more |= len0[rr] > 1;
@@ -690,19 +701,31 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
             if (!per_cu_l[ntl]) {
                 int n = 0;
                 hipError_t e = ntl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                         &n, emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS>, 256, 0)
+                                         &n, emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, false>, 256, 0)
                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                         &n, emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS>, 256, 0);
+                                         &n, emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, false>, 256, 0);
                 per_cu_l[ntl] = (e == hipSuccess && n > 0) ? n : 2;
             }
             int64_t blocks = (a.B + 3) / 4;
             const int64_t cap = (int64_t)kNumCu * per_cu_l[ntl];
             if (blocks > cap) blocks = cap;
+            const bool bag1 = HAS_INDIRECT && (PTRS || a.bag1);
+            if constexpr (HAS_INDIRECT && !WEIGHTED) {
+                if (bag1) {
+                    if (ntl == 0)
+                        hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true>),
+                                           dim3((unsigned)blocks), dim3(256), 0, st, a);
+                    else
+                        hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>),
+                                           dim3((unsigned)blocks), dim3(256), 0, st, a);
+                    return;
+                }
+            }
             if (ntl == 0)
-                hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS>),
+                hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, false>),
                                    dim3((unsigned)blocks), dim3(256), 0, st, a);
             else
-                hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS>),
+                hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, false>),
                                    dim3((unsigned)blocks), dim3(256), 0, st, a);
             return;
         }
@@ -764,7 +787,7 @@ int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_
     }
     a.R = R; a.B = B; a.F = F; a.d = d; a.itself = itself ? 1 : 0;
     a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
-    a.dummy_i64 = iota; a.dummy_f32 = x;
+    a.dummy_i64 = iota; a.dummy_f32 = x; a.bag1 = 1;
     if (!launch_cpq<32, false, true, true>(a, st)) { set_error("fused_interact_from_row_ptrs: no kernel for d=%d", d); return EVS_EINVAL; }
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
@@ -801,7 +824,7 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
         EVS_REQUIRE(feats[f].src || (feats[f].indices && feats[f].n_rows == 0), "evs_emb_interact_dot: feats[%d].src is NULL", f);
         EVS_REQUIRE(reinterpret_cast<uintptr_t>(feats[f].src) % 16 == 0, "evs_emb_interact_dot: feats[%d].src must be 16-byte aligned", f);
         if (feats[f].indices) {
-            EVS_REQUIRE(feats[f].offsets, "evs_emb_interact_dot: feats[%d].offsets is NULL", f);
+            // offsets == NULL: one index per bag (bag b = indices[b]); checked for all features below
             EVS_REQUIRE(feats[f].offsets_len == 0 || (feats[f].offsets_len >= B && feats[f].offsets_len < (1ll << 31)),
                         "evs_emb_interact_dot: feats[%d].offsets_len must be 0 or in [B, 2^31)", f);
             EVS_REQUIRE(feats[f].nnz >= 0 && feats[f].n_rows >= 0 && feats[f].nnz < (1ll << 31) && feats[f].n_rows < (1ll << 31),
@@ -820,12 +843,24 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     bool weighted = false, indirect = false;
     a.dummy_i64 = nullptr;
+    a.bag1 = 0;
+    {
+        int n_ind = 0, n_nooff = 0;
+        for (int f = 0; f < F; f++) if (feats[f].indices) { n_ind++; if (!feats[f].offsets) n_nooff++; }
+        EVS_REQUIRE(n_nooff == 0 || n_nooff == n_ind, "evs_emb_interact_dot: either every indirect feature has offsets or none (one index per bag)");
+        a.bag1 = n_ind > 0 && n_nooff == n_ind;
+        if (a.bag1) {
+            EVS_REQUIRE(codec == 32 && evs_fused_dim_supported(d), "evs_emb_interact_dot: offsets == NULL needs fp32 tables");
+            for (int f = 0; f < F; f++)
+                if (feats[f].indices) EVS_REQUIRE(feats[f].nnz >= B && !feats[f].row_weights, "evs_emb_interact_dot: one-index-per-bag features need nnz >= B and no row weights");
+        }
+    }
     a.dummy_f32 = reinterpret_cast<const float *>(feats[0].src);
     for (int f = 0; f < F; f++) {
         if (!feats[f].indices) continue;
         indirect = true;
         weighted |= feats[f].row_weights != nullptr;
-        if (!a.dummy_i64) a.dummy_i64 = feats[f].offsets;  // B >= 1 entries, always readable
+        if (!a.dummy_i64) a.dummy_i64 = feats[f].offsets ? feats[f].offsets : feats[f].indices;  // >= B readable entries
         if (feats[f].n_rows == 0 || !feats[f].src) a.src[f] = a.zeros;  // never dereferenced for a valid row
     }
     EVS_REQUIRE(!weighted || codec == 32, "evs_emb_interact_dot: weighted pooling is only built for fp32 tables");
@@ -855,8 +890,7 @@ extern "C" int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec, 
     using namespace evs;
     EVS_REQUIRE(T >= 0 && T + 1 <= EVS_MAX_FEATURES, "evs_emb_interact_dot_stacked: T=%d (need T+1 <= %d)", T,
                 EVS_MAX_FEATURES);
-    EVS_REQUIRE(B == 0 || (tables && n_rows && x && indices_base && offsets_base),
-                "evs_emb_interact_dot_stacked: NULL argument");
+    EVS_REQUIRE(B == 0 || (tables && n_rows && x && indices_base), "evs_emb_interact_dot_stacked: NULL argument");
     evs_feature ft[EVS_MAX_FEATURES];
     ft[0].src = x; ft[0].stride = x_stride; ft[0].indices = nullptr; ft[0].offsets = nullptr;
     ft[0].nnz = 0; ft[0].n_rows = 0; ft[0].row_weights = nullptr; ft[0].offsets_len = 0;
@@ -864,7 +898,7 @@ extern "C" int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec, 
         evs_feature &f = ft[k + 1];
         f.src = tables[k]; f.stride = 0;
         f.indices = indices_base + (int64_t)k * indices_row_stride;
-        f.offsets = offsets_base + (int64_t)k * offsets_row_stride;
+        f.offsets = offsets_base ? offsets_base + (int64_t)k * offsets_row_stride : nullptr;  // NULL: one index per bag
         f.nnz = nnz_per_table; f.n_rows = n_rows[k];
         f.row_weights = row_weights ? row_weights[k] : nullptr;
         f.offsets_len = 0;

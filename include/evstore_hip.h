@@ -131,7 +131,7 @@ typedef struct evs_feature {
     const void *src;
     int64_t stride;
     const int64_t *indices;
-    const int64_t *offsets;
+    const int64_t *offsets;   /* indirect: B bag starts; NULL on EVERY indirect feature = one index per bag */
     int64_t nnz;
     int64_t n_rows;
     const float *row_weights;
@@ -148,7 +148,9 @@ EVS_API int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const evs_f
 
 /* Stacked-layout form (Criteo collate: indices and offsets are (T,B) int64 tensors, see
  * evs_embedding_bag_sum_stacked): feature 0 = x (B,d) with row stride x_stride floats,
- * feature k+1 = bag-sum over tables[k].  F = T + 1. */
+ * feature k+1 = bag-sum over tables[k].  F = T + 1.  offsets_base == NULL declares ONE INDEX PER BAG
+ * (the Criteo collate's offsets = arange(B), dlrm_data_pytorch.py:407-408): bag b = indices[k][b]; the
+ * offsets stage of the kernel is skipped (fp32 tables, unweighted). */
 EVS_API int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec,
                                  const void *const *tables, const int64_t *n_rows,
                                  const float *x, int64_t x_stride,

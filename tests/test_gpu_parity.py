@@ -282,3 +282,22 @@ def test_sharded_hip_backend_two_virtual_ranks(E, orc):
             recv = torch.cat([sends[p][r * Bl:(r + 1) * Bl].reshape(-1) for p in range(world)])
             R = op.finish((None, recv, Bg, Bl, out_splits), x[r * Bl:(r + 1) * Bl], lS_o, lS_i)
             assert torch.equal(R, want[r * Bl:(r + 1) * Bl]), (policy, r)
+
+
+def test_fused_one_index_per_bag_fast_path(E):
+    """offsets == NULL (Criteo: offsets = arange) gives the same bits as the general path."""
+    from bench import KAGGLE_LN, make_tables
+    ln = [min(n, 5000) for n in KAGGLE_LN]
+    ev = make_tables(ln, 36, seed=2)
+    B = 777
+    g = torch.Generator(device="cuda").manual_seed(1)
+    idx = torch.stack([torch.randint(0, n, (B,), device="cuda", generator=g) for n in ln])
+    off = torch.arange(B, device="cuda").repeat(26, 1)
+    x = torch.rand(B, 36, device="cuda")
+    a = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
+    b = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True, check_indices=True)
+    assert torch.equal(a, b)
+    idx[3, 5] = ln[3]  # out of range is still reported
+    E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))

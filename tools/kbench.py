@@ -47,6 +47,8 @@ def main():
         ly_tab = E.apply_emb(batches[0][0], batches[0][1], ev, None)
         i_tab = timeit(lambda i: E.interact_features(x, ly_tab), a.iters)
         f_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev), a.iters)
+        f1_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev, one_index_per_bag=True), a.iters)
+        print("B=%6d  fused, one index per bag   %7.1f us (%.2f G lookups/s)" % (B, f1_us, 26 * B / f1_us / 1e3))
         fb = B * (26 * (4 * d + 16) + 4 * d + 4 * (d + 351)) / 1e3
         print("B=%6d  fused gather+interact %7.1f us (%5.0f GB/s algorithmic, %.2f G lookups/s)" % (B, f_us, fb / f_us, 26 * B / f_us / 1e3))
         if a.fused_only:
