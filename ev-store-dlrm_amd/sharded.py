@@ -114,7 +114,8 @@ class HipBackend:
                     f.src, f.stride = v.data_ptr(), int(v.stride(0)) if B > 1 else d
                 else:
                     _, k, idx, off, nnz, off_len = s
-                    f.src, f.indices, f.offsets = ev.raw[k].data_ptr(), idx.data_ptr(), off.data_ptr()
+                    f.src, f.indices = ev.raw[k].data_ptr(), idx.data_ptr()
+                    f.offsets = off.data_ptr() if off is not None else None
                     f.nnz, f.n_rows, f.offsets_len = int(nnz), ev.n_rows[k], int(off_len)
             ent = (feats, specs if out is not None else None)   # keep the list alive only when it can recur
             if out is not None:
@@ -135,9 +136,11 @@ class ShardedEmbeddingInteract:
     """
 
     def __init__(self, ln_emb, d, rank, world, local_weights, backend, policy="rows+replicate",
-                 replicate_max_rows=1_000_000, group=None, itself=False):
+                 replicate_max_rows=1_000_000, group=None, itself=False, one_index_per_bag=False):
         self.ln_emb, self.d, self.rank, self.world = list(ln_emb), int(d), rank, world
         self.group, self.itself, self.backend = group, itself, backend
+        # lS_o[k] == arange(B) for every table (Criteo collate): replicated tables skip the offsets stage
+        self.one_index_per_bag = one_index_per_bag
         self.owner = plan_placement(ln_emb, world, policy, replicate_max_rows)
         self.own = [[t for t in range(len(ln_emb)) if self.owner[t] == r] for r in range(world)]
         self.my_own = self.own[rank]
@@ -207,8 +210,10 @@ class ShardedEmbeddingInteract:
                     specs[t] = ("dense", block[:, j, :])
             pos += out_splits[p]
         for t in self.replicated:  # looked up locally, only for this rank's samples
-            off = lS_o[t]
-            specs[t] = ("indirect", self.local_id[t], lS_i[t], off[b0:], int(lS_i[t].numel()), Bg - b0)
+            if self.one_index_per_bag:
+                specs[t] = ("indirect", self.local_id[t], lS_i[t][b0:], None, Bg - b0, 0)
+            else:
+                specs[t] = ("indirect", self.local_id[t], lS_i[t], lS_o[t][b0:], int(lS_i[t].numel()), Bg - b0)
         return self.backend.interact_mixed(x_local, specs, self.ev, self.d, self.itself, out=out)
 
     # ---- pre-planned steady state: all per-batch Python (views, pointer tables) done once -------------
@@ -230,7 +235,10 @@ class ShardedEmbeddingInteract:
                     specs[t] = ("dense", block[:, j, :])
             pos += out_splits[p]
         for t in self.replicated:
-            specs[t] = ("indirect", self.local_id[t], lS_i[t], lS_o[t][b0:], int(lS_i[t].numel()), Bg - b0)
+            if self.one_index_per_bag:
+                specs[t] = ("indirect", self.local_id[t], lS_i[t][b0:], None, Bg - b0, 0)
+            else:
+                specs[t] = ("indirect", self.local_id[t], lS_i[t], lS_o[t][b0:], int(lS_i[t].numel()), Bg - b0)
         return {"send": send, "recv": recv, "in": in_splits, "out": out_splits, "specs": specs, "x": x_local,
                 "R": out, "ids": [self.local_id[t] for t in self.my_own],
                 "lo": [lS_o[t] for t in self.my_own], "li": [lS_i[t] for t in self.my_own]}
@@ -272,7 +280,7 @@ def bench_sharded(args, ln_emb, rank, world, dev):
         g.manual_seed(1000 + t)
         a = float(np.sqrt(1.0 / ln_emb[t]))
         weights[t] = torch.empty((ln_emb[t], d), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
-    op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy)
+    op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy, one_index_per_bag=True)
     # every rank generates the same full-batch indices (same seed), as the reference feeds them
     g.manual_seed(7)
     nb = 4

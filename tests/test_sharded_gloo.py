@@ -35,6 +35,9 @@ class OracleBackend:
                 ly.append(s[1].numpy().copy())
             else:
                 _, k, idx, off, nnz, off_len = s
+                if off is None:  # one index per bag: bag b = idx[b]
+                    ly.append(ev[k][idx.numpy()[:B]].copy())
+                    continue
                 off = off.numpy()
                 assert off_len == off.shape[0]
                 # slice semantics of evs_feature.offsets_len: bag b ends at off[b+1] while it exists
