@@ -11,7 +11,16 @@ root, prec, total = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 layers = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc  # noqa: E402
-from evstore_dlrm_amd.cache_algo import cpp_socket_client as cli  # noqa: E402
+
+# plain ctypes, exactly the binding of cache_algo/cpp_socket_client.py:69-83 (no torch import: fast child)
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = ctypes.CDLL(os.path.join(_root, "ev-store-dlrm_amd", "lib", "libevstore_hip.so"))
+L.ev_lookup.argtypes = [ctypes.POINTER(ctypes.c_int)]
+L.ev_lookup.restype = ctypes.POINTER(ctypes.c_float)
+L.get_ev_values.argtypes = [ctypes.POINTER(ctypes.c_int)]
+L.get_ev_values.restype = ctypes.POINTER(ctypes.c_float)
+L.evs_manager_perfect_hit.restype = ctypes.c_longlong
+L.evs_manager_aprx_hit.restype = ctypes.c_longlong
 
 reqs = np.load(os.path.join(root, "reqs.npy"))
 raws = [np.fromfile(os.path.join(root, {32: "ev-table", 16: "ev-table-16", 8: "ev-table-8", 4: "ev-table-4"}[prec],
@@ -26,7 +35,6 @@ os.environ["EVS_SECONDARY_PRECISION"] = "4"
 if layers == 3:
     os.environ["EVS_ALTKEY_DIR"] = os.path.join(root, "altkeys")
     os.environ["EVS_SIZE_PROPORTION"] = "40-40-20"
-cli.init_ctypes_lib()
 fp32_tabs = [orc.decode(r, prec, 36) for r in raws]
 if layers >= 2:
     raws4 = [np.fromfile(os.path.join(root, "ev-table-4", "binary", "ev-table-%d.bin" % (k + 1)), np.uint8).reshape(-1, 18)
@@ -42,18 +50,19 @@ else:
 perfect = 0
 ok = True
 for i, rq in enumerate(reqs):
-    ly = cli.request_to_cpp_cache([int(v) for v in rq])
+    ptr = L.ev_lookup((ctypes.c_int * 26)(*[int(v) for v in rq]))
+    if not ptr:
+        print("ev_lookup returned NULL"); break
+    got = np.ctypeslib.as_array(ptr, shape=(26, 36)).copy()
     if layers >= 2:
         _, vals, p = o.request(rq)
         perfect += p
     else:
         hit, vals = o.request(rq)
         perfect += int(hit.all())
-    got = np.stack([t.numpy()[0] for t in ly])
     if not np.array_equal(got.view(np.uint32), vals.view(np.uint32)):
         ok = False
         break
-L = cli.cache_manager_cpp
 same_buf = ctypes.addressof(L.get_ev_values(None).contents) == ctypes.addressof(
     L.ev_lookup((ctypes.c_int * 26)(*[int(v) for v in reqs[0]])).contents)
 counter = int(L.evs_manager_perfect_hit())

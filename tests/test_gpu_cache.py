@@ -373,3 +373,26 @@ def test_three_tier_c1c2c3_vs_oracle(E, orc):
     st, so = c3.stats(), o.c3_state()
     assert st == so and st["n_hit"] > 50 and st["error"] == 0
     assert (tiers == 3).sum() == st["n_hit"]
+
+
+def test_zz_cpp_socket_client_mirror(E, orc, tmp_path):
+    """request_to_cpp_cache / print_n_reset_perfect_hit of the ctypes client mirror, in-process
+    (the cache manager is a process-wide singleton: this test runs last in this file)."""
+    from evstore_dlrm_amd.cache_algo import cpp_socket_client as cli
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    (tmp_path / "ev-table" / "binary").mkdir(parents=True)
+    for k, w in enumerate(tabs):
+        w.tofile(tmp_path / "ev-table" / "binary" / ("ev-table-%d.bin" % (k + 1)))
+    cli.init_ctypes_lib(ev_table_root=str(tmp_path), main_precision=32, total_size=300)
+    o = orc.EvLFU(300, tabs, variant="cpp")
+    perfect = 0
+    for rq in t["requests"][:150]:
+        ly = cli.request_to_cpp_cache([int(v) for v in rq])
+        hit, vals = o.request(rq)
+        perfect += int(hit.all())
+        assert len(ly) == 26 and ly[0].shape == (1, 36)
+        assert np.array_equal(np.stack([v.numpy()[0] for v in ly]), vals)
+    assert int(cli.cache_manager_cpp.evs_manager_perfect_hit()) == perfect
+    cli.print_n_reset_perfect_hit()
+    assert int(cli.cache_manager_cpp.evs_manager_perfect_hit()) == 0
