@@ -801,6 +801,27 @@ __device__ __forceinline__ int block_reserve(int *counter, bool flag, int *s_tot
     return s_tot[nw] + s_tot[wave] + rank;
 }
 
+// Same with a per-thread COUNT: thread gets the base index of its n consecutive tickets.
+__device__ __forceinline__ int block_reserve_n(int *counter, int n, int *s_tot /* >= 8 ints of LDS */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    __syncthreads();
+    if (lane == 63) s_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < nw; w++) { const int c = s_tot[w]; s_tot[w] = tot; tot += c; }
+        s_tot[nw] = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    return s_tot[nw] + s_tot[wave] + incl - n;
+}
+
 // K1: one 32-lane half-wave per request (T <= 32): probe, agg_hit by ballot, priority bump, miss record,
 // and the address of every key's row (table-major (T,B) pointer table consumed by the fused
 // interaction kernel in pointer mode, or by cache_rows_from_ptrs_kernel when the rows are wanted).
@@ -925,10 +946,19 @@ __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs a
         if ((int)threadIdx.x < w) { s_h[threadIdx.x] += s_h[threadIdx.x + w]; s_p[threadIdx.x] += s_p[threadIdx.x + w]; }
         __syncthreads();
     }
-    __shared__ int cnt[kMaxBuckets];
-    if ((int)threadIdx.x <= T) cnt[threadIdx.x] = b->cnt[threadIdx.x];  // one parallel fetch, not T serial ones
+    // the state block is fetched by all threads at once and written back the same way: thread 0 works in LDS
+    __shared__ BatchState sb;
+    {
+        const int nw = (int)(sizeof(BatchState) / sizeof(int));
+        int *dst = reinterpret_cast<int *>(&sb);
+        const int *src = reinterpret_cast<const int *>(args.bs);
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+    }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    b = &sb;
+    if (threadIdx.x == 0) {
+    int cnt[kMaxBuckets];  // planning copy: the real histogram is updated by the evict / assign kernels
+    for (int p = 0; p <= T; p++) cnt[p] = sb.cnt[p];
     b->n_hits += s_h[0]; b->n_perfect_hits += s_p[0];
     b->pstar = -1; b->rem = 0; b->ticket = 0; b->flush_t = 0; b->ticket_t = 0;
     if (cnt[T] >= args.max_perfect && b->n_new > 0) {  // EvLFU flush (EvLFU_C1.py:36-44), once per batch
@@ -950,39 +980,65 @@ __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs a
         b->n_evict += need;
     }
     b->do_rebuild = (b->n_tomb + (need > 0 ? need : 0) + b->flush_t) > args.nslot / 4;
+    }
+    __syncthreads();
+    {
+        const int nw = (int)(sizeof(BatchState) / sizeof(int));
+        const int *src = reinterpret_cast<const int *>(&sb);
+        int *dst = reinterpret_cast<int *>(args.bs);
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+    }
 }
 
 // K4: evict every entry below the cut, `rem` entries at the cut, `flush_t` entries of the top priority.
+// Each thread owns kEvictPerThread consecutive entries per pass so that the three shared counters
+// (two ticket counters, the free-stack top) see one atomic per 2048 entries, not one per entry.
+constexpr int kEvictPerThread = 8;
 __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs args) {
     __shared__ int s_tot[8];
     __shared__ int s_delta[kMaxBuckets];
     BatchState *b = args.bs;
     const int pstar = b->pstar, rem = b->rem, flush_t = b->flush_t, T = args.T;
-    if (pstar < 0 && flush_t == 0) return;  // uniform: read before any thread changes it (nothing in this kernel does)
+    if (pstar < 0 && flush_t == 0) return;  // uniform: nothing in this kernel changes these three
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
     __syncthreads();
-    const int stride = gridDim.x * blockDim.x;
-    const int iters = (args.cap + stride - 1) / stride;
-    for (int it = 0; it < iters; it++) {
-        const int e = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool live = e < args.cap && args.a.ekey[e] != kEmpty;
-        const int p = live ? args.a.eagg[e] : -1;
-        bool victim = false;
-        // tickets are handed out per block: one atomic per block and pass, not one per entry
-        const bool want_t = live && p == T && flush_t > 0;
-        const int tk_t = block_reserve(&b->ticket_t, want_t, s_tot);
-        if (want_t && tk_t < flush_t) victim = true;
-        const bool want_c = live && !victim && pstar >= 0 && p == pstar;
-        const int tk_c = block_reserve(&b->ticket, want_c, s_tot);
-        if (want_c && tk_c < rem) victim = true;
-        if (live && !victim && pstar >= 0 && p < pstar) victim = true;
-        const int fi = block_reserve(&b->n_free, victim, s_tot);
-        if (victim) {
-            args.a.keys[args.eslot[e]] = kTomb;
-            args.a.ekey[e] = kEmpty;
-            atomicSub(&s_delta[p], 1);
-            args.a.free_stack[fi] = e;
+    const long long per_pass = (long long)gridDim.x * blockDim.x * kEvictPerThread;
+    const int passes = (int)((args.cap + per_pass - 1) / per_pass);
+    for (int it = 0; it < passes; it++) {
+        const long long e0 = it * per_pass + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * kEvictPerThread;
+        int prio[kEvictPerThread];
+        int n_t = 0, n_c = 0;
+#pragma unroll
+        for (int j = 0; j < kEvictPerThread; j++) {
+            const long long e = e0 + j;
+            prio[j] = (e < args.cap && args.a.ekey[e] != kEmpty) ? args.a.eagg[e] : -1;
+            n_t += (prio[j] == T && flush_t > 0);
         }
+        int tk_t = block_reserve_n(&b->ticket_t, n_t, s_tot);
+        unsigned victim = 0;
+#pragma unroll
+        for (int j = 0; j < kEvictPerThread; j++)
+            if (prio[j] == T && flush_t > 0) { if (tk_t++ < flush_t) victim |= 1u << j; }
+#pragma unroll
+        for (int j = 0; j < kEvictPerThread; j++)
+            n_c += (prio[j] >= 0 && !((victim >> j) & 1) && pstar >= 0 && prio[j] == pstar);
+        int tk_c = block_reserve_n(&b->ticket, n_c, s_tot);
+#pragma unroll
+        for (int j = 0; j < kEvictPerThread; j++) {
+            if (prio[j] < 0 || ((victim >> j) & 1) || pstar < 0) continue;
+            if (prio[j] == pstar) { if (tk_c++ < rem) victim |= 1u << j; }
+            else if (prio[j] < pstar) victim |= 1u << j;
+        }
+        int fi = block_reserve_n(&b->n_free, __popc(victim), s_tot);
+#pragma unroll
+        for (int j = 0; j < kEvictPerThread; j++)
+            if ((victim >> j) & 1) {
+                const long long e = e0 + j;
+                args.a.keys[args.eslot[e]] = kTomb;
+                args.a.ekey[e] = kEmpty;
+                atomicSub(&s_delta[prio[j]], 1);
+                args.a.free_stack[fi++] = (int)e;
+            }
     }
     __syncthreads();
     int gone = 0;

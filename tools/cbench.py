@@ -3,5 +3,6 @@ sys.path.insert(0, '/root/repo')
 import bench, evstore_dlrm_amd as E
 dev = torch.device('cuda')
 ev = bench.make_tables(bench.KAGGLE_LN, 36)
-r = bench.cache_tier_section(ev, bench.KAGGLE_LN, 36, 16384, dev, steps=30, warmup=20)
-print("ms/step %.4f hit %.3f" % (r["ms_per_step"], r["hit_rate"]))
+for alpha in [float(a) for a in sys.argv[1:]] or [1.05]:
+    r = bench.cache_tier_section(ev, bench.KAGGLE_LN, 36, 16384, dev, steps=30, warmup=60, alpha=alpha, batch1=False)
+    print("alpha %.2f ms/step %.4f hit %.3f resident %d evictions %d" % (alpha, r["ms_per_step"], r["hit_rate"], r["resident_entries"], r["evictions"]))
