@@ -203,10 +203,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from evstore_dlrm_amd import sharded
         result = sharded.bench_sharded(args, KAGGLE_LN, rank, world, dev)
-        if rank == 0:
-            print(json.dumps(result))
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0:
+            # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            sys.stdout.flush()
+            print(json.dumps(result), flush=True)
         return
 
     B, d, T = args.batch, args.dim, len(KAGGLE_LN)

@@ -1,0 +1,69 @@
+"""CPU: host-side logic of the product package that needs no GPU -- storage manager readers over the
+reference's on-disk format, the host row decoders, placement planning, module surfaces."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle as orc
+
+
+def test_storage_manager_file_and_mmap_readers(tmp_path):
+    from evstore_dlrm_amd.emb_storage import storage_manager as sm
+    t = load_golden("cache_traces")
+    tabs = orc.kaggle_tables([int(n) for n in t["n_rows"]], int(t["table_seed"]))
+    (tmp_path / "binary").mkdir()
+    for k, w in enumerate(tabs):
+        w.tofile(tmp_path / "binary" / ("ev-table-%d.bin" % (k + 1)))
+    for st in (sm.EmbStorage.FILEPY, sm.EmbStorage.MMAPFILEPY, sm.EmbStorage.DUMMY):
+        sm.storage_type, sm.ev_precs = st, 32
+        sm.load_ev_table_into_emb_stor(str(tmp_path))
+        for (tb, r), want in zip(t["reader_probe"], t["reader_rows"]):
+            assert np.array_equal(np.asarray(sm.get_val_from_storage(int(tb), int(r)), np.float32), want)
+        vals = sm.get_arr_val_from_storage([[1, 0], [26, 17]])
+        assert len(vals) == 2 and len(vals[0]) == 36
+        _, ly = sm.request_to_emb_storage([int(v) for v in t["requests"][0]])
+        assert len(ly) == 26 and tuple(ly[0].shape) == (1, 36) and ly[0].requires_grad
+        assert np.array_equal(ly[5].detach().numpy()[0], tabs[5][t["requests"][0][5]])
+        sm.close_any_db_conn()
+
+
+@pytest.mark.parametrize("bits", [16, 8, 4])
+def test_host_row_decoders_match_oracle(tmp_path, bits):
+    from evstore_dlrm_amd import codecs_host
+    from evstore_dlrm_amd.emb_storage import storage_manager as sm
+    rs = np.random.RandomState(bits)
+    w = rs.uniform(-1, 1, size=(40, 36)).astype(np.float32)
+    raw = orc.encode_table(w, bits)
+    want = orc.decode(raw, bits, 36)
+    for r in range(40):
+        got = codecs_host.decode_row(raw[r].tobytes(), bits, 36)
+        assert np.array_equal(got.view(np.uint32), want[r].view(np.uint32))
+    # and through the storage manager with a reduced-precision store
+    (tmp_path / "binary").mkdir()
+    for k in range(26):
+        raw.tofile(tmp_path / "binary" / ("ev-table-%d.bin" % (k + 1)))
+    sm.storage_type, sm.ev_precs = sm.EmbStorage.FILEPY, bits
+    sm.load_ev_table_into_emb_stor(str(tmp_path))
+    assert np.array_equal(np.asarray(sm.get_val_from_storage(3, 7), np.float32).view(np.uint32), want[7].view(np.uint32))
+    sm.close_any_db_conn()
+    sm.ev_precs = 32
+
+
+def test_unsupported_storage_type_exits():
+    from evstore_dlrm_amd.emb_storage import storage_manager as sm
+    sm.storage_type = sm.EmbStorage.ROCKSDB
+    with pytest.raises(SystemExit):
+        sm.load_ev_table_into_emb_stor("/nonexistent")
+    sm.storage_type = sm.EmbStorage.DUMMY
+
+
+def test_fused_supported_shapes_and_module_surface():
+    import evstore_dlrm_amd as E
+    from evstore_dlrm_amd import dlrm_ops, evstore_ops
+    from evstore_dlrm_amd.cache_algo import EvLFU_C1, LRU, LFU, cpp_socket_client
+    assert dlrm_ops.fused_supported(27, 36) and dlrm_ops.fused_supported(9, 16) and not dlrm_ops.fused_supported(33, 36)
+    assert not dlrm_ops.fused_supported(27, 20)
+    for mod, fn in ((EvLFU_C1, "request_to_ev_lfu"), (LRU, "request_to_lru"), (LFU, "request_to_lfu")):
+        assert callable(getattr(mod, "init")) and callable(getattr(mod, fn))
+    assert callable(evstore_ops.apply_emb_evstore) and callable(cpp_socket_client.request_to_cpp_cache)
+    assert E._lib.lib().evs_fused_dim_supported(36) == 1 and E._lib.lib().evs_fused_dim_supported(40) == 0

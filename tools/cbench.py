@@ -1,5 +1,6 @@
 import sys, torch, time
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, evstore_dlrm_amd as E
 dev = torch.device('cuda')
 ev = bench.make_tables(bench.KAGGLE_LN, 36)
