@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libevstore_hip.so")
+LIB_PATH = os.environ.get("EVS_LIB_PATH") or os.path.join(_HERE, "lib", "libevstore_hip.so")  # env: developer A/B builds
 _lib = None
 
 EVS_OK, EVS_EINVAL, EVS_EHIP, EVS_EINDEX, EVS_ENOMEM, EVS_ESTATE, EVS_EIO = 0, -1, -2, -3, -4, -5, -6

@@ -392,13 +392,25 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
 // from LDS with ds_read_b128 (row stride 144 B: the 16 rows of a tile land on distinct banks).
 // Row addresses are computed in the MFMA mapping (lane = row) and handed to the DMA mapping
 // (lane = row piece) with one 64-bit shuffle per instruction.  The rows of sample k+1 are in
-// flight into the wave's LDS slot while the MFMAs and stores of sample k run; the row registers
-// are single-buffered (24 VGPRs instead of 48), so more waves fit per SIMD.
+// flight into the wave's LDS slot while the MFMAs of sample k run; the row registers are
+// single-buffered (24 VGPRs instead of 48), so more waves fit per SIMD.
+//
+// Output: the accumulator layout scatters a sample's packed triangle as 64-byte runs (12 store
+// instructions, ~70 partial-line write requests per sample -- more L2 write requests than the
+// whole gather has read requests; with them the kernel ran 94 us at B=65536, without any output
+// 58 us).  The row is therefore staged in a second per-wave LDS slot (ds_write_b32 from the
+// accumulators + the x passthrough copied from row 0 of the row slot) and leaves as contiguous
+// 16-byte-per-lane buffer stores one iteration LATER, right after the top-of-loop wait and before
+// the next sample's DMA is issued, so the write-acks overlap the MFMAs like the row fetch does
+// (78 us).  Rows >= F of the 16*NT-row tile are never fetched (their products are never stored).
 // ------------------------------------------------------------------------------------------
 // BAG1: every indirect feature has exactly one index per bag and no offsets array (the Criteo collate,
 // dlrm_data_pytorch.py:407-408: offsets = arange) -- the offsets stage of the pipeline disappears.
+#ifndef EVS_LB
+#define EVS_LB 4
+#endif
 template <int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1>
-__global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_kernel(const FusedArgs args) {
+__global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb_interact_dot_lds_kernel(const FusedArgs args) {
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
     constexpr int d = 4 * (4 * CQ + REM);
@@ -408,6 +420,9 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_k
     constexpr int NINSTR = (NROWS + RPI - 1) / RPI;
     constexpr int row_bytes = d * 4;
     __shared__ __attribute__((aligned(16))) char s_rows[4][NINSTR * 1024];
+    // output row of one sample (x passthrough + packed triangle), staged so it leaves as contiguous stores
+    constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
+    __shared__ __attribute__((aligned(16))) float s_out[4][OUT_MAX + 16];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int r16 = lane & 15;
@@ -471,6 +486,32 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_k
 
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     char *my_lds = s_rows[wave_in_block];
+    float *my_out = s_out[wave_in_block];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {  // never-stored elements go to a dump slot past the row
+        zo00[v] = zo00[v] == kOob ? 4 * (OUT_MAX + r16) : zo00[v];
+        zo10[v] = zo10[v] == kOob ? 4 * (OUT_MAX + r16) : zo10[v];
+        zo11[v] = zo11[v] == kOob ? 4 * (OUT_MAX + r16) : zo11[v];
+    }
+    auto flush_out = [&](int64_t bp) {
+        float *Rb = args.R + bp * (int64_t)out_row;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, out_row * 4, 0x00020000);
+        const int n4 = out_row >> 2;   // whole 16-byte pieces; the 0..3 trailing floats go as dwords
+#pragma unroll
+        for (int h = 0; h < (OUT_MAX + 255) / 256; h++) {
+            if (h * 64 < n4) {
+                const int e4 = lane + 64 * h;
+                const float4 v = reinterpret_cast<const float4 *>(my_out)[e4 < n4 ? e4 : 0];
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, 0);
+            }
+        }
+        if (out_row & 3) {
+            const int e = 4 * n4 + (lane & 3);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, 0);
+        }
+    };
     const int64_t waves_total = (int64_t)gridDim.x * 4;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave_in_block;
     if (wave_id >= B) return;
@@ -558,15 +599,13 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_k
         if constexpr (NR == 2) pub = (q == 1) ? (unsigned long long)rowp[1] : pub;
 #pragma unroll
         for (int j = 0; j < NINSTR; j++) {
+            if (j * RPI >= F) break;   // rows >= F only feed accumulator elements that are never stored
             const unsigned long long p = __shfl(pub, dma_src[j] < 0 ? 0 : dma_src[j]);
             const char *g = dma_src[j] < 0 ? zeros_l : reinterpret_cast<const char *>(p) + dma_piece * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                              (__attribute__((address_space(3))) void *)(my_lds + j * 1024), 16, 0, 0);
         }
     };
-
-    const float *x_base = reinterpret_cast<const float *>(args.src[0]);
-    const int64_t x_stride = args.stride[0];
 
     // ---- prologue ---------------------------------------------------------------------
     issue_off(0);
@@ -594,17 +633,17 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_k
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) { st0[rr] = HAS_INDIRECT ? st1[rr] : 0; len0[rr] = HAS_INDIRECT ? len1[rr] : 0; w0[rr] = w1[rr]; }
         // the LDS slot is free again once the reads above have returned
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (k + 1 < n_samples) issue_rows(k + 1);
-        issue_idx(k + 2);
-        issue_off(k + 3);
-
-        float xv[(d + 63) / 64];
+        float xv[(d + 63) / 64];   // x[b] is row 0 of the slot
 #pragma unroll
         for (int h = 0; h < (d + 63) / 64; h++) {
             const int e = lane + 64 * h;
-            xv[h] = x_base[b * x_stride + (e < d ? e : 0)];
+            xv[h] = reinterpret_cast<const float *>(my_lds)[e < d ? e : 0];
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (k > 0) flush_out(b - waves_total);   // sample k-1 leaves while sample k+1 arrives
+        if (k + 1 < n_samples) issue_rows(k + 1);
+        issue_idx(k + 2);
+        issue_off(k + 3);
         if constexpr (WEIGHTED) {
 #pragma unroll
             for (int rr = 0; rr < NR; rr++)
@@ -643,6 +682,10 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_k
             }
         }
 
+#ifdef EVS_X_NOCOMPUTE  // developer A/B (tools/variants.sh): the gather + LDS staging alone
+        if (a[0][0].x == 123.456f) args.R[b] = xv[0];
+        continue;
+#endif
         f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -667,22 +710,27 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : 4)) emb_interact_dot_lds_k
                 }
             }
         }
-        float *Rb = args.R + b * (int64_t)out_row;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, out_row * 4, 0x00020000);
+#ifdef EVS_X_NOSTORE  // developer A/B (tools/variants.sh): everything but the output traffic
+        if (c00[0] + c10[1] + c11[2] + c00[3] + c10[0] + c11[1] + c00[2] + c10[3] + c11[0] + c00[1] + c10[2] + c11[3] == 123.456f)
+            args.R[b * (int64_t)out_row + lane] = xv[0];
+        continue;
+#endif
+        // stage the output row: x passthrough, then the packed lower triangle straight from the accumulators
 #pragma unroll
         for (int h = 0; h < (d + 63) / 64; h++) {
             const int e = lane + 64 * h;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv[h]), rs, e < d ? 4 * e : kOob, 0, 0);
+            my_out[e < d ? e : OUT_MAX + r16] = xv[h];
         }
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c00[v]), rs, zo00[v], 0, 0);
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00[v]) = c00[v];
             if constexpr (NT == 2) {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c10[v]), rs, zo10[v], 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c11[v]), rs, zo11[v], 0, 0);
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10[v]) = c10[v];
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11[v]) = c11[v];
             }
         }
     }
+    flush_out(wave_id + (int64_t)(n_samples - 1) * waves_total);
     if (bad) atomicOr(args.err, 1);
 }
 
