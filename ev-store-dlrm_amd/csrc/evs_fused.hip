@@ -175,6 +175,11 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
     int st2[NR], len2[NR];             // bag start/length of the sample whose index is in flight
     Stage sA, sB;
 
+    // every offsets array (and the dummy, >= B entries) has two readable entries around any bag
+    bool short_off = false;
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) short_off |= lf[rr].off_len < 2;
+    const bool pair_ok = !__any(short_off);
     auto sample_b = [&](int n) -> int64_t {
         const int64_t b = wave_id + (int64_t)n * waves_total;
         return b < B ? b : B - 1;  // past-the-end pipeline slots re-read the last sample
@@ -184,8 +189,15 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
             const int b = (int)sample_b(n);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {  // dense/idle lanes read a dummy offsets array
-                off0[rr] = lf[rr].off[b];
-                off1[rr] = lf[rr].off[(b + 1 < lf[rr].off_len) ? b + 1 : b];
+                if (pair_ok) {  // offsets[b], offsets[b+1] as ONE 16-byte load (the last bag reads [b-1], [b])
+                    const bool has_next = b + 1 < lf[rr].off_len;
+                    const longlong2 v = *reinterpret_cast<const longlong2 *>(lf[rr].off + (has_next ? b : b - 1));
+                    off0[rr] = has_next ? v.x : v.y;
+                    off1[rr] = v.y;
+                } else {
+                    off0[rr] = lf[rr].off[b];
+                    off1[rr] = lf[rr].off[(b + 1 < lf[rr].off_len) ? b + 1 : b];
+                }
             }
         }
     };
@@ -520,10 +532,16 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
 
     int64_t off0[NR], off1[NR];
     int64_t idx_raw[NR];
-    int st2[NR], len2[NR];
-    int st1[NR], len1[NR];    // bag of the sample whose rows are in LDS / in flight
+    // per-feature bag facts travel through the pipeline as wave masks (SGPRs), not per-lane registers:
+    // has = bag non-empty, more = bag longer than one index (the rare path re-reads its offsets)
+    unsigned long long has2[NR], more2[NR], more1[NR];
     float w1[NR];
 
+    // every offsets array (and the dummy, >= B entries) has two readable entries around any bag
+    bool short_off = false;
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) short_off |= lf[rr].off_len < 2;
+    const bool pair_ok = !__any(short_off);
     auto sample_b = [&](int n) -> int64_t {
         const int64_t b = wave_id + (int64_t)n * waves_total;
         return b < B ? b : B - 1;
@@ -532,9 +550,16 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
         if constexpr (HAS_INDIRECT && !BAG1) {
             const int b = (int)sample_b(n);
 #pragma unroll
-            for (int rr = 0; rr < NR; rr++) {
-                off0[rr] = lf[rr].off[b];
-                off1[rr] = lf[rr].off[(b + 1 < lf[rr].off_len) ? b + 1 : b];
+            for (int rr = 0; rr < NR; rr++) {  // dense/idle lanes read a dummy offsets array
+                if (pair_ok) {  // offsets[b], offsets[b+1] as ONE 16-byte load (the last bag reads [b-1], [b])
+                    const bool has_next = b + 1 < lf[rr].off_len;
+                    const longlong2 v = *reinterpret_cast<const longlong2 *>(lf[rr].off + (has_next ? b : b - 1));
+                    off0[rr] = has_next ? v.x : v.y;
+                    off1[rr] = v.y;
+                } else {
+                    off0[rr] = lf[rr].off[b];
+                    off1[rr] = lf[rr].off[(b + 1 < lf[rr].off_len) ? b + 1 : b];
+                }
             }
         }
     };
@@ -543,8 +568,8 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
             const int b = (int)sample_b(n);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {
-                st2[rr] = b;
-                len2[rr] = lf[rr].indirect ? 1 : 0;
+                has2[rr] = __ballot(lf[rr].indirect);
+                more2[rr] = 0;
                 idx_raw[rr] = lf[rr].idx[lf[rr].indirect ? b : 0];
             }
         } else if constexpr (HAS_INDIRECT) {
@@ -557,9 +582,10 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
                 const bool valid = (s0 >= 0) & (e0 >= s0) & (e0 <= nnz);
                 bad |= lf[rr].indirect & !valid;
                 const bool use = lf[rr].indirect & valid;
-                st2[rr] = use ? (int)s0 : 0;
-                len2[rr] = use ? (int)(e0 - s0) : 0;
-                const int64_t *ip = (len2[rr] > 0) ? lf[rr].idx + st2[rr] : args.dummy_i64;
+                const int len = use ? (int)(e0 - s0) : 0;
+                has2[rr] = __ballot(len > 0);
+                more2[rr] = __ballot(len > 1);
+                const int64_t *ip = (len > 0) ? lf[rr].idx + (int)s0 : args.dummy_i64;
                 idx_raw[rr] = *ip;
             }
         }
@@ -574,12 +600,11 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
             bool ok = true;
             if constexpr (HAS_INDIRECT) {
                 const bool in_range = PTRS ? idx_raw[rr] != 0 : (uint64_t)idx_raw[rr] < (uint64_t)lf[rr].n_rows;
-                const bool has = len2[rr] > 0;
+                const bool has = (has2[rr] >> lane) & 1;
                 if constexpr (!PTRS) bad |= lf[rr].indirect & has & !in_range;
                 ok = !lf[rr].indirect | (has & in_range);
                 mult = lf[rr].indirect ? (ok ? (unsigned)idx_raw[rr] : 0u) : mult;
-                st1[rr] = st2[rr];
-                len1[rr] = len2[rr];
+                more1[rr] = more2[rr];
             }
             const char *row = lf[rr].src + (uint64_t)mult * (uint64_t)lf[rr].scale;
             if constexpr (PTRS) {
@@ -628,10 +653,10 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
             for (int m = 0; m < REM; m++)
                 a[rr][CQ + m] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] - q * CQ * 16 + kRemOff + m * 16);
         }
-        int st0[NR], len0[NR];
+        unsigned long long more0[NR];
         float w0[NR];
 #pragma unroll
-        for (int rr = 0; rr < NR; rr++) { st0[rr] = HAS_INDIRECT ? st1[rr] : 0; len0[rr] = HAS_INDIRECT ? len1[rr] : 0; w0[rr] = w1[rr]; }
+        for (int rr = 0; rr < NR; rr++) { more0[rr] = HAS_INDIRECT ? more1[rr] : 0; w0[rr] = w1[rr]; }
         // the LDS slot is free again once the reads above have returned
         float xv[(d + 63) / 64];   // x[b] is row 0 of the slot
 #pragma unroll
@@ -654,14 +679,16 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
                 }
         }
         if constexpr (HAS_INDIRECT && !PTRS && !BAG1) {
-            bool more = false;
-#pragma unroll
-            for (int rr = 0; rr < NR; rr++) more |= len0[rr] > 1;
-            if (__any(more)) {  // bags longer than one index: remaining elements, in index order
+            if ((more0[0] | more0[NR - 1]) != 0) {  // bags longer than one index: remaining elements, in index order
 #pragma unroll
                 for (int rr = 0; rr < NR; rr++) {
-                    for (int j = 1; j < len0[rr]; j++) {
-                        const int64_t r = lf[rr].idx[st0[rr] + j];
+                    int64_t s0 = 0, e0 = 0;
+                    if ((more0[rr] >> lane) & 1) {  // offsets were validated when the mask was built
+                        s0 = lf[rr].off[b];
+                        e0 = (b + 1 < lf[rr].off_len) ? lf[rr].off[b + 1] : (int64_t)lf[rr].nnz;
+                    }
+                    for (int64_t j = s0 + 1; j < e0; j++) {
+                        const int64_t r = lf[rr].idx[j];
                         if ((uint64_t)r >= (uint64_t)lf[rr].n_rows) { bad = true; continue; }
                         const char *row = lf[rr].src + (uint64_t)(unsigned)r * (uint64_t)lf[rr].scale + q * CQ * 16;
                         float w = 1.0f;
