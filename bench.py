@@ -36,11 +36,18 @@ KAGGLE_LN = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 
 HBM_PEAK_GBPS = 8000.0  # MI355X datasheet HBM3E bandwidth (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
-def make_tables(ln_emb, d, seed=0, device="cuda"):
-    """Synthetic tables, U(-sqrt(1/n), sqrt(1/n)) fp32 (dlrm_s_pytorch.py:279-283), made on the GPU."""
+def make_tables(ln_emb, d, seed=0, device="cuda", bits=32):
+    """Synthetic tables, U(-sqrt(1/n), sqrt(1/n)) fp32 (dlrm_s_pytorch.py:279-283), made on the GPU.
+    bits 16/8/4: random codes in the reference's reduced-precision row layout (any code decodes)."""
     import evstore_dlrm_amd as E
     g = torch.Generator(device=device).manual_seed(seed)
     ws = []
+    if bits != 32:
+        hi = 15 if bits == 4 else 256   # u4: both nibbles in 0..14 (the 15-entry table)
+        for n in ln_emb:
+            c = torch.randint(0, hi, (n, d * bits // 8), device=device, generator=g, dtype=torch.uint8)
+            ws.append(c | (torch.randint(0, 15, c.shape, device=device, generator=g, dtype=torch.uint8) << 4) if bits == 4 else c)
+        return E.EVTables(ws, d, bits)
     for n in ln_emb:
         a = float(np.sqrt(1.0 / n))
         ws.append(torch.empty((n, d), dtype=torch.float32, device=device).uniform_(-a, a, generator=g))

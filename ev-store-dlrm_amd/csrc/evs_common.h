@@ -61,6 +61,49 @@ __device__ __constant__ const float kU4Lut[16] = {
     1.0f, 0.8f, 0.6f, 0.4f, 0.0625f, 0.00390625f, 0.0000153f, 0.0f,
     -0.0000153f, -0.00390625f, -0.0625f, -0.4f, -0.6f, -0.8f, -1.0f, __builtin_nanf("")};
 
+// Decode through a per-block LDS table: u8 -> all 256 values (the exact expression above has an
+// IEEE division per element), u4 -> the 16 entries (a per-lane index into __constant__ memory is a
+// vector-memory gather), u16 -> the 536 magnitudes of the v > 65000 tail (the division again); the
+// u16 main range stays arithmetic (two fp64 ops).
+template <int CODEC> struct CodecLut { static constexpr int kEntries = 1; };
+template <> struct CodecLut<16> { static constexpr int kEntries = 536; };
+template <> struct CodecLut<8> { static constexpr int kEntries = 256; };
+template <> struct CodecLut<4> { static constexpr int kEntries = 16; };
+
+// every thread of the block calls this, then __syncthreads()
+template <int CODEC>
+__device__ __forceinline__ void codec_lut_init(float *lut) {
+    for (int i = threadIdx.x; i < CodecLut<CODEC>::kEntries; i += blockDim.x) {
+        if constexpr (CODEC == 8) lut[i] = dec_u8((unsigned)i);
+        else if constexpr (CODEC == 4) lut[i] = kU4Lut[i];
+        else if constexpr (CODEC == 16) lut[i] = (float)__dadd_rn(0.65, (double)__fdiv_rn((float)i, 100.0f));
+        else lut[i] = 0.f;
+    }
+}
+template <int CODEC>
+__device__ __forceinline__ float dec_code(unsigned v, const float *lut) {
+    if constexpr (CODEC == 16) {
+        const bool tail = v > 65000u;
+        const float t = lut[tail ? v - 65000u : 0u];
+        const float m = (float)__dsub_rn(__dmul_rn((double)(float)v, 0.00002), 0.65);
+        return tail ? ((v & 1u) ? -t : t) : m;
+    } else {
+        return lut[v];
+    }
+}
+// one chunk = 4 consecutive elements: 8 / 4 / 2 raw bytes in w0 (and w1 for u16)
+template <int CODEC>
+__device__ __forceinline__ float4 dec_chunk(unsigned w0, unsigned w1, const float *lut) {
+    if constexpr (CODEC == 16) {
+        return make_float4(dec_code<16>(w0 & 0xffffu, lut), dec_code<16>(w0 >> 16, lut),
+                           dec_code<16>(w1 & 0xffffu, lut), dec_code<16>(w1 >> 16, lut));
+    } else if constexpr (CODEC == 8) {
+        return make_float4(lut[w0 & 0xffu], lut[(w0 >> 8) & 0xffu], lut[(w0 >> 16) & 0xffu], lut[(w0 >> 24) & 0xffu]);
+    } else {  // u4: element 2j is the HIGH nibble of byte j (script/reduce_precision.py:321)
+        return make_float4(lut[(w0 >> 4) & 15u], lut[w0 & 15u], lut[(w0 >> 12) & 15u], lut[(w0 >> 8) & 15u]);
+    }
+}
+
 // XCD-aware split of `n_items` (ordered so that neighbours share data, e.g. table-major)
 // over the grid: blocks b and b+8 share an XCD (and its 4 MiB L2), so XCD x owns the
 // contiguous item range [x*n/8, (x+1)*n/8) and its blocks stride through it.

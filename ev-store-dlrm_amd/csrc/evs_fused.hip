@@ -47,24 +47,31 @@ struct FusedArgs {
     const float *dummy_f32;
     const void *zeros;         // >= 1 KiB of zero bytes (idle lanes / empty bags read rows from it)
     int bag1;                  // every indirect feature: one index per bag, no offsets array
+    int enc_lds;               // reduced precision: feature 0 is x, every other feature a 4-byte aligned table
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// chunk = 4 consecutive elements of a row.  Reduced-precision chunks travel through the software
+// pipeline RAW (bits parked in .x/.y of the float4 slot) and are decoded when the sample is
+// consumed -- decoding at issue time would wait for the load and serialise the pipeline.
 template <int CODEC>
-__device__ __forceinline__ float4 load_chunk(const char *row, int chunk) {
+__device__ __forceinline__ float4 load_raw(const char *row, int chunk) {
     if constexpr (CODEC == 32) {
         return reinterpret_cast<const float4 *>(row)[chunk];
     } else if constexpr (CODEC == 16) {
         const uint2 v = reinterpret_cast<const uint2 *>(row)[chunk];
-        return make_float4(dec_u16(v.x & 0xffffu), dec_u16(v.x >> 16), dec_u16(v.y & 0xffffu), dec_u16(v.y >> 16));
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), 0.f, 0.f);
     } else if constexpr (CODEC == 8) {
-        const unsigned v = reinterpret_cast<const unsigned *>(row)[chunk];
-        return make_float4(dec_u8(v & 0xffu), dec_u8((v >> 8) & 0xffu), dec_u8((v >> 16) & 0xffu), dec_u8(v >> 24));
+        return make_float4(__uint_as_float(reinterpret_cast<const unsigned *>(row)[chunk]), 0.f, 0.f, 0.f);
     } else {
-        const unsigned v = reinterpret_cast<const unsigned short *>(row)[chunk];
-        return make_float4(kU4Lut[(v >> 4) & 15u], kU4Lut[v & 15u], kU4Lut[(v >> 12) & 15u], kU4Lut[(v >> 8) & 15u]);
+        return make_float4(__uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(row)[chunk]), 0.f, 0.f, 0.f);
     }
+}
+template <int CODEC>
+__device__ __forceinline__ float4 decode_raw(const float4 raw, const float *lut) {
+    if constexpr (CODEC == 32) return raw;
+    else return dec_chunk<CODEC>(__float_as_uint(raw.x), __float_as_uint(raw.y), lut);
 }
 
 // per-lane view of one row of T (one feature)
@@ -153,6 +160,12 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
         const int base = (gi * (gi - 1 + 2 * itself)) / 2;
         zo10[v] = (NT == 2 && gi < F) ? 4 * (d + base + r16) : kOob;
         zo11[v] = (NT == 2 && gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : kOob;
+    }
+
+    __shared__ float s_lut[CodecLut<CODEC>::kEntries];
+    if constexpr (CODEC != 32) {
+        codec_lut_init<CODEC>(s_lut);
+        __syncthreads();
     }
 
     // wave-uniform bookkeeping in SGPRs
@@ -254,9 +267,9 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
             } else {
                 if (lf[rr].indirect) {
 #pragma unroll
-                    for (int c = 0; c < CQ; c++) S.a[rr][c] = load_chunk<CODEC>(row, c);
+                    for (int c = 0; c < CQ; c++) S.a[rr][c] = load_raw<CODEC>(row, c);
 #pragma unroll
-                    for (int m = 0; m < REM; m++) S.a[rr][CQ + m] = load_chunk<CODEC>(row + rem_delta, m);
+                    for (int m = 0; m < REM; m++) S.a[rr][CQ + m] = load_raw<CODEC>(row + rem_delta, m);
                 } else {
 #pragma unroll
                     for (int c = 0; c < CQ; c++) S.a[rr][c] = reinterpret_cast<const float4 *>(row)[c];
@@ -290,8 +303,9 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
         for (int rr = 0; rr < NR; rr++)
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                if constexpr (HAS_INDIRECT && CODEC != 32) {
-                    if (!S.first[rr]) S.a[rr][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (HAS_INDIRECT && CODEC != 32) {  // decode now; dense lanes keep their fp32 chunk
+                    const float4 dv = decode_raw<CODEC>(S.a[rr][c], s_lut);
+                    if (lf[rr].indirect) S.a[rr][c] = S.first[rr] ? dv : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 if constexpr (WEIGHTED) {
                     S.a[rr][c].x = __fmul_rn(S.a[rr][c].x, S.w[rr]); S.a[rr][c].y = __fmul_rn(S.a[rr][c].y, S.w[rr]);
@@ -314,7 +328,7 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
                         if constexpr (WEIGHTED) { if (lf[rr].rw) w = lf[rr].rw[r]; }
 #pragma unroll
                         for (int c = 0; c < NC; c++) {
-                            float4 t = c < CQ ? load_chunk<CODEC>(row, c) : load_chunk<CODEC>(row + lf[rr].rem_delta, c - CQ);
+                            float4 t = decode_raw<CODEC>(c < CQ ? load_raw<CODEC>(row, c) : load_raw<CODEC>(row + lf[rr].rem_delta, c - CQ), s_lut);
                             if constexpr (WEIGHTED) {
                                 t.x = __fmul_rn(t.x, w); t.y = __fmul_rn(t.y, w);
                                 t.z = __fmul_rn(t.z, w); t.w = __fmul_rn(t.w, w);
@@ -353,6 +367,10 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
         }
         // one buffer resource per output row: base = R + b*out_row (SGPRs), bounds = one row
         float *Rb = args.R + b * (int64_t)out_row;
+#ifdef EVS_X_NOSTORE_REG
+        if (c00[0] + c10[1] + c11[2] + c00[3] + c10[0] + c11[1] + c00[2] + c10[3] + c11[0] + c00[1] + c10[2] + c11[3] == 123.456f) Rb[lane] = xv[0];
+        return;
+#endif
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, out_row * 4, 0x00020000);
 #pragma unroll
         for (int h = 0; h < (d + 63) / 64; h++) {
@@ -421,17 +439,49 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
 #ifndef EVS_LB
 #define EVS_LB 4
 #endif
-template <int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1>
-__global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb_interact_dot_lds_kernel(const FusedArgs args) {
+#ifndef EVS_LB_GEN
+#define EVS_LB_GEN 4
+#endif
+// resident blocks per CU the register allocator is asked to fit (more VGPRs per wave where the
+// pipeline state or the decode temporaries would otherwise spill)
+template <int CODEC, int CQ, bool BAG1>
+constexpr int lds_min_blocks() {
+    if (CQ >= 8) return 2;
+    if (CQ >= 4) return 3;
+    if (CODEC == 16) return 3;
+    if (CODEC != 32 && !BAG1) return 3;
+    return BAG1 ? EVS_LB : EVS_LB_GEN;
+}
+// CODEC != 32 (reduced-precision tables; feature 0 = x dense fp32, every other feature a table):
+// the slot holds x in its first KiB (one 16-byte-per-lane DMA) and the ENCODED rows packed dword by
+// dword behind it (4-byte-per-lane DMA: lane g of the phase moves dword g%RBd of table row g/RBd;
+// u4 rows, 2-byte aligned, travel as their enclosing aligned dword window and the half-word phase
+// rides along as a wave mask).  The MFMA operands are read as raw chunks (ds_read_u16/b32/b64) and
+// decoded through the per-block LDS table (evs_common.h) -- x chunks overwrite row 0 afterwards.
+template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1>
+__global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_interact_dot_lds_kernel(const FusedArgs args) {
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
     constexpr int d = 4 * (4 * CQ + REM);
-    constexpr int LPRD = d / 4;             // DMA lanes per row (16 B each)
-    constexpr int RPI = 64 / LPRD;          // rows per DMA instruction
+    constexpr int LPRD = d / 4;             // DMA lanes per fp32 row (16 B each)
+    constexpr int RPI = 64 / LPRD;          // fp32 rows per DMA instruction
     constexpr int NROWS = 16 * NT;
-    constexpr int NINSTR = (NROWS + RPI - 1) / RPI;
-    constexpr int row_bytes = d * 4;
+    constexpr bool ENC = CODEC != 32;
+    static_assert(!ENC || (HAS_INDIRECT && !PTRS), "encoded rows come from tables");
+    constexpr int enc_row_bytes = d * CODEC / 8;
+    // dwords DMA'd per encoded row (u4 rows that are not dword multiples: the aligned window around them)
+    constexpr int RBd = (enc_row_bytes % 4 == 0) ? enc_row_bytes / 4 : (enc_row_bytes + 2 + 3) / 4;
+    constexpr int NI2 = ((NROWS - 1) * RBd + 63) / 64;
+    constexpr int kEncBase = 1024;          // encoded rows start behind the x KiB
+    constexpr int kChunkBytes = CODEC / 2;  // 4 elements
+    constexpr int NINSTR = ENC ? 1 + (NI2 + 3) / 4 : (NROWS + RPI - 1) / RPI;   // slot size in KiB
+    constexpr int row_bytes = ENC ? enc_row_bytes : d * 4;
     __shared__ __attribute__((aligned(16))) char s_rows[4][NINSTR * 1024];
+    __shared__ float s_lut[CodecLut<CODEC>::kEntries];
+    if constexpr (ENC) {
+        codec_lut_init<CODEC>(s_lut);
+        __syncthreads();
+    }
     // output row of one sample (x passthrough + packed triangle), staged so it leaves as contiguous stores
     constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
     __shared__ __attribute__((aligned(16))) float s_out[4][OUT_MAX + 16];
@@ -469,9 +519,10 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
 
     // DMA mapping of this lane: for instruction j it moves piece dma_piece of row j*RPI + lane/LPRD
     const int dma_piece = lane % LPRD;
-    int dma_src[NINSTR];     // lane that holds the row address in the MFMA mapping, or -1
+    constexpr int NDMA = ENC ? 1 : NINSTR;
+    int dma_src[NDMA];     // lane that holds the row address in the MFMA mapping, or -1
 #pragma unroll
-    for (int j = 0; j < NINSTR; j++) {
+    for (int j = 0; j < NDMA; j++) {
         const int row = j * RPI + lane / LPRD;
         dma_src[j] = (lane < RPI * LPRD && row < NROWS) ? (row & 15) + 16 * (row >> 4) : -1;
     }
@@ -480,9 +531,10 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
 #pragma unroll
     for (int rr = 0; rr < NR; rr++) {
         const int row = r16 + 16 * rr;
-        lds_off[rr] = (row / RPI) * 1024 + (row % RPI) * row_bytes + q * CQ * 16;
+        if constexpr (ENC) lds_off[rr] = kEncBase + (row > 0 ? row - 1 : 0) * RBd * 4 + q * CQ * kChunkBytes;
+        else lds_off[rr] = (row / RPI) * 1024 + (row % RPI) * row_bytes + q * CQ * 16;
     }
-    constexpr int kRemOff = 4 * CQ * 16;  // from the row start
+    constexpr int kRemOff = 4 * CQ * (ENC ? kChunkBytes : 16);  // from the row start
 
     constexpr int kOob = 0x7ffffff0;
     int zo00[4], zo10[4], zo11[4];
@@ -535,6 +587,7 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
     // per-feature bag facts travel through the pipeline as wave masks (SGPRs), not per-lane registers:
     // has = bag non-empty, more = bag longer than one index (the rare path re-reads its offsets)
     unsigned long long has2[NR], more2[NR], more1[NR];
+    unsigned long long ok1[NR], sub1[NR];   // ENC: row present (else it decodes as zeros); u4 half-word phase
     float w1[NR];
 
     // every offsets array (and the dummy, >= B entries) has two readable entries around any bag
@@ -611,6 +664,12 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
                 if (lf[rr].indirect) row = reinterpret_cast<const char *>(idx_raw[rr]);
             }
             rowp[rr] = ok ? row : zeros_l;
+            if constexpr (ENC) {
+                ok1[rr] = __ballot(ok);
+                const bool odd = lf[rr].indirect & ok & (((uintptr_t)row & 2u) != 0);
+                sub1[rr] = __ballot(odd);
+                if (lf[rr].indirect) rowp[rr] = reinterpret_cast<const char *>((uintptr_t)rowp[rr] & ~(uintptr_t)3);
+            }
             w1[rr] = 1.0f;
             if constexpr (WEIGHTED) {
                 const bool has_w = lf[rr].indirect && lf[rr].rw;
@@ -622,13 +681,35 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
         // lanes of k-slot q publish the address of tile-row set q (rows 16q..16q+15)
         unsigned long long pub = (unsigned long long)rowp[0];
         if constexpr (NR == 2) pub = (q == 1) ? (unsigned long long)rowp[1] : pub;
+        if constexpr (ENC) {
+            {   // x: lanes 0..LPRD-1 move its d*4 bytes, the others park zeros behind it
+                const unsigned long long p = __shfl(pub, 0);
+                const char *g = lane < LPRD ? reinterpret_cast<const char *>(p) + lane * 16 : zeros_l;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)my_lds, 16, 0, 0);
+            }
+            const int n_dw = (F - 1) * RBd;
 #pragma unroll
-        for (int j = 0; j < NINSTR; j++) {
-            if (j * RPI >= F) break;   // rows >= F only feed accumulator elements that are never stored
-            const unsigned long long p = __shfl(pub, dma_src[j] < 0 ? 0 : dma_src[j]);
-            const char *g = dma_src[j] < 0 ? zeros_l : reinterpret_cast<const char *>(p) + dma_piece * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                             (__attribute__((address_space(3))) void *)(my_lds + j * 1024), 16, 0, 0);
+            for (int j = 0; j < NI2; j++) {
+                if (j * 64 >= n_dw) break;
+                const int gidx = j * 64 + lane;
+                const int f = 1 + gidx / RBd;
+                const int w = gidx - (f - 1) * RBd;
+                const bool on = gidx < n_dw;
+                const unsigned long long p = __shfl(pub, on ? (f & 15) + 16 * (f >> 4) : 0);
+                const char *g = on ? reinterpret_cast<const char *>(p) + 4 * w : zeros_l;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(my_lds + kEncBase + j * 256), 4, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NDMA; j++) {
+                if (j * RPI >= F) break;   // rows >= F only feed accumulator elements that are never stored
+                const unsigned long long p = __shfl(pub, dma_src[j] < 0 ? 0 : dma_src[j]);
+                const char *g = dma_src[j] < 0 ? zeros_l : reinterpret_cast<const char *>(p) + dma_piece * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(my_lds + j * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -645,13 +726,37 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
         // rows of sample k have landed once every outstanding vector-memory op has retired
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float4 a[NR][NC];
+        if constexpr (ENC) {
 #pragma unroll
-        for (int rr = 0; rr < NR; rr++) {
+            for (int rr = 0; rr < NR; rr++) {
+                const int sub = (int)((sub1[rr] >> lane) & 1) * 2;
+                const bool present = (ok1[rr] >> lane) & 1;
 #pragma unroll
-            for (int c = 0; c < CQ; c++) a[rr][c] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] + c * 16);
+                for (int c = 0; c < NC; c++) {
+                    const char *cp = my_lds + lds_off[rr] + sub +
+                                     (c < CQ ? c * kChunkBytes : -q * CQ * kChunkBytes + kRemOff + (c - CQ) * kChunkBytes);
+                    unsigned w0 = 0, w1r = 0;
+                    if constexpr (CODEC == 16) { const uint2 v = *reinterpret_cast<const uint2 *>(cp); w0 = v.x; w1r = v.y; }
+                    else if constexpr (CODEC == 8) w0 = *reinterpret_cast<const unsigned *>(cp);
+                    else w0 = *reinterpret_cast<const unsigned short *>(cp);
+                    const float4 dv = dec_chunk<CODEC>(w0, w1r, s_lut);
+                    a[rr][c] = present ? dv : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (r16 == 0) {   // row 0 is x: plain fp32 chunks from the first KiB
 #pragma unroll
-            for (int m = 0; m < REM; m++)
-                a[rr][CQ + m] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] - q * CQ * 16 + kRemOff + m * 16);
+                for (int c = 0; c < NC; c++)
+                    a[0][c] = *reinterpret_cast<const float4 *>(my_lds + (c < CQ ? (q * CQ + c) * 16 : 4 * CQ * 16 + (c - CQ) * 16));
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+                for (int c = 0; c < CQ; c++) a[rr][c] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] + c * 16);
+#pragma unroll
+                for (int m = 0; m < REM; m++)
+                    a[rr][CQ + m] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] - q * CQ * 16 + kRemOff + m * 16);
+            }
         }
         unsigned long long more0[NR];
         float w0[NR];
@@ -690,13 +795,13 @@ __global__ void __launch_bounds__(256, (CQ >= 8 ? 2 : CQ >= 4 ? 3 : EVS_LB)) emb
                     for (int64_t j = s0 + 1; j < e0; j++) {
                         const int64_t r = lf[rr].idx[j];
                         if ((uint64_t)r >= (uint64_t)lf[rr].n_rows) { bad = true; continue; }
-                        const char *row = lf[rr].src + (uint64_t)(unsigned)r * (uint64_t)lf[rr].scale + q * CQ * 16;
+                        const char *row = lf[rr].src + (uint64_t)(unsigned)r * (uint64_t)lf[rr].scale + q * CQ * (ENC ? kChunkBytes : 16);
                         float w = 1.0f;
                         if constexpr (WEIGHTED) { if (lf[rr].rw) w = lf[rr].rw[r]; }
 #pragma unroll
                         for (int c = 0; c < NC; c++) {
-                            float4 t = c < CQ ? reinterpret_cast<const float4 *>(row)[c]
-                                              : reinterpret_cast<const float4 *>(row - q * CQ * 16 + kRemOff)[c - CQ];
+                            float4 t = decode_raw<CODEC>(c < CQ ? load_raw<CODEC>(row, c)
+                                                                : load_raw<CODEC>(row - q * CQ * (ENC ? kChunkBytes : 16) + kRemOff, c - CQ), s_lut);
                             if constexpr (WEIGHTED) {
                                 t.x = __fmul_rn(t.x, w); t.y = __fmul_rn(t.y, w);
                                 t.z = __fmul_rn(t.z, w); t.w = __fmul_rn(t.w, w);
@@ -767,64 +872,41 @@ static bool use_lds_rows() {
     return v != 0;
 }
 
+// persistent grid: exactly the resident waves of THIS kernel, each walking its samples through the pipeline
+template <auto K>
+static void launch_persistent(const FusedArgs &a, hipStream_t st) {
+    static int per_cu = 0;
+    if (!per_cu) {
+        int n = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K, 256, 0);
+        per_cu = (e == hipSuccess && n > 0) ? n : 2;
+    }
+    int64_t blocks = (a.B + 3) / 4;
+    const int64_t cap = (int64_t)kNumCu * per_cu;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(K, dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+
 template <int CODEC, int CQ, int REM, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS>
 static void launch_nt(const FusedArgs &a, hipStream_t st) {
-    if constexpr (CODEC == 32 && (4 * CQ + REM) <= 32) {
-        if (use_lds_rows()) {
-            static int per_cu_l[2] = {0, 0};
-            const int ntl = a.F <= 16 ? 0 : 1;
-            if (!per_cu_l[ntl]) {
-                int n = 0;
-                hipError_t e = ntl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                         &n, emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, false>, 256, 0)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                         &n, emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, false>, 256, 0);
-                per_cu_l[ntl] = (e == hipSuccess && n > 0) ? n : 2;
-            }
-            int64_t blocks = (a.B + 3) / 4;
-            const int64_t cap = (int64_t)kNumCu * per_cu_l[ntl];
-            if (blocks > cap) blocks = cap;
-            const bool bag1 = HAS_INDIRECT && (PTRS || a.bag1);
+    const bool nt2 = a.F > 16;
+    // rows through LDS: fp32 always; reduced precision when feature 0 is x and every other feature a table
+    if constexpr ((4 * CQ + REM) <= 32 && (CODEC == 32 || (HAS_INDIRECT && !PTRS && !WEIGHTED))) {
+        if (use_lds_rows() && (CODEC == 32 || a.enc_lds)) {
             if constexpr (HAS_INDIRECT && !WEIGHTED) {
-                if (bag1) {
-                    if (ntl == 0)
-                        hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true>),
-                                           dim3((unsigned)blocks), dim3(256), 0, st, a);
-                    else
-                        hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>),
-                                           dim3((unsigned)blocks), dim3(256), 0, st, a);
+                if (PTRS || a.bag1) {
+                    if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
+                    else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
                     return;
                 }
             }
-            if (ntl == 0)
-                hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, false>),
-                                   dim3((unsigned)blocks), dim3(256), 0, st, a);
-            else
-                hipLaunchKernelGGL((emb_interact_dot_lds_kernel<CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, false>),
-                                   dim3((unsigned)blocks), dim3(256), 0, st, a);
+            if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, false>>(a, st);
+            else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, false>>(a, st);
             return;
         }
     }
-    // persistent grid: exactly the resident waves, each walking its samples through the pipeline
-    static int per_cu[2] = {0, 0};
-    const int nt = a.F <= 16 ? 0 : 1;
-    if (!per_cu[nt]) {
-        int n = 0;
-        hipError_t e = nt ? hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                &n, emb_interact_dot_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS>, 256, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                &n, emb_interact_dot_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS>, 256, 0);
-        per_cu[nt] = (e == hipSuccess && n > 0) ? n : 2;
-    }
-    int64_t blocks = (a.B + 3) / 4;
-    const int64_t cap = (int64_t)kNumCu * per_cu[nt];
-    if (blocks > cap) blocks = cap;
-    if (nt == 0)
-        hipLaunchKernelGGL((emb_interact_dot_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS>), dim3((unsigned)blocks),
-                           dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((emb_interact_dot_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS>), dim3((unsigned)blocks),
-                           dim3(256), 0, st, a);
+    if (nt2) launch_persistent<emb_interact_dot_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS>>(a, st);
+    else launch_persistent<emb_interact_dot_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS>>(a, st);
 }
 
 template <int CODEC, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS = false>
@@ -862,7 +944,7 @@ int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_
     }
     a.R = R; a.B = B; a.F = F; a.d = d; a.itself = itself ? 1 : 0;
     a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
-    a.dummy_i64 = iota; a.dummy_f32 = x; a.bag1 = 1;
+    a.dummy_i64 = iota; a.dummy_f32 = x; a.bag1 = 1; a.enc_lds = 0;
     if (!launch_cpq<32, false, true, true>(a, st)) { set_error("fused_interact_from_row_ptrs: no kernel for d=%d", d); return EVS_EINVAL; }
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
@@ -924,8 +1006,11 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
         for (int f = 0; f < F; f++) if (feats[f].indices) { n_ind++; if (!feats[f].offsets) n_nooff++; }
         EVS_REQUIRE(n_nooff == 0 || n_nooff == n_ind, "evs_emb_interact_dot: either every indirect feature has offsets or none (one index per bag)");
         a.bag1 = n_ind > 0 && n_nooff == n_ind;
+        a.enc_lds = codec != 32 && n_ind == F - 1;
+        for (int f = 1; f < F && a.enc_lds; f++)
+            a.enc_lds = feats[f].indices && !feats[f].row_weights && reinterpret_cast<uintptr_t>(feats[f].src) % 4 == 0;
         if (a.bag1) {
-            EVS_REQUIRE(codec == 32 && evs_fused_dim_supported(d), "evs_emb_interact_dot: offsets == NULL needs fp32 tables");
+            EVS_REQUIRE(codec == 32 || a.enc_lds, "evs_emb_interact_dot: offsets == NULL with reduced-precision tables needs x + tables only");
             for (int f = 0; f < F; f++)
                 if (feats[f].indices) EVS_REQUIRE(feats[f].nnz >= B && !feats[f].row_weights, "evs_emb_interact_dot: one-index-per-bag features need nnz >= B and no row weights");
         }

@@ -42,42 +42,41 @@ struct RowPiece;  // 4 consecutive elements of a row -> float4
 template <>
 struct RowPiece<32> {
     static constexpr int kBytes = 16;
-    __device__ static __forceinline__ float4 load(const void *row, int piece) {
+    __device__ static __forceinline__ float4 load(const void *row, int piece, const float *) {
         return reinterpret_cast<const float4 *>(row)[piece];
     }
 };
 template <>
 struct RowPiece<16> {
     static constexpr int kBytes = 8;
-    __device__ static __forceinline__ float4 load(const void *row, int piece) {
-        uint2 v = reinterpret_cast<const uint2 *>(row)[piece];  // 4 native-endian ushorts
-        return make_float4(dec_u16(v.x & 0xffffu), dec_u16(v.x >> 16), dec_u16(v.y & 0xffffu),
-                           dec_u16(v.y >> 16));
+    __device__ static __forceinline__ float4 load(const void *row, int piece, const float *lut) {
+        const uint2 v = reinterpret_cast<const uint2 *>(row)[piece];  // 4 native-endian ushorts
+        return dec_chunk<16>(v.x, v.y, lut);
     }
 };
 template <>
 struct RowPiece<8> {
     static constexpr int kBytes = 4;
-    __device__ static __forceinline__ float4 load(const void *row, int piece) {
-        unsigned v = reinterpret_cast<const unsigned *>(row)[piece];
-        return make_float4(dec_u8(v & 0xffu), dec_u8((v >> 8) & 0xffu), dec_u8((v >> 16) & 0xffu),
-                           dec_u8(v >> 24));
+    __device__ static __forceinline__ float4 load(const void *row, int piece, const float *lut) {
+        return dec_chunk<8>(reinterpret_cast<const unsigned *>(row)[piece], 0u, lut);
     }
 };
 template <>
 struct RowPiece<4> {
     static constexpr int kBytes = 2;
-    __device__ static __forceinline__ float4 load(const void *row, int piece) {
-        unsigned v = reinterpret_cast<const unsigned short *>(row)[piece];  // byte0 | byte1<<8
-        // element 2j is the HIGH nibble of byte j (script/reduce_precision.py:321)
-        return make_float4(kU4Lut[(v >> 4) & 15u], kU4Lut[v & 15u], kU4Lut[(v >> 12) & 15u],
-                           kU4Lut[(v >> 8) & 15u]);
+    __device__ static __forceinline__ float4 load(const void *row, int piece, const float *lut) {
+        return dec_chunk<4>(reinterpret_cast<const unsigned short *>(row)[piece], 0u, lut);  // byte0 | byte1<<8
     }
 };
 
 // LPR = lanes per row (d = 4*LPR).  LPR_T > 0: compile-time, LPR_T == 0: runtime (args.d/4).
 template <int CODEC, int LPR_T, int UNROLL>
 __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs args) {
+    __shared__ float s_lut[CodecLut<CODEC>::kEntries];
+    if constexpr (CODEC != 32) {
+        codec_lut_init<CODEC>(s_lut);
+        __syncthreads();
+    }
     const int LPR = LPR_T > 0 ? LPR_T : args.d / 4;
     const int RPW = kWave / LPR;  // bags per wave per unroll slot
     const int lane = threadIdx.x & (kWave - 1);
@@ -152,7 +151,7 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 w[u] = 1.0f;
                 if (r[u] >= 0) {
-                    v[u] = RowPiece<CODEC>::load(W + r[u] * row_bytes, piece);
+                    v[u] = RowPiece<CODEC>::load(W + r[u] * row_bytes, piece, s_lut);
                     if (rw) w[u] = rw[r[u]];
                 }
             }

@@ -203,7 +203,7 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
     dot products fp32 MFMA chains).  "dot" interaction only.
     one_index_per_bag=True asserts lS_o[k] == arange(B) for every table (what
     collate_wrapper_criteo_offset always produces, dlrm_data_pytorch.py:407-408): lS_o is then
-    not read at all (stacked fp32 path only).
+    not read at all (stacked path only).
     """
     ev = _as_evtables(emb_l)
     T, d = len(ev), ev.d
@@ -222,7 +222,7 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
         assert lS_i.dtype == torch.int64 and lS_o.dtype == torch.int64 and lS_i.is_cuda and lS_o.is_cuda
         assert lS_i.stride(1) == 1 and lS_o.stride(1) == 1 and lS_o.shape[1] == B
         rw_c, _keep = _row_weights_c(ev, v_W_l)
-        no_off = one_index_per_bag and rw_c is None and ev.codec == 32 and int(lS_i.shape[1]) == B
+        no_off = one_index_per_bag and rw_c is None and int(lS_i.shape[1]) == B
         _lib.check(L.evs_emb_interact_dot_stacked(
             B, T, d, ev.codec, ev._tables_c, ev._n_rows_c, x.data_ptr(), int(x.stride(0)) if B > 1 else d,
             lS_i.data_ptr(), lS_i.stride(0), int(lS_i.shape[1]), None if no_off else lS_o.data_ptr(), lS_o.stride(0), rw_c,

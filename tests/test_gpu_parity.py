@@ -234,9 +234,10 @@ def test_fused_gather_interact_vs_golden(E, orc, name):
 
 
 @pytest.mark.parametrize("codec", [16, 8, 4])
-def test_fused_codec_tiers(E, orc, codec):
-    d = 36
-    rs = np.random.RandomState(codec)
+@pytest.mark.parametrize("bits_d", [36, 16, 64, 128])
+def test_fused_codec_tiers(E, orc, codec, bits_d):
+    d = bits_d
+    rs = np.random.RandomState(codec + d)
     n_rows = [700, 3, 41]
     T, B = len(n_rows), 97
     raws = [orc.encode_table(rs.uniform(-1, 1, size=(n, d)).astype(np.float32), codec) for n in n_rows]
@@ -249,6 +250,37 @@ def test_fused_codec_tiers(E, orc, codec):
     ly = orc.apply_emb(lS_o, lS_i, raws, None, codec, d)
     Ro = orc.interact_features(x, ly)
     np.testing.assert_allclose(R.cpu().numpy(), Ro, rtol=RTOL, atol=2e-6)
+
+
+@pytest.mark.parametrize("codec", [16, 8, 4])
+def test_fused_codec_26_tables_one_index_per_bag(E, orc, codec):
+    """Kaggle-shaped (26 tables, F=27: two MFMA tile rows) reduced-precision tables through the fused
+    kernel: offsets given, offsets == NULL and the two-call path give the same bits; oracle within RTOL.
+    Odd row counts and odd row ids exercise the 2-byte-aligned u4 rows."""
+    from bench import KAGGLE_LN
+    d, B = 36, 301
+    rs = np.random.RandomState(70 + codec)
+    ln = [min(n, 333) | 1 for n in KAGGLE_LN]
+    raws = [orc.encode_table(rs.uniform(-1, 1, size=(n, d)).astype(np.float32), codec) for n in ln]
+    ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, codec)
+    idx_np = np.stack([rs.randint(0, n, size=B) for n in ln]).astype(np.int64)
+    idx_np[:, -1] = np.array(ln) - 1   # the last row of every table (window ends at the table end)
+    idx = torch.from_numpy(idx_np).cuda()
+    off = torch.arange(B, device="cuda").repeat(26, 1)
+    x_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    x = torch.from_numpy(x_np).cuda()
+    a = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
+    b = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True, check_indices=True)
+    c = E.interact_features(x, E.apply_emb(off, idx, ev, None))
+    assert torch.equal(a, b) and torch.equal(a, c)
+    ly = orc.apply_emb([np.arange(B, dtype=np.int64)] * 26, list(idx_np), raws, None, codec, d)
+    np.testing.assert_allclose(a.cpu().numpy(), orc.interact_features(x_np, ly), rtol=RTOL, atol=2e-6)
+    # the x passthrough and an out-of-range index (row skipped, flag raised)
+    assert torch.equal(a[:, :d], x)
+    idx[7, 3] = ln[7]
+    E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
 def test_sharded_hip_backend_two_virtual_ranks(E, orc):

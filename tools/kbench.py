@@ -32,13 +32,23 @@ def main():
     ap.add_argument("--dim", type=int, default=36)
     ap.add_argument("--dist", default="uniform")
     ap.add_argument("--fused-only", action="store_true")
+    ap.add_argument("--bits", type=int, default=32, help="table precision 32|16|8|4 (reduced: fused timings only)")
     a = ap.parse_args()
     d = a.dim
-    ev = bench.make_tables(bench.KAGGLE_LN, d)
+    ev = bench.make_tables(bench.KAGGLE_LN, d, bits=a.bits)
     T = 26
     for B in a.batch:
         batches = bench.make_batches(bench.KAGGLE_LN, B, 8, 1, "cuda", a.dist)
         x = torch.rand(B, d, device="cuda")
+        if a.bits != 32:
+            row = d * a.bits // 8
+            f_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev), a.iters)
+            f1_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev, one_index_per_bag=True), a.iters)
+            g_us = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None), a.iters)
+            fb = B * (26 * (row + 8) + 4 * d + 4 * (d + 351)) / 1e3
+            print("B=%6d u%d fused one-index/bag %7.1f us (%5.0f GB/s algorithmic, %.2f G lookups/s) | offsets %7.1f us | gather only %7.1f us"
+                  % (B, a.bits, f1_us, fb / f1_us, 26 * B / f1_us / 1e3, f_us, g_us), flush=True)
+            continue
         tile = torch.empty(B, T + 1, d, device="cuda")
         g_tile = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None, out=tile), a.iters)
         ly_tile = E.apply_emb(batches[0][0], batches[0][1], ev, None, out=tile)
