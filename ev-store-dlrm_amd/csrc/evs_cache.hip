@@ -746,23 +746,40 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
 // ------------------------------------------------------------------------------------------
 constexpr unsigned long long kTomb = ~0ull;
 constexpr int kPending = -2;
+// The batched path keeps its own hash: ONE 8-byte word per slot = key (38 bits: (table+1) << 32 | row)
+// | entry index (26 bits), so a probe is a single random access and the table for 3.4 M entries is
+// 64 MiB (it stays inside the 256 MiB Infinity Cache; a 4x larger table measured 2.5x slower).  While a
+// key is being inserted the entry field carries kFieldPend + its pending priority, so the duplicates of
+// one batch fold their agg_hit into the word with a 64-bit atomicMax.  kEmpty = 0 and kTomb = ~0 are
+// not valid keys (table+1 is in 1..32).
+constexpr int kKeyBits = 38;
+constexpr unsigned long long kKeyMask = (1ull << kKeyBits) - 1ull;
+constexpr unsigned kFieldPend = (1u << (64 - kKeyBits)) - 128u;
+constexpr long long kMaxBatchedCap = (long long)kFieldPend - 1;
+__device__ __forceinline__ unsigned long long make_word(unsigned long long key, unsigned field) {
+    return key | ((unsigned long long)field << kKeyBits);
+}
 
 struct BatchState {
     int n_miss, n_new, n_free, count, n_tomb;
     int cnt[kMaxBuckets];
-    int pstar, rem, ticket, flush_t, ticket_t, do_rebuild, n_assign;
+    int pstar, need, ticket, flush_t, ticket_t, do_rebuild, n_assign;
+    int hand, win;   // eviction scans the entry window [hand, hand + win) (mod cap), then the hand moves on
     long long batch_id, n_hits, n_requests, n_perfect_hits, n_evict, n_flush;
 };
 
 struct BatchArgs {
     BatchState *bs;
     CacheArrays a;
+    unsigned long long *slots;   // packed hash words (see above)
     int *eslot;            // hash slot of each entry
-    int *estamp;           // batch id of the last insert / promotion
-    int *slot_aux;         // pending priority of a slot being inserted
     unsigned long long *miss_key; int *miss_agg;   // miss list (capacity max_batch * T)
-    int *new_slot;                                 // unique new keys (hash slots)
-    int *agg_out;                                  // per-request agg_hit
+    int *miss_slot;                                // the empty hash slot the probe of a miss ended on
+    int *new_slot;                                 // unique new keys (hash slots), 256 per K2 block
+    int *block_cnt, *block_base;                   // per K2 block: number of new keys, exclusive scan
+    int *part1, *part2;                            // replica rows of K1 / K5 totals (kReplicas x kPartCols each)
+    int *host_tomb;                                // mapped host word: tombstone count after this batch
+    int g1, g2;
     long long *row_ptrs;                           // (T,B) address of each key's row (arena / backing / 0)
     const unsigned char *backing[kMaxTables];
     long long backing_rows[kMaxTables];
@@ -772,12 +789,17 @@ struct BatchArgs {
     int cap, T, d, codec, row_bytes, max_perfect, flush_n, nslot;
 };
 
-__device__ __forceinline__ int probe_ro(const CacheArrays &a, unsigned long long mask, unsigned long long key) {
+__device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigned long long mask, unsigned long long key,
+                                        unsigned long long &end_slot) {
     unsigned long long i = mix64(key) & mask;
     for (;;) {
-        const unsigned long long k = a.keys[i];
-        if (k == key) return a.slot_entry[i];
-        if (k == kEmpty) return -1;
+        const unsigned long long w = slots[i];
+        if ((w & kKeyMask) == key) {
+            end_slot = i;
+            const unsigned f = (unsigned)(w >> kKeyBits);
+            return f >= kFieldPend ? kPending : (int)f;
+        }
+        if (w == kEmpty) { end_slot = i; return -1; }
         i = (i + 1) & mask;  // tombstones and other keys: keep walking
     }
 }
@@ -822,48 +844,67 @@ __device__ __forceinline__ int block_reserve_n(int *counter, int n, int *s_tot /
     return s_tot[nw] + s_tot[wave] + incl - n;
 }
 
+// Shared counters: a device-scope atomic on ONE address costs ~10 ns and same-address atomics serialise, so
+// 1 664 blocks each adding their hit totals and histogram moves took 29 us of a 46 us kernel.  The batch
+// kernels therefore add their per-block totals into kReplicas replica rows (block j -> row j % kReplicas,
+// 160 B apart, fire-and-forget atomics: a handful per address) that the next single-block kernel folds and
+// clears: K1 -> K3 (plan), K5 -> K6b (end-of-batch bookkeeping).  (Per-block rows folded by one block were
+// no better: a thread walking 277 rows is 277 dependent round trips.)
+constexpr int kPartCols = 40;   // 0..32 priority-histogram deltas, 37 dropped, 38 hits, 39 perfect requests
+constexpr int kReplicas = 32;
+constexpr int kProbeGridMax = 8192;   // one request pair per wave up to B = 65 536, then the blocks loop
+
 // K1: one 32-lane half-wave per request (T <= 32): probe, agg_hit by ballot, priority bump, miss record,
-// and the address of every key's row (table-major (T,B) pointer table consumed by the fused
-// interaction kernel in pointer mode, or by cache_rows_from_ptrs_kernel when the rows are wanted).
-// No global counters are touched per key: misses go to the fixed slot (request, table) of the miss
-// arrays, the per-request agg_hit goes to agg_out, priority-histogram moves are folded per block.
+// and the address of every key's row ((B,T) pointer table consumed by the fused interaction kernel in
+// pointer mode, or by cache_rows_from_ptrs_kernel when the rows are wanted).  Misses go to the fixed slot
+// (request, table) of the miss arrays.  A block walks requests blockIdx*8, +gridDim*8, ...
 __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
+    __shared__ int s_sum[2];   // hits / perfect requests of this block
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
+    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
     const int T = args.T;
-    const long long req = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + half;
-    const bool req_on = req < args.B;
-    const bool key_on = req_on && hl < T;
-    int row = key_on ? args.requests[req * T + hl] : -1;
-    const bool ok = key_on && row >= 0 && row < args.backing_rows[hl < T ? hl : 0];
-    const unsigned long long key = ((unsigned long long)(hl + 1) << 32) | (unsigned)row;
-    int e = ok ? probe_ro(args.a, args.mask, key) : -1;
-    if (e == kPending) e = -1;
-    const unsigned long long hm = __ballot(e >= 0);
-    const unsigned hmask = (unsigned)(half ? (hm >> 32) : hm);
-    const int agg = __popc(hmask);
-    // monotone max like update_agg_hit; the plain read first keeps hot entries (thousands of requests of
-    // one batch hit the same few rows of the tiny tables) from serialising on one atomic address
-    if (e >= 0 && args.a.eagg[e] < agg) {
-        const int old = atomicMax(&args.a.eagg[e], agg);
-        if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); args.estamp[e] = (int)args.bs->batch_id; }
+    const long long req_stride = (long long)gridDim.x * 8;
+    for (long long req = (long long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half; req - half - (threadIdx.x >> 6) * 2 < args.B;
+         req += req_stride) {
+        const bool req_on = req < args.B;
+        const bool key_on = req_on && hl < T;
+        int row = key_on ? args.requests[req * T + hl] : -1;
+        const bool ok = key_on && row >= 0 && row < args.backing_rows[hl < T ? hl : 0];
+        const unsigned long long key = ((unsigned long long)(hl + 1) << 32) | (unsigned)row;
+        unsigned long long end_slot = 0;
+        int e = ok ? probe_ro(args.slots, args.mask, key, end_slot) : -1;
+        if (e == kPending) e = -1;
+        const unsigned long long hm = __ballot(e >= 0);
+        const unsigned hmask = (unsigned)(half ? (hm >> 32) : hm);
+        const int agg = __popc(hmask);
+        // monotone max like update_agg_hit; the plain read first keeps hot entries (thousands of requests of
+        // one batch hit the same few rows of the tiny tables) from serialising on one atomic address
+        if (e >= 0 && args.a.eagg[e] < agg) {
+            const int old = atomicMax(&args.a.eagg[e], agg);
+            if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
+        }
+        // where the row lives right now: arena for a hit, backing store for a miss, 0 for a bad row id
+        const unsigned char *src = nullptr;
+        if (e >= 0) src = args.a.arena + (long long)e * args.row_bytes;
+        else if (ok) src = args.backing[hl] + (long long)row * args.row_bytes;
+        if (key_on) {
+            args.hit[req * T + hl] = e >= 0 ? 1 : 0;
+            args.miss_key[req * T + hl] = (ok && e < 0) ? key : kEmpty;
+            args.miss_agg[req * T + hl] = agg;
+            args.miss_slot[req * T + hl] = (int)end_slot;
+            args.row_ptrs[req * T + hl] = (long long)src;
+        }
+        if (req_on && hl == 0) { atomicAdd(&s_sum[0], agg); if (agg == T) atomicAdd(&s_sum[1], 1); }
     }
-    if (key_on) {
-        args.hit[req * T + hl] = e >= 0 ? 1 : 0;
-        args.miss_key[req * T + hl] = (ok && e < 0) ? key : kEmpty;
-        args.miss_agg[req * T + hl] = agg;
-    }
-    if (req_on && hl == 0) args.agg_out[req] = agg;
-    // where the row lives right now: arena for a hit, backing store for a miss, 0 for a bad row id
-    const unsigned char *src = nullptr;
-    if (e >= 0) src = args.a.arena + (long long)e * args.row_bytes;
-    else if (ok) src = args.backing[hl] + (long long)row * args.row_bytes;
-    if (key_on) args.row_ptrs[(long long)hl * args.B + req] = (long long)src;
     __syncthreads();
-    for (int i = threadIdx.x; i <= T; i += blockDim.x)
-        if (s_delta[i]) atomicAdd(&args.bs->cnt[i], s_delta[i]);
+    if (threadIdx.x < kPartCols) {
+        const int i = threadIdx.x;
+        const int v = i <= T ? s_delta[i] : i == 38 ? s_sum[0] : i == 39 ? s_sum[1] : 0;
+        if (v) atomicAdd(&args.part1[(blockIdx.x % kReplicas) * kPartCols + i], v);
+    }
 }
 
 // rows (B,T,d) fp32 from the pointer table (only when the caller wants the pooled rows themselves)
@@ -877,7 +918,7 @@ __global__ void __launch_bounds__(256) cache_rows_from_ptrs_kernel(const long lo
             const int piece = (int)(i - rowi * lpr);
             const long long b = rowi / T;
             const int t = (int)(rowi - b * T);
-            const long long p = row_ptrs[(long long)t * B + b];
+            const long long p = row_ptrs[b * T + t];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p) v = reinterpret_cast<const float4 *>(p)[piece];
             reinterpret_cast<float4 *>(out)[i] = v;
@@ -889,7 +930,7 @@ __global__ void __launch_bounds__(256) cache_rows_from_ptrs_kernel(const long lo
             const int c = (int)(i - rowi * d);
             const long long b = rowi / T;
             const int t = (int)(rowi - b * T);
-            const long long p = row_ptrs[(long long)t * B + b];
+            const long long p = row_ptrs[b * T + t];
             out[i] = p ? decode_elem(reinterpret_cast<const unsigned char *>(p), codec, c) : 0.f;
         }
     }
@@ -898,88 +939,109 @@ __global__ void iota_kernel(long long *p, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = i;
 }
 
-// K2: de-duplicate the misses through the hash (first CAS on an empty slot wins), collect unique new keys.
+// K2: de-duplicate the misses through the hash (first CAS on an empty slot wins).  One thread per (request,
+// table) position; block j lists its unique new keys in new_slot[j*256 ...] and their number in block_cnt[j].
 __global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs args) {
     __shared__ int s_tot[8];
     const long long n = args.B * args.T;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long iters = (n + stride - 1) / stride;
-    for (long long it = 0; it < iters; it++) {
-        const long long m = it * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-        const unsigned long long key = m < n ? args.miss_key[m] : kEmpty;
-        bool is_new = false;
-        int slot = -1;
-        if (key != kEmpty) {
-            const int agg = args.miss_agg[m];
-            unsigned long long i = mix64(key) & args.mask;
-            for (;;) {
-                unsigned long long k = args.a.keys[i];
-                if (k == kEmpty) {
-                    const unsigned long long prev = atomicCAS(&args.a.keys[i], kEmpty, key);
-                    if (prev == kEmpty) {  // this thread owns the new key
-                        args.a.slot_entry[i] = kPending;
-                        atomicMax(&args.slot_aux[i], agg);
-                        is_new = true; slot = (int)i;
-                        break;
-                    }
-                    k = prev;
-                }
-                if (k == key) { atomicMax(&args.slot_aux[i], agg); break; }  // duplicate miss of this batch
-                i = (i + 1) & args.mask;
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long key = m < n ? args.miss_key[m] : kEmpty;
+    bool is_new = false;
+    int slot = -1;
+    if (key != kEmpty) {
+        const int agg = args.miss_agg[m];
+        // the probe ended on an empty slot: every copy of this key inserted in this batch sits at or after it
+        unsigned long long i = (unsigned long long)(unsigned)args.miss_slot[m];
+        const unsigned long long mine = make_word(key, kFieldPend + (unsigned)agg);
+        for (;;) {
+            unsigned long long w = args.slots[i];
+            if (w == kEmpty) {
+                const unsigned long long prev = atomicCAS(&args.slots[i], kEmpty, mine);
+                if (prev == kEmpty) { is_new = true; slot = (int)i; break; }  // this thread owns the new key
+                w = prev;
             }
+            if ((w & kKeyMask) == key) { atomicMax(&args.slots[i], mine); break; }  // duplicate miss of this batch
+            i = (i + 1) & args.mask;
         }
-        const int idx = block_reserve(&args.bs->n_new, is_new, s_tot);
-        if (is_new) args.new_slot[idx] = slot;
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bm = __ballot(is_new);
+    if (lane == 0) s_tot[wave] = __popcll(bm);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 4; w++) { if (w < wave) base += s_tot[w]; tot += s_tot[w]; }
+    if (is_new) args.new_slot[(long long)blockIdx.x * 256 + base + __popcll(bm & ((1ull << lane) - 1ull))] = slot;
+    if (threadIdx.x == 0) args.block_cnt[blockIdx.x] = tot;
 }
 
-// K3: one block sums the per-request agg_hit and decides how many entries must go and where the cut is.
+// K3: one block folds K1's partial rows, scans K2's per-block counts into list bases, and thread 0 decides how
+// many entries must go, the priority cut and the scan window.
 __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs args) {
-    __shared__ long long s_h[256], s_p[256];
-    BatchState *b = args.bs;
-    const int T = args.T;
-    long long h = 0, pf = 0;
-    for (long long r = threadIdx.x; r < args.B; r += blockDim.x) { const int a = args.agg_out[r]; h += a; pf += (a == T); }
-    s_h[threadIdx.x] = h; s_p[threadIdx.x] = pf;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) { s_h[threadIdx.x] += s_h[threadIdx.x + w]; s_p[threadIdx.x] += s_p[threadIdx.x + w]; }
-        __syncthreads();
-    }
-    // the state block is fetched by all threads at once and written back the same way: thread 0 works in LDS
     __shared__ BatchState sb;
+    __shared__ long long s_col[kPartCols];
+    __shared__ int s_scan[256];
+    const int T = args.T;
     {
         const int nw = (int)(sizeof(BatchState) / sizeof(int));
         int *dst = reinterpret_cast<int *>(&sb);
         const int *src = reinterpret_cast<const int *>(args.bs);
         for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
     }
+    if (threadIdx.x < kPartCols) s_col[threadIdx.x] = 0;
     __syncthreads();
-    b = &sb;
+    for (int i = threadIdx.x; i < kReplicas * kPartCols; i += blockDim.x) {   // fold and clear K1's replica rows
+        const int v = args.part1[i];
+        if (v) { atomicAdd(reinterpret_cast<unsigned long long *>(&s_col[i % kPartCols]), (unsigned long long)(long long)v); args.part1[i] = 0; }
+    }
+    // exclusive scan of block_cnt[0..g2): each thread owns a contiguous run
+    const int per = (args.g2 + 255) / 256;
+    const int r0 = threadIdx.x * per, r1 = r0 + per < args.g2 ? r0 + per : args.g2;
+    int mine = 0;
+    for (int r = r0; r < r1; r++) mine += args.block_cnt[r];
+    s_scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = (int)threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    {
+        int run = s_scan[threadIdx.x] - mine;
+        for (int r = r0; r < r1; r++) { args.block_base[r] = run; run += args.block_cnt[r]; }
+    }
+    BatchState *b = &sb;
     if (threadIdx.x == 0) {
-    int cnt[kMaxBuckets];  // planning copy: the real histogram is updated by the evict / assign kernels
-    for (int p = 0; p <= T; p++) cnt[p] = sb.cnt[p];
-    b->n_hits += s_h[0]; b->n_perfect_hits += s_p[0];
-    b->pstar = -1; b->rem = 0; b->ticket = 0; b->flush_t = 0; b->ticket_t = 0;
-    if (cnt[T] >= args.max_perfect && b->n_new > 0) {  // EvLFU flush (EvLFU_C1.py:36-44), once per batch
-        b->flush_t = args.flush_n < cnt[T] ? args.flush_n : cnt[T];
-        cnt[T] -= b->flush_t;
-        b->n_flush++;
-    }
-    const int n_new = b->n_new < args.cap ? b->n_new : args.cap;
-    b->n_assign = n_new;
-    int need = n_new - (b->n_free + b->flush_t);
-    const int live = b->count - b->flush_t;
-    if (need > live) need = live;
-    if (need > 0) {
-        int acc = 0;
-        for (int p = 0; p <= T; p++) {
-            if (acc + cnt[p] >= need) { b->pstar = p; b->rem = need - acc; break; }
-            acc += cnt[p];
+        for (int p = 0; p <= T; p++) b->cnt[p] += (int)s_col[p];
+        b->n_hits += s_col[38]; b->n_perfect_hits += s_col[39];
+        b->n_new = s_scan[255];
+        int cnt[kMaxBuckets];  // planning copy: the real histogram is updated by the evict / assign kernels
+        for (int p = 0; p <= T; p++) cnt[p] = sb.cnt[p];
+        b->pstar = -1; b->need = 0; b->ticket = 0; b->flush_t = 0; b->ticket_t = 0; b->win = 0;
+        if (cnt[T] >= args.max_perfect && b->n_new > 0) {  // EvLFU flush (EvLFU_C1.py:36-44), once per batch
+            b->flush_t = args.flush_n < cnt[T] ? args.flush_n : cnt[T];
+            cnt[T] -= b->flush_t;
+            b->n_flush++;
         }
-        b->n_evict += need;
-    }
-    b->do_rebuild = (b->n_tomb + (need > 0 ? need : 0) + b->flush_t) > args.nslot / 4;
+        const int n_new = b->n_new < args.cap ? b->n_new : args.cap;
+        b->n_assign = n_new;
+        int need = n_new - (b->n_free + b->flush_t);
+        const int live = b->count - b->flush_t;
+        if (need > live) need = live;
+        if (need > 0) {
+            long long acc = 0;
+            for (int p = 0; p <= T; p++) {
+                acc += cnt[p];
+                if (acc >= need) { b->pstar = p; break; }
+            }
+            // candidates (priority <= pstar) are `acc` of the cap entry indices: scan twice the expected span
+            long long w = (long long)need * args.cap / (acc > 0 ? acc : 1) * 2 + 16384;
+            if (w > args.cap) w = args.cap;
+            b->need = need; b->win = (int)w;
+            b->n_evict += need;
+        }
+        if (b->flush_t > 0) b->win = args.cap;  // the flush takes its victims from the whole arena
+        b->do_rebuild = (b->n_tomb + (need > 0 ? need : 0) + b->flush_t) > args.nslot / 8;
     }
     __syncthreads();
     {
@@ -990,55 +1052,66 @@ __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs a
     }
 }
 
-// K4: evict every entry below the cut, `rem` entries at the cut, `flush_t` entries of the top priority.
-// Each thread owns kEvictPerThread consecutive entries per pass so that the three shared counters
-// (two ticket counters, the free-stack top) see one atomic per 2048 entries, not one per entry.
+// K4: walk the entry window [hand, hand + win) and evict up to `need` entries whose priority is at or
+// below the cut (and `flush_t` entries of the top priority when the EvLFU flush fires).  The hand
+// moves on afterwards, so inside the low priorities the oldest fills go first -- the clock-hand
+// stand-in for the reference's per-bucket FIFO -- and a batch touches ~2 * need / density entries
+// instead of the whole arena.  Each thread owns kEvictPerThread consecutive entries so that the
+// shared counters (tickets, free-stack top) see one atomic per 2048 entries, not one per entry.
 constexpr int kEvictPerThread = 8;
 __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs args) {
     __shared__ int s_tot[8];
     __shared__ int s_delta[kMaxBuckets];
     BatchState *b = args.bs;
-    const int pstar = b->pstar, rem = b->rem, flush_t = b->flush_t, T = args.T;
-    if (pstar < 0 && flush_t == 0) return;  // uniform: nothing in this kernel changes these three
+    const int pstar = b->pstar, need = b->need, flush_t = b->flush_t, T = args.T, win = b->win, hand = b->hand;
+    const int n_free0 = b->n_free;
+    const long long per_pass = (long long)gridDim.x * blockDim.x * kEvictPerThread;
+    if (win <= 0 || (long long)blockIdx.x * blockDim.x * kEvictPerThread >= win) return;  // block-uniform
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
     __syncthreads();
-    const long long per_pass = (long long)gridDim.x * blockDim.x * kEvictPerThread;
-    const int passes = (int)((args.cap + per_pass - 1) / per_pass);
+    const int passes = (int)((win + per_pass - 1) / per_pass);
     for (int it = 0; it < passes; it++) {
-        const long long e0 = it * per_pass + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * kEvictPerThread;
-        int prio[kEvictPerThread];
+        const long long o0 = it * per_pass + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * kEvictPerThread;
+        int prio[kEvictPerThread], ent[kEvictPerThread];
         int n_t = 0, n_c = 0;
 #pragma unroll
         for (int j = 0; j < kEvictPerThread; j++) {
-            const long long e = e0 + j;
-            prio[j] = (e < args.cap && args.a.ekey[e] != kEmpty) ? args.a.eagg[e] : -1;
+            const long long o = o0 + j;
+            long long e = hand + o;
+            if (e >= args.cap) e -= args.cap;
+            ent[j] = (int)e;
+            prio[j] = (o < win && args.a.ekey[e] != kEmpty) ? args.a.eagg[e] : -1;
             n_t += (prio[j] == T && flush_t > 0);
         }
-        int tk_t = block_reserve_n(&b->ticket_t, n_t, s_tot);
-        unsigned victim = 0;
+        // a victim's ticket is also its place on the free stack: flush victims take n_free + [0, flush_t),
+        // the others n_free + flush_t + [0, need); K6b adds what was handed out to n_free
+        unsigned victim = 0, fvict = 0;
+        int tk_t = 0;
+        if (flush_t > 0) {  // uniform
+            tk_t = block_reserve_n(&b->ticket_t, n_t, s_tot);
+            int k = tk_t;
+#pragma unroll
+            for (int j = 0; j < kEvictPerThread; j++)
+                if (prio[j] == T) { if (k++ < flush_t) fvict |= 1u << j; }
+        }
 #pragma unroll
         for (int j = 0; j < kEvictPerThread; j++)
-            if (prio[j] == T && flush_t > 0) { if (tk_t++ < flush_t) victim |= 1u << j; }
-#pragma unroll
-        for (int j = 0; j < kEvictPerThread; j++)
-            n_c += (prio[j] >= 0 && !((victim >> j) & 1) && pstar >= 0 && prio[j] == pstar);
+            n_c += (prio[j] >= 0 && !((fvict >> j) & 1) && prio[j] <= pstar);
         int tk_c = block_reserve_n(&b->ticket, n_c, s_tot);
 #pragma unroll
         for (int j = 0; j < kEvictPerThread; j++) {
-            if (prio[j] < 0 || ((victim >> j) & 1) || pstar < 0) continue;
-            if (prio[j] == pstar) { if (tk_c++ < rem) victim |= 1u << j; }
-            else if (prio[j] < pstar) victim |= 1u << j;
+            int pos = -1;
+            if ((fvict >> j) & 1) pos = n_free0 + tk_t++;
+            else if (prio[j] >= 0 && prio[j] <= pstar) { if (tk_c < need) pos = n_free0 + flush_t + tk_c; tk_c++; }
+            if (pos < 0) continue;
+            victim |= 1u << j;
+            const int e = ent[j];
+            args.slots[args.eslot[e]] = kTomb;
+            args.a.ekey[e] = kEmpty;
+            atomicSub(&s_delta[prio[j]], 1);
+            args.a.free_stack[pos] = e;
         }
-        int fi = block_reserve_n(&b->n_free, __popc(victim), s_tot);
-#pragma unroll
-        for (int j = 0; j < kEvictPerThread; j++)
-            if ((victim >> j) & 1) {
-                const long long e = e0 + j;
-                args.a.keys[args.eslot[e]] = kTomb;
-                args.a.ekey[e] = kEmpty;
-                atomicSub(&s_delta[prio[j]], 1);
-                args.a.free_stack[fi++] = (int)e;
-            }
+        (void)victim;
     }
     __syncthreads();
     int gone = 0;
@@ -1047,70 +1120,97 @@ __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs 
     if (gone) { atomicSub(&b->count, gone); atomicAdd(&b->n_tomb, gone); }
 }
 
-// K5: give every unique new key an entry and fill its arena row from the backing store.
-// The free stack holds n_free entries; new key i simply takes free_stack[n_free - 1 - i] (no atomics).
+// K5: give every unique new key an entry and fill its arena row from the backing store: block j serves the
+// keys K2's block j listed, 16 lanes per key (lane 0 does the bookkeeping, all of them move 16-byte pieces
+// of the row).  New key i of the batch (list base + rank) takes free_stack[n_free - 1 - i] -- no atomics.
 __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
+    __shared__ int s_drop;
     BatchState *b = args.bs;
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
+    if (threadIdx.x == 0) s_drop = 0;
     __syncthreads();
-    const int n_new = b->n_new, n_free = b->n_free;
+    // the free stack as K4 left it: what was free plus the victims it handed out
+    const int n_free = b->n_free + (b->ticket_t < b->flush_t ? b->ticket_t : b->flush_t) + (b->ticket < b->need ? b->ticket : b->need);
     const int n_assign = b->n_assign < n_free ? b->n_assign : n_free;
-    int dropped = 0, added = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += gridDim.x * blockDim.x) {
-        const int slot = args.new_slot[i];
-        const int agg = args.slot_aux[slot];
-        args.slot_aux[slot] = 0;
-        if (i >= n_assign) { args.a.keys[slot] = kTomb; dropped++; continue; }  // no room: forget the key
+    const int sub = threadIdx.x & 15;
+    const int my_cnt = args.block_cnt[blockIdx.x], my_base = args.block_base[blockIdx.x];
+    for (int local = threadIdx.x >> 4; local < my_cnt; local += 16) {
+        const int i = my_base + local;
+        const int slot = args.new_slot[(long long)blockIdx.x * 256 + local];
+        if (i >= n_assign) {  // no room: forget the key
+            if (sub == 0) { args.slots[slot] = kTomb; atomicAdd(&s_drop, 1); }
+            continue;
+        }
         const int e = args.a.free_stack[n_free - 1 - i];
-        const unsigned long long key = args.a.keys[slot];
-        args.a.ekey[e] = key; args.a.eagg[e] = agg; args.eslot[e] = slot; args.estamp[e] = (int)b->batch_id;
-        args.a.slot_entry[slot] = e;
-        atomicAdd(&s_delta[agg], 1);
-        added++;
+        const unsigned long long w = args.slots[slot];
+        const unsigned long long key = w & kKeyMask;
+        // every lane of the group must have read the pending word before lane 0 replaces it
+        __builtin_amdgcn_wave_barrier();
+        if (sub == 0) {
+            const int agg = (int)((unsigned)(w >> kKeyBits) - kFieldPend);
+            args.a.ekey[e] = key; args.a.eagg[e] = agg; args.eslot[e] = slot;
+            args.slots[slot] = make_word(key, (unsigned)e);
+            atomicAdd(&s_delta[agg], 1);
+        }
         const int t = (int)(key >> 32) - 1;
         const unsigned char *srow = args.backing[t] + (long long)(unsigned)(key & 0xffffffffull) * args.row_bytes;
         unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
         if ((args.row_bytes & 15) == 0) {
-            for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c);
+            for (int c = sub * 16; c < args.row_bytes; c += 256) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c);
         } else {
-            for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c];
+            for (int c = sub; c < args.row_bytes; c += 16) drow[c] = srow[c];
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i <= args.T; i += blockDim.x)
-        if (s_delta[i]) atomicAdd(&b->cnt[i], s_delta[i]);
-    if (dropped) atomicAdd(&b->n_tomb, dropped);
-    (void)added;
+    if (threadIdx.x < kPartCols) {
+        const int i = threadIdx.x;
+        const int v = i <= args.T ? s_delta[i] : i == 37 ? s_drop : 0;
+        if (v) atomicAdd(&args.part2[(blockIdx.x % kReplicas) * kPartCols + i], v);
+    }
 }
 
 // K6a/K6b: rebuild the hash without tombstones when they pile up (decided in K3).
 __global__ void __launch_bounds__(256) cache_batch_clear_kernel(const BatchArgs args) {
-    if (!args.bs->do_rebuild) return;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < args.nslot; i += (long long)gridDim.x * blockDim.x)
-        args.a.keys[i] = kEmpty;
+        args.slots[i] = kEmpty;
 }
-// ... and the end-of-batch bookkeeping (thread 0 of block 0)
+// ... and the end-of-batch bookkeeping (block 0: folds K5's partial rows, then thread 0 closes the batch)
 __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchArgs args) {
+    __shared__ int s_col[kPartCols];
     BatchState *b = args.bs;
-    const bool rebuild = b->do_rebuild != 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const int take = b->n_assign < b->n_free ? b->n_assign : b->n_free;
-        b->n_free -= take; b->count += take;
-        if (rebuild) b->n_tomb = 0;
-        b->n_miss = 0; b->n_new = 0; b->batch_id++;
-        b->n_requests += args.B;
+    const bool rebuild = args.B < 0;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < kPartCols) s_col[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < kReplicas * kPartCols; i += blockDim.x) {   // fold and clear K5's replica rows
+            const int v = args.part2[i];
+            if (v) { atomicAdd(&s_col[i % kPartCols], v); args.part2[i] = 0; }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x <= args.T && s_col[threadIdx.x]) b->cnt[threadIdx.x] += s_col[threadIdx.x];
+        if (threadIdx.x == 0) {
+            b->n_free += (b->ticket_t < b->flush_t ? b->ticket_t : b->flush_t) + (b->ticket < b->need ? b->ticket : b->need);
+            const int take = b->n_assign < b->n_free ? b->n_assign : b->n_free;
+            b->n_free -= take; b->count += take;
+            b->n_tomb += s_col[37];
+            if (b->need > 0 && b->win > 0) { long long h = (long long)b->hand + b->win; b->hand = (int)(h % args.cap); }
+            if (rebuild) b->n_tomb = 0;
+            b->n_miss = 0; b->n_new = 0; b->batch_id++;
+            b->n_requests += rebuild ? -args.B : args.B;
+            *args.host_tomb = b->n_tomb;
+        }
     }
     if (!rebuild) return;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < args.cap; e += gridDim.x * blockDim.x) {
         const unsigned long long key = args.a.ekey[e];
         if (key == kEmpty) continue;
         unsigned long long i = mix64(key) & args.mask;
+        const unsigned long long w = make_word(key, (unsigned)e);
         for (;;) {
-            if (args.a.keys[i] == kEmpty && atomicCAS(&args.a.keys[i], kEmpty, key) == kEmpty) break;
+            if (args.slots[i] == kEmpty && atomicCAS(&args.slots[i], kEmpty, w) == kEmpty) break;
             i = (i + 1) & args.mask;
         }
-        args.a.slot_entry[i] = e;
         args.eslot[e] = (int)i;
     }
 }
@@ -1131,20 +1231,26 @@ struct evs_cache {
     bool has_backing = false;
     // batched path
     evs::BatchState *bs = nullptr;
-    int *eslot = nullptr, *estamp = nullptr, *slot_aux = nullptr, *miss_agg = nullptr, *new_slot = nullptr, *agg_out = nullptr;
+    int *eslot = nullptr, *miss_agg = nullptr, *new_slot = nullptr, *miss_slot = nullptr;
+    int *block_cnt = nullptr, *block_base = nullptr, *part1 = nullptr, *part2 = nullptr;
+    unsigned long long *bslots = nullptr;
     long long *row_ptrs = nullptr, *iota = nullptr;
     unsigned long long *miss_key = nullptr;
     long long max_batch = 0;
     int used = 0;  // 0 fresh, 1 exact path, 2 batched path
+    int *host_tomb = nullptr;   // mapped host word: tombstones after the last finished batch (read without a sync)
+    int *host_tomb_dev = nullptr;
 };
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
     void *ptrs[] = {c->st, c->a.keys, c->a.slot_entry, c->a.ekey, c->a.eagg, c->a.efreq, c->a.prev, c->a.next,
                     c->a.free_stack, c->a.arena, c->a.lfu_head, c->a.lfu_tail, c->a.lfu_len,
-                    c->bs, c->eslot, c->estamp, c->slot_aux, c->miss_agg, c->new_slot, c->miss_key, c->agg_out, c->row_ptrs, c->iota};
+                    c->bs, c->eslot, c->bslots, c->miss_agg, c->new_slot, c->miss_key, c->miss_slot, c->row_ptrs, c->iota,
+                    c->block_cnt, c->block_base, c->part1, c->part2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->host_tomb) (void)hipHostFree(c->host_tomb);
     delete c;
     return EVS_OK;
 }
@@ -1322,6 +1428,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
     EVS_REQUIRE(c->host.n_tables <= 32, "evs_cache_lookup_batch: at most 32 tables");
     if (!c->has_backing) { set_error("evs_cache_lookup_batch: call evs_cache_set_backing first"); return EVS_ESTATE; }
     if (c->used == 1) { set_error("evs_cache_lookup_batch: this cache is used through the exact path"); return EVS_ESTATE; }
+    EVS_REQUIRE(c->host.cap <= kMaxBatchedCap, "evs_cache_lookup_batch: capacity above %lld entries needs wider hash words", kMaxBatchedCap);
     if (B == 0) return EVS_OK;
     EVS_REQUIRE(B > 0 && B < (1ll << 31) / 32 && rows && hit, "evs_cache_lookup_batch: bad argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1333,20 +1440,29 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         EVS_HIP_CHECK(hipMalloc(&c->bs, sizeof(BatchState)));
         EVS_HIP_CHECK(hipMemcpy(c->bs, &h, sizeof h, hipMemcpyHostToDevice));
         EVS_HIP_CHECK(hipMalloc(&c->eslot, cap * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->estamp, cap * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->slot_aux, c->nslot * 4));
-        EVS_HIP_CHECK(hipMemset(c->slot_aux, 0, c->nslot * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->bslots, c->nslot * 8));
+        EVS_HIP_CHECK(hipMemset(c->bslots, 0, c->nslot * 8));
+        EVS_HIP_CHECK(hipMalloc(&c->part1, kReplicas * kPartCols * 4));
+        EVS_HIP_CHECK(hipMemset(c->part1, 0, kReplicas * kPartCols * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->part2, kReplicas * kPartCols * 4));
+        EVS_HIP_CHECK(hipMemset(c->part2, 0, kReplicas * kPartCols * 4));
+        EVS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_tomb), sizeof(int), hipHostMallocMapped));
+        *c->host_tomb = 0;
+        EVS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->host_tomb_dev), c->host_tomb, 0));
     }
+    const long long g2 = (B * T + 255) / 256;
     if (B > c->max_batch) {
         if (c->miss_key) {
             EVS_HIP_CHECK(hipStreamSynchronize(st));
-            void *old[] = {c->miss_key, c->miss_agg, c->new_slot, c->agg_out, c->row_ptrs, c->iota};
+            void *old[] = {c->miss_key, c->miss_agg, c->miss_slot, c->new_slot, c->row_ptrs, c->iota, c->block_cnt, c->block_base};
             for (void *p : old) (void)hipFree(p);
         }
         EVS_HIP_CHECK(hipMalloc(&c->miss_key, B * T * 8));
         EVS_HIP_CHECK(hipMalloc(&c->miss_agg, B * T * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->new_slot, B * T * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->agg_out, B * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->new_slot, g2 * 256 * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->block_cnt, g2 * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->block_base, g2 * 4));
+        EVS_HIP_CHECK(hipMalloc(&c->miss_slot, B * T * 4));
         EVS_HIP_CHECK(hipMalloc(&c->row_ptrs, B * T * 8));
         EVS_HIP_CHECK(hipMalloc(&c->iota, B * 8));
         hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(256), 0, st, c->iota, (long long)B);
@@ -1354,17 +1470,22 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
     }
     c->used = 2;
     BatchArgs a;
-    a.bs = c->bs; a.a = c->a; a.eslot = c->eslot; a.estamp = c->estamp; a.slot_aux = c->slot_aux;
-    a.miss_key = c->miss_key; a.miss_agg = c->miss_agg; a.new_slot = c->new_slot; a.agg_out = c->agg_out;
+    a.bs = c->bs; a.a = c->a; a.eslot = c->eslot; a.slots = c->bslots;
+    a.miss_key = c->miss_key; a.miss_agg = c->miss_agg; a.miss_slot = c->miss_slot; a.new_slot = c->new_slot;
     a.row_ptrs = c->row_ptrs;
     for (int k = 0; k < kMaxTables; k++) { a.backing[k] = c->backing[k]; a.backing_rows[k] = c->backing_rows[k]; }
     a.requests = rows; a.out = out; a.hit = hit; a.B = B; a.mask = c->host.nslot_mask;
     a.cap = (int)cap; a.T = T; a.d = c->host.dim; a.codec = c->host.codec; a.row_bytes = c->host.row_bytes;
     a.max_perfect = c->host.max_perfect; a.flush_n = c->host.flush_n; a.nslot = (int)c->nslot;
+    a.block_cnt = c->block_cnt; a.block_base = c->block_base; a.part1 = c->part1; a.part2 = c->part2;
+    long long g1 = (B + 7) / 8; if (g1 > kProbeGridMax) g1 = kProbeGridMax;
+    a.g1 = (int)g1; a.g2 = (int)g2;
     const int wide = kNumCu * 8;
-    const long long waves = (B + 1) / 2;
-    hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
-    // consumers of the snapshot read the rows BEFORE the policy kernels move anything
+    a.host_tomb = c->host_tomb_dev;
+    hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)g1), dim3(256), 0, st, a);
+    // consumers of the snapshot read the rows BEFORE the policy kernels move anything.  (Running K2-K4 on a
+    // side stream under the consumer was measured and is slower: 101 vs 91 us per batch -- the consumer
+    // already saturates the memory system and the two event waits cost more than the overlap returns.)
     if (out) {
         long long nb = (B * T * (long long)c->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
         hipLaunchKernelGGL(cache_rows_from_ptrs_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->row_ptrs, out,
@@ -1377,14 +1498,17 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
                                                     (const int64_t *)c->iota, itself, R, st);
         if (rc) return rc;
     }
-    long long nb = (B * T + 255) / 256; if (nb > wide) nb = wide;
-    hipLaunchKernelGGL(cache_batch_insert_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_insert_kernel, dim3((unsigned)g2), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cache_batch_plan_kernel, dim3(1), dim3(256), 0, st, a);
     long long ne = (cap + 255) / 256; if (ne > wide) ne = wide;
     hipLaunchKernelGGL(cache_batch_evict_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(cache_batch_assign_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_assign_kernel, dim3((unsigned)g2), dim3(256), 0, st, a);
+    // the hash is rebuilt without tombstones when they exceed nslot/8; the host learns the count from a
+    // mapped word K6b writes (one or two batches stale, which only means slightly longer probe chains)
+    const bool rebuild = *reinterpret_cast<volatile int *>(c->host_tomb) > (int)(c->nslot / 8);
+    if (rebuild) hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
+    a.B = rebuild ? -B : B;   // sign = "the slots were cleared: re-insert every entry"
+    hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3(rebuild ? (unsigned)ne : 1u), dim3(256), 0, st, a);
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
 }

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
                 const bool use = lf[rr].indirect & valid;
                 st2[rr] = use ? (int)s0 : 0;
                 len2[rr] = use ? (int)(e0 - s0) : 0;
-                const int64_t *ip = (len2[rr] > 0) ? lf[rr].idx + st2[rr] : args.dummy_i64;
+                const int64_t *ip = (len2[rr] > 0) ? lf[rr].idx + (PTRS ? (int64_t)st2[rr] * (F - 1) : (int64_t)st2[rr]) : args.dummy_i64;  // PTRS: (B, F-1) pointer table
                 idx_raw[rr] = *ip;
             }
         }
@@ -623,7 +623,8 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
             for (int rr = 0; rr < NR; rr++) {
                 has2[rr] = __ballot(lf[rr].indirect);
                 more2[rr] = 0;
-                idx_raw[rr] = lf[rr].idx[lf[rr].indirect ? b : 0];
+                // PTRS: the (B, F-1) pointer table of the cache tier, feature f at column f-1
+                idx_raw[rr] = lf[rr].idx[lf[rr].indirect ? (PTRS ? (int64_t)b * (F - 1) : (int64_t)b) : 0];
             }
         } else if constexpr (HAS_INDIRECT) {
             const int b = (int)sample_b(n);
@@ -925,7 +926,7 @@ static bool launch_cpq(const FusedArgs &a, hipStream_t st) {
 
 
 // Cache-tier consumer (evs_cache.hip): feature 0 = x, feature k+1 = the fp32 row at address
-// row_ptrs[k*B + b] (0 = no row -> zeros).  iota: device int64 array 0..B-1 (bag b = index b).
+// row_ptrs[b*T + k] (0 = no row -> zeros).  iota: device int64 array 0..B-1 (bag b = index b).
 int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_t x_stride,
                                  const int64_t *row_ptrs, const int64_t *iota, int itself, float *R, hipStream_t st) {
     FusedArgs a;
@@ -939,7 +940,7 @@ int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_
     if (!a.zeros || !a.err) return EVS_EHIP;
     a.src[0] = x; a.stride[0] = x_stride;
     for (int k = 0; k < T; k++) {
-        a.src[k + 1] = a.zeros; a.indices[k + 1] = row_ptrs + (int64_t)k * B; a.offsets[k + 1] = iota;
+        a.src[k + 1] = a.zeros; a.indices[k + 1] = row_ptrs + k; a.offsets[k + 1] = iota;   // (B,T) table, column k
         a.nnz[k + 1] = B; a.n_rows[k + 1] = 1;
     }
     a.R = R; a.B = B; a.F = F; a.d = d; a.itself = itself ? 1 : 0;
