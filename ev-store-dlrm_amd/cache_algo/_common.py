@@ -15,8 +15,13 @@ class _ModuleCache:
     def init(self, capacity, variant="python", device="cuda"):
         self.cache = gpu_cache.GpuCache(self.policy, capacity, self.n_tables, self.dim,
                                         storage_manager.ev_precs, variant, device)
-        self.rows = torch.empty((1, self.n_tables), dtype=torch.int32, device=device)
+        # one request at a time, like the reference: ids, hit flags (and the rows when the caller wants them on
+        # the host) live in pinned buffers the kernel reads / writes directly
         self._host_rows = torch.empty((1, self.n_tables), dtype=torch.int32).pin_memory()
+        self._host_hit = torch.empty((1, self.n_tables), dtype=torch.uint8).pin_memory()
+        self._host_out = torch.empty((1, self.n_tables, self.dim), dtype=torch.float32).pin_memory()
+        self._dev_out = torch.empty((1, self.n_tables, self.dim), dtype=torch.float32, device=device)
+        self._device = torch.device(device)
         self._bound = False
 
     def _bind(self):
@@ -35,10 +40,11 @@ class _ModuleCache:
         if not self._bound:
             self._bind()
         self._host_rows[0] = torch.as_tensor(group_row_ids, dtype=torch.int32)
-        self.rows.copy_(self._host_rows, non_blocking=True)
-        hit, out = self.cache.request(self.rows, approx_thres)
-        arr_record_hit = [bool(v) for v in hit[0].tolist()]
-        vals = out[0] if use_gpu else out[0].cpu()
+        out = self._dev_out if use_gpu else self._host_out
+        self.cache.request(self._host_rows, approx_thres, out=out, hit=self._host_hit)
+        torch.cuda.current_stream(self._device).synchronize()
+        arr_record_hit = [bool(v) for v in self._host_hit[0].tolist()]
+        vals = out[0]
         arr_emb_weights = []
         for k in range(self.n_tables):
             t = vals[k:k + 1].detach().clone()   # Tensor(1, 36), as torch.FloatTensor([val])

@@ -59,3 +59,12 @@ const void *zero_page() {
 
 extern "C" int evs_abi_version(void) { return EVS_ABI_VERSION; }
 extern "C" const char *evs_last_error(void) { return evs::g_err; }
+
+extern "C" void *evs_host_device_pointer(void *host_ptr) {
+    void *dev = nullptr;
+    if (!host_ptr || hipHostGetDevicePointer(&dev, host_ptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return dev;
+}

@@ -27,6 +27,9 @@
 #include <vector>
 #include <stdlib.h>
 
+#ifndef EVS_X_EXACT_STOP
+#define EVS_X_EXACT_STOP 0
+#endif
 namespace evs {
 
 constexpr int kMaxTables = 64;      // one lane per table
@@ -217,6 +220,8 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
     __shared__ int s_src[kMaxTables];    // >=0: arena entry to read the row from; -1: backing store; -2: copy of table s_from
     __shared__ int s_fill[kMaxTables];   // >=0: arena entry to fill from the backing row after the request
     __shared__ int s_from[kMaxTables];   // approximate mode: table whose vector is reused
+    __shared__ const unsigned char *s_rowp[kMaxTables];
+    __shared__ int s_req[kMaxTables];
     const int lane = threadIdx.x;
     CacheState *gs = args.st;
     const CacheArrays a = args.a;
@@ -227,12 +232,16 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
         h.min_c1 = cs.min_c1; h.n_perfect = cs.n_perfect; h.count = cs.count; h.n_free = cs.n_free;
         h.n_flush = cs.n_flush; h.n_evict = cs.n_evict; h.least_freq = cs.least_freq; h.error = cs.error;
     }
-    for (int b = lane; b < kMaxBuckets; b += 64) { h.head[b] = cs.head[b]; h.tail[b] = cs.tail[b]; h.len[b] = cs.len[b]; }
+    for (int b = lane; b < kMaxBuckets; b += 64) { h.head[b] = gs->head[b]; h.tail[b] = gs->tail[b]; h.len[b] = gs->len[b]; }
     __syncthreads();
     long long n_hits = 0, n_perfect_hits = 0;
+#if EVS_X_EXACT_STOP == 1
+    return;
+#endif
 
     for (long long rq = 0; rq < args.B; rq++) {
-        const int row = lane < T ? args.requests[rq * T + lane] : 0;
+        const int row = lane < T ? args.requests[rq * T + lane] : 0;   // the only read of the ids (they may live in host memory)
+        if (lane < T) s_req[lane] = row;
         const unsigned long long key = ((unsigned long long)(lane + 1) << 32) | (unsigned)row;
         const bool row_ok = lane < T && row >= 0 && row < args.backing_rows[lane < T ? lane : 0];
         if (lane < T) { s_src[lane] = -1; s_fill[lane] = -1; s_from[lane] = -1; }
@@ -244,6 +253,14 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
             const int agg_hit = __popcll(hit_mask);
             const bool pick_random = args.approx_thres > 0 && agg_hit >= args.approx_thres;  // :122-125
             bool my_hit = e >= 0;
+            // every lane fetches its own entry's key and priority now (one round trip for all T); the serial
+            // loop below re-reads them only after an insert of THIS request may have evicted / reused an entry
+            const unsigned long long pre_key = e >= 0 ? ld(&a.ekey[e]) : 0ull;
+            const int pre_agg = e >= 0 ? ld(&a.eagg[e]) : 0;
+            bool dirty = false;
+#if EVS_X_EXACT_STOP == 2
+            if (pre_key != 12345ull || pre_agg != -7) return;
+#endif
             // ---- policy update, table order, one lane (EvLFU_C1.py:135-161) ----
             int last_hit_table = -1;
             for (int i = 0; i < T; i++) {
@@ -251,14 +268,16 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
                 const unsigned long long ki = __shfl(key, i);
                 const bool oki = __shfl((int)row_ok, i) != 0;
                 const bool hiti = (hit_mask >> i) & 1ull;
+                const unsigned long long pk = __shfl(pre_key, i);
+                const int pa = __shfl(pre_agg, i);
                 int src = -1, fill = -1, from = -1;
                 if (lane == 0 && oki) {
                     if (hiti) {
                         // update() -> update_agg_hit (:65-78); the entry may have been evicted by an
                         // earlier insert of this same request (:90-94): then re-fetch and set()
-                        const bool alive = ld(&a.ekey[ei]) == ki;
+                        const bool alive = (dirty ? ld(&a.ekey[ei]) : pk) == ki;
                         if (alive) {
-                            const int old = ld(&a.eagg[ei]);
+                            const int old = dirty ? ld(&a.eagg[ei]) : pa;
                             if (old < agg_hit) {
                                 list_unlink(a, bucket(h, old), ei);
                                 list_append(a, bucket(h, agg_hit), ei);
@@ -267,6 +286,7 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
                             src = ei;
                         } else {
                             fill = evlfu_set(cs, a, h, mask, ki, agg_hit);
+                            dirty = true;
                         }
                         last_hit_table = i;
                     } else if (pick_random) {  // :142-152: the miss reuses the previous hit's vector
@@ -274,6 +294,7 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
                         src = -2;
                     } else {
                         fill = evlfu_set(cs, a, h, mask, ki, agg_hit);
+                        dirty = true;
                     }
                     s_src[i] = src; s_fill[i] = fill; s_from[i] = from;
                 }
@@ -371,30 +392,46 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
         __syncthreads();
 
         // ---- rows: hits from the arena, misses from the backing store; then fill inserted entries ----
+#if EVS_X_EXACT_STOP == 3
+        return;
+#endif
         float *out = args.out + rq * (long long)T * d;
-        for (int i = 0; i < T; i++) {
+        if (lane < T) {   // lane i resolves where row i comes from ...
+            const int i = lane;
             int src = s_src[i];
             int tsrc = i;
+            bool zero = false;
             if (src == -2) {  // approximate mode: vector of the previous hit (or zeros when there was none)
                 tsrc = s_from[i];
-                if (tsrc < 0) { for (int c = lane; c < d; c += 64) out[i * d + c] = 0.f; continue; }
-                src = s_src[tsrc];
+                if (tsrc < 0) { zero = true; tsrc = i; } else src = s_src[tsrc];
             }
-            const int rrow = args.requests[rq * T + tsrc];
+            const int rrow = s_req[tsrc];
             const bool ok = rrow >= 0 && rrow < args.backing_rows[tsrc];
             const unsigned char *rowp = nullptr;
-            if (src >= 0) rowp = a.arena + (long long)src * rb;
-            else if (ok) rowp = args.backing[tsrc] + (long long)rrow * rb;
-            for (int c = lane; c < d; c += 64) out[i * d + c] = rowp ? decode_elem(rowp, cs.codec, c) : 0.f;
+            if (!zero) {
+                if (src >= 0) rowp = a.arena + (long long)src * rb;
+                else if (ok) rowp = args.backing[tsrc] + (long long)rrow * rb;
+            }
+            s_rowp[i] = rowp;
         }
         __syncthreads();
+        // ... and the T*d elements leave as one flat, independent stream (not T dependent row trips)
+        for (int idx = lane; idx < T * d; idx += 64) {
+            const int i = idx / d, c = idx - i * d;
+            const unsigned char *rowp = s_rowp[i];
+            out[idx] = rowp ? decode_elem(rowp, cs.codec, c) : 0.f;
+        }
+        __syncthreads();
+#if EVS_X_EXACT_STOP == 4
+        return;
+#endif
         for (int i = 0; i < T; i++) {
             const int fe = s_fill[i];
             if (fe < 0) continue;
             // the entry may already have been evicted again by a later key of this request
-            const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)args.requests[rq * T + i];
+            const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)s_req[i];
             if (ld(&a.ekey[fe]) != ki) continue;
-            const unsigned char *rowp = args.backing[i] + (long long)args.requests[rq * T + i] * rb;
+            const unsigned char *rowp = args.backing[i] + (long long)s_req[i] * rb;
             unsigned char *dst = a.arena + (long long)fe * rb;
             for (int c = lane; c < rb; c += 64) dst[c] = rowp[c];
         }
@@ -543,12 +580,12 @@ struct C1C2Args {
     int threshold;            // high_agghit_threshold (evlfu_8.hpp:70)
 };
 
-__device__ void hot_load(Hot &h, const CacheState &cs, int lane) {
+__device__ void hot_load(Hot &h, const CacheState &cs, const CacheState *gs, int lane) {  // arrays straight from memory: a dynamic index into the by-value copy would put it in scratch
     if (lane == 0) {
         h.min_c1 = cs.min_c1; h.n_perfect = cs.n_perfect; h.count = cs.count; h.n_free = cs.n_free;
         h.n_flush = cs.n_flush; h.n_evict = cs.n_evict; h.least_freq = cs.least_freq; h.error = cs.error;
     }
-    for (int b = lane; b < kMaxBuckets; b += 64) { h.head[b] = cs.head[b]; h.tail[b] = cs.tail[b]; h.len[b] = cs.len[b]; }
+    for (int b = lane; b < kMaxBuckets; b += 64) { h.head[b] = gs->head[b]; h.tail[b] = gs->tail[b]; h.len[b] = gs->len[b]; }
 }
 __device__ void hot_store(const Hot &h, CacheState *gs, int lane) {
     if (lane == 0) {
@@ -573,20 +610,21 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
     const bool has_c3 = args.c3.st != nullptr;
     // per key: which tier's row to output (1/2), from its arena entry (>=0) or its backing store (-1);
     // and the entry to fill afterwards per tier
-    __shared__ int s_tier[kMaxTables], s_src[kMaxTables], s_fill1[kMaxTables], s_fill2[kMaxTables];
+    __shared__ int s_tier[kMaxTables], s_src[kMaxTables], s_fill1[kMaxTables], s_fill2[kMaxTables], s_req[kMaxTables];
     const int lane = threadIdx.x;
     const CacheState cs1 = *args.t1.st, cs2 = *args.t2.st;
     const CacheArrays a1 = args.t1.a, a2 = args.t2.a;
     const unsigned long long m1 = cs1.nslot_mask, m2 = cs2.nslot_mask;
     const int T = cs1.n_tables, d = cs1.dim;
-    hot_load(h1, cs1, lane);
-    hot_load(h2, cs2, lane);
+    hot_load(h1, cs1, args.t1.st, lane);
+    hot_load(h2, cs2, args.t2.st, lane);
     if (has_c3 && lane == 0) s3 = *args.c3.st;
     __syncthreads();
     long long n_perfect_req = 0, n_hits = 0;
 
     for (long long rq = 0; rq < args.B; rq++) {
         const int row = lane < T ? args.requests[rq * T + lane] : 0;
+        if (lane < T) s_req[lane] = row;
         const unsigned long long key = ((unsigned long long)(lane + 1) << 32) | (unsigned)row;
         const bool ok = lane < T && row >= 0 && row < args.t1.backing_rows[lane < T ? lane : 0] &&
                         row < args.t2.backing_rows[lane < T ? lane : 0];
@@ -676,7 +714,7 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
         float *out = args.out + rq * (long long)T * d;
         for (int i = 0; i < T; i++) {
             const int tier = s_tier[i], src = s_src[i];
-            const int rrow = args.requests[rq * T + i];
+            const int rrow = s_req[i];
             const unsigned char *rowp = nullptr;
             int codec = cs1.codec;
             if (tier == 1) rowp = src >= 0 ? a1.arena + (long long)src * cs1.row_bytes
@@ -695,15 +733,15 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
         }
         __syncthreads();
         for (int i = 0; i < T; i++) {
-            const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)args.requests[rq * T + i];
+            const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)s_req[i];
             const int f1 = s_fill1[i], f2 = s_fill2[i];
             if (f1 >= 0 && ld(&a1.ekey[f1]) == ki) {
-                const unsigned char *rowp = args.t1.backing[i] + (long long)args.requests[rq * T + i] * cs1.row_bytes;
+                const unsigned char *rowp = args.t1.backing[i] + (long long)s_req[i] * cs1.row_bytes;
                 unsigned char *dst = a1.arena + (long long)f1 * cs1.row_bytes;
                 for (int c = lane; c < cs1.row_bytes; c += 64) dst[c] = rowp[c];
             }
             if (f2 >= 0 && ld(&a2.ekey[f2]) == ki) {
-                const unsigned char *rowp = args.t2.backing[i] + (long long)args.requests[rq * T + i] * cs2.row_bytes;
+                const unsigned char *rowp = args.t2.backing[i] + (long long)s_req[i] * cs2.row_bytes;
                 unsigned char *dst = a2.arena + (long long)f2 * cs2.row_bytes;
                 for (int c = lane; c < cs2.row_bytes; c += 64) dst[c] = rowp[c];
             }

@@ -180,12 +180,14 @@ static int ensure_ready() {
         if (rc) return rc;
     }
     EVS_HIP_CHECK(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
-    EVS_HIP_CHECK(hipMalloc(&m.d_rows, kEvTables * 4));
-    EVS_HIP_CHECK(hipMalloc(&m.d_out, kEvTables * kEvDim * 4));
-    EVS_HIP_CHECK(hipMalloc(&m.d_hit, kEvTables));
-    EVS_HIP_CHECK(hipHostMalloc(&m.h_rows, kEvTables * 4, hipHostMallocDefault));
-    EVS_HIP_CHECK(hipHostMalloc(&m.h_out, kEvTables * kEvDim * 4, hipHostMallocDefault));
-    EVS_HIP_CHECK(hipHostMalloc(&m.h_hit, kEvTables, hipHostMallocDefault));
+    // the 26 ids and the 936 floats of a request cross the bus inside the kernel (mapped pinned buffers):
+    // one launch + one sync per ev_lookup, no copy commands
+    EVS_HIP_CHECK(hipHostMalloc(&m.h_rows, kEvTables * 4, hipHostMallocMapped));
+    EVS_HIP_CHECK(hipHostMalloc(&m.h_out, kEvTables * kEvDim * 4, hipHostMallocMapped));
+    EVS_HIP_CHECK(hipHostMalloc(&m.h_hit, kEvTables, hipHostMallocMapped));
+    EVS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&m.d_rows), m.h_rows, 0));
+    EVS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&m.d_out), m.h_out, 0));
+    EVS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&m.d_hit), m.h_hit, 0));
     m.ready = true;
     return EVS_OK;
 }
@@ -231,14 +233,12 @@ extern "C" float *ev_lookup(int *arr) {
     }
     Manager &m = g_mgr;
     memcpy(m.h_rows, arr, kEvTables * sizeof(int));
-    if (hipMemcpyAsync(m.d_rows, m.h_rows, kEvTables * 4, hipMemcpyHostToDevice, m.stream) != hipSuccess) return nullptr;
     const int rc = m.c2 ? evs_cache_request_c1c2c3(m.c1, m.c2, m.c3, 1, m.d_rows, m.d_out, m.d_hit, 23 /* evlfu_8.hpp:70 */, m.stream)
                         : evs_cache_request(m.c1, 1, m.d_rows, m.d_out, m.d_hit, -1, m.stream);
     if (rc != EVS_OK) {
         printf("%s\n", evs_last_error());
         return nullptr;
     }
-    (void)hipMemcpyAsync(m.h_out, m.d_out, kEvTables * kEvDim * 4, hipMemcpyDeviceToHost, m.stream);
     if (hipStreamSynchronize(m.stream) != hipSuccess) return nullptr;
     memcpy(g_emb_weights_in_1d_floats, m.h_out, sizeof g_emb_weights_in_1d_floats);
     // perfectHit += request_to_*(...) (cache_manager.cpp:179-207): counted on the device (n_perfect_hits)

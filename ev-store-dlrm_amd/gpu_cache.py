@@ -15,6 +15,17 @@ POLICY = {"evlfu": 0, "lru": 1, "lfu": 2}
 EVLFU_VARIANTS = {"python": (0.3, 0.95, 1, 0), "cpp": (0.3, 0.95, 0, 2), "cython": (0.4, 1.0, 1, 1)}
 
 
+def _dev_ptr(t):
+    """Device-side address of a device tensor or of a pinned host tensor."""
+    if t.is_cuda:
+        return t.data_ptr()
+    assert t.is_pinned() and t.is_contiguous(), "host tensors must be pinned (torch.Tensor.pin_memory) and contiguous"
+    p = _lib.lib().evs_host_device_pointer(t.data_ptr())
+    if not p:
+        raise _lib.EvsError(_lib.EVS_EINVAL, "pinned tensor is not device-accessible")
+    return p
+
+
 class GpuCache:
     def __init__(self, policy, capacity, n_tables=26, dim=36, codec=32, variant="python", device="cuda"):
         self.policy, self.capacity, self.n_tables, self.dim, self.codec = policy, int(capacity), n_tables, dim, codec
@@ -47,15 +58,18 @@ class GpuCache:
         _lib.check(_lib.lib().evs_cache_set_backing(self._h, ptrs, rows))
 
     def request(self, rows, approx_thres=-1, out=None, hit=None):
-        """rows: (B, n_tables) int32 device tensor.  Requests are replayed strictly in order.
-        Returns (hit (B,T) uint8, out (B,T,dim) fp32), both on the device."""
-        assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
+        """rows: (B, n_tables) int32 tensor.  Requests are replayed strictly in order.
+        Returns (hit (B,T) uint8, out (B,T,dim) fp32).
+        rows / out / hit may be device tensors or PINNED host tensors (torch pin_memory): pinned buffers are
+        read and written by the kernel itself, so the reference's one-request-at-a-time loop costs one launch
+        and one synchronise per request instead of two copies around it (synchronise before reading them)."""
+        assert rows.dtype == torch.int32 and rows.is_contiguous() and (rows.is_cuda or rows.is_pinned())
         B = int(rows.shape[0])
         if out is None:
             out = torch.empty((B, self.n_tables, self.dim), dtype=torch.float32, device=self.device)
         if hit is None:
             hit = torch.empty((B, self.n_tables), dtype=torch.uint8, device=self.device)
-        _lib.check(_lib.lib().evs_cache_request(self._h, B, rows.data_ptr(), out.data_ptr(), hit.data_ptr(),
+        _lib.check(_lib.lib().evs_cache_request(self._h, B, _dev_ptr(rows), _dev_ptr(out), _dev_ptr(hit),
                                                 int(approx_thres), torch.cuda.current_stream(self.device).cuda_stream))
         return hit, out
 

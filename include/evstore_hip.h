@@ -96,6 +96,13 @@ EVS_API int evs_embedding_bag_sum_stacked(int T, int64_t B, int d, int codec,
  * an out-of-range index (and clears the flag), else 0. */
 EVS_API int evs_check_index_errors(void *stream);
 
+/* Device-side address of a pinned (hipHostMalloc / torch pin_memory) host buffer, NULL when the
+ * buffer is not device-accessible.  The batch-1 entry points (evs_cache_request*, ev_lookup) take
+ * such pointers for the ids, the rows and the hit flags: a request of 26 ids and 936 floats then
+ * crosses the bus inside the kernel -- one launch and one synchronise per request, no copy commands
+ * (the reference's loop is one request at a time: cache_manager.cpp:231-237). */
+EVS_API void *evs_host_device_pointer(void *host_ptr);
+
 /* ---------------------------------------------------------------------------
  * a3: DLRM_Net.interact_features, arch_interaction_op="dot"
  *     (dlrm_s_pytorch.py:483-516)
