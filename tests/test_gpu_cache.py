@@ -45,6 +45,29 @@ def _run(E, policy, cap, tabs, reqs, chunk, approx=-1, variant="python", codec=3
     return c, np.concatenate(hits), np.concatenate(outs)
 
 
+def test_evlfu_trace_through_pinned_host_buffers(E, orc):
+    """The reference's loop is one request at a time with ids and rows on the host: the same golden trace
+    through PINNED host tensors (read / written by the kernel itself, no copies) gives the same bits."""
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    reqs = t["requests"][:400]
+    c = E.GpuCache("evlfu", 300, 26, 36, 32, "python")
+    c.set_backing([torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in tabs])
+    rows = torch.empty((1, 26), dtype=torch.int32).pin_memory()
+    out = torch.empty((1, 26, 36), dtype=torch.float32).pin_memory()
+    hit = torch.empty((1, 26), dtype=torch.uint8).pin_memory()
+    want = _unpack(t["evlfu_cap300_hits"], len(t["requests"]))[:400]
+    for i, rq in enumerate(reqs):
+        rows[0] = torch.from_numpy(rq.astype(np.int32))
+        c.request(rows, out=out, hit=hit)
+        torch.cuda.synchronize()
+        assert np.array_equal(hit[0].numpy().astype(bool), want[i]), i
+        for k in range(26):
+            assert np.array_equal(out[0, k].numpy(), tabs[k][rq[k]])
+    with pytest.raises(AssertionError):   # pageable host memory is refused, not silently copied
+        c.request(torch.zeros((1, 26), dtype=torch.int32))
+
+
 @pytest.mark.parametrize("cap,chunk", [(64, 1), (300, 7), (768, 1500), (2000, 64), (79, 1), (80, 33), (82, 1200)])
 def test_evlfu_trace_matches_reference(E, orc, cap, chunk):
     t = load_golden("cache_traces")
