@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Measurement sweep over the configurations SURVEY.md 8(d) lists (one MI355X):
+  cfg 2  Kaggle shape, all tables in HBM: B in {1,128,2048,16384,65536}, d in {36,16,64}, fp32 + u16/u8/u4
+  cfg 3  EvLFU C1 at 10 % of the rows: batched path at B in {2048,16384}, batch-1 exact path
+  cfg 4  Terabyte-shaped tables (MLPerf DLRM cardinalities capped at 40 M rows: external / synthetic), d=64 and 128
+  cfg 5  C1 (u8) + C2 (u4) two-tier exact path, batch-1 and B=2048 replay
+Prints a markdown report (committed as profiles/r01_sweep.md).  usage: python tools/sweep.py [--quick]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import evstore_dlrm_amd as E  # noqa: E402
+from evstore_dlrm_amd import gpu_cache  # noqa: E402
+
+# MLPerf DLRM (Criteo Terabyte) cardinalities with --max-ind-range=40000000 (bench/run_and_time.sh:17);
+# not in the reference tree: external, used as a synthetic shape only
+TERABYTE_LN = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
+               4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+HBM_PEAK = 8000.0
+
+
+def per_batch_us(fn, n_batches, iters):
+    """p50 / p95 / mean per-batch latency with one HIP event pair per batch (inputs resident)."""
+    for i in range(10):
+        fn(i)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for i in range(iters):
+        ev[i][0].record()
+        fn(i)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    lat = np.array([a.elapsed_time(b) * 1e3 for a, b in ev])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return float(np.percentile(lat, 50)), float(np.percentile(lat, 95)), e0.elapsed_time(e1) * 1e3 / iters
+
+
+def fused_rows(ln, d, bits, batches_B, iters, label):
+    ev = bench.make_tables(ln, d, bits=bits)
+    T = len(ln)
+    P = (T + 1) * T // 2
+    out = []
+    for B in batches_B:
+        bs = bench.make_batches(ln, B, 8, 1, "cuda", "uniform")
+        x = torch.rand(B, d, device="cuda")
+        R = torch.empty((B, d + P), device="cuda")
+        row_b = d * bits // 8
+        p50, p95, mean = per_batch_us(lambda i: E.apply_emb_interact(x, bs[i % 8][0], bs[i % 8][1], ev, out=R, one_index_per_bag=True), 8, iters)
+        g50, _, gmean = per_batch_us(lambda i: E.apply_emb_interact(x, bs[i % 8][0], bs[i % 8][1], ev, out=R), 8, iters)
+        alg = B * (T * (row_b + 8) + 4 * d + 4 * (d + P))
+        out.append("| %s | %d | %d | %d | %.1f | %.1f | %.2f | %.0f | %.1f%% | %.1f | %.2f |" % (
+            label, d, bits, B, p50, p95, T * B / mean / 1e3, alg / mean / 1e3, alg / mean / 1e3 / HBM_PEAK * 100, g50, T * B / gmean / 1e3))
+        if bits == 32 and B >= 128:
+            t50, _, tmean = per_batch_us(lambda i: E.interact_features(x, E.apply_emb(bs[i % 8][0], bs[i % 8][1], ev, None)), 8, max(20, iters // 4))
+            out[-1] += " %.1f | %.2f |" % (t50, T * B / tmean / 1e3)
+        else:
+            out[-1] += " – | – |"
+    del ev
+    torch.cuda.empty_cache()
+    return out
+
+
+def cache_rows(ln, d, iters):
+    """One cache, filled to capacity with 60 batches of 16 384 (Zipf 0.75), then timed at B = 2048 and 16 384."""
+    dev = torch.device("cuda")
+    ev = bench.make_tables(ln, d)
+    T = len(ln)
+    cap = int(0.10 * sum(ln))
+    cache = E.GpuCache("evlfu", cap, T, d, 32, "python", dev)
+    cache.set_backing(ev)
+    F = T + 1
+    warm = bench.make_batches(ln, 16384, 60, seed=3, device=dev, dist="zipf", alpha=0.75)
+    x = torch.rand((16384, d), device=dev)
+    R = torch.empty((16384, d + F * (F - 1) // 2), device=dev)
+    hit = torch.empty((16384, T), dtype=torch.uint8, device=dev)
+    for b in warm:
+        cache.lookup_interact(b[1].t().contiguous().to(torch.int32), x, out=R, hit=hit)
+    del warm
+    out = []
+    for B in (2048, 16384):
+        bs = bench.make_batches(ln, B, iters, seed=11 + B, device=dev, dist="zipf", alpha=0.75)
+        rows = [b[1].t().contiguous().to(torch.int32) for b in bs]
+        s0 = cache.batch_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in rows:
+            cache.lookup_interact(r, x[:B], out=R[:B], hit=hit[:B])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        s1 = cache.batch_stats()
+        out.append("| batched EvLFU C1, %d entries = 10 %% of the rows (full), Zipf 0.75 | %d | %.1f | %.2f | %.3f | %d |" % (
+            s1["size"], B, dt / iters * 1e6, T * B * iters / dt / 1e9, (s1["n_hits"] - s0["n_hits"]) / (T * B * iters),
+            s1["n_evict"] - s0["n_evict"]))
+    return out, ev
+
+
+def exact_rows(ev, ln, d, n_req):
+    """batch-1 exact paths: C1 fp32 (cfg 3) and C1 u8 + C2 u4 (cfg 5); ids and rows in pinned host buffers."""
+    T = len(ln)
+    dev = torch.device("cuda")
+    bs = bench.make_batches(ln, 256, (n_req + 255) // 256 + 1, seed=5, device=dev, dist="zipf", alpha=0.75)
+    reqs = torch.cat([b[1].t().contiguous().to(torch.int32) for b in bs])[:n_req].contiguous()
+    host = reqs.cpu()
+    rows = torch.empty((1, T), dtype=torch.int32).pin_memory()
+    o = torch.empty((1, T, d), dtype=torch.float32).pin_memory()
+    h = torch.empty((1, T), dtype=torch.uint8).pin_memory()
+    out = []
+    cap = 200000
+    c = E.GpuCache("evlfu", cap, T, d, 32, "python", dev)
+    c.set_backing(ev)
+    lat = []
+    for i in range(n_req):
+        t0 = time.perf_counter()
+        rows.copy_(host[i:i + 1])
+        c.request(rows, out=o, hit=h)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e6)
+    st = c.stats()
+    out.append("| C1 fp32 exact (cfg 3), %d entries | 1 | %.1f | %.1f | %.3f |" % (cap, np.percentile(lat[200:], 50), np.percentile(lat[200:], 95), st["n_hits"] / (T * n_req)))
+    t0 = time.perf_counter()
+    c.request(reqs[:2048].contiguous())
+    torch.cuda.synchronize()
+    out.append("| C1 fp32 exact, 2048 requests replayed in one launch | 2048 | %.1f per request | – | – |" % ((time.perf_counter() - t0) * 1e6 / 2048))
+    del c
+    ev8, ev4 = bench.make_tables(ln, d, bits=8, seed=8), bench.make_tables(ln, d, bits=4, seed=4)
+    c1 = E.GpuCache("evlfu", 9000, T, d, 8, "cpp", dev)      # 1 : 2 entries like "48-48-4" (evlfu_8.cpp:63-78), small enough
+    c2 = E.GpuCache("evlfu", 18000, T, d, 4, "cpp", dev)     # that C1 fills and the odd/even routing to C2 starts
+    c1.set_backing(ev8)
+    c2.set_backing(ev4)
+    tier = torch.empty((1, T), dtype=torch.uint8, device=dev)
+    od = torch.empty((1, T, d), device=dev)
+    rd = torch.empty((1, T), dtype=torch.int32, device=dev)
+    lat = []
+    n_c1 = n_c2 = 0
+    for i in range(n_req):
+        t0 = time.perf_counter()
+        rd.copy_(host[i:i + 1], non_blocking=True)
+        gpu_cache.request_c1c2(c1, c2, rd, out=od, tier=tier)
+        o.copy_(od, non_blocking=True)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e6)
+    t_all, _ = gpu_cache.request_c1c2(c1, c2, reqs[:2048].contiguous())
+    n_c1, n_c2 = int((t_all == 1).sum()), int((t_all == 2).sum())
+    out.append("| C1 u8 (9 000) + C2 u4 (18 000) exact (cfg 5) | 1 | %.1f | %.1f | C1 %.3f / C2 %.3f (of the next 2048 requests) |" % (
+        np.percentile(lat[200:], 50), np.percentile(lat[200:], 95), n_c1 / (2048 * T), n_c2 / (2048 * T)))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    a = ap.parse_args()
+    it = 50 if a.quick else 200
+    print("# Round-1 sweep (one MI355X, synthetic uniform indices unless stated; HBM peak used: 8 000 GB/s)\n")
+    print("`fused` = `apply_emb_interact` (one kernel; one index per bag declared); `offsets` = the same with `lS_o` read and")
+    print("validated; `two-call` = `apply_emb` then `interact_features`.  Latencies are per batch, HIP events, inputs resident.")
+    print("GB/s = algorithmic bytes (SURVEY 8(d): rows + indices + x read, R written) / mean batch time.\n")
+    print("| shape | d | bits | B | fused p50 µs | p95 µs | G lookups/s | GB/s | of peak | offsets p50 µs | G lookups/s | two-call p50 µs | G lookups/s |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    Bs = [1, 128, 2048, 16384] if a.quick else [1, 128, 2048, 16384, 65536]
+    for line in fused_rows(bench.KAGGLE_LN, 36, 32, Bs, it, "Kaggle (cfg 2)"):
+        print(line, flush=True)
+    for d in (16, 64):
+        for line in fused_rows(bench.KAGGLE_LN, d, 32, [2048, 16384], it, "Kaggle"):
+            print(line, flush=True)
+    for bits in (16, 8, 4):
+        for line in fused_rows(bench.KAGGLE_LN, 36, bits, [2048, 16384], it, "Kaggle, reduced precision"):
+            print(line, flush=True)
+    for d in (64, 128):
+        for line in fused_rows(TERABYTE_LN, d, 32, [2048, 16384], it, "Terabyte-shaped (cfg 4, 1 GPU)"):
+            print(line, flush=True)
+    print("\n| cache tier | B | µs per batch | G lookups/s | hit rate | evictions in the timed batches |")
+    print("|---|---|---|---|---|---|")
+    rows, ev = cache_rows(bench.KAGGLE_LN, 36, 30)
+    for line in rows:
+        print(line, flush=True)
+    print("\n| exact (reference batch-1 semantics), ids and rows on the host | B | p50 µs | p95 µs | hit rate |")
+    print("|---|---|---|---|---|")
+    for line in exact_rows(ev, bench.KAGGLE_LN, 36, 800 if a.quick else 1500):
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
