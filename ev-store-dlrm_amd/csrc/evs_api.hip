@@ -55,6 +55,33 @@ const void *zero_page() {
     return pages[dev];
 }
 
+// Flag slot of one optimistic launch pair (evs_fused.hip): a ring of 1024 device ints per device and a
+// process-wide id counter.  The bag-1 kernel writes the pair's id into its slot when the bet is lost; the
+// general kernel runs only if it finds its id there.  Nothing is ever reset: an id is used once.
+int *optimistic_slot(int *id_out) {
+    static std::mutex mu;
+    static int *rings[64] = {nullptr};
+    static int next_id = 1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        set_error("hipGetDevice failed (no usable GPU?)");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!rings[dev]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, 1024 * sizeof(int)) != hipSuccess || hipMemset(p, 0, 1024 * sizeof(int)) != hipSuccess) {
+            set_error("hipMalloc of the optimistic-launch flags failed");
+            return nullptr;
+        }
+        rings[dev] = static_cast<int *>(p);
+    }
+    if (next_id >= 0x7ffffff0) next_id = 1;
+    const int id = next_id++;
+    *id_out = id;
+    return rings[dev] + (id & 1023);
+}
+
 }  // namespace evs
 
 extern "C" int evs_abi_version(void) { return EVS_ABI_VERSION; }

@@ -36,6 +36,7 @@ void set_error(const char *fmt, ...);
 int *index_error_flag();
 // 4 KiB of zeros in HBM (one per device): the "row" read by lanes that have nothing to fetch
 const void *zero_page();
+int *optimistic_slot(int *id_out);   // evs_api.hip
 
 // ---- codecs: bit-exact device restatements of the reference decoders ----------------
 // 8-bit: mixed_precs_caching/evlfu_8.cpp:370-378, all fp32, division kept as a division

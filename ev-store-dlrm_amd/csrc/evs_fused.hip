@@ -46,7 +46,10 @@ struct FusedArgs {
     const int64_t *dummy_i64;  // any readable int64 (lanes with nothing to fetch read it)
     const float *dummy_f32;
     const void *zeros;         // >= 1 KiB of zero bytes (idle lanes / empty bags read rows from it)
-    int bag1;                  // every indirect feature: one index per bag, no offsets array
+    int bag1;                  // 1: every indirect feature has one index per bag, no offsets array;
+                               // 2: offsets ARE given and the launch bets they are arange (see opt_flag)
+    int *opt_flag; int opt_id; // optimistic launch triple: offsets_arange_kernel writes opt_id here when an offsets
+                               // array is not arange; then the bag-1 loop runs if it is absent, the general loop if present
     int enc_lds;               // reduced precision: feature 0 is x, every other feature a 4-byte aligned table
 };
 
@@ -460,6 +463,12 @@ constexpr int lds_min_blocks() {
 // decoded through the per-block LDS table (evs_common.h) -- x chunks overwrite row 0 afterwards.
 template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1>
 __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_interact_dot_lds_kernel(const FusedArgs args) {
+    if constexpr (HAS_INDIRECT && !PTRS) {   // optimistic launch triple (see offsets_arange_kernel): the bag-1 loop runs
+        if (args.opt_flag) {                   // when the offsets are arange, the general loop when they are not
+            const bool ragged = *args.opt_flag == args.opt_id;
+            if (BAG1 ? ragged : !ragged) return;
+        }
+    }
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
     constexpr int d = 4 * (4 * CQ + REM);
@@ -590,6 +599,7 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
     unsigned long long ok1[NR], sub1[NR];   // ENC: row present (else it decodes as zeros); u4 half-word phase
     float w1[NR];
 
+
     // every offsets array (and the dummy, >= B entries) has two readable entries around any bag
     bool short_off = false;
 #pragma unroll
@@ -625,6 +635,7 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
                 more2[rr] = 0;
                 // PTRS: the (B, F-1) pointer table of the cache tier, feature f at column f-1
                 idx_raw[rr] = lf[rr].idx[lf[rr].indirect ? (PTRS ? (int64_t)b * (F - 1) : (int64_t)b) : 0];
+
             }
         } else if constexpr (HAS_INDIRECT) {
             const int b = (int)sample_b(n);
@@ -726,6 +737,7 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
         const int64_t b = wave_id + (int64_t)k * waves_total;  // wave-uniform
         // rows of sample k have landed once every outstanding vector-memory op has retired
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
         float4 a[NR][NC];
         if constexpr (ENC) {
 #pragma unroll
@@ -867,6 +879,28 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
     if (bad) atomicOr(args.err, 1);
 }
 
+// offsets[f][b] == b for every indirect feature and every bag (and offsets[f][B] == B where the array has B+1
+// entries; an array of B entries needs nnz == B, checked on the host)?  Coalesced read of 8*T*B bytes.
+__global__ void __launch_bounds__(256) offsets_arange_kernel(const FusedArgs args) {
+    const int64_t n = args.B * args.F;
+    bool ragged = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / args.B);
+        const int64_t b = i - (int64_t)f * args.B;
+        const int64_t *off = args.indices[f] ? args.offsets[f] : nullptr;
+        if (!off) continue;
+        ragged |= off[b] != b;
+        if (b == args.B - 1 && args.off_len[f] > args.B) ragged |= off[args.B] != args.B;
+    }
+    if (__any(ragged) && (threadIdx.x & 63) == 0) atomicMax(args.opt_flag, args.opt_id);
+}
+
+static bool optimistic_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_OPTIMISTIC"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 static bool use_lds_rows() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("EVS_FUSED_LDS"); v = e ? atoi(e) : 1; }
@@ -895,10 +929,18 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
     if constexpr ((4 * CQ + REM) <= 32 && (CODEC == 32 || (HAS_INDIRECT && !PTRS && !WEIGHTED))) {
         if (use_lds_rows() && (CODEC == 32 || a.enc_lds)) {
             if constexpr (HAS_INDIRECT && !WEIGHTED) {
-                if (PTRS || a.bag1) {
+                if (PTRS || a.bag1 == 1) {
                     if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
                     else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
                     return;
+                }
+                if constexpr (!PTRS) {
+                    if (a.bag1 == 2) {   // optimistic triple: arange check, the bag-1 loop, then (below) the general loop
+                        int nb = (int)((a.B * a.F + 255) / 256); if (nb > kNumCu * 4) nb = kNumCu * 4;
+                        hipLaunchKernelGGL(offsets_arange_kernel, dim3(nb), dim3(256), 0, st, a);
+                        if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
+                        else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
+                    }
                 }
             }
             if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, false>>(a, st);
@@ -945,7 +987,7 @@ int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_
     }
     a.R = R; a.B = B; a.F = F; a.d = d; a.itself = itself ? 1 : 0;
     a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
-    a.dummy_i64 = iota; a.dummy_f32 = x; a.bag1 = 1; a.enc_lds = 0;
+    a.dummy_i64 = iota; a.dummy_f32 = x; a.bag1 = 1; a.enc_lds = 0; a.opt_flag = nullptr; a.opt_id = 0;
     if (!launch_cpq<32, false, true, true>(a, st)) { set_error("fused_interact_from_row_ptrs: no kernel for d=%d", d); return EVS_EINVAL; }
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
@@ -1025,6 +1067,22 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
         if (feats[f].n_rows == 0 || !feats[f].src) a.src[f] = a.zeros;  // never dereferenced for a valid row
     }
     EVS_REQUIRE(!weighted || codec == 32, "evs_emb_interact_dot: weighted pooling is only built for fp32 tables");
+    // Offsets given: bet that they are arange (what the Criteo collate always produces).  A small kernel reads
+    // the offsets once (coalesced) and records the verdict; the one-index-per-bag loop and the general loop are
+    // both launched and the one that does not apply returns at once -- no host round trip.  Needs idx[b]
+    // readable for every b (nnz >= B) and a last bag that ends at B.
+    a.opt_flag = nullptr; a.opt_id = 0;
+    // (three launches: below ~8 k samples the two extra launches cost more than the faster loop returns)
+    if (indirect && !a.bag1 && !weighted && (codec == 32 || a.enc_lds) && B >= 8192 && optimistic_enabled()) {
+        bool can = true;
+        for (int f = 0; f < F && can; f++)
+            if (feats[f].indices) can = feats[f].nnz >= B && (a.off_len[f] > B || feats[f].nnz == B);
+        if (can) {
+            a.opt_flag = optimistic_slot(&a.opt_id);
+            if (!a.opt_flag) return EVS_EHIP;
+            a.bag1 = 2;
+        }
+    }
     bool ok;
     if (!indirect) {
         ok = launch_cpq<32, false, false>(a, st);

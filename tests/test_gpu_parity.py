@@ -283,6 +283,51 @@ def test_fused_codec_26_tables_one_index_per_bag(E, orc, codec):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
+@pytest.mark.parametrize("codec", [32, 8])
+def test_fused_optimistic_offsets_pair(E, orc, codec):
+    """lS_o given: the library bets on offsets == arange (bag-1 loop with the check folded in) and falls back to
+    the general loop on the device when the bet is lost.  Won bet, lost bet (one offset moved, one table ragged,
+    a longer last bag) and B+1-entry offsets all give the bits of the two-call path."""
+    from bench import KAGGLE_LN
+    d, B = 36, 8192 + 77   # the bet is placed from 8192 samples up
+    rs = np.random.RandomState(5 + codec)
+    ln = [min(n, 400) for n in KAGGLE_LN]
+    if codec == 32:
+        ev = E.EVTables.from_fp32([torch.from_numpy(rs.uniform(-1, 1, size=(n, d)).astype(np.float32)) for n in ln])
+    else:
+        ev = E.EVTables([torch.from_numpy(orc.encode_table(rs.uniform(-1, 1, size=(n, d)).astype(np.float32), codec)).cuda() for n in ln], d, codec)
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+
+    def run(offs, idxs):
+        o = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in offs]
+        i = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in idxs]
+        a = E.apply_emb_interact(x, o, i, ev, check_indices=True)
+        b = E.interact_features(x, E.apply_emb(o, i, ev, None))
+        assert torch.equal(a, b)
+        return a
+
+    idx = [rs.randint(0, n, size=B) for n in ln]
+    ar = [np.arange(B) for _ in ln]
+    won = run(ar, idx)
+    assert torch.equal(won, E.apply_emb_interact(x, torch.arange(B, device="cuda").repeat(26, 1), torch.from_numpy(np.stack(idx)).cuda(), ev,
+                                                  one_index_per_bag=True))
+    # lost: one offset of one table moved (bag 5000 empty, bag 4999 of two)
+    off2 = [a.copy() for a in ar]
+    off2[7][5000] = 5001
+    run(off2, idx)
+    # lost: one table ragged (0..3 indices per bag), the others arange
+    lens = rs.randint(0, 4, size=B)
+    off3 = [a.copy() for a in ar]
+    idx3 = list(idx)
+    off3[11] = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    idx3[11] = rs.randint(0, ln[11], size=int(lens.sum()) + 5)
+    run(off3, idx3)
+    # arange offsets but a longer last bag (nnz = B + 3): not eligible for the bet
+    idx4 = list(idx)
+    idx4[3] = rs.randint(0, ln[3], size=B + 3)
+    run(ar, idx4)
+
+
 def test_sharded_hip_backend_two_virtual_ranks(E, orc):
     """The sharded op with the HIP backend: two 'ranks' on one GPU, the all-to-all done by hand
     (block copies) -- validates send layout, receive-block feature pointers and the batch-slice
