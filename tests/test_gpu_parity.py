@@ -208,6 +208,23 @@ def test_full_size_kaggle_properties(E):
     li, lj = torch.tril_indices(27, 27, offset=-1, device="cuda")
     ref = torch.cat([x, Z[:, li, lj]], dim=1)
     torch.testing.assert_close(R, ref, rtol=1e-5, atol=1e-5)
+    # the bench configuration itself (B = 16384): fused kernel with the offsets bet, with offsets == NULL, and the
+    # two-call path agree bit for bit; a checksum of checksums pins the x passthrough and the row order
+    B2 = 16384
+    idx2 = torch.stack([torch.randint(0, n, (B2,), device="cuda", generator=g) for n in KAGGLE_LN])
+    off2b = torch.arange(B2, device="cuda").repeat(26, 1)
+    x2 = torch.randn(B2, 36, device="cuda")
+    a = E.apply_emb_interact(x2, off2b, idx2, ev, check_indices=True)
+    b = E.apply_emb_interact(x2, off2b, idx2, ev, one_index_per_bag=True)
+    c = E.interact_features(x2, E.apply_emb(off2b, idx2, ev))
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(a[:, :36], x2)
+    # Z[b, pair(k+1, 0)] = <row_k, x>: recompute column 0 of the triangle for three tables from the table rows
+    for k in (0, 9, 25):
+        f = k + 1
+        col = 36 + f * (f - 1) // 2
+        want = (ev.fp32_view(k)[idx2[k]].double() * x2.double()).sum(1)
+        torch.testing.assert_close(a[:, col].double(), want, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ["dlrm_ragged_small", "dlrm_kaggle_small", "dlrm_weighted_itself", "dlrm_d64",
