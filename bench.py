@@ -184,8 +184,9 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache-tier", action="store_true", help="skip the configs[2] (EvLFU cache) section")
-    ap.add_argument("--placement", default="rows+replicate", choices=["count", "rows", "rows+replicate"],
-                    help="table placement for --gpus > 1 (sharded.plan_placement)")
+    ap.add_argument("--placement", default="hbm", choices=["hbm", "count", "rows", "rows+replicate"],
+                    help="table placement for --gpus > 1 (sharded.plan_placement); hbm = replicate what fits --replicate-gb")
+    ap.add_argument("--replicate-gb", type=float, default=64.0, help="per-GPU HBM budget for replicated tables (hbm placement)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one process")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()

@@ -33,10 +33,27 @@ from .dlrm_ops import EVTables, _stream_ptr
 
 
 # ----------------------------------------------------------------------------- placement
-def plan_placement(ln_emb, world, policy="rows+replicate", replicate_max_rows=1_000_000):
-    """-> owner[t] in {0..world-1} or -1 (replicated on every rank)."""
+def plan_placement(ln_emb, world, policy="rows+replicate", replicate_max_rows=1_000_000, replicate_budget_rows=None):
+    """-> owner[t] in {0..world-1} or -1 (replicated on every rank).
+    count            contiguous by table count (extend_distributed.get_my_slice)
+    rows             LPT greedy on row counts (BASELINE: "tables shard by row-count")
+    rows+replicate   tables of at most replicate_max_rows rows on every rank, the rest by rows
+    hbm              the same with the threshold set by memory: smallest tables first are replicated while their rows
+                     fit replicate_budget_rows per GPU (288 GB of HBM3E: the whole Kaggle model is 4.9 GB), the rest
+                     by rows.  Replicated tables need no exchange at all."""
     T = len(ln_emb)
     owner = [0] * T
+    if policy == "hbm":
+        budget = replicate_budget_rows if replicate_budget_rows is not None else sum(ln_emb)
+        used = 0
+        thr = -1
+        for n in sorted(ln_emb):
+            if used + n > budget:
+                break
+            used += n
+            thr = n
+        # ties: every table with <= thr rows was counted or the loop stopped before its size
+        return plan_placement(ln_emb, world, "rows+replicate", replicate_max_rows=thr)
     if policy == "count":  # extend_distributed.get_my_slice: contiguous by table count
         k, m = divmod(T, world)
         t = 0
@@ -67,7 +84,7 @@ class HipBackend:
     """libevstore_hip.so kernels (the product path)."""
 
     def __init__(self, device):
-        self.device = device
+        self.device = torch.device(device)
         self._cache = {}
 
     def make_tables(self, weights, d):
@@ -136,15 +153,17 @@ class ShardedEmbeddingInteract:
     """
 
     def __init__(self, ln_emb, d, rank, world, local_weights, backend, policy="rows+replicate",
-                 replicate_max_rows=1_000_000, group=None, itself=False, one_index_per_bag=False):
+                 replicate_max_rows=1_000_000, group=None, itself=False, one_index_per_bag=False,
+                 replicate_budget_rows=None):
         self.ln_emb, self.d, self.rank, self.world = list(ln_emb), int(d), rank, world
         self.group, self.itself, self.backend = group, itself, backend
         # lS_o[k] == arange(B) for every table (Criteo collate): replicated tables skip the offsets stage
         self.one_index_per_bag = one_index_per_bag
-        self.owner = plan_placement(ln_emb, world, policy, replicate_max_rows)
+        self.owner = plan_placement(ln_emb, world, policy, replicate_max_rows, replicate_budget_rows)
         self.own = [[t for t in range(len(ln_emb)) if self.owner[t] == r] for r in range(world)]
         self.my_own = self.own[rank]
         self.replicated = [t for t in range(len(ln_emb)) if self.owner[t] == -1]
+        self.any_sharded = any(o >= 0 for o in self.owner)
         held = self.my_own + self.replicated
         assert sorted(local_weights.keys()) == sorted(held), "rank %d must hold tables %s" % (rank, held)
         self.local_id = {t: i for i, t in enumerate(held)}
@@ -185,6 +204,9 @@ class ShardedEmbeddingInteract:
         """pool() + launch the all-to-all (async)."""
         Bg = int(lS_o[0].shape[0])
         Bl, in_splits, out_splits = self._splits(Bg)
+        if not self.any_sharded:   # every table replicated: nothing to pool for others, nothing to exchange
+            like = lS_o[0].new_empty((0,), dtype=torch.float32)
+            return (None, self._buffers(Bg, slot, like)[1], Bg, Bl, out_splits)
         send, recv = self.pool(lS_o, lS_i, slot)
         work = None
         if self.world > 1:
@@ -244,6 +266,11 @@ class ShardedEmbeddingInteract:
                 "lo": [lS_o[t] for t in self.my_own], "li": [lS_i[t] for t in self.my_own]}
 
     def run_start(self, pl):
+        """Pooling gather of the owned tables + the all-to-all (async); nothing when every table is replicated.  Same stream as the interaction: a
+        separate pooling stream with per-slot events was measured at world=1 and LOST (66-76 us per step against
+        47) -- at this batch size the step is bounded by host-side launch cost, not by GPU overlap."""
+        if not self.any_sharded:
+            return None
         self.backend.bag_sum_into(self.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], len(self.my_own), self.d)
         if self.world > 1:
             return dist.all_to_all_single(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"], group=self.group,
@@ -263,16 +290,14 @@ class ShardedEmbeddingInteract:
 
 
 # ----------------------------------------------------------------------------- bench (N > 1)
-def bench_sharded(args, ln_emb, rank, world, dev):
-    """Weak scaling: global batch = world * args.batch; every rank times the same K steps."""
-    from bench import HBM_PEAK_GBPS  # noqa: F401  (kept for symmetry of the report)
+def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roofline):
+    """Time args.steps steps of one placement policy (all ranks in lockstep); returns a dict."""
     d = args.dim
     T = len(ln_emb)
     Bl = args.batch
     Bg = Bl * world
     backend = HipBackend(dev)
-    policy = getattr(args, "placement", "rows+replicate")
-    owner = plan_placement(ln_emb, world, policy)
+    owner = plan_placement(ln_emb, world, policy, replicate_budget_rows=budget_rows)
     held = [t for t in range(T) if owner[t] in (rank, -1)]
     g = torch.Generator(device=dev)
     weights = {}
@@ -280,7 +305,8 @@ def bench_sharded(args, ln_emb, rank, world, dev):
         g.manual_seed(1000 + t)
         a = float(np.sqrt(1.0 / ln_emb[t]))
         weights[t] = torch.empty((ln_emb[t], d), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
-    op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy, one_index_per_bag=True)
+    op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy, one_index_per_bag=True,
+                                  replicate_budget_rows=budget_rows)
     # every rank generates the same full-batch indices (same seed), as the reference feeds them
     g.manual_seed(7)
     nb = 4
@@ -319,17 +345,84 @@ def bench_sharded(args, ln_emb, rank, world, dev):
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    n_sh = sum(1 for t in range(T) if owner[t] >= 0)
+    n_rep = T - n_sh
+    res = {"dt": dt, "owner": owner, "n_sharded": n_sh, "n_replicated": n_rep,
+           "a2a_bytes": 4 * d * Bl * n_sh * (world - 1), "roofline": None}
+    # roofline of the launches a rank issues per batch (rank 0, HIP events on the launch stream, after the timed
+    # region): the pooling gather of its own tables over the GLOBAL batch (if any) and the interaction over its
+    # LOCAL batch (received pooled vectors dense, replicated tables gathered inside the kernel)
+    if want_roofline and rank == 0:
+        from bench import HBM_PEAK_GBPS as peak
+        n_own = len(op.my_own)
+        pl = plans[(0, 0)]
+        iters = 20
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        t_pool = t_fin = 0.0
+        for _ in range(iters):
+            ev[0].record()
+            if n_own:
+                backend.bag_sum_into(op.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], n_own, d)
+            ev[1].record()
+            backend.interact_mixed(pl["x"], pl["specs"], op.ev, d, op.itself, out=pl["R"])
+            ev[2].record()
+            torch.cuda.synchronize()
+            t_pool += ev[0].elapsed_time(ev[1])
+            t_fin += ev[1].elapsed_time(ev[2])
+        t_pool, t_fin = t_pool / iters, t_fin / iters
+        pool_bytes = n_own * Bg * (4 * d + 8 + 4 * d)            # row + index read, pooled vector written (one index/bag)
+        fin_bytes = Bl * (4 * d * (1 + n_sh) + n_rep * (4 * d + 8) + 4 * (d + P))
+        dom = ("pool", pool_bytes, t_pool) if (n_own and t_pool >= t_fin) else ("interact", fin_bytes, t_fin)
+        res["roofline"] = {
+            "bound": "hbm",
+            "kernel": "embedding_bag_sum_kernel (own tables x global batch)" if dom[0] == "pool" else
+                      "emb_interact_dot_lds_kernel (local batch: %d received dense features + %d replicated tables)" % (n_sh, n_rep),
+            "achieved": dom[1] / dom[2] / 1e6, "peak": peak, "unit": "GB/s", "frac": dom[1] / dom[2] / 1e6 / peak,
+            "traffic": None, "bytes_per_launch": dom[1], "avg_launch_ms": dom[2],
+            "pool": {"ms": t_pool, "bytes": pool_bytes, "tables": n_own}, "interact": {"ms": t_fin, "bytes": fin_bytes}}
+    del op, plans, weights
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_sharded(args, ln_emb, rank, world, dev):
+    """Weak scaling: global batch = world * args.batch; every rank times the same K steps.
+    The headline placement is memory-aware ("hbm"): tables are replicated on every GPU while they fit the
+    per-GPU budget (--replicate-gb), the rest is sharded by rows and exchanged with one all_to_all_single per
+    batch.  The whole Kaggle model is 4.9 GB, so on 288 GB parts nothing needs exchanging; the table-sharded
+    all-to-all path (rows+replicate, tables above 1 M rows sharded) is timed beside it in the same run."""
+    d = args.dim
+    T = len(ln_emb)
+    Bl = args.batch
+    Bg = Bl * world
+    policy = getattr(args, "placement", "hbm")
+    budget_rows = int(getattr(args, "replicate_gb", 64.0) * 1e9 / (4 * d))
+    main = _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, True)
+    extra = None
+    if main["n_sharded"] == 0:   # the exchange path, for the record
+        e = _bench_policy(args, ln_emb, rank, world, dev, "rows+replicate", None, True)
+        extra = {"value": T * Bg * args.steps / e["dt"], "unit": "lookups/s", "ms_per_step": e["dt"] / args.steps * 1e3,
+                 "placement": "rows+replicate (tables above 1 M rows sharded by rows, one all_to_all_single per batch)",
+                 "owner": e["owner"], "a2a_bytes_per_step_all_links": e["a2a_bytes"], "roofline": e["roofline"]}
+    dt = main["dt"]
     lookups = T * Bg
-    a2a_bytes = 4 * d * Bl * sum(1 for t in range(T) if owner[t] >= 0) * (world - 1)
+    if main["n_sharded"] == 0:
+        what = ("all %d tables replicated on every GPU (%.1f GB of %s GB HBM): pure data parallel, no exchange step"
+                % (T, sum(ln_emb) * 4 * d / 1e9, "288"))
+        par = "replicated tables x%d (data parallel)" % world
+    else:
+        what = ("%d tables sharded by rows + %d replicated (%s), one all_to_all_single of pooled vectors per batch over "
+                "RCCL/xGMI" % (main["n_sharded"], main["n_replicated"], policy))
+        par = "table-sharded x%d + a2a" % world
     return {
         "metric": "inference lookups/sec, Criteo-Kaggle 26-table DLRM (apply_emb + interact_features)",
         "value": lookups * args.steps / dt, "unit": "lookups/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Criteo-Kaggle 26 tables x d=%d fp32 sharded over %d GPUs (%s), one all_to_all_single "
-                               "of pooled vectors per batch over RCCL/xGMI, uniform indices" % (d, world, policy),
-                   "batch_per_gpu": Bl, "global_batch": Bg, "tables": T, "dim": d,
-                   "parallelism": "table-sharded x%d + a2a" % world,
-                   "owner": owner, "a2a_bytes_per_step_all_links": a2a_bytes},
-        "roofline": None, "cpu_baseline": None,
+        "config": {"workload": "Criteo-Kaggle 26 tables x d=%d fp32 over %d GPUs: %s; uniform indices, one index per bag"
+                               % (d, world, what),
+                   "batch_per_gpu": Bl, "global_batch": Bg, "tables": T, "dim": d, "parallelism": par,
+                   "placement": policy, "owner": main["owner"], "a2a_bytes_per_step_all_links": main["a2a_bytes"]},
+        "roofline": main["roofline"], "cpu_baseline": None, "table_sharded_a2a": extra,
     }

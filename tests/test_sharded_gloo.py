@@ -70,10 +70,12 @@ def _worker(rank, world, port, policy, q):
         from evstore_dlrm_amd import sharded
         Bg = 6 * world
         tabs, lS_o, lS_i, x = _data(3, Bg)
-        owner = sharded.plan_placement(LN, world, policy, replicate_max_rows=100)
+        budget = {"hbm": sum(LN), "hbm-partial": 150}.get(policy)   # everything replicated / only the small tables
+        pol = "hbm" if policy.startswith("hbm") else policy
+        owner = sharded.plan_placement(LN, world, pol, replicate_max_rows=100, replicate_budget_rows=budget)
         held = {t: torch.from_numpy(tabs[t]) for t in range(len(LN)) if owner[t] in (rank, -1)}
-        op = sharded.ShardedEmbeddingInteract(LN, D, rank, world, held, OracleBackend(), policy=policy,
-                                              replicate_max_rows=100)
+        op = sharded.ShardedEmbeddingInteract(LN, D, rank, world, held, OracleBackend(), policy=pol,
+                                              replicate_max_rows=100, replicate_budget_rows=budget)
         Bl = Bg // world
         R = op.forward(torch.from_numpy(x[rank * Bl:(rank + 1) * Bl]), [torch.from_numpy(o) for o in lS_o],
                        [torch.from_numpy(i) for i in lS_i])
@@ -93,7 +95,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,policy", [(2, "count"), (2, "rows"), (2, "rows+replicate"), (3, "rows+replicate")])
+@pytest.mark.parametrize("world,policy", [(2, "count"), (2, "rows"), (2, "rows+replicate"), (3, "rows+replicate"),
+                                          (2, "hbm"), (2, "hbm-partial")])
 def test_sharded_forward_matches_single_process(world, policy):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -108,6 +111,11 @@ def test_sharded_forward_matches_single_process(world, policy):
     owner = res[0][2]
     if policy == "rows+replicate":
         assert all((o == -1) == (LN[t] <= 100) for t, o in enumerate(owner))
+    if policy == "hbm":          # the whole model fits the budget: no table is sharded, no exchange happens
+        assert all(o == -1 for o in owner)
+    if policy == "hbm-partial":  # smallest tables first while they fit 150 rows
+        rep = sorted(LN[t] for t, o in enumerate(owner) if o == -1)
+        assert rep and sum(rep) <= 150 and any(o >= 0 for o in owner)
 
 
 def test_placement_policies():
@@ -121,6 +129,10 @@ def test_placement_policies():
     assert max(load) == 10131227  # one giant table alone on a rank: row balance != work balance
     rep = sharded.plan_placement(KAGGLE_LN, 8, "rows+replicate")
     assert sum(1 for o in rep if o >= 0) == 5 and sum(KAGGLE_LN[t] for t, o in enumerate(rep) if o == -1) < 600000
+    # memory-aware: 64 GB per GPU holds the whole 4.9 GB model; 1 GB holds everything but the four largest tables
+    assert all(o == -1 for o in sharded.plan_placement(KAGGLE_LN, 8, "hbm", replicate_budget_rows=int(64e9 / 144)))
+    one_gb = sharded.plan_placement(KAGGLE_LN, 8, "hbm", replicate_budget_rows=int(1e9 / 144))
+    assert sum(1 for o in one_gb if o >= 0) == 4 and sorted(o for o in one_gb if o >= 0) == [0, 1, 2, 3]
 
 
 def test_ext_dist_helpers_match_reference_semantics():
