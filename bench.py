@@ -323,11 +323,46 @@ def main():
                      "bytes_per_launch": kernel_bytes, "avg_launch_ms": kernel_ms},
         "general_offsets_path": {"value": lookups * args.steps / dtg, "unit": "lookups/s",
                                  "ms_per_step": dtg / args.steps * 1e3,
-                                 "note": "same fused launch, lS_o read and validated (any bag size)"},
+                                 "note": ""},
         "two_call_path": {"value": lookups * args.steps / dt2, "unit": "lookups/s",
                           "ms_per_step": dt2 / args.steps * 1e3,
                           "note": "apply_emb (fused 26-table gather) then interact_features, (T,B,d) intermediate in HBM"},
     }
+    result["general_offsets_path"]["note"] = ("lS_o given (any bag size allowed): offsets checked on the device, the one-index "
+                                              "loop runs when they are arange, the general loop when not")
+    # ---- the same launch at a larger batch (fixed launch / pipeline-fill cost amortised), and reduced precision ----
+    if B < 65536:
+        Bb = 65536
+        bb = make_batches(KAGGLE_LN, Bb, 4, seed=9, device=dev, dist=args.dist)
+        xb = torch.rand((Bb, d), device=dev)
+        Rb = torch.empty((Bb, d + P), device=dev)
+
+        def timed(fn, n):
+            for i in range(5):
+                fn(i)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(n):
+                fn(i)
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / n
+
+        ms = timed(lambda i: E.apply_emb_interact(xb, bb[i % 4][0], bb[i % 4][1], ev, None, out=Rb, one_index_per_bag=True), 100)
+        result["large_batch"] = {"batch": Bb, "ms_per_step": ms, "value": T * Bb / ms * 1e3, "unit": "lookups/s",
+                                 "achieved": Bb * bytes_per_sample / ms / 1e6, "frac": Bb * bytes_per_sample / ms / 1e6 / HBM_PEAK_GBPS}
+        red = {}
+        for bits in (8, 4):
+            evq = make_tables(KAGGLE_LN, d, seed=bits, device=dev, bits=bits)
+            ms = timed(lambda i: E.apply_emb_interact(xb, bb[i % 4][0], bb[i % 4][1], evq, None, out=Rb, one_index_per_bag=True), 100)
+            bq = T * (d * bits // 8 + 8) + 4 * d + 4 * (d + P)
+            red["u%d" % bits] = {"ms_per_step": ms, "value": T * Bb / ms * 1e3, "achieved": Bb * bq / ms / 1e6,
+                                 "frac": Bb * bq / ms / 1e6 / HBM_PEAK_GBPS, "bytes_per_sample": bq}
+            del evq
+        result["reduced_precision_tables"] = {"batch": Bb, "unit": "lookups/s", **red,
+                                              "note": "C2-tier row formats (evlfu_8 / evlfu_4) decoded inside the fused kernel"}
+        del bb, xb, Rb
+        torch.cuda.empty_cache()
     if not args.no_cache_tier:
         result["cache_tier"] = cache_tier_section(ev, KAGGLE_LN, d, B, dev)
     if not args.no_cpu_baseline:
