@@ -353,7 +353,7 @@ def main():
                                  "achieved": Bb * bytes_per_sample / ms / 1e6, "frac": Bb * bytes_per_sample / ms / 1e6 / HBM_PEAK_GBPS}
         red = {}
         for bits in (8, 4):
-            evq = make_tables(KAGGLE_LN, d, seed=bits, device=dev, bits=bits)
+            evq = ev.encode(bits)   # the same tables through the GPU batch encoders (reduce_precision.py semantics)
             ms = timed(lambda i: E.apply_emb_interact(xb, bb[i % 4][0], bb[i % 4][1], evq, None, out=Rb, one_index_per_bag=True), 100)
             bq = T * (d * bits // 8 + 8) + 4 * d + 4 * (d + P)
             red["u%d" % bits] = {"ms_per_step": ms, "value": T * Bb / ms * 1e3, "achieved": Bb * bq / ms / 1e6,

@@ -48,6 +48,7 @@ _PROTOS = {
                                              _vp, _i64, _i64, _vp]),
     "evs_check_index_errors": (_int, [_vp]),
     "evs_host_device_pointer": (_vp, [_vp]),
+    "evs_encode_table": (_int, [_int, _i64, _int, _vp, _vp, _vp]),
     "evs_interact_dot": (_int, [_i64, _int, _int, _pp, _i64p, _int, _vp, _vp]),
     "evs_fused_dim_supported": (_int, [_int]),
     "evs_emb_interact_dot": (_int, [_i64, _int, _int, _int, C.POINTER(EvsFeature), _int, _vp, _vp]),

@@ -82,6 +82,18 @@ class EVTables:
             raws.append(torch.from_numpy(a).to(device))
         return cls(raws, d, codec)
 
+    def encode(self, bits):
+        """The offline encoders on the GPU (script/reduce_precision.py + convert_ev_to_binary.py): these fp32
+        tables in the reference's 16 / 8 / 4-bit row format, bit-exact with the reference's Python arithmetic."""
+        assert self.codec == 32 and bits in (16, 8, 4)
+        out = []
+        stream = _stream_ptr(self.device)
+        for k, t in enumerate(self.raw):
+            dst = torch.empty((self.n_rows[k], self.d * bits // 8), dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib().evs_encode_table(bits, self.n_rows[k], self.d, t.data_ptr(), dst.data_ptr(), stream))
+            out.append(dst)
+        return EVTables(out, self.d, bits)
+
     def __len__(self):
         return len(self.raw)
 

@@ -96,6 +96,16 @@ EVS_API int evs_embedding_bag_sum_stacked(int T, int64_t B, int d, int codec,
  * an out-of-range index (and clears the flag), else 0. */
 EVS_API int evs_check_index_errors(void *stream);
 
+/* ---------------------------------------------------------------------------
+ * a11: the offline encoders as a GPU batch tool
+ *     (script/reduce_precision.py:26-51 u16, :140-172 + :321 u4, :270 u8;
+ *      script/convert_ev_to_binary.py:31-69 byte layout)
+ * src: n_rows x d fp32 (device), dst: n_rows x (d*codec/8) bytes (device), the
+ * reference's ev-table-N.bin layout for that precision.  Bit-exact with the
+ * reference's Python arithmetic (fp64 on the widened fp32 values).
+ * ------------------------------------------------------------------------- */
+EVS_API int evs_encode_table(int codec, int64_t n_rows, int d, const float *src, void *dst, void *stream);
+
 /* Device-side address of a pinned (hipHostMalloc / torch pin_memory) host buffer, NULL when the
  * buffer is not device-accessible.  The batch-1 entry points (evs_cache_request*, ev_lookup) take
  * such pointers for the ids, the rows and the hit flags: a request of 26 ids and 936 floats then

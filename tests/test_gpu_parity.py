@@ -137,6 +137,37 @@ def test_exhaustive_decode_tables_on_gpu(E, orc):
     assert np.array_equal(out[ok].view(np.uint32), t["u4"][ok].view(np.uint32))
 
 
+@pytest.mark.parametrize("codec", [16, 8, 4])
+def test_gpu_batch_encoders_bit_exact(E, orc, codec):
+    """a11 as a GPU tool: EVTables.encode == the oracle's encoders (pinned to the reference's own outputs in
+    tests/golden/encoders.npz) byte for byte -- random values, every threshold of the three codecs and its fp32
+    neighbours, the u16 tail, values outside [-1, 1]; and decode(encode(x)) stays within the codec's step."""
+    rs = np.random.RandomState(codec)
+    d = 36
+    edges = [0.0, -0.0, 1.0, -1.0, 0.65, -0.65, 0.8, 0.6, 0.4, 0.25, 0.015, 0.00025, -0.8, -0.6, -0.4, -0.25, -0.015,
+             -0.00025, 0.5, -0.5, 1e-7, -1e-7, 0.6501, -0.6501, 0.66, -0.66, 0.99, -0.99, 1.2, -1.2, 2.0 / 254 - 1, 1.0 / 254]
+    e32 = np.array(edges, dtype=np.float32)
+    near = np.concatenate([e32, np.nextafter(e32, np.float32(2)), np.nextafter(e32, np.float32(-2))])
+    grid = np.linspace(-1.05, 1.05, 36 * 400 - near.size).astype(np.float32)
+    special = np.concatenate([near, grid]).reshape(-1, d)
+    tabs = [rs.uniform(-1, 1, size=(1000, d)).astype(np.float32), special,
+            (rs.standard_normal(size=(333, d)) * 0.3).astype(np.float32)]
+    ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    enc = ev.encode(codec)
+    for k, t in enumerate(tabs):
+        want = orc.encode_table(t, codec)
+        got = enc.raw[k].cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (codec, k, np.argwhere(got != want)[:5])
+    # round trip through the GPU decode path (bag of one row = the decoded row)
+    n = tabs[0].shape[0]
+    idx = [torch.arange(t.shape[0], device="cuda") for t in tabs]
+    off = [torch.arange(t.shape[0], device="cuda") for t in tabs]
+    ly = E.apply_emb(off, idx, enc, None)
+    step = {16: 2.1e-2, 8: 1.0 / 254 + 1e-6, 4: 0.21}[codec]
+    back = ly[0].cpu().numpy()
+    assert back.shape == (n, d) and np.max(np.abs(back - tabs[0])) <= step
+
+
 def test_edge_cases(E, orc):
     rs = np.random.RandomState(1)
     W = rs.randn(50, 16).astype(np.float32)
