@@ -810,6 +810,7 @@ struct BatchArgs {
     BatchState *bs;
     CacheArrays a;
     unsigned long long *slots;   // packed hash words (see above)
+    int *estamp; int stamp;      // host-memory miss tier: entries hit in the running batch (estamp[e] == stamp) are not evicted
     int *eslot;            // hash slot of each entry
     // per (request, table) position: bit 31 = valid miss, bit 30 = hit, bits 24..29 = agg_hit of the request,
     // bits 0..23 = (empty hash slot the probe of a miss ended on) >> hint_shift.  One 4-byte store per key in
@@ -927,6 +928,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
             const int old = atomicMax(&args.a.eagg[e], agg);
             if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
         }
+        if (args.estamp && e >= 0) args.estamp[e] = args.stamp;
         // where the row lives right now: arena for a hit, backing store for a miss, 0 for a bad row id
         const unsigned char *src = nullptr;
         if (e >= 0) src = args.a.arena + (long long)e * args.row_bytes;
@@ -1125,7 +1127,7 @@ __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs 
             long long e = hand + o;
             if (e >= args.cap) e -= args.cap;
             ent[j] = (int)e;
-            prio[j] = (o < win && args.a.ekey[e] != kEmpty) ? args.a.eagg[e] : -1;
+            prio[j] = (o < win && args.a.ekey[e] != kEmpty && !(args.estamp && args.estamp[e] == args.stamp)) ? args.a.eagg[e] : -1;
             n_t += (prio[j] == T && flush_t > 0);
         }
         // a victim's ticket is also its place on the free stack: flush victims take n_free + [0, flush_t),
@@ -1260,6 +1262,22 @@ __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchAr
     }
 }
 
+// Host-memory miss tier: after the fill (K5) every missed key that got an entry is served from its ARENA row, so
+// each missing row crosses the bus once (the de-duplicated fetch of K5) instead of once per request that asked
+// for it plus once for the fill.  One thread per (request, table) position; keys that found no room keep their
+// host address.
+__global__ void __launch_bounds__(256) cache_batch_patch_ptrs_kernel(const BatchArgs args) {
+    const long long n = args.B * args.T;
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const unsigned info = args.miss_info[m];
+    if (!(info & 0x80000000u)) return;
+    const unsigned long long key = ((unsigned long long)(m % args.T + 1) << 32) | (unsigned)args.requests[m];
+    unsigned long long end_slot;
+    const int e = probe_ro(args.slots, args.mask, key, end_slot);
+    if (e >= 0) args.row_ptrs[m] = (long long)(args.a.arena + (long long)e * args.row_bytes);
+}
+
 }  // namespace evs
 
 // ------------------------------------------------------------------------------------------
@@ -1283,6 +1301,9 @@ struct evs_cache {
     long long *row_ptrs = nullptr, *iota = nullptr;
     long long max_batch = 0;
     int used = 0;  // 0 fresh, 1 exact path, 2 batched path
+    int *estamp = nullptr;      // allocated when the backing tables live in host memory
+    bool host_backing = false;
+    long long stamp_counter = 0;
     int *host_tomb = nullptr;   // mapped host word: tombstones after the last finished batch (read without a sync)
     int *host_tomb_dev = nullptr;
 };
@@ -1291,7 +1312,7 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
     void *ptrs[] = {c->st, c->a.keys, c->a.slot_entry, c->a.ekey, c->a.eagg, c->a.efreq, c->a.prev, c->a.next,
                     c->a.free_stack, c->a.arena, c->a.lfu_head, c->a.lfu_tail, c->a.lfu_len,
-                    c->bs, c->eslot, c->bslots, c->miss_info, c->new_slot, c->row_ptrs, c->iota,
+                    c->bs, c->eslot, c->estamp, c->bslots, c->miss_info, c->new_slot, c->row_ptrs, c->iota,
                     c->block_cnt, c->block_base, c->part1, c->part2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1369,6 +1390,14 @@ extern "C" int evs_cache_set_backing(evs_cache *c, const void *const *tables, co
         c->backing_rows[k] = n_rows[k];
     }
     c->has_backing = true;
+    // where the miss tier lives decides the order of the batched pipeline (see cache_batch_impl)
+    c->host_backing = false;
+    for (int k = 0; k < c->host.n_tables && !c->host_backing; k++) {
+        if (!tables[k]) continue;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, tables[k]) == hipSuccess) c->host_backing = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
     return EVS_OK;
 }
 
@@ -1527,27 +1556,48 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
     a.g1 = (int)g1; a.g2 = (int)g2;
     const int wide = kNumCu * 8;
     a.host_tomb = c->host_tomb_dev;
+    // Host-memory miss tier: hits of this batch are pinned (stamp), the policy update runs FIRST, the missed keys
+    // that got an entry are re-pointed at their arena rows and only then do the consumers read -- every missing
+    // row crosses the bus once (K5's de-duplicated fetch).  Miss tier in HBM: consumers first, as measured best.
+    const bool host_tier = c->host_backing;
+    a.estamp = nullptr; a.stamp = 0;
+    if (host_tier) {
+        if (!c->estamp) {
+            EVS_HIP_CHECK(hipMalloc(&c->estamp, cap * 4));
+            EVS_HIP_CHECK(hipMemsetAsync(c->estamp, 0, cap * 4, st));
+        }
+        a.estamp = c->estamp;
+        a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;   // never 0, distinct for consecutive batches
+    }
     hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)g1), dim3(256), 0, st, a);
+    auto consumers = [&]() -> int {
+        if (out) {
+            long long nb = (B * T * (long long)c->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
+            hipLaunchKernelGGL(cache_rows_from_ptrs_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->row_ptrs, out,
+                               (long long)B, T, c->host.dim, c->host.codec);
+        }
+        if (R) {
+            const int rc = fused_interact_from_row_ptrs(B, T, c->host.dim, x, x_stride, (const int64_t *)c->row_ptrs,
+                                                        (const int64_t *)c->iota, itself, R, st);
+            if (rc) return rc;
+        }
+        return EVS_OK;
+    };
+    if (R) EVS_REQUIRE(c->host.codec == 32 && evs_fused_dim_supported(c->host.dim) && T + 1 <= EVS_MAX_FEATURES,
+                       "evs_cache_lookup_interact: needs an fp32 cache, a fused-kernel dimension and T <= 31");
     // consumers of the snapshot read the rows BEFORE the policy kernels move anything.  (Running K2-K4 on a
     // side stream under the consumer was measured and is slower: 101 vs 91 us per batch -- the consumer
     // already saturates the memory system and the two event waits cost more than the overlap returns.)
-    if (out) {
-        long long nb = (B * T * (long long)c->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
-        hipLaunchKernelGGL(cache_rows_from_ptrs_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->row_ptrs, out,
-                           (long long)B, T, c->host.dim, c->host.codec);
-    }
-    if (R) {
-        EVS_REQUIRE(c->host.codec == 32 && evs_fused_dim_supported(c->host.dim) && T + 1 <= EVS_MAX_FEATURES,
-                    "evs_cache_lookup_interact: needs an fp32 cache, a fused-kernel dimension and T <= 31");
-        const int rc = fused_interact_from_row_ptrs(B, T, c->host.dim, x, x_stride, (const int64_t *)c->row_ptrs,
-                                                    (const int64_t *)c->iota, itself, R, st);
-        if (rc) return rc;
-    }
+    if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
     hipLaunchKernelGGL(cache_batch_insert_kernel, dim3((unsigned)g2), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cache_batch_plan_kernel, dim3(1), dim3(256), 0, st, a);
     long long ne = (cap + 255) / 256; if (ne > wide) ne = wide;
     hipLaunchKernelGGL(cache_batch_evict_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cache_batch_assign_kernel, dim3((unsigned)g2), dim3(256), 0, st, a);
+    if (host_tier) {
+        hipLaunchKernelGGL(cache_batch_patch_ptrs_kernel, dim3((unsigned)g2), dim3(256), 0, st, a);
+        const int rc = consumers(); if (rc) return rc;
+    }
     // the hash is rebuilt without tombstones when they exceed nslot/8; the host learns the count from a
     // mapped word K6b writes (one or two batches stale, which only means slightly longer probe chains)
     const bool rebuild = *reinterpret_cast<volatile int *>(c->host_tomb) > (int)(c->nslot / 8);

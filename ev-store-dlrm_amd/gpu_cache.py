@@ -53,7 +53,7 @@ class GpuCache:
         rb = self.dim * self.codec // 8
         n_rows = [int(t.numel() * t.element_size() // rb) for t in raws]
         self._backing = raws  # keep alive
-        ptrs = (C.c_void_p * self.n_tables)(*[t.data_ptr() for t in raws])
+        ptrs = (C.c_void_p * self.n_tables)(*[_dev_ptr(t) for t in raws])   # pinned host tables: their device-side address
         rows = (C.c_int64 * self.n_tables)(*n_rows)
         _lib.check(_lib.lib().evs_cache_set_backing(self._h, ptrs, rows))
 

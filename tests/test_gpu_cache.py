@@ -329,6 +329,31 @@ def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch):
     assert rate_b <= rate_s + 0.05, (rate_b, rate_s)
 
 
+def test_batched_cache_over_host_memory_backing(E, orc):
+    """the miss tier in pinned HOST memory (the reference's C3 / mmap miss path): the batched
+    lookup serves hits from the HBM arena and misses straight from host rows (pointer table -> fused kernel),
+    fills the arena from host rows, and gives the bits of the all-HBM path."""
+    n_rows = [500, 7, 9000, 40, 2500, 3] + [100] * 20
+    tabs = orc.kaggle_tables(n_rows, 9)
+    host = [torch.from_numpy(np.ascontiguousarray(t)).pin_memory() for t in tabs]
+    dev = [torch.from_numpy(t).cuda() for t in tabs]
+    ch = E.GpuCache("evlfu", 2500, 26, 36, 32)
+    cd = E.GpuCache("evlfu", 2500, 26, 36, 32)
+    ch.set_backing(host)
+    cd.set_backing(dev)
+    reqs = _zipf_requests(n_rows, 1200, 6)
+    r = torch.from_numpy(reqs).cuda()
+    for s in range(0, 1200, 300):
+        x = torch.rand(300, 36, device="cuda")
+        hit_h, R_h = ch.lookup_interact(r[s:s + 300].contiguous(), x)
+        hit_d, R_d = cd.lookup_interact(r[s:s + 300].contiguous(), x)
+        assert torch.equal(R_h, R_d) and torch.equal(hit_h, hit_d)
+        hb, rows = ch.lookup_batch(r[s:s + 300].contiguous())
+        for k in range(26):
+            assert np.array_equal(rows[:, k, :].cpu().numpy(), tabs[k][reqs[s:s + 300, k]])
+    assert ch.batch_stats()["n_hits"] > 0 and ch.batch_stats()["size"] > 0
+
+
 def test_batched_and_exact_paths_do_not_mix(E, orc):
     tabs = orc.kaggle_tables([50] * 26, 1)
     c = E.GpuCache("evlfu", 100, 26, 36, 32)

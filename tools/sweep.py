@@ -103,6 +103,49 @@ def cache_rows(ln, d, iters):
         out.append("| batched EvLFU C1, %d entries = 10 %% of the rows (full), Zipf 0.75 | %d | %.1f | %.2f | %.3f | %d |" % (
             s1["size"], B, dt / iters * 1e6, T * B * iters / dt / 1e9, (s1["n_hits"] - s0["n_hits"]) / (T * B * iters),
             s1["n_evict"] - s0["n_evict"]))
+    # the same cache in front of tables that live in pinned HOST memory (the reference's C3 / mmap miss path):
+    # misses cross the bus inside the consumer kernel and the fill kernel; no cache = every row crosses it
+    try:
+        host = [t.cpu().pin_memory() for t in ev.raw]
+        ch = E.GpuCache("evlfu", cap, T, d, 32, "python", dev)
+        ch.set_backing(host)
+        warm = bench.make_batches(ln, 16384, 60, seed=3, device=dev, dist="zipf", alpha=0.75)
+        for b in warm:
+            ch.lookup_interact(b[1].t().contiguous().to(torch.int32), x, out=R, hit=hit)
+        del warm
+        bs = bench.make_batches(ln, 16384, iters, seed=77, device=dev, dist="zipf", alpha=0.75)
+        rows = [b[1].t().contiguous().to(torch.int32) for b in bs]
+        s0 = ch.batch_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in rows:
+            ch.lookup_interact(r, x, out=R, hit=hit)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        s1 = ch.batch_stats()
+        out.append("| the same cache, tables (miss tier) in pinned host memory | 16384 | %.1f | %.2f | %.3f | %d |" % (
+            dt / iters * 1e6, T * 16384 * iters / dt / 1e9, (s1["n_hits"] - s0["n_hits"]) / (T * 16384 * iters), s1["n_evict"] - s0["n_evict"]))
+        evh = E.EVTables.__new__(E.EVTables)   # host-resident tables straight into the fused kernel (no cache)
+        hp = [E.gpu_cache._dev_ptr(t) for t in host]
+        import ctypes as C
+        evh.d, evh.codec, evh.row_bytes, evh.raw, evh.device, evh.n_rows = d, 32, 4 * d, host, dev, list(ln)
+        evh._tables_c = (C.c_void_p * T)(*hp)
+        evh._n_rows_c = (C.c_int64 * T)(*ln)
+        idx = [b[1] for b in bs[:4]]
+        off = torch.arange(16384, device=dev).repeat(T, 1)
+        for i in range(2):
+            E.apply_emb_interact(x, off, idx[i], evh, out=R, one_index_per_bag=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(8):
+            E.apply_emb_interact(x, off, idx[i % 4], evh, out=R, one_index_per_bag=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out.append("| no cache, every row read from pinned host memory by the fused kernel | 16384 | %.1f | %.3f | – | – |" % (
+            dt / 8 * 1e6, T * 16384 * 8 / dt / 1e9))
+        del ch, host
+    except Exception as ex:   # pinning 4.9 GB can fail on a small box
+        out.append("| host-memory miss tier | – | failed: %r | | | |" % (ex,))
     return out, ev
 
 
