@@ -198,8 +198,11 @@ EVS_API int evs_cache_create(evs_cache **out, int policy, int64_t capacity, int 
                              double flush_rate, double perfect_item_cap, int flush_extra, int perfect_mode);
 EVS_API int evs_cache_destroy(evs_cache *c);
 /* Miss path: tables[k] is DEVICE-ACCESSIBLE memory holding table k in the cache's codec
- * (HBM, or pinned host memory mapped into the device = the host-mmap miss tier);
- * HOST arrays of n_tables entries. */
+ * (HBM, or pinned host memory mapped into the device = the host-mmap miss tier,
+ * emb_storage/mmap_file_read.py / evlfu_8.cpp:191-250); HOST arrays of n_tables entries.
+ * With host-memory tables the batched lookups fetch each missing row once (de-duplicated,
+ * into the arena) and serve the whole batch from HBM; hits of the running batch are never
+ * evicted by it. */
 EVS_API int evs_cache_set_backing(evs_cache *c, const void *const *tables, const int64_t *n_rows);
 /* B requests replayed strictly in order (exact reference semantics; B=1 is the reference's
  * request_to_ev_lfu / request_to_lru / request_to_lfu).  rows: device (B, n_tables) int32;
