@@ -128,6 +128,44 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
     dt = time.perf_counter() - t0
     s1 = cache.batch_stats()
     looks = T * B * steps
+    # the same cache in front of tables that stay in pinned HOST memory (the reference's C3 / mmap miss path): each
+    # missing row crosses the bus once; beside it, the fused kernel reading every row from host memory uncached
+    host_tier = None
+    if batch1:
+        try:
+            host = [t.cpu().pin_memory() for t in ev.raw]
+            ch = E.GpuCache("evlfu", cap, T, d, 32, "python", dev)
+            ch.set_backing(host)
+            for i in range(warmup):
+                ch.lookup_interact(rows[i % len(rows)], x, out=out, hit=hit)
+            h0 = ch.batch_stats()
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for i in range(steps):
+                ch.lookup_interact(rows[(warmup + i) % len(rows)], x, out=out, hit=hit)
+            torch.cuda.synchronize()
+            dth = time.perf_counter() - th
+            h1 = ch.batch_stats()
+            import ctypes as C
+            evh = E.EVTables.__new__(E.EVTables)
+            evh.d, evh.codec, evh.row_bytes, evh.raw, evh.device, evh.n_rows = d, 32, 4 * d, host, dev, list(ln_emb)
+            evh._tables_c = (C.c_void_p * T)(*[E.gpu_cache._dev_ptr(t) for t in host])
+            evh._n_rows_c = (C.c_int64 * T)(*ln_emb)
+            off = batches[0][0]
+            E.apply_emb_interact(x, off, batches[0][1], evh, out=out, one_index_per_bag=True)
+            torch.cuda.synchronize()
+            tn = time.perf_counter()
+            for i in range(6):
+                E.apply_emb_interact(x, off, batches[(warmup + i) % len(batches)][1], evh, out=out, one_index_per_bag=True)
+            torch.cuda.synchronize()
+            dtn = (time.perf_counter() - tn) / 6
+            host_tier = {"value": looks / dth, "unit": "lookups/s", "ms_per_step": dth / steps * 1e3,
+                         "hit_rate": (h1["n_hits"] - h0["n_hits"]) / looks,
+                         "uncached_host_reads": {"value": T * B / dtn, "ms_per_step": dtn * 1e3},
+                         "note": "tables (miss tier) in pinned host memory, cache in HBM; uncached = the fused kernel reading every row over the bus"}
+            del ch, host, evh
+        except Exception as e:  # pinning 4.9 GB can fail on a small box
+            host_tier = {"error": repr(e)}
     # batch-1 exact path (the reference's per-request semantics: one request, rows back on the host) and the
     # oracle's sequential EvLFU on the host cores, same Zipf stream, smaller cache so both warm up quickly
     if not batch1:
@@ -167,7 +205,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
                          "in-memory tables, %.2f s" % (n1, dtc)}
     except Exception as e:  # the oracle is test infrastructure: its absence must not break the bench
         cpu = {"error": str(e)}
-    return {"value": looks / dt, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
+    return {"value": looks / dt, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
             "hit_rate": (s1["n_hits"] - s0["n_hits"]) / looks, "capacity_entries": cap,
             "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"],
             "workload": "BASELINE configs[2]: EvLFU C1 in HBM at %.0f%% of 33.76M rows, Zipf(alpha=%.2f) indices, "
