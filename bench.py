@@ -123,7 +123,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        step(i)
+        step(warmup + i)   # batches the cache has not seen
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     s1 = cache.batch_stats()
