@@ -160,9 +160,8 @@ def test_gpu_batch_encoders_bit_exact(E, orc, codec):
         assert got.shape == want.shape and np.array_equal(got, want), (codec, k, np.argwhere(got != want)[:5])
     # round trip through the GPU decode path (bag of one row = the decoded row)
     n = tabs[0].shape[0]
-    idx = [torch.arange(t.shape[0], device="cuda") for t in tabs]
-    off = [torch.arange(t.shape[0], device="cuda") for t in tabs]
-    ly = E.apply_emb(off, idx, enc, None)
+    one = E.EVTables([enc.raw[0]], d, codec)
+    ly = E.apply_emb([torch.arange(n, device="cuda")], [torch.arange(n, device="cuda")], one, None, check_indices=True)
     step = {16: 2.1e-2, 8: 1.0 / 254 + 1e-6, 4: 0.21}[codec]
     back = ly[0].cpu().numpy()
     assert back.shape == (n, d) and np.max(np.abs(back - tabs[0])) <= step
