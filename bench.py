@@ -146,11 +146,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
             torch.cuda.synchronize()
             dth = time.perf_counter() - th
             h1 = ch.batch_stats()
-            import ctypes as C
-            evh = E.EVTables.__new__(E.EVTables)
-            evh.d, evh.codec, evh.row_bytes, evh.raw, evh.device, evh.n_rows = d, 32, 4 * d, host, dev, list(ln_emb)
-            evh._tables_c = (C.c_void_p * T)(*[E.gpu_cache._dev_ptr(t) for t in host])
-            evh._n_rows_c = (C.c_int64 * T)(*ln_emb)
+            evh = E.EVTables(host, d, 32, device=dev)   # host-resident tables straight into the fused kernel
             off = batches[0][0]
             E.apply_emb_interact(x, off, batches[0][1], evh, out=out, one_index_per_bag=True)
             torch.cuda.synchronize()

@@ -55,22 +55,33 @@ class EVTables:
     one gather kernel that decodes on load.
     """
 
-    def __init__(self, raw_tables, d, codec=32):
+    def __init__(self, raw_tables, d, codec=32, device=None):
+        """raw_tables: tensors in HBM, or PINNED host tensors (the host-memory miss tier: the kernels read the
+        rows over the bus; `device` then names the GPU that runs them)."""
         assert codec in (32, 16, 8, 4)
         self.d, self.codec = int(d), int(codec)
         self.row_bytes = self.d * self.codec // 8
         self.raw = []
+        ptrs = []
         for t in raw_tables:
-            assert t.is_cuda, "EVTables live in HBM: move the tensors to the GPU first"
+            assert t.is_cuda or t.is_pinned(), "EVTables live in HBM or in pinned host memory"
             t = t.contiguous()
             if t.dtype != torch.uint8:
                 t = t.view(torch.uint8)
             t = t.reshape(-1, self.row_bytes)
             self.raw.append(t)
-        self.device = self.raw[0].device if self.raw else torch.device("cuda")
+            if t.is_cuda:
+                ptrs.append(t.data_ptr())
+            else:
+                p = _lib.lib().evs_host_device_pointer(t.data_ptr())
+                if not p:
+                    raise _lib.EvsError(_lib.EVS_EINVAL, "pinned table is not device-accessible")
+                ptrs.append(p)
+        on_gpu = [t.device for t in self.raw if t.is_cuda]
+        self.device = torch.device(device) if device is not None else (on_gpu[0] if on_gpu else torch.device("cuda"))
         self.n_rows = [int(t.shape[0]) for t in self.raw]
         T = len(self.raw)
-        self._tables_c = (C.c_void_p * T)(*[t.data_ptr() for t in self.raw])
+        self._tables_c = (C.c_void_p * T)(*ptrs)
         self._n_rows_c = (C.c_int64 * T)(*self.n_rows)
 
     # ---- constructors -------------------------------------------------------------

@@ -188,6 +188,28 @@ def test_edge_cases(E, orc):
     E._lib.check(E._lib.lib().evs_check_index_errors(None))  # flag cleared
 
 
+def test_tables_in_pinned_host_memory(E, orc):
+    """The host-memory miss tier without a cache: EVTables over PINNED host tensors give the bits of the HBM tables
+    through apply_emb, the fused kernel and the reduced-precision path."""
+    rs = np.random.RandomState(12)
+    n_rows, d, B = [300, 5, 4100], 36, 257
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in n_rows]
+    lens = rs.randint(0, 3, size=(3, B))
+    lS_i = [_dev(rs.randint(0, n_rows[k], size=int(lens[k].sum())).astype(np.int64)) for k in range(3)]
+    lS_o = [_dev(np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64)) for k in range(3)]
+    x = _dev(rs.uniform(-1, 1, size=(B, d)).astype(np.float32))
+    for codec in (32, 8):
+        raws = [torch.from_numpy(orc.encode_table(t, codec)) for t in tabs]
+        ev_h = E.EVTables([r.pin_memory() for r in raws], d, codec, device="cuda")
+        ev_d = E.EVTables([r.cuda() for r in raws], d, codec)
+        a = E.apply_emb(lS_o, lS_i, ev_h, None, check_indices=True)
+        b = E.apply_emb(lS_o, lS_i, ev_d, None)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+        assert torch.equal(E.apply_emb_interact(x, lS_o, lS_i, ev_h), E.apply_emb_interact(x, lS_o, lS_i, ev_d))
+    with pytest.raises(AssertionError):
+        E.EVTables([torch.zeros(4, d)], d, 32)   # pageable host memory is refused
+
+
 def test_odd_dim_falls_to_scalar_kernel(E, orc):
     rs = np.random.RandomState(2)
     W = rs.randn(40, 10).astype(np.float32)  # d=10: not a multiple of 4

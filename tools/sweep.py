@@ -125,12 +125,7 @@ def cache_rows(ln, d, iters):
         s1 = ch.batch_stats()
         out.append("| the same cache, tables (miss tier) in pinned host memory | 16384 | %.1f | %.2f | %.3f | %d |" % (
             dt / iters * 1e6, T * 16384 * iters / dt / 1e9, (s1["n_hits"] - s0["n_hits"]) / (T * 16384 * iters), s1["n_evict"] - s0["n_evict"]))
-        evh = E.EVTables.__new__(E.EVTables)   # host-resident tables straight into the fused kernel (no cache)
-        hp = [E.gpu_cache._dev_ptr(t) for t in host]
-        import ctypes as C
-        evh.d, evh.codec, evh.row_bytes, evh.raw, evh.device, evh.n_rows = d, 32, 4 * d, host, dev, list(ln)
-        evh._tables_c = (C.c_void_p * T)(*hp)
-        evh._n_rows_c = (C.c_int64 * T)(*ln)
+        evh = E.EVTables(host, d, 32, device=dev)   # host-resident tables straight into the fused kernel (no cache)
         idx = [b[1] for b in bs[:4]]
         off = torch.arange(16384, device=dev).repeat(T, 1)
         for i in range(2):
