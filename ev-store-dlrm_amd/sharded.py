@@ -100,7 +100,7 @@ class HipBackend:
         fast = ("gid", id(lS_i_rows), id(lS_o_rows), send.data_ptr())
         ent = self._cache.get(fast)
         if ent is None:
-            ent = ((C.c_void_p * n)(*[ev.raw[k].data_ptr() for k in table_ids_local]),
+            ent = ((C.c_void_p * n)(*[ev._tables_c[k] for k in table_ids_local]),
                    (C.c_int64 * n)(*[ev.n_rows[k] for k in table_ids_local]),
                    (C.c_void_p * n)(*[t.data_ptr() for t in lS_i_rows]),
                    (C.c_void_p * n)(*[t.data_ptr() for t in lS_o_rows]),
@@ -131,7 +131,7 @@ class HipBackend:
                     f.src, f.stride = v.data_ptr(), int(v.stride(0)) if B > 1 else d
                 else:
                     _, k, idx, off, nnz, off_len = s
-                    f.src, f.indices = ev.raw[k].data_ptr(), idx.data_ptr()
+                    f.src, f.indices = ev._tables_c[k], idx.data_ptr()
                     f.offsets = off.data_ptr() if off is not None else None
                     f.nnz, f.n_rows, f.offsets_len = int(nnz), ev.n_rows[k], int(off_len)
             ent = (feats, specs if out is not None else None)   # keep the list alive only when it can recur
