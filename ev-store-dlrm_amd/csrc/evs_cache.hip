@@ -811,6 +811,7 @@ struct BatchArgs {
     CacheArrays a;
     unsigned long long *slots;   // packed hash words (see above)
     int *estamp; int stamp;      // host-memory miss tier: entries hit in the running batch (estamp[e] == stamp) are not evicted
+    const unsigned long long *other_slots; unsigned long long other_mask;   // two-tier: the other tier's hash (keys it holds are skipped)
     int *eslot;            // hash slot of each entry
     // per (request, table) position: bit 31 = valid miss, bit 30 = hit, bits 24..29 = agg_hit of the request,
     // bits 0..23 = (empty hash slot the probe of a miss ended on) >> hint_shift.  One 4-byte store per key in
@@ -834,7 +835,9 @@ struct BatchArgs {
 __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigned long long mask, unsigned long long key,
                                         unsigned long long &end_slot) {
     unsigned long long i = mix64(key) & mask;
-    for (;;) {
+    // bounded: a batch with more unique new keys than free slots (tiny cache, huge batch) can leave the table without
+    // an empty word until the next rebuild -- the walk then ends after one lap instead of never
+    for (unsigned long long steps = 0; steps <= mask; steps++) {
         const unsigned long long w = slots[i];
         if ((w & kKeyMask) == key) {
             end_slot = i;
@@ -844,6 +847,8 @@ __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigne
         if (w == kEmpty) { end_slot = i; return -1; }
         i = (i + 1) & mask;  // tombstones and other keys: keep walking
     }
+    end_slot = i;
+    return -1;
 }
 
 // One atomic per BLOCK instead of one per thread: every thread of the block calls this in uniform
@@ -977,6 +982,94 @@ __global__ void __launch_bounds__(256) cache_rows_from_ptrs_kernel(const long lo
         }
     }
 }
+// ---- two-tier batched probe (see evs_cache_lookup_batch_c1c2) ----------------------------------------------
+struct TwoTierArgs {
+    unsigned char *row_tier;   // (B,T): 1 = row in C1's codec, 2 = row in C2's codec, 0 = no row
+    unsigned char *tier_out;   // (B,T) user output: 1 = C1 hit, 2 = C2 hit, 0 = miss
+    int threshold;             // high_agghit_threshold (evlfu_8.hpp:70)
+};
+
+__global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs a1, const BatchArgs a2, const TwoTierArgs tt) {
+    __shared__ int s_d1[kMaxBuckets], s_d2[kMaxBuckets];
+    __shared__ int s_sum[3];   // C1 hits, C2 hits, perfect requests
+    for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) { s_d1[i] = 0; s_d2[i] = 0; }
+    if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+    const int T = a1.T;
+    const bool c1_full = a1.bs->count >= a1.cap;   // snapshot: the policy kernels of this batch run later
+    const long long req_stride = (long long)gridDim.x * 8;
+    for (long long req = (long long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half; req - half - (threadIdx.x >> 6) * 2 < a1.B;
+         req += req_stride) {
+        const bool req_on = req < a1.B;
+        const bool key_on = req_on && hl < T;
+        int row = key_on ? a1.requests[req * T + hl] : -1;
+        const bool ok = key_on && row >= 0 && row < a1.backing_rows[hl < T ? hl : 0] && row < a2.backing_rows[hl < T ? hl : 0];
+        const unsigned long long key = ((unsigned long long)(hl + 1) << 32) | (unsigned)row;
+        unsigned long long end1 = 0, end2 = 0;
+        int e1 = ok ? probe_ro(a1.slots, a1.mask, key, end1) : -1;
+        if (e1 == kPending) e1 = -1;
+        int e2 = (ok && e1 < 0) ? probe_ro(a2.slots, a2.mask, key, end2) : -1;
+        if (e2 == kPending) e2 = -1;
+        const unsigned long long hm = __ballot(e1 >= 0 || e2 >= 0);
+        const int agg = __popc((unsigned)(half ? (hm >> 32) : hm));
+        if (e1 >= 0 && a1.a.eagg[e1] < agg) {
+            const int old = atomicMax(&a1.a.eagg[e1], agg);
+            if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
+        }
+        if (e2 >= 0 && a2.a.eagg[e2] < agg) {
+            const int old = atomicMax(&a2.a.eagg[e2], agg);
+            if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
+        }
+        // evlfu_8.cpp:570-601: where a double miss goes
+        const bool miss = ok && e1 < 0 && e2 < 0;
+        const int dest = !c1_full ? 1 : (agg < tt.threshold ? ((hl & 1) ? 1 : 2) : 2);
+        const unsigned char *src = nullptr;
+        int codec_of = 0;
+        if (e1 >= 0) { src = a1.a.arena + (long long)e1 * a1.row_bytes; codec_of = 1; }
+        else if (e2 >= 0) { src = a2.a.arena + (long long)e2 * a2.row_bytes; codec_of = 2; }
+        else if (miss && dest == 1) { src = a1.backing[hl] + (long long)row * a1.row_bytes; codec_of = 1; }
+        else if (miss) { src = a2.backing[hl] + (long long)row * a2.row_bytes; codec_of = 2; }
+        if (key_on) {
+            const long long m = req * T + hl;
+            a1.miss_info[m] = ((miss && dest == 1) ? 0x80000000u : 0u) | (e1 >= 0 ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
+                              (unsigned)(end1 >> a1.hint_shift);
+            a2.miss_info[m] = ((miss && dest == 2) ? 0x80000000u : 0u) | (e2 >= 0 ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
+                              (unsigned)(end2 >> a2.hint_shift);
+            a1.row_ptrs[m] = (long long)src;
+            tt.row_tier[m] = (unsigned char)codec_of;
+            tt.tier_out[m] = e1 >= 0 ? 1 : (e2 >= 0 ? 2 : 0);
+        }
+        const unsigned long long h1 = __ballot(e1 >= 0), h2 = __ballot(e2 >= 0);
+        if (req_on && hl == 0) {
+            atomicAdd(&s_sum[0], __popc((unsigned)(half ? (h1 >> 32) : h1)));
+            atomicAdd(&s_sum[1], __popc((unsigned)(half ? (h2 >> 32) : h2)));
+            if (agg == T) atomicAdd(&s_sum[2], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartCols) {
+        const int i = threadIdx.x;
+        const int v1 = i <= T ? s_d1[i] : i == 38 ? s_sum[0] : i == 39 ? s_sum[2] : 0;
+        const int v2 = i <= T ? s_d2[i] : i == 38 ? s_sum[1] : 0;
+        if (v1) atomicAdd(&a1.part1[(blockIdx.x % kReplicas) * kPartCols + i], v1);
+        if (v2) atomicAdd(&a2.part1[(blockIdx.x % kReplicas) * kPartCols + i], v2);
+    }
+}
+
+// rows (B,T,d) fp32 from the pointer table, each row decoded with the codec of the tier that serves it
+__global__ void __launch_bounds__(256) cache_rows_from_ptrs2_kernel(const long long *row_ptrs, const unsigned char *row_tier,
+                                                                    float *out, long long B, int T, int d, int codec1, int codec2) {
+    const long long n = B * T * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long rowi = i / d;
+        const int c = (int)(i - rowi * d);
+        const long long p = row_ptrs[rowi];
+        const int which = row_tier[rowi];
+        out[i] = (p && which) ? decode_elem(reinterpret_cast<const unsigned char *>(p), which == 1 ? codec1 : codec2, c) : 0.f;
+    }
+}
+
 __global__ void iota_kernel(long long *p, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = i;
 }
@@ -988,11 +1081,19 @@ __global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs
     const long long n = args.B * args.T;
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned info = m < n ? args.miss_info[m] : 0u;
-    if (m < n) args.hit[m] = (info >> 30) & 1u;
+    if (m < n && args.hit) args.hit[m] = (info >> 30) & 1u;
     bool is_new = false;
     int slot = -1;
-    if (info & 0x80000000u) {
-        const unsigned long long key = ((unsigned long long)(m % args.T + 1) << 32) | (unsigned)args.requests[m];
+    bool wanted = (info & 0x80000000u) != 0;
+    unsigned long long key = 0;
+    if (wanted) {
+        key = ((unsigned long long)(m % args.T + 1) << 32) | (unsigned)args.requests[m];
+        if (args.other_slots) {   // two-tier: the other tier took this key in this very batch
+            unsigned long long es;
+            if (probe_ro(args.other_slots, args.other_mask, key, es) != -1) wanted = false;
+        }
+    }
+    if (wanted) {
         const int agg = (int)((info >> 24) & 63u);
         // the probe ended on an empty slot: every copy of this key inserted in this batch sits at or after it.
         // With hint_shift > 0 the hint is rounded down; it is used only when it still lies on the probe path.
@@ -1000,7 +1101,7 @@ __global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs
         const unsigned long long hint = (unsigned long long)(info & 0xffffffu) << args.hint_shift;
         unsigned long long i = ((hint - h) & args.mask) < (args.mask >> 1) ? hint : h;
         const unsigned long long mine = make_word(key, kFieldPend + (unsigned)agg);
-        for (;;) {
+        for (unsigned long long steps = 0; steps <= args.mask; steps++) {   // one lap at most: a full table drops the key
             unsigned long long w = args.slots[i];
             if (w == kEmpty) {
                 const unsigned long long prev = atomicCAS(&args.slots[i], kEmpty, mine);
@@ -1254,7 +1355,7 @@ __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchAr
         if (key == kEmpty) continue;
         unsigned long long i = mix64(key) & args.mask;
         const unsigned long long w = make_word(key, (unsigned)e);
-        for (;;) {
+        for (unsigned long long steps = 0; steps <= args.mask; steps++) {   // entries <= cap < nslot/2: always ends early
             if (args.slots[i] == kEmpty && atomicCAS(&args.slots[i], kEmpty, w) == kEmpty) break;
             i = (i + 1) & args.mask;
         }
@@ -1299,6 +1400,7 @@ struct evs_cache {
     int *block_cnt = nullptr, *block_base = nullptr, *part1 = nullptr, *part2 = nullptr;
     unsigned long long *bslots = nullptr;
     long long *row_ptrs = nullptr, *iota = nullptr;
+    unsigned char *row_tier = nullptr;   // two-tier batched lookup: which tier's codec decodes each row
     long long max_batch = 0;
     int used = 0;  // 0 fresh, 1 exact path, 2 batched path
     int *estamp = nullptr;      // allocated when the backing tables live in host memory
@@ -1312,7 +1414,7 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
     void *ptrs[] = {c->st, c->a.keys, c->a.slot_entry, c->a.ekey, c->a.eagg, c->a.efreq, c->a.prev, c->a.next,
                     c->a.free_stack, c->a.arena, c->a.lfu_head, c->a.lfu_tail, c->a.lfu_len,
-                    c->bs, c->eslot, c->estamp, c->bslots, c->miss_info, c->new_slot, c->row_ptrs, c->iota,
+                    c->bs, c->eslot, c->estamp, c->bslots, c->miss_info, c->new_slot, c->row_ptrs, c->iota, c->row_tier,
                     c->block_cnt, c->block_base, c->part1, c->part2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1494,18 +1596,16 @@ extern "C" int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, c
 }
 
 // ---- batched path --------------------------------------------------------------------------
-static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit, const float *x,
-                            int64_t x_stride, int itself, float *R, void *stream) {
+// allocate / grow the batched-path state of one cache and describe it in `a` (everything but the per-call outputs)
+static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream_t st, evs::BatchArgs &a, const char *who) {
     using namespace evs;
-    EVS_REQUIRE(c, "evs_cache_lookup_batch: NULL cache");
-    EVS_REQUIRE(c->host.policy == kEvLFU, "evs_cache_lookup_batch: EvLFU only");
-    EVS_REQUIRE(c->host.n_tables <= 32, "evs_cache_lookup_batch: at most 32 tables");
-    if (!c->has_backing) { set_error("evs_cache_lookup_batch: call evs_cache_set_backing first"); return EVS_ESTATE; }
-    if (c->used == 1) { set_error("evs_cache_lookup_batch: this cache is used through the exact path"); return EVS_ESTATE; }
-    EVS_REQUIRE(c->host.cap <= kMaxBatchedCap, "evs_cache_lookup_batch: capacity above %lld entries needs wider hash words", kMaxBatchedCap);
-    if (B == 0) return EVS_OK;
-    EVS_REQUIRE(B > 0 && B < (1ll << 31) / 32 && rows && hit, "evs_cache_lookup_batch: bad argument");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    EVS_REQUIRE(c, "%s: NULL cache", who);
+    EVS_REQUIRE(c->host.policy == kEvLFU, "%s: EvLFU only", who);
+    EVS_REQUIRE(c->host.n_tables <= 32, "%s: at most 32 tables", who);
+    if (!c->has_backing) { set_error("%s: call evs_cache_set_backing first", who); return EVS_ESTATE; }
+    if (c->used == 1) { set_error("%s: this cache is used through the exact path", who); return EVS_ESTATE; }
+    EVS_REQUIRE(c->host.cap <= kMaxBatchedCap, "%s: capacity above %lld entries needs wider hash words", who, kMaxBatchedCap);
+    EVS_REQUIRE(B > 0 && B < (1ll << 31) / 32 && rows, "%s: bad argument", who);
     const int T = c->host.n_tables;
     const long long cap = c->host.cap;
     if (!c->bs) {
@@ -1528,7 +1628,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
     if (B > c->max_batch) {
         if (c->miss_info) {
             EVS_HIP_CHECK(hipStreamSynchronize(st));
-            void *old[] = {c->miss_info, c->new_slot, c->row_ptrs, c->iota, c->block_cnt, c->block_base};
+            void *old[] = {c->miss_info, c->new_slot, c->row_ptrs, c->iota, c->block_cnt, c->block_base, c->row_tier};
             for (void *p : old) (void)hipFree(p);
         }
         EVS_HIP_CHECK(hipMalloc(&c->miss_info, B * T * 4));
@@ -1536,31 +1636,70 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         EVS_HIP_CHECK(hipMalloc(&c->block_cnt, g2 * 4));
         EVS_HIP_CHECK(hipMalloc(&c->block_base, g2 * 4));
         EVS_HIP_CHECK(hipMalloc(&c->row_ptrs, B * T * 8));
+        EVS_HIP_CHECK(hipMalloc(&c->row_tier, B * T));
         EVS_HIP_CHECK(hipMalloc(&c->iota, B * 8));
         hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(256), 0, st, c->iota, (long long)B);
         c->max_batch = B;
     }
     c->used = 2;
-    BatchArgs a;
     a.bs = c->bs; a.a = c->a; a.eslot = c->eslot; a.slots = c->bslots;
     a.miss_info = c->miss_info; a.new_slot = c->new_slot;
     a.hint_shift = 0;
     while ((c->nslot >> a.hint_shift) > (1ll << 24)) a.hint_shift++;
     a.row_ptrs = c->row_ptrs;
     for (int k = 0; k < kMaxTables; k++) { a.backing[k] = c->backing[k]; a.backing_rows[k] = c->backing_rows[k]; }
-    a.requests = rows; a.out = out; a.hit = hit; a.B = B; a.mask = c->host.nslot_mask;
+    a.requests = rows; a.out = nullptr; a.hit = nullptr; a.B = B; a.mask = c->host.nslot_mask;
     a.cap = (int)cap; a.T = T; a.d = c->host.dim; a.codec = c->host.codec; a.row_bytes = c->host.row_bytes;
     a.max_perfect = c->host.max_perfect; a.flush_n = c->host.flush_n; a.nslot = (int)c->nslot;
     a.block_cnt = c->block_cnt; a.block_base = c->block_base; a.part1 = c->part1; a.part2 = c->part2;
     long long g1 = (B + 7) / 8; if (g1 > kProbeGridMax) g1 = kProbeGridMax;
     a.g1 = (int)g1; a.g2 = (int)g2;
-    const int wide = kNumCu * 8;
     a.host_tomb = c->host_tomb_dev;
+    a.estamp = nullptr; a.stamp = 0;
+    a.other_slots = nullptr; a.other_mask = 0;
+    return EVS_OK;
+}
+
+// K2..K5 of one cache (its misses are described by a.miss_info)
+static void batch_policy(evs_cache *c, const evs::BatchArgs &a, hipStream_t st) {
+    using namespace evs;
+    const int wide = kNumCu * 8;
+    hipLaunchKernelGGL(cache_batch_insert_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_plan_kernel, dim3(1), dim3(256), 0, st, a);
+    long long ne = ((long long)a.cap + 255) / 256; if (ne > wide) ne = wide;
+    hipLaunchKernelGGL(cache_batch_evict_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_assign_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
+}
+
+// K6: close the batch; the hash is rebuilt without tombstones when they exceed nslot/8 -- the host learns the count
+// from a mapped word K6b writes (one or two batches stale, which only means slightly longer probe chains)
+static void batch_close(evs_cache *c, evs::BatchArgs a, hipStream_t st) {
+    using namespace evs;
+    const int wide = kNumCu * 8;
+    long long ne = ((long long)a.cap + 255) / 256; if (ne > wide) ne = wide;
+    const bool rebuild = *reinterpret_cast<volatile int *>(c->host_tomb) > (int)(c->nslot / 8);
+    if (rebuild) hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
+    a.B = rebuild ? -a.B : a.B;   // sign = "the slots were cleared: re-insert every entry"
+    hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3(rebuild ? (unsigned)ne : 1u), dim3(256), 0, st, a);
+}
+
+static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit, const float *x,
+                            int64_t x_stride, int itself, float *R, void *stream) {
+    using namespace evs;
+    if (B == 0) return EVS_OK;
+    EVS_REQUIRE(hit, "evs_cache_lookup_batch: NULL hit");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    BatchArgs a;
+    const int prc = batch_prepare(c, B, rows, st, a, "evs_cache_lookup_batch");
+    if (prc) return prc;
+    const int T = c->host.n_tables;
+    const long long cap = c->host.cap;
+    const int wide = kNumCu * 8;
+    a.out = out; a.hit = hit;
     // Host-memory miss tier: hits of this batch are pinned (stamp), the policy update runs FIRST, the missed keys
     // that got an entry are re-pointed at their arena rows and only then do the consumers read -- every missing
     // row crosses the bus once (K5's de-duplicated fetch).  Miss tier in HBM: consumers first, as measured best.
     const bool host_tier = c->host_backing;
-    a.estamp = nullptr; a.stamp = 0;
     if (host_tier) {
         if (!c->estamp) {
             EVS_HIP_CHECK(hipMalloc(&c->estamp, cap * 4));
@@ -1569,7 +1708,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         a.estamp = c->estamp;
         a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;   // never 0, distinct for consecutive batches
     }
-    hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)g1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)a.g1), dim3(256), 0, st, a);
     auto consumers = [&]() -> int {
         if (out) {
             long long nb = (B * T * (long long)c->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
@@ -1589,21 +1728,51 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
     // side stream under the consumer was measured and is slower: 101 vs 91 us per batch -- the consumer
     // already saturates the memory system and the two event waits cost more than the overlap returns.)
     if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
-    hipLaunchKernelGGL(cache_batch_insert_kernel, dim3((unsigned)g2), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(cache_batch_plan_kernel, dim3(1), dim3(256), 0, st, a);
-    long long ne = (cap + 255) / 256; if (ne > wide) ne = wide;
-    hipLaunchKernelGGL(cache_batch_evict_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(cache_batch_assign_kernel, dim3((unsigned)g2), dim3(256), 0, st, a);
+    batch_policy(c, a, st);
     if (host_tier) {
-        hipLaunchKernelGGL(cache_batch_patch_ptrs_kernel, dim3((unsigned)g2), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(cache_batch_patch_ptrs_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
         const int rc = consumers(); if (rc) return rc;
     }
-    // the hash is rebuilt without tombstones when they exceed nslot/8; the host learns the count from a
-    // mapped word K6b writes (one or two batches stale, which only means slightly longer probe chains)
-    const bool rebuild = *reinterpret_cast<volatile int *>(c->host_tomb) > (int)(c->nslot / 8);
-    if (rebuild) hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
-    a.B = rebuild ? -B : B;   // sign = "the slots were cleared: re-insert every entry"
-    hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3(rebuild ? (unsigned)ne : 1u), dim3(256), 0, st, a);
+    batch_close(c, a, st);
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
+}
+
+// ---- batched two-tier lookup (C1 main precision + C2 secondary precision), snapshot semantics ------------------
+// The throughput form of request_to_c1_c2 (mixed_precs_caching/evlfu_8.cpp:669-796), no reference counterpart
+// (the reference is batch-1): every key of the batch is probed in C1, then in C2, against the tiers as they
+// stand when the call starts; agg_hit of a request = keys found in either tier; a hit is served (and its priority
+// raised) in the tier that holds it; a double miss is routed by the reference's rule evaluated on the snapshot --
+// C1 not full: C1; C1 full and agg_hit < threshold: odd table index -> C1, even -> C2; else C2 -- served from the
+// destination tier's backing table at that tier's precision and inserted there once per batch (a key two requests
+// route differently goes to C1).  Each tier then runs the single-tier policy update (K2-K6) on its own misses.
+extern "C" int evs_cache_lookup_batch_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
+                                           uint8_t *tier, int high_agghit_threshold, void *stream) {
+    using namespace evs;
+    if (B == 0) return EVS_OK;
+    EVS_REQUIRE(c1 && c2 && out && tier, "evs_cache_lookup_batch_c1c2: NULL argument");
+    EVS_REQUIRE(c1->host.n_tables == c2->host.n_tables && c1->host.dim == c2->host.dim,
+                "evs_cache_lookup_batch_c1c2: the tiers must agree on n_tables and dim");
+    EVS_REQUIRE(!c1->host_backing && !c2->host_backing, "evs_cache_lookup_batch_c1c2: backing tables must be in HBM");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    BatchArgs a1, a2;
+    int rc = batch_prepare(c1, B, rows, st, a1, "evs_cache_lookup_batch_c1c2");
+    if (rc) return rc;
+    rc = batch_prepare(c2, B, rows, st, a2, "evs_cache_lookup_batch_c1c2");
+    if (rc) return rc;
+    const int T = c1->host.n_tables;
+    const int wide = kNumCu * 8;
+    TwoTierArgs tt;
+    tt.row_tier = c1->row_tier; tt.tier_out = tier; tt.threshold = high_agghit_threshold;
+    hipLaunchKernelGGL(cache_batch_probe2_kernel, dim3((unsigned)a1.g1), dim3(256), 0, st, a1, a2, tt);
+    long long nb = (B * T * (long long)c1->host.dim + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(cache_rows_from_ptrs2_kernel, dim3((unsigned)nb), dim3(256), 0, st, c1->row_ptrs, c1->row_tier, out,
+                       (long long)B, T, c1->host.dim, c1->host.codec, c2->host.codec);
+    batch_policy(c1, a1, st);
+    a2.other_slots = c1->bslots; a2.other_mask = c1->host.nslot_mask;   // a key C1 just took is not inserted in C2 too
+    batch_policy(c2, a2, st);
+    batch_close(c1, a1, st);
+    batch_close(c2, a2, st);
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
 }

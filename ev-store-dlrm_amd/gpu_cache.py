@@ -156,6 +156,20 @@ def request_c1c2(c1, c2, rows, threshold=23, out=None, tier=None):
     return tier, out
 
 
+def lookup_batch_c1c2(c1, c2, rows, threshold=23, out=None, tier=None):
+    """Batched two-tier lookup with snapshot semantics (include/evstore_hip.h: evs_cache_lookup_batch_c1c2): the
+    throughput form of request_c1c2.  Returns (tier (B,T) uint8: 1 = C1 hit, 2 = C2 hit, 0 = miss; out (B,T,dim) fp32)."""
+    assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
+    B = int(rows.shape[0])
+    if out is None:
+        out = torch.empty((B, c1.n_tables, c1.dim), dtype=torch.float32, device=c1.device)
+    if tier is None:
+        tier = torch.empty((B, c1.n_tables), dtype=torch.uint8, device=c1.device)
+    _lib.check(_lib.lib().evs_cache_lookup_batch_c1c2(c1._h, c2._h, B, rows.data_ptr(), out.data_ptr(), tier.data_ptr(),
+                                                      int(threshold), torch.cuda.current_stream(c1.device).cuda_stream))
+    return tier, out
+
+
 class GpuAltKeyTier:
     """C3: key -> alt-key map with second-chance FIFO (deterministic re-specification of
     mixed_precs_caching/aprx_embedding.cpp).  alt_tables: per table a device uint32 tensor (viewed as int32 is fine)

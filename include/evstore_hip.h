@@ -229,6 +229,15 @@ EVS_API int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, cons
  * evs_cache_request (exact) or by evs_cache_lookup_batch, never both (EVS_ESTATE). */
 EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
                                    void *stream);
+/* Batched two-tier lookup, snapshot semantics: the throughput form of evs_cache_request_c1c2 (no reference
+ * counterpart).  Every key is probed in C1, then in C2, against the tiers as they stand when the call starts;
+ * agg_hit of a request counts keys found in either tier; a hit is served, and its priority raised, in the tier
+ * that holds it; a double miss is routed by the reference's rule (evlfu_8.cpp:570-601) evaluated on the snapshot
+ * -- C1 not full: C1; C1 full and agg_hit < threshold: odd table index -> C1, even -> C2; else C2 -- served from
+ * the destination tier's backing table at that tier's precision and inserted there once per batch.  out: (B,T,dim)
+ * fp32; tier (B,T): 1 = C1 hit, 2 = C2 hit, 0 = miss.  Both caches take the batched path from then on. */
+EVS_API int evs_cache_lookup_batch_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
+                                        uint8_t *tier, int high_agghit_threshold, void *stream);
 /* The same lookup feeding the interaction directly: R = interact_features(x, [rows of the 26 keys])
  * (B, d + F(F-1)/2) without materialising the rows -- the probe writes a table of row addresses
  * (arena row for a hit, backing row for a miss) that the fused MFMA kernel consumes.  fp32 caches,

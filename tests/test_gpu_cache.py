@@ -354,6 +354,25 @@ def test_batched_cache_over_host_memory_backing(E, orc):
     assert ch.batch_stats()["n_hits"] > 0 and ch.batch_stats()["size"] > 0
 
 
+def test_batched_cache_smaller_than_one_batch(E, orc):
+    """A cache far smaller than the unique keys of one batch: the hash can run out of empty words between
+    rebuilds; every walk is bounded, rows stay exact, the cache never exceeds its capacity."""
+    n_rows = [400] * 26
+    tabs = orc.kaggle_tables(n_rows, 3)
+    c = E.GpuCache("evlfu", 60, 26, 36, 32)
+    c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
+    rs = np.random.RandomState(0)
+    for it in range(6):
+        rq = rs.randint(0, 400, size=(600, 26)).astype(np.int32)
+        hit, out = c.lookup_batch(torch.from_numpy(rq).cuda())
+        out = out.cpu().numpy()
+        for k in range(26):
+            assert np.array_equal(out[:, k, :], tabs[k][rq[:, k]])
+        st = c.batch_stats()
+        d = c.batch_dump()
+        assert st["size"] == len(d) <= 60 and len({(int(t), int(r)) for _, t, r in d}) == len(d)
+
+
 def test_batched_and_exact_paths_do_not_mix(E, orc):
     tabs = orc.kaggle_tables([50] * 26, 1)
     c = E.GpuCache("evlfu", 100, 26, 36, 32)
@@ -382,6 +401,68 @@ def test_cache_lookup_interact_equals_rows_then_interact(E, orc):
         want = E.apply_emb_interact(x, off, idx, ev)
         assert torch.equal(R, want)
     assert c.batch_stats()["n_hits"] > 0
+
+
+@pytest.mark.parametrize("thr", [23, 20])
+def test_batched_two_tier_c1c2(E, orc, thr):
+    """Batched C1 (u8) + C2 (u4) lookup, snapshot semantics: tier flags = residency when the batch starts; rows at
+    the precision of the tier that serves them (hit) or of the destination tier (miss, routed by the reference's
+    rule on the snapshot); no key in both tiers; C2 untouched until C1 is full; histograms consistent."""
+    from evstore_dlrm_amd import gpu_cache
+    rs = np.random.RandomState(31)
+    n, T, d = 300, 26, 36
+    ws = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for _ in range(T)]
+    raw8 = [orc.encode_table(w, 8) for w in ws]
+    raw4 = [orc.encode_table(w, 4) for w in ws]
+    dec8 = [orc.decode(r, 8, d) for r in raw8]
+    dec4 = [orc.decode(r, 4, d) for r in raw4]
+    cap1, cap2 = 500, 900
+    c1 = E.GpuCache("evlfu", cap1, T, d, 8, "cpp")
+    c2 = E.GpuCache("evlfu", cap2, T, d, 4, "cpp")
+    c1.set_backing([torch.from_numpy(r).cuda() for r in raw8])
+    c2.set_backing([torch.from_numpy(r).cuda() for r in raw4])
+    reqs = np.minimum(rs.zipf(1.25, size=(3000, T)) - 1, n - 1).astype(np.int32)
+    r = torch.from_numpy(reqs).cuda()
+    R1, R2 = {}, {}
+    saw_c2 = False
+    for s in range(0, len(reqs), 250):
+        rq = reqs[s:s + 250]
+        tier, out = gpu_cache.lookup_batch_c1c2(c1, c2, r[s:s + 250].contiguous(), threshold=thr)
+        tier, out = tier.cpu().numpy(), out.cpu().numpy()
+        c1_full = len(R1) >= cap1
+        for b in range(len(rq)):
+            in1 = np.array([(k + 1, int(rq[b, k])) in R1 for k in range(T)])
+            in2 = np.array([(k + 1, int(rq[b, k])) in R2 for k in range(T)]) & ~in1
+            assert np.array_equal(tier[b] == 1, in1) and np.array_equal(tier[b] == 2, in2), (s, b)
+            agg = int(in1.sum() + in2.sum())
+            for k in range(T):
+                row = int(rq[b, k])
+                if in1[k]:
+                    want = dec8[k][row]
+                elif in2[k]:
+                    want = dec4[k][row]
+                else:
+                    dest = 1 if not c1_full else ((1 if k % 2 == 1 else 2) if agg < thr else 2)
+                    want = dec8[k][row] if dest == 1 else dec4[k][row]
+                assert np.array_equal(out[b, k].view(np.uint32), want.view(np.uint32)), (s, b, k)
+        d1, d2 = c1.batch_dump(), c2.batch_dump()
+        st1, st2 = c1.batch_stats(), c2.batch_stats()
+        n1 = {(int(t), int(rw)): int(p) for p, t, rw in d1}
+        n2 = {(int(t), int(rw)): int(p) for p, t, rw in d2}
+        assert len(n1) == len(d1) == st1["size"] <= cap1 and len(n2) == len(d2) == st2["size"] <= cap2
+        assert not (set(n1) & set(n2)), "a key lives in one tier"
+        assert np.array_equal(np.bincount(d1[:, 0], minlength=T + 1), np.array(st1["hist"]))
+        if len(d2):
+            assert np.array_equal(np.bincount(d2[:, 0], minlength=T + 1), np.array(st2["hist"]))
+        if not c1_full:
+            assert len(n2) == len(R2), "C2 is left alone while C1 has room"
+        for key, p in n1.items():
+            if key in R1:
+                assert p >= R1[key]
+        saw_c2 |= len(n2) > 0
+        R1, R2 = n1, n2
+    assert saw_c2 and len(R1) == cap1
+    assert c1.batch_stats()["n_requests"] == len(reqs)
 
 
 def test_three_tier_c1c2c3_vs_oracle(E, orc):
