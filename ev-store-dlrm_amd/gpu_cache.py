@@ -170,6 +170,14 @@ def lookup_batch_c1c2(c1, c2, rows, threshold=23, out=None, tier=None):
     return tier, out
 
 
+def lookup_interact_c1c2(c1, c2, rows, x, threshold=23, itself=False, out=None, tier=None):
+    """lookup_batch_c1c2 followed by interact_features over the served rows (dense features read in place from the
+    (B,T,dim) rows: no copy).  Returns (tier, R)."""
+    from .dlrm_ops import interact_features
+    tier, out = lookup_batch_c1c2(c1, c2, rows, threshold, out, tier)
+    return tier, interact_features(x, list(out.unbind(1)), "dot", itself)
+
+
 class GpuAltKeyTier:
     """C3: key -> alt-key map with second-chance FIFO (deterministic re-specification of
     mixed_precs_caching/aprx_embedding.cpp).  alt_tables: per table a device uint32 tensor (viewed as int32 is fine)

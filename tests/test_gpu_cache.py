@@ -463,6 +463,17 @@ def test_batched_two_tier_c1c2(E, orc, thr):
         R1, R2 = n1, n2
     assert saw_c2 and len(R1) == cap1
     assert c1.batch_stats()["n_requests"] == len(reqs)
+    # the same lookup feeding the interaction: R == interact_features over the rows it served
+    x = torch.rand(250, d, device="cuda")
+    rows_buf = torch.empty((250, T, d), device="cuda")
+    t2, R = gpu_cache.lookup_interact_c1c2(c1, c2, r[:250].contiguous(), x, threshold=thr, out=rows_buf)
+    assert torch.equal(R, E.interact_features(x, list(rows_buf.unbind(1)))) and torch.equal(R[:, :d], x)
+    t2, rb = t2.cpu().numpy(), rows_buf.cpu().numpy()
+    for b in range(0, 250, 7):
+        for k in range(T):
+            if t2[b, k]:
+                want = (dec8 if t2[b, k] == 1 else dec4)[k][int(reqs[b, k])]
+                assert np.array_equal(rb[b, k].view(np.uint32), want.view(np.uint32))
 
 
 def test_three_tier_c1c2c3_vs_oracle(E, orc):
