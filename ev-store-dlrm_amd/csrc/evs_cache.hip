@@ -1058,14 +1058,42 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
 }
 
 // rows (B,T,d) fp32 from the pointer table, each row decoded with the codec of the tier that serves it
+// (row_tier == NULL: every row in codec1).  d % 4 == 0: one thread per 4-element chunk, raw chunk in (16 / 8 / 4 /
+// 2 bytes), float4 out, decode through per-block LDS tables (evs_common.h); other d: element by element.
 __global__ void __launch_bounds__(256) cache_rows_from_ptrs2_kernel(const long long *row_ptrs, const unsigned char *row_tier,
                                                                     float *out, long long B, int T, int d, int codec1, int codec2) {
+    __shared__ float s_lut16[CodecLut<16>::kEntries], s_lut8[CodecLut<8>::kEntries], s_lut4[CodecLut<4>::kEntries];
+    if (codec1 == 16 || codec2 == 16) codec_lut_init<16>(s_lut16);
+    if (codec1 == 8 || codec2 == 8) codec_lut_init<8>(s_lut8);
+    if (codec1 == 4 || codec2 == 4) codec_lut_init<4>(s_lut4);
+    __syncthreads();
+    if ((d & 3) == 0) {
+        const int cpr = d >> 2;
+        const long long n = B * T * cpr;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const long long rowi = i / cpr;
+            const int c = (int)(i - rowi * cpr);
+            const long long p = row_ptrs[rowi];
+            const int which = row_tier ? row_tier[rowi] : 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p && which) {
+                const int codec = which == 1 ? codec1 : codec2;
+                const unsigned char *row = reinterpret_cast<const unsigned char *>(p);
+                if (codec == 32) v = reinterpret_cast<const float4 *>(row)[c];
+                else if (codec == 16) { const uint2 w = reinterpret_cast<const uint2 *>(row)[c]; v = dec_chunk<16>(w.x, w.y, s_lut16); }
+                else if (codec == 8) v = dec_chunk<8>(reinterpret_cast<const unsigned *>(row)[c], 0u, s_lut8);
+                else v = dec_chunk<4>(reinterpret_cast<const unsigned short *>(row)[c], 0u, s_lut4);
+            }
+            reinterpret_cast<float4 *>(out)[i] = v;
+        }
+        return;
+    }
     const long long n = B * T * d;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long rowi = i / d;
         const int c = (int)(i - rowi * d);
         const long long p = row_ptrs[rowi];
-        const int which = row_tier[rowi];
+        const int which = row_tier ? row_tier[rowi] : 1;
         out[i] = (p && which) ? decode_elem(reinterpret_cast<const unsigned char *>(p), which == 1 ? codec1 : codec2, c) : 0.f;
     }
 }
@@ -1712,8 +1740,12 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
     auto consumers = [&]() -> int {
         if (out) {
             long long nb = (B * T * (long long)c->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
-            hipLaunchKernelGGL(cache_rows_from_ptrs_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->row_ptrs, out,
-                               (long long)B, T, c->host.dim, c->host.codec);
+            if (c->host.codec == 32)
+                hipLaunchKernelGGL(cache_rows_from_ptrs_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->row_ptrs, out,
+                                   (long long)B, T, c->host.dim, c->host.codec);
+            else   // reduced precision: chunked decode through LDS tables
+                hipLaunchKernelGGL(cache_rows_from_ptrs2_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->row_ptrs,
+                                   (const unsigned char *)nullptr, out, (long long)B, T, c->host.dim, c->host.codec, c->host.codec);
         }
         if (R) {
             const int rc = fused_interact_from_row_ptrs(B, T, c->host.dim, x, x_stride, (const int64_t *)c->row_ptrs,
@@ -1765,7 +1797,7 @@ extern "C" int evs_cache_lookup_batch_c1c2(evs_cache *c1, evs_cache *c2, int64_t
     TwoTierArgs tt;
     tt.row_tier = c1->row_tier; tt.tier_out = tier; tt.threshold = high_agghit_threshold;
     hipLaunchKernelGGL(cache_batch_probe2_kernel, dim3((unsigned)a1.g1), dim3(256), 0, st, a1, a2, tt);
-    long long nb = (B * T * (long long)c1->host.dim + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
+    long long nb = (B * T * (long long)c1->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(cache_rows_from_ptrs2_kernel, dim3((unsigned)nb), dim3(256), 0, st, c1->row_ptrs, c1->row_tier, out,
                        (long long)B, T, c1->host.dim, c1->host.codec, c2->host.codec);
     batch_policy(c1, a1, st);

@@ -1,0 +1,24 @@
+"""Developer: per-kernel profile target for the batched two-tier lookup (run under tools/prof_any.sh)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, evstore_dlrm_amd as E
+from evstore_dlrm_amd import gpu_cache
+dev = torch.device("cuda")
+ln, d, T = bench.KAGGLE_LN, 36, 26
+ev = bench.make_tables(ln, d)
+ev8, ev4 = ev.encode(8), ev.encode(4)
+budget = int(0.02 * sum(ln))
+c1 = E.GpuCache("evlfu", int(0.48 * budget) * 4, T, d, 8, "cpp", dev)
+c2 = E.GpuCache("evlfu", int(0.48 * budget) * 8, T, d, 4, "cpp", dev)
+c1.set_backing(ev8); c2.set_backing(ev4)
+B = 16384
+out = torch.empty((B, T, d), device=dev); tier = torch.empty((B, T), dtype=torch.uint8, device=dev)
+bs = bench.make_batches(ln, B, 100, seed=21, device=dev, dist="zipf", alpha=0.75)
+rq = [b[1].t().contiguous().to(torch.int32) for b in bs]
+for r in rq[:80]:
+    gpu_cache.lookup_batch_c1c2(c1, c2, r, out=out, tier=tier)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for r in rq[80:]:
+    gpu_cache.lookup_batch_c1c2(c1, c2, r, out=out, tier=tier)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("two-tier batched: %.1f us per batch, %.2f G lookups/s, C1 %d C2 %d resident" % (dt / 20 * 1e6, T * B * 20 / dt / 1e9, c1.batch_stats()["size"], c2.batch_stats()["size"]))
