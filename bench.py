@@ -167,38 +167,48 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
     if not batch1:
         return {"value": looks / dt, "ms_per_step": dt / steps * 1e3, "hit_rate": (s1["n_hits"] - s0["n_hits"]) / looks,
                 "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"]}
-    n1 = 1500
+    # batch-1 stream: Zipf(1.05), 200 k-entry cache -- a hit rate in the 90s like the reference's experiments, reached
+    # within the first thousand requests (the 10 % cache of the batched section would need ~0.5 M requests to fill)
+    n1, n_skip = 3000, 1000
     cap1 = 200000
     c1 = E.GpuCache("evlfu", cap1, T, d, 32, "python", dev)
     c1.set_backing(ev)
-    req1 = torch.cat([r[:64] for r in rows[:24]])[:n1].contiguous()
+    b1s = make_batches(ln_emb, 256, (n1 + 255) // 256, seed=13, device=dev, dist="zipf", alpha=1.05)
+    req1 = torch.cat([b[1].t().contiguous().to(torch.int32) for b in b1s])[:n1].contiguous()
     host_rows = req1.cpu()
     pin_rows = torch.empty((1, T), dtype=torch.int32).pin_memory()
     pin_out = torch.empty((1, T, d), dtype=torch.float32).pin_memory()
     pin_hit = torch.empty((1, T), dtype=torch.uint8).pin_memory()
     lat = []
+    hits1 = 0
     for i in range(n1):
         t1 = time.perf_counter()
         pin_rows.copy_(host_rows[i:i + 1])
         c1.request(pin_rows, out=pin_out, hit=pin_hit)
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t1) * 1e6)
-    b1 = {"p50_us": float(np.percentile(lat[200:], 50)), "p95_us": float(np.percentile(lat[200:], 95)),
-          "requests": n1, "capacity_entries": cap1,
-          "note": "evs_cache_request B=1 (exact reference semantics): 26 ids in, 26x36 floats + hit flags back on the host (pinned buffers read / written by the kernel), sync"}
+        if i >= n_skip:
+            hits1 += int(pin_hit.sum())
+    b1 = {"p50_us": float(np.percentile(lat[n_skip:], 50)), "p95_us": float(np.percentile(lat[n_skip:], 95)),
+          "requests": n1 - n_skip, "capacity_entries": cap1, "hit_rate": hits1 / (T * (n1 - n_skip)),
+          "note": "evs_cache_request B=1 (exact reference semantics), Zipf(1.05): 26 ids in, 26x36 floats + hit flags back on the "
+                  "host (pinned buffers read / written by the kernel), sync; first %d requests warm the cache" % n_skip}
     cpu = None
     try:
         from oracle import oracle as orc
         tabs = [ev.fp32_view(k).cpu().numpy() for k in range(T)]
         oc = orc.EvLFU(cap1, tabs, d, "python")
         hr = host_rows.numpy()
+        for i in range(n_skip):
+            oc.request(hr[i])
         t1 = time.perf_counter()
-        for i in range(n1):
+        for i in range(n_skip, n1):
             oc.request(hr[i])
         dtc = time.perf_counter() - t1
-        cpu = {"value": T * n1 / dtc, "unit": "lookups/s", "cores": 1, "kind": "port",
-               "sample": "%d batch-1 requests through oracle/evstore_oracle.c EvLFU (cache_algo/EvLFU_C1.py restated), "
-                         "in-memory tables, %.2f s" % (n1, dtc)}
+        cpu = {"value": T * (n1 - n_skip) / dtc, "unit": "lookups/s", "cores": 1, "kind": "port",
+               "us_per_request": dtc / (n1 - n_skip) * 1e6,
+               "sample": "%d batch-1 requests (same stream, after the same %d warm-up requests) through oracle/evstore_oracle.c "
+                         "EvLFU (cache_algo/EvLFU_C1.py restated), in-memory tables, %.2f s" % (n1 - n_skip, n_skip, dtc)}
     except Exception as e:  # the oracle is test infrastructure: its absence must not break the bench
         cpu = {"error": str(e)}
     return {"value": looks / dt, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
