@@ -188,6 +188,30 @@ def test_edge_cases(E, orc):
     E._lib.check(E._lib.lib().evs_check_index_errors(None))  # flag cleared
 
 
+@pytest.mark.parametrize("codec", [32, 16, 8, 4])
+def test_fused_tiny_batches(E, orc, codec):
+    """B = 1, 2, 3, 5 (the EVStore forks run B = 1): fewer samples than waves, pipeline prologue only; stacked and
+    list inputs, with and without offsets, against the two-call path and the oracle."""
+    rs = np.random.RandomState(40 + codec)
+    ln, d = [17, 300, 5, 1000, 64, 2] + [50] * 20, 36
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    raws = [orc.encode_table(t, codec) for t in tabs]
+    ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, codec)
+    for B in (1, 2, 3, 5):
+        idx_np = np.stack([rs.randint(0, n, size=B) for n in ln]).astype(np.int64)
+        idx = torch.from_numpy(idx_np).cuda()
+        off = torch.arange(B, device="cuda").repeat(26, 1)
+        x_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+        x = torch.from_numpy(x_np).cuda()
+        a = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
+        b = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
+        c = E.apply_emb_interact(x, [o for o in off], [i for i in idx], ev)
+        e = E.interact_features(x, E.apply_emb(off, idx, ev))
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, e)
+        ly = orc.apply_emb([np.arange(B, dtype=np.int64)] * 26, list(idx_np), tabs if codec == 32 else raws, None, codec, d)
+        np.testing.assert_allclose(a.cpu().numpy(), orc.interact_features(x_np, ly), rtol=RTOL, atol=2e-6)
+
+
 def test_tables_in_pinned_host_memory(E, orc):
     """The host-memory miss tier without a cache: EVTables over PINNED host tensors give the bits of the HBM tables
     through apply_emb, the fused kernel and the reduced-precision path."""
