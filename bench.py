@@ -232,6 +232,9 @@ def main():
                     help="table placement for --gpus > 1 (sharded.plan_placement); hbm = replicate what fits --replicate-gb")
     ap.add_argument("--replicate-gb", type=float, default=64.0, help="per-GPU HBM budget for replicated tables (hbm placement)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one process")
+    ap.add_argument("--shape", default="kaggle", choices=["kaggle", "terabyte"],
+                    help="N>1 only: terabyte = BASELINE configs[3], MLPerf-DLRM Criteo-Terabyte cardinalities capped at 40 M rows "
+                         "(external to the reference tree; use --dim 64 or 128): exceeds the replication budget, so the big tables shard")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -253,7 +256,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from evstore_dlrm_amd import sharded
-        result = sharded.bench_sharded(args, KAGGLE_LN, rank, world, dev)
+        ln_run = KAGGLE_LN
+        if args.shape == "terabyte":
+            ln_run = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
+                      4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+        result = sharded.bench_sharded(args, ln_run, rank, world, dev)
         dist.barrier()
         dist.destroy_process_group()
         if rank == 0:

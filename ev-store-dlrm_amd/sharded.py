@@ -419,12 +419,13 @@ def bench_sharded(args, ln_emb, rank, world, dev):
                 "RCCL/xGMI" % (main["n_sharded"], main["n_replicated"], policy))
         par = "table-sharded x%d + a2a" % world
     return {
-        "metric": "inference lookups/sec, Criteo-Kaggle 26-table DLRM (apply_emb + interact_features)",
+        "metric": "inference lookups/sec, %s 26-table DLRM (apply_emb + interact_features)"
+                  % ("Criteo-Kaggle" if sum(ln_emb) < 100_000_000 else "Criteo-Terabyte-shaped"),
         "value": lookups * args.steps / dt, "unit": "lookups/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Criteo-Kaggle 26 tables x d=%d fp32 over %d GPUs: %s; uniform indices, one index per bag"
-                               % (d, world, what),
+        "config": {"workload": "%s 26 tables (%.1f M rows) x d=%d fp32 over %d GPUs: %s; uniform indices, one index per bag"
+                               % ("Criteo-Kaggle" if sum(ln_emb) < 100_000_000 else "Criteo-Terabyte-shaped", sum(ln_emb) / 1e6, d, world, what),
                    "batch_per_gpu": Bl, "global_batch": Bg, "tables": T, "dim": d, "parallelism": par,
                    "placement": policy, "owner": main["owner"], "a2a_bytes_per_step_all_links": main["a2a_bytes"]},
         "roofline": main["roofline"], "cpu_baseline": None, "table_sharded_a2a": extra,
