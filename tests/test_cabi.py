@@ -56,3 +56,27 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert rc == E._lib.EVS_EINVAL and b"codec" in L.evs_last_error()
     rc = L.evs_interact_dot(4, 0, 16, None, None, 0, None, None)
     assert rc == E._lib.EVS_EINVAL
+
+
+def test_more_argument_checks_without_a_gpu():
+    """Every entry point validates its arguments before it touches the device: codes and messages."""
+    import ctypes as C
+    import evstore_dlrm_amd as E
+    L = E._lib.lib()
+    EINVAL = E._lib.EVS_EINVAL
+    assert L.evs_encode_table(7, 10, 36, None, None, None) == EINVAL and b"codec" in L.evs_last_error()
+    assert L.evs_encode_table(4, 10, 35, None, None, None) == EINVAL           # 4-bit rows need an even dimension
+    assert L.evs_encode_table(8, 0, 36, None, None, None) == 0                 # nothing to do is not an error
+    assert L.evs_encode_table(8, 5, 36, None, None, None) == EINVAL and b"NULL" in L.evs_last_error()
+    assert L.evs_fused_dim_supported(36) == 1 and L.evs_fused_dim_supported(20) == 0
+    h = C.c_void_p()
+    assert L.evs_cache_create(C.byref(h), 9, 10, 26, 36, 32, 0.3, 0.95, 1, 0) == EINVAL and b"policy" in L.evs_last_error()
+    assert L.evs_cache_create(C.byref(h), 0, 0, 26, 36, 32, 0.3, 0.95, 1, 0) == EINVAL and b"capacity" in L.evs_last_error()
+    assert L.evs_cache_create(C.byref(h), 0, 10, 26, 36, 5, 0.3, 0.95, 1, 0) == EINVAL and b"codec" in L.evs_last_error()
+    assert L.evs_cache_create(C.byref(h), 0, 10, 65, 36, 32, 0.3, 0.95, 1, 0) == EINVAL and b"n_tables" in L.evs_last_error()
+    assert L.evs_cache_request(None, 1, None, None, None, -1, None) == EINVAL
+    assert L.evs_cache_lookup_batch_c1c2(None, None, 4, None, None, None, 23, None) == EINVAL
+    assert L.evs_cache_lookup_batch_c1c2(None, None, 0, None, None, None, 23, None) == 0
+    assert L.evs_emb_interact_dot(4, 40, 36, 32, None, 0, None, None) == EINVAL   # more than 32 features
+    assert L.evs_emb_interact_dot(4, 27, 20, 32, None, 0, None, None) == EINVAL   # dimension the fused kernel is not built for
+    assert not L.evs_host_device_pointer(None)
