@@ -98,7 +98,7 @@ def cpu_baseline(ev, ln_emb, d, seconds=12.0):
                       "torch %s CPU EmbeddingBag+bmm loop, %.1f s" % (n, B, torch.__version__, dt)}
 
 
-def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, alpha=0.75, batch1=True):
+def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, alpha=0.75, batch1=True, host_tier_line=True):
     """BASELINE configs[2]: EvLFU C1 cache in HBM at 10 % of the rows in front of the same tables
     (the tables stay the miss tier); Zipf indices; batched snapshot-semantics lookups + interaction.
     alpha=0.75 with 60 warm-up batches fills the cache, so the timed batches run at capacity (evicting)."""
@@ -131,7 +131,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
     # the same cache in front of tables that stay in pinned HOST memory (the reference's C3 / mmap miss path): each
     # missing row crosses the bus once; beside it, the fused kernel reading every row from host memory uncached
     host_tier = None
-    if batch1:
+    if batch1 and host_tier_line:
         try:
             host = [t.cpu().pin_memory() for t in ev.raw]
             ch = E.GpuCache("evlfu", cap, T, d, 32, "python", dev)
@@ -228,6 +228,10 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache-tier", action="store_true", help="skip the configs[2] (EvLFU cache) section")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the sections that re-launch the headline kernel under other conditions (two streams, B=65536, "
+                         "reduced precision, host-memory tables): used for the rocprofv3 summaries in profiles/, whose "
+                         "per-kernel average must be the headline launch alone")
     ap.add_argument("--placement", default="hbm", choices=["hbm", "count", "rows", "rows+replicate"],
                     help="table placement for --gpus > 1 (sharded.plan_placement); hbm = replicate what fits --replicate-gb")
     ap.add_argument("--replicate-gb", type=float, default=64.0, help="per-GPU HBM budget for replicated tables (hbm placement)")
@@ -328,20 +332,22 @@ def main():
     dtg = time.perf_counter() - tg
 
     # ---- independent batches alternated over two streams: the fill / drain of consecutive launches overlap ----
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    dts = None
+    if not args.no_extras:
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
 
-    def run2(n):
-        for i in range(n):
-            with torch.cuda.stream(streams[i % 2]):
-                step(i)
+        def run2(n):
+            for i in range(n):
+                with torch.cuda.stream(streams[i % 2]):
+                    step(i)
 
-    torch.cuda.synchronize()
-    run2(10)
-    torch.cuda.synchronize()
-    ts = time.perf_counter()
-    run2(args.steps)
-    torch.cuda.synchronize()
-    dts = time.perf_counter() - ts
+        torch.cuda.synchronize()
+        run2(10)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        run2(args.steps)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - ts
 
     # ---- the same work through the two-call plugin surface (apply_emb, then interact_features) ----
     tile = torch.empty((B, F, d), device=dev, dtype=torch.float32)
@@ -391,7 +397,7 @@ def main():
         "general_offsets_path": {"value": lookups * args.steps / dtg, "unit": "lookups/s",
                                  "ms_per_step": dtg / args.steps * 1e3,
                                  "note": ""},
-        "two_streams": {"value": lookups * args.steps / dts, "unit": "lookups/s", "ms_per_step": dts / args.steps * 1e3,
+        "two_streams": None if dts is None else {"value": lookups * args.steps / dts, "unit": "lookups/s", "ms_per_step": dts / args.steps * 1e3,
                         "note": "the same launches, consecutive (independent) batches alternated over two HIP streams: "
                                 "pipeline fill and drain of neighbouring launches overlap; not the headline (per-launch "
                                 "durations overlap, so no roofline is quoted for it)"},
@@ -402,7 +408,7 @@ def main():
     result["general_offsets_path"]["note"] = ("lS_o given (any bag size allowed): offsets checked on the device, the one-index "
                                               "loop runs when they are arange, the general loop when not")
     # ---- the same launch at a larger batch (fixed launch / pipeline-fill cost amortised), and reduced precision ----
-    if B < 65536:
+    if B < 65536 and not args.no_extras:
         Bb = 65536
         bb = make_batches(KAGGLE_LN, Bb, 4, seed=9, device=dev, dist=args.dist)
         xb = torch.rand((Bb, d), device=dev)
@@ -435,7 +441,7 @@ def main():
         del bb, xb, Rb
         torch.cuda.empty_cache()
     if not args.no_cache_tier:
-        result["cache_tier"] = cache_tier_section(ev, KAGGLE_LN, d, B, dev)
+        result["cache_tier"] = cache_tier_section(ev, KAGGLE_LN, d, B, dev, host_tier_line=not args.no_extras)
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ev, KAGGLE_LN, d, args.cpu_seconds)
     print(json.dumps(result))
