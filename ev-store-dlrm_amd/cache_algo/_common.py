@@ -44,10 +44,7 @@ class _ModuleCache:
         self.cache.request(self._host_rows, approx_thres, out=out, hit=self._host_hit)
         torch.cuda.current_stream(self._device).synchronize()
         arr_record_hit = [bool(v) for v in self._host_hit[0].tolist()]
-        vals = out[0]
-        arr_emb_weights = []
-        for k in range(self.n_tables):
-            t = vals[k:k + 1].detach().clone()   # Tensor(1, 36), as torch.FloatTensor([val])
-            t.requires_grad = True
-            arr_emb_weights.append(t)
-        return arr_record_hit, arr_emb_weights
+        # 26 x Tensor(1, 36) with requires_grad, like the reference's torch.FloatTensor([val]) per table -- made as
+        # ONE fresh (26, 1, 36) tensor and its 26 views (26 separate clones were most of this function's time)
+        block = out[0].detach().clone().unsqueeze(1).requires_grad_(True)
+        return arr_record_hit, list(block.unbind(0))
