@@ -9,7 +9,9 @@ existing inference loop can call them unchanged:
 PyTorch is used for device memory and streams only; the arithmetic is in
 libevstore_hip.so (csrc/evs_gather.hip, csrc/evs_interact.hip).
 """
+import collections.abc
 import ctypes as C
+import os
 import sys
 
 import torch
@@ -36,6 +38,43 @@ class _PooledList(list):
 
 
 _feat_cache = {}
+
+# apply_emb followed by interact_features is what every DLRM forward does (dlrm_s_pytorch.py:596-601).  With lazy
+# pooling on, apply_emb returns a LazyPooled sequence that launches nothing; interact_features recognises it and
+# runs the ONE fused kernel.  Anything else that touches the pooled rows (indexing, iteration, list concatenation,
+# len is free) materialises them with the gather kernel first, so the plugin contract is unchanged.
+LAZY_POOLING = os.environ.get("EVS_LAZY_POOLING", "1") != "0"
+
+
+class LazyPooled(collections.abc.Sequence):
+    """The list apply_emb returns, not yet computed."""
+
+    def __init__(self, lS_o, lS_i, ev, v_W_l):
+        self.lS_o, self.lS_i, self.ev, self.v_W_l = lS_o, lS_i, ev, v_W_l
+        self._ly = None
+
+    def materialize(self):
+        if self._ly is None:
+            self._ly = apply_emb(self.lS_o, self.lS_i, self.ev, self.v_W_l, lazy=False)
+        return self._ly
+
+    def __len__(self):
+        return len(self.ev)
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __add__(self, other):
+        return list(self.materialize()) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self.materialize())
+
+    def __repr__(self):
+        return "LazyPooled(%d tables, %s)" % (len(self.ev), "materialized" if self._ly is not None else "pending")
 
 
 def _row_weights_c(ev, v_W_l):
@@ -145,7 +184,7 @@ def _as_evtables(emb_l):
     return ev
 
 
-def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False):
+def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy=None):
     """Drop-in for DLRM_Net.apply_emb (dlrm_s_pytorch.py:407-461).
 
     lS_o: (T,B) int64 tensor or list of T (B,) tensors -- bag START offsets.
@@ -154,11 +193,17 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False):
     v_W_l: None or list with None / per-ROW weight vectors (weighted pooling).
     Returns a list of T (B,d) fp32 tensors in table order; they are views of one
     (T,B,d) buffer, or of `out` = the (B,F,d) interaction tile (slot 0 is left for x).
-    One HIP launch for all tables.
+    One HIP launch for all tables.  lazy (default: the module switch LAZY_POOLING): return a LazyPooled sequence
+    and launch nothing until the rows are touched -- interact_features then runs the fused kernel instead.
     """
     ev = _as_evtables(emb_l)
     T, d = len(ev), ev.d
     dev = ev.device
+    if lazy is None:
+        lazy = LAZY_POOLING
+    if lazy and out is None and not check_indices and fused_supported(T + 1, d) and \
+            (ev.codec == 32 or v_W_l is None or all(w is None for w in v_W_l)):
+        return LazyPooled(lS_o, lS_i, ev, v_W_l)
     L = _lib.lib()
     stacked_o = torch.is_tensor(lS_o)
     stacked_i = torch.is_tensor(lS_i)
@@ -207,6 +252,11 @@ def interact_features(x, ly, arch_interaction_op="dot", arch_interaction_itself=
     """
     if arch_interaction_op not in ("dot", "cat"):
         sys.exit("ERROR: --arch-interaction-op=" + arch_interaction_op + " is not supported")
+    if isinstance(ly, LazyPooled):
+        if ly._ly is None and arch_interaction_op == "dot" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 \
+                and x.shape[1] == ly.ev.d and x.stride(1) == 1:
+            return apply_emb_interact(x, ly.lS_o, ly.lS_i, ly.ev, ly.v_W_l, arch_interaction_itself)
+        ly = ly.materialize()
     B, d = x.shape
     dev = x.device
     meta = getattr(ly, "_evs_meta", None)

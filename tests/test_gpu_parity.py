@@ -182,7 +182,7 @@ def test_edge_cases(E, orc):
     ly = E.apply_emb([_dev(np.array([0]))], [_dev(np.array([5]))], ev)[0].cpu().numpy()
     assert np.array_equal(ly[0], W[5])
     # out-of-range index is reported, not silently gathered
-    E.apply_emb([_dev(np.array([0]))], [_dev(np.array([50]))], ev)
+    E.apply_emb([_dev(np.array([0]))], [_dev(np.array([50]))], ev, lazy=False)
     with pytest.raises(E.EvsError):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
     E._lib.check(E._lib.lib().evs_check_index_errors(None))  # flag cleared
@@ -206,10 +206,41 @@ def test_fused_tiny_batches(E, orc, codec):
         a = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
         b = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
         c = E.apply_emb_interact(x, [o for o in off], [i for i in idx], ev)
-        e = E.interact_features(x, E.apply_emb(off, idx, ev))
+        e = E.interact_features(x, E.apply_emb(off, idx, ev, lazy=False))
         assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, e)
         ly = orc.apply_emb([np.arange(B, dtype=np.int64)] * 26, list(idx_np), tabs if codec == 32 else raws, None, codec, d)
         np.testing.assert_allclose(a.cpu().numpy(), orc.interact_features(x_np, ly), rtol=RTOL, atol=2e-6)
+
+
+def test_lazy_pooling_at_the_plugin_boundary(E, orc):
+    """apply_emb -> interact_features, the reference's own call pair, runs as ONE fused launch: apply_emb hands back
+    a LazyPooled sequence; interact_features consumes it fused; touching the rows materialises them (gather kernel)
+    with the plugin contract intact (len, indexing, iteration, [x] + ly, torch.cat)."""
+    rs = np.random.RandomState(77)
+    ln, d, B = [90, 7, 3000, 41], 36, 333
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    lens = rs.randint(0, 3, size=(4, B))
+    lS_i = [_dev(rs.randint(0, ln[k], size=int(lens[k].sum())).astype(np.int64)) for k in range(4)]
+    lS_o = [_dev(np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64)) for k in range(4)]
+    x = _dev(rs.uniform(-1, 1, size=(B, d)).astype(np.float32))
+    ly = E.apply_emb(lS_o, lS_i, ev, None)
+    assert isinstance(ly, E.dlrm_ops.LazyPooled) and len(ly) == 4 and ly._ly is None
+    R = E.interact_features(x, ly)
+    assert ly._ly is None, "the fused launch does not materialise the rows"
+    assert torch.equal(R, E.apply_emb_interact(x, lS_o, lS_i, ev))
+    eager = E.apply_emb(lS_o, lS_i, ev, None, lazy=False)
+    assert isinstance(eager, list)
+    assert torch.equal(ly[2], eager[2]) and ly._ly is not None          # indexing materialises
+    assert all(torch.equal(a, b) for a, b in zip(ly, eager))             # iteration
+    cat = torch.cat([x] + ly, dim=1)                                      # the reference's own interact_features does this
+    assert cat.shape == (B, 5 * d) and torch.equal(cat[:, d:2 * d], eager[0])
+    assert torch.equal(E.interact_features(x, ly), E.interact_features(x, eager))   # materialised: two-kernel path
+    assert isinstance(E.apply_emb(lS_o, lS_i, ev, None, check_indices=True), list)  # a check wants the rows now
+    zi = [torch.zeros_like(i) for i in lS_i]
+    assert isinstance(E.apply_emb(lS_o, zi, E.EVTables.from_fp32([torch.zeros(5, 10)] * 4), None), list)  # d the fused kernel lacks
+    # "cat" interaction and the reference-style use
+    assert torch.equal(E.interact_features(x, E.apply_emb(lS_o, lS_i, ev, None), "cat"), cat)
 
 
 def test_tables_in_pinned_host_memory(E, orc):
@@ -292,7 +323,7 @@ def test_full_size_kaggle_properties(E):
     x2 = torch.randn(B2, 36, device="cuda")
     a = E.apply_emb_interact(x2, off2b, idx2, ev, check_indices=True)
     b = E.apply_emb_interact(x2, off2b, idx2, ev, one_index_per_bag=True)
-    c = E.interact_features(x2, E.apply_emb(off2b, idx2, ev))
+    c = E.interact_features(x2, E.apply_emb(off2b, idx2, ev, lazy=False))
     assert torch.equal(a, b) and torch.equal(a, c)
     assert torch.equal(a[:, :36], x2)
     # Z[b, pair(k+1, 0)] = <row_k, x>: recompute column 0 of the triangle for three tables from the table rows
@@ -322,7 +353,7 @@ def test_fused_gather_interact_vs_golden(E, orc, name):
     R = E.apply_emb_interact(x, o, i, ev, w, bool(g["itself"]), check_indices=True)
     np.testing.assert_allclose(R.cpu().numpy(), g["R"], rtol=RTOL, atol=2e-6)
     # identical to the two-kernel path bit for bit (same pooled sums, same MFMA chain)
-    R2 = E.interact_features(x, E.apply_emb(o, i, ev, w), "dot", bool(g["itself"]))
+    R2 = E.interact_features(x, E.apply_emb(o, i, ev, w, lazy=False), "dot", bool(g["itself"]))
     assert torch.equal(R, R2)
 
 
@@ -364,7 +395,7 @@ def test_fused_codec_26_tables_one_index_per_bag(E, orc, codec):
     x = torch.from_numpy(x_np).cuda()
     a = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
     b = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True, check_indices=True)
-    c = E.interact_features(x, E.apply_emb(off, idx, ev, None))
+    c = E.interact_features(x, E.apply_emb(off, idx, ev, None, lazy=False))
     assert torch.equal(a, b) and torch.equal(a, c)
     ly = orc.apply_emb([np.arange(B, dtype=np.int64)] * 26, list(idx_np), raws, None, codec, d)
     np.testing.assert_allclose(a.cpu().numpy(), orc.interact_features(x_np, ly), rtol=RTOL, atol=2e-6)
@@ -395,7 +426,7 @@ def test_fused_optimistic_offsets_pair(E, orc, codec):
         o = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in offs]
         i = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in idxs]
         a = E.apply_emb_interact(x, o, i, ev, check_indices=True)
-        b = E.interact_features(x, E.apply_emb(o, i, ev, None))
+        b = E.interact_features(x, E.apply_emb(o, i, ev, None, lazy=False))
         assert torch.equal(a, b)
         return a
 

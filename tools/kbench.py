@@ -44,7 +44,7 @@ def main():
             row = d * a.bits // 8
             f_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev), a.iters)
             f1_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev, one_index_per_bag=True), a.iters)
-            g_us = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None), a.iters)
+            g_us = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None, lazy=False), a.iters)
             fb = B * (26 * (row + 8) + 4 * d + 4 * (d + 351)) / 1e3
             print("B=%6d u%d fused one-index/bag %7.1f us (%5.0f GB/s algorithmic, %.2f G lookups/s) | offsets %7.1f us | gather only %7.1f us"
                   % (B, a.bits, f1_us, fb / f1_us, 26 * B / f1_us / 1e3, f_us, g_us), flush=True)
@@ -53,8 +53,8 @@ def main():
         g_tile = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None, out=tile), a.iters)
         ly_tile = E.apply_emb(batches[0][0], batches[0][1], ev, None, out=tile)
         i_tile = timeit(lambda i: E.interact_features(x, ly_tile), a.iters)
-        g_tab = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None), a.iters)
-        ly_tab = E.apply_emb(batches[0][0], batches[0][1], ev, None)
+        g_tab = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None, lazy=False), a.iters)
+        ly_tab = E.apply_emb(batches[0][0], batches[0][1], ev, None, lazy=False)
         i_tab = timeit(lambda i: E.interact_features(x, ly_tab), a.iters)
         f_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev), a.iters)
         f1_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev, one_index_per_bag=True), a.iters)

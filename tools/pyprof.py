@@ -8,7 +8,7 @@ B = 128
 bs = bench.make_batches(ln, B, 4, 1, "cuda", "uniform")
 x = torch.rand(B, 36, device="cuda")
 def step(i):
-    ly = E.apply_emb(bs[i % 4][0], bs[i % 4][1], ev, None)
+    ly = E.apply_emb(bs[i % 4][0], bs[i % 4][1], ev, None, lazy=False)
     return E.interact_features(x, ly)
 for i in range(20): step(i)
 torch.cuda.synchronize()

@@ -63,7 +63,7 @@ def fused_rows(ln, d, bits, batches_B, iters, label):
         out.append("| %s | %d | %d | %d | %.1f | %.1f | %.2f | %.0f | %.1f%% | %.1f | %.2f |" % (
             label, d, bits, B, p50, p95, T * B / mean / 1e3, alg / mean / 1e3, alg / mean / 1e3 / HBM_PEAK * 100, g50, T * B / gmean / 1e3))
         if bits == 32 and B >= 128:
-            t50, _, tmean = per_batch_us(lambda i: E.interact_features(x, E.apply_emb(bs[i % 8][0], bs[i % 8][1], ev, None)), 8, max(20, iters // 4))
+            t50, _, tmean = per_batch_us(lambda i: E.interact_features(x, E.apply_emb(bs[i % 8][0], bs[i % 8][1], ev, None, lazy=False)), 8, max(20, iters // 4))
             out[-1] += " %.1f | %.2f |" % (t50, T * B / tmean / 1e3)
         else:
             out[-1] += " – | – |"
@@ -233,7 +233,7 @@ def main():
     it = 50 if a.quick else 200
     print("# Round-1 sweep (one MI355X, synthetic uniform indices unless stated; HBM peak used: 8 000 GB/s)\n")
     print("`fused` = `apply_emb_interact` (one kernel; one index per bag declared); `offsets` = the same with `lS_o` read and")
-    print("validated; `two-call` = `apply_emb` then `interact_features`.  Latencies are per batch, HIP events, inputs resident.")
+    print("validated; `two-call` = `apply_emb(lazy=False)` then `interact_features`: two kernels, the pooled rows in HBM (with lazy pooling, the default, the pair runs as the fused launch).  Latencies are per batch, HIP events, inputs resident.")
     print("GB/s = algorithmic bytes (SURVEY 8(d): rows + indices + x read, R written) / mean batch time.\n")
     print("| shape | d | bits | B | fused p50 µs | p95 µs | G lookups/s | GB/s | of peak | offsets p50 µs | G lookups/s | two-call p50 µs | G lookups/s |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
