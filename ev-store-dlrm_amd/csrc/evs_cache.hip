@@ -1636,36 +1636,56 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     EVS_REQUIRE(B > 0 && B < (1ll << 31) / 32 && rows, "%s: bad argument", who);
     const int T = c->host.n_tables;
     const long long cap = c->host.cap;
-    if (!c->bs) {
+    if (!c->bs) {   // first batched call: all-or-nothing, so a failed allocation leaves the cache as it was
         BatchState h{};
         h.n_free = (int)cap;
-        EVS_HIP_CHECK(hipMalloc(&c->bs, sizeof(BatchState)));
-        EVS_HIP_CHECK(hipMemcpy(c->bs, &h, sizeof h, hipMemcpyHostToDevice));
-        EVS_HIP_CHECK(hipMalloc(&c->eslot, cap * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->bslots, c->nslot * 8));
-        EVS_HIP_CHECK(hipMemset(c->bslots, 0, c->nslot * 8));
-        EVS_HIP_CHECK(hipMalloc(&c->part1, kReplicas * kPartCols * 4));
-        EVS_HIP_CHECK(hipMemset(c->part1, 0, kReplicas * kPartCols * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->part2, kReplicas * kPartCols * 4));
-        EVS_HIP_CHECK(hipMemset(c->part2, 0, kReplicas * kPartCols * 4));
-        EVS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_tomb), sizeof(int), hipHostMallocMapped));
-        *c->host_tomb = 0;
-        EVS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->host_tomb_dev), c->host_tomb, 0));
+        BatchState *bs = nullptr;
+        int *eslot = nullptr, *part1 = nullptr, *part2 = nullptr, *host_tomb = nullptr, *host_tomb_dev = nullptr;
+        unsigned long long *bslots = nullptr;
+        const bool ok =
+            hipMalloc(&bs, sizeof(BatchState)) == hipSuccess && hipMemcpy(bs, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc(&eslot, cap * 4) == hipSuccess &&
+            hipMalloc(&bslots, c->nslot * 8) == hipSuccess && hipMemset(bslots, 0, c->nslot * 8) == hipSuccess &&
+            hipMalloc(&part1, kReplicas * kPartCols * 4) == hipSuccess && hipMemset(part1, 0, kReplicas * kPartCols * 4) == hipSuccess &&
+            hipMalloc(&part2, kReplicas * kPartCols * 4) == hipSuccess && hipMemset(part2, 0, kReplicas * kPartCols * 4) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void **>(&host_tomb), sizeof(int), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(reinterpret_cast<void **>(&host_tomb_dev), host_tomb, 0) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            void *dev_ptrs[] = {bs, eslot, bslots, part1, part2};
+            for (void *q : dev_ptrs) if (q) (void)hipFree(q);
+            if (host_tomb) (void)hipHostFree(host_tomb);
+            set_error("%s: allocating the batched-path state failed (capacity %lld)", who, cap);
+            return EVS_ENOMEM;
+        }
+        *host_tomb = 0;
+        c->bs = bs; c->eslot = eslot; c->bslots = bslots; c->part1 = part1; c->part2 = part2;
+        c->host_tomb = host_tomb; c->host_tomb_dev = host_tomb_dev;
     }
     const long long g2 = (B * T + 255) / 256;
-    if (B > c->max_batch) {
+    if (B > c->max_batch) {   // grow the per-batch buffers: new ones first, the old ones go only when all of them exist
+        unsigned *miss_info = nullptr;
+        int *new_slot = nullptr, *block_cnt = nullptr, *block_base = nullptr;
+        long long *row_ptrs = nullptr, *iota = nullptr;
+        unsigned char *row_tier = nullptr;
+        const bool ok = hipMalloc(&miss_info, B * T * 4) == hipSuccess && hipMalloc(&new_slot, g2 * 256 * 4) == hipSuccess &&
+                        hipMalloc(&block_cnt, g2 * 4) == hipSuccess && hipMalloc(&block_base, g2 * 4) == hipSuccess &&
+                        hipMalloc(&row_ptrs, B * T * 8) == hipSuccess && hipMalloc(&row_tier, B * T) == hipSuccess &&
+                        hipMalloc(&iota, B * 8) == hipSuccess;
+        void *fresh[] = {miss_info, new_slot, block_cnt, block_base, row_ptrs, row_tier, iota};
+        if (!ok) {
+            (void)hipGetLastError();
+            for (void *q : fresh) if (q) (void)hipFree(q);
+            set_error("%s: allocating the buffers of a %lld-request batch failed", who, (long long)B);
+            return EVS_ENOMEM;
+        }
         if (c->miss_info) {
             EVS_HIP_CHECK(hipStreamSynchronize(st));
             void *old[] = {c->miss_info, c->new_slot, c->row_ptrs, c->iota, c->block_cnt, c->block_base, c->row_tier};
-            for (void *p : old) (void)hipFree(p);
+            for (void *q : old) (void)hipFree(q);
         }
-        EVS_HIP_CHECK(hipMalloc(&c->miss_info, B * T * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->new_slot, g2 * 256 * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->block_cnt, g2 * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->block_base, g2 * 4));
-        EVS_HIP_CHECK(hipMalloc(&c->row_ptrs, B * T * 8));
-        EVS_HIP_CHECK(hipMalloc(&c->row_tier, B * T));
-        EVS_HIP_CHECK(hipMalloc(&c->iota, B * 8));
+        c->miss_info = miss_info; c->new_slot = new_slot; c->block_cnt = block_cnt; c->block_base = block_base;
+        c->row_ptrs = row_ptrs; c->row_tier = row_tier; c->iota = iota;
         hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(256), 0, st, c->iota, (long long)B);
         c->max_batch = B;
     }
