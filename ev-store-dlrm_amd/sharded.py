@@ -90,15 +90,17 @@ class HipBackend:
     def make_tables(self, weights, d):
         return EVTables([w.to(self.device) for w in weights], d, 32)
 
-    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d):
-        """pooled[b][j][:] for the j-th owned table, written into send (B, n_own, d)."""
+    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False):
+        """pooled[b][j][:] for the j-th owned table, written into send (B, n_own, d).
+        planned: the caller passes the SAME list objects every step (plan / run_start): the pointer tables are then
+        cached by list identity and the lists kept alive; one-off calls build them and keep nothing."""
         B = int(send.shape[0])
         n = len(table_ids_local)
         if n == 0 or B == 0:
             return
         # planned batches pass the same list objects every step: key on identity first (no per-step tuple building)
         fast = ("gid", id(lS_i_rows), id(lS_o_rows), send.data_ptr())
-        ent = self._cache.get(fast)
+        ent = self._cache.get(fast) if planned else None
         if ent is None:
             ent = ((C.c_void_p * n)(*[ev._tables_c[k] for k in table_ids_local]),
                    (C.c_int64 * n)(*[ev.n_rows[k] for k in table_ids_local]),
@@ -106,21 +108,22 @@ class HipBackend:
                    (C.c_void_p * n)(*[t.data_ptr() for t in lS_o_rows]),
                    (C.c_int64 * n)(*[int(t.numel()) for t in lS_i_rows]),
                    lS_i_rows, lS_o_rows)  # the lists are kept alive so their ids stay unique
-            if len(self._cache) > 256:
-                self._cache.clear()
-            self._cache[fast] = ent
+            if planned:
+                if len(self._cache) > 256:
+                    self._cache.clear()
+                self._cache[fast] = ent
         L = _lib.lib()
         _lib.check(L.evs_embedding_bag_sum(n, B, d, ev.codec, ent[0], ent[1], ent[2], ent[3], ent[4], None,
                                            send.data_ptr(), d, n_own * d, _stream_ptr(self.device)))
 
-    def interact_mixed(self, x, specs, ev, d, itself, out=None):
+    def interact_mixed(self, x, specs, ev, d, itself, out=None, planned=False):
         """specs[t]: ("dense", tensor(B,d) view) | ("indirect", local_table_id, idx, off, nnz, off_len)."""
         B = int(x.shape[0])
         F = len(specs) + 1
         P = F * (F + 1) // 2 if itself else F * (F - 1) // 2
         R = out if out is not None else torch.empty((B, d + P), dtype=torch.float32, device=self.device)
         fast = ("fid", id(specs), x.data_ptr(), R.data_ptr())   # a planned batch re-uses the same specs list
-        ent = self._cache.get(fast)
+        ent = self._cache.get(fast) if planned else None
         if ent is None:
             feats = (_lib.EvsFeature * F)()
             feats[0].src, feats[0].stride = x.data_ptr(), int(x.stride(0)) if B > 1 else d
@@ -134,8 +137,8 @@ class HipBackend:
                     f.src, f.indices = ev._tables_c[k], idx.data_ptr()
                     f.offsets = off.data_ptr() if off is not None else None
                     f.nnz, f.n_rows, f.offsets_len = int(nnz), ev.n_rows[k], int(off_len)
-            ent = (feats, specs if out is not None else None)   # keep the list alive only when it can recur
-            if out is not None:
+            ent = (feats, specs if planned else None)   # keep the list alive only when it can recur
+            if planned:
                 if len(self._cache) > 256:
                     self._cache.clear()
                 self._cache[fast] = ent
@@ -271,7 +274,7 @@ class ShardedEmbeddingInteract:
         47) -- at this batch size the step is bounded by host-side launch cost, not by GPU overlap."""
         if not self.any_sharded:
             return None
-        self.backend.bag_sum_into(self.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], len(self.my_own), self.d)
+        self.backend.bag_sum_into(self.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], len(self.my_own), self.d, planned=True)
         if self.world > 1:
             return dist.all_to_all_single(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"], group=self.group,
                                           async_op=True)
@@ -281,7 +284,7 @@ class ShardedEmbeddingInteract:
     def run_finish(self, pl, work):
         if work is not None:
             work.wait()
-        return self.backend.interact_mixed(pl["x"], pl["specs"], self.ev, self.d, self.itself, out=pl["R"])
+        return self.backend.interact_mixed(pl["x"], pl["specs"], self.ev, self.d, self.itself, out=pl["R"], planned=True)
 
     def forward(self, x_local, lS_o, lS_i):
         """lS_o/lS_i: per-table offsets/indices of the FULL batch (every rank sees all of them,
@@ -363,9 +366,9 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
         for _ in range(iters):
             ev[0].record()
             if n_own:
-                backend.bag_sum_into(op.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], n_own, d)
+                backend.bag_sum_into(op.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], n_own, d, planned=True)
             ev[1].record()
-            backend.interact_mixed(pl["x"], pl["specs"], op.ev, d, op.itself, out=pl["R"])
+            backend.interact_mixed(pl["x"], pl["specs"], op.ev, d, op.itself, out=pl["R"], planned=True)
             ev[2].record()
             torch.cuda.synchronize()
             t_pool += ev[0].elapsed_time(ev[1])

@@ -22,12 +22,12 @@ class OracleBackend:
     def make_tables(self, weights, d):
         return [np.ascontiguousarray(w.numpy()) for w in weights]
 
-    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d):
+    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False):
         for j, k in enumerate(table_ids_local):
             pooled = orc.embedding_bag_sum(ev[k], lS_i_rows[j].numpy(), lS_o_rows[j].numpy())
             send[:, j, :] = torch.from_numpy(pooled)
 
-    def interact_mixed(self, x, specs, ev, d, itself, out=None):
+    def interact_mixed(self, x, specs, ev, d, itself, out=None, planned=False):
         B = x.shape[0]
         ly = []
         for s in specs:
