@@ -999,7 +999,7 @@ extern "C" int evs_fused_dim_supported(int d) {
     return d == 16 || d == 32 || d == 36 || d == 48 || d == 64 || d == 128;
 }
 
-extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const evs_feature *feats, int itself,
+extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const evs_feature *feats_in, int itself,
                                     float *R, void *stream) {
     using namespace evs;
     EVS_REQUIRE(B >= 0 && B < (1ll << 31) && F >= 1 && F <= EVS_MAX_FEATURES && evs_fused_dim_supported(d),
@@ -1007,7 +1007,15 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
                 (long long)B, F, d);
     EVS_REQUIRE(codec == 32 || codec == 16 || codec == 8 || codec == 4, "evs_emb_interact_dot: codec %d", codec);
     if (B == 0) return EVS_OK;
-    EVS_REQUIRE(feats && R, "evs_emb_interact_dot: NULL argument");
+    EVS_REQUIRE(feats_in && R, "evs_emb_interact_dot: NULL argument");
+    // A table nobody indexes in this batch arrives with nnz == 0 and, from most runtimes, a NULL indices pointer --
+    // which otherwise means "dense feature".  n_rows > 0 with offsets given marks it as a table: every bag is empty.
+    evs_feature feats[EVS_MAX_FEATURES];
+    for (int f = 0; f < F; f++) {
+        feats[f] = feats_in[f];
+        if (!feats[f].indices && feats[f].n_rows > 0 && feats[f].offsets && feats[f].nnz == 0)
+            feats[f].indices = feats[f].offsets;   // any valid address: never dereferenced
+    }
     EVS_REQUIRE(feats[0].indices == nullptr, "evs_emb_interact_dot: feature 0 (x) must be dense");
     FusedArgs a;
     for (int f = 0; f < EVS_MAX_FEATURES; f++) {

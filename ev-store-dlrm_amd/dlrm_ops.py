@@ -348,7 +348,9 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
         assert i.dtype == torch.int64 and o.dtype == torch.int64 and i.is_cuda and o.is_cuda
         assert (i.numel() == 0 or i.stride(0) == 1) and o.stride(0) == 1 and o.numel() == B
         f = feats[k + 1]
-        f.src, f.indices, f.offsets = ev._tables_c[k], i.data_ptr(), o.data_ptr()
+        # a table nobody indexes in this batch has an EMPTY index tensor whose data_ptr() is NULL -- and NULL indices
+        # mean "dense feature" in the C ABI: hand over any valid address instead (nnz = 0: never dereferenced)
+        f.src, f.indices, f.offsets = ev._tables_c[k], (i.data_ptr() or o.data_ptr()), o.data_ptr()
         f.nnz, f.n_rows = int(i.numel()), ev.n_rows[k]
         if v_W_l is not None and v_W_l[k] is not None:
             w = v_W_l[k].detach().to(dev, torch.float32).contiguous()

@@ -134,7 +134,8 @@ class HipBackend:
                     f.src, f.stride = v.data_ptr(), int(v.stride(0)) if B > 1 else d
                 else:
                     _, k, idx, off, nnz, off_len = s
-                    f.src, f.indices = ev._tables_c[k], idx.data_ptr()
+                    # empty index tensor: data_ptr() is NULL, which the C ABI reads as "dense" -- pass the table address
+                    f.src, f.indices = ev._tables_c[k], (idx.data_ptr() or ev._tables_c[k])
                     f.offsets = off.data_ptr() if off is not None else None
                     f.nnz, f.n_rows, f.offsets_len = int(nnz), ev.n_rows[k], int(off_len)
             ent = (feats, specs if planned else None)   # keep the list alive only when it can recur

@@ -147,7 +147,8 @@ EVS_API int evs_interact_dot(int64_t B, int F, int d, const float *const *feats,
 typedef struct evs_feature {
     const void *src;
     int64_t stride;
-    const int64_t *indices;
+    const int64_t *indices;   /* NULL = dense feature -- except: n_rows > 0, nnz == 0 and offsets given = a table whose
+                                 bags are all empty in this batch (an empty index array has no address) */
     const int64_t *offsets;   /* indirect: B bag starts; NULL on EVERY indirect feature = one index per bag */
     int64_t nnz;
     int64_t n_rows;

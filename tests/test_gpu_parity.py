@@ -243,6 +243,42 @@ def test_lazy_pooling_at_the_plugin_boundary(E, orc):
     assert torch.equal(E.interact_features(x, E.apply_emb(lS_o, lS_i, ev, None), "cat"), cat)
 
 
+def test_fused_table_without_indices(E, orc):
+    """A table no sample indexes (its index tensor is empty: data_ptr() == NULL, which means "dense" in the C ABI)
+    found by tools/fuzz.py: every bag of it is empty, its pooled rows are zeros -- through the Python wrapper and
+    through the raw C ABI with a NULL indices pointer."""
+    import ctypes as C
+    rs = np.random.RandomState(5)
+    ln, d, B = [17, 300, 40, 9] + [25] * 17, 32, 3     # 21 tables: two MFMA tile rows
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    lens = rs.randint(0, 3, size=(len(ln), B))
+    lens[2] = 0
+    lens[7] = 0
+    li = [rs.randint(0, ln[k], size=int(lens[k].sum())).astype(np.int64) for k in range(len(ln))]
+    lo = [np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64) for k in range(len(ln))]
+    x_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    x = _dev(x_np)
+    lS_i, lS_o = [_dev(a) for a in li], [_dev(a) for a in lo]
+    assert lS_i[2].data_ptr() == 0
+    R = E.apply_emb_interact(x, lS_o, lS_i, ev, check_indices=True)
+    want = orc.interact_features(x_np, orc.apply_emb(lo, li, tabs))
+    np.testing.assert_allclose(R.cpu().numpy(), want, rtol=RTOL, atol=4e-6)
+    assert torch.equal(R, E.interact_features(x, E.apply_emb(lS_o, lS_i, ev, lazy=False)))
+    # raw C ABI, NULL indices for the two empty tables
+    F = len(ln) + 1
+    feats = (E._lib.EvsFeature * F)()
+    feats[0].src, feats[0].stride = x.data_ptr(), d
+    for k in range(len(ln)):
+        f = feats[k + 1]
+        f.src, f.indices, f.offsets = ev.raw[k].data_ptr(), (lS_i[k].data_ptr() or None), lS_o[k].data_ptr()
+        f.nnz, f.n_rows = int(lS_i[k].numel()), ln[k]
+    R2 = torch.empty_like(R)
+    E._lib.check(E._lib.lib().evs_emb_interact_dot(B, F, d, 32, feats, 0, R2.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(R2, R)
+
+
 def test_tables_in_pinned_host_memory(E, orc):
     """The host-memory miss tier without a cache: EVTables over PINNED host tensors give the bits of the HBM tables
     through apply_emb, the fused kernel and the reduced-precision path."""
