@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the cache tier on the GPU against the oracle (checker only):
+  exact path   EvLFU (three variants, approx mode) / LRU / LFU, random tables, capacities, streams and chunk sizes:
+               hit flags, rows, final list order and counters
+  two tiers    request_c1c2 against oracle.C1C2: tier codes, rows, both tiers' final lists
+  batched      lookup_batch with random capacities / batch sizes (incl. caches smaller than one batch): snapshot hit
+               flags, exact rows, no duplicate keys, size <= capacity, histogram consistent
+usage: python tools/fuzz_cache.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import evstore_dlrm_amd as E  # noqa: E402
+from evstore_dlrm_amd import gpu_cache  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def _stream(rs, n_rows, n_req):
+    T = len(n_rows)
+    kind = rs.choice(["zipf", "uniform", "hot"])
+    if kind == "zipf":
+        a = rs.uniform(1.05, 1.6)
+        r = np.stack([np.minimum(rs.zipf(a, size=n_req) - 1, n_rows[k] - 1) for k in range(T)], axis=1)
+    elif kind == "uniform":
+        r = np.stack([rs.randint(0, n_rows[k], size=n_req) for k in range(T)], axis=1)
+    else:
+        r = np.stack([rs.randint(0, min(n_rows[k], 4), size=n_req) for k in range(T)], axis=1)
+    return r.astype(np.int32)
+
+
+def exact_case(rs, case):
+    T = int(rs.choice([1, 2, 5, 13, 26, 26, 26, 40]))
+    d = int(rs.choice([4, 16, 36, 36, 64]))
+    n_rows = [int(rs.choice([1, 3, 20, 200, 3000])) for _ in range(T)]
+    policy = rs.choice(["evlfu", "evlfu", "evlfu", "lru", "lfu"])
+    variant = rs.choice(["python", "cpp", "cython"]) if policy == "evlfu" else "python"
+    cap = int(rs.choice([1, 2, 7, T, 3 * T, 64, 500, 5000]))
+    n_req = int(rs.choice([1, 10, 200, 1200]))
+    approx = int(rs.choice([-1, -1, -1, max(1, T // 2), T])) if policy == "evlfu" and variant == "python" else -1
+    tag = "exact case %d: %s/%s T=%d d=%d cap=%d n_req=%d approx=%d rows=%s" % (case, policy, variant, T, d, cap, n_req, approx, n_rows[:6])
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in n_rows]
+    reqs = _stream(rs, n_rows, n_req)
+    if policy == "evlfu":
+        o = orc.EvLFU(cap, tabs, d, variant)
+    elif policy == "lru":
+        o = orc.LRU(cap, tabs, d)
+    else:
+        o = orc.LFU(cap, tabs, d)
+    if approx > 0:
+        return tag + " (skipped: approx mode draws random vectors in the reference)"
+    want_h, want_o = [], []
+    try:
+        for rq in reqs:
+            h, out = o.request(rq) if policy != "evlfu" else o.request(rq, approx)
+            want_h.append(h.copy()); want_o.append(out.copy())
+    except RuntimeError:
+        return tag + " (skipped: the reference raises on this stream)"
+    c = E.GpuCache(policy, cap, T, d, 32, variant)
+    c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
+    r = torch.from_numpy(reqs).cuda()
+    chunk = int(rs.choice([1, 3, 64, 5000]))
+    hits, outs = [], []
+    for s in range(0, n_req, chunk):
+        h, out = c.request(r[s:s + chunk].contiguous(), approx)
+        hits.append(h.cpu().numpy().astype(bool)); outs.append(out.cpu().numpy())
+    hits, outs = np.concatenate(hits), np.concatenate(outs)
+    assert np.array_equal(hits, np.stack(want_h)), tag + ": hit flags"
+    assert np.array_equal(outs.view(np.uint32), np.stack(want_o).view(np.uint32)), tag + ": rows"
+    got = c.dump()
+    if policy == "lru":
+        got = got[:, 1:]   # the GPU dump carries a (constant) priority column for LRU
+    assert np.array_equal(got, o.dump()), tag + ": final lists"
+    if policy == "evlfu":
+        st, so = c.stats(), o.state()
+        assert [st["min_c1"], st["n_perfect"], st["size"], st["n_flush"]] == [so["min_c1"], so["n_perfect"], so["size"], so["n_flush"]], tag + ": state"
+    return tag
+
+
+def c1c2_case(rs, case):
+    T, d = 26, 36
+    n = int(rs.choice([5, 60, 400]))
+    ws = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for _ in range(T)]
+    raw8 = [orc.encode_table(w, 8) for w in ws]
+    raw4 = [orc.encode_table(w, 4) for w in ws]
+    dec8 = [orc.decode(r, 8, d) for r in raw8]
+    dec4 = [orc.decode(r, 4, d) for r in raw4]
+    cap1, cap2 = int(rs.choice([30, 100, 600])), int(rs.choice([30, 200, 1200]))
+    thr = int(rs.choice([23, 23, 15, 26]))
+    n_req = int(rs.choice([50, 600, 1500]))
+    tag = "c1c2 case %d: n=%d cap1=%d cap2=%d thr=%d n_req=%d" % (case, n, cap1, cap2, thr, n_req)
+    reqs = _stream(rs, [n] * T, n_req)
+    o = orc.C1C2(cap1, cap2, dec8, dec4, d, thr)
+    want_t, want_o = [], []
+    for rq in reqs:
+        t, out = o.request(rq)[:2]
+        want_t.append(t.copy()); want_o.append(out.copy())
+    c1 = E.GpuCache("evlfu", cap1, T, d, 8, "cpp")
+    c2 = E.GpuCache("evlfu", cap2, T, d, 4, "cpp")
+    c1.set_backing([torch.from_numpy(r).cuda() for r in raw8])
+    c2.set_backing([torch.from_numpy(r).cuda() for r in raw4])
+    r = torch.from_numpy(reqs).cuda()
+    chunk = int(rs.choice([1, 17, 4000]))
+    tiers, outs = [], []
+    for s in range(0, n_req, chunk):
+        t, out = gpu_cache.request_c1c2(c1, c2, r[s:s + chunk].contiguous(), threshold=thr)
+        tiers.append(t.cpu().numpy()); outs.append(out.cpu().numpy())
+    assert np.array_equal(np.concatenate(tiers), np.stack(want_t)), tag + ": tier codes"
+    assert np.array_equal(np.concatenate(outs).view(np.uint32), np.stack(want_o).view(np.uint32)), tag + ": rows"
+    assert np.array_equal(c1.dump(), o.c1.dump()) and np.array_equal(c2.dump(), o.c2.dump()), tag + ": final lists"
+    return tag
+
+
+def batched_case(rs, case):
+    T = int(rs.choice([1, 7, 26, 26, 32]))
+    d = int(rs.choice([16, 36, 36, 64]))
+    n_rows = [int(rs.choice([2, 30, 500, 8000])) for _ in range(T)]
+    cap = int(rs.choice([1, 5, 60, 700, 6000]))
+    B = int(rs.choice([1, 9, 100, 700, 3000]))
+    n_batches = int(rs.choice([2, 6, 15]))
+    tag = "batched case %d: T=%d d=%d cap=%d B=%d batches=%d rows=%s" % (case, T, d, cap, B, n_batches, n_rows[:6])
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in n_rows]
+    c = E.GpuCache("evlfu", cap, T, d, 32, rs.choice(["python", "cpp"]))
+    c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
+    reqs = _stream(rs, n_rows, B * n_batches)
+    resident = {}
+    hits_total = 0
+    use_interact = d in (16, 36, 64) and T + 1 <= 32
+    for s in range(0, len(reqs), B):
+        rq = reqs[s:s + B]
+        rt = torch.from_numpy(rq).cuda()
+        if use_interact and rs.randint(0, 2):
+            x = torch.rand(len(rq), d, device="cuda")
+            hit, R = c.lookup_interact(rt, x)
+            rows = np.stack([tabs[k][rq[:, k]] for k in range(T)], axis=1)
+            want = orc.interact_features(x.cpu().numpy(), [rows[:, k, :] for k in range(T)])
+            np.testing.assert_allclose(R.cpu().numpy(), want, rtol=1e-5, atol=2e-6 * (d / 36.0), err_msg=tag)
+        else:
+            hit, out = c.lookup_batch(rt)
+            out = out.cpu().numpy()
+            for k in range(T):
+                assert np.array_equal(out[:, k, :], tabs[k][rq[:, k]]), tag + ": rows of table %d" % k
+        hit = hit.cpu().numpy().astype(bool)
+        want_hit = np.array([[(k + 1, int(rq[b, k])) in resident for k in range(T)] for b in range(len(rq))])
+        assert np.array_equal(hit, want_hit), tag + ": snapshot hit flags"
+        hits_total += int(hit.sum())
+        dmp, st = c.batch_dump(), c.batch_stats()
+        keys = [(int(t), int(rw)) for _, t, rw in dmp]
+        assert len(set(keys)) == len(keys) == st["size"] <= cap, tag + ": duplicates / size"
+        assert np.array_equal(np.bincount(dmp[:, 0], minlength=T + 1)[:T + 1], np.array(st["hist"])), tag + ": histogram"
+        new_res = {(int(t), int(rw)): int(p) for p, t, rw in dmp}
+        for key, p in new_res.items():
+            if key in resident:
+                assert p >= resident[key], tag + ": priority went down"
+        resident = new_res
+    st = c.batch_stats()
+    assert st["n_hits"] == hits_total and st["n_requests"] == len(reqs), tag + ": counters"
+    return tag
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rs = np.random.RandomState(seed)
+    t0 = time.time()
+    n = [0, 0, 0]
+    last = ""
+    while time.time() - t0 < seconds:
+        which = int(rs.choice([0, 0, 1, 2, 2]))
+        last = (exact_case, c1c2_case, batched_case)[which](rs, sum(n))
+        n[which] += 1
+    print("cache fuzz ok: %d exact, %d two-tier, %d batched cases in %.0f s (seed %d); last %s" % (n[0], n[1], n[2], time.time() - t0, seed, last))
+
+
+if __name__ == "__main__":
+    main()
