@@ -801,7 +801,7 @@ __device__ __forceinline__ unsigned long long make_word(unsigned long long key, 
 struct BatchState {
     int n_miss, n_new, n_free, count, n_tomb;
     int cnt[kMaxBuckets];
-    int pstar, need, ticket, flush_t, ticket_t, do_rebuild, n_assign;
+    int pstar, need, ticket, flush_t, ticket_t, pos_ticket, do_rebuild, n_assign;
     int hand, win;   // eviction scans the entry window [hand, hand + win) (mod cap), then the hand moves on
     long long batch_id, n_hits, n_requests, n_perfect_hits, n_evict, n_flush;
 };
@@ -1193,7 +1193,7 @@ __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs a
         b->n_new = s_scan[255];
         int cnt[kMaxBuckets];  // planning copy: the real histogram is updated by the evict / assign kernels
         for (int p = 0; p <= T; p++) cnt[p] = sb.cnt[p];
-        b->pstar = -1; b->need = 0; b->ticket = 0; b->flush_t = 0; b->ticket_t = 0; b->win = 0;
+        b->pstar = -1; b->need = 0; b->ticket = 0; b->flush_t = 0; b->ticket_t = 0; b->pos_ticket = 0; b->win = 0;
         if (cnt[T] >= args.max_perfect && b->n_new > 0) {  // EvLFU flush (EvLFU_C1.py:36-44), once per batch
             b->flush_t = args.flush_n < cnt[T] ? args.flush_n : cnt[T];
             cnt[T] -= b->flush_t;
@@ -1259,8 +1259,10 @@ __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs 
             prio[j] = (o < win && args.a.ekey[e] != kEmpty && !(args.estamp && args.estamp[e] == args.stamp)) ? args.a.eagg[e] : -1;
             n_t += (prio[j] == T && flush_t > 0);
         }
-        // a victim's ticket is also its place on the free stack: flush victims take n_free + [0, flush_t),
-        // the others n_free + flush_t + [0, need); K6b adds what was handed out to n_free
+        // no flush (the usual batch): a victim's ticket is also its place on the free stack, n_free + [0, need).
+        // Flush batches: the planned number of flush victims may not be reached (hits of the running batch are pinned
+        // with a host-memory miss tier), so both kinds of victims take their places from one more counter -- a gap
+        // in the stack would hand out stale, possibly live, entries (found by tools/fuzz_cache.py).
         unsigned victim = 0, fvict = 0;
         int tk_t = 0;
         if (flush_t > 0) {  // uniform
@@ -1276,18 +1278,20 @@ __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs 
         int tk_c = block_reserve_n(&b->ticket, n_c, s_tot);
 #pragma unroll
         for (int j = 0; j < kEvictPerThread; j++) {
-            int pos = -1;
-            if ((fvict >> j) & 1) pos = n_free0 + tk_t++;
-            else if (prio[j] >= 0 && prio[j] <= pstar) { if (tk_c < need) pos = n_free0 + flush_t + tk_c; tk_c++; }
-            if (pos < 0) continue;
-            victim |= 1u << j;
+            if ((fvict >> j) & 1) victim |= 1u << j;
+            else if (prio[j] >= 0 && prio[j] <= pstar) { if (tk_c < need) victim |= 1u << j; tk_c++; }
+        }
+        int pos = n_free0 + (tk_c - n_c);                 // no flush: victims of this thread are a prefix of its tickets
+        if (flush_t > 0) pos = n_free0 + block_reserve_n(&b->pos_ticket, __popc(victim), s_tot);   // uniform
+#pragma unroll
+        for (int j = 0; j < kEvictPerThread; j++) {
+            if (!((victim >> j) & 1)) continue;
             const int e = ent[j];
             args.slots[args.eslot[e]] = kTomb;
             args.a.ekey[e] = kEmpty;
             atomicSub(&s_delta[prio[j]], 1);
-            args.a.free_stack[pos] = e;
+            args.a.free_stack[pos++] = e;
         }
-        (void)victim;
     }
     __syncthreads();
     int gone = 0;
@@ -1307,7 +1311,7 @@ __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs
     if (threadIdx.x == 0) s_drop = 0;
     __syncthreads();
     // the free stack as K4 left it: what was free plus the victims it handed out
-    const int n_free = b->n_free + (b->ticket_t < b->flush_t ? b->ticket_t : b->flush_t) + (b->ticket < b->need ? b->ticket : b->need);
+    const int n_free = b->n_free + (b->flush_t > 0 ? b->pos_ticket : (b->ticket < b->need ? b->ticket : b->need));
     const int n_assign = b->n_assign < n_free ? b->n_assign : n_free;
     const int sub = threadIdx.x & 15;
     const int my_cnt = args.block_cnt[blockIdx.x], my_base = args.block_base[blockIdx.x];
@@ -1366,7 +1370,7 @@ __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchAr
         __syncthreads();
         if ((int)threadIdx.x <= args.T && s_col[threadIdx.x]) b->cnt[threadIdx.x] += s_col[threadIdx.x];
         if (threadIdx.x == 0) {
-            b->n_free += (b->ticket_t < b->flush_t ? b->ticket_t : b->flush_t) + (b->ticket < b->need ? b->ticket : b->need);
+            b->n_free += b->flush_t > 0 ? b->pos_ticket : (b->ticket < b->need ? b->ticket : b->need);
             const int take = b->n_assign < b->n_free ? b->n_assign : b->n_free;
             b->n_free -= take; b->count += take;
             b->n_tomb += s_col[37];

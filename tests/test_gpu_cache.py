@@ -373,6 +373,30 @@ def test_batched_cache_smaller_than_one_batch(E, orc):
         assert st["size"] == len(d) <= 60 and len({(int(t), int(r)) for _, t, r in d}) == len(d)
 
 
+def test_batched_host_tier_flush_with_pinned_hits(E, orc):
+    """Found by tools/fuzz_cache.py: one table (every hit has the top priority, so the EvLFU flush fires), a 50-entry
+    cache in front of host-memory tables, batches far larger than the cache.  Hits of the running batch are pinned,
+    so the flush finds fewer victims than planned; the free stack must stay gap-free or live entries are handed out
+    again and rows come back wrong."""
+    rs = np.random.RandomState(0)
+    n, d = 500, 16
+    tab = rs.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    for host in (True, False):
+        c = E.GpuCache("evlfu", 50, 1, d, 32, "python")
+        c.set_backing([torch.from_numpy(tab).pin_memory() if host else torch.from_numpy(tab).cuda()])
+        for it in range(6):
+            rq = rs.randint(0, n, size=(700, 1)).astype(np.int32)
+            hit, out = c.lookup_batch(torch.from_numpy(rq).cuda())
+            assert np.array_equal(out.cpu().numpy()[:, 0, :], tab[rq[:, 0]]), (host, it)
+            x = torch.rand(700, d, device="cuda")
+            hit, R = c.lookup_interact(torch.from_numpy(rq).cuda(), x)
+            want = (torch.from_numpy(tab[rq[:, 0]]).cuda() * x).sum(1)
+            torch.testing.assert_close(R[:, d], want, rtol=1e-5, atol=2e-6)
+            st = c.batch_stats()
+            dmp = c.batch_dump()
+            assert st["size"] == len(dmp) <= 50 and len({int(r) for _, _, r in dmp}) == len(dmp)
+
+
 def test_batched_and_exact_paths_do_not_mix(E, orc):
     tabs = orc.kaggle_tables([50] * 26, 1)
     c = E.GpuCache("evlfu", 100, 26, 36, 32)

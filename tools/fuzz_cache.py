@@ -123,13 +123,18 @@ def batched_case(rs, case):
     B = int(rs.choice([1, 9, 100, 700, 3000]))
     n_batches = int(rs.choice([2, 6, 15]))
     tag = "batched case %d: T=%d d=%d cap=%d B=%d batches=%d rows=%s" % (case, T, d, cap, B, n_batches, n_rows[:6])
-    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in n_rows]
-    c = E.GpuCache("evlfu", cap, T, d, 32, rs.choice(["python", "cpp"]))
-    c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
+    codec = int(rs.choice([32, 32, 16, 8, 4]))
+    host = codec == 32 and rs.randint(0, 4) == 0     # the miss tier in pinned host memory
+    tag += " codec=%d host=%s" % (codec, host)
+    src = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in n_rows]
+    raws = [orc.encode_table(t, codec) for t in src]
+    tabs = src if codec == 32 else [orc.decode(r, codec, d) for r in raws]      # what a lookup must return
+    c = E.GpuCache("evlfu", cap, T, d, codec, rs.choice(["python", "cpp"]))
+    c.set_backing([torch.from_numpy(r).pin_memory() if host else torch.from_numpy(r).cuda() for r in raws])
     reqs = _stream(rs, n_rows, B * n_batches)
     resident = {}
     hits_total = 0
-    use_interact = d in (16, 36, 64) and T + 1 <= 32
+    use_interact = codec == 32 and d in (16, 36, 64) and T + 1 <= 32
     for s in range(0, len(reqs), B):
         rq = reqs[s:s + B]
         rt = torch.from_numpy(rq).cuda()
@@ -162,18 +167,69 @@ def batched_case(rs, case):
     return tag
 
 
+def batched2_case(rs, case):
+    T, d = 26, 36
+    n = int(rs.choice([20, 300]))
+    ws = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for _ in range(T)]
+    raw8 = [orc.encode_table(w, 8) for w in ws]
+    raw4 = [orc.encode_table(w, 4) for w in ws]
+    dec8 = [orc.decode(r, 8, d) for r in raw8]
+    dec4 = [orc.decode(r, 4, d) for r in raw4]
+    cap1, cap2 = int(rs.choice([40, 300, 2000])), int(rs.choice([40, 600, 4000]))
+    thr = int(rs.choice([23, 20, 26]))
+    B = int(rs.choice([1, 30, 250, 900]))
+    n_batches = int(rs.choice([3, 8, 14]))
+    tag = "batched two-tier case %d: n=%d cap1=%d cap2=%d thr=%d B=%d batches=%d" % (case, n, cap1, cap2, thr, B, n_batches)
+    c1 = E.GpuCache("evlfu", cap1, T, d, 8, "cpp")
+    c2 = E.GpuCache("evlfu", cap2, T, d, 4, "cpp")
+    c1.set_backing([torch.from_numpy(r).cuda() for r in raw8])
+    c2.set_backing([torch.from_numpy(r).cuda() for r in raw4])
+    reqs = _stream(rs, [n] * T, B * n_batches)
+    R1, R2 = {}, {}
+    for s in range(0, len(reqs), B):
+        rq = reqs[s:s + B]
+        tier, out = gpu_cache.lookup_batch_c1c2(c1, c2, torch.from_numpy(rq).cuda(), threshold=thr)
+        tier, out = tier.cpu().numpy(), out.cpu().numpy()
+        c1_full = len(R1) >= cap1
+        for b in range(len(rq)):
+            in1 = np.array([(k + 1, int(rq[b, k])) in R1 for k in range(T)])
+            in2 = np.array([(k + 1, int(rq[b, k])) in R2 for k in range(T)]) & ~in1
+            assert np.array_equal(tier[b] == 1, in1) and np.array_equal(tier[b] == 2, in2), tag + ": tier flags"
+            agg = int(in1.sum() + in2.sum())
+            for k in range(T):
+                row = int(rq[b, k])
+                if in1[k]:
+                    want = dec8[k][row]
+                elif in2[k]:
+                    want = dec4[k][row]
+                else:
+                    dest = 1 if not c1_full else ((1 if k % 2 == 1 else 2) if agg < thr else 2)
+                    want = dec8[k][row] if dest == 1 else dec4[k][row]
+                assert np.array_equal(out[b, k].view(np.uint32), want.view(np.uint32)), tag + ": row (%d,%d)" % (b, k)
+        d1, d2 = c1.batch_dump(), c2.batch_dump()
+        n1 = {(int(t), int(rw)): int(p) for p, t, rw in d1}
+        n2 = {(int(t), int(rw)): int(p) for p, t, rw in d2}
+        assert len(n1) == len(d1) == c1.batch_stats()["size"] <= cap1 and len(n2) == len(d2) == c2.batch_stats()["size"] <= cap2, tag + ": sizes"
+        assert not (set(n1) & set(n2)), tag + ": a key in both tiers"
+        if not c1_full:
+            assert len(n2) == len(R2), tag + ": C2 touched while C1 had room"
+        R1, R2 = n1, n2
+    return tag
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rs = np.random.RandomState(seed)
     t0 = time.time()
-    n = [0, 0, 0]
+    n = [0, 0, 0, 0]
     last = ""
     while time.time() - t0 < seconds:
-        which = int(rs.choice([0, 0, 1, 2, 2]))
-        last = (exact_case, c1c2_case, batched_case)[which](rs, sum(n))
+        which = int(rs.choice([0, 0, 1, 2, 2, 3]))
+        last = (exact_case, c1c2_case, batched_case, batched2_case)[which](rs, sum(n))
         n[which] += 1
-    print("cache fuzz ok: %d exact, %d two-tier, %d batched cases in %.0f s (seed %d); last %s" % (n[0], n[1], n[2], time.time() - t0, seed, last))
+    print("cache fuzz ok: %d exact, %d two-tier, %d batched, %d batched two-tier cases in %.0f s (seed %d); last %s" % (
+        n[0], n[1], n[2], n[3], time.time() - t0, seed, last))
 
 
 if __name__ == "__main__":
