@@ -315,6 +315,8 @@ class C1C2C3(C1C2):
         self._alt = [np.ascontiguousarray(a, np.uint32) for a in alt_tables]
         arr = (C.c_void_p * self.T)(*[a.ctypes.data for a in self._alt])
         self.c3 = lib().orc_aprx_new(cap_c3, arr, self.T)
+        if not self.c3:
+            raise ValueError("alt-key tier capacity must be >= 50 (aprx_embedding.cpp:33 asserts cap_C3 >= IO_JOB_Q_SIZE)")
 
     def request(self, rows):
         self._rows[:] = rows

@@ -115,6 +115,43 @@ def c1c2_case(rs, case):
     return tag
 
 
+def c1c2c3_case(rs, case):
+    T, d = 26, 36
+    n = int(rs.choice([8, 80, 400]))
+    ws = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for _ in range(T)]
+    raw8 = [orc.encode_table(w, 8) for w in ws]
+    raw4 = [orc.encode_table(w, 4) for w in ws]
+    dec8 = [orc.decode(r, 8, d) for r in raw8]
+    dec4 = [orc.decode(r, 4, d) for r in raw4]
+    alt = [(rs.randint(0, n, size=n) * 100 + rs.randint(1, T + 1, size=n)).astype(np.uint32) for _ in range(T)]
+    cap1, cap2, cap3 = int(rs.choice([30, 150, 600])), int(rs.choice([30, 300, 1200])), int(rs.choice([50, 51, 99, 120, 400]))
+    thr = int(rs.choice([23, 23, 12]))
+    n_req = int(rs.choice([60, 700, 1600]))
+    tag = "c1c2c3 case %d: n=%d caps=%d/%d/%d thr=%d n_req=%d" % (case, n, cap1, cap2, cap3, thr, n_req)
+    reqs = _stream(rs, [n] * T, n_req)
+    o = orc.C1C2C3(cap1, cap2, cap3, dec8, dec4, alt, d, thr)
+    want_t, want_o = [], []
+    for rq in reqs:
+        t, out, _ = o.request(rq)
+        want_t.append(t.copy()); want_o.append(out.copy())
+    c1 = E.GpuCache("evlfu", cap1, T, d, 8, "cpp")
+    c2 = E.GpuCache("evlfu", cap2, T, d, 4, "cpp")
+    c1.set_backing([torch.from_numpy(r).cuda() for r in raw8])
+    c2.set_backing([torch.from_numpy(r).cuda() for r in raw4])
+    c3 = gpu_cache.GpuAltKeyTier(cap3, [torch.from_numpy(a.view(np.int32)).cuda() for a in alt])
+    r = torch.from_numpy(reqs).cuda()
+    chunk = int(rs.choice([1, 29, 5000]))
+    tiers, outs = [], []
+    for s in range(0, n_req, chunk):
+        t, out = gpu_cache.request_c1c2c3(c1, c2, c3, r[s:s + chunk].contiguous(), threshold=thr)
+        tiers.append(t.cpu().numpy()); outs.append(out.cpu().numpy())
+    assert np.array_equal(np.concatenate(tiers), np.stack(want_t)), tag + ": tier codes"
+    assert np.array_equal(np.concatenate(outs).view(np.uint32), np.stack(want_o).view(np.uint32)), tag + ": rows"
+    assert np.array_equal(c1.dump(), o.c1.dump()) and np.array_equal(c2.dump(), o.c2.dump()), tag + ": final lists"
+    assert c3.stats() == o.c3_state(), tag + ": alt-key tier counters"
+    return tag
+
+
 def batched_case(rs, case):
     T = int(rs.choice([1, 7, 26, 26, 32]))
     d = int(rs.choice([16, 36, 36, 64]))
@@ -222,14 +259,16 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rs = np.random.RandomState(seed)
     t0 = time.time()
-    n = [0, 0, 0, 0]
+    n = [0, 0, 0, 0, 0]
     last = ""
     while time.time() - t0 < seconds:
-        which = int(rs.choice([0, 0, 1, 2, 2, 3]))
-        last = (exact_case, c1c2_case, batched_case, batched2_case)[which](rs, sum(n))
+        which = int(rs.choice([0, 0, 1, 2, 2, 3, 4]))
+        if os.environ.get("EVS_FUZZ_VERBOSE"):
+            print("-> case %d kind %d" % (sum(n), which), flush=True)
+        last = (exact_case, c1c2_case, batched_case, batched2_case, c1c2c3_case)[which](rs, sum(n))
         n[which] += 1
-    print("cache fuzz ok: %d exact, %d two-tier, %d batched, %d batched two-tier cases in %.0f s (seed %d); last %s" % (
-        n[0], n[1], n[2], n[3], time.time() - t0, seed, last))
+    print("cache fuzz ok: %d exact, %d two-tier, %d batched, %d batched two-tier, %d three-tier cases in %.0f s (seed %d); last %s" % (
+        n[0], n[1], n[2], n[3], n[4], time.time() - t0, seed, last))
 
 
 if __name__ == "__main__":
