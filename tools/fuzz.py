@@ -64,6 +64,103 @@ def one_case(rs, case):
     return tag
 
 
+def interact_case(rs, case):
+    """interact_features over dense features with arbitrary row strides (views of a wider buffer), dot +- itself, cat."""
+    d = int(rs.choice([16, 32, 36, 48, 64, 128, 20, 7]))
+    F = int(rs.choice([2, 3, 9, 16, 17, 27, 32]))
+    B = int(rs.choice([1, 2, 77, 1000, 5000]))
+    itself = bool(rs.randint(0, 2))
+    pad = int(rs.choice([0, 4, 12]))
+    buf = torch.from_numpy(rs.uniform(-1, 1, size=(B, F, d + pad)).astype(np.float32)).cuda()
+    feats = [buf[:, f, :d] for f in range(F)]
+    tag = "interact case %d: d=%d F=%d B=%d itself=%s pad=%d" % (case, d, F, B, itself, pad)
+    x_np = feats[0].cpu().numpy()
+    ly_np = [f.cpu().numpy() for f in feats[1:]]
+    R = E.interact_features(feats[0], feats[1:], "dot", itself)
+    want = orc.interact_features(x_np, ly_np, itself=itself)
+    np.testing.assert_allclose(R.cpu().numpy(), want, rtol=1e-5, atol=2e-6 * max(1.0, d / 36.0), err_msg=tag)
+    assert torch.equal(R[:, :d], feats[0]), tag + ": x passthrough"
+    cat = E.interact_features(feats[0], feats[1:], "cat")
+    assert torch.equal(cat, torch.cat(feats, dim=1)), tag + ": cat"
+    return tag
+
+
+def tile_case(rs, case):
+    """apply_emb straight into the (B,F,d) interaction tile, then interact_features over the tile's views."""
+    d = int(rs.choice([16, 36, 64]))
+    T = int(rs.choice([1, 5, 15, 16, 26]))
+    B = int(rs.choice([1, 3, 200, 3000]))
+    ln = [int(rs.choice([2, 50, 4000])) for _ in range(T)]
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    lens = rs.randint(0, 3, size=(T, B))
+    li = [rs.randint(0, ln[k], size=int(lens[k].sum())).astype(np.int64) for k in range(T)]
+    lo = [np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64) for k in range(T)]
+    tag = "tile case %d: d=%d T=%d B=%d" % (case, d, T, B)
+    x_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    tile = torch.zeros((B, T + 1, d), device="cuda")
+    tile[:, 0, :] = torch.from_numpy(x_np).cuda()
+    ly = E.apply_emb([torch.from_numpy(a).cuda() for a in lo], [torch.from_numpy(a).cuda() for a in li], ev, None, out=tile)
+    want_ly = orc.apply_emb(lo, li, tabs)
+    for k in range(T):
+        assert np.array_equal(tile[:, k + 1, :].cpu().numpy().view(np.uint32), want_ly[k].view(np.uint32)), tag + ": tile slot %d" % (k + 1)
+    R = E.interact_features(tile[:, 0, :], ly)
+    np.testing.assert_allclose(R.cpu().numpy(), orc.interact_features(x_np, want_ly), rtol=1e-5, atol=2e-6 * (d / 36.0) * 4, err_msg=tag)
+    return tag
+
+
+def sharded_case(rs, case):
+    """The sharded op on virtual ranks (one GPU, the all-to-all done by block copies) against the single-rank result."""
+    from evstore_dlrm_amd import sharded
+    T = int(rs.choice([2, 6, 13, 26]))
+    world = int(rs.choice([1, 2, 3, 4]))
+    d = int(rs.choice([16, 36, 64]))
+    Bl = int(rs.choice([1, 5, 48, 300]))
+    Bg = world * Bl
+    ln = [int(rs.choice([3, 40, 900, 20000, 90000])) for _ in range(T)]
+    policy = rs.choice(["count", "rows", "rows+replicate", "hbm"])
+    thr = int(rs.choice([10, 1000, 50000]))
+    budget = int(rs.choice([0, 500, 30000, 10 ** 9]))
+    bag1 = bool(rs.randint(0, 2))
+    tag = "sharded case %d: T=%d world=%d d=%d Bl=%d policy=%s thr=%d budget=%d bag1=%s" % (case, T, world, d, Bl, policy, thr, budget, bag1)
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    lens = np.ones((T, Bg), dtype=np.int64) if bag1 else rs.randint(0, 4, size=(T, Bg))
+    lS_i = [torch.from_numpy(rs.randint(0, ln[k], size=int(lens[k].sum())).astype(np.int64)).cuda() for k in range(T)]
+    lS_o = [torch.from_numpy(np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64)).cuda() for k in range(T)]
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(Bg, d)).astype(np.float32)).cuda()
+    want = E.apply_emb_interact(x, lS_o, lS_i, E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs]))
+    owner = sharded.plan_placement(ln, world, policy, replicate_max_rows=thr, replicate_budget_rows=budget)
+    ops = []
+    for r in range(world):
+        held = {t: torch.from_numpy(tabs[t]) for t in range(T) if owner[t] in (r, -1)}
+        ops.append(sharded.ShardedEmbeddingInteract(ln, d, r, world, held, sharded.HipBackend(torch.device("cuda")), policy=policy,
+                                                    replicate_max_rows=thr, replicate_budget_rows=budget, one_index_per_bag=bag1))
+        assert ops[-1].owner == owner, tag + ": ranks disagree on the placement"
+    sends = [op.pool(lS_o, lS_i)[0] if len(op.my_own) else None for op in ops]   # the exchange itself is done by hand below
+    torch.cuda.synchronize()
+    for r, op in enumerate(ops):
+        _, _, out_splits = op._splits(Bg)
+        blocks = [sends[p][r * Bl:(r + 1) * Bl].reshape(-1) for p in range(world) if len(ops[p].my_own)]
+        recv = torch.cat(blocks) if blocks else x.new_empty((0,))
+        R = op.finish((None, recv, Bg, Bl, out_splits), x[r * Bl:(r + 1) * Bl], lS_o, lS_i)
+        assert torch.equal(R, want[r * Bl:(r + 1) * Bl]), tag + ": rank %d" % r
+    return tag
+
+
+def encode_case(rs, case):
+    d = int(rs.choice([2, 16, 36, 64]))
+    n = int(rs.choice([1, 7, 500]))
+    kind = rs.choice(["uniform", "normal", "wide", "tiny"])
+    w = {"uniform": lambda: rs.uniform(-1, 1, size=(n, d)), "normal": lambda: rs.standard_normal(size=(n, d)) * 0.4,
+         "wide": lambda: rs.uniform(-1.3, 1.3, size=(n, d)), "tiny": lambda: rs.standard_normal(size=(n, d)) * 1e-4}[kind]().astype(np.float32)
+    ev = E.EVTables.from_fp32([torch.from_numpy(w)])
+    tag = "encode case %d: d=%d n=%d %s" % (case, d, n, kind)
+    for bits in (16, 8, 4):
+        got = ev.encode(bits).raw[0].cpu().numpy()
+        assert np.array_equal(got, orc.encode_table(w, bits)), tag + ": %d-bit codes" % bits
+    return tag
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -71,8 +168,12 @@ def main():
     t0 = time.time()
     n = 0
     last = ""
+    kinds = (one_case, one_case, one_case, interact_case, tile_case, sharded_case, encode_case)
     while time.time() - t0 < seconds:
-        last = one_case(rs, n)
+        fn = kinds[int(rs.randint(0, len(kinds)))]
+        if os.environ.get("EVS_FUZZ_VERBOSE"):
+            print("-> case %d %s" % (n, fn.__name__), flush=True)
+        last = fn(rs, n)
         n += 1
     print("fuzz ok: %d cases in %.0f s (seed %d); last %s" % (n, time.time() - t0, seed, last))
 
