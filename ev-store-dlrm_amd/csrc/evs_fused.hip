@@ -927,7 +927,8 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
     const bool nt2 = a.F > 16;
     // rows through LDS: fp32 always; reduced precision when feature 0 is x and every other feature a table
     if constexpr ((4 * CQ + REM) <= 32 && (CODEC == 32 || (HAS_INDIRECT && !PTRS && !WEIGHTED))) {
-        if (use_lds_rows() && (CODEC == 32 || a.enc_lds)) {
+        // (offsets == NULL exists only in the LDS kernel: the developer switch cannot take that away)
+        if ((use_lds_rows() || a.bag1 == 1) && (CODEC == 32 || a.enc_lds)) {
             if constexpr (HAS_INDIRECT && !WEIGHTED) {
                 if (PTRS || a.bag1 == 1) {
                     if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);

@@ -224,7 +224,7 @@ def test_lazy_pooling_at_the_plugin_boundary(E, orc):
     lS_i = [_dev(rs.randint(0, ln[k], size=int(lens[k].sum())).astype(np.int64)) for k in range(4)]
     lS_o = [_dev(np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64)) for k in range(4)]
     x = _dev(rs.uniform(-1, 1, size=(B, d)).astype(np.float32))
-    ly = E.apply_emb(lS_o, lS_i, ev, None)
+    ly = E.apply_emb(lS_o, lS_i, ev, None, lazy=True)
     assert isinstance(ly, E.dlrm_ops.LazyPooled) and len(ly) == 4 and ly._ly is None
     R = E.interact_features(x, ly)
     assert ly._ly is None, "the fused launch does not materialise the rows"
@@ -240,7 +240,7 @@ def test_lazy_pooling_at_the_plugin_boundary(E, orc):
     zi = [torch.zeros_like(i) for i in lS_i]
     assert isinstance(E.apply_emb(lS_o, zi, E.EVTables.from_fp32([torch.zeros(5, 10)] * 4), None), list)  # d the fused kernel lacks
     # "cat" interaction and the reference-style use
-    assert torch.equal(E.interact_features(x, E.apply_emb(lS_o, lS_i, ev, None), "cat"), cat)
+    assert torch.equal(E.interact_features(x, E.apply_emb(lS_o, lS_i, ev, None, lazy=True), "cat"), cat)
 
 
 def test_fused_table_without_indices(E, orc):
@@ -277,6 +277,38 @@ def test_fused_table_without_indices(E, orc):
     E._lib.check(E._lib.lib().evs_emb_interact_dot(B, F, d, 32, feats, 0, R2.data_ptr(), None))
     torch.cuda.synchronize()
     assert torch.equal(R2, R)
+
+
+@pytest.mark.parametrize("codec", [8, 4, 16])
+def test_fused_mixed_dense_and_encoded_features(E, orc, codec):
+    """x, a second DENSE fp32 feature and reduced-precision tables in one call (raw C ABI): not the x + tables layout
+    of the LDS codec kernel, so the register-direct kernel runs -- against the oracle."""
+    rs = np.random.RandomState(60 + codec)
+    d, B = 36, 131
+    ln = [50, 7, 900]
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    raws = [orc.encode_table(t, codec) for t in tabs]
+    dev = [torch.from_numpy(r).cuda() for r in raws]
+    lens = rs.randint(0, 3, size=(3, B))
+    li = [rs.randint(0, ln[k], size=int(lens[k].sum())).astype(np.int64) for k in range(3)]
+    lo = [np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64) for k in range(3)]
+    x_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    y_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    x, y = _dev(x_np), _dev(y_np)
+    lS_i, lS_o = [_dev(a) for a in li], [_dev(a) for a in lo]
+    F = 5
+    feats = (E._lib.EvsFeature * F)()
+    feats[0].src, feats[0].stride = x.data_ptr(), d
+    feats[1].src, feats[1].stride = y.data_ptr(), d
+    for k in range(3):
+        f = feats[k + 2]
+        f.src, f.indices, f.offsets = dev[k].data_ptr(), (lS_i[k].data_ptr() or lS_o[k].data_ptr()), lS_o[k].data_ptr()
+        f.nnz, f.n_rows = int(lS_i[k].numel()), ln[k]
+    R = torch.empty((B, d + F * (F - 1) // 2), device="cuda")
+    E._lib.check(E._lib.lib().evs_emb_interact_dot(B, F, d, codec, feats, 0, R.data_ptr(), None))
+    E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    want = orc.interact_features(x_np, [y_np] + orc.apply_emb(lo, li, raws, None, codec, d))
+    np.testing.assert_allclose(R.cpu().numpy(), want, rtol=RTOL, atol=4e-6)
 
 
 def test_tables_in_pinned_host_memory(E, orc):
