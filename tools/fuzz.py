@@ -37,8 +37,10 @@ def one_case(rs, case):
     w_np = [rs.uniform(0.5, 1.5, size=ln[k]).astype(np.float32) if weighted and rs.randint(0, 2) else None for k in range(T)]
     if not any(w is not None for w in w_np):
         w_np = None
-    x_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
-    x = torch.from_numpy(x_np).cuda()
+    pad = int(rs.choice([0, 0, 4, 28]))      # x as a row-strided view of a wider buffer (the bottom MLP's output tile)
+    xw = rs.uniform(-1, 1, size=(B, d + pad)).astype(np.float32)
+    x_np = np.ascontiguousarray(xw[:, :d])
+    x = torch.from_numpy(xw).cuda()[:, :d]
     lS_i = [torch.from_numpy(a).cuda() for a in lS_i_np]
     lS_o = [torch.from_numpy(a).cuda() for a in lS_o_np]
     w = None if w_np is None else [None if a is None else torch.from_numpy(a).cuda() for a in w_np]
