@@ -4,9 +4,10 @@ Drop-in for the hot path of ucare-uchicago/ev-store-dlrm (see DESIGN.md,
 INTEGRATION.md).  Importable as `evstore_dlrm_amd` through the shim at the
 repository root (the directory name carries a hyphen).
 """
-from . import _lib
+from . import _lib, dlrm_ops, gpu_cache
 from ._lib import EvsError, build
-from .dlrm_ops import EVTables, apply_emb, apply_emb_interact, interact_features
-from .gpu_cache import GpuCache
+from .dlrm_ops import EVTables, LazyPooled, apply_emb, apply_emb_interact, fused_supported, interact_features
+from .gpu_cache import GpuAltKeyTier, GpuCache, lookup_batch_c1c2, lookup_interact_c1c2, request_c1c2, request_c1c2c3
 
-__all__ = ["EvsError", "build", "GpuCache", "EVTables", "apply_emb", "apply_emb_interact", "interact_features"]
+__all__ = ["EvsError", "build", "EVTables", "LazyPooled", "apply_emb", "apply_emb_interact", "interact_features", "fused_supported",
+           "GpuCache", "GpuAltKeyTier", "request_c1c2", "request_c1c2c3", "lookup_batch_c1c2", "lookup_interact_c1c2"]
