@@ -51,6 +51,7 @@ struct FusedArgs {
     int *opt_flag; int opt_id; // optimistic launch triple: offsets_arange_kernel writes opt_id here when an offsets
                                // array is not arange; then the bag-1 loop runs if it is absent, the general loop if present
     int enc_lds;               // reduced precision: feature 0 is x, every other feature a 4-byte aligned table
+    int tile_per;              // index-tile kernel: samples per block (block i owns [i * tile_per, (i + 1) * tile_per))
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -452,8 +453,12 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
 #endif
 // resident blocks per CU the register allocator is asked to fit (more VGPRs per wave where the
 // pipeline state or the decode temporaries would otherwise spill)
-template <int CODEC, int CQ, bool BAG1>
+#ifndef EVS_LB_TILE
+#define EVS_LB_TILE 4
+#endif
+template <int CODEC, int CQ, bool BAG1, bool TILE = false>
 constexpr int lds_min_blocks() {
+    if (TILE && CQ < 4) return EVS_LB_TILE;
     if (CQ >= 8) return 2;
     if (CQ >= 4) return 3;
     if (CODEC == 16) return 3;
@@ -466,8 +471,12 @@ constexpr int lds_min_blocks() {
 // u4 rows, 2-byte aligned, travel as their enclosing aligned dword window and the half-word phase
 // rides along as a wave mask).  The MFMA operands are read as raw chunks (ds_read_u16/b32/b64) and
 // decoded through the per-block LDS table (evs_common.h) -- x chunks overwrite row 0 afterwards.
-template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1>
-__global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_interact_dot_lds_kernel(const FusedArgs args) {
+// TILE (bag-1 tables): a block owns a CONTIGUOUS sample range and its 256 threads keep a
+// [F-1][16] tile of the next 16 samples' indices in LDS (one 128-byte line per table and chunk, loaded one
+// chunk ahead, two barriers per 4 iterations); the row stage reads its indices from there instead of one
+// dependent 8-byte global load per lane.
+template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1, bool TILE = false>
+__global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())) emb_interact_dot_lds_kernel(const FusedArgs args) {
     if constexpr (HAS_INDIRECT && !PTRS) {   // optimistic launch triple (see offsets_arange_kernel): the bag-1 loop runs
         if (args.opt_flag) {                   // when the offsets are arange, the general loop when they are not
             const bool ragged = *args.opt_flag == args.opt_id;
@@ -490,7 +499,9 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
     constexpr int kChunkBytes = CODEC / 2;  // 4 elements
     constexpr int NINSTR = ENC ? 1 + (NI2 + 3) / 4 : (NROWS + RPI - 1) / RPI;   // slot size in KiB
     constexpr int row_bytes = ENC ? enc_row_bytes : d * 4;
+    static_assert(!TILE || (BAG1 && HAS_INDIRECT && !PTRS && !WEIGHTED), "index tiles: plain bag-1 tables");
     __shared__ __attribute__((aligned(16))) char s_rows[4][NINSTR * 1024];
+    __shared__ int s_idx[TILE ? 2 * 512 : 1];
     __shared__ float s_lut[CodecLut<CODEC>::kEntries];
     if constexpr (ENC) {
         codec_lut_init<CODEC>(s_lut);
@@ -590,12 +601,27 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, EVS_OUT_CPOL);
         }
     };
-    const int64_t waves_total = (int64_t)gridDim.x * 4;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave_in_block;
-    if (wave_id >= B) return;
-    const int n_samples = (int)((B - wave_id + waves_total - 1) / waves_total);
     bool bad = false;
-
+    // sample n of this wave is b = wave_id + n * wave_step: strided over the grid, or (TILE) over the block's range
+    int64_t waves_total = (int64_t)gridDim.x * 4;
+    int64_t wave_id = (int64_t)blockIdx.x * 4 + wave_in_block;
+    int n_samples, k_end;
+    int64_t blk_first = 0, blk_end = 0;
+    if constexpr (TILE) {
+        const int64_t per = args.tile_per;
+        blk_first = (int64_t)blockIdx.x * per;
+        blk_end = blk_first + per < B ? blk_first + per : B;
+        if (blk_first >= blk_end) return;       // block-uniform
+        const int blk_n = (int)(blk_end - blk_first);
+        wave_id = blk_first + wave_in_block;
+        waves_total = 4;
+        n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
+        k_end = (blk_n + 3) / 4;                // every wave walks the block's iterations (barriers)
+    } else {
+        if (wave_id >= B) return;
+        n_samples = (int)((B - wave_id + waves_total - 1) / waves_total);
+        k_end = n_samples;
+    }
     int64_t off0[NR], off1[NR];
     int64_t idx_raw[NR];
     // per-feature bag facts travel through the pipeline as wave masks (SGPRs), not per-lane registers:
@@ -612,7 +638,47 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
     const bool pair_ok = !__any(short_off);
     auto sample_b = [&](int n) -> int64_t {
         const int64_t b = wave_id + (int64_t)n * waves_total;
+        if constexpr (TILE) return b < blk_end ? b : blk_end - 1;
         return b < B ? b : B - 1;
+    };
+    // TILE: thread e (and e + 256) of the block owns tile element (table e >> 4, sample-in-chunk e & 15)
+    const int64_t *tile_p[2] = {nullptr, nullptr};
+    unsigned tile_nr[2] = {0, 0};
+    int64_t tile_v[2] = {0, 0};
+    int tile_off[NR];
+    if constexpr (TILE) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = 1 + (((int)threadIdx.x + 256 * h) >> 4);
+            if (f < F) { tile_p[h] = ka->indices[f]; tile_nr[h] = (unsigned)ka->n_rows[f]; }
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int f = r16 + 16 * rr;
+            tile_off[rr] = (f >= 1 && f < F ? f - 1 : 0) * 16 + wave_in_block;
+        }
+    }
+    auto tile_load = [&](int c) {       // chunk c of the block -> registers
+        if constexpr (TILE) {
+            const int64_t bs = blk_first + 16 * (int64_t)c + (threadIdx.x & 15);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                tile_v[h] = -1;
+                if (tile_p[h] && bs < blk_end) tile_v[h] = tile_p[h][bs];
+            }
+        }
+    };
+    auto tile_store = [&](int c) {      // registers -> tile buffer c & 1 (row ids as int32, -1 = none / out of range)
+        if constexpr (TILE) {
+            const int64_t bs = blk_first + 16 * (int64_t)c + (threadIdx.x & 15);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const bool live = tile_p[h] && bs < blk_end;
+                const bool in_range = (uint64_t)tile_v[h] < (uint64_t)tile_nr[h];
+                bad |= live & !in_range;
+                s_idx[(c & 1) * 512 + (int)threadIdx.x + 256 * h] = (live & in_range) ? (int)tile_v[h] : -1;
+            }
+        }
     };
     auto issue_off = [&](int n) {
         if constexpr (HAS_INDIRECT && !BAG1) {
@@ -632,7 +698,14 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
         }
     };
     auto issue_idx = [&](int n) {
-        if constexpr (HAS_INDIRECT && BAG1) {
+        if constexpr (TILE) {
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                has2[rr] = __ballot(lf[rr].indirect);
+                more2[rr] = 0;
+                idx_raw[rr] = s_idx[((n >> 2) & 1) * 512 + tile_off[rr] + 4 * (n & 3)];
+            }
+        } else if constexpr (HAS_INDIRECT && BAG1) {
             const int b = (int)sample_b(n);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {
@@ -669,9 +742,9 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
             unsigned mult = (unsigned)b;
             bool ok = true;
             if constexpr (HAS_INDIRECT) {
-                const bool in_range = PTRS ? idx_raw[rr] != 0 : (uint64_t)idx_raw[rr] < (uint64_t)lf[rr].n_rows;
+                const bool in_range = TILE ? idx_raw[rr] >= 0 : PTRS ? idx_raw[rr] != 0 : (uint64_t)idx_raw[rr] < (uint64_t)lf[rr].n_rows;
                 const bool has = (has2[rr] >> lane) & 1;
-                if constexpr (!PTRS) bad |= lf[rr].indirect & has & !in_range;
+                if constexpr (!PTRS && !TILE) bad |= lf[rr].indirect & has & !in_range;   // (TILE: checked by tile_store)
                 ok = !lf[rr].indirect | (has & in_range);
                 mult = lf[rr].indirect ? (ok ? (unsigned)idx_raw[rr] : 0u) : mult;
                 more1[rr] = more2[rr];
@@ -731,6 +804,12 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
     };
 
     // ---- prologue ---------------------------------------------------------------------
+    if constexpr (TILE) {
+        tile_load(0);
+        tile_store(0);
+        tile_load(1);
+        __syncthreads();
+    }
     issue_off(0);
     issue_idx(0);
     issue_off(1);
@@ -738,10 +817,19 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
     issue_idx(1);
     issue_off(2);
 
-    for (int k = 0; k < n_samples; k++) {
+    for (int k = 0; k < k_end; k++) {
         const int64_t b = wave_id + (int64_t)k * waves_total;  // wave-uniform
         // rows of sample k have landed once every outstanding vector-memory op has retired
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (TILE) {
+            if ((k & 3) == 0) {   // chunk k/4 + 1 (in registers since the last turn) replaces chunk k/4 - 1
+                __syncthreads();
+                tile_store((k >> 2) + 1);
+                __syncthreads();
+                tile_load((k >> 2) + 2);
+            }
+            if (k >= n_samples) continue;
+        }
 
         float4 a[NR][NC];
         if constexpr (ENC) {
@@ -880,7 +968,7 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1>())) emb_
             }
         }
     }
-    flush_out(wave_id + (int64_t)(n_samples - 1) * waves_total);
+    if (!TILE || n_samples > 0) flush_out(wave_id + (int64_t)(n_samples - 1) * waves_total);
     if (bad) atomicOr(args.err, 1);
 }
 
@@ -927,6 +1015,36 @@ static void launch_persistent(const FusedArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(K, dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 
+// index-tile kernel: same resident grid, each block a contiguous sample range (whole 16-sample chunks when the
+// batch is large enough to keep every block busy that way)
+static int tile_mode() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_TILE"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static int64_t tile_min_batch() {
+    static int64_t v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_TILE_MIN_B"); v = e ? atoll(e) : 4096; }
+    return v;
+}
+template <auto K>
+static void launch_tile(FusedArgs a, hipStream_t st) {
+    static int per_cu = 0;
+    if (!per_cu) {
+        int n = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K, 256, 0);
+        per_cu = (e == hipSuccess && n > 0) ? n : 2;
+    }
+    const int64_t cap = (int64_t)kNumCu * per_cu;
+    int64_t per = (a.B + cap - 1) / cap;
+    static int align = 0;
+    if (!align) { const char *e = getenv("EVS_FUSED_TILE_ALIGN"); align = e ? atoi(e) : 4; if (align < 1) align = 1; }
+    per = (per + align - 1) / align * align;
+    a.tile_per = (int)per;
+    const int64_t blocks = (a.B + per - 1) / per;
+    hipLaunchKernelGGL(K, dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+
 template <int CODEC, int CQ, int REM, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS>
 static void launch_nt(const FusedArgs &a, hipStream_t st) {
     const bool nt2 = a.F > 16;
@@ -935,6 +1053,13 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
         // (offsets == NULL exists only in the LDS kernel: the developer switch cannot take that away)
         if ((use_lds_rows() || a.bag1 == 1) && (CODEC == 32 || a.enc_lds)) {
             if constexpr (HAS_INDIRECT && !WEIGHTED) {
+                if constexpr (!PTRS && CODEC == 32) {   // (encoded rows: no gain for u8 / u4, slower for u16 -- measured)
+                    if (a.bag1 == 1 && tile_mode() && a.B >= tile_min_batch()) {
+                        if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
+                        else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
+                        return;
+                    }
+                }
                 if (PTRS || a.bag1 == 1) {
                     if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
                     else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
@@ -944,7 +1069,16 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                     if (a.bag1 == 2) {   // optimistic triple: arange check, the bag-1 loop, then (below) the general loop
                         int nb = (int)((a.B * a.F + 255) / 256); if (nb > kNumCu * 4) nb = kNumCu * 4;
                         hipLaunchKernelGGL(offsets_arange_kernel, dim3(nb), dim3(256), 0, st, a);
-                        if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
+                        bool tiled = false;
+                        if constexpr (CODEC == 32) {
+                            if (tile_mode() && a.B >= tile_min_batch()) {
+                                tiled = true;
+                                if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
+                                else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
+                            }
+                        }
+                        if (tiled) {
+                        } else if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
                         else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
                     }
                 }

@@ -570,3 +570,37 @@ def test_fused_one_index_per_bag_fast_path(E):
     E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
     with pytest.raises(E.EvsError):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
+
+
+@pytest.mark.parametrize("codec,T,B,d", [(32, 26, 4096, 36), (32, 26, 5003, 36), (32, 31, 4100, 16), (32, 5, 4099, 64),
+                                         (8, 26, 5003, 36), (4, 26, 4097, 36), (16, 26, 4096, 36), (32, 26, 20000, 36)])
+def test_fused_index_tile_kernel(E, orc, codec, T, B, d):
+    """Batches of >= 4096 samples with offsets == NULL run the index-tile kernel (a block owns a contiguous sample
+    range, indices staged through LDS): same bits as the general loop, ragged last chunk, out-of-range and
+    negative indices skipped and reported like everywhere else."""
+    rs = np.random.RandomState(900 + codec + T)
+    ln = [int(rs.choice([1, 7, 300, 5000])) for _ in range(T)]
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    raws = [orc.encode_table(t, codec) for t in tabs]
+    ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, codec)
+    idx_np = np.stack([rs.randint(0, n, size=B) for n in ln]).astype(np.int64)
+    idx = torch.from_numpy(idx_np).cuda()
+    off = torch.arange(B, device="cuda").repeat(T, 1)
+    x_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    x = torch.from_numpy(x_np).cuda()
+    for itself in (False, True):
+        a = E.apply_emb_interact(x, off, idx, ev, None, itself, check_indices=True)
+        b = E.apply_emb_interact(x, off, idx, ev, None, itself, one_index_per_bag=True, check_indices=True)
+        assert torch.equal(a, b)
+    if B <= 5003:
+        ly = orc.apply_emb([np.arange(B, dtype=np.int64)] * T, list(idx_np), tabs if codec == 32 else raws, None, codec, d)
+        np.testing.assert_allclose(b.cpu().numpy(), orc.interact_features(x_np, ly, itself=True), rtol=RTOL, atol=2e-6 * max(1.0, d / 36.0))
+    idx[T - 1, B - 1] = ln[T - 1]
+    idx[0, 17] = -1
+    a = E.apply_emb_interact(x, off, idx, ev)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    b = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    assert torch.equal(a, b)
