@@ -454,8 +454,9 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
 // resident blocks per CU the register allocator is asked to fit (more VGPRs per wave where the
 // pipeline state or the decode temporaries would otherwise spill)
 #ifndef EVS_LB_TILE
-#define EVS_LB_TILE 4
+#define EVS_LB_TILE 5
 #endif
+constexpr int kTileMaxF = 28;
 template <int CODEC, int CQ, bool BAG1, bool TILE = false>
 constexpr int lds_min_blocks() {
     if (TILE && CQ < 4) return EVS_LB_TILE;
@@ -500,8 +501,14 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
     constexpr int NINSTR = ENC ? 1 + (NI2 + 3) / 4 : (NROWS + RPI - 1) / RPI;   // slot size in KiB
     constexpr int row_bytes = ENC ? enc_row_bytes : d * 4;
     static_assert(!TILE || (BAG1 && HAS_INDIRECT && !PTRS && !WEIGHTED), "index tiles: plain bag-1 tables");
-    __shared__ __attribute__((aligned(16))) char s_rows[4][NINSTR * 1024];
+    // TILE launches have F <= kTileMaxF: rows past that are never fetched (nor their products stored), and the
+    // slot KiB they would take pays for the index tile -- 5 blocks per CU stay resident
+    constexpr int kTileSlot = (kTileMaxF + RPI - 1) / RPI;
+    constexpr int NSLOT = (TILE && !ENC && kTileSlot < NINSTR) ? kTileSlot : NINSTR;
+    __shared__ __attribute__((aligned(16))) char s_rows[4][NSLOT * 1024];
     __shared__ int s_idx[TILE ? 2 * 512 : 1];
+    __shared__ const int64_t *s_tile_p[TILE ? 32 : 1];   // per table: index array / row count (kept out of the VGPRs)
+    __shared__ unsigned s_tile_nr[TILE ? 32 : 1];
     __shared__ float s_lut[CodecLut<CODEC>::kEntries];
     if constexpr (ENC) {
         codec_lut_init<CODEC>(s_lut);
@@ -544,7 +551,7 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
 
     // DMA mapping of this lane: for instruction j it moves piece dma_piece of row j*RPI + lane/LPRD
     const int dma_piece = lane % LPRD;
-    constexpr int NDMA = ENC ? 1 : NINSTR;
+    constexpr int NDMA = ENC ? 1 : NSLOT;
     int dma_src[NDMA];     // lane that holds the row address in the MFMA mapping, or -1
 #pragma unroll
     for (int j = 0; j < NDMA; j++) {
@@ -642,16 +649,15 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
         return b < B ? b : B - 1;
     };
     // TILE: thread e (and e + 256) of the block owns tile element (table e >> 4, sample-in-chunk e & 15)
-    const int64_t *tile_p[2] = {nullptr, nullptr};
-    unsigned tile_nr[2] = {0, 0};
     int64_t tile_v[2] = {0, 0};
     int tile_off[NR];
     if constexpr (TILE) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int f = 1 + (((int)threadIdx.x + 256 * h) >> 4);
-            if (f < F) { tile_p[h] = ka->indices[f]; tile_nr[h] = (unsigned)ka->n_rows[f]; }
+        if (threadIdx.x < 32) {
+            const int f = 1 + (int)threadIdx.x;
+            s_tile_p[threadIdx.x] = f < F ? ka->indices[f] : nullptr;
+            s_tile_nr[threadIdx.x] = f < F ? (unsigned)ka->n_rows[f] : 0u;
         }
+        __syncthreads();
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) {
             const int f = r16 + 16 * rr;
@@ -664,7 +670,8 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 tile_v[h] = -1;
-                if (tile_p[h] && bs < blk_end) tile_v[h] = tile_p[h][bs];
+                const int64_t *tp = s_tile_p[((int)threadIdx.x >> 4) + 16 * h];
+                if (tp && bs < blk_end) tile_v[h] = tp[bs];
             }
         }
     };
@@ -673,8 +680,8 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
             const int64_t bs = blk_first + 16 * (int64_t)c + (threadIdx.x & 15);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const bool live = tile_p[h] && bs < blk_end;
-                const bool in_range = (uint64_t)tile_v[h] < (uint64_t)tile_nr[h];
+                const bool live = s_tile_p[((int)threadIdx.x >> 4) + 16 * h] != nullptr && bs < blk_end;
+                const bool in_range = (uint64_t)tile_v[h] < (uint64_t)s_tile_nr[((int)threadIdx.x >> 4) + 16 * h];
                 bad |= live & !in_range;
                 s_idx[(c & 1) * 512 + (int)threadIdx.x + 256 * h] = (live & in_range) ? (int)tile_v[h] : -1;
             }
@@ -1054,7 +1061,7 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
         if ((use_lds_rows() || a.bag1 == 1) && (CODEC == 32 || a.enc_lds)) {
             if constexpr (HAS_INDIRECT && !WEIGHTED) {
                 if constexpr (!PTRS && CODEC == 32) {   // (encoded rows: no gain for u8 / u4, slower for u16 -- measured)
-                    if (a.bag1 == 1 && tile_mode() && a.B >= tile_min_batch()) {
+                    if (a.bag1 == 1 && tile_mode() && a.B >= tile_min_batch() && a.F <= kTileMaxF) {
                         if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                         else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                         return;
@@ -1071,7 +1078,7 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                         hipLaunchKernelGGL(offsets_arange_kernel, dim3(nb), dim3(256), 0, st, a);
                         bool tiled = false;
                         if constexpr (CODEC == 32) {
-                            if (tile_mode() && a.B >= tile_min_batch()) {
+                            if (tile_mode() && a.B >= tile_min_batch() && a.F <= kTileMaxF) {
                                 tiled = true;
                                 if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                                 else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
