@@ -457,8 +457,10 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
 #define EVS_LB_TILE 5
 #endif
 constexpr int kTileMaxF = 28;
-template <int CODEC, int CQ, bool BAG1, bool TILE = false>
+constexpr int kOptErr = 1024;   // opt_flag[kOptErr]: index errors of a CHECK launch (second half of the flag ring)
+template <int CODEC, int CQ, bool BAG1, bool TILE = false, bool CHECK = false>
 constexpr int lds_min_blocks() {
+    if (CHECK && CQ < 4) return 4;          // (the offsets tile values take 4 more VGPRs)
     if (TILE && CQ < 4) return EVS_LB_TILE;
     if (CQ >= 8) return 2;
     if (CQ >= 4) return 3;
@@ -476,11 +478,19 @@ constexpr int lds_min_blocks() {
 // [F-1][16] tile of the next 16 samples' indices in LDS (one 128-byte line per table and chunk, loaded one
 // chunk ahead, two barriers per 4 iterations); the row stage reads its indices from there instead of one
 // dependent 8-byte global load per lane.
-template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1, bool TILE = false>
-__global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())) emb_interact_dot_lds_kernel(const FusedArgs args) {
-    if constexpr (HAS_INDIRECT && !PTRS) {   // optimistic launch triple (see offsets_arange_kernel): the bag-1 loop runs
-        if (args.opt_flag) {                   // when the offsets are arange, the general loop when they are not
+// CHECK (with TILE, offsets given): the block also loads the OFFSETS tile of every chunk and compares it with
+// arange -- the bet of the optimistic launch is verified by the loop that profits from it.  A lost bet raises
+// opt_flag (the general loop, launched behind, then recomputes the whole output); index errors seen under a
+// lost bet may belong to positions no bag refers to, so they are parked in opt_flag[kOptErr] and only the
+// general kernel's early exit (bet won) turns them into the error flag.
+template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1, bool TILE = false, bool CHECK = false>
+__global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CHECK>())) emb_interact_dot_lds_kernel(const FusedArgs args) {
+    static_assert(!CHECK || TILE, "the offsets check rides on the index tiles");
+    if constexpr (HAS_INDIRECT && !PTRS && !CHECK) {   // optimistic launches (see offsets_arange_kernel): the bag-1 loop runs
+        if (args.opt_flag) {                             // when the offsets are arange, the general loop when they are not
             const bool ragged = *args.opt_flag == args.opt_id;
+            if (!BAG1 && !ragged && blockIdx.x == 0 && threadIdx.x == 0 && args.opt_flag[kOptErr] == args.opt_id)
+                atomicOr(args.err, 1);
             if (BAG1 ? ragged : !ragged) return;
         }
     }
@@ -509,6 +519,7 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
     __shared__ int s_idx[TILE ? 2 * 512 : 1];
     __shared__ const int64_t *s_tile_p[TILE ? 32 : 1];   // per table: index array / row count (kept out of the VGPRs)
     __shared__ unsigned s_tile_nr[TILE ? 32 : 1];
+    __shared__ const int64_t *s_tile_o[CHECK ? 32 : 1];  // CHECK: offsets arrays
     __shared__ float s_lut[CodecLut<CODEC>::kEntries];
     if constexpr (ENC) {
         codec_lut_init<CODEC>(s_lut);
@@ -650,12 +661,20 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
     };
     // TILE: thread e (and e + 256) of the block owns tile element (table e >> 4, sample-in-chunk e & 15)
     int64_t tile_v[2] = {0, 0};
+    int64_t tile_o[2] = {0, 0};
+    bool ragged_seen = false;
     int tile_off[NR];
     if constexpr (TILE) {
         if (threadIdx.x < 32) {
             const int f = 1 + (int)threadIdx.x;
             s_tile_p[threadIdx.x] = f < F ? ka->indices[f] : nullptr;
             s_tile_nr[threadIdx.x] = f < F ? (unsigned)ka->n_rows[f] : 0u;
+            if constexpr (CHECK) {
+                const int64_t *op = (f < F && ka->indices[f]) ? ka->offsets[f] : nullptr;
+                s_tile_o[threadIdx.x] = op;
+                // arrays of B + 1 entries: the last bag must end at B (block 0 looks)
+                if (op && blockIdx.x == 0 && ka->off_len[f] > B) ragged_seen |= op[B] != B;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -672,6 +691,10 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
                 tile_v[h] = -1;
                 const int64_t *tp = s_tile_p[((int)threadIdx.x >> 4) + 16 * h];
                 if (tp && bs < blk_end) tile_v[h] = tp[bs];
+                if constexpr (CHECK) {
+                    tile_o[h] = bs;
+                    if (tp && bs < blk_end) tile_o[h] = s_tile_o[((int)threadIdx.x >> 4) + 16 * h][bs];
+                }
             }
         }
     };
@@ -683,6 +706,7 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
                 const bool live = s_tile_p[((int)threadIdx.x >> 4) + 16 * h] != nullptr && bs < blk_end;
                 const bool in_range = (uint64_t)tile_v[h] < (uint64_t)s_tile_nr[((int)threadIdx.x >> 4) + 16 * h];
                 bad |= live & !in_range;
+                if constexpr (CHECK) ragged_seen |= tile_o[h] != bs;
                 s_idx[(c & 1) * 512 + (int)threadIdx.x + 256 * h] = (live & in_range) ? (int)tile_v[h] : -1;
             }
         }
@@ -976,7 +1000,12 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE>())
         }
     }
     if (!TILE || n_samples > 0) flush_out(wave_id + (int64_t)(n_samples - 1) * waves_total);
-    if (bad) atomicOr(args.err, 1);
+    if constexpr (CHECK) {
+        if (ragged_seen) atomicMax(args.opt_flag, args.opt_id);
+        if (bad) atomicMax(args.opt_flag + kOptErr, args.opt_id);
+    } else {
+        if (bad) atomicOr(args.err, 1);
+    }
 }
 
 // offsets[f][b] == b for every indirect feature and every bag (and offsets[f][B] == B where the array has B+1
@@ -1034,6 +1063,9 @@ static int64_t tile_min_batch() {
     if (v < 0) { const char *e = getenv("EVS_FUSED_TILE_MIN_B"); v = e ? atoll(e) : 4096; }
     return v;
 }
+static bool tile_eligible(const FusedArgs &a, int codec) {
+    return codec == 32 && tile_mode() && a.B >= tile_min_batch() && a.F <= kTileMaxF;
+}
 template <auto K>
 static void launch_tile(FusedArgs a, hipStream_t st) {
     static int per_cu = 0;
@@ -1061,7 +1093,7 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
         if ((use_lds_rows() || a.bag1 == 1) && (CODEC == 32 || a.enc_lds)) {
             if constexpr (HAS_INDIRECT && !WEIGHTED) {
                 if constexpr (!PTRS && CODEC == 32) {   // (encoded rows: no gain for u8 / u4, slower for u16 -- measured)
-                    if (a.bag1 == 1 && tile_mode() && a.B >= tile_min_batch() && a.F <= kTileMaxF) {
+                    if (a.bag1 == 1 && tile_eligible(a, CODEC)) {
                         if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                         else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                         return;
@@ -1074,15 +1106,17 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                 }
                 if constexpr (!PTRS) {
                     if (a.bag1 == 2) {   // optimistic triple: arange check, the bag-1 loop, then (below) the general loop
-                        int nb = (int)((a.B * a.F + 255) / 256); if (nb > kNumCu * 4) nb = kNumCu * 4;
-                        hipLaunchKernelGGL(offsets_arange_kernel, dim3(nb), dim3(256), 0, st, a);
                         bool tiled = false;
-                        if constexpr (CODEC == 32) {
-                            if (tile_mode() && a.B >= tile_min_batch() && a.F <= kTileMaxF) {
+                        if constexpr (CODEC == 32) {   // the index-tile loop checks the offsets itself: two launches
+                            if (tile_eligible(a, CODEC)) {
                                 tiled = true;
-                                if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
-                                else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
+                                if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
+                                else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
                             }
+                        }
+                        if (!tiled) {   // three launches: arange check, the bag-1 loop, then (below) the general loop
+                            int nb = (int)((a.B * a.F + 255) / 256); if (nb > kNumCu * 4) nb = kNumCu * 4;
+                            hipLaunchKernelGGL(offsets_arange_kernel, dim3(nb), dim3(256), 0, st, a);
                         }
                         if (tiled) {
                         } else if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
@@ -1227,8 +1261,9 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
     // both launched and the one that does not apply returns at once -- no host round trip.  Needs idx[b]
     // readable for every b (nnz >= B) and a last bag that ends at B.
     a.opt_flag = nullptr; a.opt_id = 0;
-    // (three launches: below ~8 k samples the two extra launches cost more than the faster loop returns)
-    if (indirect && !a.bag1 && !weighted && (codec == 32 || a.enc_lds) && B >= 8192 && optimistic_enabled()) {
+    // (three launches: below ~8 k samples the two extra launches cost more than the faster loop returns; with the
+    // check folded into the index-tile loop it is two launches and pays from the tile kernel's minimum batch on)
+    if (indirect && !a.bag1 && !weighted && (codec == 32 || a.enc_lds) && (B >= 8192 || tile_eligible(a, codec)) && optimistic_enabled()) {
         bool can = true;
         for (int f = 0; f < F && can; f++)
             if (feats[f].indices) can = feats[f].nnz >= B && (a.off_len[f] > B || feats[f].nnz == B);

@@ -346,8 +346,10 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
     for k in range(T):
         i, o = lS_i[k], lS_o[k]
         assert i.dtype == torch.int64 and o.dtype == torch.int64 and i.is_cuda and o.is_cuda
-        assert (i.numel() == 0 or i.stride(0) == 1) and o.stride(0) == 1 and o.numel() == B
+        # (B + 1 offsets: EmbeddingBag's include_last_offset form, the last entry ends the last bag)
+        assert (i.numel() == 0 or i.stride(0) == 1) and o.stride(0) == 1 and o.numel() in (B, B + 1)
         f = feats[k + 1]
+        f.offsets_len = int(o.numel())
         # a table nobody indexes in this batch has an EMPTY index tensor whose data_ptr() is NULL -- and NULL indices
         # mean "dense feature" in the C ABI: hand over any valid address instead (nnz = 0: never dereferenced)
         f.src, f.indices, f.offsets = ev._tables_c[k], (i.data_ptr() or o.data_ptr()), o.data_ptr()

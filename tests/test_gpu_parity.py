@@ -475,13 +475,13 @@ def test_fused_codec_26_tables_one_index_per_bag(E, orc, codec):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
-@pytest.mark.parametrize("codec", [32, 8])
-def test_fused_optimistic_offsets_pair(E, orc, codec):
+@pytest.mark.parametrize("codec,B", [(32, 8192 + 77), (8, 8192 + 77), (32, 4096 + 5), (32, 20000)])
+def test_fused_optimistic_offsets_pair(E, orc, codec, B):
     """lS_o given: the library bets on offsets == arange (bag-1 loop with the check folded in) and falls back to
     the general loop on the device when the bet is lost.  Won bet, lost bet (one offset moved, one table ragged,
     a longer last bag) and B+1-entry offsets all give the bits of the two-call path."""
     from bench import KAGGLE_LN
-    d, B = 36, 8192 + 77   # the bet is placed from 8192 samples up
+    d = 36   # the bet is placed from 8192 samples up (fp32 rows: from 4096, checked inside the index-tile loop)
     rs = np.random.RandomState(5 + codec)
     ln = [min(n, 400) for n in KAGGLE_LN]
     if codec == 32:
@@ -503,9 +503,9 @@ def test_fused_optimistic_offsets_pair(E, orc, codec):
     won = run(ar, idx)
     assert torch.equal(won, E.apply_emb_interact(x, torch.arange(B, device="cuda").repeat(26, 1), torch.from_numpy(np.stack(idx)).cuda(), ev,
                                                   one_index_per_bag=True))
-    # lost: one offset of one table moved (bag 5000 empty, bag 4999 of two)
+    # lost: one offset of one table moved (bag 4000 empty, bag 3999 of two)
     off2 = [a.copy() for a in ar]
-    off2[7][5000] = 5001
+    off2[7][4000] = 4001
     run(off2, idx)
     # lost: one table ragged (0..3 indices per bag), the others arange
     lens = rs.randint(0, 4, size=B)
@@ -518,6 +518,35 @@ def test_fused_optimistic_offsets_pair(E, orc, codec):
     idx4 = list(idx)
     idx4[3] = rs.randint(0, ln[3], size=B + 3)
     run(ar, idx4)
+    # B + 1 entries: won when the last one is B; lost when the last bag ends early -- and then an out-of-range index
+    # at the position no bag refers to is NOT an error (the bag-1 loop saw it, the verdict belongs to the general loop)
+    def run1(offs, idxs):   # include_last_offset form against the two-call path on its B-entry equivalent
+        o = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in offs]
+        i = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in idxs]
+        a = E.apply_emb_interact(x, o, i, ev, check_indices=True)
+        b = E.interact_features(x, E.apply_emb([v[:B] for v in o], [v[:int(w[B])] for v, w in zip(i, offs)], ev, None, lazy=False))
+        assert torch.equal(a, b)
+        return a
+
+    ar1 = [np.arange(B + 1) for _ in ln]
+    assert torch.equal(run1(ar1, idx), won)
+    off5 = [a.copy() for a in ar1]
+    off5[2][B] = B - 1
+    idx5 = [a.copy() for a in idx]
+    idx5[2][B - 1] = ln[2] + 9
+    run1(off5, idx5)
+    # won bet, out-of-range index: reported (and the row skipped) exactly like the two-call path
+    idx6 = [a.copy() for a in idx]
+    idx6[25][B - 2] = ln[25]
+    o = [torch.from_numpy(v.astype(np.int64)).cuda() for v in ar]
+    i = [torch.from_numpy(v.astype(np.int64)).cuda() for v in idx6]
+    a = E.apply_emb_interact(x, o, i, ev)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    b = E.interact_features(x, E.apply_emb(o, i, ev, None, lazy=False))
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    assert torch.equal(a, b)
 
 
 def test_sharded_hip_backend_two_virtual_ranks(E, orc):
