@@ -403,7 +403,7 @@ def main():
                                % (d, args.dist),
                    "batch_per_gpu": B, "global_batch": B, "tables": T, "dim": d, "parallelism": "single"},
         "p50_batch_latency_ms": float(np.percentile(lat, 50)), "p95_batch_latency_ms": float(np.percentile(lat, 95)),
-        "roofline": {"bound": "hbm", "kernel": "emb_interact_dot_lds_kernel<32,2,1,2,false,true,false,true,true>", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "emb_interact_dot_lds_kernel<32,2,1,2,false,true,false,true,true,false>", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "bytes_per_launch": kernel_bytes, "avg_launch_ms": kernel_ms},
         "general_offsets_path": {"value": lookups * args.steps / dtg, "unit": "lookups/s",

@@ -47,7 +47,8 @@ struct FusedArgs {
     const float *dummy_f32;
     const void *zeros;         // >= 1 KiB of zero bytes (idle lanes / empty bags read rows from it)
     int bag1;                  // 1: every indirect feature has one index per bag, no offsets array;
-                               // 2: offsets ARE given and the launch bets they are arange (see opt_flag)
+                               // 2: offsets ARE given and the launch bets they are arange (see opt_flag);
+                               // 3: the same bet, checked inside the index-tile loop
     int *opt_flag; int opt_id; // optimistic launch triple: offsets_arange_kernel writes opt_id here when an offsets
                                // array is not arange; then the bag-1 loop runs if it is absent, the general loop if present
     int enc_lds;               // reduced precision: feature 0 is x, every other feature a 4-byte aligned table
@@ -1105,18 +1106,22 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                     return;
                 }
                 if constexpr (!PTRS) {
+                    if constexpr (CODEC == 32) {
+                        if (a.bag1 == 3) {   // optimistic pair: the index-tile loop checks the offsets itself, then the general loop
+                            if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
+                            else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
+                        }
+                    }
                     if (a.bag1 == 2) {   // optimistic triple: arange check, the bag-1 loop, then (below) the general loop
+                        int nb = (int)((a.B * a.F + 255) / 256); if (nb > kNumCu * 4) nb = kNumCu * 4;
+                        hipLaunchKernelGGL(offsets_arange_kernel, dim3(nb), dim3(256), 0, st, a);
                         bool tiled = false;
-                        if constexpr (CODEC == 32) {   // the index-tile loop checks the offsets itself: two launches
+                        if constexpr (CODEC == 32) {
                             if (tile_eligible(a, CODEC)) {
                                 tiled = true;
-                                if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
-                                else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
+                                if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
+                                else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                             }
-                        }
-                        if (!tiled) {   // three launches: arange check, the bag-1 loop, then (below) the general loop
-                            int nb = (int)((a.B * a.F + 255) / 256); if (nb > kNumCu * 4) nb = kNumCu * 4;
-                            hipLaunchKernelGGL(offsets_arange_kernel, dim3(nb), dim3(256), 0, st, a);
                         }
                         if (tiled) {
                         } else if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
@@ -1263,14 +1268,21 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
     a.opt_flag = nullptr; a.opt_id = 0;
     // (three launches: below ~8 k samples the two extra launches cost more than the faster loop returns; with the
     // check folded into the index-tile loop it is two launches and pays from the tile kernel's minimum batch on)
+    // The folded check pays a whole wasted launch when the bet is lost, so it is placed only on whole batches
+    // (nnz == B, B or B + 1 offsets); batch SLICES of longer arrays (offsets_len > B + 1: their offsets do not start at
+    // 0 unless the slice does) keep the cheap separate check.
     if (indirect && !a.bag1 && !weighted && (codec == 32 || a.enc_lds) && (B >= 8192 || tile_eligible(a, codec)) && optimistic_enabled()) {
-        bool can = true;
+        bool can = true, whole = true;
         for (int f = 0; f < F && can; f++)
-            if (feats[f].indices) can = feats[f].nnz >= B && (a.off_len[f] > B || feats[f].nnz == B);
-        if (can) {
+            if (feats[f].indices) {
+                can = feats[f].nnz >= B && (a.off_len[f] > B || feats[f].nnz == B);
+                whole = whole && feats[f].nnz == B && a.off_len[f] <= B + 1;
+            }
+        const bool pair = whole && tile_eligible(a, codec);
+        if (can && (pair || B >= 8192)) {
             a.opt_flag = optimistic_slot(&a.opt_id);
             if (!a.opt_flag) return EVS_EHIP;
-            a.bag1 = 2;
+            a.bag1 = pair ? 3 : 2;
         }
     }
     bool ok;

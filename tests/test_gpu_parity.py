@@ -633,3 +633,26 @@ def test_fused_index_tile_kernel(E, orc, codec, T, B, d):
     with pytest.raises(E.EvsError):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
     assert torch.equal(a, b)
+
+
+def test_fused_offsets_bet_on_batch_slices(E):
+    """Batch slices of longer offsets arrays (the sharded op's replicated tables: offsets + b0, offsets_len = Bg - b0)
+    with arange offsets: slice 0 wins the bet, the later slices (their offsets start at b0) lose it on the device and
+    the last one (B entries, nnz = Bg) places none -- every slice equals its rows of the whole-batch result."""
+    from evstore_dlrm_amd import sharded
+    d, T, Bl, world = 36, 26, 8200, 3
+    Bg = Bl * world
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ln = [int(n) for n in torch.randint(1, 3000, (T,)).tolist()]
+    ev = E.EVTables.from_fp32([torch.rand(n, d) * 2 - 1 for n in ln])
+    idx = [torch.randint(0, n, (Bg,), device="cuda", generator=g) for n in ln]
+    off = [torch.arange(Bg, device="cuda") for _ in ln]
+    x = torch.rand(Bg, d, device="cuda") * 2 - 1
+    want = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
+    be = sharded.HipBackend(torch.device("cuda"))
+    for r in range(world):
+        b0 = r * Bl
+        specs = [("indirect", k, idx[k], off[k][b0:], Bg, Bg - b0) for k in range(T)]
+        R = be.interact_mixed(x[b0:b0 + Bl], specs, ev, d, False)
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+        assert torch.equal(R, want[b0:b0 + Bl]), r

@@ -14,6 +14,6 @@ for set in \
   i=$((i+1))
   timeout 240 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-cache-tier > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
 done
-python3 $ROOT/tools/pmc_summary.py $OUT "lds_kernel<32, 2, 1, 2, false, true, false, true, true>" > $OUT/sq_summary.txt
+python3 $ROOT/tools/pmc_summary.py $OUT "lds_kernel<32, 2, 1, 2, false, true, false, true, true, false>" > $OUT/sq_summary.txt
 find $OUT -name "*.csv" -size +2M -delete
 cat $OUT/sq_summary.txt
