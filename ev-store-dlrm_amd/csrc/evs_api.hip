@@ -70,8 +70,7 @@ int *optimistic_slot(int *id_out) {
     std::lock_guard<std::mutex> lk(mu);
     if (!rings[dev]) {
         void *p = nullptr;
-        // (second half: the parked index-error flags of launches that check the offsets themselves)
-        if (hipMalloc(&p, 2048 * sizeof(int)) != hipSuccess || hipMemset(p, 0, 2048 * sizeof(int)) != hipSuccess) {
+        if (hipMalloc(&p, 1024 * sizeof(int)) != hipSuccess || hipMemset(p, 0, 1024 * sizeof(int)) != hipSuccess) {
             set_error("hipMalloc of the optimistic-launch flags failed");
             return nullptr;
         }

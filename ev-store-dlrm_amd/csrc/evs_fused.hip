@@ -48,7 +48,7 @@ struct FusedArgs {
     const void *zeros;         // >= 1 KiB of zero bytes (idle lanes / empty bags read rows from it)
     int bag1;                  // 1: every indirect feature has one index per bag, no offsets array;
                                // 2: offsets ARE given and the launch bets they are arange (see opt_flag);
-                               // 3: the same bet, checked inside the index-tile loop
+                               // 3: offsets given, whole batch: the index-tile loop checks them chunk by chunk itself
     int *opt_flag; int opt_id; // optimistic launch triple: offsets_arange_kernel writes opt_id here when an offsets
                                // array is not arange; then the bag-1 loop runs if it is absent, the general loop if present
     int enc_lds;               // reduced precision: feature 0 is x, every other feature a 4-byte aligned table
@@ -458,7 +458,6 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
 #define EVS_LB_TILE 5
 #endif
 constexpr int kTileMaxF = 28;
-constexpr int kOptErr = 1024;   // opt_flag[kOptErr]: index errors of a CHECK launch (second half of the flag ring)
 template <int CODEC, int CQ, bool BAG1, bool TILE = false, bool CHECK = false>
 constexpr int lds_min_blocks() {
     if (CHECK && CQ < 4) return 4;          // (the offsets tile values take 4 more VGPRs)
@@ -479,19 +478,19 @@ constexpr int lds_min_blocks() {
 // [F-1][16] tile of the next 16 samples' indices in LDS (one 128-byte line per table and chunk, loaded one
 // chunk ahead, two barriers per 4 iterations); the row stage reads its indices from there instead of one
 // dependent 8-byte global load per lane.
-// CHECK (with TILE, offsets given): the block also loads the OFFSETS tile of every chunk and compares it with
-// arange -- the bet of the optimistic launch is verified by the loop that profits from it.  A lost bet raises
-// opt_flag (the general loop, launched behind, then recomputes the whole output); index errors seen under a
-// lost bet may belong to positions no bag refers to, so they are parked in opt_flag[kOptErr] and only the
-// general kernel's early exit (bet won) turns them into the error flag.
+// CHECK (with TILE, offsets given, whole batches: nnz == B): the block also loads the OFFSETS of every chunk and
+// checks that each of its bags is exactly {idx[b]} (offsets[b] == b and the bag ends at b + 1).  The verdict is
+// per chunk and block-wide (__syncthreads_or at the barrier the tile needs anyway); a block's results depend on
+// its own bags only, so a chunk that fails the check sends THAT block -- from that chunk on -- into a slow
+// in-kernel loop that pools its bags straight from global memory (general semantics: empty bags, several
+// indices, bad offsets / indices skipped and flagged) and feeds the same MFMA + output code.  No flag, no second
+// launch; the index errors a failed chunk's tile saw are dropped (they may sit at positions no bag refers to).
 template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1, bool TILE = false, bool CHECK = false>
 __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CHECK>())) emb_interact_dot_lds_kernel(const FusedArgs args) {
     static_assert(!CHECK || TILE, "the offsets check rides on the index tiles");
     if constexpr (HAS_INDIRECT && !PTRS && !CHECK) {   // optimistic launches (see offsets_arange_kernel): the bag-1 loop runs
         if (args.opt_flag) {                             // when the offsets are arange, the general loop when they are not
             const bool ragged = *args.opt_flag == args.opt_id;
-            if (!BAG1 && !ragged && blockIdx.x == 0 && threadIdx.x == 0 && args.opt_flag[kOptErr] == args.opt_id)
-                atomicOr(args.err, 1);
             if (BAG1 ? ragged : !ragged) return;
         }
     }
@@ -520,7 +519,8 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
     __shared__ int s_idx[TILE ? 2 * 512 : 1];
     __shared__ const int64_t *s_tile_p[TILE ? 32 : 1];   // per table: index array / row count (kept out of the VGPRs)
     __shared__ unsigned s_tile_nr[TILE ? 32 : 1];
-    __shared__ const int64_t *s_tile_o[CHECK ? 32 : 1];  // CHECK: offsets arrays
+    __shared__ const int64_t *s_tile_o[CHECK ? 32 : 1];  // CHECK: offsets arrays, their readable entries
+    __shared__ int s_tile_ol[CHECK ? 32 : 1];
     __shared__ float s_lut[CodecLut<CODEC>::kEntries];
     if constexpr (ENC) {
         codec_lut_init<CODEC>(s_lut);
@@ -662,8 +662,9 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
     };
     // TILE: thread e (and e + 256) of the block owns tile element (table e >> 4, sample-in-chunk e & 15)
     int64_t tile_v[2] = {0, 0};
-    int64_t tile_o[2] = {0, 0};
-    bool ragged_seen = false;
+    int64_t tile_o[2] = {0, 0}, tile_e[2] = {0, 0};
+    bool ragged_seen = false, bad_tile = false;
+    int fallback_from = 0x7fffffff;   // CHECK: first iteration (of every wave of the block) that runs the slow loop
     int tile_off[NR];
     if constexpr (TILE) {
         if (threadIdx.x < 32) {
@@ -671,10 +672,8 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
             s_tile_p[threadIdx.x] = f < F ? ka->indices[f] : nullptr;
             s_tile_nr[threadIdx.x] = f < F ? (unsigned)ka->n_rows[f] : 0u;
             if constexpr (CHECK) {
-                const int64_t *op = (f < F && ka->indices[f]) ? ka->offsets[f] : nullptr;
-                s_tile_o[threadIdx.x] = op;
-                // arrays of B + 1 entries: the last bag must end at B (block 0 looks)
-                if (op && blockIdx.x == 0 && ka->off_len[f] > B) ragged_seen |= op[B] != B;
+                s_tile_o[threadIdx.x] = (f < F && ka->indices[f]) ? ka->offsets[f] : nullptr;
+                s_tile_ol[threadIdx.x] = f < F ? (int)ka->off_len[f] : 0;
             }
         }
         __syncthreads();
@@ -692,9 +691,13 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
                 tile_v[h] = -1;
                 const int64_t *tp = s_tile_p[((int)threadIdx.x >> 4) + 16 * h];
                 if (tp && bs < blk_end) tile_v[h] = tp[bs];
-                if constexpr (CHECK) {
-                    tile_o[h] = bs;
-                    if (tp && bs < blk_end) tile_o[h] = s_tile_o[((int)threadIdx.x >> 4) + 16 * h][bs];
+                if constexpr (CHECK) {   // start and end of bag bs (the last bag of a B-entry array ends at nnz == B)
+                    tile_o[h] = bs; tile_e[h] = bs + 1;
+                    if (tp && bs < blk_end) {
+                        const int64_t *op = s_tile_o[((int)threadIdx.x >> 4) + 16 * h];
+                        tile_o[h] = op[bs];
+                        if (bs + 1 < s_tile_ol[((int)threadIdx.x >> 4) + 16 * h]) tile_e[h] = op[bs + 1];
+                    }
                 }
             }
         }
@@ -706,8 +709,12 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
             for (int h = 0; h < 2; h++) {
                 const bool live = s_tile_p[((int)threadIdx.x >> 4) + 16 * h] != nullptr && bs < blk_end;
                 const bool in_range = (uint64_t)tile_v[h] < (uint64_t)s_tile_nr[((int)threadIdx.x >> 4) + 16 * h];
-                bad |= live & !in_range;
-                if constexpr (CHECK) ragged_seen |= tile_o[h] != bs;
+                if constexpr (CHECK) {
+                    bad_tile |= live & !in_range;
+                    ragged_seen |= (tile_o[h] != bs) | (tile_e[h] != bs + 1);
+                } else {
+                    bad |= live & !in_range;
+                }
                 s_idx[(c & 1) * 512 + (int)threadIdx.x + 256 * h] = (live & in_range) ? (int)tile_v[h] : -1;
             }
         }
@@ -835,17 +842,65 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
         }
     };
 
+    // the interaction of one sample (operands in the MFMA layout) and the staging of its output row
+    auto interact = [&](const float4 (&a)[NR][NC], f32x4 &c00, f32x4 &c10, f32x4 &c11) {
+        c00 = f32x4{0.f, 0.f, 0.f, 0.f}; c10 = f32x4{0.f, 0.f, 0.f, 0.f}; c11 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float e0[4] = {a[0][c].x, a[0][c].y, a[0][c].z, a[0][c].w};
+            const float e1[4] = {a[NR - 1][c].x, a[NR - 1][c].y, a[NR - 1][c].z, a[NR - 1][c].w};
+            if (c < CQ) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[e], e0[e], c00, 0, 0, 0);
+                    if constexpr (NT == 2) {
+                        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e0[e], c10, 0, 0, 0);
+                        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e1[e], c11, 0, 0, 0);
+                    }
+                }
+            } else {
+                const float s0 = q == 0 ? e0[0] : q == 1 ? e0[1] : q == 2 ? e0[2] : e0[3];
+                const float s1 = q == 0 ? e1[0] : q == 1 ? e1[1] : q == 2 ? e1[2] : e1[3];
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, s0, c00, 0, 0, 0);
+                if constexpr (NT == 2) {
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s0, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s1, c11, 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto stage_row = [&](const float (&xv)[(d + 63) / 64], const f32x4 &c00, const f32x4 &c10, const f32x4 &c11) {
+        // stage the output row: x passthrough, then the packed lower triangle straight from the accumulators
+#pragma unroll
+        for (int h = 0; h < (d + 63) / 64; h++) {
+            const int e = lane + 64 * h;
+            my_out[e < d ? e : OUT_MAX + r16] = xv[h];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00[v]) = c00[v];
+            if constexpr (NT == 2) {
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10[v]) = c10[v];
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11[v]) = c11[v];
+            }
+        }
+    };
     // ---- prologue ---------------------------------------------------------------------
     if constexpr (TILE) {
         tile_load(0);
         tile_store(0);
         tile_load(1);
-        __syncthreads();
+        if constexpr (CHECK) {
+            if (__syncthreads_or(ragged_seen)) fallback_from = 0; else bad |= bad_tile;
+            ragged_seen = false; bad_tile = false;
+        } else {
+            __syncthreads();
+        }
     }
     issue_off(0);
     issue_idx(0);
     issue_off(1);
-    issue_rows(0);
+    if (!CHECK || fallback_from > 0) issue_rows(0);
     issue_idx(1);
     issue_off(2);
 
@@ -853,12 +908,21 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
         const int64_t b = wave_id + (int64_t)k * waves_total;  // wave-uniform
         // rows of sample k have landed once every outstanding vector-memory op has retired
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (CHECK) {
+            if (k >= fallback_from) break;   // block-uniform: the rest of this block's samples take the slow loop below
+        }
         if constexpr (TILE) {
             if ((k & 3) == 0) {   // chunk k/4 + 1 (in registers since the last turn) replaces chunk k/4 - 1
                 __syncthreads();
                 tile_store((k >> 2) + 1);
-                __syncthreads();
-                tile_load((k >> 2) + 2);
+                if constexpr (CHECK) {   // (block-uniform: every wave leaves the tile protocol at the same iteration)
+                    if (__syncthreads_or(ragged_seen)) fallback_from = k + 4; else bad |= bad_tile;
+                    ragged_seen = false; bad_tile = false;
+                    if (fallback_from == 0x7fffffff) tile_load((k >> 2) + 2);
+                } else {
+                    __syncthreads();
+                    tile_load((k >> 2) + 2);
+                }
             }
             if (k >= n_samples) continue;
         }
@@ -909,7 +973,7 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (k > 0) flush_out(b - waves_total);   // sample k-1 leaves while sample k+1 arrives
-        if (k + 1 < n_samples) issue_rows(k + 1);
+        if (k + 1 < n_samples && (!CHECK || k + 1 < fallback_from)) issue_rows(k + 1);
         issue_idx(k + 2);
         issue_off(k + 3);
         if constexpr (WEIGHTED) {
@@ -956,57 +1020,82 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
         if (a[0][0].x == 123.456f) args.R[b] = xv[0];
         continue;
 #endif
-        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const float e0[4] = {a[0][c].x, a[0][c].y, a[0][c].z, a[0][c].w};
-            const float e1[4] = {a[NR - 1][c].x, a[NR - 1][c].y, a[NR - 1][c].z, a[NR - 1][c].w};
-            if (c < CQ) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[e], e0[e], c00, 0, 0, 0);
-                    if constexpr (NT == 2) {
-                        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e0[e], c10, 0, 0, 0);
-                        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e1[e], c11, 0, 0, 0);
-                    }
-                }
-            } else {
-                const float s0 = q == 0 ? e0[0] : q == 1 ? e0[1] : q == 2 ? e0[2] : e0[3];
-                const float s1 = q == 0 ? e1[0] : q == 1 ? e1[1] : q == 2 ? e1[2] : e1[3];
-                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, s0, c00, 0, 0, 0);
-                if constexpr (NT == 2) {
-                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s0, c10, 0, 0, 0);
-                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s1, c11, 0, 0, 0);
-                }
-            }
-        }
+        f32x4 c00, c10, c11;
+        interact(a, c00, c10, c11);
 #ifdef EVS_X_NOSTORE  // developer A/B (tools/variants.sh): everything but the output traffic
         if (c00[0] + c10[1] + c11[2] + c00[3] + c10[0] + c11[1] + c00[2] + c10[3] + c11[0] + c00[1] + c10[2] + c11[3] == 123.456f)
             args.R[b * (int64_t)out_row + lane] = xv[0];
         continue;
 #endif
-        // stage the output row: x passthrough, then the packed lower triangle straight from the accumulators
-#pragma unroll
-        for (int h = 0; h < (d + 63) / 64; h++) {
-            const int e = lane + 64 * h;
-            my_out[e < d ? e : OUT_MAX + r16] = xv[h];
-        }
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00[v]) = c00[v];
-            if constexpr (NT == 2) {
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10[v]) = c10[v];
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11[v]) = c11[v];
-            }
-        }
+        stage_row(xv, c00, c10, c11);
     }
-    if (!TILE || n_samples > 0) flush_out(wave_id + (int64_t)(n_samples - 1) * waves_total);
     if constexpr (CHECK) {
-        if (ragged_seen) atomicMax(args.opt_flag, args.opt_id);
-        if (bad) atomicMax(args.opt_flag + kOptErr, args.opt_id);
+        const int n_fast = n_samples < fallback_from ? n_samples : fallback_from;
+        if (n_fast > 0) flush_out(wave_id + (int64_t)(n_fast - 1) * waves_total);
+        // slow loop (rare): pool this lane's feature of sample b straight from global memory, general bag semantics
+        for (int k = fallback_from; k < n_samples; k++) {
+            const int64_t b = wave_id + (int64_t)k * waves_total;
+            float4 a[NR][NC];
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) {
+                    const int f = r16 + 16 * rr;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) a[rr][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (f >= F) continue;
+                    // byte offset of chunk c inside a row: this lane's k-slot chunks, then the shared remainder chunks
+                    auto chunk_at = [&](const char *row, int c) -> float4 {
+                        return *reinterpret_cast<const float4 *>(row + (c < CQ ? (q * CQ + c) * 16 : kRemOff + (c - CQ) * 16));
+                    };
+                    const int64_t *ip = ka->indices[f];
+                    const char *src = reinterpret_cast<const char *>(ka->src[f]);
+                    if (!ip) {
+                        const char *row = src + (uint64_t)b * (uint64_t)(ka->stride[f] * 4);
+#pragma unroll
+                        for (int c = 0; c < NC; c++) a[rr][c] = chunk_at(row, c);
+                        continue;
+                    }
+                    const int64_t *op = ka->offsets[f];
+                    const int64_t nnz = ka->nnz[f];
+                    int64_t s0 = op[b];
+                    int64_t e0 = (b + 1 < ka->off_len[f]) ? op[b + 1] : nnz;
+                    if (!((s0 >= 0) & (e0 >= s0) & (e0 <= nnz))) { bad = true; s0 = e0 = 0; }
+                    const uint64_t n_rows = (uint64_t)ka->n_rows[f];
+                    for (int64_t j = s0; j < e0; j++) {
+                        const int64_t r = ip[j];
+                        if ((uint64_t)r >= n_rows) { bad = true; continue; }   // skipped; a skipped FIRST row counts as zeros
+                        const char *row = src + (uint64_t)r * (uint64_t)row_bytes;
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            const float4 t = chunk_at(row, c);
+                            if (j == s0) { a[rr][c] = t; continue; }
+                            a[rr][c].x = __fadd_rn(a[rr][c].x, t.x); a[rr][c].y = __fadd_rn(a[rr][c].y, t.y);
+                            a[rr][c].z = __fadd_rn(a[rr][c].z, t.z); a[rr][c].w = __fadd_rn(a[rr][c].w, t.w);
+                        }
+                    }
+                }
+                if (r16 == 0) {   // x (row 0 of the slot) is read back below for the passthrough columns
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                        if (c < CQ || q == 0)
+                            *reinterpret_cast<float4 *>(my_lds + (c < CQ ? (q * CQ + c) * 16 : kRemOff + (c - CQ) * 16)) = a[0][c];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float xv[(d + 63) / 64];
+#pragma unroll
+            for (int h = 0; h < (d + 63) / 64; h++) {
+                const int e = lane + 64 * h;
+                xv[h] = reinterpret_cast<const float *>(my_lds)[e < d ? e : 0];
+            }
+            f32x4 c00, c10, c11;
+            interact(a, c00, c10, c11);
+            stage_row(xv, c00, c10, c11);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            flush_out(b);
+        }
     } else {
-        if (bad) atomicOr(args.err, 1);
+        if (!TILE || n_samples > 0) flush_out(wave_id + (int64_t)(n_samples - 1) * waves_total);
     }
+    if (bad) atomicOr(args.err, 1);
 }
 
 // offsets[f][b] == b for every indirect feature and every bag (and offsets[f][B] == B where the array has B+1
@@ -1107,9 +1196,10 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                 }
                 if constexpr (!PTRS) {
                     if constexpr (CODEC == 32) {
-                        if (a.bag1 == 3) {   // optimistic pair: the index-tile loop checks the offsets itself, then the general loop
+                        if (a.bag1 == 3) {   // the index-tile loop checks the offsets itself and pools failing chunks the slow way
                             if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
                             else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
+                            return;
                         }
                     }
                     if (a.bag1 == 2) {   // optimistic triple: arange check, the bag-1 loop, then (below) the general loop
@@ -1266,11 +1356,11 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
     // both launched and the one that does not apply returns at once -- no host round trip.  Needs idx[b]
     // readable for every b (nnz >= B) and a last bag that ends at B.
     a.opt_flag = nullptr; a.opt_id = 0;
-    // (three launches: below ~8 k samples the two extra launches cost more than the faster loop returns; with the
-    // check folded into the index-tile loop it is two launches and pays from the tile kernel's minimum batch on)
-    // The folded check pays a whole wasted launch when the bet is lost, so it is placed only on whole batches
-    // (nnz == B, B or B + 1 offsets); batch SLICES of longer arrays (offsets_len > B + 1: their offsets do not start at
-    // 0 unless the slice does) keep the cheap separate check.
+    // (three launches: below ~8 k samples the two extra launches cost more than the faster loop returns.)
+    // Whole fp32 batches (every table nnz == B, B or B + 1 offsets) from the tile kernel's minimum batch on need no bet
+    // at all: ONE launch of the index-tile loop that checks its own bags and pools the chunks that fail the slow way
+    // (bag1 = 3).  Batch SLICES of longer arrays (offsets_len > B + 1: their offsets do not start at 0 unless the
+    // slice does) keep the separate check.
     if (indirect && !a.bag1 && !weighted && (codec == 32 || a.enc_lds) && (B >= 8192 || tile_eligible(a, codec)) && optimistic_enabled()) {
         bool can = true, whole = true;
         for (int f = 0; f < F && can; f++)
@@ -1278,11 +1368,12 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
                 can = feats[f].nnz >= B && (a.off_len[f] > B || feats[f].nnz == B);
                 whole = whole && feats[f].nnz == B && a.off_len[f] <= B + 1;
             }
-        const bool pair = whole && tile_eligible(a, codec);
-        if (can && (pair || B >= 8192)) {
+        if (can && whole && tile_eligible(a, codec)) {
+            a.bag1 = 3;
+        } else if (can && B >= 8192) {
             a.opt_flag = optimistic_slot(&a.opt_id);
             if (!a.opt_flag) return EVS_EHIP;
-            a.bag1 = pair ? 3 : 2;
+            a.bag1 = 2;
         }
     }
     bool ok;

@@ -498,6 +498,14 @@ def test_fused_optimistic_offsets_pair(E, orc, codec, B):
         assert torch.equal(a, b)
         return a
 
+    def run1(offs, idxs):   # include_last_offset form against the two-call path on its B-entry equivalent
+        o = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in offs]
+        i = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in idxs]
+        a = E.apply_emb_interact(x, o, i, ev, check_indices=True)
+        b = E.interact_features(x, E.apply_emb([v[:B] for v in o], [v[:int(w[B])] for v, w in zip(i, offs)], ev, None, lazy=False))
+        assert torch.equal(a, b)
+        return a
+
     idx = [rs.randint(0, n, size=B) for n in ln]
     ar = [np.arange(B) for _ in ln]
     won = run(ar, idx)
@@ -514,20 +522,40 @@ def test_fused_optimistic_offsets_pair(E, orc, codec, B):
     off3[11] = np.concatenate([[0], np.cumsum(lens)[:-1]])
     idx3[11] = rs.randint(0, ln[11], size=int(lens.sum()) + 5)
     run(off3, idx3)
+    # lost in many places, nnz still == B: units moved between random bags of a few tables (empty bags, bags of 2-4,
+    # in first / middle / last chunks of blocks) -- the blocks that see them pool those chunks the slow way
+    off6 = [a.copy() for a in ar]
+    for k in (0, 5, 25):
+        lens6 = np.ones(B, dtype=np.int64)
+        for _ in range(40 if k else 3):
+            src_b, dst_b = rs.randint(0, B, size=2)
+            if lens6[src_b] > 0:
+                lens6[src_b] -= 1
+                lens6[dst_b] += 1
+        if k == 25:
+            lens6[B - 1] += lens6[0]; lens6[0] = 0      # first bag empty, last bag longer
+        assert lens6.sum() == B
+        off6[k] = np.concatenate([[0], np.cumsum(lens6)[:-1]])
+    run(off6, idx)
+    run1([np.concatenate([o, [B]]) for o in off6], idx)
+    # offsets that go backwards (bag 70 of table 4 would end before it starts): flagged, the bag pools nothing
+    off7 = [a.copy() for a in ar]
+    off7[4][71] = 60
+    o = [torch.from_numpy(v.astype(np.int64)).cuda() for v in off7]
+    i = [torch.from_numpy(v.astype(np.int64)).cuda() for v in idx]
+    a7 = E.apply_emb_interact(x, o, i, ev)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    b7 = E.interact_features(x, E.apply_emb(o, i, ev, None, lazy=False))
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    assert torch.equal(a7, b7)
     # arange offsets but a longer last bag (nnz = B + 3): not eligible for the bet
     idx4 = list(idx)
     idx4[3] = rs.randint(0, ln[3], size=B + 3)
     run(ar, idx4)
     # B + 1 entries: won when the last one is B; lost when the last bag ends early -- and then an out-of-range index
     # at the position no bag refers to is NOT an error (the bag-1 loop saw it, the verdict belongs to the general loop)
-    def run1(offs, idxs):   # include_last_offset form against the two-call path on its B-entry equivalent
-        o = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in offs]
-        i = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in idxs]
-        a = E.apply_emb_interact(x, o, i, ev, check_indices=True)
-        b = E.interact_features(x, E.apply_emb([v[:B] for v in o], [v[:int(w[B])] for v, w in zip(i, offs)], ev, None, lazy=False))
-        assert torch.equal(a, b)
-        return a
-
     ar1 = [np.arange(B + 1) for _ in ln]
     assert torch.equal(run1(ar1, idx), won)
     off5 = [a.copy() for a in ar1]

@@ -20,7 +20,7 @@ def one_case(rs, case):
     B = int(rs.choice([1, 2, 3, 4, 5, 63, 64, 65, 257, 1000, 4099, 9000]))
     codec = int(rs.choice([32, 32, 16, 8, 4]))
     itself = bool(rs.randint(0, 2))
-    mode = rs.choice(["arange", "ragged", "ragged", "empty-heavy"])
+    mode = rs.choice(["arange", "ragged", "ragged", "empty-heavy", "moved"])
     weighted = codec == 32 and rs.randint(0, 4) == 0 and mode != "arange"
     ln = [int(rs.choice([1, 2, 3, 17, 300, 5000])) for _ in range(T)]
     tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
@@ -28,6 +28,13 @@ def one_case(rs, case):
     ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, codec)
     if mode == "arange":
         lens = np.ones((T, B), dtype=np.int64)
+    elif mode == "moved":      # nnz == B, a few units moved between bags: the in-kernel offsets check and its slow loop
+        lens = np.ones((T, B), dtype=np.int64)
+        for _ in range(int(rs.choice([1, 3, 40]))):
+            k, src_b, dst_b = rs.randint(0, T), rs.randint(0, B), rs.randint(0, B)
+            if lens[k, src_b] > 0:
+                lens[k, src_b] -= 1
+                lens[k, dst_b] += 1
     elif mode == "ragged":
         lens = rs.randint(0, 4, size=(T, B))
     else:
