@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
 constexpr int kTileMaxF = 28;
 template <int CODEC, int CQ, bool BAG1, bool TILE = false, bool CHECK = false>
 constexpr int lds_min_blocks() {
-    if (CHECK && CQ < 4) return 4;          // (the offsets tile values take 4 more VGPRs)
+    if (CHECK && CQ < 4) return 4;          // (bag starts / ends in flight + the slow loop: 110 VGPRs at d = 36)
     if (TILE && CQ < 4) return EVS_LB_TILE;
     if (CQ >= 8) return 2;
     if (CQ >= 4) return 3;
@@ -487,7 +487,7 @@ constexpr int lds_min_blocks() {
 // launch; the index errors a failed chunk's tile saw are dropped (they may sit at positions no bag refers to).
 template <int CODEC, int CQ, int REM, int NT, bool WEIGHTED, bool HAS_INDIRECT, bool PTRS, bool BAG1, bool TILE = false, bool CHECK = false>
 __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CHECK>())) emb_interact_dot_lds_kernel(const FusedArgs args) {
-    static_assert(!CHECK || TILE, "the offsets check rides on the index tiles");
+    static_assert(!CHECK || (TILE && CODEC == 32), "the offsets check rides on the index tiles; its slow loop pools fp32 rows");
     if constexpr (HAS_INDIRECT && !PTRS && !CHECK) {   // optimistic launches (see offsets_arange_kernel): the bag-1 loop runs
         if (args.opt_flag) {                             // when the offsets are arange, the general loop when they are not
             const bool ragged = *args.opt_flag == args.opt_id;
