@@ -1150,7 +1150,7 @@ static int tile_mode() {
 }
 static int64_t tile_min_batch() {
     static int64_t v = -1;
-    if (v < 0) { const char *e = getenv("EVS_FUSED_TILE_MIN_B"); v = e ? atoll(e) : 4096; }
+    if (v < 0) { const char *e = getenv("EVS_FUSED_TILE_MIN_B"); v = e ? atoll(e) : 2048; }   // (below: one chunk per block at most, nothing to win)
     return v;
 }
 static bool tile_eligible(const FusedArgs &a, int codec) {

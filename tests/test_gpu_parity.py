@@ -475,13 +475,13 @@ def test_fused_codec_26_tables_one_index_per_bag(E, orc, codec):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
-@pytest.mark.parametrize("codec,B", [(32, 8192 + 77), (8, 8192 + 77), (32, 4096 + 5), (32, 20000)])
+@pytest.mark.parametrize("codec,B", [(32, 8192 + 77), (8, 8192 + 77), (32, 4096 + 5), (32, 2048 + 3), (32, 20000)])
 def test_fused_optimistic_offsets_pair(E, orc, codec, B):
     """lS_o given: the library bets on offsets == arange (bag-1 loop with the check folded in) and falls back to
     the general loop on the device when the bet is lost.  Won bet, lost bet (one offset moved, one table ragged,
     a longer last bag) and B+1-entry offsets all give the bits of the two-call path."""
     from bench import KAGGLE_LN
-    d = 36   # the bet is placed from 8192 samples up (fp32 rows: from 4096, checked inside the index-tile loop)
+    d = 36   # the bet is placed from 8192 samples up (fp32 rows: from 2048, checked inside the index-tile loop)
     rs = np.random.RandomState(5 + codec)
     ln = [min(n, 400) for n in KAGGLE_LN]
     if codec == 32:
@@ -511,9 +511,9 @@ def test_fused_optimistic_offsets_pair(E, orc, codec, B):
     won = run(ar, idx)
     assert torch.equal(won, E.apply_emb_interact(x, torch.arange(B, device="cuda").repeat(26, 1), torch.from_numpy(np.stack(idx)).cuda(), ev,
                                                   one_index_per_bag=True))
-    # lost: one offset of one table moved (bag 4000 empty, bag 3999 of two)
+    # lost: one offset of one table moved (bag B/2 empty, the bag before it of two)
     off2 = [a.copy() for a in ar]
-    off2[7][4000] = 4001
+    off2[7][B // 2] = B // 2 + 1
     run(off2, idx)
     # lost: one table ragged (0..3 indices per bag), the others arange
     lens = rs.randint(0, 4, size=B)
@@ -629,10 +629,10 @@ def test_fused_one_index_per_bag_fast_path(E):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
-@pytest.mark.parametrize("codec,T,B,d", [(32, 26, 4096, 36), (32, 26, 5003, 36), (32, 31, 4100, 16), (32, 5, 4099, 64),
+@pytest.mark.parametrize("codec,T,B,d", [(32, 26, 2048, 36), (32, 26, 4096, 36), (32, 26, 5003, 36), (32, 31, 4100, 16), (32, 5, 4099, 64),
                                          (8, 26, 5003, 36), (4, 26, 4097, 36), (16, 26, 4096, 36), (32, 26, 20000, 36)])
 def test_fused_index_tile_kernel(E, orc, codec, T, B, d):
-    """Batches of >= 4096 samples with offsets == NULL run the index-tile kernel (a block owns a contiguous sample
+    """Batches of >= 2048 samples with offsets == NULL run the index-tile kernel (a block owns a contiguous sample
     range, indices staged through LDS): same bits as the general loop, ragged last chunk, out-of-range and
     negative indices skipped and reported like everywhere else."""
     rs = np.random.RandomState(900 + codec + T)
