@@ -461,7 +461,7 @@ constexpr int kTileMaxF = 28;
 template <int CODEC, int CQ, bool BAG1, bool TILE = false, bool CHECK = false>
 constexpr int lds_min_blocks() {
     if (CHECK && CQ < 4) return 4;          // (bag starts / ends in flight + the slow loop: 110 VGPRs at d = 36)
-    if (TILE && CQ < 4) return EVS_LB_TILE;
+    if (TILE && CQ < 4) return CQ < 3 ? EVS_LB_TILE : 4;   // (d = 48: the LDS slots allow 4 blocks)
     if (CQ >= 8) return 2;
     if (CQ >= 4) return 3;
     if (CODEC == 16) return 3;
