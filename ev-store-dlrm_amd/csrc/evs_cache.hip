@@ -1647,11 +1647,11 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
         int *eslot = nullptr, *part1 = nullptr, *part2 = nullptr, *host_tomb = nullptr, *host_tomb_dev = nullptr;
         unsigned long long *bslots = nullptr;
         const bool ok =
-            hipMalloc(&bs, sizeof(BatchState)) == hipSuccess && hipMemcpy(bs, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc(&bs, sizeof(BatchState)) == hipSuccess && hipMemcpy(bs, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess &&   // blocking copy
             hipMalloc(&eslot, cap * 4) == hipSuccess &&
-            hipMalloc(&bslots, c->nslot * 8) == hipSuccess && hipMemset(bslots, 0, c->nslot * 8) == hipSuccess &&
-            hipMalloc(&part1, kReplicas * kPartCols * 4) == hipSuccess && hipMemset(part1, 0, kReplicas * kPartCols * 4) == hipSuccess &&
-            hipMalloc(&part2, kReplicas * kPartCols * 4) == hipSuccess && hipMemset(part2, 0, kReplicas * kPartCols * 4) == hipSuccess &&
+            hipMalloc(&bslots, c->nslot * 8) == hipSuccess && hipMemsetAsync(bslots, 0, c->nslot * 8, st) == hipSuccess &&   // ordered on the caller's stream
+            hipMalloc(&part1, kReplicas * kPartCols * 4) == hipSuccess && hipMemsetAsync(part1, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
+            hipMalloc(&part2, kReplicas * kPartCols * 4) == hipSuccess && hipMemsetAsync(part2, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
             hipHostMalloc(reinterpret_cast<void **>(&host_tomb), sizeof(int), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer(reinterpret_cast<void **>(&host_tomb_dev), host_tomb, 0) == hipSuccess;
         if (!ok) {

@@ -33,17 +33,34 @@ def _stream_ptr(device):
 
 class _PooledList(list):
     """What apply_emb returns: a plain list of T (B,d) views plus where they live, so that interact_features can
-    address the T features arithmetically instead of asking 27 tensors for their pointers and strides."""
+    address the T features arithmetically instead of asking 27 tensors for their pointers and strides.
+    Any mutation (a caller swapping in a cached row tensor for one table, say) drops that shortcut."""
     __slots__ = ("_evs_meta",)
+
+    def _dirty(name):
+        base = getattr(list, name)
+
+        def f(self, *a, **k):
+            self._evs_meta = None
+            return base(self, *a, **k)
+        f.__name__ = name
+        return f
+
+    for _n in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove",
+               "clear", "reverse", "sort"):
+        locals()[_n] = _dirty(_n)
+    del _n, _dirty
 
 
 _feat_cache = {}
 
 # apply_emb followed by interact_features is what every DLRM forward does (dlrm_s_pytorch.py:596-601).  With lazy
-# pooling on, apply_emb returns a LazyPooled sequence that launches nothing; interact_features recognises it and
-# runs the ONE fused kernel.  Anything else that touches the pooled rows (indexing, iteration, list concatenation,
-# len is free) materialises them with the gather kernel first, so the plugin contract is unchanged.
-LAZY_POOLING = os.environ.get("EVS_LAZY_POOLING", "1") != "0"
+# pooling on (EVS_LAZY_POOLING=1, or apply_emb(..., lazy=True)), apply_emb returns a LazyPooled sequence that launches
+# nothing; interact_features recognises it and runs the ONE fused kernel.  Indexing, iteration, list concatenation and
+# this package's ext_dist.alltoall materialise the rows with the gather kernel first -- but LazyPooled is a Sequence,
+# not a list: torch.cat / torch.stack on it raise TypeError, and isinstance(ly, list) is False.  The plugin contract
+# says "returns a list", so the DEFAULT is the eager list; the fusion is opt-in (or call apply_emb_interact).
+LAZY_POOLING = os.environ.get("EVS_LAZY_POOLING", "0") == "1"
 
 
 class LazyPooled(collections.abc.Sequence):

@@ -80,6 +80,8 @@ def alltoall(inputs, per_rank_table_splits, group=None):
     Sends rows [batch slice of peer p] of cat(inputs, dim=1); receives from source rank p a
     (B_local, T_p*d) block -- "local tables x full batch" -> "all tables x local batch".
     """
+    if hasattr(inputs, "materialize"):   # dlrm_ops.LazyPooled: torch.cat takes lists / tuples only
+        inputs = inputs.materialize()
     batch_size, emb_dim = inputs[0].size()
     local_table_num = len(inputs)
     local_batch_num, batch_splits = get_split_lengths(batch_size)

@@ -46,14 +46,18 @@ def plan_placement(ln_emb, world, policy="rows+replicate", replicate_max_rows=1_
     if policy == "hbm":
         budget = replicate_budget_rows if replicate_budget_rows is not None else sum(ln_emb)
         used = 0
-        thr = -1
-        for n in sorted(ln_emb):
+        rep = set()
+        for n, t in sorted((n, t) for t, n in enumerate(ln_emb)):   # smallest first, exactly while they fit
             if used + n > budget:
                 break
             used += n
-            thr = n
-        # ties: every table with <= thr rows was counted or the loop stopped before its size
-        return plan_placement(ln_emb, world, "rows+replicate", replicate_max_rows=thr)
+            rep.add(t)
+        sub = [t for t in range(T) if t not in rep]
+        sub_owner = plan_placement([ln_emb[t] for t in sub], world, "rows")
+        owner = [-1] * T
+        for t, o in zip(sub, sub_owner):
+            owner[t] = o
+        return owner
     if policy == "count":  # extend_distributed.get_my_slice: contiguous by table count
         k, m = divmod(T, world)
         t = 0

@@ -11,44 +11,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import oracle as orc
+from _dist_helpers import OracleBackend
 
 LN = [50, 3, 4000, 17, 2500, 9, 1200]
 D = 16
-
-
-class OracleBackend:
-    """test-only stand-in for HipBackend (same methods, numpy/oracle arithmetic)."""
-
-    def make_tables(self, weights, d):
-        return [np.ascontiguousarray(w.numpy()) for w in weights]
-
-    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False):
-        for j, k in enumerate(table_ids_local):
-            pooled = orc.embedding_bag_sum(ev[k], lS_i_rows[j].numpy(), lS_o_rows[j].numpy())
-            send[:, j, :] = torch.from_numpy(pooled)
-
-    def interact_mixed(self, x, specs, ev, d, itself, out=None, planned=False):
-        B = x.shape[0]
-        ly = []
-        for s in specs:
-            if s[0] == "dense":
-                ly.append(s[1].numpy().copy())
-            else:
-                _, k, idx, off, nnz, off_len = s
-                if off is None:  # one index per bag: bag b = idx[b]
-                    ly.append(ev[k][idx.numpy()[:B]].copy())
-                    continue
-                off = off.numpy()
-                assert off_len == off.shape[0]
-                # slice semantics of evs_feature.offsets_len: bag b ends at off[b+1] while it exists
-                ends = np.concatenate([off[1:], [nnz]])[:B]
-                starts = off[:B]
-                rows = np.zeros((B, d), np.float32)
-                for b in range(B):
-                    rows[b] = orc.embedding_bag_sum(ev[k], idx.numpy()[starts[b]:ends[b]], np.array([0]))[0] \
-                        if ends[b] > starts[b] else 0
-                ly.append(rows)
-        return torch.from_numpy(orc.interact_features(x.numpy(), ly, itself))
 
 
 def _data(seed, Bg):
