@@ -76,6 +76,7 @@ _PROTOS = {
     "evs_manager_perfect_hit": (C.c_longlong, []),
     "evs_manager_set_altkey_dir": (_int, [C.c_char_p]),
     "evs_manager_aprx_hit": (C.c_longlong, []),
+    "evs_manager_tier_capacity": (C.c_longlong, [_int]),
     "ev_lookup": (C.POINTER(C.c_float), [C.POINTER(C.c_int)]),
     "get_ev_values": (C.POINTER(C.c_float), [C.POINTER(C.c_int)]),
     "print_perfect_hit": (None, []),

@@ -25,6 +25,7 @@ struct Manager {
     bool ready = false;
     int n_layer = 1, main_prec = 32, secondary_prec = 4, backing_kind = 0;
     long long total_size = 75425;
+    long long cap1 = 0, cap2 = 0, cap3 = 0;   // entries per tier, as configured
     std::string proportion = "", root = "";
     evs_cache *c1 = nullptr, *c2 = nullptr;
     evs_aprx *c3 = nullptr;
@@ -119,9 +120,13 @@ static int ensure_ready() {
     }
     int rc = load_tables(m, m.main_prec, m.tables, m.rows);
     if (rc) return rc;
-    // sizes are in fp32-row equivalents: cache_manager.cpp:46-53, evlfu_8.cpp:86-92 (x4 for 8-bit rows, x8 for 4-bit);
-    // two tiers without a proportion string split TOTAL_SIZE evenly (evlfu_8.cpp:86-88, cache_manager.cpp:36-38)
-    // capacities (evlfu_8.cpp:63-92): "a-b-c" proportions when three tiers are on, else equal shares
+    // Entries per tier exactly as the reference's constructors compute them; sizes are in fp32-row equivalents.
+    //   one tier  (cache_manager.cpp:40-53): TOTAL_SIZE x 32/main
+    //   two tiers (cache_manager.cpp:36-38 cacheSize = TOTAL_SIZE/2; evlfu_8.cpp:86-88): C1 = share x 32/main;
+    //     C2 = share x 32/secondary -- except an 8-bit SECONDARY tier under a 32- or 16-bit main tier: the reference
+    //     builds it as EVLFU_8BIT(cap_C1*4 | cap_C1*2, ...) (evlfu_32.cpp:102, evlfu_16.cpp:95) and that constructor
+    //     multiplies by 4 again (evlfu_8.cpp:93), i.e. share x 16 entries.  Reproduced: hit rates must match the build.
+    //   three tiers (8-bit main only, evlfu_8.cpp:63-85): "a-b-c" proportions x4 / x8 / x36, else equal thirds
     long long share1 = m.total_size, share2 = 0, share3 = 0;
     if (m.n_layer == 2) { share1 = share2 = m.total_size / 2; }
     if (m.n_layer == 3) {
@@ -133,8 +138,10 @@ static int ensure_ready() {
             share1 = share2 = share3 = m.total_size / 3;
         }
     }
-    const long long share = share1;
-    const long long cap = share * (32 / m.main_prec);
+    const long long cap = share1 * (32 / m.main_prec);
+    long long cap2 = share2 * (32 / m.secondary_prec);
+    if (m.n_layer >= 2 && m.secondary_prec == 8 && m.main_prec > 8) cap2 = share2 * 16;
+    m.cap1 = cap; m.cap2 = m.n_layer >= 2 ? cap2 : 0; m.cap3 = (m.n_layer == 3 && share3 * 36 >= 50) ? share3 * 36 : 0;
     // mixed_precs_caching constants: 0.3 / 0.95, n keys flushed, n_perfect -= n (evlfu_8.hpp:50-51, evlfu_8.cpp:256-270)
     rc = evs_cache_create(&m.c1, 0, cap, kEvTables, kEvDim, m.main_prec, 0.3, 0.95, 0, 2);
     if (rc) return rc;
@@ -145,7 +152,7 @@ static int ensure_ready() {
     if (m.n_layer >= 2) {
         rc = load_tables(m, m.secondary_prec, m.tables2, m.rows2);
         if (rc) return rc;
-        rc = evs_cache_create(&m.c2, 0, share2 * (32 / m.secondary_prec), kEvTables, kEvDim, m.secondary_prec, 0.3, 0.95, 0, 2);
+        rc = evs_cache_create(&m.c2, 0, cap2, kEvTables, kEvDim, m.secondary_prec, 0.3, 0.95, 0, 2);
         if (rc) return rc;
         for (int k = 0; k < kEvTables; k++) rows64[k] = m.rows2[k];
         rc = evs_cache_set_backing(m.c2, m.tables2, (const int64_t *)rows64);
@@ -199,6 +206,12 @@ extern "C" int evs_manager_set_altkey_dir(const char *dir) {
     EVS_REQUIRE(!g_mgr.ready && dir, "evs_manager_set_altkey_dir: call before the first lookup");
     g_mgr.altkey_dir = dir;
     return EVS_OK;
+}
+
+extern "C" long long evs_manager_tier_capacity(int tier) {  // entries of tier 1 / 2 / 3 (0: absent or not yet configured)
+    using namespace evs;
+    if (!g_mgr.ready) return 0;
+    return tier == 1 ? g_mgr.cap1 : tier == 2 ? g_mgr.cap2 : tier == 3 ? g_mgr.cap3 : 0;
 }
 
 extern "C" long long evs_manager_aprx_hit() {  // evlfu_8bit->aprx_ev_hit (cache_manager.cpp:279)

@@ -288,7 +288,10 @@ EVS_API int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_tripl
  *   needs evs_manager_set_altkey_dir / EVS_ALTKEY_DIR; sizes from size_proportion "a-b-c" as evlfu_8.cpp:63-92),
  *   main_precision 32|16|8|4, secondary_precision 16|8|4,
  *   total_size in fp32-row equivalents (one tier: capacity = total_size * 32/main_precision entries;
- *   two tiers: total_size/2 each, i.e. (total/2)*32/main and (total/2)*32/secondary entries),
+ *   two tiers: total_size/2 each, i.e. (total/2)*32/main and (total/2)*32/secondary entries -- except an 8-bit
+ *   secondary tier under a 32/16-bit main tier, which gets (total/2)*16 entries because the reference's
+ *   EVLFU_8BIT constructor multiplies an already-multiplied capacity by 4 again: evlfu_32.cpp:102, evlfu_16.cpp:95,
+ *   evlfu_8.cpp:93; evs_manager_tier_capacity reports what was built),
  *   ev_table_root = directory holding ev-table/binary, ev-table-16/binary, ev-table-8/binary,
  *   ev-table-4/binary (evlfu_*.hpp EV_TABLE_PATH), backing 0 = tables in HBM, 1 = pinned host.
  *   Without a call, ev_lookup reads EVS_N_CACHING_LAYER, EVS_MAIN_PRECISION, EVS_TOTAL_SIZE,
@@ -299,6 +302,7 @@ EVS_API int evs_manager_configure(int n_caching_layer, int main_precision, int s
                                   int backing);
 EVS_API int evs_manager_set_altkey_dir(const char *dir);  /* n_caching_layer 3: directory of the alt-key ev-table-N.bin files */
 EVS_API long long evs_manager_perfect_hit(void);
+EVS_API long long evs_manager_tier_capacity(int tier);   /* entries of tier 1 | 2 | 3 as configured (0 = absent) */
 EVS_API long long evs_manager_aprx_hit(void);             /* evlfu_8bit->aprx_ev_hit (cache_manager.cpp:279) */
 EVS_API float *ev_lookup(int *arr);                      /* cache_manager.cpp:231 */
 EVS_API float *get_ev_values(int *arr);                  /* cache_manager.cpp:257 */

@@ -285,6 +285,34 @@ def kaggle_tables(n_rows, seed, d=36):
             for n in n_rows]
 
 
+def ref_tier_capacities(n_layer, main, secondary, total_size, proportion=""):
+    """Entries per tier as the reference's constructors compute them (sizes are in fp32-row equivalents):
+    cache_manager.cpp:31-53 (cacheSize = TOTAL_SIZE / n for 1 or 2 layers; main 32 -> cacheSize, 16 -> x2, 4 -> x8, and the
+    8-bit main tier gets TOTAL_SIZE itself), evlfu_8.cpp:57-97 (x4 for its own rows; with a C2: total/2*4 and total/2*8;
+    three tiers: the "a-b-c" proportion, x4 / x8 / x36), evlfu_32.cpp:99-105 and evlfu_16.cpp:93-97 (C2 = cap_C1 x2 / x4 /
+    x8 for a 16 / 8 / 4-bit secondary tier from a 32-bit main, x2 / x4 from a 16-bit main).  NB an 8-bit SECONDARY tier is
+    built through EVLFU_8BIT's constructor, which multiplies by 4 again (evlfu_8.cpp:93): (TOTAL/2)*16 entries, not *4.
+    -> (cap_c1, cap_c2, cap_c3) with 0 for an absent tier."""
+    if main == 8:
+        if n_layer == 3 and proportion:
+            p1, p2, p3 = [int(v) for v in proportion.split("-")]
+            return (p1 * total_size // 100) * 4, (p2 * total_size // 100) * 8, (p3 * total_size // 100) * 36
+        if n_layer == 3:
+            return total_size // 3 * 4, total_size // 3 * 8, total_size // 3 * 36
+        if n_layer == 2:
+            return total_size // 2 * 4, total_size // 2 * 8, 0
+        return total_size * 4, 0, 0
+    cs = total_size // 2 if n_layer == 2 else total_size
+    c1 = cs * (32 // main)
+    if n_layer < 2:
+        return c1, 0, 0
+    if main == 32:
+        c2 = {16: c1 * 2, 8: c1 * 4 * 4, 4: c1 * 8}[secondary]
+    else:   # main 16
+        c2 = {8: c1 * 2 * 4, 4: c1 * 4}[secondary]
+    return c1, c2, 0
+
+
 class C1C2:
     """Two-tier request (mixed_precs_caching/evlfu_8.cpp:669-796).  tables_c1 / tables_c2: the rows
     decoded at each tier's precision (fp32 arrays)."""

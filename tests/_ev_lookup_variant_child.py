@@ -1,0 +1,86 @@
+"""Child process of tests/test_gpu_cache.py::test_cabi_precision_builds_vs_compiled_reference: the request stream of
+tests/golden/mgr_variants.npz through libevstore_hip's ev_lookup, configured like one precision build of the reference
+cache manager (N_CACHING_LAYER / MAIN_PRECISION / SECONDARY_PRECISION / TOTAL_SIZE, cache_manager.cpp:13-17), compared
+with what the COMPILED reference served (precision of every row) and with the oracle (every row, bit for bit).
+The manager is a process-wide singleton, hence one process per build."""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+root, var = sys.argv[1], sys.argv[2]
+layers, main, sec, total = [int(v) for v in var.split("-")]
+_repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _repo)
+sys.path.insert(0, os.path.join(_repo, "tests", "golden"))
+from oracle import oracle as orc  # noqa: E402
+import make_golden as G  # noqa: E402  (variant_tables: the fixture's tables and requests from their seed)
+
+L = ctypes.CDLL(os.path.join(_repo, "ev-store-dlrm_amd", "lib", "libevstore_hip.so"))
+L.ev_lookup.argtypes = [ctypes.POINTER(ctypes.c_int)]
+L.ev_lookup.restype = ctypes.POINTER(ctypes.c_float)
+L.evs_manager_tier_capacity.restype = ctypes.c_longlong
+L.evs_manager_perfect_hit.restype = ctypes.c_longlong
+
+tabs, reqs = G.variant_tables(orc)
+g = np.load(os.path.join(_repo, "tests", "golden", "mgr_variants.npz"))
+assert np.array_equal(reqs, g["requests"])
+for sub, j in (("ev-table", 0), ("ev-table-16", 1), ("ev-table-8", 2), ("ev-table-4", 3)):
+    os.makedirs(os.path.join(root, sub, "binary"))
+    for k, t in enumerate(tabs):
+        t[j].tofile(os.path.join(root, sub, "binary", "ev-table-%d.bin" % (k + 1)))
+dec = {32: [t[0] for t in tabs], 16: [orc.decode(t[1], 16, 36) for t in tabs],
+       8: [orc.decode(t[2], 8, 36) for t in tabs], 4: [orc.decode(t[3], 4, 36) for t in tabs]}
+os.environ.update({"EVS_EV_TABLE_ROOT": root, "EVS_MAIN_PRECISION": str(main), "EVS_SECONDARY_PRECISION": str(sec),
+                   "EVS_TOTAL_SIZE": str(total), "EVS_N_CACHING_LAYER": str(layers), "EVS_BACKING": "hbm"})
+c1, c2, _ = orc.ref_tier_capacities(layers, main, sec, total)
+o = orc.C1C2(c1, c2, dec[main], dec[sec]) if layers == 2 else orc.EvLFU(c1, dec[main], 36, "cpp")
+ref = g["v" + var.replace("-", "_") + "_served"]
+ref_perfect = [int(v) for v in g["v" + var.replace("-", "_") + "_perfect"]]
+blk = int(g["block"])
+served = np.zeros_like(ref)
+exact = True
+perfect, counter_prev = [], 0
+for i, rq in enumerate(reqs):
+    ptr = L.ev_lookup((ctypes.c_int * 26)(*[int(v) for v in rq]))
+    if not ptr:
+        print("ev_lookup returned NULL")
+        sys.exit(3)
+    got = np.ctypeslib.as_array(ptr, shape=(26, 36)).copy()
+    vals = o.request(rq)[1]
+    exact = exact and np.array_equal(got.view(np.uint32), vals.view(np.uint32))
+    for k in range(26):
+        for b in ((main, sec) if layers == 2 else (main,)):
+            if np.array_equal(got[k], dec[b][k][rq[k]]):
+                served[i, k] = b
+                break
+    if (i + 1) % blk == 0:
+        c = int(L.evs_manager_perfect_hit())
+        perfect.append(c - counter_prev)
+        counter_prev = c
+caps = [int(L.evs_manager_tier_capacity(t)) for t in (1, 2, 3)]
+res = {"exact_vs_oracle": bool(exact), "caps": caps, "caps_ref": [c1, c2], "no_garbage": bool((served != 0).all())}
+if layers == 2:
+    first_ref = int(np.argmax((ref == sec).any(1)))
+    res["first_ref"] = first_ref
+    res["first_mine"] = int(np.argmax((served == sec).any(1)))
+    res["prefill_equal"] = bool(np.array_equal(served[:first_ref], ref[:first_ref]))
+    agree = []
+    for a in range(0, len(reqs), blk):
+        ok = ref[a:a + blk] != 0
+        agree.append(float((served[a:a + blk][ok] == ref[a:a + blk][ok]).mean()))
+    res["min_block_agreement"] = min(agree)
+    nb = first_ref // blk
+else:
+    nb = 0
+    tot = 0
+    for i in range(len(reqs) // blk):   # blocks before the single tier fills: 26 new keys per request at most
+        tot += blk * 26
+        if tot < c1:
+            nb = i + 1
+res["perfect_prefix_equal"] = perfect[:nb] == ref_perfect[:nb]
+res["nb"] = nb
+res["perfect"] = [sum(perfect), sum(ref_perfect)]
+print("RESULT " + json.dumps(res))

@@ -406,9 +406,157 @@ sys.stdout.flush(); os._exit(0)
     print([l for l in out.stdout.splitlines() if l.startswith("c1c2")], out.stderr[-500:])
 
 
+# --------------------------------------------------------------------------
+# a8: the C++ EvLFU of the Cython build (flush 0.4 / perfect cap 1.0), COMPILED from the reference
+# (oracle/_ref/ref_cython_evlfu = cache_algo/EvLFU_C1_Cython/EvLFU.cpp + oracle/ref/ref_cython_evlfu_driver.cpp)
+# --------------------------------------------------------------------------
+CYTHON_CAPS = (52, 64, 78, 300, 768)
+
+
+def gen_cython_traces():
+    import subprocess
+    orc = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle")
+    subprocess.check_call(["make", "-s", "-C", orc, "ref"])
+    n_rows = [min(n, 600) for n in KAGGLE_LN]
+    root = tempfile.mkdtemp(prefix="evs_cython_")
+    tdir = os.path.join(root, "stored_model", "criteo_kaggle_all_mmap", "epoch-00", "ev-table")
+    tabs = make_bin_tables(tdir, n_rows, seed=7)          # the same tables as cache_traces.npz
+    streams = {"main": zipf_stream(n_rows, 1500, seed=11),
+               "flush": zipf_stream(n_rows, 1200, seed=13, n_hot=3, p_hot=0.7, distinct_hot=True)}
+    out = {"n_rows": np.asarray(n_rows, np.int64), "table_seed": np.int64(7),
+           "requests": streams["main"], "requests_flush": streams["flush"]}
+    for sname, reqs in streams.items():
+        for cap in CYTHON_CAPS:
+            rq = os.path.join(root, "req.bin")
+            with open(rq, "wb") as f:
+                f.write(struct.pack("<ii", len(reqs), cap))
+                f.write(np.ascontiguousarray(reqs, np.int32).tobytes())
+            res = os.path.join(root, "out.bin")
+            p = subprocess.run([os.path.join(orc, "_ref", "ref_cython_evlfu"), rq, res], capture_output=True, text=True,
+                               env=dict(os.environ, EVS_REF_ROOT=root), timeout=600)
+            assert p.returncode == 0, p.stderr
+            nflush = p.stdout.count("flushing!")
+            raw = open(res, "rb").read()
+            n = len(reqs)
+            hits = np.frombuffer(raw, np.uint8, n * 26).reshape(n, 26).astype(bool)
+            o = n * 26
+            rows = np.frombuffer(raw, np.float32, n * 26 * 36, o).reshape(n, 26, 36)
+            o += n * 26 * 36 * 4
+            state = np.frombuffer(raw, np.int64, 3, o)
+            m = int(np.frombuffer(raw, np.int64, 1, o + 24)[0])
+            tri = np.frombuffer(raw, np.int64, 3 * m, o + 32).reshape(m, 3)
+            for i in range(n):      # the rows are always the true table rows
+                for k in range(26):
+                    assert np.array_equal(rows[i, k], tabs[k][reqs[i, k]]), (sname, cap, i, k)
+            tag = "cython_%s_cap%d" % (sname, cap)
+            out[tag + "_hits"] = np.packbits(hits, axis=1)
+            out[tag + "_final_buckets"] = tri.copy()
+            out[tag + "_state"] = np.asarray(list(state) + [nflush], np.int64)
+            print(tag, "hits", int(hits.sum()), "perfect", int(hits.all(1).sum()), "flushes", nflush, "size", int(state[2]))
+    np.savez_compressed(os.path.join(HERE, "cython_traces.npz"), **out)
+    print("wrote cython_traces")
+
+
+# --------------------------------------------------------------------------
+# a9 siblings: the other precision builds of the COMPILED reference cache manager
+# (oracle/_ref/libcachemanager_ref_<layers>-<main>-<secondary>-<TOTAL_SIZE>.so, oracle/Makefile MGR_VARIANTS)
+# --------------------------------------------------------------------------
+MGR_VARIANTS = ["2-32-16-4000", "2-32-8-4000", "2-32-4-4000", "2-16-8-4000", "2-16-4-4000", "2-8-4-4000",
+                "1-32-4-3000", "1-16-4-3000", "1-8-4-3000", "1-4-4-3000"]
+VAR_ROWS, VAR_SEED, VAR_NREQ, VAR_BLOCK = 2500, 17, 2000, 100
+
+
+def variant_tables(orc):
+    """(fp32 rows, raw16, raw8, raw4) per table; one RandomState stream; then the request stream."""
+    rs = np.random.RandomState(VAR_SEED)
+    tabs = []
+    for k in range(26):
+        w = rs.uniform(-1, 1, size=(VAR_ROWS, 36)).astype(np.float32)
+        tabs.append((w, orc.encode_table(w, 16), orc.encode_table(w, 8), orc.encode_table(w, 4)))
+    N = VAR_ROWS
+    reqs = np.zeros((VAR_NREQ, 26), np.int32)
+    for i in range(VAR_NREQ):
+        fresh = (i + rs.randint(0, 2, 26)) % N
+        back = rs.randint(0, max(1, min(i, N)), 26)
+        reqs[i] = np.where(rs.rand(26) < 0.85, fresh, back)
+        if i > 30 and rs.rand() < 0.3:
+            reqs[i] = reqs[i - 1 - rs.randint(25)]
+            reqs[i] = np.where(rs.rand(26) < 0.06, rs.randint(0, N, 26), reqs[i])
+    return tabs, reqs
+
+
+def gen_mgr_variants():
+    """One child process per build (global constructors, reader threads that never join)."""
+    import subprocess
+    root_repo = os.path.dirname(os.path.dirname(HERE))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root_repo, "oracle"), "ref"])
+    out = {"n_rows": np.int64(VAR_ROWS), "seed": np.int64(VAR_SEED), "block": np.int64(VAR_BLOCK)}
+    for var in MGR_VARIANTS:
+        code = r"""
+import os, sys, ctypes, re, tempfile, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import oracle as orc
+import make_golden as G
+root = tempfile.mkdtemp(prefix='evs_var_')
+base = root + '/stored_model/criteo_kaggle_all_mmap/epoch-00/'
+for sub in ('ev-table', 'ev-table-16', 'ev-table-8', 'ev-table-4'):
+    os.makedirs(base + sub + '/binary')
+tabs, reqs = G.variant_tables(orc)
+for k, (w, r16, r8, r4) in enumerate(tabs):
+    for sub, a in (('ev-table', w), ('ev-table-16', r16), ('ev-table-8', r8), ('ev-table-4', r4)):
+        a.tofile(base + sub + '/binary/ev-table-%%d.bin' %% (k + 1))
+os.environ['EVS_REF_ROOT'] = root
+log = root + '/stdout.txt'
+fd = os.open(log, os.O_WRONLY | os.O_CREAT)
+os.dup2(fd, 1)
+L = ctypes.CDLL(%r)
+L.ev_lookup.argtypes = [ctypes.POINTER(ctypes.c_int)]
+L.ev_lookup.restype = ctypes.POINTER(ctypes.c_float)
+dec = {32: [t[0] for t in tabs], 16: [orc.decode(t[1], 16, 36) for t in tabs],
+       8: [orc.decode(t[2], 8, 36) for t in tabs], 4: [orc.decode(t[3], 4, 36) for t in tabs]}
+order = (%d, %d) if %d == 2 else (%d,)
+served = np.zeros(reqs.shape, np.uint8)
+for i in range(len(reqs)):
+    p = L.ev_lookup((ctypes.c_int * 26)(*[int(v) for v in reqs[i]]))
+    o = np.ctypeslib.as_array(p, shape=(26, 36)).copy()
+    for k in range(26):
+        for b in order:
+            if np.array_equal(o[k], dec[b][k][reqs[i, k]]):
+                served[i, k] = b
+                break
+    if (i + 1) %% G.VAR_BLOCK == 0:
+        L.print_perfect_hit()
+ctypes.CDLL(None).fflush(None)
+perfect = [int(m) for m in re.findall(r'Perfect hit\s+= (\d+)', open(log).read())]
+np.savez(%r, served=served, perfect=np.asarray(perfect, np.int64), requests=reqs)
+os._exit(0)
+"""
+        L_, M_, S_, T_ = [int(v) for v in var.split("-")]
+        tmp_out = os.path.join(tempfile.mkdtemp(prefix="evs_varout_"), "o.npz")
+        src = code % (root_repo, HERE, os.path.join(root_repo, "oracle", "_ref", "libcachemanager_ref_%s.so" % var),
+                      M_, S_, L_, M_, tmp_out)
+        r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=1800)
+        assert os.path.exists(tmp_out), (var, r.stderr[-2000:])
+        g = np.load(tmp_out)
+        tag = "v" + var.replace("-", "_")
+        out[tag + "_served"] = g["served"]
+        out[tag + "_perfect"] = g["perfect"]
+        out["requests"] = g["requests"]
+        print(var, "served", {int(b): int((g["served"] == b).sum()) for b in np.unique(g["served"])},
+              "perfect/block", g["perfect"][:8].tolist(), "...", int(g["perfect"].sum()))
+    np.savez_compressed(os.path.join(HERE, "mgr_variants.npz"), **out)
+    print("wrote mgr_variants")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        gen_mgr_variants()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "c1c2":
         gen_c1c2()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cython":
+        gen_cython_traces()
         return
     D, DP, SM, FR, MFR, EvLFU_C1, LRU, LFU = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "codec":
@@ -435,6 +583,8 @@ def main():
     gen_encoder_vectors()
     gen_codec_tables()
     gen_c1c2()
+    gen_cython_traces()
+    gen_mgr_variants()
 
 
 if __name__ == "__main__":

@@ -128,6 +128,25 @@ def test_evlfu_variants_vs_oracle(E, orc, variant):
     np.testing.assert_array_equal(c.dump(), o.dump())
 
 
+@pytest.mark.parametrize("stream,cap,chunk", [("main", 64, 1), ("main", 768, 100), ("flush", 52, 1), ("flush", 78, 33),
+                                              ("flush", 300, 1200), ("main", 300, 7)])
+def test_evlfu_cython_variant_matches_compiled_reference(E, orc, stream, cap, chunk):
+    """variant='cython' on the GPU against traces of the reference's COMPILED C++ (EvLFU_C1_Cython/EvLFU.cpp,
+    tests/golden/cython_traces.npz): hit flags, rows, final list order and counters bit-exact, flushes included."""
+    t = load_golden("cython_traces")
+    tabs = _tables(orc, t)
+    reqs = t["requests_flush"] if stream == "flush" else t["requests"]
+    tag = "cython_%s_cap%d" % (stream, cap)
+    c, hits, outs = _run(E, "evlfu", cap, tabs, reqs, chunk, variant="cython")
+    want = _unpack(t[tag + "_hits"], len(reqs))
+    assert np.array_equal(hits, want)
+    for k in range(26):
+        assert np.array_equal(outs[:, k, :], tabs[k][reqs[:, k]])
+    np.testing.assert_array_equal(c.dump(), t[tag + "_final_buckets"])
+    st = c.stats()
+    assert [st["min_c1"], st["n_perfect"], st["size"], st["n_flush"]] == list(t[tag + "_state"])
+
+
 @pytest.mark.parametrize("codec", [8, 4, 16])
 def test_cache_over_reduced_precision_rows(E, orc, codec):
     """a cache tier holding 8/4/16-bit rows (the reference's C2 precisions) decodes on output."""
@@ -217,6 +236,32 @@ def test_reference_cabi_ev_lookup(E, orc, tmp_path, prec, layers):
     if layers == 3:
         # the child's extra ev_lookup probe may add alt-key hits of its own
         assert r["aprx"][1] <= r["aprx"][0] <= r["aprx"][1] + 26 and "C3 Indiv-Hit" in out.stdout
+
+
+@pytest.mark.parametrize("var", ["2-32-16-4000", "2-32-8-4000", "2-32-4-4000", "2-16-8-4000", "2-16-4-4000", "2-8-4-4000",
+                                 "1-32-4-3000", "1-16-4-3000", "1-4-4-3000"])
+def test_cabi_precision_builds_vs_compiled_reference(E, orc, tmp_path, var):
+    """a9's sibling builds (MAIN_PRECISION 32 / 16 with a 16 / 8 / 4-bit C2, and the single-tier builds): ev_lookup of
+    libevstore_hip configured like the build == what the reference COMPILED with those #defines served
+    (tests/golden/mgr_variants.npz: serving precision of every key identical until C1 fills, >= 99 % per block after,
+    perfect-hit counter identical while nothing was evicted), every row bit-identical to the oracle, and the tier
+    capacities equal the reference constructors' (incl. the x16 of an 8-bit C2)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ev_lookup_variant_child.py")
+    out = subprocess.run([sys.executable, child, str(tmp_path), var], capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(line[0][7:])
+    assert r["exact_vs_oracle"] and r["no_garbage"], r
+    assert r["caps"][:2] == r["caps_ref"], r
+    assert r["perfect_prefix_equal"] and r["nb"] >= 1, r
+    if var.startswith("2-"):
+        assert r["first_mine"] == r["first_ref"] and r["prefill_equal"] and r["min_block_agreement"] >= 0.99, r
+    else:
+        assert abs(r["perfect"][0] - r["perfect"][1]) <= max(8, 0.4 * r["perfect"][1]), r
 
 
 def test_two_tier_c1c2_vs_oracle(E, orc):

@@ -137,6 +137,29 @@ def test_evlfu_trace(cap):
         assert st["n_flush"] >= 1
 
 
+@pytest.mark.parametrize("stream,cap", [("main", 52), ("main", 64), ("main", 78), ("main", 300), ("main", 768),
+                                        ("flush", 52), ("flush", 64), ("flush", 78), ("flush", 300), ("flush", 768)])
+def test_evlfu_cython_variant_trace(stream, cap):
+    """variant='cython' (flush 0.4 / perfect cap 1.0, n+1 keys flushed) against traces of the COMPILED reference
+    C++ (cache_algo/EvLFU_C1_Cython/EvLFU.cpp:70-232 built by oracle/Makefile -> _ref/ref_cython_evlfu):
+    hit flags of every request, final list order, min_C1 / n_perfect / size, number of flushes."""
+    t = load_golden("cython_traces")
+    tabs = _tables_for_traces(t)
+    reqs = t["requests_flush"] if stream == "flush" else t["requests"]
+    c = orc.EvLFU(cap, tabs, 36, "cython")
+    tag = "cython_%s_cap%d" % (stream, cap)
+    want = _unpack_hits(t[tag + "_hits"], len(reqs))
+    for i, rq in enumerate(reqs):
+        hit, vals = c.request(rq)
+        assert np.array_equal(hit, want[i]), "request %d" % i
+        assert np.array_equal(vals[5], tabs[5][rq[5]])
+    np.testing.assert_array_equal(c.dump(), t[tag + "_final_buckets"])
+    st = c.state()
+    assert [st["min_c1"], st["n_perfect"], st["size"], st["n_flush"]] == list(t[tag + "_state"])
+    if stream == "flush" and cap in (52, 78):
+        assert st["n_flush"] >= 1
+
+
 def test_evlfu_approx_mode_trace():
     t = load_golden("cache_traces")
     tabs = _tables_for_traces(t)
@@ -228,3 +251,95 @@ def test_c1c2_routing_matches_compiled_reference():
     for a in range(first_ref - first_ref % 500, len(reqs), 500):
         ok = ref[a:a + 500] != 0
         assert (mine[a:a + 500][ok] == ref[a:a + 500][ok]).mean() >= 0.995
+
+
+# ------------------------------------------------------------------ the other precision builds of the reference manager
+def _variant_decoded():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as G
+    tabs, reqs = G.variant_tables(orc)
+    dec = {32: [t[0] for t in tabs], 16: [orc.decode(t[1], 16, 36) for t in tabs],
+           8: [orc.decode(t[2], 8, 36) for t in tabs], 4: [orc.decode(t[3], 4, 36) for t in tabs]}
+    return dec, reqs
+
+
+def test_tier_capacities_as_the_reference_constructs_them():
+    assert orc.ref_tier_capacities(3, 8, 4, 75425, "48-48-4") == (144816, 289632, 108612)   # c1c2_ref.npz's build
+    assert orc.ref_tier_capacities(2, 32, 8, 4000) == (2000, 32000, 0)    # the double x4 of an 8-bit secondary tier
+    assert orc.ref_tier_capacities(2, 16, 8, 4000) == (4000, 32000, 0)
+    assert orc.ref_tier_capacities(2, 32, 16, 4000) == (2000, 4000, 0)
+    assert orc.ref_tier_capacities(2, 32, 4, 4000) == (2000, 16000, 0)
+    assert orc.ref_tier_capacities(2, 16, 4, 4000) == (4000, 16000, 0)
+    assert orc.ref_tier_capacities(2, 8, 4, 4000) == (8000, 16000, 0)
+    assert orc.ref_tier_capacities(1, 4, 4, 3000) == (24000, 0, 0)
+
+
+@pytest.mark.parametrize("var", ["2-32-16-4000", "2-32-8-4000", "2-32-4-4000", "2-16-8-4000", "2-16-4-4000", "2-8-4-4000"])
+def test_c1c2_precision_builds_match_compiled_reference(var):
+    """request_to_c1_c2 of the 32- and 16-bit main tiers (evlfu_32.cpp:319-473, evlfu_16.cpp:443-592) and the plain 8/4
+    two-tier build, each COMPILED from the reference with its #defines set (oracle/Makefile MGR_VARIANTS): the serving
+    precision of every key equals the oracle's until C1 fills (afterwards the C++ evicts in unordered_set order:
+    agreement >= 99 % per 100-request block, garbage rows of the reference -- hazard g -- excluded), with the
+    capacities the reference's constructors compute (incl. the x16 of an 8-bit secondary tier)."""
+    g = load_golden("mgr_variants")
+    dec, reqs = _variant_decoded()
+    assert np.array_equal(reqs, g["requests"])
+    L, M, S, T = [int(v) for v in var.split("-")]
+    ref = g["v" + var.replace("-", "_") + "_served"]
+    c1, c2, _ = orc.ref_tier_capacities(L, M, S, T)
+    c = orc.C1C2(c1, c2, dec[M], dec[S])
+    mine = np.zeros_like(ref)
+    perfect = []
+    blk = int(g["block"])
+    n_perf = 0
+    for i, rq in enumerate(reqs):
+        tier, out, rc = c.request(rq)
+        n_perf += int(rc == 1)
+        for k in range(26):
+            mine[i, k] = M if np.array_equal(out[k], dec[M][k][rq[k]]) else (S if np.array_equal(out[k], dec[S][k][rq[k]]) else 0)
+        if (i + 1) % blk == 0:
+            perfect.append(n_perf)
+            n_perf = 0
+    assert (mine != 0).all()
+    first_ref = int(np.argmax((ref == S).any(1)))
+    assert int(np.argmax((mine == S).any(1))) == first_ref and first_ref > 20
+    assert np.array_equal(mine[:first_ref], ref[:first_ref])
+    agree = []
+    for a in range(0, len(reqs), blk):
+        ok = ref[a:a + blk] != 0
+        agree.append((mine[a:a + blk][ok] == ref[a:a + blk][ok]).mean())
+    assert min(agree) >= 0.99, agree
+    # perfect-hit counter (cache_manager.cpp:262-290 prints and resets it): exact while nothing was evicted
+    nb = first_ref // blk
+    assert perfect[:nb] == list(g["v" + var.replace("-", "_") + "_perfect"][:nb])
+
+
+@pytest.mark.parametrize("var", ["1-32-4-3000", "1-16-4-3000", "1-8-4-3000", "1-4-4-3000"])
+def test_single_tier_precision_builds_perfect_hits(var):
+    """N_CACHING_LAYER 1 builds (request_to_ev_lfu of evlfu_32/16/8/4.cpp): rows decode at the tier's precision and the
+    perfect-hit counter per 100 requests equals the oracle's EvLFU('cpp') with the reference's capacity until the cache
+    fills, and stays within a band afterwards (eviction order of an unordered_set)."""
+    g = load_golden("mgr_variants")
+    dec, reqs = _variant_decoded()
+    L, M, S, T = [int(v) for v in var.split("-")]
+    tag = "v" + var.replace("-", "_")
+    served = g[tag + "_served"]
+    assert ((served == M) | (served == 0)).all() and (served == 0).mean() < 0.005
+    cap = orc.ref_tier_capacities(1, M, S, T)[0]
+    c = orc.EvLFU(cap, dec[M], 36, "cpp")
+    blk = int(g["block"])
+    perfect, n = [], 0
+    fill_at = None
+    for i, rq in enumerate(reqs):
+        hit, vals = c.request(rq)
+        n += int(hit.all())
+        if fill_at is None and c.state()["size"] >= cap:
+            fill_at = i
+        if (i + 1) % blk == 0:
+            perfect.append(n)
+            n = 0
+    ref = list(g[tag + "_perfect"])
+    nb = (fill_at if fill_at is not None else len(reqs)) // blk
+    assert nb >= 1 and perfect[:nb] == ref[:nb]
+    assert abs(sum(perfect) - sum(ref)) <= max(8, 0.4 * sum(ref)), (sum(perfect), sum(ref))
