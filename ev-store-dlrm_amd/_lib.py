@@ -68,6 +68,8 @@ _PROTOS = {
     "evs_aprx_destroy": (_int, [_vp]),
     "evs_aprx_set_altkeys": (_int, [_vp, _pp, _i64p]),
     "evs_aprx_stats": (_int, [_vp, _i64p, _vp]),
+    "evs_aprx_apply_ops": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "evs_aprx_dump_queue": (_i64, [_vp, _i64p, _i64, _vp]),
     "evs_cache_request_c1c2c3": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "evs_cache_stats": (_int, [_vp, _i64p, _vp]),
     "evs_cache_reset_counters": (_int, [_vp, _vp]),

@@ -563,6 +563,47 @@ __device__ __forceinline__ void aprx_queue_key(AprxState &s, unsigned long long 
     if (s.n_pending < kAprxBatch) s.pending[s.n_pending++] = key;
     if (s.n_pending == kAprxBatch) s.batch_ready = 1;
 }
+// APRX_EV's public single-key methods in order, one lane (the tier is sequential by definition): op 0 insert_altkey
+// (aprx_embedding.cpp:278-288), 1 get_altkey_str (:341-350), 2 set_recency_flag_c3 (:402-411), 3 evict_one_key (:390-400).
+// These are the operations of the tier that ARE pinned to the compiled reference (tests/golden/aprx_ops.npz); the
+// request path above uses the same device functions.
+__global__ void aprx_ops_kernel(AprxArrays x, long long n, const int *ops, unsigned *res) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    AprxState s = *x.st;
+    for (long long i = 0; i < n && !s.error; i++) {
+        const int op = ops[3 * i], t1 = ops[3 * i + 1], row = ops[3 * i + 2];
+        unsigned out = 0;
+        if (t1 < 1 || t1 > kMaxTables || row < 0 || (op == 0 && (long long)row >= x.alt_rows[t1 - 1])) { s.error = 3; break; }
+        const unsigned long long key = ((unsigned long long)(unsigned)t1 << 32) | (unsigned)row;
+        if (op == 0) {
+            const unsigned alt = x.alt_tables[t1 - 1][row];
+            if (s.count >= s.cap) aprx_evict_one(x, s);
+            if (s.qtail - s.qhead >= s.qcap) { s.error = 1; break; }
+            x.queue[s.qtail % s.qcap] = key; s.qtail++;
+            int e = aprx_find(x, s.mask, key);
+            if (e < 0) {
+                if (s.n_free <= 0) { s.error = 2; break; }
+                e = x.free_stack[--s.n_free];
+                st(&x.ekey[e], key);
+                aprx_put(x, s.mask, key, e);
+                s.count++;
+            }
+            st(&x.ealt[e], alt);
+            st(&x.eflag[e], (unsigned char)0);
+            out = alt;
+        } else if (op == 1) {
+            const int e = aprx_find(x, s.mask, key);
+            out = e >= 0 ? ld(&x.ealt[e]) : 0xffffffffu;
+        } else if (op == 2) {
+            const int e = aprx_find(x, s.mask, key);
+            if (e >= 0) st(&x.eflag[e], (unsigned char)1);
+        } else if (op == 3) {
+            aprx_evict_one(x, s);
+        }
+        res[i] = out;
+    }
+    *x.st = s;
+}
 
 struct TierArgs {
     CacheState *st;
@@ -1944,6 +1985,34 @@ extern "C" int evs_aprx_set_altkeys(evs_aprx *p, const uint32_t *const *alt_tabl
     }
     p->has_alt = true;
     return EVS_OK;
+}
+
+extern "C" int evs_aprx_apply_ops(evs_aprx *p, int64_t n, const int32_t *ops, uint32_t *res, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(p && (n == 0 || (ops && res)) && n >= 0, "evs_aprx_apply_ops: bad argument");
+    if (!p->has_alt) { set_error("evs_aprx_apply_ops: call evs_aprx_set_altkeys first"); return EVS_ESTATE; }
+    if (n == 0) return EVS_OK;
+    hipLaunchKernelGGL(aprx_ops_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), p->x, (long long)n, ops, res);
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
+}
+
+// the FIFO front to back as (table_1based, row) pairs on the host, stale duplicates included; returns the length
+extern "C" int64_t evs_aprx_dump_queue(evs_aprx *p, int64_t *pairs, int64_t max_pairs, void *stream) {
+    using namespace evs;
+    if (!p) { set_error("evs_aprx_dump_queue: NULL tier"); return EVS_EINVAL; }
+    AprxState h;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(&h, p->x.st, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return EVS_EHIP;
+    std::vector<unsigned long long> q((size_t)h.qcap);
+    if (hipMemcpy(q.data(), p->x.queue, (size_t)h.qcap * 8, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+    int64_t n = 0;
+    for (long long i = h.qhead; i < h.qtail; i++, n++)
+        if (pairs && n < max_pairs) {
+            pairs[2 * n] = (int64_t)(q[(size_t)(i % h.qcap)] >> 32);
+            pairs[2 * n + 1] = (int64_t)(q[(size_t)(i % h.qcap)] & 0xffffffffull);
+        }
+    return n;
 }
 
 // out4 (host): [size, n_hit, n_pending, error]

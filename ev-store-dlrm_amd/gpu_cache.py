@@ -208,6 +208,26 @@ class GpuAltKeyTier:
         _lib.check(_lib.lib().evs_aprx_stats(self._h, s, torch.cuda.current_stream(self.device).cuda_stream))
         return dict(size=int(s[0]), n_hit=int(s[1]), n_pending=int(s[2]), error=int(s[3]))
 
+    def apply_ops(self, ops):
+        """APRX_EV's single-key methods in order: ops (n,3) int32 device tensor of (op, table_1based, row) with op 0
+        insert_altkey | 1 get_altkey | 2 set_recency_flag | 3 evict_one_key (aprx_embedding.cpp:278-288,341-350,390-411).
+        -> uint32-valued int64 tensor: the alt key for op 0 / 1 (0xffffffff = miss), else 0."""
+        assert ops.dtype == torch.int32 and ops.is_cuda and ops.is_contiguous() and ops.dim() == 2 and ops.shape[1] == 3
+        res = torch.zeros((ops.shape[0],), dtype=torch.int32, device=self.device)
+        _lib.check(_lib.lib().evs_aprx_apply_ops(self._h, int(ops.shape[0]), ops.data_ptr(), res.data_ptr(),
+                                                 torch.cuda.current_stream(self.device).cuda_stream))
+        return res.to(torch.int64) & 0xffffffff
+
+    def queue(self):
+        """the FIFO front to back as (n,2) int64 (table_1based, row), stale duplicates included"""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        n = int(_lib.lib().evs_aprx_dump_queue(self._h, None, 0, st))
+        if n < 0:
+            _lib.check(n)
+        out = (C.c_int64 * (2 * max(n, 1)))()
+        _lib.lib().evs_aprx_dump_queue(self._h, out, n, st)
+        return torch.tensor(list(out)[:2 * n], dtype=torch.int64).view(n, 2)
+
 
 def request_c1c2c3(c1, c2, c3, rows, threshold=23, out=None, tier=None):
     """request_to_c1_c2_c3 (evlfu_8.cpp:492-667): tier codes 1 C1 hit, 2 C2 hit, 3 alt-key hit, 0 miss."""

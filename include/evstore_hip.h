@@ -265,6 +265,14 @@ EVS_API int evs_aprx_create(evs_aprx **out, int64_t capacity, int n_tables);
 EVS_API int evs_aprx_destroy(evs_aprx *p);
 EVS_API int evs_aprx_set_altkeys(evs_aprx *p, const uint32_t *const *alt_tables, const int64_t *n_rows);
 EVS_API int evs_aprx_stats(evs_aprx *p, int64_t *out4 /* size, n_hit, n_pending, error */, void *stream);
+/* APRX_EV's public single-key methods applied in order (the part of the tier that IS pinned to the compiled reference,
+ * driven single-threaded): ops = n x (op, table_1based, row), op 0 insert_altkey (aprx_embedding.cpp:278-288: evict one
+ * when full, push on the FIFO, map[key] = {alt key of the row, false}), 1 get_altkey_str (:341-350), 2 set_recency_flag_c3
+ * (:402-411), 3 evict_one_key (:390-400, second chance :360-388).  res[i] (device): op 0 the alt key, op 1 the alt key or
+ * 0xffffffff on a miss, else 0.  evs_aprx_dump_queue: the FIFO front to back as (table_1based, row) pairs (host),
+ * stale duplicates included (print_all_keys_in_c3, :430-434); returns its length. */
+EVS_API int evs_aprx_apply_ops(evs_aprx *p, int64_t n, const int32_t *ops, uint32_t *res, void *stream);
+EVS_API int64_t evs_aprx_dump_queue(evs_aprx *p, int64_t *pairs, int64_t max_pairs, void *stream);
 /* evs_cache_request_c1c2 with the alt-key tier (c3 may be NULL = plain two tiers). */
 EVS_API int evs_cache_request_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows,
                                      float *out, uint8_t *tier, int high_agghit_threshold, void *stream);

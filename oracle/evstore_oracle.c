@@ -850,6 +850,52 @@ static void aprx_queue_key(orc_aprx *x, uint64_t key) {
        and one request evicts at most 2*T <= 128 keys -> keep the first 50, count the overflow as dropped */
     if (x->n_pending == ORC_APRX_BATCH) x->batch_ready = 1;
 }
+/* The tier's public single-key methods, for the ops that CAN be pinned to the reference (driven single-threaded by
+ * oracle/ref/ref_aprx_driver.cpp): op 0 insert_altkey (aprx_embedding.cpp:278-288: evict one when full, push the key on
+ * the FIFO -- duplicates allowed --, map[key] = {alt from the alt-key file, false}), 1 get_altkey_str (:341-350),
+ * 2 set_recency_flag_c3 (:402-411), 3 evict_one_key (:390-400).  Same aprx_evict_one / map / FIFO as the request path.
+ * ops: n x (op, table_1based, row); res: n x uint32 (op 0: the alt key; op 1: the alt key or 0xffffffff; else 0). */
+void orc_aprx_apply_ops(orc_aprx *x, int64_t n, const int32_t *ops, uint32_t *res) {
+    for (int64_t i = 0; i < n; i++) {
+        const int op = ops[3 * i];
+        const uint64_t key = ((uint64_t)(uint32_t)ops[3 * i + 1] << 32) | (uint32_t)ops[3 * i + 2];
+        res[i] = 0;
+        if (op == 0) {
+            const uint32_t alt = x->alt_tables[ops[3 * i + 1] - 1][(uint32_t)ops[3 * i + 2]];
+            if (x->count >= x->cap) aprx_evict_one(x);
+            if (x->qtail - x->qhead >= x->qcap) { x->error = 1; return; }
+            x->queue[x->qtail % x->qcap] = key; x->qtail++;
+            int32_t e = map_get(&x->map, key);
+            if (e < 0) {
+                if (x->n_free <= 0) { x->error = 2; return; }
+                e = x->free_stack[--x->n_free];
+                x->ekey[e] = key;
+                map_put(&x->map, key, e);
+                x->count++;
+            }
+            x->ealt[e] = alt; x->eflag[e] = 0;
+            res[i] = alt;
+        } else if (op == 1) {
+            const int32_t e = map_get(&x->map, key);
+            res[i] = e >= 0 ? x->ealt[e] : 0xffffffffu;
+        } else if (op == 2) {
+            const int32_t e = map_get(&x->map, key);
+            if (e >= 0) x->eflag[e] = 1;
+        } else if (op == 3) {
+            aprx_evict_one(x);
+        }
+    }
+}
+/* the FIFO front to back as (table_1based, row) pairs, stale duplicates included (print_all_keys_in_c3, :430-434) */
+int64_t orc_aprx_dump_queue(const orc_aprx *x, int64_t *pairs, int64_t max_pairs) {
+    int64_t n = 0;
+    for (int64_t q = x->qhead; q < x->qtail; q++, n++)
+        if (pairs && n < max_pairs) {
+            pairs[2 * n] = (int64_t)(x->queue[q % x->qcap] >> 32);
+            pairs[2 * n + 1] = (int64_t)(x->queue[q % x->qcap] & 0xffffffffu);
+        }
+    return n;
+}
 void orc_aprx_state(const orc_aprx *x, int64_t *out4) { out4[0] = x->count; out4[1] = x->n_hit; out4[2] = x->n_pending; out4[3] = x->error; }
 
 /* request_to_c1_c2_c3 (evlfu_8.cpp:492-667).  tier_out: 1 C1 hit, 2 C2 hit, 3 alt-key hit, 0 miss. */

@@ -61,6 +61,9 @@ def lib():
         L.orc_aprx_new.argtypes = [C.c_int64, C.POINTER(C.c_void_p), C.c_int]
         L.orc_aprx_free.argtypes = [C.c_void_p]
         L.orc_aprx_state.argtypes = [C.c_void_p, _i64p]
+        L.orc_aprx_apply_ops.argtypes = [C.c_void_p, C.c_int64, _i32p, C.POINTER(C.c_uint32)]
+        L.orc_aprx_dump_queue.restype = C.c_int64
+        L.orc_aprx_dump_queue.argtypes = [C.c_void_p, _i64p, C.c_int64]
         L.orc_c1c2c3_request.restype = C.c_int
         L.orc_c1c2c3_request.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _i32p, _u8p, _f32p, C.c_int]
         for p in ("lru", "lfu"):
@@ -332,6 +335,41 @@ class C1C2:
         if rc < 0:
             raise RuntimeError("orc_c1c2_request rc=%d" % rc)
         return self._tier.copy(), self._out, rc
+
+
+class AltKeyTier:
+    """The alt-key tier alone, through APRX_EV's public single-key methods (aprx_embedding.cpp:278-288,341-350,390-411);
+    PINNED to the reference driven single-threaded (tests/golden/aprx_ops.npz).  ops: (n,3) int32 rows of
+    (op, table_1based, row), op 0 insert | 1 lookup | 2 set recency flag | 3 evict one."""
+
+    def __init__(self, cap, alt_tables):
+        self._alt = [np.ascontiguousarray(a, np.uint32) for a in alt_tables]
+        arr = (C.c_void_p * len(self._alt))(*[a.ctypes.data for a in self._alt])
+        self._h = lib().orc_aprx_new(cap, arr, len(self._alt))
+        if not self._h:
+            raise ValueError("alt-key tier capacity must be >= 50")
+
+    def apply(self, ops):
+        ops = np.ascontiguousarray(ops, np.int32).reshape(-1, 3)
+        res = np.zeros(len(ops), np.uint32)
+        lib().orc_aprx_apply_ops(self._h, len(ops), _p(ops, _i32p), _p(res, C.POINTER(C.c_uint32)))
+        return res
+
+    def queue(self):
+        n = lib().orc_aprx_dump_queue(self._h, None, 0)
+        out = np.zeros((n, 2), np.int64)
+        lib().orc_aprx_dump_queue(self._h, _p(out, _i64p), n)
+        return out
+
+    def state(self):
+        s = np.zeros(4, np.int64)
+        lib().orc_aprx_state(self._h, _p(s, _i64p))
+        return dict(size=int(s[0]), n_hit=int(s[1]), n_pending=int(s[2]), error=int(s[3]))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_aprx_free(self._h)
+            self._h = None
 
 
 class C1C2C3(C1C2):

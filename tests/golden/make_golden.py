@@ -548,7 +548,71 @@ os._exit(0)
     print("wrote mgr_variants")
 
 
+# --------------------------------------------------------------------------
+# a12: the alt-key tier APRX_EV driven SINGLE-THREADED through its public methods
+# (oracle/_ref/ref_aprx_driver = mixed_precs_caching/aprx_embedding.cpp + oracle/ref/ref_aprx_driver.cpp)
+# --------------------------------------------------------------------------
+APRX_ROWS, APRX_SEED = 400, 23
+APRX_CASES = [(50, 2500), (64, 3000), (257, 6000)]   # (capacity, number of ops)
+
+
+def aprx_inputs():
+    """alt-key tables (uint32: alt_row*100 + alt_table_1based) and one op stream per case, from the seed."""
+    rs = np.random.RandomState(APRX_SEED)
+    alt = [(rs.randint(0, APRX_ROWS, size=APRX_ROWS) * 100 + rs.randint(1, 27, size=APRX_ROWS)).astype(np.uint32)
+           for _ in range(26)]
+    cases = []
+    for cap, n in APRX_CASES:
+        ops = np.zeros((n, 3), np.int32)
+        hot = [(int(rs.randint(1, 27)), int(rs.randint(0, APRX_ROWS))) for _ in range(cap)]
+        for i in range(n):
+            u = rs.rand()
+            op = 0 if u < 0.45 else (1 if u < 0.75 else (2 if u < 0.97 else 3))
+            if rs.rand() < 0.6:
+                t, r = hot[rs.randint(len(hot))]
+            else:
+                t, r = int(rs.randint(1, 27)), int(rs.randint(0, APRX_ROWS))
+            ops[i] = (op, t, r)
+        cases.append((cap, ops))
+    return alt, cases
+
+
+def gen_aprx_ops():
+    import subprocess
+    orc = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle")
+    subprocess.check_call(["make", "-s", "-C", orc, "ref"])
+    alt, cases = aprx_inputs()
+    root = tempfile.mkdtemp(prefix="evs_aprx_")
+    adir = os.path.join(root, "stored_model", "criteo_kaggle_all", "alternative-keys", "1000n-euclid003-newrank", "binary")
+    os.makedirs(adir)
+    for k, a in enumerate(alt):
+        a.astype(">u4").tofile(os.path.join(adir, "ev-table-%d.bin" % (k + 1)))   # convert_altkeys_to_binary.py:34,49
+    out = {"n_rows": np.int64(APRX_ROWS), "seed": np.int64(APRX_SEED)}
+    for cap, ops in cases:
+        fo = os.path.join(root, "ops.bin")
+        with open(fo, "wb") as f:
+            f.write(struct.pack("<ii", len(ops), cap))
+            f.write(ops.tobytes())
+        res = os.path.join(root, "res.bin")
+        p = subprocess.run([os.path.join(orc, "_ref", "ref_aprx_driver"), fo, res], capture_output=True, text=True,
+                           env=dict(os.environ, EVS_REF_ROOT=root), timeout=600)
+        assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
+        r = np.fromfile(res, np.uint32)
+        qline = p.stdout.split("=" * 52)[-1].split()
+        q = np.asarray([[int(v) for v in k.split("-")] for k in qline], np.int64).reshape(-1, 2)
+        out["cap%d_ops" % cap] = ops
+        out["cap%d_res" % cap] = r
+        out["cap%d_queue" % cap] = q
+        print("aprx cap", cap, "ops", len(ops), "lookup hits", int(((ops[:, 0] == 1) & (r != 0xffffffff)).sum()),
+              "of", int((ops[:, 0] == 1).sum()), "queue", len(q))
+    np.savez_compressed(os.path.join(HERE, "aprx_ops.npz"), **out)
+    print("wrote aprx_ops")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "aprx":
+        gen_aprx_ops()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "variants":
         gen_mgr_variants()
         return
@@ -585,6 +649,7 @@ def main():
     gen_c1c2()
     gen_cython_traces()
     gen_mgr_variants()
+    gen_aprx_ops()
 
 
 if __name__ == "__main__":

@@ -545,6 +545,27 @@ def test_batched_two_tier_c1c2(E, orc, thr):
                 assert np.array_equal(rb[b, k].view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("cap", [50, 64, 257])
+def test_altkey_tier_ops_match_reference_driven_single_threaded(E, orc, cap):
+    """a12, the pinnable part: APRX_EV's public methods (insert_altkey / get_altkey_str / set_recency_flag_c3 /
+    evict_one_key) on the GPU tier against the COMPILED reference driven single-threaded (tests/golden/aprx_ops.npz):
+    lookup results, alt keys and the final FIFO order bit-exact."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as G
+    g = load_golden("aprx_ops")
+    alt = G.aprx_inputs()[0]
+    t = E.GpuAltKeyTier(cap, [torch.from_numpy(a.view(np.int32).copy()).cuda() for a in alt])
+    ops = torch.from_numpy(g["cap%d_ops" % cap].astype(np.int32)).cuda().contiguous()
+    half = len(ops) // 2       # two calls: the state carries over
+    res = torch.cat([t.apply_ops(ops[:half].contiguous()), t.apply_ops(ops[half:].contiguous())])
+    st = t.stats()
+    assert st["error"] == 0 and st["size"] <= cap
+    np.testing.assert_array_equal(res.cpu().numpy().astype(np.uint32), g["cap%d_res" % cap])
+    np.testing.assert_array_equal(t.queue().numpy(), g["cap%d_queue" % cap])
+
+
 def test_three_tier_c1c2c3_vs_oracle(E, orc):
     """a12: request_to_c1_c2_c3 with the alt-key tier (deterministic re-specification) == the oracle:
     tier codes (incl. 3 = alt-key hit), values, both tiers' final lists, C3 counters."""

@@ -343,3 +343,29 @@ def test_single_tier_precision_builds_perfect_hits(var):
     nb = (fill_at if fill_at is not None else len(reqs)) // blk
     assert nb >= 1 and perfect[:nb] == ref[:nb]
     assert abs(sum(perfect) - sum(ref)) <= max(8, 0.4 * sum(ref)), (sum(perfect), sum(ref))
+
+
+# ------------------------------------------------------------------ a12: the alt-key tier's single-key methods
+def _aprx_alt_tables():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as G
+    return G.aprx_inputs()[0]
+
+
+@pytest.mark.parametrize("cap", [50, 64, 257])
+def test_altkey_tier_ops_match_reference_driven_single_threaded(cap):
+    """APRX_EV's public methods (insert_altkey, get_altkey_str, set_recency_flag_c3, evict_one_key;
+    aprx_embedding.cpp:278-288,341-350,360-411) of the COMPILED reference, driven from one thread by
+    oracle/ref/ref_aprx_driver.cpp: every lookup result, every alt key decoded from the big-endian files, and the
+    final FIFO (stale duplicates included) equal the oracle's.  What stays unpinned: WHEN an evicted-key batch
+    becomes visible (5 racing threads) and insert_altkey_batched_obj itself (uninitialised loop counters)."""
+    g = load_golden("aprx_ops")
+    alt = _aprx_alt_tables()
+    t = orc.AltKeyTier(cap, alt)
+    ops = g["cap%d_ops" % cap]
+    res = t.apply(ops)
+    assert t.state()["error"] == 0
+    np.testing.assert_array_equal(res, g["cap%d_res" % cap])
+    np.testing.assert_array_equal(t.queue(), g["cap%d_queue" % cap])
+    assert t.state()["size"] <= cap
