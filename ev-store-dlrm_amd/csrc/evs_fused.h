@@ -1,0 +1,39 @@
+// Shared between the fused gather + interaction kernels (evs_fused.hip, evs_fused_rf.hip).
+#pragma once
+#include "evs_common.h"
+
+namespace evs {
+
+struct FusedArgs {
+    const void *src[EVS_MAX_FEATURES];        // dense: fp32 rows; indirect: table bytes
+    int64_t stride[EVS_MAX_FEATURES];         // dense: floats between samples
+    const int64_t *indices[EVS_MAX_FEATURES]; // NULL => dense
+    const int64_t *offsets[EVS_MAX_FEATURES];
+    int64_t nnz[EVS_MAX_FEATURES];
+    int64_t n_rows[EVS_MAX_FEATURES];
+    int64_t off_len[EVS_MAX_FEATURES];
+    const float *row_w[EVS_MAX_FEATURES];
+    float *R;
+    int64_t B;
+    int F, d, itself, P;
+    int *err;
+    const int64_t *dummy_i64;  // any readable int64 (lanes with nothing to fetch read it)
+    const float *dummy_f32;
+    const void *zeros;         // >= 1 KiB of zero bytes (idle lanes / empty bags read rows from it)
+    int bag1;                  // 1: every indirect feature has one index per bag, no offsets array;
+                               // 2: offsets ARE given and the launch bets they are arange (see opt_flag);
+                               // 3: offsets given, whole batch: the index-tile loop checks them chunk by chunk itself
+    int *opt_flag; int opt_id; // optimistic launch triple: offsets_arange_kernel writes opt_id here when an offsets
+                               // array is not arange; then the bag-1 loop runs if it is absent, the general loop if present
+    int enc_lds;               // reduced precision: feature 0 is x, every other feature a 4-byte aligned table
+    int tile_per;              // index-tile kernel: samples per block (block i owns [i * tile_per, (i + 1) * tile_per))
+};
+
+
+constexpr int kTileMaxF = 28;   // index-tile launches: x + at most 27 tables
+
+// evs_fused_rf.hip: the rows-in-flight-in-registers form of the bag-1 index-tile loop (fp32 tables, d in {16, 32, 36},
+// F <= kTileMaxF); returns false when it has no kernel for the shape (the caller then uses the LDS-DMA loop)
+bool launch_rf(const FusedArgs &a, hipStream_t st);
+
+}  // namespace evs

@@ -25,35 +25,11 @@
 //   C/D layout: lane holds Z[i = 4*(lane>>4)+v][j = lane&15] -> row-major strict lower
 //   triangle at R[b][d + i(i-1)/2 + j].
 #include "evs_common.h"
+#include "evs_fused.h"
 
 #include <stdlib.h>
 
 namespace evs {
-
-struct FusedArgs {
-    const void *src[EVS_MAX_FEATURES];        // dense: fp32 rows; indirect: table bytes
-    int64_t stride[EVS_MAX_FEATURES];         // dense: floats between samples
-    const int64_t *indices[EVS_MAX_FEATURES]; // NULL => dense
-    const int64_t *offsets[EVS_MAX_FEATURES];
-    int64_t nnz[EVS_MAX_FEATURES];
-    int64_t n_rows[EVS_MAX_FEATURES];
-    int64_t off_len[EVS_MAX_FEATURES];
-    const float *row_w[EVS_MAX_FEATURES];
-    float *R;
-    int64_t B;
-    int F, d, itself, P;
-    int *err;
-    const int64_t *dummy_i64;  // any readable int64 (lanes with nothing to fetch read it)
-    const float *dummy_f32;
-    const void *zeros;         // >= 1 KiB of zero bytes (idle lanes / empty bags read rows from it)
-    int bag1;                  // 1: every indirect feature has one index per bag, no offsets array;
-                               // 2: offsets ARE given and the launch bets they are arange (see opt_flag);
-                               // 3: offsets given, whole batch: the index-tile loop checks them chunk by chunk itself
-    int *opt_flag; int opt_id; // optimistic launch triple: offsets_arange_kernel writes opt_id here when an offsets
-                               // array is not arange; then the bag-1 loop runs if it is absent, the general loop if present
-    int enc_lds;               // reduced precision: feature 0 is x, every other feature a 4-byte aligned table
-    int tile_per;              // index-tile kernel: samples per block (block i owns [i * tile_per, (i + 1) * tile_per))
-};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -457,7 +433,6 @@ __global__ void __launch_bounds__(256) emb_interact_dot_kernel(const FusedArgs a
 #ifndef EVS_LB_TILE
 #define EVS_LB_TILE 5
 #endif
-constexpr int kTileMaxF = 28;
 template <int CODEC, int CQ, bool BAG1, bool TILE = false, bool CHECK = false>
 constexpr int lds_min_blocks() {
     if (CHECK && CQ < 4) return 4;          // (bag starts / ends in flight + the slow loop: 110 VGPRs at d = 36)
@@ -836,6 +811,10 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
                 if (j * RPI >= F) break;   // rows >= F only feed accumulator elements that are never stored
                 const unsigned long long p = __shfl(pub, dma_src[j] < 0 ? 0 : dma_src[j]);
                 const char *g = dma_src[j] < 0 ? zeros_l : reinterpret_cast<const char *>(p) + dma_piece * 16;
+#ifdef EVS_X_NODMA   // developer A/B: everything but the row fetch (the slot keeps whatever it holds)
+                if (g == reinterpret_cast<const char *>(0x1234)) args.R[lane] = 1.f;
+                continue;
+#endif
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                                  (__attribute__((address_space(3))) void *)(my_lds + j * 1024), 16, 0, 0);
             }
@@ -844,6 +823,14 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
 
     // the interaction of one sample (operands in the MFMA layout) and the staging of its output row
     auto interact = [&](const float4 (&a)[NR][NC], f32x4 &c00, f32x4 &c10, f32x4 &c11) {
+#ifdef EVS_X_NOMFMA   // developer A/B: the matrix-core work replaced by three adds per operand chunk
+        c00 = f32x4{0.f, 0.f, 0.f, 0.f}; c10 = c00; c11 = c00;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            c00[c & 3] += a[0][c].x + a[0][c].y; c10[c & 3] += a[NR - 1][c].z; c11[c & 3] += a[NR - 1][c].w + a[0][c].z;
+        }
+        return;
+#endif
         c00 = f32x4{0.f, 0.f, 0.f, 0.f}; c10 = f32x4{0.f, 0.f, 0.f, 0.f}; c11 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -1184,6 +1171,7 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
             if constexpr (HAS_INDIRECT && !WEIGHTED) {
                 if constexpr (!PTRS && CODEC == 32) {   // (encoded rows: no gain for u8 / u4, slower for u16 -- measured)
                     if (a.bag1 == 1 && tile_eligible(a, CODEC)) {
+                        if (launch_rf(a, st)) return;   // rows in flight in registers (evs_fused_rf.hip): d = 16 / 32 / 36
                         if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                         else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                         return;

@@ -1,0 +1,307 @@
+// Fused embedding gather + pairwise-dot interaction, "rows in flight in registers" form of the bag-1 index-tile loop.
+//
+// Same computation and the same bits as emb_interact_dot_lds_kernel<..., BAG1, TILE> (evs_fused.hip):
+//     R[b] = [ x[b] | strict-lower(T[b] T[b]^T) ],  T[b] = [x[b]; W_0[idx_0[b]]; ...; W_{F-2}[idx_{F-2}[b]]]
+// (dlrm_s_pytorch.py:407-461 apply_emb with one index per bag -- the Criteo collate, dlrm_data_pytorch.py:407-408 --
+//  followed by :483-516 interact_features), one wavefront per sample, MFMA 16x16x4 f32 chains, output row staged
+// in LDS and written one iteration later.  What changes is WHERE a sample's rows wait while they travel:
+//
+//   LDS-DMA loop:  the rows of sample k+1 are DMA'd into the wave's single 4 KiB LDS slot while sample k computes: one
+//                  sample in flight per wave, and a 16 384-sample launch (4 samples per wave) is a chain of 4 memory
+//                  round trips per wave plus fill and drain.
+//   this kernel:   a block owns ONE 16-sample chunk; the rows of all 4 samples of a wave are requested at once and
+//                  travel in REGISTERS, in the DMA-shaped mapping (LPRD = d/4 consecutive lanes fetch one row as d*4
+//                  contiguous bytes with one global_load_dwordx4 each; 64/LPRD rows per instruction, every line
+//                  requested once): 16 VGPRs hold one d=36 sample.  The LDS slot is only the transpose buffer between
+//                  that mapping and the MFMA operand mapping (ds_write_b128 x 4, ds_read_b128 x 6 per sample).  The
+//                  code is straight-line, so hipcc's own counted s_waitcnt vmcnt(15..12) consumes sample u while
+//                  samples u+1.. stay in flight (with any branch around a memory operation the waitcnt pass takes the
+//                  minimum over paths and drains everything: measured).
+// Used for batches whose blocks are all resident at once (B <= 16 x 4 x 256 = 16 384); larger batches keep the LDS-DMA
+// loop, whose steady state is bound by the per-CU vector-memory / LDS pipes rather than by latency.
+// Measured (same box, A/B by EVS_FUSED_RF): B = 16 384: 20.5 -> 18.9 us, B = 8 192: 12.5 -> 11.4 us.
+//
+// Row addresses need no cross-lane traffic here: the index tile in LDS has one row PER FEATURE (x and dense features
+// carry the sample number as their "index"), and a lane of the DMA mapping reads the tile entry of the row it fetches.
+#include "evs_fused.h"
+
+#include <stdlib.h>
+
+namespace evs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4 *gf4_t;
+
+#ifndef EVS_RF_DEPTH
+#define EVS_RF_DEPTH 4
+#endif
+#ifndef EVS_RF_LB
+#define EVS_RF_LB 4
+#endif
+#ifndef EVS_OUT_CPOL
+#define EVS_OUT_CPOL 2   // nt: R is written once and streams out (see evs_fused.hip)
+#endif
+
+template <int CQ, int REM, int NT, int D>
+__global__ void __launch_bounds__(256, EVS_RF_LB) emb_interact_rf_kernel(const FusedArgs args) {
+    constexpr int NR = NT;
+    constexpr int NC = CQ + REM;
+    constexpr int d = 4 * (4 * CQ + REM);
+    constexpr int LPRD = d / 4;             // lanes per fp32 row (16 B each)
+    constexpr int RPI = 64 / LPRD;          // rows per load instruction
+    constexpr int NROWS = 16 * NT;
+    constexpr int MAXF = NT == 2 ? kTileMaxF : 16;
+    constexpr int NJ = (MAXF + RPI - 1) / RPI;   // load instructions per sample
+    constexpr int row_bytes = d * 4;
+    static_assert(NJ * RPI <= 32, "a tile row per fetched row");
+    __shared__ __attribute__((aligned(16))) char s_rows[4][NJ * 1024];   // per wave: transpose buffer (DMA image of one sample)
+    __shared__ int s_idx[2 * 512];                                        // [2][32 features][16 samples]: row id, sample id (dense), -1 = zeros
+    __shared__ const int64_t *s_tile_p[32];
+    __shared__ unsigned s_tile_nr[32];
+    __shared__ int s_tile_kind[32];                                       // 0 absent, 1 dense (x, received pooled vectors), 2 table
+    __shared__ unsigned long long s_feat_base[32];                        // per feature: first row / bytes between rows -- read per
+    __shared__ unsigned s_feat_scale[32];                                 // load instead of living in 12 VGPRs per lane
+    constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
+    __shared__ __attribute__((aligned(16))) float s_out[4][OUT_MAX + 16];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int F = args.F, itself = args.itself;
+    const int out_row = d + args.P;
+    const int64_t B = args.B;
+    const FusedArgs *ka = (const FusedArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    char *my_lds = s_rows[wave_in_block];
+    float *my_out = s_out[wave_in_block];
+    const char *zeros_l = reinterpret_cast<const char *>(args.zeros);
+
+    // ---- the block's sample range and the feature table of the tile ------------------------------------
+    const int64_t per = args.tile_per;
+    const int64_t blk_first = (int64_t)blockIdx.x * per;
+    const int64_t blk_end = blk_first + per < B ? blk_first + per : B;
+    if (blk_first >= blk_end) return;       // block-uniform
+    const int blk_n = (int)(blk_end - blk_first);
+    const int n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
+    if (threadIdx.x < 32) {
+        const int f = (int)threadIdx.x;
+        const int64_t *ip = f < F ? ka->indices[f] : nullptr;
+        s_tile_p[f] = ip;
+        s_tile_nr[f] = f < F ? (unsigned)ka->n_rows[f] : 0u;
+        s_tile_kind[f] = f >= F ? 0 : (ip ? 2 : 1);
+        s_feat_base[f] = f < F ? (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]) : 0ull;
+        s_feat_scale[f] = f >= F ? 0u : (ip ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4));
+    }
+    __syncthreads();
+
+    // ---- DMA-shaped mapping: for load j this lane fetches piece dma_piece of row j*RPI + dma_r0.  Lanes past the last
+    // whole row of an instruction (lane 63 at d = 36) mirror the last piece: the same 16 bytes, one request, and their
+    // copy lands in the padding of the 1 KiB image block.  Rows >= F have tile entries -1 and read the zero page.
+    const int lane_eff = lane < RPI * LPRD ? lane : RPI * LPRD - 1;
+    const int dma_piece16 = (lane_eff % LPRD) * 16;
+    const int dma_r0 = lane_eff / LPRD;
+    // ---- MFMA operand mapping (as the LDS-DMA loop: row r at (r / RPI) KiB + (r % RPI) * row_bytes) -------
+    int lds_off[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const int row = r16 + 16 * rr;
+        lds_off[rr] = (row / RPI) * 1024 + (row % RPI) * row_bytes + q * CQ * 16;
+    }
+    constexpr int kRemOff = 4 * CQ * 16;
+    constexpr int kOob = 0x7ffffff0;
+    // (`on` false: a zero-length buffer resource, the hardware drops every store -- the loop body has no branch around
+    //  its vector-memory operations, see the main loop)
+    auto flush_out = [&](int64_t bp, bool on) {
+        float *Rb = args.R + (on ? bp : 0) * (int64_t)out_row;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, on ? out_row * 4 : 0, 0x00020000);
+        const int n4 = out_row >> 2;   // whole 16-byte pieces; the 0..3 trailing floats go as dwords
+        // (always the same number of store instructions: out-of-range lanes and whole out-of-range instructions are
+        //  dropped by the buffer bounds check, and the waitcnt bookkeeping stays static)
+#pragma unroll
+        for (int h = 0; h < (OUT_MAX + 255) / 256; h++) {
+            const int e4 = lane + 64 * h;
+            const float4 v = reinterpret_cast<const float4 *>(my_out)[e4 < n4 ? e4 : 0];
+            u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, EVS_OUT_CPOL);
+        }
+        {
+            const int e = 4 * n4 + (lane & 3);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, EVS_OUT_CPOL);
+        }
+    };
+
+    // ---- index tiles: thread e (and e + 256) owns tile element (feature e >> 4, sample-in-chunk e & 15) ----
+    bool bad = false;
+    int64_t tile_v[2] = {-1, -1};
+    const int64_t *dummy_i = args.dummy_i64;   // any readable int64 (lanes with nothing to load read it)
+    auto tile_load = [&](int c) {       // chunk c of the block -> registers; no branch, no use of the value before tile_store
+        const int64_t bs = blk_first + 16 * (int64_t)c + (threadIdx.x & 15);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            const bool table = s_tile_kind[f] == 2 && bs < blk_end;
+            const int64_t *ap = table ? s_tile_p[f] + bs : dummy_i;
+            // (explicitly global: a flat load would force every later wait to vmcnt(0))
+            tile_v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(ap));
+        }
+    };
+    auto tile_store = [&](int c) {      // registers -> tile buffer c & 1
+        const int64_t bs = blk_first + 16 * (int64_t)c + (threadIdx.x & 15);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            const int kind = s_tile_kind[f];
+            const bool live = kind != 0 && bs < blk_end && c >= 0;
+            const int64_t v = kind == 2 ? tile_v[h] : bs;       // dense features (x, received pooled vectors): the sample number
+            const bool in_range = kind == 1 || (uint64_t)v < (uint64_t)s_tile_nr[f];
+            bad |= live & !in_range;
+            s_idx[(c & 1) * 512 + (int)threadIdx.x + 256 * h] = (live & in_range) ? (int)v : -1;
+        }
+    };
+
+    // ---- the rows of this wave's sample n -> registers (D samples in flight) ----------------------------
+    f32x4 ring[D][NJ];
+    auto issue = [&](int n, f32x4 (&slot)[NJ]) {
+        const int m = wave_in_block + 4 * n;              // block-local sample
+        const int tb = ((m >> 4) & 1) * 512 + (m & 15);
+        const unsigned phantom = (unsigned)n < (unsigned)n_samples ? 0u : 0xffffffffu;   // past this wave's samples: every lane reads the zero page
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int r = dma_r0 + j * RPI;               // < 32: tile rows >= F hold -1
+            const int iv = s_idx[tb + r * 16];
+            // branch-free on purpose (bit blend, not a select: the compiler turns a select over these LDS reads into
+            // control flow and serialises the four loads): -1 -> the zero page
+            const unsigned neg = (unsigned)(iv >> 31) | phantom;
+            const unsigned long long p = s_feat_base[r] + (unsigned long long)((unsigned)iv & ~neg) * (unsigned long long)s_feat_scale[r] + dma_piece16;
+            const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
+            const unsigned long long pa = p ^ ((p ^ (unsigned long long)reinterpret_cast<uintptr_t>(zeros_l)) & m64);
+            slot[j] = *reinterpret_cast<gf4_t>((uintptr_t)pa);
+        }
+    };
+    auto interact = [&](const float4 (&a)[NR][NC], f32x4 &c00, f32x4 &c10, f32x4 &c11) {
+        c00 = f32x4{0.f, 0.f, 0.f, 0.f}; c10 = f32x4{0.f, 0.f, 0.f, 0.f}; c11 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float e0[4] = {a[0][c].x, a[0][c].y, a[0][c].z, a[0][c].w};
+            const float e1[4] = {a[NR - 1][c].x, a[NR - 1][c].y, a[NR - 1][c].z, a[NR - 1][c].w};
+            if (c < CQ) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[e], e0[e], c00, 0, 0, 0);
+                    if constexpr (NT == 2) {
+                        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e0[e], c10, 0, 0, 0);
+                        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e1[e], c11, 0, 0, 0);
+                    }
+                }
+            } else {   // the REM trailing chunks are held by all four k-slots; slot q contributes element q
+                const float s0 = q == 0 ? e0[0] : q == 1 ? e0[1] : q == 2 ? e0[2] : e0[3];
+                const float s1 = q == 0 ? e1[0] : q == 1 ? e1[1] : q == 2 ? e1[2] : e1[3];
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, s0, c00, 0, 0, 0);
+                if constexpr (NT == 2) {
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s0, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s1, c11, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- one chunk, straight line -------------------------------------------------------------------------
+    // index tile of the block's 16 samples -> LDS; the rows of ALL of this wave's samples (at most 4) are requested at
+    // once; the samples are consumed in order as their rows arrive (counted vmcnt: no branch, so hipcc's waitcnt
+    // insertion keeps the younger samples in flight); the output row of sample u leaves under the MFMAs of sample u+1.
+    static_assert(D == 4, "a block owns one 16-sample chunk: 4 samples per wave");
+    tile_load(0);
+    tile_store(0);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < D; u++) issue(u, ring[u]);      // (samples past the block's end: every lane reads the zero page)
+    __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink three of the four requests below the first consume
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;   // wave-uniform
+        // the image of sample u: what the row DMA of the LDS loop would have left in the slot
+#pragma unroll
+        for (int j = 0; j < NJ; j++) *reinterpret_cast<f32x4 *>(my_lds + j * 1024 + lane * 16) = ring[u][j];
+        float4 a[NR][NC];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+            for (int c = 0; c < CQ; c++) a[rr][c] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] + c * 16);
+#pragma unroll
+            for (int m = 0; m < REM; m++)
+                a[rr][CQ + m] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] - q * CQ * 16 + kRemOff + m * 16);
+        }
+        float xv[(d + 63) / 64];   // x[b] is row 0 of the image
+#pragma unroll
+        for (int h = 0; h < (d + 63) / 64; h++) {
+            const int e = lane + 64 * h;
+            xv[h] = reinterpret_cast<const float *>(my_lds)[e < d ? e : 0];
+        }
+        flush_out(b - 4, u > 0 && u - 1 < n_samples);    // sample u-1 leaves under the MFMAs of sample u
+        f32x4 c00, c10, c11;
+        interact(a, c00, c10, c11);
+        // stage the output row: x passthrough, then the packed lower triangle straight from the accumulators
+#pragma unroll
+        for (int h = 0; h < (d + 63) / 64; h++) {
+            const int e = lane + 64 * h;
+            my_out[e < d ? e : OUT_MAX + r16] = xv[h];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {   // never-stored elements go to a dump slot behind the row
+            const int i = 4 * q + v;
+            const int dump = 4 * (OUT_MAX + r16);
+            const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
+            if constexpr (NT == 2) {
+                const int gi = 16 + i;
+                const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+                const int zo10 = gi < F ? 4 * (d + base + r16) : dump;
+                const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = c10[v];
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[v];
+            }
+        }
+    }
+    flush_out(blk_first + wave_in_block + 12, n_samples == 4);
+    if (bad) atomicOr(args.err, 1);
+}
+
+static int rf_mode() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_RF"); v = e ? atoi(e) : 1; }   // developer switch: 0 = the LDS-DMA loop
+    return v;
+}
+
+template <auto K>
+static void launch_rf_grid(FusedArgs a, hipStream_t st) {
+    a.tile_per = 16;   // one 16-sample chunk per block: 4 samples per wave, all requested at once
+    hipLaunchKernelGGL(K, dim3((unsigned)((a.B + 15) / 16)), dim3(256), 0, st, a);
+}
+
+// the batch sizes this form is for: every block resident at once (4 blocks of 256 threads per CU at 128 VGPRs)
+static int64_t rf_max_batch() {
+    static int64_t v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_RF_MAX_B"); v = e ? atoll(e) : 16ll * kNumCu * EVS_RF_LB; }
+    return v;
+}
+
+bool launch_rf(const FusedArgs &a, hipStream_t st) {
+    if (!rf_mode() || a.F > kTileMaxF || a.bag1 != 1 || a.B > rf_max_batch()) return false;
+    const bool nt2 = a.F > 16;
+    switch (a.d) {
+    case 16:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<1, 0, 2, EVS_RF_DEPTH>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<1, 0, 1, EVS_RF_DEPTH>>(a, st);
+        return true;
+    case 32:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 0, 2, EVS_RF_DEPTH>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 0, 1, EVS_RF_DEPTH>>(a, st);
+        return true;
+    case 36:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 1, 2, EVS_RF_DEPTH>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 1, 1, EVS_RF_DEPTH>>(a, st);
+        return true;
+    default:
+        return false;
+    }
+}
+
+}  // namespace evs
