@@ -73,16 +73,44 @@ def make_batches(ln_emb, B, n_batches, seed, device, dist="uniform", alpha=1.05)
     return out
 
 
-def cpu_baseline(ev, ln_emb, d, seconds=12.0):
+def physical_cores():
+    """(physical cores, logical CPUs) of this host from /proc/cpuinfo (distinct (physical id, core id) pairs)."""
+    logical = os.cpu_count() or 1
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        n = len(pairs) or logical
+    except OSError:
+        n = logical
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return max(1, n), logical
+
+
+def cpu_baseline(ev, ln_emb, d, B, seconds=12.0):
     """The reference's CPU path (per-table nn.EmbeddingBag loop + cat/bmm/tril gather,
-    dlrm_s_pytorch.py:407-461,:483-516) restated in oracle/dlrm_cpu.py, timed on the host cores."""
+    dlrm_s_pytorch.py:407-461,:483-516) restated in oracle/dlrm_cpu.py, timed on the host cores at the GPU's batch size
+    with one torch thread per PHYSICAL core (same batch sizes; the upstream recipe pins one socket's cores)."""
     from oracle import dlrm_cpu
-    B = 2048
+    cores, logical = physical_cores()
+    torch.set_num_threads(cores)
     tables = [ev.fp32_view(k).cpu() for k in range(len(ln_emb))]
     model = dlrm_cpu.CpuHotPath(tables)
     g = torch.Generator().manual_seed(1)
     batches = []
-    for _ in range(4):
+    for _ in range(2):
         lS_i = torch.stack([torch.randint(0, n, (B,), generator=g) for n in ln_emb])
         lS_o = torch.arange(B).repeat(len(ln_emb), 1)
         batches.append((lS_o, lS_i, torch.rand(B, d, generator=g)))
@@ -92,10 +120,114 @@ def cpu_baseline(ev, ln_emb, d, seconds=12.0):
         model.step(*batches[n % len(batches)])
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": len(ln_emb) * B * n / dt, "unit": "lookups/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "%d batches of B=%d over the same 26 Kaggle-shaped fp32 tables (copied from HBM), "
-                      "torch %s CPU EmbeddingBag+bmm loop, %.1f s" % (n, B, torch.__version__, dt)}
+    return {"value": len(ln_emb) * B * n / dt, "unit": "lookups/s", "cores": cores, "logical_cpus": logical,
+            "kind": "port", "ms_per_batch": dt / n * 1e3,
+            "sample": "%d batches of B=%d (the GPU's batch size) over the same 26 Kaggle-shaped fp32 tables (copied from HBM), "
+                      "torch %s CPU EmbeddingBag+bmm loop, %d threads = physical cores, %.1f s" % (n, B, torch.__version__, cores, dt)}
+
+
+def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
+    """a16 as a measurement: the reference moves X, lS_o, lS_i to the device for EVERY batch (dlrm_wrap,
+    dlrm_s_pytorch.py:131-147: 13*4 + 26*8 + 26*8 = 468 bytes per sample) and stamps wall-clock at the top of each
+    request (dlrm_s_pytorch_C1.py:965).  (1) that loop as written: pinned host batches, copies and the fused launch on
+    one stream, the result consumed (synchronised) per request; (2) the same bytes on a COPY stream, double-buffered
+    under the launch of the previous batch (throughput form).  Never the headline `value`."""
+    import evstore_dlrm_amd as E
+    from evstore_dlrm_amd import inference_loop as IL
+    T = len(ln_emb)
+    F = T + 1
+    g = torch.Generator().manual_seed(5)
+    host = []
+    for _ in range(8):
+        lS_i = torch.stack([torch.randint(0, n, (B,), generator=g) for n in ln_emb])
+        host.append((torch.rand(B, 13, generator=g), torch.arange(B).repeat(T, 1).contiguous(), lS_i))
+    ld = IL.PinnedBatches(host, n_req)
+    x_dev = torch.rand((B, d), device=dev)          # the bottom-MLP output the hot path consumes (the MLP itself is not the path)
+    out = torch.empty((B, d + F * (F - 1) // 2), device=dev)
+
+    def forward(X, lS_o, lS_i):
+        return E.apply_emb_interact(x_dev, lS_o, lS_i, ev, None, out=out)   # lS_o given, as the loader hands it over
+
+    IL.inference(IL.PinnedBatches(host, 20), forward, True, dev, consume=lambda Z: torch.cuda.synchronize(), non_blocking=True)
+    stamps = IL.inference(ld, forward, True, dev, consume=lambda Z: torch.cuda.synchronize(), non_blocking=True)
+    serial = {"p50_ms": IL.percentile_ms(stamps, 50), "p95_ms": IL.percentile_ms(stamps, 95),
+              "value": T * B * (len(stamps) - 1) / (stamps[-1] - stamps[0]), "unit": "lookups/s"}
+    # double-buffered: copies of batch i+1 on a copy stream under the launch of batch i
+    cs, ks = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    slots = [(torch.empty((B, 13), device=dev), torch.empty((T, B), dtype=torch.int64, device=dev),
+              torch.empty((T, B), dtype=torch.int64, device=dev)) for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+    used = [torch.cuda.Event() for _ in range(2)]
+
+    def run(n):
+        for i in range(n):
+            sl = i % 2
+            X, lo, li = ld.batches[i % len(ld.batches)]
+            with torch.cuda.stream(cs):
+                if i >= 2:
+                    cs.wait_event(used[sl])
+                slots[sl][0].copy_(X, non_blocking=True)
+                slots[sl][1].copy_(lo, non_blocking=True)
+                slots[sl][2].copy_(li, non_blocking=True)
+                copied[sl].record(cs)
+            with torch.cuda.stream(ks):
+                ks.wait_event(copied[sl])
+                E.apply_emb_interact(x_dev, slots[sl][1], slots[sl][2], ev, None, out=out)
+                used[sl].record(ks)
+
+    run(10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(n_req)
+    torch.cuda.synchronize()
+    dto = time.perf_counter() - t0
+    return {"bytes_per_sample": 13 * 4 + 2 * 8 * T, "requests": n_req, "batch": B,
+            "as_the_reference_loop": serial,
+            "copy_stream_overlapped": {"ms_per_batch": dto / n_req * 1e3, "value": T * B * n_req / dto, "unit": "lookups/s"},
+            "note": "per batch X (B,13) fp32, lS_o and lS_i (26,B) int64 from PINNED host memory (dlrm_wrap); latency = "
+                    "difference of consecutive loop-top wall-clock stamps, result synchronised per request; PCIe Gen5 x16"}
+
+
+def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=None):
+    """BASELINE configs[2] with the reference's own semantics: --test-mini-batch-size=1 through apply_emb_evstore and the
+    EvLFU_C1 cache module (dlrm_s_pytorch_C1.py:227-275, cache_algo/EvLFU_C1.py:97-166), tables (the miss tier) in HBM.
+    Warm-up = one full replay of the workload (dlrm_s_pytorch_C1.py:2224-2242), then the timed replay; latency =
+    difference of consecutive loop-top stamps (:965); the 1000-point CDF is written like calculate_and_write_cdf (:299-326)."""
+    from evstore_dlrm_amd import evstore_ops
+    from evstore_dlrm_amd import inference_loop as IL
+    from evstore_dlrm_amd.cache_algo import EvLFU_C1
+    from evstore_dlrm_amd.emb_storage import storage_manager as sm
+    T = len(ln_emb)
+    sm.use_device_tables(ev, 32)
+    EvLFU_C1.init(cap)
+    evstore_ops.cache_algo = "evlfu"
+    b1s = make_batches(ln_emb, 256, (n_req + 255) // 256, seed=13, device=dev, dist="zipf", alpha=1.05)
+    rows = torch.cat([b[1].t().contiguous() for b in b1s])[:n_req].cpu()       # (n_req, 26) int64
+    X = torch.zeros(1, 13)
+    lS_o = torch.zeros((T, 1), dtype=torch.int64)
+    ld = [(X, lS_o, rows[i].reshape(T, 1)) for i in range(n_req)]
+
+    def forward(X, lS_o, lS_i):
+        return evstore_ops.apply_emb_evstore(lS_o, lS_i, None, None, use_gpu=True, use_emb_cache=True)
+
+    IL.inference(ld, forward, True, dev)          # warm-up: the whole workload once
+    evstore_ops.perfect_hit = 0
+    h0 = EvLFU_C1.stats()["n_hits"]
+    stamps = IL.inference(ld, forward, True, dev)
+    hits = EvLFU_C1.stats()["n_hits"] - h0
+    res = {"p50_us": IL.percentile_ms(stamps, 50) * 1e3, "p95_us": IL.percentile_ms(stamps, 95) * 1e3,
+           "requests": n_req, "capacity_entries": cap, "hit_rate": hits / (T * n_req), "perfect_hits": evstore_ops.perfect_hit,
+           "value": T * n_req / (stamps[-1] - stamps[0]), "unit": "lookups/s",
+           "note": "apply_emb_evstore(use_gpu=True, use_emb_cache=True) per request behind dlrm_wrap: 26 ids to the device "
+                   "and back (as the reference does, dlrm_s_pytorch_C1.py:233-239), one exact-policy launch, 26 x Tensor(1,36) "
+                   "on the device; Zipf(1.05); warm-up = one full replay"}
+    if cdf_dir:
+        try:
+            res["cdf_csv"] = os.path.relpath(IL.calculate_and_write_cdf(cdf_dir, "evlfu", stamps), ROOT)
+        except Exception as e:
+            res["cdf_csv"] = "not written: %r" % (e,)
+    sm.close_any_db_conn()
+    return res
 
 
 def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, alpha=0.75, batch1=True, host_tier_line=True):
@@ -120,14 +252,26 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
     for i in range(warmup):
         step(i)
     s0 = cache.batch_stats()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    e0.record()
     for i in range(steps):
         step(warmup + i)   # batches the cache has not seen
+    e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / steps
     s1 = cache.batch_stats()
     looks = T * B * steps
+    # algorithmic bytes of one cached batch: the fused launch's 5 644 B per sample + per lookup one 8-byte key
+    # and a 4-byte slot / priority word of the probe = 5 956 B per sample at T = 26, d = 36; the batch is several launches
+    # (probe, consumer, policy update), so `achieved` is bytes over the whole batch's device time (HIP events)
+    tier_bytes = B * (T * (4 * d + 8) + 4 * d + 4 * (d + F * (F - 1) // 2) + T * 12)
+    tier_roof = {"bound": "hbm", "kernel": "the batch's launch chain: cache_batch_probe_gather + fused consumer (pointer mode) + policy update",
+                 "achieved": tier_bytes / dev_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                 "frac": tier_bytes / dev_ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": tier_bytes,
+                 "avg_launch_ms": dev_ms}
     # the same cache in front of tables that stay in pinned HOST memory (the reference's C3 / mmap miss path): each
     # missing row crosses the bus once; beside it, the fused kernel reading every row from host memory uncached
     host_tier = None
@@ -166,7 +310,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
     # oracle's sequential EvLFU on the host cores, same Zipf stream, smaller cache so both warm up quickly
     if not batch1:
         return {"value": looks / dt, "ms_per_step": dt / steps * 1e3, "hit_rate": (s1["n_hits"] - s0["n_hits"]) / looks,
-                "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"]}
+                "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"], "roofline": tier_roof}
     # batch-1 stream: Zipf(1.05), 200 k-entry cache -- a hit rate in the 90s like the reference's experiments, reached
     # within the first thousand requests (the 10 % cache of the batched section would need ~0.5 M requests to fill)
     n1, n_skip = 3000, 1000
@@ -211,7 +355,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
                          "EvLFU (cache_algo/EvLFU_C1.py restated), in-memory tables, %.2f s" % (n1 - n_skip, n_skip, dtc)}
     except Exception as e:  # the oracle is test infrastructure: its absence must not break the bench
         cpu = {"error": str(e)}
-    return {"value": looks / dt, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
+    return {"value": looks / dt, "roofline": tier_roof, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
             "hit_rate": (s1["n_hits"] - s0["n_hits"]) / looks, "capacity_entries": cap,
             "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"],
             "workload": "BASELINE configs[2]: EvLFU C1 in HBM at %.0f%% of 33.76M rows, Zipf(alpha=%.2f) indices, "
@@ -234,13 +378,26 @@ def main():
                     help="skip the sections that re-launch the headline kernel under other conditions (two streams, B=65536, "
                          "reduced precision, host-memory tables): used for the rocprofv3 summaries in profiles/, whose "
                          "per-kernel average must be the headline launch alone")
-    ap.add_argument("--placement", default="hbm", choices=["hbm", "count", "rows", "rows+replicate"],
-                    help="table placement for --gpus > 1 (sharded.plan_placement); hbm = replicate what fits --replicate-gb")
+    ap.add_argument("--placement", default="rows+replicate", choices=["rows+replicate", "rows", "count", "hbm"],
+                    help="table placement for --gpus > 1 (sharded.plan_placement): rows+replicate (default) = tables above 1 M rows "
+                         "sharded by row count + one RCCL all_to_all_single per batch, the small ones replicated; rows = every table "
+                         "sharded; count = the reference's contiguous split; hbm = replicate what fits --replicate-gb (no exchange "
+                         "when the whole model fits) -- timed beside the headline as `replicated_all`")
+    ap.add_argument("--sharded-mode", default="auto", choices=["auto", "graph", "pipelined"],
+                    help="N>1 step loop: graph = each planned step (pool, all-to-all, interaction) captured once as a HIP graph and "
+                         "replayed; pipelined = eager, exchange of batch i+1 under the interaction of batch i; auto = graph with one "
+                         "rank, pipelined with several")
+    ap.add_argument("--settle-s", type=float, default=0.35,
+                    help="clock-settle phase: at least this many seconds of the same launches right before the timed region "
+                         "(untimed, reported as settle_s; --steps / --warmup keep their meaning)")
+    ap.add_argument("--n-batches", type=int, default=64, help="distinct synthetic batches cycled by the timed loop")
+    ap.add_argument("--cdf-dir", default=os.path.join(ROOT, "gpurun_out", "cdf"), help="where the B=1 latency CDF CSV goes")
     ap.add_argument("--replicate-gb", type=float, default=64.0, help="per-GPU HBM budget for replicated tables (hbm placement)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one process")
     ap.add_argument("--shape", default="kaggle", choices=["kaggle", "terabyte"],
                     help="N>1 only: terabyte = BASELINE configs[3], MLPerf-DLRM Criteo-Terabyte cardinalities capped at 40 M rows "
-                         "(external to the reference tree; use --dim 64 or 128): exceeds the replication budget, so the big tables shard")
+                         "(external to the reference tree; --dim 64 or 128): with the default placement the tables above 1 M rows "
+                         "(7 of 26, 97 %% of the rows) shard by rows at either width")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -281,7 +438,8 @@ def main():
     F = T + 1
     P = F * (F - 1) // 2
     ev = make_tables(KAGGLE_LN, d, seed=0, device=dev)
-    batches = make_batches(KAGGLE_LN, B, 8, seed=1, device=dev, dist=args.dist)
+    # >= 64 distinct batches: 64 x 26 x B rows touch far more than the 256 MiB Infinity Cache between two uses of a line
+    batches = make_batches(KAGGLE_LN, B, max(1, args.n_batches), seed=1, device=dev, dist=args.dist)
     xs = [torch.rand((B, d), device=dev) for _ in range(2)]
     Rbuf = [torch.empty((B, d + P), device=dev, dtype=torch.float32) for _ in range(2)]
 
@@ -300,6 +458,16 @@ def main():
         step(i)
     E._lib.check(E._lib.lib().evs_check_index_errors(None))
     torch.cuda.synchronize()
+    # ---- clock settle: the GPU ramps its clocks over the first few hundred microseconds of sustained work; a 20-step
+    # region right after an idle gap reads ~15 % low.  Untimed, same launches, >= --settle-s seconds of them.
+    t_s = time.perf_counter()
+    n_settle = 0
+    while time.perf_counter() - t_s < args.settle_s:
+        for i in range(50):
+            step(n_settle + i)
+        n_settle += 50
+        torch.cuda.synchronize()
+    settle_s = time.perf_counter() - t_s
 
     # ---- timed region: exactly K steps, nothing but the launches between the two syncs ----
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -317,7 +485,7 @@ def main():
 
     # ---- per-batch latency (sync per step), outside the throughput region ------------------
     lat = []
-    for i in range(min(args.steps, 200)):
+    for i in range(min(max(args.steps, 50), 200)):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         step(i)
@@ -359,9 +527,9 @@ def main():
         ly = E.apply_emb(lS_o, lS_i, ev, None, lazy=False)
         return E.interact_features(xs[i % 2], ly)
 
-    def step2_lazy(i):   # the same two calls as a drop-in user writes them: lazy pooling fuses them into one launch
+    def step2_lazy(i):   # the same two calls with lazy pooling switched on (EVS_LAZY_POOLING=1 / lazy=True): one fused launch
         lS_o, lS_i = batches[i % len(batches)]
-        return E.interact_features(xs[i % 2], E.apply_emb(lS_o, lS_i, ev, None))
+        return E.interact_features(xs[i % 2], E.apply_emb(lS_o, lS_i, ev, None, lazy=True))
 
     for i in range(5):
         step2(i)
@@ -405,7 +573,11 @@ def main():
                                % (d, args.dist),
                    "batch_per_gpu": B, "global_batch": B, "tables": T, "dim": d, "parallelism": "single"},
         "p50_batch_latency_ms": float(np.percentile(lat, 50)), "p95_batch_latency_ms": float(np.percentile(lat, 95)),
-        "roofline": {"bound": "hbm", "kernel": "emb_interact_dot_lds_kernel<32,2,1,2,false,true,false,true,true,false>", "achieved": achieved,
+        "settle_s": settle_s,
+        "roofline": {"bound": "hbm",
+                     "kernel": "emb_interact_rf_kernel<2,1,2,4>" if (B <= 16384 and d == 36 and os.environ.get("EVS_FUSED_RF", "1") != "0")
+                               else "emb_interact_dot_lds_kernel<32,2,1,2,false,true,false,true,true,false>",
+                     "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "bytes_per_launch": kernel_bytes, "avg_launch_ms": kernel_ms},
         "general_offsets_path": {"value": lookups * args.steps / dtg, "unit": "lookups/s",
@@ -419,8 +591,9 @@ def main():
                           "ms_per_step": dt2 / args.steps * 1e3,
                           "note": "apply_emb(lazy=False) (26-table gather) then interact_features: two kernels, (T,B,d) intermediate in HBM"},
         "two_call_lazy": {"value": lookups * args.steps / dt2l, "unit": "lookups/s", "ms_per_step": dt2l / args.steps * 1e3,
-                          "note": "the same two calls as the reference's forward writes them (default lazy pooling): apply_emb launches "
-                                  "nothing, interact_features runs the fused kernel"},
+                          "note": "the same two calls with lazy pooling on (EVS_LAZY_POOLING=1 or apply_emb(..., lazy=True); off by "
+                                  "default because the lazy result is a Sequence, not a list): apply_emb launches nothing, "
+                                  "interact_features runs the fused kernel"},
     }
     result["general_offsets_path"]["note"] = ("lS_o given (any bag size allowed): offsets checked on the device, the one-index "
                                               "loop runs when they are arange, the general loop when not")
@@ -457,10 +630,20 @@ def main():
                                               "note": "C2-tier row formats (evlfu_8 / evlfu_4) decoded inside the fused kernel"}
         del bb, xb, Rb
         torch.cuda.empty_cache()
+    if not args.no_extras:
+        try:
+            result["h2d_inclusive"] = h2d_inclusive_section(ev, KAGGLE_LN, d, B, dev)
+        except Exception as e:   # a side measurement must not take the headline down
+            result["h2d_inclusive"] = {"error": repr(e)}
     if not args.no_cache_tier:
         result["cache_tier"] = cache_tier_section(ev, KAGGLE_LN, d, B, dev, host_tier_line=not args.no_extras)
+        if d == 36:
+            try:
+                result["cache_tier"]["batch1_evstore_plugin"] = batch1_plugin_section(ev, KAGGLE_LN, d, dev, cdf_dir=args.cdf_dir)
+            except Exception as e:
+                result["cache_tier"]["batch1_evstore_plugin"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(ev, KAGGLE_LN, d, args.cpu_seconds)
+        result["cpu_baseline"] = cpu_baseline(ev, KAGGLE_LN, d, B, args.cpu_seconds)
     print(json.dumps(result))
 
 

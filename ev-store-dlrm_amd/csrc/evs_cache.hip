@@ -1197,6 +1197,7 @@ __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs a
     __shared__ BatchState sb;
     __shared__ long long s_col[kPartCols];
     __shared__ int s_scan[256];
+    __shared__ int s_plan_cnt[kMaxBuckets];
     const int T = args.T;
     {
         const int nw = (int)(sizeof(BatchState) / sizeof(int));
@@ -1210,29 +1211,47 @@ __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs a
         const int v = args.part1[i];
         if (v) { atomicAdd(reinterpret_cast<unsigned long long *>(&s_col[i % kPartCols]), (unsigned long long)(long long)v); args.part1[i] = 0; }
     }
-    // exclusive scan of block_cnt[0..g2): each thread owns a contiguous run
-    const int per = (args.g2 + 255) / 256;
-    const int r0 = threadIdx.x * per, r1 = r0 + per < args.g2 ? r0 + per : args.g2;
-    int mine = 0;
-    for (int r = r0; r < r1; r++) mine += args.block_cnt[r];
-    s_scan[threadIdx.x] = mine;
+    // exclusive scan of block_cnt[0..g2).  The counts come in through LDS with coalesced, independent loads (a thread
+    // walking its own run of global entries is `per` DEPENDENT round trips, twice: that was most of this kernel's 11 us);
+    // each thread then scans its contiguous run out of LDS.  Tiles of kScanTile counts; `carry` chains the tiles.
+    constexpr int kScanTile = 8192;
+    __shared__ int s_cnt[kScanTile];
+    int carry = 0;
+    for (int t0 = 0; t0 < args.g2; t0 += kScanTile) {
+        const int nt = args.g2 - t0 < kScanTile ? args.g2 - t0 : kScanTile;
+        for (int i = threadIdx.x; i < nt; i += blockDim.x) s_cnt[i] = args.block_cnt[t0 + i];
+        __syncthreads();
+        const int per = (nt + 255) / 256;
+        const int r0 = threadIdx.x * per, r1 = r0 + per < nt ? r0 + per : nt;
+        int mine = 0;
+        for (int r = r0; r < r1; r++) mine += s_cnt[r];
+        s_scan[threadIdx.x] = mine;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int v = (int)threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int run = carry + s_scan[threadIdx.x] - mine;
+        for (int r = r0; r < r1; r++) { const int c = s_cnt[r]; s_cnt[r] = run; run += c; }
+        const int tile_total = s_scan[255];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt; i += blockDim.x) args.block_base[t0 + i] = s_cnt[i];
+        carry += tile_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) s_scan[255] = carry;   // (read below as the number of new keys)
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int v = (int)threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
-        __syncthreads();
-        s_scan[threadIdx.x] += v;
-        __syncthreads();
-    }
-    {
-        int run = s_scan[threadIdx.x] - mine;
-        for (int r = r0; r < r1; r++) { args.block_base[r] = run; run += args.block_cnt[r]; }
-    }
     BatchState *b = &sb;
     if (threadIdx.x == 0) {
         for (int p = 0; p <= T; p++) b->cnt[p] += (int)s_col[p];
         b->n_hits += s_col[38]; b->n_perfect_hits += s_col[39];
         b->n_new = s_scan[255];
-        int cnt[kMaxBuckets];  // planning copy: the real histogram is updated by the evict / assign kernels
+        // planning copy of the histogram (the real one is updated by the evict / assign kernels) -- in LDS: as a local
+        // array it is indexed dynamically, lands in scratch memory, and a kernel with a scratch segment pays for its set-up
+        // at every dispatch (this kernel: 12 -> ~6 us)
+        int *cnt = s_plan_cnt;
         for (int p = 0; p <= T; p++) cnt[p] = sb.cnt[p];
         b->pstar = -1; b->need = 0; b->ticket = 0; b->flush_t = 0; b->ticket_t = 0; b->pos_ticket = 0; b->win = 0;
         if (cnt[T] >= args.max_perfect && b->n_new > 0) {  // EvLFU flush (EvLFU_C1.py:36-44), once per batch
@@ -1399,9 +1418,17 @@ __global__ void __launch_bounds__(256) cache_batch_clear_kernel(const BatchArgs 
 // ... and the end-of-batch bookkeeping (block 0: folds K5's partial rows, then thread 0 closes the batch)
 __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchArgs args) {
     __shared__ int s_col[kPartCols];
-    BatchState *b = args.bs;
+    __shared__ BatchState sb;
     const bool rebuild = args.B < 0;
     if (blockIdx.x == 0) {
+        // the state comes in and goes out with parallel loads / stores; thread 0 works on the LDS copy (walking the
+        // fields in global memory was ~10 dependent round trips: most of this kernel's 10 us)
+        const int nw = (int)(sizeof(BatchState) / sizeof(int));
+        {
+            int *dst = reinterpret_cast<int *>(&sb);
+            const int *src = reinterpret_cast<const int *>(args.bs);
+            for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+        }
         if (threadIdx.x < kPartCols) s_col[threadIdx.x] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < kReplicas * kPartCols; i += blockDim.x) {   // fold and clear K5's replica rows
@@ -1409,7 +1436,9 @@ __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchAr
             if (v) { atomicAdd(&s_col[i % kPartCols], v); args.part2[i] = 0; }
         }
         __syncthreads();
+        BatchState *b = &sb;
         if ((int)threadIdx.x <= args.T && s_col[threadIdx.x]) b->cnt[threadIdx.x] += s_col[threadIdx.x];
+        __syncthreads();
         if (threadIdx.x == 0) {
             b->n_free += b->flush_t > 0 ? b->pos_ticket : (b->ticket < b->need ? b->ticket : b->need);
             const int take = b->n_assign < b->n_free ? b->n_assign : b->n_free;
@@ -1420,6 +1449,12 @@ __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchAr
             b->n_miss = 0; b->n_new = 0; b->batch_id++;
             b->n_requests += rebuild ? -args.B : args.B;
             *args.host_tomb = b->n_tomb;
+        }
+        __syncthreads();
+        {
+            const int *src = reinterpret_cast<const int *>(&sb);
+            int *dst = reinterpret_cast<int *>(args.bs);
+            for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
         }
     }
     if (!rebuild) return;

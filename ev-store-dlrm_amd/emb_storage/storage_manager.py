@@ -88,6 +88,17 @@ def load_ev_table_into_emb_stor(ev_path_c1, overwrite_db=True):
         exit(-1)
 
 
+def use_device_tables(tables, precs=32, storage=None):
+    """MI355X-native shortcut for callers that already hold the tables (EVTables.raw, or raw uint8 tensors in HBM / pinned
+    host memory): the same state load_ev_table_into_emb_stor leaves behind, without going through .bin files."""
+    global storage_type, ev_precs, _tables
+    raws = tables.raw if hasattr(tables, "raw") else list(tables)
+    assert len(raws) == N_EV_TABLE
+    ev_precs = precs
+    storage_type = storage if storage is not None else (EmbStorage.HBM if raws[0].is_cuda else EmbStorage.PINNED)
+    _tables = [t.reshape(-1) if t.dtype == torch.uint8 else t.view(torch.uint8).reshape(-1) for t in raws]
+
+
 def device_tables():
     """Raw row tensors the GPU cache can read misses from (HBM or PINNED storage only)."""
     if storage_type not in (EmbStorage.HBM, EmbStorage.PINNED) or _tables is None:

@@ -194,7 +194,8 @@ class ShardedEmbeddingInteract:
         if key not in self._bufs:
             Bl, _, out_splits = self._splits(Bg)
             send = like.new_empty((Bg, max(len(self.my_own), 0), self.d), dtype=torch.float32)
-            recv = like.new_empty((sum(out_splits),), dtype=torch.float32)
+            # one rank: nothing to exchange -- the "received" block is the send buffer itself (no copy)
+            recv = send.view(-1) if self.world == 1 else like.new_empty((sum(out_splits),), dtype=torch.float32)
             self._bufs[key] = (send, recv)
         return self._bufs[key]
 
@@ -219,8 +220,6 @@ class ShardedEmbeddingInteract:
         work = None
         if self.world > 1:
             work = dist.all_to_all_single(recv, send.view(-1), out_splits, in_splits, group=self.group, async_op=True)
-        else:
-            recv.copy_(send.view(-1))
         return (work, recv, Bg, Bl, out_splits)
 
     def finish(self, handle, x_local, lS_o, lS_i, out=None):
@@ -283,8 +282,28 @@ class ShardedEmbeddingInteract:
         if self.world > 1:
             return dist.all_to_all_single(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"], group=self.group,
                                           async_op=True)
-        pl["recv"].copy_(pl["send"].view(-1))
-        return None
+        return None   # one rank: recv aliases send
+
+    def step(self, pl):
+        """One whole planned step on the current stream: pool -> all-to-all -> interaction (no overlap between steps)."""
+        return self.run_finish(pl, self.run_start(pl))
+
+    def capture_step(self, pl):
+        """The planned step as a HIP graph (torch.cuda.CUDAGraph over the library's launches on torch's capture stream):
+        a replay costs one host call instead of the Python / ctypes marshalling of two launches and a collective.
+        Captured after two eager runs on a side stream (first-use allocations inside the library must not happen
+        during capture).  The exchange of a multi-rank step is captured with it (RCCL collectives are capturable)."""
+        side = torch.cuda.Stream(device=self.backend.device)
+        side.wait_stream(torch.cuda.current_stream(self.backend.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.step(pl)
+        torch.cuda.current_stream(self.backend.device).wait_stream(side)
+        torch.cuda.synchronize(self.backend.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.step(pl)
+        return g
 
     def run_finish(self, pl, work):
         if work is not None:
@@ -331,7 +350,25 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     # nb batches x 2 pipeline slots, planned once (serving loops re-use their staged buffers)
     plans = {(j, sl): op.plan(x, batches[j][0], batches[j][1], out=outs[sl], slot=sl) for j in range(nb) for sl in (0, 1)}
 
+    # mode of the timed loop: "graph" = every planned step captured once as a HIP graph and replayed (one host call per
+    # step; the default with one rank, where the host marshalling of two launches is what bounds the step);
+    # "pipelined" = eager, the exchange of batch i+1 in flight under the interaction of batch i (the default with
+    # several ranks; --sharded-mode graph captures the RCCL collective with the kernels).
+    mode = getattr(args, "sharded_mode", "auto")
+    if mode == "auto":
+        mode = "graph" if world == 1 else "pipelined"
+    graphs = None
+    if mode == "graph":
+        try:
+            graphs = [op.capture_step(plans[(j, 0)]) for j in range(nb)]
+        except Exception as ex:   # capture not possible here: the eager loop still measures the path
+            graphs, mode = None, "pipelined (graph capture failed: %r)" % (ex,)
+
     def run(steps):
+        if graphs is not None:
+            for i in range(steps):
+                graphs[i % nb].replay()
+            return
         # two-deep software pipeline: exchange of batch i+1 overlaps the interaction of batch i
         h = op.run_start(plans[(0, 0)])
         for i in range(steps):
@@ -342,6 +379,7 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
             h = nxt
 
     run(args.warmup)
+    run(1500)   # clock settle: a FIXED number of untimed steps (every rank must issue the same collectives)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -355,7 +393,9 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     dt = float(tmax.item())
     n_sh = sum(1 for t in range(T) if owner[t] >= 0)
     n_rep = T - n_sh
-    res = {"dt": dt, "owner": owner, "n_sharded": n_sh, "n_replicated": n_rep,
+    res = {"dt": dt, "owner": owner, "n_sharded": n_sh, "n_replicated": n_rep, "mode": mode,
+           # bytes that leave a rank per step (its pooled vectors for the other ranks' batch slices), and over all ranks
+           "a2a_bytes_per_rank": 4 * d * Bl * len(op.my_own) * (world - 1),
            "a2a_bytes": 4 * d * Bl * n_sh * (world - 1), "roofline": None}
     # roofline of the launches a rank issues per batch (rank 0, HIP events on the launch stream, after the timed
     # region): the pooling gather of its own tables over the GLOBAL batch (if any) and the interaction over its
@@ -385,56 +425,65 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
         res["roofline"] = {
             "bound": "hbm",
             "kernel": "embedding_bag_sum_kernel (own tables x global batch)" if dom[0] == "pool" else
-                      "emb_interact_dot_lds_kernel (local batch: %d received dense features + %d replicated tables)" % (n_sh, n_rep),
+                      "fused gather + interaction kernel (local batch: %d received dense features + %d replicated tables)" % (n_sh, n_rep),
             "achieved": dom[1] / dom[2] / 1e6, "peak": peak, "unit": "GB/s", "frac": dom[1] / dom[2] / 1e6 / peak,
             "traffic": None, "bytes_per_launch": dom[1], "avg_launch_ms": dom[2],
             "pool": {"ms": t_pool, "bytes": pool_bytes, "tables": n_own}, "interact": {"ms": t_fin, "bytes": fin_bytes}}
-    del op, plans, weights
+    del op, plans, weights, graphs
     torch.cuda.empty_cache()
     return res
 
 
 def bench_sharded(args, ln_emb, rank, world, dev):
     """Weak scaling: global batch = world * args.batch; every rank times the same K steps.
-    The headline placement is memory-aware ("hbm"): tables are replicated on every GPU while they fit the
-    per-GPU budget (--replicate-gb), the rest is sharded by rows and exchanged with one all_to_all_single per
-    batch.  The whole Kaggle model is 4.9 GB, so on 288 GB parts nothing needs exchanging; the table-sharded
-    all-to-all path (rows+replicate, tables above 1 M rows sharded) is timed beside it in the same run."""
+    The HEADLINE placement is BASELINE.json's: tables sharded by row count across the ranks with ONE RCCL
+    all_to_all_single of pooled vectors per batch ("rows+replicate": tables of at most 1 M rows are replicated and looked
+    up locally, so their pooled vectors never cross xGMI; "rows" shards every table).  The memory-aware placement
+    ("hbm": replicate whatever fits --replicate-gb per GPU; for the 4.9 GB Kaggle model that is everything, i.e. pure
+    data parallel with no exchange) is timed beside it in the same run as `replicated_all`."""
     d = args.dim
     T = len(ln_emb)
     Bl = args.batch
     Bg = Bl * world
-    policy = getattr(args, "placement", "hbm")
+    policy = getattr(args, "placement", "rows+replicate")
     budget_rows = int(getattr(args, "replicate_gb", 64.0) * 1e9 / (4 * d))
     main = _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, True)
     extra = None
-    if main["n_sharded"] == 0:   # the exchange path, for the record
+    if policy != "hbm":   # the no-exchange alternative, when the model fits the per-GPU budget
         try:
-            e = _bench_policy(args, ln_emb, rank, world, dev, "rows+replicate", None, True)
-            extra = {"value": T * Bg * args.steps / e["dt"], "unit": "lookups/s", "ms_per_step": e["dt"] / args.steps * 1e3,
-                     "placement": "rows+replicate (tables above 1 M rows sharded by rows, one all_to_all_single per batch)",
-                     "owner": e["owner"], "a2a_bytes_per_step_all_links": e["a2a_bytes"], "roofline": e["roofline"]}
+            if sum(ln_emb) <= budget_rows:
+                e = _bench_policy(args, ln_emb, rank, world, dev, "hbm", budget_rows, True)
+                extra = {"value": T * Bg * args.steps / e["dt"], "unit": "lookups/s", "ms_per_step": e["dt"] / args.steps * 1e3,
+                         "placement": "hbm (every table replicated on every GPU: %.1f GB of 288 GB; data parallel, no exchange step)"
+                                      % (sum(ln_emb) * 4 * d / 1e9),
+                         "mode": e["mode"], "roofline": e["roofline"]}
+            else:
+                extra = {"skipped": "the model (%.1f GB) exceeds the replication budget of %.0f GB per GPU"
+                                    % (sum(ln_emb) * 4 * d / 1e9, getattr(args, "replicate_gb", 64.0))}
         except Exception as ex:  # the headline number must survive a failure of the side measurement
             extra = {"error": repr(ex)}
     dt = main["dt"]
     lookups = T * Bg
+    shape = "Criteo-Kaggle" if sum(ln_emb) < 100_000_000 else "Criteo-Terabyte-shaped"
     if main["n_sharded"] == 0:
-        what = ("all %d tables replicated on every GPU (%.1f GB of %s GB HBM): pure data parallel, no exchange step"
-                % (T, sum(ln_emb) * 4 * d / 1e9, "288"))
+        what = ("all %d tables replicated on every GPU (%.1f GB of 288 GB): pure data parallel, no exchange step"
+                % (T, sum(ln_emb) * 4 * d / 1e9))
         par = "replicated tables x%d (data parallel)" % world
     else:
         what = ("%d tables sharded by rows + %d replicated (%s), one all_to_all_single of pooled vectors per batch over "
                 "RCCL/xGMI" % (main["n_sharded"], main["n_replicated"], policy))
         par = "table-sharded x%d + a2a" % world
     return {
-        "metric": "inference lookups/sec, %s 26-table DLRM (apply_emb + interact_features)"
-                  % ("Criteo-Kaggle" if sum(ln_emb) < 100_000_000 else "Criteo-Terabyte-shaped"),
+        "metric": "inference lookups/sec, %s 26-table DLRM (apply_emb + interact_features)" % shape,
         "value": lookups * args.steps / dt, "unit": "lookups/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s 26 tables (%.1f M rows) x d=%d fp32 over %d GPUs: %s; uniform indices, one index per bag"
-                               % ("Criteo-Kaggle" if sum(ln_emb) < 100_000_000 else "Criteo-Terabyte-shaped", sum(ln_emb) / 1e6, d, world, what),
+                               % (shape, sum(ln_emb) / 1e6, d, world, what),
                    "batch_per_gpu": Bl, "global_batch": Bg, "tables": T, "dim": d, "parallelism": par,
-                   "placement": policy, "owner": main["owner"], "a2a_bytes_per_step_all_links": main["a2a_bytes"]},
-        "roofline": main["roofline"], "cpu_baseline": None, "table_sharded_a2a": extra,
+                   "placement": policy, "owner": main["owner"], "step_mode": main["mode"],
+                   "observed_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                   "a2a_bytes_per_step_per_rank": main["a2a_bytes_per_rank"],
+                   "a2a_bytes_per_step_all_links": main["a2a_bytes"]},
+        "roofline": main["roofline"], "cpu_baseline": None, "replicated_all": extra,
     }

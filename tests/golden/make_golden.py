@@ -609,7 +609,52 @@ def gen_aprx_ops():
     print("wrote aprx_ops")
 
 
+# --------------------------------------------------------------------------
+# a16: calculate_and_write_cdf (dlrm_s_pytorch_C1.py:299-326) on fixed time stamps
+# --------------------------------------------------------------------------
+def cdf_stamps(n, seed):
+    rs = np.random.RandomState(seed)
+    lat = rs.gamma(2.0, 0.0004, size=n) + 0.0002
+    return [float(v) for v in np.concatenate([[1700000000.0], 1700000000.0 + np.cumsum(lat)])]
+
+
+def gen_cdf():
+    import io, contextlib
+    D = import_reference_c1()
+    out = {}
+    for n, seed in ((5000, 3), (2345, 4)):
+        stamps = cdf_stamps(n, seed)
+        tmp = tempfile.mkdtemp(prefix="evs_cdf_")
+        cwd = os.getcwd()
+        os.chdir(tmp)   # the reference then tries ./script/plot_cdf.py, which is absent here: its failure is ignored
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                D.calculate_and_write_cdf(os.path.join(tmp, "cdf"), "evlfu", stamps)
+        finally:
+            os.chdir(cwd)
+        txt = open(os.path.join(tmp, "cdf", "evlfu-cdf.csv")).read()
+        out["n%d_seed%d_csv" % (n, seed)] = np.frombuffer(txt.encode(), np.uint8)
+        print("cdf", n, "requests ->", txt.count("\n") - 1, "points")
+    np.savez_compressed(os.path.join(HERE, "cdf.npz"), **out)
+    print("wrote cdf")
+
+
+def import_reference_c1():
+    """dlrm_s_pytorch_C1 (the EVStore fork) -- needs the same stubs as dlrm_s_pytorch plus its cache modules"""
+    import_reference()
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import dlrm_s_pytorch_C1 as D1
+    finally:
+        os.chdir(cwd)
+    return D1
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cdf":
+        gen_cdf()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "aprx":
         gen_aprx_ops()
         return
@@ -650,6 +695,7 @@ def main():
     gen_cython_traces()
     gen_mgr_variants()
     gen_aprx_ops()
+    gen_cdf()
 
 
 if __name__ == "__main__":

@@ -770,3 +770,39 @@ def test_apply_emb_returns_a_real_list_by_default(E, orc):
     R = E.interact_features(x, ly2)
     want = orc.interact_features(g["x"], [v.cpu().numpy() for v in ly2])
     np.testing.assert_allclose(R.cpu().numpy(), want, rtol=RTOL, atol=2e-6)
+
+
+def test_sharded_step_as_hip_graph_replays_the_eager_result(E, orc):
+    """One rank (no exchange: the received block aliases the send buffer): the planned step captured as a HIP graph
+    gives the eager step's bits on every replay, for new index / x contents written into the planned buffers, and both
+    equal the oracle."""
+    from evstore_dlrm_amd import sharded
+    rs = np.random.RandomState(5)
+    ln = [1500000, 40, 1200000, 7, 333, 2000001]
+    d, B = 36, 4096
+    dev = torch.device("cuda")
+    tabs = {t: torch.from_numpy(rs.uniform(-1, 1, size=(n, d)).astype(np.float32)) for t, n in enumerate(ln)}
+    op = sharded.ShardedEmbeddingInteract(ln, d, 0, 1, tabs, sharded.HipBackend(dev), policy="rows+replicate",
+                                          one_index_per_bag=True)
+    assert op.any_sharded and len(op.replicated) == 3
+    off = [torch.arange(B, device=dev)] * len(ln)
+    idx = [torch.from_numpy(rs.randint(0, n, size=B).astype(np.int64)).cuda() for n in ln]
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+    F = len(ln) + 1
+    R = torch.empty((B, d + F * (F - 1) // 2), device=dev)
+    pl = op.plan(x, off, idx, out=R)
+    assert pl["recv"].data_ptr() == pl["send"].data_ptr()
+    want = op.step(pl).clone()
+    g = op.capture_step(pl)
+    for rep in range(3):
+        if rep:   # new contents in the planned buffers
+            for k, n in enumerate(ln):
+                idx[k].copy_(torch.from_numpy(rs.randint(0, n, size=B).astype(np.int64)))
+            x.copy_(torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)))
+            want = op.step(pl).clone()
+        R.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(R, want), rep
+        ly = orc.apply_emb([o.cpu().numpy() for o in off], [i.cpu().numpy() for i in idx], [tabs[t].numpy() for t in range(len(ln))])
+        np.testing.assert_allclose(R.cpu().numpy(), orc.interact_features(x.cpu().numpy(), ly), rtol=RTOL, atol=2e-6)

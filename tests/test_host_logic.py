@@ -67,3 +67,42 @@ def test_fused_supported_shapes_and_module_surface():
         assert callable(getattr(mod, "init")) and callable(getattr(mod, fn))
     assert callable(evstore_ops.apply_emb_evstore) and callable(cpp_socket_client.request_to_cpp_cache)
     assert E._lib.lib().evs_fused_dim_supported(36) == 1 and E._lib.lib().evs_fused_dim_supported(40) == 0
+
+
+def test_cdf_writer_and_latency_definition_match_the_reference(tmp_path):
+    """a16: calculate_and_write_cdf (dlrm_s_pytorch_C1.py:299-326) -- byte-identical CSV to what the reference's own
+    function wrote for the same time stamps (tests/golden/cdf.npz, make_golden.py gen_cdf)."""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as G
+    from evstore_dlrm_amd import inference_loop as IL
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cdf.npz"))
+    for n, seed in ((5000, 3), (2345, 4)):
+        stamps = G.cdf_stamps(n, seed)
+        out = IL.calculate_and_write_cdf(str(tmp_path / ("cdf%d" % n)), "evlfu", stamps)
+        assert out.endswith("evlfu-cdf.csv")
+        assert open(out).read() == bytes(g["n%d_seed%d_csv" % (n, seed)]).decode()
+        assert len(IL.latencies(stamps)) == n - 1     # the reference's loop bound drops the last request
+    # short runs (below 1000 requests the reference divides by zero): every point kept
+    out = IL.calculate_and_write_cdf(str(tmp_path / "short"), "lru", G.cdf_stamps(40, 1))
+    assert open(out).read().count("\n") == 1 + 39
+
+
+def test_inference_loop_stamps_and_dlrm_wrap_order():
+    """inference(): one stamp per request at the top of the loop plus one at the end; dlrm_wrap hands the forward the
+    batch in the reference's argument order (dlrm_s_pytorch.py:131-147)."""
+    import torch
+    from evstore_dlrm_amd import inference_loop as IL
+    seen = []
+
+    def fwd(X, lS_o, lS_i):
+        seen.append((tuple(X.shape), tuple(lS_o.shape), len(lS_i)))
+        return X.sum()
+
+    ld = [(torch.zeros(4, 13), torch.zeros(3, 4, dtype=torch.int64), [torch.zeros(4, dtype=torch.int64)] * 3)] * 5
+    got = []
+    stamps = IL.inference(ld, fwd, use_gpu=False, device="cpu", consume=got.append)
+    assert len(stamps) == 6 and stamps == sorted(stamps) and len(got) == 5
+    assert seen[0] == ((4, 13), (3, 4), 3)

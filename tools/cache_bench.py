@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Developer micro-benchmark: the batched cache tier alone (bench.py's configs[2] section without the side lines)."""
+import json
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+torch.cuda.set_device(0)
+ev = bench.make_tables(bench.KAGGLE_LN, 36, seed=0, device="cuda")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+r = bench.cache_tier_section(ev, bench.KAGGLE_LN, 36, B, torch.device("cuda"), batch1=False)
+print(json.dumps(r))
