@@ -57,6 +57,12 @@ _PROTOS = {
     "evs_cache_create": (_int, [_pp, _int, _i64, _int, _int, _int, C.c_double, C.c_double, _int, _int]),
     "evs_cache_destroy": (_int, [_vp]),
     "evs_cache_set_backing": (_int, [_vp, _pp, _i64p]),
+    "evs_filetier_open": (_int, [_pp, _int, C.POINTER(C.c_char_p), _i64, _i64]),
+    "evs_filetier_info": (_int, [_vp, _i64p, _pp, C.POINTER(C.c_int), _i64p]),
+    "evs_filetier_fetch": (_int, [_vp, _i64, _vp, _vp, C.c_uint32]),
+    "evs_filetier_close": (_int, [_vp]),
+    "evs_cache_set_file_backing": (_int, [_vp, _vp]),
+    "evs_cache_staged_rows": (_i64, [_vp]),
     "evs_cache_request": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "evs_cache_request_c1c2": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "evs_cache_lookup_batch_c1c2": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _int, _vp]),

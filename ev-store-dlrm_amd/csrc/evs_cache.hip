@@ -844,6 +844,7 @@ struct BatchState {
     int cnt[kMaxBuckets];
     int pstar, need, ticket, flush_t, ticket_t, pos_ticket, do_rebuild, n_assign;
     int hand, win;   // eviction scans the entry window [hand, hand + win) (mod cap), then the hand moves on
+    int n_orphan;    // file mode: missed keys of staged tables the full hash could not take (served from staging, never cached)
     long long batch_id, n_hits, n_requests, n_perfect_hits, n_evict, n_flush;
 };
 
@@ -871,6 +872,14 @@ struct BatchArgs {
     long long B;
     unsigned long long mask;
     int cap, T, d, codec, row_bytes, max_perfect, flush_n, nslot;
+    // file-backed miss tier (evs_filetier.hip): tables in staged_mask have no device-visible address; the rows of the
+    // batch's new keys are copied by the host into `staging` (row i = new key i of the batch, pinned + mapped)
+    unsigned staged_mask;
+    const unsigned char *staging;
+    unsigned long long *new_keys;   // new key i of the batch (table_1based << 32 | row), for the host's reader pool;
+                                    // orphans (n_orphan) are listed from the END of the array downwards
+    long long stage_rows;           // rows of `staging` / entries of new_keys (= B * T)
+    int *slot_stage;                // hash slot -> index of the new key it holds in this batch
 };
 
 __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigned long long mask, unsigned long long key,
@@ -1170,15 +1179,23 @@ __global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs
         const unsigned long long hint = (unsigned long long)(info & 0xffffffu) << args.hint_shift;
         unsigned long long i = ((hint - h) & args.mask) < (args.mask >> 1) ? hint : h;
         const unsigned long long mine = make_word(key, kFieldPend + (unsigned)agg);
+        bool placed = false;
         for (unsigned long long steps = 0; steps <= args.mask; steps++) {   // one lap at most: a full table drops the key
             unsigned long long w = args.slots[i];
             if (w == kEmpty) {
                 const unsigned long long prev = atomicCAS(&args.slots[i], kEmpty, mine);
-                if (prev == kEmpty) { is_new = true; slot = (int)i; break; }  // this thread owns the new key
+                if (prev == kEmpty) { is_new = true; slot = (int)i; placed = true; break; }  // this thread owns the new key
                 w = prev;
             }
-            if ((w & kKeyMask) == key) { atomicMax(&args.slots[i], mine); break; }  // duplicate miss of this batch
+            if ((w & kKeyMask) == key) { atomicMax(&args.slots[i], mine); placed = true; break; }  // duplicate miss of this batch
             i = (i + 1) & args.mask;
+        }
+        // file mode: a dropped key of a STAGED table has no address the consumer could read -- the host stages its row
+        // for this one position (listed from the end of new_keys; row_ptrs carries -(1 + orphan index) to the patch kernel)
+        if (!placed && args.new_keys && ((args.staged_mask >> (int)(m % args.T)) & 1u)) {
+            const int oi = atomicAdd(&args.bs->n_orphan, 1);
+            args.new_keys[args.stage_rows - 1 - oi] = key;
+            args.row_ptrs[m] = -(long long)(1 + oi);
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1379,7 +1396,8 @@ __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs
         const int i = my_base + local;
         const int slot = args.new_slot[(long long)blockIdx.x * 256 + local];
         if (i >= n_assign) {  // no room: forget the key
-            if (sub == 0) { args.slots[slot] = kTomb; atomicAdd(&s_drop, 1); }
+            // (file mode: the key stays pending until the consumers have read its staged row -- cache_batch_unstage_kernel)
+            if (sub == 0 && !args.staging) { args.slots[slot] = kTomb; atomicAdd(&s_drop, 1); }
             continue;
         }
         const int e = args.a.free_stack[n_free - 1 - i];
@@ -1394,7 +1412,8 @@ __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs
             atomicAdd(&s_delta[agg], 1);
         }
         const int t = (int)(key >> 32) - 1;
-        const unsigned char *srow = args.backing[t] + (long long)(unsigned)(key & 0xffffffffull) * args.row_bytes;
+        const unsigned char *srow = ((args.staged_mask >> t) & 1u) ? args.staging + (long long)i * args.row_bytes
+                                                                 : args.backing[t] + (long long)(unsigned)(key & 0xffffffffull) * args.row_bytes;
         unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
         if ((args.row_bytes & 15) == 0) {
             for (int c = sub * 16; c < args.row_bytes; c += 256) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c);
@@ -1446,7 +1465,7 @@ __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchAr
             b->n_tomb += s_col[37];
             if (b->need > 0 && b->win > 0) { long long h = (long long)b->hand + b->win; b->hand = (int)(h % args.cap); }
             if (rebuild) b->n_tomb = 0;
-            b->n_miss = 0; b->n_new = 0; b->batch_id++;
+            b->n_miss = 0; b->n_new = 0; b->n_orphan = 0; b->batch_id++;
             b->n_requests += rebuild ? -args.B : args.B;
             *args.host_tomb = b->n_tomb;
         }
@@ -1483,8 +1502,40 @@ __global__ void __launch_bounds__(256) cache_batch_patch_ptrs_kernel(const Batch
     if (!(info & 0x80000000u)) return;
     const unsigned long long key = ((unsigned long long)(m % args.T + 1) << 32) | (unsigned)args.requests[m];
     unsigned long long end_slot;
+    if (args.staging && args.row_ptrs[m] < 0) {   // orphan of the full hash: its own staged row
+        args.row_ptrs[m] = (long long)(args.staging + (args.stage_rows + args.row_ptrs[m]) * args.row_bytes);
+        return;
+    }
     const int e = probe_ro(args.slots, args.mask, key, end_slot);
     if (e >= 0) args.row_ptrs[m] = (long long)(args.a.arena + (long long)e * args.row_bytes);
+    else if (e == kPending && args.staging && ((args.staged_mask >> (int)(m % args.T)) & 1u))   // no room in the cache: the staged copy
+        args.row_ptrs[m] = (long long)(args.staging + (long long)args.slot_stage[end_slot] * args.row_bytes);
+}
+
+// File mode, after K2 / K3: the batch's new keys as one list for the host's reader pool (new key i = list base of
+// K2's block + rank, the same numbering K5 uses), and for every new key the hash slot -> i map the patch kernel needs.
+__global__ void __launch_bounds__(256) cache_batch_list_kernel(const BatchArgs args) {
+    const int my_cnt = args.block_cnt[blockIdx.x], my_base = args.block_base[blockIdx.x];
+    for (int local = threadIdx.x; local < my_cnt; local += blockDim.x) {
+        const int slot = args.new_slot[(long long)blockIdx.x * 256 + local];
+        args.new_keys[my_base + local] = args.slots[slot] & kKeyMask;
+        args.slot_stage[slot] = my_base + local;
+    }
+}
+// File mode, after the consumers: new keys that found no room stop being pending (K5 tombstones them at once in the
+// other modes; here their staged rows had to stay addressable through the hash until the batch was served).
+__global__ void __launch_bounds__(256) cache_batch_unstage_kernel(const BatchArgs args) {
+    __shared__ int s_drop;
+    if (threadIdx.x == 0) s_drop = 0;
+    __syncthreads();
+    BatchState *b = args.bs;
+    const int n_free = b->n_free + (b->flush_t > 0 ? b->pos_ticket : (b->ticket < b->need ? b->ticket : b->need));
+    const int n_assign = b->n_assign < n_free ? b->n_assign : n_free;
+    const int my_cnt = args.block_cnt[blockIdx.x], my_base = args.block_base[blockIdx.x];
+    for (int local = threadIdx.x; local < my_cnt; local += blockDim.x)
+        if (my_base + local >= n_assign) { args.slots[args.new_slot[(long long)blockIdx.x * 256 + local]] = kTomb; atomicAdd(&s_drop, 1); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_drop) atomicAdd(&args.part2[(blockIdx.x % kReplicas) * kPartCols + 37], s_drop);
 }
 
 }  // namespace evs
@@ -1516,6 +1567,14 @@ struct evs_cache {
     long long stamp_counter = 0;
     int *host_tomb = nullptr;   // mapped host word: tombstones after the last finished batch (read without a sync)
     int *host_tomb_dev = nullptr;
+    // file-backed miss tier
+    evs_filetier *ft = nullptr;
+    unsigned staged_mask = 0;
+    unsigned long long *new_keys = nullptr, *new_keys_host = nullptr;
+    unsigned char *staging = nullptr, *staging_dev = nullptr;
+    int *slot_stage = nullptr;
+    long long staging_rows = 0;
+    long long n_staged_rows = 0;   // rows the reader pool has fetched so far (statistics)
 };
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
@@ -1523,10 +1582,12 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
     void *ptrs[] = {c->st, c->a.keys, c->a.slot_entry, c->a.ekey, c->a.eagg, c->a.efreq, c->a.prev, c->a.next,
                     c->a.free_stack, c->a.arena, c->a.lfu_head, c->a.lfu_tail, c->a.lfu_len,
                     c->bs, c->eslot, c->estamp, c->bslots, c->miss_info, c->new_slot, c->row_ptrs, c->iota, c->row_tier,
-                    c->block_cnt, c->block_base, c->part1, c->part2};
+                    c->block_cnt, c->block_base, c->part1, c->part2, c->new_keys, c->slot_stage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->host_tomb) (void)hipHostFree(c->host_tomb);
+    if (c->new_keys_host) (void)hipHostFree(c->new_keys_host);
+    if (c->staging) (void)hipHostFree(c->staging);
     delete c;
     return EVS_OK;
 }
@@ -1611,11 +1672,35 @@ extern "C" int evs_cache_set_backing(evs_cache *c, const void *const *tables, co
     return EVS_OK;
 }
 
+// The miss tier is a set of ev-table-N.bin files (evs_filetier_open): registered tables are read by the kernels over the
+// bus like pinned host tables; the others ("staged") are served through the host's reader pool -- batched lookups only.
+extern "C" int evs_cache_set_file_backing(evs_cache *c, evs_filetier *ft) {
+    using namespace evs;
+    EVS_REQUIRE(c && ft, "evs_cache_set_file_backing: NULL argument");
+    EVS_REQUIRE(filetier_tables(ft) == c->host.n_tables, "evs_cache_set_file_backing: the tier has %d tables, the cache %d",
+                filetier_tables(ft), c->host.n_tables);
+    EVS_REQUIRE(filetier_row_bytes(ft) == c->host.row_bytes, "evs_cache_set_file_backing: row size %lld, the cache's rows have %d bytes",
+                filetier_row_bytes(ft), c->host.row_bytes);
+    c->staged_mask = 0;
+    for (int k = 0; k < c->host.n_tables; k++) {
+        c->backing[k] = reinterpret_cast<const unsigned char *>(filetier_dev(ft, k));
+        c->backing_rows[k] = filetier_rows(ft, k);
+        if (!c->backing[k] && c->backing_rows[k] > 0) c->staged_mask |= 1u << k;
+    }
+    c->ft = ft;
+    c->has_backing = true;
+    c->host_backing = true;
+    return EVS_OK;
+}
+
+extern "C" int64_t evs_cache_staged_rows(evs_cache *c) { return c ? c->n_staged_rows : 0; }
+
 extern "C" int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
                                  int approx_thres, void *stream) {
     using namespace evs;
     EVS_REQUIRE(c, "evs_cache_request: NULL cache");
     if (!c->has_backing) { set_error("evs_cache_request: call evs_cache_set_backing first"); return EVS_ESTATE; }
+    if (c->staged_mask) { set_error("evs_cache_request: a file-backed tier with staged tables serves batched lookups only"); return EVS_ESTATE; }
     if (B == 0) return EVS_OK;
     EVS_REQUIRE(B > 0 && rows && out && hit, "evs_cache_request: NULL argument");
     CacheArgs args;
@@ -1785,18 +1870,77 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     a.host_tomb = c->host_tomb_dev;
     a.estamp = nullptr; a.stamp = 0;
     a.other_slots = nullptr; a.other_mask = 0;
+    a.staged_mask = 0; a.staging = nullptr; a.new_keys = nullptr; a.slot_stage = nullptr; a.stage_rows = 0;
     return EVS_OK;
 }
 
 // K2..K5 of one cache (its misses are described by a.miss_info)
-static void batch_policy(evs_cache *c, const evs::BatchArgs &a, hipStream_t st) {
+static void batch_policy_a(evs_cache *c, const evs::BatchArgs &a, hipStream_t st) {   // K2, K3
     using namespace evs;
-    const int wide = kNumCu * 8;
     hipLaunchKernelGGL(cache_batch_insert_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cache_batch_plan_kernel, dim3(1), dim3(256), 0, st, a);
+}
+static void batch_policy_b(evs_cache *c, const evs::BatchArgs &a, hipStream_t st) {   // K4, K5
+    using namespace evs;
+    const int wide = kNumCu * 8;
     long long ne = ((long long)a.cap + 255) / 256; if (ne > wide) ne = wide;
     hipLaunchKernelGGL(cache_batch_evict_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cache_batch_assign_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
+}
+static void batch_policy(evs_cache *c, const evs::BatchArgs &a, hipStream_t st) {
+    batch_policy_a(c, a, st);
+    batch_policy_b(c, a, st);
+}
+
+// File mode between K3 and K4: list the batch's new keys, hand them to the host's reader pool, which copies their rows
+// out of the file mappings into the pinned staging buffer (row i = new key i).  Two small device-to-host copies and
+// one synchronise per batch: this is the capacity tier (tables larger than what may be pinned), not the fast one.
+extern "C" int evs_filetier_fetch(evs_filetier *ft, int64_t n, const uint64_t *keys, void *dst, uint32_t skip_mask);
+static int batch_stage_prepare(evs_cache *c, evs::BatchArgs &a, hipStream_t st) {   // before K2: buffers and arguments
+    using namespace evs;
+    const long long want = a.B * a.T;
+    if (want > c->staging_rows) {
+        EVS_HIP_CHECK(hipStreamSynchronize(st));
+        if (c->new_keys) (void)hipFree(c->new_keys);
+        if (c->new_keys_host) (void)hipHostFree(c->new_keys_host);
+        if (c->staging) (void)hipHostFree(c->staging);
+        c->new_keys = nullptr; c->new_keys_host = nullptr; c->staging = nullptr; c->staging_rows = 0;
+        EVS_HIP_CHECK(hipMalloc(&c->new_keys, want * 8));
+        EVS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->new_keys_host), want * 8 + 8, hipHostMallocDefault));
+        EVS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->staging), want * (long long)a.row_bytes, hipHostMallocMapped));
+        EVS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->staging_dev), c->staging, 0));
+        c->staging_rows = want;
+    }
+    if (!c->slot_stage) EVS_HIP_CHECK(hipMalloc(&c->slot_stage, c->nslot * 4));
+    a.staged_mask = c->staged_mask; a.staging = c->staging_dev; a.new_keys = c->new_keys; a.slot_stage = c->slot_stage;
+    a.stage_rows = c->staging_rows;
+    return EVS_OK;
+}
+static int batch_stage_rows(evs_cache *c, evs::BatchArgs &a, hipStream_t st) {      // between K3 and K4
+    using namespace evs;
+    hipLaunchKernelGGL(cache_batch_list_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
+    int cnt[2] = {0, 0};
+    EVS_HIP_CHECK(hipMemcpyAsync(&cnt[0], &a.bs->n_new, sizeof(int), hipMemcpyDeviceToHost, st));
+    EVS_HIP_CHECK(hipMemcpyAsync(&cnt[1], &a.bs->n_orphan, sizeof(int), hipMemcpyDeviceToHost, st));
+    EVS_HIP_CHECK(hipStreamSynchronize(st));
+    const long long rows = c->staging_rows;
+    long long n_new = cnt[0] < rows ? cnt[0] : rows;
+    long long n_orph = cnt[1] < rows - n_new ? cnt[1] : rows - n_new;
+    if (n_new > 0) EVS_HIP_CHECK(hipMemcpyAsync(c->new_keys_host, c->new_keys, (size_t)n_new * 8, hipMemcpyDeviceToHost, st));
+    if (n_orph > 0) EVS_HIP_CHECK(hipMemcpyAsync(c->new_keys_host + (rows - n_orph), c->new_keys + (rows - n_orph), (size_t)n_orph * 8,
+                                                 hipMemcpyDeviceToHost, st));
+    if (n_new > 0 || n_orph > 0) EVS_HIP_CHECK(hipStreamSynchronize(st));
+    uint32_t skip = 0;
+    for (int k = 0; k < a.T; k++) if (!((c->staged_mask >> k) & 1u)) skip |= 1u << k;
+    const long long lo[2] = {0, rows - n_orph}, len[2] = {n_new, n_orph};
+    for (int part = 0; part < 2; part++) {
+        if (len[part] <= 0) continue;
+        const int rc = evs_filetier_fetch(c->ft, len[part], reinterpret_cast<const uint64_t *>(c->new_keys_host + lo[part]),
+                                          c->staging + lo[part] * (long long)a.row_bytes, skip);
+        if (rc) return rc;
+        for (long long i = 0; i < len[part]; i++) c->n_staged_rows += ((c->staged_mask >> ((int)(c->new_keys_host[lo[part] + i] >> 32) - 1)) & 1u);
+    }
+    return EVS_OK;
 }
 
 // K6: close the batch; the hash is rebuilt without tombstones when they exceed nslot/8 -- the host learns the count
@@ -1860,11 +2004,16 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
     // side stream under the consumer was measured and is slower: 101 vs 91 us per batch -- the consumer
     // already saturates the memory system and the two event waits cost more than the overlap returns.)
     if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
-    batch_policy(c, a, st);
+    const bool file_mode = c->ft && c->staged_mask;
+    if (file_mode) { const int rc = batch_stage_prepare(c, a, st); if (rc) return rc; }
+    batch_policy_a(c, a, st);
+    if (file_mode) { const int rc = batch_stage_rows(c, a, st); if (rc) return rc; }
+    batch_policy_b(c, a, st);
     if (host_tier) {
         hipLaunchKernelGGL(cache_batch_patch_ptrs_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
         const int rc = consumers(); if (rc) return rc;
     }
+    if (file_mode) hipLaunchKernelGGL(cache_batch_unstage_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
     batch_close(c, a, st);
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;

@@ -136,4 +136,13 @@ int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// evs_filetier.hip (accessors for evs_cache.hip)
+}  // namespace evs
+struct evs_filetier;
+namespace evs {
+int filetier_tables(const evs_filetier *ft);
+long long filetier_row_bytes(const evs_filetier *ft);
+long long filetier_rows(const evs_filetier *ft, int k);
+const void *filetier_dev(const evs_filetier *ft, int k);
+
 }  // namespace evs

@@ -26,6 +26,46 @@ def _dev_ptr(t):
     return p
 
 
+class FileTier:
+    """File-backed miss tier (evs_filetier_*): ev-table-N.bin files mapped read-only; tables registered with the GPU
+    smallest first while they fit pinned_budget_bytes (read zero-copy by the kernels), the rest served through the
+    host's reader pool (mmap_file_read.py:32-40 semantics: row r at byte row_bytes * r)."""
+
+    def __init__(self, paths, row_bytes, pinned_budget_bytes):
+        self.paths, self.row_bytes, self.n_tables = list(paths), int(row_bytes), len(paths)
+        arr = (C.c_char_p * self.n_tables)(*[p.encode() for p in self.paths])
+        h = C.c_void_p()
+        _lib.check(_lib.lib().evs_filetier_open(C.byref(h), self.n_tables, arr, self.row_bytes, int(pinned_budget_bytes)))
+        self._h = h
+        rows = (C.c_int64 * self.n_tables)()
+        ptrs = (C.c_void_p * self.n_tables)()
+        reg = (C.c_int * self.n_tables)()
+        pinned = C.c_int64()
+        _lib.check(_lib.lib().evs_filetier_info(self._h, rows, ptrs, reg, C.byref(pinned)))
+        self.n_rows = [int(v) for v in rows]
+        self.registered = [bool(v) for v in reg]
+        self.pinned_bytes = int(pinned.value)
+
+    def fetch(self, keys):
+        """the reader pool: keys (n,) uint64 numpy array of (table_1based << 32 | row) -> (n, row_bytes) uint8"""
+        import numpy as np
+        keys = np.ascontiguousarray(keys, np.uint64)
+        out = np.zeros((len(keys), self.row_bytes), np.uint8)
+        _lib.check(_lib.lib().evs_filetier_fetch(self._h, len(keys), keys.ctypes.data, out.ctypes.data, 0))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().evs_filetier_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GpuCache:
     def __init__(self, policy, capacity, n_tables=26, dim=36, codec=32, variant="python", device="cuda"):
         self.policy, self.capacity, self.n_tables, self.dim, self.codec = policy, int(capacity), n_tables, dim, codec
@@ -56,6 +96,16 @@ class GpuCache:
         ptrs = (C.c_void_p * self.n_tables)(*[_dev_ptr(t) for t in raws])   # pinned host tables: their device-side address
         rows = (C.c_int64 * self.n_tables)(*n_rows)
         _lib.check(_lib.lib().evs_cache_set_backing(self._h, ptrs, rows))
+
+    def set_file_backing(self, tier):
+        """tier: FileTier -- the miss tier is a set of .bin files (registered tables zero-copy, the rest staged by the
+        host's reader pool; batched lookups only when any table is staged)."""
+        assert tier.n_tables == self.n_tables and tier.row_bytes == self.dim * self.codec // 8
+        self._backing = tier  # keep alive
+        _lib.check(_lib.lib().evs_cache_set_file_backing(self._h, tier._h))
+
+    def staged_rows(self):
+        return int(_lib.lib().evs_cache_staged_rows(self._h))
 
     def request(self, rows, approx_thres=-1, out=None, hit=None):
         """rows: (B, n_tables) int32 tensor.  Requests are replayed strictly in order.

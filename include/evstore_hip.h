@@ -250,6 +250,24 @@ EVS_API int evs_cache_lookup_interact(evs_cache *c, int64_t B, const int32_t *ro
 EVS_API int evs_cache_batch_stats(evs_cache *c, int64_t *out8, int64_t *hist, void *stream);
 /* resident (priority, table_1based, row) triples of the batched path, unordered; returns the count. */
 EVS_API int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream);
+/* File-backed miss tier: the reference's mmap miss path (emb_storage/mmap_file_read.py:32-40,
+ * reader pool mixed_precs_caching/evlfu_8.cpp:191-250) under the GPU cache.  evs_filetier_open maps every
+ * ev-table-N.bin read-only (row r at byte row_bytes * r) and REGISTERS tables with the GPU (hipHostRegister, mapped:
+ * kernels read them over the bus, zero-copy) smallest first while their total fits pinned_budget_bytes; the others stay
+ * plain mappings ("staged"): the batched lookup lists the batch's de-duplicated new keys, a pool of host threads copies
+ * those rows out of the mappings into a pinned staging buffer and the fill kernel takes them from there -- every missing
+ * row is read from the file once per batch.  evs_cache_set_file_backing replaces evs_cache_set_backing; with staged
+ * tables only the batched lookups (evs_cache_lookup_batch / _interact) are served.  The tier outlives the cache's use
+ * of it; evs_filetier_close unmaps.  evs_filetier_fetch is the reader pool itself (host memory in, host memory out). */
+typedef struct evs_filetier evs_filetier;
+EVS_API int evs_filetier_open(evs_filetier **out, int n_tables, const char *const *paths, int64_t row_bytes,
+                              int64_t pinned_budget_bytes);
+EVS_API int evs_filetier_info(evs_filetier *ft, int64_t *n_rows, const void **dev_ptrs, int *registered, int64_t *pinned_bytes);
+EVS_API int evs_filetier_fetch(evs_filetier *ft, int64_t n, const uint64_t *keys /* table_1based << 32 | row */, void *dst,
+                               uint32_t skip_mask);
+EVS_API int evs_filetier_close(evs_filetier *ft);
+EVS_API int evs_cache_set_file_backing(evs_cache *c, evs_filetier *ft);
+EVS_API int64_t evs_cache_staged_rows(evs_cache *c);   /* rows the reader pool has fetched for this cache so far */
 /* a12: the alt-key ("approximate embedding") tier C3 -- mixed_precs_caching/aprx_embedding.cpp and
  * evlfu_8.cpp:474-490,492-667 (request_to_c1_c2_c3).  DETERMINISTIC RE-SPECIFICATION, parity unpinned:
  * the reference fills the tier from asynchronous threads racing the request thread.  Here keys evicted

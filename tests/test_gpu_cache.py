@@ -418,6 +418,65 @@ def test_batched_cache_smaller_than_one_batch(E, orc):
         assert st["size"] == len(d) <= 60 and len({(int(t), int(r)) for _, t, r in d}) == len(d)
 
 
+@pytest.mark.parametrize("budget_kb,cap", [(0, 3000), (200, 3000), (10 ** 6, 3000), (200, 40)])
+def test_file_backed_miss_tier(E, orc, tmp_path, budget_kb, cap):
+    """SURVEY 8(f).1 / mmap_file_read.py:32-40: the miss tier is a directory of ev-table-N.bin files larger than the
+    pinned budget.  Tables are registered (zero-copy) smallest first while they fit; the rest are STAGED: the host's
+    reader pool copies the batch's de-duplicated new rows out of the mappings.  Rows exact for hits, staged misses,
+    registered misses and keys that found no room (cap=40: a cache smaller than one batch); cache invariants; the
+    fused consumer gives the same R as the rows; every staged row is read from the file once per batch at most."""
+    rs = np.random.RandomState(9)
+    n_rows = [3000 if k % 5 == 0 else (40 if k % 3 == 0 else 700) for k in range(26)]
+    tabs = [rs.uniform(-1, 1, size=(n, 36)).astype(np.float32) for n in n_rows]
+    paths = []
+    for k, w in enumerate(tabs):
+        p = tmp_path / ("ev-table-%d.bin" % (k + 1))
+        w.tofile(p)
+        paths.append(str(p))
+    total = sum(n * 144 for n in n_rows)
+    ft = E.FileTier(paths, 144, budget_kb * 1024)
+    assert ft.pinned_bytes <= budget_kb * 1024 and ft.n_rows == n_rows
+    if budget_kb == 0:
+        assert not any(ft.registered)
+    elif budget_kb * 1024 >= total:
+        assert all(ft.registered)
+    else:   # the file set is larger than the pinned budget: the small tables are registered, the big ones staged
+        assert any(ft.registered) and not all(ft.registered)
+        assert max(n for n, r in zip(n_rows, ft.registered) if r) <= min(n for n, r in zip(n_rows, ft.registered) if not r)
+    c = E.GpuCache("evlfu", cap, 26, 36, 32)
+    c.set_file_backing(ft)
+    B = 500
+    for it in range(8):
+        hot = rs.rand(B, 26) < 0.6
+        rq = np.where(hot, rs.randint(0, 25, size=(B, 26)), np.stack([rs.randint(0, n, size=B) for n in n_rows], 1)).astype(np.int32)
+        rq = np.minimum(rq, np.asarray(n_rows, np.int32) - 1)
+        r = torch.from_numpy(rq).cuda()
+        before = c.staged_rows()
+        hit, out = c.lookup_batch(r)
+        out = out.cpu().numpy()
+        for k in range(26):
+            assert np.array_equal(out[:, k, :], tabs[k][rq[:, k]]), (it, k)
+        staged_keys = {(k, int(v)) for k in range(26) if not ft.registered[k] for v in rq[:, k]}
+        if cap >= 1000:    # every missing row is read from its file once per batch at most
+            assert c.staged_rows() - before <= len(staged_keys)
+        else:              # a hash smaller than the batch's misses: the keys it drops are staged per request position
+            assert c.staged_rows() - before <= B * sum(1 for k in range(26) if not ft.registered[k])
+        x = torch.rand(B, 36, device="cuda")
+        _, R = c.lookup_interact(r, x)
+        want = orc.interact_features(x.cpu().numpy(), [tabs[k][rq[:, k]] for k in range(26)])
+        np.testing.assert_allclose(R.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+        st = c.batch_stats()
+        d = c.batch_dump()
+        assert st["size"] == len(d) <= cap and len({(int(t), int(rr)) for _, t, rr in d}) == len(d)
+    assert c.batch_stats()["n_hits"] > 0
+    if not all(ft.registered):
+        assert c.staged_rows() > 0
+        with pytest.raises(E.EvsError):   # the exact batch-1 machine cannot wait for the host's reader pool
+            c2 = E.GpuCache("evlfu", 100, 26, 36, 32)
+            c2.set_file_backing(ft)
+            c2.request(torch.zeros((1, 26), dtype=torch.int32, device="cuda"))
+
+
 def test_batched_host_tier_flush_with_pinned_hits(E, orc):
     """Found by tools/fuzz_cache.py: one table (every hit has the top priority, so the EvLFU flush fires), a 50-entry
     cache in front of host-memory tables, batches far larger than the cache.  Hits of the running batch are pinned,

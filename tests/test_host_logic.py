@@ -106,3 +106,30 @@ def test_inference_loop_stamps_and_dlrm_wrap_order():
     stamps = IL.inference(ld, fwd, use_gpu=False, device="cpu", consume=got.append)
     assert len(stamps) == 6 and stamps == sorted(stamps) and len(got) == 5
     assert seen[0] == ((4, 13), (3, 4), 3)
+
+
+def test_file_tier_reader_pool_reads_the_reference_file_format(tmp_path):
+    """evs_filetier_open / _fetch without a GPU (budget 0: nothing is registered): rows come back exactly as the
+    reference's mmap reader returns them (emb_storage/mmap_file_read.py:32-40: seek(144 * row), read(144))."""
+    import numpy as np
+    import evstore_dlrm_amd as E
+    rs = np.random.RandomState(2)
+    n_rows = [50, 3, 4000, 17]
+    tabs = [rs.uniform(-1, 1, size=(n, 36)).astype(np.float32) for n in n_rows]
+    paths = []
+    for k, w in enumerate(tabs):
+        p = tmp_path / ("ev-table-%d.bin" % (k + 1))
+        w.tofile(p)
+        paths.append(str(p))
+    ft = E.FileTier(paths, 144, 0)
+    assert ft.n_rows == n_rows and not any(ft.registered) and ft.pinned_bytes == 0
+    keys = np.array([((t + 1) << 32) | r for t, r in ((0, 0), (2, 3999), (1, 2), (3, 16), (2, 17), (0, 49))] * 1500, np.uint64)
+    got = ft.fetch(keys).view(np.float32)      # 9000 keys: the threaded path
+    for i in range(0, len(keys), 997):
+        t, r = int(keys[i] >> 32) - 1, int(keys[i] & 0xffffffff)
+        assert np.array_equal(got[i], tabs[t][r])
+    ft.close()
+    with pytest.raises(E.EvsError):
+        E.FileTier([paths[0], str(tmp_path / "missing.bin")], 144, 0)
+    with pytest.raises(E.EvsError):
+        E.FileTier(paths, 100, 0)   # not a whole number of rows
