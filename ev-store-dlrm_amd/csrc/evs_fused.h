@@ -27,6 +27,11 @@ struct FusedArgs {
                                // array is not arange; then the bag-1 loop runs if it is absent, the general loop if present
     int enc_lds;               // reduced precision: feature 0 is x, every other feature a 4-byte aligned table
     int tile_per;              // index-tile kernel: samples per block (block i owns [i * tile_per, (i + 1) * tile_per))
+    // first top-MLP layer fused behind the interaction (evs_fused_rf.hip, MLP variant): Z1 = act(R W1^T + b1)
+    const float *w1p;          // W1 zero-padded to (n1 rounded up to 16) x kp floats, kp = K rounded up to 16, K = d + P
+    const float *b1;           // n1 biases
+    float *z1;                 // (B, n1) out
+    int n1, kp, relu, write_r; // write_r: also store R (B, d + P)
 };
 
 
@@ -35,5 +40,7 @@ constexpr int kTileMaxF = 28;   // index-tile launches: x + at most 27 tables
 // evs_fused_rf.hip: the rows-in-flight-in-registers form of the bag-1 index-tile loop (fp32 tables, d in {16, 32, 36},
 // F <= kTileMaxF); returns false when it has no kernel for the shape (the caller then uses the LDS-DMA loop)
 bool launch_rf(const FusedArgs &a, hipStream_t st);
+// the same kernel with the first top-MLP layer behind it (any batch size); false = no kernel for the shape
+bool launch_rf_mlp(const FusedArgs &a, hipStream_t st);
 
 }  // namespace evs

@@ -1405,3 +1405,45 @@ extern "C" int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec, 
     }
     return evs_emb_interact_dot(B, T + 1, d, codec, ft, itself, R, stream);
 }
+
+// R = interact_features(x, apply_emb(...)) followed by the FIRST layer of the top MLP, Z1 = act(R W1^T + b1), in one
+// launch (dlrm_s_pytorch.py:596-605: ly = apply_emb; z = interact_features; p = apply_mlp(z, top_l)).  One index per
+// bag (the Criteo collate), fp32 tables, d in {16, 32, 36}, T <= 27.  w1_padded: W1 (n1 x K, K = d + P) zero-padded to
+// (n1 rounded up to 16) rows of kp = (K rounded up to 16) floats, 16-byte aligned.  R may be NULL (not written).
+extern "C" int evs_emb_interact_mlp1_stacked(int64_t B, int T, int d, const void *const *tables, const int64_t *n_rows,
+                                             const float *x, int64_t x_stride, const int64_t *indices_base,
+                                             int64_t indices_row_stride, int itself, const float *w1_padded, int kp,
+                                             const float *b1, int n1, int relu, float *Z1, float *R, void *stream) {
+    using namespace evs;
+    const int F = T + 1;
+    EVS_REQUIRE(B >= 0 && B < (1ll << 31) && T >= 1 && F <= kTileMaxF && (d == 16 || d == 32 || d == 36),
+                "evs_emb_interact_mlp1_stacked: unsupported shape B=%lld T=%d d=%d (need T <= %d, d in {16,32,36})", (long long)B, T, d, kTileMaxF - 1);
+    if (B == 0) return EVS_OK;
+    const int P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    const int K = d + P;
+    EVS_REQUIRE(tables && n_rows && x && indices_base && w1_padded && b1 && Z1, "evs_emb_interact_mlp1_stacked: NULL argument");
+    EVS_REQUIRE(n1 >= 1 && kp == (K + 15) / 16 * 16, "evs_emb_interact_mlp1_stacked: kp must be K = %d rounded up to 16 (got %d), n1 >= 1", K, kp);
+    EVS_REQUIRE(reinterpret_cast<uintptr_t>(w1_padded) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && x_stride % 4 == 0,
+                "evs_emb_interact_mlp1_stacked: w1_padded and x must be 16-byte aligned");
+    FusedArgs a;
+    for (int f = 0; f < EVS_MAX_FEATURES; f++) {
+        a.src[f] = nullptr; a.stride[f] = 0; a.indices[f] = nullptr; a.offsets[f] = nullptr; a.nnz[f] = 0;
+        a.n_rows[f] = 0; a.row_w[f] = nullptr; a.off_len[f] = B;
+    }
+    a.src[0] = x; a.stride[0] = x_stride;
+    for (int k = 0; k < T; k++) {
+        EVS_REQUIRE(tables[k] && reinterpret_cast<uintptr_t>(tables[k]) % 16 == 0 && n_rows[k] >= 0 && n_rows[k] < (1ll << 31),
+                    "evs_emb_interact_mlp1_stacked: table %d must be 16-byte aligned with fewer than 2^31 rows", k);
+        a.src[k + 1] = tables[k]; a.indices[k + 1] = indices_base + (int64_t)k * indices_row_stride;
+        a.nnz[k + 1] = B; a.n_rows[k + 1] = n_rows[k];
+    }
+    a.zeros = zero_page();
+    a.err = index_error_flag();
+    if (!a.zeros || !a.err) return EVS_EHIP;
+    a.R = R; a.B = B; a.F = F; a.d = d; a.itself = itself ? 1 : 0; a.P = P;
+    a.dummy_i64 = indices_base; a.dummy_f32 = x; a.bag1 = 1; a.enc_lds = 0; a.opt_flag = nullptr; a.opt_id = 0; a.tile_per = 16;
+    a.w1p = w1_padded; a.b1 = b1; a.z1 = Z1; a.n1 = n1; a.kp = kp; a.relu = relu ? 1 : 0; a.write_r = R ? 1 : 0;
+    if (!launch_rf_mlp(a, reinterpret_cast<hipStream_t>(stream))) { set_error("evs_emb_interact_mlp1_stacked: no kernel for this shape"); return EVS_EINVAL; }
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
+}

@@ -43,8 +43,18 @@ typedef const __attribute__((address_space(1))) f32x4 *gf4_t;
 #define EVS_OUT_CPOL 2   // nt: R is written once and streams out (see evs_fused.hip)
 #endif
 
-template <int CQ, int REM, int NT, int D>
-__global__ void __launch_bounds__(256, EVS_RF_LB) emb_interact_rf_kernel(const FusedArgs args) {
+// MLP: the first top-MLP layer (dlrm_s_pytorch.py:601-605: p = apply_mlp(z, top_l); its first nn.Linear + ReLU) fused
+// behind the interaction.  The 16 output rows of the block's chunk stay in LDS (s_R, zero-padded to kp columns) and are
+// the A operand (M = 16 samples) of Z1 = act(R W1^T + b1): 16 x 16 output tiles, one v_mfma_f32_16x16x4_f32 chain of
+// kp / 4 steps each, the four waves taking the n1 / 16 tiles in turn; W1 arrives zero-padded and row-aligned (w1p) and
+// is read straight from L2 (the whole 0.8 MB matrix is re-read per 16 samples: 0.8 GB of L2 traffic at B = 16 384, and
+// 100 MFMAs per tile -- with the layer the kernel is matrix-core-bound, not HBM-bound).  k-slot q of the MFMA owns the
+// contiguous columns [q * kp/4, (q+1) * kp/4) of both operands, so they are read as 16-byte pieces.  R itself is
+// written only when asked for.
+constexpr int kMlpRowStride = 452;   // floats per staged row: kp <= 448 (F <= 28, d <= 36, diagonal kept) + 4 (bank spread)
+
+template <int CQ, int REM, int NT, int D, bool MLP = false>
+__global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_kernel(const FusedArgs args) {
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
     constexpr int d = 4 * (4 * CQ + REM);
@@ -63,7 +73,11 @@ __global__ void __launch_bounds__(256, EVS_RF_LB) emb_interact_rf_kernel(const F
     __shared__ unsigned long long s_feat_base[32];                        // per feature: first row / bytes between rows -- read per
     __shared__ unsigned s_feat_scale[32];                                 // load instead of living in 12 VGPRs per lane
     constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
-    __shared__ __attribute__((aligned(16))) float s_out[4][OUT_MAX + 16];
+    // staged output rows: one slot per wave (flushed an iteration later), or with MLP all 16 rows of the chunk
+    constexpr int kOutRows = MLP ? 16 : 4;
+    constexpr int kOutStride = MLP ? kMlpRowStride : OUT_MAX + 16;
+    __shared__ __attribute__((aligned(16))) float s_out[kOutRows][kOutStride];
+    __shared__ float s_dump[MLP ? 4 * 16 : 1];   // MLP: where the never-stored accumulator elements go
 
     const int lane = threadIdx.x & (kWave - 1);
     const int r16 = lane & 15;
@@ -74,7 +88,7 @@ __global__ void __launch_bounds__(256, EVS_RF_LB) emb_interact_rf_kernel(const F
     const FusedArgs *ka = (const FusedArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     char *my_lds = s_rows[wave_in_block];
-    float *my_out = s_out[wave_in_block];
+    float *my_out = s_out[wave_in_block];   // (MLP: re-pointed per sample)
     const char *zeros_l = reinterpret_cast<const char *>(args.zeros);
 
     // ---- the block's sample range and the feature table of the tile ------------------------------------
@@ -113,6 +127,7 @@ __global__ void __launch_bounds__(256, EVS_RF_LB) emb_interact_rf_kernel(const F
     // (`on` false: a zero-length buffer resource, the hardware drops every store -- the loop body has no branch around
     //  its vector-memory operations, see the main loop)
     auto flush_out = [&](int64_t bp, bool on) {
+        if constexpr (MLP) on = on && args.write_r;
         float *Rb = args.R + (on ? bp : 0) * (int64_t)out_row;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, on ? out_row * 4 : 0, 0x00020000);
         const int n4 = out_row >> 2;   // whole 16-byte pieces; the 0..3 trailing floats go as dwords
@@ -241,16 +256,22 @@ __global__ void __launch_bounds__(256, EVS_RF_LB) emb_interact_rf_kernel(const F
         flush_out(b - 4, u > 0 && u - 1 < n_samples);    // sample u-1 leaves under the MFMAs of sample u
         f32x4 c00, c10, c11;
         interact(a, c00, c10, c11);
+        if constexpr (MLP) my_out = s_out[wave_in_block + 4 * u];
+        // never-stored elements go to a dump slot: behind the row, or (MLP) in a block of their own
+        const int dump = MLP ? (int)(reinterpret_cast<char *>(&s_dump[wave_in_block * 16 + r16]) - reinterpret_cast<char *>(my_out))
+                             : 4 * (OUT_MAX + r16);
         // stage the output row: x passthrough, then the packed lower triangle straight from the accumulators
 #pragma unroll
         for (int h = 0; h < (d + 63) / 64; h++) {
             const int e = lane + 64 * h;
-            my_out[e < d ? e : OUT_MAX + r16] = xv[h];
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + (e < d ? 4 * e : dump)) = xv[h];
+        }
+        if constexpr (MLP) {   // zero the padding columns [K, kp) of the GEMM operand
+            if (lane < args.kp - out_row) my_out[out_row + lane] = 0.f;
         }
 #pragma unroll
-        for (int v = 0; v < 4; v++) {   // never-stored elements go to a dump slot behind the row
+        for (int v = 0; v < 4; v++) {
             const int i = 4 * q + v;
-            const int dump = 4 * (OUT_MAX + r16);
             const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
             *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
             if constexpr (NT == 2) {
@@ -263,8 +284,62 @@ __global__ void __launch_bounds__(256, EVS_RF_LB) emb_interact_rf_kernel(const F
             }
         }
     }
+    if constexpr (MLP) my_out = s_out[wave_in_block + 12];
     flush_out(blk_first + wave_in_block + 12, n_samples == 4);
     if (bad) atomicOr(args.err, 1);
+    if constexpr (MLP) {
+        __syncthreads();   // the chunk's 16 staged rows are complete
+        const int kp = args.kp, kq = kp >> 2, n1 = args.n1;
+        const int n_tiles = (n1 + 15) >> 4;
+        const float *arow = &s_out[r16][q * kq];                          // A: sample r16, k-slot q
+        for (int nt = wave_in_block; nt < n_tiles; nt += 4) {
+            const int n = 16 * nt + r16;
+            const float *wrow = args.w1p + (size_t)n * kp + q * kq;       // B: output n, k-slot q (rows padded to 16 * n_tiles)
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // software pipeline: the operand pieces of step group g + 1 (kPf steps of 4 MFMAs) are requested before the
+            // MFMAs of group g issue -- W1 comes from L2 (~500 cycles), a load-use loop runs at 4 MFMAs per round trip
+            // (measured at B = 16 384, n1 = 512: 229 -> 137 us; two tiles per wave sharing the A pieces: 195 us, dropped)
+            constexpr int kPf = 5;
+            const int nj = kq >> 2;                    // 16-byte pieces per k-slot
+            f32x4 bq[kPf];
+            float4 aq[kPf];
+#pragma unroll
+            for (int p = 0; p < kPf; p++) {
+                const int j = p < nj ? p : 0;
+                bq[p] = *reinterpret_cast<gf4_t>(reinterpret_cast<uintptr_t>(wrow + 4 * j));
+                aq[p] = *reinterpret_cast<const float4 *>(arow + 4 * j);
+            }
+            for (int g = 0; g < nj; g += kPf) {
+                f32x4 bc[kPf];
+                float4 ac[kPf];
+#pragma unroll
+                for (int p = 0; p < kPf; p++) { bc[p] = bq[p]; ac[p] = aq[p]; }
+#pragma unroll
+                for (int p = 0; p < kPf; p++) {        // next group (clamped: the last group re-reads piece 0, unused)
+                    const int j = g + kPf + p < nj ? g + kPf + p : 0;
+                    bq[p] = *reinterpret_cast<gf4_t>(reinterpret_cast<uintptr_t>(wrow + 4 * j));
+                    aq[p] = *reinterpret_cast<const float4 *>(arow + 4 * j);
+                }
+#pragma unroll
+                for (int p = 0; p < kPf; p++) {
+                    if (g + p < nj) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[p].x, bc[p][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[p].y, bc[p][1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[p].z, bc[p][2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[p].w, bc[p][3], acc, 0, 0, 0);
+                    }
+                }
+            }
+            const float bias = n < n1 ? args.b1[n] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {   // lane holds Z1[sample 4q + v][output n]
+                const int m = 4 * q + v;
+                float z = acc[v] + bias;
+                if (args.relu) z = z > 0.f ? z : 0.f;
+                if (m < blk_n && n < n1) args.z1[(blk_first + m) * (int64_t)n1 + n] = z;
+            }
+        }
+    }
 }
 
 static int rf_mode() {
@@ -284,6 +359,24 @@ static int64_t rf_max_batch() {
     static int64_t v = -1;
     if (v < 0) { const char *e = getenv("EVS_FUSED_RF_MAX_B"); v = e ? atoll(e) : 16ll * kNumCu * EVS_RF_LB; }
     return v;
+}
+
+bool launch_rf_mlp(const FusedArgs &a, hipStream_t st) {
+    if (a.F > kTileMaxF || a.bag1 != 1 || a.kp > kMlpRowStride - 4 || (a.kp & 15) || a.kp < a.d + a.P) return false;
+    const bool nt2 = a.F > 16;
+    switch (a.d) {
+    case 16:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<1, 0, 2, 4, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<1, 0, 1, 4, true>>(a, st);
+        return true;
+    case 32:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 0, 2, 4, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 0, 1, 4, true>>(a, st);
+        return true;
+    case 36:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 1, 2, 4, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 1, 1, 4, true>>(a, st);
+        return true;
+    default:
+        return false;
+    }
 }
 
 bool launch_rf(const FusedArgs &a, hipStream_t st) {

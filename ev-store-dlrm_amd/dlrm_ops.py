@@ -380,3 +380,48 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
     if check_indices:
         _lib.check(L.evs_check_index_errors(stream))
     return R
+
+
+_w1_cache = {}
+
+
+def pad_top_layer(W1, K):
+    """W1 (n1, K) -> the layout evs_emb_interact_mlp1_stacked reads: zero-padded to ((n1+15)//16*16, (K+15)//16*16), cached per
+    weight tensor (and its version counter: an in-place update re-pads)."""
+    key = (W1.data_ptr(), tuple(W1.shape), W1._version)
+    hit = _w1_cache.get(key)
+    if hit is None:
+        n1 = int(W1.shape[0])
+        kp = (K + 15) // 16 * 16
+        hit = torch.zeros(((n1 + 15) // 16 * 16, kp), dtype=torch.float32, device=W1.device)
+        hit[:n1, :K] = W1.detach().to(torch.float32)
+        if len(_w1_cache) > 16:
+            _w1_cache.clear()
+        _w1_cache[key] = hit
+    return hit
+
+
+def apply_emb_interact_mlp1(x, lS_o, lS_i, emb_l, W1, b1, relu=True, arch_interaction_itself=False, return_R=False):
+    """Z1 = act(interact_features(x, apply_emb(lS_o, lS_i, emb_l)) @ W1.T + b1) in ONE kernel: the first nn.Linear (+ ReLU) of
+    the top MLP (dlrm_s_pytorch.py:601-605 with create_mlp :205-245) behind the fused gather + interaction, R staying in
+    LDS.  Criteo layout only: lS_i (T,B) int64 with one index per bag (lS_o must be arange and is not read), fp32 tables,
+    d in {16, 32, 36}, T <= 27.  W1: (n1, d + P) as nn.Linear.weight, b1: (n1,).  -> Z1 (B, n1) [, R (B, d + P)]."""
+    ev = _as_evtables(emb_l)
+    T, d = len(ev), ev.d
+    F = T + 1
+    B = int(x.shape[0])
+    P = F * (F + 1) // 2 if arch_interaction_itself else F * (F - 1) // 2
+    K = d + P
+    assert ev.codec == 32 and torch.is_tensor(lS_i) and lS_i.dtype == torch.int64 and lS_i.is_cuda and lS_i.shape == (T, B) and lS_i.stride(1) == 1
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, d) and x.stride(1) == 1
+    assert W1.shape[1] == K and b1.shape == (W1.shape[0],) and W1.is_cuda and b1.is_cuda
+    n1 = int(W1.shape[0])
+    w1p = pad_top_layer(W1, K)
+    b1c = b1.detach().to(torch.float32).contiguous()
+    Z1 = torch.empty((B, n1), dtype=torch.float32, device=ev.device)
+    R = torch.empty((B, K), dtype=torch.float32, device=ev.device) if return_R else None
+    _lib.check(_lib.lib().evs_emb_interact_mlp1_stacked(
+        B, T, d, ev._tables_c, ev._n_rows_c, x.data_ptr(), int(x.stride(0)) if B > 1 else d, lS_i.data_ptr(), lS_i.stride(0),
+        int(bool(arch_interaction_itself)), w1p.data_ptr(), int(w1p.shape[1]), b1c.data_ptr(), n1, int(bool(relu)),
+        Z1.data_ptr(), R.data_ptr() if R is not None else None, _stream_ptr(ev.device)))
+    return (Z1, R) if return_R else Z1

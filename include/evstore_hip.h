@@ -176,6 +176,16 @@ EVS_API int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec,
                                  int64_t nnz_per_table,
                                  const int64_t *offsets_base, int64_t offsets_row_stride,
                                  const float *const *row_weights, int itself, float *R, void *stream);
+/* SURVEY 8(f).3, second half: the apply_emb -> interact_features -> FIRST top-MLP layer chain of
+ * DLRM_Net.sequential_forward (dlrm_s_pytorch.py:596-605) in one launch: Z1 = act(R W1^T + b1), act = ReLU when relu != 0
+ * (create_mlp, dlrm_s_pytorch.py:205-245: nn.Linear + nn.ReLU).  The interaction rows of 16 samples stay in LDS and feed
+ * fp32 MFMA tiles against W1; R reaches HBM only when R != NULL.  One index per bag (indices (T,B) int64, bag b = index b),
+ * fp32 tables, d in {16, 32, 36}, T <= 27.  w1_padded: W1 (n1 x K row-major, K = d + P) zero-padded to ((n1 + 15) / 16 * 16)
+ * rows of kp = (K + 15) / 16 * 16 floats, 16-byte aligned; b1: n1 floats; Z1: (B, n1) fp32. */
+EVS_API int evs_emb_interact_mlp1_stacked(int64_t B, int T, int d, const void *const *tables, const int64_t *n_rows,
+                                          const float *x, int64_t x_stride, const int64_t *indices_base,
+                                          int64_t indices_row_stride, int itself, const float *w1_padded, int kp,
+                                          const float *b1, int n1, int relu, float *Z1, float *R, void *stream);
 
 /* "cat" interaction (dlrm_s_pytorch.py:506-508): R[b] = [x[b] | ly_0[b] | ...], (B, F*d). */
 EVS_API int evs_interact_cat(int64_t B, int F, int d, const float *const *feats,

@@ -806,3 +806,63 @@ def test_sharded_step_as_hip_graph_replays_the_eager_result(E, orc):
         assert torch.equal(R, want), rep
         ly = orc.apply_emb([o.cpu().numpy() for o in off], [i.cpu().numpy() for i in idx], [tabs[t].numpy() for t in range(len(ln))])
         np.testing.assert_allclose(R.cpu().numpy(), orc.interact_features(x.cpu().numpy(), ly), rtol=RTOL, atol=2e-6)
+
+
+# ---- first top-MLP layer fused behind the interaction (dlrm_s_pytorch.py:601-605) ----
+@pytest.mark.parametrize("name", ["dist_w2_kaggle", "dist_w4_kaggle"])
+def test_fused_top_mlp_first_layer_vs_reference_Z(E, name):
+    """apply_emb -> interact_features -> first top layer (Linear + ReLU) in one launch, against what the REFERENCE's
+    DLRM_Net produced (fixtures of tests/golden/make_golden_dist.py: per-rank x, R, Z and the MLP weights): R when asked
+    for, Z1 through the recorded last layer (Linear + Sigmoid) = the recorded Z, within 1e-5."""
+    from _dist_helpers import load_dist
+    f = load_dist(name)
+    T, d, Bg = len(f["ln_emb"]), f["d"], f["Bg"]
+    x = _dev(np.concatenate([r["x"] for r in f["ranks"]]))
+    R_ref = np.concatenate([r["R"] for r in f["ranks"]])
+    Z_ref = np.concatenate([r["Z"] for r in f["ranks"]])
+    ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in f["tables"]])
+    lS_i = _dev(np.stack(f["lS_i"]))
+    lS_o = _dev(f["lS_o"])
+    W2, b2, W3, b3 = [f["mlp"][i] for i in (4, 5, 6, 7)]
+    Z1, R = E.apply_emb_interact_mlp1(x, lS_o, lS_i, ev, _dev(W2), _dev(b2), relu=True, return_R=True)
+    np.testing.assert_allclose(R.cpu().numpy(), R_ref, rtol=RTOL, atol=2e-6)
+    want1 = np.maximum(R_ref.astype(np.float64) @ W2.T.astype(np.float64) + b2, 0)
+    np.testing.assert_allclose(Z1.cpu().numpy(), want1, rtol=RTOL, atol=5e-6)
+    Z = 1.0 / (1.0 + np.exp(-(Z1.cpu().numpy().astype(np.float64) @ W3.T + b3)))
+    np.testing.assert_allclose(Z, Z_ref, rtol=RTOL, atol=1e-6)
+    Z1b = E.apply_emb_interact_mlp1(x, lS_o, lS_i, ev, _dev(W2), _dev(b2), relu=True)      # R not written
+    assert torch.equal(Z1, Z1b)
+
+
+@pytest.mark.parametrize("B,n1,T,d,itself", [(1000, 512, 26, 36, False), (16384, 512, 26, 36, False), (37, 40, 26, 36, True),
+                                              (300, 16, 5, 16, False), (129, 256, 27, 32, False), (1, 1, 26, 36, False)])
+def test_fused_top_mlp_first_layer_shapes(E, orc, B, n1, T, d, itself):
+    """The Kaggle top MLP's first layer (387 -> 512) and odd shapes (ragged last chunk, n1 not a multiple of 16, kept
+    diagonal, F <= 16): Z1 against a float64 product of the fused kernel's own R (which is oracle-checked), linear and
+    with ReLU; bad indices are flagged like everywhere else."""
+    rs = np.random.RandomState(B + n1)
+    ln = [int(v) for v in rs.randint(1, 5000, size=T)]
+    ev = E.EVTables.from_fp32([torch.from_numpy(rs.uniform(-1, 1, size=(n, d)).astype(np.float32)) for n in ln])
+    idx_np = np.stack([rs.randint(0, n, size=B) for n in ln]).astype(np.int64)
+    idx = _dev(idx_np)
+    off = torch.arange(B, device="cuda").repeat(T, 1)
+    x_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    x = _dev(x_np)
+    F = T + 1
+    K = d + (F * (F + 1) // 2 if itself else F * (F - 1) // 2)
+    W = rs.normal(0, 0.2, size=(n1, K)).astype(np.float32)
+    b = rs.normal(0, 0.1, size=(n1,)).astype(np.float32)
+    R = E.apply_emb_interact(x, off, idx, ev, None, itself, one_index_per_bag=True)
+    if B <= 1000:
+        ly = orc.apply_emb([np.arange(B, dtype=np.int64)] * T, list(idx_np), [ev.fp32_view(k).cpu().numpy() for k in range(T)])
+        np.testing.assert_allclose(R.cpu().numpy(), orc.interact_features(x_np, ly, itself), rtol=RTOL, atol=2e-6)
+    lin = R.cpu().numpy().astype(np.float64) @ W.T.astype(np.float64) + b
+    for relu in (True, False):
+        Z1, R2 = E.apply_emb_interact_mlp1(x, off, idx, ev, _dev(W), _dev(b), relu=relu, arch_interaction_itself=itself, return_R=True)
+        assert torch.equal(R2, R)
+        np.testing.assert_allclose(Z1.cpu().numpy(), np.maximum(lin, 0) if relu else lin, rtol=RTOL, atol=2e-5)
+    E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    idx[T - 1, B - 1] = ln[T - 1]
+    E.apply_emb_interact_mlp1(x, off, idx, ev, _dev(W), _dev(b), arch_interaction_itself=itself)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
