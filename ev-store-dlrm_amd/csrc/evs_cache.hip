@@ -2027,11 +2027,32 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
 // C1 not full: C1; C1 full and agg_hit < threshold: odd table index -> C1, even -> C2; else C2 -- served from the
 // destination tier's backing table at that tier's precision and inserted there once per batch (a key two requests
 // route differently goes to C1).  Each tier then runs the single-tier policy update (K2-K6) on its own misses.
+static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out, uint8_t *tier,
+                           int high_agghit_threshold, const float *x, int64_t x_stride, int itself, float *R, void *stream);
+
 extern "C" int evs_cache_lookup_batch_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
                                            uint8_t *tier, int high_agghit_threshold, void *stream) {
+    EVS_REQUIRE(out || B == 0, "evs_cache_lookup_batch_c1c2: NULL out");
+    return batch_c1c2_impl(c1, c2, B, rows, out, tier, high_agghit_threshold, nullptr, 0, 0, nullptr, stream);
+}
+
+// ... with the interaction as the consumer: R = interact_features(x, rows served by the two tiers), every row decoded
+// from the precision of the tier that serves it INSIDE the interaction kernel (evs_mixed.hip) -- no fp32 (B,T,d) rows
+extern "C" int evs_cache_lookup_interact_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, const float *x,
+                                              int64_t x_stride, int itself, float *R, uint8_t *tier,
+                                              int high_agghit_threshold, void *stream) {
+    EVS_REQUIRE((x && R) || B == 0, "evs_cache_lookup_interact_c1c2: NULL x / R");
+    EVS_REQUIRE(x_stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0, "evs_cache_lookup_interact_c1c2: x must be 16-byte aligned, stride %% 4 == 0");
+    return batch_c1c2_impl(c1, c2, B, rows, nullptr, tier, high_agghit_threshold, x, x_stride, itself, R, stream);
+}
+
+static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out, uint8_t *tier,
+                           int high_agghit_threshold, const float *x, int64_t x_stride, int itself, float *R, void *stream) {
     using namespace evs;
     if (B == 0) return EVS_OK;
-    EVS_REQUIRE(c1 && c2 && out && tier, "evs_cache_lookup_batch_c1c2: NULL argument");
+    EVS_REQUIRE(c1 && c2 && tier, "evs_cache_lookup_batch_c1c2: NULL argument");
+    if (R) EVS_REQUIRE((c1->host.dim == 16 || c1->host.dim == 32 || c1->host.dim == 36) && c1->host.n_tables + 1 <= EVS_MAX_FEATURES,
+                       "evs_cache_lookup_interact_c1c2: d must be 16, 32 or 36 and T <= 31");
     EVS_REQUIRE(c1->host.n_tables == c2->host.n_tables && c1->host.dim == c2->host.dim,
                 "evs_cache_lookup_batch_c1c2: the tiers must agree on n_tables and dim");
     EVS_REQUIRE(!c1->host_backing && !c2->host_backing, "evs_cache_lookup_batch_c1c2: backing tables must be in HBM");
@@ -2046,9 +2067,16 @@ extern "C" int evs_cache_lookup_batch_c1c2(evs_cache *c1, evs_cache *c2, int64_t
     TwoTierArgs tt;
     tt.row_tier = c1->row_tier; tt.tier_out = tier; tt.threshold = high_agghit_threshold;
     hipLaunchKernelGGL(cache_batch_probe2_kernel, dim3((unsigned)a1.g1), dim3(256), 0, st, a1, a2, tt);
-    long long nb = (B * T * (long long)c1->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(cache_rows_from_ptrs2_kernel, dim3((unsigned)nb), dim3(256), 0, st, c1->row_ptrs, c1->row_tier, out,
-                       (long long)B, T, c1->host.dim, c1->host.codec, c2->host.codec);
+    if (out) {
+        long long nb = (B * T * (long long)c1->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(cache_rows_from_ptrs2_kernel, dim3((unsigned)nb), dim3(256), 0, st, c1->row_ptrs, c1->row_tier, out,
+                           (long long)B, T, c1->host.dim, c1->host.codec, c2->host.codec);
+    }
+    if (R) {
+        rc = interact_from_mixed_rows(B, T, c1->host.dim, x, x_stride, c1->row_ptrs, c1->row_tier, c1->host.codec, c2->host.codec,
+                                      itself, R, st);
+        if (rc) return rc;
+    }
     batch_policy(c1, a1, st);
     a2.other_slots = c1->bslots; a2.other_mask = c1->host.nslot_mask;   // a key C1 just took is not inserted in C2 too
     batch_policy(c2, a2, st);

@@ -220,12 +220,26 @@ def lookup_batch_c1c2(c1, c2, rows, threshold=23, out=None, tier=None):
     return tier, out
 
 
-def lookup_interact_c1c2(c1, c2, rows, x, threshold=23, itself=False, out=None, tier=None):
-    """lookup_batch_c1c2 followed by interact_features over the served rows (dense features read in place from the
-    (B,T,dim) rows: no copy).  Returns (tier, R)."""
-    from .dlrm_ops import interact_features
-    tier, out = lookup_batch_c1c2(c1, c2, rows, threshold, out, tier)
-    return tier, interact_features(x, list(out.unbind(1)), "dot", itself)
+def lookup_interact_c1c2(c1, c2, rows, x, threshold=23, itself=False, out=None, tier=None, fused=True):
+    """The two-tier snapshot lookup with interact_features as its consumer -> (tier, R).  fused (default): every row is
+    decoded from the precision of the tier that serves it inside the interaction kernel (evs_cache_lookup_interact_c1c2);
+    fused=False: lookup_batch_c1c2 into fp32 (B,T,dim) rows (`out`), then the dense interaction over them."""
+    if not fused or c1.dim not in (16, 32, 36):
+        from .dlrm_ops import interact_features
+        tier, rows_fp32 = lookup_batch_c1c2(c1, c2, rows, threshold, out, tier)
+        return tier, interact_features(x, list(rows_fp32.unbind(1)), "dot", itself)
+    assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
+    B = int(rows.shape[0])
+    F = c1.n_tables + 1
+    P = F * (F + 1) // 2 if itself else F * (F - 1) // 2
+    R = torch.empty((B, c1.dim + P), dtype=torch.float32, device=c1.device)
+    if tier is None:
+        tier = torch.empty((B, c1.n_tables), dtype=torch.uint8, device=c1.device)
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, c1.dim) and x.stride(1) == 1
+    _lib.check(_lib.lib().evs_cache_lookup_interact_c1c2(
+        c1._h, c2._h, B, rows.data_ptr(), x.data_ptr(), int(x.stride(0)) if B > 1 else c1.dim, int(bool(itself)),
+        R.data_ptr(), tier.data_ptr(), int(threshold), torch.cuda.current_stream(c1.device).cuda_stream))
+    return tier, R
 
 
 class GpuAltKeyTier:

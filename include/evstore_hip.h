@@ -249,6 +249,12 @@ EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows,
  * fp32; tier (B,T): 1 = C1 hit, 2 = C2 hit, 0 = miss.  Both caches take the batched path from then on. */
 EVS_API int evs_cache_lookup_batch_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
                                         uint8_t *tier, int high_agghit_threshold, void *stream);
+/* The same two-tier snapshot lookup with the interaction as its consumer (BASELINE configs[4] end to end):
+ * R = interact_features(x, rows) with every row decoded from the precision of the tier that serves it inside the
+ * interaction kernel -- the fp32 (B,T,d) rows are never materialised.  d in {16, 32, 36}, T <= 31. */
+EVS_API int evs_cache_lookup_interact_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, const float *x,
+                                           int64_t x_stride, int itself, float *R, uint8_t *tier,
+                                           int high_agghit_threshold, void *stream);
 /* The same lookup feeding the interaction directly: R = interact_features(x, [rows of the 26 keys])
  * (B, d + F(F-1)/2) without materialising the rows -- the probe writes a table of row addresses
  * (arena row for a hit, backing row for a miss) that the fused MFMA kernel consumes.  fp32 caches,

@@ -594,7 +594,7 @@ def test_batched_two_tier_c1c2(E, orc, thr):
     # the same lookup feeding the interaction: R == interact_features over the rows it served
     x = torch.rand(250, d, device="cuda")
     rows_buf = torch.empty((250, T, d), device="cuda")
-    t2, R = gpu_cache.lookup_interact_c1c2(c1, c2, r[:250].contiguous(), x, threshold=thr, out=rows_buf)
+    t2, R = gpu_cache.lookup_interact_c1c2(c1, c2, r[:250].contiguous(), x, threshold=thr, out=rows_buf, fused=False)
     assert torch.equal(R, E.interact_features(x, list(rows_buf.unbind(1)))) and torch.equal(R[:, :d], x)
     t2, rb = t2.cpu().numpy(), rows_buf.cpu().numpy()
     for b in range(0, 250, 7):
@@ -602,6 +602,49 @@ def test_batched_two_tier_c1c2(E, orc, thr):
             if t2[b, k]:
                 want = (dec8 if t2[b, k] == 1 else dec4)[k][int(reqs[b, k])]
                 assert np.array_equal(rb[b, k].view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("codecs,d", [((8, 4), 36), ((32, 8), 36), ((32, 4), 32), ((8, 4), 16)])
+def test_two_tier_mixed_codec_interaction_consumer(E, orc, codecs, d):
+    """configs[4] end to end without the fp32 (B,T,d) rows: evs_cache_lookup_interact_c1c2 decodes every row from the
+    precision of the tier that serves it inside the interaction kernel.  Which tier serves a MISS depends on the
+    routing, so the tables hold only values every codec represents exactly (-1, 0, 1: u8 codes 0 / 127 / 254, u4 codes
+    14 / 7 / 0): whatever tier serves a key, its row must decode to the same fp32 values -- and does only if address,
+    row size and decoder all belong to that tier.  R against the oracle over the true rows; tier codes against the
+    snapshot (a key reported in C1 / C2 was resident there before the call)."""
+    from evstore_dlrm_amd import gpu_cache
+    rs = np.random.RandomState(17)
+    T = 26
+    n_rows = [300] * T
+    ws = [rs.randint(-1, 2, size=(n, d)).astype(np.float32) for n in n_rows]
+    raws = {c: [orc.encode_table(w, c) for w in ws] for c in codecs}
+    for c in codecs:
+        assert all(np.array_equal(orc.decode(raws[c][k], c, d), ws[k]) for k in range(T))
+    c1 = E.GpuCache("evlfu", 400, T, d, codecs[0], "cpp")
+    c2 = E.GpuCache("evlfu", 900, T, d, codecs[1], "cpp")
+    c1.set_backing([torch.from_numpy(a).cuda() for a in raws[codecs[0]]])
+    c2.set_backing([torch.from_numpy(a).cuda() for a in raws[codecs[1]]])
+    B = 333
+    saw = set()
+    for it in range(8):
+        hot = rs.rand(B, T) < 0.7
+        rq = np.where(hot, rs.randint(0, 12, size=(B, T)), rs.randint(0, 300, size=(B, T))).astype(np.int32)
+        r = torch.from_numpy(rq).cuda()
+        x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+        in1 = {(int(t), int(rw)) for _, t, rw in c1.batch_dump()} if it else set()
+        in2 = {(int(t), int(rw)) for _, t, rw in c2.batch_dump()} if it else set()
+        tier, R = gpu_cache.lookup_interact_c1c2(c1, c2, r, x, itself=bool(it & 1))
+        want = orc.interact_features(x.cpu().numpy(), [ws[k][rq[:, k]] for k in range(T)], bool(it & 1))
+        np.testing.assert_allclose(R.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+        assert torch.equal(R[:, :d], x)
+        tn = tier.cpu().numpy()
+        for b in range(0, B, 5):
+            for k in range(T):
+                key = (k + 1, int(rq[b, k]))
+                assert tn[b, k] == (1 if key in in1 else (2 if key in in2 else 0)), (it, b, k)
+        saw |= set(np.unique(tn).tolist())
+    assert saw == {0, 1, 2}
+    assert c1.batch_stats()["size"] <= 400 and c2.batch_stats()["size"] <= 900
 
 
 @pytest.mark.parametrize("cap", [50, 64, 257])
