@@ -251,6 +251,13 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
 
     for i in range(warmup):
         step(i)
+    # clock settle (as for the headline): keep the GPU busy with replayed warm-up batches for >= 0.35 s -- a 3 ms timed
+    # region right after the host-side batch generation otherwise reads anywhere between 105 and 165 us per batch
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < 0.35:
+        for i in range(20):
+            step(i % warmup)
+        torch.cuda.synchronize()
     s0 = cache.batch_stats()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -385,8 +392,8 @@ def main():
                          "when the whole model fits) -- timed beside the headline as `replicated_all`")
     ap.add_argument("--sharded-mode", default="auto", choices=["auto", "graph", "pipelined"],
                     help="N>1 step loop: graph = each planned step (pool, all-to-all, interaction) captured once as a HIP graph and "
-                         "replayed; pipelined = eager, exchange of batch i+1 under the interaction of batch i; auto = graph with one "
-                         "rank, pipelined with several")
+                         "replayed; pipelined = eager, exchange of batch i+1 under the interaction of batch i; auto = pipelined "
+                         "(graph replay measured slower on this stack)")
     ap.add_argument("--settle-s", type=float, default=0.35,
                     help="clock-settle phase: at least this many seconds of the same launches right before the timed region "
                          "(untimed, reported as settle_s; --steps / --warmup keep their meaning)")

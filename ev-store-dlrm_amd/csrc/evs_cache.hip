@@ -947,7 +947,7 @@ __device__ __forceinline__ int block_reserve_n(int *counter, int n, int *s_tot /
 // 160 B apart, fire-and-forget atomics: a handful per address) that the next single-block kernel folds and
 // clears: K1 -> K3 (plan), K5 -> K6b (end-of-batch bookkeeping).  (Per-block rows folded by one block were
 // no better: a thread walking 277 rows is 277 dependent round trips.)
-constexpr int kPartCols = 40;   // 0..32 priority-histogram deltas, 37 dropped, 38 hits, 39 perfect requests
+constexpr int kPartCols = 40;   // 0..32 priority-histogram deltas, 36 recycled tombstones, 37 dropped, 38 hits, 39 perfect requests
 constexpr int kReplicas = 32;
 constexpr int kProbeGridMax = 8192;   // one request pair per wave up to B = 65 536, then the blocks loop
 
@@ -1160,7 +1160,7 @@ __global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned info = m < n ? args.miss_info[m] : 0u;
     if (m < n && args.hit) args.hit[m] = (info >> 30) & 1u;
-    bool is_new = false;
+    bool is_new = false, recycled = false;
     int slot = -1;
     bool wanted = (info & 0x80000000u) != 0;
     unsigned long long key = 0;
@@ -1173,21 +1173,24 @@ __global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs
     }
     if (wanted) {
         const int agg = (int)((info >> 24) & 63u);
-        // the probe ended on an empty slot: every copy of this key inserted in this batch sits at or after it.
-        // With hint_shift > 0 the hint is rounded down; it is used only when it still lies on the probe path.
-        const unsigned long long h = mix64(key) & args.mask;
-        const unsigned long long hint = (unsigned long long)(info & 0xffffffu) << args.hint_shift;
-        unsigned long long i = ((hint - h) & args.mask) < (args.mask >> 1) ? hint : h;
+        // Walk from the key's HOME slot and take the first slot that is empty OR a tombstone.  Recycling tombstones is
+        // what keeps the chains short in steady state: an insert that only ever took empty slots left every evicted
+        // entry's slot dead until the next rebuild, and after a few thousand batches at capacity the probe kernel ran
+        // 3x slower (17 -> 53 us at B = 16 384) although the table was never more than 55 % occupied.  Every copy of a
+        // key inserted in this batch walks the same sequence and claims with a CAS, so duplicates still meet: the
+        // loser of a race re-reads the slot and finds either its own key (a duplicate: fold the priority) or another
+        // key (walk on).  The key is known to be absent from the table (K1 walked to an empty slot without finding it).
+        unsigned long long i = mix64(key) & args.mask;
         const unsigned long long mine = make_word(key, kFieldPend + (unsigned)agg);
         bool placed = false;
         for (unsigned long long steps = 0; steps <= args.mask; steps++) {   // one lap at most: a full table drops the key
             unsigned long long w = args.slots[i];
-            if (w == kEmpty) {
-                const unsigned long long prev = atomicCAS(&args.slots[i], kEmpty, mine);
-                if (prev == kEmpty) { is_new = true; slot = (int)i; placed = true; break; }  // this thread owns the new key
+            if (w == kEmpty || w == kTomb) {
+                const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
+                if (prev == w) { is_new = true; slot = (int)i; placed = true; recycled = (w == kTomb); break; }  // this thread owns the new key
                 w = prev;
             }
-            if ((w & kKeyMask) == key) { atomicMax(&args.slots[i], mine); placed = true; break; }  // duplicate miss of this batch
+            if ((w & kKeyMask) == key && w != kTomb) { atomicMax(&args.slots[i], mine); placed = true; break; }  // duplicate miss of this batch
             i = (i + 1) & args.mask;
         }
         // file mode: a dropped key of a STAGED table has no address the consumer could read -- the host stages its row
@@ -1206,6 +1209,9 @@ __global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs
     for (int w = 0; w < 4; w++) { if (w < wave) base += s_tot[w]; tot += s_tot[w]; }
     if (is_new) args.new_slot[(long long)blockIdx.x * 256 + base + __popcll(bm & ((1ull << lane) - 1ull))] = slot;
     if (threadIdx.x == 0) args.block_cnt[blockIdx.x] = tot;
+    // tombstones taken back into use: K3 subtracts them from the count that decides on a rebuild (replica column 36)
+    const unsigned long long rm = __ballot(recycled);
+    if (lane == 0 && rm) atomicAdd(&args.part1[(blockIdx.x % kReplicas) * kPartCols + 36], __popcll(rm));
 }
 
 // K3: one block folds K1's partial rows, scans K2's per-block counts into list bases, and thread 0 decides how
@@ -1264,6 +1270,8 @@ __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs a
     if (threadIdx.x == 0) {
         for (int p = 0; p <= T; p++) b->cnt[p] += (int)s_col[p];
         b->n_hits += s_col[38]; b->n_perfect_hits += s_col[39];
+        b->n_tomb -= (int)s_col[36];   // tombstones K2 recycled
+        if (b->n_tomb < 0) b->n_tomb = 0;
         b->n_new = s_scan[255];
         // planning copy of the histogram (the real one is updated by the evict / assign kernels) -- in LDS: as a local
         // array it is indexed dynamically, lands in scratch memory, and a kernel with a scratch segment pays for its set-up
@@ -1567,6 +1575,10 @@ struct evs_cache {
     long long stamp_counter = 0;
     int *host_tomb = nullptr;   // mapped host word: tombstones after the last finished batch (read without a sync)
     int *host_tomb_dev = nullptr;
+    // device memory comes in three slabs (create / first batched call / per-batch buffers): one allocation each, carved
+    // at 256-byte boundaries.  (Fifteen separate hipMallocs left the batched path bimodal from process to process --
+    // 105 or 160 us per 16 384-request batch on the same box -- depending on how the driver happened to back them.)
+    void *slab_create = nullptr, *slab_batch = nullptr, *slab_perbatch = nullptr;
     // file-backed miss tier
     evs_filetier *ft = nullptr;
     unsigned staged_mask = 0;
@@ -1579,10 +1591,7 @@ struct evs_cache {
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
-    void *ptrs[] = {c->st, c->a.keys, c->a.slot_entry, c->a.ekey, c->a.eagg, c->a.efreq, c->a.prev, c->a.next,
-                    c->a.free_stack, c->a.arena, c->a.lfu_head, c->a.lfu_tail, c->a.lfu_len,
-                    c->bs, c->eslot, c->estamp, c->bslots, c->miss_info, c->new_slot, c->row_ptrs, c->iota, c->row_tier,
-                    c->block_cnt, c->block_base, c->part1, c->part2, c->new_keys, c->slot_stage};
+    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->host_tomb) (void)hipHostFree(c->host_tomb);
@@ -1591,6 +1600,24 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
     delete c;
     return EVS_OK;
 }
+
+// one device allocation carved into 256-byte aligned pieces
+namespace {
+struct SlabPlan {
+    struct Item { void **where; size_t bytes; };
+    std::vector<Item> items;
+    template <typename P> void add(P **where, long long bytes) { items.push_back({reinterpret_cast<void **>(where), (size_t)(bytes > 0 ? bytes : 1)}); }
+    size_t total() const { size_t t = 0; for (auto &i : items) t += (i.bytes + 255) & ~(size_t)255; return t; }
+    bool carve(void **slab_out) const {
+        void *base = nullptr;
+        if (hipMalloc(&base, total()) != hipSuccess) { (void)hipGetLastError(); return false; }
+        size_t off = 0;
+        for (auto &i : items) { *i.where = static_cast<char *>(base) + off; off += (i.bytes + 255) & ~(size_t)255; }
+        *slab_out = base;
+        return true;
+    }
+};
+}  // namespace
 
 extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, int n_tables, int dim, int codec,
                                 double flush_rate, double perfect_item_cap, int flush_extra, int perfect_mode) {
@@ -1616,29 +1643,28 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
     h.perfect_mode = perfect_mode;
     h.n_free = (int)capacity; h.least_freq = 1;
     for (int b = 0; b < kMaxBuckets; b++) { h.head[b] = -1; h.tail[b] = -1; h.len[b] = 0; }
-#define EVS_ALLOC(ptr, bytes)                                                                     \
-    do {                                                                                          \
-        if (hipMalloc(reinterpret_cast<void **>(&(ptr)), (bytes)) != hipSuccess) {                \
-            set_error("evs_cache_create: hipMalloc(%lld bytes) failed", (long long)(bytes));      \
-            evs_cache_destroy(c);                                                                 \
-            return EVS_ENOMEM;                                                                    \
-        }                                                                                         \
-    } while (0)
-    EVS_ALLOC(c->st, sizeof(CacheState));
-    EVS_ALLOC(c->a.keys, nslot * 8);
-    EVS_ALLOC(c->a.slot_entry, nslot * 4);
-    EVS_ALLOC(c->a.ekey, capacity * 8);
-    EVS_ALLOC(c->a.eagg, capacity * 4);
-    EVS_ALLOC(c->a.efreq, capacity * 8);
-    EVS_ALLOC(c->a.prev, capacity * 4);
-    EVS_ALLOC(c->a.next, capacity * 4);
-    EVS_ALLOC(c->a.free_stack, capacity * 4);
-    EVS_ALLOC(c->a.arena, capacity * (long long)h.row_bytes);
     c->a.lfu_max_freq = policy == kLFU ? (1ll << 22) : 1;
-    EVS_ALLOC(c->a.lfu_head, c->a.lfu_max_freq * 4);
-    EVS_ALLOC(c->a.lfu_tail, c->a.lfu_max_freq * 4);
-    EVS_ALLOC(c->a.lfu_len, c->a.lfu_max_freq * 4);
-#undef EVS_ALLOC
+    {
+        SlabPlan sp;
+        sp.add(&c->st, sizeof(CacheState));
+        sp.add(&c->a.keys, nslot * 8);
+        sp.add(&c->a.slot_entry, nslot * 4);
+        sp.add(&c->a.ekey, capacity * 8);
+        sp.add(&c->a.eagg, capacity * 4);
+        sp.add(&c->a.efreq, capacity * 8);
+        sp.add(&c->a.prev, capacity * 4);
+        sp.add(&c->a.next, capacity * 4);
+        sp.add(&c->a.free_stack, capacity * 4);
+        sp.add(&c->a.arena, capacity * (long long)h.row_bytes);
+        sp.add(&c->a.lfu_head, c->a.lfu_max_freq * 4);
+        sp.add(&c->a.lfu_tail, c->a.lfu_max_freq * 4);
+        sp.add(&c->a.lfu_len, c->a.lfu_max_freq * 4);
+        if (!sp.carve(&c->slab_create)) {
+            set_error("evs_cache_create: hipMalloc(%lld bytes) failed", (long long)sp.total());
+            evs_cache_destroy(c);
+            return EVS_ENOMEM;
+        }
+    }
     EVS_HIP_CHECK(hipMemset(c->a.keys, 0, nslot * 8));
     EVS_HIP_CHECK(hipMemset(c->a.ekey, 0, capacity * 8));
     EVS_HIP_CHECK(hipMemset(c->a.lfu_head, 0xff, c->a.lfu_max_freq * 4));
@@ -1807,48 +1833,48 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
         BatchState *bs = nullptr;
         int *eslot = nullptr, *part1 = nullptr, *part2 = nullptr, *host_tomb = nullptr, *host_tomb_dev = nullptr;
         unsigned long long *bslots = nullptr;
+        void *slab = nullptr;
+        SlabPlan sp;
+        sp.add(&bs, sizeof(BatchState)); sp.add(&eslot, cap * 4); sp.add(&bslots, c->nslot * 8);
+        sp.add(&part1, kReplicas * kPartCols * 4); sp.add(&part2, kReplicas * kPartCols * 4);
         const bool ok =
-            hipMalloc(&bs, sizeof(BatchState)) == hipSuccess && hipMemcpy(bs, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess &&   // blocking copy
-            hipMalloc(&eslot, cap * 4) == hipSuccess &&
-            hipMalloc(&bslots, c->nslot * 8) == hipSuccess && hipMemsetAsync(bslots, 0, c->nslot * 8, st) == hipSuccess &&   // ordered on the caller's stream
-            hipMalloc(&part1, kReplicas * kPartCols * 4) == hipSuccess && hipMemsetAsync(part1, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
-            hipMalloc(&part2, kReplicas * kPartCols * 4) == hipSuccess && hipMemsetAsync(part2, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
+            sp.carve(&slab) && hipMemcpy(bs, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess &&   // blocking copy
+            hipMemsetAsync(bslots, 0, c->nslot * 8, st) == hipSuccess &&                               // ordered on the caller's stream
+            hipMemsetAsync(part1, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
+            hipMemsetAsync(part2, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
             hipHostMalloc(reinterpret_cast<void **>(&host_tomb), sizeof(int), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer(reinterpret_cast<void **>(&host_tomb_dev), host_tomb, 0) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
-            void *dev_ptrs[] = {bs, eslot, bslots, part1, part2};
-            for (void *q : dev_ptrs) if (q) (void)hipFree(q);
+            if (slab) (void)hipFree(slab);
             if (host_tomb) (void)hipHostFree(host_tomb);
             set_error("%s: allocating the batched-path state failed (capacity %lld)", who, cap);
             return EVS_ENOMEM;
         }
         *host_tomb = 0;
+        c->slab_batch = slab;
         c->bs = bs; c->eslot = eslot; c->bslots = bslots; c->part1 = part1; c->part2 = part2;
         c->host_tomb = host_tomb; c->host_tomb_dev = host_tomb_dev;
     }
     const long long g2 = (B * T + 255) / 256;
-    if (B > c->max_batch) {   // grow the per-batch buffers: new ones first, the old ones go only when all of them exist
+    if (B > c->max_batch) {   // grow the per-batch buffers: the new slab first, the old one goes only when the new one exists
         unsigned *miss_info = nullptr;
         int *new_slot = nullptr, *block_cnt = nullptr, *block_base = nullptr;
         long long *row_ptrs = nullptr, *iota = nullptr;
         unsigned char *row_tier = nullptr;
-        const bool ok = hipMalloc(&miss_info, B * T * 4) == hipSuccess && hipMalloc(&new_slot, g2 * 256 * 4) == hipSuccess &&
-                        hipMalloc(&block_cnt, g2 * 4) == hipSuccess && hipMalloc(&block_base, g2 * 4) == hipSuccess &&
-                        hipMalloc(&row_ptrs, B * T * 8) == hipSuccess && hipMalloc(&row_tier, B * T) == hipSuccess &&
-                        hipMalloc(&iota, B * 8) == hipSuccess;
-        void *fresh[] = {miss_info, new_slot, block_cnt, block_base, row_ptrs, row_tier, iota};
-        if (!ok) {
-            (void)hipGetLastError();
-            for (void *q : fresh) if (q) (void)hipFree(q);
+        void *slab = nullptr;
+        SlabPlan sp;
+        sp.add(&miss_info, B * T * 4); sp.add(&new_slot, g2 * 256 * 4); sp.add(&block_cnt, g2 * 4); sp.add(&block_base, g2 * 4);
+        sp.add(&row_ptrs, B * T * 8); sp.add(&row_tier, B * T); sp.add(&iota, B * 8);
+        if (!sp.carve(&slab)) {
             set_error("%s: allocating the buffers of a %lld-request batch failed", who, (long long)B);
             return EVS_ENOMEM;
         }
-        if (c->miss_info) {
+        if (c->slab_perbatch) {
             EVS_HIP_CHECK(hipStreamSynchronize(st));
-            void *old[] = {c->miss_info, c->new_slot, c->row_ptrs, c->iota, c->block_cnt, c->block_base, c->row_tier};
-            for (void *q : old) (void)hipFree(q);
+            (void)hipFree(c->slab_perbatch);
         }
+        c->slab_perbatch = slab;
         c->miss_info = miss_info; c->new_slot = new_slot; c->block_cnt = block_cnt; c->block_base = block_base;
         c->row_ptrs = row_ptrs; c->row_tier = row_tier; c->iota = iota;
         hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(256), 0, st, c->iota, (long long)B);

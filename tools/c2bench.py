@@ -21,4 +21,17 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for r in rq[80:]:
     gpu_cache.lookup_batch_c1c2(c1, c2, r, out=out, tier=tier)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print("two-tier batched: %.1f us per batch, %.2f G lookups/s, C1 %d C2 %d resident" % (dt / 20 * 1e6, T * B * 20 / dt / 1e9, c1.batch_stats()["size"], c2.batch_stats()["size"]))
+print("two-tier batched, fp32 rows out: %.1f us per batch, %.2f G lookups/s, C1 %d C2 %d resident" % (dt / 20 * 1e6, T * B * 20 / dt / 1e9, c1.batch_stats()["size"], c2.batch_stats()["size"]))
+# the same lookup feeding the interaction: rows materialised then dense interaction, vs decoded inside the consumer
+x = torch.rand((B, d), device=dev)
+bs2 = bench.make_batches(ln, B, 60, seed=22, device=dev, dist="zipf", alpha=0.75)
+rq2 = [b[1].t().contiguous().to(torch.int32) for b in bs2]
+for fused in (False, True):
+    for r in rq2[:10]:
+        gpu_cache.lookup_interact_c1c2(c1, c2, r, x, out=out, tier=tier, fused=fused)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for r in rq2[10:30] if not fused else rq2[30:50]:
+        gpu_cache.lookup_interact_c1c2(c1, c2, r, x, out=out, tier=tier, fused=fused)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("two-tier batched + interaction (%s): %.1f us per batch, %.2f G lookups/s"
+          % ("mixed-codec consumer" if fused else "fp32 rows, then dense interaction", dt / 20 * 1e6, T * B * 20 / dt / 1e9))
