@@ -70,8 +70,10 @@ struct RowPiece<4> {
 };
 
 // LPR = lanes per row (d = 4*LPR).  LPR_T > 0: compile-time, LPR_T == 0: runtime (args.d/4).
-template <int CODEC, int LPR_T, int UNROLL>
+template <int CODEC, int LPR_T, int UNROLL, bool BAG1>
 __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs args) {
+    // BAG1: offsets == NULL for every table = one index per bag (bag b reads indices[b]): no offsets loads in front
+    // of the index load, no wave-wide trip count -- the row gather of the sharded step's send buffer.
     __shared__ float s_lut[CodecLut<CODEC>::kEntries];
     if constexpr (CODEC != 32) {
         codec_lut_init<CODEC>(s_lut);
@@ -106,28 +108,38 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs
 
         int64_t s[UNROLL], len[UNROLL];
         int64_t maxlen = 0;
+        if constexpr (BAG1) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            const int64_t b = b0 + (int64_t)u * RPW + slot;
-            s[u] = 0;
-            len[u] = 0;
-            if (lane_on && b < B) {
-                const int64_t st = off[b];
-                const int64_t en = (b + 1 < B) ? off[b + 1] : nnz;
-                if (st >= 0 && en >= st && en <= nnz) {
-                    s[u] = st;
-                    len[u] = en - st;
-                } else {
-                    bad = true;
-                }
+            for (int u = 0; u < UNROLL; u++) {
+                const int64_t b = b0 + (int64_t)u * RPW + slot;
+                s[u] = b;
+                len[u] = (lane_on && b < B) ? 1 : 0;
             }
-            maxlen = len[u] > maxlen ? len[u] : maxlen;
-        }
-        // wave-wide max bag length (all lanes must run the same trip count)
+            maxlen = 1;
+        } else {
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const int64_t o = __shfl_xor(maxlen, m, kWave);
-            maxlen = o > maxlen ? o : maxlen;
+            for (int u = 0; u < UNROLL; u++) {
+                const int64_t b = b0 + (int64_t)u * RPW + slot;
+                s[u] = 0;
+                len[u] = 0;
+                if (lane_on && b < B) {
+                    const int64_t st = off[b];
+                    const int64_t en = (b + 1 < B) ? off[b + 1] : nnz;
+                    if (st >= 0 && en >= st && en <= nnz) {
+                        s[u] = st;
+                        len[u] = en - st;
+                    } else {
+                        bad = true;
+                    }
+                }
+                maxlen = len[u] > maxlen ? len[u] : maxlen;
+            }
+            // wave-wide max bag length (all lanes must run the same trip count)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const int64_t o = __shfl_xor(maxlen, m, kWave);
+                maxlen = o > maxlen ? o : maxlen;
+            }
         }
 
         float4 acc[UNROLL];
@@ -201,8 +213,9 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_scalar_kernel(const Gat
         const int t = __builtin_amdgcn_readfirstlane((int)(item / args.B));
         const int64_t b = item - (int64_t)t * args.B;
         const int64_t nnz = args.nnz[t];
-        int64_t st = args.offsets[t][b];
-        int64_t en = (b + 1 < args.B) ? args.offsets[t][b + 1] : nnz;
+        const int64_t *off = args.offsets[t];  // NULL: one index per bag
+        int64_t st = off ? off[b] : b;
+        int64_t en = off ? ((b + 1 < args.B) ? off[b + 1] : nnz) : b + 1;
         if (!(st >= 0 && en >= st && en <= nnz)) { bad = true; en = st = 0; }
         const unsigned char *W = reinterpret_cast<const unsigned char *>(args.table[t]);
         const float *rw = args.row_w[t];
@@ -230,7 +243,7 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_scalar_kernel(const Gat
 }
 
 template <int CODEC, int LPR_T, int UNROLL>
-static void launch_vec(const GatherArgs &a, int lpr, hipStream_t stream) {
+static void launch_vec(const GatherArgs &a, int lpr, hipStream_t stream, bool bag1) {
     GatherArgs args = a;
     const int rpw = kWave / lpr;
     const int bags_per_item = rpw * UNROLL;
@@ -240,22 +253,26 @@ static void launch_vec(const GatherArgs &a, int lpr, hipStream_t stream) {
     const int64_t cap = (int64_t)kNumCu * 8;  // 8 blocks of 256 threads per CU
     if (blocks > cap) blocks = cap;
     blocks = round_up((int)blocks, kNumXcd);
-    hipLaunchKernelGGL((embedding_bag_sum_kernel<CODEC, LPR_T, UNROLL>), dim3((unsigned)blocks), dim3(256), 0,
-                       stream, args);
+    if (bag1)
+        hipLaunchKernelGGL((embedding_bag_sum_kernel<CODEC, LPR_T, UNROLL, true>), dim3((unsigned)blocks), dim3(256), 0,
+                           stream, args);
+    else
+        hipLaunchKernelGGL((embedding_bag_sum_kernel<CODEC, LPR_T, UNROLL, false>), dim3((unsigned)blocks), dim3(256),
+                           0, stream, args);
 }
 
 template <int CODEC>
-static void launch_codec(const GatherArgs &a, bool vec_ok, hipStream_t stream) {
+static void launch_codec(const GatherArgs &a, bool vec_ok, hipStream_t stream, bool bag1) {
     const int d = a.d;
     if (vec_ok && d % 4 == 0 && d <= 256) {
         const int lpr = d / 4;
         switch (lpr) {
-        case 4: launch_vec<CODEC, 4, 4>(a, lpr, stream); return;    // d = 16
-        case 8: launch_vec<CODEC, 8, 4>(a, lpr, stream); return;    // d = 32
-        case 9: launch_vec<CODEC, 9, 4>(a, lpr, stream); return;    // d = 36 (every EVStore script)
-        case 16: launch_vec<CODEC, 16, 4>(a, lpr, stream); return;  // d = 64
-        case 32: launch_vec<CODEC, 32, 4>(a, lpr, stream); return;  // d = 128
-        default: launch_vec<CODEC, 0, 4>(a, lpr, stream); return;
+        case 4: launch_vec<CODEC, 4, 4>(a, lpr, stream, bag1); return;    // d = 16
+        case 8: launch_vec<CODEC, 8, 4>(a, lpr, stream, bag1); return;    // d = 32
+        case 9: launch_vec<CODEC, 9, 4>(a, lpr, stream, bag1); return;    // d = 36 (every EVStore script)
+        case 16: launch_vec<CODEC, 16, 4>(a, lpr, stream, bag1); return;  // d = 64
+        case 32: launch_vec<CODEC, 32, 4>(a, lpr, stream, bag1); return;  // d = 128
+        default: launch_vec<CODEC, 0, 4>(a, lpr, stream, bag1); return;
         }
     }
     GatherArgs args = a;
@@ -279,7 +296,16 @@ extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const v
     EVS_REQUIRE(codec == 32 || codec == 16 || codec == 8 || codec == 4, "evs_embedding_bag_sum: codec %d", codec);
     EVS_REQUIRE(codec != 4 || d % 2 == 0, "evs_embedding_bag_sum: 4-bit rows need an even d (got %d)", d);
     if (T == 0 || B == 0) return EVS_OK;
-    EVS_REQUIRE(tables && n_rows && indices && offsets && nnz && out, "evs_embedding_bag_sum: NULL argument");
+    EVS_REQUIRE(tables && n_rows && indices && nnz && out, "evs_embedding_bag_sum: NULL argument");
+    // offsets == NULL, or every offsets[k] == NULL: one index per bag (bag b of table k reads indices[k][b])
+    bool bag1 = offsets == nullptr;
+    if (!bag1) {
+        int n_null = 0;
+        for (int k = 0; k < T; k++) n_null += offsets[k] == nullptr;
+        EVS_REQUIRE(n_null == 0 || n_null == T, "evs_embedding_bag_sum: offsets NULL for %d of %d tables (all or none)",
+                    n_null, T);
+        bag1 = n_null == T;
+    }
     int *err = index_error_flag();
     if (!err) return EVS_EHIP;
     bool vec_ok = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && out_table_stride % 4 == 0 &&
@@ -287,7 +313,8 @@ extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const v
     for (int k = 0; k < T; k++) {
         EVS_REQUIRE(n_rows[k] >= 0 && nnz[k] >= 0, "evs_embedding_bag_sum: table %d has negative size", k);
         EVS_REQUIRE(tables[k] || n_rows[k] == 0, "evs_embedding_bag_sum: table %d is NULL", k);
-        EVS_REQUIRE(offsets[k], "evs_embedding_bag_sum: offsets[%d] is NULL", k);
+        EVS_REQUIRE(!bag1 || nnz[k] >= B, "evs_embedding_bag_sum: table %d has %lld indices for %lld one-index bags", k,
+                    (long long)nnz[k], (long long)B);
         EVS_REQUIRE(indices[k] || nnz[k] == 0, "evs_embedding_bag_sum: indices[%d] is NULL", k);
         if (reinterpret_cast<uintptr_t>(tables[k]) % 16 != 0) vec_ok = false;
     }
@@ -299,7 +326,7 @@ extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const v
             const bool on = k < n;
             a.table[k] = on ? tables[k0 + k] : nullptr;
             a.indices[k] = on ? indices[k0 + k] : nullptr;
-            a.offsets[k] = on ? offsets[k0 + k] : nullptr;
+            a.offsets[k] = (on && !bag1) ? offsets[k0 + k] : nullptr;
             a.row_w[k] = (on && row_weights) ? row_weights[k0 + k] : nullptr;
             a.n_rows[k] = on ? n_rows[k0 + k] : 0;
             a.nnz[k] = on ? nnz[k0 + k] : 0;
@@ -313,10 +340,10 @@ extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const v
         a.err = err;
         a.chunks_per_table = 0;
         switch (codec) {
-        case 32: launch_codec<32>(a, vec_ok, st); break;
-        case 16: launch_codec<16>(a, vec_ok, st); break;
-        case 8: launch_codec<8>(a, vec_ok, st); break;
-        default: launch_codec<4>(a, vec_ok, st); break;
+        case 32: launch_codec<32>(a, vec_ok, st, bag1); break;
+        case 16: launch_codec<16>(a, vec_ok, st, bag1); break;
+        case 8: launch_codec<8>(a, vec_ok, st, bag1); break;
+        default: launch_codec<4>(a, vec_ok, st, bag1); break;
         }
         EVS_HIP_CHECK(hipGetLastError());
     }

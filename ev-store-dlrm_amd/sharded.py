@@ -94,8 +94,9 @@ class HipBackend:
     def make_tables(self, weights, d):
         return EVTables([w.to(self.device) for w in weights], d, 32)
 
-    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False):
+    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False, bag1=False):
         """pooled[b][j][:] for the j-th owned table, written into send (B, n_own, d).
+        bag1: the caller states one index per bag (offsets = arange): the library's NULL-offsets row gather.
         planned: the caller passes the SAME list objects every step (plan / run_start): the pointer tables are then
         cached by list identity and the lists kept alive; one-off calls build them and keep nothing."""
         B = int(send.shape[0])
@@ -103,13 +104,13 @@ class HipBackend:
         if n == 0 or B == 0:
             return
         # planned batches pass the same list objects every step: key on identity first (no per-step tuple building)
-        fast = ("gid", id(lS_i_rows), id(lS_o_rows), send.data_ptr())
+        fast = ("gid", id(lS_i_rows), id(lS_o_rows), send.data_ptr(), bag1)
         ent = self._cache.get(fast) if planned else None
         if ent is None:
             ent = ((C.c_void_p * n)(*[ev._tables_c[k] for k in table_ids_local]),
                    (C.c_int64 * n)(*[ev.n_rows[k] for k in table_ids_local]),
                    (C.c_void_p * n)(*[t.data_ptr() for t in lS_i_rows]),
-                   (C.c_void_p * n)(*[t.data_ptr() for t in lS_o_rows]),
+                   None if bag1 else (C.c_void_p * n)(*[t.data_ptr() for t in lS_o_rows]),
                    (C.c_int64 * n)(*[int(t.numel()) for t in lS_i_rows]),
                    lS_i_rows, lS_o_rows)  # the lists are kept alive so their ids stay unique
             if planned:
@@ -206,7 +207,7 @@ class ShardedEmbeddingInteract:
         send, recv = self._buffers(Bg, slot, like)
         ids = [self.local_id[t] for t in self.my_own]
         self.backend.bag_sum_into(self.ev, ids, [lS_o[t] for t in self.my_own], [lS_i[t] for t in self.my_own],
-                                  send, len(self.my_own), self.d)
+                                  send, len(self.my_own), self.d, bag1=self.one_index_per_bag)
         return send, recv
 
     def start(self, lS_o, lS_i, slot=0):
@@ -278,7 +279,8 @@ class ShardedEmbeddingInteract:
         47) -- at this batch size the step is bounded by host-side launch cost, not by GPU overlap."""
         if not self.any_sharded:
             return None
-        self.backend.bag_sum_into(self.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], len(self.my_own), self.d, planned=True)
+        self.backend.bag_sum_into(self.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], len(self.my_own), self.d, planned=True,
+                                  bag1=self.one_index_per_bag)
         if self.world > 1:
             return dist.all_to_all_single(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"], group=self.group,
                                           async_op=True)
@@ -412,7 +414,7 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
         for _ in range(iters):
             ev[0].record()
             if n_own:
-                backend.bag_sum_into(op.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], n_own, d, planned=True)
+                backend.bag_sum_into(op.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], n_own, d, planned=True, bag1=True)
             ev[1].record()
             backend.interact_mixed(pl["x"], pl["specs"], op.ev, d, op.itself, out=pl["R"], planned=True)
             ev[2].record()

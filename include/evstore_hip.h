@@ -69,6 +69,9 @@ EVS_API const char *evs_last_error(void);
  *   (B,F,d) interaction tile: out = T + d,  table_stride = d, bag_stride = F*d
  * Out-of-range indices contribute nothing and raise a sticky device flag read
  * by evs_check_index_errors() (nn.EmbeddingBag raises; a kernel cannot).
+ * offsets == NULL (or every offsets[k] == NULL) states that each bag holds ONE index
+ * (offsets = arange(B), what every EVStore script feeds): bag b of table k reads
+ * indices[k][b], nnz[k] >= B; the offsets loads in front of the index load go away.
  * ------------------------------------------------------------------------- */
 EVS_API int evs_embedding_bag_sum(int T, int64_t B, int d, int codec,
                           const void *const *tables, const int64_t *n_rows,

@@ -18,7 +18,7 @@ class OracleBackend:
     def make_tables(self, weights, d):
         return [np.ascontiguousarray(w.numpy()) for w in weights]
 
-    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False):
+    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False, bag1=False):
         for j, k in enumerate(table_ids_local):
             pooled = orc.embedding_bag_sum(ev[k], lS_i_rows[j].numpy(), lS_o_rows[j].numpy())
             send[:, j, :] = torch.from_numpy(pooled)

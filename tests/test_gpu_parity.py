@@ -866,3 +866,61 @@ def test_fused_top_mlp_first_layer_shapes(E, orc, B, n1, T, d, itself):
     E.apply_emb_interact_mlp1(x, off, idx, ev, _dev(W), _dev(b), arch_interaction_itself=itself)
     with pytest.raises(E.EvsError):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
+
+
+@pytest.mark.parametrize("codec,d,B", [(32, 36, 16384 + 5), (32, 36, 3), (32, 16, 1000), (32, 64, 777), (32, 10, 50),
+                                      (16, 36, 4099), (8, 36, 4099), (4, 36, 4099), (32, 20, 333)])
+def test_bag_sum_null_offsets_is_the_one_index_row_gather(E, orc, codec, d, B):
+    """evs_embedding_bag_sum with offsets == NULL (one index per bag -- the sharded step's send-buffer gather):
+    bit-equal to the oracle's EmbeddingBag over offsets = arange(B), in the (B, T_own, d) send layout, and to the
+    library's own offsets form; too few indices and a part-NULL offsets table are refused."""
+    import ctypes as C
+    from evstore_dlrm_amd import _lib
+    rs = np.random.RandomState(codec * 1000 + d + B)
+    ln = [3000, 7, 120000]
+    T = len(ln)
+    if codec == 32:
+        tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+        ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    else:
+        raws = [orc.encode_table(rs.uniform(-1, 1, size=(n, d)).astype(np.float32), codec) for n in ln]
+        tabs = raws
+        ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, codec)
+    idx = [rs.randint(0, n, size=B + 3).astype(np.int64) for n in ln]   # nnz > B: the tail is never read
+    idx_d = [torch.from_numpy(i).cuda() for i in idx]
+    off_d = torch.arange(B, dtype=torch.int64, device="cuda")
+    send = torch.full((B, T, d), float("nan"), device="cuda")
+    L = _lib.lib()
+    tp = (C.c_void_p * T)(*ev._tables_c)
+    nr = (C.c_int64 * T)(*ln)
+    ip = (C.c_void_p * T)(*[t.data_ptr() for t in idx_d])
+    nz = (C.c_int64 * T)(*[B + 3] * T)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.evs_embedding_bag_sum(T, B, d, codec, tp, nr, ip, None, nz, None, send.data_ptr(), d, T * d, st))
+    _lib.check(L.evs_check_index_errors(st))
+    got = send.cpu().numpy()
+    for k in range(T):
+        want = orc.embedding_bag_sum(tabs[k], idx[k][:B], np.arange(B, dtype=np.int64), None, codec, d)
+        assert np.array_equal(got[:, k, :].view(np.uint32), want.view(np.uint32)), k
+    # the offsets form of the same call (offsets = arange, nnz = B) gives the same bits
+    send2 = torch.empty_like(send)
+    op = (C.c_void_p * T)(*[off_d.data_ptr()] * T)
+    nz2 = (C.c_int64 * T)(*[B] * T)
+    _lib.check(L.evs_embedding_bag_sum(T, B, d, codec, tp, nr, ip, op, nz2, None, send2.data_ptr(), d, T * d, st))
+    assert torch.equal(send.view(torch.int32), send2.view(torch.int32))
+    # all-NULL entries mean the same; part-NULL and short index arrays are refused
+    opn = (C.c_void_p * T)(*[None] * T)
+    send3 = torch.empty_like(send)
+    _lib.check(L.evs_embedding_bag_sum(T, B, d, codec, tp, nr, ip, opn, nz, None, send3.data_ptr(), d, T * d, st))
+    assert torch.equal(send.view(torch.int32), send3.view(torch.int32))
+    opp = (C.c_void_p * T)(off_d.data_ptr(), None, off_d.data_ptr())
+    assert L.evs_embedding_bag_sum(T, B, d, codec, tp, nr, ip, opp, nz, None, send3.data_ptr(), d, T * d, st) != 0
+    nzs = (C.c_int64 * T)(*[B - 1] * T)
+    assert L.evs_embedding_bag_sum(T, B, d, codec, tp, nr, ip, None, nzs, None, send3.data_ptr(), d, T * d, st) != 0
+    # an out-of-range index raises the sticky flag and contributes nothing
+    bad = idx_d[0].clone()
+    bad[B // 2] = ln[0]
+    ipb = (C.c_void_p * T)(bad.data_ptr(), idx_d[1].data_ptr(), idx_d[2].data_ptr())
+    _lib.check(L.evs_embedding_bag_sum(T, B, d, codec, tp, nr, ipb, None, nz, None, send3.data_ptr(), d, T * d, st))
+    assert L.evs_check_index_errors(st) != 0
+    assert float(send3[B // 2, 0].abs().max()) == 0.0
