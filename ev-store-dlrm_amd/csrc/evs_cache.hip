@@ -880,24 +880,30 @@ struct BatchArgs {
                                     // orphans (n_orphan) are listed from the END of the array downwards
     long long stage_rows;           // rows of `staging` / entries of new_keys (= B * T)
     int *slot_stage;                // hash slot -> index of the new key it holds in this batch
+    int rebuild;                    // the host rebuilds the hash right after this batch's close: no tombstones remain
 };
 
+// Read-only probe.  Found: the entry (or kPending) and end_slot = the key's slot.  Not found: -1 and end_slot = the
+// first slot of the chain an insert of this key may take -- the first tombstone the walk passed, else the empty word
+// it ended on (K2 starts its claim there instead of walking the chain again).
 __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigned long long mask, unsigned long long key,
                                         unsigned long long &end_slot) {
     unsigned long long i = mix64(key) & mask;
+    long long first_tomb = -1;
     // bounded: a batch with more unique new keys than free slots (tiny cache, huge batch) can leave the table without
     // an empty word until the next rebuild -- the walk then ends after one lap instead of never
     for (unsigned long long steps = 0; steps <= mask; steps++) {
         const unsigned long long w = slots[i];
-        if ((w & kKeyMask) == key) {
+        if ((w & kKeyMask) == key && w != kTomb) {
             end_slot = i;
             const unsigned f = (unsigned)(w >> kKeyBits);
             return f >= kFieldPend ? kPending : (int)f;
         }
-        if (w == kEmpty) { end_slot = i; return -1; }
+        if (w == kEmpty) { end_slot = first_tomb >= 0 ? (unsigned long long)first_tomb : i; return -1; }
+        if (w == kTomb && first_tomb < 0) first_tomb = (long long)i;
         i = (i + 1) & mask;  // tombstones and other keys: keep walking
     }
-    end_slot = i;
+    end_slot = first_tomb >= 0 ? (unsigned long long)first_tomb : i;
     return -1;
 }
 
@@ -1154,68 +1160,13 @@ __global__ void iota_kernel(long long *p, long long n) {
 
 // K2: de-duplicate the misses through the hash (first CAS on an empty slot wins).  One thread per (request,
 // table) position; block j lists its unique new keys in new_slot[j*256 ...] and their number in block_cnt[j].
-__global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs args) {
-    __shared__ int s_tot[8];
-    const long long n = args.B * args.T;
-    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned info = m < n ? args.miss_info[m] : 0u;
-    if (m < n && args.hit) args.hit[m] = (info >> 30) & 1u;
-    bool is_new = false, recycled = false;
-    int slot = -1;
-    bool wanted = (info & 0x80000000u) != 0;
-    unsigned long long key = 0;
-    if (wanted) {
-        key = ((unsigned long long)(m % args.T + 1) << 32) | (unsigned)args.requests[m];
-        if (args.other_slots) {   // two-tier: the other tier took this key in this very batch
-            unsigned long long es;
-            if (probe_ro(args.other_slots, args.other_mask, key, es) != -1) wanted = false;
-        }
-    }
-    if (wanted) {
-        const int agg = (int)((info >> 24) & 63u);
-        // Walk from the key's HOME slot and take the first slot that is empty OR a tombstone.  Recycling tombstones is
-        // what keeps the chains short in steady state: an insert that only ever took empty slots left every evicted
-        // entry's slot dead until the next rebuild, and after a few thousand batches at capacity the probe kernel ran
-        // 3x slower (17 -> 53 us at B = 16 384) although the table was never more than 55 % occupied.  Every copy of a
-        // key inserted in this batch walks the same sequence and claims with a CAS, so duplicates still meet: the
-        // loser of a race re-reads the slot and finds either its own key (a duplicate: fold the priority) or another
-        // key (walk on).  The key is known to be absent from the table (K1 walked to an empty slot without finding it).
-        unsigned long long i = mix64(key) & args.mask;
-        const unsigned long long mine = make_word(key, kFieldPend + (unsigned)agg);
-        bool placed = false;
-        for (unsigned long long steps = 0; steps <= args.mask; steps++) {   // one lap at most: a full table drops the key
-            unsigned long long w = args.slots[i];
-            if (w == kEmpty || w == kTomb) {
-                const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
-                if (prev == w) { is_new = true; slot = (int)i; placed = true; recycled = (w == kTomb); break; }  // this thread owns the new key
-                w = prev;
-            }
-            if ((w & kKeyMask) == key && w != kTomb) { atomicMax(&args.slots[i], mine); placed = true; break; }  // duplicate miss of this batch
-            i = (i + 1) & args.mask;
-        }
-        // file mode: a dropped key of a STAGED table has no address the consumer could read -- the host stages its row
-        // for this one position (listed from the end of new_keys; row_ptrs carries -(1 + orphan index) to the patch kernel)
-        if (!placed && args.new_keys && ((args.staged_mask >> (int)(m % args.T)) & 1u)) {
-            const int oi = atomicAdd(&args.bs->n_orphan, 1);
-            args.new_keys[args.stage_rows - 1 - oi] = key;
-            args.row_ptrs[m] = -(long long)(1 + oi);
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long bm = __ballot(is_new);
-    if (lane == 0) s_tot[wave] = __popcll(bm);
-    __syncthreads();
-    int base = 0, tot = 0;
-    for (int w = 0; w < 4; w++) { if (w < wave) base += s_tot[w]; tot += s_tot[w]; }
-    if (is_new) args.new_slot[(long long)blockIdx.x * 256 + base + __popcll(bm & ((1ull << lane) - 1ull))] = slot;
-    if (threadIdx.x == 0) args.block_cnt[blockIdx.x] = tot;
-    // tombstones taken back into use: K3 subtracts them from the count that decides on a rebuild (replica column 36)
-    const unsigned long long rm = __ballot(recycled);
-    if (lane == 0 && rm) atomicAdd(&args.part1[(blockIdx.x % kReplicas) * kPartCols + 36], __popcll(rm));
-}
+constexpr int kCutDensity = 4;
+constexpr long long kCheapWindow = 262144;
 
-// K3: one block folds K1's partial rows, scans K2's per-block counts into list bases, and thread 0 decides how
-// many entries must go, the priority cut and the scan window.
+// K3, the plan: one block folds K1's partial rows, scans K2's per-block counts into list bases, and thread 0 decides
+// how many entries must go, the priority cut and the scan window.  (Folding it into K2 as "the last block to finish
+// plans" was built and measured: the returning ticket atomics -- even two-level -- and the serial tail cost more than
+// the launch saves: K2 + K3 23.9 us apart, 27 us merged.  Same for the close behind K5: 16.8 us apart, 21 us merged.)
 __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs args) {
     __shared__ BatchState sb;
     __shared__ long long s_col[kPartCols];
@@ -1290,10 +1241,19 @@ __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs a
         const int live = b->count - b->flush_t;
         if (need > live) need = live;
         if (need > 0) {
+            // The cut: the first priority whose cumulative count covers `need` -- unless the candidates would then be so
+            // sparse that the window below becomes a large part of the arena (a 40-60 us scan, measured every other
+            // batch at the 10 % Kaggle cache, where the priorities below the mode hold 30-60 k entries against 49 k
+            // evictions per batch): then the cut moves up until the candidates are kCutDensity x need (or the window is
+            // cheap, or the top priority is reached).  The hand still reaches every low-priority entry within one lap.
             long long acc = 0;
             for (int p = 0; p <= T; p++) {
                 acc += cnt[p];
-                if (acc >= need) { b->pstar = p; break; }
+                if (acc < need) continue;
+                if (p == T || acc >= (long long)need * kCutDensity || (long long)need * args.cap / acc * 2 <= kCheapWindow) {
+                    b->pstar = p;
+                    break;
+                }
             }
             // candidates (priority <= pstar) are `acc` of the cap entry indices: scan twice the expected span
             long long w = (long long)need * args.cap / (acc > 0 ? acc : 1) * 2 + 16384;
@@ -1313,6 +1273,68 @@ __global__ void __launch_bounds__(256) cache_batch_plan_kernel(const BatchArgs a
     }
 }
 
+__global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs args) {
+    __shared__ int s_tot[8];
+    const long long n = args.B * args.T;
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned info = m < n ? args.miss_info[m] : 0u;
+    if (m < n && args.hit) args.hit[m] = (info >> 30) & 1u;
+    bool is_new = false, recycled = false;
+    int slot = -1;
+    bool wanted = (info & 0x80000000u) != 0;
+    unsigned long long key = 0;
+    if (wanted) {
+        key = ((unsigned long long)(m % args.T + 1) << 32) | (unsigned)args.requests[m];
+        if (args.other_slots) {   // two-tier: the other tier took this key in this very batch
+            unsigned long long es;
+            if (probe_ro(args.other_slots, args.other_mask, key, es) != -1) wanted = false;
+        }
+    }
+    if (wanted) {
+        const int agg = (int)((info >> 24) & 63u);
+        // Walk from the key's HOME slot and take the first slot that is empty OR a tombstone.  Recycling tombstones is
+        // what keeps the chains short in steady state: an insert that only ever took empty slots left every evicted
+        // entry's slot dead until the next rebuild, and after a few thousand batches at capacity the probe kernel ran
+        // 3x slower (17 -> 53 us at B = 16 384) although the table was never more than 55 % occupied.  Every copy of a
+        // key inserted in this batch walks the same sequence and claims with a CAS, so duplicates still meet: the
+        // loser of a race re-reads the slot and finds either its own key (a duplicate: fold the priority) or another
+        // key (walk on).  The key is known to be absent from the table (K1 walked to an empty slot without finding it).
+        // The walk starts at the first reusable slot K1's probe saw on the chain (every copy of a key carries the same hint:
+        // one snapshot), or at the home slot when the hint had to be shortened (tables above 2^24 slots).
+        unsigned long long i = args.hint_shift == 0 ? (unsigned long long)(info & 0xffffffu) : (mix64(key) & args.mask);
+        const unsigned long long mine = make_word(key, kFieldPend + (unsigned)agg);
+        bool placed = false;
+        for (unsigned long long steps = 0; steps <= args.mask; steps++) {   // one lap at most: a full table drops the key
+            unsigned long long w = args.slots[i];
+            if (w == kEmpty || w == kTomb) {
+                const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
+                if (prev == w) { is_new = true; slot = (int)i; placed = true; recycled = (w == kTomb); break; }  // this thread owns the new key
+                w = prev;
+            }
+            if ((w & kKeyMask) == key && w != kTomb) { atomicMax(&args.slots[i], mine); placed = true; break; }  // duplicate miss of this batch
+            i = (i + 1) & args.mask;
+        }
+        // file mode: a dropped key of a STAGED table has no address the consumer could read -- the host stages its row
+        // for this one position (listed from the end of new_keys; row_ptrs carries -(1 + orphan index) to the patch kernel)
+        if (!placed && args.new_keys && ((args.staged_mask >> (int)(m % args.T)) & 1u)) {
+            const int oi = atomicAdd(&args.bs->n_orphan, 1);
+            args.new_keys[args.stage_rows - 1 - oi] = key;
+            args.row_ptrs[m] = -(long long)(1 + oi);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bm = __ballot(is_new);
+    if (lane == 0) s_tot[wave] = __popcll(bm);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 4; w++) { if (w < wave) base += s_tot[w]; tot += s_tot[w]; }
+    if (is_new) args.new_slot[(long long)blockIdx.x * 256 + base + __popcll(bm & ((1ull << lane) - 1ull))] = slot;
+    if (threadIdx.x == 0) args.block_cnt[blockIdx.x] = tot;
+    // tombstones taken back into use: the plan subtracts them from the count that decides on a rebuild (replica column 36)
+    const unsigned long long rm = __ballot(recycled);
+    if (lane == 0 && rm) atomicAdd(&args.part1[(blockIdx.x % kReplicas) * kPartCols + 36], __popcll(rm));
+}
+
 // K4: walk the entry window [hand, hand + win) and evict up to `need` entries whose priority is at or
 // below the cut (and `flush_t` entries of the top priority when the EvLFU flush fires).  The hand
 // moves on afterwards, so inside the low priorities the oldest fills go first -- the clock-hand
@@ -1323,13 +1345,16 @@ constexpr int kEvictPerThread = 8;
 __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs args) {
     __shared__ int s_tot[8];
     __shared__ int s_delta[kMaxBuckets];
+    __shared__ int s_tomb;
     BatchState *b = args.bs;
     const int pstar = b->pstar, need = b->need, flush_t = b->flush_t, T = args.T, win = b->win, hand = b->hand;
     const int n_free0 = b->n_free;
     const long long per_pass = (long long)gridDim.x * blockDim.x * kEvictPerThread;
     if (win <= 0 || (long long)blockIdx.x * blockDim.x * kEvictPerThread >= win) return;  // block-uniform
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
+    if (threadIdx.x == 0) s_tomb = 0;
     __syncthreads();
+    int n_tombs = 0;
     const int passes = (int)((win + per_pass - 1) / per_pass);
     for (int it = 0; it < passes; it++) {
         const long long o0 = it * per_pass + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * kEvictPerThread;
@@ -1368,21 +1393,91 @@ __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs 
         }
         int pos = n_free0 + (tk_c - n_c);                 // no flush: victims of this thread are a prefix of its tickets
         if (flush_t > 0) pos = n_free0 + block_reserve_n(&b->pos_ticket, __popc(victim), s_tot);   // uniform
+        // (Giving a slot whose successor is empty back as EMPTY instead of a tombstone halves the tombstones and the
+        // rebuilds -- ~3 us per batch amortised -- but the successor read is one more dependent round trip for every
+        // victim: +6 us in this kernel.  Measured, not kept.)  Two passes so that the 8 victims' loads are independent.
+        int sl[kEvictPerThread];
+#pragma unroll
+        for (int j = 0; j < kEvictPerThread; j++) sl[j] = ((victim >> j) & 1) ? args.eslot[ent[j]] : 0;
 #pragma unroll
         for (int j = 0; j < kEvictPerThread; j++) {
             if (!((victim >> j) & 1)) continue;
             const int e = ent[j];
-            args.slots[args.eslot[e]] = kTomb;
+            args.slots[sl[j]] = kTomb;
+            n_tombs++;
             args.a.ekey[e] = kEmpty;
             atomicSub(&s_delta[prio[j]], 1);
             args.a.free_stack[pos++] = e;
         }
     }
+    if (n_tombs) atomicAdd(&s_tomb, n_tombs);
     __syncthreads();
     int gone = 0;
     for (int i = threadIdx.x; i <= T; i += blockDim.x)
         if (s_delta[i]) { atomicAdd(&b->cnt[i], s_delta[i]); gone -= s_delta[i]; }
-    if (gone) { atomicSub(&b->count, gone); atomicAdd(&b->n_tomb, gone); }
+    if (gone) atomicSub(&b->count, gone);
+    if (threadIdx.x == 0 && s_tomb) atomicAdd(&b->n_tomb, s_tomb);
+}
+
+// K6, end-of-batch bookkeeping (one block): folds K5's partial rows, then thread 0 closes the batch.  The state comes
+// in and goes out with parallel loads / stores; thread 0 works on the LDS copy (walking the fields in global memory
+// was ~10 dependent round trips).
+__global__ void __launch_bounds__(256) cache_batch_close_kernel(const BatchArgs args) {
+    __shared__ int s_col[kPartCols];
+    __shared__ BatchState sb;
+    const int nw = (int)(sizeof(BatchState) / sizeof(int));
+    {
+        int *dst = reinterpret_cast<int *>(&sb);
+        const int *src = reinterpret_cast<const int *>(args.bs);
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+    }
+    if (threadIdx.x < kPartCols) s_col[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kReplicas * kPartCols; i += blockDim.x) {   // fold and clear K5's replica rows
+        const int v = args.part2[i];
+        if (v) { atomicAdd(&s_col[i % kPartCols], v); args.part2[i] = 0; }
+    }
+    __syncthreads();
+    BatchState *b = &sb;
+    if ((int)threadIdx.x <= args.T && s_col[threadIdx.x]) b->cnt[threadIdx.x] += s_col[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        b->n_free += b->flush_t > 0 ? b->pos_ticket : (b->ticket < b->need ? b->ticket : b->need);
+        const int take = b->n_assign < b->n_free ? b->n_assign : b->n_free;
+        b->n_free -= take; b->count += take;
+        b->n_tomb += s_col[37];
+        if (args.rebuild) b->n_tomb = 0;
+        if (b->need > 0 && b->win > 0) { long long h = (long long)b->hand + b->win; b->hand = (int)(h % args.cap); }
+        b->n_miss = 0; b->n_new = 0; b->n_orphan = 0; b->batch_id++;
+        b->n_requests += args.B;
+        *args.host_tomb = b->n_tomb;
+    }
+    __syncthreads();
+    {
+        const int *src = reinterpret_cast<const int *>(&sb);
+        int *dst = reinterpret_cast<int *>(args.bs);
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// Rebuild the hash without tombstones when they pile up (the host reads the count the close left in mapped memory):
+// clear, then every entry back into its chain.
+__global__ void __launch_bounds__(256) cache_batch_clear_kernel(const BatchArgs args) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < args.nslot; i += (long long)gridDim.x * blockDim.x)
+        args.slots[i] = kEmpty;
+}
+__global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchArgs args) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < args.cap; e += gridDim.x * blockDim.x) {
+        const unsigned long long key = args.a.ekey[e];
+        if (key == kEmpty) continue;
+        unsigned long long i = mix64(key) & args.mask;
+        const unsigned long long w = make_word(key, (unsigned)e);
+        for (unsigned long long steps = 0; steps <= args.mask; steps++) {   // entries <= cap < nslot/2: always ends early
+            if (args.slots[i] == kEmpty && atomicCAS(&args.slots[i], kEmpty, w) == kEmpty) break;
+            i = (i + 1) & args.mask;
+        }
+        args.eslot[e] = (int)i;
+    }
 }
 
 // K5: give every unique new key an entry and fill its arena row from the backing store: block j serves the
@@ -1434,67 +1529,6 @@ __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs
         const int i = threadIdx.x;
         const int v = i <= args.T ? s_delta[i] : i == 37 ? s_drop : 0;
         if (v) atomicAdd(&args.part2[(blockIdx.x % kReplicas) * kPartCols + i], v);
-    }
-}
-
-// K6a/K6b: rebuild the hash without tombstones when they pile up (decided in K3).
-__global__ void __launch_bounds__(256) cache_batch_clear_kernel(const BatchArgs args) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < args.nslot; i += (long long)gridDim.x * blockDim.x)
-        args.slots[i] = kEmpty;
-}
-// ... and the end-of-batch bookkeeping (block 0: folds K5's partial rows, then thread 0 closes the batch)
-__global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchArgs args) {
-    __shared__ int s_col[kPartCols];
-    __shared__ BatchState sb;
-    const bool rebuild = args.B < 0;
-    if (blockIdx.x == 0) {
-        // the state comes in and goes out with parallel loads / stores; thread 0 works on the LDS copy (walking the
-        // fields in global memory was ~10 dependent round trips: most of this kernel's 10 us)
-        const int nw = (int)(sizeof(BatchState) / sizeof(int));
-        {
-            int *dst = reinterpret_cast<int *>(&sb);
-            const int *src = reinterpret_cast<const int *>(args.bs);
-            for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
-        }
-        if (threadIdx.x < kPartCols) s_col[threadIdx.x] = 0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < kReplicas * kPartCols; i += blockDim.x) {   // fold and clear K5's replica rows
-            const int v = args.part2[i];
-            if (v) { atomicAdd(&s_col[i % kPartCols], v); args.part2[i] = 0; }
-        }
-        __syncthreads();
-        BatchState *b = &sb;
-        if ((int)threadIdx.x <= args.T && s_col[threadIdx.x]) b->cnt[threadIdx.x] += s_col[threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            b->n_free += b->flush_t > 0 ? b->pos_ticket : (b->ticket < b->need ? b->ticket : b->need);
-            const int take = b->n_assign < b->n_free ? b->n_assign : b->n_free;
-            b->n_free -= take; b->count += take;
-            b->n_tomb += s_col[37];
-            if (b->need > 0 && b->win > 0) { long long h = (long long)b->hand + b->win; b->hand = (int)(h % args.cap); }
-            if (rebuild) b->n_tomb = 0;
-            b->n_miss = 0; b->n_new = 0; b->n_orphan = 0; b->batch_id++;
-            b->n_requests += rebuild ? -args.B : args.B;
-            *args.host_tomb = b->n_tomb;
-        }
-        __syncthreads();
-        {
-            const int *src = reinterpret_cast<const int *>(&sb);
-            int *dst = reinterpret_cast<int *>(args.bs);
-            for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
-        }
-    }
-    if (!rebuild) return;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < args.cap; e += gridDim.x * blockDim.x) {
-        const unsigned long long key = args.a.ekey[e];
-        if (key == kEmpty) continue;
-        unsigned long long i = mix64(key) & args.mask;
-        const unsigned long long w = make_word(key, (unsigned)e);
-        for (unsigned long long steps = 0; steps <= args.mask; steps++) {   // entries <= cap < nslot/2: always ends early
-            if (args.slots[i] == kEmpty && atomicCAS(&args.slots[i], kEmpty, w) == kEmpty) break;
-            i = (i + 1) & args.mask;
-        }
-        args.eslot[e] = (int)i;
     }
 }
 
@@ -1587,6 +1621,10 @@ struct evs_cache {
     int *slot_stage = nullptr;
     long long staging_rows = 0;
     long long n_staged_rows = 0;   // rows the reader pool has fetched so far (statistics)
+    // fork / join of one batch: the hash part of the policy update (K2, K4) on a side stream under the consumer
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int fork_mode = -1;            // -1: not decided yet (EVS_CACHE_FORK, default off), 0 / 1
 };
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
@@ -1597,6 +1635,9 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
     if (c->host_tomb) (void)hipHostFree(c->host_tomb);
     if (c->new_keys_host) (void)hipHostFree(c->new_keys_host);
     if (c->staging) (void)hipHostFree(c->staging);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     return EVS_OK;
 }
@@ -1897,6 +1938,10 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     a.estamp = nullptr; a.stamp = 0;
     a.other_slots = nullptr; a.other_mask = 0;
     a.staged_mask = 0; a.staging = nullptr; a.new_keys = nullptr; a.slot_stage = nullptr; a.stage_rows = 0;
+    // the tombstone count the close of an EARLIER batch left in mapped host memory (no synchronisation: a rebuild one or
+    // two batches late is as good); cleared here so that one report triggers one rebuild
+    a.rebuild = *reinterpret_cast<volatile int *>(c->host_tomb) > (int)(c->nslot / 8);
+    if (a.rebuild) *reinterpret_cast<volatile int *>(c->host_tomb) = 0;
     return EVS_OK;
 }
 
@@ -1975,10 +2020,11 @@ static void batch_close(evs_cache *c, evs::BatchArgs a, hipStream_t st) {
     using namespace evs;
     const int wide = kNumCu * 8;
     long long ne = ((long long)a.cap + 255) / 256; if (ne > wide) ne = wide;
-    const bool rebuild = *reinterpret_cast<volatile int *>(c->host_tomb) > (int)(c->nslot / 8);
-    if (rebuild) hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
-    a.B = rebuild ? -a.B : a.B;   // sign = "the slots were cleared: re-insert every entry"
-    hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3(rebuild ? (unsigned)ne : 1u), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cache_batch_close_kernel, dim3(1), dim3(256), 0, st, a);
+    if (a.rebuild) {   // decided in batch_prepare, so that the close already reports zero tombstones
+        hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
+    }
 }
 
 static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit, const float *x,
@@ -2026,11 +2072,42 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
     };
     if (R) EVS_REQUIRE(c->host.codec == 32 && evs_fused_dim_supported(c->host.dim) && T + 1 <= EVS_MAX_FEATURES,
                        "evs_cache_lookup_interact: needs an fp32 cache, a fused-kernel dimension and T <= 31");
-    // consumers of the snapshot read the rows BEFORE the policy kernels move anything.  (Running K2-K4 on a
-    // side stream under the consumer was measured and is slower: 101 vs 91 us per batch -- the consumer
-    // already saturates the memory system and the two event waits cost more than the overlap returns.)
-    if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
+    // consumers of the snapshot read the rows BEFORE the policy kernels move anything
     const bool file_mode = c->ft && c->staged_mask;
+    if (c->fork_mode < 0) {
+        const char *e = getenv("EVS_CACHE_FORK");
+        c->fork_mode = (e && e[0] == '1') ? 1 : 0;
+    }
+    // Fork / join inside the batch (EVS_CACHE_FORK=1, off by default): K2, K3 and K4 only touch the hash, the
+    // priorities and the free stack -- nothing the consumer reads (row addresses, arena and backing rows) -- so they
+    // can run on a side stream UNDER the consumer, K5 (which overwrites arena rows) joining behind both.  Same
+    // snapshot semantics, same results -- and slower on this stack: 148 us per batch against 125 (300 unseen batches,
+    // B = 16 384): both sides slow down when they overlap (consumer 22 -> 25 us, K2 27 -> 37) and the two
+    // cross-stream event waits cost more than the overlap returns.
+    const bool fork = c->fork_mode == 1 && !host_tier && !file_mode && (R || out);
+    if (fork) {
+        if (!c->side) {
+            EVS_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            EVS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            EVS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        EVS_HIP_CHECK(hipEventRecord(c->ev_fork, st));
+        EVS_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        batch_policy_a(c, a, c->side);
+        {
+            const int widef = kNumCu * 8;
+            long long ne = ((long long)a.cap + 255) / 256; if (ne > widef) ne = widef;
+            hipLaunchKernelGGL(cache_batch_evict_kernel, dim3((unsigned)ne), dim3(256), 0, c->side, a);
+        }
+        EVS_HIP_CHECK(hipEventRecord(c->ev_join, c->side));
+        const int rc = consumers(); if (rc) return rc;
+        EVS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0));
+        hipLaunchKernelGGL(cache_batch_assign_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
+        batch_close(c, a, st);
+        EVS_HIP_CHECK(hipGetLastError());
+        return EVS_OK;
+    }
+    if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
     if (file_mode) { const int rc = batch_stage_prepare(c, a, st); if (rc) return rc; }
     batch_policy_a(c, a, st);
     if (file_mode) { const int rc = batch_stage_rows(c, a, st); if (rc) return rc; }
