@@ -63,6 +63,7 @@ _PROTOS = {
     "evs_filetier_fetch": (_int, [_vp, _i64, _vp, _vp, C.c_uint32]),
     "evs_filetier_close": (_int, [_vp]),
     "evs_cache_set_file_backing": (_int, [_vp, _vp]),
+    "evs_cache_set_batch_policy": (_int, [_vp, _int]),
     "evs_cache_staged_rows": (_i64, [_vp]),
     "evs_cache_request": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "evs_cache_request_c1c2": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _int, _vp]),

@@ -824,6 +824,9 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
 // exactly (evs_cache_request) or batched (evs_cache_lookup_batch), never both.
 // ------------------------------------------------------------------------------------------
 constexpr unsigned long long kTomb = ~0ull;
+// second tombstone value (sampled policy update: tombstones written in batches of odd parity, see there); neither
+// value can equal a key (table field 63)
+constexpr unsigned long long kTomb1 = ~0ull - 1ull;
 constexpr int kPending = -2;
 // The batched path keeps its own hash: ONE 8-byte word per slot = key (38 bits: (table+1) << 32 | row)
 // | entry index (26 bits), so a probe is a single random access and the table for 3.4 M entries is
@@ -852,10 +855,11 @@ struct BatchArgs {
     BatchState *bs;
     CacheArrays a;
     unsigned long long *slots;   // packed hash words (see above)
-    int *estamp; int stamp;      // host-memory miss tier: entries hit in the running batch (estamp[e] == stamp) are not evicted
+    int *estamp; int stamp;      // entries with estamp[e] == stamp are not evicted in the running batch: its hits when the miss
+    int stamp_hits;              // tier is host memory (stamp_hits), and what the sampled update inserted in it
     const unsigned long long *other_slots; unsigned long long other_mask;   // two-tier: the other tier's hash (keys it holds are skipped)
     int *eslot;            // hash slot of each entry
-    // per (request, table) position: bit 31 = valid miss, bit 30 = hit, bits 24..29 = agg_hit of the request,
+    // per (request, table) position: bit 31 = valid miss, bit 30 = hit (of a miss: the hinted slot is a tombstone), bits 24..29 = agg_hit of the request,
     // bits 0..23 = (empty hash slot the probe of a miss ended on) >> hint_shift.  One 4-byte store per key in
     // K1 (with the 8-byte row address) instead of five streams: the stores were 11 us of its 18.7.
     unsigned *miss_info;
@@ -880,30 +884,38 @@ struct BatchArgs {
                                     // orphans (n_orphan) are listed from the END of the array downwards
     long long stage_rows;           // rows of `staging` / entries of new_keys (= B * T)
     int *slot_stage;                // hash slot -> index of the new key it holds in this batch
-    int rebuild;                    // the host rebuilds the hash right after this batch's close: no tombstones remain
+    int rebuild;                    // after this batch's close the host 1: rebuilds the hash (no tombstones remain), 2: sweeps it
+    int tomb_parity;                // sampled update: parity of this batch (its tombstones are kTomb1 when odd); -1 otherwise
 };
 
 // Read-only probe.  Found: the entry (or kPending) and end_slot = the key's slot.  Not found: -1 and end_slot = the
 // first slot of the chain an insert of this key may take -- the first tombstone the walk passed, else the empty word
 // it ended on (K2 starts its claim there instead of walking the chain again).
 __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigned long long mask, unsigned long long key,
-                                        unsigned long long &end_slot) {
+                                        unsigned long long &end_slot, unsigned long long reusable_tomb = kTomb,
+                                        bool *hint_is_tomb = nullptr) {
     unsigned long long i = mix64(key) & mask;
     long long first_tomb = -1;
+    if (hint_is_tomb) *hint_is_tomb = false;
     // bounded: a batch with more unique new keys than free slots (tiny cache, huge batch) can leave the table without
     // an empty word until the next rebuild -- the walk then ends after one lap instead of never
     for (unsigned long long steps = 0; steps <= mask; steps++) {
         const unsigned long long w = slots[i];
-        if ((w & kKeyMask) == key && w != kTomb) {
+        if ((w & kKeyMask) == key) {
             end_slot = i;
             const unsigned f = (unsigned)(w >> kKeyBits);
             return f >= kFieldPend ? kPending : (int)f;
         }
-        if (w == kEmpty) { end_slot = first_tomb >= 0 ? (unsigned long long)first_tomb : i; return -1; }
-        if (w == kTomb && first_tomb < 0) first_tomb = (long long)i;
+        if (w == kEmpty) {
+            end_slot = first_tomb >= 0 ? (unsigned long long)first_tomb : i;
+            if (hint_is_tomb) *hint_is_tomb = first_tomb >= 0;
+            return -1;
+        }
+        if (w == reusable_tomb && first_tomb < 0) first_tomb = (long long)i;
         i = (i + 1) & mask;  // tombstones and other keys: keep walking
     }
     end_slot = first_tomb >= 0 ? (unsigned long long)first_tomb : i;
+    if (hint_is_tomb) *hint_is_tomb = first_tomb >= 0;
     return -1;
 }
 
@@ -978,7 +990,8 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         const bool ok = key_on && row >= 0 && row < args.backing_rows[hl < T ? hl : 0];
         const unsigned long long key = ((unsigned long long)(hl + 1) << 32) | (unsigned)row;
         unsigned long long end_slot = 0;
-        int e = ok ? probe_ro(args.slots, args.mask, key, end_slot) : -1;
+        bool hint_tomb = false;
+        int e = ok ? probe_ro(args.slots, args.mask, key, end_slot, args.tomb_parity == 1 ? kTomb : args.tomb_parity == 0 ? kTomb1 : kTomb, &hint_tomb) : -1;
         if (e == kPending) e = -1;
         const unsigned long long hm = __ballot(e >= 0);
         const unsigned hmask = (unsigned)(half ? (hm >> 32) : hm);
@@ -989,13 +1002,14 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
             const int old = atomicMax(&args.a.eagg[e], agg);
             if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
         }
-        if (args.estamp && e >= 0) args.estamp[e] = args.stamp;
+        if (args.stamp_hits && e >= 0) args.estamp[e] = args.stamp;
         // where the row lives right now: arena for a hit, backing store for a miss, 0 for a bad row id
         const unsigned char *src = nullptr;
         if (e >= 0) src = args.a.arena + (long long)e * args.row_bytes;
         else if (ok) src = args.backing[hl] + (long long)row * args.row_bytes;
         if (key_on) {
-            const unsigned info = ((ok && e < 0) ? 0x80000000u : 0u) | (e >= 0 ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
+            // bit 30: hit -- or, for a miss (bit 31), "the hinted slot is a tombstone" (what the insert's first CAS expects)
+            const unsigned info = ((ok && e < 0) ? 0x80000000u : 0u) | ((e >= 0 || (ok && hint_tomb)) ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
                                   (unsigned)(end_slot >> args.hint_shift);
             args.miss_info[req * T + hl] = info;
             args.row_ptrs[req * T + hl] = (long long)src;
@@ -1278,7 +1292,7 @@ __global__ void __launch_bounds__(256) cache_batch_insert_kernel(const BatchArgs
     const long long n = args.B * args.T;
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned info = m < n ? args.miss_info[m] : 0u;
-    if (m < n && args.hit) args.hit[m] = (info >> 30) & 1u;
+    if (m < n && args.hit) args.hit[m] = (info >> 30) & ~(info >> 31) & 1u;
     bool is_new = false, recycled = false;
     int slot = -1;
     bool wanted = (info & 0x80000000u) != 0;
@@ -1446,7 +1460,7 @@ __global__ void __launch_bounds__(256) cache_batch_close_kernel(const BatchArgs 
         const int take = b->n_assign < b->n_free ? b->n_assign : b->n_free;
         b->n_free -= take; b->count += take;
         b->n_tomb += s_col[37];
-        if (args.rebuild) b->n_tomb = 0;
+        if (args.rebuild == 1) b->n_tomb = 0;
         if (b->need > 0 && b->win > 0) { long long h = (long long)b->hand + b->win; b->hand = (int)(h % args.cap); }
         b->n_miss = 0; b->n_new = 0; b->n_orphan = 0; b->batch_id++;
         b->n_requests += args.B;
@@ -1468,7 +1482,7 @@ __global__ void __launch_bounds__(256) cache_batch_clear_kernel(const BatchArgs 
 }
 __global__ void __launch_bounds__(256) cache_batch_reinsert_kernel(const BatchArgs args) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < args.cap; e += gridDim.x * blockDim.x) {
-        const unsigned long long key = args.a.ekey[e];
+        const unsigned long long key = args.a.ekey[e] & kKeyMask;   // (the sampled update keeps a batch stamp above the key)
         if (key == kEmpty) continue;
         unsigned long long i = mix64(key) & args.mask;
         const unsigned long long w = make_word(key, (unsigned)e);
@@ -1530,6 +1544,308 @@ __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs
         const int v = i <= args.T ? s_delta[i] : i == 37 ? s_drop : 0;
         if (v) atomicAdd(&args.part2[(blockIdx.x % kReplicas) * kPartCols + i], v);
     }
+}
+
+// ---- the sampled policy update: K2..K5 as ONE kernel --------------------------------------------------------------
+// The plan-based update above is five dependent launches whose work is tiny and whose time is round trips (insert ->
+// plan -> evict -> assign -> close: ~50 of the batch's ~100 us at B = 16 384).  This form removes every dependency
+// BETWEEN new keys instead: the thread that wins the hash slot of a new key also finds that key's victim by itself --
+// it samples one aligned group of kSampleGroup entries (chosen by a hash of the key and the batch number), takes a
+// free entry if the group has one, else the entry of lowest priority, claims it with a CAS on its key word, unhooks
+// the old key from the hash, and hands the entry to the new key.  No plan, no tickets, no free stack, no scan: the
+// eviction decision is "lowest priority of 8 sampled entries" (the sampled-LFU of Redis) instead of "lowest priority
+// in a clock-hand window"; tests/test_gpu_cache.py holds both against the sequential oracle's hit rate.
+//   Entries inserted or hit in this batch carry the batch stamp and are never victims.  Inserts and evictions now
+// run side by side, so a slot freed by an eviction must not become claimable in the launch that freed it: a copy of
+// a key that arrives late would take it although another copy already sits further down the chain (two entries for
+// one key -- tools/fuzz_cache.py found it).  Tombstones therefore come in two values, by batch parity; a batch writes
+// its own value and re-uses only the other one (K1's hint follows the same rule).  What threads tell each other inside the launch travels as agent-scope atomics only (the 8 XCDs'
+// L2s are not coherent with each other): the key word of an entry (free / claimed / key), its stamp, its priority,
+// the hash words.  A key whose group and every following group hold nothing claimable is dropped (tiny caches).
+constexpr unsigned long long kClaimed = ~0ull;   // ekey of an entry a thread owns while it moves it
+constexpr int kSampleGroup = 8;
+constexpr unsigned kStampMask = (1u << (64 - kKeyBits)) - 1u;   // the batch stamp rides in the 26 bits above the key
+// Words that threads of ONE launch hand to each other are written and read with read-modify-write atomics only (those
+// are performed where all 8 XCDs meet; plain and sc1 accesses may be served by an XCD's own L2).
+__device__ __forceinline__ unsigned long long ld_agent(unsigned long long *p) { return atomicOr(p, 0ull); }
+__device__ __forceinline__ void st_agent(int *p, int v) { atomicExch(p, v); }
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { atomicExch(p, v); }
+
+// One sampled group: key words, priorities and hash slots of kSampleGroup consecutive entries (plain loads, all
+// independent: one round trip).  Entries that may not be taken read as kClaimed: those filled in this batch (their
+// key word carries this batch's stamp -- so no second look is needed after the CAS: a CAS that expects an older word
+// fails on them), and, with a host-memory miss tier, those hit in it (stamped by K1, an earlier launch).
+struct SampleWindow {
+    unsigned long long k[kSampleGroup];
+    int pr[kSampleGroup], sl[kSampleGroup];
+};
+__device__ __forceinline__ void sampled_load(const BatchArgs &args, long long e0, SampleWindow &w) {
+    const unsigned stamp26 = (unsigned)args.stamp & kStampMask;
+#pragma unroll
+    for (int j = 0; j < kSampleGroup; j++) {
+        const bool on = e0 + j < args.cap;
+        w.k[j] = on ? args.a.ekey[e0 + j] : kClaimed;
+        w.pr[j] = on ? args.a.eagg[e0 + j] : 0;
+        w.sl[j] = on ? args.eslot[e0 + j] : 0;
+        const bool hit_now = on && args.stamp_hits && args.estamp[e0 + j] == args.stamp;
+        if (w.k[j] != kEmpty && ((unsigned)(w.k[j] >> kKeyBits) == stamp26 || hit_now)) w.k[j] = kClaimed;
+    }
+}
+// Take the best entry of the window: a free one, else the lowest priority.  Returns the entry (its key word is kClaimed,
+// it belongs to the caller; if it held a key, that key's hash word is already a tombstone) or -1.
+// One exit, flags instead of continue / break / return out of the nested loops: the early-exit form of this function
+// came back from hipcc 7.2 returning a garbage entry index on the evict path (found with guards on the GPU).
+__device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0, const SampleWindow &w, int &old_prio) {
+    unsigned tried = 0;
+    bool more = true;
+    int result = -1;
+#pragma unroll 1
+    for (int r = 0; r < kSampleGroup && more && result < 0; r++) {
+        int best = -1, bp = 0x7fffffff, bs = 0;
+        unsigned long long bk = 0;
+#pragma unroll
+        for (int j = 0; j < kSampleGroup; j++) {
+            const int pj = w.k[j] == kEmpty ? -1 : w.pr[j];
+            const bool cand = !((tried >> j) & 1u) && w.k[j] != kClaimed && pj < bp;
+            best = cand ? j : best; bp = cand ? pj : bp; bk = cand ? w.k[j] : bk; bs = cand ? w.sl[j] : bs;
+        }
+        more = best >= 0;
+        if (more) {
+            tried |= 1u << best;
+            const long long e = e0 + best;
+            if (atomicCAS(&args.a.ekey[e], bk, kClaimed) == bk) {   // else somebody else was faster
+                if (bk != kEmpty) st_agent(&args.slots[bs], args.tomb_parity ? kTomb1 : kTomb);
+                old_prio = bp;
+                result = (int)e;
+            }
+        }
+    }
+    return result;
+}
+
+// replica columns of part2 in this mode: 0..32 histogram deltas, 33 entries taken from the free ones (count delta),
+// 34 evictions, 35 tombstone delta (evicted + dropped - recycled)
+__global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArgs args) {
+    __shared__ int s_delta[kMaxBuckets];
+    __shared__ int s_stat[3];
+    __shared__ int s_ncopy;
+    __shared__ const unsigned char *s_src[256];
+    __shared__ unsigned char *s_dst[256];
+    for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
+    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_ncopy = 0;
+    __syncthreads();
+    const long long n = args.B * args.T;
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned info = m < n ? args.miss_info[m] : 0u;
+    if (m < n && args.hit) args.hit[m] = (info >> 30) & ~(info >> 31) & 1u;
+    if (info & 0x80000000u) {
+        const int t = (int)(m % args.T);
+        const unsigned row = (unsigned)args.requests[m];
+        const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
+        const int agg = (int)((info >> 24) & 63u);
+        const unsigned long long mine = make_word(key, kFieldPend + (unsigned)agg);
+        const unsigned long long my_tomb = args.tomb_parity ? kTomb1 : kTomb, old_tomb = args.tomb_parity ? kTomb : kTomb1;
+        // the victim group depends on the key and the batch only: its loads go out together with the first CAS
+        const long long n_groups = ((long long)args.cap + kSampleGroup - 1) / kSampleGroup;
+        long long g = (long long)(mix64(key ^ ((unsigned long long)(unsigned)args.stamp * 0x9e3779b97f4a7c15ull)) % (unsigned long long)n_groups);
+        SampleWindow win;
+        sampled_load(args, g * kSampleGroup, win);
+        // The walk starts at the first reusable slot K1's probe saw on the chain (every copy of a key carries the same
+        // hint: one snapshot), or at the home slot when the hint had to be shortened (tables above 2^24 slots); K1 also
+        // said whether that slot was empty or a tombstone, so the first access is the CAS itself.
+        unsigned long long i = args.hint_shift == 0 ? (unsigned long long)(info & 0xffffffu) : (mix64(key) & args.mask);
+        unsigned long long w = (args.hint_shift == 0 && (info & 0x40000000u)) ? old_tomb : kEmpty;
+        long long slot = -1;
+        bool recycled = false, walking = true;
+        for (unsigned long long steps = 0; steps <= args.mask && walking; steps++) {   // one lap at most: a full table drops the key
+            bool step_on = true;
+            if (w == kEmpty || w == old_tomb) {
+                const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
+                if (prev == w) { slot = (long long)i; recycled = (w == old_tomb); walking = false; step_on = false; }   // this thread owns the new key
+                else w = prev;
+            }
+            if (step_on && (w & kKeyMask) == key) {   // another copy of this key got here first
+                bool folding = true;
+                while (folding) {
+                    const unsigned f = (unsigned)(w >> kKeyBits);
+                    if (f >= kFieldPend) {               // still pending: fold the priority into the word
+                        if (w >= mine) folding = false;
+                        else {
+                            const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
+                            if (prev == w) folding = false;
+                            else { w = prev; if ((w & kKeyMask) != key) folding = false; }   // its owner dropped it meanwhile: let it go
+                        }
+                    } else {                             // already has its entry: raise the priority there (as a hit would)
+                        const int old = atomicMax(&args.a.eagg[f], agg);
+                        if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
+                        folding = false;
+                    }
+                }
+                walking = false; step_on = false;
+            }
+            if (step_on) {
+                // somebody else's key, or a slot that is not for re-use: next slot -- and if that one looks usable, CAS it
+                i = (i + 1) & args.mask;
+                w = ld_agent(&args.slots[i]);
+            }
+        }
+        if (slot >= 0) {
+            if (recycled) atomicSub(&s_stat[2], 1);
+            int old_prio = -1, e = -1;
+            for (long long tries = 0; tries < n_groups && e < 0; tries++) {
+                if (tries) sampled_load(args, g * kSampleGroup, win);
+                e = sampled_take(args, g * kSampleGroup, win, old_prio);
+                g = g + 1 == n_groups ? 0 : g + 1;
+            }
+            if (e < 0) {
+                atomicExch(&args.slots[slot], my_tomb);   // no entry to be had: forget the key
+                atomicAdd(&s_stat[2], 1);
+            } else {
+                if (old_prio >= 0) { atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); atomicAdd(&s_stat[2], 1); }
+                else atomicAdd(&s_stat[0], 1);
+                st_agent(&args.a.eagg[e], agg);
+                args.eslot[e] = (int)slot;
+                st_agent(&args.a.ekey[e], key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits));
+                atomicAdd(&s_delta[agg], 1);
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the priority is acknowledged before a copy of the key can find the entry
+                unsigned long long pw = mine;
+                int agg_f = agg;
+                for (;;) {   // pending word -> entry word; copies of the key may still be raising the pending priority
+                    const unsigned long long prev = atomicCAS(&args.slots[slot], pw, make_word(key, (unsigned)e));
+                    if (prev == pw) break;
+                    pw = prev;
+                    agg_f = (int)((unsigned)(pw >> kKeyBits) - kFieldPend);
+                }
+                if (agg_f > agg) {
+                    const int old = atomicMax(&args.a.eagg[e], agg_f);
+                    if (old < agg_f) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg_f], 1); }
+                }
+                const int ci = atomicAdd(&s_ncopy, 1);
+                s_src[ci] = args.backing[t] + (long long)row * args.row_bytes;
+                s_dst[ci] = args.a.arena + (long long)e * args.row_bytes;
+            }
+        }
+    }
+    __syncthreads();
+    // the block's new rows into the arena, 16 lanes per row
+    const int nc = s_ncopy, sub = threadIdx.x & 15;
+    for (int r = threadIdx.x >> 4; r < nc; r += 16) {
+        const unsigned char *srow = s_src[r];
+        unsigned char *drow = s_dst[r];
+        if ((args.row_bytes & 15) == 0) {
+            for (int c = sub * 16; c < args.row_bytes; c += 256) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c);
+        } else {
+            for (int c = sub; c < args.row_bytes; c += 16) drow[c] = srow[c];
+        }
+    }
+    if (threadIdx.x < kPartCols) {
+        const int i = threadIdx.x;
+        const int v = i <= args.T ? s_delta[i] : (i >= 33 && i <= 35) ? s_stat[i - 33] : 0;
+        if (v) atomicAdd(&args.part2[(blockIdx.x % kReplicas) * kPartCols + i], v);
+    }
+}
+
+// close of a sampled batch (one block): folds K1's and the update's replica rows into the state
+__global__ void __launch_bounds__(256) cache_batch_sampled_close_kernel(const BatchArgs args, int *host_flush) {
+    __shared__ long long s_col[2][kPartCols];
+    __shared__ BatchState sb;
+    const int nw = (int)(sizeof(BatchState) / sizeof(int));
+    {
+        int *dst = reinterpret_cast<int *>(&sb);
+        const int *src = reinterpret_cast<const int *>(args.bs);
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+    }
+    if (threadIdx.x < 2 * kPartCols) s_col[threadIdx.x / kPartCols][threadIdx.x % kPartCols] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kReplicas * kPartCols; i += blockDim.x) {
+        const int v1 = args.part1[i], v2 = args.part2[i];
+        if (v1) { atomicAdd(reinterpret_cast<unsigned long long *>(&s_col[0][i % kPartCols]), (unsigned long long)(long long)v1); args.part1[i] = 0; }
+        if (v2) { atomicAdd(reinterpret_cast<unsigned long long *>(&s_col[1][i % kPartCols]), (unsigned long long)(long long)v2); args.part2[i] = 0; }
+    }
+    __syncthreads();
+    BatchState *b = &sb;
+    if ((int)threadIdx.x <= args.T) b->cnt[threadIdx.x] += (int)(s_col[0][threadIdx.x] + s_col[1][threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        b->n_hits += s_col[0][38]; b->n_perfect_hits += s_col[0][39];
+        b->count += (int)s_col[1][33];
+        b->n_free = args.cap - b->count;
+        b->n_evict += s_col[1][34];
+        b->n_tomb += (int)s_col[1][35];
+        if (b->n_tomb < 0) b->n_tomb = 0;
+        if (args.rebuild == 1) b->n_tomb = 0;
+        b->batch_id++;
+        b->n_requests += args.B;
+        b->ticket_t = 0;
+        *args.host_tomb = b->n_tomb;
+        *host_flush = b->cnt[args.T] >= args.max_perfect ? 1 : 0;   // EvLFU flush (EvLFU_C1.py:36-44): the host launches it
+    }
+    __syncthreads();
+    {
+        const int *src = reinterpret_cast<const int *>(&sb);
+        int *dst = reinterpret_cast<int *>(args.bs);
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// EvLFU flush in sampled mode (rare: the top bucket has reached max_perfect): flush_n entries of the top priority go,
+// first come first served over the arena.  Runs alone on the stream, between two batches (the close of a batch raises a
+// flag in mapped host memory; the next batched call, or a stats / dump call, runs the flush first).
+__global__ void __launch_bounds__(256) cache_batch_sampled_flush_kernel(BatchState *b, CacheArrays a, unsigned long long *slots,
+                                                                        const int *eslot, int cap, int T, int flush_n) {
+    __shared__ int s_tot[8];
+    __shared__ int s_gone;
+    if (threadIdx.x == 0) s_gone = 0;
+    const int want = flush_n < b->cnt[T] ? flush_n : b->cnt[T];
+    __syncthreads();
+    for (long long e0 = (long long)blockIdx.x * blockDim.x; e0 < cap; e0 += (long long)gridDim.x * blockDim.x) {   // block-uniform trip count
+        const long long e = e0 + threadIdx.x;
+        const bool top = e < cap && a.ekey[e] != kEmpty && a.eagg[e] == T;
+        const int tk = block_reserve(&b->ticket_t, top, s_tot);
+        if (top && tk < want) {
+            slots[eslot[e]] = kTomb;
+            a.ekey[e] = kEmpty;
+            atomicAdd(&s_gone, 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_gone) {
+        atomicSub(&b->cnt[T], s_gone); atomicSub(&b->count, s_gone); atomicAdd(&b->n_free, s_gone);
+        atomicAdd(&b->n_tomb, s_gone);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&b->n_flush), 1ull);
+}
+
+// Tombstone sweep (between two batches, instead of most rebuilds): a tombstone whose successor is EMPTY ends its chain
+// and can be EMPTY itself -- and so can the tombstones in front of it.  One thread per run of kSweepRun slots, walking
+// backwards from the state of the slot behind its run (read before anybody could have changed it to "empty" only
+// makes the answer conservative).  One pass over the slot array (64 MB at the 10 % Kaggle cache: ~20 us) against
+// ~170 us for clear + re-insert.
+constexpr int kSweepRun = 16;
+__global__ void __launch_bounds__(256) cache_batch_sweep_kernel(BatchState *b, unsigned long long *slots, long long nslot) {
+    __shared__ int s_freed;
+    if (threadIdx.x == 0) s_freed = 0;
+    __syncthreads();
+    int freed = 0;
+    for (long long r0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * kSweepRun; r0 < nslot; r0 += (long long)gridDim.x * blockDim.x * kSweepRun) {
+        unsigned long long w[kSweepRun];
+#pragma unroll
+        for (int j = 0; j < kSweepRun; j++) w[j] = r0 + j < nslot ? slots[r0 + j] : kEmpty;
+        const long long nx = r0 + kSweepRun < nslot ? r0 + kSweepRun : 0;
+        bool next_empty = slots[nx] == kEmpty;
+#pragma unroll
+        for (int j = kSweepRun - 1; j >= 0; j--) {
+            if (r0 + j < nslot) {
+                const bool tomb = w[j] >= kTomb1;
+                if (tomb && next_empty) { slots[r0 + j] = kEmpty; freed++; }
+                else next_empty = w[j] == kEmpty;
+            }
+        }
+    }
+    if (freed) atomicAdd(&s_freed, freed);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_freed) atomicSub(&b->n_tomb, s_freed);
 }
 
 // Host-memory miss tier: after the fill (K5) every missed key that got an entry is served from its ARENA row, so
@@ -1625,6 +1941,8 @@ struct evs_cache {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int fork_mode = -1;            // -1: not decided yet (EVS_CACHE_FORK, default off), 0 / 1
+    long long batch_calls = 0, last_sweep_call = -100;   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
+    int batch_policy = -1;         // policy update of the batched path: 0 plan-based (K2..K6), 1 sampled (one kernel); -1: EVS_CACHE_POLICY, default sampled
 };
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
@@ -1762,6 +2080,14 @@ extern "C" int evs_cache_set_file_backing(evs_cache *c, evs_filetier *ft) {
 
 extern "C" int64_t evs_cache_staged_rows(evs_cache *c) { return c ? c->n_staged_rows : 0; }
 
+extern "C" int evs_cache_set_batch_policy(evs_cache *c, int policy) {
+    using namespace evs;
+    EVS_REQUIRE(c && (policy == 0 || policy == 1), "evs_cache_set_batch_policy: bad argument");
+    if (c->used == 2) { set_error("evs_cache_set_batch_policy: the batched path is already in use"); return EVS_ESTATE; }
+    c->batch_policy = policy;
+    return EVS_OK;
+}
+
 extern "C" int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
                                  int approx_thres, void *stream) {
     using namespace evs;
@@ -1883,7 +2209,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
             hipMemsetAsync(bslots, 0, c->nslot * 8, st) == hipSuccess &&                               // ordered on the caller's stream
             hipMemsetAsync(part1, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
             hipMemsetAsync(part2, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
-            hipHostMalloc(reinterpret_cast<void **>(&host_tomb), sizeof(int), hipHostMallocMapped) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void **>(&host_tomb), 2 * sizeof(int), hipHostMallocMapped) == hipSuccess &&   // [0] tombstones, [1] flush wanted
             hipHostGetDevicePointer(reinterpret_cast<void **>(&host_tomb_dev), host_tomb, 0) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
@@ -1892,7 +2218,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
             set_error("%s: allocating the batched-path state failed (capacity %lld)", who, cap);
             return EVS_ENOMEM;
         }
-        *host_tomb = 0;
+        host_tomb[0] = 0; host_tomb[1] = 0;
         c->slab_batch = slab;
         c->bs = bs; c->eslot = eslot; c->bslots = bslots; c->part1 = part1; c->part2 = part2;
         c->host_tomb = host_tomb; c->host_tomb_dev = host_tomb_dev;
@@ -1935,13 +2261,21 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     long long g1 = (B + 7) / 8; if (g1 > kProbeGridMax) g1 = kProbeGridMax;
     a.g1 = (int)g1; a.g2 = (int)g2;
     a.host_tomb = c->host_tomb_dev;
-    a.estamp = nullptr; a.stamp = 0;
+    a.estamp = nullptr; a.stamp = 0; a.stamp_hits = 0;
     a.other_slots = nullptr; a.other_mask = 0;
     a.staged_mask = 0; a.staging = nullptr; a.new_keys = nullptr; a.slot_stage = nullptr; a.stage_rows = 0;
-    // the tombstone count the close of an EARLIER batch left in mapped host memory (no synchronisation: a rebuild one or
-    // two batches late is as good); cleared here so that one report triggers one rebuild
-    a.rebuild = *reinterpret_cast<volatile int *>(c->host_tomb) > (int)(c->nslot / 8);
-    if (a.rebuild) *reinterpret_cast<volatile int *>(c->host_tomb) = 0;
+    // Tombstone housekeeping, from the count the close of an EARLIER batch left in mapped host memory (no synchronisation:
+    // one or two batches late is as good; cleared here so that one report triggers one action): past nslot / 8 the
+    // table is swept (tombstones at the end of their chains become empty again); if the count is back there within
+    // three calls the sweep did not help enough and the hash is rebuilt.
+    a.tomb_parity = -1;
+    a.rebuild = 0;
+    c->batch_calls++;
+    if (*reinterpret_cast<volatile int *>(c->host_tomb) > (int)(c->nslot / 8)) {
+        *reinterpret_cast<volatile int *>(c->host_tomb) = 0;
+        if (c->batch_calls - c->last_sweep_call <= 3) a.rebuild = 1;
+        else { a.rebuild = 2; c->last_sweep_call = c->batch_calls; }
+    }
     return EVS_OK;
 }
 
@@ -2016,15 +2350,34 @@ static int batch_stage_rows(evs_cache *c, evs::BatchArgs &a, hipStream_t st) {  
 
 // K6: close the batch; the hash is rebuilt without tombstones when they exceed nslot/8 -- the host learns the count
 // from a mapped word K6b writes (one or two batches stale, which only means slightly longer probe chains)
-static void batch_close(evs_cache *c, evs::BatchArgs a, hipStream_t st) {
+static void batch_housekeeping(evs_cache *c, const evs::BatchArgs &a, hipStream_t st) {
     using namespace evs;
     const int wide = kNumCu * 8;
-    long long ne = ((long long)a.cap + 255) / 256; if (ne > wide) ne = wide;
-    hipLaunchKernelGGL(cache_batch_close_kernel, dim3(1), dim3(256), 0, st, a);
-    if (a.rebuild) {   // decided in batch_prepare, so that the close already reports zero tombstones
+    if (a.rebuild == 1) {   // decided in batch_prepare, so that the close already reports zero tombstones
+        long long ne = ((long long)a.cap + 255) / 256; if (ne > wide) ne = wide;
         hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
         hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
+    } else if (a.rebuild == 2) {
+        long long nb = (c->nslot / kSweepRun + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(cache_batch_sweep_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->bs, c->bslots, c->nslot);
     }
+}
+static void batch_close(evs_cache *c, evs::BatchArgs a, hipStream_t st) {
+    using namespace evs;
+    hipLaunchKernelGGL(cache_batch_close_kernel, dim3(1), dim3(256), 0, st, a);
+    batch_housekeeping(c, a, st);
+}
+// sampled policy: the EvLFU flush the close of an earlier batch asked for (a flag in mapped host memory)
+static void sampled_flush_if_wanted(evs_cache *c, hipStream_t st) {
+    using namespace evs;
+    if (c->batch_policy != 1 || !c->host_tomb || !c->bs) return;
+    volatile int *flags = reinterpret_cast<volatile int *>(c->host_tomb);
+    if (!flags[1]) return;
+    flags[1] = 0;
+    const int wide = kNumCu * 8;
+    long long nf = ((long long)c->host.cap + 255) / 256; if (nf > wide) nf = wide;
+    hipLaunchKernelGGL(cache_batch_sampled_flush_kernel, dim3((unsigned)nf), dim3(256), 0, st, c->bs, c->a, c->bslots, c->eslot,
+                       (int)c->host.cap, c->host.n_tables, c->host.flush_n);
 }
 
 static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit, const float *x,
@@ -2049,10 +2402,9 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
             EVS_HIP_CHECK(hipMalloc(&c->estamp, cap * 4));
             EVS_HIP_CHECK(hipMemsetAsync(c->estamp, 0, cap * 4, st));
         }
-        a.estamp = c->estamp;
+        a.estamp = c->estamp; a.stamp_hits = 1;
         a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;   // never 0, distinct for consecutive batches
     }
-    hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)a.g1), dim3(256), 0, st, a);
     auto consumers = [&]() -> int {
         if (out) {
             long long nb = (B * T * (long long)c->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
@@ -2074,6 +2426,29 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
                        "evs_cache_lookup_interact: needs an fp32 cache, a fused-kernel dimension and T <= 31");
     // consumers of the snapshot read the rows BEFORE the policy kernels move anything
     const bool file_mode = c->ft && c->staged_mask;
+    if (c->batch_policy < 0) {
+        const char *e = getenv("EVS_CACHE_POLICY");
+        c->batch_policy = (e && e[0] == 'p') ? 0 : 1;   // "plan" / "sampled"
+    }
+    if (c->batch_policy == 1 && !file_mode) {
+        // Sampled policy update: probe -> consumers -> ONE update kernel -> close.  (Host-memory miss tier: the update
+        // first -- it fetches each missing row once -- then the re-pointed consumers.)
+        if (!host_tier) a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;   // (host tier: set above, with the hit stamps)
+        a.tomb_parity = a.stamp & 1;
+        sampled_flush_if_wanted(c, st);   // EvLFU flush the close of an earlier batch asked for: before this batch's probe
+        hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)a.g1), dim3(256), 0, st, a);
+        if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
+        hipLaunchKernelGGL(cache_batch_sampled_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
+        if (host_tier) {
+            hipLaunchKernelGGL(cache_batch_patch_ptrs_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
+            const int rc = consumers(); if (rc) return rc;
+        }
+        hipLaunchKernelGGL(cache_batch_sampled_close_kernel, dim3(1), dim3(256), 0, st, a, c->host_tomb_dev + 1);
+        batch_housekeeping(c, a, st);
+        EVS_HIP_CHECK(hipGetLastError());
+        return EVS_OK;
+    }
+    hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)a.g1), dim3(256), 0, st, a);
     if (c->fork_mode < 0) {
         const char *e = getenv("EVS_CACHE_FORK");
         c->fork_mode = (e && e[0] == '1') ? 1 : 0;
@@ -2210,6 +2585,8 @@ extern "C" int evs_cache_batch_stats(evs_cache *c, int64_t *out8, int64_t *hist,
     EVS_REQUIRE(c && out8 && c->bs, "evs_cache_batch_stats: the batched path has not been used");
     BatchState h;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    EVS_HIP_CHECK(hipStreamSynchronize(st));
+    sampled_flush_if_wanted(c, st);   // what is reported is the state the next batch will see
     EVS_HIP_CHECK(hipMemcpyAsync(&h, c->bs, sizeof h, hipMemcpyDeviceToHost, st));
     EVS_HIP_CHECK(hipStreamSynchronize(st));
     out8[0] = h.count; out8[1] = h.n_free; out8[2] = h.n_tomb; out8[3] = h.n_flush; out8[4] = h.n_evict;
@@ -2223,6 +2600,8 @@ extern "C" int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t 
     using namespace evs;
     if (!c || !c->bs) return EVS_EINVAL;
     if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return EVS_EHIP;
+    sampled_flush_if_wanted(c, reinterpret_cast<hipStream_t>(stream));
+    if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return EVS_EHIP;
     const int64_t cap = c->host.cap;
     std::vector<unsigned long long> ekey(cap);
     std::vector<int> eagg(cap);
@@ -2231,7 +2610,8 @@ extern "C" int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t 
     int64_t n = 0;
     for (int64_t e = 0; e < cap; e++) {
         if (!ekey[e]) continue;
-        if (n < max_triples && triples) { triples[3 * n] = eagg[e]; triples[3 * n + 1] = (int64_t)(ekey[e] >> 32); triples[3 * n + 2] = (int64_t)(ekey[e] & 0xffffffffull); }
+        const unsigned long long key = ekey[e] & evs::kKeyMask;   // (the sampled update keeps a batch stamp above the key)
+        if (n < max_triples && triples) { triples[3 * n] = eagg[e]; triples[3 * n + 1] = (int64_t)(key >> 32); triples[3 * n + 2] = (int64_t)(key & 0xffffffffull); }
         n++;
     }
     return n;

@@ -107,6 +107,12 @@ class GpuCache:
     def staged_rows(self):
         return int(_lib.lib().evs_cache_staged_rows(self._h))
 
+    def set_batch_policy(self, policy):
+        """'sampled' (one update kernel, victim = lowest priority of 8 sampled entries) or 'plan' (insert / plan / evict /
+        assign, clock-hand window); before the first batched lookup."""
+        _lib.check(_lib.lib().evs_cache_set_batch_policy(self._h, {"plan": 0, "sampled": 1}[policy]))
+        return self
+
     def request(self, rows, approx_thres=-1, out=None, hit=None):
         """rows: (B, n_tables) int32 tensor.  Requests are replayed strictly in order.
         Returns (hit (B,T) uint8, out (B,T,dim) fp32).

@@ -243,6 +243,14 @@ EVS_API int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, cons
  * evs_cache_request (exact) or by evs_cache_lookup_batch, never both (EVS_ESTATE). */
 EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
                                    void *stream);
+/* How the batched path of this cache makes room (before its first batched call; EVS_ESTATE afterwards):
+ *   1 "sampled" (default; EVS_CACHE_POLICY=plan in the environment selects 0): one kernel after the consumers -- the
+ *     thread that inserts a new key picks that key's victim itself, the lowest priority of one sampled group of 8
+ *     entries (free entries first), and fills the entry;
+ *   0 "plan": insert -> plan -> evict -> assign -> close, the lowest priorities of a clock-hand window go, exactly as
+ *     many as the batch needs (the file-backed miss tier and the two-tier lookup always take this form).
+ * Served rows and hit flags are the same under both; which keys stay resident differs. */
+EVS_API int evs_cache_set_batch_policy(evs_cache *c, int policy);
 /* Batched two-tier lookup, snapshot semantics: the throughput form of evs_cache_request_c1c2 (no reference
  * counterpart).  Every key is probed in C1, then in C2, against the tiers as they stand when the call starts;
  * agg_hit of a request counts keys found in either tier; a hit is served, and its priority raised, in the tier

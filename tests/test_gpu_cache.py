@@ -317,16 +317,20 @@ def _zipf_requests(n_rows, n_req, seed, alpha=1.15):
     return reqs
 
 
+POLICIES = ["sampled", "plan"]   # evs_cache_set_batch_policy: one update kernel with sampled victims / insert-plan-evict-assign
+
+
+@pytest.mark.parametrize("policy", POLICIES)
 @pytest.mark.parametrize("cap_frac,batch", [(0.10, 256), (0.02, 64), (0.5, 1024)])
-def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch):
-    """Batched (snapshot) EvLFU: rows exact, hit flags = residency at batch start, no duplicate keys,
-    size <= capacity, histogram consistent, priorities monotone; hit rate tracks the sequential oracle."""
+def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch, policy):
+    """Batched (snapshot) EvLFU under both policy updates: rows exact, hit flags = residency at batch start, no duplicate
+    keys, size <= capacity, histogram consistent, priorities monotone; hit rate tracks the sequential oracle."""
     n_rows = [3000, 40, 20000, 700, 5, 9000, 1500, 12, 26000, 300, 8000, 64, 2200, 17000, 3, 450, 5000, 90, 13000,
               2, 7000, 30, 1000, 11000, 150, 4000]
     tabs = orc.kaggle_tables(n_rows, 21)
     cap = int(cap_frac * sum(n_rows))
     reqs = _zipf_requests(n_rows, 4096, 2)
-    c = E.GpuCache("evlfu", cap, 26, 36, 32, "python")
+    c = E.GpuCache("evlfu", cap, 26, 36, 32, "python").set_batch_policy(policy)
     c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
     r = torch.from_numpy(reqs).cuda()
     resident = {}
@@ -349,9 +353,11 @@ def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch):
         for key, p in new_res.items():
             if key in resident:
                 assert p >= resident[key]
-        # every key of the batch that could be kept is resident afterwards when there was room
+        # every key of the batch that could be kept is resident afterwards when there was room (the sampled update may
+        # pick a key that was HIT in this batch as a victim while free entries remain elsewhere: missed keys only there)
         if st["size"] < cap:
-            assert all((k + 1, int(rq[b, k])) in new_res for b in range(len(rq)) for k in range(26))
+            assert all((k + 1, int(rq[b, k])) in new_res for b in range(len(rq)) for k in range(26)
+                       if policy == "plan" or not hit[b, k])
         resident = new_res
     st = c.batch_stats()
     assert st["n_hits"] == hits_total and st["n_requests"] == len(reqs)
@@ -374,7 +380,8 @@ def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch):
     assert rate_b <= rate_s + 0.05, (rate_b, rate_s)
 
 
-def test_batched_cache_over_host_memory_backing(E, orc):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_batched_cache_over_host_memory_backing(E, orc, policy):
     """the miss tier in pinned HOST memory (the reference's C3 / mmap miss path): the batched
     lookup serves hits from the HBM arena and misses straight from host rows (pointer table -> fused kernel),
     fills the arena from host rows, and gives the bits of the all-HBM path."""
@@ -382,8 +389,8 @@ def test_batched_cache_over_host_memory_backing(E, orc):
     tabs = orc.kaggle_tables(n_rows, 9)
     host = [torch.from_numpy(np.ascontiguousarray(t)).pin_memory() for t in tabs]
     dev = [torch.from_numpy(t).cuda() for t in tabs]
-    ch = E.GpuCache("evlfu", 2500, 26, 36, 32)
-    cd = E.GpuCache("evlfu", 2500, 26, 36, 32)
+    ch = E.GpuCache("evlfu", 2500, 26, 36, 32).set_batch_policy(policy)
+    cd = E.GpuCache("evlfu", 2500, 26, 36, 32).set_batch_policy(policy)
     ch.set_backing(host)
     cd.set_backing(dev)
     reqs = _zipf_requests(n_rows, 1200, 6)
@@ -392,19 +399,22 @@ def test_batched_cache_over_host_memory_backing(E, orc):
         x = torch.rand(300, 36, device="cuda")
         hit_h, R_h = ch.lookup_interact(r[s:s + 300].contiguous(), x)
         hit_d, R_d = cd.lookup_interact(r[s:s + 300].contiguous(), x)
-        assert torch.equal(R_h, R_d) and torch.equal(hit_h, hit_d)
+        assert torch.equal(R_h, R_d)   # the rows are the table rows wherever they are served from
+        if policy == "plan":           # (the sampled update's victims depend on thread timing: residency may differ)
+            assert torch.equal(hit_h, hit_d)
         hb, rows = ch.lookup_batch(r[s:s + 300].contiguous())
         for k in range(26):
             assert np.array_equal(rows[:, k, :].cpu().numpy(), tabs[k][reqs[s:s + 300, k]])
     assert ch.batch_stats()["n_hits"] > 0 and ch.batch_stats()["size"] > 0
 
 
-def test_batched_cache_smaller_than_one_batch(E, orc):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_batched_cache_smaller_than_one_batch(E, orc, policy):
     """A cache far smaller than the unique keys of one batch: the hash can run out of empty words between
     rebuilds; every walk is bounded, rows stay exact, the cache never exceeds its capacity."""
     n_rows = [400] * 26
     tabs = orc.kaggle_tables(n_rows, 3)
-    c = E.GpuCache("evlfu", 60, 26, 36, 32)
+    c = E.GpuCache("evlfu", 60, 26, 36, 32).set_batch_policy(policy)
     c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
     rs = np.random.RandomState(0)
     for it in range(6):
@@ -477,7 +487,8 @@ def test_file_backed_miss_tier(E, orc, tmp_path, budget_kb, cap):
             c2.request(torch.zeros((1, 26), dtype=torch.int32, device="cuda"))
 
 
-def test_batched_host_tier_flush_with_pinned_hits(E, orc):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_batched_host_tier_flush_with_pinned_hits(E, orc, policy):
     """Found by tools/fuzz_cache.py: one table (every hit has the top priority, so the EvLFU flush fires), a 50-entry
     cache in front of host-memory tables, batches far larger than the cache.  Hits of the running batch are pinned,
     so the flush finds fewer victims than planned; the free stack must stay gap-free or live entries are handed out
@@ -486,7 +497,7 @@ def test_batched_host_tier_flush_with_pinned_hits(E, orc):
     n, d = 500, 16
     tab = rs.uniform(-1, 1, size=(n, d)).astype(np.float32)
     for host in (True, False):
-        c = E.GpuCache("evlfu", 50, 1, d, 32, "python")
+        c = E.GpuCache("evlfu", 50, 1, d, 32, "python").set_batch_policy(policy)
         c.set_backing([torch.from_numpy(tab).pin_memory() if host else torch.from_numpy(tab).cuda()])
         for it in range(6):
             rq = rs.randint(0, n, size=(700, 1)).astype(np.int32)
@@ -511,12 +522,13 @@ def test_batched_and_exact_paths_do_not_mix(E, orc):
         c.request(rows)
 
 
-def test_cache_lookup_interact_equals_rows_then_interact(E, orc):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_cache_lookup_interact_equals_rows_then_interact(E, orc, policy):
     """evs_cache_lookup_interact (pointer-table + fused MFMA kernel) == interact_features over the table rows."""
     n_rows = [500, 7, 9000, 40, 2500, 3] + [100] * 20
     tabs = orc.kaggle_tables(n_rows, 5)
     dev = [torch.from_numpy(t).cuda() for t in tabs]
-    c = E.GpuCache("evlfu", 2000, 26, 36, 32)
+    c = E.GpuCache("evlfu", 2000, 26, 36, 32).set_batch_policy(policy)
     c.set_backing(dev)
     reqs = _zipf_requests(n_rows, 900, 4)
     r = torch.from_numpy(reqs).cuda()
