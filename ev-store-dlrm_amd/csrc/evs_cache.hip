@@ -1464,7 +1464,8 @@ __global__ void __launch_bounds__(256) cache_batch_close_kernel(const BatchArgs 
         if (b->need > 0 && b->win > 0) { long long h = (long long)b->hand + b->win; b->hand = (int)(h % args.cap); }
         b->n_miss = 0; b->n_new = 0; b->n_orphan = 0; b->batch_id++;
         b->n_requests += args.B;
-        *args.host_tomb = b->n_tomb;
+        args.host_tomb[0] = b->n_tomb;
+        args.host_tomb[2] = (int)b->batch_id;   // the ordinal of this close: the host ignores reports older than its last sweep / rebuild
     }
     __syncthreads();
     {
@@ -1552,7 +1553,8 @@ __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs
 // BETWEEN new keys instead: the thread that wins the hash slot of a new key also finds that key's victim by itself --
 // it samples one aligned group of kSampleGroup entries (chosen by a hash of the key and the batch number), takes a
 // free entry if the group has one, else the entry of lowest priority, claims it with a CAS on its key word, unhooks
-// the old key from the hash, and hands the entry to the new key.  No plan, no tickets, no free stack, no scan: the
+// the old key from the hash, and hands the entry to the new key (only then does it claim the key's hash slot: see the
+// kernel).  No plan, no tickets, no free stack, no scan: the
 // eviction decision is "lowest priority of 8 sampled entries" (the sampled-LFU of Redis) instead of "lowest priority
 // in a clock-hand window"; tests/test_gpu_cache.py holds both against the sequential oracle's hit rate.
 //   Entries inserted or hit in this batch carry the batch stamp and are never victims.  Inserts and evictions now
@@ -1588,6 +1590,8 @@ __device__ __forceinline__ void sampled_load(const BatchArgs &args, long long e0
         w.pr[j] = on ? args.a.eagg[e0 + j] : 0;
         w.sl[j] = on ? args.eslot[e0 + j] : 0;
         const bool hit_now = on && args.stamp_hits && args.estamp[e0 + j] == args.stamp;
+        // a word with this batch's stamp: filled in this launch -- or taken and given back in it (key part 0): its
+        // row may still be on its way out of another XCD's L2, so it is not handed out again before the next batch
         if (w.k[j] != kEmpty && ((unsigned)(w.k[j] >> kKeyBits) == stamp26 || hit_now)) w.k[j] = kClaimed;
     }
 }
@@ -1605,7 +1609,7 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
         unsigned long long bk = 0;
 #pragma unroll
         for (int j = 0; j < kSampleGroup; j++) {
-            const int pj = w.k[j] == kEmpty ? -1 : w.pr[j];
+            const int pj = (w.k[j] & kKeyMask) == kEmpty ? -1 : w.pr[j];
             const bool cand = !((tried >> j) & 1u) && w.k[j] != kClaimed && pj < bp;
             best = cand ? j : best; bp = cand ? pj : bp; bk = cand ? w.k[j] : bk; bs = cand ? w.sl[j] : bs;
         }
@@ -1614,7 +1618,7 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
             tried |= 1u << best;
             const long long e = e0 + best;
             if (atomicCAS(&args.a.ekey[e], bk, kClaimed) == bk) {   // else somebody else was faster
-                if (bk != kEmpty) st_agent(&args.slots[bs], args.tomb_parity ? kTomb1 : kTomb);
+                if ((bk & kKeyMask) != kEmpty) st_agent(&args.slots[bs], args.tomb_parity ? kTomb1 : kTomb);
                 old_prio = bp;
                 result = (int)e;
             }
@@ -1623,17 +1627,66 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
     return result;
 }
 
-// replica columns of part2 in this mode: 0..32 histogram deltas, 33 entries taken from the free ones (count delta),
-// 34 evictions, 35 tombstone delta (evicted + dropped - recycled)
+// One thread copies one row.  All loads first: a load / store pair per 16 bytes is one dependent round trip each (the
+// compiler cannot prove the two rows apart) and cost 11 us of the update kernel; fixed piece counts keep the pieces in
+// registers (a runtime-indexed array, or a switch over the sizes inside one kernel, went to scratch / LDS: 32 -> 43-52 us),
+// so the update kernel is compiled per row size.
+template <int N>
+__device__ __forceinline__ void copy_row_pieces(const unsigned char *src, unsigned char *dst) {
+    // named scalars, not an array: hipcc 7.2 kept a float4[N] here in scratch (or promoted it to LDS) although every index
+    // is a constant after unrolling
+    const float4 *p = reinterpret_cast<const float4 *>(src);
+    float4 *q = reinterpret_cast<float4 *>(dst);
+    float4 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15;
+    if constexpr (N > 0) a0 = p[0];
+    if constexpr (N > 1) a1 = p[1];
+    if constexpr (N > 2) a2 = p[2];
+    if constexpr (N > 3) a3 = p[3];
+    if constexpr (N > 4) a4 = p[4];
+    if constexpr (N > 5) a5 = p[5];
+    if constexpr (N > 6) a6 = p[6];
+    if constexpr (N > 7) a7 = p[7];
+    if constexpr (N > 8) a8 = p[8];
+    if constexpr (N > 9) a9 = p[9];
+    if constexpr (N > 10) a10 = p[10];
+    if constexpr (N > 11) a11 = p[11];
+    if constexpr (N > 12) a12 = p[12];
+    if constexpr (N > 13) a13 = p[13];
+    if constexpr (N > 14) a14 = p[14];
+    if constexpr (N > 15) a15 = p[15];
+    if constexpr (N > 0) q[0] = a0;
+    if constexpr (N > 1) q[1] = a1;
+    if constexpr (N > 2) q[2] = a2;
+    if constexpr (N > 3) q[3] = a3;
+    if constexpr (N > 4) q[4] = a4;
+    if constexpr (N > 5) q[5] = a5;
+    if constexpr (N > 6) q[6] = a6;
+    if constexpr (N > 7) q[7] = a7;
+    if constexpr (N > 8) q[8] = a8;
+    if constexpr (N > 9) q[9] = a9;
+    if constexpr (N > 10) q[10] = a10;
+    if constexpr (N > 11) q[11] = a11;
+    if constexpr (N > 12) q[12] = a12;
+    if constexpr (N > 13) q[13] = a13;
+    if constexpr (N > 14) q[14] = a14;
+    if constexpr (N > 15) q[15] = a15;
+}
+
+// replica columns of part2 in this mode: 0..32 histogram deltas, 33 count delta (entries taken from the free ones minus
+// victims given back), 34 evictions, 35 tombstone delta (evicted - recycled)
+//
+// Order inside a thread: the ENTRY first, the hash slot last, with the final word.  There is no pending state: the
+// copy of a key that wins the slot is the one that inserted it (with its request's agg_hit as the priority); a copy
+// that finds the key already there gives its entry back as a free one (a wasted eviction per duplicate miss of a
+// batch -- those are few: hot keys are hits).  That keeps the dependent chain at four round trips -- request + probe
+// record, victim group (with the source row), CAS on the entry, CAS on the slot -- instead of six with a pending word
+// that is finalised later.
+template <int PIECES>   // 16-byte pieces of a row (0: any row size, piece by piece)
 __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
-    __shared__ int s_ncopy;
-    __shared__ const unsigned char *s_src[256];
-    __shared__ unsigned char *s_dst[256];
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_ncopy = 0;
     __syncthreads();
     const long long n = args.B * args.T;
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1644,101 +1697,65 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
         const unsigned row = (unsigned)args.requests[m];
         const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
         const int agg = (int)((info >> 24) & 63u);
-        const unsigned long long mine = make_word(key, kFieldPend + (unsigned)agg);
-        const unsigned long long my_tomb = args.tomb_parity ? kTomb1 : kTomb, old_tomb = args.tomb_parity ? kTomb : kTomb1;
-        // the victim group depends on the key and the batch only: its loads go out together with the first CAS
+        const unsigned long long old_tomb = args.tomb_parity ? kTomb : kTomb1;
+        // The victim group depends on the key, the batch and the POSITION in the batch: copies of one missing key must
+        // not all start on the same 8 entries (16 384 copies of a hot key in a cold cache walked the arena group by
+        // group behind each other: a 23 ms launch).
         const long long n_groups = ((long long)args.cap + kSampleGroup - 1) / kSampleGroup;
-        long long g = (long long)(mix64(key ^ ((unsigned long long)(unsigned)args.stamp * 0x9e3779b97f4a7c15ull)) % (unsigned long long)n_groups);
+        long long g = (long long)(mix64(key ^ ((unsigned long long)(unsigned)args.stamp * 0x9e3779b97f4a7c15ull) ^ ((unsigned long long)m << 40)) % (unsigned long long)n_groups);
         SampleWindow win;
         sampled_load(args, g * kSampleGroup, win);
-        // The walk starts at the first reusable slot K1's probe saw on the chain (every copy of a key carries the same
-        // hint: one snapshot), or at the home slot when the hint had to be shortened (tables above 2^24 slots); K1 also
-        // said whether that slot was empty or a tombstone, so the first access is the CAS itself.
-        unsigned long long i = args.hint_shift == 0 ? (unsigned long long)(info & 0xffffffu) : (mix64(key) & args.mask);
-        unsigned long long w = (args.hint_shift == 0 && (info & 0x40000000u)) ? old_tomb : kEmpty;
-        long long slot = -1;
-        bool recycled = false, walking = true;
-        for (unsigned long long steps = 0; steps <= args.mask && walking; steps++) {   // one lap at most: a full table drops the key
-            bool step_on = true;
-            if (w == kEmpty || w == old_tomb) {
-                const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
-                if (prev == w) { slot = (long long)i; recycled = (w == old_tomb); walking = false; step_on = false; }   // this thread owns the new key
-                else w = prev;
-            }
-            if (step_on && (w & kKeyMask) == key) {   // another copy of this key got here first
-                bool folding = true;
-                while (folding) {
-                    const unsigned f = (unsigned)(w >> kKeyBits);
-                    if (f >= kFieldPend) {               // still pending: fold the priority into the word
-                        if (w >= mine) folding = false;
-                        else {
-                            const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
-                            if (prev == w) folding = false;
-                            else { w = prev; if ((w & kKeyMask) != key) folding = false; }   // its owner dropped it meanwhile: let it go
-                        }
-                    } else {                             // already has its entry: raise the priority there (as a hit would)
-                        const int old = atomicMax(&args.a.eagg[f], agg);
-                        if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
-                        folding = false;
-                    }
-                }
-                walking = false; step_on = false;
-            }
-            if (step_on) {
-                // somebody else's key, or a slot that is not for re-use: next slot -- and if that one looks usable, CAS it
-                i = (i + 1) & args.mask;
-                w = ld_agent(&args.slots[i]);
-            }
+        // a look at the hinted slot (same round trip): if another copy of the key is already in, there is nothing to do
+        const unsigned long long hint = args.hint_shift == 0 ? (unsigned long long)(info & 0xffffffu) : (mix64(key) & args.mask);
+        const bool already = (args.slots[hint] & kKeyMask) == key;
+        int old_prio = -1, e = -1;
+        for (long long tries = 0; tries < n_groups && e < 0 && !already; tries++) {
+            if (tries) sampled_load(args, g * kSampleGroup, win);
+            e = sampled_take(args, g * kSampleGroup, win, old_prio);
+            g = g + 1 == n_groups ? 0 : g + 1;
         }
-        if (slot >= 0) {
-            if (recycled) atomicSub(&s_stat[2], 1);
-            int old_prio = -1, e = -1;
-            for (long long tries = 0; tries < n_groups && e < 0; tries++) {
-                if (tries) sampled_load(args, g * kSampleGroup, win);
-                e = sampled_take(args, g * kSampleGroup, win, old_prio);
-                g = g + 1 == n_groups ? 0 : g + 1;
+        if (e >= 0) {   // (else: nothing claimable anywhere -- a cache smaller than the batch's keys: the key is not kept)
+            if (old_prio >= 0) { atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); atomicAdd(&s_stat[2], 1); }
+            // the row, the priority, the key word (with this batch's stamp: nobody takes the entry away again)
+            const unsigned char *srow = args.backing[t] + (long long)row * args.row_bytes;
+            unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
+            if constexpr (PIECES > 0) copy_row_pieces<PIECES>(srow, drow);
+            else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
+            else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
+            args.a.eagg[e] = agg;
+            st_agent(&args.a.ekey[e], key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits));
+            // The hash slot, with the final word.  The walk starts at the first reusable slot K1's probe saw on the chain
+            // (every copy of a key carries the same hint: one snapshot), or at the home slot when the hint had to be
+            // shortened (tables above 2^24 slots); K1 also said whether that slot was empty or a tombstone, so the first
+            // access is the CAS itself.
+            const unsigned long long mine = make_word(key, (unsigned)e);
+            unsigned long long i = hint;
+            unsigned long long w = (args.hint_shift == 0 && (info & 0x40000000u)) ? old_tomb : kEmpty;
+            int placed = 0;   // 1: inserted, 2: another copy of the key was faster
+            bool recycled = false;
+            for (unsigned long long steps = 0; steps <= args.mask && !placed; steps++) {   // one lap at most: a full table drops the key
+                if (w == kEmpty || w == old_tomb) {
+                    const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
+                    if (prev == w) { placed = 1; recycled = (w == old_tomb); }
+                    else w = prev;
+                }
+                if (!placed) {
+                    if ((w & kKeyMask) == key) placed = 2;
+                    else { i = (i + 1) & args.mask; w = ld_agent(&args.slots[i]); }   // somebody else's key, or not for re-use: next slot
+                }
             }
-            if (e < 0) {
-                atomicExch(&args.slots[slot], my_tomb);   // no entry to be had: forget the key
-                atomicAdd(&s_stat[2], 1);
-            } else {
-                if (old_prio >= 0) { atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); atomicAdd(&s_stat[2], 1); }
-                else atomicAdd(&s_stat[0], 1);
-                st_agent(&args.a.eagg[e], agg);
-                args.eslot[e] = (int)slot;
-                st_agent(&args.a.ekey[e], key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits));
+            if (placed == 1) {
+                args.eslot[e] = (int)i;
                 atomicAdd(&s_delta[agg], 1);
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the priority is acknowledged before a copy of the key can find the entry
-                unsigned long long pw = mine;
-                int agg_f = agg;
-                for (;;) {   // pending word -> entry word; copies of the key may still be raising the pending priority
-                    const unsigned long long prev = atomicCAS(&args.slots[slot], pw, make_word(key, (unsigned)e));
-                    if (prev == pw) break;
-                    pw = prev;
-                    agg_f = (int)((unsigned)(pw >> kKeyBits) - kFieldPend);
-                }
-                if (agg_f > agg) {
-                    const int old = atomicMax(&args.a.eagg[e], agg_f);
-                    if (old < agg_f) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg_f], 1); }
-                }
-                const int ci = atomicAdd(&s_ncopy, 1);
-                s_src[ci] = args.backing[t] + (long long)row * args.row_bytes;
-                s_dst[ci] = args.a.arena + (long long)e * args.row_bytes;
+                if (old_prio < 0) atomicAdd(&s_stat[0], 1);
+                if (recycled) atomicSub(&s_stat[2], 1);
+            } else {   // a duplicate (or no slot in a full table): the entry goes back as a free one
+                st_agent(&args.a.ekey[e], (unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits);   // free from the next batch on
+                if (old_prio >= 0) atomicSub(&s_stat[0], 1);
             }
         }
     }
     __syncthreads();
-    // the block's new rows into the arena, 16 lanes per row
-    const int nc = s_ncopy, sub = threadIdx.x & 15;
-    for (int r = threadIdx.x >> 4; r < nc; r += 16) {
-        const unsigned char *srow = s_src[r];
-        unsigned char *drow = s_dst[r];
-        if ((args.row_bytes & 15) == 0) {
-            for (int c = sub * 16; c < args.row_bytes; c += 256) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c);
-        } else {
-            for (int c = sub; c < args.row_bytes; c += 16) drow[c] = srow[c];
-        }
-    }
     if (threadIdx.x < kPartCols) {
         const int i = threadIdx.x;
         const int v = i <= args.T ? s_delta[i] : (i >= 33 && i <= 35) ? s_stat[i - 33] : 0;
@@ -1778,7 +1795,8 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_close_kernel(const Ba
         b->batch_id++;
         b->n_requests += args.B;
         b->ticket_t = 0;
-        *args.host_tomb = b->n_tomb;
+        args.host_tomb[0] = b->n_tomb;
+        args.host_tomb[2] = (int)b->batch_id;   // the ordinal of this close: the host ignores reports older than its last sweep / rebuild
         *host_flush = b->cnt[args.T] >= args.max_perfect ? 1 : 0;   // EvLFU flush (EvLFU_C1.py:36-44): the host launches it
     }
     __syncthreads();
@@ -1801,7 +1819,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_flush_kernel(BatchSta
     __syncthreads();
     for (long long e0 = (long long)blockIdx.x * blockDim.x; e0 < cap; e0 += (long long)gridDim.x * blockDim.x) {   // block-uniform trip count
         const long long e = e0 + threadIdx.x;
-        const bool top = e < cap && a.ekey[e] != kEmpty && a.eagg[e] == T;
+        const bool top = e < cap && (a.ekey[e] & kKeyMask) != kEmpty && a.eagg[e] == T;
         const int tk = block_reserve(&b->ticket_t, top, s_tot);
         if (top && tk < want) {
             slots[eslot[e]] = kTomb;
@@ -1907,6 +1925,7 @@ struct evs_cache {
     evs::CacheState *st = nullptr;
     evs::CacheArrays a{};
     long long nslot = 0;
+    long long bnslot = 0;   // slots of the batched path's hash (its own, sparser table: see evs_cache_create)
     const unsigned char *backing[evs::kMaxTables] = {nullptr};
     long long backing_rows[evs::kMaxTables] = {0};
     bool has_backing = false;
@@ -1941,7 +1960,7 @@ struct evs_cache {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int fork_mode = -1;            // -1: not decided yet (EVS_CACHE_FORK, default off), 0 / 1
-    long long batch_calls = 0, last_sweep_call = -100;   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
+    long long batch_calls = 0, last_sweep_call = -100, last_hk_call = 0;   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
     int batch_policy = -1;         // policy update of the batched path: 0 plan-based (K2..K6), 1 sampled (one kernel); -1: EVS_CACHE_POLICY, default sampled
 };
 
@@ -1995,6 +2014,10 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
     long long nslot = 16;
     while (nslot < capacity * 2 + 8) nslot <<= 1;
     c->nslot = nslot;
+    // The batched path keeps its own hash, twice as sparse (load <= 0.25 instead of <= 0.5) while that still fits the 24-bit
+    // slot hints: deletions leave tombstones, and how often they have to be swept / the table rebuilt (~170 us at 3.4 M
+    // entries) is a matter of tombstones per slot -- 16 us per batch amortised at load 0.4, a third of that here.
+    c->bnslot = (nslot * 2 <= (1ll << 24)) ? nslot * 2 : nslot;
     h.nslot_mask = (unsigned long long)(nslot - 1);
     h.min_c1 = 0; h.n_perfect = 0;
     h.max_perfect = (int)(capacity * perfect_item_cap);          // EvLFU_C1.py:30
@@ -2202,14 +2225,14 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
         unsigned long long *bslots = nullptr;
         void *slab = nullptr;
         SlabPlan sp;
-        sp.add(&bs, sizeof(BatchState)); sp.add(&eslot, cap * 4); sp.add(&bslots, c->nslot * 8);
+        sp.add(&bs, sizeof(BatchState)); sp.add(&eslot, cap * 4); sp.add(&bslots, c->bnslot * 8);
         sp.add(&part1, kReplicas * kPartCols * 4); sp.add(&part2, kReplicas * kPartCols * 4);
         const bool ok =
             sp.carve(&slab) && hipMemcpy(bs, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess &&   // blocking copy
-            hipMemsetAsync(bslots, 0, c->nslot * 8, st) == hipSuccess &&                               // ordered on the caller's stream
+            hipMemsetAsync(bslots, 0, c->bnslot * 8, st) == hipSuccess &&                               // ordered on the caller's stream
             hipMemsetAsync(part1, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
             hipMemsetAsync(part2, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
-            hipHostMalloc(reinterpret_cast<void **>(&host_tomb), 2 * sizeof(int), hipHostMallocMapped) == hipSuccess &&   // [0] tombstones, [1] flush wanted
+            hipHostMalloc(reinterpret_cast<void **>(&host_tomb), 4 * sizeof(int), hipHostMallocMapped) == hipSuccess &&   // [0] tombstones, [1] flush wanted, [2] which close reported [0]
             hipHostGetDevicePointer(reinterpret_cast<void **>(&host_tomb_dev), host_tomb, 0) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
@@ -2218,7 +2241,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
             set_error("%s: allocating the batched-path state failed (capacity %lld)", who, cap);
             return EVS_ENOMEM;
         }
-        host_tomb[0] = 0; host_tomb[1] = 0;
+        host_tomb[0] = 0; host_tomb[1] = 0; host_tomb[2] = 0; host_tomb[3] = 0;
         c->slab_batch = slab;
         c->bs = bs; c->eslot = eslot; c->bslots = bslots; c->part1 = part1; c->part2 = part2;
         c->host_tomb = host_tomb; c->host_tomb_dev = host_tomb_dev;
@@ -2251,12 +2274,12 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     a.bs = c->bs; a.a = c->a; a.eslot = c->eslot; a.slots = c->bslots;
     a.miss_info = c->miss_info; a.new_slot = c->new_slot;
     a.hint_shift = 0;
-    while ((c->nslot >> a.hint_shift) > (1ll << 24)) a.hint_shift++;
+    while ((c->bnslot >> a.hint_shift) > (1ll << 24)) a.hint_shift++;
     a.row_ptrs = c->row_ptrs;
     for (int k = 0; k < kMaxTables; k++) { a.backing[k] = c->backing[k]; a.backing_rows[k] = c->backing_rows[k]; }
-    a.requests = rows; a.out = nullptr; a.hit = nullptr; a.B = B; a.mask = c->host.nslot_mask;
+    a.requests = rows; a.out = nullptr; a.hit = nullptr; a.B = B; a.mask = (unsigned long long)(c->bnslot - 1);
     a.cap = (int)cap; a.T = T; a.d = c->host.dim; a.codec = c->host.codec; a.row_bytes = c->host.row_bytes;
-    a.max_perfect = c->host.max_perfect; a.flush_n = c->host.flush_n; a.nslot = (int)c->nslot;
+    a.max_perfect = c->host.max_perfect; a.flush_n = c->host.flush_n; a.nslot = (int)c->bnslot;
     a.block_cnt = c->block_cnt; a.block_base = c->block_base; a.part1 = c->part1; a.part2 = c->part2;
     long long g1 = (B + 7) / 8; if (g1 > kProbeGridMax) g1 = kProbeGridMax;
     a.g1 = (int)g1; a.g2 = (int)g2;
@@ -2265,16 +2288,21 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     a.other_slots = nullptr; a.other_mask = 0;
     a.staged_mask = 0; a.staging = nullptr; a.new_keys = nullptr; a.slot_stage = nullptr; a.stage_rows = 0;
     // Tombstone housekeeping, from the count the close of an EARLIER batch left in mapped host memory (no synchronisation:
-    // one or two batches late is as good; cleared here so that one report triggers one action): past nslot / 8 the
+    // a few batches late is as good): past nslot / 8 the
     // table is swept (tombstones at the end of their chains become empty again); if the count is back there within
     // three calls the sweep did not help enough and the hash is rebuilt.
     a.tomb_parity = -1;
     a.rebuild = 0;
-    c->batch_calls++;
-    if (*reinterpret_cast<volatile int *>(c->host_tomb) > (int)(c->nslot / 8)) {
-        *reinterpret_cast<volatile int *>(c->host_tomb) = 0;
-        if (c->batch_calls - c->last_sweep_call <= 3) a.rebuild = 1;
-        else { a.rebuild = 2; c->last_sweep_call = c->batch_calls; }
+    c->batch_calls++;   // = the ordinal of this call's close
+    {
+        volatile int *hk = reinterpret_cast<volatile int *>(c->host_tomb);
+        const long long seq = hk[2];
+        // (the device runs behind the host: a report is only news if its close came after the last sweep / rebuild)
+        if (seq > c->last_hk_call && hk[0] > (int)(c->bnslot / 8)) {
+            if (seq - c->last_sweep_call <= 3) a.rebuild = 1;
+            else { a.rebuild = 2; c->last_sweep_call = c->batch_calls; }
+            c->last_hk_call = c->batch_calls;
+        }
     }
     return EVS_OK;
 }
@@ -2316,7 +2344,7 @@ static int batch_stage_prepare(evs_cache *c, evs::BatchArgs &a, hipStream_t st) 
         EVS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->staging_dev), c->staging, 0));
         c->staging_rows = want;
     }
-    if (!c->slot_stage) EVS_HIP_CHECK(hipMalloc(&c->slot_stage, c->nslot * 4));
+    if (!c->slot_stage) EVS_HIP_CHECK(hipMalloc(&c->slot_stage, c->bnslot * 4));
     a.staged_mask = c->staged_mask; a.staging = c->staging_dev; a.new_keys = c->new_keys; a.slot_stage = c->slot_stage;
     a.stage_rows = c->staging_rows;
     return EVS_OK;
@@ -2358,8 +2386,8 @@ static void batch_housekeeping(evs_cache *c, const evs::BatchArgs &a, hipStream_
         hipLaunchKernelGGL(cache_batch_clear_kernel, dim3((unsigned)wide), dim3(256), 0, st, a);
         hipLaunchKernelGGL(cache_batch_reinsert_kernel, dim3((unsigned)ne), dim3(256), 0, st, a);
     } else if (a.rebuild == 2) {
-        long long nb = (c->nslot / kSweepRun + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
-        hipLaunchKernelGGL(cache_batch_sweep_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->bs, c->bslots, c->nslot);
+        long long nb = (c->bnslot / kSweepRun + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(cache_batch_sweep_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->bs, c->bslots, c->bnslot);
     }
 }
 static void batch_close(evs_cache *c, evs::BatchArgs a, hipStream_t st) {
@@ -2436,9 +2464,45 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         if (!host_tier) a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;   // (host tier: set above, with the hit stamps)
         a.tomb_parity = a.stamp & 1;
         sampled_flush_if_wanted(c, st);   // EvLFU flush the close of an earlier batch asked for: before this batch's probe
+        if (c->fork_mode < 0) {
+            const char *e = getenv("EVS_CACHE_FORK");
+            c->fork_mode = (e && e[0] == '1') ? 1 : 0;
+        }
+        // EVS_CACHE_FORK=1: the update runs on a side stream UNDER the consumer.  What makes that legal: with the hits of
+        // the batch stamped (K1) the update never takes an entry the consumer reads, and the consumer reads nothing
+        // else the update writes.
+        const bool fork = c->fork_mode == 1 && !host_tier && (R || out);
+        if (fork) {
+            if (!c->estamp) {
+                EVS_HIP_CHECK(hipMalloc(&c->estamp, cap * 4));
+                EVS_HIP_CHECK(hipMemsetAsync(c->estamp, 0, cap * 4, st));
+            }
+            a.estamp = c->estamp; a.stamp_hits = 1;
+            if (!c->side) {
+                EVS_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+                EVS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                EVS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+        }
         hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)a.g1), dim3(256), 0, st, a);
-        if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
-        hipLaunchKernelGGL(cache_batch_sampled_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
+        hipStream_t su = st;
+        if (fork) {
+            EVS_HIP_CHECK(hipEventRecord(c->ev_fork, st));
+            EVS_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            su = c->side;
+        } else if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
+        switch (a.row_bytes) {
+        case 144: hipLaunchKernelGGL(cache_batch_sampled_kernel<9>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;    // d = 36 fp32
+        case 256: hipLaunchKernelGGL(cache_batch_sampled_kernel<16>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;   // d = 64 fp32
+        case 128: hipLaunchKernelGGL(cache_batch_sampled_kernel<8>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
+        case 64: hipLaunchKernelGGL(cache_batch_sampled_kernel<4>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
+        default: hipLaunchKernelGGL(cache_batch_sampled_kernel<0>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
+        }
+        if (fork) {
+            EVS_HIP_CHECK(hipEventRecord(c->ev_join, c->side));
+            const int rc = consumers(); if (rc) return rc;
+            EVS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0));
+        }
         if (host_tier) {
             hipLaunchKernelGGL(cache_batch_patch_ptrs_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
             const int rc = consumers(); if (rc) return rc;
@@ -2556,7 +2620,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, int64_t B, const int32_
         if (rc) return rc;
     }
     batch_policy(c1, a1, st);
-    a2.other_slots = c1->bslots; a2.other_mask = c1->host.nslot_mask;   // a key C1 just took is not inserted in C2 too
+    a2.other_slots = c1->bslots; a2.other_mask = (unsigned long long)(c1->bnslot - 1);   // a key C1 just took is not inserted in C2 too
     batch_policy(c2, a2, st);
     batch_close(c1, a1, st);
     batch_close(c2, a2, st);
@@ -2609,8 +2673,8 @@ extern "C" int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t 
     if (hipMemcpy(eagg.data(), c->a.eagg, cap * 4, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
     int64_t n = 0;
     for (int64_t e = 0; e < cap; e++) {
-        if (!ekey[e]) continue;
-        const unsigned long long key = ekey[e] & evs::kKeyMask;   // (the sampled update keeps a batch stamp above the key)
+        const unsigned long long key = ekey[e] & evs::kKeyMask;
+        if (!key) continue;   // (the sampled update keeps a batch stamp above the key)
         if (n < max_triples && triples) { triples[3 * n] = eagg[e]; triples[3 * n + 1] = (int64_t)(key >> 32); triples[3 * n + 2] = (int64_t)(key & 0xffffffffull); }
         n++;
     }
