@@ -230,15 +230,19 @@ def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=No
     return res
 
 
-def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, alpha=0.75, batch1=True, host_tier_line=True,
-                       settle_s=0.35):
+def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, alpha=0.75, batch1=True, host_tier_line=True,
+                       settle_s=0.35, policy=None):
     """BASELINE configs[2]: EvLFU C1 cache in HBM at 10 % of the rows in front of the same tables
     (the tables stay the miss tier); Zipf indices; batched snapshot-semantics lookups + interaction.
-    alpha=0.75 with 60 warm-up batches fills the cache, so the timed batches run at capacity (evicting)."""
+    alpha=0.75 with 60 warm-up batches fills the cache, so the timed batches run at capacity (evicting); 200 timed
+    batches, none seen before, so that the hash housekeeping (a tombstone sweep every ~28 batches) is inside the
+    number.  policy: 'sampled' (library default) / 'plan' (evs_cache_set_batch_policy)."""
     import evstore_dlrm_amd as E
     T = len(ln_emb)
     cap = int(frac * sum(ln_emb))
     cache = E.GpuCache("evlfu", cap, T, d, 32, "python", dev)
+    if policy:
+        cache.set_batch_policy(policy)
     cache.set_backing(ev)
     batches = make_batches(ln_emb, B, warmup + steps, seed=3, device=dev, dist="zipf", alpha=alpha)  # no batch repeats
     rows = [b[1].t().contiguous().to(torch.int32) for b in batches]  # (B,T) int32 request rows
@@ -293,10 +297,11 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
             h0 = ch.batch_stats()
             torch.cuda.synchronize()
             th = time.perf_counter()
-            for i in range(steps):
+            hsteps = min(steps, 30)
+            for i in range(hsteps):
                 ch.lookup_interact(rows[(warmup + i) % len(rows)], x, out=out, hit=hit)
             torch.cuda.synchronize()
-            dth = time.perf_counter() - th
+            dth = (time.perf_counter() - th) * steps / hsteps   # (scaled: `looks` counts all the timed batches)
             h1 = ch.batch_stats()
             evh = E.EVTables(host, d, 32, device=dev)   # host-resident tables straight into the fused kernel
             off = batches[0][0]
@@ -308,7 +313,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
             torch.cuda.synchronize()
             dtn = (time.perf_counter() - tn) / 6
             host_tier = {"value": looks / dth, "unit": "lookups/s", "ms_per_step": dth / steps * 1e3,
-                         "hit_rate": (h1["n_hits"] - h0["n_hits"]) / looks,
+                         "hit_rate": (h1["n_hits"] - h0["n_hits"]) / (T * B * hsteps), "timed_batches": hsteps,
                          "uncached_host_reads": {"value": T * B / dtn, "ms_per_step": dtn * 1e3},
                          "note": "tables (miss tier) in pinned host memory, cache in HBM; uncached = the fused kernel reading every row over the bus"}
             del ch, host, evh
@@ -318,7 +323,8 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
     # oracle's sequential EvLFU on the host cores, same Zipf stream, smaller cache so both warm up quickly
     if not batch1:
         return {"value": looks / dt, "ms_per_step": dt / steps * 1e3, "hit_rate": (s1["n_hits"] - s0["n_hits"]) / looks,
-                "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"], "roofline": tier_roof}
+                "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"], "roofline": tier_roof,
+                "policy": policy or "sampled", "timed_batches": steps}
     # batch-1 stream: Zipf(1.05), 200 k-entry cache -- a hit rate in the 90s like the reference's experiments, reached
     # within the first thousand requests (the 10 % cache of the batched section would need ~0.5 M requests to fill)
     n1, n_skip = 3000, 1000
@@ -363,7 +369,15 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=30, warmup=60, frac=0.10, al
                          "EvLFU (cache_algo/EvLFU_C1.py restated), in-memory tables, %.2f s" % (n1 - n_skip, n_skip, dtc)}
     except Exception as e:  # the oracle is test infrastructure: its absence must not break the bench
         cpu = {"error": str(e)}
-    return {"value": looks / dt, "roofline": tier_roof, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
+    plan = None
+    if policy is None:   # the other policy update beside the default, shorter
+        try:
+            pl = cache_tier_section(ev, ln_emb, d, B, dev, steps=100, warmup=warmup, frac=frac, alpha=alpha, batch1=False, settle_s=0.1, policy="plan")
+            plan = {"value": pl["value"], "ms_per_step": pl["ms_per_step"], "hit_rate": pl["hit_rate"], "timed_batches": 100,
+                    "note": "evs_cache_set_batch_policy(0): insert / plan / evict / assign / close (the round-1 form)"}
+        except Exception as e:
+            plan = {"error": repr(e)}
+    return {"value": looks / dt, "policy": policy or "sampled", "timed_batches": steps, "plan_policy": plan, "roofline": tier_roof, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
             "hit_rate": (s1["n_hits"] - s0["n_hits"]) / looks, "capacity_entries": cap,
             "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"],
             "workload": "BASELINE configs[2]: EvLFU C1 in HBM at %.0f%% of 33.76M rows, Zipf(alpha=%.2f) indices, "
