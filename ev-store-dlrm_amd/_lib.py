@@ -68,6 +68,9 @@ _PROTOS = {
     "evs_cache_request": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "evs_cache_request_c1c2": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "evs_cache_lookup_batch_c1c2": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _int, _vp]),
+    "evs_cache_lookup_batch_c1c2c3": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, _vp]),
+    "evs_cache_lookup_interact_c1c2c3": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _int, _vp]),
+    "evs_aprx_batch_dump": (_i64, [_vp, _i64p, _i64, _i64p, _vp]),
     "evs_cache_lookup_interact_c1c2": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _int, _vp]),
     "evs_cache_lookup_batch": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "evs_cache_lookup_interact": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp]),

@@ -885,6 +885,7 @@ struct BatchArgs {
     long long stage_rows;           // rows of `staging` / entries of new_keys (= B * T)
     int *slot_stage;                // hash slot -> index of the new key it holds in this batch
     int rebuild;                    // after this batch's close the host 1: rebuilds the hash (no tombstones remain), 2: sweeps it
+    unsigned long long *evicted_keys;   // (alt-key tier attached) the key each free-stack position held before K4 put it there; bit 63 = flushed, not evicted
     int tomb_parity;                // sampled update: parity of this batch (its tombstones are kTomb1 when odd); -1 otherwise
 };
 
@@ -1053,17 +1054,43 @@ __global__ void __launch_bounds__(256) cache_rows_from_ptrs_kernel(const long lo
     }
 }
 // ---- two-tier batched probe (see evs_cache_lookup_batch_c1c2) ----------------------------------------------
+// Batched form of the alt-key tier C3 (aprx_embedding.cpp: a map key -> {alt key, recency flag} with second-chance FIFO
+// eviction).  The alt key of a key is a pure function of the key (the alt-key tables), so what the tier holds is a SET
+// of keys with one flag each.  For the batched path the set is kSetWays-way set-associative: set = hash(key) % nset, one
+// 64-byte line of key words (bit 38 = the recency flag), second chance within the set (a newcomer takes an empty way,
+// else an unflagged one; when every way is flagged the flags are cleared and it takes the way its hash names).  No
+// global FIFO, no tombstones, every operation one line and one CAS -- the exact FIFO order lives in the batch-1
+// machine above (and is what tests/golden/aprx_ops.npz pins); the batched forms have no reference counterpart.
+constexpr int kSetWays = 8;
+constexpr unsigned long long kC3Flag = 1ull << kKeyBits;
+struct C3Batch {
+    unsigned long long *tags;   // nset x kSetWays key words; nullptr: no alt-key tier
+    long long nset;
+    long long *stat;            // [0] members, [1] alt hits served
+    const unsigned *alt_tables[kMaxTables];
+    long long alt_rows[kMaxTables];
+};
+__device__ __forceinline__ long long c3_find(const C3Batch &c3, unsigned long long key) {
+    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
+    long long found = -1;
+#pragma unroll
+    for (int w = 0; w < kSetWays; w++)
+        if ((c3.tags[base + w] & kKeyMask) == key) found = base + w;
+    return found;
+}
+
 struct TwoTierArgs {
     unsigned char *row_tier;   // (B,T): 1 = row in C1's codec, 2 = row in C2's codec, 0 = no row
-    unsigned char *tier_out;   // (B,T) user output: 1 = C1 hit, 2 = C2 hit, 0 = miss
+    unsigned char *tier_out;   // (B,T) user output: 1 = C1 hit, 2 = C2 hit, 3 = alt-key hit (the alt row is served), 0 = miss
     int threshold;             // high_agghit_threshold (evlfu_8.hpp:70)
+    C3Batch c3;
 };
 
 __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs a1, const BatchArgs a2, const TwoTierArgs tt) {
     __shared__ int s_d1[kMaxBuckets], s_d2[kMaxBuckets];
-    __shared__ int s_sum[3];   // C1 hits, C2 hits, perfect requests
+    __shared__ int s_sum[4];   // C1 hits, C2 hits, perfect requests, alt-key hits
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) { s_d1[i] = 0; s_d2[i] = 0; }
-    if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_sum[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
     const int T = a1.T;
@@ -1081,7 +1108,25 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         if (e1 == kPending) e1 = -1;
         int e2 = (ok && e1 < 0) ? probe_ro(a2.slots, a2.mask, key, end2) : -1;
         if (e2 == kPending) e2 = -1;
-        const unsigned long long hm = __ballot(e1 >= 0 || e2 >= 0);
+        // alt-key probe for a double miss (find_approximate_ev, evlfu_8.cpp:474-490): the key is in C3 and its alt row
+        // is resident in C1, else in C2 -> that row is served; the request's agg_hit counts it, nothing is inserted
+        int alt_tier = 0, ea = -1;
+        if (tt.c3.tags && ok && e1 < 0 && e2 < 0) {
+            const long long w3 = c3_find(tt.c3, key);
+            if (w3 >= 0) {
+                const unsigned alt = tt.c3.alt_tables[hl][row];
+                const unsigned at = alt % 100u, ar = alt / 100u;
+                if (at >= 1 && at <= (unsigned)T && (long long)ar < a1.backing_rows[at - 1] && (long long)ar < a2.backing_rows[at - 1]) {
+                    const unsigned long long akey = ((unsigned long long)at << 32) | ar;
+                    unsigned long long es;
+                    ea = probe_ro(a1.slots, a1.mask, akey, es);
+                    if (ea >= 0) alt_tier = 1;
+                    else { ea = probe_ro(a2.slots, a2.mask, akey, es); if (ea >= 0) alt_tier = 2; }
+                    if (alt_tier) atomicOr(&tt.c3.tags[w3], kC3Flag);   // set_recency_flag_c3
+                }
+            }
+        }
+        const unsigned long long hm = __ballot(e1 >= 0 || e2 >= 0 || alt_tier != 0);
         const int agg = __popc((unsigned)(half ? (hm >> 32) : hm));
         if (e1 >= 0 && a1.a.eagg[e1] < agg) {
             const int old = atomicMax(&a1.a.eagg[e1], agg);
@@ -1092,12 +1137,14 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
             if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
         }
         // evlfu_8.cpp:570-601: where a double miss goes
-        const bool miss = ok && e1 < 0 && e2 < 0;
+        const bool miss = ok && e1 < 0 && e2 < 0 && alt_tier == 0;
         const int dest = !c1_full ? 1 : (agg < tt.threshold ? ((hl & 1) ? 1 : 2) : 2);
         const unsigned char *src = nullptr;
         int codec_of = 0;
         if (e1 >= 0) { src = a1.a.arena + (long long)e1 * a1.row_bytes; codec_of = 1; }
         else if (e2 >= 0) { src = a2.a.arena + (long long)e2 * a2.row_bytes; codec_of = 2; }
+        else if (alt_tier == 1) { src = a1.a.arena + (long long)ea * a1.row_bytes; codec_of = 1; }   // the ALT row, at the precision of the tier holding it
+        else if (alt_tier == 2) { src = a2.a.arena + (long long)ea * a2.row_bytes; codec_of = 2; }
         else if (miss && dest == 1) { src = a1.backing[hl] + (long long)row * a1.row_bytes; codec_of = 1; }
         else if (miss) { src = a2.backing[hl] + (long long)row * a2.row_bytes; codec_of = 2; }
         if (key_on) {
@@ -1108,13 +1155,14 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
                               (unsigned)(end2 >> a2.hint_shift);
             a1.row_ptrs[m] = (long long)src;
             tt.row_tier[m] = (unsigned char)codec_of;
-            tt.tier_out[m] = e1 >= 0 ? 1 : (e2 >= 0 ? 2 : 0);
+            tt.tier_out[m] = e1 >= 0 ? 1 : (e2 >= 0 ? 2 : (alt_tier ? 3 : 0));
         }
-        const unsigned long long h1 = __ballot(e1 >= 0), h2 = __ballot(e2 >= 0);
+        const unsigned long long h1 = __ballot(e1 >= 0), h2 = __ballot(e2 >= 0), h3 = __ballot(alt_tier != 0);
         if (req_on && hl == 0) {
             atomicAdd(&s_sum[0], __popc((unsigned)(half ? (h1 >> 32) : h1)));
             atomicAdd(&s_sum[1], __popc((unsigned)(half ? (h2 >> 32) : h2)));
             if (agg == T) atomicAdd(&s_sum[2], 1);
+            if (h3) atomicAdd(&s_sum[3], __popc((unsigned)(half ? (h3 >> 32) : h3)));
         }
     }
     __syncthreads();
@@ -1125,6 +1173,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         if (v1) atomicAdd(&a1.part1[(blockIdx.x % kReplicas) * kPartCols + i], v1);
         if (v2) atomicAdd(&a2.part1[(blockIdx.x % kReplicas) * kPartCols + i], v2);
     }
+    if (threadIdx.x == 0 && tt.c3.tags && s_sum[3]) atomicAdd(reinterpret_cast<unsigned long long *>(&tt.c3.stat[1]), (unsigned long long)s_sum[3]);
 }
 
 // rows (B,T,d) fp32 from the pointer table, each row decoded with the codec of the tier that serves it
@@ -1419,6 +1468,7 @@ __global__ void __launch_bounds__(256) cache_batch_evict_kernel(const BatchArgs 
             const int e = ent[j];
             args.slots[sl[j]] = kTomb;
             n_tombs++;
+            if (args.evicted_keys) args.evicted_keys[pos] = (args.a.ekey[e] & kKeyMask) | (((fvict >> j) & 1) ? (1ull << 63) : 0ull);
             args.a.ekey[e] = kEmpty;
             atomicSub(&s_delta[prio[j]], 1);
             args.a.free_stack[pos++] = e;
@@ -1866,6 +1916,46 @@ __global__ void __launch_bounds__(256) cache_batch_sweep_kernel(BatchState *b, u
     if (threadIdx.x == 0 && s_freed) atomicSub(&b->n_tomb, s_freed);
 }
 
+// Alt-key tier, batched fill: the keys K4 EVICTED from this tier in this batch (not the flushed ones: evlfu_8.cpp:617-620,
+// 654-658 queue last_evicted only) become members of C3.  One thread per victim; positions [n_free, n_free + victims)
+// of the free stack are K4's (the state is the one K3 / K4 left: the close has not run yet).
+__global__ void __launch_bounds__(256) c3_batch_insert_kernel(const BatchArgs args, const C3Batch c3) {
+    const BatchState *b = args.bs;
+    const int n_vict = b->flush_t > 0 ? b->pos_ticket : (b->ticket < b->need ? b->ticket : b->need);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_vict) return;
+    const unsigned long long rec = args.evicted_keys[b->n_free + i];
+    if (rec >> 63) return;
+    const unsigned long long key = rec & kKeyMask;
+    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
+    for (int attempt = 0; attempt < 4; attempt++) {   // (a CAS lost to another newcomer of the same set: look again)
+        unsigned long long w[kSetWays];
+        int present = 0, empty = -1, plain = -1;
+#pragma unroll
+        for (int j = 0; j < kSetWays; j++) {
+            w[j] = atomicOr(&c3.tags[base + j], 0ull);
+            present |= (w[j] & kKeyMask) == key;
+            if (w[j] == 0ull && empty < 0) empty = j;
+            if (w[j] != 0ull && !(w[j] & kC3Flag) && plain < 0) plain = j;
+        }
+        if (present) return;
+        int way = empty >= 0 ? empty : plain;
+        if (way < 0) {   // every way has had its second chance now
+#pragma unroll
+            for (int j = 0; j < kSetWays; j++) atomicAnd(&c3.tags[base + j], ~kC3Flag);
+            way = (int)((key >> 3) % kSetWays);
+        }
+        unsigned long long expect = 0ull;
+#pragma unroll
+        for (int j = 0; j < kSetWays; j++) expect = j == way ? w[j] : expect;
+        if (empty < 0 && plain < 0) expect &= ~kC3Flag;
+        if (atomicCAS(&c3.tags[base + way], expect, key) == expect) {
+            if (expect == 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(&c3.stat[0]), 1ull);
+            return;
+        }
+    }
+}
+
 // Host-memory miss tier: after the fill (K5) every missed key that got an entry is served from its ARENA row, so
 // each missing row crosses the bus once (the de-duplicated fetch of K5) instead of once per request that asked
 // for it plus once for the fill.  One thread per (request, table) position; keys that found no room keep their
@@ -1919,7 +2009,17 @@ __global__ void __launch_bounds__(256) cache_batch_unstage_kernel(const BatchArg
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-struct evs_aprx;
+struct evs_aprx {
+    evs::AprxArrays x{};
+    long long nslot = 0, cap = 0;
+    int n_tables = 0;
+    bool has_alt = false;
+    // batched form: the set-associative key set (see C3Batch)
+    unsigned long long *tags = nullptr;
+    long long nset = 0;
+    long long *bstat = nullptr;   // device: [0] members, [1] alt hits served
+    int used = 0;                 // 0 fresh, 1 exact machine, 2 batched form
+};
 struct evs_cache {
     evs::CacheState host;      // configuration mirror
     evs::CacheState *st = nullptr;
@@ -1960,13 +2060,14 @@ struct evs_cache {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int fork_mode = -1;            // -1: not decided yet (EVS_CACHE_FORK, default off), 0 / 1
-    long long batch_calls = 0, last_sweep_call = -100, last_hk_call = 0;   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
+    long long batch_calls = 0, last_sweep_call = -100, last_hk_call = 0;
+    unsigned long long *evicted_keys = nullptr;   // batched three-tier lookup: what K4 evicted, for the alt-key tier   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
     int batch_policy = -1;         // policy update of the batched path: 0 plan-based (K2..K6), 1 sampled (one kernel); -1: EVS_CACHE_POLICY, default sampled
 };
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
-    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage};
+    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage, c->evicted_keys};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->host_tomb) (void)hipHostFree(c->host_tomb);
@@ -2291,6 +2392,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     // a few batches late is as good): past nslot / 8 the
     // table is swept (tombstones at the end of their chains become empty again); if the count is back there within
     // three calls the sweep did not help enough and the hash is rebuilt.
+    a.evicted_keys = nullptr;
     a.tomb_parity = -1;
     a.rebuild = 0;
     c->batch_calls++;   // = the ordinal of this call's close
@@ -2569,13 +2671,13 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
 // C1 not full: C1; C1 full and agg_hit < threshold: odd table index -> C1, even -> C2; else C2 -- served from the
 // destination tier's backing table at that tier's precision and inserted there once per batch (a key two requests
 // route differently goes to C1).  Each tier then runs the single-tier policy update (K2-K6) on its own misses.
-static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out, uint8_t *tier,
+static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows, float *out, uint8_t *tier,
                            int high_agghit_threshold, const float *x, int64_t x_stride, int itself, float *R, void *stream);
 
 extern "C" int evs_cache_lookup_batch_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
                                            uint8_t *tier, int high_agghit_threshold, void *stream) {
     EVS_REQUIRE(out || B == 0, "evs_cache_lookup_batch_c1c2: NULL out");
-    return batch_c1c2_impl(c1, c2, B, rows, out, tier, high_agghit_threshold, nullptr, 0, 0, nullptr, stream);
+    return batch_c1c2_impl(c1, c2, nullptr, B, rows, out, tier, high_agghit_threshold, nullptr, 0, 0, nullptr, stream);
 }
 
 // ... with the interaction as the consumer: R = interact_features(x, rows served by the two tiers), every row decoded
@@ -2585,10 +2687,50 @@ extern "C" int evs_cache_lookup_interact_c1c2(evs_cache *c1, evs_cache *c2, int6
                                               int high_agghit_threshold, void *stream) {
     EVS_REQUIRE((x && R) || B == 0, "evs_cache_lookup_interact_c1c2: NULL x / R");
     EVS_REQUIRE(x_stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0, "evs_cache_lookup_interact_c1c2: x must be 16-byte aligned, stride %% 4 == 0");
-    return batch_c1c2_impl(c1, c2, B, rows, nullptr, tier, high_agghit_threshold, x, x_stride, itself, R, stream);
+    return batch_c1c2_impl(c1, c2, nullptr, B, rows, nullptr, tier, high_agghit_threshold, x, x_stride, itself, R, stream);
 }
 
-static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out, uint8_t *tier,
+// ---- batched THREE-tier lookup: the two-tier snapshot lookup with the alt-key tier C3 (request_to_c1_c2_c3,
+// evlfu_8.cpp:492-667, as a throughput form; no reference counterpart).  A double miss whose key is a member of C3 and
+// whose alt row is resident in C1 (else C2) when the call starts is served that row (tier code 3), decoded at the
+// precision of the tier holding it; its recency flag is set, the request's agg_hit counts it, nothing is inserted for
+// it.  The keys this batch's policy update EVICTS from C1 / C2 become members of C3 (visible from the next batch on).
+extern "C" int evs_cache_lookup_batch_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows,
+                                             float *out, uint8_t *tier, int high_agghit_threshold, void *stream) {
+    EVS_REQUIRE(out || B == 0, "evs_cache_lookup_batch_c1c2c3: NULL out");
+    EVS_REQUIRE(c3, "evs_cache_lookup_batch_c1c2c3: NULL alt-key tier");
+    return batch_c1c2_impl(c1, c2, c3, B, rows, out, tier, high_agghit_threshold, nullptr, 0, 0, nullptr, stream);
+}
+extern "C" int evs_cache_lookup_interact_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows,
+                                                const float *x, int64_t x_stride, int itself, float *R, uint8_t *tier,
+                                                int high_agghit_threshold, void *stream) {
+    EVS_REQUIRE((x && R) || B == 0, "evs_cache_lookup_interact_c1c2c3: NULL x / R");
+    EVS_REQUIRE(c3, "evs_cache_lookup_interact_c1c2c3: NULL alt-key tier");
+    EVS_REQUIRE(x_stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0, "evs_cache_lookup_interact_c1c2c3: x must be 16-byte aligned, stride %% 4 == 0");
+    return batch_c1c2_impl(c1, c2, c3, B, rows, nullptr, tier, high_agghit_threshold, x, x_stride, itself, R, stream);
+}
+// out4 (host): [members, alt hits served, capacity of the sets, 0]; pairs (host, may be NULL): (table_1based, row, flag) triples
+extern "C" int64_t evs_aprx_batch_dump(evs_aprx *p, int64_t *triples, int64_t max_triples, int64_t *out4, void *stream) {
+    using namespace evs;
+    if (!p) { set_error("evs_aprx_batch_dump: NULL tier"); return EVS_EINVAL; }
+    if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return EVS_EHIP;
+    const long long n = p->nset * kSetWays;
+    std::vector<unsigned long long> tags(n);
+    long long st[2] = {0, 0};
+    if (hipMemcpy(tags.data(), p->tags, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+    if (hipMemcpy(st, p->bstat, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+    int64_t m = 0;
+    for (long long i = 0; i < n; i++) {
+        if (!tags[i]) continue;
+        const unsigned long long key = tags[i] & kKeyMask;
+        if (triples && m < max_triples) { triples[3 * m] = (int64_t)(key >> 32); triples[3 * m + 1] = (int64_t)(key & 0xffffffffull); triples[3 * m + 2] = (tags[i] & kC3Flag) ? 1 : 0; }
+        m++;
+    }
+    if (out4) { out4[0] = st[0]; out4[1] = st[1]; out4[2] = n; out4[3] = 0; }
+    return m;
+}
+
+static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows, float *out, uint8_t *tier,
                            int high_agghit_threshold, const float *x, int64_t x_stride, int itself, float *R, void *stream) {
     using namespace evs;
     if (B == 0) return EVS_OK;
@@ -2608,6 +2750,23 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, int64_t B, const int32_
     const int wide = kNumCu * 8;
     TwoTierArgs tt;
     tt.row_tier = c1->row_tier; tt.tier_out = tier; tt.threshold = high_agghit_threshold;
+    tt.c3.tags = nullptr; tt.c3.nset = 0; tt.c3.stat = nullptr;
+    for (int k = 0; k < kMaxTables; k++) { tt.c3.alt_tables[k] = nullptr; tt.c3.alt_rows[k] = 0; }
+    if (c3) {
+        EVS_REQUIRE(c3->n_tables == T, "evs_cache_lookup_batch_c1c2c3: the alt-key tier was made for %d tables", c3->n_tables);
+        if (!c3->has_alt) { set_error("evs_cache_lookup_batch_c1c2c3: call evs_aprx_set_altkeys first"); return EVS_ESTATE; }
+        if (c3->used == 1) { set_error("evs_cache_lookup_batch_c1c2c3: this alt-key tier is used through the exact path"); return EVS_ESTATE; }
+        c3->used = 2;
+        for (evs_cache *c : {c1, c2})
+            if (!c->evicted_keys) EVS_HIP_CHECK(hipMalloc(&c->evicted_keys, (long long)c->host.cap * 8));
+        a1.evicted_keys = c1->evicted_keys; a2.evicted_keys = c2->evicted_keys;
+        tt.c3.tags = c3->tags; tt.c3.nset = c3->nset; tt.c3.stat = c3->bstat;
+        for (int k = 0; k < T; k++) {
+            tt.c3.alt_tables[k] = c3->x.alt_tables[k]; tt.c3.alt_rows[k] = c3->x.alt_rows[k];
+            EVS_REQUIRE(c3->x.alt_rows[k] >= c1->backing_rows[k] && c3->x.alt_rows[k] >= c2->backing_rows[k],
+                        "evs_cache_lookup_batch_c1c2c3: alt-key table %d is shorter than the embedding table", k);
+        }
+    }
     hipLaunchKernelGGL(cache_batch_probe2_kernel, dim3((unsigned)a1.g1), dim3(256), 0, st, a1, a2, tt);
     if (out) {
         long long nb = (B * T * (long long)c1->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
@@ -2620,8 +2779,10 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, int64_t B, const int32_
         if (rc) return rc;
     }
     batch_policy(c1, a1, st);
+    if (c3) hipLaunchKernelGGL(c3_batch_insert_kernel, dim3((unsigned)a1.g2), dim3(256), 0, st, a1, tt.c3);   // what C1 evicted
     a2.other_slots = c1->bslots; a2.other_mask = (unsigned long long)(c1->bnslot - 1);   // a key C1 just took is not inserted in C2 too
     batch_policy(c2, a2, st);
+    if (c3) hipLaunchKernelGGL(c3_batch_insert_kernel, dim3((unsigned)a2.g2), dim3(256), 0, st, a2, tt.c3);   // what C2 evicted
     batch_close(c1, a1, st);
     batch_close(c2, a2, st);
     EVS_HIP_CHECK(hipGetLastError());
@@ -2682,16 +2843,9 @@ extern "C" int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t 
 }
 
 // ---- a12: alt-key tier object --------------------------------------------------------------------
-struct evs_aprx {
-    evs::AprxArrays x{};
-    long long nslot = 0, cap = 0;
-    int n_tables = 0;
-    bool has_alt = false;
-};
-
 extern "C" int evs_aprx_destroy(evs_aprx *p) {
     if (!p) return EVS_OK;
-    void *ptrs[] = {p->x.st, p->x.keys, p->x.slot_entry, p->x.ekey, p->x.ealt, p->x.eflag, p->x.free_stack, p->x.queue};
+    void *ptrs[] = {p->x.st, p->x.keys, p->x.slot_entry, p->x.ekey, p->x.ealt, p->x.eflag, p->x.free_stack, p->x.queue, p->tags, p->bstat};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
     return EVS_OK;
@@ -2724,7 +2878,12 @@ extern "C" int evs_aprx_create(evs_aprx **out, int64_t capacity, int n_tables) {
     EVS_ALLOC(p->x.eflag, capacity);
     EVS_ALLOC(p->x.free_stack, capacity * 4);
     EVS_ALLOC(p->x.queue, h.qcap * 8);
+    p->nset = capacity / kSetWays > 0 ? capacity / kSetWays : 1;   // the batched form's sets: at most `capacity` members
+    EVS_ALLOC(p->tags, p->nset * kSetWays * 8);
+    EVS_ALLOC(p->bstat, 2 * 8);
 #undef EVS_ALLOC
+    EVS_HIP_CHECK(hipMemset(p->tags, 0, p->nset * kSetWays * 8));
+    EVS_HIP_CHECK(hipMemset(p->bstat, 0, 2 * 8));
     EVS_HIP_CHECK(hipMemset(p->x.keys, 0, nslot * 8));
     std::vector<int> fs(capacity);
     for (int64_t i = 0; i < capacity; i++) fs[i] = (int)(capacity - 1 - i);
@@ -2790,6 +2949,10 @@ extern "C" int evs_cache_request_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *
                                         float *out, uint8_t *tier, int high_agghit_threshold, void *stream) {
     using namespace evs;
     EVS_REQUIRE(c1 && c2, "evs_cache_request_c1c2c3: NULL cache");
+    if (c3) {
+        if (c3->used == 2) { evs::set_error("evs_cache_request_c1c2c3: this alt-key tier is used through the batched path"); return EVS_ESTATE; }
+        c3->used = 1;
+    }
     EVS_REQUIRE(c1->host.policy == kEvLFU && c2->host.policy == kEvLFU, "evs_cache_request_c1c2c3: both tiers must be EvLFU");
     EVS_REQUIRE(c1->host.n_tables == c2->host.n_tables && c1->host.dim == c2->host.dim,
                 "evs_cache_request_c1c2c3: the tiers disagree on n_tables/dim");

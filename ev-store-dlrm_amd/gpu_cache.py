@@ -212,27 +212,41 @@ def request_c1c2(c1, c2, rows, threshold=23, out=None, tier=None):
     return tier, out
 
 
-def lookup_batch_c1c2(c1, c2, rows, threshold=23, out=None, tier=None):
+def lookup_batch_c1c2(c1, c2, rows, threshold=23, out=None, tier=None, c3=None):
     """Batched two-tier lookup with snapshot semantics (include/evstore_hip.h: evs_cache_lookup_batch_c1c2): the
-    throughput form of request_c1c2.  Returns (tier (B,T) uint8: 1 = C1 hit, 2 = C2 hit, 0 = miss; out (B,T,dim) fp32)."""
+    throughput form of request_c1c2.  Returns (tier (B,T) uint8: 1 = C1 hit, 2 = C2 hit, 0 = miss; out (B,T,dim) fp32).
+    c3 (GpuAltKeyTier): the three-tier form (evs_cache_lookup_batch_c1c2c3) -- tier code 3 = the alt row was served."""
     assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
     B = int(rows.shape[0])
     if out is None:
         out = torch.empty((B, c1.n_tables, c1.dim), dtype=torch.float32, device=c1.device)
     if tier is None:
         tier = torch.empty((B, c1.n_tables), dtype=torch.uint8, device=c1.device)
-    _lib.check(_lib.lib().evs_cache_lookup_batch_c1c2(c1._h, c2._h, B, rows.data_ptr(), out.data_ptr(), tier.data_ptr(),
-                                                      int(threshold), torch.cuda.current_stream(c1.device).cuda_stream))
+    st = torch.cuda.current_stream(c1.device).cuda_stream
+    if c3 is None:
+        _lib.check(_lib.lib().evs_cache_lookup_batch_c1c2(c1._h, c2._h, B, rows.data_ptr(), out.data_ptr(), tier.data_ptr(),
+                                                          int(threshold), st))
+    else:
+        _lib.check(_lib.lib().evs_cache_lookup_batch_c1c2c3(c1._h, c2._h, c3._h, B, rows.data_ptr(), out.data_ptr(),
+                                                            tier.data_ptr(), int(threshold), st))
     return tier, out
 
 
-def lookup_interact_c1c2(c1, c2, rows, x, threshold=23, itself=False, out=None, tier=None, fused=True):
+def lookup_batch_c1c2c3(c1, c2, c3, rows, threshold=23, out=None, tier=None):
+    return lookup_batch_c1c2(c1, c2, rows, threshold, out, tier, c3=c3)
+
+
+def lookup_interact_c1c2c3(c1, c2, c3, rows, x, threshold=23, itself=False, out=None, tier=None, fused=True):
+    return lookup_interact_c1c2(c1, c2, rows, x, threshold, itself, out, tier, fused, c3=c3)
+
+
+def lookup_interact_c1c2(c1, c2, rows, x, threshold=23, itself=False, out=None, tier=None, fused=True, c3=None):
     """The two-tier snapshot lookup with interact_features as its consumer -> (tier, R).  fused (default): every row is
     decoded from the precision of the tier that serves it inside the interaction kernel (evs_cache_lookup_interact_c1c2);
     fused=False: lookup_batch_c1c2 into fp32 (B,T,dim) rows (`out`), then the dense interaction over them."""
     if not fused or c1.dim not in (16, 32, 36):
         from .dlrm_ops import interact_features
-        tier, rows_fp32 = lookup_batch_c1c2(c1, c2, rows, threshold, out, tier)
+        tier, rows_fp32 = lookup_batch_c1c2(c1, c2, rows, threshold, out, tier, c3=c3)
         return tier, interact_features(x, list(rows_fp32.unbind(1)), "dot", itself)
     assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
     B = int(rows.shape[0])
@@ -242,9 +256,15 @@ def lookup_interact_c1c2(c1, c2, rows, x, threshold=23, itself=False, out=None, 
     if tier is None:
         tier = torch.empty((B, c1.n_tables), dtype=torch.uint8, device=c1.device)
     assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, c1.dim) and x.stride(1) == 1
-    _lib.check(_lib.lib().evs_cache_lookup_interact_c1c2(
-        c1._h, c2._h, B, rows.data_ptr(), x.data_ptr(), int(x.stride(0)) if B > 1 else c1.dim, int(bool(itself)),
-        R.data_ptr(), tier.data_ptr(), int(threshold), torch.cuda.current_stream(c1.device).cuda_stream))
+    xs = int(x.stride(0)) if B > 1 else c1.dim
+    st = torch.cuda.current_stream(c1.device).cuda_stream
+    if c3 is None:
+        _lib.check(_lib.lib().evs_cache_lookup_interact_c1c2(
+            c1._h, c2._h, B, rows.data_ptr(), x.data_ptr(), xs, int(bool(itself)), R.data_ptr(), tier.data_ptr(), int(threshold), st))
+    else:
+        _lib.check(_lib.lib().evs_cache_lookup_interact_c1c2c3(
+            c1._h, c2._h, c3._h, B, rows.data_ptr(), x.data_ptr(), xs, int(bool(itself)), R.data_ptr(), tier.data_ptr(),
+            int(threshold), st))
     return tier, R
 
 
@@ -277,6 +297,18 @@ class GpuAltKeyTier:
         s = (C.c_int64 * 4)()
         _lib.check(_lib.lib().evs_aprx_stats(self._h, s, torch.cuda.current_stream(self.device).cuda_stream))
         return dict(size=int(s[0]), n_hit=int(s[1]), n_pending=int(s[2]), error=int(s[3]))
+
+    def batch_dump(self):
+        """Batched form: (members as an (n,3) int64 array of (table_1based, row, recency flag), stats dict)."""
+        import numpy as np
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        o4 = (C.c_int64 * 4)()
+        n = _lib.lib().evs_aprx_batch_dump(self._h, None, 0, o4, st)
+        if n < 0:
+            _lib.check(int(n))
+        out = np.zeros((max(n, 1), 3), np.int64)
+        _lib.lib().evs_aprx_batch_dump(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), n, o4, st)
+        return out[:n], dict(members=int(o4[0]), n_hit=int(o4[1]), capacity=int(o4[2]))
 
     def apply_ops(self, ops):
         """APRX_EV's single-key methods in order: ops (n,3) int32 device tensor of (op, table_1based, row) with op 0

@@ -266,6 +266,24 @@ EVS_API int evs_cache_lookup_batch_c1c2(evs_cache *c1, evs_cache *c2, int64_t B,
 EVS_API int evs_cache_lookup_interact_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, const float *x,
                                            int64_t x_stride, int itself, float *R, uint8_t *tier,
                                            int high_agghit_threshold, void *stream);
+/* Batched THREE-tier lookup: the two calls above with the alt-key tier C3 (the throughput form of request_to_c1_c2_c3,
+ * evlfu_8.cpp:492-667; no reference counterpart).  A double miss whose key is a member of C3 and whose alt row is
+ * resident in C1 (else C2) when the call starts is served that row -- tier code 3, decoded at the precision of the
+ * tier holding it; its recency flag is set, the request's agg_hit counts it, nothing is inserted for it.  The keys
+ * this batch's policy update EVICTS (not flushes) from C1 / C2 become members of C3, visible from the next batch on.
+ * In this form C3 is an 8-way set-associative key set with second chance inside each set (the alt key of a key is a
+ * pure function of the key: the tier only has to remember WHICH keys it knows): one line and one CAS per operation,
+ * no global FIFO -- the exact FIFO order is the batch-1 machine's (evs_cache_request_c1c2c3, evs_aprx_apply_ops).
+ * A tier object is driven by one of the two forms, never both (EVS_ESTATE). */
+typedef struct evs_aprx evs_aprx;   /* (created with evs_aprx_create, below) */
+EVS_API int evs_cache_lookup_batch_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows,
+                                          float *out, uint8_t *tier, int high_agghit_threshold, void *stream);
+EVS_API int evs_cache_lookup_interact_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B, const int32_t *rows,
+                                             const float *x, int64_t x_stride, int itself, float *R, uint8_t *tier,
+                                             int high_agghit_threshold, void *stream);
+/* Members of the batched C3 as (table_1based, row, recency flag) triples (host; may be NULL), returns their number;
+ * out4 (host, may be NULL): [members counted on insert, alt hits served, capacity of the sets, 0].  Synchronises. */
+EVS_API int64_t evs_aprx_batch_dump(evs_aprx *p, int64_t *triples, int64_t max_triples, int64_t *out4, void *stream);
 /* The same lookup feeding the interaction directly: R = interact_features(x, [rows of the 26 keys])
  * (B, d + F(F-1)/2) without materialising the rows -- the probe writes a table of row addresses
  * (arena row for a hit, backing row for a miss) that the fused MFMA kernel consumes.  fp32 caches,

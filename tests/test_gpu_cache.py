@@ -740,3 +740,90 @@ def test_zz_cpp_socket_client_mirror(E, orc, tmp_path):
     assert int(cli.cache_manager_cpp.evs_manager_perfect_hit()) == perfect
     cli.print_n_reset_perfect_hit()
     assert int(cli.cache_manager_cpp.evs_manager_perfect_hit()) == 0
+
+
+@pytest.mark.parametrize("codecs,d", [((8, 4), 36), ((32, 8), 16)])
+def test_batched_three_tier_c1c2c3(E, orc, codecs, d):
+    """f2 / configs[4]: the batched three-tier lookup (evs_cache_lookup_batch_c1c2c3 / _interact_c1c2c3), snapshot
+    semantics.  Tier codes against the state before the call: 1 / 2 = resident in C1 / C2; 3 = a double miss whose key is
+    a member of C3 and whose ALT row is resident in C1 (else C2) -- that row is served, at the precision of the tier
+    holding it; 0 = miss, routed by the reference's rule with the alt hits counted in agg_hit.  C3 fills with keys the
+    batch's policy update removed from C1 / C2, never beyond its capacity; recency flags only on keys that were served
+    through their alt key.  The tables hold values every codec represents exactly (-1, 0, 1), so a row decoded with the
+    wrong tier's codec or row size cannot come out right."""
+    from evstore_dlrm_amd import gpu_cache
+    rs = np.random.RandomState(41)
+    T, n, thr = 26, 300, 23
+    ws = [rs.randint(-1, 2, size=(n, d)).astype(np.float32) for _ in range(T)]
+    raws = {c: [orc.encode_table(w, c) for w in ws] for c in codecs}
+    for c in codecs:
+        assert all(np.array_equal(orc.decode(raws[c][k], c, d), ws[k]) for k in range(T))
+    # alt key of (table t, row r): the hot row r % 8 of table (t + 1) % T  (alt_row * 100 + alt_table_1based)
+    alt = [np.array([(r % 8) * 100 + ((t + 1) % T + 1) for r in range(n)], dtype=np.uint32) for t in range(T)]
+    cap1, cap2, cap3 = 400, 700, 800
+    c1 = E.GpuCache("evlfu", cap1, T, d, codecs[0], "cpp")
+    c2 = E.GpuCache("evlfu", cap2, T, d, codecs[1], "cpp")
+    c1.set_backing([torch.from_numpy(a).cuda() for a in raws[codecs[0]]])
+    c2.set_backing([torch.from_numpy(a).cuda() for a in raws[codecs[1]]])
+    c3 = E.GpuAltKeyTier(cap3, [torch.from_numpy(a.view(np.int32)).cuda() for a in alt])
+    B = 250
+    R1, R2, M3 = {}, {}, set()
+    ever_alt, removed, n3_total = set(), set(), 0
+    saw = set()
+    for it in range(14):
+        hot = rs.rand(B, T) < 0.6
+        rq = np.where(hot, rs.randint(0, 8, size=(B, T)), rs.randint(0, n, size=(B, T))).astype(np.int32)
+        r = torch.from_numpy(rq).cuda()
+        if it % 3 == 2:   # the interaction form: R over the rows the tier codes say were served
+            x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+            tier, Rm = gpu_cache.lookup_interact_c1c2c3(c1, c2, c3, r, x, threshold=thr, itself=bool(it & 1))
+            out = None
+        else:
+            tier, out = gpu_cache.lookup_batch_c1c2c3(c1, c2, c3, r, threshold=thr)
+            out = out.cpu().numpy()
+        tier = tier.cpu().numpy()
+        c1_full = len(R1) >= cap1
+        served = np.empty((B, T, d), np.float32)
+        for b in range(B):
+            in1 = np.array([(k + 1, int(rq[b, k])) in R1 for k in range(T)])
+            in2 = np.array([(k + 1, int(rq[b, k])) in R2 for k in range(T)]) & ~in1
+            in3 = np.zeros(T, bool)
+            for k in range(T):
+                key = (k + 1, int(rq[b, k]))
+                if not in1[k] and not in2[k] and key in M3:
+                    a = int(alt[k][rq[b, k]])
+                    akey = (a % 100, a // 100)
+                    in3[k] = akey in R1 or akey in R2
+            want_tier = np.where(in1, 1, np.where(in2, 2, np.where(in3, 3, 0)))
+            assert np.array_equal(tier[b], want_tier), (it, b)
+            for k in range(T):
+                if in3[k]:
+                    a = int(alt[k][rq[b, k]])
+                    served[b, k] = ws[a % 100 - 1][a // 100]
+                    ever_alt.add((k + 1, int(rq[b, k])))
+                else:
+                    served[b, k] = ws[k][rq[b, k]]
+            n3_total += int(in3.sum())
+        if out is not None:
+            assert np.array_equal(out, served), it
+        else:
+            want = orc.interact_features(x.cpu().numpy(), [served[:, k, :] for k in range(T)], bool(it & 1))
+            np.testing.assert_allclose(Rm.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+        saw |= set(np.unique(tier).tolist())
+        d1, d2 = c1.batch_dump(), c2.batch_dump()
+        n1 = {(int(t), int(rw)) for _, t, rw in d1}
+        n2 = {(int(t), int(rw)) for _, t, rw in d2}
+        assert len(n1) == len(d1) <= cap1 and len(n2) == len(d2) <= cap2 and not (n1 & n2)
+        removed |= (set(R1) - n1) | (set(R2) - n2)
+        m3, st3 = c3.batch_dump()
+        members = {(int(t), int(rw)) for t, rw, _ in m3}
+        assert len(members) == len(m3) == st3["members"] <= st3["capacity"] <= cap3
+        assert members <= removed, "C3 holds only keys the tiers gave up"
+        assert {(int(t), int(rw)) for t, rw, f in m3 if f} <= ever_alt, "a recency flag means the key was served through its alt key"
+        assert st3["n_hit"] == n3_total
+        R1, R2, M3 = {k: 1 for k in n1}, {k: 1 for k in n2}, members
+    assert saw == {0, 1, 2, 3} and len(M3) > 0
+    # the two forms of the tier do not mix
+    with pytest.raises(E.EvsError):
+        gpu_cache.request_c1c2c3(E.GpuCache("evlfu", 50, T, d, codecs[0], "cpp"), E.GpuCache("evlfu", 50, T, d, codecs[1], "cpp"), c3,
+                                 torch.zeros((1, T), dtype=torch.int32, device="cuda"))

@@ -35,3 +35,21 @@ for fused in (False, True):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("two-tier batched + interaction (%s): %.1f us per batch, %.2f G lookups/s"
           % ("mixed-codec consumer" if fused else "fp32 rows, then dense interaction", dt / 20 * 1e6, T * B * 20 / dt / 1e9))
+# three tiers (configs[4]): the same two tiers + the alt-key tier C3 (alt key of (t, r): row r % 4096 of the same table,
+# so alt rows are hot rows and likely resident)
+import numpy as np
+alt = [torch.from_numpy(((np.arange(n, dtype=np.int64) % min(n, 4096)) * 100 + (t + 1)).astype(np.uint32).view(np.int32)).to(dev)
+       for t, n in enumerate(ln)]
+c3 = E.GpuAltKeyTier(int(0.04 * budget) * 8 + 64, alt, dev)
+bs3 = bench.make_batches(ln, B, 70, seed=23, device=dev, dist="zipf", alpha=0.75)
+rq3 = [b[1].t().contiguous().to(torch.int32) for b in bs3]
+for r in rq3[:30]:
+    gpu_cache.lookup_interact_c1c2c3(c1, c2, c3, r, x, tier=tier)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n3 = 0
+for r in rq3[30:70]:
+    gpu_cache.lookup_interact_c1c2c3(c1, c2, c3, r, x, tier=tier)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+m3, st3 = c3.batch_dump()
+print("three-tier batched + interaction (mixed-codec consumer): %.1f us per batch, %.2f G lookups/s; C3 %d members of %d, %d alt hits served"
+      % (dt / 40 * 1e6, T * B * 40 / dt / 1e9, st3["members"], st3["capacity"], st3["n_hit"]))
