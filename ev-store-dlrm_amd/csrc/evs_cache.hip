@@ -869,7 +869,8 @@ struct BatchArgs {
     int *part1, *part2;                            // replica rows of K1 / K5 totals (kReplicas x kPartCols each)
     int *host_tomb;                                // mapped host word: tombstone count after this batch
     int g1, g2;
-    long long *row_ptrs;                           // (T,B) address of each key's row (arena / backing / 0)
+    long long *row_ptrs;                           // (B,T) address of each key's row (arena / backing / 0)
+    int *row_ids;                                  // (B,T), instead of row_ptrs when the rows-in-registers consumer follows: bit 30 = arena entry, else the table row, -1 = none
     const unsigned char *backing[kMaxTables];
     long long backing_rows[kMaxTables];
     const int *requests; float *out; unsigned char *hit;
@@ -1013,7 +1014,8 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
             const unsigned info = ((ok && e < 0) ? 0x80000000u : 0u) | ((e >= 0 || (ok && hint_tomb)) ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
                                   (unsigned)(end_slot >> args.hint_shift);
             args.miss_info[req * T + hl] = info;
-            args.row_ptrs[req * T + hl] = (long long)src;
+            if (args.row_ids) args.row_ids[req * T + hl] = e >= 0 ? (int)(0x40000000u | (unsigned)e) : (ok ? row : -1);
+            else args.row_ptrs[req * T + hl] = (long long)src;
         }
         if (req_on && hl == 0) { atomicAdd(&s_sum[0], agg); if (agg == T) atomicAdd(&s_sum[1], 1); }
     }
@@ -2376,7 +2378,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     a.miss_info = c->miss_info; a.new_slot = c->new_slot;
     a.hint_shift = 0;
     while ((c->bnslot >> a.hint_shift) > (1ll << 24)) a.hint_shift++;
-    a.row_ptrs = c->row_ptrs;
+    a.row_ptrs = c->row_ptrs; a.row_ids = nullptr;
     for (int k = 0; k < kMaxTables; k++) { a.backing[k] = c->backing[k]; a.backing_rows[k] = c->backing_rows[k]; }
     a.requests = rows; a.out = nullptr; a.hit = nullptr; a.B = B; a.mask = (unsigned long long)(c->bnslot - 1);
     a.cap = (int)cap; a.T = T; a.d = c->host.dim; a.codec = c->host.codec; a.row_bytes = c->host.row_bytes;
@@ -2546,12 +2548,23 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
                                    (const unsigned char *)nullptr, out, (long long)B, T, c->host.dim, c->host.codec, c->host.codec);
         }
         if (R) {
-            const int rc = fused_interact_from_row_ptrs(B, T, c->host.dim, x, x_stride, (const int64_t *)c->row_ptrs,
-                                                        (const int64_t *)c->iota, itself, R, st);
+            const int rc = a.row_ids
+                ? fused_interact_from_row_ids(B, T, c->host.dim, x, x_stride, a.row_ids, c->a.arena,
+                                              reinterpret_cast<const void *const *>(c->backing), itself, R, st)
+                : fused_interact_from_row_ptrs(B, T, c->host.dim, x, x_stride, (const int64_t *)c->row_ptrs,
+                                               (const int64_t *)c->iota, itself, R, st);
             if (rc) return rc;
         }
         return EVS_OK;
     };
+    // The interaction alone as the consumer, tables in HBM, a shape the rows-in-registers kernel takes: K1 writes 4-byte
+    // row ids (arena entry / table row) instead of 8-byte addresses and that kernel reads them (22.9 -> ~20 us at
+    // B = 16 384).  The 8-byte address table is the (B,T) int64 buffer either way: the ids use its first half.
+    if (R && !out && !host_tier && !(c->ft && c->staged_mask) && c->host.codec == 32 && fused_row_ids_supported(B, T, c->host.dim)) {
+        bool small = true;
+        for (int k = 0; k < T; k++) small = small && c->backing_rows[k] < (1ll << 30);
+        if (small) a.row_ids = reinterpret_cast<int *>(c->row_ptrs);
+    }
     if (R) EVS_REQUIRE(c->host.codec == 32 && evs_fused_dim_supported(c->host.dim) && T + 1 <= EVS_MAX_FEATURES,
                        "evs_cache_lookup_interact: needs an fp32 cache, a fused-kernel dimension and T <= 31");
     // consumers of the snapshot read the rows BEFORE the policy kernels move anything

@@ -134,6 +134,12 @@ __device__ __forceinline__ XcdRange xcd_range(int64_t n_items, int units_per_blo
 int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_t x_stride, const int64_t *row_ptrs,
                                  const int64_t *iota, int itself, float *R, hipStream_t st);
 
+// evs_fused.hip / evs_fused_rf.hip: the same over ONE (B,T) table of 32-bit row ids -- bit 30 set: row (id & 0x3fffffff)
+// of `arena`, clear: row id of table k, -1: the zero row (fp32 rows; is there a kernel: fused_row_ids_supported)
+bool fused_row_ids_supported(int64_t B, int T, int d);
+int fused_interact_from_row_ids(int64_t B, int T, int d, const float *x, int64_t x_stride, const int *row_ids,
+                                const void *arena, const void *const *tables, int itself, float *R, hipStream_t st);
+
 // evs_mixed.hip: interaction over x + T rows given as (address, codec class) pairs, decoded on the fly
 int interact_from_mixed_rows(long long B, int T, int d, const float *x, long long x_stride, const long long *row_ptrs,
                              const unsigned char *row_class, int codec1, int codec2, int itself, float *R, hipStream_t st);

@@ -32,6 +32,10 @@ struct FusedArgs {
     const float *b1;           // n1 biases
     float *z1;                 // (B, n1) out
     int n1, kp, relu, write_r; // write_r: also store R (B, d + P)
+    // cache consumer (evs_fused_rf.hip, IDS variant): features 1..F-1 are given as ONE (B, F-1) int32 table of row ids --
+    // bit 30 set: row (id & 0x3fffffff) of `arena`; clear: row id of the feature's own table src[f]; -1: the zero row
+    const int *row_ids;
+    const void *arena;
 };
 
 
@@ -42,5 +46,9 @@ constexpr int kTileMaxF = 28;   // index-tile launches: x + at most 27 tables
 bool launch_rf(const FusedArgs &a, hipStream_t st);
 // the same kernel with the first top-MLP layer behind it (any batch size); false = no kernel for the shape
 bool launch_rf_mlp(const FusedArgs &a, hipStream_t st);
+// the same kernel reading a (B, F-1) table of 32-bit row ids (the cache tier's consumer); rf_ids_supported: is there a
+// kernel for this shape (the probe kernel has to know which table to write before the consumer is launched)
+bool rf_ids_supported(int64_t B, int F, int d);
+bool launch_rf_ids(const FusedArgs &a, hipStream_t st);
 
 }  // namespace evs

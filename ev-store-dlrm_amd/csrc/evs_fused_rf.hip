@@ -53,7 +53,10 @@ typedef const __attribute__((address_space(1))) f32x4 *gf4_t;
 // written only when asked for.
 constexpr int kMlpRowStride = 452;   // floats per staged row: kp <= 448 (F <= 28, d <= 36, diagonal kept) + 4 (bank spread)
 
-template <int CQ, int REM, int NT, int D, bool MLP = false>
+// IDS: the cache tier's consumer -- features 1..F-1 come as one (B, F-1) int32 table of row ids (FusedArgs::row_ids): bit 30
+// says "row of the cache arena", else the row of the feature's own table; 4 bytes per key instead of an 8-byte address,
+// and the rows travel exactly as in the plain launch.
+template <int CQ, int REM, int NT, int D, bool MLP = false, bool IDS = false>
 __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_kernel(const FusedArgs args) {
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
@@ -101,11 +104,12 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     if (threadIdx.x < 32) {
         const int f = (int)threadIdx.x;
         const int64_t *ip = f < F ? ka->indices[f] : nullptr;
+        const bool table = IDS ? (f >= 1 && f < F) : ip != nullptr;
         s_tile_p[f] = ip;
         s_tile_nr[f] = f < F ? (unsigned)ka->n_rows[f] : 0u;
-        s_tile_kind[f] = f >= F ? 0 : (ip ? 2 : 1);
+        s_tile_kind[f] = f >= F ? 0 : (table ? 2 : 1);
         s_feat_base[f] = f < F ? (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]) : 0ull;
-        s_feat_scale[f] = f >= F ? 0u : (ip ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4));
+        s_feat_scale[f] = f >= F ? 0u : (table ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4));
     }
     __syncthreads();
 
@@ -156,9 +160,14 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
             const bool table = s_tile_kind[f] == 2 && bs < blk_end;
-            const int64_t *ap = table ? s_tile_p[f] + bs : dummy_i;
-            // (explicitly global: a flat load would force every later wait to vmcnt(0))
-            tile_v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(ap));
+            if constexpr (IDS) {
+                const int *ap = table ? args.row_ids + bs * (int64_t)(F - 1) + (f - 1) : reinterpret_cast<const int *>(dummy_i);
+                tile_v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(ap));
+            } else {
+                const int64_t *ap = table ? s_tile_p[f] + bs : dummy_i;
+                // (explicitly global: a flat load would force every later wait to vmcnt(0))
+                tile_v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(ap));
+            }
         }
     };
     auto tile_store = [&](int c) {      // registers -> tile buffer c & 1
@@ -169,7 +178,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             const int kind = s_tile_kind[f];
             const bool live = kind != 0 && bs < blk_end && c >= 0;
             const int64_t v = kind == 2 ? tile_v[h] : bs;       // dense features (x, received pooled vectors): the sample number
-            const bool in_range = kind == 1 || (uint64_t)v < (uint64_t)s_tile_nr[f];
+            const bool in_range = kind == 1 || (IDS ? v >= 0 : (uint64_t)v < (uint64_t)s_tile_nr[f]);   // (IDS: the probe kernel checked the row ids)
             bad |= live & !in_range;
             s_idx[(c & 1) * 512 + (int)threadIdx.x + 256 * h] = (live & in_range) ? (int)v : -1;
         }
@@ -188,7 +197,14 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             // branch-free on purpose (bit blend, not a select: the compiler turns a select over these LDS reads into
             // control flow and serialises the four loads): -1 -> the zero page
             const unsigned neg = (unsigned)(iv >> 31) | phantom;
-            const unsigned long long p = s_feat_base[r] + (unsigned long long)((unsigned)iv & ~neg) * (unsigned long long)s_feat_scale[r] + dma_piece16;
+            unsigned long long base = s_feat_base[r];
+            unsigned idx = (unsigned)iv & ~neg;
+            if constexpr (IDS) {   // bit 30: a row of the cache arena (bit blend, as below: no select over LDS reads)
+                const unsigned long long in_arena = 0ull - (unsigned long long)((idx >> 30) & 1u);
+                base ^= (base ^ (unsigned long long)reinterpret_cast<uintptr_t>(args.arena)) & in_arena;
+                idx &= 0x3fffffffu;
+            }
+            const unsigned long long p = base + (unsigned long long)idx * (unsigned long long)s_feat_scale[r] + dma_piece16;
             const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
             const unsigned long long pa = p ^ ((p ^ (unsigned long long)reinterpret_cast<uintptr_t>(zeros_l)) & m64);
             slot[j] = *reinterpret_cast<gf4_t>((uintptr_t)pa);
@@ -376,6 +392,25 @@ bool launch_rf_mlp(const FusedArgs &a, hipStream_t st) {
         return true;
     default:
         return false;
+    }
+}
+
+bool rf_ids_supported(int64_t B, int F, int d) {
+    return rf_mode() && F <= kTileMaxF && B <= rf_max_batch() && (d == 16 || d == 32 || d == 36);
+}
+bool launch_rf_ids(const FusedArgs &a, hipStream_t st) {
+    if (!rf_ids_supported(a.B, a.F, a.d) || !a.row_ids || !a.arena) return false;
+    const bool nt2 = a.F > 16;
+    switch (a.d) {
+    case 16:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<1, 0, 2, EVS_RF_DEPTH, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<1, 0, 1, EVS_RF_DEPTH, false, true>>(a, st);
+        return true;
+    case 32:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 0, 2, EVS_RF_DEPTH, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 0, 1, EVS_RF_DEPTH, false, true>>(a, st);
+        return true;
+    default:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 1, 2, EVS_RF_DEPTH, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 1, 1, EVS_RF_DEPTH, false, true>>(a, st);
+        return true;
     }
 }
 
