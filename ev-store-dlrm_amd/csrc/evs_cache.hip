@@ -886,6 +886,10 @@ struct BatchArgs {
     long long stage_rows;           // rows of `staging` / entries of new_keys (= B * T)
     int *slot_stage;                // hash slot -> index of the new key it holds in this batch
     int rebuild;                    // after this batch's close the host 1: rebuilds the hash (no tombstones remain), 2: sweeps it
+    // sampled update, tables in HBM: K1 block j lists its misses itself (records of 16 bytes: row, table | agg << 8 | hint
+    // kind << 16, hinted slot, request position) at miss_rec + j * list_cap, their number in list_cnt[j]; the update
+    // kernel runs one wave per list instead of one thread per (request, table) position
+    uint4 *miss_rec; int *list_cnt; int list_cap;
     unsigned long long *evicted_keys;   // (alt-key tier attached) the key each free-stack position held before K4 put it there; bit 63 = flushed, not evicted
     int tomb_parity;                // sampled update: parity of this batch (its tombstones are kTomb1 when odd); -1 otherwise
 };
@@ -978,8 +982,10 @@ constexpr int kProbeGridMax = 8192;   // one request pair per wave up to B = 65 
 __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_sum[2];   // hits / perfect requests of this block
+    __shared__ int s_list_n;   // list mode: misses this block has listed so far
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
     if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_list_n = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
     const int T = args.T;
@@ -1013,9 +1019,24 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
             // bit 30: hit -- or, for a miss (bit 31), "the hinted slot is a tombstone" (what the insert's first CAS expects)
             const unsigned info = ((ok && e < 0) ? 0x80000000u : 0u) | ((e >= 0 || (ok && hint_tomb)) ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
                                   (unsigned)(end_slot >> args.hint_shift);
-            args.miss_info[req * T + hl] = info;
+            if (!args.miss_rec) args.miss_info[req * T + hl] = info;
+            else if (args.hit) args.hit[req * T + hl] = e >= 0;
             if (args.row_ids) args.row_ids[req * T + hl] = e >= 0 ? (int)(0x40000000u | (unsigned)e) : (ok ? row : -1);
             else args.row_ptrs[req * T + hl] = (long long)src;
+        }
+        if (args.miss_rec) {   // list mode: the half-wave's misses, packed, behind the block's earlier ones
+            const bool is_miss = ok && e < 0;
+            const unsigned long long mm = __ballot(is_miss);
+            const unsigned mh = (unsigned)(half ? (mm >> 32) : mm);
+            int base = 0;
+            if (hl == 0 && mh) base = atomicAdd(&s_list_n, __popc(mh));
+            base = __shfl(base, half * 32, 64);
+            if (is_miss) {
+                const int at = base + __popc(mh & ((1u << hl) - 1u));
+                args.miss_rec[(long long)blockIdx.x * args.list_cap + at] =
+                    make_uint4((unsigned)row, (unsigned)hl | ((unsigned)agg << 8) | (hint_tomb ? 0x10000u : 0u),
+                               (unsigned)(end_slot >> args.hint_shift), (unsigned)(req * T + hl));
+            }
         }
         if (req_on && hl == 0) { atomicAdd(&s_sum[0], agg); if (agg == T) atomicAdd(&s_sum[1], 1); }
     }
@@ -1025,6 +1046,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         const int v = i <= T ? s_delta[i] : i == 38 ? s_sum[0] : i == 39 ? s_sum[1] : 0;
         if (v) atomicAdd(&args.part1[(blockIdx.x % kReplicas) * kPartCols + i], v);
     }
+    if (args.miss_rec && threadIdx.x == 0) args.list_cnt[blockIdx.x] = s_list_n;
 }
 
 // rows (B,T,d) fp32 from the pointer table (only when the caller wants the pooled rows themselves)
@@ -1681,49 +1703,9 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
 
 // One thread copies one row.  All loads first: a load / store pair per 16 bytes is one dependent round trip each (the
 // compiler cannot prove the two rows apart) and cost 11 us of the update kernel; fixed piece counts keep the pieces in
-// registers (a runtime-indexed array, or a switch over the sizes inside one kernel, went to scratch / LDS: 32 -> 43-52 us),
-// so the update kernel is compiled per row size.
-template <int N>
-__device__ __forceinline__ void copy_row_pieces(const unsigned char *src, unsigned char *dst) {
-    // named scalars, not an array: hipcc 7.2 kept a float4[N] here in scratch (or promoted it to LDS) although every index
-    // is a constant after unrolling
-    const float4 *p = reinterpret_cast<const float4 *>(src);
-    float4 *q = reinterpret_cast<float4 *>(dst);
-    float4 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15;
-    if constexpr (N > 0) a0 = p[0];
-    if constexpr (N > 1) a1 = p[1];
-    if constexpr (N > 2) a2 = p[2];
-    if constexpr (N > 3) a3 = p[3];
-    if constexpr (N > 4) a4 = p[4];
-    if constexpr (N > 5) a5 = p[5];
-    if constexpr (N > 6) a6 = p[6];
-    if constexpr (N > 7) a7 = p[7];
-    if constexpr (N > 8) a8 = p[8];
-    if constexpr (N > 9) a9 = p[9];
-    if constexpr (N > 10) a10 = p[10];
-    if constexpr (N > 11) a11 = p[11];
-    if constexpr (N > 12) a12 = p[12];
-    if constexpr (N > 13) a13 = p[13];
-    if constexpr (N > 14) a14 = p[14];
-    if constexpr (N > 15) a15 = p[15];
-    if constexpr (N > 0) q[0] = a0;
-    if constexpr (N > 1) q[1] = a1;
-    if constexpr (N > 2) q[2] = a2;
-    if constexpr (N > 3) q[3] = a3;
-    if constexpr (N > 4) q[4] = a4;
-    if constexpr (N > 5) q[5] = a5;
-    if constexpr (N > 6) q[6] = a6;
-    if constexpr (N > 7) q[7] = a7;
-    if constexpr (N > 8) q[8] = a8;
-    if constexpr (N > 9) q[9] = a9;
-    if constexpr (N > 10) q[10] = a10;
-    if constexpr (N > 11) q[11] = a11;
-    if constexpr (N > 12) q[12] = a12;
-    if constexpr (N > 13) q[13] = a13;
-    if constexpr (N > 14) q[14] = a14;
-    if constexpr (N > 15) q[15] = a15;
-}
-
+// registers (a runtime-indexed array, a switch over the sizes inside one kernel, a float4[N] with constant indices and a
+// struct of named float4 members all went to scratch or were promoted to LDS under hipcc 7.2: 32 -> 43-52 us), so the
+// update kernel is compiled per row size and the pieces are plain local variables.
 // replica columns of part2 in this mode: 0..32 histogram deltas, 33 count delta (entries taken from the free ones minus
 // victims given back), 34 evictions, 35 tombstone delta (evicted - recycled)
 //
@@ -1733,6 +1715,104 @@ __device__ __forceinline__ void copy_row_pieces(const unsigned char *src, unsign
 // batch -- those are few: hot keys are hits).  That keeps the dependent chain at four round trips -- request + probe
 // record, victim group (with the source row), CAS on the entry, CAS on the slot -- instead of six with a pending word
 // that is finalised later.
+// one missed key of the batch: victim, row, key word, hash slot (see the comment above); m = its position in the batch
+template <int PIECES>
+__device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t, unsigned row, int agg, unsigned hint_slot, bool hint_tomb,
+                                                   long long m, int *s_delta, int *s_stat) {
+    const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
+    const unsigned long long old_tomb = args.tomb_parity ? kTomb : kTomb1;
+    // The victim group depends on the key, the batch and the POSITION in the batch: copies of one missing key must
+    // not all start on the same 8 entries (16 384 copies of a hot key in a cold cache walked the arena group by
+    // group behind each other: a 23 ms launch).
+    const long long n_groups = ((long long)args.cap + kSampleGroup - 1) / kSampleGroup;
+    long long g = (long long)(mix64(key ^ ((unsigned long long)(unsigned)args.stamp * 0x9e3779b97f4a7c15ull) ^ ((unsigned long long)m << 40)) % (unsigned long long)n_groups);
+    SampleWindow win;
+    sampled_load(args, g * kSampleGroup, win);
+    // the source row travels with the victim group (same round trip)
+    const unsigned char *srow = args.backing[t] + (long long)row * args.row_bytes;
+    float4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
+    if constexpr (PIECES > 0) r0 = reinterpret_cast<const float4 *>(srow)[0];
+    if constexpr (PIECES > 1) r1 = reinterpret_cast<const float4 *>(srow)[1];
+    if constexpr (PIECES > 2) r2 = reinterpret_cast<const float4 *>(srow)[2];
+    if constexpr (PIECES > 3) r3 = reinterpret_cast<const float4 *>(srow)[3];
+    if constexpr (PIECES > 4) r4 = reinterpret_cast<const float4 *>(srow)[4];
+    if constexpr (PIECES > 5) r5 = reinterpret_cast<const float4 *>(srow)[5];
+    if constexpr (PIECES > 6) r6 = reinterpret_cast<const float4 *>(srow)[6];
+    if constexpr (PIECES > 7) r7 = reinterpret_cast<const float4 *>(srow)[7];
+    if constexpr (PIECES > 8) r8 = reinterpret_cast<const float4 *>(srow)[8];
+    if constexpr (PIECES > 9) r9 = reinterpret_cast<const float4 *>(srow)[9];
+    if constexpr (PIECES > 10) r10 = reinterpret_cast<const float4 *>(srow)[10];
+    if constexpr (PIECES > 11) r11 = reinterpret_cast<const float4 *>(srow)[11];
+    if constexpr (PIECES > 12) r12 = reinterpret_cast<const float4 *>(srow)[12];
+    if constexpr (PIECES > 13) r13 = reinterpret_cast<const float4 *>(srow)[13];
+    if constexpr (PIECES > 14) r14 = reinterpret_cast<const float4 *>(srow)[14];
+    if constexpr (PIECES > 15) r15 = reinterpret_cast<const float4 *>(srow)[15];
+    // a look at the hinted slot (same round trip): if another copy of the key is already in, there is nothing to do
+    const unsigned long long hint = args.hint_shift == 0 ? (unsigned long long)hint_slot : (mix64(key) & args.mask);
+    const bool already = (args.slots[hint] & kKeyMask) == key;
+    int old_prio = -1, e = -1;
+    for (long long tries = 0; tries < n_groups && e < 0 && !already; tries++) {
+        if (tries) sampled_load(args, g * kSampleGroup, win);
+        e = sampled_take(args, g * kSampleGroup, win, old_prio);
+        g = g + 1 == n_groups ? 0 : g + 1;
+    }
+    if (e >= 0) {   // (else: nothing claimable anywhere -- a cache smaller than the batch's keys: the key is not kept)
+        if (old_prio >= 0) { atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); atomicAdd(&s_stat[2], 1); }
+        // the row, the priority, the key word (with this batch's stamp: nobody takes the entry away again)
+        unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
+        if constexpr (PIECES > 0) {
+        if constexpr (PIECES > 0) reinterpret_cast<float4 *>(drow)[0] = r0;
+        if constexpr (PIECES > 1) reinterpret_cast<float4 *>(drow)[1] = r1;
+        if constexpr (PIECES > 2) reinterpret_cast<float4 *>(drow)[2] = r2;
+        if constexpr (PIECES > 3) reinterpret_cast<float4 *>(drow)[3] = r3;
+        if constexpr (PIECES > 4) reinterpret_cast<float4 *>(drow)[4] = r4;
+        if constexpr (PIECES > 5) reinterpret_cast<float4 *>(drow)[5] = r5;
+        if constexpr (PIECES > 6) reinterpret_cast<float4 *>(drow)[6] = r6;
+        if constexpr (PIECES > 7) reinterpret_cast<float4 *>(drow)[7] = r7;
+        if constexpr (PIECES > 8) reinterpret_cast<float4 *>(drow)[8] = r8;
+        if constexpr (PIECES > 9) reinterpret_cast<float4 *>(drow)[9] = r9;
+        if constexpr (PIECES > 10) reinterpret_cast<float4 *>(drow)[10] = r10;
+        if constexpr (PIECES > 11) reinterpret_cast<float4 *>(drow)[11] = r11;
+        if constexpr (PIECES > 12) reinterpret_cast<float4 *>(drow)[12] = r12;
+        if constexpr (PIECES > 13) reinterpret_cast<float4 *>(drow)[13] = r13;
+        if constexpr (PIECES > 14) reinterpret_cast<float4 *>(drow)[14] = r14;
+        if constexpr (PIECES > 15) reinterpret_cast<float4 *>(drow)[15] = r15;
+        } else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
+        else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
+        args.a.eagg[e] = agg;
+        st_agent(&args.a.ekey[e], key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits));
+        // The hash slot, with the final word.  The walk starts at the first reusable slot K1's probe saw on the chain
+        // (every copy of a key carries the same hint: one snapshot), or at the home slot when the hint had to be
+        // shortened (tables above 2^24 slots); K1 also said whether that slot was empty or a tombstone, so the first
+        // access is the CAS itself.
+        const unsigned long long mine = make_word(key, (unsigned)e);
+        unsigned long long i = hint;
+        unsigned long long w = (args.hint_shift == 0 && hint_tomb) ? old_tomb : kEmpty;
+        int placed = 0;   // 1: inserted, 2: another copy of the key was faster
+        bool recycled = false;
+        for (unsigned long long steps = 0; steps <= args.mask && !placed; steps++) {   // one lap at most: a full table drops the key
+            if (w == kEmpty || w == old_tomb) {
+                const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
+                if (prev == w) { placed = 1; recycled = (w == old_tomb); }
+                else w = prev;
+            }
+            if (!placed) {
+                if ((w & kKeyMask) == key) placed = 2;
+                else { i = (i + 1) & args.mask; w = ld_agent(&args.slots[i]); }   // somebody else's key, or not for re-use: next slot
+            }
+        }
+        if (placed == 1) {
+            args.eslot[e] = (int)i;
+            atomicAdd(&s_delta[agg], 1);
+            if (old_prio < 0) atomicAdd(&s_stat[0], 1);
+            if (recycled) atomicSub(&s_stat[2], 1);
+        } else {   // a duplicate (or no slot in a full table): the entry goes back as a free one
+            st_agent(&args.a.ekey[e], (unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits);   // free from the next batch on
+            if (old_prio >= 0) atomicSub(&s_stat[0], 1);
+        }
+    }
+}
+
 template <int PIECES>   // 16-byte pieces of a row (0: any row size, piece by piece)
 __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
@@ -1744,68 +1824,33 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned info = m < n ? args.miss_info[m] : 0u;
     if (m < n && args.hit) args.hit[m] = (info >> 30) & ~(info >> 31) & 1u;
-    if (info & 0x80000000u) {
-        const int t = (int)(m % args.T);
-        const unsigned row = (unsigned)args.requests[m];
-        const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
-        const int agg = (int)((info >> 24) & 63u);
-        const unsigned long long old_tomb = args.tomb_parity ? kTomb : kTomb1;
-        // The victim group depends on the key, the batch and the POSITION in the batch: copies of one missing key must
-        // not all start on the same 8 entries (16 384 copies of a hot key in a cold cache walked the arena group by
-        // group behind each other: a 23 ms launch).
-        const long long n_groups = ((long long)args.cap + kSampleGroup - 1) / kSampleGroup;
-        long long g = (long long)(mix64(key ^ ((unsigned long long)(unsigned)args.stamp * 0x9e3779b97f4a7c15ull) ^ ((unsigned long long)m << 40)) % (unsigned long long)n_groups);
-        SampleWindow win;
-        sampled_load(args, g * kSampleGroup, win);
-        // a look at the hinted slot (same round trip): if another copy of the key is already in, there is nothing to do
-        const unsigned long long hint = args.hint_shift == 0 ? (unsigned long long)(info & 0xffffffu) : (mix64(key) & args.mask);
-        const bool already = (args.slots[hint] & kKeyMask) == key;
-        int old_prio = -1, e = -1;
-        for (long long tries = 0; tries < n_groups && e < 0 && !already; tries++) {
-            if (tries) sampled_load(args, g * kSampleGroup, win);
-            e = sampled_take(args, g * kSampleGroup, win, old_prio);
-            g = g + 1 == n_groups ? 0 : g + 1;
-        }
-        if (e >= 0) {   // (else: nothing claimable anywhere -- a cache smaller than the batch's keys: the key is not kept)
-            if (old_prio >= 0) { atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); atomicAdd(&s_stat[2], 1); }
-            // the row, the priority, the key word (with this batch's stamp: nobody takes the entry away again)
-            const unsigned char *srow = args.backing[t] + (long long)row * args.row_bytes;
-            unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
-            if constexpr (PIECES > 0) copy_row_pieces<PIECES>(srow, drow);
-            else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
-            else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
-            args.a.eagg[e] = agg;
-            st_agent(&args.a.ekey[e], key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits));
-            // The hash slot, with the final word.  The walk starts at the first reusable slot K1's probe saw on the chain
-            // (every copy of a key carries the same hint: one snapshot), or at the home slot when the hint had to be
-            // shortened (tables above 2^24 slots); K1 also said whether that slot was empty or a tombstone, so the first
-            // access is the CAS itself.
-            const unsigned long long mine = make_word(key, (unsigned)e);
-            unsigned long long i = hint;
-            unsigned long long w = (args.hint_shift == 0 && (info & 0x40000000u)) ? old_tomb : kEmpty;
-            int placed = 0;   // 1: inserted, 2: another copy of the key was faster
-            bool recycled = false;
-            for (unsigned long long steps = 0; steps <= args.mask && !placed; steps++) {   // one lap at most: a full table drops the key
-                if (w == kEmpty || w == old_tomb) {
-                    const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
-                    if (prev == w) { placed = 1; recycled = (w == old_tomb); }
-                    else w = prev;
-                }
-                if (!placed) {
-                    if ((w & kKeyMask) == key) placed = 2;
-                    else { i = (i + 1) & args.mask; w = ld_agent(&args.slots[i]); }   // somebody else's key, or not for re-use: next slot
-                }
-            }
-            if (placed == 1) {
-                args.eslot[e] = (int)i;
-                atomicAdd(&s_delta[agg], 1);
-                if (old_prio < 0) atomicAdd(&s_stat[0], 1);
-                if (recycled) atomicSub(&s_stat[2], 1);
-            } else {   // a duplicate (or no slot in a full table): the entry goes back as a free one
-                st_agent(&args.a.ekey[e], (unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits);   // free from the next batch on
-                if (old_prio >= 0) atomicSub(&s_stat[0], 1);
-            }
-        }
+    if (info & 0x80000000u)
+        sampled_insert_one<PIECES>(args, (int)(m % args.T), (unsigned)args.requests[m], (int)((info >> 24) & 63u), info & 0xffffffu,
+                                   (info & 0x40000000u) != 0, m, s_delta, s_stat);
+    __syncthreads();
+    if (threadIdx.x < kPartCols) {
+        const int i = threadIdx.x;
+        const int v = i <= args.T ? s_delta[i] : (i >= 33 && i <= 35) ? s_stat[i - 33] : 0;
+        if (v) atomicAdd(&args.part2[(blockIdx.x % kReplicas) * kPartCols + i], v);
+    }
+}
+
+// List form (tables in HBM): block j takes the misses K1's block j listed, one wave, a record per lane -- 2 048 waves of
+// mostly busy lanes instead of 6 656 waves with one lane in eight busy, and everything a miss needs arrives with its
+// record (the per-position form reads the probe word, then the request row, then starts).
+template <int PIECES>
+__global__ void __launch_bounds__(64) cache_batch_sampled_list_kernel(const BatchArgs args) {
+    __shared__ int s_delta[kMaxBuckets];
+    __shared__ int s_stat[3];
+    for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
+    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = args.list_cnt[blockIdx.x];
+    const uint4 *rec = args.miss_rec + (long long)blockIdx.x * args.list_cap;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint4 r = rec[i];
+        sampled_insert_one<PIECES>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, (r.y & 0x10000u) != 0, (long long)r.w,
+                                   s_delta, s_stat);
     }
     __syncthreads();
     if (threadIdx.x < kPartCols) {
@@ -1816,7 +1861,15 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
 }
 
 // close of a sampled batch (one block): folds K1's and the update's replica rows into the state
-__global__ void __launch_bounds__(256) cache_batch_sampled_close_kernel(const BatchArgs args, int *host_flush) {
+// (It only folds counters, and nothing the probe or the update read depends on them: it runs every kCloseEvery-th batch,
+// before a sweep / rebuild, and before anything reads the state -- 5 us per batch become 0.6.)
+struct CloseArgs {
+    BatchState *bs; int *part1, *part2; int *host_words;   // host_words: [0] tombstones, [1] flush wanted, [2] ordinal of the close
+    int T, cap, max_perfect, rebuild, n_batches;
+    long long n_requests;
+};
+constexpr int kCloseEvery = 8;
+__global__ void __launch_bounds__(256) cache_batch_sampled_close_kernel(const CloseArgs args) {
     __shared__ long long s_col[2][kPartCols];
     __shared__ BatchState sb;
     const int nw = (int)(sizeof(BatchState) / sizeof(int));
@@ -1844,12 +1897,12 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_close_kernel(const Ba
         b->n_tomb += (int)s_col[1][35];
         if (b->n_tomb < 0) b->n_tomb = 0;
         if (args.rebuild == 1) b->n_tomb = 0;
-        b->batch_id++;
-        b->n_requests += args.B;
+        b->batch_id += args.n_batches;
+        b->n_requests += args.n_requests;
         b->ticket_t = 0;
-        args.host_tomb[0] = b->n_tomb;
-        args.host_tomb[2] = (int)b->batch_id;   // the ordinal of this close: the host ignores reports older than its last sweep / rebuild
-        *host_flush = b->cnt[args.T] >= args.max_perfect ? 1 : 0;   // EvLFU flush (EvLFU_C1.py:36-44): the host launches it
+        args.host_words[0] = b->n_tomb;
+        args.host_words[2] = (int)b->batch_id;   // the ordinal of the last closed batch: the host ignores reports older than its last sweep / rebuild
+        args.host_words[1] = b->cnt[args.T] >= args.max_perfect ? 1 : 0;   // EvLFU flush (EvLFU_C1.py:36-44): the host launches it
     }
     __syncthreads();
     {
@@ -2038,6 +2091,7 @@ struct evs_cache {
     int *block_cnt = nullptr, *block_base = nullptr, *part1 = nullptr, *part2 = nullptr;
     unsigned long long *bslots = nullptr;
     long long *row_ptrs = nullptr, *iota = nullptr;
+    uint4 *miss_rec = nullptr; int *list_cnt = nullptr;   // sampled update, list form
     unsigned char *row_tier = nullptr;   // two-tier batched lookup: which tier's codec decodes each row
     long long max_batch = 0;
     int used = 0;  // 0 fresh, 1 exact path, 2 batched path
@@ -2063,6 +2117,7 @@ struct evs_cache {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int fork_mode = -1;            // -1: not decided yet (EVS_CACHE_FORK, default off), 0 / 1
     long long batch_calls = 0, last_sweep_call = -100, last_hk_call = 0;
+    int pending_batches = 0; long long pending_requests = 0;   // sampled update: batches whose counters the close has not folded yet
     unsigned long long *evicted_keys = nullptr;   // batched three-tier lookup: what K4 evicted, for the alt-key tier   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
     int batch_policy = -1;         // policy update of the batched path: 0 plan-based (K2..K6), 1 sampled (one kernel); -1: EVS_CACHE_POLICY, default sampled
 };
@@ -2355,10 +2410,14 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
         int *new_slot = nullptr, *block_cnt = nullptr, *block_base = nullptr;
         long long *row_ptrs = nullptr, *iota = nullptr;
         unsigned char *row_tier = nullptr;
+        uint4 *miss_rec = nullptr; int *list_cnt = nullptr;
         void *slab = nullptr;
         SlabPlan sp;
+        long long g1n = (B + 7) / 8; if (g1n > kProbeGridMax) g1n = kProbeGridMax;
+        const long long iters = (B + 8 * g1n - 1) / (8 * g1n);
         sp.add(&miss_info, B * T * 4); sp.add(&new_slot, g2 * 256 * 4); sp.add(&block_cnt, g2 * 4); sp.add(&block_base, g2 * 4);
         sp.add(&row_ptrs, B * T * 8); sp.add(&row_tier, B * T); sp.add(&iota, B * 8);
+        sp.add(&miss_rec, g1n * iters * 8 * T * 16); sp.add(&list_cnt, g1n * 4);   // K1's per-block miss lists (sampled update)
         if (!sp.carve(&slab)) {
             set_error("%s: allocating the buffers of a %lld-request batch failed", who, (long long)B);
             return EVS_ENOMEM;
@@ -2369,7 +2428,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
         }
         c->slab_perbatch = slab;
         c->miss_info = miss_info; c->new_slot = new_slot; c->block_cnt = block_cnt; c->block_base = block_base;
-        c->row_ptrs = row_ptrs; c->row_tier = row_tier; c->iota = iota;
+        c->row_ptrs = row_ptrs; c->row_tier = row_tier; c->iota = iota; c->miss_rec = miss_rec; c->list_cnt = list_cnt;
         hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(256), 0, st, c->iota, (long long)B);
         c->max_batch = B;
     }
@@ -2394,7 +2453,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     // a few batches late is as good): past nslot / 8 the
     // table is swept (tombstones at the end of their chains become empty again); if the count is back there within
     // three calls the sweep did not help enough and the hash is rebuilt.
-    a.evicted_keys = nullptr;
+    a.evicted_keys = nullptr; a.miss_rec = nullptr; a.list_cnt = nullptr; a.list_cap = 0;
     a.tomb_parity = -1;
     a.rebuild = 0;
     c->batch_calls++;   // = the ordinal of this call's close
@@ -2499,6 +2558,17 @@ static void batch_close(evs_cache *c, evs::BatchArgs a, hipStream_t st) {
     hipLaunchKernelGGL(cache_batch_close_kernel, dim3(1), dim3(256), 0, st, a);
     batch_housekeeping(c, a, st);
 }
+// sampled policy: fold the counters of the batches since the last close
+static void sampled_close_pending(evs_cache *c, int rebuild, hipStream_t st) {
+    using namespace evs;
+    if (c->batch_policy != 1 || !c->bs || c->pending_batches == 0) return;
+    CloseArgs ca;
+    ca.bs = c->bs; ca.part1 = c->part1; ca.part2 = c->part2; ca.host_words = c->host_tomb_dev;
+    ca.T = c->host.n_tables; ca.cap = (int)c->host.cap; ca.max_perfect = c->host.max_perfect; ca.rebuild = rebuild;
+    ca.n_batches = c->pending_batches; ca.n_requests = c->pending_requests;
+    hipLaunchKernelGGL(cache_batch_sampled_close_kernel, dim3(1), dim3(256), 0, st, ca);
+    c->pending_batches = 0; c->pending_requests = 0;
+}
 // sampled policy: the EvLFU flush the close of an earlier batch asked for (a flag in mapped host memory)
 static void sampled_flush_if_wanted(evs_cache *c, hipStream_t st) {
     using namespace evs;
@@ -2579,6 +2649,10 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         if (!host_tier) a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;   // (host tier: set above, with the hit stamps)
         a.tomb_parity = a.stamp & 1;
         sampled_flush_if_wanted(c, st);   // EvLFU flush the close of an earlier batch asked for: before this batch's probe
+        if (!host_tier) {   // K1 lists the misses itself (the patch kernel of the host tier reads the per-position records)
+            a.miss_rec = c->miss_rec; a.list_cnt = c->list_cnt;
+            a.list_cap = (int)((B + 8 * (long long)a.g1 - 1) / (8 * (long long)a.g1)) * 8 * T;
+        }
         if (c->fork_mode < 0) {
             const char *e = getenv("EVS_CACHE_FORK");
             c->fork_mode = (e && e[0] == '1') ? 1 : 0;
@@ -2606,12 +2680,22 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
             EVS_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
             su = c->side;
         } else if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
-        switch (a.row_bytes) {
-        case 144: hipLaunchKernelGGL(cache_batch_sampled_kernel<9>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;    // d = 36 fp32
-        case 256: hipLaunchKernelGGL(cache_batch_sampled_kernel<16>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;   // d = 64 fp32
-        case 128: hipLaunchKernelGGL(cache_batch_sampled_kernel<8>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
-        case 64: hipLaunchKernelGGL(cache_batch_sampled_kernel<4>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
-        default: hipLaunchKernelGGL(cache_batch_sampled_kernel<0>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
+        if (a.miss_rec) {   // K1 listed the misses: one wave per list
+            switch (a.row_bytes) {
+            case 144: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<9>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;    // d = 36 fp32
+            case 256: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<16>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;   // d = 64 fp32
+            case 128: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<8>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;
+            case 64: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<4>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;
+            default: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<0>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;
+            }
+        } else {
+            switch (a.row_bytes) {
+            case 144: hipLaunchKernelGGL(cache_batch_sampled_kernel<9>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;    // d = 36 fp32
+            case 256: hipLaunchKernelGGL(cache_batch_sampled_kernel<16>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;   // d = 64 fp32
+            case 128: hipLaunchKernelGGL(cache_batch_sampled_kernel<8>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
+            case 64: hipLaunchKernelGGL(cache_batch_sampled_kernel<4>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
+            default: hipLaunchKernelGGL(cache_batch_sampled_kernel<0>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
+            }
         }
         if (fork) {
             EVS_HIP_CHECK(hipEventRecord(c->ev_join, c->side));
@@ -2622,7 +2706,8 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
             hipLaunchKernelGGL(cache_batch_patch_ptrs_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a);
             const int rc = consumers(); if (rc) return rc;
         }
-        hipLaunchKernelGGL(cache_batch_sampled_close_kernel, dim3(1), dim3(256), 0, st, a, c->host_tomb_dev + 1);
+        c->pending_batches++; c->pending_requests += B;
+        if (c->pending_batches >= kCloseEvery || a.rebuild) sampled_close_pending(c, a.rebuild, st);
         batch_housekeeping(c, a, st);
         EVS_HIP_CHECK(hipGetLastError());
         return EVS_OK;
@@ -2823,6 +2908,7 @@ extern "C" int evs_cache_batch_stats(evs_cache *c, int64_t *out8, int64_t *hist,
     EVS_REQUIRE(c && out8 && c->bs, "evs_cache_batch_stats: the batched path has not been used");
     BatchState h;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    sampled_close_pending(c, 0, st);
     EVS_HIP_CHECK(hipStreamSynchronize(st));
     sampled_flush_if_wanted(c, st);   // what is reported is the state the next batch will see
     EVS_HIP_CHECK(hipMemcpyAsync(&h, c->bs, sizeof h, hipMemcpyDeviceToHost, st));
@@ -2837,6 +2923,7 @@ extern "C" int evs_cache_batch_stats(evs_cache *c, int64_t *out8, int64_t *hist,
 extern "C" int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream) {
     using namespace evs;
     if (!c || !c->bs) return EVS_EINVAL;
+    sampled_close_pending(c, 0, reinterpret_cast<hipStream_t>(stream));
     if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return EVS_EHIP;
     sampled_flush_if_wanted(c, reinterpret_cast<hipStream_t>(stream));
     if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return EVS_EHIP;
