@@ -3,6 +3,7 @@
   exact path   EvLFU (three variants, approx mode) / LRU / LFU, random tables, capacities, streams and chunk sizes:
                hit flags, rows, final list order and counters
   two tiers    request_c1c2 against oracle.C1C2: tier codes, rows, both tiers' final lists
+  batched3     lookup_batch_c1c2c3 (alt-key tier as a key set): tier codes, rows, C3 membership / flags / size
   batched      lookup_batch with random capacities / batch sizes (incl. caches smaller than one batch): snapshot hit
                flags, exact rows, no duplicate keys, size <= capacity, histogram consistent
 usage: python tools/fuzz_cache.py [seconds] [seed]"""
@@ -256,21 +257,77 @@ def batched2_case(rs, case):
     return tag
 
 
+def batched3_case(rs, case):
+    """Batched three-tier lookup against the snapshot: tier codes (3 = key in C3 and its alt row resident), served rows
+    (tables of -1 / 0 / 1: exact in every codec), C3 members are keys the tiers gave up, flags only on keys served
+    through their alt key, size <= capacity, hit counter."""
+    T = int(rs.choice([3, 26]))
+    d = int(rs.choice([16, 36]))
+    n = int(rs.choice([20, 300]))
+    ca, cb = [(8, 4), (32, 8), (32, 4)][int(rs.randint(0, 3))]
+    ws = [rs.randint(-1, 2, size=(n, d)).astype(np.float32) for _ in range(T)]
+    raws = {c: [orc.encode_table(w, c) for w in ws] for c in (ca, cb)}
+    spread = int(rs.choice([4, 16]))
+    alt = [np.array([(r % spread) * 100 + ((t + 1) % T + 1) for r in range(n)], dtype=np.uint32) for t in range(T)]
+    cap1, cap2, cap3 = int(rs.choice([40, 300])), int(rs.choice([40, 600])), int(rs.choice([50, 64, 800]))
+    thr = int(rs.choice([23, 20]))
+    B = int(rs.choice([1, 30, 250]))
+    n_batches = int(rs.choice([4, 12]))
+    tag = "batched three-tier case %d: T=%d d=%d n=%d codecs=%d/%d caps=%d/%d/%d thr=%d B=%d batches=%d" % (
+        case, T, d, n, ca, cb, cap1, cap2, cap3, thr, B, n_batches)
+    c1 = E.GpuCache("evlfu", cap1, T, d, ca, "cpp")
+    c2 = E.GpuCache("evlfu", cap2, T, d, cb, "cpp")
+    c1.set_backing([torch.from_numpy(a).cuda() for a in raws[ca]])
+    c2.set_backing([torch.from_numpy(a).cuda() for a in raws[cb]])
+    c3 = E.GpuAltKeyTier(cap3, [torch.from_numpy(a.view(np.int32)).cuda() for a in alt])
+    reqs = _stream(rs, [n] * T, B * n_batches)
+    R1, R2, M3 = set(), set(), set()
+    ever_alt, removed, n3 = set(), set(), 0
+    for s in range(0, len(reqs), B):
+        rq = reqs[s:s + B]
+        tier, out = gpu_cache.lookup_batch_c1c2c3(c1, c2, c3, torch.from_numpy(rq).cuda(), threshold=thr)
+        tier, out = tier.cpu().numpy(), out.cpu().numpy()
+        for b in range(len(rq)):
+            for k in range(T):
+                key = (k + 1, int(rq[b, k]))
+                a = int(alt[k][rq[b, k]])
+                akey = (a % 100, a // 100)
+                want_t = 1 if key in R1 else 2 if key in R2 else 3 if (key in M3 and (akey in R1 or akey in R2)) else 0
+                assert tier[b, k] == want_t, tag + ": tier code (%d,%d) %d != %d" % (b, k, tier[b, k], want_t)
+                want = ws[akey[0] - 1][akey[1]] if want_t == 3 else ws[k][rq[b, k]]
+                assert np.array_equal(out[b, k], want), tag + ": row (%d,%d)" % (b, k)
+                if want_t == 3:
+                    ever_alt.add(key)
+                    n3 += 1
+        n1 = {(int(t), int(rw)) for _, t, rw in c1.batch_dump()}
+        n2 = {(int(t), int(rw)) for _, t, rw in c2.batch_dump()}
+        assert len(n1) <= cap1 and len(n2) <= cap2 and not (n1 & n2), tag + ": tiers"
+        removed |= (R1 - n1) | (R2 - n2)
+        m3, st3 = c3.batch_dump()
+        members = {(int(t), int(rw)) for t, rw, _ in m3}
+        assert len(members) == len(m3) == st3["members"] <= st3["capacity"] <= cap3, tag + ": C3 size"
+        assert members <= removed, tag + ": C3 member the tiers never gave up"
+        assert {(int(t), int(rw)) for t, rw, f in m3 if f} <= ever_alt, tag + ": recency flag without an alt hit"
+        assert st3["n_hit"] == n3, tag + ": alt hit counter"
+        R1, R2, M3 = n1, n2, members
+    return tag
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rs = np.random.RandomState(seed)
     t0 = time.time()
-    n = [0, 0, 0, 0, 0]
+    n = [0, 0, 0, 0, 0, 0]
     last = ""
     while time.time() - t0 < seconds:
-        which = int(rs.choice([0, 0, 1, 2, 2, 3, 4]))
+        which = int(rs.choice([0, 0, 1, 2, 2, 3, 4, 5]))
         if os.environ.get("EVS_FUZZ_VERBOSE"):
             print("-> case %d kind %d" % (sum(n), which), flush=True)
-        last = (exact_case, c1c2_case, batched_case, batched2_case, c1c2c3_case)[which](rs, sum(n))
+        last = (exact_case, c1c2_case, batched_case, batched2_case, c1c2c3_case, batched3_case)[which](rs, sum(n))
         n[which] += 1
-    print("cache fuzz ok: %d exact, %d two-tier, %d batched, %d batched two-tier, %d three-tier cases in %.0f s (seed %d); last %s" % (
-        n[0], n[1], n[2], n[3], n[4], time.time() - t0, seed, last))
+    print("cache fuzz ok: %d exact, %d two-tier, %d batched, %d batched two-tier, %d three-tier, %d batched three-tier cases in %.0f s (seed %d); last %s" % (
+        n[0], n[1], n[2], n[3], n[4], n[5], time.time() - t0, seed, last))
 
 
 if __name__ == "__main__":
