@@ -25,6 +25,12 @@ for set in \
   timeout 240 rocprofv3 --pmc $set --output-format csv -d $OUT/sq$i -- python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-cache-tier > $OUT/sq$i.log 2>&1 || echo "sq pass $i failed"
 done
 python3 $ROOT/tools/pmc_summary.py $OUT "emb_interact_rf_kernel" > $OUT/pmc_summary.txt
+# the cache tier alone: 600 batches it has not seen (housekeeping included), kernel statistics and per-dispatch deciles
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ctrace -- python3 $ROOT/tools/cache_bench.py 16384 600 0 > $OUT/cache_bench_600.json 2> $OUT/cache_bench_600.err
+f=$(find $OUT/ctrace -name "*kernel_stats.csv" | head -1); grep -E "evs::|Name" $f > $OUT/cache_kernel_stats.csv
+t=$(find $OUT/ctrace -name "*kernel_trace.csv" | head -1); python3 $ROOT/tools/ktrace_deciles.py $t | grep "evs::" > $OUT/cache_kernel_deciles.txt
+rm -rf $OUT/ctrace
+EVS_CACHE_POLICY=plan python3 $ROOT/tools/cache_bench.py 16384 600 0 > $OUT/cache_bench_600_plan.json 2>/dev/null
 cd $ROOT
 timeout 900 python3 tools/sweep.py > $OUT/sweep.md 2> $OUT/sweep.err
 timeout 200 python3 tools/mlp_bench.py > $OUT/mlp_bench.log 2>&1

@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     a = ap.parse_args()
     it = 50 if a.quick else 200
-    print("# Round-1 sweep (one MI355X, synthetic uniform indices unless stated; HBM peak used: 8 000 GB/s)\n")
+    print("# Round-2 sweep (one MI355X, synthetic uniform indices unless stated; HBM peak used: 8 000 GB/s)\n")
     print("`fused` = `apply_emb_interact` (one kernel; one index per bag declared); `offsets` = the same with `lS_o` read and")
     print("validated; `two-call` = `apply_emb(lazy=False)` then `interact_features`: two kernels, the pooled rows in HBM (with lazy pooling, the default, the pair runs as the fused launch).  Latencies are per batch, HIP events, inputs resident.")
     print("GB/s = algorithmic bytes (SURVEY 8(d): rows + indices + x read, R written) / mean batch time.\n")
