@@ -288,6 +288,11 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const int i = 4 * q + v;
+#ifdef EVS_X_FLATSTAGE   // developer A/B (timing only, wrong R): every staging store conflict-free, lane-linear addresses
+            const int zo00 = 4 * (d + lane + 64 * v), zo10 = 4 * (d + 256 + lane + 64 * (v & 3)), zo11 = 4 * (d + lane + 64 * ((v + 1) & 3));
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
+            if constexpr (NT == 2) {
+#else
             const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
             *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
             if constexpr (NT == 2) {
@@ -295,6 +300,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
                 const int base = (gi * (gi - 1 + 2 * itself)) / 2;
                 const int zo10 = gi < F ? 4 * (d + base + r16) : dump;
                 const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
+#endif
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = c10[v];
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[v];
             }

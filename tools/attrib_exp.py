@@ -21,5 +21,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 for v in sys.argv[1:]:
     print("== " + v, flush=True)
-    env = dict(os.environ, EVS_LIB_PATH=os.path.join(ROOT, "ev-store-dlrm_amd", "lib", "var", "libevstore_hip_%s.so" % v), EVS_FUSED_RF="0")
+    env = dict(os.environ, EVS_LIB_PATH=os.path.join(ROOT, "ev-store-dlrm_amd", "lib", "var", "libevstore_hip_%s.so" % v), EVS_FUSED_RF=os.environ.get("EVS_ATTRIB_RF", "0"))
     subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, timeout=600)
