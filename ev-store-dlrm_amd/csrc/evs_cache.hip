@@ -890,6 +890,9 @@ struct BatchArgs {
     // kind << 16, hinted slot, request position) at miss_rec + j * list_cap, their number in list_cnt[j]; the update
     // kernel runs one wave per list instead of one thread per (request, table) position
     uint4 *miss_rec; int *list_cnt; int list_cap;
+    // sampled update with the alt-key tier attached: kReplicas victim lists of vict_cap keys each in evicted_keys, their
+    // lengths in vict_cnt (zeroed by the consumer kernel)
+    int *vict_cnt; int vict_cap;
     unsigned long long *evicted_keys;   // (alt-key tier attached) the key each free-stack position held before K4 put it there; bit 63 = flushed, not evicted
     int tomb_parity;                // sampled update: parity of this batch (its tombstones are kTomb1 when odd); -1 otherwise
 };
@@ -1118,7 +1121,9 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
     __syncthreads();
     const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
     const int T = a1.T;
-    const bool c1_full = a1.bs->count >= a1.cap;   // snapshot: the policy kernels of this batch run later
+    // snapshot: the policy kernels of this batch run later.  (Sampled update: a large cache stops a fraction of a per
+    // cent short of its capacity -- the last free entries are not worth hunting -- so "full" has that much slack there.)
+    const bool c1_full = a1.bs->count >= a1.cap - (a1.tomb_parity >= 0 && a1.cap > 65536 ? a1.cap / 256 : 0);
     const long long req_stride = (long long)gridDim.x * 8;
     for (long long req = (long long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half; req - half - (threadIdx.x >> 6) * 2 < a1.B;
          req += req_stride) {
@@ -1128,9 +1133,10 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         const bool ok = key_on && row >= 0 && row < a1.backing_rows[hl < T ? hl : 0] && row < a2.backing_rows[hl < T ? hl : 0];
         const unsigned long long key = ((unsigned long long)(hl + 1) << 32) | (unsigned)row;
         unsigned long long end1 = 0, end2 = 0;
-        int e1 = ok ? probe_ro(a1.slots, a1.mask, key, end1) : -1;
+        bool ht1 = false, ht2 = false;   // sampled update: is the hinted slot a (re-usable) tombstone
+        int e1 = ok ? probe_ro(a1.slots, a1.mask, key, end1, a1.tomb_parity == 1 ? kTomb : a1.tomb_parity == 0 ? kTomb1 : kTomb, &ht1) : -1;
         if (e1 == kPending) e1 = -1;
-        int e2 = (ok && e1 < 0) ? probe_ro(a2.slots, a2.mask, key, end2) : -1;
+        int e2 = (ok && e1 < 0) ? probe_ro(a2.slots, a2.mask, key, end2, a2.tomb_parity == 1 ? kTomb : a2.tomb_parity == 0 ? kTomb1 : kTomb, &ht2) : -1;
         if (e2 == kPending) e2 = -1;
         // alt-key probe for a double miss (find_approximate_ev, evlfu_8.cpp:474-490): the key is in C3 and its alt row
         // is resident in C1, else in C2 -> that row is served; the request's agg_hit counts it, nothing is inserted
@@ -1173,9 +1179,10 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         else if (miss) { src = a2.backing[hl] + (long long)row * a2.row_bytes; codec_of = 2; }
         if (key_on) {
             const long long m = req * T + hl;
-            a1.miss_info[m] = ((miss && dest == 1) ? 0x80000000u : 0u) | (e1 >= 0 ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
+            // (bit 30: hit -- or, of a miss, "the hinted slot is a tombstone", as in K1)
+            a1.miss_info[m] = ((miss && dest == 1) ? 0x80000000u : 0u) | ((e1 >= 0 || (miss && dest == 1 && ht1)) ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
                               (unsigned)(end1 >> a1.hint_shift);
-            a2.miss_info[m] = ((miss && dest == 2) ? 0x80000000u : 0u) | (e2 >= 0 ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
+            a2.miss_info[m] = ((miss && dest == 2) ? 0x80000000u : 0u) | ((e2 >= 0 || (miss && dest == 2 && ht2)) ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
                               (unsigned)(end2 >> a2.hint_shift);
             a1.row_ptrs[m] = (long long)src;
             tt.row_tier[m] = (unsigned char)codec_of;
@@ -1640,6 +1647,7 @@ __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs
 // the hash words.  A key whose group and every following group hold nothing claimable is dropped (tiny caches).
 constexpr unsigned long long kClaimed = ~0ull;   // ekey of an entry a thread owns while it moves it
 constexpr int kSampleGroup = 8;
+constexpr int kFreeHunt = 64;     // groups a new key looks at for a FREE entry while the cache is not full
 constexpr unsigned kStampMask = (1u << (64 - kKeyBits)) - 1u;   // the batch stamp rides in the 26 bits above the key
 // Words that threads of ONE launch hand to each other are written and read with read-modify-write atomics only (those
 // are performed where all 8 XCDs meet; plain and sc1 accesses may be served by an XCD's own L2).
@@ -1673,7 +1681,8 @@ __device__ __forceinline__ void sampled_load(const BatchArgs &args, long long e0
 // it belongs to the caller; if it held a key, that key's hash word is already a tombstone) or -1.
 // One exit, flags instead of continue / break / return out of the nested loops: the early-exit form of this function
 // came back from hipcc 7.2 returning a garbage entry index on the evict path (found with guards on the GPU).
-__device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0, const SampleWindow &w, int &old_prio) {
+__device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0, const SampleWindow &w, int &old_prio,
+                                            unsigned long long &old_key, bool free_only = false) {
     unsigned tried = 0;
     bool more = true;
     int result = -1;
@@ -1684,7 +1693,7 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
 #pragma unroll
         for (int j = 0; j < kSampleGroup; j++) {
             const int pj = (w.k[j] & kKeyMask) == kEmpty ? -1 : w.pr[j];
-            const bool cand = !((tried >> j) & 1u) && w.k[j] != kClaimed && pj < bp;
+            const bool cand = !((tried >> j) & 1u) && w.k[j] != kClaimed && pj < bp && (!free_only || pj < 0);
             best = cand ? j : best; bp = cand ? pj : bp; bk = cand ? w.k[j] : bk; bs = cand ? w.sl[j] : bs;
         }
         more = best >= 0;
@@ -1694,6 +1703,7 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
             if (atomicCAS(&args.a.ekey[e], bk, kClaimed) == bk) {   // else somebody else was faster
                 if ((bk & kKeyMask) != kEmpty) st_agent(&args.slots[bs], args.tomb_parity ? kTomb1 : kTomb);
                 old_prio = bp;
+                old_key = bk & kKeyMask;
                 result = (int)e;
             }
         }
@@ -1709,125 +1719,153 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
 // replica columns of part2 in this mode: 0..32 histogram deltas, 33 count delta (entries taken from the free ones minus
 // victims given back), 34 evictions, 35 tombstone delta (evicted - recycled)
 //
-// Order inside a thread: the ENTRY first, the hash slot last, with the final word.  There is no pending state: the
-// copy of a key that wins the slot is the one that inserted it (with its request's agg_hit as the priority); a copy
-// that finds the key already there gives its entry back as a free one (a wasted eviction per duplicate miss of a
-// batch -- those are few: hot keys are hits).  That keeps the dependent chain at four round trips -- request + probe
-// record, victim group (with the source row), CAS on the entry, CAS on the slot -- instead of six with a pending word
-// that is finalised later.
-// one missed key of the batch: victim, row, key word, hash slot (see the comment above); m = its position in the batch
-template <int PIECES>
+// Order inside a thread: the hash slot first (a pending word: the copy of a key that wins it is the one that inserts the
+// key, with its request's agg_hit as the priority; the others stop there), then the entry, then nothing but stores --
+// three dependent round trips: the miss record, {slot CAS, victim group, source row}, the CAS on the entry.
+// one missed key of the batch: victim, row, key word, hash slot (see the comment above); m = its position in the batch.
+// PIECES pieces of type U make one row (0: any row size, byte by byte)
+template <int PIECES, typename U>
 __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t, unsigned row, int agg, unsigned hint_slot, bool hint_tomb,
-                                                   long long m, int *s_delta, int *s_stat) {
+                                                   long long m, int *s_delta, int *s_stat, unsigned long long *s_vict = nullptr,
+                                                   int *s_nvict = nullptr) {
     const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
-    const unsigned long long old_tomb = args.tomb_parity ? kTomb : kTomb1;
+    if (args.other_slots) {   // two tiers: the other tier took this key in this very batch
+        unsigned long long es;
+        if (probe_ro(args.other_slots, args.other_mask, key, es) != -1) return;
+    }
+    const unsigned long long my_tomb = args.tomb_parity ? kTomb1 : kTomb, old_tomb = args.tomb_parity ? kTomb : kTomb1;
     // The victim group depends on the key, the batch and the POSITION in the batch: copies of one missing key must
-    // not all start on the same 8 entries (16 384 copies of a hot key in a cold cache walked the arena group by
-    // group behind each other: a 23 ms launch).
+    // not all start on the same 8 entries.  Its loads, and the source row, go out together with the slot CAS.
     const long long n_groups = ((long long)args.cap + kSampleGroup - 1) / kSampleGroup;
     long long g = (long long)(mix64(key ^ ((unsigned long long)(unsigned)args.stamp * 0x9e3779b97f4a7c15ull) ^ ((unsigned long long)m << 40)) % (unsigned long long)n_groups);
     SampleWindow win;
     sampled_load(args, g * kSampleGroup, win);
-    // the source row travels with the victim group (same round trip)
     const unsigned char *srow = args.backing[t] + (long long)row * args.row_bytes;
-    float4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
-    if constexpr (PIECES > 0) r0 = reinterpret_cast<const float4 *>(srow)[0];
-    if constexpr (PIECES > 1) r1 = reinterpret_cast<const float4 *>(srow)[1];
-    if constexpr (PIECES > 2) r2 = reinterpret_cast<const float4 *>(srow)[2];
-    if constexpr (PIECES > 3) r3 = reinterpret_cast<const float4 *>(srow)[3];
-    if constexpr (PIECES > 4) r4 = reinterpret_cast<const float4 *>(srow)[4];
-    if constexpr (PIECES > 5) r5 = reinterpret_cast<const float4 *>(srow)[5];
-    if constexpr (PIECES > 6) r6 = reinterpret_cast<const float4 *>(srow)[6];
-    if constexpr (PIECES > 7) r7 = reinterpret_cast<const float4 *>(srow)[7];
-    if constexpr (PIECES > 8) r8 = reinterpret_cast<const float4 *>(srow)[8];
-    if constexpr (PIECES > 9) r9 = reinterpret_cast<const float4 *>(srow)[9];
-    if constexpr (PIECES > 10) r10 = reinterpret_cast<const float4 *>(srow)[10];
-    if constexpr (PIECES > 11) r11 = reinterpret_cast<const float4 *>(srow)[11];
-    if constexpr (PIECES > 12) r12 = reinterpret_cast<const float4 *>(srow)[12];
-    if constexpr (PIECES > 13) r13 = reinterpret_cast<const float4 *>(srow)[13];
-    if constexpr (PIECES > 14) r14 = reinterpret_cast<const float4 *>(srow)[14];
-    if constexpr (PIECES > 15) r15 = reinterpret_cast<const float4 *>(srow)[15];
-    // a look at the hinted slot (same round trip): if another copy of the key is already in, there is nothing to do
-    const unsigned long long hint = args.hint_shift == 0 ? (unsigned long long)hint_slot : (mix64(key) & args.mask);
-    const bool already = (args.slots[hint] & kKeyMask) == key;
+    U r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
+    if constexpr (PIECES > 0) r0 = reinterpret_cast<const U *>(srow)[0];
+    if constexpr (PIECES > 1) r1 = reinterpret_cast<const U *>(srow)[1];
+    if constexpr (PIECES > 2) r2 = reinterpret_cast<const U *>(srow)[2];
+    if constexpr (PIECES > 3) r3 = reinterpret_cast<const U *>(srow)[3];
+    if constexpr (PIECES > 4) r4 = reinterpret_cast<const U *>(srow)[4];
+    if constexpr (PIECES > 5) r5 = reinterpret_cast<const U *>(srow)[5];
+    if constexpr (PIECES > 6) r6 = reinterpret_cast<const U *>(srow)[6];
+    if constexpr (PIECES > 7) r7 = reinterpret_cast<const U *>(srow)[7];
+    if constexpr (PIECES > 8) r8 = reinterpret_cast<const U *>(srow)[8];
+    if constexpr (PIECES > 9) r9 = reinterpret_cast<const U *>(srow)[9];
+    if constexpr (PIECES > 10) r10 = reinterpret_cast<const U *>(srow)[10];
+    if constexpr (PIECES > 11) r11 = reinterpret_cast<const U *>(srow)[11];
+    if constexpr (PIECES > 12) r12 = reinterpret_cast<const U *>(srow)[12];
+    if constexpr (PIECES > 13) r13 = reinterpret_cast<const U *>(srow)[13];
+    if constexpr (PIECES > 14) r14 = reinterpret_cast<const U *>(srow)[14];
+    if constexpr (PIECES > 15) r15 = reinterpret_cast<const U *>(srow)[15];
+    // 1. The hash slot, with a PENDING word: that is what de-duplicates the copies of a key (the loser of the CAS sees
+    //    the key and stops -- it takes no entry; an earlier form claimed the entry first and gave it back, which let a
+    //    batch with hundreds of copies of its hot missing keys evict half of a small cache for nothing).  The walk starts
+    //    at the first reusable slot K1's probe saw on the chain (every copy of a key carries the same hint: one
+    //    snapshot), or at the home slot when the hint had to be shortened (tables above 2^24 slots); K1 also said
+    //    whether that slot was empty or a tombstone, so the first access is the CAS itself.
+    const unsigned long long pend = make_word(key, kFieldPend + (unsigned)agg);
+    unsigned long long i = args.hint_shift == 0 ? (unsigned long long)hint_slot : (mix64(key) & args.mask);
+    unsigned long long w = (args.hint_shift == 0 && hint_tomb) ? old_tomb : kEmpty;
+    int placed = 0;   // 1: the slot is this thread's, 2: another copy of the key was faster
+    bool recycled = false;
+    for (unsigned long long steps = 0; steps <= args.mask && !placed; steps++) {   // one lap at most: a full table drops the key
+        if (w == kEmpty || w == old_tomb) {
+            const unsigned long long prev = atomicCAS(&args.slots[i], w, pend);
+            if (prev == w) { placed = 1; recycled = (w == old_tomb); }
+            else w = prev;
+        }
+        if (!placed) {
+            if ((w & kKeyMask) == key) placed = 2;
+            else { i = (i + 1) & args.mask; w = ld_agent(&args.slots[i]); }   // somebody else's key, or not for re-use: next slot
+        }
+    }
+    if (placed != 1) return;
+    if (recycled) atomicSub(&s_stat[2], 1);
+    // 2. The entry.  While the cache still has free entries (count of the last close) a key whose group has none looks
+    //    at a few more groups for one before it evicts anything: a small cache fills to exactly its capacity that way
+    //    (the two-tier routing asks "is C1 full"); a large one stops hunting once less than 1/256 of it is free.
     int old_prio = -1, e = -1;
-    for (long long tries = 0; tries < n_groups && e < 0 && !already; tries++) {
+    unsigned long long old_key = 0;
+    const int n_free = args.cap - args.bs->count;
+    if (n_free > 0 && (args.cap <= 65536 || n_free > args.cap / 256)) {
+        e = sampled_take(args, g * kSampleGroup, win, old_prio, old_key, true);
+        long long gf = g;
+        for (int hunt = 1; hunt < kFreeHunt && e < 0 && hunt < n_groups; hunt++) {
+            gf = gf + 1 == n_groups ? 0 : gf + 1;
+            SampleWindow wf;
+            sampled_load(args, gf * kSampleGroup, wf);
+            e = sampled_take(args, gf * kSampleGroup, wf, old_prio, old_key, true);
+        }
+    }
+    for (long long tries = 0; tries < n_groups && e < 0; tries++) {
         if (tries) sampled_load(args, g * kSampleGroup, win);
-        e = sampled_take(args, g * kSampleGroup, win, old_prio);
+        e = sampled_take(args, g * kSampleGroup, win, old_prio, old_key);
         g = g + 1 == n_groups ? 0 : g + 1;
     }
-    if (e >= 0) {   // (else: nothing claimable anywhere -- a cache smaller than the batch's keys: the key is not kept)
-        if (old_prio >= 0) { atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); atomicAdd(&s_stat[2], 1); }
-        // the row, the priority, the key word (with this batch's stamp: nobody takes the entry away again)
-        unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
-        if constexpr (PIECES > 0) {
-        if constexpr (PIECES > 0) reinterpret_cast<float4 *>(drow)[0] = r0;
-        if constexpr (PIECES > 1) reinterpret_cast<float4 *>(drow)[1] = r1;
-        if constexpr (PIECES > 2) reinterpret_cast<float4 *>(drow)[2] = r2;
-        if constexpr (PIECES > 3) reinterpret_cast<float4 *>(drow)[3] = r3;
-        if constexpr (PIECES > 4) reinterpret_cast<float4 *>(drow)[4] = r4;
-        if constexpr (PIECES > 5) reinterpret_cast<float4 *>(drow)[5] = r5;
-        if constexpr (PIECES > 6) reinterpret_cast<float4 *>(drow)[6] = r6;
-        if constexpr (PIECES > 7) reinterpret_cast<float4 *>(drow)[7] = r7;
-        if constexpr (PIECES > 8) reinterpret_cast<float4 *>(drow)[8] = r8;
-        if constexpr (PIECES > 9) reinterpret_cast<float4 *>(drow)[9] = r9;
-        if constexpr (PIECES > 10) reinterpret_cast<float4 *>(drow)[10] = r10;
-        if constexpr (PIECES > 11) reinterpret_cast<float4 *>(drow)[11] = r11;
-        if constexpr (PIECES > 12) reinterpret_cast<float4 *>(drow)[12] = r12;
-        if constexpr (PIECES > 13) reinterpret_cast<float4 *>(drow)[13] = r13;
-        if constexpr (PIECES > 14) reinterpret_cast<float4 *>(drow)[14] = r14;
-        if constexpr (PIECES > 15) reinterpret_cast<float4 *>(drow)[15] = r15;
-        } else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
-        else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
-        args.a.eagg[e] = agg;
-        st_agent(&args.a.ekey[e], key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits));
-        // The hash slot, with the final word.  The walk starts at the first reusable slot K1's probe saw on the chain
-        // (every copy of a key carries the same hint: one snapshot), or at the home slot when the hint had to be
-        // shortened (tables above 2^24 slots); K1 also said whether that slot was empty or a tombstone, so the first
-        // access is the CAS itself.
-        const unsigned long long mine = make_word(key, (unsigned)e);
-        unsigned long long i = hint;
-        unsigned long long w = (args.hint_shift == 0 && hint_tomb) ? old_tomb : kEmpty;
-        int placed = 0;   // 1: inserted, 2: another copy of the key was faster
-        bool recycled = false;
-        for (unsigned long long steps = 0; steps <= args.mask && !placed; steps++) {   // one lap at most: a full table drops the key
-            if (w == kEmpty || w == old_tomb) {
-                const unsigned long long prev = atomicCAS(&args.slots[i], w, mine);
-                if (prev == w) { placed = 1; recycled = (w == old_tomb); }
-                else w = prev;
-            }
-            if (!placed) {
-                if ((w & kKeyMask) == key) placed = 2;
-                else { i = (i + 1) & args.mask; w = ld_agent(&args.slots[i]); }   // somebody else's key, or not for re-use: next slot
-            }
-        }
-        if (placed == 1) {
-            args.eslot[e] = (int)i;
-            atomicAdd(&s_delta[agg], 1);
-            if (old_prio < 0) atomicAdd(&s_stat[0], 1);
-            if (recycled) atomicSub(&s_stat[2], 1);
-        } else {   // a duplicate (or no slot in a full table): the entry goes back as a free one
-            st_agent(&args.a.ekey[e], (unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits);   // free from the next batch on
-            if (old_prio >= 0) atomicSub(&s_stat[0], 1);
-        }
+    if (e < 0) {   // nothing claimable anywhere (a cache smaller than the batch's keys): the key is not kept
+        st_agent(&args.slots[i], my_tomb);
+        atomicAdd(&s_stat[2], 1);
+        return;
     }
+    if (old_prio >= 0) {
+        atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); atomicAdd(&s_stat[2], 1);
+        if (s_vict) s_vict[atomicAdd(s_nvict, 1)] = old_key;   // for the alt-key tier
+    } else atomicAdd(&s_stat[0], 1);
+    // 3. Everything else is stores nobody waits for: the row, the priority, the slot index, the key word (with this
+    //    batch's stamp: nobody takes the entry away again), the final hash word.
+    unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
+    if constexpr (PIECES > 0) {
+        if constexpr (PIECES > 0) reinterpret_cast<U *>(drow)[0] = r0;
+        if constexpr (PIECES > 1) reinterpret_cast<U *>(drow)[1] = r1;
+        if constexpr (PIECES > 2) reinterpret_cast<U *>(drow)[2] = r2;
+        if constexpr (PIECES > 3) reinterpret_cast<U *>(drow)[3] = r3;
+        if constexpr (PIECES > 4) reinterpret_cast<U *>(drow)[4] = r4;
+        if constexpr (PIECES > 5) reinterpret_cast<U *>(drow)[5] = r5;
+        if constexpr (PIECES > 6) reinterpret_cast<U *>(drow)[6] = r6;
+        if constexpr (PIECES > 7) reinterpret_cast<U *>(drow)[7] = r7;
+        if constexpr (PIECES > 8) reinterpret_cast<U *>(drow)[8] = r8;
+        if constexpr (PIECES > 9) reinterpret_cast<U *>(drow)[9] = r9;
+        if constexpr (PIECES > 10) reinterpret_cast<U *>(drow)[10] = r10;
+        if constexpr (PIECES > 11) reinterpret_cast<U *>(drow)[11] = r11;
+        if constexpr (PIECES > 12) reinterpret_cast<U *>(drow)[12] = r12;
+        if constexpr (PIECES > 13) reinterpret_cast<U *>(drow)[13] = r13;
+        if constexpr (PIECES > 14) reinterpret_cast<U *>(drow)[14] = r14;
+        if constexpr (PIECES > 15) reinterpret_cast<U *>(drow)[15] = r15;
+    } else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
+    else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
+    args.a.eagg[e] = agg;
+    args.eslot[e] = (int)i;
+    st_agent(&args.a.ekey[e], key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits));
+    st_agent(&args.slots[i], make_word(key, (unsigned)e));
+    atomicAdd(&s_delta[agg], 1);
 }
 
-template <int PIECES>   // 16-byte pieces of a row (0: any row size, piece by piece)
+template <int PIECES, typename U>
 __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
+    __shared__ unsigned long long s_vict[256];   // keys this block evicted (alt-key tier attached)
+    __shared__ int s_nvict, s_vbase;
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nvict = 0;
     __syncthreads();
     const long long n = args.B * args.T;
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned info = m < n ? args.miss_info[m] : 0u;
     if (m < n && args.hit) args.hit[m] = (info >> 30) & ~(info >> 31) & 1u;
     if (info & 0x80000000u)
-        sampled_insert_one<PIECES>(args, (int)(m % args.T), (unsigned)args.requests[m], (int)((info >> 24) & 63u), info & 0xffffffu,
-                                   (info & 0x40000000u) != 0, m, s_delta, s_stat);
+        sampled_insert_one<PIECES, U>(args, (int)(m % args.T), (unsigned)args.requests[m], (int)((info >> 24) & 63u), info & 0xffffffu,
+                                   (info & 0x40000000u) != 0, m, s_delta, s_stat, args.vict_cnt ? s_vict : nullptr, &s_nvict);
     __syncthreads();
+    if (args.vict_cnt && s_nvict) {   // the block's victims behind one of the kReplicas lists: one atomic per block
+        const int r = blockIdx.x % kReplicas;
+        if (threadIdx.x == 0) s_vbase = atomicAdd(&args.vict_cnt[r], s_nvict);
+        __syncthreads();
+        for (int i = threadIdx.x; i < s_nvict; i += blockDim.x)
+            if (s_vbase + i < args.vict_cap) args.evicted_keys[(long long)r * args.vict_cap + s_vbase + i] = s_vict[i];
+    }
     if (threadIdx.x < kPartCols) {
         const int i = threadIdx.x;
         const int v = i <= args.T ? s_delta[i] : (i >= 33 && i <= 35) ? s_stat[i - 33] : 0;
@@ -1838,7 +1876,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
 // List form (tables in HBM): block j takes the misses K1's block j listed, one wave, a record per lane -- 2 048 waves of
 // mostly busy lanes instead of 6 656 waves with one lane in eight busy, and everything a miss needs arrives with its
 // record (the per-position form reads the probe word, then the request row, then starts).
-template <int PIECES>
+template <int PIECES, typename U>
 __global__ void __launch_bounds__(64) cache_batch_sampled_list_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
@@ -1849,7 +1887,7 @@ __global__ void __launch_bounds__(64) cache_batch_sampled_list_kernel(const Batc
     const uint4 *rec = args.miss_rec + (long long)blockIdx.x * args.list_cap;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const uint4 r = rec[i];
-        sampled_insert_one<PIECES>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, (r.y & 0x10000u) != 0, (long long)r.w,
+        sampled_insert_one<PIECES, U>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, (r.y & 0x10000u) != 0, (long long)r.w,
                                    s_delta, s_stat);
     }
     __syncthreads();
@@ -2011,6 +2049,50 @@ __global__ void __launch_bounds__(256) c3_batch_insert_kernel(const BatchArgs ar
     }
 }
 
+// the same fill from the victim lists of the sampled update (kReplicas lists; the kernel empties them)
+__device__ __forceinline__ void c3_insert_key(const C3Batch &c3, unsigned long long key) {
+    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
+    bool done = false;
+    for (int attempt = 0; attempt < 4 && !done; attempt++) {   // (a CAS lost to another newcomer of the same set: look again)
+        unsigned long long w[kSetWays];
+        int present = 0, empty = -1, plain = -1;
+#pragma unroll
+        for (int j = 0; j < kSetWays; j++) {
+            w[j] = atomicOr(&c3.tags[base + j], 0ull);
+            present |= (w[j] & kKeyMask) == key;
+            if (w[j] == 0ull && empty < 0) empty = j;
+            if (w[j] != 0ull && !(w[j] & kC3Flag) && plain < 0) plain = j;
+        }
+        if (present) done = true;
+        else {
+            int way = empty >= 0 ? empty : plain;
+            if (way < 0) {   // every way has had its second chance now
+#pragma unroll
+                for (int j = 0; j < kSetWays; j++) atomicAnd(&c3.tags[base + j], ~kC3Flag);
+                way = (int)((key >> 3) % kSetWays);
+            }
+            unsigned long long expect = 0ull;
+#pragma unroll
+            for (int j = 0; j < kSetWays; j++) expect = j == way ? w[j] : expect;
+            if (empty < 0 && plain < 0) expect &= ~kC3Flag;
+            if (atomicCAS(&c3.tags[base + way], expect, key) == expect) {
+                if (expect == 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(&c3.stat[0]), 1ull);
+                done = true;
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) c3_batch_insert_lists_kernel(const BatchArgs args, const C3Batch c3) {
+    const int r = blockIdx.x % kReplicas, part = blockIdx.x / kReplicas, parts = gridDim.x / kReplicas;
+    int n = args.vict_cnt[r];
+    if (n > args.vict_cap) n = args.vict_cap;
+    for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x)
+        c3_insert_key(c3, args.evicted_keys[(long long)r * args.vict_cap + i]);
+    __syncthreads();
+    // (the list is emptied by the close of the tier: see c3_lists_reset_kernel)
+}
+__global__ void c3_lists_reset_kernel(int *vict_cnt) { if (threadIdx.x < kReplicas) vict_cnt[threadIdx.x] = 0; }
+
 // Host-memory miss tier: after the fill (K5) every missed key that got an entry is served from its ARENA row, so
 // each missing row crosses the bus once (the de-duplicated fetch of K5) instead of once per request that asked
 // for it plus once for the fill.  One thread per (request, table) position; keys that found no room keep their
@@ -2118,13 +2200,14 @@ struct evs_cache {
     int fork_mode = -1;            // -1: not decided yet (EVS_CACHE_FORK, default off), 0 / 1
     long long batch_calls = 0, last_sweep_call = -100, last_hk_call = 0;
     int pending_batches = 0; long long pending_requests = 0;   // sampled update: batches whose counters the close has not folded yet
-    unsigned long long *evicted_keys = nullptr;   // batched three-tier lookup: what K4 evicted, for the alt-key tier   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
+    unsigned long long *evicted_keys = nullptr;   // batched three-tier lookup: what K4 evicted, for the alt-key tier
+    unsigned long long *vict_keys = nullptr; int *vict_cnt = nullptr; long long vict_cap = 0;   // ... what the sampled update evicted (kReplicas lists)   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
     int batch_policy = -1;         // policy update of the batched path: 0 plan-based (K2..K6), 1 sampled (one kernel); -1: EVS_CACHE_POLICY, default sampled
 };
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
-    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage, c->evicted_keys};
+    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage, c->evicted_keys, c->vict_keys, c->vict_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->host_tomb) (void)hipHostFree(c->host_tomb);
@@ -2453,7 +2536,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     // a few batches late is as good): past nslot / 8 the
     // table is swept (tombstones at the end of their chains become empty again); if the count is back there within
     // three calls the sweep did not help enough and the hash is rebuilt.
-    a.evicted_keys = nullptr; a.miss_rec = nullptr; a.list_cnt = nullptr; a.list_cap = 0;
+    a.evicted_keys = nullptr; a.vict_cnt = nullptr; a.vict_cap = 0; a.miss_rec = nullptr; a.list_cnt = nullptr; a.list_cap = 0;
     a.tomb_parity = -1;
     a.rebuild = 0;
     c->batch_calls++;   // = the ordinal of this call's close
@@ -2558,6 +2641,36 @@ static void batch_close(evs_cache *c, evs::BatchArgs a, hipStream_t st) {
     hipLaunchKernelGGL(cache_batch_close_kernel, dim3(1), dim3(256), 0, st, a);
     batch_housekeeping(c, a, st);
 }
+// the sampled update, compiled per row size (row_bytes = PIECES pieces of 16 / 8 / 4 / 2 bytes, at most 16 of them)
+template <int PIECES, typename U>
+static void launch_sampled_update_t(const evs::BatchArgs &a, hipStream_t st) {
+    using namespace evs;
+    if (a.miss_rec) hipLaunchKernelGGL((cache_batch_sampled_list_kernel<PIECES, U>), dim3((unsigned)a.g1), dim3(64), 0, st, a);   // K1 listed the misses: one wave per list
+    else hipLaunchKernelGGL((cache_batch_sampled_kernel<PIECES, U>), dim3((unsigned)a.g2), dim3(256), 0, st, a);
+}
+static void launch_sampled_update(const evs::BatchArgs &a, hipStream_t st) {
+    switch (a.row_bytes) {
+    case 144: launch_sampled_update_t<9, float4>(a, st); break;     // d = 36 fp32
+    case 256: launch_sampled_update_t<16, float4>(a, st); break;    // d = 64 fp32
+    case 128: launch_sampled_update_t<8, float4>(a, st); break;     // d = 32 fp32, d = 64 u16
+    case 64: launch_sampled_update_t<4, float4>(a, st); break;      // d = 16 fp32, d = 32 u16, d = 64 u8
+    case 32: launch_sampled_update_t<2, float4>(a, st); break;
+    case 16: launch_sampled_update_t<1, float4>(a, st); break;
+    case 72: launch_sampled_update_t<9, uint2>(a, st); break;       // d = 36 u16
+    case 36: launch_sampled_update_t<9, unsigned>(a, st); break;    // d = 36 u8
+    case 18: launch_sampled_update_t<9, unsigned short>(a, st); break;   // d = 36 u4
+    case 8: launch_sampled_update_t<1, uint2>(a, st); break;
+    default: launch_sampled_update_t<0, float4>(a, st); break;
+    }
+}
+
+static int resolved_batch_policy(evs_cache *c) {
+    if (c->batch_policy < 0) {
+        const char *e = getenv("EVS_CACHE_POLICY");
+        c->batch_policy = (e && e[0] == 'p') ? 0 : 1;   // "plan" / "sampled"
+    }
+    return c->batch_policy;
+}
 // sampled policy: fold the counters of the batches since the last close
 static void sampled_close_pending(evs_cache *c, int rebuild, hipStream_t st) {
     using namespace evs;
@@ -2639,11 +2752,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
                        "evs_cache_lookup_interact: needs an fp32 cache, a fused-kernel dimension and T <= 31");
     // consumers of the snapshot read the rows BEFORE the policy kernels move anything
     const bool file_mode = c->ft && c->staged_mask;
-    if (c->batch_policy < 0) {
-        const char *e = getenv("EVS_CACHE_POLICY");
-        c->batch_policy = (e && e[0] == 'p') ? 0 : 1;   // "plan" / "sampled"
-    }
-    if (c->batch_policy == 1 && !file_mode) {
+    if (resolved_batch_policy(c) == 1 && !file_mode) {
         // Sampled policy update: probe -> consumers -> ONE update kernel -> close.  (Host-memory miss tier: the update
         // first -- it fetches each missing row once -- then the re-pointed consumers.)
         if (!host_tier) a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;   // (host tier: set above, with the hit stamps)
@@ -2680,23 +2789,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
             EVS_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
             su = c->side;
         } else if (!host_tier) { const int rc = consumers(); if (rc) return rc; }
-        if (a.miss_rec) {   // K1 listed the misses: one wave per list
-            switch (a.row_bytes) {
-            case 144: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<9>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;    // d = 36 fp32
-            case 256: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<16>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;   // d = 64 fp32
-            case 128: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<8>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;
-            case 64: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<4>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;
-            default: hipLaunchKernelGGL(cache_batch_sampled_list_kernel<0>, dim3((unsigned)a.g1), dim3(64), 0, su, a); break;
-            }
-        } else {
-            switch (a.row_bytes) {
-            case 144: hipLaunchKernelGGL(cache_batch_sampled_kernel<9>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;    // d = 36 fp32
-            case 256: hipLaunchKernelGGL(cache_batch_sampled_kernel<16>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;   // d = 64 fp32
-            case 128: hipLaunchKernelGGL(cache_batch_sampled_kernel<8>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
-            case 64: hipLaunchKernelGGL(cache_batch_sampled_kernel<4>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
-            default: hipLaunchKernelGGL(cache_batch_sampled_kernel<0>, dim3((unsigned)a.g2), dim3(256), 0, su, a); break;
-            }
-        }
+        launch_sampled_update(a, su);
         if (fork) {
             EVS_HIP_CHECK(hipEventRecord(c->ev_join, c->side));
             const int rc = consumers(); if (rc) return rc;
@@ -2865,6 +2958,32 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
                         "evs_cache_lookup_batch_c1c2c3: alt-key table %d is shorter than the embedding table", k);
         }
     }
+    // both tiers on the sampled update (the default): the probe follows the parity rule of each tier's tombstones
+    const bool sampled2 = resolved_batch_policy(c1) == 1 && resolved_batch_policy(c2) == 1;
+    if (sampled2) {
+        for (int k = 0; k < 2; k++) {
+            evs_cache *c = k ? c2 : c1;
+            BatchArgs &a = k ? a2 : a1;
+            a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;
+            a.tomb_parity = a.stamp & 1;
+            sampled_flush_if_wanted(c, st);
+            if (c3) {   // victim lists for the alt-key tier: kReplicas lists, a block adds at most 256 keys to one of them
+                const long long need = ((long long)a.g2 + kReplicas - 1) / kReplicas * 256;
+                if (need > c->vict_cap) {
+                    EVS_HIP_CHECK(hipStreamSynchronize(st));
+                    if (c->vict_keys) (void)hipFree(c->vict_keys);
+                    c->vict_keys = nullptr; c->vict_cap = 0;
+                    EVS_HIP_CHECK(hipMalloc(&c->vict_keys, need * kReplicas * 8));
+                    c->vict_cap = need;
+                }
+                if (!c->vict_cnt) {
+                    EVS_HIP_CHECK(hipMalloc(&c->vict_cnt, kReplicas * 4));
+                    EVS_HIP_CHECK(hipMemsetAsync(c->vict_cnt, 0, kReplicas * 4, st));
+                }
+                a.evicted_keys = c->vict_keys; a.vict_cnt = c->vict_cnt; a.vict_cap = (int)c->vict_cap;
+            }
+        }
+    }
     hipLaunchKernelGGL(cache_batch_probe2_kernel, dim3((unsigned)a1.g1), dim3(256), 0, st, a1, a2, tt);
     if (out) {
         long long nb = (B * T * (long long)c1->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
@@ -2875,6 +2994,28 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         rc = interact_from_mixed_rows(B, T, c1->host.dim, x, x_stride, c1->row_ptrs, c1->row_tier, c1->host.codec, c2->host.codec,
                                       itself, R, st);
         if (rc) return rc;
+    }
+    if (sampled2) {
+        // one update kernel per tier (per-position form: the probe wrote a record per (request, table) and tier); the
+        // routing reads each tier's entry count, so the counters are folded every batch here
+        for (int k = 0; k < 2; k++) {
+            BatchArgs &a = k ? a2 : a1;
+            if (k) { a.other_slots = c1->bslots; a.other_mask = (unsigned long long)(c1->bnslot - 1); }   // a key C1 just took is not inserted in C2 too
+            launch_sampled_update(a, st);
+            if (c3) {
+                hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(kReplicas * 8), dim3(256), 0, st, a, tt.c3);
+                hipLaunchKernelGGL(c3_lists_reset_kernel, dim3(1), dim3(64), 0, st, a.vict_cnt);
+            }
+        }
+        for (int k = 0; k < 2; k++) {
+            evs_cache *c = k ? c2 : c1;
+            BatchArgs &a = k ? a2 : a1;
+            c->pending_batches++; c->pending_requests += B;
+            sampled_close_pending(c, a.rebuild, st);
+            batch_housekeeping(c, a, st);
+        }
+        EVS_HIP_CHECK(hipGetLastError());
+        return EVS_OK;
     }
     batch_policy(c1, a1, st);
     if (c3) hipLaunchKernelGGL(c3_batch_insert_kernel, dim3((unsigned)a1.g2), dim3(256), 0, st, a1, tt.c3);   // what C1 evicted

@@ -543,8 +543,9 @@ def test_cache_lookup_interact_equals_rows_then_interact(E, orc, policy):
     assert c.batch_stats()["n_hits"] > 0
 
 
+@pytest.mark.parametrize("policy", POLICIES)
 @pytest.mark.parametrize("thr", [23, 20])
-def test_batched_two_tier_c1c2(E, orc, thr):
+def test_batched_two_tier_c1c2(E, orc, thr, policy):
     """Batched C1 (u8) + C2 (u4) lookup, snapshot semantics: tier flags = residency when the batch starts; rows at
     the precision of the tier that serves them (hit) or of the destination tier (miss, routed by the reference's
     rule on the snapshot); no key in both tiers; C2 untouched until C1 is full; histograms consistent."""
@@ -557,8 +558,8 @@ def test_batched_two_tier_c1c2(E, orc, thr):
     dec8 = [orc.decode(r, 8, d) for r in raw8]
     dec4 = [orc.decode(r, 4, d) for r in raw4]
     cap1, cap2 = 500, 900
-    c1 = E.GpuCache("evlfu", cap1, T, d, 8, "cpp")
-    c2 = E.GpuCache("evlfu", cap2, T, d, 4, "cpp")
+    c1 = E.GpuCache("evlfu", cap1, T, d, 8, "cpp").set_batch_policy(policy)
+    c2 = E.GpuCache("evlfu", cap2, T, d, 4, "cpp").set_batch_policy(policy)
     c1.set_backing([torch.from_numpy(r).cuda() for r in raw8])
     c2.set_backing([torch.from_numpy(r).cuda() for r in raw4])
     reqs = np.minimum(rs.zipf(1.25, size=(3000, T)) - 1, n - 1).astype(np.int32)
@@ -616,8 +617,9 @@ def test_batched_two_tier_c1c2(E, orc, thr):
                 assert np.array_equal(rb[b, k].view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("policy", POLICIES)
 @pytest.mark.parametrize("codecs,d", [((8, 4), 36), ((32, 8), 36), ((32, 4), 32), ((8, 4), 16)])
-def test_two_tier_mixed_codec_interaction_consumer(E, orc, codecs, d):
+def test_two_tier_mixed_codec_interaction_consumer(E, orc, codecs, d, policy):
     """configs[4] end to end without the fp32 (B,T,d) rows: evs_cache_lookup_interact_c1c2 decodes every row from the
     precision of the tier that serves it inside the interaction kernel.  Which tier serves a MISS depends on the
     routing, so the tables hold only values every codec represents exactly (-1, 0, 1: u8 codes 0 / 127 / 254, u4 codes
@@ -632,8 +634,8 @@ def test_two_tier_mixed_codec_interaction_consumer(E, orc, codecs, d):
     raws = {c: [orc.encode_table(w, c) for w in ws] for c in codecs}
     for c in codecs:
         assert all(np.array_equal(orc.decode(raws[c][k], c, d), ws[k]) for k in range(T))
-    c1 = E.GpuCache("evlfu", 400, T, d, codecs[0], "cpp")
-    c2 = E.GpuCache("evlfu", 900, T, d, codecs[1], "cpp")
+    c1 = E.GpuCache("evlfu", 400, T, d, codecs[0], "cpp").set_batch_policy(policy)
+    c2 = E.GpuCache("evlfu", 900, T, d, codecs[1], "cpp").set_batch_policy(policy)
     c1.set_backing([torch.from_numpy(a).cuda() for a in raws[codecs[0]]])
     c2.set_backing([torch.from_numpy(a).cuda() for a in raws[codecs[1]]])
     B = 333
@@ -742,8 +744,9 @@ def test_zz_cpp_socket_client_mirror(E, orc, tmp_path):
     assert int(cli.cache_manager_cpp.evs_manager_perfect_hit()) == 0
 
 
+@pytest.mark.parametrize("policy", POLICIES)
 @pytest.mark.parametrize("codecs,d", [((8, 4), 36), ((32, 8), 16)])
-def test_batched_three_tier_c1c2c3(E, orc, codecs, d):
+def test_batched_three_tier_c1c2c3(E, orc, codecs, d, policy):
     """f2 / configs[4]: the batched three-tier lookup (evs_cache_lookup_batch_c1c2c3 / _interact_c1c2c3), snapshot
     semantics.  Tier codes against the state before the call: 1 / 2 = resident in C1 / C2; 3 = a double miss whose key is
     a member of C3 and whose ALT row is resident in C1 (else C2) -- that row is served, at the precision of the tier
@@ -761,8 +764,8 @@ def test_batched_three_tier_c1c2c3(E, orc, codecs, d):
     # alt key of (table t, row r): the hot row r % 8 of table (t + 1) % T  (alt_row * 100 + alt_table_1based)
     alt = [np.array([(r % 8) * 100 + ((t + 1) % T + 1) for r in range(n)], dtype=np.uint32) for t in range(T)]
     cap1, cap2, cap3 = 400, 700, 800
-    c1 = E.GpuCache("evlfu", cap1, T, d, codecs[0], "cpp")
-    c2 = E.GpuCache("evlfu", cap2, T, d, codecs[1], "cpp")
+    c1 = E.GpuCache("evlfu", cap1, T, d, codecs[0], "cpp").set_batch_policy(policy)
+    c2 = E.GpuCache("evlfu", cap2, T, d, codecs[1], "cpp").set_batch_policy(policy)
     c1.set_backing([torch.from_numpy(a).cuda() for a in raws[codecs[0]]])
     c2.set_backing([torch.from_numpy(a).cuda() for a in raws[codecs[1]]])
     c3 = E.GpuAltKeyTier(cap3, [torch.from_numpy(a.view(np.int32)).cuda() for a in alt])

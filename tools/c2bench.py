@@ -13,12 +13,12 @@ c2 = E.GpuCache("evlfu", int(0.48 * budget) * 8, T, d, 4, "cpp", dev)
 c1.set_backing(ev8); c2.set_backing(ev4)
 B = 16384
 out = torch.empty((B, T, d), device=dev); tier = torch.empty((B, T), dtype=torch.uint8, device=dev)
-bs = bench.make_batches(ln, B, 100, seed=21, device=dev, dist="zipf", alpha=0.75)
+bs = bench.make_batches(ln, B, 200, seed=21, device=dev, dist="zipf", alpha=0.75)   # 180 to fill both tiers, 20 timed
 rq = [b[1].t().contiguous().to(torch.int32) for b in bs]
-for r in rq[:80]:
+for r in rq[:180]:
     gpu_cache.lookup_batch_c1c2(c1, c2, r, out=out, tier=tier)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for r in rq[80:]:
+for r in rq[180:]:
     gpu_cache.lookup_batch_c1c2(c1, c2, r, out=out, tier=tier)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("two-tier batched, fp32 rows out: %.1f us per batch, %.2f G lookups/s, C1 %d C2 %d resident" % (dt / 20 * 1e6, T * B * 20 / dt / 1e9, c1.batch_stats()["size"], c2.batch_stats()["size"]))

@@ -220,8 +220,10 @@ def batched2_case(rs, case):
     B = int(rs.choice([1, 30, 250, 900]))
     n_batches = int(rs.choice([3, 8, 14]))
     tag = "batched two-tier case %d: n=%d cap1=%d cap2=%d thr=%d B=%d batches=%d" % (case, n, cap1, cap2, thr, B, n_batches)
-    c1 = E.GpuCache("evlfu", cap1, T, d, 8, "cpp")
-    c2 = E.GpuCache("evlfu", cap2, T, d, 4, "cpp")
+    policy = str(rs.choice(["sampled", "sampled", "plan"]))
+    tag += " policy=%s" % policy
+    c1 = E.GpuCache("evlfu", cap1, T, d, 8, "cpp").set_batch_policy(policy)
+    c2 = E.GpuCache("evlfu", cap2, T, d, 4, "cpp").set_batch_policy(policy)
     c1.set_backing([torch.from_numpy(r).cuda() for r in raw8])
     c2.set_backing([torch.from_numpy(r).cuda() for r in raw4])
     reqs = _stream(rs, [n] * T, B * n_batches)
@@ -275,8 +277,10 @@ def batched3_case(rs, case):
     n_batches = int(rs.choice([4, 12]))
     tag = "batched three-tier case %d: T=%d d=%d n=%d codecs=%d/%d caps=%d/%d/%d thr=%d B=%d batches=%d" % (
         case, T, d, n, ca, cb, cap1, cap2, cap3, thr, B, n_batches)
-    c1 = E.GpuCache("evlfu", cap1, T, d, ca, "cpp")
-    c2 = E.GpuCache("evlfu", cap2, T, d, cb, "cpp")
+    policy = str(rs.choice(["sampled", "sampled", "plan"]))
+    tag += " policy=%s" % policy
+    c1 = E.GpuCache("evlfu", cap1, T, d, ca, "cpp").set_batch_policy(policy)
+    c2 = E.GpuCache("evlfu", cap2, T, d, cb, "cpp").set_batch_policy(policy)
     c1.set_backing([torch.from_numpy(a).cuda() for a in raws[ca]])
     c2.set_backing([torch.from_numpy(a).cuda() for a in raws[cb]])
     c3 = E.GpuAltKeyTier(cap3, [torch.from_numpy(a.view(np.int32)).cuda() for a in alt])
