@@ -1701,7 +1701,7 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
             tried |= 1u << best;
             const long long e = e0 + best;
             if (atomicCAS(&args.a.ekey[e], bk, kClaimed) == bk) {   // else somebody else was faster
-                if ((bk & kKeyMask) != kEmpty) st_agent(&args.slots[bs], args.tomb_parity ? kTomb1 : kTomb);
+                if ((bk & kKeyMask) != kEmpty) args.slots[bs] = args.tomb_parity ? kTomb1 : kTomb;   // (plain: a walker that still sees the old key walks on, as it would have)
                 old_prio = bp;
                 old_key = bk & kKeyMask;
                 result = (int)e;
@@ -1777,7 +1777,7 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
         }
         if (!placed) {
             if ((w & kKeyMask) == key) placed = 2;
-            else { i = (i + 1) & args.mask; w = ld_agent(&args.slots[i]); }   // somebody else's key, or not for re-use: next slot
+            else { i = (i + 1) & args.mask; w = args.slots[i]; }   // somebody else's key, or not for re-use: next slot (a plain read: the CAS is the arbiter)
         }
     }
     if (placed != 1) return;
@@ -1804,7 +1804,7 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
         g = g + 1 == n_groups ? 0 : g + 1;
     }
     if (e < 0) {   // nothing claimable anywhere (a cache smaller than the batch's keys): the key is not kept
-        st_agent(&args.slots[i], my_tomb);
+        args.slots[i] = my_tomb;
         atomicAdd(&s_stat[2], 1);
         return;
     }
@@ -1836,8 +1836,11 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
     args.a.eagg[e] = agg;
     args.eslot[e] = (int)i;
-    st_agent(&args.a.ekey[e], key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits));
-    st_agent(&args.slots[i], make_word(key, (unsigned)e));
+    // (plain stores: whoever looks at these words during the launch either sees the old value -- a claimed entry, the
+    //  pending word of this key -- or the new one, and both mean "not yours"; 255 k returning-or-not atomics per batch
+    //  at the memory side were a third of this kernel)
+    args.a.ekey[e] = key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits);
+    args.slots[i] = make_word(key, (unsigned)e);
     atomicAdd(&s_delta[agg], 1);
 }
 
