@@ -1009,10 +1009,12 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         const int agg = __popc(hmask);
         // monotone max like update_agg_hit; the plain read first keeps hot entries (thousands of requests of
         // one batch hit the same few rows of the tiny tables) from serialising on one atomic address
+#ifndef EVS_X_NOPRIO   // developer A/B (timing only): what the priority read per hit costs the probe
         if (e >= 0 && args.a.eagg[e] < agg) {
             const int old = atomicMax(&args.a.eagg[e], agg);
             if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
         }
+#endif
         if (args.stamp_hits && e >= 0) args.estamp[e] = args.stamp;
         // where the row lives right now: arena for a hit, backing store for a miss, 0 for a bad row id
         const unsigned char *src = nullptr;
