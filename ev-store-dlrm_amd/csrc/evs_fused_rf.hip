@@ -370,10 +370,17 @@ static int rf_mode() {
     return v;
 }
 
+// developer switch: bytes of dynamic LDS added to every block, i.e. fewer blocks per CU (27 KB static: 4 per CU; +20 KB: 3;
+// +40 KB: 2) -- does a launch whose blocks arrive in two waves overlap its own fill and drain?
+static unsigned rf_pad_lds() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_RF_PADLDS"); v = e ? atoi(e) : 0; }
+    return (unsigned)v;
+}
 template <auto K>
 static void launch_rf_grid(FusedArgs a, hipStream_t st) {
     a.tile_per = 16;   // one 16-sample chunk per block: 4 samples per wave, all requested at once
-    hipLaunchKernelGGL(K, dim3((unsigned)((a.B + 15) / 16)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(K, dim3((unsigned)((a.B + 15) / 16)), dim3(256), rf_pad_lds(), st, a);
 }
 
 // the batch sizes this form is for: every block resident at once (4 blocks of 256 threads per CU at 128 VGPRs)
