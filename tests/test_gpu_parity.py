@@ -924,3 +924,51 @@ def test_bag_sum_null_offsets_is_the_one_index_row_gather(E, orc, codec, d, B):
     _lib.check(L.evs_embedding_bag_sum(T, B, d, codec, tp, nr, ipb, None, nz, None, send3.data_ptr(), d, T * d, st))
     assert L.evs_check_index_errors(st) != 0
     assert float(send3[B // 2, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_hip_one_index_per_bag_virtual_ranks_vs_oracle(E, orc, world):
+    """The configuration bench.py --gpus N runs: ShardedEmbeddingInteract(one_index_per_bag=True) on the HIP backend -- the
+    pool of the owned tables is the offsets-free row gather (evs_embedding_bag_sum with offsets == NULL), the replicated
+    tables go into the interaction kernel as indirect features without offsets, eager and planned steps -- with `world`
+    virtual ranks on one GPU and the exchange done by hand: send layout bit-equal to the oracle's pooled rows, R of every
+    rank within 1e-5 of the oracle on its batch slice."""
+    from evstore_dlrm_amd import sharded
+    rs = np.random.RandomState(70 + world)
+    ln = [5000, 3, 1_200_000, 40, 2_000_000, 17, 900, 1_500_000]
+    d, Bl = 36, 64
+    Bg = world * Bl
+    T = len(ln)
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    idx = [rs.randint(0, n, size=Bg).astype(np.int64) for n in ln]
+    off = np.arange(Bg, dtype=np.int64)
+    lS_i = [torch.from_numpy(i).cuda() for i in idx]
+    lS_o = [torch.from_numpy(off).cuda() for _ in ln]
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(Bg, d)).astype(np.float32)).cuda()
+    ly_o = orc.apply_emb([off] * T, idx, tabs)
+    R_o = orc.interact_features(x.cpu().numpy(), ly_o)
+    for policy in ("rows+replicate", "rows"):
+        ops = []
+        for r in range(world):
+            owner = sharded.plan_placement(ln, world, policy, replicate_max_rows=1_000_000)
+            held = {t: torch.from_numpy(tabs[t]) for t in range(T) if owner[t] in (r, -1)}
+            ops.append(sharded.ShardedEmbeddingInteract(ln, d, r, world, held, sharded.HipBackend(torch.device("cuda")),
+                                                        policy=policy, replicate_max_rows=1_000_000, one_index_per_bag=True))
+        assert any(op.any_sharded for op in ops)
+        sends = [op.pool(lS_o, lS_i)[0] for op in ops]
+        torch.cuda.synchronize()
+        for op, send in zip(ops, sends):
+            for j, t in enumerate(op.my_own):
+                assert np.array_equal(send[:, j, :].cpu().numpy().view(np.uint32), ly_o[t].view(np.uint32)), (policy, t)
+        for r, op in enumerate(ops):
+            _, _, out_splits = op._splits(Bg)
+            recv = torch.cat([sends[p][r * Bl:(r + 1) * Bl].reshape(-1) for p in range(world)])
+            R = op.finish((None, recv, Bg, Bl, out_splits), x[r * Bl:(r + 1) * Bl], lS_o, lS_i)
+            np.testing.assert_allclose(R.cpu().numpy(), R_o[r * Bl:(r + 1) * Bl], rtol=RTOL, atol=2e-6)
+            # the planned form (what the bench loop runs): the pool into this rank's send buffer, the exchange by hand
+            # into its receive buffer, the interaction from the plan
+            out = torch.empty_like(R)
+            pl = op.plan(x[r * Bl:(r + 1) * Bl], lS_o, lS_i, out=out)
+            pl["recv"].copy_(recv)
+            op.run_finish(pl, None)
+            assert torch.equal(out, R), (policy, r)
