@@ -830,3 +830,35 @@ def test_batched_three_tier_c1c2c3(E, orc, codecs, d, policy):
     with pytest.raises(E.EvsError):
         gpu_cache.request_c1c2c3(E.GpuCache("evlfu", 50, T, d, codecs[0], "cpp"), E.GpuCache("evlfu", 50, T, d, codecs[1], "cpp"), c3,
                                  torch.zeros((1, T), dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("policy,cap,B", [("sampled", 9_000_000, 60_000), ("plan", 9_000_000, 60_000), ("sampled", 400_000, 70_001),
+                                            ("plan", 400_000, 70_001)])
+def test_batched_cache_above_the_slot_hint_range(E, orc, policy, cap, B):
+    """A cache whose hash has more than 2^24 slots (9 M entries): the probe's slot hints no longer fit their 24 bits, the
+    inserts walk from the key's home slot instead -- and a batch above 65 536 requests (the probe's blocks loop, their
+    miss lists hold more than one round): same invariants (rows exact, hit flags = residency at batch start, no
+    duplicate keys, size <= capacity, histogram consistent)."""
+    T, d, n = 4, 16, 3_000_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    tabs = [torch.rand((n, d), generator=g, device="cuda") for _ in range(T)]
+    c = E.GpuCache("evlfu", cap, T, d, 32, "python").set_batch_policy(policy)
+    c.set_backing(tabs)
+    rs = np.random.RandomState(9)
+    resident = set()
+    for it in range(4):
+        hot = rs.rand(B, T) < 0.5
+        rq = np.where(hot, rs.randint(0, 50_000, size=(B, T)), rs.randint(0, n, size=(B, T))).astype(np.int32)
+        r = torch.from_numpy(rq).cuda()
+        hit, out = c.lookup_batch(r)
+        for k in range(T):
+            assert torch.equal(out[:, k, :], tabs[k][r[:, k].long()]), (it, k)
+        hit = hit.cpu().numpy().astype(bool)
+        want = np.array([[(k + 1, int(rq[b, k])) in resident for k in range(T)] for b in range(0, B, 37)])
+        assert np.array_equal(hit[::37], want), it
+        dmp, st = c.batch_dump(), c.batch_stats()
+        keys = {(int(t), int(rw)) for _, t, rw in dmp}
+        assert len(keys) == len(dmp) == st["size"] <= cap
+        assert np.array_equal(np.bincount(dmp[:, 0], minlength=T + 1), np.array(st["hist"]))
+        assert all((k + 1, int(rq[b, k])) in keys for b in range(0, B, 101) for k in range(T) if not hit[b, k])
+        resident = keys
