@@ -22,6 +22,7 @@
 //     all lanes (arena -> out for hits, backing store -> out and -> arena for inserts).
 //   * cache_probe_gather_kernel (batched, snapshot semantics) -- see the section below.
 #include "evs_common.h"
+#include "evs_hash.h"
 
 #include <mutex>
 #include <vector>
@@ -33,8 +34,6 @@
 namespace evs {
 
 constexpr int kMaxTables = 64;      // one lane per table
-constexpr int kMaxBuckets = 65;     // EvLFU priorities 0..n_tables
-constexpr unsigned long long kEmpty = 0ull;
 
 enum Policy { kEvLFU = 0, kLRU = 1, kLFU = 2 };
 
@@ -76,10 +75,6 @@ struct CacheArgs {
     int approx_thres;
 };
 
-__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
-    return x;
-}
 
 // agent-scope accesses: the probing lanes must see what lane 0 wrote in the previous request
 template <typename T>
@@ -823,24 +818,6 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
 // The priority lists of the exact path are NOT maintained here: a cache object is used either
 // exactly (evs_cache_request) or batched (evs_cache_lookup_batch), never both.
 // ------------------------------------------------------------------------------------------
-constexpr unsigned long long kTomb = ~0ull;
-// second tombstone value (sampled policy update: tombstones written in batches of odd parity, see there); neither
-// value can equal a key (table field 63)
-constexpr unsigned long long kTomb1 = ~0ull - 1ull;
-constexpr int kPending = -2;
-// The batched path keeps its own hash: ONE 8-byte word per slot = key (38 bits: (table+1) << 32 | row)
-// | entry index (26 bits), so a probe is a single random access and the table for 3.4 M entries is
-// 64 MiB (it stays inside the 256 MiB Infinity Cache; a 4x larger table measured 2.5x slower).  While a
-// key is being inserted the entry field carries kFieldPend + its pending priority, so the duplicates of
-// one batch fold their agg_hit into the word with a 64-bit atomicMax.  kEmpty = 0 and kTomb = ~0 are
-// not valid keys (table+1 is in 1..32).
-constexpr int kKeyBits = 38;
-constexpr unsigned long long kKeyMask = (1ull << kKeyBits) - 1ull;
-constexpr unsigned kFieldPend = (1u << (64 - kKeyBits)) - 128u;
-constexpr long long kMaxBatchedCap = (long long)kFieldPend - 1;
-__device__ __forceinline__ unsigned long long make_word(unsigned long long key, unsigned field) {
-    return key | ((unsigned long long)field << kKeyBits);
-}
 
 struct BatchState {
     int n_miss, n_new, n_free, count, n_tomb;
@@ -896,37 +873,6 @@ struct BatchArgs {
     unsigned long long *evicted_keys;   // (alt-key tier attached) the key each free-stack position held before K4 put it there; bit 63 = flushed, not evicted
     int tomb_parity;                // sampled update: parity of this batch (its tombstones are kTomb1 when odd); -1 otherwise
 };
-
-// Read-only probe.  Found: the entry (or kPending) and end_slot = the key's slot.  Not found: -1 and end_slot = the
-// first slot of the chain an insert of this key may take -- the first tombstone the walk passed, else the empty word
-// it ended on (K2 starts its claim there instead of walking the chain again).
-__device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigned long long mask, unsigned long long key,
-                                        unsigned long long &end_slot, unsigned long long reusable_tomb = kTomb,
-                                        bool *hint_is_tomb = nullptr) {
-    unsigned long long i = mix64(key) & mask;
-    long long first_tomb = -1;
-    if (hint_is_tomb) *hint_is_tomb = false;
-    // bounded: a batch with more unique new keys than free slots (tiny cache, huge batch) can leave the table without
-    // an empty word until the next rebuild -- the walk then ends after one lap instead of never
-    for (unsigned long long steps = 0; steps <= mask; steps++) {
-        const unsigned long long w = slots[i];
-        if ((w & kKeyMask) == key) {
-            end_slot = i;
-            const unsigned f = (unsigned)(w >> kKeyBits);
-            return f >= kFieldPend ? kPending : (int)f;
-        }
-        if (w == kEmpty) {
-            end_slot = first_tomb >= 0 ? (unsigned long long)first_tomb : i;
-            if (hint_is_tomb) *hint_is_tomb = first_tomb >= 0;
-            return -1;
-        }
-        if (w == reusable_tomb && first_tomb < 0) first_tomb = (long long)i;
-        i = (i + 1) & mask;  // tombstones and other keys: keep walking
-    }
-    end_slot = first_tomb >= 0 ? (unsigned long long)first_tomb : i;
-    if (hint_is_tomb) *hint_is_tomb = first_tomb >= 0;
-    return -1;
-}
 
 // One atomic per BLOCK instead of one per thread: every thread of the block calls this in uniform
 // control flow; threads with flag set get consecutive indices starting at the value the block
@@ -1882,7 +1828,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
 // mostly busy lanes instead of 6 656 waves with one lane in eight busy, and everything a miss needs arrives with its
 // record (the per-position form reads the probe word, then the request row, then starts).
 template <int PIECES, typename U>
-__global__ void __launch_bounds__(64) cache_batch_sampled_list_kernel(const BatchArgs args) {
+__global__ void __launch_bounds__(128) cache_batch_sampled_list_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
@@ -2650,7 +2596,8 @@ static void batch_close(evs_cache *c, evs::BatchArgs a, hipStream_t st) {
 template <int PIECES, typename U>
 static void launch_sampled_update_t(const evs::BatchArgs &a, hipStream_t st) {
     using namespace evs;
-    if (a.miss_rec) hipLaunchKernelGGL((cache_batch_sampled_list_kernel<PIECES, U>), dim3((unsigned)a.g1), dim3(64), 0, st, a);   // K1 listed the misses: one wave per list
+    // K1 listed the misses: one wave per list (two when the lists are those of the folded probe's 16-sample blocks: twice as long)
+    if (a.miss_rec) hipLaunchKernelGGL((cache_batch_sampled_list_kernel<PIECES, U>), dim3((unsigned)a.g1), dim3(a.list_cap > 8 * a.T ? 128 : 64), 0, st, a);
     else hipLaunchKernelGGL((cache_batch_sampled_kernel<PIECES, U>), dim3((unsigned)a.g2), dim3(256), 0, st, a);
 }
 static void launch_sampled_update(const evs::BatchArgs &a, hipStream_t st) {
@@ -2787,9 +2734,26 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
                 EVS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
             }
         }
+        // the probe inside the consumer: one launch instead of two when the consumer is the rows-in-registers kernel
+        // (EVS_CACHE_FOLD=0: the two-launch form)
+        static const bool fold_on = !(getenv("EVS_CACHE_FOLD") && getenv("EVS_CACHE_FOLD")[0] == '0');
+        const bool fold = fold_on && a.row_ids && a.miss_rec && !fork && R && !out;
+        if (fold) {
+            ProbeArgs pa;
+            pa.slots = a.slots; pa.mask = a.mask; pa.reusable_tomb = a.tomb_parity ? kTomb : kTomb1;
+            pa.eagg = a.a.eagg; pa.requests = rows; pa.hit = hit;
+            pa.miss_rec = a.miss_rec; pa.list_cnt = a.list_cnt; pa.list_cap = 16 * T;
+            pa.part1 = a.part1; pa.hint_shift = a.hint_shift; pa.T = T;
+            a.list_cap = 16 * T;
+            a.g1 = (int)((B + 15) / 16);   // the update kernel runs one wave per list: here a list per 16-sample block
+            const int rc = fused_probe_interact(B, T, c->host.dim, x, x_stride, pa, c->a.arena,
+                                                reinterpret_cast<const void *const *>(c->backing), c->backing_rows, itself, R, st);
+            if (rc) return rc;
+        } else
         hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)a.g1), dim3(256), 0, st, a);
         hipStream_t su = st;
-        if (fork) {
+        if (fold) {
+        } else if (fork) {
             EVS_HIP_CHECK(hipEventRecord(c->ev_fork, st));
             EVS_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
             su = c->side;

@@ -1,6 +1,7 @@
 // Shared between the fused gather + interaction kernels (evs_fused.hip, evs_fused_rf.hip).
 #pragma once
 #include "evs_common.h"
+#include "evs_hash.h"
 
 namespace evs {
 
@@ -36,6 +37,9 @@ struct FusedArgs {
     // bit 30 set: row (id & 0x3fffffff) of `arena`; clear: row id of the feature's own table src[f]; -1: the zero row
     const int *row_ids;
     const void *arena;
+    // ... or the kernel probes the cache itself (PROBE variant): the (B, F-1) request rows in, hit flags, miss lists and
+    // hit statistics out -- cache_batch_probe_gather_kernel folded into the head of this launch
+    ProbeArgs probe;
 };
 
 
@@ -50,5 +54,7 @@ bool launch_rf_mlp(const FusedArgs &a, hipStream_t st);
 // kernel for this shape (the probe kernel has to know which table to write before the consumer is launched)
 bool rf_ids_supported(int64_t B, int F, int d);
 bool launch_rf_ids(const FusedArgs &a, hipStream_t st);
+// ... probing the cache itself (FusedArgs::probe filled in); same shapes as launch_rf_ids; one block per 16 samples
+bool launch_rf_probe(const FusedArgs &a, hipStream_t st);
 
 }  // namespace evs

@@ -1276,8 +1276,34 @@ int fused_interact_from_row_ids(int64_t B, int T, int d, const float *x, int64_t
     a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
     a.dummy_i64 = reinterpret_cast<const int64_t *>(a.zeros); a.dummy_f32 = x; a.bag1 = 1; a.enc_lds = 0; a.opt_flag = nullptr; a.opt_id = 0;
     a.w1p = nullptr; a.b1 = nullptr; a.z1 = nullptr; a.n1 = 0; a.kp = 0; a.relu = 0; a.write_r = 1;
-    a.row_ids = row_ids; a.arena = arena;
+    a.row_ids = row_ids; a.arena = arena; a.probe = ProbeArgs{};
     if (!launch_rf_ids(a, st)) { set_error("fused_interact_from_row_ids: no kernel for B=%lld T=%d d=%d", (long long)B, T, d); return EVS_EINVAL; }
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
+}
+
+// ... and with the cache probe folded in (evs_fused_rf.hip, PROBE variant): the request rows in, R, hit flags, the miss
+// lists and the hit statistics out.  One block per 16 samples: probe.list_cnt needs ceil(B / 16) entries, probe.miss_rec
+// ceil(B / 16) * probe.list_cap records with list_cap >= 16 * T.
+int fused_probe_interact(int64_t B, int T, int d, const float *x, int64_t x_stride, const ProbeArgs &probe, const void *arena,
+                         const void *const *tables, const long long *table_rows, int itself, float *R, hipStream_t st) {
+    FusedArgs a;
+    const int F = T + 1;
+    for (int f = 0; f < EVS_MAX_FEATURES; f++) {
+        a.src[f] = nullptr; a.stride[f] = 0; a.indices[f] = nullptr; a.offsets[f] = nullptr; a.nnz[f] = 0;
+        a.n_rows[f] = 0; a.row_w[f] = nullptr; a.off_len[f] = B;
+    }
+    a.zeros = zero_page();
+    a.err = index_error_flag();
+    if (!a.zeros || !a.err) return EVS_EHIP;
+    a.src[0] = x; a.stride[0] = x_stride;
+    for (int k = 0; k < T; k++) { a.src[k + 1] = tables[k]; a.n_rows[k + 1] = table_rows[k]; }
+    a.R = R; a.B = B; a.F = F; a.d = d; a.itself = itself ? 1 : 0;
+    a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    a.dummy_i64 = reinterpret_cast<const int64_t *>(a.zeros); a.dummy_f32 = x; a.bag1 = 1; a.enc_lds = 0; a.opt_flag = nullptr; a.opt_id = 0;
+    a.w1p = nullptr; a.b1 = nullptr; a.z1 = nullptr; a.n1 = 0; a.kp = 0; a.relu = 0; a.write_r = 1;
+    a.row_ids = nullptr; a.arena = arena; a.probe = probe;
+    if (!launch_rf_probe(a, st)) { set_error("fused_probe_interact: no kernel for B=%lld T=%d d=%d", (long long)B, T, d); return EVS_EINVAL; }
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
 }

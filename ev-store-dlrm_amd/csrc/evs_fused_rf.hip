@@ -56,7 +56,10 @@ constexpr int kMlpRowStride = 452;   // floats per staged row: kp <= 448 (F <= 2
 // IDS: the cache tier's consumer -- features 1..F-1 come as one (B, F-1) int32 table of row ids (FusedArgs::row_ids): bit 30
 // says "row of the cache arena", else the row of the feature's own table; 4 bytes per key instead of an 8-byte address,
 // and the rows travel exactly as in the plain launch.
-template <int CQ, int REM, int NT, int D, bool MLP = false, bool IDS = false>
+// PROBE (implies IDS): the kernel reads the REQUEST rows and probes the cache's hash itself in its head -- what
+// cache_batch_probe_gather_kernel does as a launch of its own (hash probe, agg_hit per request, priority bump, hit flags,
+// the block's miss list for the update kernel, hit statistics) -- and goes on with the ids it found.
+template <int CQ, int REM, int NT, int D, bool MLP = false, bool IDS = false, bool PROBE = false>
 __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_kernel(const FusedArgs args) {
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     if (threadIdx.x < 32) {
         const int f = (int)threadIdx.x;
         const int64_t *ip = f < F ? ka->indices[f] : nullptr;
-        const bool table = IDS ? (f >= 1 && f < F) : ip != nullptr;
+        const bool table = (IDS || PROBE) ? (f >= 1 && f < F) : ip != nullptr;
         s_tile_p[f] = ip;
         s_tile_nr[f] = f < F ? (unsigned)ka->n_rows[f] : 0u;
         s_tile_kind[f] = f >= F ? 0 : (table ? 2 : 1);
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             const unsigned neg = (unsigned)(iv >> 31) | phantom;
             unsigned long long base = s_feat_base[r];
             unsigned idx = (unsigned)iv & ~neg;
-            if constexpr (IDS) {   // bit 30: a row of the cache arena (bit blend, as below: no select over LDS reads)
+            if constexpr (IDS || PROBE) {   // bit 30: a row of the cache arena (bit blend, as below: no select over LDS reads)
                 const unsigned long long in_arena = 0ull - (unsigned long long)((idx >> 30) & 1u);
                 base ^= (base ^ (unsigned long long)reinterpret_cast<uintptr_t>(args.arena)) & in_arena;
                 idx &= 0x3fffffffu;
@@ -242,9 +245,78 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     // once; the samples are consumed in order as their rows arrive (counted vmcnt: no branch, so hipcc's waitcnt
     // insertion keeps the younger samples in flight); the output row of sample u leaves under the MFMAs of sample u+1.
     static_assert(D == 4, "a block owns one 16-sample chunk: 4 samples per wave");
-    tile_load(0);
-    tile_store(0);
-    __syncthreads();
+    if constexpr (PROBE) {
+        // ---- the cache probe, folded in: thread e (and e + 256) owns key (table (e >> 4) - 1, sample e & 15) -------------
+        __shared__ int s_agg[16];                 // hits per request of the chunk
+        __shared__ int s_pdelta[kMaxBuckets];     // priority histogram moves
+        __shared__ int s_psum[2];                 // hits / perfect requests
+        __shared__ int s_nlist;                   // misses listed
+        const ProbeArgs &pa = args.probe;
+        const int T = pa.T;
+        for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_pdelta[i] = 0;
+        if (threadIdx.x < 16) s_agg[threadIdx.x] = 0;
+        if (threadIdx.x < 2) s_psum[threadIdx.x] = 0;
+        if (threadIdx.x == 0) s_nlist = 0;
+        __syncthreads();
+        int pe[2], prow[2];
+        unsigned phint[2];
+        bool pok[2], ptomb[2], pact[2];
+        const int64_t bs = blk_first + (threadIdx.x & 15);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            pact[h] = f >= 1 && f < F && bs < blk_end;
+            const int *rp = pact[h] ? pa.requests + bs * (int64_t)T + (f - 1) : reinterpret_cast<const int *>(dummy_i);
+            prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
+            pok[h] = pact[h] && prow[h] >= 0 && (unsigned)prow[h] < s_tile_nr[f];
+            pe[h] = -1; phint[h] = 0; ptomb[h] = false;
+            if (pok[h]) {
+                const unsigned long long key = ((unsigned long long)f << 32) | (unsigned)prow[h];   // table_1based = f
+                unsigned long long end_slot = 0;
+                bool ht = false;
+                int e = probe_ro(pa.slots, pa.mask, key, end_slot, pa.reusable_tomb, &ht);
+                if (e == kPending) e = -1;
+                pe[h] = e; phint[h] = (unsigned)(end_slot >> pa.hint_shift); ptomb[h] = ht;
+                if (e >= 0) atomicAdd(&s_agg[threadIdx.x & 15], 1);
+            }
+        }
+        __syncthreads();
+        const int agg = s_agg[threadIdx.x & 15];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            // monotone max like update_agg_hit; the plain read first keeps hot entries from serialising on one address
+            if (pe[h] >= 0 && pa.eagg[pe[h]] < agg) {
+                const int old = atomicMax(&pa.eagg[pe[h]], agg);
+                if (old < agg) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
+            }
+            int v = -1;
+            if (f == 0) v = bs < blk_end ? (int)bs : -1;                 // x: the sample number
+            else if (pact[h]) v = pe[h] >= 0 ? (int)(0x40000000u | (unsigned)pe[h]) : (pok[h] ? prow[h] : -1);
+            s_idx[(int)threadIdx.x + 256 * h] = v;
+            if (pact[h]) {
+                const int64_t m = bs * (int64_t)T + (f - 1);
+                if (pa.hit) pa.hit[m] = pe[h] >= 0;
+                if (pok[h] && pe[h] < 0) {
+                    const int at = atomicAdd(&s_nlist, 1);
+                    pa.miss_rec[(int64_t)blockIdx.x * pa.list_cap + at] =
+                        make_uint4((unsigned)prow[h], (unsigned)(f - 1) | ((unsigned)agg << 8) | (ptomb[h] ? 0x10000u : 0u), phint[h], (unsigned)m);
+                }
+            }
+            if (f == 1 && bs < blk_end) { atomicAdd(&s_psum[0], agg); if (agg == T) atomicAdd(&s_psum[1], 1); }
+        }
+        __syncthreads();
+        if (threadIdx.x < 40) {   // the block's totals into one of the replica rows (folded by the cache's close)
+            const int i = threadIdx.x;
+            const int v = i <= T ? s_pdelta[i] : i == 38 ? s_psum[0] : i == 39 ? s_psum[1] : 0;
+            if (v) atomicAdd(&pa.part1[(blockIdx.x % 32) * 40 + i], v);
+        }
+        if (threadIdx.x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
+    } else {
+        tile_load(0);
+        tile_store(0);
+        __syncthreads();
+    }
 #pragma unroll
     for (int u = 0; u < D; u++) issue(u, ring[u]);      // (samples past the block's end: every lane reads the zero page)
     __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink three of the four requests below the first consume
@@ -423,6 +495,22 @@ bool launch_rf_ids(const FusedArgs &a, hipStream_t st) {
         return true;
     default:
         if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 1, 2, EVS_RF_DEPTH, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 1, 1, EVS_RF_DEPTH, false, true>>(a, st);
+        return true;
+    }
+}
+
+bool launch_rf_probe(const FusedArgs &a, hipStream_t st) {
+    if (!rf_ids_supported(a.B, a.F, a.d) || !a.probe.slots || !a.arena) return false;
+    const bool nt2 = a.F > 16;
+    switch (a.d) {
+    case 16:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<1, 0, 2, EVS_RF_DEPTH, false, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<1, 0, 1, EVS_RF_DEPTH, false, false, true>>(a, st);
+        return true;
+    case 32:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 0, 2, EVS_RF_DEPTH, false, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 0, 1, EVS_RF_DEPTH, false, false, true>>(a, st);
+        return true;
+    default:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 1, 2, EVS_RF_DEPTH, false, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 1, 1, EVS_RF_DEPTH, false, false, true>>(a, st);
         return true;
     }
 }

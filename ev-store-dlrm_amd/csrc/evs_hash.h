@@ -1,0 +1,82 @@
+// The batched cache path's hash (gfx950 only): constants, word layout and the read-only probe -- shared by evs_cache.hip
+// (probe, update and housekeeping kernels) and evs_fused_rf.hip (the probe folded into the interaction kernel).
+#pragma once
+#include "evs_common.h"
+
+namespace evs {
+
+constexpr int kMaxBuckets = 65;     // EvLFU priorities 0..n_tables
+constexpr unsigned long long kEmpty = 0ull;
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+constexpr unsigned long long kTomb = ~0ull;
+// second tombstone value (sampled policy update: tombstones written in batches of odd parity, see there); neither
+// value can equal a key (table field 63)
+constexpr unsigned long long kTomb1 = ~0ull - 1ull;
+constexpr int kPending = -2;
+// The batched path keeps its own hash: ONE 8-byte word per slot = key (38 bits: (table+1) << 32 | row)
+// | entry index (26 bits), so a probe is a single random access and the table for 3.4 M entries is
+// 128 MiB (load <= 0.25; it stays inside the 256 MiB Infinity Cache).  While a
+// key is being inserted the entry field carries kFieldPend + its pending priority, so the duplicates of
+// one batch fold their agg_hit into the word with a 64-bit atomicMax.  kEmpty = 0 and kTomb = ~0 are
+// not valid keys (table+1 is in 1..32).
+constexpr int kKeyBits = 38;
+constexpr unsigned long long kKeyMask = (1ull << kKeyBits) - 1ull;
+constexpr unsigned kFieldPend = (1u << (64 - kKeyBits)) - 128u;
+constexpr long long kMaxBatchedCap = (long long)kFieldPend - 1;
+__device__ __forceinline__ unsigned long long make_word(unsigned long long key, unsigned field) {
+    return key | ((unsigned long long)field << kKeyBits);
+}
+
+// Read-only probe.  Found: the entry (or kPending) and end_slot = the key's slot.  Not found: -1 and end_slot = the
+// first slot of the chain an insert of this key may take -- the first tombstone the walk passed, else the empty word
+// it ended on (K2 starts its claim there instead of walking the chain again).
+__device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigned long long mask, unsigned long long key,
+                                        unsigned long long &end_slot, unsigned long long reusable_tomb = kTomb,
+                                        bool *hint_is_tomb = nullptr) {
+    unsigned long long i = mix64(key) & mask;
+    long long first_tomb = -1;
+    if (hint_is_tomb) *hint_is_tomb = false;
+    // bounded: a batch with more unique new keys than free slots (tiny cache, huge batch) can leave the table without
+    // an empty word until the next rebuild -- the walk then ends after one lap instead of never
+    for (unsigned long long steps = 0; steps <= mask; steps++) {
+        const unsigned long long w = slots[i];
+        if ((w & kKeyMask) == key) {
+            end_slot = i;
+            const unsigned f = (unsigned)(w >> kKeyBits);
+            return f >= kFieldPend ? kPending : (int)f;
+        }
+        if (w == kEmpty) {
+            end_slot = first_tomb >= 0 ? (unsigned long long)first_tomb : i;
+            if (hint_is_tomb) *hint_is_tomb = first_tomb >= 0;
+            return -1;
+        }
+        if (w == reusable_tomb && first_tomb < 0) first_tomb = (long long)i;
+        i = (i + 1) & mask;  // tombstones and other keys: keep walking
+    }
+    end_slot = first_tomb >= 0 ? (unsigned long long)first_tomb : i;
+    if (hint_is_tomb) *hint_is_tomb = first_tomb >= 0;
+    return -1;
+}
+
+
+// Folded probe (evs_fused_rf.hip, PROBE variant): what cache_batch_probe_gather_kernel needs of a cache, by value
+struct ProbeArgs {
+    const unsigned long long *slots; unsigned long long mask;
+    unsigned long long reusable_tomb;     // the tombstone value this batch may re-use (parity rule)
+    int *eagg;                            // priorities (monotone max of agg_hit)
+    const int *requests;                  // (B,T) int32 row ids
+    unsigned char *hit;                   // (B,T) out, may be NULL
+    uint4 *miss_rec; int *list_cnt; int list_cap;   // per block: its misses as 16-byte records (see BatchArgs::miss_rec)
+    int *part1;                           // replica rows of the hit / histogram totals
+    int hint_shift, T;
+};
+
+// evs_fused.hip: interaction over x + the T rows the cache serves, the probe folded into the kernel (fp32 rows; is there a
+// kernel for the shape: fused_row_ids_supported)
+int fused_probe_interact(int64_t B, int T, int d, const float *x, int64_t x_stride, const ProbeArgs &probe, const void *arena,
+                         const void *const *tables, const long long *table_rows, int itself, float *R, hipStream_t st);
+
+}  // namespace evs
