@@ -1828,7 +1828,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
 // mostly busy lanes instead of 6 656 waves with one lane in eight busy, and everything a miss needs arrives with its
 // record (the per-position form reads the probe word, then the request row, then starts).
 template <int PIECES, typename U>
-__global__ void __launch_bounds__(128) cache_batch_sampled_list_kernel(const BatchArgs args) {
+__global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
@@ -1836,7 +1836,10 @@ __global__ void __launch_bounds__(128) cache_batch_sampled_list_kernel(const Bat
     __syncthreads();
     const int n = args.list_cnt[blockIdx.x];
     const uint4 *rec = args.miss_rec + (long long)blockIdx.x * args.list_cap;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    // (records dealt round-robin over the block's waves: a 50-record list on two waves is 25 busy lanes each, not one wave
+    //  of 50 and an idle one)
+    const int nw = (int)blockDim.x >> 6;
+    for (int i = ((int)threadIdx.x & 63) * nw + ((int)threadIdx.x >> 6); i < n; i += 64 * nw) {
         const uint4 r = rec[i];
         sampled_insert_one<PIECES, U>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, (r.y & 0x10000u) != 0, (long long)r.w,
                                    s_delta, s_stat);
@@ -2592,12 +2595,19 @@ static void batch_close(evs_cache *c, evs::BatchArgs a, hipStream_t st) {
     hipLaunchKernelGGL(cache_batch_close_kernel, dim3(1), dim3(256), 0, st, a);
     batch_housekeeping(c, a, st);
 }
+// threads per miss list (EVS_CACHE_LIST_WAVES overrides: developer A/B)
+static unsigned sampled_list_threads(const evs::BatchArgs &a) {
+    static int w = -1;
+    if (w < 0) { const char *e = getenv("EVS_CACHE_LIST_WAVES"); w = e ? atoi(e) : 0; }
+    if (w >= 1 && w <= 4) return 64u * (unsigned)w;
+    return a.list_cap > 8 * a.T ? 128u : 64u;
+}
 // the sampled update, compiled per row size (row_bytes = PIECES pieces of 16 / 8 / 4 / 2 bytes, at most 16 of them)
 template <int PIECES, typename U>
 static void launch_sampled_update_t(const evs::BatchArgs &a, hipStream_t st) {
     using namespace evs;
     // K1 listed the misses: one wave per list (two when the lists are those of the folded probe's 16-sample blocks: twice as long)
-    if (a.miss_rec) hipLaunchKernelGGL((cache_batch_sampled_list_kernel<PIECES, U>), dim3((unsigned)a.g1), dim3(a.list_cap > 8 * a.T ? 128 : 64), 0, st, a);
+    if (a.miss_rec) hipLaunchKernelGGL((cache_batch_sampled_list_kernel<PIECES, U>), dim3((unsigned)a.g1), dim3(sampled_list_threads(a)), 0, st, a);
     else hipLaunchKernelGGL((cache_batch_sampled_kernel<PIECES, U>), dim3((unsigned)a.g2), dim3(256), 0, st, a);
 }
 static void launch_sampled_update(const evs::BatchArgs &a, hipStream_t st) {
