@@ -258,26 +258,50 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         if (threadIdx.x < 2) s_psum[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_nlist = 0;
         __syncthreads();
-        int pe[2], prow[2];
+        int pe[2], prow[2], pprio[2];
         unsigned phint[2];
         bool pok[2], ptomb[2], pact[2];
+        unsigned long long pkey[2], phome[2], pw0[2];
         const int64_t bs = blk_first + (threadIdx.x & 15);
+        // the thread's two keys side by side, one round trip per step for both: request rows, home slots, priorities
+        // (a key whose home slot holds neither it nor nothing walks its chain with probe_ro: rare at load <= 0.25)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
             pact[h] = f >= 1 && f < F && bs < blk_end;
             const int *rp = pact[h] ? pa.requests + bs * (int64_t)T + (f - 1) : reinterpret_cast<const int *>(dummy_i);
             prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
             pok[h] = pact[h] && prow[h] >= 0 && (unsigned)prow[h] < s_tile_nr[f];
-            pe[h] = -1; phint[h] = 0; ptomb[h] = false;
+            pkey[h] = ((unsigned long long)f << 32) | (unsigned)prow[h];   // table_1based = f
+            phome[h] = mix64(pkey[h]) & pa.mask;
+            pw0[h] = pa.slots[pok[h] ? phome[h] : 0];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            pe[h] = -1; phint[h] = 0; ptomb[h] = false; pprio[h] = 0x7fffffff;
             if (pok[h]) {
-                const unsigned long long key = ((unsigned long long)f << 32) | (unsigned)prow[h];   // table_1based = f
-                unsigned long long end_slot = 0;
+                unsigned long long end_slot = phome[h];
                 bool ht = false;
-                int e = probe_ro(pa.slots, pa.mask, key, end_slot, pa.reusable_tomb, &ht);
-                if (e == kPending) e = -1;
+                int e = -1;
+                if ((pw0[h] & kKeyMask) == pkey[h]) {
+                    const unsigned fld = (unsigned)(pw0[h] >> kKeyBits);
+                    e = fld >= kFieldPend ? -1 : (int)fld;
+                } else if (pw0[h] != kEmpty) {
+                    e = probe_ro(pa.slots, pa.mask, pkey[h], end_slot, pa.reusable_tomb, &ht);
+                    if (e == kPending) e = -1;
+                }
                 pe[h] = e; phint[h] = (unsigned)(end_slot >> pa.hint_shift); ptomb[h] = ht;
-                if (e >= 0) atomicAdd(&s_agg[threadIdx.x & 15], 1);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (pe[h] >= 0) {
+                atomicAdd(&s_agg[threadIdx.x & 15], 1);
+                pprio[h] = pa.eagg[pe[h]];   // asked for now: it travels while the block meets
             }
         }
         __syncthreads();
@@ -286,7 +310,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
             // monotone max like update_agg_hit; the plain read first keeps hot entries from serialising on one address
-            if (pe[h] >= 0 && pa.eagg[pe[h]] < agg) {
+            if (pe[h] >= 0 && pprio[h] < agg) {
                 const int old = atomicMax(&pa.eagg[pe[h]], agg);
                 if (old < agg) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
             }
