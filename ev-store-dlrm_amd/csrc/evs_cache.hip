@@ -869,7 +869,7 @@ struct BatchArgs {
     uint4 *miss_rec; int *list_cnt; int list_cap;
     // sampled update with the alt-key tier attached: kReplicas victim lists of vict_cap keys each in evicted_keys, their
     // lengths in vict_cnt (zeroed by the consumer kernel)
-    int *vict_cnt; int vict_cap;
+    int *vict_cnt, *vict_other; int vict_cap;
     unsigned long long *evicted_keys;   // (alt-key tier attached) the key each free-stack position held before K4 put it there; bit 63 = flushed, not evicted
     int tomb_parity;                // sampled update: parity of this batch (its tombstones are kTomb1 when odd); -1 otherwise
 };
@@ -2037,15 +2037,15 @@ __device__ __forceinline__ void c3_insert_key(const C3Batch &c3, unsigned long l
     }
 }
 __global__ void __launch_bounds__(256) c3_batch_insert_lists_kernel(const BatchArgs args, const C3Batch c3) {
+    // (args.vict_cnt points at this batch's half of the 2 x kReplicas list lengths -- halves by batch parity; the other
+    //  half, consumed one batch ago, is zeroed here for the next batch: no launch just to reset 32 counters)
     const int r = blockIdx.x % kReplicas, part = blockIdx.x / kReplicas, parts = gridDim.x / kReplicas;
     int n = args.vict_cnt[r];
     if (n > args.vict_cap) n = args.vict_cap;
     for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x)
         c3_insert_key(c3, args.evicted_keys[(long long)r * args.vict_cap + i]);
-    __syncthreads();
-    // (the list is emptied by the close of the tier: see c3_lists_reset_kernel)
+    if (part == 0 && threadIdx.x == 0) args.vict_other[r] = 0;
 }
-__global__ void c3_lists_reset_kernel(int *vict_cnt) { if (threadIdx.x < kReplicas) vict_cnt[threadIdx.x] = 0; }
 
 // Host-memory miss tier: after the fill (K5) every missed key that got an entry is served from its ARENA row, so
 // each missing row crosses the bus once (the de-duplicated fetch of K5) instead of once per request that asked
@@ -2490,7 +2490,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     // a few batches late is as good): past nslot / 8 the
     // table is swept (tombstones at the end of their chains become empty again); if the count is back there within
     // three calls the sweep did not help enough and the hash is rebuilt.
-    a.evicted_keys = nullptr; a.vict_cnt = nullptr; a.vict_cap = 0; a.miss_rec = nullptr; a.list_cnt = nullptr; a.list_cap = 0;
+    a.evicted_keys = nullptr; a.vict_cnt = nullptr; a.vict_other = nullptr; a.vict_cap = 0; a.miss_rec = nullptr; a.list_cnt = nullptr; a.list_cap = 0;
     a.tomb_parity = -1;
     a.rebuild = 0;
     c->batch_calls++;   // = the ordinal of this call's close
@@ -2956,10 +2956,11 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
                     c->vict_cap = need;
                 }
                 if (!c->vict_cnt) {
-                    EVS_HIP_CHECK(hipMalloc(&c->vict_cnt, kReplicas * 4));
-                    EVS_HIP_CHECK(hipMemsetAsync(c->vict_cnt, 0, kReplicas * 4, st));
+                    EVS_HIP_CHECK(hipMalloc(&c->vict_cnt, 2 * kReplicas * 4));
+                    EVS_HIP_CHECK(hipMemsetAsync(c->vict_cnt, 0, 2 * kReplicas * 4, st));
                 }
-                a.evicted_keys = c->vict_keys; a.vict_cnt = c->vict_cnt; a.vict_cap = (int)c->vict_cap;
+                a.evicted_keys = c->vict_keys; a.vict_cap = (int)c->vict_cap;
+                a.vict_cnt = c->vict_cnt + (a.stamp & 1) * kReplicas; a.vict_other = c->vict_cnt + (1 - (a.stamp & 1)) * kReplicas;
             }
         }
     }
@@ -2983,7 +2984,6 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             launch_sampled_update(a, st);
             if (c3) {
                 hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(kReplicas * 8), dim3(256), 0, st, a, tt.c3);
-                hipLaunchKernelGGL(c3_lists_reset_kernel, dim3(1), dim3(64), 0, st, a.vict_cnt);
             }
         }
         for (int k = 0; k < 2; k++) {
