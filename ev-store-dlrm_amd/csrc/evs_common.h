@@ -46,15 +46,25 @@ __device__ __forceinline__ float dec_u8(unsigned v) {
     f = __fmul_rn(f, 2.0f);
     return __fsub_rn(f, 1.0f);
 }
-// 16-bit: mixed_precs_caching/evlfu_16.cpp:332-356 -- the reference mixes float and
-// double ((float)v * 0.00002 is a double product), so this does too.
+// 16-bit: mixed_precs_caching/evlfu_16.cpp:332-356 -- the reference mixes float and double: (float)v * 0.00002 is a
+// double product, 0.65 is subtracted in double, the result is rounded to float.  For the main range (v <= 65 000) that is
+// bit for bit  fma(w, ch, w * cl)  in fp32 with w = v - 32 500, ch = fl32(0.00002), cl = fl32(0.00002 - ch): 0.65 is
+// 32 500 x 0.00002 up to 1e-17, far below half a float ulp of every non-zero result, and the three fp32 roundings land
+// on the same float as the three of the reference -- checked for all 65 001 codes against the double formula with exact
+// rational arithmetic before it went in, and by tests/test_gpu_parity.py::test_exhaustive_decode_tables_on_gpu against the
+// compiled reference decoder on every run.  Four fp32 instructions instead of two conversions and two fp64 operations
+// per element (fp64 and the conversions run at a half / a quarter of the fp32 rate).
+__device__ __forceinline__ float dec_u16_main(unsigned v) {
+    const float w = (float)((int)v - 32500);
+    return __fmaf_rn(w, 2e-05f, __fmul_rn(w, 5.052425e-13f));
+}
 __device__ __forceinline__ float dec_u16(unsigned v) {
     if (v > 65000u) {
         float diff = __fdiv_rn((float)(int)(v - 65000u), 100.0f);
         double m = __dadd_rn(0.65, (double)diff);
         return (v & 1u) ? (float)(-m) : (float)m;
     }
-    return (float)__dsub_rn(__dmul_rn((double)(float)v, 0.00002), 0.65);
+    return dec_u16_main(v);
 }
 // 4-bit look-up table (mixed_precs_caching/evlfu_4.hpp:46); entry 15 is out of bounds in
 // the reference and never emitted by its encoder: it decodes to NaN here.
@@ -65,7 +75,7 @@ __device__ __constant__ const float kU4Lut[16] = {
 // Decode through a per-block LDS table: u8 -> all 256 values (the exact expression above has an
 // IEEE division per element), u4 -> the 16 entries (a per-lane index into __constant__ memory is a
 // vector-memory gather), u16 -> the 536 magnitudes of the v > 65000 tail (the division again); the
-// u16 main range stays arithmetic (two fp64 ops).
+// u16 main range stays arithmetic (dec_u16_main: four fp32 instructions).
 template <int CODEC> struct CodecLut { static constexpr int kEntries = 1; };
 template <> struct CodecLut<16> { static constexpr int kEntries = 536; };
 template <> struct CodecLut<8> { static constexpr int kEntries = 256; };
@@ -86,7 +96,7 @@ __device__ __forceinline__ float dec_code(unsigned v, const float *lut) {
     if constexpr (CODEC == 16) {
         const bool tail = v > 65000u;
         const float t = lut[tail ? v - 65000u : 0u];
-        const float m = (float)__dsub_rn(__dmul_rn((double)(float)v, 0.00002), 0.65);
+        const float m = dec_u16_main(v);
         return tail ? ((v & 1u) ? -t : t) : m;
     } else {
         return lut[v];
