@@ -561,6 +561,19 @@ def main():
         step2(i)
     torch.cuda.synchronize()
     dt2 = time.perf_counter() - t2
+
+    def step2_declared(i):   # the same two calls, the caller stating one index per bag: the gather does not read lS_o
+        lS_o, lS_i = batches[i % len(batches)]
+        return E.interact_features(xs[i % 2], E.apply_emb(lS_o, lS_i, ev, None, lazy=False, one_index_per_bag=True))
+
+    for i in range(5):
+        step2_declared(i)
+    torch.cuda.synchronize()
+    t2d = time.perf_counter()
+    for i in range(args.steps):
+        step2_declared(i)
+    torch.cuda.synchronize()
+    dt2d = time.perf_counter() - t2d
     for i in range(5):
         step2_lazy(i)
     torch.cuda.synchronize()
@@ -612,6 +625,9 @@ def main():
         "two_call_path": {"value": lookups * args.steps / dt2, "unit": "lookups/s",
                           "ms_per_step": dt2 / args.steps * 1e3,
                           "note": "apply_emb(lazy=False) (26-table gather) then interact_features: two kernels, (T,B,d) intermediate in HBM"},
+        "two_call_one_index_declared": {"value": lookups * args.steps / dt2d, "unit": "lookups/s", "ms_per_step": dt2d / args.steps * 1e3,
+                                        "note": "apply_emb(..., lazy=False, one_index_per_bag=True) then interact_features: the gather is the "
+                                                "offsets-free row gather"},
         "two_call_lazy": {"value": lookups * args.steps / dt2l, "unit": "lookups/s", "ms_per_step": dt2l / args.steps * 1e3,
                           "note": "the same two calls with lazy pooling on (EVS_LAZY_POOLING=1 or apply_emb(..., lazy=True); off by "
                                   "default because the lazy result is a Sequence, not a list): apply_emb launches nothing, "

@@ -359,16 +359,17 @@ extern "C" int evs_embedding_bag_sum_stacked(int T, int64_t B, int d, int codec,
     using namespace evs;
     EVS_REQUIRE(T >= 0 && T <= 4096, "evs_embedding_bag_sum_stacked: bad T=%d", T);
     if (T == 0 || B == 0) return EVS_OK;
-    EVS_REQUIRE(indices_base && offsets_base, "evs_embedding_bag_sum_stacked: NULL argument");
+    EVS_REQUIRE(indices_base, "evs_embedding_bag_sum_stacked: NULL argument");
+    // offsets_base == NULL: one index per bag for every table (see evs_embedding_bag_sum)
     const int64_t *idx[4096];
     const int64_t *off[4096];
     int64_t nnz[4096];
     for (int k = 0; k < T; k++) {
         idx[k] = indices_base + (int64_t)k * indices_row_stride;
-        off[k] = offsets_base + (int64_t)k * offsets_row_stride;
+        off[k] = offsets_base ? offsets_base + (int64_t)k * offsets_row_stride : nullptr;
         nnz[k] = nnz_per_table;
     }
-    return evs_embedding_bag_sum(T, B, d, codec, tables, n_rows, idx, off, nnz, row_weights, out,
+    return evs_embedding_bag_sum(T, B, d, codec, tables, n_rows, idx, offsets_base ? off : nullptr, nnz, row_weights, out,
                                  out_table_stride, out_bag_stride, stream);
 }
 

@@ -201,7 +201,7 @@ def _as_evtables(emb_l):
     return ev
 
 
-def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy=None):
+def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy=None, one_index_per_bag=False):
     """Drop-in for DLRM_Net.apply_emb (dlrm_s_pytorch.py:407-461).
 
     lS_o: (T,B) int64 tensor or list of T (B,) tensors -- bag START offsets.
@@ -212,6 +212,9 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy
     (T,B,d) buffer, or of `out` = the (B,F,d) interaction tile (slot 0 is left for x).
     One HIP launch for all tables.  lazy (default: the module switch LAZY_POOLING): return a LazyPooled sequence
     and launch nothing until the rows are touched -- interact_features then runs the fused kernel instead.
+    one_index_per_bag=True asserts lS_o[k] == arange(B) for every table (what collate_wrapper_criteo_offset always
+    produces, dlrm_data_pytorch.py:407-408; list form: every lS_i[k] has B entries): lS_o is then not read and the
+    launch is the offsets-free row gather (33.4 -> 24.9 us for the 26 Kaggle tables at B = 16 384).
     """
     ev = _as_evtables(emb_l)
     T, d = len(ev), ev.d
@@ -240,10 +243,11 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy
         assert lS_i.dtype == torch.int64 and lS_o.dtype == torch.int64
         assert lS_i.is_cuda and lS_o.is_cuda, "indices/offsets must already be on the GPU (dlrm_wrap does this)"
         assert lS_i.stride(1) == 1 and lS_o.stride(1) == 1
+        no_off = one_index_per_bag and int(lS_i.shape[1]) == B
         rc = L.evs_embedding_bag_sum_stacked(
             T, B, d, ev.codec, ev._tables_c, ev._n_rows_c,
             lS_i.data_ptr(), lS_i.stride(0), int(lS_i.shape[1]),
-            lS_o.data_ptr(), lS_o.stride(0), rw_c, out_ptr, tstride, bstride, stream)
+            None if no_off else lS_o.data_ptr(), lS_o.stride(0), rw_c, out_ptr, tstride, bstride, stream)
     else:
         li = [lS_i[k] for k in range(T)]
         lo = [lS_o[k] for k in range(T)]
@@ -252,7 +256,8 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy
         idx_c = (C.c_void_p * T)(*[t.data_ptr() for t in li])
         off_c = (C.c_void_p * T)(*[t.data_ptr() for t in lo])
         nnz_c = (C.c_int64 * T)(*[int(t.numel()) for t in li])
-        rc = L.evs_embedding_bag_sum(T, B, d, ev.codec, ev._tables_c, ev._n_rows_c, idx_c, off_c, nnz_c, rw_c,
+        no_off = one_index_per_bag and all(int(t.numel()) == B for t in li)
+        rc = L.evs_embedding_bag_sum(T, B, d, ev.codec, ev._tables_c, ev._n_rows_c, idx_c, None if no_off else off_c, nnz_c, rw_c,
                                      out_ptr, tstride, bstride, stream)
     _lib.check(rc)
     if check_indices:

@@ -85,7 +85,7 @@ EVS_API int evs_embedding_bag_sum(int T, int64_t B, int d, int codec,
  * table): indices[k] = indices_base + k*indices_row_stride (B entries each, i.e.
  * nnz[k] = nnz_per_table), offsets[k] = offsets_base + k*offsets_row_stride.
  * Strides in elements.  Saves the caller from building four T-long pointer arrays
- * per batch. */
+ * per batch.  offsets_base == NULL: one index per bag (as offsets == NULL above). */
 EVS_API int evs_embedding_bag_sum_stacked(int T, int64_t B, int d, int codec,
                           const void *const *tables, const int64_t *n_rows,
                           const int64_t *indices_base, int64_t indices_row_stride,

@@ -972,3 +972,31 @@ def test_sharded_hip_one_index_per_bag_virtual_ranks_vs_oracle(E, orc, world):
             pl["recv"].copy_(recv)
             op.run_finish(pl, None)
             assert torch.equal(out, R), (policy, r)
+
+
+def test_apply_emb_one_index_per_bag_declared(E, orc):
+    """apply_emb(..., one_index_per_bag=True): the caller states lS_o == arange, the launch does not read it (offsets-free
+    row gather) -- same bits as the offsets form and the oracle, stacked and list arguments, per-row weights, into the
+    (T,B,d) buffer and into the (B,F,d) tile."""
+    rs = np.random.RandomState(90)
+    ln = [4000, 3, 90000, 17, 2500]
+    T, d, B = len(ln), 36, 777
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    ev = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    idx = np.stack([rs.randint(0, n, size=B) for n in ln]).astype(np.int64)
+    off = np.tile(np.arange(B, dtype=np.int64), (T, 1))
+    w = [rs.uniform(0.5, 1.5, size=n).astype(np.float32) if k % 2 else None for k, n in enumerate(ln)]
+    wd = [None if v is None else _dev(v) for v in w]
+    want = orc.apply_emb(list(off), list(idx), tabs, w)
+    for stacked in (True, False):
+        o = _dev(off) if stacked else [_dev(r) for r in off]
+        i = _dev(idx) if stacked else [_dev(r) for r in idx]
+        a = E.apply_emb(o, i, ev, wd, lazy=False, one_index_per_bag=True, check_indices=True)
+        b = E.apply_emb(o, i, ev, wd, lazy=False)
+        for k in range(T):
+            assert np.array_equal(a[k].cpu().numpy().view(np.uint32), want[k].view(np.uint32)), (stacked, k)
+            assert torch.equal(a[k], b[k])
+        tile = torch.zeros((B, T + 1, d), device="cuda")
+        E.apply_emb(o, i, ev, wd, out=tile, lazy=False, one_index_per_bag=True)
+        for k in range(T):
+            assert np.array_equal(tile[:, k + 1, :].cpu().numpy().view(np.uint32), want[k].view(np.uint32))
