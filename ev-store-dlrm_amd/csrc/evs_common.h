@@ -106,8 +106,13 @@ __device__ __forceinline__ float dec_code(unsigned v, const float *lut) {
 template <int CODEC>
 __device__ __forceinline__ float4 dec_chunk(unsigned w0, unsigned w1, const float *lut) {
     if constexpr (CODEC == 16) {
-        return make_float4(dec_code<16>(w0 & 0xffffu, lut), dec_code<16>(w0 >> 16, lut),
-                           dec_code<16>(w1 & 0xffffu, lut), dec_code<16>(w1 >> 16, lut));
+        // tail codes (> 65 000: |x| > 0.65) are rare in trained tables: when no lane of the wave holds one in this chunk --
+        // a wave-uniform test -- the table read and the selects of the tail are skipped for the whole wave
+        const unsigned a = w0 & 0xffffu, b = w0 >> 16, c = w1 & 0xffffu, e = w1 >> 16;
+        const bool tail = a > 65000u || b > 65000u || c > 65000u || e > 65000u;
+        if (__builtin_amdgcn_ballot_w64(tail) == 0ull)
+            return make_float4(dec_u16_main(a), dec_u16_main(b), dec_u16_main(c), dec_u16_main(e));
+        return make_float4(dec_code<16>(a, lut), dec_code<16>(b, lut), dec_code<16>(c, lut), dec_code<16>(e, lut));
     } else if constexpr (CODEC == 8) {
         return make_float4(lut[w0 & 0xffu], lut[(w0 >> 8) & 0xffu], lut[(w0 >> 16) & 0xffu], lut[(w0 >> 24) & 0xffu]);
     } else {  // u4: element 2j is the HIGH nibble of byte j (script/reduce_precision.py:321)
