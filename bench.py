@@ -36,12 +36,16 @@ KAGGLE_LN = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 
 HBM_PEAK_GBPS = 8000.0  # MI355X datasheet HBM3E bandwidth (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
-def make_tables(ln_emb, d, seed=0, device="cuda", bits=32):
+def make_tables(ln_emb, d, seed=0, device="cuda", bits=32, codes="random"):
     """Synthetic tables, U(-sqrt(1/n), sqrt(1/n)) fp32 (dlrm_s_pytorch.py:279-283), made on the GPU.
-    bits 16/8/4: random codes in the reference's reduced-precision row layout (any code decodes)."""
+    bits 16/8/4: codes "random" = uniformly random codes in the reference's reduced-precision row layout (any code
+    decodes; for u16 that includes 0.8 % codes of the |x| > 0.65 tail, which trained tables do not hold); "encoded" =
+    the fp32 tables above through the reference's encoders (script/reduce_precision.py, on the GPU: EVTables.encode)."""
     import evstore_dlrm_amd as E
     g = torch.Generator(device=device).manual_seed(seed)
     ws = []
+    if bits != 32 and codes == "encoded":
+        return make_tables(ln_emb, d, seed, device).encode(bits)
     if bits != 32:
         hi = 15 if bits == 4 else 256   # u4: both nibbles in 0..14 (the 15-entry table)
         for n in ln_emb:

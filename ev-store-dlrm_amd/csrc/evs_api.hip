@@ -55,6 +55,31 @@ const void *zero_page() {
     return pages[dev];
 }
 
+const void *zero_code_page(int codec) {
+    static std::mutex mu;
+    static void *pages[64][3] = {};
+    const int k = codec == 16 ? 0 : codec == 8 ? 1 : codec == 4 ? 2 : -1;
+    int dev = 0;
+    if (k < 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        set_error("zero_code_page: codec %d / no usable GPU", codec);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pages[dev][k]) {
+        void *p = nullptr;
+        // u16: 32 500 = 0x7ef4 -> w = 0 -> fma(0, ch, 0) = +0; u8: 127 / 254 * 2 - 1 = 0 exactly; u4: table entry 7 = 0.0
+        hipError_t e = hipMalloc(&p, 1024);
+        if (e == hipSuccess) e = k == 0 ? hipMemsetD16(p, 0x7ef4, 512) : hipMemset(p, k == 1 ? 0x7f : 0x77, 1024);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            set_error("hipMalloc of the zero-code page failed");
+            return nullptr;
+        }
+        pages[dev][k] = p;
+    }
+    return pages[dev][k];
+}
+
 // Flag slot of one optimistic launch pair (evs_fused.hip): a ring of 1024 device ints per device and a
 // process-wide id counter.  The bag-1 kernel writes the pair's id into its slot when the bet is lost; the
 // general kernel runs only if it finds its id there.  Nothing is ever reset: an id is used once.

@@ -36,6 +36,8 @@ void set_error(const char *fmt, ...);
 int *index_error_flag();
 // 4 KiB of zeros in HBM (one per device): the "row" read by lanes that have nothing to fetch
 const void *zero_page();
+// 1 KiB of the code that decodes to exactly 0.0f (one per device and codec): u16 32 500, u8 127, u4 nibble 7
+const void *zero_code_page(int codec);
 int *optimistic_slot(int *id_out);   // evs_api.hip
 
 // ---- codecs: bit-exact device restatements of the reference decoders ----------------

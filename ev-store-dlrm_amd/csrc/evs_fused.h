@@ -40,6 +40,8 @@ struct FusedArgs {
     // ... or the kernel probes the cache itself (PROBE variant): the (B, F-1) request rows in, hit flags, miss lists and
     // hit statistics out -- cache_batch_probe_gather_kernel folded into the head of this launch
     ProbeArgs probe;
+    // evs_fused_rfq.hip: 1 KiB of the code that decodes to 0.0f (zero_code_page) -- the "row" of an absent table row
+    const void *zero_codes;
 };
 
 
@@ -56,5 +58,9 @@ bool rf_ids_supported(int64_t B, int F, int d);
 bool launch_rf_ids(const FusedArgs &a, hipStream_t st);
 // ... probing the cache itself (FusedArgs::probe filled in); same shapes as launch_rf_ids; one block per 16 samples
 bool launch_rf_probe(const FusedArgs &a, hipStream_t st);
+
+// evs_fused_rfq.hip: reduced-precision tables (codec 16 / 8 / 4), encoded rows in flight in registers in the MFMA operand
+// mapping; bag1 == 1 (no offsets) or 2 (the one-index-per-bag leg of the optimistic triple); false = no kernel for the shape
+bool launch_rfq(const FusedArgs &a, int codec, hipStream_t st);
 
 }  // namespace evs

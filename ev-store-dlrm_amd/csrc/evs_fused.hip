@@ -480,10 +480,18 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
     constexpr int enc_row_bytes = d * CODEC / 8;
     // dwords DMA'd per encoded row (u4 rows that are not dword multiples: the aligned window around them)
     constexpr int RBd = (enc_row_bytes % 4 == 0) ? enc_row_bytes / 4 : (enc_row_bytes + 2 + 3) / 4;
-    constexpr int NI2 = ((NROWS - 1) * RBd + 63) / 64;
+    // ... moved in pieces of PB bytes per lane: 16 or 12 where the row is a whole number of them (gfx950 has the 12- and
+    // 16-byte LDS DMA), else dword by dword.  A d = 36 u16 row is 6 lanes instead of 18, a u8 row 3 instead of 9: the
+    // per-lane-addressed memory instructions per sample are what bounds this kernel (7.3 -> 2.4 for u16).
+    constexpr int PB = !ENC ? 4 : (enc_row_bytes % 16 == 0 ? 16 : ((enc_row_bytes % 12 == 0 && CODEC != 4) ? 12 : 4));
+    constexpr int RP = PB == 4 ? RBd : enc_row_bytes / PB;   // pieces per row
+    // (measured on gfx950: the 12-byte DMA lays its lanes down 16 bytes apart -- dword i of a row sits at 4 i + 4 (i / 3))
+    constexpr int PS = PB == 12 ? 16 : PB;                   // LDS bytes between the pieces of neighbouring lanes
+    constexpr int kEncRowLds = PB == 4 ? RBd * 4 : RP * PS;  // LDS bytes per encoded row
+    constexpr int NI2 = ((NROWS - 1) * RP + 63) / 64;
     constexpr int kEncBase = 1024;          // encoded rows start behind the x KiB
     constexpr int kChunkBytes = CODEC / 2;  // 4 elements
-    constexpr int NINSTR = ENC ? 1 + (NI2 + 3) / 4 : (NROWS + RPI - 1) / RPI;   // slot size in KiB
+    constexpr int NINSTR = ENC ? 1 + (NI2 * 64 * PS + 1023) / 1024 : (NROWS + RPI - 1) / RPI;   // slot size in KiB
     constexpr int row_bytes = ENC ? enc_row_bytes : d * 4;
     static_assert(!TILE || (BAG1 && HAS_INDIRECT && !PTRS && !WEIGHTED), "index tiles: plain bag-1 tables");
     // TILE launches have F <= kTileMaxF: rows past that are never fetched (nor their products stored), and the
@@ -550,7 +558,8 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
 #pragma unroll
     for (int rr = 0; rr < NR; rr++) {
         const int row = r16 + 16 * rr;
-        if constexpr (ENC) lds_off[rr] = kEncBase + (row > 0 ? row - 1 : 0) * RBd * 4 + q * CQ * kChunkBytes;
+        if constexpr (ENC && PB == 12) lds_off[rr] = kEncBase + (row > 0 ? row - 1 : 0) * kEncRowLds;   // (chunk offsets: below)
+        else if constexpr (ENC) lds_off[rr] = kEncBase + (row > 0 ? row - 1 : 0) * kEncRowLds + q * CQ * kChunkBytes;
         else lds_off[rr] = (row / RPI) * 1024 + (row % RPI) * row_bytes + q * CQ * 16;
     }
     constexpr int kRemOff = 4 * CQ * (ENC ? kChunkBytes : 16);  // from the row start
@@ -792,18 +801,22 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                                  (__attribute__((address_space(3))) void *)my_lds, 16, 0, 0);
             }
-            const int n_dw = (F - 1) * RBd;
+            const int n_dw = (F - 1) * RP;
 #pragma unroll
             for (int j = 0; j < NI2; j++) {
                 if (j * 64 >= n_dw) break;
                 const int gidx = j * 64 + lane;
-                const int f = 1 + gidx / RBd;
-                const int w = gidx - (f - 1) * RBd;
+                const int f = 1 + gidx / RP;
+                const int w = gidx - (f - 1) * RP;
                 const bool on = gidx < n_dw;
                 const unsigned long long p = __shfl(pub, on ? (f & 15) + 16 * (f >> 4) : 0);
-                const char *g = on ? reinterpret_cast<const char *>(p) + 4 * w : zeros_l;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                 (__attribute__((address_space(3))) void *)(my_lds + kEncBase + j * 256), 4, 0, 0);
+                const char *g = on ? reinterpret_cast<const char *>(p) + PB * w : zeros_l;
+                const auto gp = (const __attribute__((address_space(1))) void *)g;
+                const auto lp = (__attribute__((address_space(3))) void *)(my_lds + kEncBase + j * 64 * PS);
+                // (the builtin wants a literal size)
+                if constexpr (PB == 16) __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+                else if constexpr (PB == 12) __builtin_amdgcn_global_load_lds(gp, lp, 12, 0, 0);
+                else __builtin_amdgcn_global_load_lds(gp, lp, 4, 0, 0);
             }
         } else {
 #pragma unroll
@@ -925,7 +938,15 @@ __global__ void __launch_bounds__(256, (lds_min_blocks<CODEC, CQ, BAG1, TILE, CH
                     const char *cp = my_lds + lds_off[rr] + sub +
                                      (c < CQ ? c * kChunkBytes : -q * CQ * kChunkBytes + kRemOff + (c - CQ) * kChunkBytes);
                     unsigned w0 = 0, w1r = 0;
-                    if constexpr (CODEC == 16) { const uint2 v = *reinterpret_cast<const uint2 *>(cp); w0 = v.x; w1r = v.y; }
+                    if constexpr (PB == 12) {   // 12 bytes in every 16: the chunk's dwords one by one
+                        static_assert(PB != 12 || CODEC == 16 || CODEC == 8, "12-byte pieces: whole-dword chunks");
+                        const int ch = c < CQ ? q * CQ + c : 4 * CQ + (c - CQ);
+                        const int i0 = ch * (kChunkBytes / 4);
+                        const char *rp = my_lds + lds_off[rr];
+                        w0 = *reinterpret_cast<const unsigned *>(rp + 4 * i0 + 4 * (i0 / 3));
+                        if constexpr (CODEC == 16) w1r = *reinterpret_cast<const unsigned *>(rp + 4 * (i0 + 1) + 4 * ((i0 + 1) / 3));
+                    }
+                    else if constexpr (CODEC == 16) { const uint2 v = *reinterpret_cast<const uint2 *>(cp); w0 = v.x; w1r = v.y; }
                     else if constexpr (CODEC == 8) w0 = *reinterpret_cast<const unsigned *>(cp);
                     else w0 = *reinterpret_cast<const unsigned short *>(cp);
                     const float4 dv = dec_chunk<CODEC>(w0, w1r, s_lut);
@@ -1177,6 +1198,9 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                         return;
                     }
                 }
+                if constexpr (!PTRS && CODEC != 32) {   // encoded rows in flight in registers (evs_fused_rfq.hip): d = 16 / 32 / 36
+                    if (a.bag1 == 1 && launch_rfq(a, CODEC, st)) return;
+                }
                 if (PTRS || a.bag1 == 1) {
                     if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
                     else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
@@ -1201,6 +1225,7 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                                 else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                             }
                         }
+                        if constexpr (CODEC != 32) tiled = launch_rfq(a, CODEC, st);
                         if (tiled) {
                         } else if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);
                         else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true>>(a, st);

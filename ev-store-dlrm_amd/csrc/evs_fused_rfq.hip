@@ -1,0 +1,380 @@
+// Fused embedding gather + pairwise-dot interaction over REDUCED-PRECISION tables (u16 / u8 / u4 codes), rows in flight
+// in registers.
+//
+// Same computation and the same bits as emb_interact_dot_lds_kernel<CODEC, ..., BAG1> (evs_fused.hip):
+//     R[b] = [ x[b] | strict-lower(T[b] T[b]^T) ],  T[b] = [x[b]; dec(W_0[idx_0[b]]); ...; dec(W_{F-2}[idx_{F-2}[b]])]
+// (dlrm_s_pytorch.py:407-461 apply_emb over the decoded mixed-precision tables of mixed_precs_caching/evlfu_{16,8,4}.cpp,
+//  one index per bag -- the Criteo collate, dlrm_data_pytorch.py:407-408 -- then :483-516 interact_features), one wavefront
+// per sample, the same decoders (evs_common.h) and the same MFMA 16x16x4 f32 chains in the same order.
+//
+// Why a kernel of its own.  The LDS-DMA loop keeps ONE sample per wave in flight; with encoded rows that sample is 26 x 72
+// (u16), 36 (u8) or 18 (u4) bytes, so a CU has half, a quarter, an eighth of the fp32 bytes on the wire and the launch is
+// bound by memory LATENCY at a third of the HBM rate (B = 16 384, d = 36: u16 25.7 us where the fp32 launch takes 19.3 us
+// for twice the bytes).  An encoded row is small enough to be fetched directly in the MFMA operand mapping -- lane
+// (r16, q) of row r16 + 16 rr needs the CQ chunks [q CQ, (q + 1) CQ) of that row (CQ x {8, 4, 2} contiguous bytes: one
+// load) and the REM trailing chunk (one more) -- so there is no transpose through LDS at all, and a d = 36 u16 sample in
+// flight is 13 VGPRs (16 for fp32 in evs_fused_rf.hip).  A block owns one 16-sample chunk; every wave requests the rows of
+// its 4 samples at once and consumes them in order under counted s_waitcnt vmcnt (straight-line code, see evs_fused_rf.hip).
+// x (fp32) travels one float per lane and is spread to the operand mapping through a 256-byte LDS slot per wave.
+#include "evs_fused.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+namespace evs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef EVS_RFQ_LB
+#define EVS_RFQ_LB 4
+#endif
+#ifndef EVS_OUT_CPOL
+#define EVS_OUT_CPOL 2   // nt: R is written once and streams out (see evs_fused.hip)
+#endif
+
+// N raw bytes at p (global address space: a flat load would force every later wait to vmcnt(0)) -> w[0 .. max(1, N/4))
+template <int N>
+__device__ __forceinline__ void load_raw(unsigned long long p, unsigned (&w)[N >= 4 ? N / 4 : 1]) {
+    if constexpr (N == 16) {
+        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>((uintptr_t)p);
+        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
+    } else if constexpr (N == 8) {
+        const u32x2 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x2 *>((uintptr_t)p);
+        w[0] = v[0]; w[1] = v[1];
+    } else if constexpr (N == 4) {
+        w[0] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned *>((uintptr_t)p);
+    } else {
+        static_assert(N == 2, "raw pieces of 16, 8, 4 or 2 bytes");
+        w[0] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned short *>((uintptr_t)p);
+    }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// two u16 codes of the main range (<= 65 000) -> two floats: the same value and the same three roundings as dec_u16_main
+// (evs_common.h) -- (float)v - 32 500.0f is exact, like the integer subtraction there -- written on float pairs so that
+// the subtraction, the product and the fma are one packed instruction each (v_pk_add/mul/fma_f32)
+__device__ __forceinline__ f32x2 dec_u16_main2(unsigned w) {
+    f32x2 f = {(float)(w & 0xffffu), (float)(w >> 16)};
+    f = f - 32500.0f;
+    const f32x2 lo = f * 5.052425e-13f;
+    return __builtin_elementwise_fma(f, (f32x2){2e-05f, 2e-05f}, lo);
+}
+// one chunk (4 elements).  FAST (u16 only): the caller has checked that no lane of the wave holds a tail code (> 65 000)
+template <int CODEC, bool FAST>
+__device__ __forceinline__ float4 dec_chunk_q(unsigned w0, unsigned w1, const float *lut) {
+    if constexpr (CODEC == 16 && FAST) {
+        const f32x2 a = dec_u16_main2(w0), b = dec_u16_main2(w1);
+        return make_float4(a[0], a[1], b[0], b[1]);
+    } else if constexpr (CODEC == 16) {
+        return make_float4(dec_code<16>(w0 & 0xffffu, lut), dec_code<16>(w0 >> 16, lut), dec_code<16>(w1 & 0xffffu, lut), dec_code<16>(w1 >> 16, lut));
+    } else {
+        return dec_chunk<CODEC>(w0, w1, lut);
+    }
+}
+// element e (0..3, per lane) of a chunk
+template <int CODEC, bool FAST>
+__device__ __forceinline__ float dec_elem_q(unsigned w0, unsigned w1, int e, const float *lut) {
+    if constexpr (CODEC == 16) {
+        const unsigned v = (((e & 2) ? w1 : w0) >> (16 * (e & 1))) & 0xffffu;
+        if constexpr (FAST) return dec_u16_main(v); else return dec_code<16>(v, lut);
+    } else if constexpr (CODEC == 8) {
+        return lut[(w0 >> (8 * e)) & 0xffu];
+    } else {   // u4: element 2j is the HIGH nibble of byte j
+        return lut[(w0 >> (8 * (e >> 1) + ((e & 1) ? 0 : 4))) & 15u];
+    }
+}
+
+template <int CODEC, int CQ, int REM, int NT>
+__global__ void __launch_bounds__(256, EVS_RFQ_LB) emb_interact_rfq_kernel(const FusedArgs args) {
+    // optimistic launches (offsets given, see offsets_arange_kernel in evs_fused.hip): this is the one-index-per-bag loop
+    if (args.opt_flag && *args.opt_flag == args.opt_id) return;
+    constexpr int NR = NT;
+    constexpr int NC = CQ + REM;
+    constexpr int d = 4 * (4 * CQ + REM);
+    constexpr int NROWS = 16 * NT;
+    constexpr int D = 4;                          // samples per wave, all in flight at once
+    constexpr int kChunkBytes = CODEC / 2;        // 4 elements
+    constexpr int row_bytes = d * CODEC / 8;
+    constexpr int kMainBytes = CQ * kChunkBytes;  // this lane's contiguous share of a row
+    constexpr int kMainDw = kMainBytes >= 4 ? kMainBytes / 4 : 1;
+    constexpr int kRemDw = kChunkBytes >= 4 ? kChunkBytes / 4 : 1;
+    static_assert(d <= 64, "x travels one float per lane");
+    __shared__ int s_idx[512];                    // [32 features][16 samples]: row id, sample id (x), -1 = no row
+    __shared__ __attribute__((aligned(16))) float s_x[4][64];
+    __shared__ float s_lut[CodecLut<CODEC>::kEntries];
+    constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
+    __shared__ __attribute__((aligned(16))) float s_out[4][OUT_MAX + 16];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int F = args.F, itself = args.itself;
+    const int out_row = d + args.P;
+    const int64_t B = args.B;
+    const FusedArgs *ka = (const FusedArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *my_out = s_out[wave_in_block];
+    float *my_x = s_x[wave_in_block];
+    const unsigned long long zeros_p = (unsigned long long)reinterpret_cast<uintptr_t>(args.zeros);
+    // a page of the code that decodes to exactly 0.0f (u16 32 500, u8 127, u4 7): what a lane reads for a row that does not
+    // exist (no such feature, index out of range) -- no select behind the decoder
+    const unsigned long long zc_p = (unsigned long long)reinterpret_cast<uintptr_t>(args.zero_codes);
+
+    const int64_t blk_first = (int64_t)blockIdx.x * 16;
+    const int64_t blk_end = blk_first + 16 < B ? blk_first + 16 : B;
+    if (blk_first >= blk_end) return;       // block-uniform
+    const int blk_n = (int)(blk_end - blk_first);
+    const int n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
+
+    // ---- index tile: thread e (and e + 256) owns element (feature e >> 4, sample e & 15) -------------------------------
+    bool bad = false;
+    {
+        const int64_t bs = blk_first + (threadIdx.x & 15);
+        int64_t v[2];
+        int kind[2];
+        unsigned nr[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            const int64_t *ip = (f >= 1 && f < F) ? ka->indices[f] : nullptr;
+            kind[h] = f >= F ? 0 : (f == 0 ? 1 : 2);
+            nr[h] = (f >= 1 && f < F) ? (unsigned)ka->n_rows[f] : 0u;
+            const int64_t *ap = (ip && bs < blk_end) ? ip + bs : args.dummy_i64;
+            v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(ap));
+        }
+        codec_lut_init<CODEC>(s_lut);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const bool live = kind[h] != 0 && bs < blk_end;
+            const int64_t val = kind[h] == 2 ? v[h] : bs;     // x: the sample number
+            const bool in_range = kind[h] == 1 || (uint64_t)val < (uint64_t)nr[h];
+            bad |= live & !in_range;
+            s_idx[(int)threadIdx.x + 256 * h] = (live & in_range) ? (int)val : -1;
+        }
+    }
+    // ---- this lane's rows in the MFMA operand mapping: row r16 + 16 rr, chunks [q CQ, (q + 1) CQ) and the REM tail -------
+    unsigned long long fbase[NR];
+    unsigned fscale[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const int f = r16 + 16 * rr;
+        // (row 0 -- x, fp32, spread from LDS below -- and the rows past F read the zero-code page like an absent row)
+        const bool on = f >= 1 && f < F;
+        fbase[rr] = on ? (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]) : zc_p;
+        fscale[rr] = on ? (unsigned)row_bytes : 0u;
+    }
+    const unsigned long long xbase = (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[0]);
+    const unsigned xscale = (unsigned)(ka->stride[0] * 4);
+    __syncthreads();
+
+    constexpr int kOob = 0x7ffffff0;
+    auto flush_out = [&](int64_t bp, bool on) {
+#ifdef EVS_XQ_NOSTORE   // developer A/B (timing only): R is never written
+        on = false;
+#endif
+        float *Rb = args.R + (on ? bp : 0) * (int64_t)out_row;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, on ? out_row * 4 : 0, 0x00020000);
+        const int n4 = out_row >> 2;   // whole 16-byte pieces; the 0..3 trailing floats go as dwords
+#pragma unroll
+        for (int h = 0; h < (OUT_MAX + 255) / 256; h++) {
+            const int e4 = lane + 64 * h;
+            const float4 v = reinterpret_cast<const float4 *>(my_out)[e4 < n4 ? e4 : 0];
+            u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, EVS_OUT_CPOL);
+        }
+        {
+            const int e = 4 * n4 + (lane & 3);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, EVS_OUT_CPOL);
+        }
+    };
+
+    // ---- request the rows of all D samples of this wave ----------------------------------------------------------------
+    unsigned rmain[D][NR][kMainDw], rrem[D][NR][REM > 0 ? REM : 1][kRemDw];
+    float rx[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const int m = wave_in_block + 4 * u;              // block-local sample
+        const unsigned phantom = u < n_samples ? 0u : 0xffffffffu;   // past this wave's samples: every lane reads the zero page
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int iv = s_idx[(r16 + 16 * rr) * 16 + m];
+            // branch-free (bit blends, no selects over the LDS reads -- see evs_fused_rf.hip): -1 -> the zero page
+            const unsigned neg = (unsigned)(iv >> 31) | phantom;
+            const unsigned idx = (unsigned)iv & ~neg;
+            const unsigned long long p = fbase[rr] + (unsigned long long)idx * (unsigned long long)fscale[rr];
+            const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
+            const unsigned long long pa = p ^ ((p ^ zc_p) & m64);
+            load_raw<kMainBytes>(pa + q * kMainBytes, rmain[u][rr]);
+#pragma unroll
+            for (int t = 0; t < REM; t++) load_raw<kChunkBytes>(pa + 4 * kMainBytes + t * kChunkBytes, rrem[u][rr][t]);
+        }
+        {
+            const unsigned long long p = xbase + (unsigned long long)(unsigned)(blk_first + m) * (unsigned long long)xscale + 4 * (lane < d ? lane : 0);
+            const unsigned long long m64 = ((unsigned long long)phantom << 32) | phantom;
+            const unsigned long long pa = p ^ ((p ^ zeros_p) & m64);
+            rx[u] = *reinterpret_cast<const __attribute__((address_space(1))) float *>((uintptr_t)pa);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep every request above the first consume
+
+    auto chunk_words = [&](const unsigned (&w)[kMainDw], int c, unsigned &w0, unsigned &w1) {
+        if constexpr (CODEC == 16) { w0 = w[2 * c]; w1 = w[2 * c + 1]; }
+        else if constexpr (CODEC == 8) { w0 = w[c]; w1 = 0; }
+        else { w0 = (w[0] >> (16 * c)) & 0xffffu; w1 = 0; }
+    };
+
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;   // wave-uniform
+        my_x[lane] = rx[u];
+        // operands: a[rr][c] = the 4 elements of chunk c (c < CQ: this k-slot's own chunks); of the REM trailing chunks
+        // k-slot q feeds only element q to the matrix core: a[rr][CQ + t].x holds it, nothing else is decoded
+        float4 a[NR][NC];
+        auto decode = [&](auto fast) {
+            constexpr bool FAST = decltype(fast)::value;
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    unsigned w0, w1;
+                    if (c < CQ) chunk_words(rmain[u][rr], c, w0, w1);
+                    else { w0 = rrem[u][rr][c - CQ][0]; w1 = CODEC == 16 ? rrem[u][rr][c - CQ][kRemDw - 1] : 0u; }
+#ifdef EVS_XQ_NODEC   // developer A/B (timing only, wrong R): no decode
+                    a[rr][c] = make_float4(__uint_as_float(w0), __uint_as_float(w1), __uint_as_float(w0 ^ w1), __uint_as_float(w0 + w1));
+#else
+                    if (c < CQ) a[rr][c] = dec_chunk_q<CODEC, FAST>(w0, w1, s_lut);
+                    else a[rr][c] = make_float4(dec_elem_q<CODEC, FAST>(w0, w1, q, s_lut), 0.f, 0.f, 0.f);
+#endif
+                }
+            }
+        };
+        if constexpr (CODEC == 16) {
+            // tail codes (> 65 000: |x| > 0.65, decoded through the LDS table) do not occur in tables encoded from trained
+            // embeddings: ONE wave-uniform test per sample (packed u16 max over the lane's 12 raw words) picks the decoder
+            u16x2 mx = __builtin_bit_cast(u16x2, rmain[u][0][0]);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+                for (int k = 0; k < kMainDw; k++) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, rmain[u][rr][k]));
+#pragma unroll
+                for (int t = 0; t < REM; t++)
+#pragma unroll
+                    for (int k = 0; k < kRemDw; k++) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, rrem[u][rr][t][k]));
+            }
+            const bool tail = mx[0] > 65000 || mx[1] > 65000;
+            if (__builtin_amdgcn_ballot_w64(tail) == 0ull) decode(std::true_type{}); else decode(std::false_type{});
+        } else {
+            decode(std::false_type{});
+        }
+        {   // row 0 is x: plain fp32 chunks
+#pragma unroll
+            for (int c = 0; c < CQ; c++) {
+                const float4 xa = *reinterpret_cast<const float4 *>(my_x + (q * CQ + c) * 4);
+                if (r16 == 0) a[0][c] = xa;
+            }
+#pragma unroll
+            for (int t = 0; t < REM; t++) {
+                const float xe = my_x[4 * CQ * 4 + 4 * t + q];
+                if (r16 == 0) a[0][CQ + t].x = xe;
+            }
+        }
+        const float xv = rx[u];
+        flush_out(b - 4, u > 0 && u - 1 < n_samples);    // sample u-1 leaves under the MFMAs of sample u
+        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
+#ifdef EVS_XQ_NOMFMA   // developer A/B (timing only, wrong R): three adds per operand chunk instead of the matrix-core work
+#pragma unroll
+        for (int c = 0; c < NC; c++) { c00[c & 3] += a[0][c].x + a[0][c].y; c10[c & 3] += a[NR - 1][c].z; c11[c & 3] += a[NR - 1][c].w + a[0][c].z; }
+#else
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float e0[4] = {a[0][c].x, a[0][c].y, a[0][c].z, a[0][c].w};
+            const float e1[4] = {a[NR - 1][c].x, a[NR - 1][c].y, a[NR - 1][c].z, a[NR - 1][c].w};
+            if (c < CQ) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[e], e0[e], c00, 0, 0, 0);
+                    if constexpr (NT == 2) {
+                        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e0[e], c10, 0, 0, 0);
+                        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e1[e], c11, 0, 0, 0);
+                    }
+                }
+            } else {   // the REM trailing chunks are held by all four k-slots; slot q contributes element q
+                const float s0 = e0[0], s1 = e1[0];
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, s0, c00, 0, 0, 0);
+                if constexpr (NT == 2) {
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s0, c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s1, c11, 0, 0, 0);
+                }
+            }
+        }
+#endif
+        // stage the output row: x passthrough, then the packed lower triangle straight from the accumulators;
+        // never-stored elements go to a dump slot behind the row
+        const int dump = 4 * (OUT_MAX + r16);
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + (lane < d ? 4 * lane : dump)) = xv;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int i = 4 * q + v;
+            const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
+            if constexpr (NT == 2) {
+                const int gi = 16 + i;
+                const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+                const int zo10 = gi < F ? 4 * (d + base + r16) : dump;
+                const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = c10[v];
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[v];
+            }
+        }
+    }
+    flush_out(blk_first + wave_in_block + 12, n_samples == 4);
+    if (bad) atomicOr(args.err, 1);
+}
+
+static int rfq_mode() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_RFQ"); v = e ? atoi(e) : 1; }   // developer switch: 0 = the LDS-DMA loop
+    return v;
+}
+static int64_t rfq_max_batch() {
+    static int64_t v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_RFQ_MAX_B"); v = e ? atoll(e) : (1ll << 40); }
+    return v;
+}
+
+template <int CODEC, int CQ, int REM>
+static void launch_rfq_nt(const FusedArgs &a, hipStream_t st) {
+    const unsigned blocks = (unsigned)((a.B + 15) / 16);
+    if (a.F > 16) hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, CQ, REM, 2>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, CQ, REM, 1>), dim3(blocks), dim3(256), 0, st, a);
+}
+template <int CODEC>
+static bool launch_rfq_d(const FusedArgs &a, hipStream_t st) {
+    switch (a.d) {
+    case 16: launch_rfq_nt<CODEC, 1, 0>(a, st); return true;
+    case 32: launch_rfq_nt<CODEC, 2, 0>(a, st); return true;
+    case 36: launch_rfq_nt<CODEC, 2, 1>(a, st); return true;
+    default: return false;
+    }
+}
+
+bool launch_rfq(const FusedArgs &a, int codec, hipStream_t st) {
+    if (codec != 16 && codec != 8 && codec != 4) return false;
+    if (!rfq_mode() || !a.enc_lds || a.F > kTileMaxF || (a.bag1 != 1 && a.bag1 != 2) || a.B > rfq_max_batch() || a.B >= (1ll << 31)) return false;
+    if (a.d != 16 && a.d != 32 && a.d != 36) return false;
+    FusedArgs b = a;
+    b.zero_codes = zero_code_page(codec);
+    if (!b.zero_codes) return false;
+    switch (codec) {
+    case 16: return launch_rfq_d<16>(b, st);
+    case 8: return launch_rfq_d<8>(b, st);
+    case 4: return launch_rfq_d<4>(b, st);
+    default: return false;
+    }
+}
+
+}  // namespace evs

@@ -33,9 +33,10 @@ def main():
     ap.add_argument("--dist", default="uniform")
     ap.add_argument("--fused-only", action="store_true")
     ap.add_argument("--bits", type=int, default=32, help="table precision 32|16|8|4 (reduced: fused timings only)")
+    ap.add_argument("--codes", default="random", help="reduced precision: random codes | encoded (the fp32 init through the reference's encoders)")
     a = ap.parse_args()
     d = a.dim
-    ev = bench.make_tables(bench.KAGGLE_LN, d, bits=a.bits)
+    ev = bench.make_tables(bench.KAGGLE_LN, d, bits=a.bits, codes=a.codes)
     T = 26
     for B in a.batch:
         batches = bench.make_batches(bench.KAGGLE_LN, B, 8, 1, "cuda", a.dist)
