@@ -24,6 +24,8 @@ struct FusedArgs {
     int bag1;                  // 1: every indirect feature has one index per bag, no offsets array;
                                // 2: offsets ARE given and the launch bets they are arange (see opt_flag);
                                // 3: offsets given, whole batch: the index-tile loop checks them chunk by chunk itself
+                               // 4: (reduced precision) offsets given, whole batch: evs_fused_rfq checks them per block and pools the
+                               //    blocks that fail in its own slow loop
     int *opt_flag; int opt_id; // optimistic launch triple: offsets_arange_kernel writes opt_id here when an offsets
                                // array is not arange; then the bag-1 loop runs if it is absent, the general loop if present
     int enc_lds;               // reduced precision: feature 0 is x, every other feature a 4-byte aligned table
@@ -62,5 +64,6 @@ bool launch_rf_probe(const FusedArgs &a, hipStream_t st);
 // evs_fused_rfq.hip: reduced-precision tables (codec 16 / 8 / 4), encoded rows in flight in registers in the MFMA operand
 // mapping; bag1 == 1 (no offsets) or 2 (the one-index-per-bag leg of the optimistic triple); false = no kernel for the shape
 bool launch_rfq(const FusedArgs &a, int codec, hipStream_t st);
+bool rfq_supported(const FusedArgs &a, int codec);
 
 }  // namespace evs

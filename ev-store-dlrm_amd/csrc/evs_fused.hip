@@ -1161,6 +1161,13 @@ static int64_t tile_min_batch() {
     if (v < 0) { const char *e = getenv("EVS_FUSED_TILE_MIN_B"); v = e ? atoll(e) : 2048; }   // (below: one chunk per block at most, nothing to win)
     return v;
 }
+// reduced precision, offsets given, whole batches: from this batch size on the rows-in-registers kernel checks the offsets
+// itself (evs_fused_rfq.hip, CHECK)
+static int64_t rfq_check_min_batch() {
+    static int64_t v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_RFQ_CHECK_MIN_B"); v = e ? atoll(e) : 256; }
+    return v;
+}
 static bool tile_eligible(const FusedArgs &a, int codec) {
     return codec == 32 && tile_mode() && a.B >= tile_min_batch() && a.F <= kTileMaxF;
 }
@@ -1211,6 +1218,17 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                         if (a.bag1 == 3) {   // the index-tile loop checks the offsets itself and pools failing chunks the slow way
                             if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
                             else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
+                            return;
+                        }
+                    }
+                    if constexpr (CODEC != 32) {
+                        // the rows-in-registers kernel checks the offsets itself and pools the blocks that fail the slow way
+                        if (a.bag1 == 4) {
+                            if (launch_rfq(a, CODEC, st)) return;
+                            FusedArgs g = a;   // (no zero-code page: the general loop)
+                            g.bag1 = 0;
+                            if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, false>>(g, st);
+                            else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, false>>(g, st);
                             return;
                         }
                     }
@@ -1425,7 +1443,7 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
     // at all: ONE launch of the index-tile loop that checks its own bags and pools the chunks that fail the slow way
     // (bag1 = 3).  Batch SLICES of longer arrays (offsets_len > B + 1: their offsets do not start at 0 unless the
     // slice does) keep the separate check.
-    if (indirect && !a.bag1 && !weighted && (codec == 32 || a.enc_lds) && (B >= 8192 || tile_eligible(a, codec)) && optimistic_enabled()) {
+    if (indirect && !a.bag1 && !weighted && (codec == 32 || a.enc_lds) && (B >= 8192 || tile_eligible(a, codec) || (codec != 32 && B >= rfq_check_min_batch())) && optimistic_enabled()) {
         bool can = true, whole = true;
         for (int f = 0; f < F && can; f++)
             if (feats[f].indices) {
@@ -1434,6 +1452,8 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
             }
         if (can && whole && tile_eligible(a, codec)) {
             a.bag1 = 3;
+        } else if (can && whole && B >= rfq_check_min_batch() && rfq_supported(a, codec)) {
+            a.bag1 = 4;
         } else if (can && B >= 8192) {
             a.opt_flag = optimistic_slot(&a.opt_id);
             if (!a.opt_flag) return EVS_EHIP;

@@ -27,9 +27,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef EVS_RFQ_LB
-#define EVS_RFQ_LB 4
+// blocks per CU the register allocation aims at.  Batches above 16 K samples are several generations of blocks, and what
+// bounds them is the number of samples in flight per CU: 96 VGPRs = 5 blocks (u16), 80 = 6 (u8 / u4).  Measured at
+// B = 65 536, d = 36 u16: 105 VGPRs (4 blocks) 73 us, 95 (5 blocks) 62.7 us.
+#ifndef EVS_RFQ_LB16
+#define EVS_RFQ_LB16 4
 #endif
+#ifndef EVS_RFQ_LB8
+#define EVS_RFQ_LB8 6
+#endif
+constexpr int rfq_min_blocks(int codec) { return codec == 16 ? EVS_RFQ_LB16 : EVS_RFQ_LB8; }
 #ifndef EVS_OUT_CPOL
 #define EVS_OUT_CPOL 2   // nt: R is written once and streams out (see evs_fused.hip)
 #endif
@@ -88,10 +95,18 @@ __device__ __forceinline__ float dec_elem_q(unsigned w0, unsigned w1, int e, con
     }
 }
 
-template <int CODEC, int CQ, int REM, int NT>
-__global__ void __launch_bounds__(256, EVS_RFQ_LB) emb_interact_rfq_kernel(const FusedArgs args) {
+// CHECK (offsets given, whole batches: nnz == B, B or B + 1 offsets): the block also loads the offsets of its 16 samples and
+// checks that every bag is exactly {idx[b]} (offsets[b] == b and the bag ends at b + 1) -- the Criteo collate's arange
+// offsets then cost one more line per table and block, not a kernel.  A block's results depend on its own bags only, so a
+// block that finds anything else pools ITS samples in a slow loop straight from global memory (general semantics: empty
+// bags, several indices summed in index order, bad offsets / indices skipped and flagged -- the arithmetic of the general
+// loop of evs_fused.hip) and feeds the same MFMA + output code.  No flag, no second launch.
+template <int CODEC, int CQ, int REM, int NT, bool CHECK = false>
+__global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_kernel(const FusedArgs args) {
     // optimistic launches (offsets given, see offsets_arange_kernel in evs_fused.hip): this is the one-index-per-bag loop
-    if (args.opt_flag && *args.opt_flag == args.opt_id) return;
+    if constexpr (!CHECK) {
+        if (args.opt_flag && *args.opt_flag == args.opt_id) return;
+    }
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
     constexpr int d = 4 * (4 * CQ + REM);
@@ -131,28 +146,84 @@ __global__ void __launch_bounds__(256, EVS_RFQ_LB) emb_interact_rfq_kernel(const
     const int n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
 
     // ---- index tile: thread e (and e + 256) owns element (feature e >> 4, sample e & 15) -------------------------------
-    bool bad = false;
+    bool bad = false, my_ragged = false;
     {
         const int64_t bs = blk_first + (threadIdx.x & 15);
-        int64_t v[2];
+        int64_t v[2], o0[2], o1[2];
+        bool own_end[2] = {false, false}, live_bag[2] = {false, false}, at_nnz[2] = {false, false};
+        int64_t nzv[2] = {0, 0};
         int kind[2];
         unsigned nr[2];
+        // the per-feature launch arguments of this wave's 4 + 4 features come through the scalar cache (wave-uniform
+        // addresses: s_load) and are picked per lane -- a per-lane read of the kernarg segment would be one more
+        // vector-memory round trip in front of the index loads
+        const int sel = lane >> 4;
+        typedef long long ll4 __attribute__((ext_vector_type(4)));
+        const long long m0 = -(long long)(sel == 0), m1 = -(long long)(sel == 1), m2 = -(long long)(sel == 2), m3 = -(long long)(sel == 3);
+        auto pick = [&](const int64_t *arr4) -> int64_t {   // arr4[sel], arr4 wave-uniform: one s_load_dwordx8, a bit blend
+            const ll4 a = *reinterpret_cast<const ll4 *>(arr4);   // (selects here become branches around the loads)
+            return (int64_t)((a[0] & m0) | (a[1] & m1) | (a[2] & m2) | (a[3] & m3));
+        };
+        // (every scalar load first, unconditionally and back to back: one wait for all of them)
+        int64_t k_ip[2], k_nr[2], k_op[2] = {0, 0}, k_ol[2] = {0, 0}, k_nz[2] = {0, 0};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int f = ((int)threadIdx.x >> 4) + 16 * h;
-            const int64_t *ip = (f >= 1 && f < F) ? ka->indices[f] : nullptr;
+            const int f0 = 4 * wave_in_block + 16 * h;      // wave-uniform; this lane's feature is f0 + sel (< EVS_MAX_FEATURES)
+            k_ip[h] = pick(reinterpret_cast<const int64_t *>(&ka->indices[f0]));
+            k_nr[h] = pick(&ka->n_rows[f0]);
+            if constexpr (CHECK) {
+                k_op[h] = pick(reinterpret_cast<const int64_t *>(&ka->offsets[f0]));
+                k_ol[h] = pick(&ka->off_len[f0]);
+                k_nz[h] = pick(&ka->nnz[f0]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = 4 * wave_in_block + 16 * h + sel;
+            const bool tab = f >= 1 && f < F;
+            const int64_t *ip = tab ? reinterpret_cast<const int64_t *>(k_ip[h]) : nullptr;
             kind[h] = f >= F ? 0 : (f == 0 ? 1 : 2);
-            nr[h] = (f >= 1 && f < F) ? (unsigned)ka->n_rows[f] : 0u;
+            nr[h] = tab ? (unsigned)k_nr[h] : 0u;
             const int64_t *ap = (ip && bs < blk_end) ? ip + bs : args.dummy_i64;
             v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(ap));
+            if constexpr (CHECK) {
+                // bag b ends where bag b + 1 starts: that is the neighbour lane's offset, except behind the block's last sample
+                const bool on = ip && bs < blk_end;
+                const int64_t *op = reinterpret_cast<const int64_t *>(k_op[h]);
+                const int64_t ol = k_ol[h], nz = k_nz[h];
+                const bool own = on && ((threadIdx.x & 15) == 15 || bs + 1 >= blk_end);
+#ifdef EVS_XQ_NOOFF   // developer A/B (timing only): the check without its loads
+                const int64_t *p0 = args.dummy_i64 + (op == nullptr), *p1 = args.dummy_i64 + (ol == 1);
+#else
+                const int64_t *p0 = on ? op + bs : args.dummy_i64;
+                const int64_t *p1 = (own && bs + 1 < ol) ? op + bs + 1 : args.dummy_i64;
+#endif
+                o0[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(p0));
+                o1[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(p1));
+                own_end[h] = own; live_bag[h] = on; at_nnz[h] = own && !(bs + 1 < ol); nzv[h] = nz;
+            }
+        }
+        if constexpr (CHECK) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int64_t nb = __shfl_down((long long)o0[h], 1);
+                if (!own_end[h]) o1[h] = nb;
+                if (at_nnz[h]) o1[h] = nzv[h];              // the last bag ends at nnz
+                if (!live_bag[h]) { o0[h] = bs; o1[h] = bs + 1; }
+            }
         }
         codec_lut_init<CODEC>(s_lut);
+        if constexpr (CHECK) my_ragged = o0[0] != bs || o1[0] != bs + 1 || o0[1] != bs || o1[1] != bs + 1;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const bool live = kind[h] != 0 && bs < blk_end;
             const int64_t val = kind[h] == 2 ? v[h] : bs;     // x: the sample number
             const bool in_range = kind[h] == 1 || (uint64_t)val < (uint64_t)nr[h];
-            bad |= live & !in_range;
+            // (CHECK: an index whose own bag is not {idx[b]} may sit at a position no bag refers to -- the slow loop, which
+            //  this block then runs, has the verdict on it)
+            bool mine = true;
+            if constexpr (CHECK) mine = o0[h] == bs && o1[h] == bs + 1;
+            bad |= live & !in_range & mine;
             s_idx[(int)threadIdx.x + 256 * h] = (live & in_range) ? (int)val : -1;
         }
     }
@@ -169,7 +240,19 @@ __global__ void __launch_bounds__(256, EVS_RFQ_LB) emb_interact_rfq_kernel(const
     }
     const unsigned long long xbase = (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[0]);
     const unsigned xscale = (unsigned)(ka->stride[0] * 4);
+    bool blk_ragged = false;
+#ifdef EVS_XQ_NOOR   // developer A/B (timing only): plain barrier, no verdict
     __syncthreads();
+    if (my_ragged && args.B == 12345) bad = true;
+#else
+    if constexpr (CHECK) blk_ragged = __syncthreads_or(my_ragged); else __syncthreads();
+#endif
+#ifdef EVS_XQ_NOSLOW   // developer A/B (timing only): no slow loop in the kernel
+    blk_ragged = false;
+#endif
+#ifdef EVS_XQ_NOOFF
+    blk_ragged = blk_ragged && args.B == 12345;
+#endif
 
     constexpr int kOob = 0x7ffffff0;
     auto flush_out = [&](int64_t bp, bool on) {
@@ -192,85 +275,14 @@ __global__ void __launch_bounds__(256, EVS_RFQ_LB) emb_interact_rfq_kernel(const
         }
     };
 
-    // ---- request the rows of all D samples of this wave ----------------------------------------------------------------
-    unsigned rmain[D][NR][kMainDw], rrem[D][NR][REM > 0 ? REM : 1][kRemDw];
-    float rx[D];
-#pragma unroll
-    for (int u = 0; u < D; u++) {
-        const int m = wave_in_block + 4 * u;              // block-local sample
-        const unsigned phantom = u < n_samples ? 0u : 0xffffffffu;   // past this wave's samples: every lane reads the zero page
-#pragma unroll
-        for (int rr = 0; rr < NR; rr++) {
-            const int iv = s_idx[(r16 + 16 * rr) * 16 + m];
-            // branch-free (bit blends, no selects over the LDS reads -- see evs_fused_rf.hip): -1 -> the zero page
-            const unsigned neg = (unsigned)(iv >> 31) | phantom;
-            const unsigned idx = (unsigned)iv & ~neg;
-            const unsigned long long p = fbase[rr] + (unsigned long long)idx * (unsigned long long)fscale[rr];
-            const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
-            const unsigned long long pa = p ^ ((p ^ zc_p) & m64);
-            load_raw<kMainBytes>(pa + q * kMainBytes, rmain[u][rr]);
-#pragma unroll
-            for (int t = 0; t < REM; t++) load_raw<kChunkBytes>(pa + 4 * kMainBytes + t * kChunkBytes, rrem[u][rr][t]);
-        }
-        {
-            const unsigned long long p = xbase + (unsigned long long)(unsigned)(blk_first + m) * (unsigned long long)xscale + 4 * (lane < d ? lane : 0);
-            const unsigned long long m64 = ((unsigned long long)phantom << 32) | phantom;
-            const unsigned long long pa = p ^ ((p ^ zeros_p) & m64);
-            rx[u] = *reinterpret_cast<const __attribute__((address_space(1))) float *>((uintptr_t)pa);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keep every request above the first consume
-
     auto chunk_words = [&](const unsigned (&w)[kMainDw], int c, unsigned &w0, unsigned &w1) {
         if constexpr (CODEC == 16) { w0 = w[2 * c]; w1 = w[2 * c + 1]; }
         else if constexpr (CODEC == 8) { w0 = w[c]; w1 = 0; }
         else { w0 = (w[0] >> (16 * c)) & 0xffffu; w1 = 0; }
     };
-
-#pragma unroll
-    for (int u = 0; u < D; u++) {
-        const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;   // wave-uniform
-        my_x[lane] = rx[u];
-        // operands: a[rr][c] = the 4 elements of chunk c (c < CQ: this k-slot's own chunks); of the REM trailing chunks
-        // k-slot q feeds only element q to the matrix core: a[rr][CQ + t].x holds it, nothing else is decoded
-        float4 a[NR][NC];
-        auto decode = [&](auto fast) {
-            constexpr bool FAST = decltype(fast)::value;
-#pragma unroll
-            for (int rr = 0; rr < NR; rr++) {
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    unsigned w0, w1;
-                    if (c < CQ) chunk_words(rmain[u][rr], c, w0, w1);
-                    else { w0 = rrem[u][rr][c - CQ][0]; w1 = CODEC == 16 ? rrem[u][rr][c - CQ][kRemDw - 1] : 0u; }
-#ifdef EVS_XQ_NODEC   // developer A/B (timing only, wrong R): no decode
-                    a[rr][c] = make_float4(__uint_as_float(w0), __uint_as_float(w1), __uint_as_float(w0 ^ w1), __uint_as_float(w0 + w1));
-#else
-                    if (c < CQ) a[rr][c] = dec_chunk_q<CODEC, FAST>(w0, w1, s_lut);
-                    else a[rr][c] = make_float4(dec_elem_q<CODEC, FAST>(w0, w1, q, s_lut), 0.f, 0.f, 0.f);
-#endif
-                }
-            }
-        };
-        if constexpr (CODEC == 16) {
-            // tail codes (> 65 000: |x| > 0.65, decoded through the LDS table) do not occur in tables encoded from trained
-            // embeddings: ONE wave-uniform test per sample (packed u16 max over the lane's 12 raw words) picks the decoder
-            u16x2 mx = __builtin_bit_cast(u16x2, rmain[u][0][0]);
-#pragma unroll
-            for (int rr = 0; rr < NR; rr++) {
-#pragma unroll
-                for (int k = 0; k < kMainDw; k++) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, rmain[u][rr][k]));
-#pragma unroll
-                for (int t = 0; t < REM; t++)
-#pragma unroll
-                    for (int k = 0; k < kRemDw; k++) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, rrem[u][rr][t][k]));
-            }
-            const bool tail = mx[0] > 65000 || mx[1] > 65000;
-            if (__builtin_amdgcn_ballot_w64(tail) == 0ull) decode(std::true_type{}); else decode(std::false_type{});
-        } else {
-            decode(std::false_type{});
-        }
-        {   // row 0 is x: plain fp32 chunks
+    // row 0 of the operand tile is x: plain fp32 chunks, spread from one float per lane through the wave's LDS slot
+    auto spread_x = [&](float4 (&a)[NR][NC]) {
+        {
 #pragma unroll
             for (int c = 0; c < CQ; c++) {
                 const float4 xa = *reinterpret_cast<const float4 *>(my_x + (q * CQ + c) * 4);
@@ -282,8 +294,9 @@ __global__ void __launch_bounds__(256, EVS_RFQ_LB) emb_interact_rfq_kernel(const
                 if (r16 == 0) a[0][CQ + t].x = xe;
             }
         }
-        const float xv = rx[u];
-        flush_out(b - 4, u > 0 && u - 1 < n_samples);    // sample u-1 leaves under the MFMAs of sample u
+    };
+    // the interaction of one sample (operands in the MFMA layout) and the staging of its output row
+    auto interact_stage = [&](const float4 (&a)[NR][NC], float xv) {
         f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
 #ifdef EVS_XQ_NOMFMA   // developer A/B (timing only, wrong R): three adds per operand chunk instead of the matrix-core work
 #pragma unroll
@@ -330,6 +343,137 @@ __global__ void __launch_bounds__(256, EVS_RFQ_LB) emb_interact_rfq_kernel(const
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[v];
             }
         }
+    };
+
+    if constexpr (CHECK) {
+        if (blk_ragged) {   // block-uniform, rare: this block's samples with general bag semantics, pooled straight from global memory
+            for (int u = 0; u < n_samples; u++) {
+                const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;
+                float4 a[NR][NC];
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) {
+                    const int f = r16 + 16 * rr;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) a[rr][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (f < 1 || f >= F) continue;
+                    const int64_t *ip = ka->indices[f], *op = ka->offsets[f];
+                    const unsigned long long src = (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]);
+                    const int64_t nnz = ka->nnz[f];
+                    int64_t s0 = op[b];
+                    int64_t e0 = (b + 1 < ka->off_len[f]) ? op[b + 1] : nnz;
+                    if (!((s0 >= 0) & (e0 >= s0) & (e0 <= nnz))) { bad = true; s0 = e0 = 0; }
+                    const uint64_t n_rows = (uint64_t)ka->n_rows[f];
+                    for (int64_t j = s0; j < e0; j++) {
+                        const int64_t r = ip[j];
+                        if ((uint64_t)r >= n_rows) { bad = true; continue; }   // skipped; a skipped FIRST row counts as zeros
+                        const unsigned long long row = src + (uint64_t)r * (uint64_t)row_bytes;
+                        unsigned wm[kMainDw], wr[REM > 0 ? REM : 1][kRemDw];
+                        load_raw<kMainBytes>(row + q * kMainBytes, wm);
+#pragma unroll
+                        for (int t = 0; t < REM; t++) load_raw<kChunkBytes>(row + 4 * kMainBytes + t * kChunkBytes, wr[t]);
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            unsigned w0, w1;
+                            float4 t4;
+                            if (c < CQ) { chunk_words(wm, c, w0, w1); t4 = dec_chunk_q<CODEC, false>(w0, w1, s_lut); }
+                            else {
+                                w0 = wr[c - CQ][0]; w1 = CODEC == 16 ? wr[c - CQ][kRemDw - 1] : 0u;
+                                t4 = make_float4(dec_elem_q<CODEC, false>(w0, w1, q, s_lut), 0.f, 0.f, 0.f);
+                            }
+                            if (j == s0) { a[rr][c] = t4; continue; }
+                            a[rr][c].x = __fadd_rn(a[rr][c].x, t4.x); a[rr][c].y = __fadd_rn(a[rr][c].y, t4.y);
+                            a[rr][c].z = __fadd_rn(a[rr][c].z, t4.z); a[rr][c].w = __fadd_rn(a[rr][c].w, t4.w);
+                        }
+                    }
+                }
+                const float xv = *reinterpret_cast<const float *>((uintptr_t)(xbase + (unsigned long long)b * (unsigned long long)xscale + 4 * (lane < d ? lane : 0)));
+                my_x[lane] = xv;
+                spread_x(a);
+                interact_stage(a, xv);
+                flush_out(b, true);
+            }
+            if (bad) atomicOr(args.err, 1);
+            return;
+        }
+    }
+
+    // ---- request the rows of all D samples of this wave ----------------------------------------------------------------
+    unsigned rmain[D][NR][kMainDw], rrem[D][NR][REM > 0 ? REM : 1][kRemDw];
+    float rx[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const int m = wave_in_block + 4 * u;              // block-local sample
+        const unsigned phantom = u < n_samples ? 0u : 0xffffffffu;   // past this wave's samples: every lane reads the zero page
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int iv = s_idx[(r16 + 16 * rr) * 16 + m];
+            // branch-free (bit blends, no selects over the LDS reads -- see evs_fused_rf.hip): -1 -> the zero page
+            const unsigned neg = (unsigned)(iv >> 31) | phantom;
+            const unsigned idx = (unsigned)iv & ~neg;
+            const unsigned long long p = fbase[rr] + (unsigned long long)idx * (unsigned long long)fscale[rr];
+            const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
+            const unsigned long long pa = p ^ ((p ^ zc_p) & m64);
+            load_raw<kMainBytes>(pa + q * kMainBytes, rmain[u][rr]);
+#pragma unroll
+            for (int t = 0; t < REM; t++) load_raw<kChunkBytes>(pa + 4 * kMainBytes + t * kChunkBytes, rrem[u][rr][t]);
+        }
+        {
+            const unsigned long long p = xbase + (unsigned long long)(unsigned)(blk_first + m) * (unsigned long long)xscale + 4 * (lane < d ? lane : 0);
+            const unsigned long long m64 = ((unsigned long long)phantom << 32) | phantom;
+            const unsigned long long pa = p ^ ((p ^ zeros_p) & m64);
+            rx[u] = *reinterpret_cast<const __attribute__((address_space(1))) float *>((uintptr_t)pa);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep every request above the first consume
+
+
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;   // wave-uniform
+        my_x[lane] = rx[u];
+        // operands: a[rr][c] = the 4 elements of chunk c (c < CQ: this k-slot's own chunks); of the REM trailing chunks
+        // k-slot q feeds only element q to the matrix core: a[rr][CQ + t].x holds it, nothing else is decoded
+        float4 a[NR][NC];
+        auto decode = [&](auto fast) {
+            constexpr bool FAST = decltype(fast)::value;
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    unsigned w0, w1;
+                    if (c < CQ) chunk_words(rmain[u][rr], c, w0, w1);
+                    else { w0 = rrem[u][rr][c - CQ][0]; w1 = CODEC == 16 ? rrem[u][rr][c - CQ][kRemDw - 1] : 0u; }
+#ifdef EVS_XQ_NODEC   // developer A/B (timing only, wrong R): no decode
+                    a[rr][c] = make_float4(__uint_as_float(w0), __uint_as_float(w1), __uint_as_float(w0 ^ w1), __uint_as_float(w0 + w1));
+#else
+                    if (c < CQ) a[rr][c] = dec_chunk_q<CODEC, FAST>(w0, w1, s_lut);
+                    else a[rr][c] = make_float4(dec_elem_q<CODEC, FAST>(w0, w1, q, s_lut), 0.f, 0.f, 0.f);
+#endif
+                }
+            }
+        };
+        if constexpr (CODEC == 16) {
+            // tail codes (> 65 000: |x| > 0.65, decoded through the LDS table) do not occur in tables encoded from trained
+            // embeddings: ONE wave-uniform test per sample (packed u16 max over the lane's 12 raw words) picks the decoder
+            u16x2 mx = __builtin_bit_cast(u16x2, rmain[u][0][0]);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+                for (int k = 0; k < kMainDw; k++) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, rmain[u][rr][k]));
+#pragma unroll
+                for (int t = 0; t < REM; t++)
+#pragma unroll
+                    for (int k = 0; k < kRemDw; k++) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, rrem[u][rr][t][k]));
+            }
+            const bool tail = mx[0] > 65000 || mx[1] > 65000;
+            if (__builtin_amdgcn_ballot_w64(tail) == 0ull) decode(std::true_type{}); else decode(std::false_type{});
+        } else {
+            decode(std::false_type{});
+        }
+        spread_x(a);
+        const float xv = rx[u];
+        flush_out(b - 4, u > 0 && u - 1 < n_samples);    // sample u-1 leaves under the MFMAs of sample u
+        interact_stage(a, xv);
     }
     flush_out(blk_first + wave_in_block + 12, n_samples == 4);
     if (bad) atomicOr(args.err, 1);
@@ -349,6 +493,11 @@ static int64_t rfq_max_batch() {
 template <int CODEC, int CQ, int REM>
 static void launch_rfq_nt(const FusedArgs &a, hipStream_t st) {
     const unsigned blocks = (unsigned)((a.B + 15) / 16);
+    if (a.bag1 == 4) {
+        if (a.F > 16) hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, CQ, REM, 2, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, CQ, REM, 1, true>), dim3(blocks), dim3(256), 0, st, a);
+        return;
+    }
     if (a.F > 16) hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, CQ, REM, 2>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, CQ, REM, 1>), dim3(blocks), dim3(256), 0, st, a);
 }
@@ -362,18 +511,23 @@ static bool launch_rfq_d(const FusedArgs &a, hipStream_t st) {
     }
 }
 
-bool launch_rfq(const FusedArgs &a, int codec, hipStream_t st) {
+// is there a kernel for this launch (bag1: 1 no offsets, 2 the one-index-per-bag leg of the optimistic triple, 4 offsets
+// given and checked by the kernel itself)
+bool rfq_supported(const FusedArgs &a, int codec) {
     if (codec != 16 && codec != 8 && codec != 4) return false;
-    if (!rfq_mode() || !a.enc_lds || a.F > kTileMaxF || (a.bag1 != 1 && a.bag1 != 2) || a.B > rfq_max_batch() || a.B >= (1ll << 31)) return false;
-    if (a.d != 16 && a.d != 32 && a.d != 36) return false;
+    if (!rfq_mode() || !a.enc_lds || a.F > kTileMaxF || a.B > rfq_max_batch() || a.B >= (1ll << 31)) return false;
+    return a.d == 16 || a.d == 32 || a.d == 36;
+}
+
+bool launch_rfq(const FusedArgs &a, int codec, hipStream_t st) {
+    if (!rfq_supported(a, codec) || (a.bag1 != 1 && a.bag1 != 2 && a.bag1 != 4)) return false;
     FusedArgs b = a;
     b.zero_codes = zero_code_page(codec);
     if (!b.zero_codes) return false;
     switch (codec) {
     case 16: return launch_rfq_d<16>(b, st);
     case 8: return launch_rfq_d<8>(b, st);
-    case 4: return launch_rfq_d<4>(b, st);
-    default: return false;
+    default: return launch_rfq_d<4>(b, st);
     }
 }
 

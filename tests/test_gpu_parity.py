@@ -475,13 +475,16 @@ def test_fused_codec_26_tables_one_index_per_bag(E, orc, codec):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
-@pytest.mark.parametrize("codec,B", [(32, 8192 + 77), (8, 8192 + 77), (32, 4096 + 5), (32, 2048 + 3), (32, 20000)])
+@pytest.mark.parametrize("codec,B", [(32, 8192 + 77), (8, 8192 + 77), (32, 4096 + 5), (32, 2048 + 3), (32, 20000),
+                                      (16, 8192 + 77), (16, 4096 + 5), (4, 4096 + 5), (8, 16384 + 3), (16, 2048 + 3)])
 def test_fused_optimistic_offsets_pair(E, orc, codec, B):
     """lS_o given: the library bets on offsets == arange (bag-1 loop with the check folded in) and falls back to
     the general loop on the device when the bet is lost.  Won bet, lost bet (one offset moved, one table ragged,
     a longer last bag) and B+1-entry offsets all give the bits of the two-call path."""
     from bench import KAGGLE_LN
-    d = 36   # the bet is placed from 8192 samples up (fp32 rows: from 2048, checked inside the index-tile loop)
+    # the bet is placed from 8192 samples up (fp32 rows: from 2048, checked inside the index-tile loop; reduced precision,
+    # whole batches: from 4096, checked by the rows-in-registers kernel, the general loop behind it when the check fails)
+    d = 36
     rs = np.random.RandomState(5 + codec)
     ln = [min(n, 400) for n in KAGGLE_LN]
     if codec == 32:
