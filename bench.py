@@ -661,7 +661,7 @@ def main():
         result["large_batch"] = {"batch": Bb, "ms_per_step": ms, "value": T * Bb / ms * 1e3, "unit": "lookups/s",
                                  "achieved": Bb * bytes_per_sample / ms / 1e6, "frac": Bb * bytes_per_sample / ms / 1e6 / HBM_PEAK_GBPS}
         red = {}
-        for bits in (8, 4):
+        for bits in (16, 8, 4):
             evq = ev.encode(bits)   # the same tables through the GPU batch encoders (reduce_precision.py semantics)
             ms = timed(lambda i: E.apply_emb_interact(xb, bb[i % 4][0], bb[i % 4][1], evq, None, out=Rb, one_index_per_bag=True), 100)
             bq = T * (d * bits // 8 + 8) + 4 * d + 4 * (d + P)
@@ -669,7 +669,7 @@ def main():
                                  "frac": Bb * bq / ms / 1e6 / HBM_PEAK_GBPS, "bytes_per_sample": bq}
             del evq
         result["reduced_precision_tables"] = {"batch": Bb, "unit": "lookups/s", **red,
-                                              "note": "C2-tier row formats (evlfu_8 / evlfu_4) decoded inside the fused kernel"}
+                                              "note": "the reduced-precision row formats (evlfu_16 / evlfu_8 / evlfu_4), tables encoded from the fp32 ones, decoded inside the fused kernel (evs_fused_rfq: encoded rows in flight in registers)"}
         del bb, xb, Rb
         torch.cuda.empty_cache()
     if not args.no_extras:

@@ -47,8 +47,8 @@ def per_batch_us(fn, n_batches, iters):
     return float(np.percentile(lat, 50)), float(np.percentile(lat, 95)), e0.elapsed_time(e1) * 1e3 / iters
 
 
-def fused_rows(ln, d, bits, batches_B, iters, label):
-    ev = bench.make_tables(ln, d, bits=bits)
+def fused_rows(ln, d, bits, batches_B, iters, label, codes="random"):
+    ev = bench.make_tables(ln, d, bits=bits, codes=codes)
     T = len(ln)
     P = (T + 1) * T // 2
     out = []
@@ -229,6 +229,7 @@ def exact_rows(ev, ln, d, n_req):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only-reduced", action="store_true", help="the reduced-precision rows alone")
     a = ap.parse_args()
     it = 50 if a.quick else 200
     print("# Round-2 sweep (one MI355X, synthetic uniform indices unless stated; HBM peak used: 8 000 GB/s)\n")
@@ -238,14 +239,25 @@ def main():
     print("| shape | d | bits | B | fused p50 µs | p95 µs | G lookups/s | GB/s | of peak | offsets p50 µs | G lookups/s | two-call p50 µs | G lookups/s |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     Bs = [1, 128, 2048, 16384] if a.quick else [1, 128, 2048, 16384, 65536]
+    if a.only_reduced:
+        for bits in (16, 8, 4):
+            for line in fused_rows(bench.KAGGLE_LN, 36, bits, [2048, 16384, 65536], it, "Kaggle, reduced precision, encoded tables", "encoded"):
+                print(line, flush=True)
+        for line in fused_rows(bench.KAGGLE_LN, 36, 16, [16384, 65536], it, "Kaggle, reduced precision, random codes"):
+            print(line, flush=True)
+        return
     for line in fused_rows(bench.KAGGLE_LN, 36, 32, Bs, it, "Kaggle (cfg 2)"):
         print(line, flush=True)
     for d in (16, 64):
         for line in fused_rows(bench.KAGGLE_LN, d, 32, [2048, 16384], it, "Kaggle"):
             print(line, flush=True)
+    # reduced precision: tables ENCODED from the fp32 init by the reference's encoders (what reduce_precision.py produces:
+    # no u16 code of the |x| > 0.65 tail), and uniformly random codes (0.8 % tail codes: the u16 worst case)
     for bits in (16, 8, 4):
-        for line in fused_rows(bench.KAGGLE_LN, 36, bits, [2048, 16384], it, "Kaggle, reduced precision"):
+        for line in fused_rows(bench.KAGGLE_LN, 36, bits, [2048, 16384] if a.quick else [2048, 16384, 65536], it, "Kaggle, reduced precision, encoded tables", "encoded"):
             print(line, flush=True)
+    for line in fused_rows(bench.KAGGLE_LN, 36, 16, [16384] if a.quick else [16384, 65536], it, "Kaggle, reduced precision, random codes"):
+        print(line, flush=True)
     for d in (64, 128):
         for line in fused_rows(TERABYTE_LN, d, 32, [2048, 16384], it, "Terabyte-shaped (cfg 4, 1 GPU)"):
             print(line, flush=True)
