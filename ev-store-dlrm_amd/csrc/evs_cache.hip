@@ -23,6 +23,7 @@
 //   * cache_probe_gather_kernel (batched, snapshot semantics) -- see the section below.
 #include "evs_common.h"
 #include "evs_hash.h"
+#include <type_traits>
 
 #include <mutex>
 #include <vector>
@@ -1064,8 +1065,10 @@ struct TwoTierArgs {
 __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs a1, const BatchArgs a2, const TwoTierArgs tt) {
     __shared__ int s_d1[kMaxBuckets], s_d2[kMaxBuckets];
     __shared__ int s_sum[4];   // C1 hits, C2 hits, perfect requests, alt-key hits
+    __shared__ int s_list_n[2];   // list mode (as K1): the misses this block has listed for C1 / for C2
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) { s_d1[i] = 0; s_d2[i] = 0; }
     if (threadIdx.x < 4) s_sum[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_list_n[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
     const int T = a1.T;
@@ -1128,13 +1131,33 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         if (key_on) {
             const long long m = req * T + hl;
             // (bit 30: hit -- or, of a miss, "the hinted slot is a tombstone", as in K1)
-            a1.miss_info[m] = ((miss && dest == 1) ? 0x80000000u : 0u) | ((e1 >= 0 || (miss && dest == 1 && ht1)) ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
-                              (unsigned)(end1 >> a1.hint_shift);
-            a2.miss_info[m] = ((miss && dest == 2) ? 0x80000000u : 0u) | ((e2 >= 0 || (miss && dest == 2 && ht2)) ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
-                              (unsigned)(end2 >> a2.hint_shift);
+            if (!a1.miss_rec) {
+                a1.miss_info[m] = ((miss && dest == 1) ? 0x80000000u : 0u) | ((e1 >= 0 || (miss && dest == 1 && ht1)) ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
+                                  (unsigned)(end1 >> a1.hint_shift);
+                a2.miss_info[m] = ((miss && dest == 2) ? 0x80000000u : 0u) | ((e2 >= 0 || (miss && dest == 2 && ht2)) ? 0x40000000u : 0u) | ((unsigned)agg << 24) |
+                                  (unsigned)(end2 >> a2.hint_shift);
+            }
             a1.row_ptrs[m] = (long long)src;
             tt.row_tier[m] = (unsigned char)codec_of;
             tt.tier_out[m] = e1 >= 0 ? 1 : (e2 >= 0 ? 2 : (alt_tier ? 3 : 0));
+        }
+        if (a1.miss_rec) {   // list mode: the half-wave's misses of each tier, packed, behind the block's earlier ones (as K1)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const bool is_miss = miss && dest == k + 1;
+                const unsigned long long mm = __ballot(is_miss);
+                const unsigned mh = (unsigned)(half ? (mm >> 32) : mm);
+                int base = 0;
+                if (hl == 0 && mh) base = atomicAdd(&s_list_n[k], __popc(mh));
+                base = __shfl(base, half * 32, 64);
+                if (is_miss) {
+                    const BatchArgs &ak = k ? a2 : a1;
+                    const int at = base + __popc(mh & ((1u << hl) - 1u));
+                    ak.miss_rec[(long long)blockIdx.x * ak.list_cap + at] =
+                        make_uint4((unsigned)row, (unsigned)hl | ((unsigned)agg << 8) | ((k ? ht2 : ht1) ? 0x10000u : 0u),
+                                   (unsigned)((k ? end2 : end1) >> ak.hint_shift), (unsigned)(req * T + hl));
+                }
+            }
         }
         const unsigned long long h1 = __ballot(e1 >= 0), h2 = __ballot(e2 >= 0), h3 = __ballot(alt_tier != 0);
         if (req_on && hl == 0) {
@@ -1153,6 +1176,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         if (v2) atomicAdd(&a2.part1[(blockIdx.x % kReplicas) * kPartCols + i], v2);
     }
     if (threadIdx.x == 0 && tt.c3.tags && s_sum[3]) atomicAdd(reinterpret_cast<unsigned long long *>(&tt.c3.stat[1]), (unsigned long long)s_sum[3]);
+    if (a1.miss_rec && threadIdx.x == 0) { a1.list_cnt[blockIdx.x] = s_list_n[0]; a2.list_cnt[blockIdx.x] = s_list_n[1]; }
 }
 
 // rows (B,T,d) fp32 from the pointer table, each row decoded with the codec of the tier that serves it
@@ -1672,12 +1696,19 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
 // three dependent round trips: the miss record, {slot CAS, victim group, source row}, the CAS on the entry.
 // one missed key of the batch: victim, row, key word, hash slot (see the comment above); m = its position in the batch.
 // PIECES pieces of type U make one row (0: any row size, byte by byte)
-template <int PIECES, typename U>
+// (TAIL: one more piece of another type behind the PIECES pieces -- a 36-byte row is 2 x 16 + 4 bytes, an 18-byte row 16 + 2:
+//  3 or 2 memory instructions each way instead of 9; global loads and stores of 16 bytes need no more than the row's own
+//  4- or 2-byte alignment on this part)
+struct NoTail {};
+template <int PIECES, typename U, typename TAIL = NoTail>
 __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t, unsigned row, int agg, unsigned hint_slot, bool hint_tomb,
                                                    long long m, int *s_delta, int *s_stat, unsigned long long *s_vict = nullptr,
                                                    int *s_nvict = nullptr) {
     const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
-    if (args.other_slots) {   // two tiers: the other tier took this key in this very batch
+    // two tiers: the other tier took this key in this very batch.  (Only an odd table index can be routed both ways by two
+    // requests of one batch -- probe2's rule sends an even one to C2 whatever its request's agg_hit once C1 is full, and
+    // nothing to C2 before that -- so only those keys pay for the look into the other tier's hash.)
+    if (args.other_slots && (t & 1)) {
         unsigned long long es;
         if (probe_ro(args.other_slots, args.other_mask, key, es) != -1) return;
     }
@@ -1706,6 +1737,8 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     if constexpr (PIECES > 13) r13 = reinterpret_cast<const U *>(srow)[13];
     if constexpr (PIECES > 14) r14 = reinterpret_cast<const U *>(srow)[14];
     if constexpr (PIECES > 15) r15 = reinterpret_cast<const U *>(srow)[15];
+    TAIL rt;
+    if constexpr (!std::is_same<TAIL, NoTail>::value) rt = *reinterpret_cast<const TAIL *>(srow + PIECES * sizeof(U));
     // 1. The hash slot, with a PENDING word: that is what de-duplicates the copies of a key (the loser of the CAS sees
     //    the key and stops -- it takes no entry; an earlier form claimed the entry first and gave it back, which let a
     //    batch with hundreds of copies of its hot missing keys evict half of a small cache for nothing).  The walk starts
@@ -1780,6 +1813,7 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
         if constexpr (PIECES > 13) reinterpret_cast<U *>(drow)[13] = r13;
         if constexpr (PIECES > 14) reinterpret_cast<U *>(drow)[14] = r14;
         if constexpr (PIECES > 15) reinterpret_cast<U *>(drow)[15] = r15;
+        if constexpr (!std::is_same<TAIL, NoTail>::value) *reinterpret_cast<TAIL *>(drow + PIECES * sizeof(U)) = rt;
     } else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
     else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
     args.a.eagg[e] = agg;
@@ -1792,7 +1826,7 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     atomicAdd(&s_delta[agg], 1);
 }
 
-template <int PIECES, typename U>
+template <int PIECES, typename U, typename TAIL = NoTail>
 __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
@@ -1807,7 +1841,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
     const unsigned info = m < n ? args.miss_info[m] : 0u;
     if (m < n && args.hit) args.hit[m] = (info >> 30) & ~(info >> 31) & 1u;
     if (info & 0x80000000u)
-        sampled_insert_one<PIECES, U>(args, (int)(m % args.T), (unsigned)args.requests[m], (int)((info >> 24) & 63u), info & 0xffffffu,
+        sampled_insert_one<PIECES, U, TAIL>(args, (int)(m % args.T), (unsigned)args.requests[m], (int)((info >> 24) & 63u), info & 0xffffffu,
                                    (info & 0x40000000u) != 0, m, s_delta, s_stat, args.vict_cnt ? s_vict : nullptr, &s_nvict);
     __syncthreads();
     if (args.vict_cnt && s_nvict) {   // the block's victims behind one of the kReplicas lists: one atomic per block
@@ -1827,12 +1861,16 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
 // List form (tables in HBM): block j takes the misses K1's block j listed, one wave, a record per lane -- 2 048 waves of
 // mostly busy lanes instead of 6 656 waves with one lane in eight busy, and everything a miss needs arrives with its
 // record (the per-position form reads the probe word, then the request row, then starts).
-template <int PIECES, typename U>
+constexpr int kListVictMax = 256;
+template <int PIECES, typename U, typename TAIL = NoTail>
 __global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
+    __shared__ unsigned long long s_vict[kListVictMax];   // keys this block evicted (alt-key tier attached: lists of at most kListVictMax records)
+    __shared__ int s_nvict, s_vbase;
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nvict = 0;
     __syncthreads();
     const int n = args.list_cnt[blockIdx.x];
     const uint4 *rec = args.miss_rec + (long long)blockIdx.x * args.list_cap;
@@ -1841,10 +1879,17 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const Bat
     const int nw = (int)blockDim.x >> 6;
     for (int i = ((int)threadIdx.x & 63) * nw + ((int)threadIdx.x >> 6); i < n; i += 64 * nw) {
         const uint4 r = rec[i];
-        sampled_insert_one<PIECES, U>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, (r.y & 0x10000u) != 0, (long long)r.w,
-                                   s_delta, s_stat);
+        sampled_insert_one<PIECES, U, TAIL>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, (r.y & 0x10000u) != 0, (long long)r.w,
+                                   s_delta, s_stat, args.vict_cnt ? s_vict : nullptr, &s_nvict);
     }
     __syncthreads();
+    if (args.vict_cnt && s_nvict) {   // the block's victims behind one of the kReplicas lists: one atomic per block
+        const int r = blockIdx.x % kReplicas;
+        if (threadIdx.x == 0) s_vbase = atomicAdd(&args.vict_cnt[r], s_nvict);
+        __syncthreads();
+        for (int i = threadIdx.x; i < s_nvict; i += blockDim.x)
+            if (s_vbase + i < args.vict_cap) args.evicted_keys[(long long)r * args.vict_cap + s_vbase + i] = s_vict[i];
+    }
     if (threadIdx.x < kPartCols) {
         const int i = threadIdx.x;
         const int v = i <= args.T ? s_delta[i] : (i >= 33 && i <= 35) ? s_stat[i - 33] : 0;
@@ -1861,7 +1906,13 @@ struct CloseArgs {
     long long n_requests;
 };
 constexpr int kCloseEvery = 8;
-__global__ void __launch_bounds__(256) cache_batch_sampled_close_kernel(const CloseArgs args) {
+__device__ __forceinline__ void sampled_close_block(const CloseArgs &args);
+__global__ void __launch_bounds__(256) cache_batch_sampled_close_kernel(const CloseArgs args) { sampled_close_block(args); }
+// two tiers closed by one launch (block 0: C1, block 1: C2): the second launch of a pair costs as much as the first
+__global__ void __launch_bounds__(256) cache_batch_sampled_close2_kernel(const CloseArgs args0, const CloseArgs args1) {
+    if (blockIdx.x == 0) sampled_close_block(args0); else sampled_close_block(args1);
+}
+__device__ __forceinline__ void sampled_close_block(const CloseArgs &args) {
     __shared__ long long s_col[2][kPartCols];
     __shared__ BatchState sb;
     const int nw = (int)(sizeof(BatchState) / sizeof(int));
@@ -2012,7 +2063,9 @@ __device__ __forceinline__ void c3_insert_key(const C3Batch &c3, unsigned long l
         int present = 0, empty = -1, plain = -1;
 #pragma unroll
         for (int j = 0; j < kSetWays; j++) {
-            w[j] = atomicOr(&c3.tags[base + j], 0ull);
+            // (agent-scope loads: coherent across the XCDs' L2s like the returning atomicOr(.., 0) this used to be, but eight
+            //  independent loads of one line instead of eight read-modify-writes at the memory side)
+            w[j] = __hip_atomic_load(&c3.tags[base + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             present |= (w[j] & kKeyMask) == key;
             if (w[j] == 0ull && empty < 0) empty = j;
             if (w[j] != 0ull && !(w[j] & kC3Flag) && plain < 0) plain = j;
@@ -2036,10 +2089,16 @@ __device__ __forceinline__ void c3_insert_key(const C3Batch &c3, unsigned long l
         }
     }
 }
-__global__ void __launch_bounds__(256) c3_batch_insert_lists_kernel(const BatchArgs args, const C3Batch c3) {
+// (one launch for the victims of both tiers: the first half of the grid takes C1's lists, the second C2's -- the launches
+//  are chains of four dependent round trips each, 12.5 us apiece whatever the list length)
+__global__ void __launch_bounds__(256) c3_batch_insert_lists_kernel(const BatchArgs args1, const BatchArgs args2, const C3Batch c3) {
     // (args.vict_cnt points at this batch's half of the 2 x kReplicas list lengths -- halves by batch parity; the other
     //  half, consumed one batch ago, is zeroed here for the next batch: no launch just to reset 32 counters)
-    const int r = blockIdx.x % kReplicas, part = blockIdx.x / kReplicas, parts = gridDim.x / kReplicas;
+    const int half_grid = (int)gridDim.x / 2;
+    const bool second = (int)blockIdx.x >= half_grid;
+    const BatchArgs &args = second ? args2 : args1;
+    const int bid = (int)blockIdx.x - (second ? half_grid : 0);
+    const int r = bid % kReplicas, part = bid / kReplicas, parts = half_grid / kReplicas;
     int n = args.vict_cnt[r];
     if (n > args.vict_cap) n = args.vict_cap;
     for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x)
@@ -2603,12 +2662,12 @@ static unsigned sampled_list_threads(const evs::BatchArgs &a) {
     return a.list_cap > 8 * a.T ? 128u : 64u;
 }
 // the sampled update, compiled per row size (row_bytes = PIECES pieces of 16 / 8 / 4 / 2 bytes, at most 16 of them)
-template <int PIECES, typename U>
+template <int PIECES, typename U, typename TAIL = evs::NoTail>
 static void launch_sampled_update_t(const evs::BatchArgs &a, hipStream_t st) {
     using namespace evs;
     // K1 listed the misses: one wave per list (two when the lists are those of the folded probe's 16-sample blocks: twice as long)
-    if (a.miss_rec) hipLaunchKernelGGL((cache_batch_sampled_list_kernel<PIECES, U>), dim3((unsigned)a.g1), dim3(sampled_list_threads(a)), 0, st, a);
-    else hipLaunchKernelGGL((cache_batch_sampled_kernel<PIECES, U>), dim3((unsigned)a.g2), dim3(256), 0, st, a);
+    if (a.miss_rec) hipLaunchKernelGGL((cache_batch_sampled_list_kernel<PIECES, U, TAIL>), dim3((unsigned)a.g1), dim3(sampled_list_threads(a)), 0, st, a);
+    else hipLaunchKernelGGL((cache_batch_sampled_kernel<PIECES, U, TAIL>), dim3((unsigned)a.g2), dim3(256), 0, st, a);
 }
 static void launch_sampled_update(const evs::BatchArgs &a, hipStream_t st) {
     switch (a.row_bytes) {
@@ -2618,9 +2677,9 @@ static void launch_sampled_update(const evs::BatchArgs &a, hipStream_t st) {
     case 64: launch_sampled_update_t<4, float4>(a, st); break;      // d = 16 fp32, d = 32 u16, d = 64 u8
     case 32: launch_sampled_update_t<2, float4>(a, st); break;
     case 16: launch_sampled_update_t<1, float4>(a, st); break;
-    case 72: launch_sampled_update_t<9, uint2>(a, st); break;       // d = 36 u16
-    case 36: launch_sampled_update_t<9, unsigned>(a, st); break;    // d = 36 u8
-    case 18: launch_sampled_update_t<9, unsigned short>(a, st); break;   // d = 36 u4
+    case 72: launch_sampled_update_t<4, float4, uint2>(a, st); break;            // d = 36 u16: 4 x 16 + 8
+    case 36: launch_sampled_update_t<2, float4, unsigned>(a, st); break;         // d = 36 u8: 2 x 16 + 4
+    case 18: launch_sampled_update_t<1, float4, unsigned short>(a, st); break;   // d = 36 u4: 16 + 2
     case 8: launch_sampled_update_t<1, uint2>(a, st); break;
     default: launch_sampled_update_t<0, float4>(a, st); break;
     }
@@ -2634,15 +2693,29 @@ static int resolved_batch_policy(evs_cache *c) {
     return c->batch_policy;
 }
 // sampled policy: fold the counters of the batches since the last close
-static void sampled_close_pending(evs_cache *c, int rebuild, hipStream_t st) {
-    using namespace evs;
-    if (c->batch_policy != 1 || !c->bs || c->pending_batches == 0) return;
-    CloseArgs ca;
+static evs::CloseArgs sampled_close_args(evs_cache *c, int rebuild) {
+    evs::CloseArgs ca;
     ca.bs = c->bs; ca.part1 = c->part1; ca.part2 = c->part2; ca.host_words = c->host_tomb_dev;
     ca.T = c->host.n_tables; ca.cap = (int)c->host.cap; ca.max_perfect = c->host.max_perfect; ca.rebuild = rebuild;
     ca.n_batches = c->pending_batches; ca.n_requests = c->pending_requests;
+    return ca;
+}
+static void sampled_close_pending(evs_cache *c, int rebuild, hipStream_t st) {
+    using namespace evs;
+    if (c->batch_policy != 1 || !c->bs || c->pending_batches == 0) return;
+    const CloseArgs ca = sampled_close_args(c, rebuild);
     hipLaunchKernelGGL(cache_batch_sampled_close_kernel, dim3(1), dim3(256), 0, st, ca);
     c->pending_batches = 0; c->pending_requests = 0;
+}
+// ... of both tiers of a two-tier lookup, one launch
+static void sampled_close_pending2(evs_cache *c1, int rebuild1, evs_cache *c2, int rebuild2, hipStream_t st) {
+    using namespace evs;
+    const bool on1 = c1->batch_policy == 1 && c1->bs && c1->pending_batches, on2 = c2->batch_policy == 1 && c2->bs && c2->pending_batches;
+    if (!on1 || !on2) { sampled_close_pending(c1, rebuild1, st); sampled_close_pending(c2, rebuild2, st); return; }
+    const CloseArgs ca1 = sampled_close_args(c1, rebuild1), ca2 = sampled_close_args(c2, rebuild2);
+    hipLaunchKernelGGL(cache_batch_sampled_close2_kernel, dim3(2), dim3(256), 0, st, ca1, ca2);
+    c1->pending_batches = 0; c1->pending_requests = 0;
+    c2->pending_batches = 0; c2->pending_requests = 0;
 }
 // sampled policy: the EvLFU flush the close of an earlier batch asked for (a flag in mapped host memory)
 static void sampled_flush_if_wanted(evs_cache *c, hipStream_t st) {
@@ -2964,6 +3037,16 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             }
         }
     }
+    if (sampled2) {
+        // the probe lists each tier's misses per block (as K1 does for one tier); with the alt-key tier attached a list
+        // kernel block stages its victims in LDS: lists of at most kListVictMax records
+        const long long lc = (B + 8 * (long long)a1.g1 - 1) / (8 * (long long)a1.g1) * 8 * T;
+        static const bool list_on = !(getenv("EVS_CACHE_LIST2") && getenv("EVS_CACHE_LIST2")[0] == '0');
+        if (list_on && a1.g1 == a2.g1 && (!c3 || lc <= kListVictMax)) {
+            a1.miss_rec = c1->miss_rec; a1.list_cnt = c1->list_cnt; a1.list_cap = (int)lc;
+            a2.miss_rec = c2->miss_rec; a2.list_cnt = c2->list_cnt; a2.list_cap = (int)lc;
+        }
+    }
     hipLaunchKernelGGL(cache_batch_probe2_kernel, dim3((unsigned)a1.g1), dim3(256), 0, st, a1, a2, tt);
     if (out) {
         long long nb = (B * T * (long long)c1->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
@@ -2982,17 +3065,13 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             BatchArgs &a = k ? a2 : a1;
             if (k) { a.other_slots = c1->bslots; a.other_mask = (unsigned long long)(c1->bnslot - 1); }   // a key C1 just took is not inserted in C2 too
             launch_sampled_update(a, st);
-            if (c3) {
-                hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(kReplicas * 8), dim3(256), 0, st, a, tt.c3);
-            }
         }
-        for (int k = 0; k < 2; k++) {
-            evs_cache *c = k ? c2 : c1;
-            BatchArgs &a = k ? a2 : a1;
-            c->pending_batches++; c->pending_requests += B;
-            sampled_close_pending(c, a.rebuild, st);
-            batch_housekeeping(c, a, st);
-        }
+        if (c3) hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(2 * kReplicas * 8), dim3(256), 0, st, a1, a2, tt.c3);   // what the two tiers evicted
+        c1->pending_batches++; c1->pending_requests += B;
+        c2->pending_batches++; c2->pending_requests += B;
+        sampled_close_pending2(c1, a1.rebuild, c2, a2.rebuild, st);
+        batch_housekeeping(c1, a1, st);
+        batch_housekeeping(c2, a2, st);
         EVS_HIP_CHECK(hipGetLastError());
         return EVS_OK;
     }

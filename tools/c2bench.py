@@ -15,6 +15,7 @@ B = 16384
 out = torch.empty((B, T, d), device=dev); tier = torch.empty((B, T), dtype=torch.uint8, device=dev)
 bs = bench.make_batches(ln, B, 200, seed=21, device=dev, dist="zipf", alpha=0.75)   # 180 to fill both tiers, 20 timed
 rq = [b[1].t().contiguous().to(torch.int32) for b in bs]
+ONLY3 = os.environ.get("C2BENCH_ONLY3") == "1"   # profile target: fill, then the three-tier lookups alone
 for r in rq[:180]:
     gpu_cache.lookup_batch_c1c2(c1, c2, r, out=out, tier=tier)
 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -26,7 +27,7 @@ print("two-tier batched, fp32 rows out: %.1f us per batch, %.2f G lookups/s, C1 
 x = torch.rand((B, d), device=dev)
 bs2 = bench.make_batches(ln, B, 60, seed=22, device=dev, dist="zipf", alpha=0.75)
 rq2 = [b[1].t().contiguous().to(torch.int32) for b in bs2]
-for fused in (False, True):
+for fused in (() if ONLY3 else (False, True)):
     for r in rq2[:10]:
         gpu_cache.lookup_interact_c1c2(c1, c2, r, x, out=out, tier=tier, fused=fused)
     torch.cuda.synchronize(); t0 = time.perf_counter()
