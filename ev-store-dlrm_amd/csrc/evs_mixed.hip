@@ -12,6 +12,8 @@
 // output row and 16-byte stores as evs_fused_rf.hip.
 #include "evs_common.h"
 
+#include <stdlib.h>
+
 namespace evs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -168,6 +170,244 @@ __global__ void __launch_bounds__(256) interact_mixed_rows_kernel(const MixedArg
     }
 }
 
+// ---- codec pair (8, 4), the reference's as-shipped tiers: rows in flight in registers ------------------------------------
+// The kernel above takes one sample per wave at a time: pointer -> row chunk -> decode -> LDS image -> operands, two
+// dependent round trips per sample with nothing else of the wave in flight (34 us at B = 16 384).  This form is
+// evs_fused_rfq.hip's: a block owns 16 samples, their (address, class) pairs go through an LDS tile, every wave requests
+// the rows of its 4 samples at once, each lane exactly the bytes it feeds the matrix core (row r16 + 16 rr, chunks
+// [q CQ, (q + 1) CQ) and the REM tail), and consumes them in order under counted s_waitcnt vmcnt.  The two classes differ
+// in row size (d bytes / d/2 bytes), so a lane loads the WIDER class's piece for either class -- for a u4 row from a
+// start clamped into the row, shifted into place afterwards (no byte outside the row is read) -- and decodes through ONE
+// LDS table: entries 0..255 the u8 values, 256..271 the u4 values, the index picked per lane.  Absent rows read the
+// u8 zero-code page (code 127 = 0.0f exactly).
+struct Mixed84Args {
+    MixedArgs m;
+    const void *zero_codes8;
+    const void *zeros;
+};
+
+template <int N>
+__device__ __forceinline__ void mixed_load_raw(unsigned long long p, unsigned (&w)[N >= 4 ? N / 4 : 1]) {
+    if constexpr (N == 8) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x2 *>((uintptr_t)p);
+        w[0] = v[0]; w[1] = v[1];
+    } else if constexpr (N == 4) {
+        w[0] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned *>((uintptr_t)p);
+    } else {
+        static_assert(N == 2, "raw pieces of 8, 4 or 2 bytes");
+        w[0] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned short *>((uintptr_t)p);
+    }
+}
+
+template <int CQ, int REM, int NT>
+__global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84Args margs) {
+    const MixedArgs &args = margs.m;
+    constexpr int NR = NT, NC = CQ + REM;
+    constexpr int d = 4 * (4 * CQ + REM);
+    constexpr int NROWS = 16 * NT;
+    constexpr int D = 4;
+    constexpr int RB2 = d / 2;                      // bytes of a u4 row (a u8 row: d)
+    constexpr int W1 = CQ * 4, W2 = CQ * 2;         // this lane's main piece per class
+    constexpr int WM = W1;                          // loaded width (the wider class)
+    constexpr int WMdw = WM >= 4 ? WM / 4 : 1;
+    static_assert(RB2 >= WM && (REM == 0 || RB2 >= 4), "the clamped window must fit a u4 row");
+    __shared__ unsigned long long s_ptr[512];       // [32 features][16 samples]: row address (feature 0 = x: unused)
+    __shared__ unsigned char s_cls[512];
+    __shared__ __attribute__((aligned(16))) float s_x[4][64];
+    __shared__ float s_lut[256 + 16];
+    constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
+    __shared__ __attribute__((aligned(16))) float s_out[4][OUT_MAX + 16];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int T = args.T, F = T + 1, itself = args.itself;
+    const int out_row = d + args.P;
+    const long long B = args.B;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *my_out = s_out[wave_in_block];
+    float *my_x = s_x[wave_in_block];
+    const unsigned long long zc_p = (unsigned long long)reinterpret_cast<uintptr_t>(margs.zero_codes8);
+    const unsigned long long zeros_p = (unsigned long long)reinterpret_cast<uintptr_t>(margs.zeros);
+
+    const long long blk_first = (long long)blockIdx.x * 16;
+    const long long blk_end = blk_first + 16 < B ? blk_first + 16 : B;
+    if (blk_first >= blk_end) return;
+    const int blk_n = (int)(blk_end - blk_first);
+    const int n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
+
+    // ---- the tile: the block's 16 x T (address, class) pairs are one contiguous run of each array ----------------------
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) { s_ptr[i] = zc_p; s_cls[i] = 1; }
+    for (int i = threadIdx.x; i < 256 + 16; i += blockDim.x) s_lut[i] = i < 256 ? dec_u8((unsigned)i) : kU4Lut[i - 256];
+    __syncthreads();
+    {
+        const int n = blk_n * T;
+        const long long base = blk_first * T;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int i = (int)threadIdx.x + 256 * h;
+            const bool on = i < n;
+            const long long pv = *reinterpret_cast<const __attribute__((address_space(1))) long long *>(
+                reinterpret_cast<uintptr_t>(on ? args.row_ptrs + base + i : args.row_ptrs));
+            const unsigned char cv = args.row_class ? *reinterpret_cast<const __attribute__((address_space(1))) unsigned char *>(
+                reinterpret_cast<uintptr_t>(on ? args.row_class + base + i : args.row_class)) : (unsigned char)1;
+            if (on && pv && cv) {
+                const int sidx = i / T, k = i - sidx * T;
+                s_ptr[(k + 1) * 16 + sidx] = (unsigned long long)pv;
+                s_cls[(k + 1) * 16 + sidx] = cv;
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr int kOob = 0x7ffffff0;
+    auto flush_out = [&](long long bp, bool on) {
+        float *Rb = args.R + (on ? bp : 0) * (long long)out_row;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, on ? out_row * 4 : 0, 0x00020000);
+        const int n4 = out_row >> 2;
+#pragma unroll
+        for (int h = 0; h < (OUT_MAX + 255) / 256; h++) {
+            const int e4 = lane + 64 * h;
+            const float4 v = reinterpret_cast<const float4 *>(my_out)[e4 < n4 ? e4 : 0];
+            u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, 2);
+        }
+        {
+            const int e = 4 * n4 + (lane & 3);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, 2);
+        }
+    };
+
+    // ---- request the rows of all D samples of this wave -----------------------------------------------------------------
+    // class 2 (u4): the WM-byte window starts at min(q W2, RB2 - WM); the wanted bytes sit sh2 bytes into it
+    const int st2 = q * W2 < RB2 - WM ? q * W2 : RB2 - WM;
+    const int sh2 = (q * W2 - st2) * 8;                        // bits
+    constexpr int rst2 = REM ? (4 * W2 + 4 <= RB2 ? 4 * W2 : RB2 - 4) : 0;   // REM chunk of a u4 row: 2 bytes at 4 W2, loaded as 4
+    constexpr int rsh2 = REM ? (4 * W2 - rst2) * 8 : 0;
+    unsigned rmain[D][NR][WMdw], rrem[D][NR][REM > 0 ? REM : 1];
+    float rx[D];
+    unsigned cls2 = 0;   // bit u * NR + rr: the row is of class 2
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const int m = wave_in_block + 4 * u;
+        const bool phantom = u >= n_samples;
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int row = r16 + 16 * rr;
+            unsigned long long p = s_ptr[row * 16 + m];
+            const bool c2 = s_cls[row * 16 + m] == 2 && !phantom;
+            if (phantom) p = zc_p;
+            mixed_load_raw<WM>(p + (c2 ? st2 : q * W1), rmain[u][rr]);
+            if constexpr (REM > 0) {
+                unsigned t[1];
+                mixed_load_raw<4>(p + (c2 ? rst2 : 4 * W1), t);
+                rrem[u][rr][0] = t[0];
+            }
+            cls2 |= (c2 ? 1u : 0u) << (u * NR + rr);
+        }
+        {
+            const unsigned long long p = phantom ? zeros_p : (unsigned long long)reinterpret_cast<uintptr_t>(args.x + (blk_first + m) * args.x_stride + (lane < d ? lane : 0));
+            rx[u] = *reinterpret_cast<const __attribute__((address_space(1))) float *>((uintptr_t)p);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // one 4-element chunk: u8 -> bytes of w8, u4 -> nibbles of the low 16 bits of w4 (element 2j = the HIGH nibble of byte j)
+    auto dec = [&](unsigned w8, unsigned w4, bool c2) -> float4 {
+        const unsigned i0 = c2 ? 256u + ((w4 >> 4) & 15u) : (w8 & 255u);
+        const unsigned i1 = c2 ? 256u + (w4 & 15u) : ((w8 >> 8) & 255u);
+        const unsigned i2 = c2 ? 256u + ((w4 >> 12) & 15u) : ((w8 >> 16) & 255u);
+        const unsigned i3 = c2 ? 256u + ((w4 >> 8) & 15u) : (w8 >> 24);
+        return make_float4(s_lut[i0], s_lut[i1], s_lut[i2], s_lut[i3]);
+    };
+
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const long long b = blk_first + wave_in_block + 4 * (long long)u;
+        my_x[lane] = rx[u];
+        float4 a[NR][NC];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const bool c2 = (cls2 >> (u * NR + rr)) & 1u;
+            // class 2: the wanted W2 bytes, shifted down to bit 0 of a 32-bit word
+            unsigned lo4;
+            if constexpr (WMdw == 2) lo4 = (unsigned)((((unsigned long long)rmain[u][rr][1] << 32) | rmain[u][rr][0]) >> sh2);
+            else lo4 = rmain[u][rr][0] >> sh2;
+#pragma unroll
+            for (int c = 0; c < CQ; c++) {
+                const unsigned w8 = rmain[u][rr][WMdw == 2 ? c : 0];
+                a[rr][c] = dec(w8, lo4 >> (16 * c), c2);
+            }
+            if constexpr (REM > 0) {   // k-slot q feeds only element q of the REM chunk to the matrix core
+                const unsigned w8 = rrem[u][rr][0], w4 = rrem[u][rr][0] >> rsh2;
+                const unsigned i8 = (w8 >> (8 * q)) & 255u;
+                const unsigned i4 = 256u + ((w4 >> (8 * (q >> 1) + ((q & 1) ? 0 : 4))) & 15u);
+                a[rr][CQ] = make_float4(s_lut[c2 ? i4 : i8], 0.f, 0.f, 0.f);
+            }
+        }
+        {   // row 0 is x: plain fp32 chunks, spread through the wave's LDS slot
+#pragma unroll
+            for (int c = 0; c < CQ; c++) {
+                const float4 xa = *reinterpret_cast<const float4 *>(my_x + (q * CQ + c) * 4);
+                if (r16 == 0) a[0][c] = xa;
+            }
+#pragma unroll
+            for (int t = 0; t < REM; t++) {
+                const float xe = my_x[4 * CQ * 4 + 4 * t + q];
+                if (r16 == 0) a[0][CQ + t].x = xe;
+            }
+        }
+        const float xv = rx[u];
+        flush_out(b - 4, u > 0 && u - 1 < n_samples);
+        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c10 = c00, c11 = c00;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float e0[4] = {a[0][c].x, a[0][c].y, a[0][c].z, a[0][c].w};
+            const float e1[4] = {a[NR - 1][c].x, a[NR - 1][c].y, a[NR - 1][c].z, a[NR - 1][c].w};
+            if (c < CQ) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[e], e0[e], c00, 0, 0, 0);
+                    if constexpr (NT == 2) {
+                        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e0[e], c10, 0, 0, 0);
+                        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e1[e], c11, 0, 0, 0);
+                    }
+                }
+            } else {
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[0], e0[0], c00, 0, 0, 0);
+                if constexpr (NT == 2) {
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[0], e0[0], c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[0], e1[0], c11, 0, 0, 0);
+                }
+            }
+        }
+        const int dump = 4 * (OUT_MAX + r16);
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + (lane < d ? 4 * lane : dump)) = xv;
+#pragma unroll
+        for (int vv = 0; vv < 4; vv++) {
+            const int i = 4 * q + vv;
+            const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[vv];
+            if constexpr (NT == 2) {
+                const int gi = 16 + i;
+                const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+                const int zo10 = gi < F ? 4 * (d + base + r16) : dump;
+                const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = c10[vv];
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[vv];
+            }
+        }
+    }
+    flush_out(blk_first + wave_in_block + 12, n_samples == 4);
+}
+
+template <int CQ, int REM>
+static void launch_mixed84(const Mixed84Args &a, hipStream_t st) {
+    const unsigned blocks = (unsigned)((a.m.B + 15) / 16);
+    if (a.m.T + 1 > 16) hipLaunchKernelGGL((interact_mixed84_kernel<CQ, REM, 2>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((interact_mixed84_kernel<CQ, REM, 1>), dim3(blocks), dim3(256), 0, st, a);
+}
+
 template <auto K>
 static void launch_mixed(const MixedArgs &a, hipStream_t st) {
     static int per_cu = 0;
@@ -190,6 +430,20 @@ int interact_from_mixed_rows(long long B, int T, int d, const float *x, long lon
     a.x = x; a.x_stride = x_stride; a.row_ptrs = row_ptrs; a.row_class = row_class; a.R = R; a.B = B; a.T = T;
     a.itself = itself ? 1 : 0; a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2; a.codec1 = codec1; a.codec2 = codec2;
     const bool nt2 = F > 16;
+    static const bool rfq_on = !(getenv("EVS_MIXED_RFQ") && getenv("EVS_MIXED_RFQ")[0] == '0');
+    if (rfq_on && codec1 == 8 && codec2 == 4 && F <= 28 && (d == 16 || d == 32 || d == 36)) {
+        Mixed84Args ma;
+        ma.m = a; ma.zero_codes8 = zero_code_page(8); ma.zeros = zero_page();
+        if (ma.zero_codes8 && ma.zeros) {
+            switch (d) {
+            case 16: launch_mixed84<1, 0>(ma, st); break;
+            case 32: launch_mixed84<2, 0>(ma, st); break;
+            default: launch_mixed84<2, 1>(ma, st); break;
+            }
+            EVS_HIP_CHECK(hipGetLastError());
+            return EVS_OK;
+        }
+    }
     switch (d) {
     case 16: if (nt2) launch_mixed<interact_mixed_rows_kernel<1, 0, 2>>(a, st); else launch_mixed<interact_mixed_rows_kernel<1, 0, 1>>(a, st); break;
     case 32: if (nt2) launch_mixed<interact_mixed_rows_kernel<2, 0, 2>>(a, st); else launch_mixed<interact_mixed_rows_kernel<2, 0, 1>>(a, st); break;

@@ -618,8 +618,9 @@ def test_batched_two_tier_c1c2(E, orc, thr, policy):
 
 
 @pytest.mark.parametrize("policy", POLICIES)
-@pytest.mark.parametrize("codecs,d", [((8, 4), 36), ((32, 8), 36), ((32, 4), 32), ((8, 4), 16)])
-def test_two_tier_mixed_codec_interaction_consumer(E, orc, codecs, d, policy):
+@pytest.mark.parametrize("codecs,d,T", [((8, 4), 36, 26), ((32, 8), 36, 26), ((32, 4), 32, 26), ((8, 4), 16, 26), ((8, 4), 32, 26),
+                                        ((8, 4), 36, 9), ((8, 4), 36, 27)])
+def test_two_tier_mixed_codec_interaction_consumer(E, orc, codecs, d, T, policy):
     """configs[4] end to end without the fp32 (B,T,d) rows: evs_cache_lookup_interact_c1c2 decodes every row from the
     precision of the tier that serves it inside the interaction kernel.  Which tier serves a MISS depends on the
     routing, so the tables hold only values every codec represents exactly (-1, 0, 1: u8 codes 0 / 127 / 254, u4 codes
@@ -628,7 +629,6 @@ def test_two_tier_mixed_codec_interaction_consumer(E, orc, codecs, d, policy):
     snapshot (a key reported in C1 / C2 was resident there before the call)."""
     from evstore_dlrm_amd import gpu_cache
     rs = np.random.RandomState(17)
-    T = 26
     n_rows = [300] * T
     ws = [rs.randint(-1, 2, size=(n, d)).astype(np.float32) for n in n_rows]
     raws = {c: [orc.encode_table(w, c) for w in ws] for c in codecs}
