@@ -287,10 +287,28 @@ def batched3_case(rs, case):
     reqs = _stream(rs, [n] * T, B * n_batches)
     R1, R2, M3 = set(), set(), set()
     ever_alt, removed, n3 = set(), set(), 0
+    # half of the cases go through the interaction consumer (rows decoded inside the kernel, nothing materialised): R is
+    # checked against the rows the tier codes imply
+    use_interact = bool(rs.randint(0, 2)) and T + 1 <= 28
+    itself = bool(rs.randint(0, 2))
+    tag += " interact=%s" % use_interact
     for s in range(0, len(reqs), B):
         rq = reqs[s:s + B]
-        tier, out = gpu_cache.lookup_batch_c1c2c3(c1, c2, c3, torch.from_numpy(rq).cuda(), threshold=thr)
-        tier, out = tier.cpu().numpy(), out.cpu().numpy()
+        if use_interact:
+            x_np = rs.uniform(-1, 1, size=(len(rq), d)).astype(np.float32)
+            tier, Rg = gpu_cache.lookup_interact_c1c2c3(c1, c2, c3, torch.from_numpy(rq).cuda(), torch.from_numpy(x_np).cuda(),
+                                                       threshold=thr, itself=itself)
+            tier = tier.cpu().numpy()
+            out = np.empty((len(rq), T, d), dtype=np.float32)
+            for b in range(len(rq)):
+                for k in range(T):
+                    a = int(alt[k][rq[b, k]])
+                    out[b, k] = ws[a % 100 - 1][a // 100] if tier[b, k] == 3 else ws[k][rq[b, k]]
+            want_R = orc.interact_features(x_np, [out[:, k] for k in range(T)], itself)
+            np.testing.assert_allclose(Rg.cpu().numpy(), want_R, rtol=1e-5, atol=2e-6, err_msg=tag + ": R")
+        else:
+            tier, out = gpu_cache.lookup_batch_c1c2c3(c1, c2, c3, torch.from_numpy(rq).cuda(), threshold=thr)
+            tier, out = tier.cpu().numpy(), out.cpu().numpy()
         for b in range(len(rq)):
             for k in range(T):
                 key = (k + 1, int(rq[b, k]))
