@@ -34,7 +34,6 @@
 #endif
 namespace evs {
 
-constexpr int kMaxTables = 64;      // one lane per table
 
 enum Policy { kEvLFU = 0, kLRU = 1, kLFU = 2 };
 
@@ -1037,24 +1036,6 @@ __global__ void __launch_bounds__(256) cache_rows_from_ptrs_kernel(const long lo
 // else an unflagged one; when every way is flagged the flags are cleared and it takes the way its hash names).  No
 // global FIFO, no tombstones, every operation one line and one CAS -- the exact FIFO order lives in the batch-1
 // machine above (and is what tests/golden/aprx_ops.npz pins); the batched forms have no reference counterpart.
-constexpr int kSetWays = 8;
-constexpr unsigned long long kC3Flag = 1ull << kKeyBits;
-struct C3Batch {
-    unsigned long long *tags;   // nset x kSetWays key words; nullptr: no alt-key tier
-    long long nset;
-    long long *stat;            // [0] members, [1] alt hits served
-    const unsigned *alt_tables[kMaxTables];
-    long long alt_rows[kMaxTables];
-};
-__device__ __forceinline__ long long c3_find(const C3Batch &c3, unsigned long long key) {
-    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
-    long long found = -1;
-#pragma unroll
-    for (int w = 0; w < kSetWays; w++)
-        if ((c3.tags[base + w] & kKeyMask) == key) found = base + w;
-    return found;
-}
-
 struct TwoTierArgs {
     unsigned char *row_tier;   // (B,T): 1 = row in C1's codec, 2 = row in C2's codec, 0 = no row
     unsigned char *tier_out;   // (B,T) user output: 1 = C1 hit, 2 = C2 hit, 3 = alt-key hit (the alt row is served), 0 = miss
@@ -1861,7 +1842,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
 // List form (tables in HBM): block j takes the misses K1's block j listed, one wave, a record per lane -- 2 048 waves of
 // mostly busy lanes instead of 6 656 waves with one lane in eight busy, and everything a miss needs arrives with its
 // record (the per-position form reads the probe word, then the request row, then starts).
-constexpr int kListVictMax = 256;
+constexpr int kListVictMax = 512;   // (the folded two-tier probe lists 16 T <= 432 records per block)
 template <int PIECES, typename U, typename TAIL = NoTail>
 __global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
@@ -3047,13 +3028,38 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             a2.miss_rec = c2->miss_rec; a2.list_cnt = c2->list_cnt; a2.list_cap = (int)lc;
         }
     }
+    // The probe inside the consumer (the (u8, u4) rows-in-registers kernel of evs_mixed.hip): one launch instead of two, and
+    // the (address, class) pairs never leave the block.  EVS_CACHE_FOLD2=0: the two-launch form.
+    static const bool fold2_on = !(getenv("EVS_CACHE_FOLD2") && getenv("EVS_CACHE_FOLD2")[0] == '0');
+    const bool fold2 = fold2_on && sampled2 && a1.miss_rec && R && !out && B <= 65536 && T <= 32 &&
+                       mixed84_supported(T, c1->host.dim, c1->host.codec, c2->host.codec);
+    if (fold2) {
+        Probe2Args pa;
+        for (int k = 0; k < 2; k++) {
+            evs_cache *c = k ? c2 : c1;
+            BatchArgs &a = k ? a2 : a1;
+            TierProbe &tp = k ? pa.t2 : pa.t1;
+            a.g1 = (int)((B + 15) / 16);   // the update kernel runs one block per list: here a list per 16-sample block
+            a.list_cap = 16 * T;
+            tp.slots = a.slots; tp.mask = a.mask; tp.reusable_tomb = a.tomb_parity ? kTomb : kTomb1;
+            tp.eagg = a.a.eagg; tp.arena = a.a.arena; tp.row_bytes = a.row_bytes;
+            for (int t = 0; t < 32; t++) { tp.backing[t] = t < T ? a.backing[t] : nullptr; tp.backing_rows[t] = t < T ? a.backing_rows[t] : 0; }
+            tp.miss_rec = a.miss_rec; tp.list_cnt = a.list_cnt; tp.part1 = a.part1; tp.hint_shift = a.hint_shift;
+            tp.count = &a.bs->count; tp.cap = a.cap; tp.full_slack = a.cap > 65536 ? a.cap / 256 : 0;
+            (void)c;
+        }
+        pa.requests = rows; pa.tier_out = tier; pa.threshold = high_agghit_threshold; pa.T = T; pa.list_cap = 16 * T;
+        pa.c3 = tt.c3;
+        rc = probe2_interact_mixed84(B, T, c1->host.dim, x, x_stride, pa, itself, R, st);
+        if (rc) return rc;
+    } else
     hipLaunchKernelGGL(cache_batch_probe2_kernel, dim3((unsigned)a1.g1), dim3(256), 0, st, a1, a2, tt);
     if (out) {
         long long nb = (B * T * (long long)c1->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
         hipLaunchKernelGGL(cache_rows_from_ptrs2_kernel, dim3((unsigned)nb), dim3(256), 0, st, c1->row_ptrs, c1->row_tier, out,
                            (long long)B, T, c1->host.dim, c1->host.codec, c2->host.codec);
     }
-    if (R) {
+    if (R && !fold2) {
         rc = interact_from_mixed_rows(B, T, c1->host.dim, x, x_stride, c1->row_ptrs, c1->row_tier, c1->host.codec, c2->host.codec,
                                       itself, R, st);
         if (rc) return rc;

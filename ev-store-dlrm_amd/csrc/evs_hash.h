@@ -62,6 +62,56 @@ __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigne
 }
 
 
+constexpr int kMaxTables = 64;      // one lane per table (exact path)
+
+// Batched form of the alt-key tier C3 (see evs_cache.hip): a kSetWays-way set-associative set of key words
+constexpr int kSetWays = 8;
+constexpr unsigned long long kC3Flag = 1ull << kKeyBits;
+struct C3Batch {
+    unsigned long long *tags;   // nset x kSetWays key words; nullptr: no alt-key tier
+    long long nset;
+    long long *stat;            // [0] members, [1] alt hits served
+    const unsigned *alt_tables[kMaxTables];
+    long long alt_rows[kMaxTables];
+};
+__device__ __forceinline__ long long c3_find(const C3Batch &c3, unsigned long long key) {
+    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
+    long long found = -1;
+#pragma unroll
+    for (int w = 0; w < kSetWays; w++)
+        if ((c3.tags[base + w] & kKeyMask) == key) found = base + w;
+    return found;
+}
+
+
+// Folded two-tier probe (evs_mixed.hip, PROBE variant of the (u8, u4) consumer): what cache_batch_probe2_kernel needs of
+// each tier, by value
+struct TierProbe {
+    const unsigned long long *slots; unsigned long long mask;
+    unsigned long long reusable_tomb;     // the tombstone value this batch may re-use (parity rule)
+    int *eagg;
+    const unsigned char *arena;
+    int row_bytes;
+    const unsigned char *backing[32];
+    long long backing_rows[32];
+    uint4 *miss_rec; int *list_cnt;       // per block: the misses routed to this tier (see BatchArgs::miss_rec)
+    int *part1;                           // replica rows of the hit / histogram totals (32 x 40 ints)
+    int hint_shift;
+    const int *count; int cap, full_slack;   // entries resident at the last close; "full" = count >= cap - full_slack
+};
+struct Probe2Args {
+    TierProbe t1, t2;
+    const int *requests;                  // (B,T) int32 row ids
+    unsigned char *tier_out;              // (B,T): 1 = C1 hit, 2 = C2 hit, 3 = alt-key hit, 0 = miss
+    int threshold, T, list_cap;
+    C3Batch c3;
+};
+// evs_mixed.hip: is there a (u8, u4) rows-in-registers consumer for the shape; the two-tier probe + the interaction over
+// the rows it finds as ONE launch (blocks of 16 samples: miss lists of 16 T records per block and tier)
+bool mixed84_supported(int T, int d, int codec1, int codec2);
+int probe2_interact_mixed84(long long B, int T, int d, const float *x, long long x_stride, const Probe2Args &probe, int itself,
+                            float *R, hipStream_t st);
+
 // Folded probe (evs_fused_rf.hip, PROBE variant): what cache_batch_probe_gather_kernel needs of a cache, by value
 struct ProbeArgs {
     const unsigned long long *slots; unsigned long long mask;

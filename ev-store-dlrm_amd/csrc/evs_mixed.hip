@@ -11,6 +11,7 @@
 // the wave's LDS slot, in the layout the fp32 kernels use.  Then the same v_mfma_f32_16x16x4_f32 chains, the staged
 // output row and 16-byte stores as evs_fused_rf.hip.
 #include "evs_common.h"
+#include "evs_hash.h"
 
 #include <stdlib.h>
 
@@ -184,6 +185,7 @@ struct Mixed84Args {
     MixedArgs m;
     const void *zero_codes8;
     const void *zeros;
+    Probe2Args p;   // PROBE variant
 };
 
 template <int N>
@@ -200,7 +202,11 @@ __device__ __forceinline__ void mixed_load_raw(unsigned long long p, unsigned (&
     }
 }
 
-template <int CQ, int REM, int NT>
+// PROBE: the two-tier probe (cache_batch_probe2_kernel, evs_cache.hip) folded into the head -- thread e (and e + 256) owns key
+// (table (e >> 4) - 1, sample e & 15): both hashes, the alt-key tier, agg_hit per request (LDS), priority bumps, the routing of
+// double misses, tier codes, each tier's miss list of the block, hit statistics -- and the (address, class) pairs go straight
+// into the LDS tile instead of through two (B,T) arrays and a launch boundary.
+template <int CQ, int REM, int NT, bool PROBE = false>
 __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84Args margs) {
     const MixedArgs &args = margs.m;
     constexpr int NR = NT, NC = CQ + REM;
@@ -240,7 +246,104 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
     for (int i = threadIdx.x; i < 512; i += blockDim.x) { s_ptr[i] = zc_p; s_cls[i] = 1; }
     for (int i = threadIdx.x; i < 256 + 16; i += blockDim.x) s_lut[i] = i < 256 ? dec_u8((unsigned)i) : kU4Lut[i - 256];
     __syncthreads();
-    {
+    __shared__ int s_agg[16];                        // PROBE: hits per request of the chunk
+    __shared__ int s_d1[kMaxBuckets], s_d2[kMaxBuckets];   // priority histogram moves of the two tiers
+    __shared__ int s_sum[4];                         // C1 hits, C2 hits, perfect requests, alt-key hits
+    __shared__ int s_list_n[2];                      // misses listed for C1 / C2
+    if constexpr (PROBE) {
+        const Probe2Args &pa = margs.p;
+        for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) { s_d1[i] = 0; s_d2[i] = 0; }
+        if (threadIdx.x < 16) s_agg[threadIdx.x] = 0;
+        if (threadIdx.x < 4) s_sum[threadIdx.x] = 0;
+        if (threadIdx.x < 2) s_list_n[threadIdx.x] = 0;
+        __syncthreads();
+        const bool c1_full = *pa.t1.count >= pa.t1.cap - pa.t1.full_slack;   // snapshot, as probe2
+        const long long bs = blk_first + (threadIdx.x & 15);
+        int prow[2], e1[2], e2[2], ea[2], alt_tier[2];
+        bool act[2], ok[2], ht1[2], ht2[2];
+        unsigned long long key[2], end1[2], end2[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {   // the thread's two request rows side by side
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            act[h] = f >= 1 && f < F && bs < blk_end;
+            const int *rp = act[h] ? pa.requests + bs * (long long)T + (f - 1) : pa.requests;
+            prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h, k = f >= 1 ? f - 1 : 0;
+            ok[h] = act[h] && prow[h] >= 0 && prow[h] < pa.t1.backing_rows[k] && prow[h] < pa.t2.backing_rows[k];
+            key[h] = ((unsigned long long)f << 32) | (unsigned)prow[h];
+            end1[h] = end2[h] = 0; ht1[h] = ht2[h] = false;
+            e1[h] = ok[h] ? probe_ro(pa.t1.slots, pa.t1.mask, key[h], end1[h], pa.t1.reusable_tomb, &ht1[h]) : -1;
+            if (e1[h] == kPending) e1[h] = -1;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            e2[h] = (ok[h] && e1[h] < 0) ? probe_ro(pa.t2.slots, pa.t2.mask, key[h], end2[h], pa.t2.reusable_tomb, &ht2[h]) : -1;
+            if (e2[h] == kPending) e2[h] = -1;
+            // alt-key probe for a double miss (find_approximate_ev, evlfu_8.cpp:474-490), as in probe2
+            alt_tier[h] = 0; ea[h] = -1;
+            if (pa.c3.tags && ok[h] && e1[h] < 0 && e2[h] < 0) {
+                const int f = ((int)threadIdx.x >> 4) + 16 * h;
+                const long long w3 = c3_find(pa.c3, key[h]);
+                if (w3 >= 0) {
+                    const unsigned alt = pa.c3.alt_tables[f - 1][prow[h]];
+                    const unsigned at = alt % 100u, ar = alt / 100u;
+                    if (at >= 1 && at <= (unsigned)T && (long long)ar < pa.t1.backing_rows[at - 1] && (long long)ar < pa.t2.backing_rows[at - 1]) {
+                        const unsigned long long akey = ((unsigned long long)at << 32) | ar;
+                        unsigned long long es;
+                        ea[h] = probe_ro(pa.t1.slots, pa.t1.mask, akey, es);
+                        if (ea[h] >= 0) alt_tier[h] = 1;
+                        else { ea[h] = probe_ro(pa.t2.slots, pa.t2.mask, akey, es); if (ea[h] >= 0) alt_tier[h] = 2; }
+                        if (alt_tier[h]) atomicOr(&pa.c3.tags[w3], kC3Flag);   // set_recency_flag_c3
+                    }
+                }
+            }
+            if (e1[h] >= 0 || e2[h] >= 0 || alt_tier[h]) atomicAdd(&s_agg[threadIdx.x & 15], 1);
+        }
+        __syncthreads();
+        const int agg = s_agg[threadIdx.x & 15];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h, k = f >= 1 ? f - 1 : 0;
+            if (e1[h] >= 0 && pa.t1.eagg[e1[h]] < agg) {
+                const int old = atomicMax(&pa.t1.eagg[e1[h]], agg);
+                if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
+            }
+            if (e2[h] >= 0 && pa.t2.eagg[e2[h]] < agg) {
+                const int old = atomicMax(&pa.t2.eagg[e2[h]], agg);
+                if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
+            }
+            // evlfu_8.cpp:570-601: where a double miss goes
+            const bool miss = ok[h] && e1[h] < 0 && e2[h] < 0 && alt_tier[h] == 0;
+            const int dest = !c1_full ? 1 : (agg < pa.threshold ? ((k & 1) ? 1 : 2) : 2);
+            const unsigned char *src = nullptr;
+            int codec_of = 0;
+            if (e1[h] >= 0) { src = pa.t1.arena + (long long)e1[h] * pa.t1.row_bytes; codec_of = 1; }
+            else if (e2[h] >= 0) { src = pa.t2.arena + (long long)e2[h] * pa.t2.row_bytes; codec_of = 2; }
+            else if (alt_tier[h] == 1) { src = pa.t1.arena + (long long)ea[h] * pa.t1.row_bytes; codec_of = 1; }
+            else if (alt_tier[h] == 2) { src = pa.t2.arena + (long long)ea[h] * pa.t2.row_bytes; codec_of = 2; }
+            else if (miss && dest == 1) { src = pa.t1.backing[k] + (long long)prow[h] * pa.t1.row_bytes; codec_of = 1; }
+            else if (miss) { src = pa.t2.backing[k] + (long long)prow[h] * pa.t2.row_bytes; codec_of = 2; }
+            if (act[h]) {
+                const long long m = bs * (long long)T + k;
+                if (src) { s_ptr[f * 16 + ((int)threadIdx.x & 15)] = (unsigned long long)reinterpret_cast<uintptr_t>(src); s_cls[f * 16 + ((int)threadIdx.x & 15)] = (unsigned char)codec_of; }
+                pa.tier_out[m] = e1[h] >= 0 ? 1 : (e2[h] >= 0 ? 2 : (alt_tier[h] ? 3 : 0));
+                if (miss) {
+                    const TierProbe &tp = dest == 1 ? pa.t1 : pa.t2;
+                    const int at = atomicAdd(&s_list_n[dest - 1], 1);
+                    tp.miss_rec[(long long)blockIdx.x * pa.list_cap + at] =
+                        make_uint4((unsigned)prow[h], (unsigned)k | ((unsigned)agg << 8) | ((dest == 1 ? ht1[h] : ht2[h]) ? 0x10000u : 0u),
+                                   (unsigned)((dest == 1 ? end1[h] : end2[h]) >> tp.hint_shift), (unsigned)m);
+                }
+                if (e1[h] >= 0) atomicAdd(&s_sum[0], 1);
+                if (e2[h] >= 0) atomicAdd(&s_sum[1], 1);
+                if (alt_tier[h]) atomicAdd(&s_sum[3], 1);
+            }
+            if (f == 1 && bs < blk_end && agg == T) atomicAdd(&s_sum[2], 1);
+        }
+    } else {
         const int n = blk_n * T;
         const long long base = blk_first * T;
 #pragma unroll
@@ -259,6 +362,20 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
         }
     }
     __syncthreads();
+    if constexpr (PROBE) {   // the block's totals into one replica row per tier (folded by the caches' close), its list lengths
+        const Probe2Args &pa = margs.p;
+        if (threadIdx.x < 40) {
+            const int i = threadIdx.x;
+            const int v1 = i <= T ? s_d1[i] : i == 38 ? s_sum[0] : i == 39 ? s_sum[2] : 0;
+            const int v2 = i <= T ? s_d2[i] : i == 38 ? s_sum[1] : 0;
+            if (v1) atomicAdd(&pa.t1.part1[(blockIdx.x % 32) * 40 + i], v1);
+            if (v2) atomicAdd(&pa.t2.part1[(blockIdx.x % 32) * 40 + i], v2);
+        }
+        if (threadIdx.x == 0) {
+            pa.t1.list_cnt[blockIdx.x] = s_list_n[0]; pa.t2.list_cnt[blockIdx.x] = s_list_n[1];
+            if (pa.c3.tags && s_sum[3]) atomicAdd(reinterpret_cast<unsigned long long *>(&pa.c3.stat[1]), (unsigned long long)s_sum[3]);
+        }
+    }
 
     constexpr int kOob = 0x7ffffff0;
     auto flush_out = [&](long long bp, bool on) {
@@ -402,10 +519,39 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
 }
 
 template <int CQ, int REM>
-static void launch_mixed84(const Mixed84Args &a, hipStream_t st) {
+static void launch_mixed84(const Mixed84Args &a, bool probe, hipStream_t st) {
     const unsigned blocks = (unsigned)((a.m.B + 15) / 16);
+    if (probe) {
+        if (a.m.T + 1 > 16) hipLaunchKernelGGL((interact_mixed84_kernel<CQ, REM, 2, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((interact_mixed84_kernel<CQ, REM, 1, true>), dim3(blocks), dim3(256), 0, st, a);
+        return;
+    }
     if (a.m.T + 1 > 16) hipLaunchKernelGGL((interact_mixed84_kernel<CQ, REM, 2>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((interact_mixed84_kernel<CQ, REM, 1>), dim3(blocks), dim3(256), 0, st, a);
+}
+
+// is there a (u8, u4) rows-in-registers kernel for the shape (the two-tier lookup folds its probe into it)
+bool mixed84_supported(int T, int d, int codec1, int codec2) {
+    static const bool rfq_on = !(getenv("EVS_MIXED_RFQ") && getenv("EVS_MIXED_RFQ")[0] == '0');
+    return rfq_on && codec1 == 8 && codec2 == 4 && T + 1 <= 28 && (d == 16 || d == 32 || d == 36);
+}
+// the two-tier probe and the interaction over the rows it finds, one launch (evs_cache.hip fills `probe`)
+int probe2_interact_mixed84(long long B, int T, int d, const float *x, long long x_stride, const Probe2Args &probe, int itself,
+                            float *R, hipStream_t st) {
+    Mixed84Args ma;
+    const int F = T + 1;
+    ma.m.x = x; ma.m.x_stride = x_stride; ma.m.row_ptrs = nullptr; ma.m.row_class = nullptr; ma.m.R = R; ma.m.B = B; ma.m.T = T;
+    ma.m.itself = itself ? 1 : 0; ma.m.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2; ma.m.codec1 = 8; ma.m.codec2 = 4;
+    ma.zero_codes8 = zero_code_page(8); ma.zeros = zero_page(); ma.p = probe;
+    if (!ma.zero_codes8 || !ma.zeros) return EVS_EHIP;
+    switch (d) {
+    case 16: launch_mixed84<1, 0>(ma, true, st); break;
+    case 32: launch_mixed84<2, 0>(ma, true, st); break;
+    case 36: launch_mixed84<2, 1>(ma, true, st); break;
+    default: set_error("probe2_interact_mixed84: no kernel for d=%d", d); return EVS_EINVAL;
+    }
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
 }
 
 template <auto K>
@@ -430,15 +576,14 @@ int interact_from_mixed_rows(long long B, int T, int d, const float *x, long lon
     a.x = x; a.x_stride = x_stride; a.row_ptrs = row_ptrs; a.row_class = row_class; a.R = R; a.B = B; a.T = T;
     a.itself = itself ? 1 : 0; a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2; a.codec1 = codec1; a.codec2 = codec2;
     const bool nt2 = F > 16;
-    static const bool rfq_on = !(getenv("EVS_MIXED_RFQ") && getenv("EVS_MIXED_RFQ")[0] == '0');
-    if (rfq_on && codec1 == 8 && codec2 == 4 && F <= 28 && (d == 16 || d == 32 || d == 36)) {
+    if (mixed84_supported(T, d, codec1, codec2)) {
         Mixed84Args ma;
-        ma.m = a; ma.zero_codes8 = zero_code_page(8); ma.zeros = zero_page();
+        ma.m = a; ma.zero_codes8 = zero_code_page(8); ma.zeros = zero_page(); ma.p = Probe2Args{};
         if (ma.zero_codes8 && ma.zeros) {
             switch (d) {
-            case 16: launch_mixed84<1, 0>(ma, st); break;
-            case 32: launch_mixed84<2, 0>(ma, st); break;
-            default: launch_mixed84<2, 1>(ma, st); break;
+            case 16: launch_mixed84<1, 0>(ma, false, st); break;
+            case 32: launch_mixed84<2, 0>(ma, false, st); break;
+            default: launch_mixed84<2, 1>(ma, false, st); break;
             }
             EVS_HIP_CHECK(hipGetLastError());
             return EVS_OK;
