@@ -77,6 +77,51 @@ def make_batches(ln_emb, B, n_batches, seed, device, dist="uniform", alpha=1.05)
     return out
 
 
+def mixed_tiers_section(ev, ln_emb, d, B, dev, fill=180, steps=40, alpha=0.75):
+    """BASELINE configs[4]: C1 (u8) + C2 (u4) mixed-precision tiers and the alt-key tier C3 in front of the tables (HBM miss
+    tier), batched snapshot-semantics lookups with the interaction as the consumer (rows decoded inside the kernel).
+    The reference's "48-48-4" split of 2 % of the rows (evlfu_8.cpp:63-78: capacities in fp32-row equivalents, x4 / x8 /
+    x36 entries); both tiers full before the timed batches, none of which the tiers have seen."""
+    import evstore_dlrm_amd as E
+    from evstore_dlrm_amd import gpu_cache
+    T = len(ln_emb)
+    ev8, ev4 = ev.encode(8), ev.encode(4)
+    budget = int(0.02 * sum(ln_emb))
+    c1 = E.GpuCache("evlfu", int(0.48 * budget) * 4, T, d, 8, "cpp", dev)
+    c2 = E.GpuCache("evlfu", int(0.48 * budget) * 8, T, d, 4, "cpp", dev)
+    c1.set_backing(ev8); c2.set_backing(ev4)
+    tier = torch.empty((B, T), dtype=torch.uint8, device=dev)
+    x = torch.rand((B, d), device=dev)
+    rq = [b[1].t().contiguous().to(torch.int32) for b in make_batches(ln_emb, B, fill + 2 * steps, seed=21, device=dev, dist="zipf", alpha=alpha)]
+    out = {}
+
+    def timed(fn, lo, hi):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in rq[lo:hi]:
+            fn(r)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (hi - lo)
+
+    for r in rq[:fill]:
+        gpu_cache.lookup_interact_c1c2(c1, c2, r, x, tier=tier)
+    ms = timed(lambda r: gpu_cache.lookup_interact_c1c2(c1, c2, r, x, tier=tier), fill, fill + steps)
+    out["two_tier"] = {"ms_per_step": ms, "value": T * B / ms * 1e3, "c1_entries": c1.batch_stats()["size"], "c2_entries": c2.batch_stats()["size"]}
+    alt = [torch.from_numpy(((np.arange(n, dtype=np.int64) % min(n, 4096)) * 100 + (t + 1)).astype(np.uint32).view(np.int32)).to(dev)
+           for t, n in enumerate(ln_emb)]   # alt key of (t, r): row r % 4096 of the same table (hot rows: likely resident)
+    c3 = E.GpuAltKeyTier(int(0.04 * budget) * 8 + 64, alt, dev)
+    for r in rq[fill - 30:fill]:
+        gpu_cache.lookup_interact_c1c2c3(c1, c2, c3, r, x, tier=tier)
+    ms = timed(lambda r: gpu_cache.lookup_interact_c1c2c3(c1, c2, c3, r, x, tier=tier), fill + steps, fill + 2 * steps)
+    _, st3 = c3.batch_dump()
+    out["three_tier"] = {"ms_per_step": ms, "value": T * B / ms * 1e3, "c3_members": st3["members"], "alt_hits_served": st3["n_hit"]}
+    out.update({"unit": "lookups/s", "batch": B, "tiers": "u8 C1 + u4 C2 (+ alt-key C3), 48-48-4 of 2 % of the rows",
+                "note": "batched lookups, probe + mixed-precision interaction in one launch, one update kernel per tier"})
+    return out
+
+
 def physical_cores():
     """(physical cores, logical CPUs) of this host from /proc/cpuinfo (distinct (physical id, core id) pairs)."""
     logical = os.cpu_count() or 1
@@ -684,6 +729,11 @@ def main():
                 result["cache_tier"]["batch1_evstore_plugin"] = batch1_plugin_section(ev, KAGGLE_LN, d, dev, cdf_dir=args.cdf_dir)
             except Exception as e:
                 result["cache_tier"]["batch1_evstore_plugin"] = {"error": repr(e)}
+            if not args.no_extras:
+                try:
+                    result["cache_tier"]["mixed_precision_tiers"] = mixed_tiers_section(ev, KAGGLE_LN, d, B, dev)
+                except Exception as e:
+                    result["cache_tier"]["mixed_precision_tiers"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ev, KAGGLE_LN, d, B, args.cpu_seconds)
     print(json.dumps(result))
