@@ -870,6 +870,9 @@ struct BatchArgs {
     // sampled update with the alt-key tier attached: kReplicas victim lists of vict_cap keys each in evicted_keys, their
     // lengths in vict_cnt (zeroed by the consumer kernel)
     int *vict_cnt, *vict_other; int vict_cap;
+    // ... or the evicting thread makes its victim a member of the alt-key set itself, behind its own stores (no lists, no
+    // insert launch): the set's key words / number of sets / counters
+    unsigned long long *c3_tags; long long c3_nset; long long *c3_stat;
     unsigned long long *evicted_keys;   // (alt-key tier attached) the key each free-stack position held before K4 put it there; bit 63 = flushed, not evicted
     int tomb_parity;                // sampled update: parity of this batch (its tombstones are kTomb1 when odd); -1 otherwise
 };
@@ -1677,6 +1680,43 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
 // three dependent round trips: the miss record, {slot CAS, victim group, source row}, the CAS on the entry.
 // one missed key of the batch: victim, row, key word, hash slot (see the comment above); m = its position in the batch.
 // PIECES pieces of type U make one row (0: any row size, byte by byte)
+// the alt-key set's fill: one evicted key becomes a member (second chance within its set)
+struct C3Set { unsigned long long *tags; long long nset; long long *stat; };
+__device__ __forceinline__ void c3_insert_key(const C3Set &c3, unsigned long long key) {
+    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
+    bool done = false;
+    for (int attempt = 0; attempt < 4 && !done; attempt++) {   // (a CAS lost to another newcomer of the same set: look again)
+        unsigned long long w[kSetWays];
+        int present = 0, empty = -1, plain = -1;
+#pragma unroll
+        for (int j = 0; j < kSetWays; j++) {
+            // (agent-scope loads: coherent across the XCDs' L2s like the returning atomicOr(.., 0) this used to be, but eight
+            //  independent loads of one line instead of eight read-modify-writes at the memory side)
+            w[j] = __hip_atomic_load(&c3.tags[base + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            present |= (w[j] & kKeyMask) == key;
+            if (w[j] == 0ull && empty < 0) empty = j;
+            if (w[j] != 0ull && !(w[j] & kC3Flag) && plain < 0) plain = j;
+        }
+        if (present) done = true;
+        else {
+            int way = empty >= 0 ? empty : plain;
+            if (way < 0) {   // every way has had its second chance now
+#pragma unroll
+                for (int j = 0; j < kSetWays; j++) atomicAnd(&c3.tags[base + j], ~kC3Flag);
+                way = (int)((key >> 3) % kSetWays);
+            }
+            unsigned long long expect = 0ull;
+#pragma unroll
+            for (int j = 0; j < kSetWays; j++) expect = j == way ? w[j] : expect;
+            if (empty < 0 && plain < 0) expect &= ~kC3Flag;
+            if (atomicCAS(&c3.tags[base + way], expect, key) == expect) {
+                if (expect == 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(&c3.stat[0]), 1ull);
+                done = true;
+            }
+        }
+    }
+}
+
 // (TAIL: one more piece of another type behind the PIECES pieces -- a 36-byte row is 2 x 16 + 4 bytes, an 18-byte row 16 + 2:
 //  3 or 2 memory instructions each way instead of 9; global loads and stores of 16 bytes need no more than the row's own
 //  4- or 2-byte alignment on this part)
@@ -1774,6 +1814,7 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
         atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); atomicAdd(&s_stat[2], 1);
         if (s_vict) s_vict[atomicAdd(s_nvict, 1)] = old_key;   // for the alt-key tier
     } else atomicAdd(&s_stat[0], 1);
+    const bool c3_inline = old_prio >= 0 && args.c3_tags != nullptr;
     // 3. Everything else is stores nobody waits for: the row, the priority, the slot index, the key word (with this
     //    batch's stamp: nobody takes the entry away again), the final hash word.
     unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
@@ -1805,6 +1846,7 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     args.a.ekey[e] = key | ((unsigned long long)((unsigned)args.stamp & kStampMask) << kKeyBits);
     args.slots[i] = make_word(key, (unsigned)e);
     atomicAdd(&s_delta[agg], 1);
+    if (c3_inline) c3_insert_key(C3Set{args.c3_tags, args.c3_nset, args.c3_stat}, old_key & kKeyMask);   // what this thread evicted -> the alt-key set
 }
 
 template <int PIECES, typename U, typename TAIL = NoTail>
@@ -2036,40 +2078,6 @@ __global__ void __launch_bounds__(256) c3_batch_insert_kernel(const BatchArgs ar
 }
 
 // the same fill from the victim lists of the sampled update (kReplicas lists; the kernel empties them)
-__device__ __forceinline__ void c3_insert_key(const C3Batch &c3, unsigned long long key) {
-    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
-    bool done = false;
-    for (int attempt = 0; attempt < 4 && !done; attempt++) {   // (a CAS lost to another newcomer of the same set: look again)
-        unsigned long long w[kSetWays];
-        int present = 0, empty = -1, plain = -1;
-#pragma unroll
-        for (int j = 0; j < kSetWays; j++) {
-            // (agent-scope loads: coherent across the XCDs' L2s like the returning atomicOr(.., 0) this used to be, but eight
-            //  independent loads of one line instead of eight read-modify-writes at the memory side)
-            w[j] = __hip_atomic_load(&c3.tags[base + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            present |= (w[j] & kKeyMask) == key;
-            if (w[j] == 0ull && empty < 0) empty = j;
-            if (w[j] != 0ull && !(w[j] & kC3Flag) && plain < 0) plain = j;
-        }
-        if (present) done = true;
-        else {
-            int way = empty >= 0 ? empty : plain;
-            if (way < 0) {   // every way has had its second chance now
-#pragma unroll
-                for (int j = 0; j < kSetWays; j++) atomicAnd(&c3.tags[base + j], ~kC3Flag);
-                way = (int)((key >> 3) % kSetWays);
-            }
-            unsigned long long expect = 0ull;
-#pragma unroll
-            for (int j = 0; j < kSetWays; j++) expect = j == way ? w[j] : expect;
-            if (empty < 0 && plain < 0) expect &= ~kC3Flag;
-            if (atomicCAS(&c3.tags[base + way], expect, key) == expect) {
-                if (expect == 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(&c3.stat[0]), 1ull);
-                done = true;
-            }
-        }
-    }
-}
 // (one launch for the victims of both tiers: the first half of the grid takes C1's lists, the second C2's -- the launches
 //  are chains of four dependent round trips each, 12.5 us apiece whatever the list length)
 __global__ void __launch_bounds__(256) c3_batch_insert_lists_kernel(const BatchArgs args1, const BatchArgs args2, const C3Batch c3) {
@@ -2083,7 +2091,7 @@ __global__ void __launch_bounds__(256) c3_batch_insert_lists_kernel(const BatchA
     int n = args.vict_cnt[r];
     if (n > args.vict_cap) n = args.vict_cap;
     for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x)
-        c3_insert_key(c3, args.evicted_keys[(long long)r * args.vict_cap + i]);
+        c3_insert_key(C3Set{c3.tags, c3.nset, c3.stat}, args.evicted_keys[(long long)r * args.vict_cap + i]);
     if (part == 0 && threadIdx.x == 0) args.vict_other[r] = 0;
 }
 
@@ -2530,7 +2538,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     // a few batches late is as good): past nslot / 8 the
     // table is swept (tombstones at the end of their chains become empty again); if the count is back there within
     // three calls the sweep did not help enough and the hash is rebuilt.
-    a.evicted_keys = nullptr; a.vict_cnt = nullptr; a.vict_other = nullptr; a.vict_cap = 0; a.miss_rec = nullptr; a.list_cnt = nullptr; a.list_cap = 0;
+    a.evicted_keys = nullptr; a.vict_cnt = nullptr; a.vict_other = nullptr; a.vict_cap = 0; a.c3_tags = nullptr; a.c3_nset = 0; a.c3_stat = nullptr; a.miss_rec = nullptr; a.list_cnt = nullptr; a.list_cap = 0;
     a.tomb_parity = -1;
     a.rebuild = 0;
     c->batch_calls++;   // = the ordinal of this call's close
@@ -3000,6 +3008,10 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;
             a.tomb_parity = a.stamp & 1;
             sampled_flush_if_wanted(c, st);
+            static const bool c3_inline_on = !(getenv("EVS_CACHE_C3INLINE") && getenv("EVS_CACHE_C3INLINE")[0] == '0');
+            if (c3 && c3_inline_on) {   // the evicting thread inserts its victim into the alt-key set itself
+                a.c3_tags = c3->tags; a.c3_nset = c3->nset; a.c3_stat = c3->bstat;
+            } else
             if (c3) {   // victim lists for the alt-key tier: kReplicas lists, a block adds at most 256 keys to one of them
                 const long long need = ((long long)a.g2 + kReplicas - 1) / kReplicas * 256;
                 if (need > c->vict_cap) {
@@ -3072,7 +3084,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             if (k) { a.other_slots = c1->bslots; a.other_mask = (unsigned long long)(c1->bnslot - 1); }   // a key C1 just took is not inserted in C2 too
             launch_sampled_update(a, st);
         }
-        if (c3) hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(2 * kReplicas * 8), dim3(256), 0, st, a1, a2, tt.c3);   // what the two tiers evicted
+        if (c3 && !a1.c3_tags) hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(2 * kReplicas * 8), dim3(256), 0, st, a1, a2, tt.c3);   // what the two tiers evicted
         c1->pending_batches++; c1->pending_requests += B;
         c2->pending_batches++; c2->pending_requests += B;
         sampled_close_pending2(c1, a1.rebuild, c2, a2.rebuild, st);
