@@ -1969,6 +1969,7 @@ __device__ __forceinline__ void sampled_close_block(const CloseArgs &args) {
         args.host_words[0] = b->n_tomb;
         args.host_words[2] = (int)b->batch_id;   // the ordinal of the last closed batch: the host ignores reports older than its last sweep / rebuild
         args.host_words[1] = b->cnt[args.T] >= args.max_perfect ? 1 : 0;   // EvLFU flush (EvLFU_C1.py:36-44): the host launches it
+        args.host_words[3] = b->count >= args.cap - (args.cap > 65536 ? args.cap / 256 : 0) ? 1 : 0;   // "full" as the two-tier routing reads it
     }
     __syncthreads();
     {
@@ -2200,7 +2201,7 @@ struct evs_cache {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int fork_mode = -1;            // -1: not decided yet (EVS_CACHE_FORK, default off), 0 / 1
-    long long batch_calls = 0, last_sweep_call = -100, last_hk_call = 0;
+    long long batch_calls = 0, last_sweep_call = -100, last_hk_call = 0, last_flush_call = 0;
     int pending_batches = 0; long long pending_requests = 0;   // sampled update: batches whose counters the close has not folded yet
     unsigned long long *evicted_keys = nullptr;   // batched three-tier lookup: what K4 evicted, for the alt-key tier
     unsigned long long *vict_keys = nullptr; int *vict_cnt = nullptr; long long vict_cap = 0;   // ... what the sampled update evicted (kReplicas lists)   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
@@ -2713,6 +2714,7 @@ static void sampled_flush_if_wanted(evs_cache *c, hipStream_t st) {
     volatile int *flags = reinterpret_cast<volatile int *>(c->host_tomb);
     if (!flags[1]) return;
     flags[1] = 0;
+    c->last_flush_call = c->batch_calls;   // "full" reports of closes before this call are void
     const int wide = kNumCu * 8;
     long long nf = ((long long)c->host.cap + 255) / 256; if (nf > wide) nf = wide;
     hipLaunchKernelGGL(cache_batch_sampled_flush_kernel, dim3((unsigned)nf), dim3(256), 0, st, c->bs, c->a, c->bslots, c->eslot,
@@ -3087,7 +3089,15 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         if (c3 && !a1.c3_tags) hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(2 * kReplicas * 8), dim3(256), 0, st, a1, a2, tt.c3);   // what the two tiers evicted
         c1->pending_batches++; c1->pending_requests += B;
         c2->pending_batches++; c2->pending_requests += B;
-        sampled_close_pending2(c1, a1.rebuild, c2, a2.rebuild, st);
+        // The close only folds counters, and the one thing the next probe reads of them is "is C1 full" (the routing rule).
+        // Once a close that ran after C1's last flush has reported it full -- nothing but a flush takes entries away -- the
+        // counters are folded every kCloseEvery-th batch as in the single-tier path (5 us per batch become 0.6); while C1
+        // fills, every batch.  (EVS_CACHE_LAZY2=0: every batch.)
+        static const bool lazy2_on = !(getenv("EVS_CACHE_LAZY2") && getenv("EVS_CACHE_LAZY2")[0] == '0');
+        volatile int *rep1 = reinterpret_cast<volatile int *>(c1->host_tomb);
+        const bool c1_known_full = lazy2_on && rep1 && rep1[3] == 1 && (long long)rep1[2] >= c1->last_flush_call && c1->last_flush_call < c1->batch_calls;
+        if (!c1_known_full || c1->pending_batches >= kCloseEvery || c2->pending_batches >= kCloseEvery || a1.rebuild || a2.rebuild)
+            sampled_close_pending2(c1, a1.rebuild, c2, a2.rebuild, st);
         batch_housekeeping(c1, a1, st);
         batch_housekeeping(c2, a2, st);
         EVS_HIP_CHECK(hipGetLastError());
