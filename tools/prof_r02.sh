@@ -31,6 +31,14 @@ f=$(find $OUT/ctrace -name "*kernel_stats.csv" | head -1); grep -E "evs::|Name" 
 t=$(find $OUT/ctrace -name "*kernel_trace.csv" | head -1); python3 $ROOT/tools/ktrace_deciles.py $t | grep "evs::" > $OUT/cache_kernel_deciles.txt
 rm -rf $OUT/ctrace
 EVS_CACHE_POLICY=plan python3 $ROOT/tools/cache_bench.py 16384 600 0 > $OUT/cache_bench_600_plan.json 2>/dev/null
+# configs[4]: the two- and three-tier batched lookups (c2bench), kernel statistics
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2trace -- python3 $ROOT/tools/c2bench.py > $OUT/c2bench_prof.log 2>&1
+f=$(find $OUT/c2trace -name "*kernel_stats.csv" | head -1); grep -E "evs::|Name" $f > $OUT/c2_kernel_stats.csv
+rm -rf $OUT/c2trace
+# reduced-precision fused launches (tables encoded from the fp32 ones), kernel statistics
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rqtrace -- python3 $ROOT/tools/kbench.py --fused-only --bits 16 --codes encoded --batch 16384 65536 --iters 300 > $OUT/kbench_u16.log 2>&1
+f=$(find $OUT/rqtrace -name "*kernel_stats.csv" | head -1); grep -E "evs::|Name" $f > $OUT/u16_kernel_stats.csv
+rm -rf $OUT/rqtrace
 cd $ROOT
 timeout 900 python3 tools/sweep.py > $OUT/sweep.md 2> $OUT/sweep.err
 timeout 200 python3 tools/mlp_bench.py > $OUT/mlp_bench.log 2>&1
