@@ -206,11 +206,11 @@ def exact_rows(ev, ln, d, n_req):
     Bq = 16384
     outq = torch.empty((Bq, T, d), device=dev)
     tierq = torch.empty((Bq, T), dtype=torch.uint8, device=dev)
-    warm = bench.make_batches(ln, Bq, 80, seed=21, device=dev, dist="zipf", alpha=0.75)
+    warm = bench.make_batches(ln, Bq, 180, seed=21, device=dev, dist="zipf", alpha=0.75)   # both tiers full before the timed batches
     for b in warm:
         gpu_cache.lookup_batch_c1c2(b1, b2, b[1].t().contiguous().to(torch.int32), out=outq, tier=tierq)
     del warm
-    bsq = bench.make_batches(ln, Bq, 20, seed=22, device=dev, dist="zipf", alpha=0.75)
+    bsq = bench.make_batches(ln, Bq, 40, seed=22, device=dev, dist="zipf", alpha=0.75)
     rq = [b[1].t().contiguous().to(torch.int32) for b in bsq]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
