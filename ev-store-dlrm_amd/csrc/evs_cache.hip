@@ -835,6 +835,10 @@ struct BatchArgs {
     int *estamp; int stamp;      // entries with estamp[e] == stamp are not evicted in the running batch: its hits when the miss
     int stamp_hits;              // tier is host memory (stamp_hits), and what the sampled update inserted in it
     const unsigned long long *other_slots; unsigned long long other_mask;   // two-tier: the other tier's hash (keys it holds are skipped)
+    // two-tier, sampled update: the probe stamps (hash of) every key it routes to C1 into a filter; C2's update skips a key
+    // whose filter word carries this batch's stamp -- the two tiers' updates no longer depend on each other (one launch).
+    // A collision only skips an insert (the key is not cached this time); 2^20 words against ~10^4 marks per batch.
+    unsigned *route_filter; unsigned route_mask, route_stamp;
     int *eslot;            // hash slot of each entry
     // per (request, table) position: bit 31 = valid miss, bit 30 = hit (of a miss: the hinted slot is a tombstone), bits 24..29 = agg_hit of the request,
     // bits 0..23 = (empty hash slot the probe of a miss ended on) >> hint_shift.  One 4-byte store per key in
@@ -1043,6 +1047,7 @@ struct TwoTierArgs {
     unsigned char *row_tier;   // (B,T): 1 = row in C1's codec, 2 = row in C2's codec, 0 = no row
     unsigned char *tier_out;   // (B,T) user output: 1 = C1 hit, 2 = C2 hit, 3 = alt-key hit (the alt row is served), 0 = miss
     int threshold;             // high_agghit_threshold (evlfu_8.hpp:70)
+    unsigned *route_filter; unsigned route_mask, route_stamp;   // see BatchArgs::route_filter (nullptr: not used)
     C3Batch c3;
 };
 
@@ -1112,6 +1117,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         else if (alt_tier == 2) { src = a2.a.arena + (long long)ea * a2.row_bytes; codec_of = 2; }
         else if (miss && dest == 1) { src = a1.backing[hl] + (long long)row * a1.row_bytes; codec_of = 1; }
         else if (miss) { src = a2.backing[hl] + (long long)row * a2.row_bytes; codec_of = 2; }
+        if (tt.route_filter && miss && dest == 1 && (hl & 1)) tt.route_filter[mix64(key) & tt.route_mask] = tt.route_stamp;
         if (key_on) {
             const long long m = req * T + hl;
             // (bit 30: hit -- or, of a miss, "the hinted slot is a tombstone", as in K1)
@@ -1729,6 +1735,7 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     // two tiers: the other tier took this key in this very batch.  (Only an odd table index can be routed both ways by two
     // requests of one batch -- probe2's rule sends an even one to C2 whatever its request's agg_hit once C1 is full, and
     // nothing to C2 before that -- so only those keys pay for the look into the other tier's hash.)
+    if (args.route_filter && (t & 1) && args.route_filter[mix64(key) & args.route_mask] == args.route_stamp) return;
     if (args.other_slots && (t & 1)) {
         unsigned long long es;
         if (probe_ro(args.other_slots, args.other_mask, key, es) != -1) return;
@@ -1885,8 +1892,19 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
 // mostly busy lanes instead of 6 656 waves with one lane in eight busy, and everything a miss needs arrives with its
 // record (the per-position form reads the probe word, then the request row, then starts).
 constexpr int kListVictMax = 512;   // (the folded two-tier probe lists 16 T <= 432 records per block)
+template <int PIECES, typename U, typename TAIL>
+__device__ __forceinline__ void sampled_list_block(const BatchArgs &args, int bid);
 template <int PIECES, typename U, typename TAIL = NoTail>
-__global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const BatchArgs args) {
+__global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const BatchArgs args) { sampled_list_block<PIECES, U, TAIL>(args, (int)blockIdx.x); }
+// both tiers of a two-tier lookup in one launch (their updates are independent once the probe has stamped the route
+// filter): blocks [0, g1) take C1's lists, [g1, 2 g1) C2's
+template <int P1, typename U1, typename T1, int P2, typename U2, typename T2>
+__global__ void __launch_bounds__(256) cache_batch_sampled_list2_kernel(const BatchArgs args1, const BatchArgs args2) {
+    if ((int)blockIdx.x < args1.g1) sampled_list_block<P1, U1, T1>(args1, (int)blockIdx.x);
+    else sampled_list_block<P2, U2, T2>(args2, (int)blockIdx.x - args1.g1);
+}
+template <int PIECES, typename U, typename TAIL>
+__device__ __forceinline__ void sampled_list_block(const BatchArgs &args, int bid) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
     __shared__ unsigned long long s_vict[kListVictMax];   // keys this block evicted (alt-key tier attached: lists of at most kListVictMax records)
@@ -1895,8 +1913,8 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const Bat
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_nvict = 0;
     __syncthreads();
-    const int n = args.list_cnt[blockIdx.x];
-    const uint4 *rec = args.miss_rec + (long long)blockIdx.x * args.list_cap;
+    const int n = args.list_cnt[bid];
+    const uint4 *rec = args.miss_rec + (long long)bid * args.list_cap;
     // (records dealt round-robin over the block's waves: a 50-record list on two waves is 25 busy lanes each, not one wave
     //  of 50 and an idle one)
     const int nw = (int)blockDim.x >> 6;
@@ -1907,7 +1925,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const Bat
     }
     __syncthreads();
     if (args.vict_cnt && s_nvict) {   // the block's victims behind one of the kReplicas lists: one atomic per block
-        const int r = blockIdx.x % kReplicas;
+        const int r = bid % kReplicas;
         if (threadIdx.x == 0) s_vbase = atomicAdd(&args.vict_cnt[r], s_nvict);
         __syncthreads();
         for (int i = threadIdx.x; i < s_nvict; i += blockDim.x)
@@ -1916,7 +1934,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const Bat
     if (threadIdx.x < kPartCols) {
         const int i = threadIdx.x;
         const int v = i <= args.T ? s_delta[i] : (i >= 33 && i <= 35) ? s_stat[i - 33] : 0;
-        if (v) atomicAdd(&args.part2[(blockIdx.x % kReplicas) * kPartCols + i], v);
+        if (v) atomicAdd(&args.part2[(bid % kReplicas) * kPartCols + i], v);
     }
 }
 
@@ -2204,13 +2222,14 @@ struct evs_cache {
     long long batch_calls = 0, last_sweep_call = -100, last_hk_call = 0, last_flush_call = 0;
     int pending_batches = 0; long long pending_requests = 0;   // sampled update: batches whose counters the close has not folded yet
     unsigned long long *evicted_keys = nullptr;   // batched three-tier lookup: what K4 evicted, for the alt-key tier
+    unsigned *route_filter = nullptr;   // two-tier sampled update (held by C1): see BatchArgs::route_filter
     unsigned long long *vict_keys = nullptr; int *vict_cnt = nullptr; long long vict_cap = 0;   // ... what the sampled update evicted (kReplicas lists)   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
     int batch_policy = -1;         // policy update of the batched path: 0 plan-based (K2..K6), 1 sampled (one kernel); -1: EVS_CACHE_POLICY, default sampled
 };
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
-    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage, c->evicted_keys, c->vict_keys, c->vict_cnt};
+    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage, c->evicted_keys, c->vict_keys, c->vict_cnt, c->route_filter};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->host_tomb) (void)hipHostFree(c->host_tomb);
@@ -2533,7 +2552,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     a.g1 = (int)g1; a.g2 = (int)g2;
     a.host_tomb = c->host_tomb_dev;
     a.estamp = nullptr; a.stamp = 0; a.stamp_hits = 0;
-    a.other_slots = nullptr; a.other_mask = 0;
+    a.other_slots = nullptr; a.other_mask = 0; a.route_filter = nullptr; a.route_mask = 0; a.route_stamp = 0;
     a.staged_mask = 0; a.staging = nullptr; a.new_keys = nullptr; a.slot_stage = nullptr; a.stage_rows = 0;
     // Tombstone housekeeping, from the count the close of an EARLIER batch left in mapped host memory (no synchronisation:
     // a few batches late is as good): past nslot / 8 the
@@ -2673,6 +2692,22 @@ static void launch_sampled_update(const evs::BatchArgs &a, hipStream_t st) {
     case 8: launch_sampled_update_t<1, uint2>(a, st); break;
     default: launch_sampled_update_t<0, float4>(a, st); break;
     }
+}
+
+// both tiers' list updates as one launch (the pairs of row sizes a u8 C1 + u4 C2 make); false: no merged kernel for the pair
+static bool launch_sampled_update_pair(const evs::BatchArgs &a1, const evs::BatchArgs &a2, hipStream_t st) {
+    using namespace evs;
+    static const bool on = !(getenv("EVS_CACHE_PAIR") && getenv("EVS_CACHE_PAIR")[0] == '0');
+    if (!on || !a1.miss_rec || !a2.miss_rec || a1.g1 != a2.g1 || sampled_list_threads(a1) != sampled_list_threads(a2)) return false;
+    const dim3 grid((unsigned)(2 * a1.g1)), block(sampled_list_threads(a1));
+    if (a1.row_bytes == 36 && a2.row_bytes == 18)
+        hipLaunchKernelGGL((cache_batch_sampled_list2_kernel<2, float4, unsigned, 1, float4, unsigned short>), grid, block, 0, st, a1, a2);
+    else if (a1.row_bytes == 32 && a2.row_bytes == 16)
+        hipLaunchKernelGGL((cache_batch_sampled_list2_kernel<2, float4, NoTail, 1, float4, NoTail>), grid, block, 0, st, a1, a2);
+    else if (a1.row_bytes == 16 && a2.row_bytes == 8)
+        hipLaunchKernelGGL((cache_batch_sampled_list2_kernel<1, float4, NoTail, 1, uint2, NoTail>), grid, block, 0, st, a1, a2);
+    else return false;
+    return true;
 }
 
 static int resolved_batch_policy(evs_cache *c) {
@@ -2984,6 +3019,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     const int wide = kNumCu * 8;
     TwoTierArgs tt;
     tt.row_tier = c1->row_tier; tt.tier_out = tier; tt.threshold = high_agghit_threshold;
+    tt.route_filter = nullptr; tt.route_mask = 0; tt.route_stamp = 0;
     tt.c3.tags = nullptr; tt.c3.nset = 0; tt.c3.stat = nullptr;
     for (int k = 0; k < kMaxTables; k++) { tt.c3.alt_tables[k] = nullptr; tt.c3.alt_rows[k] = 0; }
     if (c3) {
@@ -3003,6 +3039,12 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     }
     // both tiers on the sampled update (the default): the probe follows the parity rule of each tier's tombstones
     const bool sampled2 = resolved_batch_policy(c1) == 1 && resolved_batch_policy(c2) == 1;
+    constexpr unsigned kRouteWords = 1u << 20;
+    static const bool route_on = !(getenv("EVS_CACHE_ROUTEFILTER") && getenv("EVS_CACHE_ROUTEFILTER")[0] == '0');
+    if (sampled2 && route_on && !c1->route_filter) {
+        EVS_HIP_CHECK(hipMalloc(&c1->route_filter, kRouteWords * 4));
+        EVS_HIP_CHECK(hipMemsetAsync(c1->route_filter, 0, kRouteWords * 4, st));
+    }
     if (sampled2) {
         for (int k = 0; k < 2; k++) {
             evs_cache *c = k ? c2 : c1;
@@ -3044,6 +3086,10 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     }
     // The probe inside the consumer (the (u8, u4) rows-in-registers kernel of evs_mixed.hip): one launch instead of two, and
     // the (address, class) pairs never leave the block.  EVS_CACHE_FOLD2=0: the two-launch form.
+    if (sampled2 && c1->route_filter) {
+        tt.route_filter = c1->route_filter; tt.route_mask = kRouteWords - 1; tt.route_stamp = (unsigned)a1.stamp;
+        a2.route_filter = c1->route_filter; a2.route_mask = kRouteWords - 1; a2.route_stamp = (unsigned)a1.stamp;
+    }
     static const bool fold2_on = !(getenv("EVS_CACHE_FOLD2") && getenv("EVS_CACHE_FOLD2")[0] == '0');
     const bool fold2 = fold2_on && sampled2 && a1.miss_rec && R && !out && B <= 65536 && T <= 32 &&
                        mixed84_supported(T, c1->host.dim, c1->host.codec, c2->host.codec);
@@ -3064,6 +3110,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         }
         pa.requests = rows; pa.tier_out = tier; pa.threshold = high_agghit_threshold; pa.T = T; pa.list_cap = 16 * T;
         pa.c3 = tt.c3;
+        pa.route_filter = tt.route_filter; pa.route_mask = tt.route_mask; pa.route_stamp = tt.route_stamp;
         rc = probe2_interact_mixed84(B, T, c1->host.dim, x, x_stride, pa, itself, R, st);
         if (rc) return rc;
     } else
@@ -3081,10 +3128,10 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     if (sampled2) {
         // one update kernel per tier (per-position form: the probe wrote a record per (request, table) and tier); the
         // routing reads each tier's entry count, so the counters are folded every batch here
-        for (int k = 0; k < 2; k++) {
-            BatchArgs &a = k ? a2 : a1;
-            if (k) { a.other_slots = c1->bslots; a.other_mask = (unsigned long long)(c1->bnslot - 1); }   // a key C1 just took is not inserted in C2 too
-            launch_sampled_update(a, st);
+        if (!a2.route_filter) { a2.other_slots = c1->bslots; a2.other_mask = (unsigned long long)(c1->bnslot - 1); }   // a key C1 just took is not inserted in C2 too
+        if (!(a2.route_filter && launch_sampled_update_pair(a1, a2, st))) {
+            launch_sampled_update(a1, st);
+            launch_sampled_update(a2, st);
         }
         if (c3 && !a1.c3_tags) hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(2 * kReplicas * 8), dim3(256), 0, st, a1, a2, tt.c3);   // what the two tiers evicted
         c1->pending_batches++; c1->pending_requests += B;

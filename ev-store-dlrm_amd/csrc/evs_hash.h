@@ -104,6 +104,7 @@ struct Probe2Args {
     const int *requests;                  // (B,T) int32 row ids
     unsigned char *tier_out;              // (B,T): 1 = C1 hit, 2 = C2 hit, 3 = alt-key hit, 0 = miss
     int threshold, T, list_cap;
+    unsigned *route_filter; unsigned route_mask, route_stamp;   // keys routed to C1 are stamped here (evs_cache.hip: BatchArgs::route_filter)
     C3Batch c3;
 };
 // evs_mixed.hip: is there a (u8, u4) rows-in-registers consumer for the shape; the two-tier probe + the interaction over

@@ -326,6 +326,7 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
             else if (alt_tier[h] == 2) { src = pa.t2.arena + (long long)ea[h] * pa.t2.row_bytes; codec_of = 2; }
             else if (miss && dest == 1) { src = pa.t1.backing[k] + (long long)prow[h] * pa.t1.row_bytes; codec_of = 1; }
             else if (miss) { src = pa.t2.backing[k] + (long long)prow[h] * pa.t2.row_bytes; codec_of = 2; }
+            if (pa.route_filter && miss && dest == 1 && (k & 1)) pa.route_filter[mix64(key[h]) & pa.route_mask] = pa.route_stamp;
             if (act[h]) {
                 const long long m = bs * (long long)T + k;
                 if (src) { s_ptr[f * 16 + ((int)threadIdx.x & 15)] = (unsigned long long)reinterpret_cast<uintptr_t>(src); s_cls[f * 16 + ((int)threadIdx.x & 15)] = (unsigned char)codec_of; }
