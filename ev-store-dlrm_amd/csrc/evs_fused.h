@@ -52,6 +52,9 @@ constexpr int kTileMaxF = 28;   // index-tile launches: x + at most 27 tables
 // evs_fused_rf.hip: the rows-in-flight-in-registers form of the bag-1 index-tile loop (fp32 tables, d in {16, 32, 36},
 // F <= kTileMaxF); returns false when it has no kernel for the shape (the caller then uses the LDS-DMA loop)
 bool launch_rf(const FusedArgs &a, hipStream_t st);
+// ... with lS_o given (bag1 == 3: whole batches): the offsets of each block's 16 samples checked in the kernel, the blocks
+// that fail pooled in its own slow loop
+bool launch_rf_check(const FusedArgs &a, hipStream_t st);
 // the same kernel with the first top-MLP layer behind it (any batch size); false = no kernel for the shape
 bool launch_rf_mlp(const FusedArgs &a, hipStream_t st);
 // the same kernel reading a (B, F-1) table of 32-bit row ids (the cache tier's consumer); rf_ids_supported: is there a

@@ -1215,6 +1215,7 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                 }
                 if constexpr (!PTRS) {
                     if constexpr (CODEC == 32) {
+                        if (a.bag1 == 3 && launch_rf_check(a, st)) return;   // rows in flight in registers, offsets checked per block
                         if (a.bag1 == 3) {   // the index-tile loop checks the offsets itself and pools failing chunks the slow way
                             if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);
                             else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true, true>>(a, st);

@@ -59,8 +59,15 @@ constexpr int kMlpRowStride = 452;   // floats per staged row: kp <= 448 (F <= 2
 // PROBE (implies IDS): the kernel reads the REQUEST rows and probes the cache's hash itself in its head -- what
 // cache_batch_probe_gather_kernel does as a launch of its own (hash probe, agg_hit per request, priority bump, hit flags,
 // the block's miss list for the update kernel, hit statistics) -- and goes on with the ids it found.
-template <int CQ, int REM, int NT, int D, bool MLP = false, bool IDS = false, bool PROBE = false>
+// CHECK (lS_o given, whole batches: nnz == B, B or B + 1 offsets -- what the reference's loop passes): the block also loads
+// the offsets of its 16 samples and checks that every bag is exactly {idx[b]} (offsets[b] == b and the bag ends at b + 1:
+// the neighbour lane's offset, one extra load behind the block's last sample).  A block that finds anything else pools ITS
+// samples in a slow loop straight from global memory (general semantics: empty bags, several indices summed in index
+// order, bad offsets / indices skipped and flagged -- the arithmetic of evs_fused.hip's general loop) and feeds the same
+// MFMA + output code: no flag, no second launch, as in the index-tile loop of evs_fused.hip and in evs_fused_rfq.hip.
+template <int CQ, int REM, int NT, int D, bool MLP = false, bool IDS = false, bool PROBE = false, bool CHECK = false>
 __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_kernel(const FusedArgs args) {
+    static_assert(!CHECK || (!MLP && !IDS && !PROBE), "the offsets check belongs to the plain launch");
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
     constexpr int d = 4 * (4 * CQ + REM);
@@ -78,6 +85,8 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     __shared__ int s_tile_kind[32];                                       // 0 absent, 1 dense (x, received pooled vectors), 2 table
     __shared__ unsigned long long s_feat_base[32];                        // per feature: first row / bytes between rows -- read per
     __shared__ unsigned s_feat_scale[32];                                 // load instead of living in 12 VGPRs per lane
+    __shared__ const int64_t *s_tile_o[CHECK ? 32 : 1];                   // CHECK: offsets arrays, their readable entries, nnz
+    __shared__ int64_t s_tile_ol[CHECK ? 32 : 1], s_tile_nz[CHECK ? 32 : 1];
     constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
     // staged output rows: one slot per wave (flushed an iteration later), or with MLP all 16 rows of the chunk
     constexpr int kOutRows = MLP ? 16 : 4;
@@ -113,6 +122,11 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         s_tile_kind[f] = f >= F ? 0 : (table ? 2 : 1);
         s_feat_base[f] = f < F ? (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]) : 0ull;
         s_feat_scale[f] = f >= F ? 0u : (table ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4));
+        if constexpr (CHECK) {
+            s_tile_o[f] = table ? ka->offsets[f] : nullptr;
+            s_tile_ol[f] = table ? ka->off_len[f] : 0;
+            s_tile_nz[f] = table ? ka->nnz[f] : 0;
+        }
     }
     __syncthreads();
 
@@ -154,8 +168,9 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     };
 
     // ---- index tiles: thread e (and e + 256) owns tile element (feature e >> 4, sample-in-chunk e & 15) ----
-    bool bad = false;
+    bool bad = false, my_ragged = false;
     int64_t tile_v[2] = {-1, -1};
+    int64_t tile_o0[2] = {0, 0}, tile_o1[2] = {0, 0};   // CHECK: offsets[b] and where bag b ends
     const int64_t *dummy_i = args.dummy_i64;   // any readable int64 (lanes with nothing to load read it)
     auto tile_load = [&](int c) {       // chunk c of the block -> registers; no branch, no use of the value before tile_store
         const int64_t bs = blk_first + 16 * (int64_t)c + (threadIdx.x & 15);
@@ -171,6 +186,14 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
                 // (explicitly global: a flat load would force every later wait to vmcnt(0))
                 tile_v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(ap));
             }
+            if constexpr (CHECK) {
+                const int64_t *op = s_tile_o[f];
+                const bool own = table && ((threadIdx.x & 15) == 15 || bs + 1 >= blk_end);
+                const int64_t *p0 = table ? op + bs : dummy_i;
+                const int64_t *p1 = (own && bs + 1 < s_tile_ol[f]) ? op + bs + 1 : dummy_i;
+                tile_o0[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(p0));
+                tile_o1[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(p1));
+            }
         }
     };
     auto tile_store = [&](int c) {      // registers -> tile buffer c & 1
@@ -182,7 +205,21 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             const bool live = kind != 0 && bs < blk_end && c >= 0;
             const int64_t v = kind == 2 ? tile_v[h] : bs;       // dense features (x, received pooled vectors): the sample number
             const bool in_range = kind == 1 || (IDS ? v >= 0 : (uint64_t)v < (uint64_t)s_tile_nr[f]);   // (IDS: the probe kernel checked the row ids)
-            bad |= live & !in_range;
+            bool mine = true;
+            if constexpr (CHECK) {
+                // (an index whose own bag is not {idx[b]} may sit at a position no bag refers to: the slow loop, which this
+                //  block then runs, has the verdict on it)
+                const bool table = kind == 2 && bs < blk_end;
+                const bool own = table && ((threadIdx.x & 15) == 15 || bs + 1 >= blk_end);
+                int64_t o0 = tile_o0[h], o1 = tile_o1[h];
+                const int64_t nb = __shfl_down((long long)tile_o0[h], 1);
+                if (!own) o1 = nb;
+                if (own && !(bs + 1 < s_tile_ol[f])) o1 = s_tile_nz[f];   // the last bag ends at nnz
+                if (!table) { o0 = bs; o1 = bs + 1; }
+                mine = o0 == bs && o1 == bs + 1;
+                my_ragged |= !mine;
+            }
+            bad |= live & !in_range & mine;
             s_idx[(c & 1) * 512 + (int)threadIdx.x + 256 * h] = (live & in_range) ? (int)v : -1;
         }
     };
@@ -339,7 +376,84 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     } else {
         tile_load(0);
         tile_store(0);
-        __syncthreads();
+        if constexpr (CHECK) {
+            if (__syncthreads_or(my_ragged)) {   // block-uniform, rare: this block's samples with general bag semantics
+                for (int u = 0; u < n_samples; u++) {
+                    const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;
+                    float4 a[NR][NC];
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) {
+                        const int f = r16 + 16 * rr;
+#pragma unroll
+                        for (int c = 0; c < NC; c++) a[rr][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (f >= F) continue;
+                        // byte offset of chunk c inside a row: this lane's k-slot chunks, then the shared remainder chunks
+                        auto chunk_at = [&](const char *row, int c) -> float4 {
+                            return *reinterpret_cast<const float4 *>(row + (c < CQ ? (q * CQ + c) * 16 : kRemOff + (c - CQ) * 16));
+                        };
+                        const int64_t *ip = ka->indices[f];
+                        const char *src = reinterpret_cast<const char *>(ka->src[f]);
+                        if (!ip) {   // dense feature (x, received pooled vectors)
+                            const char *row = src + (uint64_t)b * (uint64_t)(ka->stride[f] * 4);
+#pragma unroll
+                            for (int c = 0; c < NC; c++) a[rr][c] = chunk_at(row, c);
+                            continue;
+                        }
+                        const int64_t *op = ka->offsets[f];
+                        const int64_t nnz = ka->nnz[f];
+                        int64_t s0 = op[b];
+                        int64_t e0 = (b + 1 < ka->off_len[f]) ? op[b + 1] : nnz;
+                        if (!((s0 >= 0) & (e0 >= s0) & (e0 <= nnz))) { bad = true; s0 = e0 = 0; }
+                        const uint64_t n_rows = (uint64_t)ka->n_rows[f];
+                        for (int64_t j = s0; j < e0; j++) {
+                            const int64_t r = ip[j];
+                            if ((uint64_t)r >= n_rows) { bad = true; continue; }   // skipped; a skipped FIRST row counts as zeros
+                            const char *row = src + (uint64_t)r * (uint64_t)row_bytes;
+#pragma unroll
+                            for (int c = 0; c < NC; c++) {
+                                const float4 t = chunk_at(row, c);
+                                if (j == s0) { a[rr][c] = t; continue; }
+                                a[rr][c].x = __fadd_rn(a[rr][c].x, t.x); a[rr][c].y = __fadd_rn(a[rr][c].y, t.y);
+                                a[rr][c].z = __fadd_rn(a[rr][c].z, t.z); a[rr][c].w = __fadd_rn(a[rr][c].w, t.w);
+                            }
+                        }
+                    }
+                    float xv[(d + 63) / 64];   // x[b] (feature 0, dense) for the passthrough columns
+#pragma unroll
+                    for (int h = 0; h < (d + 63) / 64; h++) {
+                        const int e = lane + 64 * h;
+                        xv[h] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ka->src[0]) + (uint64_t)b * (uint64_t)(ka->stride[0] * 4))[e < d ? e : 0];
+                    }
+                    f32x4 c00, c10, c11;
+                    interact(a, c00, c10, c11);
+                    const int dump = 4 * (OUT_MAX + r16);
+#pragma unroll
+                    for (int h = 0; h < (d + 63) / 64; h++) {
+                        const int e = lane + 64 * h;
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + (e < d ? 4 * e : dump)) = xv[h];
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int i = 4 * q + v;
+                        const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
+                        if constexpr (NT == 2) {
+                            const int gi = 16 + i;
+                            const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+                            const int zo10 = gi < F ? 4 * (d + base + r16) : dump;
+                            const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
+                            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = c10[v];
+                            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[v];
+                        }
+                    }
+                    flush_out(b, true);
+                }
+                if (bad) atomicOr(args.err, 1);
+                return;
+            }
+        } else {
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int u = 0; u < D; u++) issue(u, ring[u]);      // (samples past the block's end: every lane reads the zero page)
@@ -536,6 +650,26 @@ bool launch_rf_probe(const FusedArgs &a, hipStream_t st) {
     default:
         if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 1, 2, EVS_RF_DEPTH, false, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 1, 1, EVS_RF_DEPTH, false, false, true>>(a, st);
         return true;
+    }
+}
+
+// the same launch with lS_o given (whole batches, FusedArgs::bag1 == 3): the kernel checks the offsets of its 16 samples itself
+bool launch_rf_check(const FusedArgs &a, hipStream_t st) {
+    static const bool on = !(getenv("EVS_FUSED_RF_CHECK") && getenv("EVS_FUSED_RF_CHECK")[0] == '0');
+    if (!on || !rf_mode() || a.F > kTileMaxF || a.bag1 != 3 || a.B > rf_max_batch()) return false;
+    const bool nt2 = a.F > 16;
+    switch (a.d) {
+    case 16:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<1, 0, 2, EVS_RF_DEPTH, false, false, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<1, 0, 1, EVS_RF_DEPTH, false, false, false, true>>(a, st);
+        return true;
+    case 32:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 0, 2, EVS_RF_DEPTH, false, false, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 0, 1, EVS_RF_DEPTH, false, false, false, true>>(a, st);
+        return true;
+    case 36:
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 1, 2, EVS_RF_DEPTH, false, false, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 1, 1, EVS_RF_DEPTH, false, false, false, true>>(a, st);
+        return true;
+    default:
+        return false;
     }
 }
 
