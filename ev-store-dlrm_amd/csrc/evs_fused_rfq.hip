@@ -524,6 +524,7 @@ bool launch_rfq(const FusedArgs &a, int codec, hipStream_t st) {
     FusedArgs b = a;
     b.zero_codes = zero_code_page(codec);
     if (!b.zero_codes) return false;
+
     switch (codec) {
     case 16: return launch_rfq_d<16>(b, st);
     case 8: return launch_rfq_d<8>(b, st);

@@ -475,6 +475,33 @@ def test_fused_codec_26_tables_one_index_per_bag(E, orc, codec):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
+@pytest.mark.parametrize("codec,d,B", [(16, 36, 40000 + 7), (8, 36, 33000), (4, 36, 50000 + 3), (16, 16, 36000), (8, 32, 34000 + 1)])
+def test_fused_codec_large_batch(E, orc, codec, d, B):
+    """Reduced-precision tables, batches of several generations of 16-sample blocks (evs_fused_rfq.hip): one index per
+    bag declared, lS_o given (offsets checked in the kernel) and the two-call path give the same bits."""
+    from bench import KAGGLE_LN
+    rs = np.random.RandomState(900 + codec + d)
+    ln = [min(n, 500) | 1 for n in KAGGLE_LN]
+    raws = [orc.encode_table(rs.uniform(-1, 1, size=(n, d)).astype(np.float32), codec) for n in ln]
+    ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, codec)
+    idx_np = np.stack([rs.randint(0, n, size=B) for n in ln]).astype(np.int64)
+    idx_np[:, -1] = np.array(ln) - 1
+    idx = torch.from_numpy(idx_np).cuda()
+    off = torch.arange(B, device="cuda").repeat(26, 1)
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+    a = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True, check_indices=True)
+    b = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
+    assert torch.equal(a, b)
+    c = E.interact_features(x, E.apply_emb(off, idx, ev, None, lazy=False))
+    assert torch.equal(a, c) and torch.equal(a[:, :d], x)
+    # an out-of-range index in the last chunk and one in the first: rows skipped, flag raised
+    idx[3, B - 1] = ln[3]
+    idx[20, 5] = -1
+    E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+
+
 @pytest.mark.parametrize("codec,B", [(32, 8192 + 77), (8, 8192 + 77), (32, 4096 + 5), (32, 2048 + 3), (32, 20000),
                                       (16, 8192 + 77), (16, 4096 + 5), (4, 4096 + 5), (8, 16384 + 3), (16, 2048 + 3)])
 def test_fused_optimistic_offsets_pair(E, orc, codec, B):
