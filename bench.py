@@ -329,7 +329,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
     # and a 4-byte slot / priority word of the probe = 5 956 B per sample at T = 26, d = 36; the batch is several launches
     # (probe, consumer, policy update), so `achieved` is bytes over the whole batch's device time (HIP events)
     tier_bytes = B * (T * (4 * d + 8) + 4 * d + 4 * (d + F * (F - 1) // 2) + T * 12)
-    tier_roof = {"bound": "hbm", "kernel": "the batch's launch chain: cache_batch_probe_gather + fused consumer (pointer mode) + policy update",
+    tier_roof = {"bound": "hbm", "kernel": "the batch's launch chain: emb_interact_rf_kernel<..., PROBE> (cache probe + gather + interaction, one launch) + cache_batch_sampled_list_kernel (policy update), closes / sweeps amortised",
                  "achieved": tier_bytes / dev_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": tier_bytes / dev_ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": tier_bytes,
                  "avg_launch_ms": dev_ms}
