@@ -2791,6 +2791,13 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
                 hipLaunchKernelGGL(cache_rows_from_ptrs2_kernel, dim3((unsigned)nb), dim3(256), 0, st, c->row_ptrs,
                                    (const unsigned char *)nullptr, out, (long long)B, T, c->host.dim, c->host.codec, c->host.codec);
         }
+        if (R && c->host.codec != 32) {
+            // a reduced-precision tier: every row decoded inside the interaction kernel (evs_mixed.hip; all rows of one class --
+            // u8 rows take the (u8, u4) rows-in-registers kernel with every row in its first class)
+            const int rc = interact_from_mixed_rows(B, T, c->host.dim, x, x_stride, c->row_ptrs, nullptr, c->host.codec,
+                                                    c->host.codec == 8 ? 4 : c->host.codec, itself, R, st);
+            if (rc) return rc;
+        } else
         if (R) {
             const int rc = a.row_ids
                 ? fused_interact_from_row_ids(B, T, c->host.dim, x, x_stride, a.row_ids, c->a.arena,
@@ -2809,8 +2816,12 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         for (int k = 0; k < T; k++) small = small && c->backing_rows[k] < (1ll << 30);
         if (small) a.row_ids = reinterpret_cast<int *>(c->row_ptrs);
     }
-    if (R) EVS_REQUIRE(c->host.codec == 32 && evs_fused_dim_supported(c->host.dim) && T + 1 <= EVS_MAX_FEATURES,
-                       "evs_cache_lookup_interact: needs an fp32 cache, a fused-kernel dimension and T <= 31");
+    if (R && c->host.codec == 32)
+        EVS_REQUIRE(evs_fused_dim_supported(c->host.dim) && T + 1 <= EVS_MAX_FEATURES,
+                    "evs_cache_lookup_interact: needs a fused-kernel dimension and T <= 31");
+    if (R && c->host.codec != 32)
+        EVS_REQUIRE((c->host.dim == 16 || c->host.dim == 32 || c->host.dim == 36) && T + 1 <= EVS_MAX_FEATURES && !host_tier,
+                    "evs_cache_lookup_interact: a reduced-precision cache needs d in {16, 32, 36}, T <= 31 and its tables in HBM");
     // consumers of the snapshot read the rows BEFORE the policy kernels move anything
     const bool file_mode = c->ft && c->staged_mask;
     if (resolved_batch_policy(c) == 1 && !file_mode) {

@@ -286,8 +286,10 @@ EVS_API int evs_cache_lookup_interact_c1c2c3(evs_cache *c1, evs_cache *c2, evs_a
 EVS_API int64_t evs_aprx_batch_dump(evs_aprx *p, int64_t *triples, int64_t max_triples, int64_t *out4, void *stream);
 /* The same lookup feeding the interaction directly: R = interact_features(x, [rows of the 26 keys])
  * (B, d + F(F-1)/2) without materialising the rows -- the probe writes a table of row addresses
- * (arena row for a hit, backing row for a miss) that the fused MFMA kernel consumes.  fp32 caches,
- * dimensions supported by evs_fused_dim_supported. */
+ * (arena row for a hit, backing row for a miss) that the fused MFMA kernel consumes.  fp32 caches:
+ * dimensions supported by evs_fused_dim_supported (up to 16 384 requests the probe itself runs inside that
+ * kernel).  16 / 8 / 4-bit caches (tables in HBM, d in {16, 32, 36}): the rows are decoded inside the
+ * interaction kernel (the reference's one-layer reduced-precision builds, cache_manager.cpp:13-20). */
 EVS_API int evs_cache_lookup_interact(evs_cache *c, int64_t B, const int32_t *rows, const float *x, int64_t x_stride,
                                       int itself, float *R, uint8_t *hit, void *stream);
 /* out8: [size, n_free, n_tombstones, n_flush, n_evict, n_requests, n_perfect_hits, n_hits];

@@ -661,6 +661,33 @@ def test_two_tier_mixed_codec_interaction_consumer(E, orc, codecs, d, T, policy)
     assert c1.batch_stats()["size"] <= 400 and c2.batch_stats()["size"] <= 900
 
 
+@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("codec,d,T", [(8, 36, 26), (4, 36, 26), (16, 36, 26), (8, 16, 9), (4, 32, 17), (16, 16, 27)])
+def test_single_tier_reduced_precision_interaction_consumer(E, orc, codec, d, T, policy):
+    """A single reduced-precision tier (the reference's one-layer 16 / 8 / 4-bit builds) feeding the interaction: rows
+    decoded inside the kernel, hits from the arena and misses from the backing table -- the same decoded row either way,
+    so R must equal interact_features over the decoded table rows, whatever the cache holds."""
+    rs = np.random.RandomState(31 + codec + d)
+    n_rows = [200 + 7 * k for k in range(T)]
+    raws = [orc.encode_table(rs.uniform(-1, 1, size=(n, d)).astype(np.float32), codec) for n in n_rows]
+    dec = [orc.decode(r, codec, d) for r in raws]
+    c = E.GpuCache("evlfu", 500, T, d, codec, "cpp").set_batch_policy(policy)
+    c.set_backing([torch.from_numpy(a).cuda() for a in raws])
+    B = 211
+    saw_hit = saw_miss = False
+    for it in range(6):
+        hot = rs.rand(B, T) < 0.6
+        rq = np.where(hot, rs.randint(0, 10, size=(B, T)), np.stack([rs.randint(0, n, size=B) for n in n_rows], 1)).astype(np.int32)
+        x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+        hit, R = c.lookup_interact(torch.from_numpy(rq).cuda(), x, itself=bool(it & 1))
+        want = orc.interact_features(x.cpu().numpy(), [dec[k][rq[:, k]] for k in range(T)], bool(it & 1))
+        np.testing.assert_allclose(R.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+        assert torch.equal(R[:, :d], x)
+        h = hit.cpu().numpy()
+        saw_hit |= bool(h.any()); saw_miss |= bool((h == 0).any())
+    assert saw_hit and saw_miss and c.batch_stats()["size"] <= 500
+
+
 @pytest.mark.parametrize("cap", [50, 64, 257])
 def test_altkey_tier_ops_match_reference_driven_single_threaded(E, orc, cap):
     """a12, the pinnable part: APRX_EV's public methods (insert_altkey / get_altkey_str / set_recency_flag_c3 /
