@@ -174,7 +174,7 @@ def batched_case(rs, case):
     reqs = _stream(rs, n_rows, B * n_batches)
     resident = {}
     hits_total = 0
-    use_interact = codec == 32 and d in (16, 36, 64) and T + 1 <= 32
+    use_interact = T + 1 <= 32 and ((codec == 32 and d in (16, 36, 64)) or (codec != 32 and d in (16, 32, 36) and not host))
     for s in range(0, len(reqs), B):
         rq = reqs[s:s + B]
         rt = torch.from_numpy(rq).cuda()
