@@ -2793,9 +2793,11 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         }
         if (R && c->host.codec != 32) {
             // a reduced-precision tier: every row decoded inside the interaction kernel (evs_mixed.hip; all rows of one class --
-            // u8 rows take the (u8, u4) rows-in-registers kernel with every row in its first class)
-            const int rc = interact_from_mixed_rows(B, T, c->host.dim, x, x_stride, c->row_ptrs, nullptr, c->host.codec,
-                                                    c->host.codec == 8 ? 4 : c->host.codec, itself, R, st);
+            // u8 / u4 rows take the (u8, u4) rows-in-registers kernel with every row in its first / second class)
+            const int rc = c->host.codec == 4
+                ? interact_from_mixed_rows(B, T, c->host.dim, x, x_stride, c->row_ptrs, nullptr, 8, 4, itself, R, st, 2)   // every row in the pair's second class
+                : interact_from_mixed_rows(B, T, c->host.dim, x, x_stride, c->row_ptrs, nullptr, c->host.codec,
+                                           c->host.codec == 8 ? 4 : c->host.codec, itself, R, st);
             if (rc) return rc;
         } else
         if (R) {

@@ -159,7 +159,8 @@ int fused_interact_from_row_ids(int64_t B, int T, int d, const float *x, int64_t
 
 // evs_mixed.hip: interaction over x + T rows given as (address, codec class) pairs, decoded on the fly
 int interact_from_mixed_rows(long long B, int T, int d, const float *x, long long x_stride, const long long *row_ptrs,
-                             const unsigned char *row_class, int codec1, int codec2, int itself, float *R, hipStream_t st);
+                             const unsigned char *row_class, int codec1, int codec2, int itself, float *R, hipStream_t st,
+                             int default_class = 1);   // row_class == NULL: every row of this class (1 = codec1, 2 = codec2)
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

@@ -27,6 +27,7 @@ struct MixedArgs {
     float *R;
     long long B;
     int T, itself, P, codec1, codec2;
+    int default_class;                      // row_class == NULL: the class of every row
 };
 
 template <int CQ, int REM, int NT>
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) interact_mixed_rows_kernel(const MixedArg
                 v[it] = reinterpret_cast<const float4 *>(args.x + b * args.x_stride)[c];
             } else if (r < F) {
                 const long long ptr = args.row_ptrs[b * T + (r - 1)];
-                const int cls = args.row_class ? args.row_class[b * T + (r - 1)] : 1;
+                const int cls = args.row_class ? args.row_class[b * T + (r - 1)] : args.default_class;
                 const int codec = cls == 1 ? args.codec1 : args.codec2;
                 if (ptr && cls) {
                     const unsigned char *row = reinterpret_cast<const unsigned char *>(ptr);
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
             const long long pv = *reinterpret_cast<const __attribute__((address_space(1))) long long *>(
                 reinterpret_cast<uintptr_t>(on ? args.row_ptrs + base + i : args.row_ptrs));
             const unsigned char cv = args.row_class ? *reinterpret_cast<const __attribute__((address_space(1))) unsigned char *>(
-                reinterpret_cast<uintptr_t>(on ? args.row_class + base + i : args.row_class)) : (unsigned char)1;
+                reinterpret_cast<uintptr_t>(on ? args.row_class + base + i : args.row_class)) : (unsigned char)args.default_class;
             if (on && pv && cv) {
                 const int sidx = i / T, k = i - sidx * T;
                 s_ptr[(k + 1) * 16 + sidx] = (unsigned long long)pv;
@@ -542,7 +543,7 @@ int probe2_interact_mixed84(long long B, int T, int d, const float *x, long long
     Mixed84Args ma;
     const int F = T + 1;
     ma.m.x = x; ma.m.x_stride = x_stride; ma.m.row_ptrs = nullptr; ma.m.row_class = nullptr; ma.m.R = R; ma.m.B = B; ma.m.T = T;
-    ma.m.itself = itself ? 1 : 0; ma.m.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2; ma.m.codec1 = 8; ma.m.codec2 = 4;
+    ma.m.itself = itself ? 1 : 0; ma.m.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2; ma.m.codec1 = 8; ma.m.codec2 = 4; ma.m.default_class = 1;
     ma.zero_codes8 = zero_code_page(8); ma.zeros = zero_page(); ma.p = probe;
     if (!ma.zero_codes8 || !ma.zeros) return EVS_EHIP;
     switch (d) {
@@ -571,8 +572,10 @@ static void launch_mixed(const MixedArgs &a, hipStream_t st) {
 
 // evs_cache.hip: R over x + T rows (address, class) -- d in {16, 32, 36}, T <= 31
 int interact_from_mixed_rows(long long B, int T, int d, const float *x, long long x_stride, const long long *row_ptrs,
-                             const unsigned char *row_class, int codec1, int codec2, int itself, float *R, hipStream_t st) {
+                             const unsigned char *row_class, int codec1, int codec2, int itself, float *R, hipStream_t st,
+                             int default_class) {
     MixedArgs a;
+    a.default_class = default_class == 2 ? 2 : 1;
     const int F = T + 1;
     a.x = x; a.x_stride = x_stride; a.row_ptrs = row_ptrs; a.row_class = row_class; a.R = R; a.B = B; a.T = T;
     a.itself = itself ? 1 : 0; a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2; a.codec1 = codec1; a.codec2 = codec2;
