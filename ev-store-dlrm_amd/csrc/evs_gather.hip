@@ -107,6 +107,10 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs
         const int64_t nnz = args.nnz[t];
 
         int64_t s[UNROLL], len[UNROLL];
+        // offsets given: idx[b] is requested together with offsets[b] / offsets[b + 1] on the bet that bag b is {idx[b]} (the
+        // Criteo collate's arange offsets, dlrm_data_pytorch.py:407-408); a bag that starts at b takes its first index from
+        // there -- two dependent round trips in front of the rows instead of three -- any other bag reads idx[start] as before
+        int64_t spec[UNROLL], bpos[UNROLL];
         int64_t maxlen = 0;
         if constexpr (BAG1) {
 #pragma unroll
@@ -122,6 +126,9 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs
                 const int64_t b = b0 + (int64_t)u * RPW + slot;
                 s[u] = 0;
                 len[u] = 0;
+                bpos[u] = b;
+                spec[u] = -1;
+                if (lane_on && b < B && b < nnz) spec[u] = idx[b];
                 if (lane_on && b < B) {
                     const int64_t st = off[b];
                     const int64_t en = (b + 1 < B) ? off[b + 1] : nnz;
@@ -152,7 +159,10 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs
             for (int u = 0; u < UNROLL; u++) {
                 r[u] = -1;
                 if (j < len[u]) {
-                    const int64_t v = idx[s[u] + j];
+                    int64_t v;
+                    if constexpr (BAG1) v = idx[s[u] + j];
+                    else if (j == 0 && s[u] == bpos[u]) v = spec[u];
+                    else v = idx[s[u] + j];
                     if (v >= 0 && v < n_rows) r[u] = v; else bad = true;
                 }
             }
