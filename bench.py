@@ -279,6 +279,17 @@ def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=No
     return res
 
 
+def _tier_traffic(B, d, frac, alpha, policy):
+    """HBM bytes per batch of the cache tier's launch chain from the committed PMC passes (profiles/traffic.json), for the
+    configuration they were taken on; None otherwise."""
+    if policy not in (None, "sampled") or abs(frac - 0.10) > 1e-9 or abs(alpha - 0.75) > 1e-9:
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("cache_tier_B%d_d%d" % (B, d))
+    except Exception:
+        return None
+
+
 def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, alpha=0.75, batch1=True, host_tier_line=True,
                        settle_s=0.35, policy=None):
     """BASELINE configs[2]: EvLFU C1 cache in HBM at 10 % of the rows in front of the same tables
@@ -331,7 +342,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
     tier_bytes = B * (T * (4 * d + 8) + 4 * d + 4 * (d + F * (F - 1) // 2) + T * 12)
     tier_roof = {"bound": "hbm", "kernel": "the batch's launch chain: emb_interact_rf_kernel<..., PROBE> (cache probe + gather + interaction, one launch) + cache_batch_sampled_list_kernel (policy update), closes / sweeps amortised",
                  "achieved": tier_bytes / dev_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                 "frac": tier_bytes / dev_ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": tier_bytes,
+                 "frac": tier_bytes / dev_ms / 1e6 / HBM_PEAK_GBPS, "traffic": _tier_traffic(B, d, frac, alpha, policy), "bytes_per_launch": tier_bytes,
                  "avg_launch_ms": dev_ms}
     # the same cache in front of tables that stay in pinned HOST memory (the reference's C3 / mmap miss path): each
     # missing row crosses the bus once; beside it, the fused kernel reading every row from host memory uncached
