@@ -2281,6 +2281,7 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
     // slot hints: deletions leave tombstones, and how often they have to be swept / the table rebuilt (~170 us at 3.4 M
     // entries) is a matter of tombstones per slot -- 16 us per batch amortised at load 0.4, a third of that here.
     c->bnslot = (nslot * 2 <= (1ll << 24)) ? nslot * 2 : nslot;
+    if (const char *e = getenv("EVS_CACHE_HASH_SCALE")) { if (e[0] == '1') c->bnslot = nslot; }   // developer A/B: the denser table
     h.nslot_mask = (unsigned long long)(nslot - 1);
     h.min_c1 = 0; h.n_perfect = 0;
     h.max_perfect = (int)(capacity * perfect_item_cap);          // EvLFU_C1.py:30
