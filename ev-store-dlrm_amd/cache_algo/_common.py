@@ -33,6 +33,18 @@ class _ModuleCache:
         self.cache.set_backing(tabs)
         self._bound = True
 
+    def request_rows(self, group_row_ids):
+        """-> (list[bool] * T, (T, d) float32 numpy array on the host): the Cython module's return shape"""
+        if self.cache is None:
+            print("ERROR: call init(capacity) first")
+            exit(-1)
+        if not self._bound:
+            self._bind()
+        self._host_rows[0] = torch.as_tensor(group_row_ids, dtype=torch.int32)
+        self.cache.request(self._host_rows, -1, out=self._host_out, hit=self._host_hit)
+        torch.cuda.current_stream(self._device).synchronize()
+        return [bool(v) for v in self._host_hit[0].tolist()], self._host_out[0].numpy().copy()
+
     def request(self, group_row_ids, use_gpu, approx_thres=-1):
         if self.cache is None:
             print("ERROR: call init(capacity) first")

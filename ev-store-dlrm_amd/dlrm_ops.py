@@ -178,6 +178,12 @@ class EVTables:
             out.append(dst)
         return EVTables(out, self.d, bits)
 
+    def to_bin_dir(self, out_dir):
+        """Write ev-table-{1..T}.bin in the reference's storage format (script/convert_ev_to_binary.py:31-69) -- the
+        bytes in HBM ARE that format, so from_bin_dir(to_bin_dir(...)) is the identity for every precision."""
+        from . import converters
+        return converters.tables_to_bin_dir(self, out_dir)
+
     def __len__(self):
         return len(self.raw)
 

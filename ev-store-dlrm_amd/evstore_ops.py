@@ -1,12 +1,17 @@
-"""apply_emb_evstore -- mirror of dlrm_s_pytorch_C1.py:227-275 (and the _C1_C2/_C1_C2_C3 forks).
+"""apply_emb_evstore -- mirror of dlrm_s_pytorch_C1.py:227-275 and of the _C1_C2 / _C1_C2_C3 forks' version
+(dlrm_s_pytorch_C1_C2.py:227-275): ONE if-chain with every branch the forks have.
 
-Module globals `cache_algo` and `perfect_hit` as in the reference.  The lookup itself runs in the
-GPU cache tier (cache_algo/*.py -> csrc/evs_cache.hip)."""
-from .cache_algo import EvLFU_C1, LRU, LFU
+Module globals `cache_algo`, `perfect_hit` and (C1_C2 forks) `evstore_gpu_id` as in the reference.  The lookup itself
+runs in the GPU cache tier (cache_algo/*.py -> csrc/evs_cache.hip) or, for "cpp_algo", in the cache manager of
+libevstore_hip.so through the ctypes client (cache_algo/cpp_socket_client.py -> ev_lookup)."""
+import torch
+
+from .cache_algo import EvLFU, EvLFU_C1, LFU, LRU, cpp_socket_client
 from .emb_storage import storage_manager
 
 cache_algo = "evlfu"
 perfect_hit = 0
+evstore_gpu_id = 0   # dlrm_s_pytorch_C1_C2.py:1267 (--evstore-gpu-id)
 
 
 def apply_emb_evstore(lS_o, lS_i, emb_l, v_W_l, use_gpu=False, use_emb_cache=False, approx_emb_threshold=-1):
@@ -23,10 +28,22 @@ def apply_emb_evstore(lS_o, lS_i, emb_l, v_W_l, use_gpu=False, use_emb_cache=Fal
             aggHitMissRecord, ly = LRU.request_to_lru(group_rowIds, use_gpu)
         elif cache_algo == "lfu":
             aggHitMissRecord, ly = LFU.request_to_lfu(group_rowIds, use_gpu)
+        elif cache_algo == "evlfu_cython":
+            # dlrm_s_pytorch_C1.py:250-253: rows come back as 26 float lists, each wrapped in a CPU FloatTensor
+            aggHitMissRecord, tmp = EvLFU.crequest(group_rowIds, use_gpu)
+            ly = [torch.FloatTensor([tmp[i]]) for i in range(len(tmp))]
+        elif cache_algo == "cpp_algo":
+            # dlrm_s_pytorch_C1_C2.py:247-249: the ctypes boundary; the perfect-hit count lives in the library
+            # (print_perfect_hit), the forks leave aggHitMissRecord empty and count nothing here
+            aggHitMissRecord = None
+            ly = cpp_socket_client.request_to_cpp_cache(group_rowIds, use_gpu, False, evstore_gpu_id)
+        elif cache_algo == "cpp_algo_socket":
+            aggHitMissRecord = None
+            ly = cpp_socket_client.request_to_cpp_cache(group_rowIds, use_gpu, True)  # out of scope: prints + exits
         else:
             print("ERROR: This algorithm is not yet supported! " + str(cache_algo))
             exit(-1)
-        if all(aggHitMissRecord):
+        if aggHitMissRecord is not None and all(aggHitMissRecord):
             perfect_hit += 1
     else:
         _, ly = storage_manager.request_to_emb_storage(group_rowIds, use_gpu)
