@@ -825,6 +825,7 @@ struct BatchState {
     int pstar, need, ticket, flush_t, ticket_t, pos_ticket, do_rebuild, n_assign;
     int hand, win;   // eviction scans the entry window [hand, hand + win) (mod cap), then the hand moves on
     int n_orphan;    // file mode: missed keys of staged tables the full hash could not take (served from staging, never cached)
+    int flush_gone;  // sampled flush: entries the scan kernel removed, folded into the counters by its finish kernel
     long long batch_id, n_hits, n_requests, n_perfect_hits, n_evict, n_flush;
 };
 
@@ -2001,11 +2002,17 @@ __device__ __forceinline__ void sampled_close_block(const CloseArgs &args) {
 // first come first served over the arena.  Runs alone on the stream, between two batches (the close of a batch raises a
 // flag in mapped host memory; the next batched call, or a stats / dump call, runs the flush first).
 __global__ void __launch_bounds__(256) cache_batch_sampled_flush_kernel(BatchState *b, CacheArrays a, unsigned long long *slots,
-                                                                        const int *eslot, int cap, int T, int flush_n) {
+                                                                        const int *eslot, int cap, int T, int flush_n, int max_perfect) {
     __shared__ int s_tot[8];
     __shared__ int s_gone;
+    // Nothing in this launch writes cnt[T] (the finish kernel behind it does), so every block reads the same value:
+    // one decision and one `want` for the whole grid.  The flag that asked for this launch is raised by a close and
+    // cleared by the host without synchronising -- a close already in flight can raise it again after the flush has
+    // run: that second launch finds the top bucket below max_perfect and does nothing.
+    const int top_n = b->cnt[T];
+    if (top_n < max_perfect) return;
     if (threadIdx.x == 0) s_gone = 0;
-    const int want = flush_n < b->cnt[T] ? flush_n : b->cnt[T];
+    const int want = flush_n < top_n ? flush_n : top_n;
     __syncthreads();
     for (long long e0 = (long long)blockIdx.x * blockDim.x; e0 < cap; e0 += (long long)gridDim.x * blockDim.x) {   // block-uniform trip count
         const long long e = e0 + threadIdx.x;
@@ -2018,11 +2025,17 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_flush_kernel(BatchSta
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_gone) {
-        atomicSub(&b->cnt[T], s_gone); atomicSub(&b->count, s_gone); atomicAdd(&b->n_free, s_gone);
-        atomicAdd(&b->n_tomb, s_gone);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&b->n_flush), 1ull);
+    if (threadIdx.x == 0 && s_gone) atomicAdd(&b->flush_gone, s_gone);
+}
+// ... and its finish: one thread folds what the scan removed into the counters and counts the flush -- only if it
+// removed anything (n_flush is what batch_stats reports).
+__global__ void cache_batch_sampled_flush_finish_kernel(BatchState *b, int T) {
+    const int gone = b->flush_gone;
+    b->flush_gone = 0;
+    b->ticket_t = 0;
+    if (gone <= 0) return;
+    b->cnt[T] -= gone; b->count -= gone; b->n_free += gone; b->n_tomb += gone;
+    b->n_flush += 1;
 }
 
 // Tombstone sweep (between two batches, instead of most rebuilds): a tombstone whose successor is EMPTY ends its chain
@@ -2523,7 +2536,10 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
         const long long iters = (B + 8 * g1n - 1) / (8 * g1n);
         sp.add(&miss_info, B * T * 4); sp.add(&new_slot, g2 * 256 * 4); sp.add(&block_cnt, g2 * 4); sp.add(&block_base, g2 * 4);
         sp.add(&row_ptrs, B * T * 8); sp.add(&row_tier, B * T); sp.add(&iota, B * 8);
-        sp.add(&miss_rec, g1n * iters * 8 * T * 16); sp.add(&list_cnt, g1n * 4);   // K1's per-block miss lists (sampled update)
+        sp.add(&miss_rec, g1n * iters * 8 * T * 16);   // K1's per-block miss lists (sampled update)
+        // one counter per list: K1 has g1n lists, the probe folded into the consumer one per 16-sample block -- more than
+        // g1n once B > 16 * kProbeGridMax (the fold is bounded by rf_max_batch(), which EVS_FUSED_RF_MAX_B can raise)
+        sp.add(&list_cnt, std::max<long long>(g1n, (B + 15) / 16) * 4);
         if (!sp.carve(&slab)) {
             set_error("%s: allocating the buffers of a %lld-request batch failed", who, (long long)B);
             return EVS_ENOMEM;
@@ -2754,7 +2770,8 @@ static void sampled_flush_if_wanted(evs_cache *c, hipStream_t st) {
     const int wide = kNumCu * 8;
     long long nf = ((long long)c->host.cap + 255) / 256; if (nf > wide) nf = wide;
     hipLaunchKernelGGL(cache_batch_sampled_flush_kernel, dim3((unsigned)nf), dim3(256), 0, st, c->bs, c->a, c->bslots, c->eslot,
-                       (int)c->host.cap, c->host.n_tables, c->host.flush_n);
+                       (int)c->host.cap, c->host.n_tables, c->host.flush_n, c->host.max_perfect);
+    hipLaunchKernelGGL(cache_batch_sampled_flush_finish_kernel, dim3(1), dim3(1), 0, st, c->bs, c->host.n_tables);
 }
 
 static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit, const float *x,

@@ -398,18 +398,20 @@ _w1_cache = {}
 
 def pad_top_layer(W1, K):
     """W1 (n1, K) -> the layout evs_emb_interact_mlp1_stacked reads: zero-padded to ((n1+15)//16*16, (K+15)//16*16), cached per
-    weight tensor (and its version counter: an in-place update re-pads)."""
-    key = (W1.data_ptr(), tuple(W1.shape), W1._version)
+    weight TENSOR (the entry holds W1 itself: a freed weight's address, shape and version counter can all come back with
+    another model's tensor through the caching allocator) and its version counter (an in-place update re-pads)."""
+    key = id(W1)
     hit = _w1_cache.get(key)
-    if hit is None:
-        n1 = int(W1.shape[0])
-        kp = (K + 15) // 16 * 16
-        hit = torch.zeros(((n1 + 15) // 16 * 16, kp), dtype=torch.float32, device=W1.device)
-        hit[:n1, :K] = W1.detach().to(torch.float32)
-        if len(_w1_cache) > 16:
-            _w1_cache.clear()
-        _w1_cache[key] = hit
-    return hit
+    if hit is not None and hit[0] is W1 and hit[1] == W1._version and hit[2] == W1.data_ptr() and hit[3].shape[1] >= K:
+        return hit[3]
+    n1 = int(W1.shape[0])
+    kp = (K + 15) // 16 * 16
+    pad = torch.zeros(((n1 + 15) // 16 * 16, kp), dtype=torch.float32, device=W1.device)
+    pad[:n1, :K] = W1.detach().to(torch.float32)
+    if len(_w1_cache) > 16:
+        _w1_cache.clear()
+    _w1_cache[key] = (W1, W1._version, W1.data_ptr(), pad)   # W1 kept alive: id() and the address stay its own
+    return pad
 
 
 def apply_emb_interact_mlp1(x, lS_o, lS_i, emb_l, W1, b1, relu=True, arch_interaction_itself=False, return_R=False):

@@ -107,6 +107,9 @@ class HipBackend:
         fast = ("gid", id(lS_i_rows), id(lS_o_rows), send.data_ptr(), bag1)
         ent = self._cache.get(fast) if planned else None
         if ent is None:
+            # "one index per bag" is a statement about the batch: honour it only when every index list HAS B entries
+            # (as apply_emb does); anything else pools through the offsets the caller gave
+            bag1 = bag1 and all(int(t.numel()) == B for t in lS_i_rows)
             ent = ((C.c_void_p * n)(*[ev._tables_c[k] for k in table_ids_local]),
                    (C.c_int64 * n)(*[ev.n_rows[k] for k in table_ids_local]),
                    (C.c_void_p * n)(*[t.data_ptr() for t in lS_i_rows]),
