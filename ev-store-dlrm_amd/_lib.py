@@ -99,6 +99,20 @@ _PROTOS = {
     "init_global_vars": (None, []),
     "start_server_threads": (None, []),
     "evs_interact_cat": (_int, [_i64, _int, _int, _pp, _i64p, _vp, _vp]),
+    "evs_hostcache_create": (_int, [_pp, _int, _i64, _int, _int, _int, C.c_double, C.c_double, _int, _int]),
+    "evs_hostcache_destroy": (_int, [_vp]),
+    "evs_hostcache_set_backing": (_int, [_vp, _pp, _i64p]),
+    "evs_hostcache_request": (_int, [_vp, _i64, _vp, _vp, _vp, _int]),
+    "evs_hostcache_request_c1c2c3": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _int]),
+    "evs_hostcache_stats": (_int, [_vp, _i64p]),
+    "evs_hostcache_reset_counters": (_int, [_vp]),
+    "evs_hostcache_dump": (_i64, [_vp, _vp, _i64]),
+    "evs_hostaprx_create": (_int, [_pp, _i64, _int]),
+    "evs_hostaprx_destroy": (_int, [_vp]),
+    "evs_hostaprx_set_altkeys": (_int, [_vp, _pp, _i64p]),
+    "evs_hostaprx_stats": (_int, [_vp, _i64p]),
+    "evs_hostaprx_apply_ops": (_int, [_vp, _i64, _vp, _vp]),
+    "evs_hostaprx_dump_queue": (_i64, [_vp, _i64p, _i64]),
 }
 
 

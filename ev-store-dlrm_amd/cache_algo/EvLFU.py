@@ -10,8 +10,8 @@ flush_rate = 0.4            # EvLFU.cpp:12
 perfect_item_cap = 1.0      # EvLFU.cpp:13
 
 
-def cinit(capacity, device="cuda"):
-    _m.init(capacity, "cython", device)
+def cinit(capacity, device="cuda", engine="auto"):
+    _m.init(capacity, "cython", device, engine)
 
 
 def crequest(group_keys, use_gpu=False):
@@ -24,12 +24,14 @@ def crequest(group_keys, use_gpu=False):
 
 def cload_ev_tables():
     """EvLFU.cpp opens its 26 table files here (load_ev_tables, :127-151); this tier reads misses from the storage
-    manager's device-accessible tables, bound on the first request."""
-    _m._bind()
+    manager's tables (bound here, or on the first request)."""
+    if not getattr(_m, "_bound", False):
+        _m._bind()
 
 
 def cclose_ev_tables():
-    _m._bound = False
+    """close_ev_tables (EvLFU.cpp:153-160) closes the 26 FILE handles; the cache itself stays as it is.  The storage
+    manager owns the tables here: nothing to do."""
 
 
 def stats():

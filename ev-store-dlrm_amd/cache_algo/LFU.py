@@ -4,8 +4,8 @@ from ._common import _ModuleCache
 _m = _ModuleCache("lfu")
 
 
-def init(capacity, device="cuda"):
-    _m.init(capacity, "python", device)
+def init(capacity, device="cuda", engine="auto"):
+    _m.init(capacity, "python", device, engine)
 
 
 def request_to_lfu(group_row_ids, use_gpu=False):

@@ -1,7 +1,16 @@
-"""Shared plumbing of the three cache modules (module-global state, like the reference's)."""
+"""Shared plumbing of the cache modules (module-global state, like the reference's).
+
+Two engines behind the same surface, picked when the first request binds the storage manager's tables
+(init(..., engine="auto")):
+  host  the exact policy on the host (csrc/evs_hostcache.hip): a few microseconds per request, rows read from
+        host-readable tables (EmbStorage.DUMMY / PINNED tensors, or the .bin files of FILEPY / MMAPFILEPY mapped
+        read-only) -- the reference's batch-1 loop belongs here;
+  gpu   the GPU tier's exact kernel (csrc/evs_cache.hip): one launch + one synchronise per request, for tables that
+        live in HBM only (EmbStorage.HBM), or when asked for (engine="gpu": one cache shared with batched lookups).
+Both give the same hit flags, rows and list order (tests/test_hostcache.py, tests/test_gpu_cache.py)."""
+import numpy as np
 import torch
 
-from .. import gpu_cache
 from ..emb_storage import storage_manager
 
 
@@ -9,12 +18,20 @@ class _ModuleCache:
     def __init__(self, policy):
         self.policy = policy
         self.cache = None
-        self.rows = None
+        self.engine = None
+        self._args = None
         self.n_tables, self.dim = storage_manager.N_EV_TABLE, storage_manager.EV_DIMENSION
 
-    def init(self, capacity, variant="python", device="cuda"):
-        self.cache = gpu_cache.GpuCache(self.policy, capacity, self.n_tables, self.dim,
-                                        storage_manager.ev_precs, variant, device)
+    def init(self, capacity, variant="python", device="cuda", engine="auto"):
+        assert engine in ("auto", "host", "gpu")
+        self._args = (int(capacity), variant, device, engine)
+        self.cache, self.engine, self._bound = None, None, False
+
+    # ---- engines ------------------------------------------------------------------------------------------------------
+    def _make_gpu(self, tabs):
+        from .. import gpu_cache
+        capacity, variant, device, _ = self._args
+        self.cache = gpu_cache.GpuCache(self.policy, capacity, self.n_tables, self.dim, storage_manager.ev_precs, variant, device)
         # one request at a time, like the reference: ids, hit flags (and the rows when the caller wants them on
         # the host) live in pinned buffers the kernel reads / writes directly
         self._host_rows = torch.empty((1, self.n_tables), dtype=torch.int32).pin_memory()
@@ -22,41 +39,71 @@ class _ModuleCache:
         self._host_out = torch.empty((1, self.n_tables, self.dim), dtype=torch.float32).pin_memory()
         self._dev_out = torch.empty((1, self.n_tables, self.dim), dtype=torch.float32, device=device)
         self._device = torch.device(device)
-        self._bound = False
+        self.cache.set_backing(tabs)
+        self.engine = "gpu"
+
+    def _make_host(self, tabs):
+        from .. import host_cache
+        capacity, variant, device, _ = self._args
+        self.cache = host_cache.HostCache(self.policy, capacity, self.n_tables, self.dim, storage_manager.ev_precs, variant)
+        self.cache.set_backing(tabs)
+        self._rows = np.empty((1, self.n_tables), np.int32)
+        self._hit = np.empty((1, self.n_tables), np.uint8)
+        self._out = np.empty((1, self.n_tables, self.dim), np.float32)
+        self._device = torch.device(device if device != "cuda" else "cuda:0")  # EvLFU_C1.py:132 hard-codes cuda:0
+        self.engine = "host"
 
     def _bind(self):
-        tabs = storage_manager.device_tables()
-        if tabs is None:
-            print("ERROR: the GPU cache reads misses from device-accessible storage: set "
-                  "storage_manager.storage_type = EmbStorage.HBM or EmbStorage.PINNED before loading the tables")
+        if self._args is None:
+            print("ERROR: call init(capacity) first")
             exit(-1)
-        self.cache.set_backing(tabs)
+        want = self._args[3]
+        host_tabs = storage_manager.host_tables()
+        dev_tabs = storage_manager.device_tables()
+        if want == "auto":
+            want = "host" if host_tabs is not None else "gpu"
+        if want == "host":
+            if host_tabs is None:
+                print("ERROR: the host cache engine reads misses from host-readable storage (EmbStorage.DUMMY / PINNED / "
+                      "FILEPY / MMAPFILEPY); the tables are in HBM only -- use engine='gpu' or 'auto'")
+                exit(-1)
+            self._make_host(host_tabs)
+        else:
+            if dev_tabs is None:
+                print("ERROR: the GPU cache reads misses from device-accessible storage: set "
+                      "storage_manager.storage_type = EmbStorage.HBM or EmbStorage.PINNED before loading the tables")
+                exit(-1)
+            self._make_gpu(dev_tabs)
         self._bound = True
+
+    # ---- requests -----------------------------------------------------------------------------------------------------
+    def _run(self, group_row_ids, approx_thres, want_device_rows):
+        """-> (hit flags as a list of bool, rows as a (T, d) float32 tensor on the host, or on the device when the GPU
+        engine can leave them there)"""
+        if not getattr(self, "_bound", False):
+            self._bind()
+        if self.engine == "host":
+            self._rows[0] = group_row_ids
+            self.cache.request(self._rows, approx_thres, out=self._out, hit=self._hit)
+            return self._hit[0].astype(bool).tolist(), torch.from_numpy(self._out[0])
+        self._host_rows[0] = torch.as_tensor(group_row_ids, dtype=torch.int32)
+        out = self._dev_out if want_device_rows else self._host_out
+        self.cache.request(self._host_rows, approx_thres, out=out, hit=self._host_hit)
+        torch.cuda.current_stream(self._device).synchronize()
+        return [bool(v) for v in self._host_hit[0].tolist()], out[0]
 
     def request_rows(self, group_row_ids):
         """-> (list[bool] * T, (T, d) float32 numpy array on the host): the Cython module's return shape"""
-        if self.cache is None:
-            print("ERROR: call init(capacity) first")
-            exit(-1)
-        if not self._bound:
-            self._bind()
-        self._host_rows[0] = torch.as_tensor(group_row_ids, dtype=torch.int32)
-        self.cache.request(self._host_rows, -1, out=self._host_out, hit=self._host_hit)
-        torch.cuda.current_stream(self._device).synchronize()
-        return [bool(v) for v in self._host_hit[0].tolist()], self._host_out[0].numpy().copy()
+        hit, rows = self._run(group_row_ids, -1, False)
+        return hit, rows.numpy().copy()
 
     def request(self, group_row_ids, use_gpu, approx_thres=-1):
-        if self.cache is None:
-            print("ERROR: call init(capacity) first")
-            exit(-1)
-        if not self._bound:
-            self._bind()
-        self._host_rows[0] = torch.as_tensor(group_row_ids, dtype=torch.int32)
-        out = self._dev_out if use_gpu else self._host_out
-        self.cache.request(self._host_rows, approx_thres, out=out, hit=self._host_hit)
-        torch.cuda.current_stream(self._device).synchronize()
-        arr_record_hit = [bool(v) for v in self._host_hit[0].tolist()]
+        arr_record_hit, rows = self._run(group_row_ids, approx_thres, use_gpu)
         # 26 x Tensor(1, 36) with requires_grad, like the reference's torch.FloatTensor([val]) per table -- made as
         # ONE fresh (26, 1, 36) tensor and its 26 views (26 separate clones were most of this function's time)
-        block = out[0].detach().clone().unsqueeze(1).requires_grad_(True)
+        if use_gpu and not rows.is_cuda:
+            block = rows.to(self._device, copy=True)   # ONE host-to-device copy instead of 26 (EvLFU_C1.py:157-161)
+        else:
+            block = rows.detach().clone()
+        block = block.unsqueeze(1).requires_grad_(True)
         return arr_record_hit, list(block.unbind(0))

@@ -9,11 +9,22 @@
 // The reference is configured by editing #defines and recompiling (cache_manager.cpp:13-20);
 // here the same five knobs are runtime arguments of evs_manager_configure() or environment
 // variables read on the first ev_lookup (so a zero-argument dlopen + ev_lookup still works).
+//
+// Engines.  ev_lookup is ONE request per call by construction, and the policies behind it are sequential (request n sees
+// the inserts of request n-1): that is the host engine's job (evs_hostcache.hip: a few microseconds per request on one
+// core, tables = read-only mappings of the .bin files, nothing touches the GPU) and it is the DEFAULT (backing 2,
+// EVS_BACKING=host).  backing 0 / 1 (EVS_BACKING=hbm / pinned) run the same requests through the GPU tier's exact
+// kernel, one launch + one synchronise per call (~50 us) -- for a deployment that shares ONE cache between this batch-1
+// surface and the batched GPU lookups.  Same results either way (tests/_ev_lookup_child.py runs all three).
 #include "evs_common.h"
 
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 namespace evs {
@@ -23,12 +34,15 @@ constexpr int kEvTables = 26;  // N_EV_TABLE   (cache_manager.hpp:31)
 
 struct Manager {
     bool ready = false;
-    int n_layer = 1, main_prec = 32, secondary_prec = 4, backing_kind = 0;
+    int n_layer = 1, main_prec = 32, secondary_prec = 4, backing_kind = 2;   // 0 HBM, 1 pinned (GPU engine); 2 host engine
     long long total_size = 75425;
     long long cap1 = 0, cap2 = 0, cap3 = 0;   // entries per tier, as configured
     std::string proportion = "", root = "";
     evs_cache *c1 = nullptr, *c2 = nullptr;
     evs_aprx *c3 = nullptr;
+    evs_hostcache *h1 = nullptr, *h2 = nullptr;   // host engine
+    evs_hostaprx *h3 = nullptr;
+    std::vector<unsigned> host_alt[kEvTables];
     std::string altkey_dir = "";
     void *alt_tables[kEvTables] = {nullptr};
     long long alt_rows[kEvTables] = {0};
@@ -84,6 +98,53 @@ static int load_tables(Manager &m, int prec, void **tables, long long *rows) {
     return EVS_OK;
 }
 
+// host engine: the table files mapped read-only -- a miss reads one row through the page cache, exactly what the
+// reference's fseek + fread does (evlfu_8.cpp:380-414) without the two system calls
+static int map_tables(Manager &m, int prec, void **tables, long long *rows) {
+    const long long rb = (long long)kEvDim * prec / 8;
+    for (int k = 0; k < kEvTables; k++) {
+        const std::string path = m.root + "/" + precision_dir(prec) + "ev-table-" + std::to_string(k + 1) + ".bin";
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) {
+            set_error("ERROR: Failed to load_ev_tables() when opening %s", path.c_str());
+            return EVS_EIO;
+        }
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) { close(fd); set_error("%s: fstat failed", path.c_str()); return EVS_EIO; }
+        const long long bytes = (long long)sb.st_size;
+        if (bytes % rb) { close(fd); set_error("%s: not a whole number of %lld-byte rows", path.c_str(), rb); return EVS_EIO; }
+        void *p = nullptr;
+        if (bytes > 0) {
+            p = mmap(nullptr, (size_t)bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p == MAP_FAILED) { close(fd); set_error("%s: mmap failed", path.c_str()); return EVS_EIO; }
+            (void)madvise(p, (size_t)bytes, MADV_RANDOM);
+        }
+        close(fd);
+        tables[k] = p;
+        rows[k] = bytes / rb;
+    }
+    return EVS_OK;
+}
+
+static int read_altkeys(Manager &m, int k, std::vector<unsigned> &native) {
+    // alt-key files: 4-byte BIG-endian words, alt_row*100 + alt_table (script/convert_altkeys_to_binary.py:27-57)
+    const std::string path = m.altkey_dir + "/ev-table-" + std::to_string(k + 1) + ".bin";
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) { set_error("cannot open alt-key file %s", path.c_str()); return EVS_EIO; }
+    fseek(fp, 0, SEEK_END);
+    const long long bytes = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    std::vector<unsigned char> buf(bytes > 0 ? bytes : 4);
+    const size_t got = bytes ? fread(buf.data(), 1, bytes, fp) : 0;
+    fclose(fp);
+    if ((long long)got != bytes || bytes % 4) { set_error("%s: bad size", path.c_str()); return EVS_EIO; }
+    native.assign(bytes / 4 + 1, 0u);
+    for (long long r = 0; r < bytes / 4; r++)
+        native[r] = ((unsigned)buf[4 * r] << 24) | ((unsigned)buf[4 * r + 1] << 16) | ((unsigned)buf[4 * r + 2] << 8) | buf[4 * r + 3];
+    m.alt_rows[k] = bytes / 4;
+    return EVS_OK;
+}
+
 static int ensure_ready() {
     Manager &m = g_mgr;
     if (m.ready) return EVS_OK;
@@ -94,7 +155,7 @@ static int ensure_ready() {
         if ((e = getenv("EVS_SECONDARY_PRECISION"))) m.secondary_prec = atoi(e);
         if ((e = getenv("EVS_TOTAL_SIZE"))) m.total_size = atoll(e);
         if ((e = getenv("EVS_SIZE_PROPORTION"))) m.proportion = e;
-        if ((e = getenv("EVS_BACKING"))) m.backing_kind = (strcmp(e, "pinned") == 0) ? 1 : 0;
+        if ((e = getenv("EVS_BACKING"))) m.backing_kind = strcmp(e, "pinned") == 0 ? 1 : strcmp(e, "hbm") == 0 ? 0 : strcmp(e, "host") == 0 ? 2 : -1;
         if ((e = getenv("EVS_EV_TABLE_ROOT"))) m.root = e;
         if ((e = getenv("EVS_ALTKEY_DIR"))) m.altkey_dir = e;
         if (m.root.empty()) {
@@ -105,6 +166,10 @@ static int ensure_ready() {
     if (m.n_layer < 1 || m.n_layer > 3) {
         set_error("ERROR: cache_manager.cpp N_CACHING_LAYER is NOT recognized!!");  // cache_manager.cpp:224-225
         return EVS_ESTATE;
+    }
+    if (m.backing_kind < 0 || m.backing_kind > 2) {
+        set_error("backing / EVS_BACKING must be host (2, default), hbm (0) or pinned (1)");
+        return EVS_EINVAL;
     }
     if (m.n_layer == 3 && m.altkey_dir.empty()) {
         set_error("N_CACHING_LAYER=3 needs the alt-key directory (evs_manager_set_altkey_dir or EVS_ALTKEY_DIR)");
@@ -118,7 +183,8 @@ static int ensure_ready() {
         set_error("ERROR: MAIN_PRECISION %d", m.main_prec);
         return EVS_EINVAL;
     }
-    int rc = load_tables(m, m.main_prec, m.tables, m.rows);
+    const bool host_engine = m.backing_kind == 2;
+    int rc = host_engine ? map_tables(m, m.main_prec, m.tables, m.rows) : load_tables(m, m.main_prec, m.tables, m.rows);
     if (rc) return rc;
     // Entries per tier exactly as the reference's constructors compute them; sizes are in fp32-row equivalents.
     //   one tier  (cache_manager.cpp:40-53): TOTAL_SIZE x 32/main
@@ -143,9 +209,40 @@ static int ensure_ready() {
     if (m.n_layer >= 2 && m.secondary_prec == 8 && m.main_prec > 8) cap2 = share2 * 16;
     m.cap1 = cap; m.cap2 = m.n_layer >= 2 ? cap2 : 0; m.cap3 = (m.n_layer == 3 && share3 * 36 >= 50) ? share3 * 36 : 0;
     // mixed_precs_caching constants: 0.3 / 0.95, n keys flushed, n_perfect -= n (evlfu_8.hpp:50-51, evlfu_8.cpp:256-270)
+    long long rows64[kEvTables];
+    if (host_engine) {
+        rc = evs_hostcache_create(&m.h1, 0, cap, kEvTables, kEvDim, m.main_prec, 0.3, 0.95, 0, 2);
+        if (rc) return rc;
+        for (int k = 0; k < kEvTables; k++) rows64[k] = m.rows[k];
+        rc = evs_hostcache_set_backing(m.h1, m.tables, (const int64_t *)rows64);
+        if (rc) return rc;
+        if (m.n_layer >= 2) {
+            rc = map_tables(m, m.secondary_prec, m.tables2, m.rows2);
+            if (rc) return rc;
+            rc = evs_hostcache_create(&m.h2, 0, cap2, kEvTables, kEvDim, m.secondary_prec, 0.3, 0.95, 0, 2);
+            if (rc) return rc;
+            for (int k = 0; k < kEvTables; k++) rows64[k] = m.rows2[k];
+            rc = evs_hostcache_set_backing(m.h2, m.tables2, (const int64_t *)rows64);
+            if (rc) return rc;
+        }
+        if (m.cap3) {   // capacity_c3 = share * 36 (one fp32 row = 36 alt keys, evlfu_8.cpp:80)
+            const uint32_t *alt[kEvTables];
+            for (int k = 0; k < kEvTables; k++) {
+                rc = read_altkeys(m, k, m.host_alt[k]);
+                if (rc) return rc;
+                alt[k] = m.host_alt[k].data();
+                rows64[k] = m.alt_rows[k];
+            }
+            rc = evs_hostaprx_create(&m.h3, m.cap3, kEvTables);
+            if (rc) return rc;
+            rc = evs_hostaprx_set_altkeys(m.h3, alt, (const int64_t *)rows64);
+            if (rc) return rc;
+        }
+        m.ready = true;
+        return EVS_OK;
+    }
     rc = evs_cache_create(&m.c1, 0, cap, kEvTables, kEvDim, m.main_prec, 0.3, 0.95, 0, 2);
     if (rc) return rc;
-    long long rows64[kEvTables];
     for (int k = 0; k < kEvTables; k++) rows64[k] = m.rows[k];
     rc = evs_cache_set_backing(m.c1, m.tables, (const int64_t *)rows64);
     if (rc) return rc;
@@ -161,23 +258,14 @@ static int ensure_ready() {
     if (m.n_layer == 3 && share3 * 36 >= 50) {  // capacity_c3 = share * 36 (one fp32 row = 36 alt keys, evlfu_8.cpp:80)
         // alt-key files: 4-byte BIG-endian words, alt_row*100 + alt_table (script/convert_altkeys_to_binary.py:27-57)
         for (int k = 0; k < kEvTables; k++) {
-            const std::string path = m.altkey_dir + "/ev-table-" + std::to_string(k + 1) + ".bin";
-            FILE *fp = fopen(path.c_str(), "rb");
-            if (!fp) { set_error("cannot open alt-key file %s", path.c_str()); return EVS_EIO; }
-            fseek(fp, 0, SEEK_END);
-            const long long bytes = ftell(fp);
-            fseek(fp, 0, SEEK_SET);
-            std::vector<unsigned char> buf(bytes > 0 ? bytes : 4);
-            const size_t got = bytes ? fread(buf.data(), 1, bytes, fp) : 0;
-            fclose(fp);
-            if ((long long)got != bytes || bytes % 4) { set_error("%s: bad size", path.c_str()); return EVS_EIO; }
-            std::vector<unsigned> native(bytes / 4 + 1);
-            for (long long r = 0; r < bytes / 4; r++)
-                native[r] = ((unsigned)buf[4 * r] << 24) | ((unsigned)buf[4 * r + 1] << 16) | ((unsigned)buf[4 * r + 2] << 8) | buf[4 * r + 3];
+            std::vector<unsigned> native;
+            rc = read_altkeys(m, k, native);
+            if (rc) return rc;
+            const long long bytes = m.alt_rows[k] * 4;
             void *dev = nullptr;
             EVS_HIP_CHECK(hipMalloc(&dev, bytes > 0 ? bytes : 4));
             EVS_HIP_CHECK(hipMemcpy(dev, native.data(), bytes, hipMemcpyHostToDevice));
-            m.alt_tables[k] = dev; m.alt_rows[k] = bytes / 4;
+            m.alt_tables[k] = dev;
         }
         rc = evs_aprx_create(&m.c3, share3 * 36, kEvTables);
         if (rc) return rc;
@@ -216,9 +304,10 @@ extern "C" long long evs_manager_tier_capacity(int tier) {  // entries of tier 1
 
 extern "C" long long evs_manager_aprx_hit() {  // evlfu_8bit->aprx_ev_hit (cache_manager.cpp:279)
     using namespace evs;
-    if (!g_mgr.ready || !g_mgr.c3) return 0;
+    if (!g_mgr.ready || !(g_mgr.c3 || g_mgr.h3)) return 0;
     int64_t s4[4] = {0};
-    (void)evs_aprx_stats(g_mgr.c3, s4, g_mgr.stream);
+    if (g_mgr.h3) (void)evs_hostaprx_stats(g_mgr.h3, s4);
+    else (void)evs_aprx_stats(g_mgr.c3, s4, g_mgr.stream);
     return s4[1];
 }
 
@@ -245,6 +334,16 @@ extern "C" float *ev_lookup(int *arr) {
         return nullptr;
     }
     Manager &m = g_mgr;
+    if (m.h1) {   // host engine: straight into the static buffer the caller reads
+        unsigned char tier[kEvTables];
+        const int hrc = m.h2 ? evs_hostcache_request_c1c2c3(m.h1, m.h2, m.h3, 1, arr, g_emb_weights_in_1d_floats, tier, 23 /* evlfu_8.hpp:70 */)
+                             : evs_hostcache_request(m.h1, 1, arr, g_emb_weights_in_1d_floats, tier, -1);
+        if (hrc != EVS_OK) {
+            printf("%s\n", evs_last_error());
+            return nullptr;
+        }
+        return g_emb_weights_in_1d_floats;
+    }
     memcpy(m.h_rows, arr, kEvTables * sizeof(int));
     const int rc = m.c2 ? evs_cache_request_c1c2c3(m.c1, m.c2, m.c3, 1, m.d_rows, m.d_out, m.d_hit, 23 /* evlfu_8.hpp:70 */, m.stream)
                         : evs_cache_request(m.c1, 1, m.d_rows, m.d_out, m.d_hit, -1, m.stream);
@@ -264,7 +363,7 @@ extern "C" long long evs_manager_perfect_hit() {
     using namespace evs;
     if (!g_mgr.ready) return 0;
     int64_t s8[8] = {0};
-    if (evs_cache_stats(g_mgr.c1, s8, g_mgr.stream) != EVS_OK) printf("%s\n", evs_last_error());
+    if ((g_mgr.h1 ? evs_hostcache_stats(g_mgr.h1, s8) : evs_cache_stats(g_mgr.c1, s8, g_mgr.stream)) != EVS_OK) printf("%s\n", evs_last_error());
     return s8[6];
 }
 
@@ -280,7 +379,8 @@ extern "C" void print_perfect_hit() {  // cache_manager.cpp:262-290: prints, the
     printf("[epoll worker] TOTAL_SIZE      = %lld\n", g_mgr.total_size);
     printf("[epoll worker] Perfect hit     = %lld\n", evs_manager_perfect_hit());
     fflush(stdout);
-    if (g_mgr.ready) (void)evs_cache_reset_counters(g_mgr.c1, g_mgr.stream);
+    if (g_mgr.ready && g_mgr.h1) (void)evs_hostcache_reset_counters(g_mgr.h1);
+    else if (g_mgr.ready) (void)evs_cache_reset_counters(g_mgr.c1, g_mgr.stream);
 }
 
 extern "C" int ev_lookup_based_on_list_keys(int *) {  // cache_manager.cpp:239-243: dead in the reference

@@ -106,6 +106,18 @@ def device_tables():
     return _tables
 
 
+def host_tables():
+    """Host-readable row arrays for the host cache engine (csrc/evs_hostcache.hip): the DUMMY / PINNED tensors as they
+    are, the FILEPY / MMAPFILEPY files mapped read-only (np.memmap: a miss reads one row through the page cache, what
+    file_read.py:27-33 / mmap_file_read.py:32-40 do per row).  None when the tables live in HBM only."""
+    if storage_type in (EmbStorage.DUMMY, EmbStorage.PINNED) and _tables is not None:
+        return [t.numpy() for t in _tables]
+    if storage_type in (EmbStorage.FILEPY, EmbStorage.MMAPFILEPY) and len(_files) > 1:
+        return [np.memmap(f.name, dtype=np.uint8, mode="r") if os.path.getsize(f.name) else np.zeros(0, np.uint8)
+                for f in _files[1:]]
+    return None
+
+
 def get_val_from_storage(tableId, rowId):
     """storage_manager.py:73-94; tableId is 1-based."""
     rb = _row_bytes()

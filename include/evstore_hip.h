@@ -350,6 +350,46 @@ EVS_API int evs_cache_reset_counters(evs_cache *c, void *stream);
 EVS_API int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * a6-a9, a12 at batch 1: the HOST engine of the exact policies (csrc/evs_hostcache.hip).
+ * The reference's EVStore loop is one request at a time (--test-mini-batch-size=1, dlrm_s_pytorch_C1.py:236-239) and
+ * its policies are sequential by definition; a chain of dependent pointer updates is a CPU cache hierarchy's job (one
+ * wavefront replays a request in 28 us + launch + synchronise, one host core in a few).  Same policies, same constants,
+ * same argument meaning as evs_cache_create / evs_cache_request / evs_cache_request_c1c2c3 / evs_aprx_* above, same
+ * golden traces bit for bit -- but every pointer is HOST memory, there is no stream, and nothing touches the GPU:
+ *   tables[k]   any host-readable mapping of ev-table-{k+1}.bin in the tier's codec (mmap, pinned, malloc);
+ *               a miss reads ONE row from it (evlfu_8.cpp:380-414 get_from_file: fseek + fread)
+ *   rows        (B, n_tables) int32, requests replayed strictly in order
+ *   out         (B, n_tables, dim) fp32, decoded from the tier's codec
+ *   hit / tier  (B, n_tables) bytes
+ * The tier's arena (capacity x dim*codec/8 bytes) and its hash / lists live in host memory.  Errors as everywhere:
+ * EVS_EINDEX for a row id outside its table, EVS_ESTATE when the policy state is inconsistent (what the Python
+ * reference would raise on).  The batched (snapshot) lookups stay on the GPU tier.
+ * evs_hostcache_stats out8 = [min_C1 | LFU least_freq, n_perfect, size, n_flush, n_evict, n_requests, n_perfect_hits,
+ * n_hits]; evs_hostcache_dump = evs_cache_dump's triples; evs_hostaprx_* = evs_aprx_* (alt_tables: host uint32 arrays,
+ * native byte order).
+ * ------------------------------------------------------------------------- */
+typedef struct evs_hostcache evs_hostcache;
+typedef struct evs_hostaprx evs_hostaprx;
+EVS_API int evs_hostcache_create(evs_hostcache **out, int policy, int64_t capacity, int n_tables, int dim, int codec,
+                                 double flush_rate, double perfect_item_cap, int flush_extra, int perfect_mode);
+EVS_API int evs_hostcache_destroy(evs_hostcache *c);
+EVS_API int evs_hostcache_set_backing(evs_hostcache *c, const void *const *tables, const int64_t *n_rows);
+EVS_API int evs_hostcache_request(evs_hostcache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
+                                  int approx_thres);
+EVS_API int evs_hostcache_request_c1c2c3(evs_hostcache *c1, evs_hostcache *c2, evs_hostaprx *c3 /* may be NULL */,
+                                         int64_t B, const int32_t *rows, float *out, uint8_t *tier,
+                                         int high_agghit_threshold);
+EVS_API int evs_hostcache_stats(evs_hostcache *c, int64_t *out8);
+EVS_API int evs_hostcache_reset_counters(evs_hostcache *c);
+EVS_API int64_t evs_hostcache_dump(evs_hostcache *c, int64_t *triples, int64_t max_triples);
+EVS_API int evs_hostaprx_create(evs_hostaprx **out, int64_t capacity, int n_tables);
+EVS_API int evs_hostaprx_destroy(evs_hostaprx *p);
+EVS_API int evs_hostaprx_set_altkeys(evs_hostaprx *p, const uint32_t *const *alt_tables, const int64_t *n_rows);
+EVS_API int evs_hostaprx_stats(evs_hostaprx *p, int64_t *out4 /* size, n_hit, n_pending, error */);
+EVS_API int evs_hostaprx_apply_ops(evs_hostaprx *p, int64_t n, const int32_t *ops, uint32_t *res);
+EVS_API int64_t evs_hostaprx_dump_queue(evs_hostaprx *p, int64_t *pairs, int64_t max_pairs);
+
+/* ---------------------------------------------------------------------------
  * a14: the reference's cache-manager C ABI (mixed_precs_caching/cache_manager.cpp), bound by
  * cache_algo/cpp_socket_client.py:69-83 through ctypes.  Same names, same signatures.
  *   ev_lookup: reads 26 int32 row ids (0-based; table = position), returns a pointer to the

@@ -9,6 +9,7 @@ import numpy as np
 
 root, prec, total = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 layers = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+backing = sys.argv[5] if len(sys.argv) > 5 else "pinned"   # host (the default engine) | hbm | pinned (GPU engine)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc  # noqa: E402
 
@@ -29,7 +30,8 @@ raws = [np.fromfile(os.path.join(root, {32: "ev-table", 16: "ev-table-16", 8: "e
 os.environ["EVS_EV_TABLE_ROOT"] = root            # zero-argument path: configuration from the environment
 os.environ["EVS_MAIN_PRECISION"] = str(prec)
 os.environ["EVS_TOTAL_SIZE"] = str(total)
-os.environ["EVS_BACKING"] = "pinned"
+if backing != "default":
+    os.environ["EVS_BACKING"] = backing
 os.environ["EVS_N_CACHING_LAYER"] = str(layers)
 os.environ["EVS_SECONDARY_PRECISION"] = "4"
 if layers == 3:

@@ -12,6 +12,7 @@ import numpy as np
 
 root, var = sys.argv[1], sys.argv[2]
 layers, main, sec, total = [int(v) for v in var.split("-")]
+backing = sys.argv[3] if len(sys.argv) > 3 else "hbm"
 _repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, _repo)
 sys.path.insert(0, os.path.join(_repo, "tests", "golden"))
@@ -34,7 +35,7 @@ for sub, j in (("ev-table", 0), ("ev-table-16", 1), ("ev-table-8", 2), ("ev-tabl
 dec = {32: [t[0] for t in tabs], 16: [orc.decode(t[1], 16, 36) for t in tabs],
        8: [orc.decode(t[2], 8, 36) for t in tabs], 4: [orc.decode(t[3], 4, 36) for t in tabs]}
 os.environ.update({"EVS_EV_TABLE_ROOT": root, "EVS_MAIN_PRECISION": str(main), "EVS_SECONDARY_PRECISION": str(sec),
-                   "EVS_TOTAL_SIZE": str(total), "EVS_N_CACHING_LAYER": str(layers), "EVS_BACKING": "hbm"})
+                   "EVS_TOTAL_SIZE": str(total), "EVS_N_CACHING_LAYER": str(layers), "EVS_BACKING": backing})
 c1, c2, _ = orc.ref_tier_capacities(layers, main, sec, total)
 o = orc.C1C2(c1, c2, dec[main], dec[sec]) if layers == 2 else orc.EvLFU(c1, dec[main], 36, "cpp")
 ref = g["v" + var.replace("-", "_") + "_served"]
