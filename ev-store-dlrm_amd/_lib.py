@@ -28,6 +28,11 @@ def build(force=False, verbose=False):
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("build did not produce " + LIB_PATH)
+    # the PyTorch-ROCm C++ extension over the library (csrc/evs_torch_ext.cpp -> lib/_evs_torch_ext.so), g++, host only
+    from . import _ext_build
+    if os.path.getmtime(LIB_PATH) > (os.path.getmtime(_ext_build.OUT) if os.path.exists(_ext_build.OUT) else 0):
+        force = True   # relink against the library just built
+    _ext_build.build(force=force, verbose=verbose)
 
 
 _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int

@@ -97,6 +97,22 @@ class _ModuleCache:
         hit, rows = self._run(group_row_ids, -1, False)
         return hit, rows.numpy().copy()
 
+    def request_from_index_rows(self, lS_i, use_gpu, approx_thres=-1):
+        """apply_emb_evstore's whole body for the host engine in ONE extension call: element 0 of each table's index row
+        (dlrm_s_pytorch_C1.py:236-239), the exact policy, the 26 x Tensor(1, 36) list.  -> (hit flags, ly, perfect) or None
+        when this request has to take the generic path."""
+        if not getattr(self, "_bound", False):
+            self._bind()
+        if self.engine != "host" or not torch.is_tensor(lS_i) or lS_i.is_cuda or lS_i.dtype not in (torch.int64, torch.int32) \
+                or lS_i.dim() < 1 or lS_i.shape[0] != self.n_tables:
+            return None
+        from .. import _ext
+        X = _ext.ext()
+        if X is None:
+            return None
+        return X.hostcache_request_list(self.cache._h.value, lS_i, self.n_tables, self.dim, int(approx_thres), bool(use_gpu),
+                                        self._device.index or 0)
+
     def request(self, group_row_ids, use_gpu, approx_thres=-1):
         arr_record_hit, rows = self._run(group_row_ids, approx_thres, use_gpu)
         # 26 x Tensor(1, 36) with requires_grad, like the reference's torch.FloatTensor([val]) per table -- made as
@@ -105,5 +121,9 @@ class _ModuleCache:
             block = rows.to(self._device, copy=True)   # ONE host-to-device copy instead of 26 (EvLFU_C1.py:157-161)
         else:
             block = rows.detach().clone()
+        from .. import _ext
+        X = _ext.ext()
+        if X is not None:
+            return arr_record_hit, X.slices(block.unsqueeze(1), True)   # 26 leaf tensors over one block
         block = block.unsqueeze(1).requires_grad_(True)
         return arr_record_hit, list(block.unbind(0))

@@ -1,0 +1,262 @@
+// PyTorch-ROCm C++ extension over the C ABI of libevstore_hip.so (include/evstore_hip.h): the call path of the plugin
+// surface -- apply_emb / interact_features / apply_emb_interact (dlrm_s_pytorch.py:407-461, 483-516, 588-601), the cache
+// tier's request / lookup_interact, and the batch-1 EVStore request (dlrm_s_pytorch_C1.py:227-275 -> cache modules) --
+// without the Python + ctypes marshalling in front of every launch (9-11 us per call: profiles/r02_sweep.md reads
+// 10.6-11.5 us for every batch up to 2 048 samples, where the kernel itself is 4-6 us).
+//
+// What lives here: argument checks, output allocation, the pointer tables, torch's current HIP stream, ONE call into the
+// library.  No arithmetic: every kernel is in libevstore_hip.so and is reached through the same extern "C" entry points a
+// C caller uses.  Built in-tree by ev-store-dlrm_amd/_ext_build.py -> lib/_evs_torch_ext.so (g++, host only).
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+
+#include <cstdint>
+#include <cstring>
+#include <optional>
+#include <vector>
+
+#include "../../include/evstore_hip.h"
+
+namespace py = pybind11;
+
+namespace {
+
+py::object g_error_class;   // evstore_dlrm_amd._lib.EvsError, handed over by the Python side at import
+
+[[noreturn]] void raise_evs(int code) {
+    const char *msg = evs_last_error();
+    if (g_error_class) {
+        py::object exc = g_error_class(code, std::string(msg ? msg : ""));
+        PyErr_SetObject(g_error_class.ptr(), exc.ptr());
+        throw py::error_already_set();
+    }
+    throw std::runtime_error(std::string("libevstore_hip: ") + (msg ? msg : "") + " (code " + std::to_string(code) + ")");
+}
+inline void check(int rc) { if (rc != 0) raise_evs(rc); }
+
+inline void *stream_of(const c10::Device &dev) {
+    return static_cast<void *>(c10::hip::getCurrentHIPStream(dev.index()).stream());
+}
+
+// The tables of one model (dlrm_ops.EVTables): raw byte tensors kept alive, their device-side addresses and row counts
+struct Tables {
+    std::vector<at::Tensor> keep;
+    std::vector<const void *> ptrs;
+    std::vector<int64_t> n_rows;
+    int T = 0, d = 0, codec = 32;
+    c10::Device device{c10::kCUDA, 0};
+
+    Tables(std::vector<at::Tensor> raws, std::vector<int64_t> dev_ptrs, int d_, int codec_, int device_index)
+        : keep(std::move(raws)), d(d_), codec(codec_), device(c10::kCUDA, static_cast<c10::DeviceIndex>(device_index)) {
+        TORCH_CHECK(keep.size() == dev_ptrs.size(), "Tables: one address per table");
+        T = static_cast<int>(keep.size());
+        for (int k = 0; k < T; k++) {
+            ptrs.push_back(reinterpret_cast<const void *>(dev_ptrs[k]));
+            n_rows.push_back(keep[k].size(0));
+        }
+    }
+};
+
+inline int64_t pairs(int F, bool itself) { return itself ? (int64_t)F * (F + 1) / 2 : (int64_t)F * (F - 1) / 2; }
+
+inline void check_x(const at::Tensor &x, int64_t B, int d) {
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 2 && x.size(0) == B && x.size(1) == d &&
+                (d == 1 || x.stride(1) == 1), "x must be a (B, d) fp32 device tensor with unit inner stride");
+}
+inline void check_idx(const at::Tensor &t, const char *name) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kLong && t.dim() == 2 && t.stride(1) == 1, name,
+                " must be a (T, B) int64 device tensor with unit inner stride (dlrm_wrap moves it to the GPU)");
+}
+
+// R = interact_features(x, apply_emb(lS_o, lS_i, emb_l)) -- evs_emb_interact_dot_stacked
+at::Tensor apply_emb_interact(const Tables &ev, const at::Tensor &x, const std::optional<at::Tensor> &lS_o, const at::Tensor &lS_i,
+                              bool itself, std::optional<at::Tensor> out, bool one_index_per_bag, bool check_indices) {
+    const int64_t B = x.size(0);
+    const int T = ev.T, d = ev.d, F = T + 1;
+    check_x(x, B, d);
+    check_idx(lS_i, "lS_i");
+    TORCH_CHECK(lS_i.size(0) == T, "lS_i has ", lS_i.size(0), " rows, the model has ", T, " tables");
+    const bool no_off = one_index_per_bag && lS_i.size(1) == B;
+    if (!no_off) {
+        TORCH_CHECK(lS_o.has_value(), "lS_o is required unless one_index_per_bag is declared");
+        check_idx(*lS_o, "lS_o");
+        TORCH_CHECK(lS_o->size(0) == T && lS_o->size(1) == B, "lS_o must be (T, B)");
+    }
+    const int64_t K = d + pairs(F, itself);
+    at::Tensor R = out.has_value() ? *out : at::empty({B, K}, x.options());
+    TORCH_CHECK(R.is_cuda() && R.scalar_type() == at::kFloat && R.dim() == 2 && R.size(0) == B && R.size(1) == K && R.is_contiguous(),
+                "out must be a contiguous (B, d + P) fp32 device tensor");
+    void *st = stream_of(ev.device);
+    check(evs_emb_interact_dot_stacked(B, T, d, ev.codec, ev.ptrs.data(), ev.n_rows.data(), x.data_ptr<float>(),
+                                       B > 1 ? x.stride(0) : d, lS_i.data_ptr<int64_t>(), lS_i.stride(0), lS_i.size(1),
+                                       no_off ? nullptr : lS_o->data_ptr<int64_t>(), no_off ? 0 : lS_o->stride(0), nullptr,
+                                       itself ? 1 : 0, R.data_ptr<float>(), st));
+    if (check_indices) check(evs_check_index_errors(st));
+    return R;
+}
+
+// apply_emb, stacked Criteo layout -> the (T, B, d) buffer whose T slices are the list the reference returns
+at::Tensor apply_emb(const Tables &ev, const std::optional<at::Tensor> &lS_o, const at::Tensor &lS_i, bool one_index_per_bag,
+                     bool check_indices) {
+    const int T = ev.T, d = ev.d;
+    check_idx(lS_i, "lS_i");
+    TORCH_CHECK(lS_i.size(0) == T, "lS_i has ", lS_i.size(0), " rows, the model has ", T, " tables");
+    const int64_t B = lS_o.has_value() ? lS_o->size(1) : lS_i.size(1);
+    const bool no_off = one_index_per_bag && lS_i.size(1) == B;
+    if (!no_off) {
+        TORCH_CHECK(lS_o.has_value(), "lS_o is required unless one_index_per_bag is declared");
+        check_idx(*lS_o, "lS_o");
+        TORCH_CHECK(lS_o->size(0) == T, "lS_o must be (T, B)");
+    }
+    at::Tensor buf = at::empty({T, B, d}, at::TensorOptions().dtype(at::kFloat).device(ev.device));
+    void *st = stream_of(ev.device);
+    check(evs_embedding_bag_sum_stacked(T, B, d, ev.codec, ev.ptrs.data(), ev.n_rows.data(), lS_i.data_ptr<int64_t>(), lS_i.stride(0),
+                                        lS_i.size(1), no_off ? nullptr : lS_o->data_ptr<int64_t>(), no_off ? 0 : lS_o->stride(0), nullptr,
+                                        buf.data_ptr<float>(), B * d, d, st));
+    if (check_indices) check(evs_check_index_errors(st));
+    return buf;
+}
+
+// interact_features(x, ly) for "dot": ly as any list of (B, d) fp32 views
+at::Tensor interact_dot(const at::Tensor &x, const std::vector<at::Tensor> &ly, bool itself) {
+    const int64_t B = x.size(0);
+    const int d = static_cast<int>(x.size(1));
+    const int F = static_cast<int>(ly.size()) + 1;
+    check_x(x, B, d);
+    TORCH_CHECK(F <= EVS_MAX_FEATURES, "interact_features: at most ", EVS_MAX_FEATURES, " features");
+    const float *ptrs[EVS_MAX_FEATURES];
+    int64_t strides[EVS_MAX_FEATURES];
+    ptrs[0] = x.data_ptr<float>(); strides[0] = B > 1 ? x.stride(0) : d;
+    for (int f = 1; f < F; f++) {
+        const at::Tensor &t = ly[f - 1];
+        TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.dim() == 2 && t.size(0) == B && t.size(1) == d &&
+                    (d == 1 || t.stride(1) == 1), "ly[", f - 1, "] must be a (B, d) fp32 device tensor with unit inner stride");
+        ptrs[f] = t.data_ptr<float>(); strides[f] = B > 1 ? t.stride(0) : d;
+    }
+    at::Tensor R = at::empty({B, d + pairs(F, itself)}, x.options());
+    check(evs_interact_dot(B, F, d, ptrs, strides, itself ? 1 : 0, R.data_ptr<float>(), stream_of(x.device())));
+    return R;
+}
+
+// ... and the common case: ly is still the list apply_emb built = the T slices of ONE (T, B, d) buffer (or strided views
+// of a (B, F, d) tile): addressed arithmetically, no per-tensor work
+at::Tensor interact_dot_pooled(const at::Tensor &x, int64_t base, int64_t tstride, int64_t bstride, int T, bool itself) {
+    const int64_t B = x.size(0);
+    const int d = static_cast<int>(x.size(1));
+    const int F = T + 1;
+    check_x(x, B, d);
+    TORCH_CHECK(F <= EVS_MAX_FEATURES, "interact_features: at most ", EVS_MAX_FEATURES, " features");
+    const float *ptrs[EVS_MAX_FEATURES];
+    int64_t strides[EVS_MAX_FEATURES];
+    ptrs[0] = x.data_ptr<float>(); strides[0] = B > 1 ? x.stride(0) : d;
+    for (int k = 0; k < T; k++) {
+        ptrs[k + 1] = reinterpret_cast<const float *>(base) + tstride * k;
+        strides[k + 1] = B > 1 ? bstride : d;
+    }
+    at::Tensor R = at::empty({B, d + pairs(F, itself)}, x.options());
+    check(evs_interact_dot(B, F, d, ptrs, strides, itself ? 1 : 0, R.data_ptr<float>(), stream_of(x.device())));
+    return R;
+}
+
+// ---- GPU cache tier --------------------------------------------------------------------------------------------------------
+inline void *dev_ptr(const at::Tensor &t) {   // device tensor, or a pinned host tensor the kernel reads / writes itself
+    if (t.is_cuda()) return t.data_ptr();
+    TORCH_CHECK(t.is_pinned() && t.is_contiguous(), "host tensors must be pinned (torch.Tensor.pin_memory) and contiguous");
+    void *p = evs_host_device_pointer(t.data_ptr());
+    TORCH_CHECK(p, "pinned tensor is not device-accessible");
+    return p;
+}
+
+void cache_request(int64_t handle, const at::Tensor &rows, const at::Tensor &out, const at::Tensor &hit, int approx_thres, int device_index) {
+    TORCH_CHECK(rows.scalar_type() == at::kInt && rows.is_contiguous() && rows.dim() == 2, "rows must be a contiguous (B, T) int32 tensor");
+    check(evs_cache_request(reinterpret_cast<evs_cache *>(handle), rows.size(0), static_cast<const int32_t *>(dev_ptr(rows)),
+                            static_cast<float *>(dev_ptr(out)), static_cast<uint8_t *>(dev_ptr(hit)), approx_thres,
+                            stream_of(c10::Device(c10::kCUDA, static_cast<c10::DeviceIndex>(device_index)))));
+}
+
+void cache_lookup_interact(int64_t handle, const at::Tensor &rows, const at::Tensor &x, bool itself, const at::Tensor &out,
+                           const at::Tensor &hit) {
+    const int64_t B = rows.size(0);
+    TORCH_CHECK(rows.is_cuda() && rows.scalar_type() == at::kInt && rows.is_contiguous() && rows.dim() == 2, "rows must be a contiguous (B, T) int32 device tensor");
+    check_x(x, B, static_cast<int>(x.size(1)));
+    TORCH_CHECK(out.is_cuda() && out.is_contiguous() && out.scalar_type() == at::kFloat && hit.is_cuda() && hit.is_contiguous(), "out / hit must be contiguous device tensors");
+    check(evs_cache_lookup_interact(reinterpret_cast<evs_cache *>(handle), B, rows.data_ptr<int32_t>(), x.data_ptr<float>(),
+                                    B > 1 ? x.stride(0) : x.size(1), itself ? 1 : 0, out.data_ptr<float>(), hit.data_ptr<uint8_t>(),
+                                    stream_of(x.device())));
+}
+
+// ---- batch-1 EVStore request on the host engine ------------------------------------------------------------------------------
+// apply_emb_evstore -> request_to_ev_lfu / _lru / _lfu (dlrm_s_pytorch_C1.py:236-253, EvLFU_C1.py:97-166): element 0 of each
+// table's index row -> the exact policy (evs_hostcache_request) -> (hit flags, 26 x Tensor(1, d) with requires_grad) -- the
+// rows land in ONE fresh (T, 1, d) tensor, its T views are the list (use_gpu: one host-to-device copy, EvLFU_C1.py:157-161
+// makes 26).
+// The slices block[0], block[1], ... as independent tensors aliasing the block's storage -- optionally LEAF tensors with
+// requires_grad, what the reference builds one torch.FloatTensor([val]) at a time (EvLFU_C1.py:157-159).  unbind() goes
+// through the dispatcher and the autograd view machinery once per slice (0.7 us each, 18 us for 26 -- more than the policy
+// or the launch they follow); these are plain TensorImpls over the same storage (0.3 us each, Python wrapper included).
+std::vector<at::Tensor> slices(const at::Tensor &block, bool requires_grad) {
+    TORCH_CHECK(block.dim() >= 2, "slices: at least 2 dimensions");
+    const int64_t n = block.size(0), step = block.stride(0), off0 = block.storage_offset();
+    const c10::IntArrayRef sizes = block.sizes().slice(1), strides = block.strides().slice(1);
+    std::vector<at::Tensor> rows;
+    rows.reserve(n);
+    const c10::Storage &st = block.storage();
+    for (int64_t k = 0; k < n; k++) {
+        at::Tensor t = at::detail::make_tensor<c10::TensorImpl>(c10::Storage(st), block.key_set(), block.dtype());
+        c10::TensorImpl *impl = t.unsafeGetTensorImpl();
+        impl->set_storage_offset(off0 + k * step);
+        impl->set_sizes_and_strides(sizes, strides);
+        if (requires_grad) t.set_requires_grad(true);
+        rows.push_back(std::move(t));
+    }
+    return rows;
+}
+
+py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i, int T, int d, int approx_thres, bool use_gpu, int device_index) {
+    TORCH_CHECK(!lS_i.is_cuda() && lS_i.dim() >= 1 && lS_i.size(0) == T, "lS_i must be a host tensor with one row per table");
+    int32_t ids[64];
+    TORCH_CHECK(T <= 64, "at most 64 tables");
+    if (lS_i.scalar_type() == at::kLong) {
+        const int64_t *p = lS_i.data_ptr<int64_t>();
+        const int64_t s0 = lS_i.stride(0);
+        for (int k = 0; k < T; k++) ids[k] = static_cast<int32_t>(p[k * s0]);   // element 0 of each row
+    } else {
+        TORCH_CHECK(lS_i.scalar_type() == at::kInt, "lS_i must be int64 or int32");
+        const int32_t *p = lS_i.data_ptr<int32_t>();
+        const int64_t s0 = lS_i.stride(0);
+        for (int k = 0; k < T; k++) ids[k] = p[k * s0];
+    }
+    at::Tensor block = at::empty({T, 1, d}, at::TensorOptions().dtype(at::kFloat));
+    uint8_t hit[64];
+    check(evs_hostcache_request(reinterpret_cast<evs_hostcache *>(handle), 1, ids, block.data_ptr<float>(), hit, approx_thres));
+    if (use_gpu) block = block.to(c10::Device(c10::kCUDA, static_cast<c10::DeviceIndex>(device_index)));
+    py::list flags;
+    bool all = true;
+    for (int k = 0; k < T; k++) { flags.append(py::bool_(hit[k] != 0)); all = all && hit[k]; }
+    return py::make_tuple(flags, slices(block, true), all);
+}
+
+void set_error_class(py::object cls) { g_error_class = std::move(cls); }
+
+}  // namespace
+
+PYBIND11_MODULE(_evs_torch_ext, m) {
+    m.doc() = "PyTorch-ROCm C++ extension over libevstore_hip.so (call path of the DLRM plugin surface)";
+    py::class_<Tables>(m, "Tables")
+        .def(py::init<std::vector<at::Tensor>, std::vector<int64_t>, int, int, int>())
+        .def_readonly("T", &Tables::T)
+        .def_readonly("d", &Tables::d)
+        .def_readonly("codec", &Tables::codec);
+    m.def("set_error_class", &set_error_class);
+    m.def("abi_version", []() { return evs_abi_version(); });
+    m.def("apply_emb_interact", &apply_emb_interact, py::arg("ev"), py::arg("x"), py::arg("lS_o"), py::arg("lS_i"), py::arg("itself") = false,
+          py::arg("out") = py::none(), py::arg("one_index_per_bag") = false, py::arg("check_indices") = false);
+    m.def("apply_emb", &apply_emb, py::arg("ev"), py::arg("lS_o"), py::arg("lS_i"), py::arg("one_index_per_bag") = false,
+          py::arg("check_indices") = false);
+    m.def("interact_dot", &interact_dot);
+    m.def("interact_dot_pooled", &interact_dot_pooled);
+    m.def("cache_request", &cache_request);
+    m.def("cache_lookup_interact", &cache_lookup_interact);
+    m.def("hostcache_request_list", &hostcache_request_list);
+    m.def("slices", &slices);
+}

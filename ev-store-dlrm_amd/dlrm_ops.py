@@ -16,7 +16,7 @@ import sys
 
 import torch
 
-from . import _lib
+from . import _ext, _lib
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -139,6 +139,19 @@ class EVTables:
         T = len(self.raw)
         self._tables_c = (C.c_void_p * T)(*ptrs)
         self._n_rows_c = (C.c_int64 * T)(*self.n_rows)
+        self._ptrs = ptrs
+        self._xt = None
+
+    def ext_tables(self):
+        """this model's tables as the C++ extension holds them (None without the extension)"""
+        if self._xt is None:
+            X = _ext.ext()
+            if X is None:
+                return None
+            idx = self.device.index
+            self._xt = X.Tables(self.raw, [int(p) for p in self._ptrs], self.d, self.codec,
+                                torch.cuda.current_device() if idx is None else idx)
+        return self._xt
 
     # ---- constructors -------------------------------------------------------------
     @classmethod
@@ -230,9 +243,18 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy
     if lazy and out is None and not check_indices and fused_supported(T + 1, d) and \
             (ev.codec == 32 or v_W_l is None or all(w is None for w in v_W_l)):
         return LazyPooled(lS_o, lS_i, ev, v_W_l)
-    L = _lib.lib()
     stacked_o = torch.is_tensor(lS_o)
     stacked_i = torch.is_tensor(lS_i)
+    if out is None and stacked_i and stacked_o and (v_W_l is None or all(w is None for w in v_W_l)):
+        xt = ev.ext_tables()
+        if xt is not None:   # the C++ extension: checks, the (T,B,d) buffer and the launch without Python in between
+            X = _ext.ext()
+            buf = X.apply_emb(xt, lS_o, lS_i, one_index_per_bag, check_indices)
+            ly = _PooledList(X.slices(buf, False))
+            B = int(buf.shape[1])
+            ly._evs_meta = (buf.data_ptr(), B * d, d, B, d, T)
+            return ly
+    L = _lib.lib()
     B = int(lS_o.shape[1]) if stacked_o else int(lS_o[0].shape[0])
     if out is None:
         buf = torch.empty((T, B, d), dtype=torch.float32, device=dev)
@@ -288,21 +310,30 @@ def interact_features(x, ly, arch_interaction_op="dot", arch_interaction_itself=
     B, d = x.shape
     dev = x.device
     meta = getattr(ly, "_evs_meta", None)
-    fast = None
+    pooled = None
     if meta is not None and len(ly) == meta[5] and meta[3] == B and meta[4] == d and len(ly) > 0:
         base, tstride, bstride, _, _, T = meta
         # still the list apply_emb built?  (first and last element where they were put)
         if ly[0].data_ptr() == base and ly[-1].data_ptr() == base + 4 * tstride * (T - 1):
-            assert x.is_cuda and x.dtype == torch.float32 and (d == 1 or x.stride(1) == 1)
-            key = (x.data_ptr(), int(x.stride(0)) if B > 1 else d, base, tstride, bstride, T)
-            fast = _feat_cache.get(key)
-            if fast is None:
-                F = T + 1
-                fast = ((C.c_void_p * F)(key[0], *[base + 4 * tstride * k for k in range(T)]),
-                        (C.c_int64 * F)(key[1], *([bstride if B > 1 else d] * T)), F)
-                if len(_feat_cache) > 256:
-                    _feat_cache.clear()
-                _feat_cache[key] = fast
+            pooled = meta
+    X = _ext.ext() if arch_interaction_op == "dot" else None
+    if X is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+        if pooled is not None:
+            return X.interact_dot_pooled(x, pooled[0], pooled[1], pooled[2], pooled[5], bool(arch_interaction_itself))
+        return X.interact_dot(x, list(ly), bool(arch_interaction_itself))
+    fast = None
+    if pooled is not None:
+        base, tstride, bstride, _, _, T = pooled
+        assert x.is_cuda and x.dtype == torch.float32 and (d == 1 or x.stride(1) == 1)
+        key = (x.data_ptr(), int(x.stride(0)) if B > 1 else d, base, tstride, bstride, T)
+        fast = _feat_cache.get(key)
+        if fast is None:
+            F = T + 1
+            fast = ((C.c_void_p * F)(key[0], *[base + 4 * tstride * k for k in range(T)]),
+                    (C.c_int64 * F)(key[1], *([bstride if B > 1 else d] * T)), F)
+            if len(_feat_cache) > 256:
+                _feat_cache.clear()
+            _feat_cache[key] = fast
     if fast is not None:
         ptrs, strides, F = fast
     else:
@@ -351,6 +382,11 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
     assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, d) and x.stride(1) == 1
     if not fused_supported(F, d):
         return interact_features(x, apply_emb(lS_o, lS_i, ev, v_W_l), "dot", arch_interaction_itself)
+    if torch.is_tensor(lS_i) and (torch.is_tensor(lS_o) or lS_o is None) and (v_W_l is None or all(w is None for w in v_W_l)):
+        xt = ev.ext_tables()
+        if xt is not None:   # the C++ extension: checks, output and the launch without Python in between
+            return _ext.ext().apply_emb_interact(xt, x, lS_o, lS_i, bool(arch_interaction_itself), out,
+                                                 bool(one_index_per_bag), bool(check_indices))
     P = F * (F + 1) // 2 if arch_interaction_itself else F * (F - 1) // 2
     R = out if out is not None else torch.empty((B, d + P), dtype=torch.float32, device=dev)
     assert R.shape == (B, d + P) and R.is_contiguous() and R.dtype == torch.float32

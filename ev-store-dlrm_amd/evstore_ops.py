@@ -12,6 +12,7 @@ from .emb_storage import storage_manager
 cache_algo = "evlfu"
 perfect_hit = 0
 evstore_gpu_id = 0   # dlrm_s_pytorch_C1_C2.py:1267 (--evstore-gpu-id)
+_FAST = {"evlfu": EvLFU_C1, "lru": LRU, "lfu": LFU}
 
 
 def apply_emb_evstore(lS_o, lS_i, emb_l, v_W_l, use_gpu=False, use_emb_cache=False, approx_emb_threshold=-1):
@@ -20,6 +21,14 @@ def apply_emb_evstore(lS_o, lS_i, emb_l, v_W_l, use_gpu=False, use_emb_cache=Fal
     global perfect_hit
     if use_gpu:
         lS_i = lS_i.cpu().data
+    if use_emb_cache and cache_algo in _FAST:
+        # host engine + C++ extension: ids, policy and the 26 tensors in one call (same results as the generic path below)
+        mod = _FAST[cache_algo]
+        r = mod._m.request_from_index_rows(lS_i, use_gpu, approx_emb_threshold if cache_algo == "evlfu" else -1)
+        if r is not None:
+            if r[2]:
+                perfect_hit += 1
+            return r[1]
     group_rowIds = [int(sparse_index[0]) for sparse_index in lS_i.numpy()]
     if use_emb_cache:
         if cache_algo == "evlfu":

@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _ext, _lib
 
 POLICY = {"evlfu": 0, "lru": 1, "lfu": 2}
 # (flush_rate, perfect_item_cap, flush_extra, perfect_mode)
@@ -86,6 +86,9 @@ class GpuCache:
         except Exception:
             pass
 
+    def _dev_index(self):
+        return torch.cuda.current_device() if self.device.index is None else self.device.index
+
     def set_backing(self, tables):
         """tables: EVTables, or a list of uint8/float tensors (HBM or pinned host memory) in the cache's codec."""
         raws = tables.raw if hasattr(tables, "raw") else list(tables)
@@ -125,6 +128,10 @@ class GpuCache:
             out = torch.empty((B, self.n_tables, self.dim), dtype=torch.float32, device=self.device)
         if hit is None:
             hit = torch.empty((B, self.n_tables), dtype=torch.uint8, device=self.device)
+        X = _ext.ext()
+        if X is not None:
+            X.cache_request(self._h.value, rows, out, hit, int(approx_thres), self._dev_index())
+            return hit, out
         _lib.check(_lib.lib().evs_cache_request(self._h, B, _dev_ptr(rows), _dev_ptr(out), _dev_ptr(hit),
                                                 int(approx_thres), torch.cuda.current_stream(self.device).cuda_stream))
         return hit, out
@@ -153,6 +160,10 @@ class GpuCache:
         if hit is None:
             hit = torch.empty((B, self.n_tables), dtype=torch.uint8, device=self.device)
         assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, self.dim) and x.stride(1) == 1
+        X = _ext.ext()
+        if X is not None:
+            X.cache_lookup_interact(self._h.value, rows, x, bool(itself), out, hit)
+            return hit, out
         _lib.check(_lib.lib().evs_cache_lookup_interact(
             self._h, B, rows.data_ptr(), x.data_ptr(), int(x.stride(0)) if B > 1 else self.dim, int(bool(itself)),
             out.data_ptr(), hit.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))

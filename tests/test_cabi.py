@@ -80,3 +80,40 @@ def test_more_argument_checks_without_a_gpu():
     assert L.evs_emb_interact_dot(4, 40, 36, 32, None, 0, None, None) == EINVAL   # more than 32 features
     assert L.evs_emb_interact_dot(4, 27, 20, 32, None, 0, None, None) == EINVAL   # dimension the fused kernel is not built for
     assert not L.evs_host_device_pointer(None)
+
+
+def test_torch_extension_builds_loads_and_wraps_the_same_library():
+    """The PyTorch-ROCm C++ extension (csrc/evs_torch_ext.cpp) is built in-tree, loads without a GPU, reports the
+    library's ABI version, and raises the package's EvsError with the library's message on a failed call."""
+    import numpy as np
+    import torch
+    import evstore_dlrm_amd as E
+    from evstore_dlrm_amd import _ext, _ext_build, host_cache
+    if not os.path.exists(_ext_build.OUT):
+        E.build()
+    X = _ext.ext()
+    assert X is not None and X.abi_version() == 1
+    for name in ("Tables", "apply_emb", "apply_emb_interact", "interact_dot", "interact_dot_pooled", "cache_request",
+                 "cache_lookup_interact", "hostcache_request_list", "slices"):
+        assert hasattr(X, name), name
+    # slices: independent leaf tensors over one block
+    blk = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(2, 3, 4)
+    a = X.slices(blk, True)
+    assert len(a) == 2 and a[1].shape == (3, 4) and a[1].is_leaf and a[1].requires_grad and torch.equal(a[1].detach(), blk[1])
+    a[0].detach().zero_()
+    assert float(blk[0].sum()) == 0.0    # aliases, not copies
+    # one host-engine request through the extension = the ctypes wrapper's answer
+    tabs = [np.random.RandomState(k).rand(50, 36).astype(np.float32) for k in range(26)]
+    c1 = host_cache.HostCache("evlfu", 100).set_backing(tabs)
+    c2 = host_cache.HostCache("evlfu", 100).set_backing(tabs)
+    ids = torch.arange(26, dtype=torch.int64).reshape(26, 1) % 50
+    for _ in range(2):
+        flags, ly, perfect = X.hostcache_request_list(c1._h.value, ids, 26, 36, -1, False, 0)
+        hit, out = c2.request(ids.numpy().reshape(1, 26).astype(np.int32))
+        assert flags == [bool(v) for v in hit[0]] and perfect == bool(hit.all())
+        assert np.array_equal(torch.cat(ly).detach().numpy(), out[0])
+    bad = ids.clone()
+    bad[3, 0] = 50
+    with pytest.raises(E.EvsError) as e:
+        X.hostcache_request_list(c1._h.value, bad, 26, 36, -1, False, 0)
+    assert e.value.code == E._lib.EVS_EINDEX and "out of range" in str(e.value)

@@ -1030,3 +1030,59 @@ def test_apply_emb_one_index_per_bag_declared(E, orc):
         E.apply_emb(o, i, ev, wd, out=tile, lazy=False, one_index_per_bag=True)
         for k in range(T):
             assert np.array_equal(tile[:, k + 1, :].cpu().numpy().view(np.uint32), want[k].view(np.uint32))
+
+
+@pytest.mark.parametrize("bits", [32, 8])
+def test_extension_and_ctypes_call_paths_agree(E, orc, bits):
+    """The PyTorch-ROCm C++ extension (csrc/evs_torch_ext.cpp, the default call path) and the ctypes binding reach the
+    same entry points of the same library: apply_emb, interact_features, apply_emb_interact (declared one-index form,
+    lS_o-checked form, out=, check_indices) and the cache tier's lookup_interact give identical bits either way, and both
+    equal the oracle."""
+    from evstore_dlrm_amd import _ext
+    X = _ext.ext()
+    assert X is not None, "lib/_evs_torch_ext.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    rs = np.random.RandomState(11 + bits)
+    T, d, B = 26, 36, 2500
+    n_rows = [int(v) for v in rs.choice([3, 40, 999, 20000], size=T)]
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in n_rows]
+    ev32 = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    ev = ev32 if bits == 32 else ev32.encode(bits)
+    dec = tabs if bits == 32 else [orc.decode(orc.encode_table(t, bits), bits, d) for t in tabs]
+    idx = np.stack([rs.randint(0, n, size=B) for n in n_rows]).astype(np.int64)
+    off = np.tile(np.arange(B, dtype=np.int64), (T, 1))
+    x = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    xd, od, idd = _dev(x), _dev(off), _dev(idx)
+
+    def run():
+        ly = E.apply_emb(od, idd, ev, None, check_indices=True)
+        R2 = E.interact_features(xd, ly)
+        R1 = E.apply_emb_interact(xd, od, idd, ev, check_indices=True)
+        out = torch.empty_like(R1)
+        R1d = E.apply_emb_interact(xd, None, idd, ev, one_index_per_bag=True, out=out)
+        assert R1d.data_ptr() == out.data_ptr()
+        Ri = E.apply_emb_interact(xd, od, idd, ev, arch_interaction_itself=True)
+        torch.cuda.synchronize()
+        return torch.stack(list(ly)).cpu().numpy(), R2.cpu().numpy(), R1.cpu().numpy(), R1d.cpu().numpy(), Ri.cpu().numpy()
+
+    got_ext = run()
+    saved = (_ext._mod, _ext._tried)
+    _ext._mod, _ext._tried = None, True      # ctypes path
+    ev._xt = None
+    try:
+        assert _ext.ext() is None
+        got_ct = run()
+    finally:
+        _ext._mod, _ext._tried = saved
+    for a, b in zip(got_ext, got_ct):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    want = np.stack([dec[k][idx[k]] for k in range(T)])
+    assert np.array_equal(got_ext[0].view(np.uint32), want.view(np.uint32))
+    np.testing.assert_allclose(got_ext[2], orc.interact_features(x, list(want)), rtol=RTOL, atol=2e-6)
+    assert np.array_equal(got_ext[2].view(np.uint32), got_ext[3].view(np.uint32))
+    np.testing.assert_allclose(got_ext[4], orc.interact_features(x, list(want), itself=True), rtol=RTOL, atol=2e-6)
+    # a bad index through the extension raises the package's error class with the library's code
+    bad = idd.clone()
+    bad[5, 7] = n_rows[5]
+    with pytest.raises(E.EvsError) as e:
+        E.apply_emb_interact(xd, od, bad, ev, check_indices=True)
+    assert e.value.code == E._lib.EVS_EINDEX
