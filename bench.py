@@ -237,7 +237,7 @@ def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
                     "difference of consecutive loop-top wall-clock stamps, result synchronised per request; PCIe Gen5 x16"}
 
 
-def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=None):
+def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=None, engine="host", host_tabs=None):
     """BASELINE configs[2] with the reference's own semantics: --test-mini-batch-size=1 through apply_emb_evstore and the
     EvLFU_C1 cache module (dlrm_s_pytorch_C1.py:227-275, cache_algo/EvLFU_C1.py:97-166), tables (the miss tier) in HBM.
     Warm-up = one full replay of the workload (dlrm_s_pytorch_C1.py:2224-2242), then the timed replay; latency =
@@ -247,8 +247,11 @@ def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=No
     from evstore_dlrm_amd.cache_algo import EvLFU_C1
     from evstore_dlrm_amd.emb_storage import storage_manager as sm
     T = len(ln_emb)
-    sm.use_device_tables(ev, 32)
-    EvLFU_C1.init(cap)
+    if engine == "host":   # tables where the host engine reads them (the reference keeps them in files / host RAM too)
+        sm.use_device_tables(host_tabs if host_tabs is not None else [t.cpu() for t in ev.raw], 32, storage=sm.EmbStorage.DUMMY)
+    else:
+        sm.use_device_tables(ev, 32)
+    EvLFU_C1.init(cap, engine=engine)
     evstore_ops.cache_algo = "evlfu"
     b1s = make_batches(ln_emb, 256, (n_req + 255) // 256, seed=13, device=dev, dist="zipf", alpha=1.05)
     rows = torch.cat([b[1].t().contiguous() for b in b1s])[:n_req].cpu()       # (n_req, 26) int64
@@ -266,11 +269,12 @@ def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=No
     hits = EvLFU_C1.stats()["n_hits"] - h0
     res = {"p50_us": IL.percentile_ms(stamps, 50) * 1e3, "p95_us": IL.percentile_ms(stamps, 95) * 1e3,
            "requests": n_req, "capacity_entries": cap, "hit_rate": hits / (T * n_req), "perfect_hits": evstore_ops.perfect_hit,
-           "value": T * n_req / (stamps[-1] - stamps[0]), "unit": "lookups/s",
+           "value": T * n_req / (stamps[-1] - stamps[0]), "unit": "lookups/s", "engine": EvLFU_C1._m.engine,
            "note": "apply_emb_evstore(use_gpu=True, use_emb_cache=True) per request behind dlrm_wrap: 26 ids to the device "
-                   "and back (as the reference does, dlrm_s_pytorch_C1.py:233-239), one exact-policy launch, 26 x Tensor(1,36) "
-                   "on the device; Zipf(1.05); warm-up = one full replay"}
-    if cdf_dir:
+                   "and back (as the reference does, dlrm_s_pytorch_C1.py:233-239), the exact policy (host engine: in "
+                   "libevstore_hip.so on one host core, rows to the device in one copy; gpu engine: one exact-policy launch), "
+                   "26 x Tensor(1,36) on the device; Zipf(1.05); warm-up = one full replay"}
+    if cdf_dir and engine == "host":
         try:
             res["cdf_csv"] = os.path.relpath(IL.calculate_and_write_cdf(cdf_dir, "evlfu", stamps), ROOT)
         except Exception as e:
@@ -411,10 +415,39 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
           "requests": n1 - n_skip, "capacity_entries": cap1, "hit_rate": hits1 / (T * (n1 - n_skip)),
           "note": "evs_cache_request B=1 (exact reference semantics), Zipf(1.05): 26 ids in, 26x36 floats + hit flags back on the "
                   "host (pinned buffers read / written by the kernel), sync; first %d requests warm the cache" % n_skip}
+    # the same requests through the HOST engine of the exact policy (evs_hostcache_request, the cache manager's default
+    # engine behind ev_lookup): called through ctypes with pre-built pointers = what a C caller pays, plus ~1.5 us of ctypes
+    tabs = [ev.fp32_view(k).cpu().numpy() for k in range(T)]
+    b1_gpu = b1
+    try:
+        import ctypes as C
+        from evstore_dlrm_amd import host_cache as HC
+        hc = HC.HostCache("evlfu", cap1, T, d, 32, "python").set_backing(tabs)
+        L = E._lib.lib()
+        hr32 = np.ascontiguousarray(host_rows.numpy(), np.int32)
+        o_np, h_np = np.empty((1, T, d), np.float32), np.empty((1, T), np.uint8)
+        op, hp, base, hh = o_np.ctypes.data, h_np.ctypes.data, hr32.ctypes.data, hc._h
+        lat_h, hits_h = [], 0
+        for i in range(n1):
+            t1 = time.perf_counter()
+            rc = L.evs_hostcache_request(hh, 1, base + 4 * T * i, op, hp, -1)
+            lat_h.append((time.perf_counter() - t1) * 1e6)
+            if rc:
+                raise RuntimeError(L.evs_last_error())
+            if i >= n_skip:
+                hits_h += int(h_np.sum())
+        b1 = {"p50_us": float(np.percentile(lat_h[n_skip:], 50)), "p95_us": float(np.percentile(lat_h[n_skip:], 95)),
+              "requests": n1 - n_skip, "capacity_entries": cap1, "hit_rate": hits_h / (T * (n1 - n_skip)), "engine": "host",
+              "same_hits_as_gpu_engine": hits_h == hits1, "gpu_engine": b1_gpu,
+              "note": "evs_hostcache_request B=1 (exact reference semantics, the engine behind ev_lookup by default), Zipf(1.05): 26 ids "
+                      "in, 26x36 floats + hit flags out, host memory, one host core; gpu_engine = the same stream through "
+                      "evs_cache_request (one launch + synchronise per request); first %d requests warm the cache" % n_skip}
+        del hc
+    except Exception as e:
+        b1 = dict(b1_gpu, host_engine_error=repr(e))
     cpu = None
     try:
         from oracle import oracle as orc
-        tabs = [ev.fp32_view(k).cpu().numpy() for k in range(T)]
         oc = orc.EvLFU(cap1, tabs, d, "python")
         hr = host_rows.numpy()
         for i in range(n_skip):
@@ -737,7 +770,12 @@ def main():
         result["cache_tier"] = cache_tier_section(ev, KAGGLE_LN, d, B, dev, host_tier_line=not args.no_extras)
         if d == 36:
             try:
-                result["cache_tier"]["batch1_evstore_plugin"] = batch1_plugin_section(ev, KAGGLE_LN, d, dev, cdf_dir=args.cdf_dir)
+                pl = batch1_plugin_section(ev, KAGGLE_LN, d, dev, cdf_dir=args.cdf_dir, engine="host")
+                try:
+                    pl["gpu_engine"] = batch1_plugin_section(ev, KAGGLE_LN, d, dev, cdf_dir=None, engine="gpu")
+                except Exception as e:
+                    pl["gpu_engine"] = {"error": repr(e)}
+                result["cache_tier"]["batch1_evstore_plugin"] = pl
             except Exception as e:
                 result["cache_tier"]["batch1_evstore_plugin"] = {"error": repr(e)}
             if not args.no_extras:

@@ -27,8 +27,17 @@ struct GatherArgs {
     const float *row_w[EVS_MAX_TABLES_PER_LAUNCH];
     int64_t n_rows[EVS_MAX_TABLES_PER_LAUNCH];
     int64_t nnz[EVS_MAX_TABLES_PER_LAUNCH];
+    // row-split tables (sharded.py "rowsplit"): table[t] holds the global rows [row_lo, row_lo + n_rows) of a table of
+    // row_total rows; an index outside that range but inside the table belongs to another rank and contributes nothing,
+    // silently (whole tables: row_lo = 0, row_total = n_rows -- every valid index is in range)
+    int64_t row_lo[EVS_MAX_TABLES_PER_LAUNCH];
+    int64_t row_total[EVS_MAX_TABLES_PER_LAUNCH];
     float *out;
     int64_t out_tstride, out_bstride;
+    // peer-major output (the all-to-all send buffer): bag b goes to out + (b / bags_per_peer) * out_pstride + t * out_tstride
+    // + (b % bags_per_peer) * out_bstride; bags_per_peer >= B: one "peer", the plain layout
+    int64_t out_pstride;
+    unsigned bags_per_peer;
     int64_t B;
     int64_t chunks_per_table;  // ceil(B / bags-per-wave-item)
     int T;
@@ -105,6 +114,7 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs
         const float *__restrict__ rw = args.row_w[t];
         const int64_t n_rows = args.n_rows[t];
         const int64_t nnz = args.nnz[t];
+        const int64_t row_lo = args.row_lo[t], row_total = args.row_total[t];
 
         int64_t s[UNROLL], len[UNROLL];
         // offsets given: idx[b] is requested together with offsets[b] / offsets[b + 1] on the bet that bag b is {idx[b]} (the
@@ -163,7 +173,12 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs
                     if constexpr (BAG1) v = idx[s[u] + j];
                     else if (j == 0 && s[u] == bpos[u]) v = spec[u];
                     else v = idx[s[u] + j];
-                    if (v >= 0 && v < n_rows) r[u] = v; else bad = true;
+                    if (v >= 0 && v < row_total) {
+                        v -= row_lo;
+                        if (v >= 0 && v < n_rows) r[u] = v;   // (else: another rank's rows)
+                    } else {
+                        bad = true;
+                    }
                 }
             }
             float4 v[UNROLL];
@@ -201,10 +216,18 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs
         }
 
         float *__restrict__ out = args.out + (int64_t)t * args.out_tstride + (int64_t)piece * 4;
+        const bool peers = (int64_t)args.bags_per_peer < B;   // kernel-uniform
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const int64_t b = b0 + (int64_t)u * RPW + slot;
-            if (lane_on && b < B) *reinterpret_cast<float4 *>(out + b * args.out_bstride) = acc[u];
+            if (lane_on && b < B) {
+                int64_t o = b * args.out_bstride;
+                if (peers) {
+                    const unsigned q = (unsigned)b / args.bags_per_peer;
+                    o = (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+                }
+                *reinterpret_cast<float4 *>(out + o) = acc[u];
+            }
         }
     }
     if (bad) atomicOr(args.err, 1);
@@ -229,12 +252,19 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_scalar_kernel(const Gat
         if (!(st >= 0 && en >= st && en <= nnz)) { bad = true; en = st = 0; }
         const unsigned char *W = reinterpret_cast<const unsigned char *>(args.table[t]);
         const float *rw = args.row_w[t];
-        float *out = args.out + (int64_t)t * args.out_tstride + b * args.out_bstride;
+        int64_t ob = b * args.out_bstride;
+        if ((int64_t)args.bags_per_peer < args.B) {
+            const unsigned q = (unsigned)b / args.bags_per_peer;
+            ob = (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+        }
+        float *out = args.out + (int64_t)t * args.out_tstride + ob;
         for (int c = lane; c < d; c += kWave) {
             float acc = 0.f;
             for (int64_t j = st; j < en; j++) {
-                const int64_t r = args.indices[t][j];
-                if (r < 0 || r >= args.n_rows[t]) { bad = true; continue; }
+                int64_t r = args.indices[t][j];
+                if (r < 0 || r >= args.row_total[t]) { bad = true; continue; }
+                r -= args.row_lo[t];
+                if (r < 0 || r >= args.n_rows[t]) continue;   // another rank's rows
                 float v;
                 if (CODEC == 32) v = reinterpret_cast<const float *>(W)[r * d + c];
                 else if (CODEC == 16) v = dec_u16(reinterpret_cast<const unsigned short *>(W)[r * d + c]);
@@ -296,36 +326,43 @@ static void launch_codec(const GatherArgs &a, bool vec_ok, hipStream_t stream, b
 
 }  // namespace evs
 
-extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const void *const *tables,
-                                     const int64_t *n_rows, const int64_t *const *indices,
-                                     const int64_t *const *offsets, const int64_t *nnz,
-                                     const float *const *row_weights, float *out,
-                                     int64_t out_table_stride, int64_t out_bag_stride, void *stream) {
+extern "C" int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec, const void *const *tables,
+                                             const int64_t *n_rows, const int64_t *row_lo, const int64_t *row_total,
+                                             const int64_t *const *indices, const int64_t *const *offsets, const int64_t *nnz,
+                                             const float *const *row_weights, float *out, int64_t out_table_stride,
+                                             int64_t out_bag_stride, int64_t out_peer_stride, int64_t bags_per_peer,
+                                             void *stream) {
     using namespace evs;
-    EVS_REQUIRE(T >= 0 && B >= 0 && d > 0, "evs_embedding_bag_sum: bad shape T=%d B=%lld d=%d", T, (long long)B, d);
-    EVS_REQUIRE(codec == 32 || codec == 16 || codec == 8 || codec == 4, "evs_embedding_bag_sum: codec %d", codec);
-    EVS_REQUIRE(codec != 4 || d % 2 == 0, "evs_embedding_bag_sum: 4-bit rows need an even d (got %d)", d);
+    const char *who = "evs_embedding_bag_sum";
+    EVS_REQUIRE(T >= 0 && B >= 0 && d > 0, "%s: bad shape T=%d B=%lld d=%d", who, T, (long long)B, d);
+    EVS_REQUIRE(codec == 32 || codec == 16 || codec == 8 || codec == 4, "%s: codec %d", who, codec);
+    EVS_REQUIRE(codec != 4 || d % 2 == 0, "%s: 4-bit rows need an even d (got %d)", who, d);
     if (T == 0 || B == 0) return EVS_OK;
-    EVS_REQUIRE(tables && n_rows && indices && nnz && out, "evs_embedding_bag_sum: NULL argument");
+    EVS_REQUIRE(tables && n_rows && indices && nnz && out, "%s: NULL argument", who);
+    EVS_REQUIRE(B < (1ll << 31), "%s: B %lld", who, (long long)B);
+    EVS_REQUIRE((row_lo == nullptr) == (row_total == nullptr), "%s: row_lo and row_total go together", who);
+    if (bags_per_peer <= 0 || bags_per_peer >= B) { bags_per_peer = B; out_peer_stride = 0; }
     // offsets == NULL, or every offsets[k] == NULL: one index per bag (bag b of table k reads indices[k][b])
     bool bag1 = offsets == nullptr;
     if (!bag1) {
         int n_null = 0;
         for (int k = 0; k < T; k++) n_null += offsets[k] == nullptr;
-        EVS_REQUIRE(n_null == 0 || n_null == T, "evs_embedding_bag_sum: offsets NULL for %d of %d tables (all or none)",
-                    n_null, T);
+        EVS_REQUIRE(n_null == 0 || n_null == T, "%s: offsets NULL for %d of %d tables (all or none)", who, n_null, T);
         bag1 = n_null == T;
     }
     int *err = index_error_flag();
     if (!err) return EVS_EHIP;
     bool vec_ok = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && out_table_stride % 4 == 0 &&
-                  out_bag_stride % 4 == 0;
+                  out_bag_stride % 4 == 0 && out_peer_stride % 4 == 0;
     for (int k = 0; k < T; k++) {
-        EVS_REQUIRE(n_rows[k] >= 0 && nnz[k] >= 0, "evs_embedding_bag_sum: table %d has negative size", k);
-        EVS_REQUIRE(tables[k] || n_rows[k] == 0, "evs_embedding_bag_sum: table %d is NULL", k);
-        EVS_REQUIRE(!bag1 || nnz[k] >= B, "evs_embedding_bag_sum: table %d has %lld indices for %lld one-index bags", k,
+        EVS_REQUIRE(n_rows[k] >= 0 && nnz[k] >= 0, "%s: table %d has negative size", who, k);
+        EVS_REQUIRE(tables[k] || n_rows[k] == 0, "%s: table %d is NULL", who, k);
+        EVS_REQUIRE(!bag1 || nnz[k] >= B, "%s: table %d has %lld indices for %lld one-index bags", who, k,
                     (long long)nnz[k], (long long)B);
-        EVS_REQUIRE(indices[k] || nnz[k] == 0, "evs_embedding_bag_sum: indices[%d] is NULL", k);
+        EVS_REQUIRE(indices[k] || nnz[k] == 0, "%s: indices[%d] is NULL", who, k);
+        EVS_REQUIRE(!row_lo || (row_lo[k] >= 0 && row_lo[k] + n_rows[k] <= row_total[k]),
+                    "%s: table %d holds rows [%lld, %lld) of %lld", who, k, (long long)(row_lo ? row_lo[k] : 0),
+                    (long long)(row_lo ? row_lo[k] + n_rows[k] : 0), (long long)(row_total ? row_total[k] : 0));
         if (reinterpret_cast<uintptr_t>(tables[k]) % 16 != 0) vec_ok = false;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -340,10 +377,14 @@ extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const v
             a.row_w[k] = (on && row_weights) ? row_weights[k0 + k] : nullptr;
             a.n_rows[k] = on ? n_rows[k0 + k] : 0;
             a.nnz[k] = on ? nnz[k0 + k] : 0;
+            a.row_lo[k] = (on && row_lo) ? row_lo[k0 + k] : 0;
+            a.row_total[k] = on ? (row_total ? row_total[k0 + k] : n_rows[k0 + k]) : 0;
         }
         a.out = out + (int64_t)k0 * out_table_stride;
         a.out_tstride = out_table_stride;
         a.out_bstride = out_bag_stride;
+        a.out_pstride = out_peer_stride;
+        a.bags_per_peer = (unsigned)bags_per_peer;
         a.B = B;
         a.T = n;
         a.d = d;
@@ -358,6 +399,15 @@ extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const v
         EVS_HIP_CHECK(hipGetLastError());
     }
     return EVS_OK;
+}
+
+extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const void *const *tables,
+                                     const int64_t *n_rows, const int64_t *const *indices,
+                                     const int64_t *const *offsets, const int64_t *nnz,
+                                     const float *const *row_weights, float *out,
+                                     int64_t out_table_stride, int64_t out_bag_stride, void *stream) {
+    return evs_embedding_bag_sum_sharded(T, B, d, codec, tables, n_rows, nullptr, nullptr, indices, offsets, nnz, row_weights, out,
+                                         out_table_stride, out_bag_stride, 0, 0, stream);
 }
 
 extern "C" int evs_embedding_bag_sum_stacked(int T, int64_t B, int d, int codec, const void *const *tables,

@@ -392,14 +392,17 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
     assert R.shape == (B, d + P) and R.is_contiguous() and R.dtype == torch.float32
     L = _lib.lib()
     stream = _stream_ptr(dev)
-    if torch.is_tensor(lS_i) and torch.is_tensor(lS_o):  # stacked (T,B) Criteo layout: one call, no lists
-        assert lS_i.dtype == torch.int64 and lS_o.dtype == torch.int64 and lS_i.is_cuda and lS_o.is_cuda
-        assert lS_i.stride(1) == 1 and lS_o.stride(1) == 1 and lS_o.shape[1] == B
+    if torch.is_tensor(lS_i) and (torch.is_tensor(lS_o) or lS_o is None):  # stacked (T,B) Criteo layout: one call, no lists
+        assert lS_i.dtype == torch.int64 and lS_i.is_cuda and lS_i.stride(1) == 1
         rw_c, _keep = _row_weights_c(ev, v_W_l)
         no_off = one_index_per_bag and rw_c is None and int(lS_i.shape[1]) == B
+        assert no_off or lS_o is not None, "lS_o is required unless one_index_per_bag is declared"
+        if lS_o is not None:
+            assert lS_o.dtype == torch.int64 and lS_o.is_cuda and lS_o.stride(1) == 1 and lS_o.shape[1] == B
         _lib.check(L.evs_emb_interact_dot_stacked(
             B, T, d, ev.codec, ev._tables_c, ev._n_rows_c, x.data_ptr(), int(x.stride(0)) if B > 1 else d,
-            lS_i.data_ptr(), lS_i.stride(0), int(lS_i.shape[1]), None if no_off else lS_o.data_ptr(), lS_o.stride(0), rw_c,
+            lS_i.data_ptr(), lS_i.stride(0), int(lS_i.shape[1]), None if no_off else lS_o.data_ptr(),
+            0 if no_off else lS_o.stride(0), rw_c,
             int(bool(arch_interaction_itself)), R.data_ptr(), stream))
         if check_indices:
             _lib.check(L.evs_check_index_errors(stream))

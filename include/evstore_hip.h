@@ -80,6 +80,24 @@ EVS_API int evs_embedding_bag_sum(int T, int64_t B, int d, int codec,
                           float *out, int64_t out_table_stride, int64_t out_bag_stride,
                           void *stream);
 
+/* The pool step of the table-sharded forward (dlrm_s_pytorch.py:543-570 distributed_forward: every rank pools ITS
+ * tables for the FULL batch, then one all-to-all): evs_embedding_bag_sum with two extensions.
+ *   row-split tables (row_lo / row_total, HOST arrays of T, both NULL = whole tables): tables[k] holds the global rows
+ *     [row_lo[k], row_lo[k] + n_rows[k]) of a table of row_total[k] rows.  An index inside the table but outside that
+ *     range belongs to another rank: it contributes nothing, silently -- the bag's sum over THIS rank's rows is written
+ *     (zeros when it has none); only an index outside [0, row_total) raises the sticky flag.
+ *   peer-major output (out_peer_stride / bags_per_peer; bags_per_peer <= 0 or >= B = the plain layout): element (k, b, c)
+ *     goes to out[(b / bags_per_peer) * out_peer_stride + k * out_table_stride + (b % bags_per_peer) * out_bag_stride + c]
+ *     -- the block of the all_to_all_single send buffer that goes to rank b / bags_per_peer (extend_distributed.py:
+ *     389-426 builds that buffer with torch.cat; here the gather writes it in place).  Strides in floats, % 4 == 0. */
+EVS_API int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec,
+                          const void *const *tables, const int64_t *n_rows,
+                          const int64_t *row_lo, const int64_t *row_total,
+                          const int64_t *const *indices, const int64_t *const *offsets,
+                          const int64_t *nnz, const float *const *row_weights,
+                          float *out, int64_t out_table_stride, int64_t out_bag_stride,
+                          int64_t out_peer_stride, int64_t bags_per_peer, void *stream);
+
 /* Same operation for the stacked layout of the Criteo collate
  * (dlrm_data_pytorch.py:397-410: lS_i and lS_o are (T,B) int64 tensors, one row per
  * table): indices[k] = indices_base + k*indices_row_stride (B entries each, i.e.
