@@ -493,11 +493,12 @@ def main():
                     help="skip the sections that re-launch the headline kernel under other conditions (two streams, B=65536, "
                          "reduced precision, host-memory tables): used for the rocprofv3 summaries in profiles/, whose "
                          "per-kernel average must be the headline launch alone")
-    ap.add_argument("--placement", default="rows+replicate", choices=["rows+replicate", "rows", "count", "hbm"],
+    ap.add_argument("--placement", default="rows+replicate", choices=["rows+replicate", "rows", "count", "hbm", "rowsplit"],
                     help="table placement for --gpus > 1 (sharded.plan_placement): rows+replicate (default) = tables above 1 M rows "
                          "sharded by row count + one RCCL all_to_all_single per batch, the small ones replicated; rows = every table "
                          "sharded; count = the reference's contiguous split; hbm = replicate what fits --replicate-gb (no exchange "
-                         "when the whole model fits) -- timed beside the headline as `replicated_all`")
+                         "when the whole model fits) -- timed beside the headline as `replicated_all`; rowsplit = the tables above 1 M rows "
+                         "split row-wise over all ranks (every rank pools B_global * T_big / N lookups), the small ones replicated")
     ap.add_argument("--sharded-mode", default="auto", choices=["auto", "graph", "pipelined"],
                     help="N>1 step loop: graph = each planned step (pool, all-to-all, interaction) captured once as a HIP graph and "
                          "replayed; pipelined = eager, exchange of batch i+1 under the interaction of batch i; auto = pipelined "

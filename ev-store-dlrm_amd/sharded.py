@@ -17,7 +17,16 @@ MI355X-native re-design (same results, fewer bytes on xGMI and in HBM):
     "rows" (balance by row count, BASELINE.json north_star), and "rows+replicate":
     tables below `replicate_max_rows` are replicated on every rank and looked up
     locally inside the fused kernel for the local batch slice only, so their pooled
-    vectors never cross xGMI (Kaggle: 21 of 26 tables, 82 MB; 5/26 of the bytes remain).
+    vectors never cross xGMI (Kaggle: 21 of 26 tables, 82 MB; 5/26 of the bytes remain);
+    "rowsplit": the tables above the threshold are split ROW-WISE into `world` contiguous
+    ranges, the small ones replicated: with pooling factor 1 owning a
+    whole table costs B_global lookups whatever its size (5 owners pool 131 072 rows each
+    at world 8 while 3 ranks idle); row ranges make every rank pool ~ B_global * T_big / world
+    rows.  A rank pools, for EVERY bag of the global batch, the partial sum over the rows of
+    its range (evs_embedding_bag_sum_sharded) into its block of the same send buffer; the
+    receiver reads the partial of the rank whose range holds the index (one index per bag:
+    a select, bit-equal to the single-process row) or adds the `world` partials in rank
+    order (multi-index bags: fp32 sums in another order than the single process).
 The compute backend is injectable so the distributed plumbing is testable on CPU (gloo)
 with the oracle standing in for the HIP kernels (tests/test_sharded_gloo.py).
 """
@@ -34,8 +43,10 @@ from .dlrm_ops import EVTables, _stream_ptr
 
 # ----------------------------------------------------------------------------- placement
 def plan_placement(ln_emb, world, policy="rows+replicate", replicate_max_rows=1_000_000, replicate_budget_rows=None):
-    """-> owner[t] in {0..world-1} or -1 (replicated on every rank).
+    """-> owner[t] in {0..world-1}, -1 (replicated on every rank) or -2 (split row-wise over all ranks).
     count            contiguous by table count (extend_distributed.get_my_slice)
+    rowsplit         tables above replicate_max_rows split into `world` contiguous row ranges (rank r holds rows
+                     [r*n//world, (r+1)*n//world)), the others on every rank
     rows             LPT greedy on row counts (BASELINE: "tables shard by row-count")
     rows+replicate   tables of at most replicate_max_rows rows on every rank, the rest by rows
     hbm              the same with the threshold set by memory: smallest tables first are replicated while their rows
@@ -67,6 +78,8 @@ def plan_placement(ln_emb, world, policy="rows+replicate", replicate_max_rows=1_
                 owner[t] = r
                 t += 1
         return owner
+    if policy == "rowsplit":
+        return [-2 if ln_emb[t] > replicate_max_rows else -1 for t in range(T)]
     if policy not in ("rows", "rows+replicate"):
         raise ValueError("unknown placement policy %r" % policy)
     shard = list(range(T))
@@ -83,6 +96,16 @@ def plan_placement(ln_emb, world, policy="rows+replicate", replicate_max_rows=1_
     return owner
 
 
+def row_range(n, rank, world):
+    """rows [lo, hi) of an n-row table that rank `rank` holds under the rowsplit placement"""
+    return rank * n // world, (rank + 1) * n // world
+
+
+def row_owner(idx, n, world):
+    """rank whose range holds row idx (tensor or int): the largest r with r*n//world <= idx"""
+    return ((idx + 1) * world + (n - 1)) // n - 1
+
+
 # ----------------------------------------------------------------------------- backends
 class HipBackend:
     """libevstore_hip.so kernels (the product path)."""
@@ -94,17 +117,20 @@ class HipBackend:
     def make_tables(self, weights, d):
         return EVTables([w.to(self.device) for w in weights], d, 32)
 
-    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False, bag1=False):
+    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False, bag1=False,
+                     layout=None, row_lo=None, row_total=None):
         """pooled[b][j][:] for the j-th owned table, written into send (B, n_own, d).
         bag1: the caller states one index per bag (offsets = arange): the library's NULL-offsets row gather.
         planned: the caller passes the SAME list objects every step (plan / run_start): the pointer tables are then
-        cached by list identity and the lists kept alive; one-off calls build them and keep nothing."""
-        B = int(send.shape[0])
+        cached by list identity and the lists kept alive; one-off calls build them and keep nothing.
+        layout = (B, float_offset, table_stride, bag_stride, peer_stride, bags_per_peer): write into the flat buffer `send`
+        peer-major instead (evs_embedding_bag_sum_sharded); row_lo / row_total: the tables are row ranges of larger ones."""
+        B = int(send.shape[0]) if layout is None else int(layout[0])
         n = len(table_ids_local)
         if n == 0 or B == 0:
             return
         # planned batches pass the same list objects every step: key on identity first (no per-step tuple building)
-        fast = ("gid", id(lS_i_rows), id(lS_o_rows), send.data_ptr(), bag1)
+        fast = ("gid", id(lS_i_rows), id(lS_o_rows), send.data_ptr(), bag1, layout)
         ent = self._cache.get(fast) if planned else None
         if ent is None:
             # "one index per bag" is a statement about the batch: honour it only when every index list HAS B entries
@@ -115,17 +141,27 @@ class HipBackend:
                    (C.c_void_p * n)(*[t.data_ptr() for t in lS_i_rows]),
                    None if bag1 else (C.c_void_p * n)(*[t.data_ptr() for t in lS_o_rows]),
                    (C.c_int64 * n)(*[int(t.numel()) for t in lS_i_rows]),
-                   lS_i_rows, lS_o_rows)  # the lists are kept alive so their ids stay unique
+                   lS_i_rows, lS_o_rows,  # the lists are kept alive so their ids stay unique
+                   None if row_lo is None else (C.c_int64 * n)(*row_lo),
+                   None if row_total is None else (C.c_int64 * n)(*row_total))
             if planned:
                 if len(self._cache) > 256:
                     self._cache.clear()
                 self._cache[fast] = ent
         L = _lib.lib()
-        _lib.check(L.evs_embedding_bag_sum(n, B, d, ev.codec, ent[0], ent[1], ent[2], ent[3], ent[4], None,
-                                           send.data_ptr(), d, n_own * d, _stream_ptr(self.device)))
+        if layout is None and row_lo is None:
+            _lib.check(L.evs_embedding_bag_sum(n, B, d, ev.codec, ent[0], ent[1], ent[2], ent[3], ent[4], None,
+                                               send.data_ptr(), d, n_own * d, _stream_ptr(self.device)))
+            return
+        _, foff, tstride, bstride, pstride, bpp = layout if layout is not None else (B, 0, d, n_own * d, 0, 0)
+        _lib.check(L.evs_embedding_bag_sum_sharded(n, B, d, ev.codec, ent[0], ent[1], ent[7], ent[8], ent[2], ent[3], ent[4], None,
+                                                   send.data_ptr() + 4 * foff, tstride, bstride, pstride, bpp,
+                                                   _stream_ptr(self.device)))
 
     def interact_mixed(self, x, specs, ev, d, itself, out=None, planned=False):
-        """specs[t]: ("dense", tensor(B,d) view) | ("indirect", local_table_id, idx, off, nnz, off_len)."""
+        """specs[t]: ("dense", tensor(B,d) view) | ("indirect", local_table_id, idx, off, nnz, off_len) |
+        ("gathered", rows, n_rows, idx, off, nnz, off_len): like "indirect" over the fp32 rows of `rows` (a flat tensor:
+        row r = rows[r*d : (r+1)*d]) -- the row-split tables' partials inside the receive buffer."""
         B = int(x.shape[0])
         F = len(specs) + 1
         P = F * (F + 1) // 2 if itself else F * (F - 1) // 2
@@ -140,6 +176,11 @@ class HipBackend:
                 if s[0] == "dense":
                     v = s[1]
                     f.src, f.stride = v.data_ptr(), int(v.stride(0)) if B > 1 else d
+                elif s[0] == "gathered":
+                    _, rows, n_rows, idx, off, nnz, off_len = s
+                    f.src, f.indices = rows.data_ptr(), idx.data_ptr()
+                    f.offsets = off.data_ptr() if off is not None else None
+                    f.nnz, f.n_rows, f.offsets_len = int(nnz), int(n_rows), int(off_len)
                 else:
                     _, k, idx, off, nnz, off_len = s
                     # empty index tensor: data_ptr() is NULL, which the C ABI reads as "dense" -- pass the table address
@@ -175,42 +216,70 @@ class ShardedEmbeddingInteract:
         self.own = [[t for t in range(len(ln_emb)) if self.owner[t] == r] for r in range(world)]
         self.my_own = self.own[rank]
         self.replicated = [t for t in range(len(ln_emb)) if self.owner[t] == -1]
-        self.any_sharded = any(o >= 0 for o in self.owner)
-        held = self.my_own + self.replicated
+        self.split = [t for t in range(len(ln_emb)) if self.owner[t] == -2]   # row-split: this rank holds row_range(n, rank, world)
+        self.any_sharded = any(o >= 0 or o == -2 for o in self.owner)
+        held = self.my_own + self.replicated + self.split
         assert sorted(local_weights.keys()) == sorted(held), "rank %d must hold tables %s" % (rank, held)
+        for t in self.split:
+            lo, hi = row_range(self.ln_emb[t], rank, world)
+            assert int(local_weights[t].shape[0]) == hi - lo, "rank %d holds rows [%d, %d) of table %d" % (rank, lo, hi, t)
         self.local_id = {t: i for i, t in enumerate(held)}
         self.ev = backend.make_tables([local_weights[t] for t in held], d)
         self._bufs = {}
+        self._route = {}
 
     def tables_held(self):
-        return self.my_own + self.replicated
+        return self.my_own + self.replicated + self.split
 
-    # a2a element counts for a global batch of Bg samples
+    # a2a element counts for a global batch of Bg samples.  The block a rank sends to every peer: its owned tables'
+    # pooled vectors for the peer's samples, sample-major (Bl, n_own, d), then its partials of the row-split tables,
+    # table-major (n_split, Bl, d) -- the second section has the same size on every rank
     def _splits(self, Bg):
         assert Bg % self.world == 0, "batch_size %d can not split across %d ranks evenly" % (Bg, self.world)
         Bl = Bg // self.world
-        in_splits = [Bl * len(self.my_own) * self.d] * self.world
-        out_splits = [Bl * len(self.own[p]) * self.d for p in range(self.world)]
+        S = len(self.split) * Bl * self.d
+        in_splits = [Bl * len(self.my_own) * self.d + S] * self.world
+        out_splits = [Bl * len(self.own[p]) * self.d + S for p in range(self.world)]
         return Bl, in_splits, out_splits
 
     def _buffers(self, Bg, slot, like):
         key = (Bg, slot)
         if key not in self._bufs:
-            Bl, _, out_splits = self._splits(Bg)
-            send = like.new_empty((Bg, max(len(self.my_own), 0), self.d), dtype=torch.float32)
+            Bl, in_splits, out_splits = self._splits(Bg)
+            if self.split:
+                send = like.new_empty((sum(in_splits),), dtype=torch.float32)
+            else:
+                send = like.new_empty((Bg, max(len(self.my_own), 0), self.d), dtype=torch.float32)
             # one rank: nothing to exchange -- the "received" block is the send buffer itself (no copy)
             recv = send.view(-1) if self.world == 1 else like.new_empty((sum(out_splits),), dtype=torch.float32)
             self._bufs[key] = (send, recv)
         return self._bufs[key]
 
+    def _pool_into(self, send, Bg, lo_rows, li_rows, planned=False, lo_split=None, li_split=None):
+        """the pooling launch(es) of one batch: owned tables, then this rank's row ranges of the split tables"""
+        d, n_own = self.d, len(self.my_own)
+        Bl = Bg // self.world
+        if not self.split:
+            self.backend.bag_sum_into(self.ev, [self.local_id[t] for t in self.my_own], lo_rows, li_rows, send, n_own, d,
+                                      planned=planned, bag1=self.one_index_per_bag)
+            return
+        blk = Bl * n_own * d + len(self.split) * Bl * d
+        if n_own:
+            self.backend.bag_sum_into(self.ev, [self.local_id[t] for t in self.my_own], lo_rows, li_rows, send, n_own, d,
+                                      planned=planned, bag1=self.one_index_per_bag, layout=(Bg, 0, d, n_own * d, blk, Bl))
+        self.backend.bag_sum_into(self.ev, [self.local_id[t] for t in self.split], lo_split, li_split, send, len(self.split), d,
+                                  planned=planned, bag1=self.one_index_per_bag,
+                                  layout=(Bg, Bl * n_own * d, Bl * d, d, blk, Bl),
+                                  row_lo=[row_range(self.ln_emb[t], self.rank, self.world)[0] for t in self.split],
+                                  row_total=[self.ln_emb[t] for t in self.split])
+
     def pool(self, lS_o, lS_i, slot=0):
-        """Pool the owned tables for the full batch into the send layout (B_global, T_own, d)."""
+        """Pool the owned tables (and this rank's row ranges of the split tables) for the full batch into the send layout."""
         Bg = int(lS_o[0].shape[0])
         like = lS_o[0].new_empty((0,), dtype=torch.float32)
         send, recv = self._buffers(Bg, slot, like)
-        ids = [self.local_id[t] for t in self.my_own]
-        self.backend.bag_sum_into(self.ev, ids, [lS_o[t] for t in self.my_own], [lS_i[t] for t in self.my_own],
-                                  send, len(self.my_own), self.d, bag1=self.one_index_per_bag)
+        self._pool_into(send, Bg, [lS_o[t] for t in self.my_own], [lS_i[t] for t in self.my_own],
+                        lo_split=[lS_o[t] for t in self.split], li_split=[lS_i[t] for t in self.split])
         return send, recv
 
     def start(self, lS_o, lS_i, slot=0):
@@ -226,19 +295,55 @@ class ShardedEmbeddingInteract:
             work = dist.all_to_all_single(recv, send.view(-1), out_splits, in_splits, group=self.group, async_op=True)
         return (work, recv, Bg, Bl, out_splits)
 
-    def finish(self, handle, x_local, lS_o, lS_i, out=None):
-        """Wait for the exchange, then R = interact_features(x_local, ly) on this rank's batch slice."""
-        work, recv, Bg, Bl, out_splits = handle
-        if work is not None:
-            work.wait()
+    # ---- where the receiver finds things ------------------------------------------------------------------------------
+    def _split_geometry(self, Bg):
+        """(float offset of block p's split section in the receive buffer, row offset of block p relative to block 0)"""
+        Bl, _, out_splits = self._splits(Bg)
+        soff, pos = [], 0
+        for p in range(self.world):
+            soff.append(pos + Bl * len(self.own[p]) * self.d)
+            pos += out_splits[p]
+        return soff, [(o - soff[0]) // self.d for o in soff]
+
+    def _split_specs(self, recv, Bg, lS_o, lS_i):
+        """one "gathered" feature per row-split table: its rows are the `world` partials inside the receive buffer.
+        One index per bag: sample b reads the partial of the rank whose range holds idx[b] (a select: the row itself).
+        Otherwise: the bag of sample b is its `world` partials, added in rank order."""
+        if not self.split:
+            return {}
+        Bl = Bg // self.world
         b0 = self.rank * Bl
-        T = len(self.ln_emb)
-        specs = [None] * T
+        soff, rowoff = self._split_geometry(Bg)
+        n_virtual = rowoff[-1] + Bl
+        dev = recv.device
+        key = (Bg, str(dev))
+        if key not in self._route:
+            ro = torch.tensor(rowoff, dtype=torch.int64, device=dev)
+            ar = torch.arange(Bl, dtype=torch.int64, device=dev)
+            self._route[key] = (ro, ar, (ar[:, None] + ro[None, :]).reshape(-1).contiguous(), ar * self.world,
+                                torch.tensor([self.ln_emb[t] for t in self.split], dtype=torch.int64, device=dev)[:, None])
+        ro, ar, all_partials, bag_starts, n_col = self._route[key]
+        out = {}
+        if self.one_index_per_bag:
+            v = torch.stack([lS_i[t][b0:b0 + Bl] for t in self.split])                  # (n_split, Bl)
+            own = row_owner(v, n_col, self.world).clamp_(0, self.world - 1)              # (a bad index: the pool flagged it)
+            idx2 = ro[own] + ar[None, :]
+        for j, t in enumerate(self.split):
+            rows = recv[soff[0] + j * Bl * self.d:]
+            if self.one_index_per_bag:
+                out[t] = ("gathered", rows, n_virtual, idx2[j], None, Bl, 0)
+            else:
+                out[t] = ("gathered", rows, n_virtual, all_partials, bag_starts, Bl * self.world, Bl)
+        return out
+
+    def _specs(self, recv, Bg, Bl, out_splits, lS_o, lS_i):
+        b0 = self.rank * Bl
+        specs = [None] * len(self.ln_emb)
         pos = 0
         for p in range(self.world):
             n = len(self.own[p])
             if n:
-                block = recv[pos:pos + out_splits[p]].view(Bl, n, self.d)
+                block = recv[pos:pos + Bl * n * self.d].view(Bl, n, self.d)
                 for j, t in enumerate(self.own[p]):
                     specs[t] = ("dense", block[:, j, :])
             pos += out_splits[p]
@@ -247,7 +352,17 @@ class ShardedEmbeddingInteract:
                 specs[t] = ("indirect", self.local_id[t], lS_i[t][b0:], None, Bg - b0, 0)
             else:
                 specs[t] = ("indirect", self.local_id[t], lS_i[t], lS_o[t][b0:], int(lS_i[t].numel()), Bg - b0)
-        return self.backend.interact_mixed(x_local, specs, self.ev, self.d, self.itself, out=out)
+        for t, sp in self._split_specs(recv, Bg, lS_o, lS_i).items():
+            specs[t] = sp
+        return specs
+
+    def finish(self, handle, x_local, lS_o, lS_i, out=None):
+        """Wait for the exchange, then R = interact_features(x_local, ly) on this rank's batch slice."""
+        work, recv, Bg, Bl, out_splits = handle
+        if work is not None:
+            work.wait()
+        return self.backend.interact_mixed(x_local, self._specs(recv, Bg, Bl, out_splits, lS_o, lS_i), self.ev, self.d,
+                                           self.itself, out=out)
 
     # ---- pre-planned steady state: all per-batch Python (views, pointer tables) done once -------------
     def plan(self, x_local, lS_o, lS_i, out=None, slot=0):
@@ -257,24 +372,26 @@ class ShardedEmbeddingInteract:
         Bl, in_splits, out_splits = self._splits(Bg)
         like = lS_o[0].new_empty((0,), dtype=torch.float32)
         send, recv = self._buffers(Bg, slot, like)
-        b0 = self.rank * Bl
-        specs = [None] * len(self.ln_emb)
-        pos = 0
-        for p in range(self.world):
-            n = len(self.own[p])
-            if n:
-                block = recv[pos:pos + out_splits[p]].view(Bl, n, self.d)
-                for j, t in enumerate(self.own[p]):
-                    specs[t] = ("dense", block[:, j, :])
-            pos += out_splits[p]
-        for t in self.replicated:
-            if self.one_index_per_bag:
-                specs[t] = ("indirect", self.local_id[t], lS_i[t][b0:], None, Bg - b0, 0)
-            else:
-                specs[t] = ("indirect", self.local_id[t], lS_i[t], lS_o[t][b0:], int(lS_i[t].numel()), Bg - b0)
-        return {"send": send, "recv": recv, "in": in_splits, "out": out_splits, "specs": specs, "x": x_local,
-                "R": out, "ids": [self.local_id[t] for t in self.my_own],
-                "lo": [lS_o[t] for t in self.my_own], "li": [lS_i[t] for t in self.my_own]}
+        specs = self._specs(recv, Bg, Bl, out_splits, lS_o, lS_i)
+        pl = {"send": send, "recv": recv, "in": in_splits, "out": out_splits, "specs": specs, "x": x_local,
+              "R": out, "Bg": Bg, "ids": [self.local_id[t] for t in self.my_own],
+              "lo": [lS_o[t] for t in self.my_own], "li": [lS_i[t] for t in self.my_own],
+              "lo_split": [lS_o[t] for t in self.split], "li_split": [lS_i[t] for t in self.split]}
+        if self.split and self.one_index_per_bag:
+            # the route of a row-split lookup depends on the batch's indices: run_finish recomputes it INTO these tensors
+            # every step (a serving loop refills its staged index buffers in place)
+            pl["route_dst"] = [specs[t][3] for t in self.split]
+            pl["route_src"] = [lS_i[t][self.rank * Bl:(self.rank + 1) * Bl] for t in self.split]
+        return pl
+
+    def _reroute(self, pl):
+        Bg = pl["Bg"]
+        Bl = Bg // self.world
+        ro, ar, _, _, n_col = self._route[(Bg, str(pl["recv"].device))]
+        own = row_owner(torch.stack(pl["route_src"]), n_col, self.world).clamp_(0, self.world - 1)
+        idx2 = ro[own] + ar[None, :]
+        for j, dst in enumerate(pl["route_dst"]):
+            dst.copy_(idx2[j])
 
     def run_start(self, pl):
         """Pooling gather of the owned tables + the all-to-all (async); nothing when every table is replicated.  Same stream as the interaction: a
@@ -282,8 +399,7 @@ class ShardedEmbeddingInteract:
         47) -- at this batch size the step is bounded by host-side launch cost, not by GPU overlap."""
         if not self.any_sharded:
             return None
-        self.backend.bag_sum_into(self.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], len(self.my_own), self.d, planned=True,
-                                  bag1=self.one_index_per_bag)
+        self._pool_into(pl["send"], pl["Bg"], pl["lo"], pl["li"], planned=True, lo_split=pl["lo_split"], li_split=pl["li_split"])
         if self.world > 1:
             return dist.all_to_all_single(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"], group=self.group,
                                           async_op=True)
@@ -311,6 +427,8 @@ class ShardedEmbeddingInteract:
         return g
 
     def run_finish(self, pl, work):
+        if "route_dst" in pl:
+            self._reroute(pl)
         if work is not None:
             work.wait()
         return self.backend.interact_mixed(pl["x"], pl["specs"], self.ev, self.d, self.itself, out=pl["R"], planned=True)
@@ -330,13 +448,14 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     Bg = Bl * world
     backend = HipBackend(dev)
     owner = plan_placement(ln_emb, world, policy, replicate_budget_rows=budget_rows)
-    held = [t for t in range(T) if owner[t] in (rank, -1)]
+    held = [t for t in range(T) if owner[t] in (rank, -1, -2)]
     g = torch.Generator(device=dev)
     weights = {}
-    for t in held:  # same values on every rank that holds table t
+    for t in held:  # same values on every rank that holds table t (a row-split table: this rank's row range of it)
         g.manual_seed(1000 + t)
         a = float(np.sqrt(1.0 / ln_emb[t]))
-        weights[t] = torch.empty((ln_emb[t], d), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
+        lo, hi = row_range(ln_emb[t], rank, world) if owner[t] == -2 else (0, ln_emb[t])
+        weights[t] = torch.empty((hi - lo, d), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
     op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy, one_index_per_bag=True,
                                   replicate_budget_rows=budget_rows)
     # every rank generates the same full-batch indices (same seed), as the reference feeds them
@@ -398,11 +517,13 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     n_sh = sum(1 for t in range(T) if owner[t] >= 0)
-    n_rep = T - n_sh
-    res = {"dt": dt, "owner": owner, "n_sharded": n_sh, "n_replicated": n_rep, "mode": mode,
-           # bytes that leave a rank per step (its pooled vectors for the other ranks' batch slices), and over all ranks
-           "a2a_bytes_per_rank": 4 * d * Bl * len(op.my_own) * (world - 1),
-           "a2a_bytes": 4 * d * Bl * n_sh * (world - 1), "roofline": None}
+    n_split = sum(1 for t in range(T) if owner[t] == -2)
+    n_rep = T - n_sh - n_split
+    res = {"dt": dt, "owner": owner, "n_sharded": n_sh, "n_rowsplit": n_split, "n_replicated": n_rep, "mode": mode,
+           # bytes that leave a rank per step (its pooled vectors -- and its partials of the row-split tables -- for the
+           # other ranks' batch slices), and over all ranks
+           "a2a_bytes_per_rank": 4 * d * Bl * (len(op.my_own) + n_split) * (world - 1),
+           "a2a_bytes": 4 * d * Bl * (n_sh + n_split * world) * (world - 1), "roofline": None}
     # roofline of the launches a rank issues per batch (rank 0, HIP events on the launch stream, after the timed
     # region): the pooling gather of its own tables over the GLOBAL batch (if any) and the interaction over its
     # LOCAL batch (received pooled vectors dense, replicated tables gathered inside the kernel)
@@ -416,8 +537,8 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
         t_pool = t_fin = 0.0
         for _ in range(iters):
             ev[0].record()
-            if n_own:
-                backend.bag_sum_into(op.ev, pl["ids"], pl["lo"], pl["li"], pl["send"], n_own, d, planned=True, bag1=True)
+            if n_own or n_split:
+                op._pool_into(pl["send"], pl["Bg"], pl["lo"], pl["li"], planned=True, lo_split=pl["lo_split"], li_split=pl["li_split"])
             ev[1].record()
             backend.interact_mixed(pl["x"], pl["specs"], op.ev, d, op.itself, out=pl["R"], planned=True)
             ev[2].record()
@@ -425,16 +546,18 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
             t_pool += ev[0].elapsed_time(ev[1])
             t_fin += ev[1].elapsed_time(ev[2])
         t_pool, t_fin = t_pool / iters, t_fin / iters
-        pool_bytes = n_own * Bg * (4 * d + 8 + 4 * d)            # row + index read, pooled vector written (one index/bag)
-        fin_bytes = Bl * (4 * d * (1 + n_sh) + n_rep * (4 * d + 8) + 4 * (d + P))
-        dom = ("pool", pool_bytes, t_pool) if (n_own and t_pool >= t_fin) else ("interact", fin_bytes, t_fin)
+        # row + index read, pooled vector written (one index/bag); a row-split table: every index read, 1/world of the rows
+        # read, every (mostly zero) partial written
+        pool_bytes = n_own * Bg * (4 * d + 8 + 4 * d) + n_split * Bg * (8 + 4 * d // world + 4 * d)
+        fin_bytes = Bl * (4 * d * (1 + n_sh) + n_rep * (4 * d + 8) + n_split * (4 * d + 8 + 8) + 4 * (d + P))
+        dom = ("pool", pool_bytes, t_pool) if ((n_own or n_split) and t_pool >= t_fin) else ("interact", fin_bytes, t_fin)
         res["roofline"] = {
             "bound": "hbm",
             "kernel": "embedding_bag_sum_kernel (own tables x global batch)" if dom[0] == "pool" else
-                      "fused gather + interaction kernel (local batch: %d received dense features + %d replicated tables)" % (n_sh, n_rep),
+                      "fused gather + interaction kernel (local batch: %d received dense features + %d replicated tables + %d row-split tables selected from the received partials)" % (n_sh, n_rep, n_split),
             "achieved": dom[1] / dom[2] / 1e6, "peak": peak, "unit": "GB/s", "frac": dom[1] / dom[2] / 1e6 / peak,
             "traffic": None, "bytes_per_launch": dom[1], "avg_launch_ms": dom[2],
-            "pool": {"ms": t_pool, "bytes": pool_bytes, "tables": n_own}, "interact": {"ms": t_fin, "bytes": fin_bytes}}
+            "pool": {"ms": t_pool, "bytes": pool_bytes, "tables": n_own, "row_ranges": n_split}, "interact": {"ms": t_fin, "bytes": fin_bytes}}
     del op, plans, weights, graphs
     torch.cuda.empty_cache()
     return res
@@ -471,7 +594,12 @@ def bench_sharded(args, ln_emb, rank, world, dev):
     dt = main["dt"]
     lookups = T * Bg
     shape = "Criteo-Kaggle" if sum(ln_emb) < 100_000_000 else "Criteo-Terabyte-shaped"
-    if main["n_sharded"] == 0:
+    if main.get("n_rowsplit"):
+        what = ("%d tables split ROW-WISE over the %d ranks (each rank pools its row range for the global batch; the receiver "
+                "selects the partial of the rank that holds the row) + %d replicated + %d whole tables sharded (%s), one "
+                "all_to_all_single per batch over RCCL/xGMI" % (main["n_rowsplit"], world, main["n_replicated"], main["n_sharded"], policy))
+        par = "row-split x%d + a2a" % world
+    elif main["n_sharded"] == 0:
         what = ("all %d tables replicated on every GPU (%.1f GB of 288 GB): pure data parallel, no exchange step"
                 % (T, sum(ln_emb) * 4 * d / 1e9))
         par = "replicated tables x%d (data parallel)" % world

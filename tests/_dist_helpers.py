@@ -18,10 +18,32 @@ class OracleBackend:
     def make_tables(self, weights, d):
         return [np.ascontiguousarray(w.numpy()) for w in weights]
 
-    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False, bag1=False):
+    def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False, bag1=False,
+                     layout=None, row_lo=None, row_total=None):
         for j, k in enumerate(table_ids_local):
-            pooled = orc.embedding_bag_sum(ev[k], lS_i_rows[j].numpy(), lS_o_rows[j].numpy())
-            send[:, j, :] = torch.from_numpy(pooled)
+            idx, off = lS_i_rows[j].numpy(), lS_o_rows[j].numpy()
+            if row_lo is None:
+                pooled = orc.embedding_bag_sum(ev[k], idx, off)
+            else:
+                # this rank's rows [lo, lo + n) of a row_total-row table: indices of other ranks' rows contribute nothing
+                lo, n = row_lo[j], ev[k].shape[0]
+                assert ((idx >= 0) & (idx < row_total[j])).all()
+                keep = (idx >= lo) & (idx < lo + n)
+                B = off.shape[0]
+                ends = np.concatenate([off[1:], [idx.shape[0]]])
+                new_off = np.zeros(B, np.int64)
+                cnt = np.array([keep[off[b]:ends[b]].sum() for b in range(B)], np.int64)
+                new_off[1:] = np.cumsum(cnt)[:-1]
+                tab = ev[k] if n else np.zeros((1, d), np.float32)
+                pooled = orc.embedding_bag_sum(tab, idx[keep] - lo, new_off)
+            if layout is None:
+                send[:, j, :] = torch.from_numpy(pooled)
+                continue
+            B, foff, tstride, bstride, pstride, bpp = layout
+            flat = send.view(-1)
+            for b in range(B):
+                o = foff + j * tstride + (b // bpp) * pstride + (b % bpp) * bstride if bpp and bpp < B else foff + j * tstride + b * bstride
+                flat[o:o + d] = torch.from_numpy(pooled[b])
 
     def interact_mixed(self, x, specs, ev, d, itself, out=None, planned=False):
         B = x.shape[0]
@@ -29,6 +51,15 @@ class OracleBackend:
         for s in specs:
             if s[0] == "dense":
                 ly.append(s[1].numpy().copy())
+            elif s[0] == "gathered":   # a row-split table: bags over the fp32 rows of a flat buffer, summed in index order
+                _, rows, n_rows, idx, off, nnz, off_len = s
+                tab = rows.numpy()[:n_rows * d].reshape(n_rows, d)
+                idx = idx.numpy()
+                assert ((idx >= 0) & (idx < n_rows)).all()
+                if off is None:
+                    ly.append(tab[idx[:B]].copy())
+                else:
+                    ly.append(orc.embedding_bag_sum(tab, idx[:nnz], off.numpy()[:B]))
             else:
                 _, k, idx, off, nnz, off_len = s
                 if off is None:  # one index per bag: bag b = idx[b]

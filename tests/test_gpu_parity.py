@@ -1086,3 +1086,73 @@ def test_extension_and_ctypes_call_paths_agree(E, orc, bits):
     with pytest.raises(E.EvsError) as e:
         E.apply_emb_interact(xd, od, bad, ev, check_indices=True)
     assert e.value.code == E._lib.EVS_EINDEX
+
+
+@pytest.mark.parametrize("bag1", [True, False])
+@pytest.mark.parametrize("world,policy", [(8, "rows+replicate"), (8, "rows"), (8, "count"), (2, "rowsplit"), (4, "rowsplit"), (8, "rowsplit")])
+def test_sharded_hip_world8_and_rowsplit_virtual_ranks(E, orc, world, policy, bag1):
+    """The target world size (8 virtual ranks on one GPU, the exchange done by hand) with Kaggle-proportioned tables: under
+    rows+replicate 3 ranks own nothing (empty send blocks); `rowsplit` (world 2 / 4 / 8): every rank pools ITS row range of
+    the 5 large tables for the whole global batch with evs_embedding_bag_sum_sharded (ranged rows, peer-major send layout)
+    and the receiver reads the partials inside the receive buffer as gathered features.  R of every rank vs the oracle on
+    its batch slice; with one index per bag the row-split rows are the single-process rows bit for bit (checked through
+    the partials the owner wrote)."""
+    from evstore_dlrm_amd import sharded
+    rs = np.random.RandomState(500 + world + len(policy))
+    ln = [2, 2, 10131, 2202, 2, 2, 12, 2, 3, 93, 5, 8351, 3, 2, 14, 5461, 2, 5, 2, 4, 7046, 2, 2, 286, 2, 142]
+    thresh, d, Bl = 2000, 36, 48
+    Bg, T = world * Bl, len(ln)
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    if bag1:
+        idx = [rs.randint(0, n, size=Bg).astype(np.int64) for n in ln]
+        for k, n in enumerate(ln):
+            idx[k][0], idx[k][-1] = 0, n - 1
+        off = [np.arange(Bg, dtype=np.int64) for _ in ln]
+    else:
+        lens = rs.randint(0, 4, size=(T, Bg))
+        idx = [rs.randint(0, ln[k], size=lens[k].sum()).astype(np.int64) for k in range(T)]
+        off = [np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64) for k in range(T)]
+    lS_i = [torch.from_numpy(i).cuda() for i in idx]
+    lS_o = [torch.from_numpy(o).cuda() for o in off]
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(Bg, d)).astype(np.float32)).cuda()
+    ly_o = orc.apply_emb(off, idx, tabs)
+    R_o = orc.interact_features(x.cpu().numpy(), ly_o)
+    owner = sharded.plan_placement(ln, world, policy, replicate_max_rows=thresh)
+    ops = []
+    for r in range(world):
+        held = {}
+        for t in range(T):
+            if owner[t] in (r, -1):
+                held[t] = torch.from_numpy(tabs[t])
+            elif owner[t] == -2:
+                lo, hi = sharded.row_range(ln[t], r, world)
+                held[t] = torch.from_numpy(np.ascontiguousarray(tabs[t][lo:hi]))
+        ops.append(sharded.ShardedEmbeddingInteract(ln, d, r, world, held, sharded.HipBackend(torch.device("cuda")), policy=policy,
+                                                    replicate_max_rows=thresh, one_index_per_bag=bag1))
+    if policy == "rows+replicate":
+        assert sorted(len(op.my_own) for op in ops) == [0, 0, 0, 1, 1, 1, 1, 1]
+    if policy == "rowsplit":
+        assert all(len(op.split) == 5 and not op.my_own for op in ops)
+    sends = [op.pool(lS_o, lS_i)[0] for op in ops]
+    assert E._lib.lib().evs_check_index_errors(None) == 0      # rows of other ranks' ranges are skipped silently
+    torch.cuda.synchronize()
+    if policy == "rowsplit" and bag1:   # the partial of the rank that holds the row IS the row; everybody else wrote zeros
+        for j, t in enumerate(ops[0].split):
+            for b in range(0, Bg, 7):
+                p_own = int(sharded.row_owner(int(idx[t][b]), ln[t], world))
+                for p in range(world):
+                    blk = sends[p].view(world, -1)[b // Bl]
+                    part = blk[(j * Bl + b % Bl) * d:(j * Bl + b % Bl + 1) * d].cpu().numpy()
+                    want = tabs[t][idx[t][b]] if p == p_own else np.zeros(d, np.float32)
+                    assert np.array_equal(part.view(np.uint32), want.view(np.uint32)), (t, b, p)
+    for r, op in enumerate(ops):
+        _, _, out_splits = op._splits(Bg)
+        recv = torch.cat([sends[p].view(world, -1)[r] for p in range(world)]) if any(o != -1 for o in owner) else sends[r].view(-1)
+        assert recv.numel() == sum(out_splits)
+        R = op.finish((None, recv, Bg, Bl, out_splits), x[r * Bl:(r + 1) * Bl], lS_o, lS_i)
+        np.testing.assert_allclose(R.cpu().numpy(), R_o[r * Bl:(r + 1) * Bl], rtol=RTOL, atol=2e-6)
+        out = torch.empty_like(R)
+        pl = op.plan(x[r * Bl:(r + 1) * Bl], lS_o, lS_i, out=out)
+        pl["recv"].copy_(recv)
+        op.run_finish(pl, None)
+        assert torch.equal(out, R), (policy, r)
