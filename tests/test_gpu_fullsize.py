@@ -1,0 +1,271 @@
+"""GPU, FULL SIZE: exactly what bench.py times for BASELINE configs[2] (EvLFU C1 at 10 % of the Kaggle rows, the batched
+snapshot lookup with the probe folded into the interaction kernel) and configs[4] (u8 C1 + u4 C2 + the alt-key tier at the
+48-48-4 split), at the bench's shape -- Kaggle cardinalities (33.76 M rows), 3 376 257 entries, B = 16 384, T = 26, d = 36,
+both policy updates -- and a Terabyte-cardinality property test (d = 64 and 128, 40 M-row tables, byte offsets > 4 GB).
+
+No CPU reference finishes at these sizes row by row, so the checks are: residency-at-batch-start hit / tier flags (from
+the cache's own dump before the call), R bit-equal to the uncached fused launch over the same tables (a cache serves exact
+copies), R of sampled samples against the oracle, no duplicate keys, size <= capacity -- and the hit RATE against the
+sequential oracle (cache_algo/EvLFU_C1.py restated) replaying the same Zipf stream one request at a time."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+B = 16384
+D = 36
+FILL, CHECKED = 60, 3        # batches that fill the 10 % cache (bench: warmup = 60), batches checked afterwards
+RATE_BAND = 0.03             # |batched hit rate - sequential oracle hit rate| on the same batches
+
+
+@pytest.fixture(scope="module")
+def E():
+    import evstore_dlrm_amd as E
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    E._lib.lib()
+    return E
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def kaggle(E):
+    """the bench's tables and its configs[2] request stream (bench.cache_tier_section: seed 3, Zipf 0.75)"""
+    import bench
+    ln = bench.KAGGLE_LN
+    ev = bench.make_tables(ln, D)
+    batches = bench.make_batches(ln, B, FILL + CHECKED, seed=3, device="cuda", dist="zipf", alpha=0.75)
+    rows = [b[1].t().contiguous().to(torch.int32) for b in batches]
+    yield {"ln": ln, "ev": ev, "batches": batches, "rows": rows, "cap": int(0.10 * sum(ln))}
+    del ev
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="module")
+def oracle_rates(kaggle, orc):
+    """the sequential oracle over the same stream: per-batch hit counts of the CHECKED batches (policy-independent)"""
+    ev, ln = kaggle["ev"], kaggle["ln"]
+    tabs = [ev.fp32_view(k).cpu().numpy() for k in range(len(ln))]
+    o = orc.EvLFU(kaggle["cap"], tabs, D, "python")
+    hits = []
+    for i, r in enumerate(kaggle["rows"]):
+        hr = r.cpu().numpy()
+        n = 0
+        for q in hr:
+            n += int(o.request(q)[0].sum())
+        if i >= FILL:
+            hits.append(n)
+    st = o.state()
+    del o, tabs
+    return {"hits": hits, "size": st["size"]}
+
+
+def _keys(dump):
+    return (dump[:, 1].astype(np.int64) << 32) | dump[:, 2].astype(np.int64)
+
+
+def _query_keys(rows_np):
+    t = np.arange(1, rows_np.shape[1] + 1, dtype=np.int64)[None, :]
+    return (t << 32) | rows_np.astype(np.int64)
+
+
+@pytest.mark.parametrize("policy", ["sampled", "plan"])
+def test_bench_cache_tier_workload_at_full_size(E, orc, kaggle, oracle_rates, policy):
+    ev, ln, cap = kaggle["ev"], kaggle["ln"], kaggle["cap"]
+    T = len(ln)
+    assert cap == 3376257
+    cache = E.GpuCache("evlfu", cap, T, D, 32, "python", "cuda").set_batch_policy(policy)
+    cache.set_backing(ev)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.rand((B, D), device="cuda", generator=g)
+    F = T + 1
+    out = torch.empty((B, D + F * (F - 1) // 2), device="cuda")
+    hit = torch.empty((B, T), dtype=torch.uint8, device="cuda")
+    for i in range(FILL):
+        cache.lookup_interact(kaggle["rows"][i], x, out=out, hit=hit)      # the bench's step
+    st = cache.batch_stats()
+    assert st["size"] > 0.95 * cap, "the fill phase must leave the cache at capacity (the bench times it evicting)"
+    rs = np.random.RandomState(5)
+    hits_batched = []
+    for i in range(FILL, FILL + CHECKED):
+        before = np.sort(_keys(cache.batch_dump()))
+        assert before.size == np.unique(before).size                       # no duplicate keys
+        rows = kaggle["rows"][i]
+        h, R = cache.lookup_interact(rows, x, out=out, hit=hit)
+        torch.cuda.synchronize()
+        rows_np = rows.cpu().numpy()
+        want_hit = np.isin(_query_keys(rows_np), before)                  # residency when the batch starts
+        got_hit = h.cpu().numpy().astype(bool)
+        assert np.array_equal(got_hit, want_hit), "hit flags differ from the snapshot at %d positions" % int((got_hit != want_hit).sum())
+        hits_batched.append(int(got_hit.sum()))
+        # a cache serves exact copies of the table rows: R = the uncached fused launch over the same tables, bit for bit
+        off, idx = kaggle["batches"][i]
+        R_ref = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
+        assert torch.equal(R, R_ref)
+        # ... and sampled samples against the oracle
+        sel = np.sort(rs.choice(B, 48, replace=False))
+        sel_t = torch.from_numpy(sel).cuda()
+        ly = [ev.fp32_view(k)[idx[k][sel_t]].cpu().numpy() for k in range(T)]
+        want = orc.interact_features(x[sel_t].cpu().numpy(), ly)
+        np.testing.assert_allclose(R[sel_t].cpu().numpy(), want, rtol=RTOL, atol=2e-6)
+        st = cache.batch_stats()
+        after = _keys(cache.batch_dump())
+        assert after.size == st["size"] <= cap and np.unique(after).size == after.size
+        # every key a batch HIT is still resident after it under the plan policy (the sampled update may take a key that
+        # was hit in the running batch as a victim: include/evstore_hip.h, evs_cache_set_batch_policy)
+        if policy == "plan":
+            hit_keys = _query_keys(rows_np)[got_hit]
+            assert np.isin(hit_keys, np.sort(after)).all()
+    rate_b = sum(hits_batched) / (CHECKED * B * T)
+    rate_o = sum(oracle_rates["hits"]) / (CHECKED * B * T)
+    print("configs[2] full size, %s: batched hit rate %.4f, sequential oracle %.4f" % (policy, rate_b, rate_o))
+    assert abs(rate_b - rate_o) <= RATE_BAND, (policy, rate_b, rate_o)
+    del cache
+    torch.cuda.empty_cache()
+
+
+def _exact_tables(ln, d, seed):
+    """tables whose values every codec represents exactly (-1, 0, 1): what a key is served does not depend on which
+    tier the batched (racy) routing put it in"""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return [(torch.randint(0, 3, (n, d), device="cuda", generator=g, dtype=torch.int8) - 1).to(torch.float32) for n in ln]
+
+
+@pytest.mark.parametrize("policy", ["sampled", "plan"])
+def test_bench_mixed_precision_tiers_at_full_size(E, orc, policy):
+    """configs[4] as bench.mixed_tiers_section builds it: u8 C1 + u4 C2 at the 48-48-4 split of 2 % of the Kaggle rows
+    (1 296 480 + 2 592 960 entries) and the alt-key tier, B = 16 384, probe + mixed-precision interaction in one launch."""
+    import bench
+    from evstore_dlrm_amd import gpu_cache
+    ln = bench.KAGGLE_LN
+    T = len(ln)
+    ws = _exact_tables(ln, D, 9)
+    ev = E.EVTables(ws, D, 32)
+    ev8, ev4 = ev.encode(8), ev.encode(4)
+    budget = int(0.02 * sum(ln))
+    c1 = E.GpuCache("evlfu", int(0.48 * budget) * 4, T, D, 8, "cpp", "cuda").set_batch_policy(policy)
+    c2 = E.GpuCache("evlfu", int(0.48 * budget) * 8, T, D, 4, "cpp", "cuda").set_batch_policy(policy)
+    assert (c1.capacity, c2.capacity) == (1296480, 2592960)
+    c1.set_backing(ev8)
+    c2.set_backing(ev4)
+    fill, checked = 100, 2
+    rq = [b[1].t().contiguous().to(torch.int32) for b in bench.make_batches(ln, B, fill + 2 * checked + 20, seed=21, device="cuda", dist="zipf", alpha=0.75)]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand((B, D), device="cuda", generator=g)
+    tier = torch.empty((B, T), dtype=torch.uint8, device="cuda")
+    off = torch.arange(B, device="cuda", dtype=torch.int64).repeat(T, 1).contiguous()
+    for r in rq[:fill]:
+        gpu_cache.lookup_interact_c1c2(c1, c2, r, x, tier=tier)
+    assert c1.batch_stats()["size"] > 0.9 * c1.capacity
+    rs = np.random.RandomState(8)
+
+    def check(r, R, tier_np, k1, k2, alt_rows=None):
+        q = _query_keys(r.cpu().numpy())
+        in1, in2 = np.isin(q, k1), np.isin(q, k2)
+        assert np.array_equal(tier_np == 1, in1), "tier 1 flags differ from C1's residency at the batch start"
+        assert np.array_equal(tier_np == 2, in2 & ~in1), "tier 2 flags differ from C2's residency at the batch start"
+        idx = r.t().contiguous().to(torch.int64)
+        if alt_rows is not None:   # tier 3: the ALT row is served (same table here), everything else the key's own row
+            t3 = torch.from_numpy((tier_np == 3).T.copy()).cuda()
+            idx = torch.where(t3, alt_rows, idx)
+        R_ref = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)   # fp32 rows of the same values
+        torch.testing.assert_close(R, R_ref, rtol=RTOL, atol=2e-6)
+        sel = torch.from_numpy(np.sort(rs.choice(B, 32, replace=False))).cuda()
+        ly = [ws[k][idx[k][sel]].cpu().numpy() for k in range(T)]
+        np.testing.assert_allclose(R[sel].cpu().numpy(), orc.interact_features(x[sel].cpu().numpy(), ly), rtol=RTOL, atol=2e-6)
+
+    for r in rq[fill:fill + checked]:
+        k1, k2 = np.sort(_keys(c1.batch_dump())), np.sort(_keys(c2.batch_dump()))
+        assert np.unique(k1).size == k1.size and np.unique(k2).size == k2.size
+        t_, R = gpu_cache.lookup_interact_c1c2(c1, c2, r, x, tier=tier)
+        torch.cuda.synchronize()
+        check(r, R, t_.cpu().numpy(), k1, k2)
+        s1, s2 = c1.batch_stats(), c2.batch_stats()
+        assert s1["size"] <= c1.capacity and s2["size"] <= c2.capacity
+    # the alt-key tier as the bench attaches it: alt key of (t, r) = row r % 4096 of the same table
+    alt = [torch.from_numpy(((np.arange(n, dtype=np.int64) % min(n, 4096)) * 100 + (t + 1)).astype(np.uint32).view(np.int32)).cuda()
+           for t, n in enumerate(ln)]
+    c3 = E.GpuAltKeyTier(int(0.04 * budget) * 8 + 64, alt, "cuda")
+    for r in rq[fill + checked:fill + checked + 20]:
+        gpu_cache.lookup_interact_c1c2c3(c1, c2, c3, r, x, tier=tier)
+    n3 = 0
+    for r in rq[fill + checked + 20:fill + 2 * checked + 20]:
+        k1, k2 = np.sort(_keys(c1.batch_dump())), np.sort(_keys(c2.batch_dump()))
+        members, _ = c3.batch_dump()
+        mk = np.sort((members[:, 0].astype(np.int64) << 32) | members[:, 1].astype(np.int64))
+        t_, R = gpu_cache.lookup_interact_c1c2c3(c1, c2, c3, r, x, tier=tier)
+        torch.cuda.synchronize()
+        tier_np = t_.cpu().numpy()
+        q = _query_keys(r.cpu().numpy())
+        is3 = tier_np == 3
+        n3 += int(is3.sum())
+        # a tier-3 key was a double miss, a member of C3, and its alt row was resident in C1 or C2 when the batch started
+        assert not (is3 & (np.isin(q, k1) | np.isin(q, k2))).any() and np.isin(q[is3], mk).all()
+        rows_np = r.cpu().numpy().astype(np.int64)
+        alt_np = np.stack([rows_np[:, t] % min(n, 4096) for t, n in enumerate(ln)], 1)
+        aq = _query_keys(alt_np)
+        assert (np.isin(aq[is3], k1) | np.isin(aq[is3], k2)).all()
+        check(r, R, np.where(is3, 0, tier_np) if False else tier_np, k1, k2, alt_rows=torch.from_numpy(alt_np.T.copy()).cuda())
+    assert n3 > 0, "the alt-key tier never served a row: the three-tier path was not exercised"
+    del c1, c2, c3, ev, ev8, ev4, ws
+    torch.cuda.empty_cache()
+
+
+# MLPerf DLRM (Criteo Terabyte) cardinalities with --max-ind-range=40000000 (bench/run_and_time.sh:17): external, a
+# synthetic shape only (bench.py --shape terabyte, tools/sweep.py)
+TERABYTE_LN = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
+               4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_terabyte_cardinalities_properties(E, d):
+    """BASELINE configs[3]'s tables on ONE GPU (58 GB at d = 64, 116 GB at d = 128 of the 288 GB): 40 M-row tables of 10 to
+    20 GB each, row byte offsets far beyond 2^32.  bag = 1 -> every pooled row IS the addressed row (exact copy), indices
+    in the LAST rows of the giant tables included; pairs -> the fp32 sum of the two rows; the fused launch = the two-call
+    path bit for bit; x passthrough; one column of the triangle recomputed from the rows."""
+    import bench
+    ln = TERABYTE_LN
+    T = len(ln)
+    ev = bench.make_tables(ln, d, seed=2)
+    Bt = 4096
+    g = torch.Generator(device="cuda").manual_seed(11)
+    idx = torch.stack([torch.randint(0, n, (Bt,), device="cuda", generator=g) for n in ln])
+    for k, n in enumerate(ln):   # the last rows (highest byte offsets) and the first
+        idx[k, :8] = torch.arange(n - 1, max(n - 9, -1), -1, device="cuda")[:8].clamp_(0) if n >= 8 else torch.zeros(8, dtype=torch.int64, device="cuda")
+        idx[k, 8] = 0
+    assert int(idx[0, 0]) * d * 4 > 2 ** 32
+    off = torch.arange(Bt, device="cuda").repeat(T, 1)
+    ly = E.apply_emb(off, idx, ev, check_indices=True)
+    for k in (0, 5, 9, 19, 20, 21, 25):
+        assert torch.equal(ly[k], ev.fp32_view(k)[idx[k]]), k
+    ly1 = E.apply_emb(off, idx, ev, one_index_per_bag=True)
+    for k in range(T):
+        assert torch.equal(ly1[k], ly[k])
+    off2 = (torch.arange(Bt // 2, device="cuda") * 2).repeat(T, 1)
+    ly2 = E.apply_emb(off2, idx, ev)
+    for k in (0, 19, 21):
+        rows = ev.fp32_view(k)[idx[k]]
+        assert torch.equal(ly2[k], rows[0::2] + rows[1::2])
+    x = torch.randn(Bt, d, device="cuda")
+    a = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
+    b = E.apply_emb_interact(x, None, idx, ev, one_index_per_bag=True)
+    c = E.interact_features(x, ly)
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a[:, :d], x)
+    for k in (0, 9, 21, 25):
+        f = k + 1
+        col = d + f * (f - 1) // 2
+        want = (ev.fp32_view(k)[idx[k]].double() * x.double()).sum(1)
+        torch.testing.assert_close(a[:, col].double(), want, rtol=1e-5, atol=1e-6)
+    # a bad index one past the end of a giant table is caught, not read
+    bad = idx.clone()
+    bad[19, 5] = ln[19]
+    with pytest.raises(E.EvsError):
+        E.apply_emb_interact(x, off, bad, ev, check_indices=True)
+    del ev, ly, ly1, ly2
+    torch.cuda.empty_cache()

@@ -1141,16 +1141,18 @@ def test_sharded_hip_world8_and_rowsplit_virtual_ranks(E, orc, world, policy, ba
             for b in range(0, Bg, 7):
                 p_own = int(sharded.row_owner(int(idx[t][b]), ln[t], world))
                 for p in range(world):
-                    blk = sends[p].view(world, -1)[b // Bl]
+                    blk = sends[p].reshape(world, sends[p].numel() // world)[b // Bl]
                     part = blk[(j * Bl + b % Bl) * d:(j * Bl + b % Bl + 1) * d].cpu().numpy()
                     want = tabs[t][idx[t][b]] if p == p_own else np.zeros(d, np.float32)
                     assert np.array_equal(part.view(np.uint32), want.view(np.uint32)), (t, b, p)
     for r, op in enumerate(ops):
         _, _, out_splits = op._splits(Bg)
-        recv = torch.cat([sends[p].view(world, -1)[r] for p in range(world)]) if any(o != -1 for o in owner) else sends[r].view(-1)
+        recv = torch.cat([sends[p].reshape(world, sends[p].numel() // world)[r] for p in range(world)])
         assert recv.numel() == sum(out_splits)
         R = op.finish((None, recv, Bg, Bl, out_splits), x[r * Bl:(r + 1) * Bl], lS_o, lS_i)
-        np.testing.assert_allclose(R.cpu().numpy(), R_o[r * Bl:(r + 1) * Bl], rtol=RTOL, atol=2e-6)
+        # (multi-index bags: 36-term fp32 dot products of pooled sums of up to three rows -- terms up to 9 -- against the
+        # oracle's double accumulation: a few 1e-6 absolute near cancellations)
+        np.testing.assert_allclose(R.cpu().numpy(), R_o[r * Bl:(r + 1) * Bl], rtol=RTOL, atol=2e-6 if bag1 else 1e-5)
         out = torch.empty_like(R)
         pl = op.plan(x[r * Bl:(r + 1) * Bl], lS_o, lS_i, out=out)
         pl["recv"].copy_(recv)
