@@ -51,6 +51,7 @@ _PROTOS = {
     "evs_embedding_bag_sum": (_int, [_int, _i64, _int, _int, _pp, _i64p, _pp, _pp, _i64p, _pp, _vp, _i64, _i64, _vp]),
     "evs_embedding_bag_sum_sharded": (_int, [_int, _i64, _int, _int, _pp, _i64p, _i64p, _i64p, _pp, _pp, _i64p, _pp, _vp, _i64, _i64,
                                              _i64, _i64, _vp]),
+    "evs_rowsplit_route": (_int, [_int, _i64, _int, _pp, _i64p, _i64p, _pp, _vp]),
     "evs_embedding_bag_sum_stacked": (_int, [_int, _i64, _int, _int, _pp, _i64p, _vp, _i64, _i64, _vp, _i64, _pp,
                                              _vp, _i64, _i64, _vp]),
     "evs_check_index_errors": (_int, [_vp]),

@@ -410,6 +410,51 @@ extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const v
                                          out_table_stride, out_bag_stride, 0, 0, stream);
 }
 
+// ---- row-split tables, receiver side: which partial holds the row ---------------------------------------------------------
+namespace evs {
+struct RouteArgs {
+    const int64_t *idx[EVS_MAX_TABLES_PER_LAUNCH];
+    int64_t *dst[EVS_MAX_TABLES_PER_LAUNCH];
+    int64_t n_rows[EVS_MAX_TABLES_PER_LAUNCH];
+    int64_t row_off[64];
+    int64_t B;
+    int T, world;
+};
+__global__ void __launch_bounds__(256) rowsplit_route_kernel(const RouteArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B * a.T) return;
+    const int t = (int)(i / a.B);
+    const int64_t b = i - (int64_t)t * a.B;
+    const int64_t v = a.idx[t][b], n = a.n_rows[t];
+    // rank r holds rows [r*n/W, (r+1)*n/W): the largest r with r*n/W <= v  (sharded.row_owner)
+    int64_t r = n > 0 ? ((v + 1) * a.world + (n - 1)) / n - 1 : 0;
+    r = r < 0 ? 0 : (r >= a.world ? a.world - 1 : r);   // (an index outside the table: the pool launch flagged it)
+    a.dst[t][b] = a.row_off[r] + b;
+}
+}  // namespace evs
+
+extern "C" int evs_rowsplit_route(int T, int64_t B, int world, const int64_t *const *indices, const int64_t *n_rows,
+                                  const int64_t *row_off, int64_t *const *dst, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(T >= 0 && T <= EVS_MAX_TABLES_PER_LAUNCH && B >= 0 && world >= 1 && world <= 64,
+                "evs_rowsplit_route: T=%d (<= %d) B=%lld world=%d (<= 64)", T, EVS_MAX_TABLES_PER_LAUNCH, (long long)B, world);
+    if (T == 0 || B == 0) return EVS_OK;
+    EVS_REQUIRE(indices && n_rows && row_off && dst, "evs_rowsplit_route: NULL argument");
+    RouteArgs a;
+    for (int k = 0; k < EVS_MAX_TABLES_PER_LAUNCH; k++) {
+        a.idx[k] = k < T ? indices[k] : nullptr;
+        a.dst[k] = k < T ? dst[k] : nullptr;
+        a.n_rows[k] = k < T ? n_rows[k] : 0;
+        EVS_REQUIRE(k >= T || (a.idx[k] && a.dst[k]), "evs_rowsplit_route: table %d has a NULL pointer", k);
+    }
+    for (int r = 0; r < 64; r++) a.row_off[r] = r < world ? row_off[r] : 0;
+    a.B = B; a.T = T; a.world = world;
+    const int64_t n = B * T;
+    hipLaunchKernelGGL(rowsplit_route_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    EVS_HIP_CHECK(hipGetLastError());
+    return EVS_OK;
+}
+
 extern "C" int evs_embedding_bag_sum_stacked(int T, int64_t B, int d, int codec, const void *const *tables,
                                              const int64_t *n_rows, const int64_t *indices_base,
                                              int64_t indices_row_stride, int64_t nnz_per_table,

@@ -158,6 +158,20 @@ class HipBackend:
                                                    send.data_ptr() + 4 * foff, tstride, bstride, pstride, bpp,
                                                    _stream_ptr(self.device)))
 
+    def route(self, src_rows, n_rows, world, row_off, dst_rows, key=None):
+        """row-split tables, receiver side: dst[k][b] = row_off[owner(src[k][b])] + b in ONE launch (evs_rowsplit_route)"""
+        n = len(src_rows)
+        ent = self._cache.get(key) if key is not None else None
+        if ent is None:
+            ent = ((C.c_void_p * n)(*[t.data_ptr() for t in src_rows]), (C.c_int64 * n)(*n_rows), (C.c_int64 * world)(*row_off),
+                   (C.c_void_p * n)(*[t.data_ptr() for t in dst_rows]), src_rows, dst_rows)
+            if key is not None:
+                if len(self._cache) > 256:
+                    self._cache.clear()
+                self._cache[key] = ent
+        _lib.check(_lib.lib().evs_rowsplit_route(n, int(src_rows[0].numel()), world, ent[0], ent[1], ent[2], ent[3],
+                                                 _stream_ptr(self.device)))
+
     def interact_mixed(self, x, specs, ev, d, itself, out=None, planned=False):
         """specs[t]: ("dense", tensor(B,d) view) | ("indirect", local_table_id, idx, off, nnz, off_len) |
         ("gathered", rows, n_rows, idx, off, nnz, off_len): like "indirect" over the fp32 rows of `rows` (a flat tensor:
@@ -387,6 +401,11 @@ class ShardedEmbeddingInteract:
     def _reroute(self, pl):
         Bg = pl["Bg"]
         Bl = Bg // self.world
+        if hasattr(self.backend, "route"):   # one launch
+            _, rowoff = self._split_geometry(Bg)
+            self.backend.route(pl["route_src"], [self.ln_emb[t] for t in self.split], self.world, rowoff, pl["route_dst"],
+                               key=("rid", id(pl["route_src"]), id(pl["route_dst"])))
+            return
         ro, ar, _, _, n_col = self._route[(Bg, str(pl["recv"].device))]
         own = row_owner(torch.stack(pl["route_src"]), n_col, self.world).clamp_(0, self.world - 1)
         idx2 = ro[own] + ar[None, :]

@@ -98,6 +98,13 @@ EVS_API int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec,
                           float *out, int64_t out_table_stride, int64_t out_bag_stride,
                           int64_t out_peer_stride, int64_t bags_per_peer, void *stream);
 
+/* Row-split tables, receiver side (one index per bag): sample b of table k reads the partial of the rank whose row range
+ * holds indices[k][b] -- rank r holds rows [r*n/world, (r+1)*n/world) -- i.e. row  row_off[r] + b  of the partials inside
+ * the receive buffer (row_off: HOST array of `world` row offsets, one per source rank).  dst[k][b] (device, int64) receives
+ * that row number: the index list of the "gathered" feature the fused interaction kernel then reads.  T <= 32, world <= 64. */
+EVS_API int evs_rowsplit_route(int T, int64_t B, int world, const int64_t *const *indices, const int64_t *n_rows,
+                               const int64_t *row_off, int64_t *const *dst, void *stream);
+
 /* Same operation for the stacked layout of the Criteo collate
  * (dlrm_data_pytorch.py:397-410: lS_i and lS_o are (T,B) int64 tensors, one row per
  * table): indices[k] = indices_base + k*indices_row_stride (B entries each, i.e.
