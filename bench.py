@@ -727,6 +727,44 @@ def main():
                                   "default because the lazy result is a Sequence, not a list): apply_emb launches nothing, "
                                   "interact_features runs the fused kernel"},
     }
+    # ---- K batches per call: the library's own stream pair (evs_emb_interact_dot_stacked_multi) ----
+    if not args.no_extras:
+        try:
+            Kq = 8
+            nb = len(batches)
+            outs = [torch.empty_like(Rbuf[0]) for _ in range(Kq)]
+            lis = [[batches[(j * Kq + k) % nb][1] for k in range(Kq)] for j in range(nb // Kq)]
+            los = [[batches[(j * Kq + k) % nb][0] for k in range(Kq)] for j in range(nb // Kq)]
+            xs_m = [xs[k % 2] for k in range(Kq)]
+
+            def mstep(i, with_off):
+                E.apply_emb_interact_multi(xs_m, los[i % len(lis)] if with_off else None, lis[i % len(lis)], ev, outs=outs,
+                                           one_index_per_bag=not with_off)
+
+            mb = {}
+            for tag, with_off in (("declared_one_index", False), ("lS_o_given", True)):
+                for i in range(30):
+                    mstep(i, with_off)
+                n_calls = max(40, args.steps // Kq)
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                a_.record()
+                for i in range(n_calls):
+                    mstep(i, with_off)
+                b_.record()
+                torch.cuda.synchronize()
+                per = a_.elapsed_time(b_) / (n_calls * Kq)
+                bps = bytes_per_sample + (8 * T if with_off else 0)
+                mb[tag] = {"ms_per_batch": per, "value": T * B / per * 1e3,
+                           "roofline": {"bound": "hbm", "achieved": B * bps / per / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                        "frac": B * bps / per / 1e6 / HBM_PEAK_GBPS, "bytes_per_batch": B * bps,
+                                        "note": "algorithmic bytes of one batch / stream time per batch (launches of consecutive "
+                                                "batches overlap: per-kernel durations are not additive)"}}
+            result["multi_batch"] = {"batches_per_call": Kq, "batch": B, "unit": "lookups/s", **mb,
+                                     "note": "apply_emb_interact_multi: K batches per call, batch k on the library's stream k % 2 "
+                                             "(forked from / joined into the caller's stream); bit-identical to K single launches"}
+        except Exception as e:
+            result["multi_batch"] = {"error": repr(e)}
     result["general_offsets_path"]["note"] = ("lS_o given (any bag size allowed): offsets checked on the device, the one-index "
                                               "loop runs when they are arange, the general loop when not")
     # ---- the same launch at a larger batch (fixed launch / pipeline-fill cost amortised), and reduced precision ----

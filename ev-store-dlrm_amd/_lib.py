@@ -62,6 +62,7 @@ _PROTOS = {
     "evs_emb_interact_dot": (_int, [_i64, _int, _int, _int, C.POINTER(EvsFeature), _int, _vp, _vp]),
     "evs_emb_interact_dot_stacked": (_int, [_i64, _int, _int, _int, _pp, _i64p, _vp, _i64, _vp, _i64, _i64, _vp, _i64,
                                             _pp, _int, _vp, _vp]),
+    "evs_emb_interact_dot_stacked_multi": (_int, [_int, _i64, _int, _int, _int, _pp, _i64p, _pp, _i64, _pp, _i64, _i64, _pp, _i64, _int, _pp, _vp]),
     "evs_emb_interact_mlp1_stacked": (_int, [_i64, _int, _int, _pp, _i64p, _vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _int, _int, _vp, _vp, _vp]),
     "evs_cache_create": (_int, [_pp, _int, _i64, _int, _int, _int, C.c_double, C.c_double, _int, _int]),
     "evs_cache_destroy": (_int, [_vp]),

@@ -95,6 +95,43 @@ at::Tensor apply_emb_interact(const Tables &ev, const at::Tensor &x, const std::
     return R;
 }
 
+// K independent batches in one call (evs_emb_interact_dot_stacked_multi): lists of K tensors, same shapes
+std::vector<at::Tensor> apply_emb_interact_multi(const Tables &ev, const std::vector<at::Tensor> &xs,
+                                                 const std::optional<std::vector<at::Tensor>> &lS_os, const std::vector<at::Tensor> &lS_is,
+                                                 bool itself, std::optional<std::vector<at::Tensor>> outs, bool one_index_per_bag) {
+    const int K = static_cast<int>(xs.size());
+    TORCH_CHECK(K >= 1 && (int)lS_is.size() == K, "apply_emb_interact_multi: K tensors of each kind");
+    const int64_t B = xs[0].size(0);
+    const int T = ev.T, d = ev.d, F = T + 1;
+    const int64_t Kc = d + pairs(F, itself);
+    const bool no_off = one_index_per_bag && lS_is[0].size(1) == B;
+    TORCH_CHECK(no_off || (lS_os.has_value() && (int)lS_os->size() == K), "lS_o is required unless one_index_per_bag is declared");
+    std::vector<at::Tensor> R;
+    std::vector<const float *> xp(K);
+    std::vector<const int64_t *> ip(K), op(K);
+    std::vector<float *> rp(K);
+    for (int k = 0; k < K; k++) {
+        check_x(xs[k], B, d);
+        check_idx(lS_is[k], "lS_i");
+        TORCH_CHECK(lS_is[k].size(0) == T && lS_is[k].size(1) == lS_is[0].size(1) && lS_is[k].stride(0) == lS_is[0].stride(0) &&
+                    xs[k].stride(0) == xs[0].stride(0), "apply_emb_interact_multi: every batch must have the same shape and strides");
+        if (!no_off) {
+            check_idx((*lS_os)[k], "lS_o");
+            TORCH_CHECK((*lS_os)[k].size(0) == T && (*lS_os)[k].size(1) == B && (*lS_os)[k].stride(0) == (*lS_os)[0].stride(0), "lS_o must be (T, B)");
+            op[k] = (*lS_os)[k].data_ptr<int64_t>();
+        }
+        at::Tensor r = outs.has_value() ? (*outs)[k] : at::empty({B, Kc}, xs[k].options());
+        TORCH_CHECK(r.is_cuda() && r.scalar_type() == at::kFloat && r.dim() == 2 && r.size(0) == B && r.size(1) == Kc && r.is_contiguous(),
+                    "out must be a contiguous (B, d + P) fp32 device tensor");
+        xp[k] = xs[k].data_ptr<float>(); ip[k] = lS_is[k].data_ptr<int64_t>(); rp[k] = r.data_ptr<float>();
+        R.push_back(std::move(r));
+    }
+    check(evs_emb_interact_dot_stacked_multi(K, B, T, d, ev.codec, ev.ptrs.data(), ev.n_rows.data(), xp.data(), B > 1 ? xs[0].stride(0) : d,
+                                             ip.data(), lS_is[0].stride(0), lS_is[0].size(1), no_off ? nullptr : op.data(),
+                                             no_off ? 0 : (*lS_os)[0].stride(0), itself ? 1 : 0, rp.data(), stream_of(ev.device)));
+    return R;
+}
+
 // apply_emb, stacked Criteo layout -> the (T, B, d) buffer whose T slices are the list the reference returns
 at::Tensor apply_emb(const Tables &ev, const std::optional<at::Tensor> &lS_o, const at::Tensor &lS_i, bool one_index_per_bag,
                      bool check_indices) {
@@ -251,6 +288,8 @@ PYBIND11_MODULE(_evs_torch_ext, m) {
     m.def("abi_version", []() { return evs_abi_version(); });
     m.def("apply_emb_interact", &apply_emb_interact, py::arg("ev"), py::arg("x"), py::arg("lS_o"), py::arg("lS_i"), py::arg("itself") = false,
           py::arg("out") = py::none(), py::arg("one_index_per_bag") = false, py::arg("check_indices") = false);
+    m.def("apply_emb_interact_multi", &apply_emb_interact_multi, py::arg("ev"), py::arg("xs"), py::arg("lS_os"), py::arg("lS_is"),
+          py::arg("itself") = false, py::arg("outs") = py::none(), py::arg("one_index_per_bag") = false);
     m.def("apply_emb", &apply_emb, py::arg("ev"), py::arg("lS_o"), py::arg("lS_i"), py::arg("one_index_per_bag") = false,
           py::arg("check_indices") = false);
     m.def("interact_dot", &interact_dot);

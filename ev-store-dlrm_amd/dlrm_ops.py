@@ -432,6 +432,42 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
     return R
 
 
+def apply_emb_interact_multi(xs, lS_os, lS_is, emb_l, arch_interaction_itself=False, outs=None, one_index_per_bag=False):
+    """K independent batches -- lists of K x (B,d), lS_o (T,B) (or None with one_index_per_bag), lS_i (T,B) -- in ONE call:
+    [apply_emb_interact(xs[k], lS_os[k], lS_is[k], emb_l) for k in range(K)], bit for bit, with batch k on the library's
+    own stream k % 2 (forked from and joined back into torch's current stream): the drain of one launch overlaps the fill
+    of the next, the rate of a caller alternating two streams without managing any (evs_emb_interact_dot_stacked_multi).
+    Stacked Criteo layout, unweighted; every batch the same shape."""
+    ev = _as_evtables(emb_l)
+    K = len(xs)
+    assert K >= 1 and len(lS_is) == K and (lS_os is None or len(lS_os) == K) and (outs is None or len(outs) == K)
+    T, d = len(ev), ev.d
+    F = T + 1
+    if not fused_supported(F, d):
+        return [apply_emb_interact(xs[k], None if lS_os is None else lS_os[k], lS_is[k], ev, None, arch_interaction_itself,
+                                   out=None if outs is None else outs[k], one_index_per_bag=one_index_per_bag) for k in range(K)]
+    xt = ev.ext_tables()
+    if xt is not None:
+        return _ext.ext().apply_emb_interact_multi(xt, list(xs), None if lS_os is None else list(lS_os), list(lS_is),
+                                                   bool(arch_interaction_itself), None if outs is None else list(outs), bool(one_index_per_bag))
+    B = int(xs[0].shape[0])
+    P = F * (F + 1) // 2 if arch_interaction_itself else F * (F - 1) // 2
+    no_off = one_index_per_bag and int(lS_is[0].shape[1]) == B
+    assert no_off or lS_os is not None, "lS_o is required unless one_index_per_bag is declared"
+    Rs = list(outs) if outs is not None else [torch.empty((B, d + P), dtype=torch.float32, device=ev.device) for _ in range(K)]
+    for k in range(K):
+        assert xs[k].is_cuda and xs[k].dtype == torch.float32 and xs[k].shape == (B, d) and xs[k].stride() == xs[0].stride()
+        assert lS_is[k].is_cuda and lS_is[k].dtype == torch.int64 and lS_is[k].shape == lS_is[0].shape and lS_is[k].stride() == lS_is[0].stride()
+        assert Rs[k].shape == (B, d + P) and Rs[k].is_contiguous() and Rs[k].dtype == torch.float32
+        assert no_off or (lS_os[k].is_cuda and lS_os[k].dtype == torch.int64 and lS_os[k].shape == (T, B) and lS_os[k].stride() == lS_os[0].stride())
+    arr = lambda ts: (C.c_void_p * K)(*[t.data_ptr() for t in ts])
+    _lib.check(_lib.lib().evs_emb_interact_dot_stacked_multi(
+        K, B, T, d, ev.codec, ev._tables_c, ev._n_rows_c, arr(xs), int(xs[0].stride(0)) if B > 1 else d, arr(lS_is),
+        lS_is[0].stride(0), int(lS_is[0].shape[1]), None if no_off else arr(lS_os), 0 if no_off else lS_os[0].stride(0),
+        int(bool(arch_interaction_itself)), arr(Rs), _stream_ptr(ev.device)))
+    return Rs
+
+
 _w1_cache = {}
 
 

@@ -204,6 +204,18 @@ EVS_API int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec,
                                  int64_t nnz_per_table,
                                  const int64_t *offsets_base, int64_t offsets_row_stride,
                                  const float *const *row_weights, int itself, float *R, void *stream);
+
+/* K independent batches of B samples in one call (a serving loop's queue): x, indices_base, offsets_base (NULL = one
+ * index per bag for every batch) and R are HOST arrays of K device pointers, every batch with the same shape and strides.
+ * Batch k runs on the library's own stream k % 2 -- the drain of one launch overlaps the fill of the next, the rate a
+ * caller alternating two HIP streams gets -- forked from `stream` and joined back into it: work queued on `stream` before
+ * the call is visible to every batch, work queued after it sees all K results.  Bit-identical to K calls of
+ * evs_emb_interact_dot_stacked.  Not re-entrant across host threads for the same device (serialised internally). */
+EVS_API int evs_emb_interact_dot_stacked_multi(int K, int64_t B, int T, int d, int codec, const void *const *tables,
+                                               const int64_t *n_rows, const float *const *x, int64_t x_stride,
+                                               const int64_t *const *indices_base, int64_t indices_row_stride,
+                                               int64_t nnz_per_table, const int64_t *const *offsets_base,
+                                               int64_t offsets_row_stride, int itself, float *const *R, void *stream);
 /* SURVEY 8(f).3, second half: the apply_emb -> interact_features -> FIRST top-MLP layer chain of
  * DLRM_Net.sequential_forward (dlrm_s_pytorch.py:596-605) in one launch: Z1 = act(R W1^T + b1), act = ReLU when relu != 0
  * (create_mlp, dlrm_s_pytorch.py:205-245: nn.Linear + nn.ReLU).  The interaction rows of 16 samples stay in LDS and feed

@@ -117,11 +117,6 @@ def test_bench_cache_tier_workload_at_full_size(E, orc, kaggle, oracle_rates, po
         st = cache.batch_stats()
         after = _keys(cache.batch_dump())
         assert after.size == st["size"] <= cap and np.unique(after).size == after.size
-        # every key a batch HIT is still resident after it under the plan policy (the sampled update may take a key that
-        # was hit in the running batch as a victim: include/evstore_hip.h, evs_cache_set_batch_policy)
-        if policy == "plan":
-            hit_keys = _query_keys(rows_np)[got_hit]
-            assert np.isin(hit_keys, np.sort(after)).all()
     rate_b = sum(hits_batched) / (CHECKED * B * T)
     rate_o = sum(oracle_rates["hits"]) / (CHECKED * B * T)
     print("configs[2] full size, %s: batched hit rate %.4f, sequential oracle %.4f" % (policy, rate_b, rate_o))

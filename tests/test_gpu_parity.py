@@ -1158,3 +1158,44 @@ def test_sharded_hip_world8_and_rowsplit_virtual_ranks(E, orc, world, policy, ba
         pl["recv"].copy_(recv)
         op.run_finish(pl, None)
         assert torch.equal(out, R), (policy, r)
+
+
+@pytest.mark.parametrize("K,B,declared", [(2, 16384, True), (5, 4096, False), (3, 1000, True), (1, 777, False)])
+def test_multi_batch_call_equals_single_launches(E, orc, K, B, declared):
+    """evs_emb_interact_dot_stacked_multi (K batches in one call, alternating over the library's stream pair, forked from
+    and joined into the caller's stream) == K single launches, bit for bit; the join really orders the caller's stream
+    behind all K results (a copy queued right after the call sees them); through the extension and through ctypes."""
+    from evstore_dlrm_amd import _ext
+    rs = np.random.RandomState(K * 1000 + B)
+    T, d = 26, 36
+    n_rows = [int(v) for v in rs.choice([3, 40, 999, 200000], size=T)]
+    ev = E.EVTables.from_fp32([torch.from_numpy(rs.uniform(-1, 1, size=(n, d)).astype(np.float32)) for n in n_rows])
+    xs = [torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda() for _ in range(K)]
+    idx = [_dev(np.stack([rs.randint(0, n, size=B) for n in n_rows]).astype(np.int64)) for _ in range(K)]
+    off = [_dev(np.tile(np.arange(B, dtype=np.int64), (T, 1))) for _ in range(K)]
+    want = [E.apply_emb_interact(xs[k], off[k], idx[k], ev, one_index_per_bag=declared) for k in range(K)]
+    torch.cuda.synchronize()
+
+    def run():
+        outs = [torch.zeros_like(w) for w in want]
+        got = E.apply_emb_interact_multi(xs, None if declared else off, idx, ev, outs=outs, one_index_per_bag=declared)
+        snap = torch.stack(got).clone()          # queued on the caller's stream right behind the call
+        alloc = E.apply_emb_interact_multi(xs, off, idx, ev, one_index_per_bag=declared)
+        torch.cuda.synchronize()
+        for k in range(K):
+            assert got[k].data_ptr() == outs[k].data_ptr()
+            assert torch.equal(got[k], want[k]) and torch.equal(snap[k], want[k]) and torch.equal(alloc[k], want[k]), k
+
+    assert _ext.ext() is not None
+    run()
+    saved = (_ext._mod, _ext._tried)
+    _ext._mod, _ext._tried = None, True
+    ev._xt = None
+    try:
+        run()
+    finally:
+        _ext._mod, _ext._tried = saved
+    # one oracle check so that "equal to each other" cannot mean "equally wrong"
+    k = K - 1
+    ly = [ev.fp32_view(t)[idx[k][t]].cpu().numpy() for t in range(T)]
+    np.testing.assert_allclose(want[k].cpu().numpy(), orc.interact_features(xs[k].cpu().numpy(), ly), rtol=RTOL, atol=2e-6)
