@@ -308,7 +308,8 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
     if policy:
         cache.set_batch_policy(policy)
     cache.set_backing(ev)
-    batches = make_batches(ln_emb, B, warmup + steps, seed=3, device=dev, dist="zipf", alpha=alpha)  # no batch repeats
+    n_cmp = 20 if batch1 else 0   # batches on which the batched hit rate is compared with the sequential oracle's (untimed)
+    batches = make_batches(ln_emb, B, warmup + n_cmp + steps, seed=3, device=dev, dist="zipf", alpha=alpha)  # no batch repeats
     rows = [b[1].t().contiguous().to(torch.int32) for b in batches]  # (B,T) int32 request rows
     x = torch.rand((B, d), device=dev)
     F = T + 1
@@ -320,6 +321,32 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
 
     for i in range(warmup):
         step(i)
+    # hit rate against the SEQUENTIAL oracle (cache_algo/EvLFU_C1.py restated, one request at a time) on the same history:
+    # the `warmup` fill batches, then n_cmp batches on which both rates are taken (tests/test_gpu_fullsize.py asserts the
+    # band at this very configuration)
+    oracle_cmp = None
+    if n_cmp:
+        c0 = cache.batch_stats()
+        for i in range(n_cmp):
+            step(warmup + i)
+        c1_ = cache.batch_stats()
+        oracle_cmp = {"batches": n_cmp, "after_fill_batches": warmup, "hit_rate_batched": (c1_["n_hits"] - c0["n_hits"]) / (T * B * n_cmp)}
+        try:
+            from oracle import oracle as orc
+            t_o = time.perf_counter()
+            tabs_o = [ev.fp32_view(k).cpu().numpy() for k in range(T)]
+            oc = orc.EvLFU(cap, tabs_o, d, "python")
+            oh = 0
+            for i in range(warmup + n_cmp):
+                for q in rows[i].cpu().numpy():
+                    h_ = oc.request(q)[0]
+                    if i >= warmup:
+                        oh += int(h_.sum())
+            oracle_cmp["oracle_hit_rate"] = oh / (T * B * n_cmp)
+            oracle_cmp["oracle_seconds"] = time.perf_counter() - t_o
+            del oc, tabs_o
+        except Exception as e:   # the oracle is test infrastructure: its absence must not break the bench
+            oracle_cmp["oracle_error"] = repr(e)
     # clock settle (as for the headline): keep the GPU busy with replayed warm-up batches for >= 0.35 s -- a 3 ms timed
     # region right after the host-side batch generation otherwise reads anywhere between 105 and 165 us per batch
     t_s = time.perf_counter()
@@ -333,7 +360,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
     t0 = time.perf_counter()
     e0.record()
     for i in range(steps):
-        step(warmup + i)   # batches the cache has not seen
+        step(warmup + n_cmp + i)   # batches the cache has not seen
     e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -470,7 +497,8 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
                     "note": "evs_cache_set_batch_policy(0): insert / plan / evict / assign / close (the round-1 form)"}
         except Exception as e:
             plan = {"error": repr(e)}
-    return {"value": looks / dt, "policy": policy or "sampled", "timed_batches": steps, "plan_policy": plan, "roofline": tier_roof, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
+    return {"value": looks / dt, "policy": policy or "sampled", "timed_batches": steps, "oracle_hit_rate": None if not oracle_cmp else oracle_cmp.get("oracle_hit_rate"),
+            "hit_rate_vs_sequential_oracle": oracle_cmp, "plan_policy": plan, "roofline": tier_roof, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
             "hit_rate": (s1["n_hits"] - s0["n_hits"]) / looks, "capacity_entries": cap,
             "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"],
             "workload": "BASELINE configs[2]: EvLFU C1 in HBM at %.0f%% of 33.76M rows, Zipf(alpha=%.2f) indices, "
