@@ -5,6 +5,8 @@
 
 namespace evs {
 
+constexpr int kMultiMax = 8;   // batches per multi launch (more: several launches)
+
 struct FusedArgs {
     const void *src[EVS_MAX_FEATURES];        // dense: fp32 rows; indirect: table bytes
     int64_t stride[EVS_MAX_FEATURES];         // dense: floats between samples
@@ -44,6 +46,15 @@ struct FusedArgs {
     ProbeArgs probe;
     // evs_fused_rfq.hip: 1 KiB of the code that decodes to 0.0f (zero_code_page) -- the "row" of an absent table row
     const void *zero_codes;
+    // evs_fused_rf.hip, K batches in ONE launch (evs_emb_interact_dot_stacked_multi): block i works on chunk i % multi_cpb of
+    // batch i / multi_cpb -- feature 0 (x), the (T, B) index / offsets arrays and R of that batch come from these tables,
+    // everything else (tables, shapes) is shared.  multi_n == 0: a plain launch.
+    int multi_n = 0, multi_cpb = 0;
+    int64_t multi_idx_stride, multi_off_stride;   // elements between the rows of two tables in a batch's (T, B) arrays
+    const float *multi_x[kMultiMax];
+    const int64_t *multi_idx[kMultiMax];
+    const int64_t *multi_off[kMultiMax];
+    float *multi_R[kMultiMax];
 };
 
 
@@ -55,6 +66,9 @@ bool launch_rf(const FusedArgs &a, hipStream_t st);
 // ... with lS_o given (bag1 == 3: whole batches): the offsets of each block's 16 samples checked in the kernel, the blocks
 // that fail pooled in its own slow loop
 bool launch_rf_check(const FusedArgs &a, hipStream_t st);
+// K batches in one launch (FusedArgs::multi_*): bag1 == 1 (declared one index per bag) or 3 (offsets given, checked per block)
+bool rf_multi_supported(int64_t B, int F, int d);
+bool launch_rf_multi(const FusedArgs &a, hipStream_t st);
 // the same kernel with the first top-MLP layer behind it (any batch size); false = no kernel for the shape
 bool launch_rf_mlp(const FusedArgs &a, hipStream_t st);
 // the same kernel reading a (B, F-1) table of 32-bit row ids (the cache tier's consumer); rf_ids_supported: is there a

@@ -1504,37 +1504,15 @@ extern "C" int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec, 
     return evs_emb_interact_dot(B, T + 1, d, codec, ft, itself, R, stream);
 }
 
-// K independent batches in ONE call (a serving loop's queue of requests): batch k runs on the library's own stream k % 2,
-// so the drain of one launch (output rows of the last samples still leaving) overlaps the fill of the next (indices, then
-// rows, before the first MFMA) -- what a caller alternating two HIP streams measures as 16.5-18.5 us per 16 384-sample batch
-// instead of 19-20 (`two_streams`), without managing streams: the pair forks from `stream` (everything
-// queued on it before the call is visible to every batch) and joins back into it (whatever the caller queues next sees all
-// K results).  Results are bit-identical to K evs_emb_interact_dot_stacked calls.
-namespace evs {
-struct StreamPair {
-    hipStream_t s[2] = {nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
-    bool ok = false;
-};
-static StreamPair *stream_pair() {
-    static std::mutex mu;
-    static StreamPair pairs[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    StreamPair &p = pairs[dev];
-    if (!p.ok) {
-        if (hipStreamCreateWithFlags(&p.s[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p.s[1], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p.join[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&p.join[1], hipEventDisableTiming) != hipSuccess)
-            return nullptr;
-        p.ok = true;
-    }
-    return &p;
-}
-static std::mutex g_multi_mu;   // one fork / join in flight per process: the pair's events are shared
-}  // namespace evs
-
+// K independent batches in ONE call (a serving loop's queue of requests) = ONE launch for up to kMultiMax of them
+// (evs_fused_rf.hip: K * ceil(B / 16) one-chunk blocks, each reading its batch's x / indices / offsets / R from a table in
+// the kernel arguments).  The hardware hands a CU the next block as one retires, so the drain of one batch (output rows
+// of its last samples still leaving) runs under the fill of the next (indices, then rows, before the first MFMA): 15.5-16.2
+// us per 16 384-sample batch instead of 19-20 for K launches -- the rate a caller alternating two HIP streams gets,
+// without any stream.  (A stream pair inside the library, forked from and joined into the caller's stream, was built first
+// and measured: 21.7-24.3 us per batch -- cross-stream event waits cost more on this stack than the overlap returns;
+// tools/multi_probe.py)  Shapes the one-chunk kernel does not take (reduced precision, d = 48 / 64 / 128,
+// F > 28) run as K launches.  Results are bit-identical to K evs_emb_interact_dot_stacked calls either way.
 extern "C" int evs_emb_interact_dot_stacked_multi(int K, int64_t B, int T, int d, int codec, const void *const *tables,
                                                   const int64_t *n_rows, const float *const *x, int64_t x_stride,
                                                   const int64_t *const *indices_base, int64_t indices_row_stride,
@@ -1543,29 +1521,59 @@ extern "C" int evs_emb_interact_dot_stacked_multi(int K, int64_t B, int T, int d
     using namespace evs;
     EVS_REQUIRE(K >= 0 && K <= 4096, "evs_emb_interact_dot_stacked_multi: K=%d", K);
     if (K == 0 || B == 0) return EVS_OK;
-    EVS_REQUIRE(x && indices_base && R, "evs_emb_interact_dot_stacked_multi: NULL argument");
+    EVS_REQUIRE(x && indices_base && R && tables && n_rows, "evs_emb_interact_dot_stacked_multi: NULL argument");
+    EVS_REQUIRE(T >= 0 && T + 1 <= EVS_MAX_FEATURES, "evs_emb_interact_dot_stacked_multi: T=%d (need T+1 <= %d)", T, EVS_MAX_FEATURES);
     for (int k = 0; k < K; k++)
-        EVS_REQUIRE(x[k] && indices_base[k] && R[k], "evs_emb_interact_dot_stacked_multi: batch %d has a NULL pointer", k);
-    if (K == 1)
-        return evs_emb_interact_dot_stacked(B, T, d, codec, tables, n_rows, x[0], x_stride, indices_base[0], indices_row_stride, nnz_per_table,
-                                            offsets_base ? offsets_base[0] : nullptr, offsets_row_stride, nullptr, itself, R[0], stream);
-    StreamPair *sp = stream_pair();
-    if (!sp) { set_error("evs_emb_interact_dot_stacked_multi: creating the stream pair failed"); return EVS_EHIP; }
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    std::lock_guard<std::mutex> lk(g_multi_mu);
-    EVS_HIP_CHECK(hipEventRecord(sp->fork, st));
-    EVS_HIP_CHECK(hipStreamWaitEvent(sp->s[0], sp->fork, 0));
-    EVS_HIP_CHECK(hipStreamWaitEvent(sp->s[1], sp->fork, 0));
-    int rc = EVS_OK;
-    for (int k = 0; k < K && rc == EVS_OK; k++)
-        rc = evs_emb_interact_dot_stacked(B, T, d, codec, tables, n_rows, x[k], x_stride, indices_base[k], indices_row_stride, nnz_per_table,
-                                          offsets_base ? offsets_base[k] : nullptr, offsets_row_stride, nullptr, itself, R[k], sp->s[k & 1]);
-    // join even after a failed launch: the caller's stream must not run ahead of what WAS queued
-    for (int j = 0; j < 2; j++) {
-        EVS_HIP_CHECK(hipEventRecord(sp->join[j], sp->s[j]));
-        EVS_HIP_CHECK(hipStreamWaitEvent(st, sp->join[j], 0));
+        EVS_REQUIRE(x[k] && indices_base[k] && R[k] && (!offsets_base || offsets_base[k]), "evs_emb_interact_dot_stacked_multi: batch %d has a NULL pointer", k);
+    const int F = T + 1;
+    static const bool one_launch = !(getenv("EVS_FUSED_MULTI") && getenv("EVS_FUSED_MULTI")[0] == '0');
+    // the one-launch form: fp32 tables, whole batches (nnz == B: what makes lS_o checkable per block), aligned operands
+    bool fast = one_launch && K > 1 && codec == 32 && T >= 1 && nnz_per_table == B && B < (1ll << 31) && rf_multi_supported(B, F, d) &&
+                x_stride % 4 == 0 && x_stride >= 0 && x_stride < (1ll << 31) && optimistic_enabled();
+    for (int k = 0; k < K && fast; k++) fast = reinterpret_cast<uintptr_t>(x[k]) % 16 == 0;
+    for (int t = 0; t < T && fast; t++) fast = tables[t] && reinterpret_cast<uintptr_t>(tables[t]) % 16 == 0 && n_rows[t] >= 0 && n_rows[t] < (1ll << 31);
+    if (!fast) {
+        for (int k = 0; k < K; k++) {
+            const int rc = evs_emb_interact_dot_stacked(B, T, d, codec, tables, n_rows, x[k], x_stride, indices_base[k], indices_row_stride, nnz_per_table,
+                                                        offsets_base ? offsets_base[k] : nullptr, offsets_row_stride, nullptr, itself, R[k], stream);
+            if (rc) return rc;
+        }
+        return EVS_OK;
     }
-    return rc;
+    FusedArgs a;
+    for (int f = 0; f < EVS_MAX_FEATURES; f++) {
+        a.src[f] = nullptr; a.stride[f] = 0; a.indices[f] = nullptr; a.offsets[f] = nullptr; a.nnz[f] = 0;
+        a.n_rows[f] = 0; a.row_w[f] = nullptr; a.off_len[f] = B;
+    }
+    a.src[0] = x[0]; a.stride[0] = x_stride;
+    for (int t = 0; t < T; t++) {
+        a.src[t + 1] = tables[t];
+        a.indices[t + 1] = indices_base[0] + (int64_t)t * indices_row_stride;   // (non-NULL marks a table; the kernel reads multi_idx)
+        a.offsets[t + 1] = offsets_base ? offsets_base[0] + (int64_t)t * offsets_row_stride : nullptr;
+        a.nnz[t + 1] = B; a.n_rows[t + 1] = n_rows[t];
+    }
+    a.zeros = zero_page();
+    a.err = index_error_flag();
+    if (!a.zeros || !a.err) return EVS_EHIP;
+    for (int t = 0; t < T; t++) if (n_rows[t] == 0) a.src[t + 1] = a.zeros;
+    a.B = B; a.F = F; a.d = d; a.itself = itself ? 1 : 0; a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    a.dummy_i64 = indices_base[0]; a.dummy_f32 = x[0]; a.bag1 = offsets_base ? 3 : 1; a.enc_lds = 0; a.opt_flag = nullptr; a.opt_id = 0;
+    a.tile_per = 16; a.row_ids = nullptr; a.arena = nullptr; a.w1p = nullptr; a.b1 = nullptr; a.z1 = nullptr; a.n1 = 0; a.kp = 0; a.relu = 0; a.write_r = 1;
+    a.zero_codes = nullptr;
+    a.multi_idx_stride = indices_row_stride; a.multi_off_stride = offsets_row_stride;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int k0 = 0; k0 < K; k0 += kMultiMax) {
+        const int n = K - k0 < kMultiMax ? K - k0 : kMultiMax;
+        for (int k = 0; k < kMultiMax; k++) {
+            const int kk = k < n ? k0 + k : k0;
+            a.multi_x[k] = x[kk]; a.multi_idx[k] = indices_base[kk]; a.multi_off[k] = offsets_base ? offsets_base[kk] : nullptr; a.multi_R[k] = R[kk];
+        }
+        a.multi_n = n;
+        a.R = R[k0];
+        if (!launch_rf_multi(a, st)) { set_error("evs_emb_interact_dot_stacked_multi: no kernel for this shape"); return EVS_EINVAL; }
+        EVS_HIP_CHECK(hipGetLastError());
+    }
+    return EVS_OK;
 }
 
 // R = interact_features(x, apply_emb(...)) followed by the FIRST layer of the top MLP, Z1 = act(R W1^T + b1), in one

@@ -107,8 +107,16 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     const char *zeros_l = reinterpret_cast<const char *>(args.zeros);
 
     // ---- the block's sample range and the feature table of the tile ------------------------------------
+    // K batches in one launch (multi_n > 0; plain and CHECK launches): block i = chunk i % multi_cpb of batch i / multi_cpb;
+    // sample numbers below are the batch's own, x / indices / offsets / R come from the batch's entries
     const int64_t per = args.tile_per;
-    const int64_t blk_first = (int64_t)blockIdx.x * per;
+    int blk_id = (int)blockIdx.x, batch_k = 0;
+    if constexpr (!MLP && !IDS && !PROBE) {
+        if (args.multi_n > 0) { batch_k = blk_id / args.multi_cpb; blk_id -= batch_k * args.multi_cpb; }
+    }
+    const bool multi = !MLP && !IDS && !PROBE && args.multi_n > 0;
+    float *const R_base = multi ? ka->multi_R[batch_k] : args.R;
+    const int64_t blk_first = (int64_t)blk_id * per;
     const int64_t blk_end = blk_first + per < B ? blk_first + per : B;
     if (blk_first >= blk_end) return;       // block-uniform
     const int blk_n = (int)(blk_end - blk_first);
@@ -116,14 +124,15 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     if (threadIdx.x < 32) {
         const int f = (int)threadIdx.x;
         const int64_t *ip = f < F ? ka->indices[f] : nullptr;
+        if (multi && f >= 1 && f < F) ip = ka->multi_idx[batch_k] + (int64_t)(f - 1) * args.multi_idx_stride;
         const bool table = (IDS || PROBE) ? (f >= 1 && f < F) : ip != nullptr;
         s_tile_p[f] = ip;
         s_tile_nr[f] = f < F ? (unsigned)ka->n_rows[f] : 0u;
         s_tile_kind[f] = f >= F ? 0 : (table ? 2 : 1);
-        s_feat_base[f] = f < F ? (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]) : 0ull;
+        s_feat_base[f] = f < F ? (unsigned long long)reinterpret_cast<uintptr_t>((multi && f == 0) ? (const void *)ka->multi_x[batch_k] : ka->src[f]) : 0ull;
         s_feat_scale[f] = f >= F ? 0u : (table ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4));
         if constexpr (CHECK) {
-            s_tile_o[f] = table ? ka->offsets[f] : nullptr;
+            s_tile_o[f] = table ? (multi ? ka->multi_off[batch_k] + (int64_t)(f - 1) * args.multi_off_stride : ka->offsets[f]) : nullptr;
             s_tile_ol[f] = table ? ka->off_len[f] : 0;
             s_tile_nz[f] = table ? ka->nnz[f] : 0;
         }
@@ -149,7 +158,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     //  its vector-memory operations, see the main loop)
     auto flush_out = [&](int64_t bp, bool on) {
         if constexpr (MLP) on = on && args.write_r;
-        float *Rb = args.R + (on ? bp : 0) * (int64_t)out_row;
+        float *Rb = R_base + (on ? bp : 0) * (int64_t)out_row;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, on ? out_row * 4 : 0, 0x00020000);
         const int n4 = out_row >> 2;   // whole 16-byte pieces; the 0..3 trailing floats go as dwords
         // (always the same number of store instructions: out-of-range lanes and whole out-of-range instructions are
@@ -391,15 +400,15 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
                         auto chunk_at = [&](const char *row, int c) -> float4 {
                             return *reinterpret_cast<const float4 *>(row + (c < CQ ? (q * CQ + c) * 16 : kRemOff + (c - CQ) * 16));
                         };
-                        const int64_t *ip = ka->indices[f];
-                        const char *src = reinterpret_cast<const char *>(ka->src[f]);
+                        const int64_t *ip = s_tile_p[f];                                            // (multi: this batch's arrays)
+                        const char *src = reinterpret_cast<const char *>((uintptr_t)s_feat_base[f]);
                         if (!ip) {   // dense feature (x, received pooled vectors)
                             const char *row = src + (uint64_t)b * (uint64_t)(ka->stride[f] * 4);
 #pragma unroll
                             for (int c = 0; c < NC; c++) a[rr][c] = chunk_at(row, c);
                             continue;
                         }
-                        const int64_t *op = ka->offsets[f];
+                        const int64_t *op = s_tile_o[f];
                         const int64_t nnz = ka->nnz[f];
                         int64_t s0 = op[b];
                         int64_t e0 = (b + 1 < ka->off_len[f]) ? op[b + 1] : nnz;
@@ -422,7 +431,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
 #pragma unroll
                     for (int h = 0; h < (d + 63) / 64; h++) {
                         const int e = lane + 64 * h;
-                        xv[h] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ka->src[0]) + (uint64_t)b * (uint64_t)(ka->stride[0] * 4))[e < d ? e : 0];
+                        xv[h] = reinterpret_cast<const float *>(reinterpret_cast<const char *>((uintptr_t)s_feat_base[0]) + (uint64_t)b * (uint64_t)(ka->stride[0] * 4))[e < d ? e : 0];
                     }
                     f32x4 c00, c10, c11;
                     interact(a, c00, c10, c11);
@@ -671,6 +680,40 @@ bool launch_rf_check(const FusedArgs &a, hipStream_t st) {
     default:
         return false;
     }
+}
+
+// K batches in one launch: K * ceil(B / 16) one-chunk blocks; the hardware hands a CU the next block as one retires, so the
+// drain of a batch's last blocks runs under the fill of the next batch's first ones (what two alternating streams give a
+// caller, without any stream: cross-stream event waits cost more here than they return -- measured)
+bool rf_multi_supported(int64_t B, int F, int d) {
+    return rf_mode() && F <= kTileMaxF && B >= 1 && (d == 16 || d == 32 || d == 36);
+}
+template <auto K>
+static void launch_rf_multi_grid(FusedArgs a, hipStream_t st) {
+    a.tile_per = 16;
+    a.multi_cpb = (int)((a.B + 15) / 16);
+    hipLaunchKernelGGL(K, dim3((unsigned)(a.multi_cpb * a.multi_n)), dim3(256), 0, st, a);
+}
+bool launch_rf_multi(const FusedArgs &a, hipStream_t st) {
+    if (!rf_multi_supported(a.B, a.F, a.d) || a.multi_n < 1 || a.multi_n > kMultiMax || !(a.bag1 == 1 || a.bag1 == 3)) return false;
+    const bool nt2 = a.F > 16;
+#define EVS_RF_MULTI(CQ_, REM_)                                                                                              \
+    do {                                                                                                                     \
+        if (a.bag1 == 1) {                                                                                                   \
+            if (nt2) launch_rf_multi_grid<emb_interact_rf_kernel<CQ_, REM_, 2, EVS_RF_DEPTH>>(a, st);                        \
+            else launch_rf_multi_grid<emb_interact_rf_kernel<CQ_, REM_, 1, EVS_RF_DEPTH>>(a, st);                            \
+        } else {                                                                                                             \
+            if (nt2) launch_rf_multi_grid<emb_interact_rf_kernel<CQ_, REM_, 2, EVS_RF_DEPTH, false, false, false, true>>(a, st); \
+            else launch_rf_multi_grid<emb_interact_rf_kernel<CQ_, REM_, 1, EVS_RF_DEPTH, false, false, false, true>>(a, st);     \
+        }                                                                                                                    \
+    } while (0)
+    switch (a.d) {
+    case 16: EVS_RF_MULTI(1, 0); return true;
+    case 32: EVS_RF_MULTI(2, 0); return true;
+    case 36: EVS_RF_MULTI(2, 1); return true;
+    default: return false;
+    }
+#undef EVS_RF_MULTI
 }
 
 bool launch_rf(const FusedArgs &a, hipStream_t st) {

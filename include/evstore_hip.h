@@ -207,10 +207,9 @@ EVS_API int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec,
 
 /* K independent batches of B samples in one call (a serving loop's queue): x, indices_base, offsets_base (NULL = one
  * index per bag for every batch) and R are HOST arrays of K device pointers, every batch with the same shape and strides.
- * Batch k runs on the library's own stream k % 2 -- the drain of one launch overlaps the fill of the next, the rate a
- * caller alternating two HIP streams gets -- forked from `stream` and joined back into it: work queued on `stream` before
- * the call is visible to every batch, work queued after it sees all K results.  Bit-identical to K calls of
- * evs_emb_interact_dot_stacked.  Not re-entrant across host threads for the same device (serialised internally). */
+ * fp32 tables with d in {16, 32, 36} and T <= 27: ONE launch per 8 batches -- a batch's last blocks drain under the
+ * next batch's first ones, the rate a caller alternating two HIP streams gets, with no stream but `stream`; other
+ * shapes: K launches.  Bit-identical to K calls of evs_emb_interact_dot_stacked either way. */
 EVS_API int evs_emb_interact_dot_stacked_multi(int K, int64_t B, int T, int d, int codec, const void *const *tables,
                                                const int64_t *n_rows, const float *const *x, int64_t x_stride,
                                                const int64_t *const *indices_base, int64_t indices_row_stride,
