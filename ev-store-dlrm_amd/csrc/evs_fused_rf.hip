@@ -153,9 +153,47 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         lds_off[rr] = (row / RPI) * 1024 + (row % RPI) * row_bytes + q * CQ * 16;
     }
     constexpr int kRemOff = 4 * CQ * 16;
+    int rem_off[NR];   // element q of the first trailing chunk of this lane's tile rows
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) rem_off[rr] = lds_off[rr] - q * CQ * 16 + kRemOff + q * 4;
     constexpr int kOob = 0x7ffffff0;
     // (`on` false: a zero-length buffer resource, the hardware drops every store -- the loop body has no branch around
     //  its vector-memory operations, see the main loop)
+#ifndef EVS_RF_OLDFLUSH
+    // lane-invariant pieces of the flush, computed once: which 16-byte piece of the staged row this lane moves in store h
+    // (an rf launch has F <= kTileMaxF: at most d + 28 * 29 / 2 = 442 floats, two store instructions of 64 x 16 bytes
+    // cover them -- the generic 32-row bound would issue a third that the bounds check always drops), its offset in R's
+    // row (kOob: dropped by the buffer bounds check), and the same for the 0..3 trailing floats
+    constexpr int kFlushMaxRow = MLP ? OUT_MAX : ((d + MAXF * (MAXF + 1) / 2 + 3) / 4) * 4;
+    constexpr int NFL = (kFlushMaxRow + 255) / 256;
+    int fl_lds[NFL], fl_off[NFL];
+    {
+        const int n4 = out_row >> 2;
+#pragma unroll
+        for (int h = 0; h < NFL; h++) {
+            const int e4 = lane + 64 * h;
+            fl_lds[h] = 16 * (e4 < n4 ? e4 : 0);
+            fl_off[h] = e4 < n4 ? 16 * e4 : kOob;
+            asm volatile("" : "+v"(fl_lds[h]), "+v"(fl_off[h]));   // (keep them in registers: the compiler otherwise re-derives them per sample)
+        }
+    }
+    int fl_tail_lds = 4 * (4 * (out_row >> 2) + (lane & 3));
+    int fl_tail_off = lane < (out_row & 3) ? fl_tail_lds : kOob;
+    asm volatile("" : "+v"(fl_tail_lds), "+v"(fl_tail_off));
+    auto flush_out = [&](int64_t bp, bool on) {
+        if constexpr (MLP) on = on && args.write_r;
+        float *Rb = R_base + (on ? bp : 0) * (int64_t)out_row;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, on ? out_row * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < NFL; h++) {
+            const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(my_out) + fl_lds[h]);
+            u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, fl_off[h], 0, EVS_OUT_CPOL);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(*reinterpret_cast<const float *>(reinterpret_cast<const char *>(my_out) + fl_tail_lds)),
+                                              rs, fl_tail_off, 0, EVS_OUT_CPOL);
+    };
+#else
     auto flush_out = [&](int64_t bp, bool on) {
         if constexpr (MLP) on = on && args.write_r;
         float *Rb = R_base + (on ? bp : 0) * (int64_t)out_row;
@@ -175,6 +213,8 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, EVS_OUT_CPOL);
         }
     };
+
+#endif
 
     // ---- index tiles: thread e (and e + 256) owns tile element (feature e >> 4, sample-in-chunk e & 15) ----
     bool bad = false, my_ragged = false;
@@ -235,56 +275,93 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
 
     // ---- the rows of this wave's sample n -> registers (D samples in flight) ----------------------------
     f32x4 ring[D][NJ];
+    // per load j this lane always fetches a row of the SAME feature (tile row dma_r0 + j * RPI): where that feature's rows
+    // start (plus this lane's 16-byte piece) and how far apart they are, read from the block's feature table once
+    unsigned long long fbase[NJ];
+    unsigned fscale[NJ];
+    int idx_lds[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int r = dma_r0 + j * RPI;               // < 32: tile rows >= F hold -1
+        fbase[j] = s_feat_base[r] + (unsigned long long)dma_piece16;
+        fscale[j] = s_feat_scale[r];
+        idx_lds[j] = 4 * (r * 16 + wave_in_block);    // byte address of tile entry (row r, sample wave_in_block) in s_idx
+    }
+    const unsigned long long zeros_piece = (unsigned long long)reinterpret_cast<uintptr_t>(zeros_l) + (unsigned long long)dma_piece16;
     auto issue = [&](int n, f32x4 (&slot)[NJ]) {
-        const int m = wave_in_block + 4 * n;              // block-local sample
-        const int tb = ((m >> 4) & 1) * 512 + (m & 15);
+        // block-local sample m = wave_in_block + 4 n (< 16: one chunk per block): tile buffer 0, entry m of each row
         const unsigned phantom = (unsigned)n < (unsigned)n_samples ? 0u : 0xffffffffu;   // past this wave's samples: every lane reads the zero page
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int r = dma_r0 + j * RPI;               // < 32: tile rows >= F hold -1
-            const int iv = s_idx[tb + r * 16];
+            const int iv = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(s_idx) + idx_lds[j] + 16 * n);
             // branch-free on purpose (bit blend, not a select: the compiler turns a select over these LDS reads into
             // control flow and serialises the four loads): -1 -> the zero page
             const unsigned neg = (unsigned)(iv >> 31) | phantom;
-            unsigned long long base = s_feat_base[r];
+            unsigned long long base = fbase[j];
             unsigned idx = (unsigned)iv & ~neg;
             if constexpr (IDS || PROBE) {   // bit 30: a row of the cache arena (bit blend, as below: no select over LDS reads)
                 const unsigned long long in_arena = 0ull - (unsigned long long)((idx >> 30) & 1u);
-                base ^= (base ^ (unsigned long long)reinterpret_cast<uintptr_t>(args.arena)) & in_arena;
+                base ^= (base ^ ((unsigned long long)reinterpret_cast<uintptr_t>(args.arena) + (unsigned long long)dma_piece16)) & in_arena;
                 idx &= 0x3fffffffu;
             }
-            const unsigned long long p = base + (unsigned long long)idx * (unsigned long long)s_feat_scale[r] + dma_piece16;
+            const unsigned long long p = base + (unsigned long long)idx * (unsigned long long)fscale[j];
             const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
-            const unsigned long long pa = p ^ ((p ^ (unsigned long long)reinterpret_cast<uintptr_t>(zeros_l)) & m64);
+            const unsigned long long pa = p ^ ((p ^ zeros_piece) & m64);
             slot[j] = *reinterpret_cast<gf4_t>((uintptr_t)pa);
         }
     };
-    auto interact = [&](const float4 (&a)[NR][NC], f32x4 &c00, f32x4 &c10, f32x4 &c11) {
+    // a: this lane's CQ k-slot chunks of tile rows r16 (+ 16); rem: element q of each of the REM trailing chunks (all four
+    // k-slots hold those chunks, slot q contributes element q -- read as ONE float from the image, not selected out of four)
+    auto interact = [&](const float4 (&a)[NR][CQ > 0 ? CQ : 1], const float (&rem)[NR][REM > 0 ? REM : 1], f32x4 &c00, f32x4 &c10, f32x4 &c11) {
         c00 = f32x4{0.f, 0.f, 0.f, 0.f}; c10 = f32x4{0.f, 0.f, 0.f, 0.f}; c11 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
+        for (int c = 0; c < CQ; c++) {
             const float e0[4] = {a[0][c].x, a[0][c].y, a[0][c].z, a[0][c].w};
             const float e1[4] = {a[NR - 1][c].x, a[NR - 1][c].y, a[NR - 1][c].z, a[NR - 1][c].w};
-            if (c < CQ) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[e], e0[e], c00, 0, 0, 0);
-                    if constexpr (NT == 2) {
-                        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e0[e], c10, 0, 0, 0);
-                        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e1[e], c11, 0, 0, 0);
-                    }
-                }
-            } else {   // the REM trailing chunks are held by all four k-slots; slot q contributes element q
-                const float s0 = q == 0 ? e0[0] : q == 1 ? e0[1] : q == 2 ? e0[2] : e0[3];
-                const float s1 = q == 0 ? e1[0] : q == 1 ? e1[1] : q == 2 ? e1[2] : e1[3];
-                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, s0, c00, 0, 0, 0);
+            for (int e = 0; e < 4; e++) {
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[e], e0[e], c00, 0, 0, 0);
                 if constexpr (NT == 2) {
-                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s0, c10, 0, 0, 0);
-                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s1, c11, 0, 0, 0);
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e0[e], c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[e], e1[e], c11, 0, 0, 0);
                 }
             }
         }
+#pragma unroll
+        for (int m = 0; m < REM; m++) {
+            const float s0 = rem[0][m], s1 = rem[NR - 1][m];
+            c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, s0, c00, 0, 0, 0);
+            if constexpr (NT == 2) {
+                c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s0, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, s1, c11, 0, 0, 0);
+            }
+        }
     };
+
+    // ---- where the accumulators go in the staged output row: lane-invariant, computed ONCE (relative to my_out; left to
+    // itself the compiler re-derives the twelve offsets -- multiplies, compares, exec-mask regions -- for every sample)
+    int zo00h[4], zo10h[4], zo11h[4];
+    {
+        const int dump0 = 4 * (OUT_MAX + r16);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int i = 4 * q + v;
+            zo00h[v] = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump0;
+            const int gi = 16 + i;
+            const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+            zo10h[v] = (NT == 2 && gi < F) ? 4 * (d + base + r16) : dump0;
+            zo11h[v] = (NT == 2 && gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump0;
+#ifndef EVS_RF_NOHOIST
+            asm volatile("" : "+v"(zo00h[v]), "+v"(zo10h[v]), "+v"(zo11h[v]));
+#endif
+        }
+    }
+    int xv_off[(d + 63) / 64];
+#pragma unroll
+    for (int h = 0; h < (d + 63) / 64; h++) {
+        const int e = lane + 64 * h;
+        xv_off[h] = e < d ? 4 * e : 4 * (OUT_MAX + r16);
+    }
 
     // ---- one chunk, straight line -------------------------------------------------------------------------
     // index tile of the block's 16 samples -> LDS; the rows of ALL of this wave's samples (at most 4) are requested at
@@ -434,7 +511,21 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
                         xv[h] = reinterpret_cast<const float *>(reinterpret_cast<const char *>((uintptr_t)s_feat_base[0]) + (uint64_t)b * (uint64_t)(ka->stride[0] * 4))[e < d ? e : 0];
                     }
                     f32x4 c00, c10, c11;
-                    interact(a, c00, c10, c11);
+                    {
+                        float4 aq[NR][CQ > 0 ? CQ : 1];
+                        float ar[NR][REM > 0 ? REM : 1];
+#pragma unroll
+                        for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+                            for (int c = 0; c < CQ; c++) aq[rr][c] = a[rr][c];
+#pragma unroll
+                            for (int m = 0; m < REM; m++) {
+                                const float4 t = a[rr][CQ + m];
+                                ar[rr][m] = q == 0 ? t.x : q == 1 ? t.y : q == 2 ? t.z : t.w;
+                            }
+                        }
+                        interact(aq, ar, c00, c10, c11);
+                    }
                     const int dump = 4 * (OUT_MAX + r16);
 #pragma unroll
                     for (int h = 0; h < (d + 63) / 64; h++) {
@@ -473,14 +564,15 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         // the image of sample u: what the row DMA of the LDS loop would have left in the slot
 #pragma unroll
         for (int j = 0; j < NJ; j++) *reinterpret_cast<f32x4 *>(my_lds + j * 1024 + lane * 16) = ring[u][j];
-        float4 a[NR][NC];
+        float4 a[NR][CQ > 0 ? CQ : 1];
+        float ar[NR][REM > 0 ? REM : 1];
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) {
 #pragma unroll
             for (int c = 0; c < CQ; c++) a[rr][c] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] + c * 16);
 #pragma unroll
             for (int m = 0; m < REM; m++)
-                a[rr][CQ + m] = *reinterpret_cast<const float4 *>(my_lds + lds_off[rr] - q * CQ * 16 + kRemOff + m * 16);
+                ar[rr][m] = *reinterpret_cast<const float *>(my_lds + rem_off[rr] + m * 16);
         }
         float xv[(d + 63) / 64];   // x[b] is row 0 of the image
 #pragma unroll
@@ -490,12 +582,24 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         }
         flush_out(b - 4, u > 0 && u - 1 < n_samples);    // sample u-1 leaves under the MFMAs of sample u
         f32x4 c00, c10, c11;
-        interact(a, c00, c10, c11);
+        interact(a, ar, c00, c10, c11);
         if constexpr (MLP) my_out = s_out[wave_in_block + 4 * u];
         // never-stored elements go to a dump slot: behind the row, or (MLP) in a block of their own
         const int dump = MLP ? (int)(reinterpret_cast<char *>(&s_dump[wave_in_block * 16 + r16]) - reinterpret_cast<char *>(my_out))
                              : 4 * (OUT_MAX + r16);
         // stage the output row: x passthrough, then the packed lower triangle straight from the accumulators
+        if constexpr (!MLP) {
+#pragma unroll
+            for (int h = 0; h < (d + 63) / 64; h++) *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + xv_off[h]) = xv[h];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00h[v]) = c00[v];
+                if constexpr (NT == 2) {
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10h[v]) = c10[v];
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11h[v]) = c11[v];
+                }
+            }
+        } else {
 #pragma unroll
         for (int h = 0; h < (d + 63) / 64; h++) {
             const int e = lane + 64 * h;
@@ -507,11 +611,6 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const int i = 4 * q + v;
-#ifdef EVS_X_FLATSTAGE   // developer A/B (timing only, wrong R): every staging store conflict-free, lane-linear addresses
-            const int zo00 = 4 * (d + lane + 64 * v), zo10 = 4 * (d + 256 + lane + 64 * (v & 3)), zo11 = 4 * (d + lane + 64 * ((v + 1) & 3));
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
-            if constexpr (NT == 2) {
-#else
             const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
             *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
             if constexpr (NT == 2) {
@@ -519,10 +618,10 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
                 const int base = (gi * (gi - 1 + 2 * itself)) / 2;
                 const int zo10 = gi < F ? 4 * (d + base + r16) : dump;
                 const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
-#endif
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = c10[v];
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[v];
             }
+        }
         }
     }
     if constexpr (MLP) my_out = s_out[wave_in_block + 12];
