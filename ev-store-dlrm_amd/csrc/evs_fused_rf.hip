@@ -555,8 +555,17 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             __syncthreads();
         }
     }
+    // scheduling barriers (EVS_RF_SB, developer A/B; bit 1: the four samples' requests leave in sample order, bit 0: the
+    // stores of sample u - 1 leave inside iteration u).  Left alone, hipcc 7.2 interleaves the requests of samples 0 and 1
+    // and sinks EVERY output store below the last MFMA of the last sample; pinned is 0.1-0.3 us faster at B = 16 384.
+#ifndef EVS_RF_SB
+#define EVS_RF_SB 3
+#endif
 #pragma unroll
-    for (int u = 0; u < D; u++) issue(u, ring[u]);      // (samples past the block's end: every lane reads the zero page)
+    for (int u = 0; u < D; u++) {
+        issue(u, ring[u]);      // (samples past the block's end: every lane reads the zero page)
+        if constexpr ((EVS_RF_SB & 2) != 0) __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink three of the four requests below the first consume
 #pragma unroll
     for (int u = 0; u < D; u++) {
@@ -623,6 +632,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             }
         }
         }
+        if constexpr ((EVS_RF_SB & 1) != 0) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (MLP) my_out = s_out[wave_in_block + 12];
     flush_out(blk_first + wave_in_block + 12, n_samples == 4);
