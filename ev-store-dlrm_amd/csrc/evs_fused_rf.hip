@@ -122,19 +122,40 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     const int blk_n = (int)(blk_end - blk_first);
     const int n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
     if (threadIdx.x < 32) {
+        // branch-free on purpose: every FusedArgs array has EVS_MAX_FEATURES = 32 entries (those past F are NULL / 0), so
+        // lane f reads entry f of each of them UNCONDITIONALLY -- all the loads leave together, one round trip -- and the
+        // tests below are selects on the values.  (Written as `f < F ? ka->x[f] : 0` the compiler puts each load behind
+        // its own branch and wait: three to six DEPENDENT round trips to the kernel arguments in front of the first index
+        // load, in every block of every launch -- the larger part of the launch's fixed cost.)
         const int f = (int)threadIdx.x;
-        const int64_t *ip = f < F ? ka->indices[f] : nullptr;
-        if (multi && f >= 1 && f < F) ip = ka->multi_idx[batch_k] + (int64_t)(f - 1) * args.multi_idx_stride;
-        const bool table = (IDS || PROBE) ? (f >= 1 && f < F) : ip != nullptr;
+        const bool on = f < F;
+        const int64_t *ip = ka->indices[f];
+        const unsigned long long src = (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]);
+        const int64_t nr = ka->n_rows[f];
+        const int64_t stride = ka->stride[f];
+        const int64_t *op = nullptr;
+        int64_t ol = 0, nz = 0;
+        if constexpr (CHECK) { op = ka->offsets[f]; ol = ka->off_len[f]; nz = ka->nnz[f]; }
+        unsigned long long mx = 0ull;
+        const int64_t *mi = nullptr, *mo = nullptr;
+        if constexpr (!MLP && !IDS && !PROBE) {
+            const int kk = multi ? batch_k : 0;   // (entry 0 is always readable)
+            mx = (unsigned long long)reinterpret_cast<uintptr_t>(ka->multi_x[kk]);
+            mi = ka->multi_idx[kk];
+            if constexpr (CHECK) mo = ka->multi_off[kk];
+        }
+        if (multi) ip = (f >= 1 && on) ? mi + (int64_t)(f - 1) * args.multi_idx_stride : nullptr;
+        if (!on) ip = nullptr;
+        const bool table = (IDS || PROBE) ? (f >= 1 && on) : ip != nullptr;
         s_tile_p[f] = ip;
-        s_tile_nr[f] = f < F ? (unsigned)ka->n_rows[f] : 0u;
-        s_tile_kind[f] = f >= F ? 0 : (table ? 2 : 1);
-        s_feat_base[f] = f < F ? (unsigned long long)reinterpret_cast<uintptr_t>((multi && f == 0) ? (const void *)ka->multi_x[batch_k] : ka->src[f]) : 0ull;
-        s_feat_scale[f] = f >= F ? 0u : (table ? (unsigned)row_bytes : (unsigned)(ka->stride[f] * 4));
+        s_tile_nr[f] = on ? (unsigned)nr : 0u;
+        s_tile_kind[f] = !on ? 0 : (table ? 2 : 1);
+        s_feat_base[f] = !on ? 0ull : ((multi && f == 0) ? mx : src);
+        s_feat_scale[f] = !on ? 0u : (table ? (unsigned)row_bytes : (unsigned)(stride * 4));
         if constexpr (CHECK) {
-            s_tile_o[f] = table ? (multi ? ka->multi_off[batch_k] + (int64_t)(f - 1) * args.multi_off_stride : ka->offsets[f]) : nullptr;
-            s_tile_ol[f] = table ? ka->off_len[f] : 0;
-            s_tile_nz[f] = table ? ka->nnz[f] : 0;
+            s_tile_o[f] = table ? (multi ? mo + (int64_t)(f - 1) * args.multi_off_stride : op) : nullptr;
+            s_tile_ol[f] = table ? ol : 0;
+            s_tile_nz[f] = table ? nz : 0;
         }
     }
     __syncthreads();
@@ -166,8 +187,8 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     // row (kOob: dropped by the buffer bounds check), and the same for the 0..3 trailing floats
     constexpr int kFlushMaxRow = MLP ? OUT_MAX : ((d + MAXF * (MAXF + 1) / 2 + 3) / 4) * 4;
     constexpr int NFL = (kFlushMaxRow + 255) / 256;
-    int fl_lds[NFL], fl_off[NFL];
-    {
+    int fl_lds[NFL], fl_off[NFL], fl_tail_lds = 0, fl_tail_off = 0;   // filled by fill_hoists(), behind the row requests
+    auto fill_flush = [&]() {
         const int n4 = out_row >> 2;
 #pragma unroll
         for (int h = 0; h < NFL; h++) {
@@ -176,10 +197,10 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             fl_off[h] = e4 < n4 ? 16 * e4 : kOob;
             asm volatile("" : "+v"(fl_lds[h]), "+v"(fl_off[h]));   // (keep them in registers: the compiler otherwise re-derives them per sample)
         }
-    }
-    int fl_tail_lds = 4 * (4 * (out_row >> 2) + (lane & 3));
-    int fl_tail_off = lane < (out_row & 3) ? fl_tail_lds : kOob;
-    asm volatile("" : "+v"(fl_tail_lds), "+v"(fl_tail_off));
+        fl_tail_lds = 4 * (4 * (out_row >> 2) + (lane & 3));
+        fl_tail_off = lane < (out_row & 3) ? fl_tail_lds : kOob;
+        asm volatile("" : "+v"(fl_tail_lds), "+v"(fl_tail_off));
+    };
     auto flush_out = [&](int64_t bp, bool on) {
         if constexpr (MLP) on = on && args.write_r;
         float *Rb = R_base + (on ? bp : 0) * (int64_t)out_row;
@@ -218,6 +239,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
 
     // ---- index tiles: thread e (and e + 256) owns tile element (feature e >> 4, sample-in-chunk e & 15) ----
     bool bad = false, my_ragged = false;
+    bool oob[2] = {false, false};
     int64_t tile_v[2] = {-1, -1};
     int64_t tile_o0[2] = {0, 0}, tile_o1[2] = {0, 0};   // CHECK: offsets[b] and where bag b ends
     const int64_t *dummy_i = args.dummy_i64;   // any readable int64 (lanes with nothing to load read it)
@@ -254,22 +276,33 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             const bool live = kind != 0 && bs < blk_end && c >= 0;
             const int64_t v = kind == 2 ? tile_v[h] : bs;       // dense features (x, received pooled vectors): the sample number
             const bool in_range = kind == 1 || (IDS ? v >= 0 : (uint64_t)v < (uint64_t)s_tile_nr[f]);   // (IDS: the probe kernel checked the row ids)
-            bool mine = true;
-            if constexpr (CHECK) {
-                // (an index whose own bag is not {idx[b]} may sit at a position no bag refers to: the slow loop, which this
-                //  block then runs, has the verdict on it)
-                const bool table = kind == 2 && bs < blk_end;
-                const bool own = table && ((threadIdx.x & 15) == 15 || bs + 1 >= blk_end);
-                int64_t o0 = tile_o0[h], o1 = tile_o1[h];
-                const int64_t nb = __shfl_down((long long)tile_o0[h], 1);
-                if (!own) o1 = nb;
-                if (own && !(bs + 1 < s_tile_ol[f])) o1 = s_tile_nz[f];   // the last bag ends at nnz
-                if (!table) { o0 = bs; o1 = bs + 1; }
-                mine = o0 == bs && o1 == bs + 1;
-                my_ragged |= !mine;
-            }
-            bad |= live & !in_range & mine;
+            if constexpr (CHECK) oob[h] = live & !in_range;   // (whether it counts is verify()'s call: see there)
+            else bad |= live & !in_range;
             s_idx[(c & 1) * 512 + (int)threadIdx.x + 256 * h] = (live & in_range) ? (int)v : -1;
+        }
+    };
+
+    // CHECK: the verdict on the offsets -- is every bag of the chunk exactly {idx[b]}?  (Taken in front of the row requests.
+    // Behind them -- rows asked for on the bet that it is, compares and the block barrier under their round trip, the slow
+    // loop at the end of the kernel overwriting what the one-index code produced -- was built and measured: 22.3 instead of
+    // 20.7 us at B = 16 384; the offsets pairs then live across the 64 row registers, 128 VGPRs and spills.)
+    auto verify = [&]() {
+        const int64_t bs = blk_first + (threadIdx.x & 15);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            // (an index whose own bag is not {idx[b]} may sit at a position no bag refers to: the slow loop, which this
+            //  block then runs, has the verdict on it)
+            const bool table = s_tile_kind[f] == 2 && bs < blk_end;
+            const bool own = table && ((threadIdx.x & 15) == 15 || bs + 1 >= blk_end);
+            int64_t o0 = tile_o0[h], o1 = tile_o1[h];
+            const int64_t nb = __shfl_down((long long)tile_o0[h], 1);
+            if (!own) o1 = nb;
+            if (own && !(bs + 1 < s_tile_ol[f])) o1 = s_tile_nz[f];   // the last bag ends at nnz
+            if (!table) { o0 = bs; o1 = bs + 1; }
+            const bool mine = o0 == bs && o1 == bs + 1;
+            my_ragged |= !mine;
+            bad |= oob[h] & mine;
         }
     };
 
@@ -341,7 +374,8 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
     // ---- where the accumulators go in the staged output row: lane-invariant, computed ONCE (relative to my_out; left to
     // itself the compiler re-derives the twelve offsets -- multiplies, compares, exec-mask regions -- for every sample)
     int zo00h[4], zo10h[4], zo11h[4];
-    {
+    int xv_off[(d + 63) / 64];
+    auto fill_stage = [&]() {
         const int dump0 = 4 * (OUT_MAX + r16);
 #pragma unroll
         for (int v = 0; v < 4; v++) {
@@ -351,22 +385,118 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             const int base = (gi * (gi - 1 + 2 * itself)) / 2;
             zo10h[v] = (NT == 2 && gi < F) ? 4 * (d + base + r16) : dump0;
             zo11h[v] = (NT == 2 && gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump0;
-#ifndef EVS_RF_NOHOIST
             asm volatile("" : "+v"(zo00h[v]), "+v"(zo10h[v]), "+v"(zo11h[v]));
-#endif
         }
-    }
-    int xv_off[(d + 63) / 64];
 #pragma unroll
-    for (int h = 0; h < (d + 63) / 64; h++) {
-        const int e = lane + 64 * h;
-        xv_off[h] = e < d ? 4 * e : 4 * (OUT_MAX + r16);
-    }
+        for (int h = 0; h < (d + 63) / 64; h++) {
+            const int e = lane + 64 * h;
+            xv_off[h] = e < d ? 4 * e : 4 * (OUT_MAX + r16);
+        }
+    };
 
-    // ---- one chunk, straight line -------------------------------------------------------------------------
-    // index tile of the block's 16 samples -> LDS; the rows of ALL of this wave's samples (at most 4) are requested at
-    // once; the samples are consumed in order as their rows arrive (counted vmcnt: no branch, so hipcc's waitcnt
-    // insertion keeps the younger samples in flight); the output row of sample u leaves under the MFMAs of sample u+1.
+    auto flush_slow = [&](int64_t bp) {   // the slow block's flush: offsets computed in place (the hoisted ones are not filled yet)
+        float *Rb = R_base + bp * (int64_t)out_row;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, out_row * 4, 0x00020000);
+        const int n4 = out_row >> 2;
+#pragma unroll
+        for (int h = 0; h < NFL; h++) {
+            const int e4 = lane + 64 * h;
+            const float4 v = reinterpret_cast<const float4 *>(my_out)[e4 < n4 ? e4 : 0];
+            u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, EVS_OUT_CPOL);
+        }
+        const int e = 4 * n4 + (lane & 3);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, EVS_OUT_CPOL);
+    };
+    // ---- CHECK, rare: a block that finds a bag other than {idx[b]} pools ITS samples with the general semantics --------
+    auto slow_block = [&]() {
+        for (int u = 0; u < n_samples; u++) {
+            const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;
+            float4 a[NR][NC];
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                const int f = r16 + 16 * rr;
+#pragma unroll
+                for (int c = 0; c < NC; c++) a[rr][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f >= F) continue;
+                // byte offset of chunk c inside a row: this lane's k-slot chunks, then the shared remainder chunks
+                auto chunk_at = [&](const char *row, int c) -> float4 {
+                    return *reinterpret_cast<const float4 *>(row + (c < CQ ? (q * CQ + c) * 16 : kRemOff + (c - CQ) * 16));
+                };
+                const int64_t *ip = s_tile_p[f];                                            // (multi: this batch's arrays)
+                const char *src = reinterpret_cast<const char *>((uintptr_t)s_feat_base[f]);
+                if (!ip) {   // dense feature (x, received pooled vectors)
+                    const char *row = src + (uint64_t)b * (uint64_t)(ka->stride[f] * 4);
+#pragma unroll
+                    for (int c = 0; c < NC; c++) a[rr][c] = chunk_at(row, c);
+                    continue;
+                }
+                const int64_t *op = s_tile_o[f];
+                const int64_t nnz = ka->nnz[f];
+                int64_t s0 = op[b];
+                int64_t e0 = (b + 1 < ka->off_len[f]) ? op[b + 1] : nnz;
+                if (!((s0 >= 0) & (e0 >= s0) & (e0 <= nnz))) { bad = true; s0 = e0 = 0; }
+                const uint64_t n_rows = (uint64_t)ka->n_rows[f];
+                for (int64_t j = s0; j < e0; j++) {
+                    const int64_t r = ip[j];
+                    if ((uint64_t)r >= n_rows) { bad = true; continue; }   // skipped; a skipped FIRST row counts as zeros
+                    const char *row = src + (uint64_t)r * (uint64_t)row_bytes;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const float4 t = chunk_at(row, c);
+                        if (j == s0) { a[rr][c] = t; continue; }
+                        a[rr][c].x = __fadd_rn(a[rr][c].x, t.x); a[rr][c].y = __fadd_rn(a[rr][c].y, t.y);
+                        a[rr][c].z = __fadd_rn(a[rr][c].z, t.z); a[rr][c].w = __fadd_rn(a[rr][c].w, t.w);
+                    }
+                }
+            }
+            float xv[(d + 63) / 64];   // x[b] (feature 0, dense) for the passthrough columns
+#pragma unroll
+            for (int h = 0; h < (d + 63) / 64; h++) {
+                const int e = lane + 64 * h;
+                xv[h] = reinterpret_cast<const float *>(reinterpret_cast<const char *>((uintptr_t)s_feat_base[0]) + (uint64_t)b * (uint64_t)(ka->stride[0] * 4))[e < d ? e : 0];
+            }
+            f32x4 c00, c10, c11;
+            {
+                float4 aq[NR][CQ > 0 ? CQ : 1];
+                float ar[NR][REM > 0 ? REM : 1];
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+                    for (int c = 0; c < CQ; c++) aq[rr][c] = a[rr][c];
+#pragma unroll
+                    for (int m = 0; m < REM; m++) {
+                        const float4 t = a[rr][CQ + m];
+                        ar[rr][m] = q == 0 ? t.x : q == 1 ? t.y : q == 2 ? t.z : t.w;
+                    }
+                }
+                interact(aq, ar, c00, c10, c11);
+            }
+            const int dump = 4 * (OUT_MAX + r16);
+#pragma unroll
+            for (int h = 0; h < (d + 63) / 64; h++) {
+                const int e = lane + 64 * h;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + (e < d ? 4 * e : dump)) = xv[h];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int i = 4 * q + v;
+                const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
+                if constexpr (NT == 2) {
+                    const int gi = 16 + i;
+                    const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+                    const int zo10 = gi < F ? 4 * (d + base + r16) : dump;
+                    const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = c10[v];
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[v];
+                }
+            }
+            flush_slow(b);
+        }
+        if (bad) atomicOr(args.err, 1);
+    };
+
     static_assert(D == 4, "a block owns one 16-sample chunk: 4 samples per wave");
     if constexpr (PROBE) {
         // ---- the cache probe, folded in: thread e (and e + 256) owns key (table (e >> 4) - 1, sample e & 15) -------------
@@ -463,92 +593,9 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         tile_load(0);
         tile_store(0);
         if constexpr (CHECK) {
+            verify();
             if (__syncthreads_or(my_ragged)) {   // block-uniform, rare: this block's samples with general bag semantics
-                for (int u = 0; u < n_samples; u++) {
-                    const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;
-                    float4 a[NR][NC];
-#pragma unroll
-                    for (int rr = 0; rr < NR; rr++) {
-                        const int f = r16 + 16 * rr;
-#pragma unroll
-                        for (int c = 0; c < NC; c++) a[rr][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (f >= F) continue;
-                        // byte offset of chunk c inside a row: this lane's k-slot chunks, then the shared remainder chunks
-                        auto chunk_at = [&](const char *row, int c) -> float4 {
-                            return *reinterpret_cast<const float4 *>(row + (c < CQ ? (q * CQ + c) * 16 : kRemOff + (c - CQ) * 16));
-                        };
-                        const int64_t *ip = s_tile_p[f];                                            // (multi: this batch's arrays)
-                        const char *src = reinterpret_cast<const char *>((uintptr_t)s_feat_base[f]);
-                        if (!ip) {   // dense feature (x, received pooled vectors)
-                            const char *row = src + (uint64_t)b * (uint64_t)(ka->stride[f] * 4);
-#pragma unroll
-                            for (int c = 0; c < NC; c++) a[rr][c] = chunk_at(row, c);
-                            continue;
-                        }
-                        const int64_t *op = s_tile_o[f];
-                        const int64_t nnz = ka->nnz[f];
-                        int64_t s0 = op[b];
-                        int64_t e0 = (b + 1 < ka->off_len[f]) ? op[b + 1] : nnz;
-                        if (!((s0 >= 0) & (e0 >= s0) & (e0 <= nnz))) { bad = true; s0 = e0 = 0; }
-                        const uint64_t n_rows = (uint64_t)ka->n_rows[f];
-                        for (int64_t j = s0; j < e0; j++) {
-                            const int64_t r = ip[j];
-                            if ((uint64_t)r >= n_rows) { bad = true; continue; }   // skipped; a skipped FIRST row counts as zeros
-                            const char *row = src + (uint64_t)r * (uint64_t)row_bytes;
-#pragma unroll
-                            for (int c = 0; c < NC; c++) {
-                                const float4 t = chunk_at(row, c);
-                                if (j == s0) { a[rr][c] = t; continue; }
-                                a[rr][c].x = __fadd_rn(a[rr][c].x, t.x); a[rr][c].y = __fadd_rn(a[rr][c].y, t.y);
-                                a[rr][c].z = __fadd_rn(a[rr][c].z, t.z); a[rr][c].w = __fadd_rn(a[rr][c].w, t.w);
-                            }
-                        }
-                    }
-                    float xv[(d + 63) / 64];   // x[b] (feature 0, dense) for the passthrough columns
-#pragma unroll
-                    for (int h = 0; h < (d + 63) / 64; h++) {
-                        const int e = lane + 64 * h;
-                        xv[h] = reinterpret_cast<const float *>(reinterpret_cast<const char *>((uintptr_t)s_feat_base[0]) + (uint64_t)b * (uint64_t)(ka->stride[0] * 4))[e < d ? e : 0];
-                    }
-                    f32x4 c00, c10, c11;
-                    {
-                        float4 aq[NR][CQ > 0 ? CQ : 1];
-                        float ar[NR][REM > 0 ? REM : 1];
-#pragma unroll
-                        for (int rr = 0; rr < NR; rr++) {
-#pragma unroll
-                            for (int c = 0; c < CQ; c++) aq[rr][c] = a[rr][c];
-#pragma unroll
-                            for (int m = 0; m < REM; m++) {
-                                const float4 t = a[rr][CQ + m];
-                                ar[rr][m] = q == 0 ? t.x : q == 1 ? t.y : q == 2 ? t.z : t.w;
-                            }
-                        }
-                        interact(aq, ar, c00, c10, c11);
-                    }
-                    const int dump = 4 * (OUT_MAX + r16);
-#pragma unroll
-                    for (int h = 0; h < (d + 63) / 64; h++) {
-                        const int e = lane + 64 * h;
-                        *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + (e < d ? 4 * e : dump)) = xv[h];
-                    }
-#pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const int i = 4 * q + v;
-                        const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
-                        *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[v];
-                        if constexpr (NT == 2) {
-                            const int gi = 16 + i;
-                            const int base = (gi * (gi - 1 + 2 * itself)) / 2;
-                            const int zo10 = gi < F ? 4 * (d + base + r16) : dump;
-                            const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
-                            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = c10[v];
-                            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[v];
-                        }
-                    }
-                    flush_out(b, true);
-                }
-                if (bad) atomicOr(args.err, 1);
+                slow_block();
                 return;
             }
         } else {
@@ -567,6 +614,10 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         if constexpr ((EVS_RF_SB & 2) != 0) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink three of the four requests below the first consume
+    // the lane-invariant staging / flush offsets: computed here, under the row requests' round trip, not in front of them
+    // (16 waves per CU start in step: every instruction in front of the first load is paid by all of them at once)
+    fill_stage();
+    fill_flush();
 #pragma unroll
     for (int u = 0; u < D; u++) {
         const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;   // wave-uniform
