@@ -262,8 +262,11 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
         float *Rb = args.R + (on ? bp : 0) * (int64_t)out_row;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, on ? out_row * 4 : 0, 0x00020000);
         const int n4 = out_row >> 2;   // whole 16-byte pieces; the 0..3 trailing floats go as dwords
+        // (an rfq launch has F <= kTileMaxF: at most d + 28 * 29 / 2 floats -- the generic 32-row bound would issue a
+        //  third store that the bounds check always drops)
+        constexpr int kFlushMaxRow = ((d + kTileMaxF * (kTileMaxF + 1) / 2 + 3) / 4) * 4;
 #pragma unroll
-        for (int h = 0; h < (OUT_MAX + 255) / 256; h++) {
+        for (int h = 0; h < (kFlushMaxRow + 255) / 256; h++) {
             const int e4 = lane + 64 * h;
             const float4 v = reinterpret_cast<const float4 *>(my_out)[e4 < n4 ? e4 : 0];
             u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--dim", type=int, default=36)
     ap.add_argument("--dist", default="uniform")
+    ap.add_argument("--n-batches", type=int, default=8, help="distinct batches cycled (bench.py: 64 = index data far beyond the Infinity Cache)")
     ap.add_argument("--fused-only", action="store_true")
     ap.add_argument("--bits", type=int, default=32, help="table precision 32|16|8|4 (reduced: fused timings only)")
     ap.add_argument("--codes", default="random", help="reduced precision: random codes | encoded (the fp32 init through the reference's encoders)")
@@ -51,27 +52,27 @@ def main():
     ev = bench.make_tables(bench.KAGGLE_LN, d, bits=a.bits, codes=a.codes)
     T = 26
     for B in a.batch:
-        batches = bench.make_batches(bench.KAGGLE_LN, B, 8, 1, "cuda", a.dist)
+        batches = bench.make_batches(bench.KAGGLE_LN, B, a.n_batches, 1, "cuda", a.dist)
         x = torch.rand(B, d, device="cuda")
         if a.bits != 32:
             row = d * a.bits // 8
-            settle(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev))
-            f_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev), a.iters)
-            f1_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev, one_index_per_bag=True), a.iters)
-            g_us = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None, lazy=False), a.iters)
+            settle(lambda i: E.apply_emb_interact(x, batches[i % len(batches)][0], batches[i % len(batches)][1], ev))
+            f_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % len(batches)][0], batches[i % len(batches)][1], ev), a.iters)
+            f1_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % len(batches)][0], batches[i % len(batches)][1], ev, one_index_per_bag=True), a.iters)
+            g_us = timeit(lambda i: E.apply_emb(batches[i % len(batches)][0], batches[i % len(batches)][1], ev, None, lazy=False), a.iters)
             fb = B * (26 * (row + 8) + 4 * d + 4 * (d + 351)) / 1e3
             print("B=%6d u%d fused one-index/bag %7.1f us (%5.0f GB/s algorithmic, %.2f G lookups/s) | offsets %7.1f us | gather only %7.1f us"
                   % (B, a.bits, f1_us, fb / f1_us, 26 * B / f1_us / 1e3, f_us, g_us), flush=True)
             continue
         tile = torch.empty(B, T + 1, d, device="cuda")
-        g_tile = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None, out=tile), a.iters)
+        g_tile = timeit(lambda i: E.apply_emb(batches[i % len(batches)][0], batches[i % len(batches)][1], ev, None, out=tile), a.iters)
         ly_tile = E.apply_emb(batches[0][0], batches[0][1], ev, None, out=tile)
         i_tile = timeit(lambda i: E.interact_features(x, ly_tile), a.iters)
-        g_tab = timeit(lambda i: E.apply_emb(batches[i % 8][0], batches[i % 8][1], ev, None, lazy=False), a.iters)
+        g_tab = timeit(lambda i: E.apply_emb(batches[i % len(batches)][0], batches[i % len(batches)][1], ev, None, lazy=False), a.iters)
         ly_tab = E.apply_emb(batches[0][0], batches[0][1], ev, None, lazy=False)
         i_tab = timeit(lambda i: E.interact_features(x, ly_tab), a.iters)
-        f_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev), a.iters)
-        f1_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % 8][0], batches[i % 8][1], ev, one_index_per_bag=True), a.iters)
+        f_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % len(batches)][0], batches[i % len(batches)][1], ev), a.iters)
+        f1_us = timeit(lambda i: E.apply_emb_interact(x, batches[i % len(batches)][0], batches[i % len(batches)][1], ev, one_index_per_bag=True), a.iters)
         print("B=%6d  fused, one index per bag   %7.1f us (%.2f G lookups/s)" % (B, f1_us, 26 * B / f1_us / 1e3))
         fb = B * (26 * (4 * d + 16) + 4 * d + 4 * (d + 351)) / 1e3
         print("B=%6d  fused gather+interact %7.1f us (%5.0f GB/s algorithmic, %.2f G lookups/s)" % (B, f_us, fb / f_us, 26 * B / f_us / 1e3))
