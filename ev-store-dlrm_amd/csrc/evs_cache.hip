@@ -39,10 +39,6 @@ enum Policy { kEvLFU = 0, kLRU = 1, kLFU = 2 };
 
 struct CacheState {
     int cap, n_tables, dim, codec, row_bytes, policy;
-    // arena row e lives at arena + e * row_stride: the row_bytes bytes of the row, then (4-byte aligned) a COPY of the entry's
-    // priority -- the batched probe reads it from the line the consumer fetches anyway instead of a line of eagg[] (see
-    // row_prio below); row_stride is a multiple of 16
-    int row_stride, prio_off;
     unsigned long long nslot_mask;
     int min_c1, n_perfect, max_perfect, flush_n, perfect_mode;
     int count;   // live entries
@@ -66,14 +62,6 @@ struct CacheArrays {
     int *lfu_head, *lfu_tail, *lfu_len;  // LFU only, indexed by frequency (< lfu_max_freq)
     long long lfu_max_freq;
 };
-
-// The in-row copy of entry e's priority (batched path).  eagg[e] stays the authoritative, compact array (the policy
-// update samples eight consecutive entries: one line); the copy is written with it on insert and raised with it by the
-// probe, which READS only the copy: a hit then costs its hash line and the two lines of its row -- the line of eagg[] it
-// used to cost on top was a quarter of the probe's HBM traffic (48 MB per 16 384-request batch at Kaggle scale).
-__device__ __forceinline__ int *row_prio(const unsigned char *arena, long long e, int row_stride, int prio_off) {
-    return reinterpret_cast<int *>(const_cast<unsigned char *>(arena) + e * row_stride + prio_off);
-}
 
 struct CacheArgs {
     CacheState *st;
@@ -234,7 +222,7 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
     const CacheArrays a = args.a;
     const CacheState cs = *gs;           // immutable config fields are read from this copy
     const unsigned long long mask = cs.nslot_mask;
-    const int T = cs.n_tables, d = cs.dim, rb = cs.row_bytes, rs = cs.row_stride;
+    const int T = cs.n_tables, d = cs.dim, rb = cs.row_bytes;
     if (lane == 0) {
         h.min_c1 = cs.min_c1; h.n_perfect = cs.n_perfect; h.count = cs.count; h.n_free = cs.n_free;
         h.n_flush = cs.n_flush; h.n_evict = cs.n_evict; h.least_freq = cs.least_freq; h.error = cs.error;
@@ -416,7 +404,7 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
             const bool ok = rrow >= 0 && rrow < args.backing_rows[tsrc];
             const unsigned char *rowp = nullptr;
             if (!zero) {
-                if (src >= 0) rowp = a.arena + (long long)src * rs;
+                if (src >= 0) rowp = a.arena + (long long)src * rb;
                 else if (ok) rowp = args.backing[tsrc] + (long long)rrow * rb;
             }
             s_rowp[i] = rowp;
@@ -439,7 +427,7 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
             const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)s_req[i];
             if (ld(&a.ekey[fe]) != ki) continue;
             const unsigned char *rowp = args.backing[i] + (long long)s_req[i] * rb;
-            unsigned char *dst = a.arena + (long long)fe * rs;
+            unsigned char *dst = a.arena + (long long)fe * rb;
             for (int c = lane; c < rb; c += 64) dst[c] = rowp[c];
         }
         __threadfence();
@@ -765,17 +753,17 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
             const int rrow = s_req[i];
             const unsigned char *rowp = nullptr;
             int codec = cs1.codec;
-            if (tier == 1) rowp = src >= 0 ? a1.arena + (long long)src * cs1.row_stride
+            if (tier == 1) rowp = src >= 0 ? a1.arena + (long long)src * cs1.row_bytes
                                            : args.t1.backing[i] + (long long)rrow * cs1.row_bytes;
             else if (tier == 2) {
                 codec = cs2.codec;
-                rowp = src >= 0 ? a2.arena + (long long)src * cs2.row_stride
+                rowp = src >= 0 ? a2.arena + (long long)src * cs2.row_bytes
                                 : args.t2.backing[i] + (long long)rrow * cs2.row_bytes;
             } else if (tier == 3) {  // alt-key hit: the ALT row, decoded at the precision of the tier holding it
-                rowp = a1.arena + (long long)src * cs1.row_stride;
+                rowp = a1.arena + (long long)src * cs1.row_bytes;
             } else if (tier == 4) {
                 codec = cs2.codec;
-                rowp = a2.arena + (long long)src * cs2.row_stride;
+                rowp = a2.arena + (long long)src * cs2.row_bytes;
             }
             for (int c = lane; c < d; c += 64) out[i * d + c] = rowp ? decode_elem(rowp, codec, c) : 0.f;
         }
@@ -785,12 +773,12 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
             const int f1 = s_fill1[i], f2 = s_fill2[i];
             if (f1 >= 0 && ld(&a1.ekey[f1]) == ki) {
                 const unsigned char *rowp = args.t1.backing[i] + (long long)s_req[i] * cs1.row_bytes;
-                unsigned char *dst = a1.arena + (long long)f1 * cs1.row_stride;
+                unsigned char *dst = a1.arena + (long long)f1 * cs1.row_bytes;
                 for (int c = lane; c < cs1.row_bytes; c += 64) dst[c] = rowp[c];
             }
             if (f2 >= 0 && ld(&a2.ekey[f2]) == ki) {
                 const unsigned char *rowp = args.t2.backing[i] + (long long)s_req[i] * cs2.row_bytes;
-                unsigned char *dst = a2.arena + (long long)f2 * cs2.row_stride;
+                unsigned char *dst = a2.arena + (long long)f2 * cs2.row_bytes;
                 for (int c = lane; c < cs2.row_bytes; c += 64) dst[c] = rowp[c];
             }
         }
@@ -870,7 +858,7 @@ struct BatchArgs {
     const int *requests; float *out; unsigned char *hit;
     long long B;
     unsigned long long mask;
-    int cap, T, d, codec, row_bytes, row_stride, prio_off, max_perfect, flush_n, nslot;
+    int cap, T, d, codec, row_bytes, max_perfect, flush_n, nslot;
     // file-backed miss tier (evs_filetier.hip): tables in staged_mask have no device-visible address; the rows of the
     // batch's new keys are copied by the host into `staging` (row i = new key i of the batch, pinned + mapped)
     unsigned staged_mask;
@@ -976,8 +964,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         // monotone max like update_agg_hit; the plain read first keeps hot entries (thousands of requests of
         // one batch hit the same few rows of the tiny tables) from serialising on one atomic address
 #ifndef EVS_X_NOPRIO   // developer A/B (timing only): what the priority read per hit costs the probe
-        if (e >= 0 && *row_prio(args.a.arena, e, args.row_stride, args.prio_off) < agg) {   // (the in-row copy: the row's own line)
-            atomicMax(row_prio(args.a.arena, e, args.row_stride, args.prio_off), agg);
+        if (e >= 0 && args.a.eagg[e] < agg) {
             const int old = atomicMax(&args.a.eagg[e], agg);
             if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
         }
@@ -985,7 +972,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         if (args.stamp_hits && e >= 0) args.estamp[e] = args.stamp;
         // where the row lives right now: arena for a hit, backing store for a miss, 0 for a bad row id
         const unsigned char *src = nullptr;
-        if (e >= 0) src = args.a.arena + (long long)e * args.row_stride;
+        if (e >= 0) src = args.a.arena + (long long)e * args.row_bytes;
         else if (ok) src = args.backing[hl] + (long long)row * args.row_bytes;
         if (key_on) {
             // bit 30: hit -- or, for a miss (bit 31), "the hinted slot is a tombstone" (what the insert's first CAS expects)
@@ -1112,13 +1099,11 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         }
         const unsigned long long hm = __ballot(e1 >= 0 || e2 >= 0 || alt_tier != 0);
         const int agg = __popc((unsigned)(half ? (hm >> 32) : hm));
-        if (e1 >= 0 && *row_prio(a1.a.arena, e1, a1.row_stride, a1.prio_off) < agg) {
-            atomicMax(row_prio(a1.a.arena, e1, a1.row_stride, a1.prio_off), agg);
+        if (e1 >= 0 && a1.a.eagg[e1] < agg) {
             const int old = atomicMax(&a1.a.eagg[e1], agg);
             if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
         }
-        if (e2 >= 0 && *row_prio(a2.a.arena, e2, a2.row_stride, a2.prio_off) < agg) {
-            atomicMax(row_prio(a2.a.arena, e2, a2.row_stride, a2.prio_off), agg);
+        if (e2 >= 0 && a2.a.eagg[e2] < agg) {
             const int old = atomicMax(&a2.a.eagg[e2], agg);
             if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
         }
@@ -1127,10 +1112,10 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         const int dest = !c1_full ? 1 : (agg < tt.threshold ? ((hl & 1) ? 1 : 2) : 2);
         const unsigned char *src = nullptr;
         int codec_of = 0;
-        if (e1 >= 0) { src = a1.a.arena + (long long)e1 * a1.row_stride; codec_of = 1; }
-        else if (e2 >= 0) { src = a2.a.arena + (long long)e2 * a2.row_stride; codec_of = 2; }
-        else if (alt_tier == 1) { src = a1.a.arena + (long long)ea * a1.row_stride; codec_of = 1; }   // the ALT row, at the precision of the tier holding it
-        else if (alt_tier == 2) { src = a2.a.arena + (long long)ea * a2.row_stride; codec_of = 2; }
+        if (e1 >= 0) { src = a1.a.arena + (long long)e1 * a1.row_bytes; codec_of = 1; }
+        else if (e2 >= 0) { src = a2.a.arena + (long long)e2 * a2.row_bytes; codec_of = 2; }
+        else if (alt_tier == 1) { src = a1.a.arena + (long long)ea * a1.row_bytes; codec_of = 1; }   // the ALT row, at the precision of the tier holding it
+        else if (alt_tier == 2) { src = a2.a.arena + (long long)ea * a2.row_bytes; codec_of = 2; }
         else if (miss && dest == 1) { src = a1.backing[hl] + (long long)row * a1.row_bytes; codec_of = 1; }
         else if (miss) { src = a2.backing[hl] + (long long)row * a2.row_bytes; codec_of = 2; }
         if (tt.route_filter && miss && dest == 1 && (hl & 1)) tt.route_filter[mix64(key) & tt.route_mask] = tt.route_stamp;
@@ -1585,14 +1570,13 @@ __global__ void __launch_bounds__(256) cache_batch_assign_kernel(const BatchArgs
         if (sub == 0) {
             const int agg = (int)((unsigned)(w >> kKeyBits) - kFieldPend);
             args.a.ekey[e] = key; args.a.eagg[e] = agg; args.eslot[e] = slot;
-            *row_prio(args.a.arena, e, args.row_stride, args.prio_off) = agg;
             args.slots[slot] = make_word(key, (unsigned)e);
             atomicAdd(&s_delta[agg], 1);
         }
         const int t = (int)(key >> 32) - 1;
         const unsigned char *srow = ((args.staged_mask >> t) & 1u) ? args.staging + (long long)i * args.row_bytes
                                                                  : args.backing[t] + (long long)(unsigned)(key & 0xffffffffull) * args.row_bytes;
-        unsigned char *drow = args.a.arena + (long long)e * args.row_stride;
+        unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
         if ((args.row_bytes & 15) == 0) {
             for (int c = sub * 16; c < args.row_bytes; c += 256) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c);
         } else {
@@ -1841,7 +1825,7 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     const bool c3_inline = old_prio >= 0 && args.c3_tags != nullptr;
     // 3. Everything else is stores nobody waits for: the row, the priority, the slot index, the key word (with this
     //    batch's stamp: nobody takes the entry away again), the final hash word.
-    unsigned char *drow = args.a.arena + (long long)e * args.row_stride;
+    unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
     if constexpr (PIECES > 0) {
         if constexpr (PIECES > 0) reinterpret_cast<U *>(drow)[0] = r0;
         if constexpr (PIECES > 1) reinterpret_cast<U *>(drow)[1] = r1;
@@ -1863,7 +1847,6 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     } else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
     else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
     args.a.eagg[e] = agg;
-    *reinterpret_cast<int *>(drow + args.prio_off) = agg;   // the in-row copy (row_prio): the row's own line
     args.eslot[e] = (int)i;
     // (plain stores: whoever looks at these words during the launch either sees the old value -- a claimed entry, the
     //  pending word of this key -- or the new one, and both mean "not yours"; 255 k returning-or-not atomics per batch
@@ -2161,7 +2144,7 @@ __global__ void __launch_bounds__(256) cache_batch_patch_ptrs_kernel(const Batch
         return;
     }
     const int e = probe_ro(args.slots, args.mask, key, end_slot);
-    if (e >= 0) args.row_ptrs[m] = (long long)(args.a.arena + (long long)e * args.row_stride);
+    if (e >= 0) args.row_ptrs[m] = (long long)(args.a.arena + (long long)e * args.row_bytes);
     else if (e == kPending && args.staging && ((args.staged_mask >> (int)(m % args.T)) & 1u))   // no room in the cache: the staged copy
         args.row_ptrs[m] = (long long)(args.staging + (long long)args.slot_stage[end_slot] * args.row_bytes);
 }
@@ -2303,8 +2286,6 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
     CacheState &h = c->host;
     h = CacheState{};
     h.cap = (int)capacity; h.n_tables = n_tables; h.dim = dim; h.codec = codec; h.row_bytes = dim * codec / 8;
-    h.prio_off = (h.row_bytes + 3) / 4 * 4;              // the in-row priority copy: behind the row, 4-byte aligned
-    h.row_stride = (h.prio_off + 4 + 15) / 16 * 16;      // rows stay 16-byte aligned (fp32 d = 36: 144 + 4 -> 160)
     h.policy = policy;
     long long nslot = 16;
     while (nslot < capacity * 2 + 8) nslot <<= 1;
@@ -2333,7 +2314,7 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
         sp.add(&c->a.prev, capacity * 4);
         sp.add(&c->a.next, capacity * 4);
         sp.add(&c->a.free_stack, capacity * 4);
-        sp.add(&c->a.arena, capacity * (long long)h.row_stride);
+        sp.add(&c->a.arena, capacity * (long long)h.row_bytes);
         sp.add(&c->a.lfu_head, c->a.lfu_max_freq * 4);
         sp.add(&c->a.lfu_tail, c->a.lfu_max_freq * 4);
         sp.add(&c->a.lfu_len, c->a.lfu_max_freq * 4);
@@ -2582,7 +2563,6 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     for (int k = 0; k < kMaxTables; k++) { a.backing[k] = c->backing[k]; a.backing_rows[k] = c->backing_rows[k]; }
     a.requests = rows; a.out = nullptr; a.hit = nullptr; a.B = B; a.mask = (unsigned long long)(c->bnslot - 1);
     a.cap = (int)cap; a.T = T; a.d = c->host.dim; a.codec = c->host.codec; a.row_bytes = c->host.row_bytes;
-    a.row_stride = c->host.row_stride; a.prio_off = c->host.prio_off;
     a.max_perfect = c->host.max_perfect; a.flush_n = c->host.flush_n; a.nslot = (int)c->bnslot;
     a.block_cnt = c->block_cnt; a.block_base = c->block_base; a.part1 = c->part1; a.part2 = c->part2;
     long long g1 = (B + 7) / 8; if (g1 > kProbeGridMax) g1 = kProbeGridMax;
@@ -2840,7 +2820,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         } else
         if (R) {
             const int rc = a.row_ids
-                ? fused_interact_from_row_ids(B, T, c->host.dim, x, x_stride, a.row_ids, c->a.arena, c->host.row_stride,
+                ? fused_interact_from_row_ids(B, T, c->host.dim, x, x_stride, a.row_ids, c->a.arena,
                                               reinterpret_cast<const void *const *>(c->backing), itself, R, st)
                 : fused_interact_from_row_ptrs(B, T, c->host.dim, x, x_stride, (const int64_t *)c->row_ptrs,
                                                (const int64_t *)c->iota, itself, R, st);
@@ -2901,7 +2881,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         if (fold) {
             ProbeArgs pa;
             pa.slots = a.slots; pa.mask = a.mask; pa.reusable_tomb = a.tomb_parity ? kTomb : kTomb1;
-            pa.eagg = a.a.eagg; pa.arena = a.a.arena; pa.row_stride = a.row_stride; pa.prio_off = a.prio_off; pa.requests = rows; pa.hit = hit;
+            pa.eagg = a.a.eagg; pa.requests = rows; pa.hit = hit;
             pa.miss_rec = a.miss_rec; pa.list_cnt = a.list_cnt; pa.list_cap = 16 * T;
             pa.part1 = a.part1; pa.hint_shift = a.hint_shift; pa.T = T;
             a.list_cap = 16 * T;
@@ -3153,7 +3133,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             a.g1 = (int)((B + 15) / 16);   // the update kernel runs one block per list: here a list per 16-sample block
             a.list_cap = 16 * T;
             tp.slots = a.slots; tp.mask = a.mask; tp.reusable_tomb = a.tomb_parity ? kTomb : kTomb1;
-            tp.eagg = a.a.eagg; tp.arena = a.a.arena; tp.row_bytes = a.row_bytes; tp.row_stride = a.row_stride; tp.prio_off = a.prio_off;
+            tp.eagg = a.a.eagg; tp.arena = a.a.arena; tp.row_bytes = a.row_bytes;
             for (int t = 0; t < 32; t++) { tp.backing[t] = t < T ? a.backing[t] : nullptr; tp.backing_rows[t] = t < T ? a.backing_rows[t] : 0; }
             tp.miss_rec = a.miss_rec; tp.list_cnt = a.list_cnt; tp.part1 = a.part1; tp.hint_shift = a.hint_shift;
             tp.count = &a.bs->count; tp.cap = a.cap; tp.full_slack = a.cap > 65536 ? a.cap / 256 : 0;

@@ -155,7 +155,7 @@ int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_
 // of `arena`, clear: row id of table k, -1: the zero row (fp32 rows; is there a kernel: fused_row_ids_supported)
 bool fused_row_ids_supported(int64_t B, int T, int d);
 int fused_interact_from_row_ids(int64_t B, int T, int d, const float *x, int64_t x_stride, const int *row_ids,
-                                const void *arena, int arena_stride, const void *const *tables, int itself, float *R, hipStream_t st);
+                                const void *arena, const void *const *tables, int itself, float *R, hipStream_t st);
 
 // evs_mixed.hip: interaction over x + T rows given as (address, codec class) pairs, decoded on the fly
 int interact_from_mixed_rows(long long B, int T, int d, const float *x, long long x_stride, const long long *row_ptrs,

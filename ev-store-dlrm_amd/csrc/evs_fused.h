@@ -41,7 +41,6 @@ struct FusedArgs {
     // bit 30 set: row (id & 0x3fffffff) of `arena`; clear: row id of the feature's own table src[f]; -1: the zero row
     const int *row_ids;
     const void *arena;
-    int arena_stride = 0;      // bytes between two arena rows (the row, a copy of the entry's priority, padding to 16)
     // ... or the kernel probes the cache itself (PROBE variant): the (B, F-1) request rows in, hit flags, miss lists and
     // hit statistics out -- cache_batch_probe_gather_kernel folded into the head of this launch
     ProbeArgs probe;

@@ -1305,7 +1305,7 @@ int fused_interact_from_row_ptrs(int64_t B, int T, int d, const float *x, int64_
 // interaction over x + T features given as one (B,T) table of 32-bit row ids (cache tier; evs_fused_rf.hip, IDS variant)
 bool fused_row_ids_supported(int64_t B, int T, int d) { return rf_ids_supported(B, T + 1, d); }
 int fused_interact_from_row_ids(int64_t B, int T, int d, const float *x, int64_t x_stride, const int *row_ids,
-                                const void *arena, int arena_stride, const void *const *tables, int itself, float *R, hipStream_t st) {
+                                const void *arena, const void *const *tables, int itself, float *R, hipStream_t st) {
     FusedArgs a;
     const int F = T + 1;
     for (int f = 0; f < EVS_MAX_FEATURES; f++) {
@@ -1321,7 +1321,7 @@ int fused_interact_from_row_ids(int64_t B, int T, int d, const float *x, int64_t
     a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
     a.dummy_i64 = reinterpret_cast<const int64_t *>(a.zeros); a.dummy_f32 = x; a.bag1 = 1; a.enc_lds = 0; a.opt_flag = nullptr; a.opt_id = 0;
     a.w1p = nullptr; a.b1 = nullptr; a.z1 = nullptr; a.n1 = 0; a.kp = 0; a.relu = 0; a.write_r = 1;
-    a.row_ids = row_ids; a.arena = arena; a.arena_stride = arena_stride; a.probe = ProbeArgs{};
+    a.row_ids = row_ids; a.arena = arena; a.probe = ProbeArgs{};
     if (!launch_rf_ids(a, st)) { set_error("fused_interact_from_row_ids: no kernel for B=%lld T=%d d=%d", (long long)B, T, d); return EVS_EINVAL; }
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
@@ -1347,7 +1347,7 @@ int fused_probe_interact(int64_t B, int T, int d, const float *x, int64_t x_stri
     a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
     a.dummy_i64 = reinterpret_cast<const int64_t *>(a.zeros); a.dummy_f32 = x; a.bag1 = 1; a.enc_lds = 0; a.opt_flag = nullptr; a.opt_id = 0;
     a.w1p = nullptr; a.b1 = nullptr; a.z1 = nullptr; a.n1 = 0; a.kp = 0; a.relu = 0; a.write_r = 1;
-    a.row_ids = nullptr; a.arena = arena; a.arena_stride = probe.row_stride; a.probe = probe;
+    a.row_ids = nullptr; a.arena = arena; a.probe = probe;
     if (!launch_rf_probe(a, st)) { set_error("fused_probe_interact: no kernel for B=%lld T=%d d=%d", (long long)B, T, d); return EVS_EINVAL; }
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;

@@ -332,15 +332,12 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             const unsigned neg = (unsigned)(iv >> 31) | phantom;
             unsigned long long base = fbase[j];
             unsigned idx = (unsigned)iv & ~neg;
-            unsigned long long in_arena = 0ull;
             if constexpr (IDS || PROBE) {   // bit 30: a row of the cache arena (bit blend, as below: no select over LDS reads)
-                in_arena = 0ull - (unsigned long long)((idx >> 30) & 1u);
+                const unsigned long long in_arena = 0ull - (unsigned long long)((idx >> 30) & 1u);
                 base ^= (base ^ ((unsigned long long)reinterpret_cast<uintptr_t>(args.arena) + (unsigned long long)dma_piece16)) & in_arena;
                 idx &= 0x3fffffffu;
             }
-            unsigned scale = fscale[j];
-            if constexpr (IDS || PROBE) scale ^= (scale ^ (unsigned)args.arena_stride) & (unsigned)in_arena;   // arena rows: their own stride
-            const unsigned long long p = base + (unsigned long long)idx * (unsigned long long)scale;
+            const unsigned long long p = base + (unsigned long long)idx * (unsigned long long)fscale[j];
             const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
             const unsigned long long pa = p ^ ((p ^ zeros_piece) & m64);
             slot[j] = *reinterpret_cast<gf4_t>((uintptr_t)pa);
@@ -557,8 +554,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
         for (int h = 0; h < 2; h++) {
             if (pe[h] >= 0) {
                 atomicAdd(&s_agg[threadIdx.x & 15], 1);
-                // (the copy inside the arena row: the row's own line, which the kernel fetches anyway -- not a line of eagg[])
-                pprio[h] = *reinterpret_cast<const int *>(pa.arena + (long long)pe[h] * pa.row_stride + pa.prio_off);   // asked for now: it travels while the block meets
+                pprio[h] = pa.eagg[pe[h]];   // asked for now: it travels while the block meets
             }
         }
         __syncthreads();
@@ -568,7 +564,6 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
             // monotone max like update_agg_hit; the plain read first keeps hot entries from serialising on one address
             if (pe[h] >= 0 && pprio[h] < agg) {
-                atomicMax(reinterpret_cast<int *>(pa.arena + (long long)pe[h] * pa.row_stride + pa.prio_off), agg);
                 const int old = atomicMax(&pa.eagg[pe[h]], agg);
                 if (old < agg) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
             }

@@ -92,7 +92,6 @@ struct TierProbe {
     int *eagg;
     const unsigned char *arena;
     int row_bytes;
-    int row_stride, prio_off;             // arena row e at arena + e * row_stride, the in-row copy of its priority at + prio_off
     const unsigned char *backing[32];
     long long backing_rows[32];
     uint4 *miss_rec; int *list_cnt;       // per block: the misses routed to this tier (see BatchArgs::miss_rec)
@@ -118,9 +117,7 @@ int probe2_interact_mixed84(long long B, int T, int d, const float *x, long long
 struct ProbeArgs {
     const unsigned long long *slots; unsigned long long mask;
     unsigned long long reusable_tomb;     // the tombstone value this batch may re-use (parity rule)
-    int *eagg;                            // priorities (monotone max of agg_hit): the compact array
-    unsigned char *arena;                 // ... and the copy inside each arena row (arena + e * row_stride + prio_off): what the
-    int row_stride, prio_off;             //     probe READS -- the line of the row the kernel fetches anyway
+    int *eagg;                            // priorities (monotone max of agg_hit)
     const int *requests;                  // (B,T) int32 row ids
     unsigned char *hit;                   // (B,T) out, may be NULL
     uint4 *miss_rec; int *list_cnt; int list_cap;   // per block: its misses as 16-byte records (see BatchArgs::miss_rec)

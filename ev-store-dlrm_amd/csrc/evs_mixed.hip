@@ -308,16 +308,11 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h, k = f >= 1 ? f - 1 : 0;
-            // (priorities are read from the copy inside the arena row -- a line the kernel fetches anyway -- and raised in both)
-            int *const rp1 = reinterpret_cast<int *>(const_cast<unsigned char *>(pa.t1.arena) + (long long)(e1[h] >= 0 ? e1[h] : 0) * pa.t1.row_stride + pa.t1.prio_off);
-            int *const rp2 = reinterpret_cast<int *>(const_cast<unsigned char *>(pa.t2.arena) + (long long)(e2[h] >= 0 ? e2[h] : 0) * pa.t2.row_stride + pa.t2.prio_off);
-            if (e1[h] >= 0 && *rp1 < agg) {
-                atomicMax(rp1, agg);
+            if (e1[h] >= 0 && pa.t1.eagg[e1[h]] < agg) {
                 const int old = atomicMax(&pa.t1.eagg[e1[h]], agg);
                 if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
             }
-            if (e2[h] >= 0 && *rp2 < agg) {
-                atomicMax(rp2, agg);
+            if (e2[h] >= 0 && pa.t2.eagg[e2[h]] < agg) {
                 const int old = atomicMax(&pa.t2.eagg[e2[h]], agg);
                 if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
             }
@@ -326,10 +321,10 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
             const int dest = !c1_full ? 1 : (agg < pa.threshold ? ((k & 1) ? 1 : 2) : 2);
             const unsigned char *src = nullptr;
             int codec_of = 0;
-            if (e1[h] >= 0) { src = pa.t1.arena + (long long)e1[h] * pa.t1.row_stride; codec_of = 1; }
-            else if (e2[h] >= 0) { src = pa.t2.arena + (long long)e2[h] * pa.t2.row_stride; codec_of = 2; }
-            else if (alt_tier[h] == 1) { src = pa.t1.arena + (long long)ea[h] * pa.t1.row_stride; codec_of = 1; }
-            else if (alt_tier[h] == 2) { src = pa.t2.arena + (long long)ea[h] * pa.t2.row_stride; codec_of = 2; }
+            if (e1[h] >= 0) { src = pa.t1.arena + (long long)e1[h] * pa.t1.row_bytes; codec_of = 1; }
+            else if (e2[h] >= 0) { src = pa.t2.arena + (long long)e2[h] * pa.t2.row_bytes; codec_of = 2; }
+            else if (alt_tier[h] == 1) { src = pa.t1.arena + (long long)ea[h] * pa.t1.row_bytes; codec_of = 1; }
+            else if (alt_tier[h] == 2) { src = pa.t2.arena + (long long)ea[h] * pa.t2.row_bytes; codec_of = 2; }
             else if (miss && dest == 1) { src = pa.t1.backing[k] + (long long)prow[h] * pa.t1.row_bytes; codec_of = 1; }
             else if (miss) { src = pa.t2.backing[k] + (long long)prow[h] * pa.t2.row_bytes; codec_of = 2; }
             if (pa.route_filter && miss && dest == 1 && (k & 1)) pa.route_filter[mix64(key[h]) & pa.route_mask] = pa.route_stamp;
