@@ -172,6 +172,25 @@ def exact_rows(ev, ln, d, n_req):
     torch.cuda.synchronize()
     out.append("| C1 fp32 exact, 2048 requests replayed in one launch | 2048 | %.1f per request | – | – |" % ((time.perf_counter() - t0) * 1e6 / 2048))
     del c
+    # the same stream through the HOST engine of the exact policy (evs_hostcache_*: what ev_lookup runs by default),
+    # tables copied to host memory, one request per call
+    from evstore_dlrm_amd import host_cache as HC
+    tabs_h = [t.cpu().numpy() for t in ev.raw]
+    hc = HC.HostCache("evlfu", cap, T, d, 32, "python").set_backing(tabs_h)
+    hr = host.numpy()
+    o_np, h_np = np.empty((1, T, d), np.float32), np.empty((1, T), np.uint8)
+    lat = []
+    for i in range(n_req):
+        t0 = time.perf_counter()
+        hc.request(hr[i:i + 1], out=o_np, hit=h_np)
+        lat.append((time.perf_counter() - t0) * 1e6)
+    sth = hc.stats()
+    out.append("| C1 fp32 exact, HOST engine (evs_hostcache_request through the Python handle), %d entries | 1 | %.1f | %.1f | %.3f |" % (
+        cap, np.percentile(lat[200:], 50), np.percentile(lat[200:], 95), sth["n_hits"] / (T * n_req)))
+    t0 = time.perf_counter()
+    hc.request(hr[:2048])
+    out.append("| C1 fp32 exact, HOST engine, 2048 requests in one call | 2048 | %.2f per request | – | – |" % ((time.perf_counter() - t0) * 1e6 / 2048))
+    del hc, tabs_h
     ev8, ev4 = bench.make_tables(ln, d, bits=8, seed=8), bench.make_tables(ln, d, bits=4, seed=4)
     c1 = E.GpuCache("evlfu", 9000, T, d, 8, "cpp", dev)      # 1 : 2 entries like "48-48-4" (evlfu_8.cpp:63-78), small enough
     c2 = E.GpuCache("evlfu", 18000, T, d, 4, "cpp", dev)     # that C1 fills and the odd/even routing to C2 starts
@@ -232,7 +251,7 @@ def main():
     ap.add_argument("--only-reduced", action="store_true", help="the reduced-precision rows alone")
     a = ap.parse_args()
     it = 50 if a.quick else 200
-    print("# Round-2 sweep (one MI355X, synthetic uniform indices unless stated; HBM peak used: 8 000 GB/s)\n")
+    print("# Round-3 sweep (one MI355X, synthetic uniform indices unless stated; HBM peak used: 8 000 GB/s)\n")
     print("`fused` = `apply_emb_interact` (one kernel; one index per bag declared); `offsets` = the same with `lS_o` read and")
     print("validated; `two-call` = `apply_emb(lazy=False)` then `interact_features`: two kernels, the pooled rows in HBM (with lazy pooling, the default, the pair runs as the fused launch).  Latencies are per batch, HIP events, inputs resident.")
     print("GB/s = algorithmic bytes (SURVEY 8(d): rows + indices + x read, R written) / mean batch time.\n")
