@@ -880,6 +880,7 @@ struct BatchArgs {
     unsigned long long *c3_tags; long long c3_nset; long long *c3_stat;
     unsigned long long *evicted_keys;   // (alt-key tier attached) the key each free-stack position held before K4 put it there; bit 63 = flushed, not evicted
     int tomb_parity;                // sampled update: parity of this batch (its tombstones are kTomb1 when odd); -1 otherwise
+    unsigned sa_nset;               // set-associative policy (evs_hash.h): number of sets, a.ekey = the sets' key words, arena row = set * kSaWays + way; 0 otherwise
 };
 
 // One atomic per BLOCK instead of one per thread: every thread of the block calls this in uniform
@@ -956,11 +957,28 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         const unsigned long long key = ((unsigned long long)(hl + 1) << 32) | (unsigned)row;
         unsigned long long end_slot = 0;
         bool hint_tomb = false;
-        int e = ok ? probe_ro(args.slots, args.mask, key, end_slot, args.tomb_parity == 1 ? kTomb : args.tomb_parity == 0 ? kTomb1 : kTomb, &hint_tomb) : -1;
-        if (e == kPending) e = -1;
+        int e = -1;
+        unsigned long long sa_w = 0ull;
+        if (args.sa_nset) {   // set-associative policy: one line, the priority inside the word
+            const unsigned set = ok ? sa_set_of(key, args.sa_nset) : 0u;
+            SaLine line;
+            sa_load(args.a.ekey, set, line);
+            const int way = sa_find(line, key, sa_w);
+            if (ok && way >= 0) e = (int)(set * (unsigned)kSaWays + (unsigned)way);
+            end_slot = set;
+        } else {
+            e = ok ? probe_ro(args.slots, args.mask, key, end_slot, args.tomb_parity == 1 ? kTomb : args.tomb_parity == 0 ? kTomb1 : kTomb, &hint_tomb) : -1;
+            if (e == kPending) e = -1;
+        }
         const unsigned long long hm = __ballot(e >= 0);
         const unsigned hmask = (unsigned)(half ? (hm >> 32) : hm);
         const int agg = __popc(hmask);
+        if (args.sa_nset) {
+            if (e >= 0 && sa_prio(sa_w) < agg) {
+                const int old = sa_prio(atomicMax(&args.a.ekey[e], (sa_w & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
+            }
+        } else {
         // monotone max like update_agg_hit; the plain read first keeps hot entries (thousands of requests of
         // one batch hit the same few rows of the tiny tables) from serialising on one atomic address
 #ifndef EVS_X_NOPRIO   // developer A/B (timing only): what the priority read per hit costs the probe
@@ -969,6 +987,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
             if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
         }
 #endif
+        }
         if (args.stamp_hits && e >= 0) args.estamp[e] = args.stamp;
         // where the row lives right now: arena for a hit, backing store for a miss, 0 for a bad row id
         const unsigned char *src = nullptr;
@@ -1857,6 +1876,104 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     if (c3_inline) c3_insert_key(C3Set{args.c3_tags, args.c3_nset, args.c3_stat}, old_key & kKeyMask);   // what this thread evicted -> the alt-key set
 }
 
+// Set-associative policy (evs_hash.h, batch policy 2): one missed key of the batch.  The record carries the key's set; its
+// line (16 key words: key | batch stamp | priority) and the source row go out together, then ONE CAS on the way of the
+// lowest priority (free ways first, lowest way index among equals; ways filled in this batch excepted), then stores
+// nobody waits for.  Two dependent round trips behind the record.
+// Copies of one missing key: every copy looks at the same words and ranks them the same way, so two copies that both
+// believe the key is absent choose the same way and the CAS lets one through; the loser's CAS returns the word that beat
+// it -- the key itself (fold the priority, done) or another key of this batch (that way is out, next best).  The line
+// is read plainly: what a plain read can return is a word as it stood at the start of the launch or one written in it,
+// and a way changes at most once per launch (old -> stamped), which is all the argument needs.
+template <int PIECES, typename U, typename TAIL = NoTail>
+__device__ __forceinline__ void sa_insert_one(const BatchArgs &args, int t, unsigned row, int agg, unsigned set, int *s_delta, int *s_stat) {
+    const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
+    unsigned long long *tags = args.a.ekey + (unsigned long long)set * kSaWays;
+    SaLine line;
+    sa_load(tags, 0u, line);
+    const unsigned char *srow = args.backing[t] + (long long)row * args.row_bytes;
+    U r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
+    if constexpr (PIECES > 0) r0 = reinterpret_cast<const U *>(srow)[0];
+    if constexpr (PIECES > 1) r1 = reinterpret_cast<const U *>(srow)[1];
+    if constexpr (PIECES > 2) r2 = reinterpret_cast<const U *>(srow)[2];
+    if constexpr (PIECES > 3) r3 = reinterpret_cast<const U *>(srow)[3];
+    if constexpr (PIECES > 4) r4 = reinterpret_cast<const U *>(srow)[4];
+    if constexpr (PIECES > 5) r5 = reinterpret_cast<const U *>(srow)[5];
+    if constexpr (PIECES > 6) r6 = reinterpret_cast<const U *>(srow)[6];
+    if constexpr (PIECES > 7) r7 = reinterpret_cast<const U *>(srow)[7];
+    if constexpr (PIECES > 8) r8 = reinterpret_cast<const U *>(srow)[8];
+    if constexpr (PIECES > 9) r9 = reinterpret_cast<const U *>(srow)[9];
+    if constexpr (PIECES > 10) r10 = reinterpret_cast<const U *>(srow)[10];
+    if constexpr (PIECES > 11) r11 = reinterpret_cast<const U *>(srow)[11];
+    if constexpr (PIECES > 12) r12 = reinterpret_cast<const U *>(srow)[12];
+    if constexpr (PIECES > 13) r13 = reinterpret_cast<const U *>(srow)[13];
+    if constexpr (PIECES > 14) r14 = reinterpret_cast<const U *>(srow)[14];
+    if constexpr (PIECES > 15) r15 = reinterpret_cast<const U *>(srow)[15];
+    TAIL rt;
+    if constexpr (!std::is_same<TAIL, NoTail>::value) rt = *reinterpret_cast<const TAIL *>(srow + PIECES * sizeof(U));
+    const unsigned cur = (unsigned)args.stamp & kSaStampMask;
+    const unsigned long long neww = sa_word(key, cur, agg);
+    unsigned long long w[kSaWays];
+#pragma unroll
+    for (int j = 0; j < kSaWays / 2; j++) { w[2 * j] = line.v[j].x; w[2 * j + 1] = line.v[j].y; }
+    int way = -1, old_prio = -1;
+    bool done = false;
+#pragma unroll 1
+    for (int attempt = 0; attempt <= kSaWays && !done; attempt++) {
+        int best = -1, bp = 0x7fffffff, dup = -1;
+        unsigned long long bw = 0ull, dw = 0ull;
+#pragma unroll
+        for (int j = 0; j < kSaWays; j++) {
+            const bool is_dup = (w[j] & kKeyMask) == key;
+            dup = is_dup ? j : dup; dw = is_dup ? w[j] : dw;
+            const int pj = w[j] == kEmpty ? -1 : sa_prio(w[j]);
+            const bool cand = (w[j] == kEmpty || sa_stamp(w[j]) != cur) && pj < bp;
+            best = cand ? j : best; bp = cand ? pj : bp; bw = cand ? w[j] : bw;
+        }
+        if (dup >= 0) {   // another copy of the key got here first: its priority is the maximum over the copies
+            if (sa_prio(dw) < agg) {
+                const int old = sa_prio(atomicMax(&tags[dup], (dw & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
+            }
+            done = true;
+        } else if (best < 0) {
+            done = true;   // every way of the set was filled in this batch: the key is not kept
+        } else {
+            const unsigned long long prev = atomicCAS(&tags[best], bw, neww);
+            if (prev == bw) { way = best; old_prio = bp; done = true; }
+            else {
+#pragma unroll
+                for (int j = 0; j < kSaWays; j++) w[j] = j == best ? prev : w[j];
+            }
+        }
+    }
+    if (way < 0) return;
+    if (old_prio >= 0) { atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); }
+    else atomicAdd(&s_stat[0], 1);
+    atomicAdd(&s_delta[agg], 1);
+    unsigned char *drow = args.a.arena + ((long long)set * kSaWays + way) * args.row_bytes;
+    if constexpr (PIECES > 0) {
+        if constexpr (PIECES > 0) reinterpret_cast<U *>(drow)[0] = r0;
+        if constexpr (PIECES > 1) reinterpret_cast<U *>(drow)[1] = r1;
+        if constexpr (PIECES > 2) reinterpret_cast<U *>(drow)[2] = r2;
+        if constexpr (PIECES > 3) reinterpret_cast<U *>(drow)[3] = r3;
+        if constexpr (PIECES > 4) reinterpret_cast<U *>(drow)[4] = r4;
+        if constexpr (PIECES > 5) reinterpret_cast<U *>(drow)[5] = r5;
+        if constexpr (PIECES > 6) reinterpret_cast<U *>(drow)[6] = r6;
+        if constexpr (PIECES > 7) reinterpret_cast<U *>(drow)[7] = r7;
+        if constexpr (PIECES > 8) reinterpret_cast<U *>(drow)[8] = r8;
+        if constexpr (PIECES > 9) reinterpret_cast<U *>(drow)[9] = r9;
+        if constexpr (PIECES > 10) reinterpret_cast<U *>(drow)[10] = r10;
+        if constexpr (PIECES > 11) reinterpret_cast<U *>(drow)[11] = r11;
+        if constexpr (PIECES > 12) reinterpret_cast<U *>(drow)[12] = r12;
+        if constexpr (PIECES > 13) reinterpret_cast<U *>(drow)[13] = r13;
+        if constexpr (PIECES > 14) reinterpret_cast<U *>(drow)[14] = r14;
+        if constexpr (PIECES > 15) reinterpret_cast<U *>(drow)[15] = r15;
+        if constexpr (!std::is_same<TAIL, NoTail>::value) *reinterpret_cast<TAIL *>(drow + PIECES * sizeof(U)) = rt;
+    } else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
+    else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
+}
+
 template <int PIECES, typename U, typename TAIL = NoTail>
 __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArgs args) {
     __shared__ int s_delta[kMaxBuckets];
@@ -1893,10 +2010,13 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
 // mostly busy lanes instead of 6 656 waves with one lane in eight busy, and everything a miss needs arrives with its
 // record (the per-position form reads the probe word, then the request row, then starts).
 constexpr int kListVictMax = 512;   // (the folded two-tier probe lists 16 T <= 432 records per block)
-template <int PIECES, typename U, typename TAIL>
+template <int PIECES, typename U, typename TAIL, bool SA = false>
 __device__ __forceinline__ void sampled_list_block(const BatchArgs &args, int bid);
 template <int PIECES, typename U, typename TAIL = NoTail>
 __global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const BatchArgs args) { sampled_list_block<PIECES, U, TAIL>(args, (int)blockIdx.x); }
+// the set-associative policy's update: the same lists, sa_insert_one per record
+template <int PIECES, typename U, typename TAIL = NoTail>
+__global__ void __launch_bounds__(256) cache_batch_sa_list_kernel(const BatchArgs args) { sampled_list_block<PIECES, U, TAIL, true>(args, (int)blockIdx.x); }
 // both tiers of a two-tier lookup in one launch (their updates are independent once the probe has stamped the route
 // filter): blocks [0, g1) take C1's lists, [g1, 2 g1) C2's
 template <int P1, typename U1, typename T1, int P2, typename U2, typename T2>
@@ -1904,7 +2024,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_list2_kernel(const Ba
     if ((int)blockIdx.x < args1.g1) sampled_list_block<P1, U1, T1>(args1, (int)blockIdx.x);
     else sampled_list_block<P2, U2, T2>(args2, (int)blockIdx.x - args1.g1);
 }
-template <int PIECES, typename U, typename TAIL>
+template <int PIECES, typename U, typename TAIL, bool SA>
 __device__ __forceinline__ void sampled_list_block(const BatchArgs &args, int bid) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
@@ -1921,6 +2041,8 @@ __device__ __forceinline__ void sampled_list_block(const BatchArgs &args, int bi
     const int nw = (int)blockDim.x >> 6;
     for (int i = ((int)threadIdx.x & 63) * nw + ((int)threadIdx.x >> 6); i < n; i += 64 * nw) {
         const uint4 r = rec[i];
+        if constexpr (SA) sa_insert_one<PIECES, U, TAIL>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, s_delta, s_stat);
+        else
         sampled_insert_one<PIECES, U, TAIL>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, (r.y & 0x10000u) != 0, (long long)r.w,
                                    s_delta, s_stat, args.vict_cnt ? s_vict : nullptr, &s_nvict);
     }
@@ -2023,6 +2145,25 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_flush_kernel(BatchSta
             a.ekey[e] = kEmpty;
             atomicAdd(&s_gone, 1);
         }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_gone) atomicAdd(&b->flush_gone, s_gone);
+}
+// the same for the set-associative policy: the top-priority ways, first come first served over the sets
+__global__ void __launch_bounds__(256) cache_batch_sa_flush_kernel(BatchState *b, unsigned long long *tags, long long n_ent, int T, int flush_n, int max_perfect) {
+    __shared__ int s_tot[8];
+    __shared__ int s_gone;
+    const int top_n = b->cnt[T];
+    if (top_n < max_perfect) return;
+    if (threadIdx.x == 0) s_gone = 0;
+    const int want = flush_n < top_n ? flush_n : top_n;
+    __syncthreads();
+    for (long long e0 = (long long)blockIdx.x * blockDim.x; e0 < n_ent; e0 += (long long)gridDim.x * blockDim.x) {   // block-uniform trip count
+        const long long e = e0 + threadIdx.x;
+        const unsigned long long w = e < n_ent ? tags[e] : kEmpty;
+        const bool top = w != kEmpty && sa_prio(w) == T;
+        const int tk = block_reserve(&b->ticket_t, top, s_tot);
+        if (top && tk < want) { tags[e] = kEmpty; atomicAdd(&s_gone, 1); }
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_gone) atomicAdd(&b->flush_gone, s_gone);
@@ -2237,7 +2378,8 @@ struct evs_cache {
     unsigned long long *evicted_keys = nullptr;   // batched three-tier lookup: what K4 evicted, for the alt-key tier
     unsigned *route_filter = nullptr;   // two-tier sampled update (held by C1): see BatchArgs::route_filter
     unsigned long long *vict_keys = nullptr; int *vict_cnt = nullptr; long long vict_cap = 0;   // ... what the sampled update evicted (kReplicas lists)   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
-    int batch_policy = -1;         // policy update of the batched path: 0 plan-based (K2..K6), 1 sampled (one kernel); -1: EVS_CACHE_POLICY, default sampled
+    int batch_policy = -1;         // policy update of the batched path: 0 plan-based (K2..K6), 1 sampled (one kernel), 2 set-associative (evs_hash.h); -1: EVS_CACHE_POLICY, default sampled
+    unsigned sa_nset = 0;          // set-associative policy: number of sets (capacity / kSaWays)
 };
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
@@ -2382,7 +2524,8 @@ extern "C" int64_t evs_cache_staged_rows(evs_cache *c) { return c ? c->n_staged_
 
 extern "C" int evs_cache_set_batch_policy(evs_cache *c, int policy) {
     using namespace evs;
-    EVS_REQUIRE(c && (policy == 0 || policy == 1), "evs_cache_set_batch_policy: bad argument");
+    EVS_REQUIRE(c && policy >= 0 && policy <= 2, "evs_cache_set_batch_policy: bad argument");
+    EVS_REQUIRE(policy != 2 || c->host.cap >= kSaWays, "evs_cache_set_batch_policy: the set-associative policy needs a capacity of at least %d entries", kSaWays);
     if (c->used == 2) { set_error("evs_cache_set_batch_policy: the batched path is already in use"); return EVS_ESTATE; }
     c->batch_policy = policy;
     return EVS_OK;
@@ -2483,6 +2626,7 @@ extern "C" int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, c
 
 // ---- batched path --------------------------------------------------------------------------
 // allocate / grow the batched-path state of one cache and describe it in `a` (everything but the per-call outputs)
+static int resolved_batch_policy(evs_cache *c, bool single_tier = true);
 static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream_t st, evs::BatchArgs &a, const char *who) {
     using namespace evs;
     EVS_REQUIRE(c, "%s: NULL cache", who);
@@ -2494,6 +2638,9 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     EVS_REQUIRE(B > 0 && B < (1ll << 31) / 32 && rows, "%s: bad argument", who);
     const int T = c->host.n_tables;
     const long long cap = c->host.cap;
+    const bool sa = resolved_batch_policy(c) == 2;   // set-associative policy: no hash, no entry arrays (the key words of the sets are c->a.ekey)
+    if (sa) c->sa_nset = (unsigned)(cap / kSaWays);
+    const long long hash_words = sa ? 1 : c->bnslot;
     if (!c->bs) {   // first batched call: all-or-nothing, so a failed allocation leaves the cache as it was
         BatchState h{};
         h.n_free = (int)cap;
@@ -2502,11 +2649,11 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
         unsigned long long *bslots = nullptr;
         void *slab = nullptr;
         SlabPlan sp;
-        sp.add(&bs, sizeof(BatchState)); sp.add(&eslot, cap * 4); sp.add(&bslots, c->bnslot * 8);
+        sp.add(&bs, sizeof(BatchState)); sp.add(&eslot, sa ? 4 : cap * 4); sp.add(&bslots, hash_words * 8);
         sp.add(&part1, kReplicas * kPartCols * 4); sp.add(&part2, kReplicas * kPartCols * 4);
         const bool ok =
             sp.carve(&slab) && hipMemcpy(bs, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess &&   // blocking copy
-            hipMemsetAsync(bslots, 0, c->bnslot * 8, st) == hipSuccess &&                               // ordered on the caller's stream
+            hipMemsetAsync(bslots, 0, hash_words * 8, st) == hipSuccess &&                               // ordered on the caller's stream
             hipMemsetAsync(part1, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
             hipMemsetAsync(part2, 0, kReplicas * kPartCols * 4, st) == hipSuccess &&
             hipHostMalloc(reinterpret_cast<void **>(&host_tomb), 4 * sizeof(int), hipHostMallocMapped) == hipSuccess &&   // [0] tombstones, [1] flush wanted, [2] which close reported [0]
@@ -2558,7 +2705,7 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     a.bs = c->bs; a.a = c->a; a.eslot = c->eslot; a.slots = c->bslots;
     a.miss_info = c->miss_info; a.new_slot = c->new_slot;
     a.hint_shift = 0;
-    while ((c->bnslot >> a.hint_shift) > (1ll << 24)) a.hint_shift++;
+    while (!sa && (c->bnslot >> a.hint_shift) > (1ll << 24)) a.hint_shift++;   // (set-associative policy: the records carry the whole set index)
     a.row_ptrs = c->row_ptrs; a.row_ids = nullptr;
     for (int k = 0; k < kMaxTables; k++) { a.backing[k] = c->backing[k]; a.backing_rows[k] = c->backing_rows[k]; }
     a.requests = rows; a.out = nullptr; a.hit = nullptr; a.B = B; a.mask = (unsigned long long)(c->bnslot - 1);
@@ -2577,9 +2724,10 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     // three calls the sweep did not help enough and the hash is rebuilt.
     a.evicted_keys = nullptr; a.vict_cnt = nullptr; a.vict_other = nullptr; a.vict_cap = 0; a.c3_tags = nullptr; a.c3_nset = 0; a.c3_stat = nullptr; a.miss_rec = nullptr; a.list_cnt = nullptr; a.list_cap = 0;
     a.tomb_parity = -1;
+    a.sa_nset = sa ? c->sa_nset : 0u;
     a.rebuild = 0;
     c->batch_calls++;   // = the ordinal of this call's close
-    {
+    if (!sa) {
         volatile int *hk = reinterpret_cast<volatile int *>(c->host_tomb);
         const long long seq = hk[2];
         // (the device runs behind the host: a report is only news if its close came after the last sweep / rebuild)
@@ -2711,6 +2859,27 @@ static void launch_sampled_update(const evs::BatchArgs &a, hipStream_t st) {
     }
 }
 
+// the set-associative policy's update (always the list form), compiled per row size like the sampled one
+template <int PIECES, typename U, typename TAIL = evs::NoTail>
+static void launch_sa_update_t(const evs::BatchArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL((evs::cache_batch_sa_list_kernel<PIECES, U, TAIL>), dim3((unsigned)a.g1), dim3(sampled_list_threads(a)), 0, st, a);
+}
+static void launch_sa_update(const evs::BatchArgs &a, hipStream_t st) {
+    switch (a.row_bytes) {
+    case 144: launch_sa_update_t<9, float4>(a, st); break;
+    case 256: launch_sa_update_t<16, float4>(a, st); break;
+    case 128: launch_sa_update_t<8, float4>(a, st); break;
+    case 64: launch_sa_update_t<4, float4>(a, st); break;
+    case 32: launch_sa_update_t<2, float4>(a, st); break;
+    case 16: launch_sa_update_t<1, float4>(a, st); break;
+    case 72: launch_sa_update_t<4, float4, uint2>(a, st); break;
+    case 36: launch_sa_update_t<2, float4, unsigned>(a, st); break;
+    case 18: launch_sa_update_t<1, float4, unsigned short>(a, st); break;
+    case 8: launch_sa_update_t<1, uint2>(a, st); break;
+    default: launch_sa_update_t<0, float4>(a, st); break;
+    }
+}
+
 // both tiers' list updates as one launch (the pairs of row sizes a u8 C1 + u4 C2 make); false: no merged kernel for the pair
 static bool launch_sampled_update_pair(const evs::BatchArgs &a1, const evs::BatchArgs &a2, hipStream_t st) {
     using namespace evs;
@@ -2727,10 +2896,17 @@ static bool launch_sampled_update_pair(const evs::BatchArgs &a1, const evs::Batc
     return true;
 }
 
-static int resolved_batch_policy(evs_cache *c) {
+// The batch policy of a cache that was not given one (evs_cache_set_batch_policy) is decided at its first batched call:
+// EVS_CACHE_POLICY = plan | sampled | setassoc, else the set-associative form where it applies -- a single tier whose
+// tables the kernels read in place (HBM), at least one full set -- and the sampled update everywhere else (host-memory
+// and file-backed miss tiers, the two- / three-tier lookups).
+static int resolved_batch_policy(evs_cache *c, bool single_tier) {
     if (c->batch_policy < 0) {
         const char *e = getenv("EVS_CACHE_POLICY");
-        c->batch_policy = (e && e[0] == 'p') ? 0 : 1;   // "plan" / "sampled"
+        const bool sa_ok = single_tier && !c->host_backing && !c->ft && c->host.cap >= evs::kSaWays;
+        if (e && e[0] == 'p') c->batch_policy = 0;
+        else if (e && e[0] == 's' && e[1] == 'a') c->batch_policy = 1;
+        else c->batch_policy = sa_ok ? 2 : 1;
     }
     return c->batch_policy;
 }
@@ -2744,7 +2920,7 @@ static evs::CloseArgs sampled_close_args(evs_cache *c, int rebuild) {
 }
 static void sampled_close_pending(evs_cache *c, int rebuild, hipStream_t st) {
     using namespace evs;
-    if (c->batch_policy != 1 || !c->bs || c->pending_batches == 0) return;
+    if ((c->batch_policy != 1 && c->batch_policy != 2) || !c->bs || c->pending_batches == 0) return;
     const CloseArgs ca = sampled_close_args(c, rebuild);
     hipLaunchKernelGGL(cache_batch_sampled_close_kernel, dim3(1), dim3(256), 0, st, ca);
     c->pending_batches = 0; c->pending_requests = 0;
@@ -2762,13 +2938,19 @@ static void sampled_close_pending2(evs_cache *c1, int rebuild1, evs_cache *c2, i
 // sampled policy: the EvLFU flush the close of an earlier batch asked for (a flag in mapped host memory)
 static void sampled_flush_if_wanted(evs_cache *c, hipStream_t st) {
     using namespace evs;
-    if (c->batch_policy != 1 || !c->host_tomb || !c->bs) return;
+    if ((c->batch_policy != 1 && c->batch_policy != 2) || !c->host_tomb || !c->bs) return;
     volatile int *flags = reinterpret_cast<volatile int *>(c->host_tomb);
     if (!flags[1]) return;
     flags[1] = 0;
     c->last_flush_call = c->batch_calls;   // "full" reports of closes before this call are void
     const int wide = kNumCu * 8;
     long long nf = ((long long)c->host.cap + 255) / 256; if (nf > wide) nf = wide;
+    if (c->batch_policy == 2) {
+        hipLaunchKernelGGL(cache_batch_sa_flush_kernel, dim3((unsigned)nf), dim3(256), 0, st, c->bs, c->a.ekey, (long long)c->sa_nset * kSaWays,
+                           c->host.n_tables, c->host.flush_n, c->host.max_perfect);
+        hipLaunchKernelGGL(cache_batch_sampled_flush_finish_kernel, dim3(1), dim3(1), 0, st, c->bs, c->host.n_tables);
+        return;
+    }
     hipLaunchKernelGGL(cache_batch_sampled_flush_kernel, dim3((unsigned)nf), dim3(256), 0, st, c->bs, c->a, c->bslots, c->eslot,
                        (int)c->host.cap, c->host.n_tables, c->host.flush_n, c->host.max_perfect);
     hipLaunchKernelGGL(cache_batch_sampled_flush_finish_kernel, dim3(1), dim3(1), 0, st, c->bs, c->host.n_tables);
@@ -2844,6 +3026,38 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
                     "evs_cache_lookup_interact: a reduced-precision cache needs d in {16, 32, 36}, T <= 31 and its tables in HBM");
     // consumers of the snapshot read the rows BEFORE the policy kernels move anything
     const bool file_mode = c->ft && c->staged_mask;
+    if (resolved_batch_policy(c) == 2) {
+        // Set-associative policy (evs_hash.h): probe (one line per key) -> consumers -> ONE update kernel (one line, one
+        // CAS and the row per new key) -> counters folded every kCloseEvery-th batch.  No hash, no tombstones, no sweeps.
+        if (host_tier || c->ft) { set_error("evs_cache_lookup_batch: the set-associative batch policy reads its miss tier in place from HBM (no host-memory / file-backed tables)"); return EVS_ESTATE; }
+        a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;
+        sampled_flush_if_wanted(c, st);
+        a.miss_rec = c->miss_rec; a.list_cnt = c->list_cnt;
+        a.list_cap = (int)((B + 8 * (long long)a.g1 - 1) / (8 * (long long)a.g1)) * 8 * T;
+        static const bool fold_on = !(getenv("EVS_CACHE_FOLD") && getenv("EVS_CACHE_FOLD")[0] == '0');
+        const bool fold = fold_on && a.row_ids && R && !out;
+        if (fold) {
+            ProbeArgs pa;
+            pa.slots = nullptr; pa.mask = 0; pa.reusable_tomb = kTomb; pa.eagg = nullptr;
+            pa.requests = rows; pa.hit = hit;
+            pa.miss_rec = a.miss_rec; pa.list_cnt = a.list_cnt; pa.list_cap = 16 * T;
+            pa.part1 = a.part1; pa.hint_shift = 0; pa.T = T;
+            pa.tags = c->a.ekey; pa.sa_nset = c->sa_nset;
+            a.list_cap = 16 * T;
+            a.g1 = (int)((B + 15) / 16);
+            const int rc = fused_probe_interact(B, T, c->host.dim, x, x_stride, pa, c->a.arena,
+                                                reinterpret_cast<const void *const *>(c->backing), c->backing_rows, itself, R, st);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)a.g1), dim3(256), 0, st, a);
+            const int rc = consumers(); if (rc) return rc;
+        }
+        launch_sa_update(a, st);
+        c->pending_batches++; c->pending_requests += B;
+        if (c->pending_batches >= kCloseEvery) sampled_close_pending(c, 0, st);
+        EVS_HIP_CHECK(hipGetLastError());
+        return EVS_OK;
+    }
     if (resolved_batch_policy(c) == 1 && !file_mode) {
         // Sampled policy update: probe -> consumers -> ONE update kernel -> close.  (Host-memory miss tier: the update
         // first -- it fetches each missing row once -- then the re-pointed consumers.)
@@ -2884,6 +3098,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
             pa.eagg = a.a.eagg; pa.requests = rows; pa.hit = hit;
             pa.miss_rec = a.miss_rec; pa.list_cnt = a.list_cnt; pa.list_cap = 16 * T;
             pa.part1 = a.part1; pa.hint_shift = a.hint_shift; pa.T = T;
+            pa.tags = nullptr; pa.sa_nset = 0;
             a.list_cap = 16 * T;
             a.g1 = (int)((B + 15) / 16);   // the update kernel runs one wave per list: here a list per 16-sample block
             const int rc = fused_probe_interact(B, T, c->host.dim, x, x_stride, pa, c->a.arena,
@@ -3040,6 +3255,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     EVS_REQUIRE(c1->host.n_tables == c2->host.n_tables && c1->host.dim == c2->host.dim,
                 "evs_cache_lookup_batch_c1c2: the tiers must agree on n_tables and dim");
     EVS_REQUIRE(!c1->host_backing && !c2->host_backing, "evs_cache_lookup_batch_c1c2: backing tables must be in HBM");
+    EVS_REQUIRE(resolved_batch_policy(c1, false) != 2 && resolved_batch_policy(c2, false) != 2, "evs_cache_lookup_batch_c1c2: the set-associative batch policy serves single tiers only");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     BatchArgs a1, a2;
     int rc = batch_prepare(c1, B, rows, st, a1, "evs_cache_lookup_batch_c1c2");
@@ -3241,7 +3457,8 @@ extern "C" int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t 
     for (int64_t e = 0; e < cap; e++) {
         const unsigned long long key = ekey[e] & evs::kKeyMask;
         if (!key) continue;   // (the sampled update keeps a batch stamp above the key)
-        if (n < max_triples && triples) { triples[3 * n] = eagg[e]; triples[3 * n + 1] = (int64_t)(key >> 32); triples[3 * n + 2] = (int64_t)(key & 0xffffffffull); }
+        const int64_t prio = c->batch_policy == 2 ? (int64_t)(ekey[e] >> evs::kSaPrioShift) : eagg[e];   // (set-associative policy: the priority rides in the key word)
+        if (n < max_triples && triples) { triples[3 * n] = prio; triples[3 * n + 1] = (int64_t)(key >> 32); triples[3 * n + 2] = (int64_t)(key & 0xffffffffull); }
         n++;
     }
     return n;

@@ -525,11 +525,34 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             const int *rp = pact[h] ? pa.requests + bs * (int64_t)T + (f - 1) : reinterpret_cast<const int *>(dummy_i);
             prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
         }
+        const bool sa = pa.sa_nset != 0;   // set-associative cache (evs_hash.h): one line per key, the priority inside the key word
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
             pok[h] = pact[h] && prow[h] >= 0 && (unsigned)prow[h] < s_tile_nr[f];
             pkey[h] = ((unsigned long long)f << 32) | (unsigned)prow[h];   // table_1based = f
+        }
+        if (sa) {
+            SaLine line[2];
+            unsigned pset[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                pset[h] = pok[h] ? sa_set_of(pkey[h], pa.sa_nset) : 0u;
+                sa_load(pa.tags, pset[h], line[h]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                unsigned long long w;
+                const int way = sa_find(line[h], pkey[h], w);
+                const bool found = pok[h] && way >= 0;
+                pe[h] = found ? (int)(pset[h] * (unsigned)kSaWays + (unsigned)way) : -1;
+                pprio[h] = found ? sa_prio(w) : 0x7fffffff;
+                pw0[h] = w; phint[h] = pset[h]; ptomb[h] = false;
+                if (found) atomicAdd(&s_agg[threadIdx.x & 15], 1);
+            }
+        } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
             phome[h] = mix64(pkey[h]) & pa.mask;
             pw0[h] = pa.slots[pok[h] ? phome[h] : 0];
         }
@@ -557,6 +580,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
                 pprio[h] = pa.eagg[pe[h]];   // asked for now: it travels while the block meets
             }
         }
+        }
         __syncthreads();
         const int agg = s_agg[threadIdx.x & 15];
 #pragma unroll
@@ -564,7 +588,9 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_ke
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
             // monotone max like update_agg_hit; the plain read first keeps hot entries from serialising on one address
             if (pe[h] >= 0 && pprio[h] < agg) {
-                const int old = atomicMax(&pa.eagg[pe[h]], agg);
+                int old;
+                if (sa) old = sa_prio(atomicMax(&pa.tags[pe[h]], (pw0[h] & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                else old = atomicMax(&pa.eagg[pe[h]], agg);
                 if (old < agg) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
             }
             int v = -1;
@@ -807,7 +833,7 @@ bool launch_rf_ids(const FusedArgs &a, hipStream_t st) {
 }
 
 bool launch_rf_probe(const FusedArgs &a, hipStream_t st) {
-    if (!rf_ids_supported(a.B, a.F, a.d) || !a.probe.slots || !a.arena) return false;
+    if (!rf_ids_supported(a.B, a.F, a.d) || (!a.probe.slots && !a.probe.sa_nset) || !a.arena) return false;
     const bool nt2 = a.F > 16;
     switch (a.d) {
     case 16:

@@ -62,6 +62,45 @@ __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigne
 }
 
 
+// ---- set-associative form of the batched cache (batch policy 2, "setassoc") ------------------------------------------
+// No hash chain and no entry arrays: key -> set = (mix64(key) >> 32) * nset >> 32, a set is kSaWays consecutive 8-byte
+// words = ONE 128-byte line, way w of set s owns arena row s * kSaWays + w.  A word = key (38 bits) | batch stamp
+// (19 bits: the batch that filled the way) | priority (7 bits, the EvLFU agg_hit maximum) -- the priority sits in the top
+// bits, so "raise the priority of this key" is one 64-bit atomicMax on the word.  A probe is one line, an insert is that
+// line + one CAS + the row; nothing ever moves, so there are no tombstones, no sweeps and no rebuilds.  The victim of a
+// new key is the lowest priority of ITS OWN set (free ways first), ways filled in the running batch excepted.
+constexpr int kSaWays = 16;
+constexpr int kSaPrioShift = 57;
+constexpr unsigned kSaStampMask = (1u << (kSaPrioShift - kKeyBits)) - 1u;
+constexpr unsigned long long kSaLowMask = (1ull << kSaPrioShift) - 1ull;
+__device__ __forceinline__ unsigned sa_set_of(unsigned long long key, unsigned nset) {
+    return (unsigned)(((mix64(key) >> 32) * (unsigned long long)nset) >> 32);
+}
+__device__ __forceinline__ unsigned long long sa_word(unsigned long long key, unsigned stamp, int prio) {
+    return key | ((unsigned long long)(stamp & kSaStampMask) << kKeyBits) | ((unsigned long long)prio << kSaPrioShift);
+}
+__device__ __forceinline__ int sa_prio(unsigned long long w) { return (int)(w >> kSaPrioShift); }
+__device__ __forceinline__ unsigned sa_stamp(unsigned long long w) { return (unsigned)(w >> kKeyBits) & kSaStampMask; }
+// the set's line, as 16-byte loads that all go out before the first one is looked at
+struct SaLine { ulonglong2 v[kSaWays / 2]; };
+__device__ __forceinline__ void sa_load(const unsigned long long *tags, unsigned set, SaLine &l) {
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(tags + (unsigned long long)set * kSaWays);
+#pragma unroll
+    for (int j = 0; j < kSaWays / 2; j++) l.v[j] = p[j];
+}
+// way holding `key` (-1: none) and its word
+__device__ __forceinline__ int sa_find(const SaLine &l, unsigned long long key, unsigned long long &word) {
+    int way = -1;
+    word = 0ull;
+#pragma unroll
+    for (int j = 0; j < kSaWays / 2; j++) {
+        const bool a = (l.v[j].x & kKeyMask) == key, b = (l.v[j].y & kKeyMask) == key;
+        way = a ? 2 * j : b ? 2 * j + 1 : way;
+        word = a ? l.v[j].x : b ? l.v[j].y : word;
+    }
+    return way;
+}
+
 constexpr int kMaxTables = 64;      // one lane per table (exact path)
 
 // Batched form of the alt-key tier C3 (see evs_cache.hip): a kSetWays-way set-associative set of key words
@@ -123,6 +162,7 @@ struct ProbeArgs {
     uint4 *miss_rec; int *list_cnt; int list_cap;   // per block: its misses as 16-byte records (see BatchArgs::miss_rec)
     int *part1;                           // replica rows of the hit / histogram totals
     int hint_shift, T;
+    unsigned long long *tags; unsigned sa_nset;   // set-associative form (sa_nset != 0): the sets' key words instead of slots / eagg
 };
 
 // evs_fused.hip: interaction over x + the T rows the cache serves, the probe folded into the kernel (fp32 rows; is there a

@@ -361,9 +361,20 @@ def _zipf_requests(n_rows, n_req, seed, alpha=1.15):
 
 
 POLICIES = ["sampled", "plan"]   # evs_cache_set_batch_policy: one update kernel with sampled victims / insert-plan-evict-assign
+POLICIES1 = POLICIES + ["setassoc"]   # ... / 16-way set-associative (single tier, tables in HBM)
+SA_WAYS = 16
 
 
-@pytest.mark.parametrize("policy", POLICIES)
+def _sa_sets(keys_tr, cap):
+    """Set of each (table_1based, row) key under the set-associative policy (csrc/evs_hash.h: sa_set_of)."""
+    k = (np.asarray([t for t, _ in keys_tr], np.uint64) << np.uint64(32)) | np.asarray([r for _, r in keys_tr], np.uint64)
+    with np.errstate(over="ignore"):
+        k ^= k >> np.uint64(33); k *= np.uint64(0xff51afd7ed558ccd); k ^= k >> np.uint64(33)
+        k *= np.uint64(0xc4ceb9fe1a85ec53); k ^= k >> np.uint64(33)
+    return ((k >> np.uint64(32)) * np.uint64(cap // SA_WAYS)) >> np.uint64(32)
+
+
+@pytest.mark.parametrize("policy", POLICIES1)
 @pytest.mark.parametrize("cap_frac,batch", [(0.10, 256), (0.02, 64), (0.5, 1024)])
 def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch, policy):
     """Batched (snapshot) EvLFU under both policy updates: rows exact, hit flags = residency at batch start, no duplicate
@@ -398,7 +409,17 @@ def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch, policy):
                 assert p >= resident[key]
         # every key of the batch that could be kept is resident afterwards when there was room (the sampled update may
         # pick a key that was HIT in this batch as a victim while free entries remain elsewhere: missed keys only there)
-        if st["size"] < cap:
+        if policy == "setassoc":
+            # every resident key sits in its own set, no set holds more than its ways, and a missed key is resident afterwards
+            # unless its set is full (it can only have been turned away by SA_WAYS other new keys of this batch)
+            kl = list(new_res)
+            per_set = np.bincount(_sa_sets(kl, cap).astype(np.int64), minlength=cap // SA_WAYS) if kl else np.zeros(1, int)
+            assert per_set.max() <= SA_WAYS
+            missed = sorted({(k + 1, int(rq[b, k])) for b in range(len(rq)) for k in range(26) if not hit[b, k]})
+            gone = [key for key in missed if key not in new_res]
+            if gone:
+                assert (per_set[_sa_sets(gone, cap).astype(np.int64)] == SA_WAYS).all()
+        elif st["size"] < cap:
             assert all((k + 1, int(rq[b, k])) in new_res for b in range(len(rq)) for k in range(26)
                        if policy == "plan" or not hit[b, k])
         resident = new_res
@@ -451,7 +472,7 @@ def test_batched_cache_over_host_memory_backing(E, orc, policy):
     assert ch.batch_stats()["n_hits"] > 0 and ch.batch_stats()["size"] > 0
 
 
-@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("policy", POLICIES1)
 def test_batched_cache_smaller_than_one_batch(E, orc, policy):
     """A cache far smaller than the unique keys of one batch: the hash can run out of empty words between
     rebuilds; every walk is bounded, rows stay exact, the cache never exceeds its capacity."""
@@ -555,6 +576,45 @@ def test_batched_host_tier_flush_with_pinned_hits(E, orc, policy):
             assert st["size"] == len(dmp) <= 50 and len({int(r) for _, _, r in dmp}) == len(dmp)
 
 
+def test_setassoc_flush_and_refusals(E, orc):
+    """Set-associative policy: one table (every hit has the top priority, so the EvLFU flush fires -- EvLFU_C1.py:36-44), a
+    small cache, batches far larger than it: rows exact, no duplicate keys, size <= capacity, flushes counted; host-memory
+    tables and the two-tier lookup are refused (the policy reads its miss tier in place from HBM, single tier)."""
+    rs = np.random.RandomState(0)
+    n, d = 500, 16
+    tab = rs.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    c = E.GpuCache("evlfu", 64, 1, d, 32, "python").set_batch_policy("setassoc")
+    c.set_backing([torch.from_numpy(tab).cuda()])
+    for it in range(8):
+        rq = rs.randint(0, 80 if it % 2 else n, size=(700, 1)).astype(np.int32)
+        hit, out = c.lookup_batch(torch.from_numpy(rq).cuda())
+        assert np.array_equal(out.cpu().numpy()[:, 0, :], tab[rq[:, 0]]), it
+        x = torch.rand(700, d, device="cuda")
+        hit, R = c.lookup_interact(torch.from_numpy(rq).cuda(), x)
+        want = (torch.from_numpy(tab[rq[:, 0]]).cuda() * x).sum(1)
+        torch.testing.assert_close(R[:, d], want, rtol=1e-5, atol=2e-6)
+        st, dmp = c.batch_stats(), c.batch_dump()
+        assert st["size"] == len(dmp) <= 64 and len({int(r) for _, _, r in dmp}) == len(dmp)
+        assert np.array_equal(np.bincount(dmp[:, 0], minlength=2), np.array(st["hist"]))
+    # every resident key requested again: every entry reaches the top priority, the top bucket passes max_perfect
+    # (0.95 x capacity) and the flush takes flush_n = int(0.3 x 64) + 1 entries away (EvLFU_C1.py:30,36-44)
+    res = c.batch_dump()[:, 2].astype(np.int32)
+    assert len(res) >= 61
+    before = c.batch_stats()
+    rq = np.resize(res, (700, 1))
+    hit, out = c.lookup_batch(torch.from_numpy(rq).cuda())
+    assert hit.all() and np.array_equal(out.cpu().numpy()[:, 0, :], tab[rq[:, 0]])
+    st, dmp = c.batch_stats(), c.batch_dump()
+    assert st["n_flush"] == before["n_flush"] + 1 and st["size"] == before["size"] - 20 == len(dmp)
+    assert set(dmp[:, 2].tolist()) <= set(res.tolist())
+    ch = E.GpuCache("evlfu", 64, 1, d, 32, "python").set_batch_policy("setassoc")
+    ch.set_backing([torch.from_numpy(tab).pin_memory()])
+    with pytest.raises(E.EvsError):
+        ch.lookup_batch(torch.zeros((4, 1), dtype=torch.int32, device="cuda"))
+    with pytest.raises(E.EvsError):
+        E.GpuCache("evlfu", 8, 1, d, 32, "python").set_batch_policy("setassoc")   # fewer entries than one set has ways
+
+
 def test_batched_and_exact_paths_do_not_mix(E, orc):
     tabs = orc.kaggle_tables([50] * 26, 1)
     c = E.GpuCache("evlfu", 100, 26, 36, 32)
@@ -565,7 +625,7 @@ def test_batched_and_exact_paths_do_not_mix(E, orc):
         c.request(rows)
 
 
-@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("policy", POLICIES1)
 def test_cache_lookup_interact_equals_rows_then_interact(E, orc, policy):
     """evs_cache_lookup_interact (pointer-table + fused MFMA kernel) == interact_features over the table rows."""
     n_rows = [500, 7, 9000, 40, 2500, 3] + [100] * 20
@@ -704,7 +764,7 @@ def test_two_tier_mixed_codec_interaction_consumer(E, orc, codecs, d, T, policy)
     assert c1.batch_stats()["size"] <= 400 and c2.batch_stats()["size"] <= 900
 
 
-@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("policy", POLICIES1)
 @pytest.mark.parametrize("codec,d,T", [(8, 36, 26), (4, 36, 26), (16, 36, 26), (8, 16, 9), (4, 32, 17), (16, 16, 27)])
 def test_single_tier_reduced_precision_interaction_consumer(E, orc, codec, d, T, policy):
     """A single reduced-precision tier (the reference's one-layer 16 / 8 / 4-bit builds) feeding the interaction: rows
@@ -917,7 +977,7 @@ def test_batched_three_tier_c1c2c3(E, orc, codecs, d, policy):
 
 
 @pytest.mark.parametrize("policy,cap,B", [("sampled", 9_000_000, 60_000), ("plan", 9_000_000, 60_000), ("sampled", 400_000, 70_001),
-                                            ("plan", 400_000, 70_001)])
+                                            ("plan", 400_000, 70_001), ("setassoc", 9_000_000, 60_000), ("setassoc", 400_000, 70_001)])
 def test_batched_cache_above_the_slot_hint_range(E, orc, policy, cap, B):
     """A cache whose hash has more than 2^24 slots (9 M entries): the probe's slot hints no longer fit their 24 bits, the
     inserts walk from the key's home slot instead -- and a batch above 65 536 requests (the probe's blocks loop, their
@@ -944,5 +1004,6 @@ def test_batched_cache_above_the_slot_hint_range(E, orc, policy, cap, B):
         keys = {(int(t), int(rw)) for _, t, rw in dmp}
         assert len(keys) == len(dmp) == st["size"] <= cap
         assert np.array_equal(np.bincount(dmp[:, 0], minlength=T + 1), np.array(st["hist"]))
-        assert all((k + 1, int(rq[b, k])) in keys for b in range(0, B, 101) for k in range(T) if not hit[b, k])
+        if policy != "setassoc":   # (a set that takes more new keys than it has ways in one batch turns the rest away)
+            assert all((k + 1, int(rq[b, k])) in keys for b in range(0, B, 101) for k in range(T) if not hit[b, k])
         resident = keys

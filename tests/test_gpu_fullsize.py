@@ -75,7 +75,7 @@ def _query_keys(rows_np):
     return (t << 32) | rows_np.astype(np.int64)
 
 
-@pytest.mark.parametrize("policy", ["sampled", "plan"])
+@pytest.mark.parametrize("policy", ["sampled", "plan", "setassoc"])
 def test_bench_cache_tier_workload_at_full_size(E, orc, kaggle, oracle_rates, policy):
     ev, ln, cap = kaggle["ev"], kaggle["ln"], kaggle["cap"]
     T = len(ln)
@@ -90,7 +90,8 @@ def test_bench_cache_tier_workload_at_full_size(E, orc, kaggle, oracle_rates, po
     for i in range(FILL):
         cache.lookup_interact(kaggle["rows"][i], x, out=out, hit=hit)      # the bench's step
     st = cache.batch_stats()
-    assert st["size"] > 0.95 * cap, "the fill phase must leave the cache at capacity (the bench times it evicting)"
+    # (the set-associative policy fills set by set: 94 % after the 60 fill batches, evicting in the sets that are full)
+    assert st["size"] > (0.90 if policy == "setassoc" else 0.95) * cap, "the fill phase must leave the cache at capacity (the bench times it evicting)"
     rs = np.random.RandomState(5)
     hits_batched = []
     for i in range(FILL, FILL + CHECKED):
