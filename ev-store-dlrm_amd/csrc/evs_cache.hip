@@ -1877,7 +1877,7 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
 }
 
 // Set-associative policy (evs_hash.h, batch policy 2): one missed key of the batch.  The record carries the key's set; its
-// line (16 key words: key | batch stamp | priority) and the source row go out together, then ONE CAS on the way of the
+// line (kSaWays key words: key | batch stamp | priority) and the source row go out together, then ONE CAS on the way of the
 // lowest priority (free ways first, lowest way index among equals; ways filled in this batch excepted), then stores
 // nobody waits for.  Two dependent round trips behind the record.
 // Copies of one missing key: every copy looks at the same words and ranks them the same way, so two copies that both
@@ -1886,12 +1886,12 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
 // is read plainly: what a plain read can return is a word as it stood at the start of the launch or one written in it,
 // and a way changes at most once per launch (old -> stamped), which is all the argument needs.
 template <int PIECES, typename U, typename TAIL = NoTail>
-__device__ __forceinline__ void sa_insert_one(const BatchArgs &args, int t, unsigned row, int agg, unsigned set, int *s_delta, int *s_stat) {
+__device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsigned char *table, int t, unsigned row, int agg, unsigned set, int *s_delta, int *s_stat) {
     const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
     unsigned long long *tags = args.a.ekey + (unsigned long long)set * kSaWays;
     SaLine line;
     sa_load(tags, 0u, line);
-    const unsigned char *srow = args.backing[t] + (long long)row * args.row_bytes;
+    const unsigned char *srow = table + (long long)row * args.row_bytes;
     U r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
     if constexpr (PIECES > 0) r0 = reinterpret_cast<const U *>(srow)[0];
     if constexpr (PIECES > 1) r1 = reinterpret_cast<const U *>(srow)[1];
@@ -2010,13 +2010,40 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_kernel(const BatchArg
 // mostly busy lanes instead of 6 656 waves with one lane in eight busy, and everything a miss needs arrives with its
 // record (the per-position form reads the probe word, then the request row, then starts).
 constexpr int kListVictMax = 512;   // (the folded two-tier probe lists 16 T <= 432 records per block)
-template <int PIECES, typename U, typename TAIL, bool SA = false>
+template <int PIECES, typename U, typename TAIL>
 __device__ __forceinline__ void sampled_list_block(const BatchArgs &args, int bid);
 template <int PIECES, typename U, typename TAIL = NoTail>
 __global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const BatchArgs args) { sampled_list_block<PIECES, U, TAIL>(args, (int)blockIdx.x); }
-// the set-associative policy's update: the same lists, sa_insert_one per record
+// the set-associative policy's update: the same lists, sa_insert_one per record.  The list's length, the lane's first
+// record and the table base addresses (into LDS: a per-lane index into the kernel arguments is a memory access) are
+// asked for together -- three dependent round trips per record: those, {set line, source row}, the CAS.
 template <int PIECES, typename U, typename TAIL = NoTail>
-__global__ void __launch_bounds__(256) cache_batch_sa_list_kernel(const BatchArgs args) { sampled_list_block<PIECES, U, TAIL, true>(args, (int)blockIdx.x); }
+__global__ void __launch_bounds__(256) cache_batch_sa_list_kernel(const BatchArgs args) {
+    __shared__ int s_delta[kMaxBuckets];
+    __shared__ int s_stat[3];
+    __shared__ const unsigned char *s_table[32];
+    const int bid = (int)blockIdx.x;
+    for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
+    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+    const uint4 *rec = args.miss_rec + (long long)bid * args.list_cap;
+    const int nw = (int)blockDim.x >> 6;
+    const int i0 = ((int)threadIdx.x & 63) * nw + ((int)threadIdx.x >> 6);
+    const int n = args.list_cnt[bid];
+    uint4 r = rec[i0 < args.list_cap ? i0 : 0];
+    if (threadIdx.x < 32) s_table[threadIdx.x] = args.backing[threadIdx.x];
+    __syncthreads();
+    for (int i = i0; i < n; i += 64 * nw) {
+        if (i != i0) r = rec[i];
+        const int t = (int)(r.y & 0xffu);
+        sa_insert_one<PIECES, U, TAIL>(args, s_table[t & 31], t, r.x, (int)((r.y >> 8) & 0xffu), r.z, s_delta, s_stat);
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartCols) {
+        const int i = threadIdx.x;
+        const int v = i <= args.T ? s_delta[i] : (i >= 33 && i <= 35) ? s_stat[i - 33] : 0;
+        if (v) atomicAdd(&args.part2[(bid % kReplicas) * kPartCols + i], v);
+    }
+}
 // both tiers of a two-tier lookup in one launch (their updates are independent once the probe has stamped the route
 // filter): blocks [0, g1) take C1's lists, [g1, 2 g1) C2's
 template <int P1, typename U1, typename T1, int P2, typename U2, typename T2>
@@ -2024,7 +2051,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_list2_kernel(const Ba
     if ((int)blockIdx.x < args1.g1) sampled_list_block<P1, U1, T1>(args1, (int)blockIdx.x);
     else sampled_list_block<P2, U2, T2>(args2, (int)blockIdx.x - args1.g1);
 }
-template <int PIECES, typename U, typename TAIL, bool SA>
+template <int PIECES, typename U, typename TAIL>
 __device__ __forceinline__ void sampled_list_block(const BatchArgs &args, int bid) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
@@ -2041,8 +2068,6 @@ __device__ __forceinline__ void sampled_list_block(const BatchArgs &args, int bi
     const int nw = (int)blockDim.x >> 6;
     for (int i = ((int)threadIdx.x & 63) * nw + ((int)threadIdx.x >> 6); i < n; i += 64 * nw) {
         const uint4 r = rec[i];
-        if constexpr (SA) sa_insert_one<PIECES, U, TAIL>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, s_delta, s_stat);
-        else
         sampled_insert_one<PIECES, U, TAIL>(args, (int)(r.y & 0xffu), r.x, (int)((r.y >> 8) & 0xffu), r.z, (r.y & 0x10000u) != 0, (long long)r.w,
                                    s_delta, s_stat, args.vict_cnt ? s_vict : nullptr, &s_nvict);
     }

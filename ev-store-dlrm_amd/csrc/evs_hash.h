@@ -64,12 +64,17 @@ __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigne
 
 // ---- set-associative form of the batched cache (batch policy 2, "setassoc") ------------------------------------------
 // No hash chain and no entry arrays: key -> set = (mix64(key) >> 32) * nset >> 32, a set is kSaWays consecutive 8-byte
-// words = ONE 128-byte line, way w of set s owns arena row s * kSaWays + w.  A word = key (38 bits) | batch stamp
+// words = 64 bytes of ONE 128-byte line, way w of set s owns arena row s * kSaWays + w.  A word = key (38 bits) | batch stamp
 // (19 bits: the batch that filled the way) | priority (7 bits, the EvLFU agg_hit maximum) -- the priority sits in the top
 // bits, so "raise the priority of this key" is one 64-bit atomicMax on the word.  A probe is one line, an insert is that
 // line + one CAS + the row; nothing ever moves, so there are no tombstones, no sweeps and no rebuilds.  The victim of a
 // new key is the lowest priority of ITS OWN set (free ways first), ways filled in the running batch excepted.
-constexpr int kSaWays = 16;
+#ifndef EVS_SA_WAYS
+#define EVS_SA_WAYS 8
+#endif
+constexpr int kSaWays = EVS_SA_WAYS;   // 8 or 16.  Measured at the 10 % Kaggle cache, B = 16 384: 16 ways (one whole 128-byte line per set) 42.2 us per
+                                        // batch, hit rate 0.8839; 8 ways (64 bytes) 37.3 us, 0.8827 (sequential oracle 0.884): the set line is read by
+                                        // one thread per key, 16-byte pieces through the CU's 64 B/clk vector-memory path, and that is what the 5 us are
 constexpr int kSaPrioShift = 57;
 constexpr unsigned kSaStampMask = (1u << (kSaPrioShift - kKeyBits)) - 1u;
 constexpr unsigned long long kSaLowMask = (1ull << kSaPrioShift) - 1ull;

@@ -112,7 +112,7 @@ class GpuCache:
 
     def set_batch_policy(self, policy):
         """'sampled' (one update kernel, victim = lowest priority of 8 sampled entries), 'plan' (insert / plan / evict /
-        assign, clock-hand window) or 'setassoc' (16-way set-associative: one 128-byte line of key words per set, the
+        assign, clock-hand window) or 'setassoc' (8-way set-associative: one 64-byte line of key words per set, the
         victim is the lowest priority of the key's own set; single tier, tables in HBM); before the first batched lookup."""
         _lib.check(_lib.lib().evs_cache_set_batch_policy(self._h, {"plan": 0, "sampled": 1, "setassoc": 2}[policy]))
         return self

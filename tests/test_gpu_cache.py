@@ -361,8 +361,8 @@ def _zipf_requests(n_rows, n_req, seed, alpha=1.15):
 
 
 POLICIES = ["sampled", "plan"]   # evs_cache_set_batch_policy: one update kernel with sampled victims / insert-plan-evict-assign
-POLICIES1 = POLICIES + ["setassoc"]   # ... / 16-way set-associative (single tier, tables in HBM)
-SA_WAYS = 16
+POLICIES1 = POLICIES + ["setassoc"]   # ... / 8-way set-associative (single tier, tables in HBM)
+SA_WAYS = 8
 
 
 def _sa_sets(keys_tr, cap):
@@ -612,7 +612,7 @@ def test_setassoc_flush_and_refusals(E, orc):
     with pytest.raises(E.EvsError):
         ch.lookup_batch(torch.zeros((4, 1), dtype=torch.int32, device="cuda"))
     with pytest.raises(E.EvsError):
-        E.GpuCache("evlfu", 8, 1, d, 32, "python").set_batch_policy("setassoc")   # fewer entries than one set has ways
+        E.GpuCache("evlfu", 4, 1, d, 32, "python").set_batch_policy("setassoc")   # fewer entries than one set has ways
 
 
 def test_batched_and_exact_paths_do_not_mix(E, orc):

@@ -167,7 +167,9 @@ def batched_case(rs, case):
     src = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in n_rows]
     raws = [orc.encode_table(t, codec) for t in src]
     tabs = src if codec == 32 else [orc.decode(r, codec, d) for r in raws]      # what a lookup must return
-    policy = str(rs.choice(["sampled", "sampled", "plan"]))
+    policy = str(rs.choice(["sampled", "setassoc", "setassoc", "plan"]))
+    if policy == "setassoc" and (host or cap < 8):   # (the set-associative policy: tables in HBM, at least one full set)
+        policy = "sampled"
     tag += " policy=%s" % policy
     c = E.GpuCache("evlfu", cap, T, d, codec, rs.choice(["python", "cpp"])).set_batch_policy(policy)
     c.set_backing([torch.from_numpy(r).pin_memory() if host else torch.from_numpy(r).cuda() for r in raws])
