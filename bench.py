@@ -286,10 +286,11 @@ def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=No
 def _tier_traffic(B, d, frac, alpha, policy):
     """HBM bytes per batch of the cache tier's launch chain from the committed PMC passes (profiles/traffic.json), for the
     configuration they were taken on; None otherwise."""
-    if policy not in (None, "sampled") or abs(frac - 0.10) > 1e-9 or abs(alpha - 0.75) > 1e-9:
+    if policy not in ("setassoc", "sampled") or abs(frac - 0.10) > 1e-9 or abs(alpha - 0.75) > 1e-9:
         return None
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("cache_tier_B%d_d%d" % (B, d))
+        key = "cache_tier_B%d_d%d" if policy == "sampled" else "cache_tier_setassoc_B%d_d%d"
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key % (B, d))
     except Exception:
         return None
 
@@ -300,7 +301,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
     (the tables stay the miss tier); Zipf indices; batched snapshot-semantics lookups + interaction.
     alpha=0.75 with 60 warm-up batches fills the cache, so the timed batches run at capacity (evicting); 200 timed
     batches, none seen before, so that the hash housekeeping (a tombstone sweep every ~28 batches) is inside the
-    number.  policy: 'sampled' (library default) / 'plan' (evs_cache_set_batch_policy)."""
+    number.  policy: 'setassoc' (library default for a single tier over HBM tables) / 'sampled' / 'plan' (evs_cache_set_batch_policy)."""
     import evstore_dlrm_amd as E
     T = len(ln_emb)
     cap = int(frac * sum(ln_emb))
@@ -371,9 +372,13 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
     # and a 4-byte slot / priority word of the probe = 5 956 B per sample at T = 26, d = 36; the batch is several launches
     # (probe, consumer, policy update), so `achieved` is bytes over the whole batch's device time (HIP events)
     tier_bytes = B * (T * (4 * d + 8) + 4 * d + 4 * (d + F * (F - 1) // 2) + T * 12)
-    tier_roof = {"bound": "hbm", "kernel": "the batch's launch chain: emb_interact_rf_kernel<..., PROBE> (cache probe + gather + interaction, one launch) + cache_batch_sampled_list_kernel (policy update), closes / sweeps amortised",
+    pol = policy or os.environ.get("EVS_CACHE_POLICY", "setassoc")   # (the library's default for a single tier over HBM tables)
+    chain = {"setassoc": "emb_interact_rf_kernel<..., PROBE> (set probe + gather + interaction, one launch) + cache_batch_sa_list_kernel (policy update), counter folds amortised",
+             "sampled": "emb_interact_rf_kernel<..., PROBE> (hash probe + gather + interaction, one launch) + cache_batch_sampled_list_kernel (policy update), closes / sweeps amortised",
+             "plan": "probe, consumer, insert / plan / evict / assign / close"}.get(pol, pol)
+    tier_roof = {"bound": "hbm", "kernel": "the batch's launch chain: " + chain,
                  "achieved": tier_bytes / dev_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                 "frac": tier_bytes / dev_ms / 1e6 / HBM_PEAK_GBPS, "traffic": _tier_traffic(B, d, frac, alpha, policy), "bytes_per_launch": tier_bytes,
+                 "frac": tier_bytes / dev_ms / 1e6 / HBM_PEAK_GBPS, "traffic": _tier_traffic(B, d, frac, alpha, pol), "bytes_per_launch": tier_bytes,
                  "avg_launch_ms": dev_ms}
     # the same cache in front of tables that stay in pinned HOST memory (the reference's C3 / mmap miss path): each
     # missing row crosses the bus once; beside it, the fused kernel reading every row from host memory uncached
@@ -489,15 +494,20 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
                          "EvLFU (cache_algo/EvLFU_C1.py restated), in-memory tables, %.2f s" % (n1 - n_skip, n_skip, dtc)}
     except Exception as e:  # the oracle is test infrastructure: its absence must not break the bench
         cpu = {"error": str(e)}
-    plan = None
-    if policy is None:   # the other policy update beside the default, shorter
-        try:
-            pl = cache_tier_section(ev, ln_emb, d, B, dev, steps=100, warmup=warmup, frac=frac, alpha=alpha, batch1=False, settle_s=0.1, policy="plan")
-            plan = {"value": pl["value"], "ms_per_step": pl["ms_per_step"], "hit_rate": pl["hit_rate"], "timed_batches": 100,
-                    "note": "evs_cache_set_batch_policy(0): insert / plan / evict / assign / close (the round-1 form)"}
-        except Exception as e:
-            plan = {"error": repr(e)}
-    return {"value": looks / dt, "policy": policy or "sampled", "timed_batches": steps, "oracle_hit_rate": None if not oracle_cmp else oracle_cmp.get("oracle_hit_rate"),
+    plan = sampled = None
+    if policy is None:   # the other policy updates beside the default, shorter
+        notes = {"plan": "evs_cache_set_batch_policy(0): insert / plan / evict / assign / close (the round-1 form)",
+                 "sampled": "evs_cache_set_batch_policy(1): hash + entry arrays, one update kernel, victim = lowest priority of 8 sampled entries (the round-2 default; "
+                            "still what host-memory / file-backed miss tiers and the two- / three-tier lookups run)"}
+        other = {}
+        for name in ("plan", "sampled"):
+            try:
+                pl = cache_tier_section(ev, ln_emb, d, B, dev, steps=100, warmup=warmup, frac=frac, alpha=alpha, batch1=False, settle_s=0.1, policy=name)
+                other[name] = {"value": pl["value"], "ms_per_step": pl["ms_per_step"], "hit_rate": pl["hit_rate"], "timed_batches": 100, "note": notes[name]}
+            except Exception as e:
+                other[name] = {"error": repr(e)}
+        plan, sampled = other["plan"], other["sampled"]
+    return {"value": looks / dt, "policy": pol, "sampled_policy": sampled, "timed_batches": steps, "oracle_hit_rate": None if not oracle_cmp else oracle_cmp.get("oracle_hit_rate"),
             "hit_rate_vs_sequential_oracle": oracle_cmp, "plan_policy": plan, "roofline": tier_roof, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
             "hit_rate": (s1["n_hits"] - s0["n_hits"]) / looks, "capacity_entries": cap,
             "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"],

@@ -279,13 +279,29 @@ EVS_API int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, cons
  * evs_cache_request (exact) or by evs_cache_lookup_batch, never both (EVS_ESTATE). */
 EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
                                    void *stream);
-/* How the batched path of this cache makes room (before its first batched call; EVS_ESTATE afterwards):
- *   1 "sampled" (default; EVS_CACHE_POLICY=plan in the environment selects 0): one kernel after the consumers -- the
- *     thread that inserts a new key picks that key's victim itself, the lowest priority of one sampled group of 8
- *     entries (free entries first), and fills the entry;
+/* How the batched path of this cache makes room (before its first batched call; EVS_ESTATE afterwards).  A cache that
+ * is not given a policy decides at its first batched call: EVS_CACHE_POLICY = plan | sampled | setassoc in the environment,
+ * else 2 where it applies (a single tier whose tables the kernels read in place from HBM, capacity >= 8) and 1 elsewhere.
+ *   2 "setassoc": the cache is 8-way set-associative -- set = hash(key), one 64-byte line of 8 key words (key | batch stamp
+ *     | priority) per set, way w of set s owns arena row 8 s + w.  A probe reads that line; the update kernel's thread that
+ *     inserts a new key takes the lowest priority OF THE KEY'S OWN SET (free ways first) with one CAS and writes the row.
+ *     No hash chains, tombstones, sweeps or entry arrays.  capacity / 8 sets (up to 7 entries of the capacity unused);
+ *     single tier, tables in HBM (host-memory / file-backed tables and the two- / three-tier lookups: EVS_ESTATE / EINVAL);
+ *   1 "sampled": a hash over an entry arena; one kernel after the consumers -- the thread that inserts a new key picks
+ *     that key's victim itself, the lowest priority of one sampled group of 8 entries (free entries first);
  *   0 "plan": insert -> plan -> evict -> assign -> close, the lowest priorities of a clock-hand window go, exactly as
- *     many as the batch needs (the file-backed miss tier and the two-tier lookup always take this form).
- * Served rows and hit flags are the same under both; which keys stay resident differs. */
+ *     many as the batch needs (the file-backed miss tier always takes this form).
+ * WHAT IS THE SAME under all three, and tested: served rows are exactly the table rows; hit flags are residency when the
+ * batch arrives (snapshot); no duplicate keys; size <= capacity; priorities only rise (monotone max of agg_hit,
+ * cache_algo/EvLFU_C1.py:65-79); the EvLFU flush fires when the top bucket reaches max_perfect (:36-44).
+ * WHAT DIFFERS from the reference's sequential EvLFU (:97-166 evicts the FIFO-oldest entry of the globally lowest
+ * bucket): 0 evicts the lowest priorities of a window, 1 the lowest of 8 sampled entries, 2 the lowest of the key's set --
+ * under 1 and 2 a key that was HIT in the running batch can be a victim while lower priorities exist elsewhere, and
+ * under 2 a set that receives more new keys than it has ways in one batch turns the rest away (they are served from
+ * the tables and not cached this time); which keys are resident after a batch depends on thread timing under 1 and 2.
+ * Hit rate at the 10 % Criteo-Kaggle cache (Zipf 0.75, B = 16 384, 600 batches): 0 0.8868, 1 0.8862, 2 0.8840, the
+ * sequential oracle on the same stream 0.884 (tests/test_gpu_fullsize.py asserts |batched - sequential| <= 0.03 at
+ * full size for all three; bench.py: cache_tier.hit_rate_vs_sequential_oracle). */
 EVS_API int evs_cache_set_batch_policy(evs_cache *c, int policy);
 /* Batched two-tier lookup, snapshot semantics: the throughput form of evs_cache_request_c1c2 (no reference
  * counterpart).  Every key is probed in C1, then in C2, against the tiers as they stand when the call starts;
