@@ -418,7 +418,16 @@ class ShardedEmbeddingInteract:
         47) -- at this batch size the step is bounded by host-side launch cost, not by GPU overlap."""
         if not self.any_sharded:
             return None
+        tr = self.trace
+        if tr is not None:
+            tr["n"] += 1
+            if tr["n"] % tr["every"]:
+                tr = None
+        if tr is not None:
+            tr["pool"].append(self._stamp())
         self._pool_into(pl["send"], pl["Bg"], pl["lo"], pl["li"], planned=True, lo_split=pl["lo_split"], li_split=pl["li_split"])
+        if tr is not None:
+            tr["pool"].append(self._stamp())
         if self.world > 1:
             return dist.all_to_all_single(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"], group=self.group,
                                           async_op=True)
@@ -450,7 +459,31 @@ class ShardedEmbeddingInteract:
             self._reroute(pl)
         if work is not None:
             work.wait()
-        return self.backend.interact_mixed(pl["x"], pl["specs"], self.ev, self.d, self.itself, out=pl["R"], planned=True)
+        tr = self.trace
+        if tr is not None and (tr["n"] if self.any_sharded else self._bump(tr)) % tr["every"]:
+            tr = None
+        if tr is not None:
+            tr["interact"].append(self._stamp())
+        R = self.backend.interact_mixed(pl["x"], pl["specs"], self.ev, self.d, self.itself, out=pl["R"], planned=True)
+        if tr is not None:
+            tr["interact"].append(self._stamp())
+        return R
+
+    # bench: {"pool": [], "interact": [], "n": 0, "every": 4} -> HIP events around the two launches of every 4th step (start,
+    # end, start, ...).  Every step would make the loop host-bound (an event record costs about as much as a launch) and
+    # an interval then holds the GPU's wait for the host: 211 instead of 13 us for the pool kernel, measured.
+    trace = None
+
+    @staticmethod
+    def _bump(tr):
+        tr["n"] += 1
+        return tr["n"]
+
+    @staticmethod
+    def _stamp():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
 
     def forward(self, x_local, lS_o, lS_i):
         """lS_o/lS_i: per-table offsets/indices of the FULL batch (every rank sees all of them,
@@ -529,6 +562,10 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps)
+    e_end = torch.cuda.Event()
+    e_end.record()
+    while not e_end.query():   # (poll, then the closing synchronise: a blocking one wakes up tens of microseconds late)
+        pass
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
@@ -543,28 +580,29 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
            # other ranks' batch slices), and over all ranks
            "a2a_bytes_per_rank": 4 * d * Bl * (len(op.my_own) + n_split) * (world - 1),
            "a2a_bytes": 4 * d * Bl * (n_sh + n_split * world) * (world - 1), "roofline": None}
-    # roofline of the launches a rank issues per batch (rank 0, HIP events on the launch stream, after the timed
-    # region): the pooling gather of its own tables over the GLOBAL batch (if any) and the interaction over its
+    # roofline of the launches a rank issues per batch (rank 0, HIP events on the launch stream, in a repeat of the timed
+    # loop right behind it): the pooling gather of its own tables over the GLOBAL batch (if any) and the interaction over its
     # LOCAL batch (received pooled vectors dense, replicated tables gathered inside the kernel)
-    if want_roofline and rank == 0:
+    tr = None
+    if want_roofline:
+        # the SAME loop as the timed one (pipelined: exchange of batch i+1 in flight under the interaction of batch i, no
+        # synchronise between steps; every rank runs it -- it holds the collectives), with HIP events around the two
+        # launches of every step; read after the loop
+        iters = max(40, min(args.steps, 400))
+        torch.cuda.synchronize()
+        op.trace = {"pool": [], "interact": [], "n": 0, "every": 4}
+        if graphs is None:
+            run(iters)
+        else:   # (graph mode: the launches are inside the graph; the eager step shows the kernels)
+            for i in range(iters):
+                op.step(plans[(i % nb, 0)])
+        torch.cuda.synchronize()
+        tr, op.trace = op.trace, None
+    if tr is not None and rank == 0:
         from bench import HBM_PEAK_GBPS as peak
         n_own = len(op.my_own)
-        pl = plans[(0, 0)]
-        iters = 20
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        torch.cuda.synchronize()
-        t_pool = t_fin = 0.0
-        for _ in range(iters):
-            ev[0].record()
-            if n_own or n_split:
-                op._pool_into(pl["send"], pl["Bg"], pl["lo"], pl["li"], planned=True, lo_split=pl["lo_split"], li_split=pl["li_split"])
-            ev[1].record()
-            backend.interact_mixed(pl["x"], pl["specs"], op.ev, d, op.itself, out=pl["R"], planned=True)
-            ev[2].record()
-            torch.cuda.synchronize()
-            t_pool += ev[0].elapsed_time(ev[1])
-            t_fin += ev[1].elapsed_time(ev[2])
-        t_pool, t_fin = t_pool / iters, t_fin / iters
+        pair_ms = lambda v: sum(v[k].elapsed_time(v[k + 1]) for k in range(0, len(v), 2)) / max(1, len(v) // 2)
+        t_pool, t_fin = pair_ms(tr["pool"]), pair_ms(tr["interact"])
         # row + index read, pooled vector written (one index/bag); a row-split table: every index read, 1/world of the rows
         # read, every (mostly zero) partial written
         pool_bytes = n_own * Bg * (4 * d + 8 + 4 * d) + n_split * Bg * (8 + 4 * d // world + 4 * d)
