@@ -1876,6 +1876,12 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     if (c3_inline) c3_insert_key(C3Set{args.c3_tags, args.c3_nset, args.c3_stat}, old_key & kKeyMask);   // what this thread evicted -> the alt-key set
 }
 
+// the piece types of a row as compiler vector types (loads through an address-space-1 pointer want trivially copyable
+// non-class types; HIP's float4 / uint2 are classes)
+template <typename U> struct SaNative { using type = U; };
+template <> struct SaNative<float4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct SaNative<uint2> { typedef unsigned type __attribute__((ext_vector_type(2))); };
+template <> struct SaNative<NoTail> { using type = int; };
 // Set-associative policy (evs_hash.h, batch policy 2): one missed key of the batch.  The record carries the key's set; its
 // line (kSaWays key words: key | batch stamp | priority) and the source row go out together, then ONE CAS on the way of the
 // lowest priority (free ways first, lowest way index among equals; ways filled in this batch excepted), then stores
@@ -1889,28 +1895,42 @@ template <int PIECES, typename U, typename TAIL = NoTail>
 __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsigned char *table, int t, unsigned row, int agg, unsigned set, int *s_delta, int *s_stat) {
     const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
     unsigned long long *tags = args.a.ekey + (unsigned long long)set * kSaWays;
+    // The set's line FIRST, then the source row, in that order in the instruction stream: vector-memory loads return in
+    // order, so the CAS can go out when the line is there (an Infinity-Cache hit: the probe read it 20 us ago) while the
+    // row -- a random line of a multi-GB table -- is still on its way.  The table base comes out of LDS: as a generic
+    // pointer its loads would be flat_load (they count on lgkmcnt too and the compiler drains everything in front of
+    // the CAS); through an address-space-1 pointer they are global_load.
     SaLine line;
     sa_load(tags, 0u, line);
+    __builtin_amdgcn_sched_barrier(0);
     const unsigned char *srow = table + (long long)row * args.row_bytes;
-    U r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
-    if constexpr (PIECES > 0) r0 = reinterpret_cast<const U *>(srow)[0];
-    if constexpr (PIECES > 1) r1 = reinterpret_cast<const U *>(srow)[1];
-    if constexpr (PIECES > 2) r2 = reinterpret_cast<const U *>(srow)[2];
-    if constexpr (PIECES > 3) r3 = reinterpret_cast<const U *>(srow)[3];
-    if constexpr (PIECES > 4) r4 = reinterpret_cast<const U *>(srow)[4];
-    if constexpr (PIECES > 5) r5 = reinterpret_cast<const U *>(srow)[5];
-    if constexpr (PIECES > 6) r6 = reinterpret_cast<const U *>(srow)[6];
-    if constexpr (PIECES > 7) r7 = reinterpret_cast<const U *>(srow)[7];
-    if constexpr (PIECES > 8) r8 = reinterpret_cast<const U *>(srow)[8];
-    if constexpr (PIECES > 9) r9 = reinterpret_cast<const U *>(srow)[9];
-    if constexpr (PIECES > 10) r10 = reinterpret_cast<const U *>(srow)[10];
-    if constexpr (PIECES > 11) r11 = reinterpret_cast<const U *>(srow)[11];
-    if constexpr (PIECES > 12) r12 = reinterpret_cast<const U *>(srow)[12];
-    if constexpr (PIECES > 13) r13 = reinterpret_cast<const U *>(srow)[13];
-    if constexpr (PIECES > 14) r14 = reinterpret_cast<const U *>(srow)[14];
-    if constexpr (PIECES > 15) r15 = reinterpret_cast<const U *>(srow)[15];
-    TAIL rt;
-    if constexpr (!std::is_same<TAIL, NoTail>::value) rt = *reinterpret_cast<const TAIL *>(srow + PIECES * sizeof(U));
+    using NU = typename SaNative<U>::type;
+    using NT = typename SaNative<TAIL>::type;
+    typedef const __attribute__((address_space(1))) NU *gsrc_t;
+    const gsrc_t gs = reinterpret_cast<gsrc_t>(reinterpret_cast<uintptr_t>(srow));
+    NU r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
+    if constexpr (PIECES > 0) r0 = gs[0];
+    if constexpr (PIECES > 1) r1 = gs[1];
+    if constexpr (PIECES > 2) r2 = gs[2];
+    if constexpr (PIECES > 3) r3 = gs[3];
+    if constexpr (PIECES > 4) r4 = gs[4];
+    if constexpr (PIECES > 5) r5 = gs[5];
+    if constexpr (PIECES > 6) r6 = gs[6];
+    if constexpr (PIECES > 7) r7 = gs[7];
+    if constexpr (PIECES > 8) r8 = gs[8];
+    if constexpr (PIECES > 9) r9 = gs[9];
+    if constexpr (PIECES > 10) r10 = gs[10];
+    if constexpr (PIECES > 11) r11 = gs[11];
+    if constexpr (PIECES > 12) r12 = gs[12];
+    if constexpr (PIECES > 13) r13 = gs[13];
+    if constexpr (PIECES > 14) r14 = gs[14];
+    if constexpr (PIECES > 15) r15 = gs[15];
+    NT rt;
+    if constexpr (!std::is_same<TAIL, NoTail>::value) {
+        typedef const __attribute__((address_space(1))) NT *gtail_t;
+        rt = *reinterpret_cast<gtail_t>(reinterpret_cast<uintptr_t>(srow + PIECES * sizeof(U)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
     const unsigned cur = (unsigned)args.stamp & kSaStampMask;
     const unsigned long long neww = sa_word(key, cur, agg);
     unsigned long long w[kSaWays];
@@ -1953,23 +1973,23 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
     atomicAdd(&s_delta[agg], 1);
     unsigned char *drow = args.a.arena + ((long long)set * kSaWays + way) * args.row_bytes;
     if constexpr (PIECES > 0) {
-        if constexpr (PIECES > 0) reinterpret_cast<U *>(drow)[0] = r0;
-        if constexpr (PIECES > 1) reinterpret_cast<U *>(drow)[1] = r1;
-        if constexpr (PIECES > 2) reinterpret_cast<U *>(drow)[2] = r2;
-        if constexpr (PIECES > 3) reinterpret_cast<U *>(drow)[3] = r3;
-        if constexpr (PIECES > 4) reinterpret_cast<U *>(drow)[4] = r4;
-        if constexpr (PIECES > 5) reinterpret_cast<U *>(drow)[5] = r5;
-        if constexpr (PIECES > 6) reinterpret_cast<U *>(drow)[6] = r6;
-        if constexpr (PIECES > 7) reinterpret_cast<U *>(drow)[7] = r7;
-        if constexpr (PIECES > 8) reinterpret_cast<U *>(drow)[8] = r8;
-        if constexpr (PIECES > 9) reinterpret_cast<U *>(drow)[9] = r9;
-        if constexpr (PIECES > 10) reinterpret_cast<U *>(drow)[10] = r10;
-        if constexpr (PIECES > 11) reinterpret_cast<U *>(drow)[11] = r11;
-        if constexpr (PIECES > 12) reinterpret_cast<U *>(drow)[12] = r12;
-        if constexpr (PIECES > 13) reinterpret_cast<U *>(drow)[13] = r13;
-        if constexpr (PIECES > 14) reinterpret_cast<U *>(drow)[14] = r14;
-        if constexpr (PIECES > 15) reinterpret_cast<U *>(drow)[15] = r15;
-        if constexpr (!std::is_same<TAIL, NoTail>::value) *reinterpret_cast<TAIL *>(drow + PIECES * sizeof(U)) = rt;
+        if constexpr (PIECES > 0) reinterpret_cast<NU *>(drow)[0] = r0;
+        if constexpr (PIECES > 1) reinterpret_cast<NU *>(drow)[1] = r1;
+        if constexpr (PIECES > 2) reinterpret_cast<NU *>(drow)[2] = r2;
+        if constexpr (PIECES > 3) reinterpret_cast<NU *>(drow)[3] = r3;
+        if constexpr (PIECES > 4) reinterpret_cast<NU *>(drow)[4] = r4;
+        if constexpr (PIECES > 5) reinterpret_cast<NU *>(drow)[5] = r5;
+        if constexpr (PIECES > 6) reinterpret_cast<NU *>(drow)[6] = r6;
+        if constexpr (PIECES > 7) reinterpret_cast<NU *>(drow)[7] = r7;
+        if constexpr (PIECES > 8) reinterpret_cast<NU *>(drow)[8] = r8;
+        if constexpr (PIECES > 9) reinterpret_cast<NU *>(drow)[9] = r9;
+        if constexpr (PIECES > 10) reinterpret_cast<NU *>(drow)[10] = r10;
+        if constexpr (PIECES > 11) reinterpret_cast<NU *>(drow)[11] = r11;
+        if constexpr (PIECES > 12) reinterpret_cast<NU *>(drow)[12] = r12;
+        if constexpr (PIECES > 13) reinterpret_cast<NU *>(drow)[13] = r13;
+        if constexpr (PIECES > 14) reinterpret_cast<NU *>(drow)[14] = r14;
+        if constexpr (PIECES > 15) reinterpret_cast<NU *>(drow)[15] = r15;
+        if constexpr (!std::is_same<TAIL, NoTail>::value) *reinterpret_cast<NT *>(drow + PIECES * sizeof(U)) = rt;   // (non-temporal stores for the row: measured, no difference)
     } else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
     else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
 }
