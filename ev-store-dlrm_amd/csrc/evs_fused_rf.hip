@@ -902,8 +902,18 @@ bool launch_rf_multi(const FusedArgs &a, hipStream_t st) {
 #undef EVS_RF_MULTI
 }
 
+// The plain launch (one index per bag declared) also takes batches ABOVE one resident generation for d = 36 and 16: with
+// the round-3 head the one-chunk blocks beat the LDS-DMA loop there too (same box, d = 36: B = 32 768 36.2 -> 32.4 us,
+// 65 536 62.1 -> 60.0, 131 072 120.0 -> 114.6, 262 144 235 -> 227; d = 16 at 65 536: 42.0 -> 38.5; d = 32 loses, 48.6 ->
+// 50.6, and keeps the loop).  The checked / probing / row-id forms stay at one generation (no gain measured for the
+// checked form: 65.6 vs 65.7 us at 65 536).  EVS_FUSED_RF_MAX_B, when set, bounds every form.
+static int64_t rf_max_batch_plain(int d) {
+    if (getenv("EVS_FUSED_RF_MAX_B") || d == 32) return rf_max_batch();
+    return 1ll << 22;
+}
+
 bool launch_rf(const FusedArgs &a, hipStream_t st) {
-    if (!rf_mode() || a.F > kTileMaxF || a.bag1 != 1 || a.B > rf_max_batch()) return false;
+    if (!rf_mode() || a.F > kTileMaxF || a.bag1 != 1 || a.B > rf_max_batch_plain(a.d)) return false;
     const bool nt2 = a.F > 16;
     switch (a.d) {
     case 16:

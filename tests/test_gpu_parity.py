@@ -502,6 +502,39 @@ def test_fused_codec_large_batch(E, orc, codec, d, B):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
+@pytest.mark.parametrize("d,B", [(36, 40000 + 7), (16, 36000 + 1), (32, 33000), (36, 131072 + 5)])
+def test_fused_fp32_large_batch(E, orc, d, B):
+    """fp32 tables, batches of several resident generations: the one-index-declared launch runs the rows-in-registers
+    one-chunk kernel there too since round 3 (d = 36 / 16; d = 32 keeps the LDS-DMA loop), lS_o given is checked inside
+    the loop kernel, the two-call path materialises the rows -- the same bits from all three, the oracle on samples."""
+    from bench import KAGGLE_LN
+    rs = np.random.RandomState(1700 + d)
+    ln = [min(n, 3000) | 1 for n in KAGGLE_LN]
+    ws = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    ev = E.EVTables.from_fp32([torch.from_numpy(w) for w in ws])
+    idx_np = np.stack([rs.randint(0, n, size=B) for n in ln]).astype(np.int64)
+    idx_np[:, -1] = np.array(ln) - 1
+    idx = torch.from_numpy(idx_np).cuda()
+    off = torch.arange(B, device="cuda").repeat(26, 1)
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+    a = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True, check_indices=True)
+    b = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
+    assert torch.equal(a, b)
+    c = E.interact_features(x, E.apply_emb(off, idx, ev, None, lazy=False))
+    assert torch.equal(a, c) and torch.equal(a[:, :d], x)
+    sel = np.sort(np.r_[rs.choice(B, 61, replace=False), [0, B - 1, B - 2]])
+    want = orc.interact_features(x[sel].cpu().numpy(), [ws[k][idx_np[k, sel]] for k in range(26)])
+    np.testing.assert_allclose(a[sel].cpu().numpy(), want, rtol=RTOL, atol=2e-6)
+    # an out-of-range index in the last chunk and one in the first: rows skipped, flag raised
+    idx[3, B - 1] = ln[3]
+    idx[20, 5] = -1
+    r = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    ok = np.ones(B, bool); ok[[5, B - 1]] = False
+    assert torch.equal(r[torch.from_numpy(ok).cuda()], a[torch.from_numpy(ok).cuda()])
+
+
 @pytest.mark.parametrize("codec,B", [(32, 8192 + 77), (8, 8192 + 77), (32, 4096 + 5), (32, 2048 + 3), (32, 20000),
                                       (16, 8192 + 77), (16, 4096 + 5), (4, 4096 + 5), (8, 16384 + 3), (16, 2048 + 3)])
 def test_fused_optimistic_offsets_pair(E, orc, codec, B):
