@@ -237,7 +237,7 @@ def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
                     "difference of consecutive loop-top wall-clock stamps, result synchronised per request; PCIe Gen5 x16"}
 
 
-def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=None, engine="host", host_tabs=None):
+def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=None, engine="host", host_tabs=None, use_gpu=True):
     """BASELINE configs[2] with the reference's own semantics: --test-mini-batch-size=1 through apply_emb_evstore and the
     EvLFU_C1 cache module (dlrm_s_pytorch_C1.py:227-275, cache_algo/EvLFU_C1.py:97-166), tables (the miss tier) in HBM.
     Warm-up = one full replay of the workload (dlrm_s_pytorch_C1.py:2224-2242), then the timed replay; latency =
@@ -260,21 +260,23 @@ def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=No
     ld = [(X, lS_o, rows[i].reshape(T, 1)) for i in range(n_req)]
 
     def forward(X, lS_o, lS_i):
-        return evstore_ops.apply_emb_evstore(lS_o, lS_i, None, None, use_gpu=True, use_emb_cache=True)
+        return evstore_ops.apply_emb_evstore(lS_o, lS_i, None, None, use_gpu=use_gpu, use_emb_cache=True)
 
-    IL.inference(ld, forward, True, dev)          # warm-up: the whole workload once
+    IL.inference(ld, forward, use_gpu, dev)          # warm-up: the whole workload once
     evstore_ops.perfect_hit = 0
     h0 = EvLFU_C1.stats()["n_hits"]
-    stamps = IL.inference(ld, forward, True, dev)
+    stamps = IL.inference(ld, forward, use_gpu, dev)
     hits = EvLFU_C1.stats()["n_hits"] - h0
     res = {"p50_us": IL.percentile_ms(stamps, 50) * 1e3, "p95_us": IL.percentile_ms(stamps, 95) * 1e3,
            "requests": n_req, "capacity_entries": cap, "hit_rate": hits / (T * n_req), "perfect_hits": evstore_ops.perfect_hit,
            "value": T * n_req / (stamps[-1] - stamps[0]), "unit": "lookups/s", "engine": EvLFU_C1._m.engine,
-           "note": "apply_emb_evstore(use_gpu=True, use_emb_cache=True) per request behind dlrm_wrap: 26 ids to the device "
+           "use_gpu": use_gpu,
+           "note": "apply_emb_evstore(use_gpu=False): the same loop with nothing on the device (dlrm_wrap copies nothing, the host engine serves 26 x Tensor(1,36) on the host) -- what the library itself costs per request through the plugin surface" if not use_gpu else
+                   "apply_emb_evstore(use_gpu=True, use_emb_cache=True) per request behind dlrm_wrap: 26 ids to the device "
                    "and back (as the reference does, dlrm_s_pytorch_C1.py:233-239), the exact policy (host engine: in "
                    "libevstore_hip.so on one host core, rows to the device in one copy; gpu engine: one exact-policy launch), "
                    "26 x Tensor(1,36) on the device; Zipf(1.05); warm-up = one full replay"}
-    if cdf_dir and engine == "host":
+    if cdf_dir and engine == "host" and use_gpu:
         try:
             res["cdf_csv"] = os.path.relpath(IL.calculate_and_write_cdf(cdf_dir, "evlfu", stamps), ROOT)
         except Exception as e:
@@ -659,6 +661,18 @@ def main():
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t1) * 1e3)
 
+    # the same with the host polling an end event instead of blocking in the synchronise (what a spinning serving thread sees)
+    lat_poll = []
+    ev_done = torch.cuda.Event()
+    for i in range(min(max(args.steps, 50), 200)):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(i)
+        ev_done.record()
+        while not ev_done.query():
+            pass
+        lat_poll.append((time.perf_counter() - t1) * 1e3)
+
     for i in range(5):
         step_general(i)
     torch.cuda.synchronize()
@@ -754,6 +768,7 @@ def main():
                                % (d, args.dist),
                    "batch_per_gpu": B, "global_batch": B, "tables": T, "dim": d, "parallelism": "single"},
         "p50_batch_latency_ms": float(np.percentile(lat, 50)), "p95_batch_latency_ms": float(np.percentile(lat, 95)),
+        "p50_batch_latency_polled_ms": float(np.percentile(lat_poll, 50)),   # the host spins on an end event instead of blocking in synchronize()
         "settle_s": settle_s,
         "roofline": {"bound": "hbm",
                      "kernel": "emb_interact_rf_kernel<2,1,2,4,false,false,false,true>" if (B <= 16384 and d == 36 and os.environ.get("EVS_FUSED_RF", "1") != "0")
@@ -865,6 +880,10 @@ def main():
         if d == 36:
             try:
                 pl = batch1_plugin_section(ev, KAGGLE_LN, d, dev, cdf_dir=args.cdf_dir, engine="host")
+                try:
+                    pl["host_only"] = batch1_plugin_section(ev, KAGGLE_LN, d, dev, cdf_dir=None, engine="host", use_gpu=False)
+                except Exception as e:
+                    pl["host_only"] = {"error": repr(e)}
                 try:
                     pl["gpu_engine"] = batch1_plugin_section(ev, KAGGLE_LN, d, dev, cdf_dir=None, engine="gpu")
                 except Exception as e:

@@ -17,6 +17,7 @@
 //   * summation order is the index order, fp32, multiply and add unfused
 //     (library is built with -ffp-contract=off) -> bit-exact with the oracle.
 #include "evs_common.h"
+#include <stdlib.h>
 
 namespace evs {
 
@@ -290,7 +291,8 @@ static void launch_vec(const GatherArgs &a, int lpr, hipStream_t stream, bool ba
     args.chunks_per_table = (a.B + bags_per_item - 1) / bags_per_item;
     const int64_t n_items = (int64_t)a.T * args.chunks_per_table;
     int64_t blocks = (n_items + 3) / 4;
-    const int64_t cap = (int64_t)kNumCu * 8;  // 8 blocks of 256 threads per CU
+    static const int cap_per_cu = getenv("EVS_GATHER_BLOCKS_PER_CU") ? atoi(getenv("EVS_GATHER_BLOCKS_PER_CU")) : 8;   // (developer A/B)
+    const int64_t cap = (int64_t)kNumCu * cap_per_cu;  // 8 blocks of 256 threads per CU
     if (blocks > cap) blocks = cap;
     blocks = round_up((int)blocks, kNumXcd);
     if (bag1)
