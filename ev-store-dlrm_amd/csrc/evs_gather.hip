@@ -44,6 +44,7 @@ struct GatherArgs {
     int T;
     int d;
     int *err;
+    const void *zeros;   // the zero page (rows-in-registers gather: what a lane reads for a bag that has no row)
 };
 
 template <int CODEC>
@@ -303,6 +304,193 @@ static void launch_vec(const GatherArgs &a, int lpr, hipStream_t stream, bool ba
                            0, stream, args);
 }
 
+// ---- one index per bag, fp32, d in {16, 32, 36}: rows in flight in registers (round 3) ----------------------------------
+// The gather of the Criteo layout is a pure row copy: bag b of table t is row idx[t][b].  The grid-stride kernel above keeps
+// UNROLL = 4 rows in flight per lane group and pays an index round trip per item; this form is the fused kernel's
+// (evs_fused_rf.hip) without its interaction: a block owns 16 samples of ALL tables, the 16 x T indices arrive in ONE round
+// trip (thread e owns (table e >> 4, sample e & 15), and e + 256), go through a 2 KB LDS tile, and every wave requests the
+// rows of its 4 samples at once -- LPRD lanes per row, RPI = 64 / LPRD rows per load instruction, NJ instructions per
+// sample, 4 NJ in flight per lane -- and stores them as they arrive (straight-line code: counted vmcnt waits).
+// CHECK (offsets given): the same threads also load offsets[b] (and the neighbour's, = where bag b ends) and check that
+// every bag of the block is exactly {idx[b]}; a block that finds anything else pools its 16 x T bags the general way
+// (index order, unfused fp32 adds, bad offsets / indices skipped and flagged: the arithmetic of the kernel above).
+// Row ranges (row_lo / row_total) and the peer-major output of the sharded step are honoured.
+typedef float gr_f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) gr_f32x4 *gr_gf4_t;
+typedef const __attribute__((address_space(1))) int64_t *gr_gi64_t;
+
+template <int LPRD, int NJ, bool CHECK>
+__global__ void __launch_bounds__(256, 4) gather_rows_kernel(const GatherArgs args) {
+    constexpr int RPI = 64 / LPRD;
+    constexpr int row_bytes = LPRD * 16;
+    static_assert(NJ * RPI <= 32, "one tile row per table");
+    __shared__ int s_idx[32 * 16];                    // [table][sample]: row of the table's local range, -1 = nothing to read
+    __shared__ unsigned long long s_base[32];
+    __shared__ unsigned long long s_obase[32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int T = args.T;
+    const int64_t B = args.B;
+    const GatherArgs *ka = (const GatherArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int64_t blk_first = (int64_t)blockIdx.x * 16;
+    const int64_t blk_end = blk_first + 16 < B ? blk_first + 16 : B;
+    if (blk_first >= blk_end) return;   // block-uniform
+    if (threadIdx.x < 32) {             // every array has 32 entries: unconditional loads, one round trip
+        const int t = (int)threadIdx.x;
+        s_base[t] = (unsigned long long)reinterpret_cast<uintptr_t>(ka->table[t]);
+        s_obase[t] = (unsigned long long)reinterpret_cast<uintptr_t>(args.out) + (unsigned long long)((int64_t)t * args.out_tstride * 4);
+    }
+    // ---- the block's index tile ---------------------------------------------------------------------------------------
+    bool bad = false, ragged = false;
+    {
+        const int64_t bs = blk_first + (threadIdx.x & 15);
+        int64_t v[2], o0[2] = {0, 0}, o1[2] = {0, 0};
+        int64_t nr[2], lo[2], tot[2], nz[2];
+        bool on[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int t = ((int)threadIdx.x >> 4) + 16 * h;   // < 32
+            on[h] = t < T && bs < blk_end;
+            const int64_t *ip = ka->indices[t], *op = ka->offsets[t];
+            nr[h] = ka->n_rows[t]; lo[h] = ka->row_lo[t]; tot[h] = ka->row_total[t]; nz[h] = ka->nnz[t];
+            const int64_t *ap = (on[h] && ip && bs < nz[h]) ? ip + bs : reinterpret_cast<const int64_t *>(&ka->B);
+            v[h] = *reinterpret_cast<gr_gi64_t>(reinterpret_cast<uintptr_t>(ap));
+            if (!(on[h] && ip && bs < nz[h])) v[h] = -1;
+            if constexpr (CHECK) {
+                const int64_t *p0 = (on[h] && op) ? op + bs : reinterpret_cast<const int64_t *>(&ka->B);
+                // where bag b ends: the next bag's start (the neighbour lane has it, except behind the block's last sample)
+                const bool own = on[h] && ((threadIdx.x & 15) == 15 || bs + 1 >= blk_end);
+                const int64_t *p1 = (own && op && bs + 1 < B) ? op + bs + 1 : reinterpret_cast<const int64_t *>(&ka->B);
+                o0[h] = *reinterpret_cast<gr_gi64_t>(reinterpret_cast<uintptr_t>(p0));
+                o1[h] = *reinterpret_cast<gr_gi64_t>(reinterpret_cast<uintptr_t>(p1));
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int t = ((int)threadIdx.x >> 4) + 16 * h;
+            int id = -1;
+            if (on[h]) {
+                if constexpr (CHECK) {
+                    const bool own = (threadIdx.x & 15) == 15 || bs + 1 >= blk_end;
+                    const int64_t nb = __shfl_down((long long)o0[h], 1);
+                    const int64_t en = own ? (bs + 1 < B ? o1[h] : nz[h]) : nb;
+                    ragged |= !(o0[h] == bs && en == bs + 1);
+                }
+                if (v[h] >= 0 && v[h] < tot[h]) {
+                    const int64_t r = v[h] - lo[h];
+                    if (r >= 0 && r < nr[h]) id = (int)r;   // (else: another rank's rows, silently)
+                } else {
+                    bad = true;
+                }
+            }
+            s_idx[t * 16 + ((int)threadIdx.x & 15)] = id;
+        }
+    }
+    const bool peers = (int64_t)args.bags_per_peer < B;   // kernel-uniform
+    auto out_off = [&](int64_t b) -> int64_t {            // element offset of bag b inside a table's block of the output
+        if (!peers) return b * args.out_bstride;
+        const unsigned q = (unsigned)b / args.bags_per_peer;
+        return (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+    };
+    if constexpr (CHECK) {
+        if (__syncthreads_or(ragged)) {
+            // ---- rare: this block's bags with general semantics, one (bag, 16-byte piece) per thread and trip ----------------
+            bad = false;   // (the verdict on an index belongs to the bag that holds it)
+            const int n_work = T * 16 * LPRD;
+            for (int wk = (int)threadIdx.x; wk < n_work; wk += 256) {
+                const int piece = wk % LPRD, bag = wk / LPRD;
+                const int t = bag >> 4;
+                const int64_t b = blk_first + (bag & 15);
+                if (b >= blk_end) continue;
+                const int64_t *ip = ka->indices[t], *op = ka->offsets[t];
+                const int64_t nzt = ka->nnz[t];
+                int64_t st = op[b], en = (b + 1 < B) ? op[b + 1] : nzt;
+                if (!(st >= 0 && en >= st && en <= nzt)) { bad = true; st = en = 0; }
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const char *W = reinterpret_cast<const char *>(ka->table[t]);
+                const int64_t tot_t = ka->row_total[t], lo_t = ka->row_lo[t], nr_t = ka->n_rows[t];
+                for (int64_t j = st; j < en; j++) {
+                    int64_t r = ip[j];
+                    if (r < 0 || r >= tot_t) { bad = true; continue; }
+                    r -= lo_t;
+                    if (r < 0 || r >= nr_t) continue;
+                    const float4 x = reinterpret_cast<const float4 *>(W + r * row_bytes)[piece];
+                    acc.x = __fadd_rn(acc.x, x.x); acc.y = __fadd_rn(acc.y, x.y); acc.z = __fadd_rn(acc.z, x.z); acc.w = __fadd_rn(acc.w, x.w);
+                }
+                *reinterpret_cast<float4 *>(args.out + (int64_t)t * args.out_tstride + out_off(b) + piece * 4) = acc;
+            }
+            if (bad) atomicOr(args.err, 1);
+            return;
+        }
+    } else {
+        __syncthreads();
+    }
+    // ---- the rows of this wave's samples wave, wave + 4, wave + 8, wave + 12 ----------------------------------------------
+    const int r0 = lane / LPRD, piece16 = (lane - r0 * LPRD) * 16;
+    const bool lane_on = r0 < RPI;
+    const unsigned long long zeros_p = (unsigned long long)reinterpret_cast<uintptr_t>(args.zeros) + (unsigned long long)piece16;
+    unsigned long long fbase[NJ], obase[NJ];
+    int tile[NJ];
+    bool t_on[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int t = (lane_on ? r0 : 0) + j * RPI;   // < 32
+        t_on[j] = lane_on && t < T;
+        fbase[j] = s_base[t] + (unsigned long long)piece16;
+        obase[j] = s_obase[t] + (unsigned long long)piece16;
+        tile[j] = t * 16 + wave;
+    }
+    gr_f32x4 ring[4][NJ];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int iv = s_idx[tile[j] + 4 * n];
+            const unsigned long long neg = 0ull - (unsigned long long)((unsigned)iv >> 31);   // -1 -> the zero page (bit blend: no branch around the load)
+            const unsigned long long p = fbase[j] + (unsigned long long)((unsigned)iv & 0x7fffffffu) * (unsigned long long)row_bytes;
+            ring[n][j] = *reinterpret_cast<gr_gf4_t>((uintptr_t)(p ^ ((p ^ zeros_p) & neg)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const int64_t b = blk_first + wave + 4 * n;   // wave-uniform
+        if (b < blk_end) {
+            const unsigned long long ob = (unsigned long long)(out_off(b) * 4);
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                if (t_on[j]) *reinterpret_cast<gr_f32x4 *>((uintptr_t)(obase[j] + ob)) = ring[n][j];
+        }
+    }
+    if (bad) atomicOr(args.err, 1);
+}
+
+// is there a rows-in-registers gather for the launch, and launch it
+static bool launch_gather_rows(const GatherArgs &a, bool vec_ok, hipStream_t stream, bool bag1) {
+    static const bool on = !(getenv("EVS_GATHER_RF") && getenv("EVS_GATHER_RF")[0] == '0');
+    if (!on || !vec_ok || a.T > 32 || !(a.d == 16 || a.d == 32 || a.d == 36) || !zero_page()) return false;
+    for (int k = 0; k < a.T; k++) {
+        if (a.row_w[k] || a.n_rows[k] >= (1ll << 31)) return false;
+        if (!bag1 && a.nnz[k] != a.B) return false;   // offsets given: the bet is on whole batches of one-index bags
+    }
+    const int rpi = 64 / (a.d / 4);
+    const int nj = (a.T + rpi - 1) / rpi;
+    const dim3 grid((unsigned)((a.B + 15) / 16)), block(256);
+    GatherArgs g = a;
+    g.zeros = zero_page();
+#define EVS_GR(L, N) \
+    do { \
+        if (bag1) hipLaunchKernelGGL((gather_rows_kernel<L, N, false>), grid, block, 0, stream, g); \
+        else hipLaunchKernelGGL((gather_rows_kernel<L, N, true>), grid, block, 0, stream, g); \
+        return true; \
+    } while (0)
+    if (a.d == 16) { if (nj <= 1) EVS_GR(4, 1); EVS_GR(4, 2); }
+    if (a.d == 32) { if (nj <= 1) EVS_GR(8, 1); if (nj <= 2) EVS_GR(8, 2); if (nj <= 3) EVS_GR(8, 3); EVS_GR(8, 4); }
+    if (nj <= 1) EVS_GR(9, 1); if (nj <= 2) EVS_GR(9, 2); if (nj <= 3) EVS_GR(9, 3); if (nj <= 4) EVS_GR(9, 4);
+    return false;   // (d = 36, T in 29..32: a fifth instruction would address tile rows past 31 -- the grid-stride kernel)
+#undef EVS_GR
+}
+
 template <int CODEC>
 static void launch_codec(const GatherArgs &a, bool vec_ok, hipStream_t stream, bool bag1) {
     const int d = a.d;
@@ -392,6 +580,8 @@ extern "C" int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec,
         a.d = d;
         a.err = err;
         a.chunks_per_table = 0;
+        a.zeros = nullptr;
+        if (codec == 32 && launch_gather_rows(a, vec_ok, st, bag1)) { EVS_HIP_CHECK(hipGetLastError()); continue; }
         switch (codec) {
         case 32: launch_codec<32>(a, vec_ok, st, bag1); break;
         case 16: launch_codec<16>(a, vec_ok, st, bag1); break;

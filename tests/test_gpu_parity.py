@@ -502,6 +502,52 @@ def test_fused_codec_large_batch(E, orc, codec, d, B):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
+@pytest.mark.parametrize("d,T,B", [(36, 26, 5000 + 3), (36, 28, 300), (36, 1, 17), (16, 32, 2049), (32, 26, 1), (32, 32, 4100), (16, 8, 64), (36, 30, 500)])
+def test_rows_in_registers_gather_vs_oracle(E, orc, d, T, B):
+    """apply_emb alone (the two-call plugin surface) on whole batches of one-index bags runs gather_rows_kernel (round 3:
+    16 samples of all tables per block, rows in flight in registers; d = 36 with T > 28 keeps the grid-stride kernel).
+    Bit-exact vs the oracle's EmbeddingBag-sum: offsets given = arange (checked per block), one index per bag declared,
+    ragged offsets with nnz == B (blocks that find them pool the general way: empty bags, two- and three-index bags, the
+    last bag running to nnz), bad indices and bad offsets (skipped, flag raised)."""
+    rs = np.random.RandomState(31 * d + T + B)
+    ln = [int(rs.choice([3, 40, 700, 9000])) for _ in range(T)]
+    ws = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    ev = E.EVTables.from_fp32([torch.from_numpy(w) for w in ws])
+    idx = [rs.randint(0, n, size=B).astype(np.int64) for n in ln]
+    off = [np.arange(B, dtype=np.int64) for _ in range(T)]
+    want = np.stack(orc.apply_emb(off, idx, ws))
+    o_t, i_t = torch.from_numpy(np.stack(off)).cuda(), torch.from_numpy(np.stack(idx)).cuda()
+    for kw in ({}, {"one_index_per_bag": True}):
+        got = torch.stack(E.apply_emb(o_t, i_t, ev, None, lazy=False, check_indices=True, **kw)).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), kw
+    assert np.array_equal(got, np.stack([ws[k][idx[k]] for k in range(T)]))   # bag = 1: exact copies of the rows
+    if B >= 8:
+        # ragged, nnz == B: a few bag boundaries moved (empty bags next to longer ones), in some tables and some blocks only
+        off2 = [o.copy() for o in off]
+        for k in range(0, T, 3):
+            for b in rs.choice(np.arange(1, B), size=min(5, B - 1), replace=False):
+                off2[k][b] = off2[k][b - 1]          # bag b-1 empty ... bag b takes its index too
+            off2[k] = np.maximum.accumulate(off2[k])
+        want2 = np.stack(orc.apply_emb(off2, idx, ws))
+        got2 = torch.stack(E.apply_emb(torch.from_numpy(np.stack(off2)).cuda(), i_t, ev, None, lazy=False, check_indices=True)).cpu().numpy()
+        assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+        assert not np.array_equal(want2, want)
+        # a bad index: row skipped (zeros at bag = 1), flag raised; a bad offset (decreasing): that bag is empty, flag raised
+        idx3 = [i.copy() for i in idx]
+        idx3[T // 2][B // 2] = ln[T // 2]
+        idx3[0][0] = -1
+        r = torch.stack(E.apply_emb(o_t, torch.from_numpy(np.stack(idx3)).cuda(), ev, None, lazy=False)).cpu().numpy()
+        with pytest.raises(E.EvsError):
+            E._lib.check(E._lib.lib().evs_check_index_errors(None))
+        w3 = want.copy(); w3[T // 2, B // 2] = 0; w3[0, 0] = 0
+        assert np.array_equal(r, w3)
+        off4 = [o.copy() for o in off]
+        off4[T - 1][B // 3] = B + 5
+        E.apply_emb(torch.from_numpy(np.stack(off4)).cuda(), i_t, ev, None, lazy=False)
+        with pytest.raises(E.EvsError):
+            E._lib.check(E._lib.lib().evs_check_index_errors(None))
+
+
 @pytest.mark.parametrize("d,B", [(36, 40000 + 7), (16, 36000 + 1), (32, 33000), (36, 131072 + 5)])
 def test_fused_fp32_large_batch(E, orc, d, B):
     """fp32 tables, batches of several resident generations: the one-index-declared launch runs the rows-in-registers
