@@ -27,7 +27,13 @@ def ext():
     import torch  # noqa: F401  (libtorch must be loaded before the extension)
     spec = importlib.util.spec_from_file_location("_evs_torch_ext", _ext_build.OUT)
     m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
+    try:
+        spec.loader.exec_module(m)
+    except (ImportError, OSError) as e:   # e.g. built against another torch: the ctypes path reaches the same library
+        import warnings
+        warnings.warn("_evs_torch_ext.so did not load (%s): calling libevstore_hip.so through ctypes; rebuild with "
+                      "__graft_entry__.build()" % (e,))
+        return None
     if m.abi_version() != 1:
         raise RuntimeError("_evs_torch_ext.so was built against another libevstore_hip ABI")
     m.set_error_class(_lib.EvsError)

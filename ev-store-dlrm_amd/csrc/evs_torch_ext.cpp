@@ -21,13 +21,16 @@ namespace py = pybind11;
 
 namespace {
 
-py::object g_error_class;   // evstore_dlrm_amd._lib.EvsError, handed over by the Python side at import
+// evstore_dlrm_amd._lib.EvsError, handed over by the Python side at import.  A raw, deliberately leaked reference: a static
+// py::object would be released by a destructor that runs after the interpreter has been finalised.
+PyObject *g_error_class = nullptr;
 
 [[noreturn]] void raise_evs(int code) {
     const char *msg = evs_last_error();
     if (g_error_class) {
-        py::object exc = g_error_class(code, std::string(msg ? msg : ""));
-        PyErr_SetObject(g_error_class.ptr(), exc.ptr());
+        py::object cls = py::reinterpret_borrow<py::object>(g_error_class);
+        py::object exc = cls(code, std::string(msg ? msg : ""));
+        PyErr_SetObject(g_error_class, exc.ptr());
         throw py::error_already_set();
     }
     throw std::runtime_error(std::string("libevstore_hip: ") + (msg ? msg : "") + " (code " + std::to_string(code) + ")");
@@ -120,6 +123,7 @@ std::vector<at::Tensor> apply_emb_interact_multi(const Tables &ev, const std::ve
             TORCH_CHECK((*lS_os)[k].size(0) == T && (*lS_os)[k].size(1) == B && (*lS_os)[k].stride(0) == (*lS_os)[0].stride(0), "lS_o must be (T, B)");
             op[k] = (*lS_os)[k].data_ptr<int64_t>();
         }
+        TORCH_CHECK(!outs.has_value() || (int)outs->size() == K, "apply_emb_interact_multi: K output tensors");
         at::Tensor r = outs.has_value() ? (*outs)[k] : at::empty({B, Kc}, xs[k].options());
         TORCH_CHECK(r.is_cuda() && r.scalar_type() == at::kFloat && r.dim() == 2 && r.size(0) == B && r.size(1) == Kc && r.is_contiguous(),
                     "out must be a contiguous (B, d + P) fp32 device tensor");
@@ -206,6 +210,9 @@ inline void *dev_ptr(const at::Tensor &t) {   // device tensor, or a pinned host
 
 void cache_request(int64_t handle, const at::Tensor &rows, const at::Tensor &out, const at::Tensor &hit, int approx_thres, int device_index) {
     TORCH_CHECK(rows.scalar_type() == at::kInt && rows.is_contiguous() && rows.dim() == 2, "rows must be a contiguous (B, T) int32 tensor");
+    TORCH_CHECK(out.scalar_type() == at::kFloat && out.is_contiguous() && hit.scalar_type() == at::kByte && hit.is_contiguous() &&
+                hit.numel() == rows.numel() && out.numel() % std::max<int64_t>(rows.numel(), 1) == 0,
+                "out must be a contiguous (B, T, d) fp32 tensor, hit a contiguous (B, T) uint8 one");
     check(evs_cache_request(reinterpret_cast<evs_cache *>(handle), rows.size(0), static_cast<const int32_t *>(dev_ptr(rows)),
                             static_cast<float *>(dev_ptr(out)), static_cast<uint8_t *>(dev_ptr(hit)), approx_thres,
                             stream_of(c10::Device(c10::kCUDA, static_cast<c10::DeviceIndex>(device_index)))));
@@ -216,7 +223,10 @@ void cache_lookup_interact(int64_t handle, const at::Tensor &rows, const at::Ten
     const int64_t B = rows.size(0);
     TORCH_CHECK(rows.is_cuda() && rows.scalar_type() == at::kInt && rows.is_contiguous() && rows.dim() == 2, "rows must be a contiguous (B, T) int32 device tensor");
     check_x(x, B, static_cast<int>(x.size(1)));
-    TORCH_CHECK(out.is_cuda() && out.is_contiguous() && out.scalar_type() == at::kFloat && hit.is_cuda() && hit.is_contiguous(), "out / hit must be contiguous device tensors");
+    const int64_t T = rows.size(1);
+    TORCH_CHECK(out.is_cuda() && out.is_contiguous() && out.scalar_type() == at::kFloat && out.numel() == B * (x.size(1) + pairs((int)T + 1, itself)) &&
+                hit.is_cuda() && hit.is_contiguous() && hit.scalar_type() == at::kByte && hit.numel() == B * T,
+                "out must be a contiguous (B, d + P) fp32 device tensor, hit a contiguous (B, T) uint8 one");
     check(evs_cache_lookup_interact(reinterpret_cast<evs_cache *>(handle), B, rows.data_ptr<int32_t>(), x.data_ptr<float>(),
                                     B > 1 ? x.stride(0) : x.size(1), itself ? 1 : 0, out.data_ptr<float>(), hit.data_ptr<uint8_t>(),
                                     stream_of(x.device())));
@@ -250,7 +260,7 @@ std::vector<at::Tensor> slices(const at::Tensor &block, bool requires_grad) {
 }
 
 py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i, int T, int d, int approx_thres, bool use_gpu, int device_index) {
-    TORCH_CHECK(!lS_i.is_cuda() && lS_i.dim() >= 1 && lS_i.size(0) == T, "lS_i must be a host tensor with one row per table");
+    TORCH_CHECK(!lS_i.is_cuda() && lS_i.dim() >= 1 && lS_i.size(0) == T && lS_i.numel() >= T, "lS_i must be a host tensor with one non-empty row per table");
     int32_t ids[64];
     TORCH_CHECK(T <= 64, "at most 64 tables");
     if (lS_i.scalar_type() == at::kLong) {
@@ -273,7 +283,10 @@ py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i, int T, 
     return py::make_tuple(flags, slices(block, true), all);
 }
 
-void set_error_class(py::object cls) { g_error_class = std::move(cls); }
+void set_error_class(py::object cls) {
+    Py_XDECREF(g_error_class);
+    g_error_class = cls.release().ptr();
+}
 
 }  // namespace
 

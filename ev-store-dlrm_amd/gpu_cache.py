@@ -26,6 +26,27 @@ def _dev_ptr(t):
     return p
 
 
+def _check_batch(cache, rows, out=None, hit=None, out_cols=None, pinned_ok=False):
+    """Shapes the kernels rely on (a wrong one is an out-of-bounds device access, not an exception): rows (B, n_tables)
+    int32 contiguous; out fp32 contiguous with B * out_cols elements (default n_tables * dim); hit / tier uint8 contiguous
+    with B * n_tables elements.  Device tensors -- or, for the exact path, pinned host tensors.  -> B"""
+    def where(t):
+        return t.is_cuda or (pinned_ok and t.is_pinned())
+    if not (rows.dtype == torch.int32 and rows.dim() == 2 and rows.shape[1] == cache.n_tables and rows.is_contiguous() and where(rows)):
+        raise ValueError("rows must be a contiguous (B, %d) int32 %s tensor, got %s %s" %
+                         (cache.n_tables, "device or pinned host" if pinned_ok else "device", tuple(rows.shape), rows.dtype))
+    B = int(rows.shape[0])
+    if out is not None:
+        n = B * (out_cols if out_cols is not None else cache.n_tables * cache.dim)
+        if not (out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n and where(out)):
+            raise ValueError("out must be a contiguous fp32 tensor of %d elements, got %s %s" % (n, tuple(out.shape), out.dtype))
+    if hit is not None:
+        if not (hit.dtype == torch.uint8 and hit.is_contiguous() and hit.numel() == B * cache.n_tables and where(hit)):
+            raise ValueError("hit / tier must be a contiguous uint8 tensor of %d elements, got %s %s" %
+                             (B * cache.n_tables, tuple(hit.shape), hit.dtype))
+    return B
+
+
 class FileTier:
     """File-backed miss tier (evs_filetier_*): ev-table-N.bin files mapped read-only; tables registered with the GPU
     smallest first while they fit pinned_budget_bytes (read zero-copy by the kernels), the rest served through the
@@ -123,8 +144,7 @@ class GpuCache:
         rows / out / hit may be device tensors or PINNED host tensors (torch pin_memory): pinned buffers are
         read and written by the kernel itself, so the reference's one-request-at-a-time loop costs one launch
         and one synchronise per request instead of two copies around it (synchronise before reading them)."""
-        assert rows.dtype == torch.int32 and rows.is_contiguous() and (rows.is_cuda or rows.is_pinned())
-        B = int(rows.shape[0])
+        B = _check_batch(self, rows, out, hit, pinned_ok=True)
         if out is None:
             out = torch.empty((B, self.n_tables, self.dim), dtype=torch.float32, device=self.device)
         if hit is None:
@@ -139,8 +159,7 @@ class GpuCache:
 
     def lookup_batch(self, rows, out=None, hit=None):
         """Batched EvLFU lookup, snapshot semantics (see include/evstore_hip.h: evs_cache_lookup_batch)."""
-        assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
-        B = int(rows.shape[0])
+        B = _check_batch(self, rows, out, hit)
         if out is None:
             out = torch.empty((B, self.n_tables, self.dim), dtype=torch.float32, device=self.device)
         if hit is None:
@@ -152,15 +171,15 @@ class GpuCache:
     def lookup_interact(self, rows, x, itself=False, out=None, hit=None):
         """R = interact_features(x, cached rows of the B requests): probe + fused MFMA kernel reading the
         rows through a pointer table (no (B,T,d) intermediate), then the batched policy update."""
-        assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
-        B = int(rows.shape[0])
         F = self.n_tables + 1
         P = F * (F + 1) // 2 if itself else F * (F - 1) // 2
+        B = _check_batch(self, rows, out, hit, out_cols=self.dim + P)
         if out is None:
             out = torch.empty((B, self.dim + P), dtype=torch.float32, device=self.device)
         if hit is None:
             hit = torch.empty((B, self.n_tables), dtype=torch.uint8, device=self.device)
-        assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, self.dim) and x.stride(1) == 1
+        if not (x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (B, self.dim) and x.stride(1) == 1):
+            raise ValueError("x must be a (B, %d) fp32 device tensor with unit inner stride" % self.dim)
         X = _ext.ext()
         if X is not None:
             X.cache_lookup_interact(self._h.value, rows, x, bool(itself), out, hit)
@@ -213,8 +232,7 @@ class GpuCache:
 def request_c1c2(c1, c2, rows, threshold=23, out=None, tier=None):
     """Two-tier request (mixed_precs_caching/evlfu_8.cpp:669-796): c1 = main-precision GpuCache, c2 =
     secondary-precision GpuCache (both variant="cpp").  Returns (tier (B,T) uint8, out (B,T,dim) fp32)."""
-    assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
-    B = int(rows.shape[0])
+    B = _check_batch(c1, rows, out, tier)
     if out is None:
         out = torch.empty((B, c1.n_tables, c1.dim), dtype=torch.float32, device=c1.device)
     if tier is None:
@@ -228,8 +246,7 @@ def lookup_batch_c1c2(c1, c2, rows, threshold=23, out=None, tier=None, c3=None):
     """Batched two-tier lookup with snapshot semantics (include/evstore_hip.h: evs_cache_lookup_batch_c1c2): the
     throughput form of request_c1c2.  Returns (tier (B,T) uint8: 1 = C1 hit, 2 = C2 hit, 0 = miss; out (B,T,dim) fp32).
     c3 (GpuAltKeyTier): the three-tier form (evs_cache_lookup_batch_c1c2c3) -- tier code 3 = the alt row was served."""
-    assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
-    B = int(rows.shape[0])
+    B = _check_batch(c1, rows, out, tier)
     if out is None:
         out = torch.empty((B, c1.n_tables, c1.dim), dtype=torch.float32, device=c1.device)
     if tier is None:
@@ -260,14 +277,14 @@ def lookup_interact_c1c2(c1, c2, rows, x, threshold=23, itself=False, out=None, 
         from .dlrm_ops import interact_features
         tier, rows_fp32 = lookup_batch_c1c2(c1, c2, rows, threshold, out, tier, c3=c3)
         return tier, interact_features(x, list(rows_fp32.unbind(1)), "dot", itself)
-    assert rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous()
-    B = int(rows.shape[0])
+    B = _check_batch(c1, rows, None, tier)
     F = c1.n_tables + 1
     P = F * (F + 1) // 2 if itself else F * (F - 1) // 2
     R = torch.empty((B, c1.dim + P), dtype=torch.float32, device=c1.device)
     if tier is None:
         tier = torch.empty((B, c1.n_tables), dtype=torch.uint8, device=c1.device)
-    assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, c1.dim) and x.stride(1) == 1
+    if not (x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (B, c1.dim) and x.stride(1) == 1):
+        raise ValueError("x must be a (B, %d) fp32 device tensor with unit inner stride" % c1.dim)
     xs = int(x.stride(0)) if B > 1 else c1.dim
     st = torch.cuda.current_stream(c1.device).cuda_stream
     if c3 is None:

@@ -64,7 +64,7 @@ def test_evlfu_trace_through_pinned_host_buffers(E, orc):
         assert np.array_equal(hit[0].numpy().astype(bool), want[i]), i
         for k in range(26):
             assert np.array_equal(out[0, k].numpy(), tabs[k][rq[k]])
-    with pytest.raises(AssertionError):   # pageable host memory is refused, not silently copied
+    with pytest.raises(ValueError):   # pageable host memory is refused, not silently copied
         c.request(torch.zeros((1, 26), dtype=torch.int32))
 
 
@@ -613,6 +613,31 @@ def test_setassoc_flush_and_refusals(E, orc):
         ch.lookup_batch(torch.zeros((4, 1), dtype=torch.int32, device="cuda"))
     with pytest.raises(E.EvsError):
         E.GpuCache("evlfu", 4, 1, d, 32, "python").set_batch_policy("setassoc")   # fewer entries than one set has ways
+
+
+def test_cache_wrappers_refuse_wrong_shapes(E, orc):
+    """The kernels trust their shapes (a wrong one is an out-of-bounds device access): rows with the wrong number of
+    columns, an `out` / `hit` of the wrong size or dtype are refused on the host, by both call paths."""
+    tabs = orc.kaggle_tables([50] * 26, 1)
+    c = E.GpuCache("evlfu", 100, 26, 36, 32)
+    c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
+    good = torch.zeros((4, 26), dtype=torch.int32, device="cuda")
+    x = torch.rand(4, 36, device="cuda")
+    for bad_rows in (torch.zeros((4, 25), dtype=torch.int32, device="cuda"), torch.zeros((4, 26), dtype=torch.int64, device="cuda"),
+                     torch.zeros((4, 52), dtype=torch.int32, device="cuda")[:, ::2]):
+        for call in (lambda r: c.lookup_batch(r), lambda r: c.lookup_interact(r, x), lambda r: c.request(r)):
+            with pytest.raises(ValueError):
+                call(bad_rows)
+    with pytest.raises(ValueError):
+        c.lookup_batch(good, out=torch.empty((4, 26, 35), device="cuda"))
+    with pytest.raises(ValueError):
+        c.lookup_batch(good, hit=torch.empty((4, 26), dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        c.lookup_interact(good, x, out=torch.empty((4, 36 + 350), device="cuda"))
+    with pytest.raises(ValueError):
+        c.lookup_interact(good, torch.rand(4, 32, device="cuda"))
+    hit, R = c.lookup_interact(good, x)
+    assert R.shape == (4, 36 + 351)
 
 
 def test_batched_and_exact_paths_do_not_mix(E, orc):
