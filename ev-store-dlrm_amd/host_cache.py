@@ -42,12 +42,14 @@ class HostCache:
         """tables: per table a host array holding the table in the cache's codec (numpy array / np.memmap of the .bin
         file / CPU or pinned torch tensor), row r at byte r * dim * codec / 8."""
         raws = tables.raw if hasattr(tables, "raw") else list(tables)
-        assert len(raws) == self.n_tables
+        if len(raws) != self.n_tables:
+            raise ValueError("%d tables for a cache of %d" % (len(raws), self.n_tables))
         rb = self.dim * self.codec // 8
         keep, ptrs, rows = [], [], []
         for t in raws:
             if hasattr(t, "is_cuda"):
-                assert not t.is_cuda, "the host engine reads its miss tier from HOST memory"
+                if t.is_cuda:
+                    raise ValueError("the host engine reads its miss tier from HOST memory")
                 t = t.contiguous().numpy()
             a = t if isinstance(t, np.ndarray) and t.flags["C_CONTIGUOUS"] else np.ascontiguousarray(t)
             keep.append(a)
@@ -65,7 +67,9 @@ class HostCache:
             out = np.empty((B, self.n_tables, self.dim), np.float32)
         if hit is None:
             hit = np.empty((B, self.n_tables), np.uint8)
-        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and hit.dtype == np.uint8 and hit.flags["C_CONTIGUOUS"]
+        if not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.size == B * self.n_tables * self.dim
+                and isinstance(hit, np.ndarray) and hit.dtype == np.uint8 and hit.flags["C_CONTIGUOUS"] and hit.size == B * self.n_tables):
+            raise ValueError("out must be a C-contiguous float32 array of B * n_tables * dim elements, hit a uint8 one of B * n_tables")
         _lib.check(_lib.lib().evs_hostcache_request(self._h, B, rows.ctypes.data, out.ctypes.data, hit.ctypes.data, int(approx_thres)))
         return hit, out
 
