@@ -1084,6 +1084,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
     // snapshot: the policy kernels of this batch run later.  (Sampled update: a large cache stops a fraction of a per
     // cent short of its capacity -- the last free entries are not worth hunting -- so "full" has that much slack there.)
     const bool c1_full = a1.bs->count >= a1.cap - (a1.tomb_parity >= 0 && a1.cap > 65536 ? a1.cap / 256 : 0);
+    const bool sa = a1.sa_nset != 0;   // (both tiers or neither)
     const long long req_stride = (long long)gridDim.x * 8;
     for (long long req = (long long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half; req - half - (threadIdx.x >> 6) * 2 < a1.B;
          req += req_stride) {
@@ -1094,10 +1095,25 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         const unsigned long long key = ((unsigned long long)(hl + 1) << 32) | (unsigned)row;
         unsigned long long end1 = 0, end2 = 0;
         bool ht1 = false, ht2 = false;   // sampled update: is the hinted slot a (re-usable) tombstone
-        int e1 = ok ? probe_ro(a1.slots, a1.mask, key, end1, a1.tomb_parity == 1 ? kTomb : a1.tomb_parity == 0 ? kTomb1 : kTomb, &ht1) : -1;
-        if (e1 == kPending) e1 = -1;
-        int e2 = (ok && e1 < 0) ? probe_ro(a2.slots, a2.mask, key, end2, a2.tomb_parity == 1 ? kTomb : a2.tomb_parity == 0 ? kTomb1 : kTomb, &ht2) : -1;
-        if (e2 == kPending) e2 = -1;
+        int e1 = -1, e2 = -1;
+        unsigned long long w1 = 0ull, w2 = 0ull;
+        bool c1_room = !c1_full;
+        if (sa) {   // set-associative tiers: both tiers' set lines in one round trip; "C1 has room" = the key's C1 set has a free way
+            const unsigned s1 = ok ? sa_set_of(key, a1.sa_nset) : 0u, s2 = ok ? sa_set_of(key, a2.sa_nset) : 0u;
+            SaLine l1, l2;
+            sa_load(a1.a.ekey, s1, l1);
+            sa_load(a2.a.ekey, s2, l2);
+            const int y1 = sa_find(l1, key, w1), y2 = sa_find(l2, key, w2);
+            if (ok && y1 >= 0) e1 = (int)(s1 * (unsigned)kSaWays + (unsigned)y1);
+            else if (ok && y2 >= 0) e2 = (int)(s2 * (unsigned)kSaWays + (unsigned)y2);
+            c1_room = sa_has_free(l1);
+            end1 = s1; end2 = s2;
+        } else {
+            e1 = ok ? probe_ro(a1.slots, a1.mask, key, end1, a1.tomb_parity == 1 ? kTomb : a1.tomb_parity == 0 ? kTomb1 : kTomb, &ht1) : -1;
+            if (e1 == kPending) e1 = -1;
+            e2 = (ok && e1 < 0) ? probe_ro(a2.slots, a2.mask, key, end2, a2.tomb_parity == 1 ? kTomb : a2.tomb_parity == 0 ? kTomb1 : kTomb, &ht2) : -1;
+            if (e2 == kPending) e2 = -1;
+        }
         // alt-key probe for a double miss (find_approximate_ev, evlfu_8.cpp:474-490): the key is in C3 and its alt row
         // is resident in C1, else in C2 -> that row is served; the request's agg_hit counts it, nothing is inserted
         int alt_tier = 0, ea = -1;
@@ -1109,15 +1125,25 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
                 if (at >= 1 && at <= (unsigned)T && (long long)ar < a1.backing_rows[at - 1] && (long long)ar < a2.backing_rows[at - 1]) {
                     const unsigned long long akey = ((unsigned long long)at << 32) | ar;
                     unsigned long long es;
-                    ea = probe_ro(a1.slots, a1.mask, akey, es);
+                    ea = sa ? sa_lookup(a1.a.ekey, a1.sa_nset, akey) : probe_ro(a1.slots, a1.mask, akey, es);
                     if (ea >= 0) alt_tier = 1;
-                    else { ea = probe_ro(a2.slots, a2.mask, akey, es); if (ea >= 0) alt_tier = 2; }
+                    else { ea = sa ? sa_lookup(a2.a.ekey, a2.sa_nset, akey) : probe_ro(a2.slots, a2.mask, akey, es); if (ea >= 0) alt_tier = 2; }
                     if (alt_tier) atomicOr(&tt.c3.tags[w3], kC3Flag);   // set_recency_flag_c3
                 }
             }
         }
         const unsigned long long hm = __ballot(e1 >= 0 || e2 >= 0 || alt_tier != 0);
         const int agg = __popc((unsigned)(half ? (hm >> 32) : hm));
+        if (sa) {   // the priority rides in the key word: one atomicMax on it
+            if (e1 >= 0 && sa_prio(w1) < agg) {
+                const int old = sa_prio(atomicMax(&a1.a.ekey[e1], (w1 & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
+            }
+            if (e2 >= 0 && sa_prio(w2) < agg) {
+                const int old = sa_prio(atomicMax(&a2.a.ekey[e2], (w2 & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
+            }
+        } else {
         if (e1 >= 0 && a1.a.eagg[e1] < agg) {
             const int old = atomicMax(&a1.a.eagg[e1], agg);
             if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
@@ -1126,9 +1152,10 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
             const int old = atomicMax(&a2.a.eagg[e2], agg);
             if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
         }
+        }
         // evlfu_8.cpp:570-601: where a double miss goes
         const bool miss = ok && e1 < 0 && e2 < 0 && alt_tier == 0;
-        const int dest = !c1_full ? 1 : (agg < tt.threshold ? ((hl & 1) ? 1 : 2) : 2);
+        const int dest = c1_room ? 1 : (agg < tt.threshold ? ((hl & 1) ? 1 : 2) : 2);
         const unsigned char *src = nullptr;
         int codec_of = 0;
         if (e1 >= 0) { src = a1.a.arena + (long long)e1 * a1.row_bytes; codec_of = 1; }
@@ -1894,6 +1921,9 @@ template <> struct SaNative<NoTail> { using type = int; };
 template <int PIECES, typename U, typename TAIL = NoTail>
 __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsigned char *table, int t, unsigned row, int agg, unsigned set, int *s_delta, int *s_stat) {
     const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
+    // two tiers: the other tier took this key in this very batch (only an odd table index can be routed both ways by two
+    // requests of one batch: see sampled_insert_one)
+    if (args.route_filter && (t & 1) && args.route_filter[mix64(key) & args.route_mask] == args.route_stamp) return;
     unsigned long long *tags = args.a.ekey + (unsigned long long)set * kSaWays;
     // The set's line FIRST, then the source row, in that order in the instruction stream: vector-memory loads return in
     // order, so the CAS can go out when the line is there (an Infinity-Cache hit: the probe read it 20 us ago) while the
@@ -1937,6 +1967,7 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
 #pragma unroll
     for (int j = 0; j < kSaWays / 2; j++) { w[2 * j] = line.v[j].x; w[2 * j + 1] = line.v[j].y; }
     int way = -1, old_prio = -1;
+    unsigned long long old_key = 0ull;
     bool done = false;
 #pragma unroll 1
     for (int attempt = 0; attempt <= kSaWays && !done; attempt++) {
@@ -1960,7 +1991,7 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
             done = true;   // every way of the set was filled in this batch: the key is not kept
         } else {
             const unsigned long long prev = atomicCAS(&tags[best], bw, neww);
-            if (prev == bw) { way = best; old_prio = bp; done = true; }
+            if (prev == bw) { way = best; old_prio = bp; old_key = bw & kKeyMask; done = true; }
             else {
 #pragma unroll
                 for (int j = 0; j < kSaWays; j++) w[j] = j == best ? prev : w[j];
@@ -1992,6 +2023,8 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
         if constexpr (!std::is_same<TAIL, NoTail>::value) *reinterpret_cast<NT *>(drow + PIECES * sizeof(U)) = rt;   // (non-temporal stores for the row: measured, no difference)
     } else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
     else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
+    // three tiers: what this thread evicted becomes a member of the alt-key set (evlfu_8.cpp:617-620,654-658), behind its own stores
+    if (old_prio >= 0 && args.c3_tags != nullptr) c3_insert_key(C3Set{args.c3_tags, args.c3_nset, args.c3_stat}, old_key);
 }
 
 template <int PIECES, typename U, typename TAIL = NoTail>
@@ -2037,12 +2070,22 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_list_kernel(const Bat
 // the set-associative policy's update: the same lists, sa_insert_one per record.  The list's length, the lane's first
 // record and the table base addresses (into LDS: a per-lane index into the kernel arguments is a memory access) are
 // asked for together -- three dependent round trips per record: those, {set line, source row}, the CAS.
+template <int PIECES, typename U, typename TAIL>
+__device__ __forceinline__ void sa_list_block(const BatchArgs &args, int bid);
 template <int PIECES, typename U, typename TAIL = NoTail>
-__global__ void __launch_bounds__(256) cache_batch_sa_list_kernel(const BatchArgs args) {
+__global__ void __launch_bounds__(256) cache_batch_sa_list_kernel(const BatchArgs args) { sa_list_block<PIECES, U, TAIL>(args, (int)blockIdx.x); }
+// both tiers of a two- / three-tier lookup in one launch: blocks [0, g1) take C1's lists, [g1, 2 g1) C2's (the route filter
+// makes the two updates independent, as for the sampled pair)
+template <int P1, typename U1, typename T1, int P2, typename U2, typename T2>
+__global__ void __launch_bounds__(256) cache_batch_sa_list2_kernel(const BatchArgs args1, const BatchArgs args2) {
+    if ((int)blockIdx.x < args1.g1) sa_list_block<P1, U1, T1>(args1, (int)blockIdx.x);
+    else sa_list_block<P2, U2, T2>(args2, (int)blockIdx.x - args1.g1);
+}
+template <int PIECES, typename U, typename TAIL>
+__device__ __forceinline__ void sa_list_block(const BatchArgs &args, int bid) {
     __shared__ int s_delta[kMaxBuckets];
     __shared__ int s_stat[3];
     __shared__ const unsigned char *s_table[32];
-    const int bid = (int)blockIdx.x;
     for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_delta[i] = 0;
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
     const uint4 *rec = args.miss_rec + (long long)bid * args.list_cap;
@@ -2925,6 +2968,24 @@ static void launch_sa_update(const evs::BatchArgs &a, hipStream_t st) {
     }
 }
 
+// ... and of a set-associative pair
+static bool launch_sa_update_pair(const evs::BatchArgs &a1, const evs::BatchArgs &a2, hipStream_t st) {
+    using namespace evs;
+    static const bool on = !(getenv("EVS_CACHE_PAIR") && getenv("EVS_CACHE_PAIR")[0] == '0');
+    if (!on || a1.g1 != a2.g1 || sampled_list_threads(a1) != sampled_list_threads(a2)) return false;
+    const dim3 grid((unsigned)(2 * a1.g1)), block(sampled_list_threads(a1));
+    if (a1.row_bytes == 36 && a2.row_bytes == 18)
+        hipLaunchKernelGGL((cache_batch_sa_list2_kernel<2, float4, unsigned, 1, float4, unsigned short>), grid, block, 0, st, a1, a2);
+    else if (a1.row_bytes == 32 && a2.row_bytes == 16)
+        hipLaunchKernelGGL((cache_batch_sa_list2_kernel<2, float4, NoTail, 1, float4, NoTail>), grid, block, 0, st, a1, a2);
+    else if (a1.row_bytes == 16 && a2.row_bytes == 8)
+        hipLaunchKernelGGL((cache_batch_sa_list2_kernel<1, float4, NoTail, 1, uint2, NoTail>), grid, block, 0, st, a1, a2);
+    else if (a1.row_bytes == 144 && a2.row_bytes == 36)
+        hipLaunchKernelGGL((cache_batch_sa_list2_kernel<9, float4, NoTail, 2, float4, unsigned>), grid, block, 0, st, a1, a2);
+    else return false;
+    return true;
+}
+
 // both tiers' list updates as one launch (the pairs of row sizes a u8 C1 + u4 C2 make); false: no merged kernel for the pair
 static bool launch_sampled_update_pair(const evs::BatchArgs &a1, const evs::BatchArgs &a2, hipStream_t st) {
     using namespace evs;
@@ -2973,7 +3034,8 @@ static void sampled_close_pending(evs_cache *c, int rebuild, hipStream_t st) {
 // ... of both tiers of a two-tier lookup, one launch
 static void sampled_close_pending2(evs_cache *c1, int rebuild1, evs_cache *c2, int rebuild2, hipStream_t st) {
     using namespace evs;
-    const bool on1 = c1->batch_policy == 1 && c1->bs && c1->pending_batches, on2 = c2->batch_policy == 1 && c2->bs && c2->pending_batches;
+    const bool on1 = (c1->batch_policy == 1 || c1->batch_policy == 2) && c1->bs && c1->pending_batches,
+               on2 = (c2->batch_policy == 1 || c2->batch_policy == 2) && c2->bs && c2->pending_batches;
     if (!on1 || !on2) { sampled_close_pending(c1, rebuild1, st); sampled_close_pending(c2, rebuild2, st); return; }
     const CloseArgs ca1 = sampled_close_args(c1, rebuild1), ca2 = sampled_close_args(c2, rebuild2);
     hipLaunchKernelGGL(cache_batch_sampled_close2_kernel, dim3(2), dim3(256), 0, st, ca1, ca2);
@@ -3300,7 +3362,20 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     EVS_REQUIRE(c1->host.n_tables == c2->host.n_tables && c1->host.dim == c2->host.dim,
                 "evs_cache_lookup_batch_c1c2: the tiers must agree on n_tables and dim");
     EVS_REQUIRE(!c1->host_backing && !c2->host_backing, "evs_cache_lookup_batch_c1c2: backing tables must be in HBM");
-    EVS_REQUIRE(resolved_batch_policy(c1, false) != 2 && resolved_batch_policy(c2, false) != 2, "evs_cache_lookup_batch_c1c2: the set-associative batch policy serves single tiers only");
+    // a pair that was given no policy takes the set-associative form where both tiers can (tables in HBM, at least one full
+    // set each); a tier with a policy of its own decides for the other; one set-associative and one hashed tier: refused
+    {
+        const bool free1 = c1->batch_policy < 0, free2 = c2->batch_policy < 0;
+        const bool sa_ok = !c1->ft && !c2->ft && c1->host.cap >= kSaWays && c2->host.cap >= kSaWays;
+        if (free1 && free2 && !(getenv("EVS_CACHE_POLICY"))) c1->batch_policy = c2->batch_policy = sa_ok ? 2 : 1;
+        else if (free1 != free2) {
+            evs_cache *set = free1 ? c2 : c1, *unset = free1 ? c1 : c2;
+            unset->batch_policy = (set->batch_policy == 2 && !sa_ok) ? 1 : set->batch_policy;
+        }
+        const int p1 = resolved_batch_policy(c1, true), p2 = resolved_batch_policy(c2, true);
+        EVS_REQUIRE((p1 == 2) == (p2 == 2), "evs_cache_lookup_batch_c1c2: both tiers take the set-associative batch policy, or neither (C1 %d, C2 %d)", p1, p2);
+        EVS_REQUIRE(p1 != 2 || sa_ok, "evs_cache_lookup_batch_c1c2: the set-associative batch policy needs both tiers' tables in HBM and at least %d entries each", kSaWays);
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     BatchArgs a1, a2;
     int rc = batch_prepare(c1, B, rows, st, a1, "evs_cache_lookup_batch_c1c2");
@@ -3330,9 +3405,13 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         }
     }
     // both tiers on the sampled update (the default): the probe follows the parity rule of each tier's tombstones
-    const bool sampled2 = resolved_batch_policy(c1) == 1 && resolved_batch_policy(c2) == 1;
+    // sa2: both tiers set-associative (evs_hash.h) -- the same flow as sampled2 (probe lists the misses per tier, one update
+    // kernel per tier, lazy closes) over set lines instead of hashes; no tombstones, no housekeeping
+    const bool sa2 = resolved_batch_policy(c1) == 2 && resolved_batch_policy(c2) == 2;
+    const bool sampled2 = sa2 || (resolved_batch_policy(c1) == 1 && resolved_batch_policy(c2) == 1);
     constexpr unsigned kRouteWords = 1u << 20;
-    static const bool route_on = !(getenv("EVS_CACHE_ROUTEFILTER") && getenv("EVS_CACHE_ROUTEFILTER")[0] == '0');
+    static const bool route_on_env = !(getenv("EVS_CACHE_ROUTEFILTER") && getenv("EVS_CACHE_ROUTEFILTER")[0] == '0');
+    const bool route_on = route_on_env || sa2;   // (the set-associative update has no cross-tier hash look-up to fall back on)
     if (sampled2 && route_on && !c1->route_filter) {
         EVS_HIP_CHECK(hipMalloc(&c1->route_filter, kRouteWords * 4));
         EVS_HIP_CHECK(hipMemsetAsync(c1->route_filter, 0, kRouteWords * 4, st));
@@ -3342,10 +3421,10 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             evs_cache *c = k ? c2 : c1;
             BatchArgs &a = k ? a2 : a1;
             a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;
-            a.tomb_parity = a.stamp & 1;
+            a.tomb_parity = sa2 ? -1 : (a.stamp & 1);
             sampled_flush_if_wanted(c, st);
             static const bool c3_inline_on = !(getenv("EVS_CACHE_C3INLINE") && getenv("EVS_CACHE_C3INLINE")[0] == '0');
-            if (c3 && c3_inline_on) {   // the evicting thread inserts its victim into the alt-key set itself
+            if (c3 && (c3_inline_on || sa2)) {   // the evicting thread inserts its victim into the alt-key set itself
                 a.c3_tags = c3->tags; a.c3_nset = c3->nset; a.c3_stat = c3->bstat;
             } else
             if (c3) {   // victim lists for the alt-key tier: kReplicas lists, a block adds at most 256 keys to one of them
@@ -3371,7 +3450,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         // kernel block stages its victims in LDS: lists of at most kListVictMax records
         const long long lc = (B + 8 * (long long)a1.g1 - 1) / (8 * (long long)a1.g1) * 8 * T;
         static const bool list_on = !(getenv("EVS_CACHE_LIST2") && getenv("EVS_CACHE_LIST2")[0] == '0');
-        if (list_on && a1.g1 == a2.g1 && (!c3 || lc <= kListVictMax)) {
+        if (sa2 || (list_on && a1.g1 == a2.g1 && (!c3 || lc <= kListVictMax))) {
             a1.miss_rec = c1->miss_rec; a1.list_cnt = c1->list_cnt; a1.list_cap = (int)lc;
             a2.miss_rec = c2->miss_rec; a2.list_cnt = c2->list_cnt; a2.list_cap = (int)lc;
         }
@@ -3398,6 +3477,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             for (int t = 0; t < 32; t++) { tp.backing[t] = t < T ? a.backing[t] : nullptr; tp.backing_rows[t] = t < T ? a.backing_rows[t] : 0; }
             tp.miss_rec = a.miss_rec; tp.list_cnt = a.list_cnt; tp.part1 = a.part1; tp.hint_shift = a.hint_shift;
             tp.count = &a.bs->count; tp.cap = a.cap; tp.full_slack = a.cap > 65536 ? a.cap / 256 : 0;
+            tp.tags = sa2 ? a.a.ekey : nullptr; tp.sa_nset = sa2 ? a.sa_nset : 0u;
             (void)c;
         }
         pa.requests = rows; pa.tier_out = tier; pa.threshold = high_agghit_threshold; pa.T = T; pa.list_cap = 16 * T;
@@ -3420,10 +3500,17 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     if (sampled2) {
         // one update kernel per tier (per-position form: the probe wrote a record per (request, table) and tier); the
         // routing reads each tier's entry count, so the counters are folded every batch here
+        if (sa2) {
+            if (!launch_sa_update_pair(a1, a2, st)) {
+                launch_sa_update(a1, st);
+                launch_sa_update(a2, st);
+            }
+        } else {
         if (!a2.route_filter) { a2.other_slots = c1->bslots; a2.other_mask = (unsigned long long)(c1->bnslot - 1); }   // a key C1 just took is not inserted in C2 too
         if (!(a2.route_filter && launch_sampled_update_pair(a1, a2, st))) {
             launch_sampled_update(a1, st);
             launch_sampled_update(a2, st);
+        }
         }
         if (c3 && !a1.c3_tags) hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(2 * kReplicas * 8), dim3(256), 0, st, a1, a2, tt.c3);   // what the two tiers evicted
         c1->pending_batches++; c1->pending_requests += B;
@@ -3434,11 +3521,14 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         // fills, every batch.  (EVS_CACHE_LAZY2=0: every batch.)
         static const bool lazy2_on = !(getenv("EVS_CACHE_LAZY2") && getenv("EVS_CACHE_LAZY2")[0] == '0');
         volatile int *rep1 = reinterpret_cast<volatile int *>(c1->host_tomb);
-        const bool c1_known_full = lazy2_on && rep1 && rep1[3] == 1 && (long long)rep1[2] >= c1->last_flush_call && c1->last_flush_call < c1->batch_calls;
+        // (set-associative tiers: the routing reads the key's own set, not the entry count -- lazy from the first batch)
+        const bool c1_known_full = sa2 || (lazy2_on && rep1 && rep1[3] == 1 && (long long)rep1[2] >= c1->last_flush_call && c1->last_flush_call < c1->batch_calls);
         if (!c1_known_full || c1->pending_batches >= kCloseEvery || c2->pending_batches >= kCloseEvery || a1.rebuild || a2.rebuild)
             sampled_close_pending2(c1, a1.rebuild, c2, a2.rebuild, st);
-        batch_housekeeping(c1, a1, st);
-        batch_housekeeping(c2, a2, st);
+        if (!sa2) {
+            batch_housekeeping(c1, a1, st);
+            batch_housekeeping(c2, a2, st);
+        }
         EVS_HIP_CHECK(hipGetLastError());
         return EVS_OK;
     }

@@ -93,6 +93,13 @@ __device__ __forceinline__ void sa_load(const unsigned long long *tags, unsigned
 #pragma unroll
     for (int j = 0; j < kSaWays / 2; j++) l.v[j] = p[j];
 }
+// does the set have a free way
+__device__ __forceinline__ bool sa_has_free(const SaLine &l) {
+    bool f = false;
+#pragma unroll
+    for (int j = 0; j < kSaWays / 2; j++) f = f || l.v[j].x == kEmpty || l.v[j].y == kEmpty;
+    return f;
+}
 // way holding `key` (-1: none) and its word
 __device__ __forceinline__ int sa_find(const SaLine &l, unsigned long long key, unsigned long long &word) {
     int way = -1;
@@ -104,6 +111,16 @@ __device__ __forceinline__ int sa_find(const SaLine &l, unsigned long long key, 
         word = a ? l.v[j].x : b ? l.v[j].y : word;
     }
     return way;
+}
+
+// entry of `key` in a set-associative tier (-1: not resident)
+__device__ __forceinline__ int sa_lookup(const unsigned long long *tags, unsigned nset, unsigned long long key) {
+    const unsigned set = sa_set_of(key, nset);
+    SaLine l;
+    sa_load(tags, set, l);
+    unsigned long long w;
+    const int way = sa_find(l, key, w);
+    return way >= 0 ? (int)(set * (unsigned)kSaWays + (unsigned)way) : -1;
 }
 
 constexpr int kMaxTables = 64;      // one lane per table (exact path)
@@ -142,6 +159,7 @@ struct TierProbe {
     int *part1;                           // replica rows of the hit / histogram totals (32 x 40 ints)
     int hint_shift;
     const int *count; int cap, full_slack;   // entries resident at the last close; "full" = count >= cap - full_slack
+    unsigned long long *tags; unsigned sa_nset;   // set-associative tier (sa_nset != 0): the sets' key words (slots / eagg unused)
 };
 struct Probe2Args {
     TierProbe t1, t2;

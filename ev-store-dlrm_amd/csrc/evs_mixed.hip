@@ -261,8 +261,9 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
         const bool c1_full = *pa.t1.count >= pa.t1.cap - pa.t1.full_slack;   // snapshot, as probe2
         const long long bs = blk_first + (threadIdx.x & 15);
         int prow[2], e1[2], e2[2], ea[2], alt_tier[2];
-        bool act[2], ok[2], ht1[2], ht2[2];
-        unsigned long long key[2], end1[2], end2[2];
+        bool act[2], ok[2], ht1[2], ht2[2], c1_room[2];
+        unsigned long long key[2], end1[2], end2[2], w1[2], w2[2];
+        const bool sa = pa.t1.sa_nset != 0;   // set-associative tiers (evs_hash.h): both tiers or neither
 #pragma unroll
         for (int h = 0; h < 2; h++) {   // the thread's two request rows side by side
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
@@ -276,6 +277,29 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
             ok[h] = act[h] && prow[h] >= 0 && prow[h] < pa.t1.backing_rows[k] && prow[h] < pa.t2.backing_rows[k];
             key[h] = ((unsigned long long)f << 32) | (unsigned)prow[h];
             end1[h] = end2[h] = 0; ht1[h] = ht2[h] = false;
+            e1[h] = e2[h] = -1; w1[h] = w2[h] = 0ull; c1_room[h] = !c1_full;
+        }
+        if (sa) {
+            // both tiers' set lines of both keys in ONE round trip (the hashed form walks C1, then C2, then reads the
+            // priority); "C1 has room" is a property of the key's own C1 set: a free way
+            SaLine l1[2], l2[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                end1[h] = ok[h] ? sa_set_of(key[h], pa.t1.sa_nset) : 0u;
+                end2[h] = ok[h] ? sa_set_of(key[h], pa.t2.sa_nset) : 0u;
+                sa_load(pa.t1.tags, (unsigned)end1[h], l1[h]);
+                sa_load(pa.t2.tags, (unsigned)end2[h], l2[h]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int y1 = sa_find(l1[h], key[h], w1[h]), y2 = sa_find(l2[h], key[h], w2[h]);
+                if (ok[h] && y1 >= 0) e1[h] = (int)((unsigned)end1[h] * (unsigned)kSaWays + (unsigned)y1);
+                else if (ok[h] && y2 >= 0) e2[h] = (int)((unsigned)end2[h] * (unsigned)kSaWays + (unsigned)y2);
+                c1_room[h] = sa_has_free(l1[h]);
+            }
+        } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
             e1[h] = ok[h] ? probe_ro(pa.t1.slots, pa.t1.mask, key[h], end1[h], pa.t1.reusable_tomb, &ht1[h]) : -1;
             if (e1[h] == kPending) e1[h] = -1;
         }
@@ -283,6 +307,10 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
         for (int h = 0; h < 2; h++) {
             e2[h] = (ok[h] && e1[h] < 0) ? probe_ro(pa.t2.slots, pa.t2.mask, key[h], end2[h], pa.t2.reusable_tomb, &ht2[h]) : -1;
             if (e2[h] == kPending) e2[h] = -1;
+        }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
             // alt-key probe for a double miss (find_approximate_ev, evlfu_8.cpp:474-490), as in probe2
             alt_tier[h] = 0; ea[h] = -1;
             if (pa.c3.tags && ok[h] && e1[h] < 0 && e2[h] < 0) {
@@ -294,9 +322,9 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
                     if (at >= 1 && at <= (unsigned)T && (long long)ar < pa.t1.backing_rows[at - 1] && (long long)ar < pa.t2.backing_rows[at - 1]) {
                         const unsigned long long akey = ((unsigned long long)at << 32) | ar;
                         unsigned long long es;
-                        ea[h] = probe_ro(pa.t1.slots, pa.t1.mask, akey, es);
+                        ea[h] = sa ? sa_lookup(pa.t1.tags, pa.t1.sa_nset, akey) : probe_ro(pa.t1.slots, pa.t1.mask, akey, es);
                         if (ea[h] >= 0) alt_tier[h] = 1;
-                        else { ea[h] = probe_ro(pa.t2.slots, pa.t2.mask, akey, es); if (ea[h] >= 0) alt_tier[h] = 2; }
+                        else { ea[h] = sa ? sa_lookup(pa.t2.tags, pa.t2.sa_nset, akey) : probe_ro(pa.t2.slots, pa.t2.mask, akey, es); if (ea[h] >= 0) alt_tier[h] = 2; }
                         if (alt_tier[h]) atomicOr(&pa.c3.tags[w3], kC3Flag);   // set_recency_flag_c3
                     }
                 }
@@ -308,6 +336,16 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h, k = f >= 1 ? f - 1 : 0;
+            if (sa) {
+                if (e1[h] >= 0 && sa_prio(w1[h]) < agg) {
+                    const int old = sa_prio(atomicMax(&pa.t1.tags[e1[h]], (w1[h] & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                    if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
+                }
+                if (e2[h] >= 0 && sa_prio(w2[h]) < agg) {
+                    const int old = sa_prio(atomicMax(&pa.t2.tags[e2[h]], (w2[h] & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                    if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
+                }
+            } else {
             if (e1[h] >= 0 && pa.t1.eagg[e1[h]] < agg) {
                 const int old = atomicMax(&pa.t1.eagg[e1[h]], agg);
                 if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
@@ -316,9 +354,10 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
                 const int old = atomicMax(&pa.t2.eagg[e2[h]], agg);
                 if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
             }
+            }
             // evlfu_8.cpp:570-601: where a double miss goes
             const bool miss = ok[h] && e1[h] < 0 && e2[h] < 0 && alt_tier[h] == 0;
-            const int dest = !c1_full ? 1 : (agg < pa.threshold ? ((k & 1) ? 1 : 2) : 2);
+            const int dest = c1_room[h] ? 1 : (agg < pa.threshold ? ((k & 1) ? 1 : 2) : 2);
             const unsigned char *src = nullptr;
             int codec_of = 0;
             if (e1[h] >= 0) { src = pa.t1.arena + (long long)e1[h] * pa.t1.row_bytes; codec_of = 1; }

@@ -153,6 +153,15 @@ def c1c2c3_case(rs, case):
     return tag
 
 
+def _sa_sets(keys_tr, cap):
+    """set of each (table_1based, row) key of a set-associative tier of `cap` entries (csrc/evs_hash.h: sa_set_of)"""
+    k = (np.asarray([t for t, _ in keys_tr], np.uint64) << np.uint64(32)) | np.asarray([r for _, r in keys_tr], np.uint64)
+    with np.errstate(over="ignore"):
+        k ^= k >> np.uint64(33); k *= np.uint64(0xff51afd7ed558ccd); k ^= k >> np.uint64(33)
+        k *= np.uint64(0xc4ceb9fe1a85ec53); k ^= k >> np.uint64(33)
+    return (((k >> np.uint64(32)) * np.uint64(cap // 8)) >> np.uint64(32)).astype(np.int64)
+
+
 def batched_case(rs, case):
     T = int(rs.choice([1, 7, 26, 26, 32]))
     d = int(rs.choice([16, 36, 36, 64]))
@@ -222,7 +231,7 @@ def batched2_case(rs, case):
     B = int(rs.choice([1, 30, 250, 900]))
     n_batches = int(rs.choice([3, 8, 14]))
     tag = "batched two-tier case %d: n=%d cap1=%d cap2=%d thr=%d B=%d batches=%d" % (case, n, cap1, cap2, thr, B, n_batches)
-    policy = str(rs.choice(["sampled", "sampled", "plan"]))
+    policy = str(rs.choice(["sampled", "setassoc", "setassoc", "plan"]))
     tag += " policy=%s" % policy
     c1 = E.GpuCache("evlfu", cap1, T, d, 8, "cpp").set_batch_policy(policy)
     c2 = E.GpuCache("evlfu", cap2, T, d, 4, "cpp").set_batch_policy(policy)
@@ -230,11 +239,16 @@ def batched2_case(rs, case):
     c2.set_backing([torch.from_numpy(r).cuda() for r in raw4])
     reqs = _stream(rs, [n] * T, B * n_batches)
     R1, R2 = {}, {}
+    sa = policy == "setassoc"
+    if sa:   # set of every key in C1 (csrc/evs_hash.h: sa_set_of)
+        set_of = _sa_sets([(k + 1, v) for k in range(T) for v in range(n)], cap1).reshape(T, n)
     for s in range(0, len(reqs), B):
         rq = reqs[s:s + B]
         tier, out = gpu_cache.lookup_batch_c1c2(c1, c2, torch.from_numpy(rq).cuda(), threshold=thr)
         tier, out = tier.cpu().numpy(), out.cpu().numpy()
         c1_full = len(R1) >= cap1
+        if sa:
+            occ = np.bincount(_sa_sets(list(R1), cap1), minlength=cap1 // 8) if R1 else np.zeros(cap1 // 8, int)
         for b in range(len(rq)):
             in1 = np.array([(k + 1, int(rq[b, k])) in R1 for k in range(T)])
             in2 = np.array([(k + 1, int(rq[b, k])) in R2 for k in range(T)]) & ~in1
@@ -247,7 +261,8 @@ def batched2_case(rs, case):
                 elif in2[k]:
                     want = dec4[k][row]
                 else:
-                    dest = 1 if not c1_full else ((1 if k % 2 == 1 else 2) if agg < thr else 2)
+                    full = occ[set_of[k, row]] >= 8 if sa else c1_full   # set-associative tiers: "C1 full" = the key's own C1 set
+                    dest = 1 if not full else ((1 if k % 2 == 1 else 2) if agg < thr else 2)
                     want = dec8[k][row] if dest == 1 else dec4[k][row]
                 assert np.array_equal(out[b, k].view(np.uint32), want.view(np.uint32)), tag + ": row (%d,%d)" % (b, k)
         d1, d2 = c1.batch_dump(), c2.batch_dump()
@@ -255,7 +270,7 @@ def batched2_case(rs, case):
         n2 = {(int(t), int(rw)): int(p) for p, t, rw in d2}
         assert len(n1) == len(d1) == c1.batch_stats()["size"] <= cap1 and len(n2) == len(d2) == c2.batch_stats()["size"] <= cap2, tag + ": sizes"
         assert not (set(n1) & set(n2)), tag + ": a key in both tiers"
-        if not c1_full:
+        if not c1_full and not sa:
             assert len(n2) == len(R2), tag + ": C2 touched while C1 had room"
         R1, R2 = n1, n2
     return tag
@@ -279,7 +294,7 @@ def batched3_case(rs, case):
     n_batches = int(rs.choice([4, 12]))
     tag = "batched three-tier case %d: T=%d d=%d n=%d codecs=%d/%d caps=%d/%d/%d thr=%d B=%d batches=%d" % (
         case, T, d, n, ca, cb, cap1, cap2, cap3, thr, B, n_batches)
-    policy = str(rs.choice(["sampled", "sampled", "plan"]))
+    policy = str(rs.choice(["sampled", "setassoc", "setassoc", "plan"]))
     tag += " policy=%s" % policy
     c1 = E.GpuCache("evlfu", cap1, T, d, ca, "cpp").set_batch_policy(policy)
     c2 = E.GpuCache("evlfu", cap2, T, d, cb, "cpp").set_batch_policy(policy)
