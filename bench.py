@@ -118,7 +118,10 @@ def mixed_tiers_section(ev, ln_emb, d, B, dev, fill=180, steps=40, alpha=0.75):
     _, st3 = c3.batch_dump()
     out["three_tier"] = {"ms_per_step": ms, "value": T * B / ms * 1e3, "c3_members": st3["members"], "alt_hits_served": st3["n_hit"]}
     out.update({"unit": "lookups/s", "batch": B, "tiers": "u8 C1 + u4 C2 (+ alt-key C3), 48-48-4 of 2 % of the rows",
-                "note": "batched lookups, probe + mixed-precision interaction in one launch, one update kernel per tier"})
+                "policy": os.environ.get("EVS_CACHE_POLICY", "setassoc"),
+                "note": "batched lookups, probe + mixed-precision interaction in one launch, both tiers' updates in one launch "
+                        "(set-associative tiers by default: both tiers' set lines in one round trip, 'C1 has room' = the key's own C1 set "
+                        "has a free way; EVS_CACHE_POLICY=sampled: the hashed tiers of round 2)"})
     return out
 
 

@@ -133,7 +133,7 @@ def _exact_tables(ln, d, seed):
     return [(torch.randint(0, 3, (n, d), device="cuda", generator=g, dtype=torch.int8) - 1).to(torch.float32) for n in ln]
 
 
-@pytest.mark.parametrize("policy", ["sampled", "plan"])
+@pytest.mark.parametrize("policy", ["sampled", "plan", "setassoc"])
 def test_bench_mixed_precision_tiers_at_full_size(E, orc, policy):
     """configs[4] as bench.mixed_tiers_section builds it: u8 C1 + u4 C2 at the 48-48-4 split of 2 % of the Kaggle rows
     (1 296 480 + 2 592 960 entries) and the alt-key tier, B = 16 384, probe + mixed-precision interaction in one launch."""
