@@ -281,12 +281,16 @@ EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows,
                                    void *stream);
 /* How the batched path of this cache makes room (before its first batched call; EVS_ESTATE afterwards).  A cache that
  * is not given a policy decides at its first batched call: EVS_CACHE_POLICY = plan | sampled | setassoc in the environment,
- * else 2 where it applies (a single tier whose tables the kernels read in place from HBM, capacity >= 8) and 1 elsewhere.
+ * else 2 where it applies (tiers whose tables the kernels read in place from HBM, capacity >= 8: a single tier, or BOTH tiers
+ * of a two- / three-tier lookup -- a pair is all set-associative or not at all) and 1 elsewhere.
  *   2 "setassoc": the cache is 8-way set-associative -- set = hash(key), one 64-byte line of 8 key words (key | batch stamp
  *     | priority) per set, way w of set s owns arena row 8 s + w.  A probe reads that line; the update kernel's thread that
  *     inserts a new key takes the lowest priority OF THE KEY'S OWN SET (free ways first) with one CAS and writes the row.
  *     No hash chains, tombstones, sweeps or entry arrays.  capacity / 8 sets (up to 7 entries of the capacity unused);
- *     single tier, tables in HBM (host-memory / file-backed tables and the two- / three-tier lookups: EVS_ESTATE / EINVAL);
+ *     tables in HBM (host-memory / file-backed tables: EVS_ESTATE).  In the two- / three-tier lookups both tiers' set
+ *     lines are read in one round trip and the routing rule's "while C1 is not full" (evlfu_8.cpp:570-601) is read PER
+ *     KEY: a double miss goes to C1 while the key's own C1 set has a free way, and by the agg_hit / odd-even rule once it
+ *     has none (the hashed forms read it off the tier's entry count);
  *   1 "sampled": a hash over an entry arena; one kernel after the consumers -- the thread that inserts a new key picks
  *     that key's victim itself, the lowest priority of one sampled group of 8 entries (free entries first);
  *   0 "plan": insert -> plan -> evict -> assign -> close, the lowest priorities of a clock-hand window go, exactly as
