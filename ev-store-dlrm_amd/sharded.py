@@ -265,7 +265,7 @@ class ShardedEmbeddingInteract:
             else:
                 send = like.new_empty((Bg, max(len(self.my_own), 0), self.d), dtype=torch.float32)
             # one rank: nothing to exchange -- the "received" block is the send buffer itself (no copy)
-            recv = send.view(-1) if self.world == 1 else like.new_empty((sum(out_splits),), dtype=torch.float32)
+            recv = send.view(-1) if not self._exchanges() else like.new_empty((sum(out_splits),), dtype=torch.float32)
             self._bufs[key] = (send, recv)
         return self._bufs[key]
 
@@ -287,6 +287,13 @@ class ShardedEmbeddingInteract:
                                   row_lo=[row_range(self.ln_emb[t], self.rank, self.world)[0] for t in self.split],
                                   row_total=[self.ln_emb[t] for t in self.split])
 
+    # one rank has nothing to exchange and the received block is the send buffer itself -- unless force_exchange asks for
+    # the collective anyway (tests: the RCCL call with this op's buffers and split lists, on the one GPU a box has)
+    force_exchange = False
+
+    def _exchanges(self):
+        return self.world > 1 or self.force_exchange
+
     def pool(self, lS_o, lS_i, slot=0):
         """Pool the owned tables (and this rank's row ranges of the split tables) for the full batch into the send layout."""
         Bg = int(lS_o[0].shape[0])
@@ -305,7 +312,7 @@ class ShardedEmbeddingInteract:
             return (None, self._buffers(Bg, slot, like)[1], Bg, Bl, out_splits)
         send, recv = self.pool(lS_o, lS_i, slot)
         work = None
-        if self.world > 1:
+        if self._exchanges():
             work = dist.all_to_all_single(recv, send.view(-1), out_splits, in_splits, group=self.group, async_op=True)
         return (work, recv, Bg, Bl, out_splits)
 
@@ -428,7 +435,7 @@ class ShardedEmbeddingInteract:
         self._pool_into(pl["send"], pl["Bg"], pl["lo"], pl["li"], planned=True, lo_split=pl["lo_split"], li_split=pl["li_split"])
         if tr is not None:
             tr["pool"].append(self._stamp())
-        if self.world > 1:
+        if self._exchanges():
             return dist.all_to_all_single(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"], group=self.group,
                                           async_op=True)
         return None   # one rank: recv aliases send

@@ -1,0 +1,59 @@
+"""Child process of tests/test_gpu_parity.py::test_sharded_step_through_rccl_at_world_1: the sharded op over HipBackend with the
+REAL RCCL all_to_all_single (backend "nccl", world size 1 -- the one GPU a test box has): device buffers, split lists, the
+asynchronous work handle and the planned / pipelined step, under every placement; results against the unsharded launch."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import evstore_dlrm_amd as E  # noqa: E402
+from evstore_dlrm_amd import sharded  # noqa: E402
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", sys.argv[1] if len(sys.argv) > 1 else "29571")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    rs = np.random.RandomState(3)
+    ln = [5000, 7, 2600, 40, 9000, 3, 12000] + [100] * 19
+    T, d, B = len(ln), 36, 1024 + 16
+    ws = [torch.from_numpy(rs.uniform(-1, 1, size=(n, d)).astype(np.float32)).to(dev) for n in ln]
+    ev = E.EVTables.from_fp32(ws)
+    idx = torch.stack([torch.from_numpy(rs.randint(0, n, size=B)) for n in ln]).to(dev)
+    off = torch.arange(B, device=dev).repeat(T, 1)
+    x = torch.rand(B, d, device=dev)
+    want = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
+    for policy in ("rows+replicate", "rows", "count", "rowsplit"):
+        owner = sharded.plan_placement(ln, 1, policy, replicate_max_rows=2000)
+        weights = {t: ws[t] for t in range(T)}
+        op = sharded.ShardedEmbeddingInteract(ln, d, 0, 1, weights, sharded.HipBackend(dev), policy=policy, one_index_per_bag=True,
+                                              replicate_max_rows=2000)
+        op.force_exchange = True
+        lo, li = [off[t] for t in range(T)], [idx[t] for t in range(T)]
+        R = op.forward(x, lo, li)
+        assert torch.equal(R, want), policy
+        out = torch.empty_like(want)
+        pl = op.plan(x, lo, li, out=out)
+        for _ in range(3):
+            op.step(pl)
+        assert torch.equal(out, want), policy + " (planned)"
+        h = op.run_start(pl)
+        out.zero_()
+        op.run_finish(pl, h)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), policy + " (pipelined)"
+        assert not op.any_sharded or pl["recv"].data_ptr() != pl["send"].data_ptr(), "the exchange must have its own receive buffer"
+        del op
+    dist.barrier()
+    dist.destroy_process_group()
+    print("NCCL_WORLD1_OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,6 @@
 """GPU parity: the HIP path (through the C ABI) vs the oracle and the golden vectors."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1278,3 +1280,21 @@ def test_multi_batch_call_equals_single_launches(E, orc, K, B, declared):
     k = K - 1
     ly = [ev.fp32_view(t)[idx[k][t]].cpu().numpy() for t in range(T)]
     np.testing.assert_allclose(want[k].cpu().numpy(), orc.interact_features(xs[k].cpu().numpy(), ly), rtol=RTOL, atol=2e-6)
+
+
+def test_sharded_step_through_rccl_at_world_1():
+    """The sharded op over HipBackend with the REAL RCCL collective (backend "nccl", world size 1: the one GPU of a test box),
+    in a child process: all_to_all_single on this op's device buffers and split lists, the async work handle, eager /
+    planned / pipelined steps, every placement -- bit-equal to the unsharded fused launch (tests/_nccl_world1_child.py).
+    Multi-rank layouts are pinned under gloo (tests/test_dist_golden.py, test_sharded_world8.py); this pins the RCCL call
+    path itself, which the driver's N > 1 runs are the first to take with more than one rank."""
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nccl_world1_child.py"), str(port)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
