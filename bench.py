@@ -562,6 +562,10 @@ def main():
     ap.add_argument("--cdf-dir", default=os.path.join(ROOT, "gpurun_out", "cdf"), help="where the B=1 latency CDF CSV goes")
     ap.add_argument("--replicate-gb", type=float, default=64.0, help="per-GPU HBM budget for replicated tables (hbm placement)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one process")
+    ap.add_argument("--exchange-mode", default="inline", choices=["inline", "async"],
+                    help="N>1: all_to_all_single(async_op=False) in stream order (default) or async_op=True with the handle waited on in front of the interaction")
+    ap.add_argument("--force-exchange", action="store_true", help="with --force-sharded on one rank: issue the RCCL all_to_all_single anyway "
+                                                                  "(a self-exchange into a separate receive buffer: what the collective call itself costs per step)")
     ap.add_argument("--shape", default="kaggle", choices=["kaggle", "terabyte"],
                     help="N>1 only: terabyte = BASELINE configs[3], MLPerf-DLRM Criteo-Terabyte cardinalities capped at 40 M rows "
                          "(external to the reference tree; --dim 64 or 128): with the default placement the tables above 1 M rows "

@@ -313,7 +313,7 @@ class ShardedEmbeddingInteract:
         send, recv = self.pool(lS_o, lS_i, slot)
         work = None
         if self._exchanges():
-            work = dist.all_to_all_single(recv, send.view(-1), out_splits, in_splits, group=self.group, async_op=True)
+            work = self._exchange(recv, send.view(-1), out_splits, in_splits)
         return (work, recv, Bg, Bl, out_splits)
 
     # ---- where the receiver finds things ------------------------------------------------------------------------------
@@ -436,9 +436,25 @@ class ShardedEmbeddingInteract:
         if tr is not None:
             tr["pool"].append(self._stamp())
         if self._exchanges():
-            return dist.all_to_all_single(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"], group=self.group,
-                                          async_op=True)
+            return self._exchange(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"])
         return None   # one rank: recv aliases send
+
+    # How the collective is issued.  The call path alone, measured at world size 1 (tools/a2a_cost.py: a self-exchange, no
+    # link time): all_to_all_single(async_op=True) + wait() costs 37.8 us of host time and 39.6 us of stream time per call (a
+    # Work object, an extra pair of cross-stream event waits); async_op=False 14.1 us host, 24.1 us stream.
+    #   "inline" (default): async_op=False, everything in stream order -- pool(i + 1), exchange(i + 1), interaction(i); the
+    #             two-deep pipeline overlaps HOST work (the next batch's launches) with device work, not the exchange with
+    #             the interaction;
+    #   "async":  async_op=True, the handle waited on in front of the interaction: the exchange of batch i + 1 runs on
+    #             RCCL's stream under the interaction of batch i -- at the price of the dearer call.
+    # One rank with the exchange forced (bench.py --force-sharded --force-exchange): 52-58 us per step inline, 63 us async.
+    exchange_mode = "inline"
+
+    def _exchange(self, recv, send, out_splits, in_splits):
+        if self.exchange_mode == "async":
+            return dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group, async_op=True)
+        dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group, async_op=False)
+        return None
 
     def step(self, pl):
         """One whole planned step on the current stream: pool -> all-to-all -> interaction (no overlap between steps)."""
@@ -448,7 +464,11 @@ class ShardedEmbeddingInteract:
         """The planned step as a HIP graph (torch.cuda.CUDAGraph over the library's launches on torch's capture stream):
         a replay costs one host call instead of the Python / ctypes marshalling of two launches and a collective.
         Captured after two eager runs on a side stream (first-use allocations inside the library must not happen
-        during capture).  The exchange of a multi-rank step is captured with it (RCCL collectives are capturable)."""
+        during capture).  Steps without an exchange only (one rank, or every table replicated): see below."""
+        if self._exchanges() and self.any_sharded:
+            # measured on this stack (ROCm 7.0 / RCCL 2.26, one rank with the exchange forced): capturing the step with its
+            # all_to_all_single inside ends in a segmentation fault at replay -- refused here, the bench falls back to the eager loop
+            raise RuntimeError("capture_step: a step that holds the RCCL all-to-all is not captured on this stack")
         side = torch.cuda.Stream(device=self.backend.device)
         side.wait_stream(torch.cuda.current_stream(self.backend.device))
         with torch.cuda.stream(side):
@@ -517,6 +537,8 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
         weights[t] = torch.empty((hi - lo, d), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
     op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy, one_index_per_bag=True,
                                   replicate_budget_rows=budget_rows)
+    op.force_exchange = bool(getattr(args, "force_exchange", False))
+    op.exchange_mode = getattr(args, "exchange_mode", "inline")
     # every rank generates the same full-batch indices (same seed), as the reference feeds them
     g.manual_seed(7)
     nb = 4
