@@ -29,23 +29,17 @@ for set in \
   timeout 240 rocprofv3 --pmc $set --output-format csv -d $OUT/sq$i -- python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-cache-tier > $OUT/sq$i.log 2>&1 || echo "sq pass $i failed"
 done
 python3 $ROOT/tools/pmc_summary.py $OUT "emb_interact_rf_kernel" > $OUT/pmc_summary.txt
-# the cache tier alone: 600 batches it has not seen (housekeeping included), kernel statistics and per-dispatch deciles
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ctrace -- python3 $ROOT/tools/cache_bench.py 16384 600 0 > $OUT/cache_bench_600.json 2> $OUT/cache_bench_600.err
-f=$(find $OUT/ctrace -name "*kernel_stats.csv" | head -1); grep -E "evs::|Name" $f > $OUT/cache_kernel_stats.csv
-t=$(find $OUT/ctrace -name "*kernel_trace.csv" | head -1); python3 $ROOT/tools/ktrace_deciles.py $t | grep "evs::" > $OUT/cache_kernel_deciles.txt
-rm -rf $OUT/ctrace
-EVS_CACHE_POLICY=plan python3 $ROOT/tools/cache_bench.py 16384 600 0 > $OUT/cache_bench_600_plan.json 2>/dev/null
-# configs[4]: the two- and three-tier batched lookups (c2bench), kernel statistics
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2trace -- python3 $ROOT/tools/c2bench.py > $OUT/c2bench_prof.log 2>&1
-f=$(find $OUT/c2trace -name "*kernel_stats.csv" | head -1); grep -E "evs::|Name" $f > $OUT/c2_kernel_stats.csv
-rm -rf $OUT/c2trace
 # reduced-precision fused launches (tables encoded from the fp32 ones), kernel statistics
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rqtrace -- python3 $ROOT/tools/kbench.py --fused-only --bits 16 --codes encoded --batch 16384 65536 --iters 300 > $OUT/kbench_u16.log 2>&1
 f=$(find $OUT/rqtrace -name "*kernel_stats.csv" | head -1); grep -E "evs::|Name" $f > $OUT/u16_kernel_stats.csv
 rm -rf $OUT/rqtrace
 cd $ROOT
 timeout 900 python3 tools/sweep.py > $OUT/sweep.md 2> $OUT/sweep.err
-timeout 200 python3 tools/c2bench.py > $OUT/c2bench.log 2>&1
+# the cache tier alone and the two- / three-tier chains: kernel statistics, deciles, the other policies, PMC traffic
+bash tools/prof_cache_r03.sh $TAG > $OUT/prof_cache.log 2>&1
+python3 tools/a2a_cost.py 2>/dev/null | grep "us/call" > $OUT/a2a_cost.log
+python3 tools/copy_probe.py > $OUT/copy_probe.log 2>&1
+python3 bench.py --force-sharded --force-exchange --steps 300 --warmup 50 --no-cpu-baseline --no-cache-tier --no-extras > $OUT/bench_force_sharded_exchange.json 2>/dev/null
 find $OUT -name "*.csv" -size +3M -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT | tail -1
