@@ -103,8 +103,9 @@ class _ModuleCache:
         when this request has to take the generic path."""
         if not getattr(self, "_bound", False):
             self._bind()
-        if self.engine != "host" or not torch.is_tensor(lS_i) or lS_i.is_cuda or lS_i.dtype not in (torch.int64, torch.int32) \
-                or lS_i.dim() < 1 or lS_i.shape[0] != self.n_tables:
+        if self.engine != "host" or not torch.is_tensor(lS_i) or lS_i.dtype not in (torch.int64, torch.int32) \
+                or lS_i.dim() < 1 or lS_i.shape[0] != self.n_tables or lS_i.numel() < self.n_tables \
+                or (lS_i.is_cuda and (lS_i.dtype != torch.int64 or not use_gpu)):
             return None
         from .. import _ext
         X = _ext.ext()

@@ -259,10 +259,25 @@ std::vector<at::Tensor> slices(const at::Tensor &block, bool requires_grad) {
     return rows;
 }
 
-py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i, int T, int d, int approx_thres, bool use_gpu, int device_index) {
-    TORCH_CHECK(!lS_i.is_cuda() && lS_i.dim() >= 1 && lS_i.size(0) == T && lS_i.numel() >= T, "lS_i must be a host tensor with one non-empty row per table");
+// lS_i may still be on the device (dlrm_wrap moved it there, dlrm_s_pytorch_C1.py:233-234 brings it back with .cpu(): a
+// pageable device-to-host copy, 20-25 us): then element 0 of each row comes over through a PINNED staging buffer (one
+// asynchronous copy + one stream synchronise), and with use_gpu the rows go back through pinned staging too (asynchronous:
+// the consumers are stream-ordered behind it; a staging slot is re-used four requests later, and every request
+// synchronises the stream first).
+py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i_in, int T, int d, int approx_thres, bool use_gpu, int device_index) {
+    TORCH_CHECK(lS_i_in.dim() >= 1 && lS_i_in.size(0) == T && lS_i_in.numel() >= T, "lS_i must have one non-empty row per table");
     int32_t ids[64];
     TORCH_CHECK(T <= 64, "at most 64 tables");
+    at::Tensor lS_i = lS_i_in;
+    if (lS_i_in.is_cuda()) {
+        static at::Tensor stage_ids;
+        if (!stage_ids.defined()) stage_ids = at::empty({64}, at::TensorOptions().dtype(at::kLong)).pin_memory();
+        TORCH_CHECK(lS_i_in.scalar_type() == at::kLong, "a device lS_i must be int64");
+        at::Tensor col = lS_i_in.dim() >= 2 ? lS_i_in.select(1, 0) : lS_i_in;
+        lS_i = stage_ids.narrow(0, 0, T);
+        lS_i.copy_(col, /*non_blocking=*/true);
+        c10::hip::getCurrentHIPStream(lS_i_in.device().index()).synchronize();
+    }
     if (lS_i.scalar_type() == at::kLong) {
         const int64_t *p = lS_i.data_ptr<int64_t>();
         const int64_t s0 = lS_i.stride(0);
@@ -273,10 +288,20 @@ py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i, int T, 
         const int64_t s0 = lS_i.stride(0);
         for (int k = 0; k < T; k++) ids[k] = p[k * s0];
     }
-    at::Tensor block = at::empty({T, 1, d}, at::TensorOptions().dtype(at::kFloat));
+    at::Tensor block;
     uint8_t hit[64];
-    check(evs_hostcache_request(reinterpret_cast<evs_hostcache *>(handle), 1, ids, block.data_ptr<float>(), hit, approx_thres));
-    if (use_gpu) block = block.to(c10::Device(c10::kCUDA, static_cast<c10::DeviceIndex>(device_index)));
+    if (use_gpu) {
+        static at::Tensor stage_rows[4];
+        static unsigned next_slot = 0;
+        at::Tensor &st = stage_rows[next_slot++ & 3u];
+        if (!st.defined() || st.size(0) != T || st.size(2) != d) st = at::empty({T, 1, d}, at::TensorOptions().dtype(at::kFloat)).pin_memory();
+        check(evs_hostcache_request(reinterpret_cast<evs_hostcache *>(handle), 1, ids, st.data_ptr<float>(), hit, approx_thres));
+        block = at::empty({T, 1, d}, at::TensorOptions().dtype(at::kFloat).device(c10::Device(c10::kCUDA, static_cast<c10::DeviceIndex>(device_index))));
+        block.copy_(st, /*non_blocking=*/true);
+    } else {
+        block = at::empty({T, 1, d}, at::TensorOptions().dtype(at::kFloat));
+        check(evs_hostcache_request(reinterpret_cast<evs_hostcache *>(handle), 1, ids, block.data_ptr<float>(), hit, approx_thres));
+    }
     py::list flags;
     bool all = true;
     for (int k = 0; k < T; k++) { flags.append(py::bool_(hit[k] != 0)); all = all && hit[k]; }

@@ -19,16 +19,17 @@ def apply_emb_evstore(lS_o, lS_i, emb_l, v_W_l, use_gpu=False, use_emb_cache=Fal
     """Takes element 0 of each table's index row (batch size 1, dlrm_s_pytorch_C1.py:236-239) -> 26 row
     ids -> cache / storage -> list of 26 Tensor(1,36).  lS_o, emb_l, v_W_l are ignored as in the reference."""
     global perfect_hit
-    if use_gpu:
-        lS_i = lS_i.cpu().data
     if use_emb_cache and cache_algo in _FAST:
-        # host engine + C++ extension: ids, policy and the 26 tensors in one call (same results as the generic path below)
+        # host engine + C++ extension: ids, policy and the 26 tensors in one call (same results as the generic path below);
+        # a device lS_i comes over through pinned staging inside that call instead of the reference's lS_i.cpu()
         mod = _FAST[cache_algo]
         r = mod._m.request_from_index_rows(lS_i, use_gpu, approx_emb_threshold if cache_algo == "evlfu" else -1)
         if r is not None:
             if r[2]:
                 perfect_hit += 1
             return r[1]
+    if use_gpu:
+        lS_i = lS_i.cpu().data
     group_rowIds = [int(sparse_index[0]) for sparse_index in lS_i.numpy()]
     if use_emb_cache:
         if cache_algo == "evlfu":
