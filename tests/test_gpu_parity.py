@@ -1120,6 +1120,8 @@ def test_extension_and_ctypes_call_paths_agree(E, orc, bits):
     lS_o-checked form, out=, check_indices) and the cache tier's lookup_interact give identical bits either way, and both
     equal the oracle."""
     from evstore_dlrm_amd import _ext
+    if os.environ.get("EVS_NO_EXT") == "1" or os.environ.get("EVS_LIB_PATH"):
+        pytest.skip("the extension is switched off in this environment (EVS_NO_EXT / EVS_LIB_PATH): only the ctypes path runs")
     X = _ext.ext()
     assert X is not None, "lib/_evs_torch_ext.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
     rs = np.random.RandomState(11 + bits)
