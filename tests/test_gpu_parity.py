@@ -1269,7 +1269,8 @@ def test_multi_batch_call_equals_single_launches(E, orc, K, B, declared):
             assert got[k].data_ptr() == outs[k].data_ptr()
             assert torch.equal(got[k], want[k]) and torch.equal(snap[k], want[k]) and torch.equal(alloc[k], want[k]), k
 
-    assert _ext.ext() is not None
+    ext_off = os.environ.get("EVS_NO_EXT") == "1" or bool(os.environ.get("EVS_LIB_PATH"))   # (then only the ctypes path exists)
+    assert ext_off or _ext.ext() is not None
     run()
     saved = (_ext._mod, _ext._tried)
     _ext._mod, _ext._tried = None, True
