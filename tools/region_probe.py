@@ -24,6 +24,7 @@ for i in range(3000):
     step(i)
 torch.cuda.synchronize()
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+MODE = sys.argv[2] if len(sys.argv) > 2 else "event"
 for rep in range(6):
     for i in range(300):
         step(i)
@@ -39,8 +40,13 @@ for rep in range(6):
     t3 = time.perf_counter()
     e1.record()
     t4 = time.perf_counter()
-    while not e1.query():
-        pass
+    if MODE == "event":
+        while not e1.query():
+            pass
+    else:   # poll the STREAM: hipStreamQuery retires completed commands as it goes
+        st = torch.cuda.current_stream()
+        while not st.query():
+            pass
     t5 = time.perf_counter()
     torch.cuda.synchronize()
     t6 = time.perf_counter()
