@@ -66,7 +66,7 @@ constexpr int kMlpRowStride = 452;   // floats per staged row: kp <= 448 (F <= 2
 // order, bad offsets / indices skipped and flagged -- the arithmetic of evs_fused.hip's general loop) and feeds the same
 // MFMA + output code: no flag, no second launch, as in the index-tile loop of evs_fused.hip and in evs_fused_rfq.hip.
 template <int CQ, int REM, int NT, int D, bool MLP = false, bool IDS = false, bool PROBE = false, bool CHECK = false>
-__global__ void __launch_bounds__(256, (MLP ? 3 : EVS_RF_LB)) emb_interact_rf_kernel(const FusedArgs args) {
+__global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) emb_interact_rf_kernel(const FusedArgs args) {
     static_assert(!CHECK || (!MLP && !IDS && !PROBE), "the offsets check belongs to the plain launch");
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
@@ -849,6 +849,14 @@ bool launch_rf_probe(const FusedArgs &a, hipStream_t st) {
 }
 
 // the same launch with lS_o given (whole batches, FusedArgs::bag1 == 3): the kernel checks the offsets of its 16 samples itself
+// d = 64 (the Terabyte scripts' width, round 3): the same kernel with CQ = 4 -- 16 lanes per row, 4 rows per load, 7 loads
+// per sample, 135 VGPRs (three blocks per CU).  Same box, B = 16 384: one index per bag declared 30.4 -> 25.6 us (0.59 -> 0.70 of
+// peak), lS_o given 33.2 -> 27.5 us; B = 65 536: 91.5 -> 89.5 us.
+static bool rf_d64() {
+    static const bool on = !(getenv("EVS_FUSED_RF_D64") && getenv("EVS_FUSED_RF_D64")[0] == '0');
+    return on;
+}
+
 bool launch_rf_check(const FusedArgs &a, hipStream_t st) {
     static const bool on = !(getenv("EVS_FUSED_RF_CHECK") && getenv("EVS_FUSED_RF_CHECK")[0] == '0');
     if (!on || !rf_mode() || a.F > kTileMaxF || a.bag1 != 3 || a.B > rf_max_batch()) return false;
@@ -863,6 +871,10 @@ bool launch_rf_check(const FusedArgs &a, hipStream_t st) {
     case 36:
         if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 1, 2, EVS_RF_DEPTH, false, false, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 1, 1, EVS_RF_DEPTH, false, false, false, true>>(a, st);
         return true;
+    case 64:
+        if (!rf_d64()) return false;
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<4, 0, 2, EVS_RF_DEPTH, false, false, false, true>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<4, 0, 1, EVS_RF_DEPTH, false, false, false, true>>(a, st);
+        return true;
     default:
         return false;
     }
@@ -872,7 +884,7 @@ bool launch_rf_check(const FusedArgs &a, hipStream_t st) {
 // drain of a batch's last blocks runs under the fill of the next batch's first ones (what two alternating streams give a
 // caller, without any stream: cross-stream event waits cost more here than they return -- measured)
 bool rf_multi_supported(int64_t B, int F, int d) {
-    return rf_mode() && F <= kTileMaxF && B >= 1 && (d == 16 || d == 32 || d == 36);
+    return rf_mode() && F <= kTileMaxF && B >= 1 && (d == 16 || d == 32 || d == 36 || (d == 64 && rf_d64()));
 }
 template <auto K>
 static void launch_rf_multi_grid(FusedArgs a, hipStream_t st) {
@@ -897,6 +909,7 @@ bool launch_rf_multi(const FusedArgs &a, hipStream_t st) {
     case 16: EVS_RF_MULTI(1, 0); return true;
     case 32: EVS_RF_MULTI(2, 0); return true;
     case 36: EVS_RF_MULTI(2, 1); return true;
+    case 64: EVS_RF_MULTI(4, 0); return true;
     default: return false;
     }
 #undef EVS_RF_MULTI
@@ -909,6 +922,7 @@ bool launch_rf_multi(const FusedArgs &a, hipStream_t st) {
 // checked form: 65.6 vs 65.7 us at 65 536).  EVS_FUSED_RF_MAX_B, when set, bounds every form.
 static int64_t rf_max_batch_plain(int d) {
     if (getenv("EVS_FUSED_RF_MAX_B") || d == 32) return rf_max_batch();
+    if (d == 64) return 1ll << 22;
     return 1ll << 22;
 }
 
@@ -925,7 +939,12 @@ bool launch_rf(const FusedArgs &a, hipStream_t st) {
     case 36:
         if (nt2) launch_rf_grid<emb_interact_rf_kernel<2, 1, 2, EVS_RF_DEPTH>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<2, 1, 1, EVS_RF_DEPTH>>(a, st);
         return true;
-    default:
+    case 64:   // 28 VGPRs per sample in flight (135 in all: three blocks per CU); EVS_FUSED_RF_D64=0: the LDS-DMA loop
+        if (!rf_d64()) return false;
+        if (nt2) launch_rf_grid<emb_interact_rf_kernel<4, 0, 2, EVS_RF_DEPTH>>(a, st); else launch_rf_grid<emb_interact_rf_kernel<4, 0, 1, EVS_RF_DEPTH>>(a, st);
+        return true;
+    default:   // (d = 128 was built the same way -- CQ = 8, 14 loads per sample, 248 VGPRs, one or two blocks per CU -- and lost to the
+               //  LDS-DMA loop: 57.5 vs 52.5 us at B = 16 384, 220 vs 182 us at 65 536; removed)
         return false;
     }
 }

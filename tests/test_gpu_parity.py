@@ -550,7 +550,7 @@ def test_rows_in_registers_gather_vs_oracle(E, orc, d, T, B):
             E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
-@pytest.mark.parametrize("d,B", [(36, 40000 + 7), (16, 36000 + 1), (32, 33000), (36, 131072 + 5)])
+@pytest.mark.parametrize("d,B", [(36, 40000 + 7), (16, 36000 + 1), (32, 33000), (36, 131072 + 5), (64, 16384 + 33), (64, 40000 + 1), (64, 2048 + 5)])
 def test_fused_fp32_large_batch(E, orc, d, B):
     """fp32 tables, batches of several resident generations: the one-index-declared launch runs the rows-in-registers
     one-chunk kernel there too since round 3 (d = 36 / 16; d = 32 keeps the LDS-DMA loop), lS_o given is checked inside
