@@ -1200,7 +1200,7 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
             if constexpr (HAS_INDIRECT && !WEIGHTED) {
                 if constexpr (!PTRS && CODEC == 32) {   // (encoded rows: no gain for u8 / u4, slower for u16 -- measured)
                     if (a.bag1 == 1 && tile_eligible(a, CODEC)) {
-                        if (launch_rf(a, st)) return;   // rows in flight in registers (evs_fused_rf.hip): d = 16 / 32 / 36
+                        if (launch_rf(a, st)) return;   // rows in flight in registers (evs_fused_rf.hip): d = 16 / 32 / 36 / 64
                         if (nt2) launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                         else launch_tile<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, true, true>>(a, st);
                         return;
