@@ -320,7 +320,7 @@ typedef const __attribute__((address_space(1))) gr_f32x4 *gr_gf4_t;
 typedef const __attribute__((address_space(1))) int64_t *gr_gi64_t;
 
 template <int LPRD, int NJ, bool CHECK>
-__global__ void __launch_bounds__(256, 4) gather_rows_kernel(const GatherArgs args) {
+__global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(const GatherArgs args) {
     constexpr int RPI = 64 / LPRD;
     constexpr int row_bytes = LPRD * 16;
     static_assert(NJ * RPI <= 32, "one tile row per table");
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256, 4) gather_rows_kernel(const GatherArgs ar
 // is there a rows-in-registers gather for the launch, and launch it
 static bool launch_gather_rows(const GatherArgs &a, bool vec_ok, hipStream_t stream, bool bag1) {
     static const bool on = !(getenv("EVS_GATHER_RF") && getenv("EVS_GATHER_RF")[0] == '0');
-    if (!on || !vec_ok || a.T > 32 || !(a.d == 16 || a.d == 32 || a.d == 36) || !zero_page()) return false;
+    if (!on || !vec_ok || a.T > 32 || !(a.d == 16 || a.d == 32 || a.d == 36 || a.d == 64) || !zero_page()) return false;
     for (int k = 0; k < a.T; k++) {
         if (a.row_w[k] || a.n_rows[k] >= (1ll << 31)) return false;
         if (!bag1 && a.nnz[k] != a.B) return false;   // offsets given: the bet is on whole batches of one-index bags
@@ -485,6 +485,10 @@ static bool launch_gather_rows(const GatherArgs &a, bool vec_ok, hipStream_t str
         return true; \
     } while (0)
     if (a.d == 16) { if (nj <= 1) EVS_GR(4, 1); EVS_GR(4, 2); }
+    if (a.d == 64) {   // 16 lanes per row, 4 rows per instruction: T <= 28 (7 instructions per sample: two blocks per CU)
+        if (nj <= 2) EVS_GR(16, 2); if (nj <= 4) EVS_GR(16, 4); if (nj <= 7) EVS_GR(16, 7);
+        return false;
+    }
     if (a.d == 32) { if (nj <= 1) EVS_GR(8, 1); if (nj <= 2) EVS_GR(8, 2); if (nj <= 3) EVS_GR(8, 3); EVS_GR(8, 4); }
     if (nj <= 1) EVS_GR(9, 1); if (nj <= 2) EVS_GR(9, 2); if (nj <= 3) EVS_GR(9, 3); if (nj <= 4) EVS_GR(9, 4);
     return false;   // (d = 36, T in 29..32: a fifth instruction would address tile rows past 31 -- the grid-stride kernel)

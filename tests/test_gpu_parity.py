@@ -504,7 +504,8 @@ def test_fused_codec_large_batch(E, orc, codec, d, B):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
-@pytest.mark.parametrize("d,T,B", [(36, 26, 5000 + 3), (36, 28, 300), (36, 1, 17), (16, 32, 2049), (32, 26, 1), (32, 32, 4100), (16, 8, 64), (36, 30, 500)])
+@pytest.mark.parametrize("d,T,B", [(36, 26, 5000 + 3), (36, 28, 300), (36, 1, 17), (16, 32, 2049), (32, 26, 1), (32, 32, 4100), (16, 8, 64), (36, 30, 500),
+                                   (64, 26, 3000 + 1), (64, 7, 130), (64, 28, 40), (64, 30, 100)])
 def test_rows_in_registers_gather_vs_oracle(E, orc, d, T, B):
     """apply_emb alone (the two-call plugin surface) on whole batches of one-index bags runs gather_rows_kernel (round 3:
     16 samples of all tables per block, rows in flight in registers; d = 36 with T > 28 keeps the grid-stride kernel).
