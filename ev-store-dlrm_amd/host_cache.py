@@ -143,6 +143,9 @@ def request_c1c2c3(c1, c2, c3, rows, high_agghit_threshold=23, out=None, tier=No
         out = np.empty((B, c1.n_tables, c1.dim), np.float32)
     if tier is None:
         tier = np.empty((B, c1.n_tables), np.uint8)
+    if not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.size == B * c1.n_tables * c1.dim
+            and isinstance(tier, np.ndarray) and tier.dtype == np.uint8 and tier.flags["C_CONTIGUOUS"] and tier.size == B * c1.n_tables):
+        raise ValueError("out must be a C-contiguous float32 array of B * n_tables * dim elements, tier a uint8 one of B * n_tables")
     _lib.check(_lib.lib().evs_hostcache_request_c1c2c3(c1._h, c2._h, c3._h if c3 is not None else None, B, rows.ctypes.data,
                                                        out.ctypes.data, tier.ctypes.data, int(high_agghit_threshold)))
     return tier, out

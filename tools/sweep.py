@@ -213,6 +213,20 @@ def exact_rows(ev, ln, d, n_req):
     out.append("| C1 u8 (9 000) + C2 u4 (18 000) exact (cfg 5) | 1 | %.1f | %.1f | C1 %.3f / C2 %.3f (of the next 2048 requests) |" % (
         np.percentile(lat[200:], 50), np.percentile(lat[200:], 95), n_c1 / (2048 * T), n_c2 / (2048 * T)))
     del c1, c2
+    # the same two-tier request stream through the HOST engine (evs_hostcache_request_c1c2c3: what ev_lookup runs by default
+    # with N_CACHING_LAYER = 2), encoded tables in host memory
+    h1 = HC.HostCache("evlfu", 9000, T, d, 8, "cpp").set_backing([t.cpu().numpy() for t in ev8.raw])
+    h2 = HC.HostCache("evlfu", 18000, T, d, 4, "cpp").set_backing([t.cpu().numpy() for t in ev4.raw])
+    t_np = np.empty((1, T), np.uint8)
+    lat = []
+    for i in range(n_req):
+        t0 = time.perf_counter()
+        HC.request_c1c2c3(h1, h2, None, hr[i:i + 1], out=o_np, tier=t_np)
+        lat.append((time.perf_counter() - t0) * 1e6)
+    t_all, _ = HC.request_c1c2c3(h1, h2, None, hr[:2048])
+    out.append("| C1 u8 (9 000) + C2 u4 (18 000) exact (cfg 5), HOST engine | 1 | %.1f | %.1f | C1 %.3f / C2 %.3f (of the next 2048 requests) |" % (
+        np.percentile(lat[200:], 50), np.percentile(lat[200:], 95), float((t_all == 1).sum()) / (2048 * T), float((t_all == 2).sum()) / (2048 * T)))
+    del h1, h2
     # cfg 5 as a throughput path: batched two-tier lookup (snapshot semantics), tiers sized 48 % : 48 % of a budget
     # of 2 % of the rows in fp32-row equivalents (u8 entries cost 1/4, u4 entries 1/8: evlfu_8.cpp:63-78)
     budget = int(0.02 * sum(ln))   # 2 % so that C1 fills inside the warm-up and the routing to C2 starts
