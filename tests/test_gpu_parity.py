@@ -1244,14 +1244,15 @@ def test_sharded_hip_world8_and_rowsplit_virtual_ranks(E, orc, world, policy, ba
         assert torch.equal(out, R), (policy, r)
 
 
-@pytest.mark.parametrize("K,B,declared", [(2, 16384, True), (5, 4096, False), (3, 1000, True), (1, 777, False)])
-def test_multi_batch_call_equals_single_launches(E, orc, K, B, declared):
-    """evs_emb_interact_dot_stacked_multi (K batches in one call, alternating over the library's stream pair, forked from
-    and joined into the caller's stream) == K single launches, bit for bit; the join really orders the caller's stream
-    behind all K results (a copy queued right after the call sees them); through the extension and through ctypes."""
+@pytest.mark.parametrize("K,B,declared,d", [(2, 16384, True, 36), (5, 4096, False, 36), (3, 1000, True, 36), (1, 777, False, 36), (9, 2048, True, 36),
+                                             (3, 5000, False, 64), (2, 300, True, 16), (4, 1200, False, 48)])
+def test_multi_batch_call_equals_single_launches(E, orc, K, B, declared, d):
+    """evs_emb_interact_dot_stacked_multi (K batches in one call: ONE launch per 8 batches for the rows-in-registers shapes
+    -- d = 16 / 32 / 36 / 64 --, K single launches for the others) == K single launches, bit for bit; a copy queued on the
+    caller's stream right after the call sees all K results; through the extension and through ctypes."""
     from evstore_dlrm_amd import _ext
     rs = np.random.RandomState(K * 1000 + B)
-    T, d = 26, 36
+    T = 26
     n_rows = [int(v) for v in rs.choice([3, 40, 999, 200000], size=T)]
     ev = E.EVTables.from_fp32([torch.from_numpy(rs.uniform(-1, 1, size=(n, d)).astype(np.float32)) for n in n_rows])
     xs = [torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda() for _ in range(K)]
