@@ -103,6 +103,7 @@ struct evs_filetier {
     long long pinned_bytes = 0;
     int n_threads = 8;
     ReaderPool *pool = nullptr;         // created by the first fetch that is worth it
+    std::mutex pool_mu;                 // ... under this lock (two caches of two threads may share a tier)
 };
 
 namespace {
@@ -216,11 +217,16 @@ extern "C" int evs_filetier_fetch(evs_filetier *ft, int64_t n, const uint64_t *k
         }
         return EVS_OK;
     }
-    if (!ft->pool) {
-        ft->pool = new ReaderPool();
-        ft->pool->start(ft->n_threads - 1);
+    ReaderPool *pool;
+    {
+        std::lock_guard<std::mutex> lk(ft->pool_mu);
+        if (!ft->pool) {
+            ft->pool = new ReaderPool();
+            ft->pool->start(ft->n_threads - 1);
+        }
+        pool = ft->pool;
     }
-    ft->pool->run(ft, keys, static_cast<char *>(dst), n, skip_mask);
+    pool->run(ft, keys, static_cast<char *>(dst), n, skip_mask);
     return EVS_OK;
 }
 
