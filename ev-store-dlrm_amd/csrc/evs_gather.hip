@@ -465,6 +465,153 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
     if (bad) atomicOr(args.err, 1);
 }
 
+// ---- multi-hot bags, fp32, unweighted: rows through LDS, every lane busy (round 3) ------------------------------------------
+// The grid-stride kernel above gives a lane group a BAG: with bags of 1..10 indices every lane of a wave loops to the
+// longest of its 28 bags, an index load and a dependent row load per trip -- half the lanes idle, twice the memory
+// instructions, 2 n dependent round trips for a bag of n.  Here a lane group takes a LOOKUP: a block owns 64 consecutive
+// bags of one table = one contiguous run of that table's index array (offsets valid and monotone -- checked; a block that
+// finds anything else pools its bags one by one, flagged as the kernel above flags them).  The run is walked in tiles of
+// 16 load instructions per block: the tile's indices in one coalesced round trip, its rows in the next (LPRD lanes per row,
+// every lane of every instruction busy), into LDS; then thread (bag, 16-byte piece) adds its bag's rows of the tile IN
+// INDEX ORDER (sequential fp32 adds from LDS: bit-exact with the oracle's loop), carrying its partial sum across tiles.
+template <int LPRD>
+__global__ void __launch_bounds__(256) bag_sum_flat_kernel(const GatherArgs args) {
+    constexpr int RPI = 64 / LPRD;              // rows per load instruction
+    constexpr int kInstr = 4;                   // load instructions per wave and tile
+    constexpr int TILE = 4 * kInstr * RPI;      // rows per tile (d = 36: 112 rows = 16 KB)
+    constexpr int BAGS = 64;
+    constexpr int row_bytes = LPRD * 16;
+    constexpr int kItems = (BAGS * LPRD + 255) / 256;   // (bag, piece) sums per thread
+    __shared__ __attribute__((aligned(16))) float4 s_tile[TILE * LPRD];
+    __shared__ unsigned char s_ok[TILE];
+    __shared__ int64_t s_st[BAGS + 1];          // bag starts; [nb] = the end of the last bag
+    __shared__ int s_bad;
+    const int64_t B = args.B;
+    const int chunks = (int)((B + BAGS - 1) / BAGS);
+    const int t = (int)(blockIdx.x / chunks);
+    const int64_t b0 = (int64_t)(blockIdx.x - (unsigned)t * chunks) * BAGS;
+    const int nb = (int)(B - b0 < BAGS ? B - b0 : BAGS);
+    const GatherArgs *ka = (const GatherArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int64_t *idx = ka->indices[t], *off = ka->offsets[t];
+    const char *W = reinterpret_cast<const char *>(ka->table[t]);
+    const int64_t nnz = ka->nnz[t], n_rows = ka->n_rows[t], row_lo = ka->row_lo[t], row_total = ka->row_total[t];
+    if (threadIdx.x == 0) s_bad = 0;
+    if ((int)threadIdx.x <= nb) {
+        const int64_t b = b0 + threadIdx.x;
+        s_st[threadIdx.x] = b < B ? off[b] : nnz;
+    }
+    __syncthreads();
+    bool bad = false;
+    if ((int)threadIdx.x < nb) {                 // every bag of the chunk a valid [start, end) inside the index array?
+        const int64_t st = s_st[threadIdx.x], en = s_st[threadIdx.x + 1];
+        if (!(st >= 0 && en >= st && en <= nnz)) atomicOr(&s_bad, 1);
+    }
+    __syncthreads();
+    const bool peers = (int64_t)args.bags_per_peer < B;
+    auto out_ptr = [&](int64_t b, int piece) -> float4 * {
+        int64_t o = b * args.out_bstride;
+        if (peers) {
+            const unsigned q = (unsigned)b / args.bags_per_peer;
+            o = (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+        }
+        return reinterpret_cast<float4 *>(args.out + (int64_t)t * args.out_tstride + o + piece * 4);
+    };
+    if (s_bad) {   // rare: a bad offset in the chunk -- bag by bag, the bad ones empty and flagged
+        for (int wk = (int)threadIdx.x; wk < nb * LPRD; wk += 256) {
+            const int i = wk / LPRD, piece = wk - i * LPRD;
+            const int64_t b = b0 + i;
+            int64_t st = off[b], en = (b + 1 < B) ? off[b + 1] : nnz;
+            if (!(st >= 0 && en >= st && en <= nnz)) { bad = true; st = en = 0; }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int64_t j = st; j < en; j++) {
+                int64_t r = idx[j];
+                if (r < 0 || r >= row_total) { bad = true; continue; }
+                r -= row_lo;
+                if (r < 0 || r >= n_rows) continue;
+                const float4 x = reinterpret_cast<const float4 *>(W + r * row_bytes)[piece];
+                acc.x = __fadd_rn(acc.x, x.x); acc.y = __fadd_rn(acc.y, x.y); acc.z = __fadd_rn(acc.z, x.z); acc.w = __fadd_rn(acc.w, x.w);
+            }
+            *out_ptr(b, piece) = acc;
+        }
+        if (bad) atomicOr(args.err, 1);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int g = lane / LPRD, piece = lane - g * LPRD;
+    const bool lane_on = g < RPI;
+    const int64_t lo = s_st[0], hi = s_st[nb];
+    float4 acc[kItems];
+    int my_bag[kItems], my_piece[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const int wk = (int)threadIdx.x + 256 * k;
+        acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        my_bag[k] = wk < nb * LPRD ? wk / LPRD : -1;
+        my_piece[k] = wk - (wk / LPRD) * LPRD;
+    }
+    for (int64_t base = lo; base < hi; base += TILE) {
+        // the tile's indices (one round trip), then its rows (the next): slot = (wave * kInstr + k) * RPI + g
+        int64_t v[kInstr];
+#pragma unroll
+        for (int k = 0; k < kInstr; k++) {
+            const int64_t e = base + (wave * kInstr + k) * RPI + g;
+            v[k] = (lane_on && e < hi) ? idx[e] : -2;
+        }
+#pragma unroll
+        for (int k = 0; k < kInstr; k++) {
+            const int slot = (wave * kInstr + k) * RPI + g;
+            int64_t r = -1;
+            if (v[k] >= 0 && v[k] < row_total) { r = v[k] - row_lo; if (r < 0 || r >= n_rows) r = -1; }
+            else if (v[k] != -2) bad = true;
+            if (lane_on) {
+                if (r >= 0) s_tile[slot * LPRD + piece] = reinterpret_cast<const float4 *>(W + r * row_bytes)[piece];
+                if (piece == 0) s_ok[slot] = r >= 0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItems; k++) {
+            if (my_bag[k] >= 0) {
+                int64_t a = s_st[my_bag[k]], b = s_st[my_bag[k] + 1];
+                a = a > base ? a : base;
+                b = b < base + TILE ? b : base + TILE;
+                for (int64_t e = a; e < b; e++) {   // index order
+                    const int slot = (int)(e - base);
+                    if (s_ok[slot]) {
+                        const float4 x = s_tile[slot * LPRD + my_piece[k]];
+                        acc[k].x = __fadd_rn(acc[k].x, x.x); acc[k].y = __fadd_rn(acc[k].y, x.y);
+                        acc[k].z = __fadd_rn(acc[k].z, x.z); acc[k].w = __fadd_rn(acc[k].w, x.w);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < kItems; k++)
+        if (my_bag[k] >= 0) *out_ptr(b0 + my_bag[k], my_piece[k]) = acc[k];
+    if (bad) atomicOr(args.err, 1);
+}
+
+static bool launch_bag_sum_flat(const GatherArgs &a, bool vec_ok, hipStream_t stream) {
+    static const bool on = !(getenv("EVS_GATHER_FLAT") && getenv("EVS_GATHER_FLAT")[0] == '0');
+    if (!on || !vec_ok || !(a.d == 16 || a.d == 32 || a.d == 36 || a.d == 64)) return false;
+    int64_t nnz = 0;
+    for (int k = 0; k < a.T; k++) { if (a.row_w[k] || !a.offsets[k]) return false; nnz += a.nnz[k]; }
+    // long bags: a tile then holds the rows of two or three bags and as few (bag, piece) threads do all the adding -- the
+    // grid-stride kernel's lane group per bag is the better form there (bags of ~38 indices, B = 2 048: 229 vs 352 us)
+    if (nnz > 16 * a.B * (int64_t)a.T) return false;
+    const int64_t chunks = (a.B + 63) / 64;
+    if (chunks * a.T >= (1ll << 31)) return false;
+    const dim3 grid((unsigned)(chunks * a.T)), block(256);
+    switch (a.d) {
+    case 16: hipLaunchKernelGGL(bag_sum_flat_kernel<4>, grid, block, 0, stream, a); return true;
+    case 32: hipLaunchKernelGGL(bag_sum_flat_kernel<8>, grid, block, 0, stream, a); return true;
+    case 36: hipLaunchKernelGGL(bag_sum_flat_kernel<9>, grid, block, 0, stream, a); return true;
+    default: hipLaunchKernelGGL(bag_sum_flat_kernel<16>, grid, block, 0, stream, a); return true;
+    }
+}
+
 // is there a rows-in-registers gather for the launch, and launch it
 static bool launch_gather_rows(const GatherArgs &a, bool vec_ok, hipStream_t stream, bool bag1) {
     static const bool on = !(getenv("EVS_GATHER_RF") && getenv("EVS_GATHER_RF")[0] == '0');
@@ -586,6 +733,7 @@ extern "C" int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec,
         a.chunks_per_table = 0;
         a.zeros = nullptr;
         if (codec == 32 && launch_gather_rows(a, vec_ok, st, bag1)) { EVS_HIP_CHECK(hipGetLastError()); continue; }
+        if (codec == 32 && !bag1 && launch_bag_sum_flat(a, vec_ok, st)) { EVS_HIP_CHECK(hipGetLastError()); continue; }
         switch (codec) {
         case 32: launch_codec<32>(a, vec_ok, st, bag1); break;
         case 16: launch_codec<16>(a, vec_ok, st, bag1); break;

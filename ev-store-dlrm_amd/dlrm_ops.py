@@ -220,6 +220,14 @@ def _as_evtables(emb_l):
     return ev
 
 
+def B_of(lS_o):
+    """batch size of a list-form offsets argument (0: not a non-empty list of 1-D tensors)"""
+    try:
+        return int(lS_o[0].shape[0]) if len(lS_o) and lS_o[0].dim() == 1 else 0
+    except Exception:
+        return 0
+
+
 def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy=None, one_index_per_bag=False):
     """Drop-in for DLRM_Net.apply_emb (dlrm_s_pytorch.py:407-461).
 
@@ -250,6 +258,15 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy
         if xt is not None:   # the C++ extension: checks, the (T,B,d) buffer and the launch without Python in between
             X = _ext.ext()
             buf = X.apply_emb(xt, lS_o, lS_i, one_index_per_bag, check_indices)
+            ly = _PooledList(X.slices(buf, False))
+            B = int(buf.shape[1])
+            ly._evs_meta = (buf.data_ptr(), B * d, d, B, d, T)
+            return ly
+    if out is None and not stacked_i and not stacked_o and (v_W_l is None or all(w is None for w in v_W_l)) and B_of(lS_o) > 0:
+        xt = ev.ext_tables()
+        if xt is not None and all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 and t.dim() == 1 for t in list(lS_o) + list(lS_i)):
+            X = _ext.ext()   # list form (the reference's random-data loader): pointer tables built in C++
+            buf = X.apply_emb_list(xt, list(lS_o), list(lS_i), bool(one_index_per_bag), bool(check_indices))
             ly = _PooledList(X.slices(buf, False))
             B = int(buf.shape[1])
             ly._evs_meta = (buf.data_ptr(), B * d, d, B, d, T)
@@ -387,6 +404,13 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
         if xt is not None:   # the C++ extension: checks, output and the launch without Python in between
             return _ext.ext().apply_emb_interact(xt, x, lS_o, lS_i, bool(arch_interaction_itself), out,
                                                  bool(one_index_per_bag), bool(check_indices))
+    # genuinely multi-hot batches in list form (fp32, unweighted): the pooling kernel that gives a lane group a LOOKUP and
+    # reduces through LDS (csrc/evs_gather.hip: bag_sum_flat_kernel) + the interaction kernel beat the fused general
+    # loop, whose lane groups own bags (B = 16 384, ~5 indices per bag: 92 vs 133 us); same bits either way
+    if out is None and ev.codec == 32 and not torch.is_tensor(lS_i) and not torch.is_tensor(lS_o) and \
+            (v_W_l is None or all(w is None for w in v_W_l)) and d in (16, 32, 36, 64) and \
+            all(int(o.numel()) == B for o in lS_o) and B * T < sum(int(i.numel()) for i in lS_i) <= 16 * B * T:
+        return interact_features(x, apply_emb(lS_o, lS_i, ev, None, lazy=False, check_indices=check_indices), "dot", arch_interaction_itself)
     P = F * (F + 1) // 2 if arch_interaction_itself else F * (F - 1) // 2
     R = out if out is not None else torch.empty((B, d + P), dtype=torch.float32, device=dev)
     assert R.shape == (B, d + P) and R.is_contiguous() and R.dtype == torch.float32
@@ -434,9 +458,9 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
 
 def apply_emb_interact_multi(xs, lS_os, lS_is, emb_l, arch_interaction_itself=False, outs=None, one_index_per_bag=False):
     """K independent batches -- lists of K x (B,d), lS_o (T,B) (or None with one_index_per_bag), lS_i (T,B) -- in ONE call:
-    [apply_emb_interact(xs[k], lS_os[k], lS_is[k], emb_l) for k in range(K)], bit for bit, with batch k on the library's
-    own stream k % 2 (forked from and joined back into torch's current stream): the drain of one launch overlaps the fill
-    of the next, the rate of a caller alternating two streams without managing any (evs_emb_interact_dot_stacked_multi).
+    [apply_emb_interact(xs[k], lS_os[k], lS_is[k], emb_l) for k in range(K)], bit for bit, as ONE launch per 8 batches for
+    the rows-in-registers shapes (evs_emb_interact_dot_stacked_multi: a batch's last blocks drain under the next batch's
+    first ones -- the rate of a caller alternating two streams, without any stream), K single launches otherwise.
     Stacked Criteo layout, unweighted; every batch the same shape."""
     ev = _as_evtables(emb_l)
     K = len(xs)

@@ -551,6 +551,61 @@ def test_rows_in_registers_gather_vs_oracle(E, orc, d, T, B):
             E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
+@pytest.mark.parametrize("d,T,B,max_bag", [(36, 26, 1000 + 3, 10), (16, 8, 128, 10), (32, 5, 65, 40), (64, 3, 700, 6), (36, 2, 64, 300), (36, 40, 50, 5)])
+def test_multi_hot_gather_through_lds_vs_oracle(E, orc, d, T, B, max_bag):
+    """Genuinely multi-hot bags in list form (the reference's random-data loader, dlrm_data_pytorch.py:1024-1065) run
+    bag_sum_flat_kernel (round 3: a lane group per LOOKUP, 64 bags of one table per block, rows through LDS, each bag's
+    rows added in index order): bit-exact vs the oracle's sequential EmbeddingBag-sum -- empty bags, bags longer than a
+    tile (112 rows), a batch that is not a whole number of 64-bag chunks, T above the stacked kernels' limit; bad indices
+    (skipped, flagged) and a bad offset (that bag empty, flagged); apply_emb_interact over the same batch = the two calls."""
+    rs = np.random.RandomState(7 * d + T + B)
+    ln = [int(rs.choice([1, 3, 40, 700, 9000])) for _ in range(T)]
+    ws = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    ev = E.EVTables.from_fp32([torch.from_numpy(w) for w in ws])
+    off, idx = [], []
+    for n in ln:
+        sizes = np.round(rs.rand(B) * max_bag).astype(np.int64)     # 0 .. max_bag: empty bags included
+        sizes[rs.randint(0, B)] = max_bag + 150                      # one bag well above a tile
+        o = np.zeros(B, np.int64); o[1:] = np.cumsum(sizes)[:-1]
+        off.append(o); idx.append(rs.randint(0, n, size=int(sizes.sum())).astype(np.int64))
+    want = np.stack(orc.apply_emb(off, idx, ws))
+    lo, li = [torch.from_numpy(o).cuda() for o in off], [torch.from_numpy(i).cuda() for i in idx]
+    got = torch.stack(E.apply_emb(lo, li, ev, None, lazy=False, check_indices=True)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if T + 1 <= 28:
+        x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+        R = E.apply_emb_interact(x, lo, li, ev)
+        assert torch.equal(R, E.interact_features(x, E.apply_emb(lo, li, ev, None, lazy=False)))
+        R_o = orc.interact_features(x.cpu().numpy(), list(want))
+        # (pooled rows of 150-index bags are O(10): the absolute floor of an fp32 dot product scales with the operands)
+        np.testing.assert_allclose(R.cpu().numpy(), R_o, rtol=RTOL, atol=2e-6 * max(1.0, float(np.abs(R_o).max())))
+    # bad indices: skipped (the bag's other rows still summed), flag raised
+    idx2 = [i.copy() for i in idx]
+    k = int(np.argmax([i.size for i in idx2]))
+    idx2[k][0] = ln[k]
+    idx2[k][-1] = -3
+    w2 = [w for w in ws]
+    r = torch.stack(E.apply_emb(lo, [torch.from_numpy(i).cuda() for i in idx2], ev, None, lazy=False)).cpu().numpy()
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    # the oracle's view of the same batch with the two bad entries dropped from their bags
+    o_k = off[k].copy()
+    keep = np.ones(idx2[k].size, bool); keep[0] = keep[-1] = False
+    o_k2 = np.array([keep[:s].sum() for s in o_k], np.int64)
+    wk = orc.embedding_bag_sum(ws[k], idx2[k][keep], o_k2)
+    assert np.array_equal(r[k].view(np.uint32), wk.view(np.uint32))
+    # a bad offset (past the index array): that bag is empty, flag raised, every other bag as before
+    off3 = [o.copy() for o in off]
+    b_bad = B // 2
+    off3[0][b_bad] = idx[0].size + 7
+    r3 = torch.stack(E.apply_emb([torch.from_numpy(o).cuda() for o in off3], li, ev, None, lazy=False)).cpu().numpy()
+    with pytest.raises(E.EvsError):
+        E._lib.check(E._lib.lib().evs_check_index_errors(None))
+    others = np.ones(B, bool); others[[b_bad - 1, b_bad]] = False   # (bag b_bad - 1 ends at the bad offset too)
+    assert np.array_equal(r3[0][others], want[0][others]) and not r3[0][b_bad].any()
+    assert np.array_equal(r3[1:], want[1:])
+
+
 @pytest.mark.parametrize("d,B", [(36, 40000 + 7), (16, 36000 + 1), (32, 33000), (36, 131072 + 5), (64, 16384 + 33), (64, 40000 + 1), (64, 2048 + 5)])
 def test_fused_fp32_large_batch(E, orc, d, B):
     """fp32 tables, batches of several resident generations: the one-index-declared launch runs the rows-in-registers
