@@ -474,7 +474,10 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
 // 16 load instructions per block: the tile's indices in one coalesced round trip, its rows in the next (LPRD lanes per row,
 // every lane of every instruction busy), into LDS; then thread (bag, 16-byte piece) adds its bag's rows of the tile IN
 // INDEX ORDER (sequential fp32 adds from LDS: bit-exact with the oracle's loop), carrying its partial sum across tiles.
-template <int LPRD>
+// SEL (long bags: an average above 16 indices): the reduction skips an invalid row with a SELECT of the old sum and is unrolled
+// four deep, so that the LDS reads of a long bag pipeline (a branch per row: 352 us for bags of ~38 indices, the select
+// 218); short bags keep the branch (74 vs 81 us at ~5 indices per bag)
+template <int LPRD, bool SEL>
 __global__ void __launch_bounds__(256) bag_sum_flat_kernel(const GatherArgs args) {
     constexpr int RPI = 64 / LPRD;              // rows per load instruction
     constexpr int kInstr = 4;                   // load instructions per wave and tile
@@ -575,12 +578,22 @@ __global__ void __launch_bounds__(256) bag_sum_flat_kernel(const GatherArgs args
                 int64_t a = s_st[my_bag[k]], b = s_st[my_bag[k] + 1];
                 a = a > base ? a : base;
                 b = b < base + TILE ? b : base + TILE;
-                for (int64_t e = a; e < b; e++) {   // index order
-                    const int slot = (int)(e - base);
-                    if (s_ok[slot]) {
+                const int s0 = (int)(a - base), s1 = (int)(b - base);
+                if constexpr (SEL) {
+#pragma unroll 4
+                    for (int slot = s0; slot < s1; slot++) {   // index order
+                        const bool ok = s_ok[slot] != 0;
                         const float4 x = s_tile[slot * LPRD + my_piece[k]];
-                        acc[k].x = __fadd_rn(acc[k].x, x.x); acc[k].y = __fadd_rn(acc[k].y, x.y);
-                        acc[k].z = __fadd_rn(acc[k].z, x.z); acc[k].w = __fadd_rn(acc[k].w, x.w);
+                        const float4 n4 = make_float4(__fadd_rn(acc[k].x, x.x), __fadd_rn(acc[k].y, x.y), __fadd_rn(acc[k].z, x.z), __fadd_rn(acc[k].w, x.w));
+                        acc[k].x = ok ? n4.x : acc[k].x; acc[k].y = ok ? n4.y : acc[k].y; acc[k].z = ok ? n4.z : acc[k].z; acc[k].w = ok ? n4.w : acc[k].w;
+                    }
+                } else {
+                    for (int slot = s0; slot < s1; slot++) {   // index order
+                        if (s_ok[slot]) {
+                            const float4 x = s_tile[slot * LPRD + my_piece[k]];
+                            acc[k].x = __fadd_rn(acc[k].x, x.x); acc[k].y = __fadd_rn(acc[k].y, x.y);
+                            acc[k].z = __fadd_rn(acc[k].z, x.z); acc[k].w = __fadd_rn(acc[k].w, x.w);
+                        }
                     }
                 }
             }
@@ -598,18 +611,23 @@ static bool launch_bag_sum_flat(const GatherArgs &a, bool vec_ok, hipStream_t st
     if (!on || !vec_ok || !(a.d == 16 || a.d == 32 || a.d == 36 || a.d == 64)) return false;
     int64_t nnz = 0;
     for (int k = 0; k < a.T; k++) { if (a.row_w[k] || !a.offsets[k]) return false; nnz += a.nnz[k]; }
-    // long bags: a tile then holds the rows of two or three bags and as few (bag, piece) threads do all the adding -- the
-    // grid-stride kernel's lane group per bag is the better form there (bags of ~38 indices, B = 2 048: 229 vs 352 us)
-    if (nnz > 16 * a.B * (int64_t)a.T) return false;
+    // very long bags: a tile holds the rows of one or two bags and as few (bag, piece) threads do all the adding -- beyond an
+    // average of 128 indices the grid-stride kernel's lane group per bag takes over (at ~38: 218 us here, 229 there)
+    static const int max_avg = getenv("EVS_GATHER_FLAT_MAXAVG") ? atoi(getenv("EVS_GATHER_FLAT_MAXAVG")) : 128;
+    if (nnz > (int64_t)max_avg * a.B * (int64_t)a.T) return false;
+    const bool sel = nnz > 16 * a.B * (int64_t)a.T;
     const int64_t chunks = (a.B + 63) / 64;
     if (chunks * a.T >= (1ll << 31)) return false;
     const dim3 grid((unsigned)(chunks * a.T)), block(256);
+#define EVS_FLAT(L) do { if (sel) hipLaunchKernelGGL((bag_sum_flat_kernel<L, true>), grid, block, 0, stream, a); \
+                         else hipLaunchKernelGGL((bag_sum_flat_kernel<L, false>), grid, block, 0, stream, a); return true; } while (0)
     switch (a.d) {
-    case 16: hipLaunchKernelGGL(bag_sum_flat_kernel<4>, grid, block, 0, stream, a); return true;
-    case 32: hipLaunchKernelGGL(bag_sum_flat_kernel<8>, grid, block, 0, stream, a); return true;
-    case 36: hipLaunchKernelGGL(bag_sum_flat_kernel<9>, grid, block, 0, stream, a); return true;
-    default: hipLaunchKernelGGL(bag_sum_flat_kernel<16>, grid, block, 0, stream, a); return true;
+    case 16: EVS_FLAT(4);
+    case 32: EVS_FLAT(8);
+    case 36: EVS_FLAT(9);
+    default: EVS_FLAT(16);
     }
+#undef EVS_FLAT
 }
 
 // is there a rows-in-registers gather for the launch, and launch it

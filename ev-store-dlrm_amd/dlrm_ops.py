@@ -409,7 +409,7 @@ def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself
     # loop, whose lane groups own bags (B = 16 384, ~5 indices per bag: 92 vs 133 us); same bits either way
     if out is None and ev.codec == 32 and not torch.is_tensor(lS_i) and not torch.is_tensor(lS_o) and \
             (v_W_l is None or all(w is None for w in v_W_l)) and d in (16, 32, 36, 64) and \
-            all(int(o.numel()) == B for o in lS_o) and B * T < sum(int(i.numel()) for i in lS_i) <= 16 * B * T:
+            all(int(o.numel()) == B for o in lS_o) and B * T < sum(int(i.numel()) for i in lS_i) <= 128 * B * T:
         return interact_features(x, apply_emb(lS_o, lS_i, ev, None, lazy=False, check_indices=check_indices), "dot", arch_interaction_itself)
     P = F * (F + 1) // 2 if arch_interaction_itself else F * (F - 1) // 2
     R = out if out is not None else torch.empty((B, d + P), dtype=torch.float32, device=dev)
