@@ -37,14 +37,25 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define EVS_RFQ_LB8 6
 #endif
 constexpr int rfq_min_blocks(int codec) { return codec == 16 ? EVS_RFQ_LB16 : EVS_RFQ_LB8; }
+#ifndef EVS_RFQ_FOLD
+#define EVS_RFQ_FOLD 1   // developer A/B: 0 = the tail chunk of a d = 36 u8 / u4 row as a load of its own
+#endif
+#ifndef EVS_RFQ_FOLD4
+#define EVS_RFQ_FOLD4 0  // u4, one index per bag declared, F > 16: the folded form needs 83 VGPRs; at the 80 of six blocks per CU two
+#endif                   // spills put scratch traffic and vmcnt(0) waits into the counted sequence (B = 65 536: 60.5 vs 55.0 us),
+                         // so that one instantiation keeps the separate tail load; the other u4 forms fold
 #ifndef EVS_OUT_CPOL
 #define EVS_OUT_CPOL 2   // nt: R is written once and streams out (see evs_fused.hip)
 #endif
 
 // N raw bytes at p (global address space: a flat load would force every later wait to vmcnt(0)) -> w[0 .. max(1, N/4))
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 template <int N>
 __device__ __forceinline__ void load_raw(unsigned long long p, unsigned (&w)[N >= 4 ? N / 4 : 1]) {
-    if constexpr (N == 16) {
+    if constexpr (N == 12) {
+        const u32x3 v = *reinterpret_cast<const __attribute__((address_space(1), aligned(4))) u32x3 *>((uintptr_t)p);
+        w[0] = v[0]; w[1] = v[1]; w[2] = v[2];
+    } else if constexpr (N == 16) {
         const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>((uintptr_t)p);
         w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
     } else if constexpr (N == 8) {
@@ -53,7 +64,7 @@ __device__ __forceinline__ void load_raw(unsigned long long p, unsigned (&w)[N >
     } else if constexpr (N == 4) {
         w[0] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned *>((uintptr_t)p);
     } else {
-        static_assert(N == 2, "raw pieces of 16, 8, 4 or 2 bytes");
+        static_assert(N == 2, "raw pieces of 16, 12, 8, 4 or 2 bytes");
         w[0] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned short *>((uintptr_t)p);
     }
 }
@@ -117,6 +128,14 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     constexpr int kMainBytes = CQ * kChunkBytes;  // this lane's contiguous share of a row
     constexpr int kMainDw = kMainBytes >= 4 ? kMainBytes / 4 : 1;
     constexpr int kRemDw = kChunkBytes >= 4 ? kChunkBytes / 4 : 1;
+    // FOLD (d = 36, u8 / u4; round 3): the trailing chunk rides in the main load.  The launch's rate is set by the number of
+    // random LINE REQUESTS, not by bytes (tools/sector_probe.hip: ~50 G lines/s from HBM whatever the size of the piece), and a
+    // separate 4- or 2-byte load of the row's tail is a second request for the same line.  u8: every lane loads 12 bytes at
+    // 8 q (k-slot 3: bytes 24..35 = its two chunks + the tail); u4: 8 bytes at 4 q, k-slot 3 at byte 10 (bytes 10..17: its
+    // chunks in the upper half + the tail) -- never past the row.  The tail travels from k-slot 3 to the other three by
+    // ds_bpermute at decode time.
+    constexpr bool FOLD = REM == 1 && CQ == 2 && (CODEC == 8 || (CODEC == 4 && (EVS_RFQ_FOLD4 || CHECK || NT == 1))) && EVS_RFQ_FOLD;
+    constexpr int kLoadDw = FOLD ? kMainDw + 1 : kMainDw;
     static_assert(d <= 64, "x travels one float per lane");
     __shared__ int s_idx[512];                    // [32 features][16 samples]: row id, sample id (x), -1 = no row
     __shared__ __attribute__((aligned(16))) float s_x[4][64];
@@ -278,7 +297,7 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
         }
     };
 
-    auto chunk_words = [&](const unsigned (&w)[kMainDw], int c, unsigned &w0, unsigned &w1) {
+    auto chunk_words = [&](const auto &w, int c, unsigned &w0, unsigned &w1) {
         if constexpr (CODEC == 16) { w0 = w[2 * c]; w1 = w[2 * c + 1]; }
         else if constexpr (CODEC == 8) { w0 = w[c]; w1 = 0; }
         else { w0 = (w[0] >> (16 * c)) & 0xffffu; w1 = 0; }
@@ -401,8 +420,9 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     }
 
     // ---- request the rows of all D samples of this wave ----------------------------------------------------------------
-    unsigned rmain[D][NR][kMainDw], rrem[D][NR][REM > 0 ? REM : 1][kRemDw];
+    unsigned rmain[D][NR][kLoadDw], rrem[D][NR][REM > 0 ? REM : 1][kRemDw];
     float rx[D];
+    const unsigned fold_off = FOLD ? (CODEC == 8 ? 8u * (unsigned)q : (q < 3 ? 4u * (unsigned)q : 10u)) : 0u;
 #pragma unroll
     for (int u = 0; u < D; u++) {
         const int m = wave_in_block + 4 * u;              // block-local sample
@@ -416,9 +436,13 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
             const unsigned long long p = fbase[rr] + (unsigned long long)idx * (unsigned long long)fscale[rr];
             const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
             const unsigned long long pa = p ^ ((p ^ zc_p) & m64);
-            load_raw<kMainBytes>(pa + q * kMainBytes, rmain[u][rr]);
+            if constexpr (FOLD) {
+                load_raw<4 * kLoadDw>(pa + fold_off, rmain[u][rr]);
+            } else {
+                load_raw<kMainBytes>(pa + q * kMainBytes, rmain[u][rr]);
 #pragma unroll
-            for (int t = 0; t < REM; t++) load_raw<kChunkBytes>(pa + 4 * kMainBytes + t * kChunkBytes, rrem[u][rr][t]);
+                for (int t = 0; t < REM; t++) load_raw<kChunkBytes>(pa + 4 * kMainBytes + t * kChunkBytes, rrem[u][rr][t]);
+            }
         }
         {
             const unsigned long long p = xbase + (unsigned long long)(unsigned)(blk_first + m) * (unsigned long long)xscale + 4 * (lane < d ? lane : 0);
@@ -437,6 +461,20 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
         // operands: a[rr][c] = the 4 elements of chunk c (c < CQ: this k-slot's own chunks); of the REM trailing chunks
         // k-slot q feeds only element q to the matrix core: a[rr][CQ + t].x holds it, nothing else is decoded
         float4 a[NR][NC];
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                unsigned tailw;
+                if constexpr (CODEC == 8) {
+                    tailw = rmain[u][rr][2];                                  // k-slot 3: bytes 32..35
+                } else {
+                    const unsigned lo = rmain[u][rr][0], hi = rmain[u][rr][1];
+                    tailw = hi >> 16;                                         // k-slot 3: bytes 16..17
+                    rmain[u][rr][0] = q < 3 ? lo : __builtin_amdgcn_alignbit(hi, lo, 16);   // ... and its chunks, bytes 12..15
+                }
+                rrem[u][rr][0][0] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (48 + r16), (int)tailw);
+            }
+        }
         auto decode = [&](auto fast) {
             constexpr bool FAST = decltype(fast)::value;
 #pragma unroll

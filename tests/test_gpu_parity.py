@@ -551,7 +551,8 @@ def test_rows_in_registers_gather_vs_oracle(E, orc, d, T, B):
             E._lib.check(E._lib.lib().evs_check_index_errors(None))
 
 
-@pytest.mark.parametrize("d,T,B,max_bag", [(36, 26, 1000 + 3, 10), (16, 8, 128, 10), (32, 5, 65, 40), (64, 3, 700, 6), (36, 2, 64, 300), (36, 40, 50, 5)])
+@pytest.mark.parametrize("d,T,B,max_bag", [(36, 26, 1000 + 3, 10), (16, 8, 128, 10), (32, 5, 65, 40), (64, 3, 700, 6), (36, 2, 64, 300), (36, 40, 50, 5),
+                                           (36, 3, 200, 100), (64, 2, 100, 60), (16, 4, 300, 90)])   # (averages above 16: the select form)
 def test_multi_hot_gather_through_lds_vs_oracle(E, orc, d, T, B, max_bag):
     """Genuinely multi-hot bags in list form (the reference's random-data loader, dlrm_data_pytorch.py:1024-1065) run
     bag_sum_flat_kernel (round 3: a lane group per LOOKUP, 64 bags of one table per block, rows through LDS, each bag's
