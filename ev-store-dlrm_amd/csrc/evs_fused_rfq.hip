@@ -431,7 +431,11 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
         for (int rr = 0; rr < NR; rr++) {
             const int iv = s_idx[(r16 + 16 * rr) * 16 + m];
             // branch-free (bit blends, no selects over the LDS reads -- see evs_fused_rf.hip): -1 -> the zero page
+#ifdef EVS_XQ_NOROWS   // developer A/B (timing only, wrong R): every row is the zero-code page -- no random access at all
+            const unsigned neg = 0xffffffffu | (unsigned)iv;
+#else
             const unsigned neg = (unsigned)(iv >> 31) | phantom;
+#endif
             const unsigned idx = (unsigned)iv & ~neg;
             const unsigned long long p = fbase[rr] + (unsigned long long)idx * (unsigned long long)fscale[rr];
             const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
@@ -446,7 +450,11 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
         }
         {
             const unsigned long long p = xbase + (unsigned long long)(unsigned)(blk_first + m) * (unsigned long long)xscale + 4 * (lane < d ? lane : 0);
+#ifdef EVS_XQ_NOX      // developer A/B (timing only, wrong R): x is never read
+            const unsigned long long m64 = ~0ull | p;
+#else
             const unsigned long long m64 = ((unsigned long long)phantom << 32) | phantom;
+#endif
             const unsigned long long pa = p ^ ((p ^ zeros_p) & m64);
             rx[u] = *reinterpret_cast<const __attribute__((address_space(1))) float *>((uintptr_t)pa);
         }
