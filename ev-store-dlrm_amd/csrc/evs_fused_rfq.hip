@@ -36,7 +36,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef EVS_RFQ_LB8
 #define EVS_RFQ_LB8 6
 #endif
-constexpr int rfq_min_blocks(int codec) { return codec == 16 ? EVS_RFQ_LB16 : EVS_RFQ_LB8; }
+#ifndef EVS_RFQ_LB4
+#define EVS_RFQ_LB4 EVS_RFQ_LB8
+#endif
+constexpr int rfq_min_blocks(int codec) { return codec == 16 ? EVS_RFQ_LB16 : codec == 4 ? EVS_RFQ_LB4 : EVS_RFQ_LB8; }
 #ifndef EVS_RFQ_FOLD
 #define EVS_RFQ_FOLD 1   // developer A/B: 0 = the tail chunk of a d = 36 u8 / u4 row as a load of its own
 #endif
