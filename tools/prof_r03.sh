@@ -33,6 +33,14 @@ python3 $ROOT/tools/pmc_summary.py $OUT "emb_interact_rf_kernel" > $OUT/pmc_summ
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rqtrace -- python3 $ROOT/tools/kbench.py --fused-only --bits 16 --codes encoded --batch 16384 65536 --iters 300 > $OUT/kbench_u16.log 2>&1
 f=$(find $OUT/rqtrace -name "*kernel_stats.csv" | head -1); grep -E "evs::|Name" $f > $OUT/u16_kernel_stats.csv
 rm -rf $OUT/rqtrace
+for bits in 8 4; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rqtrace -- python3 $ROOT/tools/kbench.py --fused-only --bits $bits --codes encoded --batch 16384 65536 --iters 300 > $OUT/kbench_u$bits.log 2>&1
+  f=$(find $OUT/rqtrace -name "*kernel_stats.csv" | head -1); grep -E "evs::|Name" $f > $OUT/u${bits}_kernel_stats.csv
+  rm -rf $OUT/rqtrace
+done
+python3 $ROOT/tools/multihot_bench.py 16384 10 > $OUT/multihot.log 2>/dev/null
+python3 $ROOT/tools/multihot_bench.py 4096 40 >> $OUT/multihot.log 2>/dev/null
+python3 $ROOT/tools/multihot_bench.py 2048 100 >> $OUT/multihot.log 2>/dev/null
 cd $ROOT
 timeout 900 python3 tools/sweep.py > $OUT/sweep.md 2> $OUT/sweep.err
 # the cache tier alone and the two- / three-tier chains: kernel statistics, deciles, the other policies, PMC traffic
