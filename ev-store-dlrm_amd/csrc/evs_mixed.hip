@@ -191,14 +191,18 @@ struct Mixed84Args {
 
 template <int N>
 __device__ __forceinline__ void mixed_load_raw(unsigned long long p, unsigned (&w)[N >= 4 ? N / 4 : 1]) {
-    if constexpr (N == 8) {
+    if constexpr (N == 12) {
+        typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 v = *reinterpret_cast<const __attribute__((address_space(1), aligned(4))) u32x3 *>((uintptr_t)p);
+        w[0] = v[0]; w[1] = v[1]; w[2] = v[2];
+    } else if constexpr (N == 8) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x2 *>((uintptr_t)p);
         w[0] = v[0]; w[1] = v[1];
     } else if constexpr (N == 4) {
         w[0] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned *>((uintptr_t)p);
     } else {
-        static_assert(N == 2, "raw pieces of 8, 4 or 2 bytes");
+        static_assert(N == 2, "raw pieces of 12, 8, 4 or 2 bytes");
         w[0] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned short *>((uintptr_t)p);
     }
 }
@@ -207,8 +211,16 @@ __device__ __forceinline__ void mixed_load_raw(unsigned long long p, unsigned (&
 // (table (e >> 4) - 1, sample e & 15): both hashes, the alt-key tier, agg_hit per request (LDS), priority bumps, the routing of
 // double misses, tier codes, each tier's miss list of the block, hit statistics -- and the (address, class) pairs go straight
 // into the LDS tile instead of through two (B,T) arrays and a launch boundary.
+// blocks per CU the PROBE form is compiled for: at 5 (96 VGPRs) it spills six registers -- scratch traffic and vmcnt(0) waits
+// inside the counted sequence; at 4 it needs 99 and spills nothing (two tiers + interaction 46.9 -> 44.6-45.8 us per batch)
+#ifndef EVS_MIXED_LB_PROBE
+#define EVS_MIXED_LB_PROBE 4
+#endif
+#ifndef EVS_MIXED_FOLD
+#define EVS_MIXED_FOLD 1   // developer A/B: 0 = the tail chunk of a d = 36 row as a load of its own
+#endif
 template <int CQ, int REM, int NT, bool PROBE = false>
-__global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84Args margs) {
+__global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_mixed84_kernel(const Mixed84Args margs) {
     const MixedArgs &args = margs.m;
     constexpr int NR = NT, NC = CQ + REM;
     constexpr int d = 4 * (4 * CQ + REM);
@@ -442,7 +454,14 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
     const int sh2 = (q * W2 - st2) * 8;                        // bits
     constexpr int rst2 = REM ? (4 * W2 + 4 <= RB2 ? 4 * W2 : RB2 - 4) : 0;   // REM chunk of a u4 row: 2 bytes at 4 W2, loaded as 4
     constexpr int rsh2 = REM ? (4 * W2 - rst2) * 8 : 0;
-    unsigned rmain[D][NR][WMdw], rrem[D][NR][REM > 0 ? REM : 1];
+    // FOLD (d = 36; see evs_fused_rfq.hip): the launch pays per random LINE REQUEST, and the tail chunk as a load of its own is
+    // a second request for the row's line.  Every lane loads 12 bytes instead: a u8 row at 8 q (k-slot 3: bytes 24..35 = its
+    // chunks + the tail), a u4 row at min(4 q, 6) (k-slot 2 and 3: bytes 6..17 -- the wanted 4 bytes sit 2 / 6 bytes into the
+    // window, the tail in its last two); the tail reaches the other k-slots by ds_bpermute at decode time.
+    constexpr bool FOLD = CQ == 2 && REM == 1 && EVS_MIXED_FOLD;
+    constexpr int LDdw = FOLD ? 3 : WMdw;
+    const int fst2 = 4 * q < 6 ? 4 * q : 6;
+    unsigned rmain[D][NR][LDdw], rrem[D][NR][REM > 0 ? REM : 1];
     float rx[D];
     unsigned cls2 = 0;   // bit u * NR + rr: the row is of class 2
 #pragma unroll
@@ -455,8 +474,12 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
             unsigned long long p = s_ptr[row * 16 + m];
             const bool c2 = s_cls[row * 16 + m] == 2 && !phantom;
             if (phantom) p = zc_p;
+            if constexpr (FOLD) {
+                mixed_load_raw<12>(p + (c2 ? fst2 : q * W1), rmain[u][rr]);
+            } else {
             mixed_load_raw<WM>(p + (c2 ? st2 : q * W1), rmain[u][rr]);
-            if constexpr (REM > 0) {
+            }
+            if constexpr (REM > 0 && !FOLD) {
                 unsigned t[1];
                 mixed_load_raw<4>(p + (c2 ? rst2 : 4 * W1), t);
                 rrem[u][rr][0] = t[0];
@@ -489,6 +512,13 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
             const bool c2 = (cls2 >> (u * NR + rr)) & 1u;
             // class 2: the wanted W2 bytes, shifted down to bit 0 of a 32-bit word
             unsigned lo4;
+            if constexpr (FOLD) {
+                // the u4 window of 12 bytes: k-slots 0 / 1 want its first word, 2 the word 2 bytes in, 3 the word 6 bytes in
+                const unsigned w0 = rmain[u][rr][0], w1 = rmain[u][rr][1], w2 = rmain[u][rr][2];
+                lo4 = q < 2 ? w0 : __builtin_amdgcn_alignbit(q == 2 ? w1 : w2, q == 2 ? w0 : w1, 16);
+                // the tail: k-slot 3 holds it -- u8 bytes 32..35 = its third word, u4 bytes 16..17 = the top half of it
+                rrem[u][rr][0] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (48 + r16), (int)(c2 ? w2 >> 16 : w2));
+            } else
             if constexpr (WMdw == 2) lo4 = (unsigned)((((unsigned long long)rmain[u][rr][1] << 32) | rmain[u][rr][0]) >> sh2);
             else lo4 = rmain[u][rr][0] >> sh2;
 #pragma unroll
@@ -497,7 +527,7 @@ __global__ void __launch_bounds__(256, 5) interact_mixed84_kernel(const Mixed84A
                 a[rr][c] = dec(w8, lo4 >> (16 * c), c2);
             }
             if constexpr (REM > 0) {   // k-slot q feeds only element q of the REM chunk to the matrix core
-                const unsigned w8 = rrem[u][rr][0], w4 = rrem[u][rr][0] >> rsh2;
+                const unsigned w8 = rrem[u][rr][0], w4 = FOLD ? rrem[u][rr][0] : rrem[u][rr][0] >> rsh2;
                 const unsigned i8 = (w8 >> (8 * q)) & 255u;
                 const unsigned i4 = 256u + ((w4 >> (8 * (q >> 1) + ((q & 1) ? 0 : 4))) & 15u);
                 a[rr][CQ] = make_float4(s_lut[c2 ? i4 : i8], 0.f, 0.f, 0.f);
