@@ -213,6 +213,40 @@ def test_bench_mixed_precision_tiers_at_full_size(E, orc, policy):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("bits,Bq", [(8, 16384 + 3), (4, 16384 + 3), (16, 16384 + 3), (8, 40000 + 7), (4, 40000 + 7)])
+def test_reduced_precision_tables_at_full_size(E, orc, bits, Bq):
+    """What bench.py's reduced-precision lines time: the 26 Kaggle tables (33.76 M rows) in the reference's u16 / u8 / u4 row
+    layouts, random codes (every code decodes; u16 with its tail codes), d = 36 -- the rows-in-registers kernel of
+    evs_fused_rfq.hip, whose d = 36 u8 / u4 rows travel as ONE load per lane with the tail chunk folded in (round 3): the
+    LAST rows of every table among the indices (a load that ran past a row would run past the table there), the declared
+    form, lS_o given and the two-call path give the same bits, and sampled samples agree with the oracle's decoders."""
+    import bench
+    ln = bench.KAGGLE_LN
+    T = len(ln)
+    ev = bench.make_tables(ln, D, seed=5, bits=bits, codes="random")
+    g = torch.Generator(device="cuda").manual_seed(17)
+    idx = torch.stack([torch.randint(0, n, (Bq,), device="cuda", generator=g) for n in ln])
+    for k, n in enumerate(ln):
+        idx[k, :4] = torch.tensor([n - 1, 0, max(n - 2, 0), n - 1], device="cuda")
+        idx[k, -1] = n - 1
+    off = torch.arange(Bq, device="cuda").repeat(T, 1)
+    x = torch.randn(Bq, D, device="cuda")
+    a = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True, check_indices=True)
+    b = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
+    assert torch.equal(a, b) and torch.equal(a[:, :D], x)
+    if Bq <= 20000:
+        c = E.interact_features(x, E.apply_emb(off, idx, ev, None, lazy=False))
+        assert torch.equal(a, c)
+    sel = np.array([0, 1, 2, 3, Bq // 2, Bq - 2, Bq - 1])
+    sel_t = torch.from_numpy(sel).cuda()
+    raws = [ev.raw[k][idx[k][sel_t]].cpu().numpy() for k in range(T)]
+    ly = [orc.decode(r, bits, D) for r in raws]
+    want = orc.interact_features(x[sel_t].cpu().numpy(), ly)
+    np.testing.assert_allclose(a[sel_t].cpu().numpy(), want, rtol=RTOL, atol=2e-6 * max(1.0, float(np.abs(want).max())))
+    del ev
+    torch.cuda.empty_cache()
+
+
 # MLPerf DLRM (Criteo Terabyte) cardinalities with --max-ind-range=40000000 (bench/run_and_time.sh:17): external, a
 # synthetic shape only (bench.py --shape terabyte, tools/sweep.py)
 TERABYTE_LN = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
