@@ -1252,6 +1252,22 @@ static void launch_nt(const FusedArgs &a, hipStream_t st) {
                     }
                 }
             }
+            if constexpr (!HAS_INDIRECT && !WEIGHTED && !PTRS && CODEC == 32) {
+                // interact_features over rows that are already there (the two-call path's second half, dlrm_s_pytorch.py:483-516):
+                // every feature is dense -- the rows-in-registers kernel takes dense features as rows addressed by the sample
+                // number (it does so for x and for the sharded step's received vectors), with no index round trip at all.
+                // Needs 16-byte aligned rows (EVS_INTERACT_RF=0: the LDS-DMA loop).
+                static const bool dense_rf = !(getenv("EVS_INTERACT_RF") && getenv("EVS_INTERACT_RF")[0] == '0');
+                bool ok = dense_rf && tile_eligible(a, CODEC);
+                for (int f = 0; f < a.F && ok; f++)
+                    ok = (reinterpret_cast<uintptr_t>(a.src[f]) & 15) == 0 && ((a.stride[f] * 4) & 15) == 0;
+                if (ok) {
+                    FusedArgs b = a;
+                    b.bag1 = 1;
+                    if (!b.dummy_i64) b.dummy_i64 = reinterpret_cast<const int64_t *>(a.zeros);   // (lanes with no index to load read it)
+                    if (launch_rf(b, st)) return;
+                }
+            }
             if (nt2) launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 2, WEIGHTED, HAS_INDIRECT, PTRS, false>>(a, st);
             else launch_persistent<emb_interact_dot_lds_kernel<CODEC, CQ, REM, 1, WEIGHTED, HAS_INDIRECT, PTRS, false>>(a, st);
             return;
