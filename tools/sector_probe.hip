@@ -101,6 +101,8 @@ int main(int argc, char **argv) {
         {"36 B row, 32 B read: 4 adjacent lanes x 8 B", 4, 2, 36}, {"36 B row, 32 B read: lanes l, l+16, .. x 8 B", 4, 2, 36, true},
         {"144 B row, 64 B read: 4 adjacent lanes x 16 B", 4, 4, 144}, {"144 B row, 64 B read: lanes l, l+16, .. x 16 B", 4, 4, 144, true},
         {"18 B row pitch 20, 16 B read: 4 adj x 4 B", 4, 1, 20}, {"18 B row pitch 20, 16 B read: l, l+16, .. x 4 B", 4, 1, 20, true},
+        {"18 B row pitch 18 (u4): 4 adj x 4 B, 2 B aligned", 4, 1, 18}, {"36 B row pitch 36 (u8), 32 B read: 4 adj x 8 B, 4 B aligned", 4, 2, 36},
+        {"18 B row pitch 18 (u4): 2 adj x 8 B, 2 B aligned", 2, 2, 18},
     };
     for (const Case &c : cases) {
         const uint64_t nrows = kaggle ? (uint64_t)ln_base[26] : span / c.rowb;
