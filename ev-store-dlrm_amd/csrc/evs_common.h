@@ -74,6 +74,17 @@ __device__ __constant__ const float kU4Lut[16] = {
     1.0f, 0.8f, 0.6f, 0.4f, 0.0625f, 0.00390625f, 0.0000153f, 0.0f,
     -0.0000153f, -0.00390625f, -0.0625f, -0.4f, -0.6f, -0.8f, -1.0f, __builtin_nanf("")};
 
+// the same 16 values without a memory access (selects on immediates): what the table fills of the kernels use -- a per-lane
+// read of kU4Lut in a kernel's head is a vector-memory round trip in front of everything else, in every block
+__device__ __forceinline__ float u4_value(unsigned c) {
+    const unsigned m = c > 7u ? 14u - c : c;          // magnitude index 0..6 (7: zero; c = 15 -> wraps: NaN below)
+    float v = 0.0f;
+    v = m == 0u ? 1.0f : v; v = m == 1u ? 0.8f : v; v = m == 2u ? 0.6f : v; v = m == 3u ? 0.4f : v;
+    v = m == 4u ? 0.0625f : v; v = m == 5u ? 0.00390625f : v; v = m == 6u ? 0.0000153f : v;
+    v = c > 7u ? -v : v;
+    return c == 15u ? __builtin_nanf("") : (c == 7u ? 0.0f : v);
+}
+
 // Decode through a per-block LDS table: u8 -> all 256 values (the exact expression above has an
 // IEEE division per element), u4 -> the 16 entries (a per-lane index into __constant__ memory is a
 // vector-memory gather), u16 -> the 536 magnitudes of the v > 65000 tail (the division again); the
@@ -88,7 +99,7 @@ template <int CODEC>
 __device__ __forceinline__ void codec_lut_init(float *lut) {
     for (int i = threadIdx.x; i < CodecLut<CODEC>::kEntries; i += blockDim.x) {
         if constexpr (CODEC == 8) lut[i] = dec_u8((unsigned)i);
-        else if constexpr (CODEC == 4) lut[i] = kU4Lut[i];
+        else if constexpr (CODEC == 4) lut[i] = u4_value((unsigned)i);
         else if constexpr (CODEC == 16) lut[i] = (float)__dadd_rn(0.65, (double)__fdiv_rn((float)i, 100.0f));
         else lut[i] = 0.f;
     }

@@ -37,16 +37,22 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define EVS_RFQ_LB8 6
 #endif
 #ifndef EVS_RFQ_LB4
-#define EVS_RFQ_LB4 EVS_RFQ_LB8
+#define EVS_RFQ_LB4 5   // u4, folded with aligned windows: 84 VGPRs in the lS_o form (6 blocks per CU = 80 would spill four; 5 vs 6 blocks measured equal)
 #endif
 constexpr int rfq_min_blocks(int codec) { return codec == 16 ? EVS_RFQ_LB16 : codec == 4 ? EVS_RFQ_LB4 : EVS_RFQ_LB8; }
 #ifndef EVS_RFQ_FOLD
 #define EVS_RFQ_FOLD 1   // developer A/B: 0 = the tail chunk of a d = 36 u8 / u4 row as a load of its own
 #endif
+#ifndef EVS_RFQ_FOLD4A
+#define EVS_RFQ_FOLD4A 1   // developer A/B: 0 = u4 windows at 4 q whatever the row's alignment
+#endif
 #ifndef EVS_RFQ_FOLD4
-#define EVS_RFQ_FOLD4 0  // u4, one index per bag declared, F > 16: the folded form needs 83 VGPRs; at the 80 of six blocks per CU two
+#define EVS_RFQ_FOLD4 1  // u4, one index per bag declared, F > 16: the folded form needs 83 VGPRs; at the 80 of six blocks per CU two
 #endif                   // spills put scratch traffic and vmcnt(0) waits into the counted sequence (B = 65 536: 60.5 vs 55.0 us),
                          // so that one instantiation keeps the separate tail load; the other u4 forms fold
+#ifndef EVS_RFQ_U4PAIR
+#define EVS_RFQ_U4PAIR 1   // developer A/B: 0 = u4 decoded nibble by nibble through the 16-entry table
+#endif
 #ifndef EVS_OUT_CPOL
 #define EVS_OUT_CPOL 2   // nt: R is written once and streams out (see evs_fused.hip)
 #endif
@@ -143,6 +149,11 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     __shared__ int s_idx[512];                    // [32 features][16 samples]: row id, sample id (x), -1 = no row
     __shared__ __attribute__((aligned(16))) float s_x[4][64];
     __shared__ float s_lut[CodecLut<CODEC>::kEntries];
+    // u4: a BYTE decodes to two elements at once (element 2j = the high nibble): one 8-byte table read and one byte
+    // extraction per two elements instead of two reads and four shift / mask operations -- vector instructions add to the
+    // matrix time on this part, and the nibble form made u4 slower than u8 for half the bytes
+    constexpr bool PAIR4 = CODEC == 4 && EVS_RFQ_U4PAIR;
+    __shared__ float2 s_lut2[PAIR4 ? 256 : 1];
     constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
     __shared__ __attribute__((aligned(16))) float s_out[4][OUT_MAX + 16];
 
@@ -235,6 +246,7 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
             }
         }
         codec_lut_init<CODEC>(s_lut);
+        if constexpr (PAIR4) s_lut2[threadIdx.x] = make_float2(u4_value(threadIdx.x >> 4), u4_value(threadIdx.x & 15u));   // (256 threads)
         if constexpr (CHECK) my_ragged = o0[0] != bs || o1[0] != bs + 1 || o0[1] != bs || o1[1] != bs + 1;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -426,6 +438,11 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     unsigned rmain[D][NR][kLoadDw], rrem[D][NR][REM > 0 ? REM : 1][kRemDw];
     float rx[D];
     const unsigned fold_off = FOLD ? (CODEC == 8 ? 8u * (unsigned)q : (q < 3 ? 4u * (unsigned)q : 10u)) : 0u;
+    // u4, folded: an 18-byte row starts 2 bytes off a dword boundary when its index is odd, and an 8-byte load off the
+    // boundary is more than one request.  k-slots 0..2 therefore start their window 2 bytes EARLIER on odd rows (the
+    // previous row's last two bytes: in bounds -- an odd row has a predecessor) and shift; k-slot 3 keeps bytes 10..17.
+    constexpr bool FOLD4A = FOLD && CODEC == 4 && EVS_RFQ_FOLD4A;
+    unsigned odd_rows = 0;   // bit u * NR + rr
 #pragma unroll
     for (int u = 0; u < D; u++) {
         const int m = wave_in_block + 4 * u;              // block-local sample
@@ -443,7 +460,11 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
             const unsigned long long p = fbase[rr] + (unsigned long long)idx * (unsigned long long)fscale[rr];
             const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
             const unsigned long long pa = p ^ ((p ^ zc_p) & m64);
-            if constexpr (FOLD) {
+            if constexpr (FOLD4A) {
+                const unsigned par = idx & 1u;                    // (an absent row: index 0, the zero-code page)
+                odd_rows |= par << (u * NR + rr);
+                load_raw<4 * kLoadDw>(pa + fold_off - (q < 3 ? 2u * par : 0u), rmain[u][rr]);
+            } else if constexpr (FOLD) {
                 load_raw<4 * kLoadDw>(pa + fold_off, rmain[u][rr]);
             } else {
                 load_raw<kMainBytes>(pa + q * kMainBytes, rmain[u][rr]);
@@ -481,6 +502,10 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
                 } else {
                     const unsigned lo = rmain[u][rr][0], hi = rmain[u][rr][1];
                     tailw = hi >> 16;                                         // k-slot 3: bytes 16..17
+                    if constexpr (FOLD4A) {
+                        const bool odd = (odd_rows >> (u * NR + rr)) & 1u;
+                        rmain[u][rr][0] = (q == 3 || odd) ? __builtin_amdgcn_alignbit(hi, lo, 16) : lo;
+                    } else
                     rmain[u][rr][0] = q < 3 ? lo : __builtin_amdgcn_alignbit(hi, lo, 16);   // ... and its chunks, bytes 12..15
                 }
                 rrem[u][rr][0][0] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (48 + r16), (int)tailw);
@@ -498,8 +523,15 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
 #ifdef EVS_XQ_NODEC   // developer A/B (timing only, wrong R): no decode
                     a[rr][c] = make_float4(__uint_as_float(w0), __uint_as_float(w1), __uint_as_float(w0 ^ w1), __uint_as_float(w0 + w1));
 #else
+                    if constexpr (PAIR4) {
+                        if (c < CQ) {
+                            const float2 p0 = s_lut2[w0 & 0xffu], p1 = s_lut2[(w0 >> 8) & 0xffu];
+                            a[rr][c] = make_float4(p0.x, p0.y, p1.x, p1.y);
+                        } else a[rr][c] = make_float4(dec_elem_q<CODEC, FAST>(w0, w1, q, s_lut), 0.f, 0.f, 0.f);
+                    } else {
                     if (c < CQ) a[rr][c] = dec_chunk_q<CODEC, FAST>(w0, w1, s_lut);
                     else a[rr][c] = make_float4(dec_elem_q<CODEC, FAST>(w0, w1, q, s_lut), 0.f, 0.f, 0.f);
+                    }
 #endif
                 }
             }

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
 
     // ---- the tile: the block's 16 x T (address, class) pairs are one contiguous run of each array ----------------------
     for (int i = threadIdx.x; i < 512; i += blockDim.x) { s_ptr[i] = zc_p; s_cls[i] = 1; }
-    for (int i = threadIdx.x; i < 256 + 16; i += blockDim.x) s_lut[i] = i < 256 ? dec_u8((unsigned)i) : kU4Lut[i - 256];
+    for (int i = threadIdx.x; i < 256 + 16; i += blockDim.x) s_lut[i] = i < 256 ? dec_u8((unsigned)i) : u4_value((unsigned)(i - 256));   // (no read of the __constant__ table: a memory round trip in the head)
     __syncthreads();
     __shared__ int s_agg[16];                        // PROBE: hits per request of the chunk
     __shared__ int s_d1[kMaxBuckets], s_d2[kMaxBuckets];   // priority histogram moves of the two tiers
