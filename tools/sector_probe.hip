@@ -103,6 +103,8 @@ int main(int argc, char **argv) {
         {"18 B row pitch 20, 16 B read: 4 adj x 4 B", 4, 1, 20}, {"18 B row pitch 20, 16 B read: l, l+16, .. x 4 B", 4, 1, 20, true},
         {"18 B row pitch 18 (u4): 4 adj x 4 B, 2 B aligned", 4, 1, 18}, {"36 B row pitch 36 (u8), 32 B read: 4 adj x 8 B, 4 B aligned", 4, 2, 36},
         {"18 B row pitch 18 (u4): 2 adj x 8 B, 2 B aligned", 2, 2, 18},
+        {"72 B row pitch 72 (u16), 64 B read: 4 adj x 16 B, 8 B aligned", 4, 4, 72}, {"80 B pitch, 64 B read: 4 adj x 16 B, 16 B aligned", 4, 4, 80},
+        {"144 B row pitch 144 (fp32), 64 B read: 4 adj x 16 B", 4, 4, 144}, {"36 B row pitch 36 (u8): 3 adj x 12 B, 4 B aligned", 3, 3, 36}, {"48 B pitch: 3 adj x 12 B... 16 B aligned rows", 3, 3, 48},
     };
     for (const Case &c : cases) {
         const uint64_t nrows = kaggle ? (uint64_t)ln_base[26] : span / c.rowb;
