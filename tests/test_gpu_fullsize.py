@@ -299,3 +299,78 @@ def test_terabyte_cardinalities_properties(E, d):
         E.apply_emb_interact(x, off, bad, ev, check_indices=True)
     del ev, ly, ly1, ly2
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("policy", ["count", "rows", "rows+replicate", "rowsplit"])
+def test_sharded_op_at_terabyte_cardinalities_eight_virtual_ranks(E, policy):
+    """BASELINE configs[3] through the SHARDED op (dlrm_s_pytorch.py:543-570 distributed_forward,
+    bench/dlrm_s_criteo_terabyte.sh:24: d = 64, --max-ind-range=40000000): 8 virtual ranks on one GPU over the 58 GB of
+    Terabyte-cardinality tables (every rank's tables are VIEWS of the one model: whole tables, or its row range of the
+    40 M-row ones under `rowsplit`), the exchange done by hand as all_to_all_single lays the blocks out
+    (extend_distributed.py:389-426).  One index per bag, indices in the LAST rows of the giant tables (byte offsets
+    beyond 2^32 inside a rank's shard): every rank's R slice equals the single-process fused launch BIT FOR BIT, through
+    the one-off and the planned step.  `rows+replicate` leaves ranks that own no table (empty send blocks); `count` is the
+    reference's 4-4-3-3-3-3-3-3 split."""
+    import bench
+    from evstore_dlrm_amd import sharded
+    ln, d, world, Bl = TERABYTE_LN, 64, 8, 512
+    T, Bg = len(ln), 8 * 512
+    ev = bench.make_tables(ln, d, seed=2)
+    g = torch.Generator(device="cuda").manual_seed(23)
+    idx = torch.stack([torch.randint(0, n, (Bg,), device="cuda", generator=g) for n in ln])
+    for k, n in enumerate(ln):
+        # the last and the first rows of every table, and -- for the row-split tables -- both ends of every rank's range
+        edge = [n - 1, 0, max(n - 2, 0)]
+        for r in range(world):
+            lo, hi = sharded.row_range(n, r, world)
+            if hi > lo:
+                edge += [lo, hi - 1]
+        e = torch.tensor(edge, device="cuda", dtype=torch.int64)
+        idx[k, :e.numel()] = e
+        idx[k, -1] = n - 1
+    assert int(idx[19, 0]) * d * 4 > 2 ** 32
+    off = torch.arange(Bg, device="cuda").repeat(T, 1)
+    x = torch.randn(Bg, d, device="cuda")
+    R_ref = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True, check_indices=True)
+    lS_o, lS_i = [off[k] for k in range(T)], [idx[k] for k in range(T)]
+    owner = sharded.plan_placement(ln, world, policy)
+    ops = []
+    for r in range(world):
+        held = {}
+        for t in range(T):
+            if owner[t] in (r, -1):
+                held[t] = ev.fp32_view(t)
+            elif owner[t] == -2:
+                lo, hi = sharded.row_range(ln[t], r, world)
+                held[t] = ev.fp32_view(t)[lo:hi]
+        op = sharded.ShardedEmbeddingInteract(ln, d, r, world, held, sharded.HipBackend(torch.device("cuda")), policy=policy,
+                                              one_index_per_bag=True)
+        for t, k in op.local_id.items():    # views, not copies: 8 ranks x 58 GB would not fit
+            lo = sharded.row_range(ln[t], r, world)[0] if owner[t] == -2 else 0
+            assert op.ev.raw[k].data_ptr() == ev.raw[t].data_ptr() + lo * d * 4
+        ops.append(op)
+    n_own = sorted(len(op.my_own) for op in ops)
+    if policy == "count":
+        assert [len(op.my_own) for op in ops] == [4, 4, 3, 3, 3, 3, 3, 3]
+    if policy == "rows":
+        assert sum(n_own) == T and n_own[0] >= 1
+    if policy == "rows+replicate":
+        assert n_own[0] == 0 and sum(n_own) == sum(1 for n in ln if n > 1_000_000), n_own   # ranks that own nothing
+    if policy == "rowsplit":
+        assert all(not op.my_own and len(op.split) == sum(1 for n in ln if n > 1_000_000) for op in ops)
+    sends = [op.pool(lS_o, lS_i)[0] if op.any_sharded else None for op in ops]
+    assert E._lib.lib().evs_check_index_errors(None) == 0
+    for r, op in enumerate(ops):
+        _, _, out_splits = op._splits(Bg)
+        recv = torch.cat([sends[p].reshape(world, sends[p].numel() // world)[r] for p in range(world)])
+        assert recv.numel() == sum(out_splits)
+        sl = slice(r * Bl, (r + 1) * Bl)
+        R = op.finish((None, recv, Bg, Bl, out_splits), x[sl], lS_o, lS_i)
+        assert torch.equal(R, R_ref[sl]), (policy, r, float((R - R_ref[sl]).abs().max()))
+        out = torch.empty_like(R)
+        pl = op.plan(x[sl], lS_o, lS_i, out=out)
+        pl["recv"].copy_(recv)
+        op.run_finish(pl, None)
+        assert torch.equal(out, R_ref[sl]), (policy, r)
+    del ops, sends, ev
+    torch.cuda.empty_cache()
