@@ -1153,6 +1153,14 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
             if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
         }
         }
+        // host-memory / file-backed miss tiers: the consumers run BEHIND the policy updates (every missing row crosses the bus
+        // once), so what this batch is served out of the arenas -- its hits and the alt rows -- must not be evicted by it
+        if (a1.stamp_hits) {
+            if (e1 >= 0) a1.estamp[e1] = a1.stamp;
+            else if (e2 >= 0) a2.estamp[e2] = a2.stamp;
+            else if (alt_tier == 1) a1.estamp[ea] = a1.stamp;
+            else if (alt_tier == 2) a2.estamp[ea] = a2.stamp;
+        }
         // evlfu_8.cpp:570-601: where a double miss goes
         const bool miss = ok && e1 < 0 && e2 < 0 && alt_tier == 0;
         const int dest = c1_room ? 1 : (agg < tt.threshold ? ((hl & 1) ? 1 : 2) : 2);
@@ -1796,24 +1804,32 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
     sampled_load(args, g * kSampleGroup, win);
     const unsigned char *srow = args.backing[t] + (long long)row * args.row_bytes;
     U r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
-    if constexpr (PIECES > 0) r0 = reinterpret_cast<const U *>(srow)[0];
-    if constexpr (PIECES > 1) r1 = reinterpret_cast<const U *>(srow)[1];
-    if constexpr (PIECES > 2) r2 = reinterpret_cast<const U *>(srow)[2];
-    if constexpr (PIECES > 3) r3 = reinterpret_cast<const U *>(srow)[3];
-    if constexpr (PIECES > 4) r4 = reinterpret_cast<const U *>(srow)[4];
-    if constexpr (PIECES > 5) r5 = reinterpret_cast<const U *>(srow)[5];
-    if constexpr (PIECES > 6) r6 = reinterpret_cast<const U *>(srow)[6];
-    if constexpr (PIECES > 7) r7 = reinterpret_cast<const U *>(srow)[7];
-    if constexpr (PIECES > 8) r8 = reinterpret_cast<const U *>(srow)[8];
-    if constexpr (PIECES > 9) r9 = reinterpret_cast<const U *>(srow)[9];
-    if constexpr (PIECES > 10) r10 = reinterpret_cast<const U *>(srow)[10];
-    if constexpr (PIECES > 11) r11 = reinterpret_cast<const U *>(srow)[11];
-    if constexpr (PIECES > 12) r12 = reinterpret_cast<const U *>(srow)[12];
-    if constexpr (PIECES > 13) r13 = reinterpret_cast<const U *>(srow)[13];
-    if constexpr (PIECES > 14) r14 = reinterpret_cast<const U *>(srow)[14];
-    if constexpr (PIECES > 15) r15 = reinterpret_cast<const U *>(srow)[15];
     TAIL rt;
-    if constexpr (!std::is_same<TAIL, NoTail>::value) rt = *reinterpret_cast<const TAIL *>(srow + PIECES * sizeof(U));
+    // Tables in HBM: the source row is requested HERE, together with the slot CAS and the victim group (one round trip for
+    // the three).  Host-memory tables (stamp_hits): only the copy of a key that wins the slot AND finds an entry reads the
+    // row -- each missing row crosses the bus once per batch, whatever the number of requests that miss it.
+    const bool late_row = args.stamp_hits != 0;
+#define EVS_SAMPLED_LOAD_ROW()                                                                                     \
+    do {                                                                                                           \
+        if constexpr (PIECES > 0) r0 = reinterpret_cast<const U *>(srow)[0];                                       \
+        if constexpr (PIECES > 1) r1 = reinterpret_cast<const U *>(srow)[1];                                       \
+        if constexpr (PIECES > 2) r2 = reinterpret_cast<const U *>(srow)[2];                                       \
+        if constexpr (PIECES > 3) r3 = reinterpret_cast<const U *>(srow)[3];                                       \
+        if constexpr (PIECES > 4) r4 = reinterpret_cast<const U *>(srow)[4];                                       \
+        if constexpr (PIECES > 5) r5 = reinterpret_cast<const U *>(srow)[5];                                       \
+        if constexpr (PIECES > 6) r6 = reinterpret_cast<const U *>(srow)[6];                                       \
+        if constexpr (PIECES > 7) r7 = reinterpret_cast<const U *>(srow)[7];                                       \
+        if constexpr (PIECES > 8) r8 = reinterpret_cast<const U *>(srow)[8];                                       \
+        if constexpr (PIECES > 9) r9 = reinterpret_cast<const U *>(srow)[9];                                       \
+        if constexpr (PIECES > 10) r10 = reinterpret_cast<const U *>(srow)[10];                                    \
+        if constexpr (PIECES > 11) r11 = reinterpret_cast<const U *>(srow)[11];                                    \
+        if constexpr (PIECES > 12) r12 = reinterpret_cast<const U *>(srow)[12];                                    \
+        if constexpr (PIECES > 13) r13 = reinterpret_cast<const U *>(srow)[13];                                    \
+        if constexpr (PIECES > 14) r14 = reinterpret_cast<const U *>(srow)[14];                                    \
+        if constexpr (PIECES > 15) r15 = reinterpret_cast<const U *>(srow)[15];                                    \
+        if constexpr (!std::is_same<TAIL, NoTail>::value) rt = *reinterpret_cast<const TAIL *>(srow + PIECES * sizeof(U)); \
+    } while (0)
+    if (!late_row) EVS_SAMPLED_LOAD_ROW();
     // 1. The hash slot, with a PENDING word: that is what de-duplicates the copies of a key (the loser of the CAS sees
     //    the key and stops -- it takes no entry; an earlier form claimed the entry first and gave it back, which let a
     //    batch with hundreds of copies of its hot missing keys evict half of a small cache for nothing).  The walk starts
@@ -1869,6 +1885,8 @@ __device__ __forceinline__ void sampled_insert_one(const BatchArgs &args, int t,
         if (s_vict) s_vict[atomicAdd(s_nvict, 1)] = old_key;   // for the alt-key tier
     } else atomicAdd(&s_stat[0], 1);
     const bool c3_inline = old_prio >= 0 && args.c3_tags != nullptr;
+    if (late_row) EVS_SAMPLED_LOAD_ROW();
+#undef EVS_SAMPLED_LOAD_ROW
     // 3. Everything else is stores nobody waits for: the row, the priority, the slot index, the key word (with this
     //    batch's stamp: nobody takes the entry away again), the final hash word.
     unsigned char *drow = args.a.arena + (long long)e * args.row_bytes;
@@ -2376,6 +2394,43 @@ __global__ void __launch_bounds__(256) cache_batch_patch_ptrs_kernel(const Batch
     if (e >= 0) args.row_ptrs[m] = (long long)(args.a.arena + (long long)e * args.row_bytes);
     else if (e == kPending && args.staging && ((args.staged_mask >> (int)(m % args.T)) & 1u))   // no room in the cache: the staged copy
         args.row_ptrs[m] = (long long)(args.staging + (long long)args.slot_stage[end_slot] * args.row_bytes);
+}
+
+// The same for a PAIR of tiers over host-memory / file-backed tables (evs_cache_lookup_batch_c1c2[c3]; the reference's tiers
+// read their misses from files inside the request: evlfu_8.cpp:380-414 get_from_file).  Both tiers' positions live in ONE
+// (B,T) pointer table (a1.row_ptrs) with a class byte each (row_tier); a position is a miss of the tier its request's
+// routing chose.  After both tiers' updates: the key has an entry in its tier -> that arena row; it is pending there with a
+// staged row (no room) -> the staged row; a C2 position whose key another request of the batch routed to C1 (only odd
+// tables can go both ways) -> C1's copy, at C1's precision; none of these (no room under the sampled update, whose
+// tables are all device-visible) -> the backing row as the probe left it.
+__global__ void __launch_bounds__(256) cache_batch_patch_ptrs2_kernel(const BatchArgs a1, const BatchArgs a2, unsigned char *row_tier) {
+    const long long n = a1.B * a1.T;
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const int k = (a1.miss_info[m] & 0x80000000u) ? 1 : ((a2.miss_info[m] & 0x80000000u) ? 2 : 0);
+    if (!k) return;
+    const BatchArgs &own = k == 1 ? a1 : a2;
+    const int t = (int)(m % a1.T);
+    const unsigned long long key = ((unsigned long long)(t + 1) << 32) | (unsigned)a1.requests[m];
+    if (own.staging && a1.row_ptrs[m] < 0) {   // orphan of the full hash: its own staged row
+        a1.row_ptrs[m] = (long long)(own.staging + (own.stage_rows + a1.row_ptrs[m]) * own.row_bytes);
+        return;
+    }
+    unsigned long long es;
+    int e = probe_ro(own.slots, own.mask, key, es);
+    if (e >= 0) { a1.row_ptrs[m] = (long long)(own.a.arena + (long long)e * own.row_bytes); return; }
+    if (e == kPending && own.staging && ((own.staged_mask >> t) & 1u)) {
+        a1.row_ptrs[m] = (long long)(own.staging + (long long)own.slot_stage[es] * own.row_bytes);
+        return;
+    }
+    if (k == 2) {
+        e = probe_ro(a1.slots, a1.mask, key, es);
+        if (e >= 0) { a1.row_ptrs[m] = (long long)(a1.a.arena + (long long)e * a1.row_bytes); row_tier[m] = 1; return; }
+        if (e == kPending && a1.staging && ((a1.staged_mask >> t) & 1u)) {
+            a1.row_ptrs[m] = (long long)(a1.staging + (long long)a1.slot_stage[es] * a1.row_bytes);
+            row_tier[m] = 1;
+        }
+    }
 }
 
 // File mode, after K2 / K3: the batch's new keys as one list for the host's reader pool (new key i = list base of
@@ -3361,20 +3416,35 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
                        "evs_cache_lookup_interact_c1c2: d must be 16, 32 or 36 and T <= 31");
     EVS_REQUIRE(c1->host.n_tables == c2->host.n_tables && c1->host.dim == c2->host.dim,
                 "evs_cache_lookup_batch_c1c2: the tiers must agree on n_tables and dim");
-    EVS_REQUIRE(!c1->host_backing && !c2->host_backing, "evs_cache_lookup_batch_c1c2: backing tables must be in HBM");
+    // Miss tiers outside HBM (BASELINE configs[4] composed: the reference's C1 / C2 read their misses from files inside the
+    // request, evlfu_8.cpp:380-414 get_from_file + the reader pool :191-250, :603-625): pinned host tables
+    // (evs_cache_set_backing) or file-backed ones (evs_cache_set_file_backing) under EITHER tier.  The pair then runs the
+    // host-tier order -- probe (hits and served alt rows stamped), both tiers' updates (each missing row fetched ONCE into its
+    // tier's arena: over the bus by the update kernel, or by the host's reader pool for staged tables), a patch kernel that
+    // points every missed position at the arena / staged copy, and only then the consumers.
+    const bool host2 = c1->host_backing || c2->host_backing;
+    const bool file2 = (c1->ft && c1->staged_mask) || (c2->ft && c2->staged_mask);
     // a pair that was given no policy takes the set-associative form where both tiers can (tables in HBM, at least one full
-    // set each); a tier with a policy of its own decides for the other; one set-associative and one hashed tier: refused
+    // set each), the sampled update over host-memory tables, the plan-based one when a tier has STAGED tables (its reader
+    // pool works between plan and assign); a tier with a policy of its own decides for the other; one set-associative and
+    // one hashed tier: refused
     {
         const bool free1 = c1->batch_policy < 0, free2 = c2->batch_policy < 0;
-        const bool sa_ok = !c1->ft && !c2->ft && c1->host.cap >= kSaWays && c2->host.cap >= kSaWays;
-        if (free1 && free2 && !(getenv("EVS_CACHE_POLICY"))) c1->batch_policy = c2->batch_policy = sa_ok ? 2 : 1;
+        const bool sa_ok = !host2 && !c1->ft && !c2->ft && c1->host.cap >= kSaWays && c2->host.cap >= kSaWays;
+        if (file2) {
+            if (free1) c1->batch_policy = 0;
+            if (free2) c2->batch_policy = 0;
+        } else if (free1 && free2 && !(getenv("EVS_CACHE_POLICY"))) c1->batch_policy = c2->batch_policy = sa_ok ? 2 : 1;
         else if (free1 != free2) {
             evs_cache *set = free1 ? c2 : c1, *unset = free1 ? c1 : c2;
             unset->batch_policy = (set->batch_policy == 2 && !sa_ok) ? 1 : set->batch_policy;
         }
         const int p1 = resolved_batch_policy(c1, true), p2 = resolved_batch_policy(c2, true);
         EVS_REQUIRE((p1 == 2) == (p2 == 2), "evs_cache_lookup_batch_c1c2: both tiers take the set-associative batch policy, or neither (C1 %d, C2 %d)", p1, p2);
+        if (p1 == 2 && host2) { set_error("evs_cache_lookup_batch_c1c2: the set-associative batch policy reads its miss tier in place from HBM (no host-memory / file-backed tables)"); return EVS_ESTATE; }
         EVS_REQUIRE(p1 != 2 || sa_ok, "evs_cache_lookup_batch_c1c2: the set-associative batch policy needs both tiers' tables in HBM and at least %d entries each", kSaWays);
+        if (file2 && (p1 != 0 || p2 != 0)) { set_error("evs_cache_lookup_batch_c1c2: a pair with staged file-backed tables takes the plan-based batch policy on both tiers (C1 %d, C2 %d)", p1, p2); return EVS_ESTATE; }
+        EVS_REQUIRE(!host2 || (p1 == p2), "evs_cache_lookup_batch_c1c2: tiers over host-memory / file-backed tables take the same batch policy (C1 %d, C2 %d)", p1, p2);
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     BatchArgs a1, a2;
@@ -3384,6 +3454,18 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     if (rc) return rc;
     const int T = c1->host.n_tables;
     const int wide = kNumCu * 8;
+    if (host2) {
+        for (int k = 0; k < 2; k++) {
+            evs_cache *c = k ? c2 : c1;
+            BatchArgs &a = k ? a2 : a1;
+            if (!c->estamp) {
+                EVS_HIP_CHECK(hipMalloc(&c->estamp, (long long)c->host.cap * 4));
+                EVS_HIP_CHECK(hipMemsetAsync(c->estamp, 0, (long long)c->host.cap * 4, st));
+            }
+            a.estamp = c->estamp; a.stamp_hits = 1;
+            a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;   // never 0, distinct for consecutive batches
+        }
+    }
     TwoTierArgs tt;
     tt.row_tier = c1->row_tier; tt.tier_out = tier; tt.threshold = high_agghit_threshold;
     tt.route_filter = nullptr; tt.route_mask = 0; tt.route_stamp = 0;
@@ -3420,7 +3502,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         for (int k = 0; k < 2; k++) {
             evs_cache *c = k ? c2 : c1;
             BatchArgs &a = k ? a2 : a1;
-            a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;
+            if (!host2) a.stamp = (int)(++c->stamp_counter % 0x7ffffffe) + 1;   // (host tiers: set above, with the hit stamps)
             a.tomb_parity = sa2 ? -1 : (a.stamp & 1);
             sampled_flush_if_wanted(c, st);
             static const bool c3_inline_on = !(getenv("EVS_CACHE_C3INLINE") && getenv("EVS_CACHE_C3INLINE")[0] == '0');
@@ -3450,7 +3532,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         // kernel block stages its victims in LDS: lists of at most kListVictMax records
         const long long lc = (B + 8 * (long long)a1.g1 - 1) / (8 * (long long)a1.g1) * 8 * T;
         static const bool list_on = !(getenv("EVS_CACHE_LIST2") && getenv("EVS_CACHE_LIST2")[0] == '0');
-        if (sa2 || (list_on && a1.g1 == a2.g1 && (!c3 || lc <= kListVictMax))) {
+        if (sa2 || (list_on && !host2 && a1.g1 == a2.g1 && (!c3 || lc <= kListVictMax))) {   // (host tiers: the patch kernel reads the per-position records)
             a1.miss_rec = c1->miss_rec; a1.list_cnt = c1->list_cnt; a1.list_cap = (int)lc;
             a2.miss_rec = c2->miss_rec; a2.list_cnt = c2->list_cnt; a2.list_cap = (int)lc;
         }
@@ -3462,7 +3544,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         a2.route_filter = c1->route_filter; a2.route_mask = kRouteWords - 1; a2.route_stamp = (unsigned)a1.stamp;
     }
     static const bool fold2_on = !(getenv("EVS_CACHE_FOLD2") && getenv("EVS_CACHE_FOLD2")[0] == '0');
-    const bool fold2 = fold2_on && sampled2 && a1.miss_rec && R && !out && B <= 65536 && T <= 32 &&
+    const bool fold2 = fold2_on && sampled2 && !host2 && a1.miss_rec && R && !out && B <= 65536 && T <= 32 &&
                        mixed84_supported(T, c1->host.dim, c1->host.codec, c2->host.codec);
     if (fold2) {
         Probe2Args pa;
@@ -3487,6 +3569,56 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         if (rc) return rc;
     } else
     hipLaunchKernelGGL(cache_batch_probe2_kernel, dim3((unsigned)a1.g1), dim3(256), 0, st, a1, a2, tt);
+    if (host2) {
+        // host-memory / file-backed miss tiers: updates first, then the re-pointed consumers
+        a2.row_ptrs = c1->row_ptrs;   // both tiers' positions live in C1's pointer table
+        if (sampled2) {
+            if (!a2.route_filter) { a2.other_slots = c1->bslots; a2.other_mask = (unsigned long long)(c1->bnslot - 1); }
+            launch_sampled_update(a1, st);   // per-position forms (a.miss_rec == NULL); the row of a new key is read by the one thread that inserts it
+            launch_sampled_update(a2, st);
+            if (c3 && !a1.c3_tags) hipLaunchKernelGGL(c3_batch_insert_lists_kernel, dim3(2 * kReplicas * 8), dim3(256), 0, st, a1, a2, tt.c3);
+        } else {
+            for (int k = 0; k < 2; k++) {
+                evs_cache *c = k ? c2 : c1;
+                BatchArgs &a = k ? a2 : a1;
+                const bool staged = c->ft && c->staged_mask;
+                if (staged) { rc = batch_stage_prepare(c, a, st); if (rc) return rc; }
+                if (k) { a2.other_slots = c1->bslots; a2.other_mask = (unsigned long long)(c1->bnslot - 1); }   // a key C1 just took is not inserted in C2 too
+                batch_policy_a(c, a, st);
+                if (staged) { rc = batch_stage_rows(c, a, st); if (rc) return rc; }   // the reader pool: each new key's row out of its file, once
+                batch_policy_b(c, a, st);
+                if (c3) hipLaunchKernelGGL(c3_batch_insert_kernel, dim3((unsigned)a.g2), dim3(256), 0, st, a, tt.c3);   // what this tier evicted
+            }
+        }
+        hipLaunchKernelGGL(cache_batch_patch_ptrs2_kernel, dim3((unsigned)a1.g2), dim3(256), 0, st, a1, a2, c1->row_tier);
+        if (out) {
+            long long nb = (B * T * (long long)c1->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
+            hipLaunchKernelGGL(cache_rows_from_ptrs2_kernel, dim3((unsigned)nb), dim3(256), 0, st, c1->row_ptrs, c1->row_tier, out,
+                               (long long)B, T, c1->host.dim, c1->host.codec, c2->host.codec);
+        }
+        if (R) {
+            rc = interact_from_mixed_rows(B, T, c1->host.dim, x, x_stride, c1->row_ptrs, c1->row_tier, c1->host.codec, c2->host.codec,
+                                          itself, R, st);
+            if (rc) return rc;
+        }
+        if (sampled2) {
+            c1->pending_batches++; c1->pending_requests += B;
+            c2->pending_batches++; c2->pending_requests += B;
+            volatile int *rep1 = reinterpret_cast<volatile int *>(c1->host_tomb);
+            const bool c1_known_full = rep1 && rep1[3] == 1 && (long long)rep1[2] >= c1->last_flush_call && c1->last_flush_call < c1->batch_calls;
+            if (!c1_known_full || c1->pending_batches >= kCloseEvery || c2->pending_batches >= kCloseEvery || a1.rebuild || a2.rebuild)
+                sampled_close_pending2(c1, a1.rebuild, c2, a2.rebuild, st);
+            batch_housekeeping(c1, a1, st);
+            batch_housekeeping(c2, a2, st);
+        } else {
+            if (c1->ft && c1->staged_mask) hipLaunchKernelGGL(cache_batch_unstage_kernel, dim3((unsigned)a1.g2), dim3(256), 0, st, a1);
+            if (c2->ft && c2->staged_mask) hipLaunchKernelGGL(cache_batch_unstage_kernel, dim3((unsigned)a2.g2), dim3(256), 0, st, a2);
+            batch_close(c1, a1, st);
+            batch_close(c2, a2, st);
+        }
+        EVS_HIP_CHECK(hipGetLastError());
+        return EVS_OK;
+    }
     if (out) {
         long long nb = (B * T * (long long)c1->host.dim / 4 + 255) / 256; if (nb > wide) nb = wide; if (nb < 1) nb = 1;
         hipLaunchKernelGGL(cache_rows_from_ptrs2_kernel, dim3((unsigned)nb), dim3(256), 0, st, c1->row_ptrs, c1->row_tier, out,

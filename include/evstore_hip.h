@@ -250,9 +250,9 @@ EVS_API int evs_cache_destroy(evs_cache *c);
 /* Miss path: tables[k] is DEVICE-ACCESSIBLE memory holding table k in the cache's codec
  * (HBM, or pinned host memory mapped into the device = the host-mmap miss tier,
  * emb_storage/mmap_file_read.py / evlfu_8.cpp:191-250); HOST arrays of n_tables entries.
- * With host-memory tables the batched lookups fetch each missing row once (de-duplicated,
- * into the arena) and serve the whole batch from HBM; hits of the running batch are never
- * evicted by it. */
+ * With host-memory tables the batched lookups (one tier, or the two- / three-tier forms) fetch
+ * each missing row once (de-duplicated, into the arena) and serve the whole batch from HBM; hits
+ * of the running batch are never evicted by it. */
 EVS_API int evs_cache_set_backing(evs_cache *c, const void *const *tables, const int64_t *n_rows);
 /* B requests replayed strictly in order (exact reference semantics; B=1 is the reference's
  * request_to_ev_lfu / request_to_lru / request_to_lfu).  rows: device (B, n_tables) int32;
@@ -313,7 +313,15 @@ EVS_API int evs_cache_set_batch_policy(evs_cache *c, int policy);
  * that holds it; a double miss is routed by the reference's rule (evlfu_8.cpp:570-601) evaluated on the snapshot
  * -- C1 not full: C1; C1 full and agg_hit < threshold: odd table index -> C1, even -> C2; else C2 -- served from
  * the destination tier's backing table at that tier's precision and inserted there once per batch.  out: (B,T,dim)
- * fp32; tier (B,T): 1 = C1 hit, 2 = C2 hit, 0 = miss.  Both caches take the batched path from then on. */
+ * fp32; tier (B,T): 1 = C1 hit, 2 = C2 hit, 0 = miss.  Both caches take the batched path from then on.
+ * MISS TIERS OUTSIDE HBM (BASELINE configs[4] composed; the reference's tiers read their misses from files inside the
+ * request: evlfu_8.cpp:380-414 get_from_file, reader pool :191-250, :603-625): either tier may sit over pinned host tables
+ * (evs_cache_set_backing) or file-backed ones (evs_cache_set_file_backing).  The pair then runs: probe (this batch's hits
+ * and served alt rows are pinned in their arenas) -> both tiers' policy updates, each missing row fetched ONCE into its
+ * tier's arena (over the bus by the thread that inserts it; staged tables: by the host's reader pool, de-duplicated) ->
+ * every missed position re-pointed at the arena / staged copy -> the consumers.  Policies: "sampled" over device-visible
+ * tables (pinned, registered), "plan" on BOTH tiers as soon as one has staged tables; "setassoc": EVS_ESTATE.  A position
+ * whose key another request of the batch routed to C1 (odd tables only) is served C1's copy at C1's precision. */
 EVS_API int evs_cache_lookup_batch_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
                                         uint8_t *tier, int high_agghit_threshold, void *stream);
 /* The same two-tier snapshot lookup with the interaction as its consumer (BASELINE configs[4] end to end):
@@ -360,7 +368,7 @@ EVS_API int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t max
  * plain mappings ("staged"): the batched lookup lists the batch's de-duplicated new keys, a pool of host threads copies
  * those rows out of the mappings into a pinned staging buffer and the fill kernel takes them from there -- every missing
  * row is read from the file once per batch.  evs_cache_set_file_backing replaces evs_cache_set_backing; with staged
- * tables only the batched lookups (evs_cache_lookup_batch / _interact) are served.  The tier outlives the cache's use
+ * tables only the batched lookups (evs_cache_lookup_batch / _interact, and the two- / three-tier forms) are served.  The tier outlives the cache's use
  * of it; evs_filetier_close unmaps.  evs_filetier_fetch is the reader pool itself (host memory in, host memory out). */
 typedef struct evs_filetier evs_filetier;
 EVS_API int evs_filetier_open(evs_filetier **out, int n_tables, const char *const *paths, int64_t row_bytes,
