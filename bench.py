@@ -117,6 +117,30 @@ def mixed_tiers_section(ev, ln_emb, d, B, dev, fill=180, steps=40, alpha=0.75):
     ms = timed(lambda r: gpu_cache.lookup_interact_c1c2c3(c1, c2, c3, r, x, tier=tier), fill + steps, fill + 2 * steps)
     _, st3 = c3.batch_dump()
     out["three_tier"] = {"ms_per_step": ms, "value": T * B / ms * 1e3, "c3_members": st3["members"], "alt_hits_served": st3["n_hit"]}
+    # configs[4] COMPOSED: the same tiers over a miss tier that is NOT in HBM -- the u8 / u4 tables in pinned host memory
+    # (the reference's C1 / C2 read their misses from files inside the request, evlfu_8.cpp:380-414); each missing row
+    # crosses the bus once per batch (de-duplicated insert), the batch is then served from the arenas
+    try:
+        h8 = [t.cpu().pin_memory() for t in ev8.raw]
+        h4 = [t.cpu().pin_memory() for t in ev4.raw]
+        c1h = E.GpuCache("evlfu", int(0.48 * budget) * 4, T, d, 8, "cpp", dev)
+        c2h = E.GpuCache("evlfu", int(0.48 * budget) * 8, T, d, 4, "cpp", dev)
+        c1h.set_backing(h8); c2h.set_backing(h4)
+        hfill, hsteps = min(fill, 120), min(steps, 20)
+        for r in rq[:hfill]:
+            gpu_cache.lookup_interact_c1c2(c1h, c2h, r, x, tier=tier)
+        s0 = (c1h.batch_stats(), c2h.batch_stats())
+        ms = timed(lambda r: gpu_cache.lookup_interact_c1c2(c1h, c2h, r, x, tier=tier), hfill, hfill + hsteps)
+        s1 = (c1h.batch_stats(), c2h.batch_stats())
+        hits = sum(b_["n_hits"] - a_["n_hits"] for a_, b_ in zip(s0, s1))
+        out["host_miss_tier"] = {"ms_per_step": ms, "value": T * B / ms * 1e3, "hit_rate": hits / (T * B * hsteps), "timed_batches": hsteps,
+                                 "c1_entries": s1[0]["size"], "c2_entries": s1[1]["size"], "policy": "sampled",
+                                 "note": "evs_cache_lookup_interact_c1c2 with BOTH tiers' tables (u8: %.2f GB, u4: %.2f GB) in pinned host memory: probe -> both tiers' "
+                                         "updates (every missing row over the bus once, into its tier's arena) -> pointer patch -> mixed-precision interaction"
+                                         % (sum(t.numel() for t in h8) / 1e9, sum(t.numel() for t in h4) / 1e9)}
+        del c1h, c2h, h8, h4
+    except Exception as e:   # pinning can fail on a small box
+        out["host_miss_tier"] = {"error": repr(e)}
     out.update({"unit": "lookups/s", "batch": B, "tiers": "u8 C1 + u4 C2 (+ alt-key C3), 48-48-4 of 2 % of the rows",
                 "policy": os.environ.get("EVS_CACHE_POLICY", "setassoc"),
                 "note": "batched lookups, probe + mixed-precision interaction in one launch, both tiers' updates in one launch "

@@ -880,7 +880,7 @@ struct BatchArgs {
     unsigned long long *c3_tags; long long c3_nset; long long *c3_stat;
     unsigned long long *evicted_keys;   // (alt-key tier attached) the key each free-stack position held before K4 put it there; bit 63 = flushed, not evicted
     int tomb_parity;                // sampled update: parity of this batch (its tombstones are kTomb1 when odd); -1 otherwise
-    unsigned sa_nset;               // set-associative policy (evs_hash.h): number of sets, a.ekey = the sets' key words, arena row = set * kSaWays + way; 0 otherwise
+    SaGeom sa; SaUniverse sau;      // set-associative policy (evs_hash.h): this tier's set records (sa.tags == nullptr otherwise), arena row = set * sa.ways + way
 };
 
 // One atomic per BLOCK instead of one per thread: every thread of the block calls this in uniform
@@ -958,13 +958,16 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         unsigned long long end_slot = 0;
         bool hint_tomb = false;
         int e = -1;
-        unsigned long long sa_w = 0ull;
-        if (args.sa_nset) {   // set-associative policy: one line, the priority inside the word
-            const unsigned set = ok ? sa_set_of(key, args.sa_nset) : 0u;
+        unsigned sa_w = 0u, sa_tag1 = 0u;
+        if (args.sa.tags) {   // set-associative policy: one line, the priority inside the word
+            unsigned set = 0u;
+            sa_split(args.sa, sa_perm(args.sau, args.sau.row_base[hl] + (ok ? (unsigned)row : 0u)), set, sa_tag1);
+            if (!ok) set = 0u;
             SaLine line;
-            sa_load(args.a.ekey, set, line);
-            const int way = sa_find(line, key, sa_w);
-            if (ok && way >= 0) e = (int)(set * (unsigned)kSaWays + (unsigned)way);
+            int way;
+            if (args.sa.ways == 8u) { sa_load<8>(args.sa, set, line); way = sa_find<8>(args.sa, line, sa_tag1, sa_w); }
+            else { sa_load<0>(args.sa, set, line); way = sa_find<0>(args.sa, line, sa_tag1, sa_w); }
+            if (ok && way >= 0) e = (int)(set * args.sa.ways + (unsigned)way);
             end_slot = set;
         } else {
             e = ok ? probe_ro(args.slots, args.mask, key, end_slot, args.tomb_parity == 1 ? kTomb : args.tomb_parity == 0 ? kTomb1 : kTomb, &hint_tomb) : -1;
@@ -973,9 +976,10 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         const unsigned long long hm = __ballot(e >= 0);
         const unsigned hmask = (unsigned)(half ? (hm >> 32) : hm);
         const int agg = __popc(hmask);
-        if (args.sa_nset) {
+        if (args.sa.tags) {
             if (e >= 0 && sa_prio(sa_w) < agg) {
-                const int old = sa_prio(atomicMax(&args.a.ekey[e], (sa_w & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                const unsigned es = (unsigned)e / args.sa.ways;
+                const int old = sa_prio(atomicMax(sa_ways_ptr(args.sa, es) + ((unsigned)e - es * args.sa.ways), sa_bump(sa_w, agg)));
                 if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
             }
         } else {
@@ -1013,7 +1017,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
                 const int at = base + __popc(mh & ((1u << hl) - 1u));
                 args.miss_rec[(long long)blockIdx.x * args.list_cap + at] =
                     make_uint4((unsigned)row, (unsigned)hl | ((unsigned)agg << 8) | (hint_tomb ? 0x10000u : 0u),
-                               (unsigned)(end_slot >> args.hint_shift), (unsigned)(req * T + hl));
+                               (unsigned)(end_slot >> args.hint_shift), args.sa.tags ? sa_tag1 : (unsigned)(req * T + hl));   // (set-associative lists: the set and the tag ARE the key)
             }
         }
         if (req_on && hl == 0) { atomicAdd(&s_sum[0], agg); if (agg == T) atomicAdd(&s_sum[1], 1); }
@@ -1084,7 +1088,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
     // snapshot: the policy kernels of this batch run later.  (Sampled update: a large cache stops a fraction of a per
     // cent short of its capacity -- the last free entries are not worth hunting -- so "full" has that much slack there.)
     const bool c1_full = a1.bs->count >= a1.cap - (a1.tomb_parity >= 0 && a1.cap > 65536 ? a1.cap / 256 : 0);
-    const bool sa = a1.sa_nset != 0;   // (both tiers or neither)
+    const bool sa = a1.sa.tags != nullptr;   // (both tiers or neither)
     const long long req_stride = (long long)gridDim.x * 8;
     for (long long req = (long long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half; req - half - (threadIdx.x >> 6) * 2 < a1.B;
          req += req_stride) {
@@ -1096,17 +1100,29 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         unsigned long long end1 = 0, end2 = 0;
         bool ht1 = false, ht2 = false;   // sampled update: is the hinted slot a (re-usable) tombstone
         int e1 = -1, e2 = -1;
-        unsigned long long w1 = 0ull, w2 = 0ull;
+        unsigned w1 = 0u, w2 = 0u, tg1 = 0u, tg2 = 0u;
         bool c1_room = !c1_full;
-        if (sa) {   // set-associative tiers: both tiers' set lines in one round trip; "C1 has room" = the key's C1 set has a free way
-            const unsigned s1 = ok ? sa_set_of(key, a1.sa_nset) : 0u, s2 = ok ? sa_set_of(key, a2.sa_nset) : 0u;
+        if (sa) {   // set-associative tiers: both tiers' ways of the key's set (a pair: ONE line) in one round trip; "C1 has room" = the key's C1 set has a free way
+            const unsigned px = sa_perm(a1.sau, a1.sau.row_base[hl] + (ok ? (unsigned)row : 0u));
+            unsigned s1 = 0u, s2 = 0u;
+            sa_split(a1.sa, px, s1, tg1);
+            sa_split(a2.sa, px, s2, tg2);
+            if (!ok) { s1 = 0u; s2 = 0u; }
             SaLine l1, l2;
-            sa_load(a1.a.ekey, s1, l1);
-            sa_load(a2.a.ekey, s2, l2);
-            const int y1 = sa_find(l1, key, w1), y2 = sa_find(l2, key, w2);
-            if (ok && y1 >= 0) e1 = (int)(s1 * (unsigned)kSaWays + (unsigned)y1);
-            else if (ok && y2 >= 0) e2 = (int)(s2 * (unsigned)kSaWays + (unsigned)y2);
-            c1_room = sa_has_free(l1);
+            int y1, y2;
+            if (a1.sa.ways == 8u && a2.sa.ways == 8u) {   // (the reference's 1 : 2 pair: way counts known to the compiler)
+                sa_load<8>(a1.sa, s1, l1);
+                sa_load<8>(a2.sa, s2, l2);
+                y1 = sa_find<8>(a1.sa, l1, tg1, w1); y2 = sa_find<8>(a2.sa, l2, tg2, w2);
+                c1_room = sa_has_free<8>(a1.sa, l1);
+            } else {
+                sa_load<0>(a1.sa, s1, l1);
+                sa_load<0>(a2.sa, s2, l2);
+                y1 = sa_find<0>(a1.sa, l1, tg1, w1); y2 = sa_find<0>(a2.sa, l2, tg2, w2);
+                c1_room = sa_has_free<0>(a1.sa, l1);
+            }
+            if (ok && y1 >= 0) e1 = (int)(s1 * a1.sa.ways + (unsigned)y1);
+            else if (ok && y2 >= 0) e2 = (int)(s2 * a2.sa.ways + (unsigned)y2);
             end1 = s1; end2 = s2;
         } else {
             e1 = ok ? probe_ro(a1.slots, a1.mask, key, end1, a1.tomb_parity == 1 ? kTomb : a1.tomb_parity == 0 ? kTomb1 : kTomb, &ht1) : -1;
@@ -1125,9 +1141,9 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
                 if (at >= 1 && at <= (unsigned)T && (long long)ar < a1.backing_rows[at - 1] && (long long)ar < a2.backing_rows[at - 1]) {
                     const unsigned long long akey = ((unsigned long long)at << 32) | ar;
                     unsigned long long es;
-                    ea = sa ? sa_lookup(a1.a.ekey, a1.sa_nset, akey) : probe_ro(a1.slots, a1.mask, akey, es);
+                    ea = sa ? sa_lookup(a1.sau, a1.sa, (int)at - 1, ar) : probe_ro(a1.slots, a1.mask, akey, es);
                     if (ea >= 0) alt_tier = 1;
-                    else { ea = sa ? sa_lookup(a2.a.ekey, a2.sa_nset, akey) : probe_ro(a2.slots, a2.mask, akey, es); if (ea >= 0) alt_tier = 2; }
+                    else { ea = sa ? sa_lookup(a2.sau, a2.sa, (int)at - 1, ar) : probe_ro(a2.slots, a2.mask, akey, es); if (ea >= 0) alt_tier = 2; }
                     if (alt_tier) atomicOr(&tt.c3.tags[w3], kC3Flag);   // set_recency_flag_c3
                 }
             }
@@ -1136,11 +1152,11 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         const int agg = __popc((unsigned)(half ? (hm >> 32) : hm));
         if (sa) {   // the priority rides in the key word: one atomicMax on it
             if (e1 >= 0 && sa_prio(w1) < agg) {
-                const int old = sa_prio(atomicMax(&a1.a.ekey[e1], (w1 & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                const int old = sa_prio(atomicMax(sa_ways_ptr(a1.sa, (unsigned)end1) + ((unsigned)e1 - (unsigned)end1 * a1.sa.ways), sa_bump(w1, agg)));
                 if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
             }
             if (e2 >= 0 && sa_prio(w2) < agg) {
-                const int old = sa_prio(atomicMax(&a2.a.ekey[e2], (w2 & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                const int old = sa_prio(atomicMax(sa_ways_ptr(a2.sa, (unsigned)end2) + ((unsigned)e2 - (unsigned)end2 * a2.sa.ways), sa_bump(w2, agg)));
                 if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
             }
         } else {
@@ -1200,7 +1216,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
                     const int at = base + __popc(mh & ((1u << hl) - 1u));
                     ak.miss_rec[(long long)blockIdx.x * ak.list_cap + at] =
                         make_uint4((unsigned)row, (unsigned)hl | ((unsigned)agg << 8) | ((k ? ht2 : ht1) ? 0x10000u : 0u),
-                                   (unsigned)((k ? end2 : end1) >> ak.hint_shift), (unsigned)(req * T + hl));
+                                   (unsigned)((k ? end2 : end1) >> ak.hint_shift), sa ? (k ? tg2 : tg1) : (unsigned)(req * T + hl));
                 }
             }
         }
@@ -1936,20 +1952,21 @@ template <> struct SaNative<NoTail> { using type = int; };
 // it -- the key itself (fold the priority, done) or another key of this batch (that way is out, next best).  The line
 // is read plainly: what a plain read can return is a word as it stood at the start of the launch or one written in it,
 // and a way changes at most once per launch (old -> stamped), which is all the argument needs.
-template <int PIECES, typename U, typename TAIL = NoTail>
-__device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsigned char *table, int t, unsigned row, int agg, unsigned set, int *s_delta, int *s_stat) {
+template <int PIECES, typename U, typename TAIL = NoTail, int W = 0>
+__device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsigned char *table, int t, unsigned row, int agg, unsigned set, unsigned tag1, int *s_delta, int *s_stat) {
+    constexpr int NW = W > 0 ? W : kSaMaxWays;   // ways the scans below walk (W = 0: any geometry, masked by args.sa.ways)
     const unsigned long long key = ((unsigned long long)(t + 1) << 32) | row;
     // two tiers: the other tier took this key in this very batch (only an odd table index can be routed both ways by two
     // requests of one batch: see sampled_insert_one)
     if (args.route_filter && (t & 1) && args.route_filter[mix64(key) & args.route_mask] == args.route_stamp) return;
-    unsigned long long *tags = args.a.ekey + (unsigned long long)set * kSaWays;
+    unsigned *tags = sa_ways_ptr(args.sa, set);
     // The set's line FIRST, then the source row, in that order in the instruction stream: vector-memory loads return in
     // order, so the CAS can go out when the line is there (an Infinity-Cache hit: the probe read it 20 us ago) while the
     // row -- a random line of a multi-GB table -- is still on its way.  The table base comes out of LDS: as a generic
     // pointer its loads would be flat_load (they count on lgkmcnt too and the compiler drains everything in front of
     // the CAS); through an address-space-1 pointer they are global_load.
     SaLine line;
-    sa_load(tags, 0u, line);
+    sa_load<W>(args.sa, set, line);
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char *srow = table + (long long)row * args.row_bytes;
     using NU = typename SaNative<U>::type;
@@ -1979,40 +1996,42 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
         rt = *reinterpret_cast<gtail_t>(reinterpret_cast<uintptr_t>(srow + PIECES * sizeof(U)));
     }
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned cur = (unsigned)args.stamp & kSaStampMask;
-    const unsigned long long neww = sa_word(key, cur, agg);
-    unsigned long long w[kSaWays];
+    const SaGeom &g = args.sa;
+    const unsigned cur = sa_cur_stamp(g, args.stamp);
+    const unsigned neww = sa_word(g, tag1, cur, agg);
+    unsigned w[NW];
 #pragma unroll
-    for (int j = 0; j < kSaWays / 2; j++) { w[2 * j] = line.v[j].x; w[2 * j + 1] = line.v[j].y; }
+    for (int j = 0; j < NW; j++) w[j] = sa_way_word(line, j);
     int way = -1, old_prio = -1;
-    unsigned long long old_key = 0ull;
+    unsigned old_word = 0u;
     bool done = false;
 #pragma unroll 1
-    for (int attempt = 0; attempt <= kSaWays && !done; attempt++) {
+    for (int attempt = 0; attempt <= NW && !done; attempt++) {
         int best = -1, bp = 0x7fffffff, dup = -1;
-        unsigned long long bw = 0ull, dw = 0ull;
+        unsigned bw = 0u, dw = 0u;
 #pragma unroll
-        for (int j = 0; j < kSaWays; j++) {
-            const bool is_dup = (w[j] & kKeyMask) == key;
+        for (int j = 0; j < NW; j++) {
+            const bool on = W > 0 || (unsigned)j < g.ways;
+            const bool is_dup = on && (w[j] & g.tag_mask) == tag1;
             dup = is_dup ? j : dup; dw = is_dup ? w[j] : dw;
-            const int pj = w[j] == kEmpty ? -1 : sa_prio(w[j]);
-            const bool cand = (w[j] == kEmpty || sa_stamp(w[j]) != cur) && pj < bp;
+            const int pj = w[j] == 0u ? -1 : sa_prio(w[j]);
+            const bool cand = on && (w[j] == 0u || sa_stamp(g, w[j]) != cur) && pj < bp;
             best = cand ? j : best; bp = cand ? pj : bp; bw = cand ? w[j] : bw;
         }
         if (dup >= 0) {   // another copy of the key got here first: its priority is the maximum over the copies
             if (sa_prio(dw) < agg) {
-                const int old = sa_prio(atomicMax(&tags[dup], (dw & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                const int old = sa_prio(atomicMax(&tags[dup], sa_bump(dw, agg)));
                 if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
             }
             done = true;
         } else if (best < 0) {
             done = true;   // every way of the set was filled in this batch: the key is not kept
         } else {
-            const unsigned long long prev = atomicCAS(&tags[best], bw, neww);
-            if (prev == bw) { way = best; old_prio = bp; old_key = bw & kKeyMask; done = true; }
+            const unsigned prev = atomicCAS(&tags[best], bw, neww);
+            if (prev == bw) { way = best; old_prio = bp; old_word = bw; done = true; }
             else {
 #pragma unroll
-                for (int j = 0; j < kSaWays; j++) w[j] = j == best ? prev : w[j];
+                for (int j = 0; j < NW; j++) w[j] = j == best ? prev : w[j];
             }
         }
     }
@@ -2020,7 +2039,7 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
     if (old_prio >= 0) { atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); }
     else atomicAdd(&s_stat[0], 1);
     atomicAdd(&s_delta[agg], 1);
-    unsigned char *drow = args.a.arena + ((long long)set * kSaWays + way) * args.row_bytes;
+    unsigned char *drow = args.a.arena + ((long long)set * g.ways + way) * args.row_bytes;
     if constexpr (PIECES > 0) {
         if constexpr (PIECES > 0) reinterpret_cast<NU *>(drow)[0] = r0;
         if constexpr (PIECES > 1) reinterpret_cast<NU *>(drow)[1] = r1;
@@ -2042,7 +2061,7 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
     } else if ((args.row_bytes & 15) == 0) { for (int c = 0; c < args.row_bytes; c += 16) *reinterpret_cast<float4 *>(drow + c) = *reinterpret_cast<const float4 *>(srow + c); }
     else { for (int c = 0; c < args.row_bytes; c++) drow[c] = srow[c]; }
     // three tiers: what this thread evicted becomes a member of the alt-key set (evlfu_8.cpp:617-620,654-658), behind its own stores
-    if (old_prio >= 0 && args.c3_tags != nullptr) c3_insert_key(C3Set{args.c3_tags, args.c3_nset, args.c3_stat}, old_key);
+    if (old_prio >= 0 && args.c3_tags != nullptr) c3_insert_key(C3Set{args.c3_tags, args.c3_nset, args.c3_stat}, sa_key_of(args.sau, g, set, old_word));
 }
 
 template <int PIECES, typename U, typename TAIL = NoTail>
@@ -2113,11 +2132,17 @@ __device__ __forceinline__ void sa_list_block(const BatchArgs &args, int bid) {
     uint4 r = rec[i0 < args.list_cap ? i0 : 0];
     if (threadIdx.x < 32) s_table[threadIdx.x] = args.backing[threadIdx.x];
     __syncthreads();
-    for (int i = i0; i < n; i += 64 * nw) {
-        if (i != i0) r = rec[i];
-        const int t = (int)(r.y & 0xffu);
-        sa_insert_one<PIECES, U, TAIL>(args, s_table[t & 31], t, r.x, (int)((r.y >> 8) & 0xffu), r.z, s_delta, s_stat);
-    }
+    // (the usual geometry -- 8-way sets: a tier alone, both tiers of the reference's 1 : 2 pair -- with the way count known to the compiler)
+    auto run = [&](auto wc) {
+        constexpr int W = decltype(wc)::value;
+        for (int i = i0; i < n; i += 64 * nw) {
+            if (i != i0) r = rec[i];
+            const int t = (int)(r.y & 0xffu);
+            sa_insert_one<PIECES, U, TAIL, W>(args, s_table[t & 31], t, r.x, (int)((r.y >> 8) & 0xffu), r.z, r.w, s_delta, s_stat);
+        }
+    };
+    if (args.sa.ways == 8u) run(std::integral_constant<int, 8>{});
+    else run(std::integral_constant<int, 0>{});
     __syncthreads();
     if (threadIdx.x < kPartCols) {
         const int i = threadIdx.x;
@@ -2256,7 +2281,7 @@ __global__ void __launch_bounds__(256) cache_batch_sampled_flush_kernel(BatchSta
     if (threadIdx.x == 0 && s_gone) atomicAdd(&b->flush_gone, s_gone);
 }
 // the same for the set-associative policy: the top-priority ways, first come first served over the sets
-__global__ void __launch_bounds__(256) cache_batch_sa_flush_kernel(BatchState *b, unsigned long long *tags, long long n_ent, int T, int flush_n, int max_perfect) {
+__global__ void __launch_bounds__(256) cache_batch_sa_flush_kernel(BatchState *b, const SaGeom g, int T, int flush_n, int max_perfect) {
     __shared__ int s_tot[8];
     __shared__ int s_gone;
     const int top_n = b->cnt[T];
@@ -2264,12 +2289,15 @@ __global__ void __launch_bounds__(256) cache_batch_sa_flush_kernel(BatchState *b
     if (threadIdx.x == 0) s_gone = 0;
     const int want = flush_n < top_n ? flush_n : top_n;
     __syncthreads();
+    const long long n_ent = ((long long)g.nset << g.sub_shift) * g.ways;
     for (long long e0 = (long long)blockIdx.x * blockDim.x; e0 < n_ent; e0 += (long long)gridDim.x * blockDim.x) {   // block-uniform trip count
         const long long e = e0 + threadIdx.x;
-        const unsigned long long w = e < n_ent ? tags[e] : kEmpty;
-        const bool top = w != kEmpty && sa_prio(w) == T;
+        const unsigned es = (unsigned)((e < n_ent ? e : 0) / g.ways);
+        unsigned *wp = sa_ways_ptr(g, es) + (unsigned)((e < n_ent ? e : 0) - (long long)es * g.ways);
+        const unsigned w = e < n_ent ? *wp : 0u;
+        const bool top = w != 0u && sa_prio(w) == T;
         const int tk = block_reserve(&b->ticket_t, top, s_tot);
-        if (top && tk < want) { tags[e] = kEmpty; atomicAdd(&s_gone, 1); }
+        if (top && tk < want) { *wp = 0u; atomicAdd(&s_gone, 1); }
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_gone) atomicAdd(&b->flush_gone, s_gone);
@@ -2522,8 +2550,109 @@ struct evs_cache {
     unsigned *route_filter = nullptr;   // two-tier sampled update (held by C1): see BatchArgs::route_filter
     unsigned long long *vict_keys = nullptr; int *vict_cnt = nullptr; long long vict_cap = 0;   // ... what the sampled update evicted (kReplicas lists)   // tombstone housekeeping: a sweep first, a rebuild if that was not enough
     int batch_policy = -1;         // policy update of the batched path: 0 plan-based (K2..K6), 1 sampled (one kernel), 2 set-associative (evs_hash.h); -1: EVS_CACHE_POLICY, default sampled
-    unsigned sa_nset = 0;          // set-associative policy: number of sets (capacity / kSaWays)
+    // set-associative policy (evs_hash.h): this tier's view of the set records and the key universe; the words themselves
+    // are one allocation a tier PAIR shares (ONE 128-byte record per set: both tiers' ways)
+    evs::SaGeom sa{};
+    evs::SaUniverse sau{};
+    struct SaShared { unsigned *tags = nullptr; size_t bytes = 0; int refs = 0; } *sa_mem = nullptr;
 };
+
+// ---- set-associative geometry (host) ----
+namespace {
+constexpr unsigned kSaSingleWays = 8;    // a tier alone: 8 ways = a 32-byte record (EVS_SA_WAYS=16: 64 bytes, developer A/B)
+bool sa_make_universe(const long long *rows1, const long long *rows2, int T, evs::SaUniverse &u) {
+    unsigned long long n = 0;
+    if (T > 32) return false;
+    for (int t = 0; t < 32; t++) {
+        u.row_base[t] = (unsigned)n;
+        if (t < T) n += (unsigned long long)std::max<long long>(rows1[t], rows2 ? rows2[t] : 0);
+        if (n >= (1ull << 32)) return false;
+    }
+    int b = 1;
+    while ((1ull << b) < n) b++;
+    u.mask = b == 32 ? 0xffffffffu : (1u << b) - 1u;
+    u.half = (unsigned)(b + 1) / 2u;
+    u.n_tables = T;
+    return true;
+}
+bool sa_make_geom(evs::SaGeom &g, unsigned nset, unsigned ways, unsigned w_off, unsigned line_words, const evs::SaUniverse &u, unsigned sub_shift = 0) {
+    if (nset < 1 || ways < 1 || ways > (unsigned)evs::kSaMaxWays || (w_off & 3u) || (sub_shift && (ways & 3u))) return false;
+    g.tags = nullptr; g.nset = nset; g.ways = ways; g.w_off = w_off; g.line_words = line_words; g.sub_shift = sub_shift;
+    unsigned l = 0;
+    while ((1ull << l) < nset) l++;
+    g.div_l = l;
+    g.div_m = nset > 1 ? (unsigned)(((1ull << 32) * ((1ull << l) - nset)) / nset + 1ull) : 0u;
+    const unsigned max_tag1 = ((u.mask / nset) >> sub_shift) + 1u;
+    unsigned tb = 1;
+    while (tb < 32 && (max_tag1 >> tb)) tb++;
+    if (tb > 22) return false;   // (at least 4 stamp bits)
+    g.tag_bits = tb; g.tag_mask = (1u << tb) - 1u;
+    return true;
+}
+unsigned sa_single_ways() {
+    static int w = -1;
+    if (w < 0) { const char *e = getenv("EVS_SA_WAYS"); w = (e && atoi(e) == 16) ? 16 : (int)kSaSingleWays; }
+    return (unsigned)w;
+}
+// can this cache take the set-associative form on its own (universe below 2^32 keys, tags that fit the word)
+bool sa_single_feasible(const evs_cache *c, evs::SaUniverse *u_out = nullptr, evs::SaGeom *g_out = nullptr) {
+    evs::SaUniverse u; evs::SaGeom g;
+    const unsigned ways = sa_single_ways();
+    if (!c->has_backing || c->host.cap < (long long)ways) return false;
+    if (!sa_make_universe(c->backing_rows, nullptr, c->host.n_tables, u)) return false;
+    if (!sa_make_geom(g, (unsigned)(c->host.cap / ways), ways, 0, ways, u)) return false;
+    if (u_out) *u_out = u;
+    if (g_out) *g_out = g;
+    return true;
+}
+// the geometry of a C1 + C2 pair that shares its set records: nset records of 128 bytes, C1's ways at word 0, C2's behind
+// them.  nset = max(cap1 / 8, ceil(cap2 / 16)); C1 min(cap1 / nset, 16) ways; C2 TWO sub-sets of 8 ways when cap2 >= 16 nset
+// (the reference's 1 : 2 split, evlfu_8.cpp:63-78: C1 8 ways + C2 2 x 8, every probe an 8-way search of 32 bytes), else
+// min(cap2 / nset, 16) ways in one.  false: no such geometry (a tier would get fewer than 4 ways) -- each tier then keeps
+// records of its own (two line requests per key)
+bool sa_pair_geometry(const evs_cache *c1, const evs_cache *c2, evs::SaUniverse &u, evs::SaGeom &g1, evs::SaGeom &g2) {
+    static const bool on = !(getenv("EVS_SA_PAIR") && getenv("EVS_SA_PAIR")[0] == '0');
+    if (!on || !c1->has_backing || !c2->has_backing || c1->host.n_tables != c2->host.n_tables) return false;
+    const long long cap1 = c1->host.cap, cap2 = c2->host.cap;
+    long long nset = std::max<long long>(std::max<long long>(cap1 / 8, (cap2 + 15) / 16), 1);
+    const long long w1 = std::min<long long>(cap1 / nset, evs::kSaMaxWays);
+    long long w2 = std::min<long long>(cap2 / nset, evs::kSaMaxWays);
+    unsigned sub2 = 0;
+    if (w2 == 16) { w2 = 8; sub2 = 1; }
+    if (w1 < 4 || w2 < 4) return false;
+    if (!sa_make_universe(c1->backing_rows, c2->backing_rows, c1->host.n_tables, u)) return false;
+    const unsigned off2 = (unsigned)((w1 + 3) / 4 * 4);
+    return sa_make_geom(g1, (unsigned)nset, (unsigned)w1, 0, 32, u) && sa_make_geom(g2, (unsigned)nset, (unsigned)w2, off2, 32, u, sub2);
+}
+int sa_alloc(evs_cache *c, evs_cache *partner, hipStream_t st) {   // the set records of c (shared with partner), zeroed on st
+    auto *m = new evs_cache::SaShared();
+    m->bytes = (size_t)c->sa.nset * c->sa.line_words * 4;
+    static const long long pad_mb = getenv("EVS_SA_PAD_MB") ? atoll(getenv("EVS_SA_PAD_MB")) : 0;   // developer A/B: allocation size vs page size
+    const size_t alloc = std::max<size_t>(m->bytes, (size_t)pad_mb << 20);
+    if (hipMalloc(&m->tags, alloc) != hipSuccess) { (void)hipGetLastError(); delete m; return EVS_ENOMEM; }
+    if (hipMemsetAsync(m->tags, 0, m->bytes, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(m->tags); delete m; return EVS_EHIP; }
+    m->refs = partner ? 2 : 1;
+    c->sa_mem = m; c->sa.tags = m->tags;
+    if (partner) { partner->sa_mem = m; partner->sa.tags = m->tags; }
+    return EVS_OK;
+}
+void sa_release(evs_cache *c) {
+    if (!c->sa_mem) return;
+    if (--c->sa_mem->refs == 0) { (void)hipFree(c->sa_mem->tags); delete c->sa_mem; }
+    c->sa_mem = nullptr; c->sa.tags = nullptr;
+}
+// host restatement of sa_key_of (evs_hash.h)
+unsigned long long sa_key_of_host(const evs::SaUniverse &u, const evs::SaGeom &g, unsigned es, unsigned w) {
+    const unsigned q = (((w & g.tag_mask) - 1u) << g.sub_shift) | (es & ((1u << g.sub_shift) - 1u));
+    unsigned x = q * g.nset + (es >> g.sub_shift);
+    x ^= x >> u.half; x = (x * evs::kSaInv2) & u.mask;
+    x ^= x >> u.half; x = (x * evs::kSaInv1) & u.mask;
+    int t = 0;
+    for (int k = 1; k < u.n_tables; k++) if (x >= u.row_base[k]) t = k;
+    return ((unsigned long long)(t + 1) << 32) | (x - u.row_base[t]);
+}
+}  // namespace
+
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
@@ -2536,6 +2665,7 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
+    sa_release(c);
     delete c;
     return EVS_OK;
 }
@@ -2668,7 +2798,7 @@ extern "C" int64_t evs_cache_staged_rows(evs_cache *c) { return c ? c->n_staged_
 extern "C" int evs_cache_set_batch_policy(evs_cache *c, int policy) {
     using namespace evs;
     EVS_REQUIRE(c && policy >= 0 && policy <= 2, "evs_cache_set_batch_policy: bad argument");
-    EVS_REQUIRE(policy != 2 || c->host.cap >= kSaWays, "evs_cache_set_batch_policy: the set-associative policy needs a capacity of at least %d entries", kSaWays);
+    EVS_REQUIRE(policy != 2 || c->host.cap >= (long long)kSaSingleWays, "evs_cache_set_batch_policy: the set-associative policy needs a capacity of at least %d entries", (int)kSaSingleWays);
     if (c->used == 2) { set_error("evs_cache_set_batch_policy: the batched path is already in use"); return EVS_ESTATE; }
     c->batch_policy = policy;
     return EVS_OK;
@@ -2781,8 +2911,15 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     EVS_REQUIRE(B > 0 && B < (1ll << 31) / 32 && rows, "%s: bad argument", who);
     const int T = c->host.n_tables;
     const long long cap = c->host.cap;
-    const bool sa = resolved_batch_policy(c) == 2;   // set-associative policy: no hash, no entry arrays (the key words of the sets are c->a.ekey)
-    if (sa) c->sa_nset = (unsigned)(cap / kSaWays);
+    const bool sa = resolved_batch_policy(c) == 2;   // set-associative policy: no hash, no entry arrays (the set records: c->sa)
+    if (sa && !c->sa.tags) {   // (a tier that starts out in a pair got its geometry there: batch_c1c2_impl)
+        if (!sa_single_feasible(c, &c->sau, &c->sa)) {
+            set_error("%s: the set-associative batch policy needs fewer than 2^32 rows over all tables and a capacity of at least rows / 2^19 entries", who);
+            return EVS_EINVAL;
+        }
+        const int arc = sa_alloc(c, nullptr, st);
+        if (arc) { set_error("%s: allocating the set records failed", who); return arc; }
+    }
     const long long hash_words = sa ? 1 : c->bnslot;
     if (!c->bs) {   // first batched call: all-or-nothing, so a failed allocation leaves the cache as it was
         BatchState h{};
@@ -2867,7 +3004,8 @@ static int batch_prepare(evs_cache *c, int64_t B, const int32_t *rows, hipStream
     // three calls the sweep did not help enough and the hash is rebuilt.
     a.evicted_keys = nullptr; a.vict_cnt = nullptr; a.vict_other = nullptr; a.vict_cap = 0; a.c3_tags = nullptr; a.c3_nset = 0; a.c3_stat = nullptr; a.miss_rec = nullptr; a.list_cnt = nullptr; a.list_cap = 0;
     a.tomb_parity = -1;
-    a.sa_nset = sa ? c->sa_nset : 0u;
+    a.sa = c->sa; a.sau = c->sau;
+    if (!sa) a.sa.tags = nullptr;
     a.rebuild = 0;
     c->batch_calls++;   // = the ordinal of this call's close
     if (!sa) {
@@ -3064,7 +3202,7 @@ static bool launch_sampled_update_pair(const evs::BatchArgs &a1, const evs::Batc
 static int resolved_batch_policy(evs_cache *c, bool single_tier) {
     if (c->batch_policy < 0) {
         const char *e = getenv("EVS_CACHE_POLICY");
-        const bool sa_ok = single_tier && !c->host_backing && !c->ft && c->host.cap >= evs::kSaWays;
+        const bool sa_ok = single_tier && !c->host_backing && !c->ft && sa_single_feasible(c);
         if (e && e[0] == 'p') c->batch_policy = 0;
         else if (e && e[0] == 's' && e[1] == 'a') c->batch_policy = 1;
         else c->batch_policy = sa_ok ? 2 : 1;
@@ -3108,7 +3246,7 @@ static void sampled_flush_if_wanted(evs_cache *c, hipStream_t st) {
     const int wide = kNumCu * 8;
     long long nf = ((long long)c->host.cap + 255) / 256; if (nf > wide) nf = wide;
     if (c->batch_policy == 2) {
-        hipLaunchKernelGGL(cache_batch_sa_flush_kernel, dim3((unsigned)nf), dim3(256), 0, st, c->bs, c->a.ekey, (long long)c->sa_nset * kSaWays,
+        hipLaunchKernelGGL(cache_batch_sa_flush_kernel, dim3((unsigned)nf), dim3(256), 0, st, c->bs, c->sa,
                            c->host.n_tables, c->host.flush_n, c->host.max_perfect);
         hipLaunchKernelGGL(cache_batch_sampled_flush_finish_kernel, dim3(1), dim3(1), 0, st, c->bs, c->host.n_tables);
         return;
@@ -3197,14 +3335,14 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         a.miss_rec = c->miss_rec; a.list_cnt = c->list_cnt;
         a.list_cap = (int)((B + 8 * (long long)a.g1 - 1) / (8 * (long long)a.g1)) * 8 * T;
         static const bool fold_on = !(getenv("EVS_CACHE_FOLD") && getenv("EVS_CACHE_FOLD")[0] == '0');
-        const bool fold = fold_on && a.row_ids && R && !out;
+        const bool fold = fold_on && a.row_ids && R && !out && c->sa.ways == 8;   // (the folded probe is compiled for 8-way sets)
         if (fold) {
             ProbeArgs pa;
             pa.slots = nullptr; pa.mask = 0; pa.reusable_tomb = kTomb; pa.eagg = nullptr;
             pa.requests = rows; pa.hit = hit;
             pa.miss_rec = a.miss_rec; pa.list_cnt = a.list_cnt; pa.list_cap = 16 * T;
             pa.part1 = a.part1; pa.hint_shift = 0; pa.T = T;
-            pa.tags = c->a.ekey; pa.sa_nset = c->sa_nset;
+            pa.sa = c->sa; pa.sau = c->sau;
             a.list_cap = 16 * T;
             a.g1 = (int)((B + 15) / 16);
             const int rc = fused_probe_interact(B, T, c->host.dim, x, x_stride, pa, c->a.arena,
@@ -3260,7 +3398,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
             pa.eagg = a.a.eagg; pa.requests = rows; pa.hit = hit;
             pa.miss_rec = a.miss_rec; pa.list_cnt = a.list_cnt; pa.list_cap = 16 * T;
             pa.part1 = a.part1; pa.hint_shift = a.hint_shift; pa.T = T;
-            pa.tags = nullptr; pa.sa_nset = 0;
+            pa.sa = evs::SaGeom{}; pa.sau = c->sau;
             a.list_cap = 16 * T;
             a.g1 = (int)((B + 15) / 16);   // the update kernel runs one wave per list: here a list per 16-sample block
             const int rc = fused_probe_interact(B, T, c->host.dim, x, x_stride, pa, c->a.arena,
@@ -3430,7 +3568,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     // one hashed tier: refused
     {
         const bool free1 = c1->batch_policy < 0, free2 = c2->batch_policy < 0;
-        const bool sa_ok = !host2 && !c1->ft && !c2->ft && c1->host.cap >= kSaWays && c2->host.cap >= kSaWays;
+        const bool sa_ok = !host2 && !c1->ft && !c2->ft && (c1->sa.tags || sa_single_feasible(c1)) && (c2->sa.tags || sa_single_feasible(c2));
         if (file2) {
             if (free1) c1->batch_policy = 0;
             if (free2) c2->batch_policy = 0;
@@ -3442,11 +3580,21 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
         const int p1 = resolved_batch_policy(c1, true), p2 = resolved_batch_policy(c2, true);
         EVS_REQUIRE((p1 == 2) == (p2 == 2), "evs_cache_lookup_batch_c1c2: both tiers take the set-associative batch policy, or neither (C1 %d, C2 %d)", p1, p2);
         if (p1 == 2 && host2) { set_error("evs_cache_lookup_batch_c1c2: the set-associative batch policy reads its miss tier in place from HBM (no host-memory / file-backed tables)"); return EVS_ESTATE; }
-        EVS_REQUIRE(p1 != 2 || sa_ok, "evs_cache_lookup_batch_c1c2: the set-associative batch policy needs both tiers' tables in HBM and at least %d entries each", kSaWays);
+        EVS_REQUIRE(p1 != 2 || sa_ok, "evs_cache_lookup_batch_c1c2: the set-associative batch policy needs both tiers' tables in HBM and at least %d entries each", (int)kSaSingleWays);
         if (file2 && (p1 != 0 || p2 != 0)) { set_error("evs_cache_lookup_batch_c1c2: a pair with staged file-backed tables takes the plan-based batch policy on both tiers (C1 %d, C2 %d)", p1, p2); return EVS_ESTATE; }
         EVS_REQUIRE(!host2 || (p1 == p2), "evs_cache_lookup_batch_c1c2: tiers over host-memory / file-backed tables take the same batch policy (C1 %d, C2 %d)", p1, p2);
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // two set-associative tiers that start out together share their set records: ONE 128-byte record per set holds C1's and
+    // C2's ways, so a key's two probes are one line request (a tier that was used alone before keeps records of its own)
+    if (resolved_batch_policy(c1) == 2 && !c1->sa.tags && !c2->sa.tags && !c1->bs && !c2->bs) {
+        SaUniverse u; SaGeom g1, g2;
+        if (sa_pair_geometry(c1, c2, u, g1, g2)) {
+            c1->sau = u; c2->sau = u; c1->sa = g1; c2->sa = g2;
+            const int arc = sa_alloc(c1, c2, st);
+            if (arc) { c1->sa = SaGeom{}; c2->sa = SaGeom{}; set_error("evs_cache_lookup_batch_c1c2: allocating the set records failed"); return arc; }
+        }
+    }
     BatchArgs a1, a2;
     int rc = batch_prepare(c1, B, rows, st, a1, "evs_cache_lookup_batch_c1c2");
     if (rc) return rc;
@@ -3545,6 +3693,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     }
     static const bool fold2_on = !(getenv("EVS_CACHE_FOLD2") && getenv("EVS_CACHE_FOLD2")[0] == '0');
     const bool fold2 = fold2_on && sampled2 && !host2 && a1.miss_rec && R && !out && B <= 65536 && T <= 32 &&
+                       (!sa2 || (c1->sa.ways == 8 && c2->sa.ways == 8)) &&   // (the folded probe is compiled for 8-way sets)
                        mixed84_supported(T, c1->host.dim, c1->host.codec, c2->host.codec);
     if (fold2) {
         Probe2Args pa;
@@ -3559,11 +3708,12 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             for (int t = 0; t < 32; t++) { tp.backing[t] = t < T ? a.backing[t] : nullptr; tp.backing_rows[t] = t < T ? a.backing_rows[t] : 0; }
             tp.miss_rec = a.miss_rec; tp.list_cnt = a.list_cnt; tp.part1 = a.part1; tp.hint_shift = a.hint_shift;
             tp.count = &a.bs->count; tp.cap = a.cap; tp.full_slack = a.cap > 65536 ? a.cap / 256 : 0;
-            tp.tags = sa2 ? a.a.ekey : nullptr; tp.sa_nset = sa2 ? a.sa_nset : 0u;
+            tp.sa = a.sa;
             (void)c;
         }
         pa.requests = rows; pa.tier_out = tier; pa.threshold = high_agghit_threshold; pa.T = T; pa.list_cap = 16 * T;
         pa.c3 = tt.c3;
+        pa.sau = a1.sau;
         pa.route_filter = tt.route_filter; pa.route_mask = tt.route_mask; pa.route_stamp = tt.route_stamp;
         rc = probe2_interact_mixed84(B, T, c1->host.dim, x, x_stride, pa, itself, R, st);
         if (rc) return rc;
@@ -3716,16 +3866,29 @@ extern "C" int64_t evs_cache_batch_dump(evs_cache *c, int64_t *triples, int64_t 
     sampled_flush_if_wanted(c, reinterpret_cast<hipStream_t>(stream));
     if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return EVS_EHIP;
     const int64_t cap = c->host.cap;
+    int64_t n = 0;
+    if (c->batch_policy == 2 && c->sa.tags) {   // set-associative policy: (set, tag) is the key, the priority rides in the word
+        const evs::SaGeom &g = c->sa;
+        std::vector<unsigned> tags((size_t)g.nset * g.line_words);
+        if (hipMemcpy(tags.data(), g.tags, tags.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
+        for (unsigned es = 0; es < (g.nset << g.sub_shift); es++)
+            for (unsigned w = 0; w < g.ways; w++) {
+                const unsigned word = tags[(size_t)(es >> g.sub_shift) * g.line_words + g.w_off + (es & ((1u << g.sub_shift) - 1u)) * g.ways + w];
+                if (!word) continue;
+                const unsigned long long key = sa_key_of_host(c->sau, g, es, word);
+                if (n < max_triples && triples) { triples[3 * n] = (int64_t)(word >> evs::kSaPrioShift); triples[3 * n + 1] = (int64_t)(key >> 32); triples[3 * n + 2] = (int64_t)(key & 0xffffffffull); }
+                n++;
+            }
+        return n;
+    }
     std::vector<unsigned long long> ekey(cap);
     std::vector<int> eagg(cap);
     if (hipMemcpy(ekey.data(), c->a.ekey, cap * 8, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
     if (hipMemcpy(eagg.data(), c->a.eagg, cap * 4, hipMemcpyDeviceToHost) != hipSuccess) return EVS_EHIP;
-    int64_t n = 0;
     for (int64_t e = 0; e < cap; e++) {
         const unsigned long long key = ekey[e] & evs::kKeyMask;
         if (!key) continue;   // (the sampled update keeps a batch stamp above the key)
-        const int64_t prio = c->batch_policy == 2 ? (int64_t)(ekey[e] >> evs::kSaPrioShift) : eagg[e];   // (set-associative policy: the priority rides in the key word)
-        if (n < max_triples && triples) { triples[3 * n] = prio; triples[3 * n + 1] = (int64_t)(key >> 32); triples[3 * n + 2] = (int64_t)(key & 0xffffffffull); }
+        if (n < max_triples && triples) { triples[3 * n] = eagg[e]; triples[3 * n + 1] = (int64_t)(key >> 32); triples[3 * n + 2] = (int64_t)(key & 0xffffffffull); }
         n++;
     }
     return n;

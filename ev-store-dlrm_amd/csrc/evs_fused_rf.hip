@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
     __shared__ int s_tile_kind[32];                                       // 0 absent, 1 dense (x, received pooled vectors), 2 table
     __shared__ unsigned long long s_feat_base[32];                        // per feature: first row / bytes between rows -- read per
     __shared__ unsigned s_feat_scale[32];                                 // load instead of living in 12 VGPRs per lane
+    __shared__ unsigned s_sa_base[PROBE ? 32 : 1];                        // PROBE, set-associative cache: dense row number of row 0 of feature f's table
     __shared__ const int64_t *s_tile_o[CHECK ? 32 : 1];                   // CHECK: offsets arrays, their readable entries, nnz
     __shared__ int64_t s_tile_ol[CHECK ? 32 : 1], s_tile_nz[CHECK ? 32 : 1];
     constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
@@ -152,6 +153,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         s_tile_kind[f] = !on ? 0 : (table ? 2 : 1);
         s_feat_base[f] = !on ? 0ull : ((multi && f == 0) ? mx : src);
         s_feat_scale[f] = !on ? 0u : (table ? (unsigned)row_bytes : (unsigned)(stride * 4));
+        if constexpr (PROBE) s_sa_base[f] = ka->probe.sau.row_base[(f + 31) & 31];   // (feature f = table f - 1; unconditional read, as above)
         if constexpr (CHECK) {
             s_tile_o[f] = table ? (multi ? mo + (int64_t)(f - 1) * args.multi_off_stride : op) : nullptr;
             s_tile_ol[f] = table ? ol : 0;
@@ -512,7 +514,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         if (threadIdx.x == 0) s_nlist = 0;
         __syncthreads();
         int pe[2], prow[2], pprio[2];
-        unsigned phint[2];
+        unsigned phint[2], ptag[2];
         bool pok[2], ptomb[2], pact[2];
         unsigned long long pkey[2], phome[2], pw0[2];
         const int64_t bs = blk_first + (threadIdx.x & 15);
@@ -525,27 +527,34 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             const int *rp = pact[h] ? pa.requests + bs * (int64_t)T + (f - 1) : reinterpret_cast<const int *>(dummy_i);
             prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
         }
-        const bool sa = pa.sa_nset != 0;   // set-associative cache (evs_hash.h): one line per key, the priority inside the key word
+        const bool sa = pa.sa.tags != nullptr;   // set-associative cache (evs_hash.h): one line per key, the priority inside the way word
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
-            pok[h] = pact[h] && prow[h] >= 0 && (unsigned)prow[h] < s_tile_nr[f];
+            const unsigned nrf = s_tile_nr[f & 31];
+            pok[h] = pact[h] & (prow[h] >= 0) & ((unsigned)prow[h] < nrf);
             pkey[h] = ((unsigned long long)f << 32) | (unsigned)prow[h];   // table_1based = f
         }
         if (sa) {
-            SaLine line[2];
             unsigned pset[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                pset[h] = pok[h] ? sa_set_of(pkey[h], pa.sa_nset) : 0u;
-                sa_load(pa.tags, pset[h], line[h]);
+                const int f = ((int)threadIdx.x >> 4) + 16 * h;
+                sa_split(pa.sa, sa_perm(pa.sau, s_sa_base[f & 31] + (pok[h] ? (unsigned)prow[h] : 0u)), pset[h], ptag[h]);
+                if (!pok[h]) pset[h] = 0u;
             }
+            // (the probe is folded into this kernel for 8-way tiers only -- the host checks: evs_cache.hip -- so the way count
+            //  is a compile-time constant: exactly two 16-byte loads and an 8-way search per key)
+            SaLine line[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) sa_load<8>(pa.sa, pset[h], line[h]);
+            __builtin_amdgcn_sched_barrier(0);   // both keys' set lines in one round trip
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                unsigned long long w;
-                const int way = sa_find(line[h], pkey[h], w);
+                unsigned w;
+                const int way = sa_find<8>(pa.sa, line[h], ptag[h], w);
                 const bool found = pok[h] && way >= 0;
-                pe[h] = found ? (int)(pset[h] * (unsigned)kSaWays + (unsigned)way) : -1;
+                pe[h] = found ? (int)(pset[h] * 8u + (unsigned)way) : -1;
                 pprio[h] = found ? sa_prio(w) : 0x7fffffff;
                 pw0[h] = w; phint[h] = pset[h]; ptomb[h] = false;
                 if (found) atomicAdd(&s_agg[threadIdx.x & 15], 1);
@@ -589,7 +598,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             // monotone max like update_agg_hit; the plain read first keeps hot entries from serialising on one address
             if (pe[h] >= 0 && pprio[h] < agg) {
                 int old;
-                if (sa) old = sa_prio(atomicMax(&pa.tags[pe[h]], (pw0[h] & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                if (sa) old = sa_prio(atomicMax(sa_ways_ptr(pa.sa, phint[h]) + ((unsigned)pe[h] & 7u), sa_bump((unsigned)pw0[h], agg)));
                 else old = atomicMax(&pa.eagg[pe[h]], agg);
                 if (old < agg) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
             }
@@ -603,7 +612,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
                 if (pok[h] && pe[h] < 0) {
                     const int at = atomicAdd(&s_nlist, 1);
                     pa.miss_rec[(int64_t)blockIdx.x * pa.list_cap + at] =
-                        make_uint4((unsigned)prow[h], (unsigned)(f - 1) | ((unsigned)agg << 8) | (ptomb[h] ? 0x10000u : 0u), phint[h], (unsigned)m);
+                        make_uint4((unsigned)prow[h], (unsigned)(f - 1) | ((unsigned)agg << 8) | (ptomb[h] ? 0x10000u : 0u), phint[h], sa ? ptag[h] : (unsigned)m);
                 }
             }
             if (f == 1 && bs < blk_end) { atomicAdd(&s_psum[0], agg); if (agg == T) atomicAdd(&s_psum[1], 1); }
@@ -833,7 +842,7 @@ bool launch_rf_ids(const FusedArgs &a, hipStream_t st) {
 }
 
 bool launch_rf_probe(const FusedArgs &a, hipStream_t st) {
-    if (!rf_ids_supported(a.B, a.F, a.d) || (!a.probe.slots && !a.probe.sa_nset) || !a.arena) return false;
+    if (!rf_ids_supported(a.B, a.F, a.d) || (!a.probe.slots && !a.probe.sa.tags) || !a.arena) return false;
     const bool nt2 = a.F > 16;
     switch (a.d) {
     case 16:

@@ -63,64 +63,153 @@ __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigne
 
 
 // ---- set-associative form of the batched cache (batch policy 2, "setassoc") ------------------------------------------
-// No hash chain and no entry arrays: key -> set = (mix64(key) >> 32) * nset >> 32, a set is kSaWays consecutive 8-byte
-// words = 64 bytes of ONE 128-byte line, way w of set s owns arena row s * kSaWays + w.  A word = key (38 bits) | batch stamp
-// (19 bits: the batch that filled the way) | priority (7 bits, the EvLFU agg_hit maximum) -- the priority sits in the top
-// bits, so "raise the priority of this key" is one 64-bit atomicMax on the word.  A probe is one line, an insert is that
-// line + one CAS + the row; nothing ever moves, so there are no tombstones, no sweeps and no rebuilds.  The victim of a
-// new key is the lowest priority of ITS OWN set (free ways first), ways filled in the running batch excepted.
-#ifndef EVS_SA_WAYS
-#define EVS_SA_WAYS 8
-#endif
-constexpr int kSaWays = EVS_SA_WAYS;   // 8 or 16.  Measured at the 10 % Kaggle cache, B = 16 384: 16 ways (one whole 128-byte line per set) 42.2 us per
-                                        // batch, hit rate 0.8839; 8 ways (64 bytes) 37.3 us, 0.8827 (sequential oracle 0.884): the set line is read by
-                                        // one thread per key, 16-byte pieces through the CU's 64 B/clk vector-memory path, and that is what the 5 us are
-constexpr int kSaPrioShift = 57;
-constexpr unsigned kSaStampMask = (1u << (kSaPrioShift - kKeyBits)) - 1u;
-constexpr unsigned long long kSaLowMask = (1ull << kSaPrioShift) - 1ull;
-__device__ __forceinline__ unsigned sa_set_of(unsigned long long key, unsigned nset) {
-    return (unsigned)(((mix64(key) >> 32) * (unsigned long long)nset) >> 32);
+// No hash chain and no entry arrays.  Round 4: the way words are 32 bits and a tier PAIR shares its set records.
+//   key universe   gid = row_base[table] + row (a dense number < N = all rows of all tables), x = P(gid) with P a
+//                  bijection of [0, 2^b), 2^b >= N (two rounds of odd multiply + xorshift on b bits)
+//   set / tag      set = x % nset, tag = x / nset: (set, tag) IS the key -- quotienting, no false positives, and the tag is
+//                  only log2(2^b / nset) bits (9 for the 2 % Kaggle tiers), so a way fits a 32-bit word:
+//                  [31:26] priority (EvLFU agg_hit maximum: "raise the priority" = one 32-bit atomicMax)
+//                  [25:tb] batch stamp (the batch that filled the way, mod 2^(26-tb)) | [tb-1:0] tag + 1 (0 = empty way)
+//   record         `line_words` consecutive words per set index.  A tier keeps 2^sub_shift SUB-SETS of `ways` ways in a record
+//                  (words [w_off + sub * ways, + ways)); the sub-set is the low bits of the quotient x / nset, the tag the
+//                  rest: effective set es = set * 2^sub_shift + sub, way w of it owns arena row es * ways + w.
+//                  One tier alone: one sub-set of 8 ways = 32 bytes.  A C1 + C2 pair that starts out together: ONE 128-byte
+//                  record per set index -- C1's 8 ways, then C2's (two 8-way sub-sets for the reference's 1 : 2 split,
+//                  evlfu_8.cpp:63-78) -- so a key's two tier probes are one line request instead of two, and each tier
+//                  still searches 8 ways.
+// A probe is one line, an insert is that line + one CAS + the row; nothing ever moves: no tombstones, sweeps, rebuilds.
+// The victim of a new key is the lowest priority of ITS OWN set (free ways first), ways filled in the running batch excepted.
+constexpr int kSaMaxWays = 16;          // per tier (4 x 16-byte pieces)
+constexpr int kSaPrioShift = 26;
+constexpr unsigned kSaLowMask = (1u << kSaPrioShift) - 1u;
+constexpr unsigned kSaMul1 = 0x9E3779B1u, kSaMul2 = 0x85EBCA6Bu;   // odd: bijections mod 2^b
+constexpr unsigned kSaInv1 = 0x0E8B2F51u, kSaInv2 = 0xA5CB9243u;   // their inverses mod 2^32 (checked at build time below)
+static_assert((unsigned)(kSaMul1 * kSaInv1) == 1u && (unsigned)(kSaMul2 * kSaInv2) == 1u, "modular inverses");
+struct SaUniverse {                     // the key universe of a cache (or of a pair): by value in kernel arguments
+    unsigned row_base[32];              // gid of row 0 of table t
+    unsigned mask;                      // 2^b - 1
+    unsigned half;                      // xorshift distance, 2 * half >= b (so the xorshift is its own inverse)
+    int n_tables;
+};
+struct SaGeom {                         // one tier's view of the set records
+    unsigned *tags;                     // nset records of line_words words (nullptr: not a set-associative tier)
+    unsigned nset;
+    unsigned div_m, div_l;              // x / nset = (umulhi(x, div_m) + ((x - umulhi(x, div_m)) >> 1)) >> (div_l - 1)   (nset >= 2)
+    unsigned tag_mask;                  // (1 << tb) - 1
+    unsigned tag_bits;
+    unsigned line_words, w_off, ways;
+    unsigned sub_shift;                 // log2 of the sub-sets per record (0: one)
+};
+// gid = row_base[table] + row.  (The kernels keep row_base in an LDS table: a per-lane index into the kernel arguments is a
+// vector-memory round trip in front of the set loads.)
+__device__ __forceinline__ unsigned sa_perm(const SaUniverse &u, unsigned gid) {
+    unsigned x = gid;
+    x = (x * kSaMul1) & u.mask; x ^= x >> u.half;
+    x = (x * kSaMul2) & u.mask; x ^= x >> u.half;
+    return x;
 }
-__device__ __forceinline__ unsigned long long sa_word(unsigned long long key, unsigned stamp, int prio) {
-    return key | ((unsigned long long)(stamp & kSaStampMask) << kKeyBits) | ((unsigned long long)prio << kSaPrioShift);
+__device__ __forceinline__ unsigned sa_unperm(const SaUniverse &u, unsigned x) {   // -> gid
+    x ^= x >> u.half; x = (x * kSaInv2) & u.mask;
+    x ^= x >> u.half; x = (x * kSaInv1) & u.mask;
+    return x;
 }
-__device__ __forceinline__ int sa_prio(unsigned long long w) { return (int)(w >> kSaPrioShift); }
-__device__ __forceinline__ unsigned sa_stamp(unsigned long long w) { return (unsigned)(w >> kKeyBits) & kSaStampMask; }
-// the set's line, as 16-byte loads that all go out before the first one is looked at
-struct SaLine { ulonglong2 v[kSaWays / 2]; };
-__device__ __forceinline__ void sa_load(const unsigned long long *tags, unsigned set, SaLine &l) {
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(tags + (unsigned long long)set * kSaWays);
+// x -> (set index = x % nset, quotient x / nset); tiers of a pair share nset: one division for both
+__device__ __forceinline__ void sa_divmod(const SaGeom &g, unsigned x, unsigned &set, unsigned &q) {
+    q = x;
+    if (g.nset > 1u) {
+        const unsigned hi = __umulhi(x, g.div_m);
+        q = (hi + ((x - hi) >> 1)) >> (g.div_l - 1u);
+    }
+    set = x - q * g.nset;
+}
+// (set index, quotient) -> (effective set, tag + 1) of one tier
+__device__ __forceinline__ void sa_place(const SaGeom &g, unsigned set, unsigned q, unsigned &es, unsigned &tag1) {
+    es = (set << g.sub_shift) | (q & ((1u << g.sub_shift) - 1u));
+    tag1 = (q >> g.sub_shift) + 1u;
+}
+// x -> (effective set, tag + 1)
+__device__ __forceinline__ void sa_split(const SaGeom &g, unsigned x, unsigned &es, unsigned &tag1) {
+    unsigned set, q;
+    sa_divmod(g, x, set, q);
+    sa_place(g, set, q, es, tag1);
+}
+__device__ __forceinline__ unsigned sa_word(const SaGeom &g, unsigned tag1, unsigned stamp, int prio) {
+    return tag1 | ((stamp << g.tag_bits) & kSaLowMask) | ((unsigned)prio << kSaPrioShift);
+}
+__device__ __forceinline__ int sa_prio(unsigned w) { return (int)(w >> kSaPrioShift); }
+__device__ __forceinline__ unsigned sa_stamp(const SaGeom &g, unsigned w) { return (w & kSaLowMask) >> g.tag_bits; }
+__device__ __forceinline__ unsigned sa_cur_stamp(const SaGeom &g, int stamp) { return ((unsigned)stamp << g.tag_bits & kSaLowMask) >> g.tag_bits; }
+__device__ __forceinline__ unsigned sa_bump(unsigned w, int agg) { return (w & kSaLowMask) | ((unsigned)agg << kSaPrioShift); }
+// a tier's ways of one set: 16-byte loads that all go out before the first one is looked at.
+// W (template): the tier's way count when the caller knows it at compile time (8 or 16: the one-tier form, the 8 + 16 pair) --
+// exactly W / 4 loads and W-way loops; W = 0: any geometry (kSaMaxWays-way loops masked by g.ways; the pieces past the tier's
+// last one re-read it UNCONDITIONALLY: a conditional load is control flow around it with a wait each).
+struct SaLine { uint4 v[kSaMaxWays / 4]; };
+__device__ __forceinline__ unsigned *sa_ways_ptr(const SaGeom &g, unsigned es) {   // es: effective set (sa_split)
+    return g.tags + (unsigned long long)(es >> g.sub_shift) * g.line_words + g.w_off + (es & ((1u << g.sub_shift) - 1u)) * g.ways;
+}
+template <int W = 0>
+__device__ __forceinline__ void sa_load(const SaGeom &g, unsigned set, SaLine &l) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4 *gp_t;
+    const gp_t p = reinterpret_cast<gp_t>(reinterpret_cast<uintptr_t>(sa_ways_ptr(g, set)));
+    if constexpr (W > 0) {
 #pragma unroll
-    for (int j = 0; j < kSaWays / 2; j++) l.v[j] = p[j];
+        for (int j = 0; j < W / 4; j++) { const u32x4 v = p[j]; l.v[j] = make_uint4(v.x, v.y, v.z, v.w); }
+    } else {
+        const unsigned last = ((g.ways + 3u) >> 2) - 1u;
+#pragma unroll
+        for (int j = 0; j < kSaMaxWays / 4; j++) {
+            const u32x4 v = p[(unsigned)j < last ? (unsigned)j : last];
+            l.v[j] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    }
 }
-// does the set have a free way
-__device__ __forceinline__ bool sa_has_free(const SaLine &l) {
+__device__ __forceinline__ unsigned sa_way_word(const SaLine &l, int j) {   // j: compile-time constant in unrolled loops
+    const uint4 &v = l.v[j >> 2];
+    return (j & 3) == 0 ? v.x : (j & 3) == 1 ? v.y : (j & 3) == 2 ? v.z : v.w;
+}
+// does the set have a free way (among this tier's ways)
+template <int W = 0>
+__device__ __forceinline__ bool sa_has_free(const SaGeom &g, const SaLine &l) {
     bool f = false;
 #pragma unroll
-    for (int j = 0; j < kSaWays / 2; j++) f = f || l.v[j].x == kEmpty || l.v[j].y == kEmpty;
+    for (int j = 0; j < (W > 0 ? W : kSaMaxWays); j++) f = f || ((W > 0 || (unsigned)j < g.ways) && sa_way_word(l, j) == 0u);
     return f;
 }
-// way holding `key` (-1: none) and its word
-__device__ __forceinline__ int sa_find(const SaLine &l, unsigned long long key, unsigned long long &word) {
+// way holding tag1 (-1: none) and its word
+template <int W = 0>
+__device__ __forceinline__ int sa_find(const SaGeom &g, const SaLine &l, unsigned tag1, unsigned &word) {
     int way = -1;
-    word = 0ull;
+    word = 0u;
 #pragma unroll
-    for (int j = 0; j < kSaWays / 2; j++) {
-        const bool a = (l.v[j].x & kKeyMask) == key, b = (l.v[j].y & kKeyMask) == key;
-        way = a ? 2 * j : b ? 2 * j + 1 : way;
-        word = a ? l.v[j].x : b ? l.v[j].y : word;
+    for (int j = 0; j < (W > 0 ? W : kSaMaxWays); j++) {
+        const unsigned w = sa_way_word(l, j);
+        const bool m = (W > 0 || (unsigned)j < g.ways) && (w & g.tag_mask) == tag1;   // (tag1 >= 1: an empty way never matches)
+        way = m ? j : way;
+        word = m ? w : word;
     }
     return way;
 }
-
-// entry of `key` in a set-associative tier (-1: not resident)
-__device__ __forceinline__ int sa_lookup(const unsigned long long *tags, unsigned nset, unsigned long long key) {
-    const unsigned set = sa_set_of(key, nset);
+// entry (arena row) of key (t, row) in a set-associative tier, -1: not resident
+template <int W = -1>   // W: the tier's way count when the caller knows it (-1: looked up in g)
+__device__ __forceinline__ int sa_lookup(const SaUniverse &u, const SaGeom &g, int t, unsigned row) {
+    unsigned set, tag1, w;
+    sa_split(g, sa_perm(u, u.row_base[t & 31] + row), set, tag1);
     SaLine l;
-    sa_load(tags, set, l);
-    unsigned long long w;
-    const int way = sa_find(l, key, w);
-    return way >= 0 ? (int)(set * (unsigned)kSaWays + (unsigned)way) : -1;
+    int way;
+    if constexpr (W > 0) { sa_load<W>(g, set, l); way = sa_find<W>(g, l, tag1, w); }
+    else if (g.ways == 8u) { sa_load<8>(g, set, l); way = sa_find<8>(g, l, tag1, w); }
+    else { sa_load<0>(g, set, l); way = sa_find<0>(g, l, tag1, w); }
+    return way >= 0 ? (int)(set * g.ways + (unsigned)way) : -1;
+}
+// the key (table_1based << 32 | row) a way word of set `set` stands for
+__device__ __forceinline__ unsigned long long sa_key_of(const SaUniverse &u, const SaGeom &g, unsigned es, unsigned w) {
+    const unsigned q = (((w & g.tag_mask) - 1u) << g.sub_shift) | (es & ((1u << g.sub_shift) - 1u));
+    const unsigned gid = sa_unperm(u, q * g.nset + (es >> g.sub_shift));
+    int t = 0;
+    for (int k = 1; k < u.n_tables; k++) t = gid >= u.row_base[k] ? k : t;
+    return ((unsigned long long)(t + 1) << 32) | (gid - u.row_base[t]);
 }
 
 constexpr int kMaxTables = 64;      // one lane per table (exact path)
@@ -159,7 +248,7 @@ struct TierProbe {
     int *part1;                           // replica rows of the hit / histogram totals (32 x 40 ints)
     int hint_shift;
     const int *count; int cap, full_slack;   // entries resident at the last close; "full" = count >= cap - full_slack
-    unsigned long long *tags; unsigned sa_nset;   // set-associative tier (sa_nset != 0): the sets' key words (slots / eagg unused)
+    SaGeom sa;                            // set-associative tier (sa.tags != nullptr): the set records (slots / eagg unused)
 };
 struct Probe2Args {
     TierProbe t1, t2;
@@ -168,6 +257,7 @@ struct Probe2Args {
     int threshold, T, list_cap;
     unsigned *route_filter; unsigned route_mask, route_stamp;   // keys routed to C1 are stamped here (evs_cache.hip: BatchArgs::route_filter)
     C3Batch c3;
+    SaUniverse sau;                       // set-associative tiers: the key universe both share
 };
 // evs_mixed.hip: is there a (u8, u4) rows-in-registers consumer for the shape; the two-tier probe + the interaction over
 // the rows it finds as ONE launch (blocks of 16 samples: miss lists of 16 T records per block and tier)
@@ -185,7 +275,7 @@ struct ProbeArgs {
     uint4 *miss_rec; int *list_cnt; int list_cap;   // per block: its misses as 16-byte records (see BatchArgs::miss_rec)
     int *part1;                           // replica rows of the hit / histogram totals
     int hint_shift, T;
-    unsigned long long *tags; unsigned sa_nset;   // set-associative form (sa_nset != 0): the sets' key words instead of slots / eagg
+    SaGeom sa; SaUniverse sau;            // set-associative form (sa.tags != nullptr): the set records instead of slots / eagg
 };
 
 // evs_fused.hip: interaction over x + the T rows the cache serves, the probe folded into the kernel (fp32 rows; is there a

@@ -10,6 +10,7 @@
 // the per-block LDS tables (evs_common.h, bit-exact with the reference's decoders) -> the fp32 image of the sample in
 // the wave's LDS slot, in the layout the fp32 kernels use.  Then the same v_mfma_f32_16x16x4_f32 chains, the staged
 // output row and 16-byte stores as evs_fused_rf.hip.
+#include <type_traits>
 #include "evs_common.h"
 #include "evs_hash.h"
 
@@ -258,6 +259,18 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
     // ---- the tile: the block's 16 x T (address, class) pairs are one contiguous run of each array ----------------------
     for (int i = threadIdx.x; i < 512; i += blockDim.x) { s_ptr[i] = zc_p; s_cls[i] = 1; }
     for (int i = threadIdx.x; i < 256 + 16; i += blockDim.x) s_lut[i] = i < 256 ? dec_u8((unsigned)i) : u4_value((unsigned)(i - 256));   // (no read of the __constant__ table: a memory round trip in the head)
+    // PROBE: per-table facts the probe indexes by LANE (a per-lane index into the kernel arguments is a vector-memory round
+    // trip, and two of them behind a short-circuit && are two DEPENDENT ones in front of the set loads): rows both tiers'
+    // tables have, dense row number of row 0 (set-associative tiers)
+    __shared__ long long s_nrows[PROBE ? 32 : 1];
+    __shared__ unsigned s_sa_base[PROBE ? 32 : 1];
+    if constexpr (PROBE) {
+        if (threadIdx.x < 32) {
+            const long long r1 = margs.p.t1.backing_rows[threadIdx.x], r2 = margs.p.t2.backing_rows[threadIdx.x];
+            s_nrows[threadIdx.x] = r1 < r2 ? r1 : r2;
+            s_sa_base[threadIdx.x] = margs.p.sau.row_base[threadIdx.x];
+        }
+    }
     __syncthreads();
     __shared__ int s_agg[16];                        // PROBE: hits per request of the chunk
     __shared__ int s_d1[kMaxBuckets], s_d2[kMaxBuckets];   // priority histogram moves of the two tiers
@@ -275,7 +288,8 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
         int prow[2], e1[2], e2[2], ea[2], alt_tier[2];
         bool act[2], ok[2], ht1[2], ht2[2], c1_room[2];
         unsigned long long key[2], end1[2], end2[2], w1[2], w2[2];
-        const bool sa = pa.t1.sa_nset != 0;   // set-associative tiers (evs_hash.h): both tiers or neither
+        unsigned tg1[2] = {0u, 0u}, tg2[2] = {0u, 0u};
+        const bool sa = pa.t1.sa.tags != nullptr;   // set-associative tiers (evs_hash.h): both tiers or neither
 #pragma unroll
         for (int h = 0; h < 2; h++) {   // the thread's two request rows side by side
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
@@ -283,10 +297,12 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
             const int *rp = act[h] ? pa.requests + bs * (long long)T + (f - 1) : pa.requests;
             prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
         }
+        __builtin_amdgcn_sched_barrier(0);   // both request rows on the wire before either is looked at
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h, k = f >= 1 ? f - 1 : 0;
-            ok[h] = act[h] && prow[h] >= 0 && prow[h] < pa.t1.backing_rows[k] && prow[h] < pa.t2.backing_rows[k];
+            const long long nr = s_nrows[k];   // (unconditional read, bitwise tests: no branch between the two keys' loads)
+            ok[h] = act[h] & (prow[h] >= 0) & ((long long)prow[h] < nr);
             key[h] = ((unsigned long long)f << 32) | (unsigned)prow[h];
             end1[h] = end2[h] = 0; ht1[h] = ht2[h] = false;
             e1[h] = e2[h] = -1; w1[h] = w2[h] = 0ull; c1_room[h] = !c1_full;
@@ -294,20 +310,36 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
         if (sa) {
             // both tiers' set lines of both keys in ONE round trip (the hashed form walks C1, then C2, then reads the
             // priority); "C1 has room" is a property of the key's own C1 set: a free way
+            // (a pair that shares its set records: both tiers' ways sit in ONE 128-byte line)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int f = ((int)threadIdx.x >> 4) + 16 * h;
+                const unsigned px = sa_perm(pa.sau, s_sa_base[(f + 31) & 31] + (ok[h] ? (unsigned)prow[h] : 0u));
+                unsigned s1, s2, sx, qx;
+                sa_divmod(pa.t1.sa, px, sx, qx);
+                sa_place(pa.t1.sa, sx, qx, s1, tg1[h]);
+                if (pa.t2.sa.nset == pa.t1.sa.nset) sa_place(pa.t2.sa, sx, qx, s2, tg2[h]);   // (a pair that shares its records: one division)
+                else sa_split(pa.t2.sa, px, s2, tg2[h]);
+                end1[h] = ok[h] ? s1 : 0u;
+                end2[h] = ok[h] ? s2 : 0u;
+            }
+            // (the probe is folded into this kernel for 8-way tiers only -- C1 8 ways + C2 8-way sub-sets, the reference's 1 : 2
+            //  pair in one 128-byte record; the host checks: evs_cache.hip -- so the way counts are compile-time constants)
             SaLine l1[2], l2[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                end1[h] = ok[h] ? sa_set_of(key[h], pa.t1.sa_nset) : 0u;
-                end2[h] = ok[h] ? sa_set_of(key[h], pa.t2.sa_nset) : 0u;
-                sa_load(pa.t1.tags, (unsigned)end1[h], l1[h]);
-                sa_load(pa.t2.tags, (unsigned)end2[h], l2[h]);
+                sa_load<8>(pa.t1.sa, (unsigned)end1[h], l1[h]);
+                sa_load<8>(pa.t2.sa, (unsigned)end2[h], l2[h]);
             }
+            __builtin_amdgcn_sched_barrier(0);   // all the set loads of the thread's two keys in ONE round trip
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int y1 = sa_find(l1[h], key[h], w1[h]), y2 = sa_find(l2[h], key[h], w2[h]);
-                if (ok[h] && y1 >= 0) e1[h] = (int)((unsigned)end1[h] * (unsigned)kSaWays + (unsigned)y1);
-                else if (ok[h] && y2 >= 0) e2[h] = (int)((unsigned)end2[h] * (unsigned)kSaWays + (unsigned)y2);
-                c1_room[h] = sa_has_free(l1[h]);
+                unsigned x1, x2;
+                const int y1 = sa_find<8>(pa.t1.sa, l1[h], tg1[h], x1), y2 = sa_find<8>(pa.t2.sa, l2[h], tg2[h], x2);
+                w1[h] = x1; w2[h] = x2;
+                if (ok[h] && y1 >= 0) e1[h] = (int)((unsigned)end1[h] * 8u + (unsigned)y1);
+                else if (ok[h] && y2 >= 0) e2[h] = (int)((unsigned)end2[h] * 8u + (unsigned)y2);
+                c1_room[h] = sa_has_free<8>(pa.t1.sa, l1[h]);
             }
         } else {
 #pragma unroll
@@ -334,9 +366,9 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
                     if (at >= 1 && at <= (unsigned)T && (long long)ar < pa.t1.backing_rows[at - 1] && (long long)ar < pa.t2.backing_rows[at - 1]) {
                         const unsigned long long akey = ((unsigned long long)at << 32) | ar;
                         unsigned long long es;
-                        ea[h] = sa ? sa_lookup(pa.t1.tags, pa.t1.sa_nset, akey) : probe_ro(pa.t1.slots, pa.t1.mask, akey, es);
+                        ea[h] = sa ? sa_lookup<8>(pa.sau, pa.t1.sa, (int)at - 1, ar) : probe_ro(pa.t1.slots, pa.t1.mask, akey, es);
                         if (ea[h] >= 0) alt_tier[h] = 1;
-                        else { ea[h] = sa ? sa_lookup(pa.t2.tags, pa.t2.sa_nset, akey) : probe_ro(pa.t2.slots, pa.t2.mask, akey, es); if (ea[h] >= 0) alt_tier[h] = 2; }
+                        else { ea[h] = sa ? sa_lookup<8>(pa.sau, pa.t2.sa, (int)at - 1, ar) : probe_ro(pa.t2.slots, pa.t2.mask, akey, es); if (ea[h] >= 0) alt_tier[h] = 2; }
                         if (alt_tier[h]) atomicOr(&pa.c3.tags[w3], kC3Flag);   // set_recency_flag_c3
                     }
                 }
@@ -349,12 +381,12 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h, k = f >= 1 ? f - 1 : 0;
             if (sa) {
-                if (e1[h] >= 0 && sa_prio(w1[h]) < agg) {
-                    const int old = sa_prio(atomicMax(&pa.t1.tags[e1[h]], (w1[h] & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                if (e1[h] >= 0 && sa_prio((unsigned)w1[h]) < agg) {
+                    const int old = sa_prio(atomicMax(sa_ways_ptr(pa.t1.sa, (unsigned)end1[h]) + ((unsigned)e1[h] & 7u), sa_bump((unsigned)w1[h], agg)));
                     if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
                 }
-                if (e2[h] >= 0 && sa_prio(w2[h]) < agg) {
-                    const int old = sa_prio(atomicMax(&pa.t2.tags[e2[h]], (w2[h] & kSaLowMask) | ((unsigned long long)agg << kSaPrioShift)));
+                if (e2[h] >= 0 && sa_prio((unsigned)w2[h]) < agg) {
+                    const int old = sa_prio(atomicMax(sa_ways_ptr(pa.t2.sa, (unsigned)end2[h]) + ((unsigned)e2[h] & 7u), sa_bump((unsigned)w2[h], agg)));
                     if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
                 }
             } else {
@@ -388,7 +420,7 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
                     const int at = atomicAdd(&s_list_n[dest - 1], 1);
                     tp.miss_rec[(long long)blockIdx.x * pa.list_cap + at] =
                         make_uint4((unsigned)prow[h], (unsigned)k | ((unsigned)agg << 8) | ((dest == 1 ? ht1[h] : ht2[h]) ? 0x10000u : 0u),
-                                   (unsigned)((dest == 1 ? end1[h] : end2[h]) >> tp.hint_shift), (unsigned)m);
+                                   (unsigned)((dest == 1 ? end1[h] : end2[h]) >> tp.hint_shift), sa ? (dest == 1 ? tg1[h] : tg2[h]) : (unsigned)m);
                 }
                 if (e1[h] >= 0) atomicAdd(&s_sum[0], 1);
                 if (e2[h] >= 0) atomicAdd(&s_sum[1], 1);

@@ -365,13 +365,37 @@ POLICIES1 = POLICIES + ["setassoc"]   # ... / 8-way set-associative (single tier
 SA_WAYS = 8
 
 
-def _sa_sets(keys_tr, cap):
-    """Set of each (table_1based, row) key under the set-associative policy (csrc/evs_hash.h: sa_set_of)."""
-    k = (np.asarray([t for t, _ in keys_tr], np.uint64) << np.uint64(32)) | np.asarray([r for _, r in keys_tr], np.uint64)
-    with np.errstate(over="ignore"):
-        k ^= k >> np.uint64(33); k *= np.uint64(0xff51afd7ed558ccd); k ^= k >> np.uint64(33)
-        k *= np.uint64(0xc4ceb9fe1a85ec53); k ^= k >> np.uint64(33)
-    return ((k >> np.uint64(32)) * np.uint64(cap // SA_WAYS)) >> np.uint64(32)
+def _sa_geom(cap, n_rows, cap2=None, n_rows2=None):
+    """Geometry of the set-associative policy restated (csrc/evs_cache.hip: sa_single_feasible / sa_pair_geometry):
+    -> (nset, ways1, ways2, bits).  One tier: cap // 8 sets of 8 ways.  A pair that starts out together: nset =
+    max(cap1 // 8, ceil(cap2 / 16)) sets, min(cap // nset, 16) ways per tier -- unless a tier would get fewer than 4 ways
+    (then each tier keeps sets of its own).  The key universe is the dense row number over all tables."""
+    rows = [max(a, b) for a, b in zip(n_rows, n_rows2 or n_rows)]
+    total = sum(rows)
+    bits = 1
+    while (1 << bits) < total:
+        bits += 1
+    if cap2 is None:
+        return cap // SA_WAYS, SA_WAYS, None, bits
+    nset = max(cap // 8, (cap2 + 15) // 16, 1)
+    w1, w2 = min(cap // nset, 16), min(cap2 // nset, 16)
+    if w1 < 4 or w2 < 4:
+        return None
+    return nset, w1, w2, bits
+
+
+def _sa_sets(keys_tr, nset, n_rows, bits):
+    """Set of each (table_1based, row) key under the set-associative policy (csrc/evs_hash.h: sa_perm / sa_split): the dense
+    row number through two rounds of odd multiply + xorshift on `bits` bits, modulo the number of sets."""
+    base = np.concatenate([[0], np.cumsum(np.asarray(n_rows, np.uint64))]).astype(np.uint64)
+    t = np.asarray([t for t, _ in keys_tr], np.int64) - 1
+    x = base[t] + np.asarray([r for _, r in keys_tr], np.uint64)
+    mask, half = np.uint64((1 << bits) - 1), np.uint64((bits + 1) // 2)
+    x = (x * np.uint64(0x9E3779B1)) & mask
+    x ^= x >> half
+    x = (x * np.uint64(0x85EBCA6B)) & mask
+    x ^= x >> half
+    return (x % np.uint64(nset)).astype(np.int64)
 
 
 @pytest.mark.parametrize("policy", POLICIES1)
@@ -413,12 +437,13 @@ def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch, policy):
             # every resident key sits in its own set, no set holds more than its ways, and a missed key is resident afterwards
             # unless its set is full (it can only have been turned away by SA_WAYS other new keys of this batch)
             kl = list(new_res)
-            per_set = np.bincount(_sa_sets(kl, cap).astype(np.int64), minlength=cap // SA_WAYS) if kl else np.zeros(1, int)
-            assert per_set.max() <= SA_WAYS
+            nset, ways, _, bits = _sa_geom(cap, n_rows)
+            per_set = np.bincount(_sa_sets(kl, nset, n_rows, bits), minlength=nset) if kl else np.zeros(1, int)
+            assert per_set.max() <= ways
             missed = sorted({(k + 1, int(rq[b, k])) for b in range(len(rq)) for k in range(26) if not hit[b, k]})
             gone = [key for key in missed if key not in new_res]
             if gone:
-                assert (per_set[_sa_sets(gone, cap).astype(np.int64)] == SA_WAYS).all()
+                assert (per_set[_sa_sets(gone, nset, n_rows, bits)] == ways).all()
         elif st["size"] < cap:
             assert all((k + 1, int(rq[b, k])) in new_res for b in range(len(rq)) for k in range(26)
                        if policy == "plan" or not hit[b, k])
@@ -700,9 +725,10 @@ def test_batched_two_tier_c1c2(E, orc, thr, policy):
         tier, out = gpu_cache.lookup_batch_c1c2(c1, c2, r[s:s + 250].contiguous(), threshold=thr)
         tier, out = tier.cpu().numpy(), out.cpu().numpy()
         c1_full = len(R1) >= cap1
-        if policy == "setassoc":   # occupancy of every C1 set when the batch starts
-            occ = np.bincount(_sa_sets(list(R1), cap1).astype(np.int64), minlength=cap1 // SA_WAYS) if R1 else np.zeros(cap1 // SA_WAYS, int)
-            set_of = _sa_sets([(k + 1, int(v)) for k in range(T) for v in range(n)], cap1).astype(np.int64).reshape(T, n)
+        if policy == "setassoc":   # occupancy of every C1 set when the batch starts (the pair shares its set records)
+            nset, ways1, ways2, bits = _sa_geom(cap1, [n] * T, cap2, [n] * T)
+            occ = np.bincount(_sa_sets(list(R1), nset, [n] * T, bits), minlength=nset) if R1 else np.zeros(nset, int)
+            set_of = _sa_sets([(k + 1, int(v)) for k in range(T) for v in range(n)], nset, [n] * T, bits).reshape(T, n)
         for b in range(len(rq)):
             in1 = np.array([(k + 1, int(rq[b, k])) in R1 for k in range(T)])
             in2 = np.array([(k + 1, int(rq[b, k])) in R2 for k in range(T)]) & ~in1
@@ -715,7 +741,7 @@ def test_batched_two_tier_c1c2(E, orc, thr, policy):
                 elif in2[k]:
                     want = dec4[k][row]
                 else:
-                    full = c1_full if policy != "setassoc" else occ[set_of[k, row]] >= SA_WAYS
+                    full = c1_full if policy != "setassoc" else occ[set_of[k, row]] >= ways1
                     dest = 1 if not full else ((1 if k % 2 == 1 else 2) if agg < thr else 2)
                     want = dec8[k][row] if dest == 1 else dec4[k][row]
                 assert np.array_equal(out[b, k].view(np.uint32), want.view(np.uint32)), (s, b, k)

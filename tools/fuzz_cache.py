@@ -153,13 +153,35 @@ def c1c2c3_case(rs, case):
     return tag
 
 
-def _sa_sets(keys_tr, cap):
-    """set of each (table_1based, row) key of a set-associative tier of `cap` entries (csrc/evs_hash.h: sa_set_of)"""
-    k = (np.asarray([t for t, _ in keys_tr], np.uint64) << np.uint64(32)) | np.asarray([r for _, r in keys_tr], np.uint64)
-    with np.errstate(over="ignore"):
-        k ^= k >> np.uint64(33); k *= np.uint64(0xff51afd7ed558ccd); k ^= k >> np.uint64(33)
-        k *= np.uint64(0xc4ceb9fe1a85ec53); k ^= k >> np.uint64(33)
-    return (((k >> np.uint64(32)) * np.uint64(cap // 8)) >> np.uint64(32)).astype(np.int64)
+def _sa_geom(cap, n_rows, cap2=None):
+    """(nset, ways of C1, bits of the key universe) of the set-associative policy -- csrc/evs_cache.hip: sa_single_feasible /
+    sa_pair_geometry restated (as tests/test_gpu_cache.py: _sa_geom): one tier cap // 8 sets of 8 ways; a pair that starts
+    out together max(cap1 // 8, ceil(cap2 / 16)) shared set records unless a tier would get fewer than 4 ways"""
+    total = sum(n_rows)
+    bits = 1
+    while (1 << bits) < total:
+        bits += 1
+    if cap2 is None:
+        return cap // 8, 8, bits
+    nset = max(cap // 8, (cap2 + 15) // 16, 1)
+    w1, w2 = min(cap // nset, 16), min(cap2 // nset, 16)
+    if w1 < 4 or w2 < 4:
+        return cap // 8, 8, bits
+    return nset, w1, bits
+
+
+def _sa_sets(keys_tr, nset, n_rows, bits):
+    """set of each (table_1based, row) key (csrc/evs_hash.h: sa_perm / sa_divmod): the dense row number through two rounds of
+    odd multiply + xorshift on `bits` bits, modulo the number of sets"""
+    base = np.concatenate([[0], np.cumsum(np.asarray(n_rows, np.uint64))]).astype(np.uint64)
+    t = np.asarray([t for t, _ in keys_tr], np.int64) - 1
+    x = base[t] + np.asarray([r for _, r in keys_tr], np.uint64)
+    mask, half = np.uint64((1 << bits) - 1), np.uint64((bits + 1) // 2)
+    x = (x * np.uint64(0x9E3779B1)) & mask
+    x ^= x >> half
+    x = (x * np.uint64(0x85EBCA6B)) & mask
+    x ^= x >> half
+    return (x % np.uint64(nset)).astype(np.int64)
 
 
 def batched_case(rs, case):
@@ -241,14 +263,15 @@ def batched2_case(rs, case):
     R1, R2 = {}, {}
     sa = policy == "setassoc"
     if sa:   # set of every key in C1 (csrc/evs_hash.h: sa_set_of)
-        set_of = _sa_sets([(k + 1, v) for k in range(T) for v in range(n)], cap1).reshape(T, n)
+        nset1, ways1, bits1 = _sa_geom(cap1, [n] * T, cap2)
+        set_of = _sa_sets([(k + 1, v) for k in range(T) for v in range(n)], nset1, [n] * T, bits1).reshape(T, n)
     for s in range(0, len(reqs), B):
         rq = reqs[s:s + B]
         tier, out = gpu_cache.lookup_batch_c1c2(c1, c2, torch.from_numpy(rq).cuda(), threshold=thr)
         tier, out = tier.cpu().numpy(), out.cpu().numpy()
         c1_full = len(R1) >= cap1
         if sa:
-            occ = np.bincount(_sa_sets(list(R1), cap1), minlength=cap1 // 8) if R1 else np.zeros(cap1 // 8, int)
+            occ = np.bincount(_sa_sets(list(R1), nset1, [n] * T, bits1), minlength=nset1) if R1 else np.zeros(nset1, int)
         for b in range(len(rq)):
             in1 = np.array([(k + 1, int(rq[b, k])) in R1 for k in range(T)])
             in2 = np.array([(k + 1, int(rq[b, k])) in R2 for k in range(T)]) & ~in1
@@ -261,7 +284,7 @@ def batched2_case(rs, case):
                 elif in2[k]:
                     want = dec4[k][row]
                 else:
-                    full = occ[set_of[k, row]] >= 8 if sa else c1_full   # set-associative tiers: "C1 full" = the key's own C1 set
+                    full = occ[set_of[k, row]] >= ways1 if sa else c1_full   # set-associative tiers: "C1 full" = the key's own C1 set
                     dest = 1 if not full else ((1 if k % 2 == 1 else 2) if agg < thr else 2)
                     want = dec8[k][row] if dest == 1 else dec4[k][row]
                 assert np.array_equal(out[b, k].view(np.uint32), want.view(np.uint32)), tag + ": row (%d,%d)" % (b, k)
