@@ -35,4 +35,4 @@ def cclose_ev_tables():
 
 
 def stats():
-    return _m.cache.stats()
+    return _m.stats()

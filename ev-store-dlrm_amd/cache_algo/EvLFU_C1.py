@@ -18,4 +18,4 @@ def request_to_ev_lfu(group_row_ids, use_gpu=False, approx_emb_thres=-1, ev_dim=
 
 
 def stats():
-    return _m.cache.stats()
+    return _m.stats()

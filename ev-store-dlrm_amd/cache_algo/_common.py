@@ -76,6 +76,13 @@ class _ModuleCache:
             self._make_gpu(dev_tabs)
         self._bound = True
 
+    def stats(self):
+        """the cache's counters; binds the engine first when nothing has been requested yet (init() only records its
+        arguments: the engine is chosen when the storage manager's tables are known)"""
+        if self.cache is None:
+            self._bind()
+        return self.cache.stats()
+
     # ---- requests -----------------------------------------------------------------------------------------------------
     def _run(self, group_row_ids, approx_thres, want_device_rows):
         """-> (hit flags as a list of bool, rows as a (T, d) float32 tensor on the host, or on the device when the GPU

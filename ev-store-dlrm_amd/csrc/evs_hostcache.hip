@@ -403,7 +403,16 @@ struct AltKeys {
 
     inline uint32_t alt_of(uint64_t key) const { return alt_tables[(int)(key >> 32) - 1][(uint32_t)key]; }
     inline bool push(uint64_t key) {
-        if (qtail - qhead >= (int64_t)fifo.size()) { error = 1; return false; }
+        if (qtail - qhead >= (int64_t)fifo.size()) {
+            // full: the reference's std::queue is unbounded, and no entry may be dropped -- a duplicate of a key, even of one
+            // that is not a member right now, is that key's turn again if it comes back before the entry is popped -- so the
+            // ring doubles, order kept
+            std::vector<uint64_t> grown(fifo.size() * 2);
+            const int64_t n = qtail - qhead;
+            for (int64_t i = 0; i < n; i++) grown[i] = fifo[(qhead + i) % fifo.size()];
+            fifo.swap(grown);
+            qhead = 0; qtail = n;
+        }
         fifo[qtail++ % fifo.size()] = key;
         return true;
     }
@@ -631,6 +640,13 @@ extern "C" int evs_hostcache_request_c1c2c3(evs_hostcache *c1, evs_hostcache *c2
                 "evs_hostcache_request_c1c2c3: both tiers must be EvLFU tiers of the same shape");
     EVS_REQUIRE(!c3 || c3->a.T == c1->t.T, "evs_hostcache_request_c1c2c3: the alt-key tier has another table count");
     if (!c1->t.bound || !c2->t.bound) { set_error("evs_hostcache_request_c1c2c3: no backing tables"); return EVS_ESTATE; }
+    if (c3) {   // alt_of() indexes alt_tables[t][row] with rows of the tiers' tables: every table must be there and long enough
+        for (int k = 0; k < c1->t.T; k++) {
+            const int64_t need = c1->t.n_rows[k] > c2->t.n_rows[k] ? c1->t.n_rows[k] : c2->t.n_rows[k];
+            if (need > 0 && !c3->a.alt_tables[k]) { set_error("evs_hostcache_request_c1c2c3: call evs_hostaprx_set_altkeys first (alt-key table %d is missing)", k + 1); return EVS_ESTATE; }
+            if (c3->a.alt_rows[k] < need) { set_error("evs_hostcache_request_c1c2c3: alt-key table %d has %lld rows, the embedding table %lld", k + 1, (long long)c3->a.alt_rows[k], (long long)need); return EVS_EINVAL; }
+        }
+    }
     if (c1->t.error || c2->t.error) { set_error("evs_hostcache_request_c1c2c3: the policy hit an inconsistency earlier"); return EVS_ESTATE; }
     for (int64_t b = 0; b < B; b++) {
         const int rc = host::tiers_request(c1->t, c2->t, c3 ? &c3->a : nullptr, rows + b * c1->t.T, tier + b * c1->t.T,

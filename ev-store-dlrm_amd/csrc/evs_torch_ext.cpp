@@ -9,6 +9,7 @@
 // C caller uses.  Built in-tree by ev-store-dlrm_amd/_ext_build.py -> lib/_evs_torch_ext.so (g++, host only).
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
 
 #include <cstdint>
 #include <cstring>
@@ -320,13 +321,25 @@ py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i_in, int 
     at::Tensor block;
     uint8_t hit[64];
     if (use_gpu) {
+        // four pinned staging slots in turn; a slot is rewritten only after the copy out of it has finished: an event recorded
+        // behind that copy ON THE STREAM IT RAN ON (the rows' device, which need not be lS_i's), waited for before the host
+        // touches the slot again -- a CPU lS_i with use_gpu, or a backed-up stream, would otherwise overwrite rows in flight
         static at::Tensor stage_rows[4];
+        static hipEvent_t stage_done[4] = {nullptr, nullptr, nullptr, nullptr};
+        static bool stage_busy[4] = {false, false, false, false};
         static unsigned next_slot = 0;
-        at::Tensor &st = stage_rows[next_slot++ & 3u];
+        const unsigned slot = next_slot++ & 3u;
+        at::Tensor &st = stage_rows[slot];
+        if (stage_busy[slot]) { (void)hipEventSynchronize(stage_done[slot]); stage_busy[slot] = false; }
         if (!st.defined() || st.size(0) != T || st.size(2) != d) st = at::empty({T, 1, d}, at::TensorOptions().dtype(at::kFloat)).pin_memory();
         check(evs_hostcache_request(reinterpret_cast<evs_hostcache *>(handle), 1, ids, st.data_ptr<float>(), hit, approx_thres));
-        block = at::empty({T, 1, d}, at::TensorOptions().dtype(at::kFloat).device(c10::Device(c10::kCUDA, static_cast<c10::DeviceIndex>(device_index))));
+        const c10::DeviceIndex dev_i = static_cast<c10::DeviceIndex>(device_index);
+        c10::hip::HIPGuard guard(dev_i);
+        block = at::empty({T, 1, d}, at::TensorOptions().dtype(at::kFloat).device(c10::Device(c10::kCUDA, dev_i)));
         block.copy_(st, /*non_blocking=*/true);
+        if (!stage_done[slot]) (void)hipEventCreateWithFlags(&stage_done[slot], hipEventDisableTiming);
+        if (stage_done[slot] && hipEventRecord(stage_done[slot], c10::hip::getCurrentHIPStream(dev_i).stream()) == hipSuccess) stage_busy[slot] = true;
+        else c10::hip::getCurrentHIPStream(dev_i).synchronize();
     } else {
         block = at::empty({T, 1, d}, at::TensorOptions().dtype(at::kFloat));
         check(evs_hostcache_request(reinterpret_cast<evs_hostcache *>(handle), 1, ids, block.data_ptr<float>(), hit, approx_thres));

@@ -325,3 +325,69 @@ def test_plugin_surface_on_the_host_engine(storage, tmp_path):
     assert np.array_equal(ly[3].detach().numpy()[0], tabs[3][reqs[0][3]])
     evstore_ops.cache_algo = "evlfu"
     sm.close_any_db_conn()
+
+
+def test_altkey_tables_are_checked_against_the_tier_tables():
+    """the three-tier request indexes alt_tables[t][row] with rows of the TIERS' tables -- a short alt-key table
+    (a truncated file) or none at all must be an error at the boundary, not a read past the end."""
+    E = evstore_dlrm_amd
+    T, n, d = 26, 40, 36
+    ws = [np.zeros((n, d), np.float32)] * T
+    raw8, raw4 = [orc.encode_table(w, 8) for w in ws], [orc.encode_table(w, 4) for w in ws]
+    c1 = H.HostCache("evlfu", 50, T, d, 8, "cpp").set_backing(raw8)
+    c2 = H.HostCache("evlfu", 50, T, d, 4, "cpp").set_backing(raw4)
+    rq = np.zeros((1, T), np.int32)
+    short = [np.ones(n if k != 7 else n - 1, np.uint32) * 101 for k in range(T)]   # table 8 one row short
+    with pytest.raises(E.EvsError) as e:
+        H.request_c1c2c3(c1, c2, H.HostAltKeyTier(64, short), rq)
+    assert e.value.code == E._lib.EVS_EINVAL and "alt-key table 8" in str(e.value)
+    # a tier whose alt-key tables were never set (created through the C ABI without evs_hostaprx_set_altkeys)
+    import ctypes as C
+    h = C.c_void_p()
+    E._lib.check(E._lib.lib().evs_hostaprx_create(C.byref(h), 64, T))
+    try:
+        out, tier = np.empty((1, T, d), np.float32), np.empty((1, T), np.uint8)
+        rc = E._lib.lib().evs_hostcache_request_c1c2c3(c1._h, c2._h, h, 1, rq.ctypes.data, out.ctypes.data, tier.ctypes.data, 23)
+        assert rc == E._lib.EVS_ESTATE
+    finally:
+        E._lib.lib().evs_hostaprx_destroy(h)
+    full = [np.ones(n, np.uint32) * 101 for _ in range(T)]
+    t_, _ = H.request_c1c2c3(c1, c2, H.HostAltKeyTier(64, full), rq)
+    assert t_.shape == (1, T)
+
+
+def test_altkey_fifo_grows_like_the_unbounded_queue_it_stands_for():
+    """re-inserting keys that are already members pushes a duplicate queue entry each time and pops nothing while
+    the tier has room (aprx_embedding.cpp:278-288: std::queue, unbounded).  The ring used to latch an error once 4 cap + 64
+    entries were queued; it doubles now, order kept: every push is in the dump, front to back."""
+    cap, T = 60, 26
+    alt = [np.arange(50, dtype=np.uint32) * 100 + (k + 1) for k in range(T)]
+    t = H.HostAltKeyTier(cap, alt)
+    keys = [(1 + i % 5, i % 7) for i in range(1500)]               # 35 distinct keys, 1 500 inserts: > 4 * 60 + 64
+    ops = np.array([[0, tb, r] for tb, r in keys], np.int32)
+    res = t.apply_ops(ops)
+    st = t.stats()
+    assert st["error"] == 0 and st["size"] == len(set(keys)) <= cap
+    np.testing.assert_array_equal(res, [r * 100 + tb for tb, r in keys])
+    q = t.queue()
+    assert q.shape == (1500, 2) and [tuple(int(v) for v in row) for row in q] == keys
+    # ... and the tier keeps working after the growth: eviction pops from the front (the first entry of a key is its turn)
+    t.apply_ops(np.array([[3, 1, 0]] * 3, np.int32))
+    assert t.stats()["error"] == 0 and t.stats()["size"] == len(set(keys)) - 3
+
+
+def test_module_stats_before_the_first_request():
+    """init() only records its arguments (the engine is chosen when the tables are known); stats() right after
+    cinit() / init() must bind the engine instead of dereferencing None."""
+    from evstore_dlrm_amd.cache_algo import EvLFU, EvLFU_C1
+    from evstore_dlrm_amd.emb_storage import storage_manager as sm
+    import torch
+    tabs = [torch.zeros((9, 36)) for _ in range(26)]
+    sm.use_device_tables(tabs, 32, storage=sm.EmbStorage.DUMMY)
+    try:
+        EvLFU.cinit(32, engine="host")
+        assert EvLFU.stats()["size"] == 0
+        EvLFU_C1.init(32, engine="host")
+        assert EvLFU_C1.stats()["n_requests"] == 0
+    finally:
+        sm.close_any_db_conn()
