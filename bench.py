@@ -34,6 +34,21 @@ if ROOT not in sys.path:
 KAGGLE_LN = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593,
              3194, 27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
 HBM_PEAK_GBPS = 8000.0  # MI355X datasheet HBM3E bandwidth (MI355X_MICROARCH.md: 8.0 TB/s spec)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md); v_mfma_f32_16x16x4_f32 = 2 * 16 * 16 * 4 flop
+
+
+def mfma_line(B, F, d, kernel_ms):
+    """MFMA side of the fused launch (north_star: "MFMA utilisation (interaction) against gfx950 peaks"): the kernel computes
+    the lower-triangle 16 x 16 tiles of Z = T T^T per sample -- F <= 16: 1 tile, F <= 32: 3 tiles -- each a chain of d / 4
+    v_mfma_f32_16x16x4_f32 (2 048 flop).  The count is what SQ_INSTS_VALU_MFMA_MOPS_F32 / SQ_INSTS_MFMA read per launch
+    (profiles/r03_pmc_summary.txt: 442 368 = 27 x 16 384 at F = 27, d = 36)."""
+    tiles = 1 if F <= 16 else 3
+    insts = tiles * (d // 4) * B
+    tflops = insts * 2048 / (kernel_ms * 1e-3) / 1e12
+    return {"insts_per_launch": insts, "inst": "v_mfma_f32_16x16x4_f32", "flop_per_launch": insts * 2048, "tflops": tflops,
+            "peak_tflops": MFMA_F32_PEAK_TFLOPS, "frac_of_157.3": tflops / MFMA_F32_PEAK_TFLOPS,
+            "useful_flop_per_launch": 2 * (F * (F - 1) // 2) * d * B,
+            "note": "the interaction rides under the gather: HBM-bound launch (SURVEY 7d), matrix pipe busy for this fraction of it"}
 
 
 def make_tables(ln_emb, d, seed=0, device="cuda", bits=32, codes="random"):
@@ -109,6 +124,20 @@ def mixed_tiers_section(ev, ln_emb, d, B, dev, fill=180, steps=40, alpha=0.75):
         gpu_cache.lookup_interact_c1c2(c1, c2, r, x, tier=tier)
     ms = timed(lambda r: gpu_cache.lookup_interact_c1c2(c1, c2, r, x, tier=tier), fill, fill + steps)
     out["two_tier"] = {"ms_per_step": ms, "value": T * B / ms * 1e3, "c1_entries": c1.batch_stats()["size"], "c2_entries": c2.batch_stats()["size"]}
+    # algorithmic bytes of one two-tier batch: per lookup the served row at its tier's precision (u8 36 B / u4 18 B:
+    # 27 B taken as the mean), its 8-byte id and one 12-byte probe (key + slot / priority word) in EACH tier; per sample x (144 B)
+    # in and R (1 548 B) out -- 26 * (27 + 8 + 2 * 12) + 144 + 1 548 = 3 226 B per sample at T = 26, d = 36
+    F = T + 1
+    tier_bytes = B * (T * (d * 3 // 4 + 8 + 2 * 12) + 4 * d + 4 * (d + F * (F - 1) // 2))
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("mixed_tiers_r04_B%d_d%d" % (B, d), {}).get("per_batch")
+    except Exception:
+        traffic = None
+    out["roofline"] = {"bound": "hbm", "kernel": "the two-tier batch's launch chain: interact_mixed84_kernel<2,1,2,true> (both tiers' set probes + mixed-precision "
+                                                  "interaction, one launch) + cache_batch_sa_list2_kernel (both tiers' updates, one launch), counter folds amortised",
+                       "achieved": tier_bytes / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": tier_bytes / ms / 1e6 / HBM_PEAK_GBPS,
+                       "traffic": traffic, "bytes_per_launch": tier_bytes, "avg_launch_ms": ms}
     alt = [torch.from_numpy(((np.arange(n, dtype=np.int64) % min(n, 4096)) * 100 + (t + 1)).astype(np.uint32).view(np.int32)).to(dev)
            for t, n in enumerate(ln_emb)]   # alt key of (t, r): row r % 4096 of the same table (hot rows: likely resident)
     c3 = E.GpuAltKeyTier(int(0.04 * budget) * 8 + 64, alt, dev)
@@ -147,6 +176,49 @@ def mixed_tiers_section(ev, ln_emb, d, B, dev, fill=180, steps=40, alpha=0.75):
                         "(set-associative tiers by default: both tiers' set lines in one round trip, 'C1 has room' = the key's own C1 set "
                         "has a free way; EVS_CACHE_POLICY=sampled: the hashed tiers of round 2)"})
     return out
+
+
+def long_bags_section(dev, B=2048, bag=100, d=64, T=8, rows=1000000, iters=200):
+    """The reference's own (multi-GPU) benchmark shape on one GPU -- bench/dlrm_s_benchmark.sh:20-45: --arch-embedding-size
+    1000000 x 8, --arch-sparse-feature-size 64, --num-indices-per-lookup 100 (fixed), mini-batch 2 048, uniform indices from
+    the random generator (dlrm_data_pytorch.py:1011-1069).  apply_emb alone (bag_sum_long_kernel: a lane group per bag, 16
+    rows of it in flight, sums in index order) and the two calls apply_emb + interact_features.  Algorithmic bytes (SURVEY
+    8(d)): per lookup 4 d + 8, per bag 8 (offset) + 4 d (pooled row)."""
+    import evstore_dlrm_amd as E
+    ev = make_tables([rows] * T, d, seed=4, device=dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    nb = 4
+    off = [torch.arange(B, device=dev, dtype=torch.int64) * bag for _ in range(T)]
+    idxs = [[torch.randint(0, rows, (B * bag,), device=dev, generator=g, dtype=torch.int64) for _ in range(T)] for _ in range(nb)]
+    x = torch.rand((B, d), device=dev)
+
+    def timed(fn):
+        for i in range(10):
+            fn(i)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for i in range(iters):
+            fn(i)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+
+    ms_g = timed(lambda i: E.apply_emb(off, idxs[i % nb], ev, None, lazy=False))
+    ms_f = timed(lambda i: E.interact_features(x, E.apply_emb(off, idxs[i % nb], ev, None, lazy=False)))
+    looks = T * B * bag
+    by = looks * (4 * d + 8) + T * B * (8 + 4 * d)
+    F = T + 1
+    by_f = by + B * (4 * d * (1 + T) + 4 * d + 4 * (d + F * (F - 1) // 2))
+    del ev
+    torch.cuda.empty_cache()
+    return {"workload": "bench/dlrm_s_benchmark.sh shape: %d tables x %d rows x d=%d fp32, %d indices per bag (fixed), B=%d, uniform" % (T, rows, d, bag, B),
+            "unit": "lookups/s",
+            "apply_emb": {"ms_per_step": ms_g, "value": looks / ms_g * 1e3, "achieved": by / ms_g / 1e6, "peak": HBM_PEAK_GBPS,
+                          "frac": by / ms_g / 1e6 / HBM_PEAK_GBPS, "bytes_per_launch": by, "kernel": "bag_sum_long_kernel<%d, ...>" % (d // 4)},
+            "apply_emb_interact": {"ms_per_step": ms_f, "value": looks / ms_f * 1e3, "achieved": by_f / ms_f / 1e6,
+                                   "frac": by_f / ms_f / 1e6 / HBM_PEAK_GBPS, "bytes_per_step": by_f,
+                                   "note": "two launches: the pooling kernel, then the interaction over the pooled rows"}}
 
 
 def physical_cores():
@@ -806,7 +878,8 @@ def main():
                                else "emb_interact_dot_lds_kernel<32,2,1,2,false,true,false,true,true,true>",
                      "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "bytes_per_launch": kernel_bytes, "avg_launch_ms": kernel_ms},
+                     "bytes_per_launch": kernel_bytes, "avg_launch_ms": kernel_ms,
+                     "mfma": mfma_line(B, F, d, kernel_ms)},
         "declared_one_index": {"value": lookups * args.steps / dtg, "unit": "lookups/s",
                                "ms_per_step": dtg / args.steps * 1e3,
                                "frac": B * bytes_per_sample_declared / (dtg / args.steps) / 1e9 / HBM_PEAK_GBPS,
@@ -901,6 +974,11 @@ def main():
                                               "note": "the reduced-precision row formats (evlfu_16 / evlfu_8 / evlfu_4), tables encoded from the fp32 ones, decoded inside the fused kernel (evs_fused_rfq: encoded rows in flight in registers)"}
         del bb, xb, Rb
         torch.cuda.empty_cache()
+    if not args.no_extras:
+        try:
+            result["reference_benchmark_shape"] = long_bags_section(dev)
+        except Exception as e:
+            result["reference_benchmark_shape"] = {"error": repr(e)}
     if not args.no_extras:
         try:
             result["h2d_inclusive"] = h2d_inclusive_section(ev, KAGGLE_LN, d, B, dev)

@@ -630,6 +630,119 @@ static bool launch_bag_sum_flat(const GatherArgs &a, bool vec_ok, hipStream_t st
 #undef EVS_FLAT
 }
 
+// ---- long bags (round 4): a lane group per BAG, K rows of it in flight, a register accumulator in index order ------------
+// The reference's own benchmark shape (bench/dlrm_s_benchmark.sh:20-45: 8 tables x 1 M rows x d = 64, 100 indices per bag,
+// mb 2 048) and every bag much longer than the tile kernel above likes: there a tile of 64-112 rows is one or two bags and
+// as few (bag, piece) threads add all of it out of LDS (0.17 of peak at 38 indices per bag).  Here the d / 4 lanes that
+// hold a pooled row own the bag: the bag's next K indices arrive as ONE coalesced load of the group (lane l takes index l),
+// each is handed to the whole group (ds_bpermute), the K rows are requested back to back -- K x 64 / LPR rows in flight
+// per wave -- and added to the accumulator IN INDEX ORDER as they return (straight-line code: counted vmcnt waits), the
+// following chunk's indices already on the wire.  An index of another rank's rows (row ranges) or out of the table reads
+// the zero page: x + 0.0f is x for every x the accumulator can hold (it starts at +0.0f and +0.0f + -0.0f = +0.0f), so the
+// sums keep the bits of the oracle's loop.  Ragged bags: a wave runs to its longest bag, the others add zero pages.
+template <int LPR, int K>
+__global__ void __launch_bounds__(256) bag_sum_long_kernel(const GatherArgs args) {
+    constexpr int G = 64 / LPR;                     // bags per wave
+    constexpr int row_bytes = LPR * 16;
+    constexpr int NIL = (K + LPR - 1) / LPR;        // index loads per lane and chunk
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LPR, piece = lane - g * LPR;
+    const bool lane_on = g < G;
+    const int64_t B = args.B;
+    const int64_t cpt = (B + G - 1) / G;            // wave items per table
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= cpt * args.T) return;               // wave-uniform
+    const int t = __builtin_amdgcn_readfirstlane((int)(item / cpt));
+    const int64_t b = (item - (int64_t)t * cpt) * G + g;
+    const char *__restrict__ W = reinterpret_cast<const char *>(args.table[t]);
+    const int64_t *__restrict__ idx = args.indices[t];
+    const int64_t *__restrict__ off = args.offsets[t];
+    const int64_t n_rows = args.n_rows[t], nnz = args.nnz[t], row_lo = args.row_lo[t], row_total = args.row_total[t];
+    const char *zeros = reinterpret_cast<const char *>(args.zeros);
+    bool bad = false;
+    int64_t st = 0;
+    int len = 0;
+    if (lane_on && b < B) {
+        const int64_t s0 = off[b], e0 = (b + 1 < B) ? off[b + 1] : nnz;
+        if (s0 >= 0 && e0 >= s0 && e0 <= nnz && e0 - s0 < (1ll << 30)) { st = s0; len = (int)(e0 - s0); }
+        else bad = true;
+    }
+    int maxlen = len;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(maxlen, m, 64); maxlen = o > maxlen ? o : maxlen; }
+    // the row id (-1: nothing to add) of index e of this lane's bag
+    auto row_of = [&](int e, bool in_chunk) -> int {
+        int r = -1;
+        if (in_chunk && e < len) {
+            const int64_t v = idx[st + e];
+            if (v >= 0 && v < row_total) { const int64_t q = v - row_lo; if (q >= 0 && q < n_rows) r = (int)q; }
+            else bad = true;
+        }
+        return r;
+    };
+    int cur[NIL], nxt[NIL];
+#pragma unroll
+    for (int i = 0; i < NIL; i++) cur[i] = row_of(piece + LPR * i, piece + LPR * i < K);
+    gr_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int gbase = g * LPR;
+    for (int pos = 0; pos < maxlen; pos += K) {
+#pragma unroll
+        for (int i = 0; i < NIL; i++) nxt[i] = row_of(pos + K + piece + LPR * i, piece + LPR * i < K);   // the next chunk's indices: on the wire under this chunk's rows
+        gr_f32x4 row[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const int r = __shfl(cur[j / LPR], gbase + (j % LPR), 64);
+            const char *p = r >= 0 ? W + (int64_t)r * row_bytes : zeros;
+            row[j] = *reinterpret_cast<const __attribute__((address_space(1))) gr_f32x4 *>(reinterpret_cast<uintptr_t>(p + piece * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all K requests out before the first add (the scheduler otherwise keeps 4 in flight)
+#pragma unroll
+        for (int j = 0; j < K; j++) {   // index order, unfused fp32 adds
+            acc.x = __fadd_rn(acc.x, row[j].x); acc.y = __fadd_rn(acc.y, row[j].y);
+            acc.z = __fadd_rn(acc.z, row[j].z); acc.w = __fadd_rn(acc.w, row[j].w);
+        }
+#pragma unroll
+        for (int i = 0; i < NIL; i++) cur[i] = nxt[i];
+    }
+    if (lane_on && b < B) {
+        int64_t o = b * args.out_bstride;
+        if ((int64_t)args.bags_per_peer < B) {
+            const unsigned q = (unsigned)b / args.bags_per_peer;
+            o = (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+        }
+        *reinterpret_cast<float4 *>(args.out + (int64_t)t * args.out_tstride + o + piece * 4) = make_float4(acc.x, acc.y, acc.z, acc.w);
+    }
+    if (bad) atomicOr(args.err, 1);
+}
+
+static bool launch_bag_sum_long(const GatherArgs &a, bool vec_ok, hipStream_t stream) {
+    static const bool on = !(getenv("EVS_GATHER_LONG") && getenv("EVS_GATHER_LONG")[0] == '0');
+    if (!on || !vec_ok || !(a.d == 16 || a.d == 32 || a.d == 36 || a.d == 64 || a.d == 128) || !zero_page()) return false;
+    int64_t nnz = 0;
+    for (int k = 0; k < a.T; k++) {
+        if (a.row_w[k] || !a.offsets[k] || a.n_rows[k] >= (1ll << 31)) return false;
+        nnz += a.nnz[k];
+    }
+    // from an average of 2 indices per bag on (measured, ragged 1..10-index bags at B = 16 384: 62 vs 75 us for the tile kernel; 9 per bag: 29 vs 48;
+    // fixed 100 per bag: 72 vs 500) -- below that the batch is mostly one-index bags and the tile kernel keeps every lane busy
+    static const int min_avg = getenv("EVS_GATHER_LONG_MINAVG") ? atoi(getenv("EVS_GATHER_LONG_MINAVG")) : 2;
+    if (nnz < (int64_t)min_avg * a.B * (int64_t)a.T) return false;
+    const int lpr = a.d / 4, G = 64 / lpr;
+    const int64_t items = (int64_t)a.T * ((a.B + G - 1) / G);
+    if ((items + 3) / 4 >= (1ll << 31)) return false;
+    GatherArgs g = a;
+    g.zeros = zero_page();
+    const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+    switch (a.d) {
+    case 16: hipLaunchKernelGGL((bag_sum_long_kernel<4, 8>), grid, block, 0, stream, g); break;
+    case 32: hipLaunchKernelGGL((bag_sum_long_kernel<8, 8>), grid, block, 0, stream, g); break;
+    case 36: hipLaunchKernelGGL((bag_sum_long_kernel<9, 9>), grid, block, 0, stream, g); break;
+    case 64: hipLaunchKernelGGL((bag_sum_long_kernel<16, 16>), grid, block, 0, stream, g); break;
+    default: hipLaunchKernelGGL((bag_sum_long_kernel<32, 16>), grid, block, 0, stream, g); break;
+    }
+    return true;
+}
+
 // is there a rows-in-registers gather for the launch, and launch it
 static bool launch_gather_rows(const GatherArgs &a, bool vec_ok, hipStream_t stream, bool bag1) {
     static const bool on = !(getenv("EVS_GATHER_RF") && getenv("EVS_GATHER_RF")[0] == '0');
@@ -751,6 +864,7 @@ extern "C" int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec,
         a.chunks_per_table = 0;
         a.zeros = nullptr;
         if (codec == 32 && launch_gather_rows(a, vec_ok, st, bag1)) { EVS_HIP_CHECK(hipGetLastError()); continue; }
+        if (codec == 32 && !bag1 && launch_bag_sum_long(a, vec_ok, st)) { EVS_HIP_CHECK(hipGetLastError()); continue; }
         if (codec == 32 && !bag1 && launch_bag_sum_flat(a, vec_ok, st)) { EVS_HIP_CHECK(hipGetLastError()); continue; }
         switch (codec) {
         case 32: launch_codec<32>(a, vec_ok, st, bag1); break;

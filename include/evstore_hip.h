@@ -283,14 +283,18 @@ EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows,
  * is not given a policy decides at its first batched call: EVS_CACHE_POLICY = plan | sampled | setassoc in the environment,
  * else 2 where it applies (tiers whose tables the kernels read in place from HBM, capacity >= 8: a single tier, or BOTH tiers
  * of a two- / three-tier lookup -- a pair is all set-associative or not at all) and 1 elsewhere.
- *   2 "setassoc": the cache is 8-way set-associative -- set = hash(key), one 64-byte line of 8 key words (key | batch stamp
- *     | priority) per set, way w of set s owns arena row 8 s + w.  A probe reads that line; the update kernel's thread that
- *     inserts a new key takes the lowest priority OF THE KEY'S OWN SET (free ways first) with one CAS and writes the row.
- *     No hash chains, tombstones, sweeps or entry arrays.  capacity / 8 sets (up to 7 entries of the capacity unused);
- *     tables in HBM (host-memory / file-backed tables: EVS_ESTATE).  In the two- / three-tier lookups both tiers' set
- *     lines are read in one round trip and the routing rule's "while C1 is not full" (evlfu_8.cpp:570-601) is read PER
- *     KEY: a double miss goes to C1 while the key's own C1 set has a free way, and by the agg_hit / odd-even rule once it
- *     has none (the hashed forms read it off the tier's entry count);
+ *   2 "setassoc": the cache is 8-way set-associative.  A key is its dense row number over all tables, permuted (a
+ *     bijection of [0, 2^b)), then SPLIT: set = x mod nset, tag = x div nset -- (set, tag) IS the key, so a way is one
+ *     32-bit word (priority 6 bits | batch stamp | tag + 1) and a set 32 bytes; way w of set s owns arena row 8 s + w.
+ *     A probe reads that record; the update kernel's thread that inserts a new key takes the lowest priority OF THE KEY'S
+ *     OWN SET (free ways first) with one CAS and writes the row.  No hash chains, tombstones, sweeps or entry arrays.
+ *     capacity / 8 sets (up to 7 entries of the capacity unused); fewer than 2^32 rows over all tables; tables in HBM
+ *     (host-memory / file-backed tables: EVS_ESTATE).  A C1 + C2 pair that starts out together SHARES its set records: one
+ *     128-byte line per set index holds C1's 8 ways and C2's ways (two 8-way sub-sets, picked by one more bit of the
+ *     quotient, for the reference's 1 : 2 capacity split, evlfu_8.cpp:63-78), so a key's two tier probes are ONE line
+ *     request; the routing rule's "while C1 is not full" (evlfu_8.cpp:570-601) is read PER KEY: a double miss goes to C1
+ *     while the key's own C1 set has a free way, and by the agg_hit / odd-even rule once it has none (the hashed forms
+ *     read it off the tier's entry count);
  *   1 "sampled": a hash over an entry arena; one kernel after the consumers -- the thread that inserts a new key picks
  *     that key's victim itself, the lowest priority of one sampled group of 8 entries (free entries first);
  *   0 "plan": insert -> plan -> evict -> assign -> close, the lowest priorities of a clock-hand window go, exactly as
@@ -304,8 +308,8 @@ EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows,
  * under 2 a set that receives more new keys than it has ways in one batch turns the rest away (they are served from
  * the tables and not cached this time); which keys are resident after a batch depends on thread timing under 1 and 2.
  * Hit rate at the 10 % Criteo-Kaggle cache (Zipf 0.75, B = 16 384, 600 batches): 0 0.8868, 1 0.8862, 2 0.8840, the
- * sequential oracle on the same stream 0.884 (tests/test_gpu_fullsize.py asserts |batched - sequential| <= 0.03 at
- * full size for all three; bench.py: cache_tier.hit_rate_vs_sequential_oracle). */
+ * sequential oracle on the same stream 0.884 (tests/test_gpu_fullsize.py asserts |batched - sequential| <= 0.01 over
+ * ten batches at full size for all three; bench.py: cache_tier.hit_rate_vs_sequential_oracle). */
 EVS_API int evs_cache_set_batch_policy(evs_cache *c, int policy);
 /* Batched two-tier lookup, snapshot semantics: the throughput form of evs_cache_request_c1c2 (no reference
  * counterpart).  Every key is probed in C1, then in C2, against the tiers as they stand when the call starts;

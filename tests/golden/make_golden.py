@@ -73,7 +73,7 @@ def sha(a):
 # a1/a3: apply_emb + interact_features
 # --------------------------------------------------------------------------
 def gen_dlrm_case(D, DP, name, ln_emb, m_spa, B, n_idx, seed, itself=False,
-                  weighted=False, criteo_layout=False, store_tables=True):
+                  weighted=False, criteo_layout=False, store_tables=True, n_idx_fixed=False):
     import torch
     np.random.seed(seed)
     torch.manual_seed(seed)
@@ -93,7 +93,7 @@ def gen_dlrm_case(D, DP, name, ln_emb, m_spa, B, n_idx, seed, itself=False,
         lS_o = torch.stack([torch.tensor(range(B)) for _ in range(T)])
     else:
         X, lS_o_l, lS_i = DP.generate_dist_input_batch(
-            m_den, ln_emb, B, n_idx, False, "uniform", 0, 1, -1, 1)
+            m_den, ln_emb, B, n_idx, n_idx_fixed, "uniform", 0, 1, -1, 1)
         lS_o = torch.stack(lS_o_l)  # collate_wrapper_random_offset (dlrm_data_pytorch.py:791)
     dlrm = D.DLRM_Net(
         m_spa, ln_emb, ln_bot, ln_top,
@@ -668,6 +668,11 @@ def main():
         gen_cython_traces()
         return
     D, DP, SM, FR, MFR, EvLFU_C1, LRU, LFU = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "bench":
+        # the reference's own benchmark shape at a reduced row count (bench/dlrm_s_benchmark.sh:20-45: 8 tables, d = 64,
+        # --num-indices-per-lookup=100 --num-indices-per-lookup-fixed=true; rows 1 000 000 -> 600, mb 2 048 -> 40)
+        gen_dlrm_case(D, DP, "dlrm_bench_shape", [600] * 8, 64, 40, 100, seed=41, n_idx_fixed=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "codec":
         gen_codec_tables()
         return

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 B = 16384
 D = 36
-FILL, CHECKED = 60, 3        # batches that fill the 10 % cache (bench: warmup = 60), batches checked afterwards
-RATE_BAND = 0.03             # |batched hit rate - sequential oracle hit rate| on the same batches
+FILL, CHECKED = 60, 10       # batches that fill the 10 % cache (bench: warmup = 60), batches checked afterwards
+RATE_BAND = 0.01             # |batched hit rate - sequential oracle hit rate| on the same batches (measured gaps: <= 0.006)
 
 
 @pytest.fixture(scope="module")

@@ -8,7 +8,7 @@ import pytest
 from conftest import load_golden, split_indices, split_tables, split_weights
 from oracle import oracle as orc
 
-DLRM_CASES = ["dlrm_ragged_small", "dlrm_kaggle_small", "dlrm_weighted_itself", "dlrm_d64", "dlrm_d128"]
+DLRM_CASES = ["dlrm_ragged_small", "dlrm_kaggle_small", "dlrm_weighted_itself", "dlrm_d64", "dlrm_bench_shape", "dlrm_d128"]
 RTOL = 1e-5  # BASELINE.json north_star: "within 1e-5 rel on fp32 pooled outputs"
 
 
