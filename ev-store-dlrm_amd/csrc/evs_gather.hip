@@ -45,6 +45,7 @@ struct GatherArgs {
     int d;
     int *err;
     const void *zeros;   // the zero page (rows-in-registers gather: what a lane reads for a bag that has no row)
+    int nt_out;          // rows-in-registers gather: non-temporal stores (an output larger than the Infinity Cache only streams through it)
 };
 
 template <int CODEC>
@@ -319,11 +320,25 @@ typedef float gr_f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) gr_f32x4 *gr_gf4_t;
 typedef const __attribute__((address_space(1))) int64_t *gr_gi64_t;
 
-template <int LPRD, int NJ, bool CHECK>
+// CODEC (round 4): the reduced-precision row formats through the same mapping -- a lane's piece of a row is 4 consecutive
+// elements = 8 / 4 / 2 encoded bytes (u16 / u8 / u4), in flight raw, decoded through the per-block LDS tables when it is
+// stored as 16 bytes of fp32; a row that is not there reads the page of the code that decodes to 0.0f (zero_code_page).
+// One request per row and instruction as for fp32 (the grid-stride kernel keeps 4 rows per lane group in flight and pays
+// an index round trip per item: u8 at B = 65 536 132 us against 62 here).
+template <int CODEC> struct GrPiece { typedef gr_f32x4 type; };
+template <> struct GrPiece<16> { typedef unsigned type __attribute__((ext_vector_type(2))); };
+template <> struct GrPiece<8> { typedef unsigned type; };
+template <> struct GrPiece<4> { typedef unsigned short type; };
+template <int CODEC, int LPRD, int NJ, bool CHECK>
 __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(const GatherArgs args) {
     constexpr int RPI = 64 / LPRD;
-    constexpr int row_bytes = LPRD * 16;
+    constexpr int PB = CODEC / 2;                     // bytes of a lane's piece (4 elements)
+    constexpr int row_bytes = LPRD * PB;
+    typedef typename GrPiece<CODEC>::type piece_t;
+    typedef const __attribute__((address_space(1))) piece_t *gpiece_t;
     static_assert(NJ * RPI <= 32, "one tile row per table");
+    __shared__ float s_lut[CodecLut<CODEC>::kEntries];
+    if constexpr (CODEC != 32) codec_lut_init<CODEC>(s_lut);   // (the barrier behind the index tile covers it)
     __shared__ int s_idx[32 * 16];                    // [table][sample]: row of the table's local range, -1 = nothing to read
     __shared__ unsigned long long s_base[32];
     __shared__ unsigned long long s_obase[32];
@@ -414,7 +429,7 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
                     if (r < 0 || r >= tot_t) { bad = true; continue; }
                     r -= lo_t;
                     if (r < 0 || r >= nr_t) continue;
-                    const float4 x = reinterpret_cast<const float4 *>(W + r * row_bytes)[piece];
+                    const float4 x = RowPiece<CODEC>::load(W + r * row_bytes, piece, s_lut);
                     acc.x = __fadd_rn(acc.x, x.x); acc.y = __fadd_rn(acc.y, x.y); acc.z = __fadd_rn(acc.z, x.z); acc.w = __fadd_rn(acc.w, x.w);
                 }
                 *reinterpret_cast<float4 *>(args.out + (int64_t)t * args.out_tstride + out_off(b) + piece * 4) = acc;
@@ -426,9 +441,9 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
         __syncthreads();
     }
     // ---- the rows of this wave's samples wave, wave + 4, wave + 8, wave + 12 ----------------------------------------------
-    const int r0 = lane / LPRD, piece16 = (lane - r0 * LPRD) * 16;
+    const int r0 = lane / LPRD, piece16 = (lane - r0 * LPRD) * 16, piece_in = (lane - r0 * LPRD) * PB;
     const bool lane_on = r0 < RPI;
-    const unsigned long long zeros_p = (unsigned long long)reinterpret_cast<uintptr_t>(args.zeros) + (unsigned long long)piece16;
+    const unsigned long long zeros_p = (unsigned long long)reinterpret_cast<uintptr_t>(args.zeros) + (unsigned long long)piece_in;
     unsigned long long fbase[NJ], obase[NJ];
     int tile[NJ];
     bool t_on[NJ];
@@ -436,11 +451,11 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
     for (int j = 0; j < NJ; j++) {
         const int t = (lane_on ? r0 : 0) + j * RPI;   // < 32
         t_on[j] = lane_on && t < T;
-        fbase[j] = s_base[t] + (unsigned long long)piece16;
+        fbase[j] = s_base[t] + (unsigned long long)piece_in;
         obase[j] = s_obase[t] + (unsigned long long)piece16;
         tile[j] = t * 16 + wave;
     }
-    gr_f32x4 ring[4][NJ];
+    piece_t ring[4][NJ];
 #pragma unroll
     for (int n = 0; n < 4; n++) {
 #pragma unroll
@@ -448,7 +463,7 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
             const int iv = s_idx[tile[j] + 4 * n];
             const unsigned long long neg = 0ull - (unsigned long long)((unsigned)iv >> 31);   // -1 -> the zero page (bit blend: no branch around the load)
             const unsigned long long p = fbase[j] + (unsigned long long)((unsigned)iv & 0x7fffffffu) * (unsigned long long)row_bytes;
-            ring[n][j] = *reinterpret_cast<gr_gf4_t>((uintptr_t)(p ^ ((p ^ zeros_p) & neg)));
+            ring[n][j] = *reinterpret_cast<gpiece_t>((uintptr_t)(p ^ ((p ^ zeros_p) & neg)));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -458,8 +473,20 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
         if (b < blk_end) {
             const unsigned long long ob = (unsigned long long)(out_off(b) * 4);
 #pragma unroll
-            for (int j = 0; j < NJ; j++)
-                if (t_on[j]) *reinterpret_cast<gr_f32x4 *>((uintptr_t)(obase[j] + ob)) = ring[n][j];
+            for (int j = 0; j < NJ; j++) {
+                gr_f32x4 o;
+                if constexpr (CODEC == 32) o = ring[n][j];
+                else {
+                    float4 f;
+                    if constexpr (CODEC == 16) f = dec_chunk<16>(ring[n][j].x, ring[n][j].y, s_lut);
+                    else f = dec_chunk<CODEC>((unsigned)ring[n][j], 0u, s_lut);
+                    o.x = f.x; o.y = f.y; o.z = f.z; o.w = f.w;
+                }
+                if (t_on[j]) {
+                    if (args.nt_out) __builtin_nontemporal_store(o, reinterpret_cast<gr_f32x4 *>((uintptr_t)(obase[j] + ob)));
+                    else *reinterpret_cast<gr_f32x4 *>((uintptr_t)(obase[j] + ob)) = o;
+                }
+            }
         }
     }
     if (bad) atomicOr(args.err, 1);
@@ -744,9 +771,11 @@ static bool launch_bag_sum_long(const GatherArgs &a, bool vec_ok, hipStream_t st
 }
 
 // is there a rows-in-registers gather for the launch, and launch it
+template <int CODEC>
 static bool launch_gather_rows(const GatherArgs &a, bool vec_ok, hipStream_t stream, bool bag1) {
     static const bool on = !(getenv("EVS_GATHER_RF") && getenv("EVS_GATHER_RF")[0] == '0');
-    if (!on || !vec_ok || a.T > 32 || !(a.d == 16 || a.d == 32 || a.d == 36 || a.d == 64) || !zero_page()) return false;
+    const void *zp = CODEC == 32 ? zero_page() : zero_code_page(CODEC);
+    if (!on || !vec_ok || a.T > 32 || !(a.d == 16 || a.d == 32 || a.d == 36 || a.d == 64) || !zp) return false;
     for (int k = 0; k < a.T; k++) {
         if (a.row_w[k] || a.n_rows[k] >= (1ll << 31)) return false;
         if (!bag1 && a.nnz[k] != a.B) return false;   // offsets given: the bet is on whole batches of one-index bags
@@ -755,11 +784,15 @@ static bool launch_gather_rows(const GatherArgs &a, bool vec_ok, hipStream_t str
     const int nj = (a.T + rpi - 1) / rpi;
     const dim3 grid((unsigned)((a.B + 15) / 16)), block(256);
     GatherArgs g = a;
-    g.zeros = zero_page();
+    g.zeros = zp;
+    {   // the pooled rows of a batch this large do not stay in the 256 MiB Infinity Cache for the next kernel anyway
+        static const long long nt_mb = getenv("EVS_GATHER_NT_MB") ? atoll(getenv("EVS_GATHER_NT_MB")) : 192;
+        g.nt_out = (long long)a.T * a.B * a.d * 4 > (nt_mb << 20) ? 1 : 0;
+    }
 #define EVS_GR(L, N) \
     do { \
-        if (bag1) hipLaunchKernelGGL((gather_rows_kernel<L, N, false>), grid, block, 0, stream, g); \
-        else hipLaunchKernelGGL((gather_rows_kernel<L, N, true>), grid, block, 0, stream, g); \
+        if (bag1) hipLaunchKernelGGL((gather_rows_kernel<CODEC, L, N, false>), grid, block, 0, stream, g); \
+        else hipLaunchKernelGGL((gather_rows_kernel<CODEC, L, N, true>), grid, block, 0, stream, g); \
         return true; \
     } while (0)
     if (a.d == 16) { if (nj <= 1) EVS_GR(4, 1); EVS_GR(4, 2); }
@@ -863,7 +896,12 @@ extern "C" int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec,
         a.err = err;
         a.chunks_per_table = 0;
         a.zeros = nullptr;
-        if (codec == 32 && launch_gather_rows(a, vec_ok, st, bag1)) { EVS_HIP_CHECK(hipGetLastError()); continue; }
+        a.nt_out = 0;
+        if ((codec == 32 && launch_gather_rows<32>(a, vec_ok, st, bag1)) || (codec == 16 && launch_gather_rows<16>(a, vec_ok, st, bag1)) ||
+            (codec == 8 && launch_gather_rows<8>(a, vec_ok, st, bag1)) || (codec == 4 && launch_gather_rows<4>(a, vec_ok, st, bag1))) {
+            EVS_HIP_CHECK(hipGetLastError());
+            continue;
+        }
         if (codec == 32 && !bag1 && launch_bag_sum_long(a, vec_ok, st)) { EVS_HIP_CHECK(hipGetLastError()); continue; }
         if (codec == 32 && !bag1 && launch_bag_sum_flat(a, vec_ok, st)) { EVS_HIP_CHECK(hipGetLastError()); continue; }
         switch (codec) {

@@ -507,6 +507,19 @@ def test_fused_codec_large_batch(E, orc, codec, d, B):
 @pytest.mark.parametrize("d,T,B", [(36, 26, 5000 + 3), (36, 28, 300), (36, 1, 17), (16, 32, 2049), (32, 26, 1), (32, 32, 4100), (16, 8, 64), (36, 30, 500),
                                    (64, 26, 3000 + 1), (64, 7, 130), (64, 28, 40), (64, 30, 100)])
 def test_rows_in_registers_gather_vs_oracle(E, orc, d, T, B):
+    _rows_in_registers_gather_case(E, orc, d, T, B, 32)
+
+
+@pytest.mark.parametrize("codec", [16, 8, 4])
+@pytest.mark.parametrize("d,T,B", [(36, 26, 5000 + 3), (36, 28, 300), (16, 32, 2049), (32, 26, 1), (64, 26, 3000 + 1), (36, 30, 500), (36, 3, 70000 + 1)])
+def test_rows_in_registers_gather_reduced_precision_vs_oracle(E, orc, codec, d, T, B):
+    """round 4: the u16 / u8 / u4 row formats through gather_rows_kernel<CODEC> (a lane's piece of a row = 8 / 4 / 2 encoded bytes
+    in flight raw, decoded through the LDS tables at the store; absent rows read the zero-code page): the same cases as the
+    fp32 test, against the oracle's decoders -- evlfu_16.cpp:332-356, evlfu_8.cpp:370-378, evlfu_4.cpp:319-341."""
+    _rows_in_registers_gather_case(E, orc, d, T, B, codec)
+
+
+def _rows_in_registers_gather_case(E, orc, d, T, B, codec):
     """apply_emb alone (the two-call plugin surface) on whole batches of one-index bags runs gather_rows_kernel (round 3:
     16 samples of all tables per block, rows in flight in registers; d = 36 with T > 28 keeps the grid-stride kernel).
     Bit-exact vs the oracle's EmbeddingBag-sum: offsets given = arange (checked per block), one index per bag declared,
@@ -515,7 +528,15 @@ def test_rows_in_registers_gather_vs_oracle(E, orc, d, T, B):
     rs = np.random.RandomState(31 * d + T + B)
     ln = [int(rs.choice([3, 40, 700, 9000])) for _ in range(T)]
     ws = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
-    ev = E.EVTables.from_fp32([torch.from_numpy(w) for w in ws])
+    if codec == 32:
+        ev = E.EVTables.from_fp32([torch.from_numpy(w) for w in ws])
+    else:   # the encoded tables; `ws` becomes what their rows decode to (the oracle's decoders)
+        raws = [orc.encode_table(w, codec) for w in ws]
+        if codec == 16:
+            for r in raws:   # a few codes of the |x| > 0.65 tail, which uniform(-1, 1) tables already hold -- and the extremes
+                r.reshape(-1).view(np.uint16)[:4] = [0, 65000, 65001, 65535]
+        ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, codec)
+        ws = [orc.decode(r, codec, d) for r in raws]
     idx = [rs.randint(0, n, size=B).astype(np.int64) for n in ln]
     off = [np.arange(B, dtype=np.int64) for _ in range(T)]
     want = np.stack(orc.apply_emb(off, idx, ws))
