@@ -278,8 +278,8 @@ def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
     """a16 as a measurement: the reference moves X, lS_o, lS_i to the device for EVERY batch (dlrm_wrap,
     dlrm_s_pytorch.py:131-147: 13*4 + 26*8 + 26*8 = 468 bytes per sample) and stamps wall-clock at the top of each
     request (dlrm_s_pytorch_C1.py:965).  (1) that loop as written: pinned host batches, copies and the fused launch on
-    one stream, the result consumed (synchronised) per request; (2) the same bytes on a COPY stream, double-buffered
-    under the launch of the previous batch (throughput form).  Never the headline `value`."""
+    one stream, the result consumed (synchronised) per request; (2) throughput forms: the batch as ONE pinned block and ONE
+    copy command (optionally int32 on the wire), on the launch's own stream or on a copy stream.  Never the headline `value`."""
     import evstore_dlrm_amd as E
     from evstore_dlrm_amd import inference_loop as IL
     T = len(ln_emb)
@@ -300,38 +300,34 @@ def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
     stamps = IL.inference(ld, forward, True, dev, consume=lambda Z: torch.cuda.synchronize(), non_blocking=True)
     serial = {"p50_ms": IL.percentile_ms(stamps, 50), "p95_ms": IL.percentile_ms(stamps, 95),
               "value": T * B * (len(stamps) - 1) / (stamps[-1] - stamps[0]), "unit": "lookups/s"}
-    # double-buffered: copies of batch i+1 on a copy stream under the launch of batch i
-    cs, ks = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    slots = [(torch.empty((B, 13), device=dev), torch.empty((T, B), dtype=torch.int64, device=dev),
-              torch.empty((T, B), dtype=torch.int64, device=dev)) for _ in range(2)]
-    copied = [torch.cuda.Event() for _ in range(2)]
-    used = [torch.cuda.Event() for _ in range(2)]
+    # throughput form: every batch ONE pinned block and ONE copy command on a copy stream, double-buffered under the launch
+    # of the previous batch (inference_loop.PackedPinnedBatches / Prefetcher); int32 = the opt-in narrow wire format
+    def overlapped(index_dtype, copy_stream=False):
+        pk = IL.PackedPinnedBatches(host, n_req, index_dtype)
+        pf = IL.Prefetcher(pk, dev, copy_stream=copy_stream)      # (its slots / stream / events are made here, outside the timed region)
+        pk.count = 16
+        for X, lo, li in pf:
+            E.apply_emb_interact(x_dev, lo, li, ev, None, out=out)
+        pk.count = n_req
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for X, lo, li in pf:
+            E.apply_emb_interact(x_dev, lo, li, ev, None, out=out)
+        torch.cuda.synchronize()
+        dto = time.perf_counter() - t0
+        return {"ms_per_batch": dto / n_req * 1e3, "value": T * B * n_req / dto, "unit": "lookups/s", "bytes_per_batch": pk.nbytes,
+                "GBps": pk.nbytes * n_req / dto / 1e9}
 
-    def run(n):
-        for i in range(n):
-            sl = i % 2
-            X, lo, li = ld.batches[i % len(ld.batches)]
-            with torch.cuda.stream(cs):
-                if i >= 2:
-                    cs.wait_event(used[sl])
-                slots[sl][0].copy_(X, non_blocking=True)
-                slots[sl][1].copy_(lo, non_blocking=True)
-                slots[sl][2].copy_(li, non_blocking=True)
-                copied[sl].record(cs)
-            with torch.cuda.stream(ks):
-                ks.wait_event(copied[sl])
-                E.apply_emb_interact(x_dev, slots[sl][1], slots[sl][2], ev, None, out=out)
-                used[sl].record(ks)
-
-    run(10)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(n_req)
-    torch.cuda.synchronize()
-    dto = time.perf_counter() - t0
+    ov64 = overlapped(torch.int64)
+    ov32 = overlapped(torch.int32)
+    ov2s = overlapped(torch.int64, copy_stream=True)
     return {"bytes_per_sample": 13 * 4 + 2 * 8 * T, "requests": n_req, "batch": B,
             "as_the_reference_loop": serial,
-            "copy_stream_overlapped": {"ms_per_batch": dto / n_req * 1e3, "value": T * B * n_req / dto, "unit": "lookups/s"},
+            "packed_one_copy_per_batch": ov64, "packed_int32_wire": ov32, "copy_stream_overlapped": ov2s,
+            "throughput_note": "packed: every batch ONE pinned block and ONE copy command queued in front of its launch on the same stream, no "
+                               "per-request synchronise (inference_loop.PackedPinnedBatches / Prefetcher); int32 wire: offsets and indices cross as "
+                               "4 bytes and are widened on the device; copy_stream_overlapped: the same copies on a second stream under the previous "
+                               "launch -- slower on this stack (cross-stream event hand-offs)",
             "note": "per batch X (B,13) fp32, lS_o and lS_i (26,B) int64 from PINNED host memory (dlrm_wrap); latency = "
                     "difference of consecutive loop-top wall-clock stamps, result synchronised per request; PCIe Gen5 x16"}
 
@@ -658,8 +654,10 @@ def main():
     ap.add_argument("--cdf-dir", default=os.path.join(ROOT, "gpurun_out", "cdf"), help="where the B=1 latency CDF CSV goes")
     ap.add_argument("--replicate-gb", type=float, default=64.0, help="per-GPU HBM budget for replicated tables (hbm placement)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one process")
-    ap.add_argument("--exchange-mode", default="inline", choices=["inline", "async"],
-                    help="N>1: all_to_all_single(async_op=False) in stream order (default) or async_op=True with the handle waited on in front of the interaction")
+    ap.add_argument("--exchange-mode", default="inline", choices=["inline", "async", "p2p"],
+                    help="N>1: all_to_all_single(async_op=False) in stream order (default), async_op=True with the handle waited on in front of the "
+                         "interaction, or p2p: no collective call -- the pooling kernel writes every peer's block straight into that peer's "
+                         "IPC-mapped receive buffer, two flag words per (peer, slot) hand it over (csrc/evs_p2p.hip)")
     ap.add_argument("--force-exchange", action="store_true", help="with --force-sharded on one rank: issue the RCCL all_to_all_single anyway "
                                                                   "(a self-exchange into a separate receive buffer: what the collective call itself costs per step)")
     ap.add_argument("--shape", default="kaggle", choices=["kaggle", "terabyte"],
@@ -806,7 +804,12 @@ def main():
     # ---- the same work through the two-call plugin surface (apply_emb, then interact_features) ----
     tile = torch.empty((B, F, d), device=dev, dtype=torch.float32)
 
-    def step2(i):   # two kernels: the pooled rows are materialised in HBM between them
+    def step2(i):   # the reference's two calls exactly as its forward writes them (dlrm_s_pytorch.py:596-601), nothing switched on:
+        lS_o, lS_i = batches[i % len(batches)]   # apply_emb's default result defers the gather, interact_features runs the fused launch
+        ly = E.apply_emb(lS_o, lS_i, ev, None)
+        return E.interact_features(xs[i % 2], ly)
+
+    def step2_eager(i):   # two kernels: the pooled rows are materialised in HBM between them
         lS_o, lS_i = batches[i % len(batches)]
         ly = E.apply_emb(lS_o, lS_i, ev, None, lazy=False)
         return E.interact_features(xs[i % 2], ly)
@@ -823,6 +826,14 @@ def main():
         step2(i)
     torch.cuda.synchronize()
     dt2 = time.perf_counter() - t2
+    for i in range(5):
+        step2_eager(i)
+    torch.cuda.synchronize()
+    t2e = time.perf_counter()
+    for i in range(args.steps):
+        step2_eager(i)
+    torch.cuda.synchronize()
+    dt2e = time.perf_counter() - t2e
 
     def step2_declared(i):   # the same two calls, the caller stating one index per bag: the gather does not read lS_o
         lS_o, lS_i = batches[i % len(batches)]
@@ -890,7 +901,11 @@ def main():
                                 "durations overlap, so no roofline is quoted for it)"},
         "two_call_path": {"value": lookups * args.steps / dt2, "unit": "lookups/s",
                           "ms_per_step": dt2 / args.steps * 1e3,
-                          "note": "apply_emb(lazy=False) (26-table gather) then interact_features: two kernels, (T,B,d) intermediate in HBM"},
+                          "note": "ly = apply_emb(lS_o, lS_i, emb_l, v_W_l); R = interact_features(x, ly) -- the reference's two calls, no switch: "
+                                  "apply_emb returns a real list whose elements materialise on first touch, interact_features on the untouched list "
+                                  "runs the ONE fused launch (dlrm_ops._DeferredRow)"},
+        "two_call_eager": {"value": lookups * args.steps / dt2e, "unit": "lookups/s", "ms_per_step": dt2e / args.steps * 1e3,
+                           "note": "apply_emb(lazy=False) (26-table gather) then interact_features: two kernels, (T,B,d) intermediate in HBM"},
         "two_call_one_index_declared": {"value": lookups * args.steps / dt2d, "unit": "lookups/s", "ms_per_step": dt2d / args.steps * 1e3,
                                         "note": "apply_emb(..., lazy=False, one_index_per_bag=True) then interact_features: the gather is the "
                                                 "offsets-free row gather"},

@@ -66,6 +66,14 @@ _PROTOS = {
     "evs_embedding_bag_sum_sharded": (_int, [_int, _i64, _int, _int, _pp, _i64p, _i64p, _i64p, _pp, _pp, _i64p, _pp, _vp, _i64, _i64,
                                              _i64, _i64, _vp]),
     "evs_rowsplit_route": (_int, [_int, _i64, _int, _pp, _i64p, _i64p, _pp, _vp]),
+    "evs_embedding_bag_sum_p2p": (_int, [_int, _i64, _int, _int, _pp, _i64p, _i64p, _i64p, _pp, _pp, _i64p, _pp, _vp, _i64, _i64,
+                                         _i64, _i64, _vp, _vp]),
+    "evs_p2p_alloc": (_int, [_pp, _i64]),
+    "evs_p2p_free": (_int, [_vp]),
+    "evs_p2p_ipc_export": (_int, [_vp, _vp]),
+    "evs_p2p_ipc_open": (_int, [_vp, _pp]),
+    "evs_p2p_ipc_close": (_int, [_vp]),
+    "evs_p2p_sync": (_int, [_int, _pp, C.c_uint32, _int, _pp, C.c_uint32, _vp]),
     "evs_embedding_bag_sum_stacked": (_int, [_int, _i64, _int, _int, _pp, _i64p, _vp, _i64, _i64, _vp, _i64, _pp,
                                              _vp, _i64, _i64, _vp]),
     "evs_check_index_errors": (_int, [_vp]),

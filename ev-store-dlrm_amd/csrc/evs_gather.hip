@@ -39,6 +39,9 @@ struct GatherArgs {
     // + (b % bags_per_peer) * out_bstride; bags_per_peer >= B: one "peer", the plain layout
     int64_t out_pstride;
     unsigned bags_per_peer;
+    // p2p exchange (evs_embedding_bag_sum_p2p): device array of one entry per peer -- what to ADD (in floats) to the local-
+    // layout address of peer q's block so that it lands in peer q's receive buffer (IPC-mapped); NULL: the local layout
+    const int64_t *peer_delta;
     int64_t B;
     int64_t chunks_per_table;  // ceil(B / bags-per-wave-item)
     int T;
@@ -228,6 +231,7 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_kernel(const GatherArgs
                 if (peers) {
                     const unsigned q = (unsigned)b / args.bags_per_peer;
                     o = (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+                    if (args.peer_delta) o += args.peer_delta[q];
                 }
                 *reinterpret_cast<float4 *>(out + o) = acc[u];
             }
@@ -259,6 +263,7 @@ __global__ void __launch_bounds__(256) embedding_bag_sum_scalar_kernel(const Gat
         if ((int64_t)args.bags_per_peer < args.B) {
             const unsigned q = (unsigned)b / args.bags_per_peer;
             ob = (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+            if (args.peer_delta) ob += args.peer_delta[q];
         }
         float *out = args.out + (int64_t)t * args.out_tstride + ob;
         for (int c = lane; c < d; c += kWave) {
@@ -405,7 +410,7 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
     auto out_off = [&](int64_t b) -> int64_t {            // element offset of bag b inside a table's block of the output
         if (!peers) return b * args.out_bstride;
         const unsigned q = (unsigned)b / args.bags_per_peer;
-        return (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+        return (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride + (args.peer_delta ? args.peer_delta[q] : 0);
     };
     if constexpr (CHECK) {
         if (__syncthreads_or(ragged)) {
@@ -543,6 +548,7 @@ __global__ void __launch_bounds__(256) bag_sum_flat_kernel(const GatherArgs args
         if (peers) {
             const unsigned q = (unsigned)b / args.bags_per_peer;
             o = (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+            if (args.peer_delta) o += args.peer_delta[q];
         }
         return reinterpret_cast<float4 *>(args.out + (int64_t)t * args.out_tstride + o + piece * 4);
     };
@@ -736,6 +742,7 @@ __global__ void __launch_bounds__(256) bag_sum_long_kernel(const GatherArgs args
         if ((int64_t)args.bags_per_peer < B) {
             const unsigned q = (unsigned)b / args.bags_per_peer;
             o = (int64_t)q * args.out_pstride + (b - (int64_t)q * args.bags_per_peer) * args.out_bstride;
+            if (args.peer_delta) o += args.peer_delta[q];
         }
         *reinterpret_cast<float4 *>(args.out + (int64_t)t * args.out_tstride + o + piece * 4) = make_float4(acc.x, acc.y, acc.z, acc.w);
     }
@@ -831,12 +838,12 @@ static void launch_codec(const GatherArgs &a, bool vec_ok, hipStream_t stream, b
 
 }  // namespace evs
 
-extern "C" int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec, const void *const *tables,
-                                             const int64_t *n_rows, const int64_t *row_lo, const int64_t *row_total,
-                                             const int64_t *const *indices, const int64_t *const *offsets, const int64_t *nnz,
-                                             const float *const *row_weights, float *out, int64_t out_table_stride,
-                                             int64_t out_bag_stride, int64_t out_peer_stride, int64_t bags_per_peer,
-                                             void *stream) {
+static int bag_sum_impl(int T, int64_t B, int d, int codec, const void *const *tables,
+                        const int64_t *n_rows, const int64_t *row_lo, const int64_t *row_total,
+                        const int64_t *const *indices, const int64_t *const *offsets, const int64_t *nnz,
+                        const float *const *row_weights, float *out, int64_t out_table_stride,
+                        int64_t out_bag_stride, int64_t out_peer_stride, int64_t bags_per_peer, const int64_t *peer_delta,
+                        void *stream) {
     using namespace evs;
     const char *who = "evs_embedding_bag_sum";
     EVS_REQUIRE(T >= 0 && B >= 0 && d > 0, "%s: bad shape T=%d B=%lld d=%d", who, T, (long long)B, d);
@@ -890,6 +897,7 @@ extern "C" int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec,
         a.out_bstride = out_bag_stride;
         a.out_pstride = out_peer_stride;
         a.bags_per_peer = (unsigned)bags_per_peer;
+        a.peer_delta = (bags_per_peer < B) ? peer_delta : nullptr;
         a.B = B;
         a.T = n;
         a.d = d;
@@ -913,6 +921,31 @@ extern "C" int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec,
         EVS_HIP_CHECK(hipGetLastError());
     }
     return EVS_OK;
+}
+
+extern "C" int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec, const void *const *tables,
+                                             const int64_t *n_rows, const int64_t *row_lo, const int64_t *row_total,
+                                             const int64_t *const *indices, const int64_t *const *offsets, const int64_t *nnz,
+                                             const float *const *row_weights, float *out, int64_t out_table_stride,
+                                             int64_t out_bag_stride, int64_t out_peer_stride, int64_t bags_per_peer,
+                                             void *stream) {
+    return bag_sum_impl(T, B, d, codec, tables, n_rows, row_lo, row_total, indices, offsets, nnz, row_weights, out, out_table_stride,
+                        out_bag_stride, out_peer_stride, bags_per_peer, nullptr, stream);
+}
+
+// p2p exchange: the sharded pooling launch writing every peer's block straight into that peer's receive buffer.  peer_delta:
+// DEVICE array of ceil(B / bags_per_peer) entries (floats, multiples of 4): added to the local-layout address of peer q's block
+// -- i.e. (peer q's mapped receive address of this rank's block) - (out + q * out_peer_stride).
+extern "C" int evs_embedding_bag_sum_p2p(int T, int64_t B, int d, int codec, const void *const *tables,
+                                         const int64_t *n_rows, const int64_t *row_lo, const int64_t *row_total,
+                                         const int64_t *const *indices, const int64_t *const *offsets, const int64_t *nnz,
+                                         const float *const *row_weights, float *out, int64_t out_table_stride,
+                                         int64_t out_bag_stride, int64_t out_peer_stride, int64_t bags_per_peer,
+                                         const int64_t *peer_delta, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(peer_delta && bags_per_peer > 0, "evs_embedding_bag_sum_p2p: needs a peer table and bags_per_peer");
+    return bag_sum_impl(T, B, d, codec, tables, n_rows, row_lo, row_total, indices, offsets, nnz, row_weights, out, out_table_stride,
+                        out_bag_stride, out_peer_stride, bags_per_peer, peer_delta, stream);
 }
 
 extern "C" int evs_embedding_bag_sum(int T, int64_t B, int d, int codec, const void *const *tables,
@@ -1002,6 +1035,7 @@ extern "C" int evs_check_index_errors(void *stream) {
     EVS_HIP_CHECK(hipStreamSynchronize(st));
     if (h) {
         EVS_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(int), st));
+        if (h & 2) { set_error("a p2p exchange wait ran out of patience (a peer did not signal): evs_p2p_sync"); return EVS_ESTATE; }
         set_error("embedding index out of range (or malformed offsets) in a previous launch");
         return EVS_EINDEX;
     }

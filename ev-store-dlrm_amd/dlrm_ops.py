@@ -34,14 +34,16 @@ def _stream_ptr(device):
 class _PooledList(list):
     """What apply_emb returns: a plain list of T (B,d) views plus where they live, so that interact_features can
     address the T features arithmetically instead of asking 27 tensors for their pointers and strides.
-    Any mutation (a caller swapping in a cached row tensor for one table, say) drops that shortcut."""
-    __slots__ = ("_evs_meta",)
+    Any mutation (a caller swapping in a cached row tensor for one table, say) drops that shortcut.
+    _evs_defer: the _Deferred state when the gather behind the list has not been launched yet (see there)."""
+    __slots__ = ("_evs_meta", "_evs_defer")
 
     def _dirty(name):
         base = getattr(list, name)
 
         def f(self, *a, **k):
             self._evs_meta = None
+            self._evs_defer = None   # (the elements still materialise on first touch: they carry the state themselves)
             return base(self, *a, **k)
         f.__name__ = name
         return f
@@ -53,6 +55,132 @@ class _PooledList(list):
 
 
 _feat_cache = {}
+
+# ---- deferred pooling: the DEFAULT result of apply_emb since round 4 ------------------------------------------------------
+# The reference's forward is `ly = apply_emb(...)` then `interact_features(x, ly)` (dlrm_s_pytorch.py:596-601).  Run as
+# written that is two kernels with a (T,B,d) intermediate (47 us per 16 384-batch); the fused launch does both in 20.  The
+# result of apply_emb is therefore a REAL list -- isinstance(ly, list), torch.cat(ly), torch.stack(ly), len, indexing all as
+# before -- whose T elements are (B,d) views of an allocated but NOT YET FILLED buffer: tensors of the subclass
+# _DeferredRow, which sees every torch function / Tensor method that touches one of them (__torch_function__: torch.cat reads
+# a list's items at the C level, but it dispatches on their TYPE first) and launches the gather into the buffer before
+# the function runs -- "materialise on first touch".  interact_features recognises the untouched list and runs the ONE
+# fused kernel from the saved (lS_o, lS_i) instead; the buffer is then never written.  Shape / dtype / device / stride
+# queries do not materialise.  What cannot be intercepted: code that takes an element's address WITHOUT going through
+# torch (a foreign C++ extension unpacking at::Tensor): call apply_emb(..., lazy=False) for that -- and indices / offsets
+# modified IN PLACE between apply_emb and the first use (checked: tensor version counters; raises instead of serving the
+# rows of the wrong batch).  EVS_DEFER_POOLING=0 switches the default back to the eager gather.
+DEFER_POOLING = os.environ.get("EVS_DEFER_POOLING", "1") == "1"
+
+
+class _Deferred:
+    """state behind one deferred apply_emb result"""
+    __slots__ = ("lS_o", "lS_i", "ev", "buf", "done", "vers", "one")
+
+    def _check(self):
+        for t, v in self.vers:
+            if t._version != v:
+                raise RuntimeError("apply_emb's indices / offsets were modified in place before its (deferred) result was first used; "
+                                   "consume the result first, or call apply_emb(..., lazy=False)")
+
+    def materialize(self):
+        if not self.done:
+            self._check()
+            apply_emb(self.lS_o, self.lS_i, self.ev, None, out=None, lazy=False, one_index_per_bag=self.one, _into=self.buf)
+            self.done = True
+            self.lS_o = self.lS_i = None
+
+
+_NO_TOUCH = None   # torch functions that only read metadata: filled on first use (the descriptors need torch loaded)
+
+
+def _no_touch():
+    global _NO_TOUCH
+    if _NO_TOUCH is None:
+        T = torch.Tensor
+        names = ("shape", "dtype", "device", "ndim", "is_cuda", "requires_grad", "layout", "grad_fn", "is_leaf", "names", "grad", "_version")
+        fs = {getattr(T, n).__get__ for n in names if hasattr(getattr(T, n, None), "__get__")}
+        fs |= {T.size, T.dim, T.stride, T.numel, T.nelement, T.is_contiguous, T.element_size, T.storage_offset, T.is_floating_point,
+               T.__len__, T.get_device, T.is_pinned, T.is_shared}
+        _NO_TOUCH = fs
+    return _NO_TOUCH
+
+
+class _DeferredRow(torch.Tensor):
+    """one (B,d) element of a deferred apply_emb result (see above)"""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func not in _no_touch():
+            for a in args:
+                st = getattr(a, "_evs_state", None) if type(a) is cls else None
+                if st is not None:
+                    st.materialize()
+                elif isinstance(a, (list, tuple)):
+                    for b in a:
+                        if type(b) is cls and b._evs_state is not None:
+                            b._evs_state.materialize()
+            if kwargs:
+                for a in kwargs.values():
+                    if type(a) is cls and a._evs_state is not None:
+                        a._evs_state.materialize()
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+_defer_pool = {}   # (T, B, d, device) -> entries [buf, rows, state]: recycled when nobody holds the previous result any more
+
+
+def _deferred_result(lS_o, lS_i, ev, one_index_per_bag, B):
+    T, d = len(ev), ev.d
+    key = (T, B, d, ev.device)
+    pool = _defer_pool.get(key)
+    if pool is None:
+        if len(_defer_pool) > 8:
+            _defer_pool.clear()
+        pool = _defer_pool[key] = []
+    ent = None
+    for e in pool:
+        # free again?  nobody but the pool holds the rows (Python references) and no view of the buffer is alive (its storage is
+        # shared by the T rows and the buffer itself)
+        if torch._C._storage_Use_Count(e[0].untyped_storage()._cdata) == e[3] and all(sys.getrefcount(r) == 3 for r in e[1]):
+            ent = e
+            break
+    if ent is None:
+        buf = torch.empty((T, B, d), dtype=torch.float32, device=ev.device)
+        st = _Deferred()
+        rows = []
+        for v in buf.unbind(0):
+            r = v.as_subclass(_DeferredRow)
+            r._evs_state = st
+            rows.append(r)
+        st.buf = buf
+        del v, r
+        ent = [buf, rows, st, torch._C._storage_Use_Count(buf.untyped_storage()._cdata)]   # (the count with nobody else looking)
+        if len(pool) < 4:
+            pool.append(ent)
+    buf, rows, st = ent[0], ent[1], ent[2]
+    st.lS_o, st.lS_i, st.ev, st.done, st.one = lS_o, lS_i, ev, False, bool(one_index_per_bag)
+    ts = ([lS_o] if torch.is_tensor(lS_o) else list(lS_o)) + ([lS_i] if torch.is_tensor(lS_i) else list(lS_i))
+    st.vers = [(t, t._version) for t in ts]
+    ly = _PooledList(rows)
+    ly._evs_meta = (buf.data_ptr(), B * d, d, B, d, T)
+    ly._evs_defer = st
+    return ly
+
+
+def materialize(ly):
+    """force the gather behind a deferred apply_emb result (no-op on anything else); returns ly"""
+    st = getattr(ly, "_evs_defer", None)
+    if st is not None:
+        st.materialize()
+    else:
+        try:
+            for t in ly:
+                if type(t) is _DeferredRow and t._evs_state is not None:
+                    t._evs_state.materialize()
+        except TypeError:
+            pass
+    return ly
 
 # apply_emb followed by interact_features is what every DLRM forward does (dlrm_s_pytorch.py:596-601).  With lazy
 # pooling on (EVS_LAZY_POOLING=1, or apply_emb(..., lazy=True)), apply_emb returns a LazyPooled sequence that launches
@@ -228,7 +356,7 @@ def B_of(lS_o):
         return 0
 
 
-def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy=None, one_index_per_bag=False):
+def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy=None, one_index_per_bag=False, _into=None):
     """Drop-in for DLRM_Net.apply_emb (dlrm_s_pytorch.py:407-461).
 
     lS_o: (T,B) int64 tensor or list of T (B,) tensors -- bag START offsets.
@@ -246,6 +374,7 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy
     ev = _as_evtables(emb_l)
     T, d = len(ev), ev.d
     dev = ev.device
+    defer = lazy is None and DEFER_POOLING and not LAZY_POOLING
     if lazy is None:
         lazy = LAZY_POOLING
     if lazy and out is None and not check_indices and fused_supported(T + 1, d) and \
@@ -253,7 +382,19 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy
         return LazyPooled(lS_o, lS_i, ev, v_W_l)
     stacked_o = torch.is_tensor(lS_o)
     stacked_i = torch.is_tensor(lS_i)
-    if out is None and stacked_i and stacked_o and (v_W_l is None or all(w is None for w in v_W_l)):
+    if defer and _into is None and out is None and not check_indices and fused_supported(T + 1, d) and \
+            (v_W_l is None or all(w is None for w in v_W_l)):
+        # the default: a real list whose elements materialise on first touch (see _DeferredRow above)
+        Bd = 0
+        if stacked_o and stacked_i and lS_o.is_cuda and lS_i.is_cuda and lS_o.dim() == 2 and lS_i.dim() == 2 and \
+                lS_o.dtype == torch.int64 and lS_i.dtype == torch.int64 and lS_i.stride(1) == 1 and lS_o.stride(1) == 1:
+            Bd = int(lS_o.shape[1])
+        elif not stacked_o and not stacked_i and B_of(lS_o) > 0 and len(lS_o) == T and len(lS_i) == T and \
+                all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 and t.dim() == 1 for t in list(lS_o) + list(lS_i)):
+            Bd = B_of(lS_o)
+        if Bd > 0:
+            return _deferred_result(lS_o, lS_i, ev, one_index_per_bag, Bd)
+    if _into is None and out is None and stacked_i and stacked_o and (v_W_l is None or all(w is None for w in v_W_l)):
         xt = ev.ext_tables()
         if xt is not None:   # the C++ extension: checks, the (T,B,d) buffer and the launch without Python in between
             X = _ext.ext()
@@ -261,8 +402,9 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy
             ly = _PooledList(X.slices(buf, False))
             B = int(buf.shape[1])
             ly._evs_meta = (buf.data_ptr(), B * d, d, B, d, T)
+            ly._evs_defer = None
             return ly
-    if out is None and not stacked_i and not stacked_o and (v_W_l is None or all(w is None for w in v_W_l)) and B_of(lS_o) > 0:
+    if _into is None and out is None and not stacked_i and not stacked_o and (v_W_l is None or all(w is None for w in v_W_l)) and B_of(lS_o) > 0:
         xt = ev.ext_tables()
         if xt is not None and all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 and t.dim() == 1 for t in list(lS_o) + list(lS_i)):
             X = _ext.ext()   # list form (the reference's random-data loader): pointer tables built in C++
@@ -270,18 +412,20 @@ def apply_emb(lS_o, lS_i, emb_l, v_W_l=None, out=None, check_indices=False, lazy
             ly = _PooledList(X.slices(buf, False))
             B = int(buf.shape[1])
             ly._evs_meta = (buf.data_ptr(), B * d, d, B, d, T)
+            ly._evs_defer = None
             return ly
     L = _lib.lib()
     B = int(lS_o.shape[1]) if stacked_o else int(lS_o[0].shape[0])
     if out is None:
-        buf = torch.empty((T, B, d), dtype=torch.float32, device=dev)
+        buf = _into if _into is not None else torch.empty((T, B, d), dtype=torch.float32, device=dev)
         out_ptr, tstride, bstride = buf.data_ptr(), B * d, d
-        ly = _PooledList(buf.unbind(0))
+        ly = _PooledList(buf.unbind(0)) if _into is None else _PooledList()
     else:  # (B, F, d) tile: table k -> out[:, k+1, :]
         assert out.shape == (B, T + 1, d) and out.is_contiguous() and out.dtype == torch.float32
         out_ptr, tstride, bstride = out.data_ptr() + 4 * d, d, (T + 1) * d
         ly = _PooledList(out.unbind(1)[1:])
     ly._evs_meta = (out_ptr, tstride, bstride, B, d, T)
+    ly._evs_defer = None
     rw_c, _keep = _row_weights_c(ev, v_W_l)
     stream = _stream_ptr(dev)
     if stacked_i and stacked_o:
@@ -324,6 +468,20 @@ def interact_features(x, ly, arch_interaction_op="dot", arch_interaction_itself=
                 and x.shape[1] == ly.ev.d and x.stride(1) == 1:
             return apply_emb_interact(x, ly.lS_o, ly.lS_i, ly.ev, ly.v_W_l, arch_interaction_itself)
         ly = ly.materialize()
+    st = getattr(ly, "_evs_defer", None)
+    if st is not None and not st.done:
+        T = len(st.ev)
+        # still the list apply_emb built, nothing touched: ONE fused launch instead of the gather + the interaction
+        if arch_interaction_op == "dot" and len(ly) == T and T > 0 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 \
+                and x.shape[1] == st.ev.d and x.stride(1) == 1 and int(x.shape[0]) == st.buf.shape[1] \
+                and getattr(ly[0], "_evs_state", None) is st and getattr(ly[-1], "_evs_state", None) is st:
+            st._check()
+            return apply_emb_interact(x, st.lS_o, st.lS_i, st.ev, None, arch_interaction_itself, one_index_per_bag=st.one)
+        st.materialize()
+    elif st is None and isinstance(ly, (list, tuple)):
+        for t in ly:   # a list the caller rebuilt or changed: its deferred elements first
+            if type(t) is _DeferredRow and t._evs_state is not None:
+                t._evs_state.materialize()
     B, d = x.shape
     dev = x.device
     meta = getattr(ly, "_evs_meta", None)

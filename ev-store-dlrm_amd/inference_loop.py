@@ -93,3 +93,102 @@ class PinnedBatches:
     def __iter__(self):
         for i in range(self.count):
             yield self.batches[i % len(self.batches)]
+
+
+class PackedPinnedBatches:
+    """A loader stand-in for the THROUGHPUT form of the loop: every batch is ONE pinned block -- X (B, 13) fp32 | lS_o (T, B) |
+    lS_i (T, B) -- so that it crosses the bus as ONE copy command instead of the three of dlrm_wrap
+    (dlrm_s_pytorch.py:131-147); the tensors a batch yields are views of its block.  index_dtype=torch.int32 is the opt-in
+    narrow wire format: offsets and indices travel as 4 bytes (Criteo's row ids fit: the largest Kaggle table has 10.1 M
+    rows) and are widened to the int64 the kernels -- and the reference -- read by a device-side copy: 468 -> 260 bytes per
+    sample at T = 26."""
+
+    def __init__(self, batches, count, index_dtype=torch.int64):
+        assert index_dtype in (torch.int64, torch.int32)
+        self.index_dtype, self.count = index_dtype, count
+        self.blocks, self.layout = [], None
+        isz = 8 if index_dtype == torch.int64 else 4
+        for X, lS_o, lS_i in batches:
+            X, lS_o, lS_i = X.contiguous(), lS_o.contiguous(), lS_i.contiguous()
+            nx = (X.numel() * 4 + 15) // 16 * 16
+            no = lS_o.numel() * isz
+            lay = (tuple(X.shape), tuple(lS_o.shape), tuple(lS_i.shape), nx, no)
+            assert self.layout in (None, lay), "every batch must have the same shape"
+            self.layout = lay
+            blk = torch.empty(nx + no + lS_i.numel() * isz, dtype=torch.uint8).pin_memory()
+            blk[:X.numel() * 4].view(torch.float32).view(X.shape).copy_(X)
+            blk[nx:nx + no].view(index_dtype).view(lS_o.shape).copy_(lS_o)
+            blk[nx + no:].view(index_dtype).view(lS_i.shape).copy_(lS_i)
+            self.blocks.append(blk)
+        self.nbytes = int(self.blocks[0].numel())
+
+    def views(self, blk):
+        """(X, lS_o, lS_i) of a block (host or device), no copy"""
+        xs, os_, is_, nx, no = self.layout
+        n_x = xs[0] * xs[1] * 4
+        return (blk[:n_x].view(torch.float32).view(xs), blk[nx:nx + no].view(self.index_dtype).view(os_),
+                blk[nx + no:].view(self.index_dtype).view(is_))
+
+    def __len__(self):
+        return self.count
+
+
+class Prefetcher:
+    """H2D staging for PackedPinnedBatches: ONE copy command per batch into a rotating device slot; the tensors a batch
+    yields are views of its slot (int32 wire batches arrive widened to int64), valid until the slot comes round again.
+      copy_stream=False (default): the copy is queued on the caller's stream in front of the batch's launches -- no
+        synchronisation, no per-request stamps: the bus stays busy back to back (7.7 MB per 16 384-batch in 0.144 ms, the
+        20 us launch behind it: 0.165 ms per batch against 0.193 for the reference loop's three copies + synchronise);
+      copy_stream=True: batch i + 1 crosses on a copy stream under batch i's launch, two event hand-offs per batch (copied
+        -> compute may start; consumed -> the slot may be overwritten).  Measured SLOWER on this stack (0.21 ms per batch
+        whatever the bytes: an event wait between two streams wakes up late when the waiting stream is idle), kept as the
+        form a longer compute phase would want.
+    for X, lS_o, lS_i in Prefetcher(ld, device): forward(...)"""
+
+    def __init__(self, ld, device, depth=2, copy_stream=False):
+        self.ld, self.device, self.depth = ld, torch.device(device), depth
+        self.cs = torch.cuda.Stream(device=self.device) if copy_stream else None
+        self.slots = [torch.empty(ld.nbytes, dtype=torch.uint8, device=self.device) for _ in range(depth)]
+        self.copied = [torch.cuda.Event() for _ in range(depth)]
+        self.used = [torch.cuda.Event() for _ in range(depth)]
+        self.wide = None
+        if ld.index_dtype == torch.int32:
+            _, os_, is_, _, _ = ld.layout
+            self.wide = [(torch.empty(os_, dtype=torch.int64, device=self.device), torch.empty(is_, dtype=torch.int64, device=self.device))
+                         for _ in range(depth)]
+
+    def _issue(self, i):
+        sl = i % self.depth
+        with torch.cuda.stream(self.cs):
+            if i >= self.depth:
+                self.cs.wait_event(self.used[sl])
+            self.slots[sl].copy_(self.ld.blocks[i % len(self.ld.blocks)], non_blocking=True)
+            self.copied[sl].record(self.cs)
+
+    def _views(self, sl):
+        X, lo, li = self.ld.views(self.slots[sl])
+        if self.wide is not None:
+            wo, wi = self.wide[sl]
+            wo.copy_(lo)
+            wi.copy_(li)
+            lo, li = wo, wi
+        return X, lo, li
+
+    def __iter__(self):
+        n = len(self.ld)
+        if self.cs is None:   # one stream: copy, then the caller's launches, in stream order
+            for i in range(n):
+                sl = i % self.depth
+                self.slots[sl].copy_(self.ld.blocks[i % len(self.ld.blocks)], non_blocking=True)
+                yield self._views(sl)
+            return
+        main = torch.cuda.current_stream(self.device)
+        for i in range(min(self.depth - 1, n)):
+            self._issue(i)
+        for i in range(n):
+            if i + self.depth - 1 < n:
+                self._issue(i + self.depth - 1)      # the next batch starts crossing now
+            sl = i % self.depth
+            main.wait_event(self.copied[sl])
+            yield self._views(sl)
+            self.used[sl].record(main)               # (behind whatever the caller queued on its stream for this batch)

@@ -118,19 +118,21 @@ class HipBackend:
         return EVTables([w.to(self.device) for w in weights], d, 32)
 
     def bag_sum_into(self, ev, table_ids_local, lS_o_rows, lS_i_rows, send, n_own, d, planned=False, bag1=False,
-                     layout=None, row_lo=None, row_total=None):
+                     layout=None, row_lo=None, row_total=None, peer_delta=None):
         """pooled[b][j][:] for the j-th owned table, written into send (B, n_own, d).
         bag1: the caller states one index per bag (offsets = arange): the library's NULL-offsets row gather.
         planned: the caller passes the SAME list objects every step (plan / run_start): the pointer tables are then
         cached by list identity and the lists kept alive; one-off calls build them and keep nothing.
         layout = (B, float_offset, table_stride, bag_stride, peer_stride, bags_per_peer): write into the flat buffer `send`
-        peer-major instead (evs_embedding_bag_sum_sharded); row_lo / row_total: the tables are row ranges of larger ones."""
+        peer-major instead (evs_embedding_bag_sum_sharded); row_lo / row_total: the tables are row ranges of larger ones.
+        peer_delta (p2p exchange): device int64 tensor, one entry per peer -- peer q's block goes to its local-layout address
+        + peer_delta[q] floats, i.e. into that peer's receive buffer (evs_embedding_bag_sum_p2p)."""
         B = int(send.shape[0]) if layout is None else int(layout[0])
         n = len(table_ids_local)
         if n == 0 or B == 0:
             return
         # planned batches pass the same list objects every step: key on identity first (no per-step tuple building)
-        fast = ("gid", id(lS_i_rows), id(lS_o_rows), send.data_ptr(), bag1, layout)
+        fast = ("gid", id(lS_i_rows), id(lS_o_rows), send.data_ptr(), bag1, layout, None if peer_delta is None else peer_delta.data_ptr())
         ent = self._cache.get(fast) if planned else None
         if ent is None:
             # "one index per bag" is a statement about the batch: honour it only when every index list HAS B entries
@@ -149,11 +151,16 @@ class HipBackend:
                     self._cache.clear()
                 self._cache[fast] = ent
         L = _lib.lib()
-        if layout is None and row_lo is None:
+        if layout is None and row_lo is None and peer_delta is None:
             _lib.check(L.evs_embedding_bag_sum(n, B, d, ev.codec, ent[0], ent[1], ent[2], ent[3], ent[4], None,
                                                send.data_ptr(), d, n_own * d, _stream_ptr(self.device)))
             return
         _, foff, tstride, bstride, pstride, bpp = layout if layout is not None else (B, 0, d, n_own * d, 0, 0)
+        if peer_delta is not None and bpp < B:
+            _lib.check(L.evs_embedding_bag_sum_p2p(n, B, d, ev.codec, ent[0], ent[1], ent[7], ent[8], ent[2], ent[3], ent[4], None,
+                                                   send.data_ptr() + 4 * foff, tstride, bstride, pstride, bpp, peer_delta.data_ptr(),
+                                                   _stream_ptr(self.device)))
+            return
         _lib.check(L.evs_embedding_bag_sum_sharded(n, B, d, ev.codec, ent[0], ent[1], ent[7], ent[8], ent[2], ent[3], ent[4], None,
                                                    send.data_ptr() + 4 * foff, tstride, bstride, pstride, bpp,
                                                    _stream_ptr(self.device)))
@@ -211,6 +218,148 @@ class HipBackend:
         return R
 
 
+# ----------------------------------------------------------------------------- exchange without a collective call
+class _P2PExchange:
+    """exchange_mode = "p2p" for one global batch size: per pipeline slot a receive buffer and a block of flag words in
+    fine-grained device memory, IPC handles exchanged ONCE over the process group, every peer's buffers mapped here.  The
+    pooling kernel writes each peer's block straight into that peer's receive buffer (HipBackend.bag_sum_into(...,
+    peer_delta=...)); the hand-over is ready[src][slot] = k ("use k of your slot holds my block") and free[dst][slot] = k
+    ("I am through with use k of it"), written with evs_p2p_sync launches on the step's own stream (csrc/evs_p2p.hip).  Signals
+    are queued and ride in the NEXT sync launch (two tiny launches per step instead of four); flush() sends what is queued.
+    Layout contract: what all_to_all_single(recv, send, out_splits, in_splits) would have delivered, block for block
+    (extend_distributed.py:389-426, :444-465)."""
+
+    def __init__(self, op, Bg, n_slots=2, virtual_peers=None):
+        """virtual_peers: None = one process per rank (handles over op.group); else the list that will hold every virtual
+        rank's exchange object of ONE process (tests): the last one to be made connects them all by plain pointers"""
+        L = _lib.lib()
+        self.op, self.W, self.r, self.n_slots = op, op.world, op.rank, n_slots
+        Bl, in_splits, out_splits = op._splits(Bg)
+        self.blk = in_splits[0]                      # floats this rank sends to every peer
+        self.my_off = sum(out_splits[:op.rank])      # where this rank's block starts inside ANY peer's receive buffer
+        self.n_recv = sum(out_splits)
+        self.dev = op.backend.device
+        self.own_recv, self.own_flags, self.recv_t, handles = [], [], [], []
+        with torch.cuda.device(self.dev):
+            for s_ in range(n_slots):
+                pr, pf = C.c_void_p(), C.c_void_p()
+                _lib.check(L.evs_p2p_alloc(C.byref(pr), max(4 * self.n_recv, 64)))
+                _lib.check(L.evs_p2p_alloc(C.byref(pf), 4 * 2 * max(self.W, 1) + 64))
+                self.own_recv.append(pr.value); self.own_flags.append(pf.value)
+                hr, hf = (C.c_char * 64)(), (C.c_char * 64)()
+                if self.W > 1 and virtual_peers is None:
+                    _lib.check(L.evs_p2p_ipc_export(pr, hr)); _lib.check(L.evs_p2p_ipc_export(pf, hf))
+                handles.append((bytes(hr), bytes(hf)))
+        # the receive buffer as a tensor the interaction kernel's feature specs can view (no copy: __cuda_array_interface__)
+        for s_ in range(n_slots):
+            self.recv_t.append(_tensor_over(self.own_recv[s_], self.n_recv, self.dev, self))
+        self.peer_recv = [[None] * self.W for _ in range(n_slots)]
+        self.peer_flags = [[None] * self.W for _ in range(n_slots)]
+        self._opened = []
+        self.k_pool = [0] * n_slots       # uses of a slot this rank has pooled into / consumed
+        self.k_done = [0] * n_slots
+        self._pending = None              # (pointer array, value): a signal that rides in the next sync launch
+        self._virtual = virtual_peers is not None
+        if self._virtual:
+            virtual_peers[self.r] = self
+            if all(v is not None for v in virtual_peers):
+                for v in virtual_peers:
+                    for s_ in range(n_slots):
+                        for p in range(self.W):
+                            v.peer_recv[s_][p], v.peer_flags[s_][p] = virtual_peers[p].own_recv[s_], virtual_peers[p].own_flags[s_]
+                    v._wire()
+            return
+        if self.W > 1:
+            allh = [None] * self.W
+            dist.all_gather_object(allh, handles, group=op.group)
+        for s_ in range(n_slots):
+            for p in range(self.W):
+                if p == self.r:
+                    self.peer_recv[s_][p], self.peer_flags[s_][p] = self.own_recv[s_], self.own_flags[s_]
+                    continue
+                with torch.cuda.device(self.dev):
+                    for which, h in enumerate(allh[p][s_]):
+                        out = C.c_void_p()
+                        _lib.check(L.evs_p2p_ipc_open(C.create_string_buffer(h, 64), C.byref(out)))
+                        self._opened.append(out.value)
+                        if which == 0:
+                            self.peer_recv[s_][p] = out.value
+                        else:
+                            self.peer_flags[s_][p] = out.value
+        self._wire()
+        if self.W > 1:
+            dist.barrier(group=op.group)  # everybody has mapped everybody before the first write
+
+    def _wire(self):
+        n_slots = self.n_slots
+        # peer q's block: local-layout address (own receive buffer + my_off + q * blk) -> peer q's receive buffer + my_off
+        self.delta, self.out_t = [], []
+        for s_ in range(n_slots):
+            base = self.own_recv[s_] + 4 * self.my_off
+            dl = [((self.peer_recv[s_][q] + 4 * self.my_off) - (base + 4 * q * self.blk)) // 4 for q in range(self.W)]
+            self.delta.append(torch.tensor(dl, dtype=torch.int64, device=self.dev))
+            self.out_t.append(self.recv_t[s_][self.my_off:])       # the pool kernels' `out`: this rank's block inside its own buffer
+        # flag words: ready[W] then free[W] in every rank's block
+        self.sig_ready = [(C.c_void_p * self.W)(*[self.peer_flags[s_][p] + 4 * self.r for p in range(self.W)]) for s_ in range(n_slots)]
+        self.sig_free = [(C.c_void_p * self.W)(*[self.peer_flags[s_][p] + 4 * (self.W + self.r) for p in range(self.W)]) for s_ in range(n_slots)]
+        self.wait_ready = [(C.c_void_p * self.W)(*[self.own_flags[s_] + 4 * q for q in range(self.W)]) for s_ in range(n_slots)]
+        self.wait_free = [(C.c_void_p * self.W)(*[self.own_flags[s_] + 4 * (self.W + q) for q in range(self.W)]) for s_ in range(n_slots)]
+
+    def _sync(self, wait=None, wait_value=0):
+        sig, sv = self._pending if self._pending is not None else (None, 0)
+        self._pending = None
+        _lib.check(_lib.lib().evs_p2p_sync(self.W if sig is not None else 0, sig, sv, self.W if wait is not None else 0, wait, wait_value,
+                                           _stream_ptr(self.dev)))
+
+    def flush(self):
+        if self._pending is not None:
+            self._sync()
+
+    def begin_pool(self, slot):
+        """before the pooling launch of the slot's next use: every peer is through with the previous one"""
+        self.k_pool[slot] += 1
+        self._sync(self.wait_free[slot], (self.k_pool[slot] - 1) & 0xffffffff)
+        return self.k_pool[slot]
+
+    def end_pool(self, slot):
+        if self._pending is not None:
+            self._sync()
+        self._pending = (self.sig_ready[slot], self.k_pool[slot] & 0xffffffff)
+
+    def begin_consume(self, slot):
+        self.k_done[slot] += 1
+        self._sync(self.wait_ready[slot], self.k_done[slot] & 0xffffffff)
+
+    def end_consume(self, slot):
+        if self._pending is not None:
+            self._sync()
+        self._pending = (self.sig_free[slot], self.k_done[slot] & 0xffffffff)
+
+    def close(self):
+        L = _lib.lib()
+        try:
+            torch.cuda.synchronize(self.dev)
+        except Exception:
+            pass
+        for p in self._opened:
+            L.evs_p2p_ipc_close(C.c_void_p(p))
+        for p in self.own_recv + self.own_flags:
+            L.evs_p2p_free(C.c_void_p(p))
+        self._opened, self.own_recv, self.own_flags = [], [], []
+
+
+class _RawMem:
+    """a device allocation of the library as something torch.as_tensor can view (kept alive by `owner`)"""
+    def __init__(self, ptr, n_floats, owner):
+        self.__cuda_array_interface__ = {"shape": (max(int(n_floats), 1),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+        self._owner = owner
+
+
+def _tensor_over(ptr, n_floats, device, owner):
+    t = torch.as_tensor(_RawMem(ptr, n_floats, owner), device=device)
+    return t[:n_floats]
+
+
 # ----------------------------------------------------------------------------- the sharded op
 class ShardedEmbeddingInteract:
     """apply_emb + all-to-all + interact_features for one rank.
@@ -241,6 +390,7 @@ class ShardedEmbeddingInteract:
         self.ev = backend.make_tables([local_weights[t] for t in held], d)
         self._bufs = {}
         self._route = {}
+        self._p2p = {}
 
     def tables_held(self):
         return self.my_own + self.replicated + self.split
@@ -256,7 +406,33 @@ class ShardedEmbeddingInteract:
         out_splits = [Bl * len(self.own[p]) * self.d + S for p in range(self.world)]
         return Bl, in_splits, out_splits
 
+    p2p_virtual = None    # tests: {Bg: [None] * world} shared by the virtual ranks of one process (see _P2PExchange)
+
+    def _p2p_state(self, Bg):
+        st = self._p2p.get(Bg)
+        if st is None:
+            vp = None if self.p2p_virtual is None else self.p2p_virtual.setdefault(Bg, [None] * self.world)
+            st = self._p2p[Bg] = _P2PExchange(self, Bg, virtual_peers=vp)
+        return st
+
+    def _p2p_slot_of(self, recv, Bg):
+        st = self._p2p_state(Bg)
+        for s_ in range(st.n_slots):
+            if st.recv_t[s_].data_ptr() == recv.data_ptr():
+                return st, s_
+        return st, None   # (a receive buffer the caller assembled: virtual-rank tests of the collective layout)
+
+    def p2p_flush(self):
+        """send the hand-over signals still queued behind the last step (exchange_mode "p2p"; a no-op otherwise)"""
+        for st in self._p2p.values():
+            st.flush()
+
     def _buffers(self, Bg, slot, like):
+        if self.exchange_mode == "p2p" and self.any_sharded:
+            # p2p: `send` is this rank's block inside its OWN receive buffer (the pool kernels' reference address; every peer's
+            # block is redirected into that peer's buffer by the per-peer delta), `recv` the whole receive buffer of the slot
+            st = self._p2p_state(Bg)
+            return st.out_t[slot % st.n_slots], st.recv_t[slot % st.n_slots]
         key = (Bg, slot)
         if key not in self._bufs:
             Bl, in_splits, out_splits = self._splits(Bg)
@@ -273,6 +449,25 @@ class ShardedEmbeddingInteract:
         """the pooling launch(es) of one batch: owned tables, then this rank's row ranges of the split tables"""
         d, n_own = self.d, len(self.my_own)
         Bl = Bg // self.world
+        if self.exchange_mode == "p2p":
+            st = self._p2p_state(Bg)
+            slot = self._p2p_slot
+            blk = st.blk
+            if not self._p2p_begun:
+                st.begin_pool(slot)
+            self._p2p_begun = False
+            pd = st.delta[slot] if self.world > 1 else None    # (one rank: its own buffer, the plain layout)
+            if n_own:
+                self.backend.bag_sum_into(self.ev, [self.local_id[t] for t in self.my_own], lo_rows, li_rows, send, n_own, d,
+                                          planned=planned, bag1=self.one_index_per_bag, layout=(Bg, 0, d, n_own * d, blk, Bl), peer_delta=pd)
+            if self.split:
+                self.backend.bag_sum_into(self.ev, [self.local_id[t] for t in self.split], lo_split, li_split, send, len(self.split), d,
+                                          planned=planned, bag1=self.one_index_per_bag,
+                                          layout=(Bg, Bl * n_own * d, Bl * d, d, blk, Bl),
+                                          row_lo=[row_range(self.ln_emb[t], self.rank, self.world)[0] for t in self.split],
+                                          row_total=[self.ln_emb[t] for t in self.split], peer_delta=pd)
+            st.end_pool(slot)
+            return
         if not self.split:
             self.backend.bag_sum_into(self.ev, [self.local_id[t] for t in self.my_own], lo_rows, li_rows, send, n_own, d,
                                       planned=planned, bag1=self.one_index_per_bag)
@@ -290,15 +485,18 @@ class ShardedEmbeddingInteract:
     # one rank has nothing to exchange and the received block is the send buffer itself -- unless force_exchange asks for
     # the collective anyway (tests: the RCCL call with this op's buffers and split lists, on the one GPU a box has)
     force_exchange = False
+    _p2p_slot = 0
+    _p2p_begun = False
 
     def _exchanges(self):
-        return self.world > 1 or self.force_exchange
+        return (self.world > 1 or self.force_exchange) and self.exchange_mode != "p2p"   # (p2p: the pool launch IS the exchange)
 
     def pool(self, lS_o, lS_i, slot=0):
         """Pool the owned tables (and this rank's row ranges of the split tables) for the full batch into the send layout."""
         Bg = int(lS_o[0].shape[0])
         like = lS_o[0].new_empty((0,), dtype=torch.float32)
         send, recv = self._buffers(Bg, slot, like)
+        self._p2p_slot = slot % 2
         self._pool_into(send, Bg, [lS_o[t] for t in self.my_own], [lS_i[t] for t in self.my_own],
                         lo_split=[lS_o[t] for t in self.split], li_split=[lS_i[t] for t in self.split])
         return send, recv
@@ -382,8 +580,14 @@ class ShardedEmbeddingInteract:
         work, recv, Bg, Bl, out_splits = handle
         if work is not None:
             work.wait()
-        return self.backend.interact_mixed(x_local, self._specs(recv, Bg, Bl, out_splits, lS_o, lS_i), self.ev, self.d,
-                                           self.itself, out=out)
+        st, slot = self._p2p_slot_of(recv, Bg) if (self.exchange_mode == "p2p" and self.any_sharded) else (None, None)
+        if slot is not None:
+            st.begin_consume(slot)       # every source's block of this use has arrived
+        R = self.backend.interact_mixed(x_local, self._specs(recv, Bg, Bl, out_splits, lS_o, lS_i), self.ev, self.d,
+                                        self.itself, out=out)
+        if slot is not None:
+            st.end_consume(slot)         # (queued: rides in the next sync launch; p2p_flush() sends it now)
+        return R
 
     # ---- pre-planned steady state: all per-batch Python (views, pointer tables) done once -------------
     def plan(self, x_local, lS_o, lS_i, out=None, slot=0):
@@ -394,7 +598,7 @@ class ShardedEmbeddingInteract:
         like = lS_o[0].new_empty((0,), dtype=torch.float32)
         send, recv = self._buffers(Bg, slot, like)
         specs = self._specs(recv, Bg, Bl, out_splits, lS_o, lS_i)
-        pl = {"send": send, "recv": recv, "in": in_splits, "out": out_splits, "specs": specs, "x": x_local,
+        pl = {"send": send, "recv": recv, "in": in_splits, "out": out_splits, "specs": specs, "x": x_local, "slot": slot % 2,
               "R": out, "Bg": Bg, "ids": [self.local_id[t] for t in self.my_own],
               "lo": [lS_o[t] for t in self.my_own], "li": [lS_i[t] for t in self.my_own],
               "lo_split": [lS_o[t] for t in self.split], "li_split": [lS_i[t] for t in self.split]}
@@ -430,6 +634,10 @@ class ShardedEmbeddingInteract:
             tr["n"] += 1
             if tr["n"] % tr["every"]:
                 tr = None
+        self._p2p_slot = pl["slot"]
+        if self.exchange_mode == "p2p":   # the wait for the peers' release in front of the stamped interval, not inside it
+            self._p2p_state(pl["Bg"]).begin_pool(pl["slot"])
+            self._p2p_begun = True
         if tr is not None:
             tr["pool"].append(self._stamp())
         self._pool_into(pl["send"], pl["Bg"], pl["lo"], pl["li"], planned=True, lo_split=pl["lo_split"], li_split=pl["li_split"])
@@ -465,6 +673,8 @@ class ShardedEmbeddingInteract:
         a replay costs one host call instead of the Python / ctypes marshalling of two launches and a collective.
         Captured after two eager runs on a side stream (first-use allocations inside the library must not happen
         during capture).  Steps without an exchange only (one rank, or every table replicated): see below."""
+        if self.exchange_mode == "p2p" and self.any_sharded:
+            raise RuntimeError("capture_step: the p2p exchange counts the uses of a slot in its flag words (a new value per step): not captured")
         if self._exchanges() and self.any_sharded:
             # measured on this stack (ROCm 7.0 / RCCL 2.26, one rank with the exchange forced): capturing the step with its
             # all_to_all_single inside ends in a segmentation fault at replay -- refused here, the bench falls back to the eager loop
@@ -489,11 +699,16 @@ class ShardedEmbeddingInteract:
         tr = self.trace
         if tr is not None and (tr["n"] if self.any_sharded else self._bump(tr)) % tr["every"]:
             tr = None
+        p2p = self.exchange_mode == "p2p" and self.any_sharded
+        if p2p:
+            self._p2p_state(pl["Bg"]).begin_consume(pl["slot"])
         if tr is not None:
             tr["interact"].append(self._stamp())
         R = self.backend.interact_mixed(pl["x"], pl["specs"], self.ev, self.d, self.itself, out=pl["R"], planned=True)
         if tr is not None:
             tr["interact"].append(self._stamp())
+        if p2p:
+            self._p2p_state(pl["Bg"]).end_consume(pl["slot"])
         return R
 
     # bench: {"pool": [], "interact": [], "n": 0, "every": 4} -> HIP events around the two launches of every 4th step (start,
@@ -586,11 +801,13 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
 
     run(args.warmup)
     run(1500)   # clock settle: a FIXED number of untimed steps (every rank must issue the same collectives)
+    op.p2p_flush()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps)
+    op.p2p_flush()
     e_end = torch.cuda.Event()
     e_end.record()
     while not e_end.query():   # (poll, then the closing synchronise: a blocking one wakes up tens of microseconds late)
@@ -703,6 +920,7 @@ def bench_sharded(args, ln_emb, rank, world, dev):
                    "batch_per_gpu": Bl, "global_batch": Bg, "tables": T, "dim": d, "parallelism": par,
                    "placement": policy, "owner": main["owner"], "step_mode": main["mode"],
                    "observed_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                   "exchange_mode": getattr(args, "exchange_mode", "inline"),
                    "a2a_bytes_per_step_per_rank": main["a2a_bytes_per_rank"],
                    "a2a_bytes_per_step_all_links": main["a2a_bytes"]},
         "roofline": main["roofline"], "cpu_baseline": None, "replicated_all": extra,

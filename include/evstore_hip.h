@@ -98,6 +98,40 @@ EVS_API int evs_embedding_bag_sum_sharded(int T, int64_t B, int d, int codec,
                           float *out, int64_t out_table_stride, int64_t out_bag_stride,
                           int64_t out_peer_stride, int64_t bags_per_peer, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * a15 without a collective call: the exchange step of the table-sharded forward (dlrm_s_pytorch.py:543-570,
+ * extend_distributed.py:389-426 All2All_Req, :444-465 All2All_Wait) as direct writes over xGMI.
+ *   evs_embedding_bag_sum_p2p   evs_embedding_bag_sum_sharded whose peer-major blocks go STRAIGHT into the peers' receive
+ *                               buffers: peer_delta (DEVICE array, one entry per peer, in floats, multiples of 4) is added to
+ *                               the local-layout address of peer q's block, i.e. peer_delta[q] = (address of this rank's
+ *                               block inside peer q's IPC-mapped receive buffer) - (out + q * out_peer_stride).
+ *   evs_p2p_alloc / _free       receive buffers and flag words: fine-grained device memory (a peer's writes are visible to
+ *                               this device's loads without a cache flush), zeroed.
+ *   evs_p2p_ipc_export / _open / _close   the 64-byte IPC handle of such a buffer, and its mapping in another process
+ *                               (hipIpcGetMemHandle / hipIpcOpenMemHandle: the handles cross the process group once).
+ *   evs_p2p_sync                one tiny launch: release-store sig_value (system scope) into n_sig words -- flag words in the
+ *                               peers' blocks: "use k of your slot holds my block" / "I am through with use k of it" -- then
+ *                               wait (acquire loads, bounded: a timeout raises the sticky flag evs_check_index_errors reads,
+ *                               EVS_ESTATE) until n_wait words of this rank's own block have reached wait_value.  Host arrays
+ *                               of device pointers, at most 64 each.
+ * The layout contract is the collective's (what all_to_all_single would have delivered, block for block); sharded.py's
+ * exchange_mode = "p2p" drives it, tests/test_p2p_exchange.py pins it against the RCCL / gloo paths.
+ * ------------------------------------------------------------------------- */
+EVS_API int evs_embedding_bag_sum_p2p(int T, int64_t B, int d, int codec,
+                          const void *const *tables, const int64_t *n_rows,
+                          const int64_t *row_lo, const int64_t *row_total,
+                          const int64_t *const *indices, const int64_t *const *offsets,
+                          const int64_t *nnz, const float *const *row_weights,
+                          float *out, int64_t out_table_stride, int64_t out_bag_stride,
+                          int64_t out_peer_stride, int64_t bags_per_peer, const int64_t *peer_delta, void *stream);
+EVS_API int evs_p2p_alloc(void **out, int64_t bytes);
+EVS_API int evs_p2p_free(void *p);
+EVS_API int evs_p2p_ipc_export(void *p, void *handle64);
+EVS_API int evs_p2p_ipc_open(const void *handle64, void **out);
+EVS_API int evs_p2p_ipc_close(void *p);
+EVS_API int evs_p2p_sync(int n_sig, uint32_t *const *sig, uint32_t sig_value, int n_wait, const uint32_t *const *wait,
+                         uint32_t wait_value, void *stream);
+
 /* Row-split tables, receiver side (one index per bag): sample b of table k reads the partial of the rank whose row range
  * holds indices[k][b] -- rank r holds rows [r*n/world, (r+1)*n/world) -- i.e. row  row_off[r] + b  of the partials inside
  * the receive buffer (row_off: HOST array of `world` row offsets, one per source rank).  dst[k][b] (device, int64) receives
