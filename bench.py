@@ -953,6 +953,37 @@ def main():
                                              "last blocks drain under the next batch's first ones; bit-identical to K single launches"}
         except Exception as e:
             result["multi_batch"] = {"error": repr(e)}
+    # ---- small batches (B = 2 048: a single launch is mostly its fixed part; a serving loop with a queue hands K batches per call) ----
+    if not args.no_extras:
+        try:
+            Bs, Kq = 2048, 8
+            sb = make_batches(KAGGLE_LN, Bs, 64, seed=17, device=dev, dist=args.dist)
+            xs_s = [torch.rand((Bs, d), device=dev) for _ in range(Kq)]
+            outs_s = [torch.empty((Bs, d + P), device=dev) for _ in range(Kq)]
+
+            def t_ev(fn, n):
+                for i in range(20):
+                    fn(i)
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                a_.record()
+                for i in range(n):
+                    fn(i)
+                b_.record()
+                torch.cuda.synchronize()
+                return a_.elapsed_time(b_) / n
+
+            one = t_ev(lambda i: E.apply_emb_interact(xs_s[0], sb[i % 64][0], sb[i % 64][1], ev, None, out=outs_s[0]), 400)
+            grp = [([sb[(j * Kq + k) % 64][0] for k in range(Kq)], [sb[(j * Kq + k) % 64][1] for k in range(Kq)]) for j in range(8)]
+            multi = t_ev(lambda i: E.apply_emb_interact_multi(xs_s, grp[i % 8][0], grp[i % 8][1], ev, outs=outs_s), 200) / Kq
+            by = Bs * bytes_per_sample
+            result["small_batch"] = {"batch": Bs, "unit": "lookups/s",
+                                     "single_launch": {"ms_per_batch": one, "value": T * Bs / one * 1e3, "frac": by / one / 1e6 / HBM_PEAK_GBPS},
+                                     "multi_8_per_call": {"ms_per_batch": multi, "value": T * Bs / multi * 1e3, "frac": by / multi / 1e6 / HBM_PEAK_GBPS},
+                                     "note": "lS_o given; single_launch = one apply_emb_interact per 2 048-sample batch (stream time: the host-side floor "
+                                             "of a launch on this stack is ~6 us); multi_8_per_call = apply_emb_interact_multi, 8 queued batches as ONE launch"}
+        except Exception as e:
+            result["small_batch"] = {"error": repr(e)}
     result["declared_one_index"]["note"] = ("apply_emb_interact(..., one_index_per_bag=True): the caller states lS_o == arange, the launch "
                                             "does not read it (5 644 algorithmic bytes per sample; frac = those bytes over the wall-clock step)")
     # ---- the same launch at a larger batch (fixed launch / pipeline-fill cost amortised), and reduced precision ----

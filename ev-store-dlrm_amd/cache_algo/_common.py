@@ -4,7 +4,7 @@ Two engines behind the same surface, picked when the first request binds the sto
 (init(..., engine="auto")):
   host  the exact policy on the host (csrc/evs_hostcache.hip): a few microseconds per request, rows read from
         host-readable tables (EmbStorage.DUMMY / PINNED tensors, or the .bin files of FILEPY / MMAPFILEPY mapped
-        read-only) -- the reference's batch-1 loop belongs here (DESIGN 3.3);
+        read-only) -- the reference's batch-1 loop belongs here (docs/HISTORY.md 3.3);
   gpu   the GPU tier's exact kernel (csrc/evs_cache.hip): one launch + one synchronise per request, for tables that
         live in HBM only (EmbStorage.HBM), or when asked for (engine="gpu": one cache shared with batched lookups).
 Both give the same hit flags, rows and list order (tests/test_hostcache.py, tests/test_gpu_cache.py)."""

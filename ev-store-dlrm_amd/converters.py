@@ -141,7 +141,7 @@ def convert_altkeys_folder(input_folder, verbose=True):
 
 
 def tables_to_bin_dir(ev, out_dir):
-    """EVTables -> out_dir/ev-table-{1..T}.bin.  The tables already sit in HBM in the on-disk byte layout,
+    """EVTables -> out_dir/ev-table-{1..T}.bin.  The tables already sit in HBM in the on-disk byte layout (docs/HISTORY.md 2),
     so this is one device-to-host copy and one write per table, whatever the precision; chained behind
     EVTables.encode(bits) it is reduce_precision.py + convert_ev_to_binary.py without the CSV round trip."""
     os.makedirs(out_dir, exist_ok=True)

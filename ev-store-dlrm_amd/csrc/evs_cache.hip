@@ -1951,7 +1951,7 @@ template <> struct SaNative<NoTail> { using type = int; };
 // believe the key is absent choose the same way and the CAS lets one through; the loser's CAS returns the word that beat
 // it -- the key itself (fold the priority, done) or another key of this batch (that way is out, next best).  The line
 // is read plainly: what a plain read can return is a word as it stood at the start of the launch or one written in it,
-// and a way changes at most once per launch (old -> stamped), which is all the argument needs.
+// and a way changes at most once per launch (old -> stamped), which is all the argument needs (docs/HISTORY.md 3.4).
 template <int PIECES, typename U, typename TAIL = NoTail, int W = 0>
 __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsigned char *table, int t, unsigned row, int agg, unsigned set, unsigned tag1, int *s_delta, int *s_stat) {
     constexpr int NW = W > 0 ? W : kSaMaxWays;   // ways the scans below walk (W = 0: any geometry, masked by args.sa.ways)

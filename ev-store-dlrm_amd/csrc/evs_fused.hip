@@ -1527,7 +1527,7 @@ extern "C" int evs_emb_interact_dot_stacked(int64_t B, int T, int d, int codec, 
 // us per 16 384-sample batch instead of 19-20 for K launches -- the rate a caller alternating two HIP streams gets,
 // without any stream.  (A stream pair inside the library, forked from and joined into the caller's stream, was built first
 // and measured: 21.7-24.3 us per batch -- cross-stream event waits cost more on this stack than the overlap returns;
-// tools/multi_probe.py)  Shapes the one-chunk kernel does not take (reduced precision, d = 48 / 64 / 128,
+// tools/multi_probe.py, docs/HISTORY.md 3.2d.)  Shapes the one-chunk kernel does not take (reduced precision, d = 48 / 64 / 128,
 // F > 28) run as K launches.  Results are bit-identical to K evs_emb_interact_dot_stacked calls either way.
 extern "C" int evs_emb_interact_dot_stacked_multi(int K, int64_t B, int T, int d, int codec, const void *const *tables,
                                                   const int64_t *n_rows, const float *const *x, int64_t x_stride,

@@ -16,9 +16,9 @@
 //                  that mapping and the MFMA operand mapping (ds_write_b128 x 4, ds_read_b128 x 6 per sample).  The
 //                  code is straight-line, so hipcc's own counted s_waitcnt vmcnt(15..12) consumes sample u while
 //                  samples u+1.. stay in flight (with any branch around a memory operation the waitcnt pass takes the
-//                  minimum over paths and drains everything: measured).
+//                  minimum over paths and drains everything: measured, see docs/HISTORY.md 3.2b).
 // Used for batches whose blocks are all resident at once (B <= 16 x 4 x 256 = 16 384); larger batches keep the LDS-DMA
-// loop, whose steady state is bound by the per-CU vector-memory / LDS pipes rather than by latency.
+// loop, whose steady state is bound by the per-CU vector-memory / LDS pipes rather than by latency (docs/HISTORY.md 3.2).
 // Measured (same box, A/B by EVS_FUSED_RF): B = 16 384: 20.5 -> 18.9 us, B = 8 192: 12.5 -> 11.4 us.
 //
 // Row addresses need no cross-lane traffic here: the index tile in LDS has one row PER FEATURE (x and dense features
@@ -891,7 +891,7 @@ bool launch_rf_check(const FusedArgs &a, hipStream_t st) {
 
 // K batches in one launch: K * ceil(B / 16) one-chunk blocks; the hardware hands a CU the next block as one retires, so the
 // drain of a batch's last blocks runs under the fill of the next batch's first ones (what two alternating streams give a
-// caller, without any stream: cross-stream event waits cost more here than they return -- measured)
+// caller, without any stream: cross-stream event waits cost more here than they return -- measured, docs/HISTORY.md 3.2d)
 bool rf_multi_supported(int64_t B, int F, int d) {
     return rf_mode() && F <= kTileMaxF && B >= 1 && (d == 16 || d == 32 || d == 36 || (d == 64 && rf_d64()));
 }

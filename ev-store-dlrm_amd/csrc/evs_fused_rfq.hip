@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     __shared__ float s_lut[CodecLut<CODEC>::kEntries];
     // u4: a BYTE decodes to two elements at once (element 2j = the high nibble): one 8-byte table read and one byte
     // extraction per two elements instead of two reads and four shift / mask operations -- vector instructions add to the
-    // matrix time on this part, and the nibble form made u4 slower than u8 for half the bytes
+    // matrix time on this part (docs/HISTORY.md 3.2c), and the nibble form made u4 slower than u8 for half the bytes
     constexpr bool PAIR4 = CODEC == 4 && EVS_RFQ_U4PAIR;
     __shared__ float2 s_lut2[PAIR4 ? 256 : 1];
     constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;

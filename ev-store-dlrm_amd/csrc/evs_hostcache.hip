@@ -1,6 +1,6 @@
 // Host engine of the EXACT, one-request-at-a-time cache policies (EvLFU / LRU / LFU, C1 + C2, C1 + C2 + alt keys).
 //
-// Why this exists: the reference's EVStore loop is batch 1 (--test-mini-batch-size=1) and its policies are
+// Why this exists (docs/HISTORY.md 3.3): the reference's EVStore loop is batch 1 (--test-mini-batch-size=1) and its policies are
 // defined sequentially -- request n sees the inserts of request n-1, and inside a request key i sees the evictions keys
 // 0..i-1 caused.  That is a chain of dependent pointer updates over a few megabytes: one wavefront replays it at ~1 us
 // per dependent access (cache_exact_kernel: 28 us per request + launch + synchronise = 51 us), one host core walks it

@@ -658,7 +658,7 @@ int64_t orc_lfu_dump(const orc_lfu *c, int64_t *out, int64_t max_triples) {
 /* evlfu_4.cpp:374-425 phase_1 / phase_2 as the C2 half.                     */
 /* Both tiers are orc_evlfu objects built with the "cpp" constants; their     */
 /* tables hold the rows already decoded at that tier's precision.             */
-/* Deviations from the C++ (documented in DESIGN.md): eviction victims are    */
+/* Deviations from the C++ (documented in DESIGN.md 4)  : eviction victims are    */
 /* FIFO-oldest (the C++ takes unordered_set::begin(), not reproducible), and  */
 /* a C1 hit whose entry was evicted earlier in the same request is served     */
 /* from storage instead of through the dangling pointer (evlfu_8.cpp:521-522).*/

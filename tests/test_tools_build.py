@@ -1,6 +1,6 @@
 """The developer probes under tools/ (HIP programs of their own, not part of the library) still cross-compile for gfx950:
 tools/sector_probe.hip (random line requests per second) and tools/coexec_probe.hip (fp32 MFMA vs VALU on one SIMD) are the
-evidence behind DESIGN.md 3.2c *Round 3*; a probe that no longer builds cannot be re-run on another part."""
+evidence behind docs/HISTORY.md 3.2c *Round 3*; a probe that no longer builds cannot be re-run on another part."""
 import os
 import subprocess
 
