@@ -48,7 +48,6 @@ struct GatherArgs {
     int d;
     int *err;
     const void *zeros;   // the zero page (rows-in-registers gather: what a lane reads for a bag that has no row)
-    int nt_out;          // rows-in-registers gather: non-temporal stores (an output larger than the Infinity Cache only streams through it)
 };
 
 template <int CODEC>
@@ -468,7 +467,11 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
             const int iv = s_idx[tile[j] + 4 * n];
             const unsigned long long neg = 0ull - (unsigned long long)((unsigned)iv >> 31);   // -1 -> the zero page (bit blend: no branch around the load)
             const unsigned long long p = fbase[j] + (unsigned long long)((unsigned)iv & 0x7fffffffu) * (unsigned long long)row_bytes;
+#ifdef EVS_GR_NOLOAD   // (developer ablation: every row = the zero page)
+            ring[n][j] = *reinterpret_cast<gpiece_t>((uintptr_t)(zeros_p + 0 * (p ^ neg)));
+#else
             ring[n][j] = *reinterpret_cast<gpiece_t>((uintptr_t)(p ^ ((p ^ zeros_p) & neg)));
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -487,9 +490,13 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
                     else f = dec_chunk<CODEC>((unsigned)ring[n][j], 0u, s_lut);
                     o.x = f.x; o.y = f.y; o.z = f.z; o.w = f.w;
                 }
+#ifdef EVS_GR_NOSTORE   // (developer ablation: only values that cannot occur are stored)
+                if (t_on[j] && o.x == 12345.678f) {
+#else
                 if (t_on[j]) {
-                    if (args.nt_out) __builtin_nontemporal_store(o, reinterpret_cast<gr_f32x4 *>((uintptr_t)(obase[j] + ob)));
-                    else *reinterpret_cast<gr_f32x4 *>((uintptr_t)(obase[j] + ob)) = o;
+#endif
+                    // (ordinary stores: non-temporal ones run at half the rate for this pattern, tools/store_pattern_probe.hip)
+                    *reinterpret_cast<gr_f32x4 *>((uintptr_t)(obase[j] + ob)) = o;
                 }
             }
         }
@@ -792,10 +799,6 @@ static bool launch_gather_rows(const GatherArgs &a, bool vec_ok, hipStream_t str
     const dim3 grid((unsigned)((a.B + 15) / 16)), block(256);
     GatherArgs g = a;
     g.zeros = zp;
-    {   // the pooled rows of a batch this large do not stay in the 256 MiB Infinity Cache for the next kernel anyway
-        static const long long nt_mb = getenv("EVS_GATHER_NT_MB") ? atoll(getenv("EVS_GATHER_NT_MB")) : 192;
-        g.nt_out = (long long)a.T * a.B * a.d * 4 > (nt_mb << 20) ? 1 : 0;
-    }
 #define EVS_GR(L, N) \
     do { \
         if (bag1) hipLaunchKernelGGL((gather_rows_kernel<CODEC, L, N, false>), grid, block, 0, stream, g); \
@@ -904,7 +907,6 @@ static int bag_sum_impl(int T, int64_t B, int d, int codec, const void *const *t
         a.err = err;
         a.chunks_per_table = 0;
         a.zeros = nullptr;
-        a.nt_out = 0;
         if ((codec == 32 && launch_gather_rows<32>(a, vec_ok, st, bag1)) || (codec == 16 && launch_gather_rows<16>(a, vec_ok, st, bag1)) ||
             (codec == 8 && launch_gather_rows<8>(a, vec_ok, st, bag1)) || (codec == 4 && launch_gather_rows<4>(a, vec_ok, st, bag1))) {
             EVS_HIP_CHECK(hipGetLastError());
