@@ -34,6 +34,8 @@ import ctypes as C
 import time
 
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -240,22 +242,40 @@ class _P2PExchange:
         self.n_recv = sum(out_splits)
         self.dev = op.backend.device
         self.own_recv, self.own_flags, self.recv_t, handles = [], [], [], []
-        with torch.cuda.device(self.dev):
-            for s_ in range(n_slots):
-                pr, pf = C.c_void_p(), C.c_void_p()
-                _lib.check(L.evs_p2p_alloc(C.byref(pr), max(4 * self.n_recv, 64)))
-                _lib.check(L.evs_p2p_alloc(C.byref(pf), 4 * 2 * max(self.W, 1) + 64))
-                self.own_recv.append(pr.value); self.own_flags.append(pf.value)
-                hr, hf = (C.c_char * 64)(), (C.c_char * 64)()
-                if self.W > 1 and virtual_peers is None:
-                    _lib.check(L.evs_p2p_ipc_export(pr, hr)); _lib.check(L.evs_p2p_ipc_export(pf, hf))
-                handles.append((bytes(hr), bytes(hf)))
+        self._opened = []
+        real = self.W > 1 and virtual_peers is None      # one process per rank: every step below is agreed on by all ranks
+        err = None
+        try:
+            if os.environ.get("EVS_P2P_INJECT_FAIL") == str(self.r):   # (tests: a rank whose set-up fails must not strand the others)
+                raise RuntimeError("injected set-up failure")
+            with torch.cuda.device(self.dev):
+                for s_ in range(n_slots):
+                    pr, pf = C.c_void_p(), C.c_void_p()
+                    _lib.check(L.evs_p2p_alloc(C.byref(pr), max(4 * self.n_recv, 64)))
+                    self.own_recv.append(pr.value)
+                    _lib.check(L.evs_p2p_alloc(C.byref(pf), 4 * 2 * max(self.W, 1) + 64))
+                    self.own_flags.append(pf.value)
+                    hr, hf = (C.c_char * 64)(), (C.c_char * 64)()
+                    if real:
+                        _lib.check(L.evs_p2p_ipc_export(pr, hr)); _lib.check(L.evs_p2p_ipc_export(pf, hf))
+                    handles.append((bytes(hr), bytes(hf)))
+        except Exception as ex:
+            if not real:
+                self.close()
+                raise
+            err = repr(ex)
+        if real:   # (a rank that failed still takes part in the collective: nobody is left waiting for it)
+            allh = [None] * self.W
+            dist.all_gather_object(allh, (err, handles), group=op.group)
+            bad = ["rank %d: %s" % (p, a[0]) for p, a in enumerate(allh) if a[0]]
+            if bad:
+                self.close()
+                raise RuntimeError("p2p exchange: buffer allocation / export failed (%s)" % "; ".join(bad))
         # the receive buffer as a tensor the interaction kernel's feature specs can view (no copy: __cuda_array_interface__)
         for s_ in range(n_slots):
             self.recv_t.append(_tensor_over(self.own_recv[s_], self.n_recv, self.dev, self))
         self.peer_recv = [[None] * self.W for _ in range(n_slots)]
         self.peer_flags = [[None] * self.W for _ in range(n_slots)]
-        self._opened = []
         self.k_pool = [0] * n_slots       # uses of a slot this rank has pooled into / consumed
         self.k_done = [0] * n_slots
         self._pending = None              # (pointer array, value): a signal that rides in the next sync launch
@@ -269,26 +289,34 @@ class _P2PExchange:
                             v.peer_recv[s_][p], v.peer_flags[s_][p] = virtual_peers[p].own_recv[s_], virtual_peers[p].own_flags[s_]
                     v._wire()
             return
-        if self.W > 1:
-            allh = [None] * self.W
-            dist.all_gather_object(allh, handles, group=op.group)
-        for s_ in range(n_slots):
-            for p in range(self.W):
-                if p == self.r:
-                    self.peer_recv[s_][p], self.peer_flags[s_][p] = self.own_recv[s_], self.own_flags[s_]
-                    continue
-                with torch.cuda.device(self.dev):
-                    for which, h in enumerate(allh[p][s_]):
-                        out = C.c_void_p()
-                        _lib.check(L.evs_p2p_ipc_open(C.create_string_buffer(h, 64), C.byref(out)))
-                        self._opened.append(out.value)
-                        if which == 0:
-                            self.peer_recv[s_][p] = out.value
-                        else:
-                            self.peer_flags[s_][p] = out.value
+        try:
+            for s_ in range(n_slots):
+                for p in range(self.W):
+                    if p == self.r:
+                        self.peer_recv[s_][p], self.peer_flags[s_][p] = self.own_recv[s_], self.own_flags[s_]
+                        continue
+                    with torch.cuda.device(self.dev):
+                        for which, h in enumerate(allh[p][1][s_]):
+                            out = C.c_void_p()
+                            _lib.check(L.evs_p2p_ipc_open(C.create_string_buffer(h, 64), C.byref(out)))
+                            self._opened.append(out.value)
+                            if which == 0:
+                                self.peer_recv[s_][p] = out.value
+                            else:
+                                self.peer_flags[s_][p] = out.value
+        except Exception as ex:
+            if not real:
+                self.close()
+                raise
+            err = repr(ex)
+        if real:
+            oks = [None] * self.W
+            dist.all_gather_object(oks, err, group=op.group)   # (also: everybody has mapped everybody before the first write)
+            bad = ["rank %d: %s" % (p, e) for p, e in enumerate(oks) if e]
+            if bad:
+                self.close()
+                raise RuntimeError("p2p exchange: mapping a peer's buffers failed (%s)" % "; ".join(bad))
         self._wire()
-        if self.W > 1:
-            dist.barrier(group=op.group)  # everybody has mapped everybody before the first write
 
     def _wire(self):
         n_slots = self.n_slots
@@ -344,7 +372,8 @@ class _P2PExchange:
         for p in self._opened:
             L.evs_p2p_ipc_close(C.c_void_p(p))
         for p in self.own_recv + self.own_flags:
-            L.evs_p2p_free(C.c_void_p(p))
+            if p:
+                L.evs_p2p_free(C.c_void_p(p))
         self._opened, self.own_recv, self.own_flags = [], [], []
 
 
@@ -799,6 +828,16 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
             op.run_finish(plans[(i % nb, i % 2)], h)
             h = nxt
 
+    if op.exchange_mode == "p2p" and world > 1:
+        # first steps over mappings no test has seen (two physical GPUs): all ranks agree that the hand-overs arrive before
+        # the long loops start -- a wait that ran out of patience sets the sticky flag on the rank that waited
+        run(2)
+        op.p2p_flush()
+        torch.cuda.synchronize()
+        ok = torch.tensor([1 if _lib.lib().evs_check_index_errors(None) == 0 else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError("p2p exchange: a hand-over did not arrive on some rank (%s)" % _lib.lib().evs_last_error())
     run(args.warmup)
     run(1500)   # clock settle: a FIXED number of untimed steps (every rank must issue the same collectives)
     op.p2p_flush()
@@ -864,6 +903,27 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     del op, plans, weights, graphs
     torch.cuda.empty_cache()
     return res
+
+
+def bench_p2p_side(args, ln_emb, rank, world, dev):
+    """The same placement and steps with exchange_mode "p2p" (no collective call in the step), as a side line of the N > 1
+    bench: never raises, and every rank returns from it (set-up failures and hand-overs that do not arrive are agreed on over
+    the process group before anybody proceeds)."""
+    import copy
+    try:
+        a = copy.copy(args)
+        a.exchange_mode = "p2p"
+        policy = getattr(args, "placement", "rows+replicate")
+        budget_rows = int(getattr(args, "replicate_gb", 64.0) * 1e9 / (4 * args.dim))
+        e = _bench_policy(a, ln_emb, rank, world, dev, policy, budget_rows, True)
+        if e["n_sharded"] == 0 and not e["n_rowsplit"]:
+            return {"skipped": "nothing is exchanged under this placement"}
+        T, Bg = len(ln_emb), args.batch * world
+        return {"value": T * Bg * args.steps / e["dt"], "unit": "lookups/s", "ms_per_step": e["dt"] / args.steps * 1e3, "roofline": e["roofline"],
+                "note": "the same step without a collective call: the pooling launch writes every peer's block into that peer's IPC-mapped "
+                        "receive buffer over xGMI, two flag words per (peer, slot) hand it over (csrc/evs_p2p.hip)"}
+    except Exception as ex:
+        return {"error": repr(ex)}
 
 
 def bench_sharded(args, ln_emb, rank, world, dev):

@@ -21,6 +21,14 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if len(sys.argv) > 4 and sys.argv[4] == "bench":   # the N > 1 bench's side line (bench.py: exchange_p2p), every rank returns
+        from types import SimpleNamespace
+        args = SimpleNamespace(dim=36, batch=512, steps=20, warmup=3, placement="rows", replicate_gb=64.0, exchange_mode="inline")
+        res = sharded.bench_p2p_side(args, [5000, 7, 2600, 40, 9000, 3, 12000] + [100] * 19, rank, world, dev)
+        dist.barrier()
+        dist.destroy_process_group()
+        print("P2P_BENCH %s" % ("error: " + res["error"] if "error" in res else "ok %.3f ms" % res["ms_per_step"]))
+        return
     rs = np.random.RandomState(3)                      # (the same model and batches in every process)
     ln = [5000, 7, 2600, 40, 9000, 3, 12000] + [100] * 19
     T, d, Bl = len(ln), 36, 96

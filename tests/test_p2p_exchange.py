@@ -126,3 +126,37 @@ def test_p2p_exchange_between_processes():
         outs.append((p.returncode, o, e))
     for r, (rc, o, e) in enumerate(outs):
         assert rc == 0 and "P2P_CHILD_OK" in o, (r, o[-1500:], e[-3000:])
+
+
+def _run_children(extra, env_extra=None, timeout=420):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_p2p_child.py")
+    procs = [subprocess.Popen([sys.executable, child, str(r), "2", str(port)] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            o, e = p.communicate()
+        outs.append((p.returncode, o, e))
+    return outs
+
+
+def test_bench_side_line_between_processes():
+    """bench.py's N > 1 side line (`exchange_p2p`: sharded.bench_p2p_side) with two processes on GPU 0 over a gloo group: the
+    warm-up agreement, the settle loop and the timed loop over real IPC mappings; every rank returns a timing."""
+    for r, (rc, o, e) in enumerate(_run_children(["bench"])):
+        assert rc == 0 and "P2P_BENCH ok" in o, (r, o[-1500:], e[-3000:])
+
+
+def test_bench_side_line_survives_a_rank_that_cannot_set_up():
+    """A rank whose buffers cannot be allocated takes part in the hand-shake all the same: BOTH ranks come back with an error
+    record (nobody waits for a peer that gave up), the process group stays usable (the barrier behind it passes)."""
+    for r, (rc, o, e) in enumerate(_run_children(["bench"], {"EVS_P2P_INJECT_FAIL": "1"}, timeout=120)):
+        assert rc == 0 and "P2P_BENCH error" in o and "injected" in o, (r, o[-1500:], e[-3000:])
