@@ -288,6 +288,11 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
     // Behind them -- rows asked for on the bet that it is, compares and the block barrier under their round trip, the slow
     // loop at the end of the kernel overwriting what the one-index code produced -- was built and measured: 22.3 instead of
     // 20.7 us at B = 16 384; the offsets pairs then live across the 64 row registers, 128 VGPRs and spills.)
+    // A bag ends where the next one starts, and the next one's start is its own lane's o0 (same feature, next sample): every lane
+    // checks that ITS bag starts at its own position, the lane of the chunk's last sample also where that bag ends -- no
+    // exchange between lanes (round 4: the shuffle and the second 64-bit compare per key were 10 VALU instructions per
+    // sample in front of the row requests).
+    bool fast_bad = false;   // out-of-range indices seen by the one-index code; they count only if the block stays on it
     auto verify = [&]() {
         const int64_t bs = blk_first + (threadIdx.x & 15);
 #pragma unroll
@@ -297,14 +302,11 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             //  block then runs, has the verdict on it)
             const bool table = s_tile_kind[f] == 2 && bs < blk_end;
             const bool own = table && ((threadIdx.x & 15) == 15 || bs + 1 >= blk_end);
-            int64_t o0 = tile_o0[h], o1 = tile_o1[h];
-            const int64_t nb = __shfl_down((long long)tile_o0[h], 1);
-            if (!own) o1 = nb;
-            if (own && !(bs + 1 < s_tile_ol[f])) o1 = s_tile_nz[f];   // the last bag ends at nnz
-            if (!table) { o0 = bs; o1 = bs + 1; }
-            const bool mine = o0 == bs && o1 == bs + 1;
-            my_ragged |= !mine;
-            bad |= oob[h] & mine;
+            int64_t o1 = tile_o1[h];
+            if (!(bs + 1 < s_tile_ol[f])) o1 = s_tile_nz[f];   // the last bag ends at nnz
+            const bool ok = (tile_o0[h] == bs) & (!own | (o1 == bs + 1));
+            my_ragged |= table & !ok;
+            fast_bad |= oob[h];
         }
     };
 
@@ -633,6 +635,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
                 slow_block();
                 return;
             }
+            bad |= fast_bad;
         } else {
             __syncthreads();
         }

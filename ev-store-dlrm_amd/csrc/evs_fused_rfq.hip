@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     const int n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
 
     // ---- index tile: thread e (and e + 256) owns element (feature e >> 4, sample e & 15) -------------------------------
-    bool bad = false, my_ragged = false;
+    bool bad = false, my_ragged = false, fast_bad = false;
     {
         const int64_t bs = blk_first + (threadIdx.x & 15);
         int64_t v[2], o0[2], o1[2];
@@ -237,17 +237,16 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
             }
         }
         if constexpr (CHECK) {
+            // a bag ends where the next one starts = the next lane's o0, which that lane checks itself: no exchange between lanes
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int64_t nb = __shfl_down((long long)o0[h], 1);
-                if (!own_end[h]) o1[h] = nb;
                 if (at_nnz[h]) o1[h] = nzv[h];              // the last bag ends at nnz
-                if (!live_bag[h]) { o0[h] = bs; o1[h] = bs + 1; }
+                const bool ok = (o0[h] == bs) & (!own_end[h] | (o1[h] == bs + 1));
+                my_ragged |= live_bag[h] & !ok;
             }
         }
         codec_lut_init<CODEC>(s_lut);
         if constexpr (PAIR4) s_lut2[threadIdx.x] = make_float2(u4_value(threadIdx.x >> 4), u4_value(threadIdx.x & 15u));   // (256 threads)
-        if constexpr (CHECK) my_ragged = o0[0] != bs || o1[0] != bs + 1 || o0[1] != bs || o1[1] != bs + 1;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const bool live = kind[h] != 0 && bs < blk_end;
@@ -255,9 +254,8 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
             const bool in_range = kind[h] == 1 || (uint64_t)val < (uint64_t)nr[h];
             // (CHECK: an index whose own bag is not {idx[b]} may sit at a position no bag refers to -- the slow loop, which
             //  this block then runs, has the verdict on it)
-            bool mine = true;
-            if constexpr (CHECK) mine = o0[h] == bs && o1[h] == bs + 1;
-            bad |= live & !in_range & mine;
+            if constexpr (CHECK) fast_bad |= live & !in_range;   // (counts only if the block stays on the one-index code)
+            else bad |= live & !in_range;
             s_idx[(int)threadIdx.x + 256 * h] = (live & in_range) ? (int)val : -1;
         }
     }
@@ -287,6 +285,7 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
 #ifdef EVS_XQ_NOOFF
     blk_ragged = blk_ragged && args.B == 12345;
 #endif
+    if (!blk_ragged) bad |= fast_bad;
 
     constexpr int kOob = 0x7ffffff0;
     auto flush_out = [&](int64_t bp, bool on) {

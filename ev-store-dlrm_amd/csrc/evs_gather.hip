@@ -390,10 +390,10 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
             int id = -1;
             if (on[h]) {
                 if constexpr (CHECK) {
+                    // (a bag ends where the next one starts = the next lane's o0, which that lane checks itself)
                     const bool own = (threadIdx.x & 15) == 15 || bs + 1 >= blk_end;
-                    const int64_t nb = __shfl_down((long long)o0[h], 1);
-                    const int64_t en = own ? (bs + 1 < B ? o1[h] : nz[h]) : nb;
-                    ragged |= !(o0[h] == bs && en == bs + 1);
+                    const int64_t en = bs + 1 < B ? o1[h] : nz[h];
+                    ragged |= !((o0[h] == bs) & (!own | (en == bs + 1)));
                 }
                 if (v[h] >= 0 && v[h] < tot[h]) {
                     const int64_t r = v[h] - lo[h];
