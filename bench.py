@@ -302,9 +302,9 @@ def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
               "value": T * B * (len(stamps) - 1) / (stamps[-1] - stamps[0]), "unit": "lookups/s"}
     # throughput form: every batch ONE pinned block and ONE copy command on a copy stream, double-buffered under the launch
     # of the previous batch (inference_loop.PackedPinnedBatches / Prefetcher); int32 = the opt-in narrow wire format
-    def overlapped(index_dtype, copy_stream=False):
+    def overlapped(index_dtype, copy_stream=False, signals=True):
         pk = IL.PackedPinnedBatches(host, n_req, index_dtype)
-        pf = IL.Prefetcher(pk, dev, copy_stream=copy_stream)      # (its slots / stream / events are made here, outside the timed region)
+        pf = IL.Prefetcher(pk, dev, copy_stream=copy_stream, signals=signals)      # (its slots / stream / signal words are made here, outside the timed region)
         pk.count = 16
         for X, lo, li in pf:
             E.apply_emb_interact(x_dev, lo, li, ev, None, out=out)
@@ -318,16 +318,19 @@ def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
         return {"ms_per_batch": dto / n_req * 1e3, "value": T * B * n_req / dto, "unit": "lookups/s", "bytes_per_batch": pk.nbytes,
                 "GBps": pk.nbytes * n_req / dto / 1e9}
 
-    ov64 = overlapped(torch.int64)
-    ov32 = overlapped(torch.int32)
+    ov64 = overlapped(torch.int64, copy_stream=False)
+    ov32 = overlapped(torch.int32, copy_stream=True)
     ov2s = overlapped(torch.int64, copy_stream=True)
+    ov2e = overlapped(torch.int64, copy_stream=True, signals=False)
     return {"bytes_per_sample": 13 * 4 + 2 * 8 * T, "requests": n_req, "batch": B,
             "as_the_reference_loop": serial,
-            "packed_one_copy_per_batch": ov64, "packed_int32_wire": ov32, "copy_stream_overlapped": ov2s,
+            "packed_one_copy_per_batch": ov64, "packed_int32_wire": ov32, "copy_stream_overlapped": ov2s, "copy_stream_event_handoffs": ov2e,
             "throughput_note": "packed: every batch ONE pinned block and ONE copy command queued in front of its launch on the same stream, no "
                                "per-request synchronise (inference_loop.PackedPinnedBatches / Prefetcher); int32 wire: offsets and indices cross as "
-                               "4 bytes and are widened on the device; copy_stream_overlapped: the same copies on a second stream under the previous "
-                               "launch -- slower on this stack (cross-stream event hand-offs)",
+                               "4 bytes on the copy stream and are widened on the device; copy_stream_overlapped: the same copies on a second stream under the previous "
+                               "launch, the two hand-overs per batch as signal words the command processors write and wait for in stream order "
+                               "(hipStreamWriteValue32 / hipStreamWaitValue32); copy_stream_event_handoffs: the same with events -- slower than one "
+                               "stream on this stack (an event wait between streams wakes up late)",
             "note": "per batch X (B,13) fp32, lS_o and lS_i (26,B) int64 from PINNED host memory (dlrm_wrap); latency = "
                     "difference of consecutive loop-top wall-clock stamps, result synchronised per request; PCIe Gen5 x16"}
 

@@ -107,3 +107,48 @@ extern "C" int evs_p2p_sync(int n_sig, uint32_t *const *sig, uint32_t sig_value,
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
 }
+
+// ---- stream-ordered signal words: hand-overs between two streams of ONE device without an event --------------------------
+// An event wait between two streams goes through the host-side scheduler on this stack (a stream that waits on an event of
+// another stream wakes up ~0.1-0.2 ms late when it was idle: tools/h2d_probe2.py).  A signal word is written and waited for
+// by the command processors themselves (hipStreamWriteValue32 / hipStreamWaitValue32, ">= value" wait): the copy stream of
+// inference_loop.Prefetcher tells the compute stream "batch k is in its slot", the compute stream tells it "slot free".
+extern "C" int evs_signal_alloc(void **out) {
+    using namespace evs;
+    EVS_REQUIRE(out, "evs_signal_alloc: NULL argument");
+    int dev = 0, ok = 0;
+    EVS_HIP_CHECK(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess || !ok) {
+        (void)hipGetLastError();
+        set_error("evs_signal_alloc: this device has no stream wait-value operations");
+        return EVS_ESTATE;
+    }
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("evs_signal_alloc: hipExtMallocWithFlags(hipMallocSignalMemory) failed");
+        return EVS_ENOMEM;
+    }
+    EVS_HIP_CHECK(hipMemset(p, 0, 8));
+    *out = p;
+    return EVS_OK;
+}
+
+extern "C" int evs_signal_free(void *p) {
+    if (p) (void)hipFree(p);
+    return EVS_OK;
+}
+
+extern "C" int evs_stream_write_value(void *stream, void *signal, uint32_t value) {
+    using namespace evs;
+    EVS_REQUIRE(signal, "evs_stream_write_value: NULL signal");
+    EVS_HIP_CHECK(hipStreamWriteValue32(reinterpret_cast<hipStream_t>(stream), signal, value, 0));
+    return EVS_OK;
+}
+
+extern "C" int evs_stream_wait_value(void *stream, void *signal, uint32_t value) {
+    using namespace evs;
+    EVS_REQUIRE(signal, "evs_stream_wait_value: NULL signal");
+    EVS_HIP_CHECK(hipStreamWaitValue32(reinterpret_cast<hipStream_t>(stream), signal, value, hipStreamWaitValueGte, 0xffffffffu));
+    return EVS_OK;
+}

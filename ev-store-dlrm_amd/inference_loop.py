@@ -136,34 +136,78 @@ class PackedPinnedBatches:
 class Prefetcher:
     """H2D staging for PackedPinnedBatches: ONE copy command per batch into a rotating device slot; the tensors a batch
     yields are views of its slot (int32 wire batches arrive widened to int64), valid until the slot comes round again.
-      copy_stream=False (default): the copy is queued on the caller's stream in front of the batch's launches -- no
+      copy_stream=False: the copy is queued on the caller's stream in front of the batch's launches -- no
         synchronisation, no per-request stamps: the bus stays busy back to back (7.7 MB per 16 384-batch in 0.144 ms, the
-        20 us launch behind it: 0.165 ms per batch against 0.193 for the reference loop's three copies + synchronise);
-      copy_stream=True: batch i + 1 crosses on a copy stream under batch i's launch, two event hand-offs per batch (copied
-        -> compute may start; consumed -> the slot may be overwritten).  Measured SLOWER on this stack (0.21 ms per batch
-        whatever the bytes: an event wait between two streams wakes up late when the waiting stream is idle), kept as the
-        form a longer compute phase would want.
+        20 us launch behind it: 0.165-0.172 ms per batch against 0.193 for the reference loop's three copies + synchronise);
+      copy_stream=True (the default where the device has stream wait-value operations: 0.160 ms per batch = 47.8 GB/s):
+        batch i + 1 crosses on a copy stream under batch i's launch.  The two hand-overs per batch (copied
+        -> compute may start; consumed -> the slot may be overwritten) are SIGNAL WORDS written and waited for by the
+        command processors in stream order (evs_stream_write_value / evs_stream_wait_value: csrc/evs_p2p.hip) -- an event
+        wait between two streams wakes up 0.1-0.2 ms late on this stack when the waiting stream is idle (0.21-0.5 ms per
+        batch, measured) -- with events as the fall-back where the device has no such operations (signals=False forces it).
     for X, lS_o, lS_i in Prefetcher(ld, device): forward(...)"""
 
-    def __init__(self, ld, device, depth=2, copy_stream=False):
+    def __init__(self, ld, device, depth=2, copy_stream=None, signals=True):
         self.ld, self.device, self.depth = ld, torch.device(device), depth
+        auto = copy_stream is None     # default: the copy stream when its hand-overs can be signal words, else one stream
+        if auto:
+            copy_stream = bool(signals)
         self.cs = torch.cuda.Stream(device=self.device) if copy_stream else None
         self.slots = [torch.empty(ld.nbytes, dtype=torch.uint8, device=self.device) for _ in range(depth)]
         self.copied = [torch.cuda.Event() for _ in range(depth)]
         self.used = [torch.cuda.Event() for _ in range(depth)]
+        self.sig = None          # per slot: (copied word, used word), counting the slot's uses
+        self.uses = [0] * depth
+        if copy_stream and signals:
+            from . import _lib
+            import ctypes as C
+            L = _lib.lib()
+            sig = []
+            try:
+                with torch.cuda.device(self.device):
+                    for _ in range(2 * depth):
+                        p = C.c_void_p()
+                        _lib.check(L.evs_signal_alloc(C.byref(p)))
+                        sig.append(p.value)
+                self.sig = [(sig[2 * i], sig[2 * i + 1]) for i in range(depth)]
+                self._L = L
+            except Exception:    # no stream wait-value operations on this device: events (or, by default, one stream)
+                for p in sig:
+                    L.evs_signal_free(C.c_void_p(p))
+                self.sig = None
+                if auto:
+                    self.cs = None
         self.wide = None
         if ld.index_dtype == torch.int32:
             _, os_, is_, _, _ = ld.layout
             self.wide = [(torch.empty(os_, dtype=torch.int64, device=self.device), torch.empty(is_, dtype=torch.int64, device=self.device))
                          for _ in range(depth)]
 
+    def __del__(self):
+        if getattr(self, "sig", None):
+            try:
+                torch.cuda.synchronize(self.device)
+                for a, b in self.sig:
+                    self._L.evs_signal_free(a)
+                    self._L.evs_signal_free(b)
+            except Exception:
+                pass
+            self.sig = None
+
     def _issue(self, i):
         sl = i % self.depth
         with torch.cuda.stream(self.cs):
-            if i >= self.depth:
+            # the slot's previous use has been consumed
+            if self.sig:
+                self._L.evs_stream_wait_value(self.cs.cuda_stream, self.sig[sl][1], self.uses[sl] & 0xffffffff)
+            elif i >= self.depth:
                 self.cs.wait_event(self.used[sl])
             self.slots[sl].copy_(self.ld.blocks[i % len(self.ld.blocks)], non_blocking=True)
-            self.copied[sl].record(self.cs)
+            self.uses[sl] += 1
+            if self.sig:
+                self._L.evs_stream_write_value(self.cs.cuda_stream, self.sig[sl][0], self.uses[sl] & 0xffffffff)
+            else:
+                self.copied[sl].record(self.cs)
 
     def _views(self, sl):
         X, lo, li = self.ld.views(self.slots[sl])
@@ -183,12 +227,28 @@ class Prefetcher:
                 yield self._views(sl)
             return
         main = torch.cuda.current_stream(self.device)
-        for i in range(min(self.depth - 1, n)):
-            self._issue(i)
-        for i in range(n):
-            if i + self.depth - 1 < n:
-                self._issue(i + self.depth - 1)      # the next batch starts crossing now
-            sl = i % self.depth
-            main.wait_event(self.copied[sl])
-            yield self._views(sl)
-            self.used[sl].record(main)               # (behind whatever the caller queued on its stream for this batch)
+        self._base = list(self.uses)
+        try:
+            for i in range(min(self.depth - 1, n)):
+                self._issue(i)
+            for i in range(n):
+                if i + self.depth - 1 < n:
+                    self._issue(i + self.depth - 1)      # the next batch starts crossing now
+                sl = i % self.depth
+                if self.sig:   # (the value the copy of batch i wrote: its slot's use count)
+                    self._L.evs_stream_wait_value(main.cuda_stream, self.sig[sl][0], self._use_of(i) & 0xffffffff)
+                else:
+                    main.wait_event(self.copied[sl])
+                yield self._views(sl)
+                if self.sig:                              # (behind whatever the caller queued on its stream for this batch)
+                    self._L.evs_stream_write_value(main.cuda_stream, self.sig[sl][1], self._use_of(i) & 0xffffffff)
+                else:
+                    self.used[sl].record(main)
+        finally:
+            if self.sig:   # a pass left early: every slot issued counts as consumed (nobody waits for a hand-over that never comes)
+                for sl in range(self.depth):
+                    self._L.evs_stream_write_value(main.cuda_stream, self.sig[sl][1], self.uses[sl] & 0xffffffff)
+
+    def _use_of(self, i):
+        """the use count of slot i % depth when batch i of the current pass was issued"""
+        return self._base[i % self.depth] + i // self.depth + 1

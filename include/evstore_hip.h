@@ -132,6 +132,15 @@ EVS_API int evs_p2p_ipc_close(void *p);
 EVS_API int evs_p2p_sync(int n_sig, uint32_t *const *sig, uint32_t sig_value, int n_wait, const uint32_t *const *wait,
                          uint32_t wait_value, void *stream);
 
+/* a16 (dlrm_wrap's per-batch H2D, dlrm_s_pytorch.py:131-147) as a two-stream pipeline: signal words that one stream of a
+ * device writes and another waits for (">= value") in stream order, executed by the command processors -- no event, no host
+ * wake-up between the copy stream and the compute stream (inference_loop.Prefetcher(copy_stream=True)).
+ * evs_signal_alloc: 8 bytes of signal memory, zeroed (EVS_ESTATE when the device has no stream wait-value operations). */
+EVS_API int evs_signal_alloc(void **out);
+EVS_API int evs_signal_free(void *signal);
+EVS_API int evs_stream_write_value(void *stream, void *signal, uint32_t value);
+EVS_API int evs_stream_wait_value(void *stream, void *signal, uint32_t value);
+
 /* Row-split tables, receiver side (one index per bag): sample b of table k reads the partial of the rank whose row range
  * holds indices[k][b] -- rank r holds rows [r*n/world, (r+1)*n/world) -- i.e. row  row_off[r] + b  of the partials inside
  * the receive buffer (row_off: HOST array of `world` row offsets, one per source rank).  dst[k][b] (device, int64) receives

@@ -1477,7 +1477,7 @@ def test_sharded_step_through_rccl_at_world_1():
     assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("copy_stream", [False, True])
+@pytest.mark.parametrize("copy_stream", [False, True, "events"])
 @pytest.mark.parametrize("wire", [torch.int64, torch.int32])
 def test_packed_pinned_batches_through_the_prefetcher(E, orc, wire, copy_stream):
     """a16, throughput form (inference_loop.PackedPinnedBatches / Prefetcher): every batch one pinned block and ONE copy command
@@ -1498,7 +1498,13 @@ def test_packed_pinned_batches_through_the_prefetcher(E, orc, wire, copy_stream)
     pk = IL.PackedPinnedBatches(host, 13, wire)
     assert pk.nbytes == (B * 13 * 4 + 15) // 16 * 16 + 2 * T * B * (8 if wire == torch.int64 else 4)
     n = 0
-    for X, lo, li in IL.Prefetcher(pk, "cuda", copy_stream=copy_stream):
+    pf = IL.Prefetcher(pk, "cuda", copy_stream=bool(copy_stream), signals=copy_stream != "events")
+    assert IL.Prefetcher(pk, "cuda").cs is not None   # the default: the copy stream with signal-word hand-overs
+    if copy_stream is True:
+        assert pf.sig is not None, "MI355X has stream wait-value operations: the hand-overs are signal words"
+    for X, lo, li in pf:   # a pass left early must not strand the copy stream (the next pass re-uses the slots)
+        break
+    for X, lo, li in pf:
         k = n % len(host)
         assert lo.dtype == torch.int64 and li.dtype == torch.int64
         assert torch.equal(X.cpu(), host[k][0]) and torch.equal(li.cpu(), host[k][2]) and torch.equal(lo.cpu(), host[k][1])
