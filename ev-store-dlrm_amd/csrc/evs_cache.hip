@@ -1760,7 +1760,7 @@ __device__ __forceinline__ int sampled_take(const BatchArgs &args, long long e0,
 // the alt-key set's fill: one evicted key becomes a member (second chance within its set)
 struct C3Set { unsigned long long *tags; long long nset; long long *stat; };
 __device__ __forceinline__ void c3_insert_key(const C3Set &c3, unsigned long long key) {
-    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
+    const long long base = c3_base(key, c3.nset);
     bool done = false;
     for (int attempt = 0; attempt < 4 && !done; attempt++) {   // (a CAS lost to another newcomer of the same set: look again)
         unsigned long long w[kSetWays];
@@ -2355,7 +2355,7 @@ __global__ void __launch_bounds__(256) c3_batch_insert_kernel(const BatchArgs ar
     const unsigned long long rec = args.evicted_keys[b->n_free + i];
     if (rec >> 63) return;
     const unsigned long long key = rec & kKeyMask;
-    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
+    const long long base = c3_base(key, c3.nset);
     for (int attempt = 0; attempt < 4; attempt++) {   // (a CAS lost to another newcomer of the same set: look again)
         unsigned long long w[kSetWays];
         int present = 0, empty = -1, plain = -1;

@@ -224,8 +224,13 @@ struct C3Batch {
     const unsigned *alt_tables[kMaxTables];
     long long alt_rows[kMaxTables];
 };
+// first word of a key's set: the high half of the hash scaled into [0, nset) by a multiply (nset < 2^32; a 64-bit modulo by a
+// run-time value is a ~150-instruction software division, in the head of every block of the three-tier probe)
+__device__ __forceinline__ long long c3_base(unsigned long long key, long long nset) {
+    return (long long)__umulhi((unsigned)(mix64(key * 0x9e3779b97f4a7c15ull) >> 32), (unsigned)nset) * kSetWays;
+}
 __device__ __forceinline__ long long c3_find(const C3Batch &c3, unsigned long long key) {
-    const long long base = (long long)(mix64(key * 0x9e3779b97f4a7c15ull) % (unsigned long long)c3.nset) * kSetWays;
+    const long long base = c3_base(key, c3.nset);
     long long found = -1;
 #pragma unroll
     for (int w = 0; w < kSetWays; w++)

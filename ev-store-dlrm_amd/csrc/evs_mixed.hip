@@ -264,11 +264,16 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
     // tables have, dense row number of row 0 (set-associative tiers)
     __shared__ long long s_nrows[PROBE ? 32 : 1];
     __shared__ unsigned s_sa_base[PROBE ? 32 : 1];
+    __shared__ unsigned long long s_back[PROBE ? 64 : 1];   // the tables the two tiers read their misses from (t1: [k], t2: [32 + k])
+    __shared__ unsigned long long s_alt[PROBE ? 32 : 1];    // the alt-key tables (three tiers)
     if constexpr (PROBE) {
         if (threadIdx.x < 32) {
             const long long r1 = margs.p.t1.backing_rows[threadIdx.x], r2 = margs.p.t2.backing_rows[threadIdx.x];
             s_nrows[threadIdx.x] = r1 < r2 ? r1 : r2;
             s_sa_base[threadIdx.x] = margs.p.sau.row_base[threadIdx.x];
+            s_back[threadIdx.x] = (unsigned long long)reinterpret_cast<uintptr_t>(margs.p.t1.backing[threadIdx.x]);
+            s_back[32 + threadIdx.x] = (unsigned long long)reinterpret_cast<uintptr_t>(margs.p.t2.backing[threadIdx.x]);
+            s_alt[threadIdx.x] = (unsigned long long)reinterpret_cast<uintptr_t>(margs.p.c3.alt_tables[threadIdx.x]);
         }
     }
     __syncthreads();
@@ -353,28 +358,83 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
             if (e2[h] == kPending) e2[h] = -1;
         }
         }
+        bool dm[2];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            // alt-key probe for a double miss (find_approximate_ev, evlfu_8.cpp:474-490), as in probe2
-            alt_tier[h] = 0; ea[h] = -1;
-            if (pa.c3.tags && ok[h] && e1[h] < 0 && e2[h] < 0) {
+        for (int h = 0; h < 2; h++) { alt_tier[h] = 0; ea[h] = -1; dm[h] = pa.c3.tags != nullptr && ok[h] && e1[h] < 0 && e2[h] < 0; }
+        if (pa.c3.tags != nullptr) {   // (wave-uniform) alt-key probe for the double misses (find_approximate_ev, evlfu_8.cpp:474-490), as in probe2
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(1))) u64x2 *gtag_t;
+            long long cb[2], w3[2];
+            unsigned alt[2];
+            u64x2 cw[2][kSetWays / 2];
+            // the key's set of the alt-key tier AND its alt-table entry in one round trip (the entry does not wait for the
+            // membership verdict), both keys of the thread side by side; lanes without a double miss read word 0 / their own request
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
                 const int f = ((int)threadIdx.x >> 4) + 16 * h;
-                const long long w3 = c3_find(pa.c3, key[h]);
-                if (w3 >= 0) {
-                    const unsigned alt = pa.c3.alt_tables[f - 1][prow[h]];
-                    const unsigned at = alt % 100u, ar = alt / 100u;
-                    if (at >= 1 && at <= (unsigned)T && (long long)ar < pa.t1.backing_rows[at - 1] && (long long)ar < pa.t2.backing_rows[at - 1]) {
-                        const unsigned long long akey = ((unsigned long long)at << 32) | ar;
+                cb[h] = dm[h] ? c3_base(key[h], pa.c3.nset) : 0ll;
+                const unsigned *ap = dm[h] ? reinterpret_cast<const unsigned *>((uintptr_t)s_alt[(f + 31) & 31]) + prow[h] : reinterpret_cast<const unsigned *>(pa.requests);
+                alt[h] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned *>(reinterpret_cast<uintptr_t>(ap));
+                const gtag_t tp = reinterpret_cast<gtag_t>(reinterpret_cast<uintptr_t>(pa.c3.tags + cb[h]));
+#pragma unroll
+                for (int w = 0; w < kSetWays / 2; w++) cw[h][w] = tp[w];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned at[2], ar[2];
+            bool va[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                w3[h] = -1;
+#pragma unroll
+                for (int w = 0; w < kSetWays; w++)
+                    if ((cw[h][w >> 1][w & 1] & kKeyMask) == key[h]) w3[h] = cb[h] + w;
+                at[h] = alt[h] % 100u; ar[h] = alt[h] / 100u;
+                va[h] = dm[h] && w3[h] >= 0 && at[h] >= 1 && at[h] <= (unsigned)T;
+                va[h] = va[h] && (long long)ar[h] < s_nrows[(at[h] - 1u) & 31u];   // (rows BOTH tiers' tables have)
+            }
+            if (sa) {
+                // both tiers' ways of the alt key in ONE round trip (a shared record: one line), as for the key itself
+                unsigned a1[2], a2[2], ag1[2], ag2[2];
+                SaLine la1[2], la2[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const unsigned px = sa_perm(pa.sau, s_sa_base[(at[h] - 1u) & 31u] + (va[h] ? ar[h] : 0u));
+                    unsigned sx, qx;
+                    sa_divmod(pa.t1.sa, px, sx, qx);
+                    sa_place(pa.t1.sa, sx, qx, a1[h], ag1[h]);
+                    if (pa.t2.sa.nset == pa.t1.sa.nset) sa_place(pa.t2.sa, sx, qx, a2[h], ag2[h]);
+                    else sa_split(pa.t2.sa, px, a2[h], ag2[h]);
+                    if (!va[h]) { a1[h] = 0u; a2[h] = 0u; }
+                    sa_load<8>(pa.t1.sa, a1[h], la1[h]);
+                    sa_load<8>(pa.t2.sa, a2[h], la2[h]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    unsigned xw;
+                    const int y1 = sa_find<8>(pa.t1.sa, la1[h], ag1[h], xw), y2 = sa_find<8>(pa.t2.sa, la2[h], ag2[h], xw);
+                    if (va[h] && y1 >= 0) { ea[h] = (int)(a1[h] * 8u + (unsigned)y1); alt_tier[h] = 1; }
+                    else if (va[h] && y2 >= 0) { ea[h] = (int)(a2[h] * 8u + (unsigned)y2); alt_tier[h] = 2; }
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (va[h]) {
+                        const unsigned long long akey = ((unsigned long long)at[h] << 32) | ar[h];
                         unsigned long long es;
-                        ea[h] = sa ? sa_lookup<8>(pa.sau, pa.t1.sa, (int)at - 1, ar) : probe_ro(pa.t1.slots, pa.t1.mask, akey, es);
+                        ea[h] = probe_ro(pa.t1.slots, pa.t1.mask, akey, es);
                         if (ea[h] >= 0) alt_tier[h] = 1;
-                        else { ea[h] = sa ? sa_lookup<8>(pa.sau, pa.t2.sa, (int)at - 1, ar) : probe_ro(pa.t2.slots, pa.t2.mask, akey, es); if (ea[h] >= 0) alt_tier[h] = 2; }
-                        if (alt_tier[h]) atomicOr(&pa.c3.tags[w3], kC3Flag);   // set_recency_flag_c3
+                        else { ea[h] = probe_ro(pa.t2.slots, pa.t2.mask, akey, es); if (ea[h] >= 0) alt_tier[h] = 2; }
                     }
                 }
             }
-            if (e1[h] >= 0 || e2[h] >= 0 || alt_tier[h]) atomicAdd(&s_agg[threadIdx.x & 15], 1);
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (alt_tier[h]) atomicOr(&pa.c3.tags[w3[h]], kC3Flag);   // set_recency_flag_c3
         }
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            if (e1[h] >= 0 || e2[h] >= 0 || alt_tier[h]) atomicAdd(&s_agg[threadIdx.x & 15], 1);
         __syncthreads();
         const int agg = s_agg[threadIdx.x & 15];
 #pragma unroll
@@ -408,8 +468,8 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
             else if (e2[h] >= 0) { src = pa.t2.arena + (long long)e2[h] * pa.t2.row_bytes; codec_of = 2; }
             else if (alt_tier[h] == 1) { src = pa.t1.arena + (long long)ea[h] * pa.t1.row_bytes; codec_of = 1; }
             else if (alt_tier[h] == 2) { src = pa.t2.arena + (long long)ea[h] * pa.t2.row_bytes; codec_of = 2; }
-            else if (miss && dest == 1) { src = pa.t1.backing[k] + (long long)prow[h] * pa.t1.row_bytes; codec_of = 1; }
-            else if (miss) { src = pa.t2.backing[k] + (long long)prow[h] * pa.t2.row_bytes; codec_of = 2; }
+            else if (miss && dest == 1) { src = reinterpret_cast<const unsigned char *>((uintptr_t)s_back[k & 31]) + (long long)prow[h] * pa.t1.row_bytes; codec_of = 1; }
+            else if (miss) { src = reinterpret_cast<const unsigned char *>((uintptr_t)s_back[32 + (k & 31)]) + (long long)prow[h] * pa.t2.row_bytes; codec_of = 2; }
             if (pa.route_filter && miss && dest == 1 && (k & 1)) pa.route_filter[mix64(key[h]) & pa.route_mask] = pa.route_stamp;
             if (act[h]) {
                 const long long m = bs * (long long)T + k;
