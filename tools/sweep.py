@@ -265,7 +265,7 @@ def main():
     ap.add_argument("--only-reduced", action="store_true", help="the reduced-precision rows alone")
     a = ap.parse_args()
     it = 50 if a.quick else 200
-    print("# Round-3 sweep (one MI355X, synthetic uniform indices unless stated; HBM peak used: 8 000 GB/s)\n")
+    print("# Round-4 sweep (one MI355X, synthetic uniform indices unless stated; HBM peak used: 8 000 GB/s)\n")
     print("`fused` = `apply_emb_interact` (one kernel; one index per bag declared); `offsets` = the same with `lS_o` read and")
     print("validated; `two-call` = `apply_emb(lazy=False)` then `interact_features`: two kernels, the pooled rows in HBM (with lazy pooling, the default, the pair runs as the fused launch).  Latencies are per batch, HIP events, inputs resident.")
     print("GB/s = algorithmic bytes (SURVEY 8(d): rows + indices + x read, R written) / mean batch time.\n")
@@ -294,6 +294,17 @@ def main():
     for d in (64, 128):
         for line in fused_rows(TERABYTE_LN, d, 32, [2048, 16384], it, "Terabyte-shaped (cfg 4, 1 GPU)"):
             print(line, flush=True)
+    # multi-hot bags (apply_emb alone and apply_emb + interact_features): the reference's benchmark shape first
+    # (bench/dlrm_s_benchmark.sh:20-45), then other widths / bag lengths
+    print("\n| long bags: tables x rows, d, indices per bag (fixed) | B | apply_emb µs | TB/s | of peak | G lookups/s | + interact_features µs |")
+    print("|---|---|---|---|---|---|---|")
+    for (B_, bag, d_, T_, rows_) in ([(2048, 100, 64, 8, 1000000), (2048, 100, 36, 8, 1000000)] if a.quick else
+                                     [(2048, 100, 64, 8, 1000000), (2048, 100, 128, 8, 1000000), (2048, 100, 32, 8, 1000000), (2048, 100, 36, 8, 1000000),
+                                      (2048, 100, 16, 8, 1000000), (2048, 38, 36, 26, 200000), (4096, 17, 36, 26, 200000)]):
+        r = bench.long_bags_section(torch.device("cuda"), B=B_, bag=bag, d=d_, T=T_, rows=rows_)
+        print("| %d x %d rows, d = %d, %d per bag | %d | %.1f | %.2f | %.1f%% | %.2f | %.1f |"
+              % (T_, rows_, d_, bag, B_, r["apply_emb"]["ms_per_step"] * 1e3, r["apply_emb"]["achieved"] / 1e3, r["apply_emb"]["frac"] * 100,
+                 r["apply_emb"]["value"] / 1e9, r["apply_emb_interact"]["ms_per_step"] * 1e3), flush=True)
     print("\n| cache tier | B | µs per batch | G lookups/s | hit rate | evictions in the timed batches |")
     print("|---|---|---|---|---|---|")
     rows, ev = cache_rows(bench.KAGGLE_LN, 36, 30)
