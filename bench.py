@@ -305,7 +305,7 @@ def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
     def overlapped(index_dtype, copy_stream=False, signals=True):
         pk = IL.PackedPinnedBatches(host, n_req, index_dtype)
         pf = IL.Prefetcher(pk, dev, copy_stream=copy_stream, signals=signals)      # (its slots / stream / signal words are made here, outside the timed region)
-        pk.count = 16
+        pk.count = max(16, 2 * len(pk.blocks))   # (every pinned block has crossed the bus before the timed pass: first-touch mappings)
         for X, lo, li in pf:
             E.apply_emb_interact(x_dev, lo, li, ev, None, out=out)
         pk.count = n_req

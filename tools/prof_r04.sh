@@ -48,6 +48,7 @@ for bits in 16 8 4; do
 done
 cd $ROOT
 timeout 900 python3 tools/sweep.py > $OUT/sweep.md 2> $OUT/sweep.err
+python3 tools/h2d_bench.py > $OUT/h2d.log 2>/dev/null
 bash tools/prof_cache_r03.sh $TAG > $OUT/prof_cache.log 2>&1
 find $OUT -name "*.csv" -size +3M -delete
 find $OUT -name "*.db" -delete
