@@ -1514,3 +1514,13 @@ def test_packed_pinned_batches_through_the_prefetcher(E, orc, wire, copy_stream)
         assert torch.equal(R, want[k]), n
         n += 1
     assert n == 13
+
+
+def test_example_inference_loop_runs():
+    """examples/dlrm_inference_demo.py --small: bottom MLP -> the drop-in apply_emb / interact_features pair -> top MLP behind the
+    packed loader and the prefetcher, end to end in a child process."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "dlrm_inference_demo.py"), "--small", "--requests", "20"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "G lookups/s" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
