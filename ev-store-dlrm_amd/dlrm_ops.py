@@ -66,7 +66,8 @@ _feat_cache = {}
 # the function runs -- "materialise on first touch".  interact_features recognises the untouched list and runs the ONE
 # fused kernel from the saved (lS_o, lS_i) instead; the buffer is then never written.  Shape / dtype / device / stride
 # queries do not materialise.  What cannot be intercepted: code that takes an element's address WITHOUT going through
-# torch (a foreign C++ extension unpacking at::Tensor): call apply_emb(..., lazy=False) for that -- and indices / offsets
+# torch (a foreign C++ extension unpacking at::Tensor, the legacy torch.utils.dlpack.to_dlpack(t); t.__dlpack__() and
+# torch.from_dlpack(t) ARE seen): call apply_emb(..., lazy=False) for that -- and indices / offsets
 # modified IN PLACE between apply_emb and the first use (checked: tensor version counters; raises instead of serving the
 # rows of the wrong batch).  EVS_DEFER_POOLING=0 switches the default back to the eager gather.
 DEFER_POOLING = os.environ.get("EVS_DEFER_POOLING", "1") == "1"
@@ -182,12 +183,12 @@ def materialize(ly):
             pass
     return ly
 
-# apply_emb followed by interact_features is what every DLRM forward does (dlrm_s_pytorch.py:596-601).  With lazy
-# pooling on (EVS_LAZY_POOLING=1, or apply_emb(..., lazy=True)), apply_emb returns a LazyPooled sequence that launches
-# nothing; interact_features recognises it and runs the ONE fused kernel.  Indexing, iteration, list concatenation and
-# this package's ext_dist.alltoall materialise the rows with the gather kernel first -- but LazyPooled is a Sequence,
-# not a list: torch.cat / torch.stack on it raise TypeError, and isinstance(ly, list) is False.  The plugin contract
-# says "returns a list", so the DEFAULT is the eager list; the fusion is opt-in (or call apply_emb_interact).
+# Round 1's opt-in form of the same idea (EVS_LAZY_POOLING=1, or apply_emb(..., lazy=True)): apply_emb returns a LazyPooled
+# sequence that launches nothing; interact_features recognises it and runs the ONE fused kernel.  Indexing, iteration, list
+# concatenation and this package's ext_dist.alltoall materialise the rows with the gather kernel first -- but LazyPooled is a
+# Sequence, not a list: torch.cat / torch.stack on it raise TypeError, and isinstance(ly, list) is False.  The plugin contract
+# says "returns a list": the DEFAULT is the deferred list above (a real list, same fusion); this stays for callers that
+# asked for it by name.
 LAZY_POOLING = os.environ.get("EVS_LAZY_POOLING", "0") == "1"
 
 
