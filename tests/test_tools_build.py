@@ -1,6 +1,7 @@
 """The developer probes under tools/ (HIP programs of their own, not part of the library) still cross-compile for gfx950:
 tools/sector_probe.hip (random line requests per second) and tools/coexec_probe.hip (fp32 MFMA vs VALU on one SIMD) are the
-evidence behind docs/HISTORY.md 3.2c *Round 3*; a probe that no longer builds cannot be re-run on another part."""
+evidence behind docs/HISTORY.md 3.2c *Round 3*, tools/store_pattern_probe.hip (store patterns, random reads + a store stream) behind
+DESIGN.md 3.1 "what bounds"; a probe that no longer builds cannot be re-run on another part."""
 import os
 import subprocess
 
@@ -11,7 +12,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("name", ["sector_probe", "coexec_probe"])
+@pytest.mark.parametrize("name", ["sector_probe", "coexec_probe", "store_pattern_probe"])
 def test_probe_cross_compiles(tmp_path, name):
     out = tmp_path / (name + ".o")
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-c", os.path.join(ROOT, "tools", name + ".hip"), "-o", str(out)],
