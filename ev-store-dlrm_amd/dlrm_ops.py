@@ -71,6 +71,10 @@ _feat_cache = {}
 # modified IN PLACE between apply_emb and the first use (checked: tensor version counters; raises instead of serving the
 # rows of the wrong batch).  EVS_DEFER_POOLING=0 switches the default back to the eager gather.
 DEFER_POOLING = os.environ.get("EVS_DEFER_POOLING", "1") == "1"
+# (two torch internals carry it -- the storage use count that says "no view of the buffer is alive" and the guard that calls
+#  a torch function without re-entering __torch_function__: a torch build without either keeps the eager default)
+if not (hasattr(torch._C, "_storage_Use_Count") and hasattr(torch._C, "DisableTorchFunctionSubclass")):
+    DEFER_POOLING = False
 
 
 class _Deferred:
