@@ -12,7 +12,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("name", ["sector_probe", "coexec_probe", "store_pattern_probe"])
+@pytest.mark.parametrize("name", ["sector_probe", "coexec_probe", "store_pattern_probe", "atomic_probe"])
 def test_probe_cross_compiles(tmp_path, name):
     out = tmp_path / (name + ".o")
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-c", os.path.join(ROOT, "tools", name + ".hip"), "-o", str(out)],
