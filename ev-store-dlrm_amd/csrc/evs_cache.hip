@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
             unsigned char *dst = a.arena + (long long)fe * rb;
             for (int c = lane; c < rb; c += 64) dst[c] = rowp[c];
         }
-        __threadfence();
+        __threadfence_block();   // (the rows are read back by this block only: a workgroup-scope fence; an agent-scope one is an L2 write-back per request, tools/atomic_probe.hip)
         __syncthreads();
     }
 
@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(64) cache_c1c2_kernel(const C1C2Args args) {
                 for (int c = lane; c < cs2.row_bytes; c += 64) dst[c] = rowp[c];
             }
         }
-        __threadfence();
+        __threadfence_block();   // (as in the one-tier kernel)
         __syncthreads();
     }
     hot_store(h1, args.t1.st, lane);
