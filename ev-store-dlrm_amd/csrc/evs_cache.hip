@@ -76,11 +76,18 @@ struct CacheArgs {
 };
 
 
-// agent-scope accesses: the probing lanes must see what lane 0 wrote in the previous request
+// the probing lanes must see what lane 0 wrote in the previous request.  The exact kernels are ONE workgroup (one wave) per
+// launch, so workgroup scope is the scope that is needed (EVS_EXACT_SCOPE_AGENT: developer A/B -- agent-scope accesses go past
+// the CU's L1 on every step of a request's chain of dependent accesses)
+#ifdef EVS_EXACT_SCOPE_AGENT
+#define EVS_EXACT_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#else
+#define EVS_EXACT_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
 template <typename T>
-__device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, EVS_EXACT_SCOPE); }
 template <typename T>
-__device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, EVS_EXACT_SCOPE); }
 
 __device__ int map_find(const CacheArrays &a, unsigned long long mask, unsigned long long key) {
     unsigned long long i = mix64(key) & mask;
