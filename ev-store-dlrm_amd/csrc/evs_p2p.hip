@@ -28,22 +28,22 @@ struct P2pSyncArgs {
 
 // one wave: lane i signals word i, then waits for word i.  Everything queued on the stream in front of this kernel is
 // complete and visible device-wide at its start (kernel boundary); the release store makes it visible system-wide before
-// the flag is.  The wait is bounded (~2 s): a peer that died must not hang the GPU.
+// the flag is, the acquire fence behind the wait keeps the next kernel's loads behind the peers' data.  The wait is bounded (~2 s): a peer that died must not hang the GPU.
 __global__ void __launch_bounds__(64) p2p_sync_kernel(const P2pSyncArgs a) {
     const int i = (int)threadIdx.x;
-    if (i < a.n_sig) {
-        __threadfence_system();
-        __hip_atomic_store(a.sig[i], a.sig_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    // (the release store carries the write-back of what this device wrote; no separate fence in front of it -- every
+    //  agent- / system-scope fence is an L2 write-back on this part, tools/atomic_probe.hip)
+    if (i < a.n_sig) __hip_atomic_store(a.sig[i], a.sig_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (i < a.n_wait) {
         long long n = 0;
-        // (wrap-safe comparison: the flags count uses of a slot)
-        while ((int)(__hip_atomic_load(a.wait[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - a.wait_value) < 0) {
+        // relaxed polls (an acquire load per poll would invalidate the caches under whatever else runs on the device), ONE
+        // acquire fence when the word is there; wrap-safe comparison: the flags count uses of a slot
+        while ((int)(__hip_atomic_load(a.wait[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.wait_value) < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (++n > a.spins) { atomicOr(a.err, 2); break; }
         }
-        __threadfence_system();
     }
+    if (a.n_wait > 0) __atomic_thread_fence(__ATOMIC_ACQUIRE);   // (system scope: the default of the builtin)
 }
 
 }  // namespace evs
