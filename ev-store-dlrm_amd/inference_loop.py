@@ -110,6 +110,9 @@ class PackedPinnedBatches:
         isz = 8 if index_dtype == torch.int64 else 4
         for X, lS_o, lS_i in batches:
             X, lS_o, lS_i = X.contiguous(), lS_o.contiguous(), lS_i.contiguous()
+            if index_dtype == torch.int32 and lS_i.numel():
+                assert int(lS_i.max()) < 2 ** 31 and int(lS_o.max()) < 2 ** 31 and int(lS_i.min()) >= -2 ** 31, \
+                    "the int32 wire format needs row ids and offsets below 2^31"
             nx = (X.numel() * 4 + 15) // 16 * 16
             no = lS_o.numel() * isz
             lay = (tuple(X.shape), tuple(lS_o.shape), tuple(lS_i.shape), nx, no)
