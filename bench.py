@@ -321,10 +321,33 @@ def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
     ov64 = overlapped(torch.int64, copy_stream=False)
     ov32 = overlapped(torch.int32, copy_stream=True)
     ov2s = overlapped(torch.int64, copy_stream=True)
+    # the batch kept RAW on the host (13 int32 counts + 26 int32 ids per sample, as the dataset holds it) and collated on the
+    # device behind its copy (collate_wrapper_criteo_offset, dlrm_data_pytorch.py:397-410 -> evs_collate_criteo_offset)
+    raw_line = None
+    try:
+        raw_host = [(torch.randint(0, 1000, (B, 13), dtype=torch.int32), h[2].t().contiguous().to(torch.int32)) for h in host]
+        pkr = IL.RawCriteoPinnedBatches(raw_host, n_req)
+        pfr = IL.Prefetcher(pkr, dev)
+        pkr.count = max(16, 2 * len(pkr.blocks))
+        for X, lo, li in pfr:
+            E.apply_emb_interact(x_dev, lo, li, ev, None, out=out)
+        pkr.count = n_req
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for X, lo, li in pfr:
+            E.apply_emb_interact(x_dev, lo, li, ev, None, out=out)
+        torch.cuda.synchronize()
+        dtr = time.perf_counter() - t0
+        raw_line = {"ms_per_batch": dtr / n_req * 1e3, "value": T * B * n_req / dtr, "unit": "lookups/s", "bytes_per_batch": pkr.nbytes,
+                    "GBps": pkr.nbytes * n_req / dtr / 1e9,
+                    "note": "the raw batch crosses (156 B per sample), one collate launch makes X = log(x_int + 1), lS_o, lS_i in HBM, then the fused launch"}
+        del pfr, pkr, raw_host
+    except Exception as e:
+        raw_line = {"error": repr(e)}
     ov2e = overlapped(torch.int64, copy_stream=True, signals=False)
     return {"bytes_per_sample": 13 * 4 + 2 * 8 * T, "requests": n_req, "batch": B,
             "as_the_reference_loop": serial,
-            "packed_one_copy_per_batch": ov64, "packed_int32_wire": ov32, "copy_stream_overlapped": ov2s, "copy_stream_event_handoffs": ov2e,
+            "packed_one_copy_per_batch": ov64, "packed_int32_wire": ov32, "copy_stream_overlapped": ov2s, "copy_stream_event_handoffs": ov2e, "raw_batch_collated_on_device": raw_line,
             "throughput_note": "packed: every batch ONE pinned block and ONE copy command queued in front of its launch on the same stream, no "
                                "per-request synchronise (inference_loop.PackedPinnedBatches / Prefetcher); int32 wire: offsets and indices cross as "
                                "4 bytes on the copy stream and are widened on the device; copy_stream_overlapped: the same copies on a second stream under the previous "

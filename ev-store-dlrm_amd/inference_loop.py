@@ -136,6 +136,59 @@ class PackedPinnedBatches:
         return self.count
 
 
+def collate_criteo_offset(x_int, x_cat, X=None, lS_o=None, lS_i=None, write_offsets=True):
+    """collate_wrapper_criteo_offset (dlrm_data_pytorch.py:397-410) on the DEVICE: the raw batch as CriteoDataset.__getitem__
+    yields it -- x_int (B, n_dense) int32 counts, x_cat (B, T) int32 ids, both on the GPU -- to (X, lS_o, lS_i) as the loader
+    hands them to dlrm_wrap: X = log(x_int + 1) fp32, lS_o = arange(B) per table and lS_i = x_cat transposed, (T, B) int64.
+    One launch (evs_collate_criteo_offset); buffers are re-used when given (write_offsets=False: lS_o already holds arange)."""
+    from . import _lib
+    from .dlrm_ops import _stream_ptr
+    assert x_int.is_cuda and x_cat.is_cuda and x_int.dtype == torch.int32 and x_cat.dtype == torch.int32
+    x_int, x_cat = x_int.contiguous(), x_cat.contiguous()
+    B, nd, T = int(x_cat.shape[0]), int(x_int.shape[1]), int(x_cat.shape[1])
+    dev = x_cat.device
+    X = torch.empty((B, nd), dtype=torch.float32, device=dev) if X is None else X
+    lS_i = torch.empty((T, B), dtype=torch.int64, device=dev) if lS_i is None else lS_i
+    if lS_o is None:
+        lS_o, write_offsets = torch.empty((T, B), dtype=torch.int64, device=dev), True
+    assert X.is_contiguous() and lS_i.is_contiguous() and lS_o.is_contiguous() and X.shape == (B, nd) and lS_i.shape == (T, B) == lS_o.shape
+    _lib.check(_lib.lib().evs_collate_criteo_offset(B, nd, T, x_int.data_ptr(), x_cat.data_ptr(), X.data_ptr(),
+                                                    lS_o.data_ptr() if write_offsets else None, lS_i.data_ptr(), _stream_ptr(dev)))
+    return X, lS_o, lS_i
+
+
+class RawCriteoPinnedBatches:
+    """A loader stand-in that keeps the batches RAW, as the dataset holds them: every batch ONE pinned block -- x_int (B, n_dense)
+    int32 | x_cat (B, T) int32 -- 156 bytes per sample at (13, 26) instead of the 468 of the collated (X, lS_o, lS_i); the
+    Prefetcher collates each batch on the device behind its copy (collate_criteo_offset).  batches: (x_int, x_cat) integer
+    arrays / tensors of one shape."""
+    raw = True
+    index_dtype = torch.int64
+
+    def __init__(self, batches, count):
+        self.count, self.blocks, self.layout = count, [], None
+        for x_int, x_cat in batches:
+            x_int = torch.as_tensor(x_int).to(torch.int32).contiguous()
+            x_cat = torch.as_tensor(x_cat).to(torch.int32).contiguous()
+            n1 = (x_int.numel() * 4 + 15) // 16 * 16
+            lay = (tuple(x_int.shape), tuple(x_cat.shape), n1)
+            assert self.layout in (None, lay) and x_int.shape[0] == x_cat.shape[0], "every batch must have the same shape"
+            self.layout = lay
+            blk = torch.empty(n1 + x_cat.numel() * 4, dtype=torch.uint8).pin_memory()
+            blk[:x_int.numel() * 4].view(torch.int32).view(x_int.shape).copy_(x_int)
+            blk[n1:].view(torch.int32).view(x_cat.shape).copy_(x_cat)
+            self.blocks.append(blk)
+        self.nbytes = int(self.blocks[0].numel())
+
+    def views(self, blk):
+        """(x_int, x_cat) of a block (host or device), no copy"""
+        s1, s2, n1 = self.layout
+        return blk[:s1[0] * s1[1] * 4].view(torch.int32).view(s1), blk[n1:].view(torch.int32).view(s2)
+
+    def __len__(self):
+        return self.count
+
+
 class Prefetcher:
     """H2D staging for PackedPinnedBatches: ONE copy command per batch into a rotating device slot; the tensors a batch
     yields are views of its slot (int32 wire batches arrive widened to int64), valid until the slot comes round again.
@@ -180,6 +233,12 @@ class Prefetcher:
                 self.sig = None
                 if auto:
                     self.cs = None
+        self.cooked = None       # raw batches: per slot the collated (X, lS_o, lS_i) the device-side collate writes
+        if getattr(ld, "raw", False):
+            (B_, nd_), (_, T_), _ = ld.layout
+            ar = torch.arange(B_, dtype=torch.int64, device=self.device).repeat(T_, 1).contiguous()
+            self.cooked = [(torch.empty((B_, nd_), dtype=torch.float32, device=self.device), ar.clone(),
+                            torch.empty((T_, B_), dtype=torch.int64, device=self.device)) for _ in range(depth)]
         self.wide = None
         if ld.index_dtype == torch.int32:
             _, os_, is_, _, _ = ld.layout
@@ -213,6 +272,11 @@ class Prefetcher:
                 self.copied[sl].record(self.cs)
 
     def _views(self, sl):
+        if self.cooked is not None:   # (lS_o was written once, when the slot was made)
+            xi, xc = self.ld.views(self.slots[sl])
+            X, lo, li = self.cooked[sl]
+            collate_criteo_offset(xi, xc, X=X, lS_o=lo, lS_i=li, write_offsets=False)
+            return X, lo, li
         X, lo, li = self.ld.views(self.slots[sl])
         if self.wide is not None:
             wo, wi = self.wide[sl]

@@ -44,3 +44,16 @@ class CpuHotPath:
     @torch.no_grad()
     def step(self, lS_o, lS_i, x):
         return self.interact_features(x, self.apply_emb(lS_o, lS_i))
+
+
+def collate_criteo_offset(x_int, x_cat):
+    """Reference dlrm_data_pytorch.py:397-410 (collate_wrapper_criteo_offset) on a raw batch -- x_int (B, n_dense) integer counts,
+    x_cat (B, T) integer ids, as CriteoDataset.__getitem__ yields them (:372-395) -- without the click column: X = log(x_int
+    as fp32 + 1), lS_o = arange(B) per table, lS_i = x_cat transposed, both (T, B) int64.  Checked against the golden vectors of
+    tests/golden/collate_criteo.npz (the reference's own function); the checker of the device-side collate."""
+    X_int = torch.log(torch.as_tensor(x_int).to(torch.float) + 1)
+    X_cat = torch.as_tensor(x_cat).to(torch.long)
+    B, T = X_cat.shape
+    lS_i = torch.stack([X_cat[:, i] for i in range(T)])
+    lS_o = torch.stack([torch.arange(B) for _ in range(T)])
+    return X_int, lS_o, lS_i

@@ -13,6 +13,7 @@ What is pinned:
   * cache_algo/EvLFU_C1.py, LRU.py, LFU.py hit traces       (EvLFU_C1.py:97, LRU.py:38, LFU.py:69)
   * emb_storage/file_read.py + mmap_file_read.py row reads  (file_read.py:27, mmap_file_read.py:32)
   * script/reduce_precision.py encoders                     (reduce_precision.py:26,:140,:270)
+  * dlrm_data_pytorch.collate_wrapper_criteo_offset         (dlrm_data_pytorch.py:397-410; `collate` mode)
 """
 import os
 import sys
@@ -672,6 +673,21 @@ def main():
         # the reference's own benchmark shape at a reduced row count (bench/dlrm_s_benchmark.sh:20-45: 8 tables, d = 64,
         # --num-indices-per-lookup=100 --num-indices-per-lookup-fixed=true; rows 1 000 000 -> 600, mb 2 048 -> 40)
         gen_dlrm_case(D, DP, "dlrm_bench_shape", [600] * 8, 64, 40, 100, seed=41, n_idx_fixed=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "collate":
+        # collate_wrapper_criteo_offset (dlrm_data_pytorch.py:397-410) on a raw batch as CriteoDataset.__getitem__ yields it
+        # (:372-395: X_int int32 counts after the negative clip, X_cat int32 ids, y): what the loader hands dlrm_wrap
+        rs = np.random.RandomState(77)
+        B = 50
+        x_int = rs.randint(0, 5000, size=(B, 13)).astype(np.int32)
+        x_int[rs.rand(B, 13) < 0.3] = 0
+        x_int[0, 0] = 2 ** 31 - 2   # (the largest count the +1 in fp32 still takes)
+        x_cat = np.stack([rs.randint(0, n, size=B) for n in KAGGLE_LN], axis=1).astype(np.int32)
+        y = rs.randint(0, 2, size=B).astype(np.float32)
+        X, lS_o, lS_i, Tt = DP.collate_wrapper_criteo_offset([(x_int[i], x_cat[i], y[i]) for i in range(B)])
+        np.savez_compressed(os.path.join(HERE, "collate_criteo.npz"), x_int=x_int, x_cat=x_cat, y=y, X=X.numpy(), lS_o=lS_o.numpy(),
+                            lS_i=lS_i.numpy(), T=Tt.numpy())
+        print("collate_criteo.npz", X.shape, lS_o.shape, lS_i.shape, X.dtype, lS_i.dtype)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "codec":
         gen_codec_tables()

@@ -1524,3 +1524,43 @@ def test_example_inference_loop_runs():
     r = subprocess.run([sys.executable, os.path.join(root, "examples", "dlrm_inference_demo.py"), "--small", "--requests", "20"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "G lookups/s" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_collate_on_the_device_equals_the_reference_collate(E, orc):
+    """evs_collate_criteo_offset (inference_loop.collate_criteo_offset): the raw batch of the dataset -> (X, lS_o, lS_i) in HBM,
+    against the reference's own collate_wrapper_criteo_offset (tests/golden/collate_criteo.npz): index tensors bit for bit, X
+    within 2 ulp of torch.log on the host; ragged batch sizes against the restatement; and the raw loader through the
+    prefetcher feeds the fused launch the same R as tensors collated on the host."""
+    from evstore_dlrm_amd import inference_loop as IL
+    from oracle import dlrm_cpu
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collate_criteo.npz"))
+    X, lo, li = IL.collate_criteo_offset(torch.from_numpy(g["x_int"]).cuda(), torch.from_numpy(g["x_cat"]).cuda())
+    assert np.array_equal(lo.cpu().numpy(), g["lS_o"]) and np.array_equal(li.cpu().numpy(), g["lS_i"])
+    np.testing.assert_array_max_ulp(X.cpu().numpy(), g["X"], maxulp=2)
+    rs = np.random.RandomState(5)
+    for B, nd, T in ((1, 13, 26), (63, 13, 26), (64, 1, 1), (65, 13, 26), (1000, 4, 64), (4097, 13, 5)):
+        xi = rs.randint(0, 100000, size=(B, nd)).astype(np.int32)
+        xc = rs.randint(0, 2 ** 31 - 1, size=(B, T)).astype(np.int32)
+        X, lo, li = IL.collate_criteo_offset(torch.from_numpy(xi).cuda(), torch.from_numpy(xc).cuda())
+        Xo, loo, lio = dlrm_cpu.collate_criteo_offset(xi, xc)
+        assert torch.equal(lo.cpu(), loo) and torch.equal(li.cpu(), lio), (B, nd, T)
+        np.testing.assert_array_max_ulp(X.cpu().numpy(), Xo.numpy(), maxulp=2)
+    # the raw loader: one pinned block of 156 bytes per sample per batch, collated behind its copy
+    T, d, B = 26, 36, 300
+    ln = [int(rs.choice([3, 40, 700, 9000])) for _ in range(T)]
+    ev = E.EVTables.from_fp32([torch.from_numpy(rs.uniform(-1, 1, size=(n, d)).astype(np.float32)) for n in ln])
+    raw = [(rs.randint(0, 50, size=(B, 13)).astype(np.int32), np.stack([rs.randint(0, n, size=B) for n in ln], axis=1).astype(np.int32)) for _ in range(5)]
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+    want = []
+    for xi, xc in raw:
+        Xo, loo, lio = dlrm_cpu.collate_criteo_offset(xi, xc)
+        want.append((Xo, E.apply_emb_interact(x, loo.cuda(), lio.cuda(), ev)))
+    pk = IL.RawCriteoPinnedBatches(raw, 12)
+    assert pk.nbytes == (B * 13 * 4 + 15) // 16 * 16 + B * T * 4
+    n = 0
+    for X, lo, li in IL.Prefetcher(pk, "cuda"):
+        k = n % len(raw)
+        np.testing.assert_array_max_ulp(X.cpu().numpy(), want[k][0].numpy(), maxulp=2)
+        assert torch.equal(E.apply_emb_interact(x, lo, li, ev), want[k][1]), n
+        n += 1
+    assert n == 12

@@ -369,3 +369,16 @@ def test_altkey_tier_ops_match_reference_driven_single_threaded(cap):
     np.testing.assert_array_equal(res, g["cap%d_res" % cap])
     np.testing.assert_array_equal(t.queue(), g["cap%d_queue" % cap])
     assert t.state()["size"] <= cap
+
+
+def test_collate_criteo_offset_restated_equals_reference():
+    """oracle/dlrm_cpu.py collate_criteo_offset against the reference's collate_wrapper_criteo_offset (dlrm_data_pytorch.py:397-410;
+    tests/golden/collate_criteo.npz, `make_golden.py collate`): the two index tensors bit for bit, X within one ulp (torch's
+    vectorised log may pick another code path on another host; on the recording host it is bit-equal)."""
+    import torch
+    from oracle import dlrm_cpu
+    g = load_golden("collate_criteo")
+    X, lS_o, lS_i = dlrm_cpu.collate_criteo_offset(g["x_int"], g["x_cat"])
+    assert X.dtype == torch.float32 and lS_o.dtype == torch.int64 and lS_i.dtype == torch.int64
+    assert np.array_equal(lS_o.numpy(), g["lS_o"]) and np.array_equal(lS_i.numpy(), g["lS_i"])
+    np.testing.assert_array_max_ulp(X.numpy(), g["X"], maxulp=1)
