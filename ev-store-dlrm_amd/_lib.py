@@ -74,7 +74,7 @@ _PROTOS = {
     "evs_p2p_ipc_open": (_int, [_vp, _pp]),
     "evs_p2p_ipc_close": (_int, [_vp]),
     "evs_p2p_sync": (_int, [_int, _pp, C.c_uint32, _int, _pp, C.c_uint32, _vp]),
-    "evs_collate_criteo_offset": (_int, [_i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evs_collate_criteo_offset": (_int, [_i64, _int, _int, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "evs_signal_alloc": (_int, [_pp]),
     "evs_signal_free": (_int, [_vp]),
     "evs_stream_write_value": (_int, [_vp, _vp, C.c_uint32]),

@@ -136,15 +136,21 @@ class PackedPinnedBatches:
         return self.count
 
 
-def collate_criteo_offset(x_int, x_cat, X=None, lS_o=None, lS_i=None, write_offsets=True):
+def collate_criteo_offset(x_int, x_cat, X=None, lS_o=None, lS_i=None, write_offsets=True, max_ind_range=-1):
     """collate_wrapper_criteo_offset (dlrm_data_pytorch.py:397-410) on the DEVICE: the raw batch as CriteoDataset.__getitem__
     yields it -- x_int (B, n_dense) int32 counts, x_cat (B, T) int32 ids, both on the GPU -- to (X, lS_o, lS_i) as the loader
     hands them to dlrm_wrap: X = log(x_int + 1) fp32, lS_o = arange(B) per table and lS_i = x_cat transposed, (T, B) int64.
-    One launch (evs_collate_criteo_offset); buffers are re-used when given (write_offsets=False: lS_o already holds arange)."""
+    One launch (evs_collate_criteo_offset); buffers are re-used when given (write_offsets=False: lS_o already holds arange).
+    x_int / x_cat may be column views of one record array (rows contiguous, any row stride): the Terabyte binary loader's
+    (B, 40) blocks (script/data_loader_terabyte.py:226-236) -- see collate_criteo_records; max_ind_range > 0: ids modulo it
+    (_transform_features, :71-72)."""
     from . import _lib
     from .dlrm_ops import _stream_ptr
     assert x_int.is_cuda and x_cat.is_cuda and x_int.dtype == torch.int32 and x_cat.dtype == torch.int32
-    x_int, x_cat = x_int.contiguous(), x_cat.contiguous()
+    if x_int.dim() != 2 or (x_int.shape[1] > 1 and x_int.stride(1) != 1):
+        x_int = x_int.contiguous()
+    if x_cat.dim() != 2 or (x_cat.shape[1] > 1 and x_cat.stride(1) != 1):
+        x_cat = x_cat.contiguous()
     B, nd, T = int(x_cat.shape[0]), int(x_int.shape[1]), int(x_cat.shape[1])
     dev = x_cat.device
     X = torch.empty((B, nd), dtype=torch.float32, device=dev) if X is None else X
@@ -152,9 +158,18 @@ def collate_criteo_offset(x_int, x_cat, X=None, lS_o=None, lS_i=None, write_offs
     if lS_o is None:
         lS_o, write_offsets = torch.empty((T, B), dtype=torch.int64, device=dev), True
     assert X.is_contiguous() and lS_i.is_contiguous() and lS_o.is_contiguous() and X.shape == (B, nd) and lS_i.shape == (T, B) == lS_o.shape
-    _lib.check(_lib.lib().evs_collate_criteo_offset(B, nd, T, x_int.data_ptr(), x_cat.data_ptr(), X.data_ptr(),
-                                                    lS_o.data_ptr() if write_offsets else None, lS_i.data_ptr(), _stream_ptr(dev)))
+    si = int(x_int.stride(0)) if B > 1 else max(nd, 1)
+    sc = int(x_cat.stride(0)) if B > 1 else T
+    _lib.check(_lib.lib().evs_collate_criteo_offset(B, nd, T, x_int.data_ptr(), max(si, nd), x_cat.data_ptr(), max(sc, T), int(max_ind_range),
+                                                    X.data_ptr(), lS_o.data_ptr() if write_offsets else None, lS_i.data_ptr(), _stream_ptr(dev)))
     return X, lS_o, lS_i
+
+
+def collate_criteo_records(rec, **kw):
+    """the Terabyte binary loader's batch -- a (B, 40) int32 block of the file: label, 13 counts, 26 ids per record
+    (CriteoBinDataset.__getitem__, script/data_loader_terabyte.py:226-236) -- collated on the device; -> X, lS_o, lS_i"""
+    assert rec.dim() == 2 and rec.shape[1] == 40 and rec.dtype == torch.int32
+    return collate_criteo_offset(rec[:, 1:14], rec[:, 14:], **kw)
 
 
 class RawCriteoPinnedBatches:
@@ -165,8 +180,8 @@ class RawCriteoPinnedBatches:
     raw = True
     index_dtype = torch.int64
 
-    def __init__(self, batches, count):
-        self.count, self.blocks, self.layout = count, [], None
+    def __init__(self, batches, count, max_ind_range=-1):
+        self.count, self.blocks, self.layout, self.max_ind_range = count, [], None, max_ind_range
         for x_int, x_cat in batches:
             x_int = torch.as_tensor(x_int).to(torch.int32).contiguous()
             x_cat = torch.as_tensor(x_cat).to(torch.int32).contiguous()
@@ -187,6 +202,28 @@ class RawCriteoPinnedBatches:
 
     def __len__(self):
         return self.count
+
+
+class RawCriteoRecordBatches(RawCriteoPinnedBatches):
+    """The same for the Terabyte binary loader: every batch is the (B, 40) int32 block CriteoBinDataset reads from its file
+    (script/data_loader_terabyte.py:226-236: label, 13 counts, 26 ids per record; 160 bytes per sample), pinned as it is;
+    the prefetcher collates it on the device (collate_criteo_records, ids modulo max_ind_range when > 0)."""
+
+    def __init__(self, records, count, max_ind_range=-1):
+        self.count, self.blocks, self.max_ind_range = count, [], max_ind_range
+        for rec in records:
+            rec = torch.as_tensor(rec).to(torch.int32).contiguous()
+            assert rec.dim() == 2 and rec.shape[1] == 40, "records are (B, 40) int32"
+            self.layout = ((int(rec.shape[0]), 13), (int(rec.shape[0]), 26), 0)
+            blk = torch.empty(rec.numel() * 4, dtype=torch.uint8).pin_memory()
+            blk.view(torch.int32).view(rec.shape).copy_(rec)
+            assert not self.blocks or blk.numel() == self.blocks[0].numel(), "every batch must have the same shape"
+            self.blocks.append(blk)
+        self.nbytes = int(self.blocks[0].numel())
+
+    def views(self, blk):
+        rec = blk.view(torch.int32).view(self.layout[0][0], 40)
+        return rec[:, 1:14], rec[:, 14:]
 
 
 class Prefetcher:
@@ -275,7 +312,7 @@ class Prefetcher:
         if self.cooked is not None:   # (lS_o was written once, when the slot was made)
             xi, xc = self.ld.views(self.slots[sl])
             X, lo, li = self.cooked[sl]
-            collate_criteo_offset(xi, xc, X=X, lS_o=lo, lS_i=li, write_offsets=False)
+            collate_criteo_offset(xi, xc, X=X, lS_o=lo, lS_i=li, write_offsets=False, max_ind_range=getattr(self.ld, "max_ind_range", -1))
             return X, lo, li
         X, lo, li = self.ld.views(self.slots[sl])
         if self.wide is not None:

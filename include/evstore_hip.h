@@ -133,12 +133,16 @@ EVS_API int evs_p2p_sync(int n_sig, uint32_t *const *sig, uint32_t sig_value, in
                          uint32_t wait_value, void *stream);
 
 /* The loader's collate on the device -- collate_wrapper_criteo_offset, dlrm_data_pytorch.py:397-410 -- from the raw batch as
- * CriteoDataset.__getitem__ yields it (:372-395): x_int (B, n_dense) int32 counts and x_cat (B, T) int32 ids, row-major, in
- * device memory -> X (B, n_dense) fp32 = log(x_int + 1) (fp32 add, then logf: within 1 ulp of torch.log on the host),
+ * CriteoDataset.__getitem__ yields it (:372-395): x_int (B, n_dense) int32 counts and x_cat (B, T) int32 ids in device
+ * memory, sample s at x_int + s * x_int_stride / x_cat + s * x_cat_stride (strides in elements: n_dense / T for separate
+ * row-major arrays) -> X (B, n_dense) fp32 = log(x_int + 1) (fp32 add, then logf: within 1-2 ulp of torch.log on the host),
  * lS_i (T, B) int64 = x_cat transposed, lS_o (T, B) int64 = arange(B) per table (lS_o NULL: not written -- the fused launch
- * can be told one_index_per_bag instead).  156 bytes per sample cross the bus instead of 468 (T = 26).  1 <= T <= 64. */
-EVS_API int evs_collate_criteo_offset(int64_t B, int n_dense, int T, const int32_t *x_int, const int32_t *x_cat, float *X,
-                                      int64_t *lS_o, int64_t *lS_i, void *stream);
+ * can be told one_index_per_bag instead).  156 bytes per sample cross the bus instead of 468 (T = 26).
+ * The Terabyte binary loader's batches (script/data_loader_terabyte.py:196-236 CriteoBinDataset, :68-87 _transform_features)
+ * are one (B, 40) int32 block of the file -- label, 13 counts, 26 ids per record: both strides 40, x_int = block + 1,
+ * x_cat = block + 14 -- with ids taken modulo max_ind_range when it is > 0 (:71-72).  1 <= T <= 64. */
+EVS_API int evs_collate_criteo_offset(int64_t B, int n_dense, int T, const int32_t *x_int, int64_t x_int_stride, const int32_t *x_cat,
+                                      int64_t x_cat_stride, int max_ind_range, float *X, int64_t *lS_o, int64_t *lS_i, void *stream);
 
 /* a16 (dlrm_wrap's per-batch H2D, dlrm_s_pytorch.py:131-147) as a two-stream pipeline: signal words that one stream of a
  * device writes and another waits for (">= value") in stream order, executed by the command processors -- no event, no host

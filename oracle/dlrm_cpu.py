@@ -57,3 +57,18 @@ def collate_criteo_offset(x_int, x_cat):
     lS_i = torch.stack([X_cat[:, i] for i in range(T)])
     lS_o = torch.stack([torch.arange(B) for _ in range(T)])
     return X_int, lS_o, lS_i
+
+
+def transform_features_terabyte(rec, max_ind_range=-1):
+    """Reference script/data_loader_terabyte.py:68-87 (_transform_features) over a (B, 40) int32 block of the binary dataset as
+    CriteoBinDataset.__getitem__ slices it (:226-236: column 0 the label, 1..13 the counts, 14..39 the ids), without the label:
+    -> X fp32 (B, 13), lS_o (26, B), lS_i (26, B) int64.  Checked against tests/golden/collate_terabyte.npz."""
+    t = torch.as_tensor(rec).view((-1, 40))
+    x_int, x_cat = t[:, 1:14], t[:, 14:]
+    if max_ind_range > 0:
+        x_cat = x_cat % max_ind_range
+    X = torch.log(x_int.clone().detach().type(torch.float) + 1)
+    x_cat = x_cat.clone().detach().type(torch.long)
+    B, T = x_cat.shape
+    lS_o = torch.arange(B).reshape(1, -1).repeat(T, 1)
+    return X, lS_o, x_cat.t().contiguous()

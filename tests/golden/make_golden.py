@@ -688,6 +688,20 @@ def main():
         np.savez_compressed(os.path.join(HERE, "collate_criteo.npz"), x_int=x_int, x_cat=x_cat, y=y, X=X.numpy(), lS_o=lS_o.numpy(),
                             lS_i=lS_i.numpy(), T=Tt.numpy())
         print("collate_criteo.npz", X.shape, lS_o.shape, lS_i.shape, X.dtype, lS_i.dtype)
+        # the Terabyte binary loader: CriteoBinDataset.__getitem__ (script/data_loader_terabyte.py:226-236) is
+        # _transform_features (:68-87) over column views of a (B, 40) int32 block of the file
+        import torch
+        import data_loader_terabyte as DLT
+        rec = np.concatenate([y.reshape(-1, 1).astype(np.int32), x_int, x_cat], axis=1).astype(np.int32)
+        t = torch.from_numpy(rec).view((-1, 40))
+        out = {}
+        for rng in (-1, 1000):
+            Xb, lo, li, yb = DLT._transform_features(x_int_batch=t[:, 1:14], x_cat_batch=t[:, 14:], y_batch=t[:, 0], max_ind_range=rng,
+                                                     flag_input_torch_tensor=True)
+            tag = "r%d" % rng if rng > 0 else "all"
+            out.update({"X_" + tag: Xb.numpy(), "lS_o_" + tag: lo.numpy(), "lS_i_" + tag: li.contiguous().numpy()})
+        np.savez_compressed(os.path.join(HERE, "collate_terabyte.npz"), rec=rec, **out)
+        print("collate_terabyte.npz", rec.shape, sorted(out))
         return
     if len(sys.argv) > 1 and sys.argv[1] == "codec":
         gen_codec_tables()

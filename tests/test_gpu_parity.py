@@ -1545,6 +1545,22 @@ def test_collate_on_the_device_equals_the_reference_collate(E, orc):
         Xo, loo, lio = dlrm_cpu.collate_criteo_offset(xi, xc)
         assert torch.equal(lo.cpu(), loo) and torch.equal(li.cpu(), lio), (B, nd, T)
         np.testing.assert_array_max_ulp(X.cpu().numpy(), Xo.numpy(), maxulp=2)
+    # the Terabyte binary loader's (B, 40) record blocks: column views of one array, ids modulo max_ind_range
+    gt = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collate_terabyte.npz"))
+    rec = torch.from_numpy(gt["rec"]).cuda()
+    for rng_, tag in ((-1, "all"), (1000, "r1000")):
+        X, lo, li = IL.collate_criteo_records(rec, max_ind_range=rng_)
+        assert np.array_equal(lo.cpu().numpy(), gt["lS_o_" + tag]) and np.array_equal(li.cpu().numpy(), gt["lS_i_" + tag])
+        np.testing.assert_array_max_ulp(X.cpu().numpy(), gt["X_" + tag], maxulp=2)
+    recs = [np.concatenate([rs.randint(0, 2, size=(200, 1)), rs.randint(0, 900, size=(200, 13)), rs.randint(0, 10 ** 6, size=(200, 26))], axis=1).astype(np.int32)
+            for _ in range(3)]
+    n = 0
+    for X, lo, li in IL.Prefetcher(IL.RawCriteoRecordBatches(recs, 7, max_ind_range=5000), "cuda"):
+        Xo, loo, lio = dlrm_cpu.transform_features_terabyte(recs[n % 3], 5000)
+        assert torch.equal(lo.cpu(), loo) and torch.equal(li.cpu(), lio), n
+        np.testing.assert_array_max_ulp(X.cpu().numpy(), Xo.numpy(), maxulp=2)
+        n += 1
+    assert n == 7
     # the raw loader: one pinned block of 156 bytes per sample per batch, collated behind its copy
     T, d, B = 26, 36, 300
     ln = [int(rs.choice([3, 40, 700, 9000])) for _ in range(T)]

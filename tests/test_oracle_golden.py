@@ -382,3 +382,15 @@ def test_collate_criteo_offset_restated_equals_reference():
     assert X.dtype == torch.float32 and lS_o.dtype == torch.int64 and lS_i.dtype == torch.int64
     assert np.array_equal(lS_o.numpy(), g["lS_o"]) and np.array_equal(lS_i.numpy(), g["lS_i"])
     np.testing.assert_array_max_ulp(X.numpy(), g["X"], maxulp=1)
+
+
+def test_terabyte_transform_features_restated_equals_reference():
+    """oracle/dlrm_cpu.py transform_features_terabyte against the reference's _transform_features over a (B, 40) record block
+    (script/data_loader_terabyte.py:68-87,226-236; tests/golden/collate_terabyte.npz), with and without max_ind_range."""
+    import torch
+    from oracle import dlrm_cpu
+    g = load_golden("collate_terabyte")
+    for rng, tag in ((-1, "all"), (1000, "r1000")):
+        X, lS_o, lS_i = dlrm_cpu.transform_features_terabyte(g["rec"], rng)
+        assert np.array_equal(lS_o.numpy(), g["lS_o_" + tag]) and np.array_equal(lS_i.numpy(), g["lS_i_" + tag])
+        np.testing.assert_array_max_ulp(X.numpy(), g["X_" + tag], maxulp=1)
