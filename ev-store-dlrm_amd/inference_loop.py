@@ -136,6 +136,46 @@ class PackedPinnedBatches:
         return self.count
 
 
+class PackedRaggedPinnedBatches:
+    """PackedPinnedBatches for the reference's RANDOM-data loader (RandomDataset + collate_wrapper_random_offset,
+    dlrm_data_pytorch.py:678-797): multi-hot batches -- X (B, m_den) fp32, lS_o (T, B) int64 bag starts, lS_i a LIST of T int64
+    tensors of different lengths.  Every batch is ONE pinned block -- X | lS_o | the T index tensors back to back (each
+    starting on 16 bytes) -- one copy command; the tensors a batch yields are views of it (lS_i: a list of T views).  Batches
+    may differ in their numbers of indices: the prefetcher's slots take the largest."""
+    index_dtype = torch.int64
+    ragged = True
+
+    def __init__(self, batches, count):
+        self.count, self.blocks, self.layouts = count, [], []
+        for X, lS_o, lS_i in batches:
+            X = X.contiguous()
+            lS_o = (torch.stack(list(lS_o)) if not torch.is_tensor(lS_o) else lS_o).contiguous()
+            nx = (X.numel() * 4 + 15) // 16 * 16
+            no = lS_o.numel() * 8
+            offs, at = [], nx + no
+            for t in lS_i:
+                offs.append((at, int(t.numel())))
+                at += (int(t.numel()) * 8 + 15) // 16 * 16
+            blk = torch.empty(max(at, 16), dtype=torch.uint8).pin_memory()
+            blk[:X.numel() * 4].view(torch.float32).view(X.shape).copy_(X)
+            blk[nx:nx + no].view(torch.int64).view(lS_o.shape).copy_(lS_o)
+            for (o, n), t in zip(offs, lS_i):
+                if n:
+                    blk[o:o + 8 * n].view(torch.int64).copy_(t.to(torch.int64))
+            self.blocks.append(blk)
+            self.layouts.append((tuple(X.shape), tuple(lS_o.shape), nx, no, offs))
+        self.nbytes = max(int(b.numel()) for b in self.blocks)
+
+    def views_of(self, k, blk):
+        """(X, lS_o, [lS_i_0 .. lS_i_{T-1}]) of batch k's block (host or device), no copy"""
+        xs, os_, nx, no, offs = self.layouts[k]
+        return (blk[:xs[0] * xs[1] * 4].view(torch.float32).view(xs), blk[nx:nx + no].view(torch.int64).view(os_),
+                [blk[o:o + 8 * n].view(torch.int64) for o, n in offs])
+
+    def __len__(self):
+        return self.count
+
+
 def collate_criteo_offset(x_int, x_cat, X=None, lS_o=None, lS_i=None, write_offsets=True, max_ind_range=-1):
     """collate_wrapper_criteo_offset (dlrm_data_pytorch.py:397-410) on the DEVICE: the raw batch as CriteoDataset.__getitem__
     yields it -- x_int (B, n_dense) int32 counts, x_cat (B, T) int32 ids, both on the GPU -- to (X, lS_o, lS_i) as the loader
@@ -301,14 +341,17 @@ class Prefetcher:
                 self._L.evs_stream_wait_value(self.cs.cuda_stream, self.sig[sl][1], self.uses[sl] & 0xffffffff)
             elif i >= self.depth:
                 self.cs.wait_event(self.used[sl])
-            self.slots[sl].copy_(self.ld.blocks[i % len(self.ld.blocks)], non_blocking=True)
+            src = self.ld.blocks[i % len(self.ld.blocks)]
+            self.slots[sl][:src.numel()].copy_(src, non_blocking=True)
             self.uses[sl] += 1
             if self.sig:
                 self._L.evs_stream_write_value(self.cs.cuda_stream, self.sig[sl][0], self.uses[sl] & 0xffffffff)
             else:
                 self.copied[sl].record(self.cs)
 
-    def _views(self, sl):
+    def _views(self, sl, i=0):
+        if getattr(self.ld, "ragged", False):
+            return self.ld.views_of(i % len(self.ld.blocks), self.slots[sl])
         if self.cooked is not None:   # (lS_o was written once, when the slot was made)
             xi, xc = self.ld.views(self.slots[sl])
             X, lo, li = self.cooked[sl]
@@ -327,8 +370,9 @@ class Prefetcher:
         if self.cs is None:   # one stream: copy, then the caller's launches, in stream order
             for i in range(n):
                 sl = i % self.depth
-                self.slots[sl].copy_(self.ld.blocks[i % len(self.ld.blocks)], non_blocking=True)
-                yield self._views(sl)
+                src = self.ld.blocks[i % len(self.ld.blocks)]
+                self.slots[sl][:src.numel()].copy_(src, non_blocking=True)
+                yield self._views(sl, i)
             return
         main = torch.cuda.current_stream(self.device)
         self._base = list(self.uses)
@@ -343,7 +387,7 @@ class Prefetcher:
                     self._L.evs_stream_wait_value(main.cuda_stream, self.sig[sl][0], self._use_of(i) & 0xffffffff)
                 else:
                     main.wait_event(self.copied[sl])
-                yield self._views(sl)
+                yield self._views(sl, i)
                 if self.sig:                              # (behind whatever the caller queued on its stream for this batch)
                     self._L.evs_stream_write_value(main.cuda_stream, self.sig[sl][1], self._use_of(i) & 0xffffffff)
                 else:

@@ -1580,3 +1580,36 @@ def test_collate_on_the_device_equals_the_reference_collate(E, orc):
         assert torch.equal(E.apply_emb_interact(x, lo, li, ev), want[k][1]), n
         n += 1
     assert n == 12
+
+
+@pytest.mark.parametrize("copy_stream", [False, True])
+def test_ragged_batches_through_the_prefetcher(E, orc, copy_stream):
+    """The random-data loader's batches (RandomDataset + collate_wrapper_random_offset, dlrm_data_pytorch.py:678-797: lS_i a list of T
+    index tensors of different lengths) as ONE pinned block each (inference_loop.PackedRaggedPinnedBatches) through the
+    prefetcher: every batch arrives as the tensors the loader yields, batches of different sizes share the slots, and the
+    pooled rows / R on them equal those on directly uploaded tensors."""
+    from evstore_dlrm_amd import inference_loop as IL
+    rs = np.random.RandomState(11)
+    T, d, B = 8, 16, 70
+    ln = [int(rs.choice([5, 60, 900, 4000])) for _ in range(T)]
+    ev = E.EVTables.from_fp32([torch.from_numpy(rs.uniform(-1, 1, size=(n, d)).astype(np.float32)) for n in ln])
+    host = []
+    for k in range(4):
+        lo, li = [], []
+        for n in ln:
+            cnt = rs.randint(0 if k == 2 else 1, 11, size=B)     # (batch 2 holds empty bags)
+            lo.append(torch.from_numpy(np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)))
+            li.append(torch.from_numpy(rs.randint(0, n, size=int(cnt.sum())).astype(np.int64)))
+        host.append((torch.from_numpy(rs.rand(B, 13).astype(np.float32)), lo, li))
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+    want = [E.apply_emb_interact(x, [o.cuda() for o in h[1]], [i.cuda() for i in h[2]], ev) for h in host]
+    pk = IL.PackedRaggedPinnedBatches(host, 9)
+    n = 0
+    for X, lo, li in IL.Prefetcher(pk, "cuda", copy_stream=copy_stream):
+        k = n % len(host)
+        assert torch.equal(X.cpu(), host[k][0]) and torch.equal(lo.cpu(), torch.stack(host[k][1]))
+        assert len(li) == T and all(torch.equal(a.cpu(), b) for a, b in zip(li, host[k][2]))
+        R = E.apply_emb_interact(x, [lo[t] for t in range(T)], li, ev)
+        assert torch.equal(R, want[k]), n
+        n += 1
+    assert n == 9
