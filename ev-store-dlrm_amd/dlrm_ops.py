@@ -69,7 +69,9 @@ _feat_cache = {}
 # torch (a foreign C++ extension unpacking at::Tensor, the legacy torch.utils.dlpack.to_dlpack(t); t.__dlpack__() and
 # torch.from_dlpack(t) ARE seen): call apply_emb(..., lazy=False) for that -- and indices / offsets
 # modified IN PLACE between apply_emb and the first use (checked: tensor version counters; raises instead of serving the
-# rows of the wrong batch).  EVS_DEFER_POOLING=0 switches the default back to the eager gather.
+# rows of the wrong batch).  A result nobody ever touches is never computed -- the forks' --ev-lookup-only mode, which calls
+# apply_emb and drops the list (dlrm_s_pytorch_C1.py:744-754), has to materialize(ly) or pass lazy=False to time anything.
+# EVS_DEFER_POOLING=0 switches the default back to the eager gather.
 DEFER_POOLING = os.environ.get("EVS_DEFER_POOLING", "1") == "1"
 # (two torch internals carry it -- the storage use count that says "no view of the buffer is alive" and the guard that calls
 #  a torch function without re-entering __torch_function__: a torch build without either keeps the eager default)
