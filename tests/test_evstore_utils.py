@@ -79,3 +79,36 @@ def test_csv_tables_into_hbm(U, tmp_path):
     ev = U.ev_tables_from_csv_dir(str(tmp_path))
     for k in range(26):
         assert torch.equal(ev.fp32_view(k).cpu(), torch.from_numpy(g["loaded_%d" % (k + 1)]))
+
+
+def test_replay_of_a_recorded_workload(U, tmp_path):
+    """tools/replay_workload.py = the reference's manual check cache_algo/EvLFU_C1_Cython/test.py on this package's modules: the
+    golden request stream written as the 26 trace files (write_inf_workload_to_file), read back, replayed through the Cython
+    EvLFU surface and through EvLFU_C1 over mmap'ed .bin tables -> the perfect-hit counts of the reference's own traces."""
+    import importlib.util
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import load_golden
+    t, tc = load_golden("cache_traces"), load_golden("cython_traces")
+    reqs = t["requests"][:400]
+    (tmp_path / "w").mkdir()
+    (tmp_path / "ev" / "binary").mkdir(parents=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        U.write_inf_workload_to_file(str(tmp_path / "w"), [[str(k + 1) + "-" + str(int(r[k])) for k in range(26)] for r in reqs])
+    from oracle import oracle as orc
+    tabs = orc.kaggle_tables([int(n) for n in t["n_rows"]], int(t["table_seed"]))   # (the tables the traces were recorded on)
+    for k, w in enumerate(tabs):
+        np.ascontiguousarray(w, np.float32).tofile(tmp_path / "ev" / "binary" / ("ev-table-%d.bin" % (k + 1)))
+    spec = importlib.util.spec_from_file_location("replay_workload", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "replay_workload.py"))
+    rw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rw)
+
+    def unpack(packed, n):
+        return np.unpackbits(packed, axis=1)[:, :26].astype(bool)[:n]
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        got = rw.main([str(tmp_path / "w"), str(tmp_path / "ev"), "--cache-size", "78", "--algo", "evlfu_cython"])
+    assert got == int(unpack(tc["cython_main_cap78_hits"], 1500)[:400].all(1).sum())
+    assert "perfect hit: %d" % got in out.getvalue() and "(400, 26)" in out.getvalue()
+    with contextlib.redirect_stdout(io.StringIO()):
+        got = rw.main([str(tmp_path / "w"), str(tmp_path / "ev"), "--cache-size", "768", "--algo", "evlfu"])
+    assert got == int(unpack(t["evlfu_cap768_hits"], 1500)[:400].all(1).sum())
