@@ -276,8 +276,8 @@ class Prefetcher:
         batch i + 1 crosses on a copy stream under batch i's launch.  The two hand-overs per batch (copied
         -> compute may start; consumed -> the slot may be overwritten) are SIGNAL WORDS written and waited for by the
         command processors in stream order (evs_stream_write_value / evs_stream_wait_value: csrc/evs_p2p.hip) -- an event
-        wait between two streams wakes up 0.1-0.2 ms late on this stack when the waiting stream is idle (0.21-0.5 ms per
-        batch, measured) -- with events as the fall-back where the device has no such operations (signals=False forces it).
+        wait between two streams costs more (0.175-0.18 ms per batch against 0.160, and 0.3-0.5 ms when the issuing core
+        has been idle) -- with events as the fall-back where the device has no such operations (signals=False forces it).
     for X, lS_o, lS_i in Prefetcher(ld, device): forward(...)"""
 
     def __init__(self, ld, device, depth=2, copy_stream=None, signals=True):
