@@ -92,7 +92,7 @@ def make_batches(ln_emb, B, n_batches, seed, device, dist="uniform", alpha=1.05)
     return out
 
 
-def mixed_tiers_section(ev, ln_emb, d, B, dev, fill=180, steps=40, alpha=0.75):
+def mixed_tiers_section(ev, ln_emb, d, B, dev, fill=180, steps=80, alpha=0.75):
     """BASELINE configs[4]: C1 (u8) + C2 (u4) mixed-precision tiers and the alt-key tier C3 in front of the tables (HBM miss
     tier), batched snapshot-semantics lookups with the interaction as the consumer (rows decoded inside the kernel).
     The reference's "48-48-4" split of 2 % of the rows (evlfu_8.cpp:63-78: capacities in fp32-row equivalents, x4 / x8 /
