@@ -133,6 +133,22 @@ class _DeferredRow(torch.Tensor):
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **(kwargs or {}))
 
+    def _plain(self):
+        """this row as an ordinary tensor (same storage), gathered"""
+        st = getattr(self, "_evs_state", None)
+        if st is not None:
+            st.materialize()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor)
+
+    def __deepcopy__(self, memo):   # (Tensor.__deepcopy__ wants new_empty() to return the subclass: a copy is a plain tensor)
+        t = self._plain().clone()
+        memo[id(self)] = t
+        return t
+
+    def __reduce_ex__(self, proto):   # pickle / torch.save: the values, as an ordinary tensor
+        return self._plain().__reduce_ex__(proto)
+
 
 _defer_pool = {}   # (T, B, d, device) -> entries [buf, rows, state]: recycled when nobody holds the previous result any more
 

@@ -1613,3 +1613,52 @@ def test_ragged_batches_through_the_prefetcher(E, orc, copy_stream):
         assert torch.equal(R, want[k]), n
         n += 1
     assert n == 9
+
+
+def test_deferred_rows_materialise_under_more_ways_of_touching_them(E, orc):
+    """More of what user code does with an element of apply_emb's (deferred) result -- an nn.Module call, copy.deepcopy, torch.save,
+    an in-place update, DLPack, __cuda_array_interface__, a comparison, .tolist(), iteration -- each on a fresh untouched result:
+    the gather runs first, the values are the eager path's."""
+    import copy
+    import io
+    rs = np.random.RandomState(3)
+    T, d, B = 5, 16, 40
+    ln = [int(rs.choice([3, 40, 700])) for _ in range(T)]
+    ws = [torch.from_numpy(rs.uniform(-1, 1, size=(n, d)).astype(np.float32)) for n in ln]
+    ev = E.EVTables.from_fp32(ws)
+    o = torch.arange(B).repeat(T, 1).cuda()
+    i = torch.stack([torch.from_numpy(rs.randint(0, n, size=B)) for n in ln]).cuda()
+    want = [t.clone() for t in E.apply_emb(o, i, ev, None, lazy=False)]
+    lin = torch.nn.Linear(d, 3).cuda()
+
+    class Cai:   # what a consumer of __cuda_array_interface__ (cupy, numba) sees
+        def __init__(self, t):
+            self.__cuda_array_interface__ = t.__cuda_array_interface__
+
+    def by_save(l):
+        buf = io.BytesIO()
+        torch.save(l[1], buf)
+        buf.seek(0)
+        return torch.load(buf).cuda()
+
+    touches = {
+        "module": lambda l: (lin(l[1]), torch.equal(lin(l[1]), lin(want[1]))),
+        "deepcopy": lambda l: (None, torch.equal(torch.as_tensor(copy.deepcopy(l[1])), want[1])),
+        "save": lambda l: (None, torch.equal(by_save(l), want[1])),
+        "inplace": lambda l: (l[1].add_(1.0), torch.equal(l[1] - 1.0, want[1]) or torch.allclose(l[1] - 1.0, want[1])),
+        "dlpack": lambda l: (None, torch.equal(torch.from_dlpack(l[1]), want[1])),
+        "cai": lambda l: (None, torch.equal(torch.as_tensor(Cai(l[1]), device="cuda"), want[1])),
+        "compare": lambda l: (None, bool((l[1] == want[1]).all())),
+        "tolist": lambda l: (None, l[1].tolist() == want[1].tolist()),
+        "iterate": lambda l: (None, all(torch.equal(a, b) for a, b in zip(l[1], want[1]))),
+        "matmul": lambda l: (None, torch.equal(l[1] @ l[2].t(), want[1] @ want[2].t())),
+    }
+    for name, f in touches.items():
+        ly = E.apply_emb(o, i, ev, None)
+        assert ly._evs_defer is not None and not ly._evs_defer.done, name
+        _, ok = f(ly)
+        assert ok, name
+        assert ly._evs_defer is None or ly._evs_defer.done, name
+        if name != "inplace":
+            assert all(torch.equal(torch.as_tensor(a), b) for a, b in zip(ly, want)), name
+        del ly
