@@ -12,6 +12,7 @@ libevstore_hip.so (csrc/evs_gather.hip, csrc/evs_interact.hip).
 import collections.abc
 import ctypes as C
 import os
+import threading
 import sys
 
 import torch
@@ -151,9 +152,15 @@ class _DeferredRow(torch.Tensor):
 
 
 _defer_pool = {}   # (T, B, d, device) -> entries [buf, rows, state]: recycled when nobody holds the previous result any more
+_defer_lock = threading.Lock()   # (two serving threads must not be handed the same free entry)
 
 
 def _deferred_result(lS_o, lS_i, ev, one_index_per_bag, B):
+    with _defer_lock:
+        return _deferred_result_locked(lS_o, lS_i, ev, one_index_per_bag, B)
+
+
+def _deferred_result_locked(lS_o, lS_i, ev, one_index_per_bag, B):
     T, d = len(ev), ev.d
     key = (T, B, d, ev.device)
     pool = _defer_pool.get(key)
