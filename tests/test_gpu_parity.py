@@ -1605,7 +1605,7 @@ def test_ragged_batches_through_the_prefetcher(E, orc, copy_stream):
     want = [E.apply_emb_interact(x, [o.cuda() for o in h[1]], [i.cuda() for i in h[2]], ev) for h in host]
     pk = IL.PackedRaggedPinnedBatches(host, 9)
     n = 0
-    for X, lo, li in IL.Prefetcher(pk, "cuda", copy_stream=copy_stream):
+    for X, lo, li in IL.Prefetcher(pk, "cuda", depth=3, copy_stream=copy_stream):   # (three slots: two batches on the bus side)
         k = n % len(host)
         assert torch.equal(X.cpu(), host[k][0]) and torch.equal(lo.cpu(), torch.stack(host[k][1]))
         assert len(li) == T and all(torch.equal(a.cpu(), b) for a, b in zip(li, host[k][2]))
