@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import evstore_dlrm_amd as E  # noqa: E402
 
+if os.environ.get("EVS_SPIN"):   # (developer A/B: how the host waits in a synchronise -- before anything creates the context)
+    import ctypes
+    print("hipSetDeviceFlags ->", ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(int(os.environ["EVS_SPIN"])))
 torch.cuda.set_device(0)
 B, d = 16384, 36
 ev = bench.make_tables(bench.KAGGLE_LN, d, seed=0, device="cuda")
