@@ -1,3 +1,4 @@
+"""Developer micro-benchmark: the exact batch-1 GPU engine per synchronised request (copy vs pinned in/out buffers)."""
 import sys, time, torch, numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,4 @@
+"""Developer check: the fused launch at a very large batch (2^20 samples) against the two-call path (values)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, evstore_dlrm_amd as E

@@ -1,3 +1,4 @@
+"""Developer micro-benchmark: the cache tier's batched lookups by policy (per-batch stream time), the target of tools/prof_cache.sh."""
 import sys, torch, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

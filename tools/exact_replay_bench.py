@@ -1,3 +1,4 @@
+"""Developer micro-benchmark: the exact batch-1 GPU engine replaying 2 048 requests per launch (us per request)."""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, evstore_dlrm_amd as E

@@ -1,4 +1,5 @@
 #!/bin/bash
+# developer A/B: the set records' allocation padded to 0 / 64 / 1024 MB (page-size hypothesis of the round-4 layout: rejected)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for pad in 0 64 1024; do
   echo "== EVS_SA_PAD_MB=$pad"
