@@ -156,6 +156,66 @@ def sharded_case(rs, case):
     return tag
 
 
+def p2p_case(rs, case):
+    """The sharded op with exchange_mode "p2p" on virtual ranks (one process, the ranks wired to each other's receive buffers):
+    random shapes / placements / slot orders, two or three rounds -- every rank's slice against the single-rank result."""
+    from evstore_dlrm_amd import sharded
+    T = int(rs.choice([2, 6, 13, 26]))
+    world = int(rs.choice([1, 2, 3, 4, 8]))
+    d = int(rs.choice([16, 36, 64]))
+    Bl = int(rs.choice([1, 5, 16, 48, 130]))
+    Bg = world * Bl
+    ln = [int(rs.choice([3, 40, 900, 20000])) for _ in range(T)]
+    policy = str(rs.choice(["count", "rows", "rows+replicate", "rowsplit"]))
+    thr = int(rs.choice([10, 1000]))
+    bag1 = bool(rs.randint(0, 2))
+    tag = "p2p case %d: T=%d world=%d d=%d Bl=%d policy=%s thr=%d bag1=%s" % (case, T, world, d, Bl, policy, thr, bag1)
+    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in ln]
+    ev_all = E.EVTables.from_fp32([torch.from_numpy(t) for t in tabs])
+    owner = sharded.plan_placement(ln, world, policy, replicate_max_rows=thr)
+    shared, ops = {}, []
+    for r in range(world):
+        held = {}
+        for t in range(T):
+            if owner[t] in (r, -1):
+                held[t] = torch.from_numpy(tabs[t])
+            elif owner[t] == -2:
+                lo, hi = sharded.row_range(ln[t], r, world)
+                held[t] = torch.from_numpy(np.ascontiguousarray(tabs[t][lo:hi]))
+        op = sharded.ShardedEmbeddingInteract(ln, d, r, world, held, sharded.HipBackend(torch.device("cuda")), policy=policy,
+                                              replicate_max_rows=thr, one_index_per_bag=bag1)
+        op.exchange_mode, op.p2p_virtual = "p2p", shared
+        ops.append(op)
+    try:
+        for op in ops:
+            if op.any_sharded:
+                op._p2p_state(Bg)
+        for rnd in range(int(rs.choice([2, 3]))):
+            lens = np.ones((T, Bg), dtype=np.int64) if bag1 else rs.randint(0, 4, size=(T, Bg))
+            lS_i = [torch.from_numpy(rs.randint(0, ln[k], size=int(lens[k].sum())).astype(np.int64)).cuda() for k in range(T)]
+            lS_o = [torch.from_numpy(np.concatenate([[0], np.cumsum(lens[k])[:-1]]).astype(np.int64)).cuda() for k in range(T)]
+            x = torch.from_numpy(rs.uniform(-1, 1, size=(Bg, d)).astype(np.float32)).cuda()
+            want = E.apply_emb_interact(x, lS_o, lS_i, ev_all)
+            hs = [op.start(lS_o, lS_i, slot=rnd % 2) for op in ops]
+            for op in ops:
+                op.p2p_flush()
+            Rs = [op.finish(hs[r], x[r * Bl:(r + 1) * Bl], lS_o, lS_i) for r, op in enumerate(ops)]
+            for op in ops:
+                op.p2p_flush()
+            assert E._lib.lib().evs_check_index_errors(None) == 0, tag + ": a hand-over did not arrive"
+            for r in range(world):
+                if policy == "rowsplit" and not bag1:   # (partials of a split bag are summed in rank order: not the single launch's order)
+                    assert torch.allclose(Rs[r], want[r * Bl:(r + 1) * Bl], rtol=1e-5, atol=1e-5), tag + ": rank %d round %d" % (r, rnd)
+                else:
+                    assert torch.equal(Rs[r], want[r * Bl:(r + 1) * Bl]), tag + ": rank %d round %d" % (r, rnd)
+    finally:
+        torch.cuda.synchronize()
+        for op in ops:
+            for st in op._p2p.values():
+                st.close()
+    return tag
+
+
 def encode_case(rs, case):
     d = int(rs.choice([2, 16, 36, 64]))
     n = int(rs.choice([1, 7, 500]))
@@ -177,7 +237,7 @@ def main():
     t0 = time.time()
     n = 0
     last = ""
-    kinds = (one_case, one_case, one_case, interact_case, tile_case, sharded_case, encode_case)
+    kinds = (one_case, one_case, one_case, interact_case, tile_case, sharded_case, p2p_case, encode_case)
     while time.time() - t0 < seconds:
         fn = kinds[int(rs.randint(0, len(kinds)))]
         if os.environ.get("EVS_FUZZ_VERBOSE"):
