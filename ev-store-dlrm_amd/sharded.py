@@ -363,6 +363,13 @@ class _P2PExchange:
             self._sync()
         self._pending = (self.sig_free[slot], self.k_done[slot] & 0xffffffff)
 
+    def __del__(self):   # (an op dropped without close(): its buffers and mappings go with it; peers are past their last step by then)
+        try:
+            if self._opened or self.own_recv or self.own_flags:
+                self.close()
+        except Exception:
+            pass
+
     def close(self):
         L = _lib.lib()
         try:
