@@ -650,6 +650,32 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
             except Exception as e:
                 other[name] = {"error": repr(e)}
         plan, sampled = other["plan"], other["sampled"]
+    # a single REDUCED-PRECISION tier (the reference's one-layer evlfu_8 build: MAIN_PRECISION 8, N_CACHING_LAYER 1) at the same
+    # capacity and stream: the probe folded into the u8 rows-in-registers consumer (evs_fused_rfq.hip, PROBE form)
+    rp_tier = None
+    if policy is None and batch1:
+        try:
+            ev8 = ev.encode(8)
+            c8 = E.GpuCache("evlfu", cap, T, d, 8, "python", dev)
+            c8.set_backing(ev8)
+            for i in range(warmup):
+                c8.lookup_interact(rows[i], x, out=out, hit=hit)
+            q0 = c8.batch_stats()
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            ea.record()
+            nq = min(steps, 100)
+            for i in range(nq):
+                c8.lookup_interact(rows[warmup + n_cmp + i], x, out=out, hit=hit)
+            eb.record()
+            torch.cuda.synchronize()
+            q1 = c8.batch_stats()
+            msq = ea.elapsed_time(eb) / nq
+            rp_tier = {"bits": 8, "ms_per_step": msq, "value": T * B / msq * 1e3, "hit_rate": (q1["n_hits"] - q0["n_hits"]) / (T * B * nq), "timed_batches": nq,
+                       "note": "GpuCache(evlfu, 10 % of the rows, codec 8) over the u8 tables: set probe + u8 gather + interaction one launch, one update launch"}
+            del c8, ev8
+        except Exception as e:
+            rp_tier = {"error": repr(e)}
     # the same tier with 4 x the requests per snapshot (what a caller with four queued batches can hand over as one): the
     # fixed costs of the two launches and the update's dependent round trips are paid once per 65 536 samples
     large = None
@@ -661,7 +687,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
         except Exception as e:
             large = {"error": repr(e)}
     return {"value": looks / dt, "policy": pol, "sampled_policy": sampled, "timed_batches": steps, "oracle_hit_rate": None if not oracle_cmp else oracle_cmp.get("oracle_hit_rate"),
-            "hit_rate_vs_sequential_oracle": oracle_cmp, "plan_policy": plan, "roofline": tier_roof, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "large_batch": large, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
+            "hit_rate_vs_sequential_oracle": oracle_cmp, "plan_policy": plan, "roofline": tier_roof, "batch1_exact": b1, "cpu_baseline_batch1": cpu, "host_miss_tier": host_tier, "large_batch": large, "reduced_precision_tier": rp_tier, "unit": "lookups/s", "ms_per_step": dt / steps * 1e3,
             "hit_rate": (s1["n_hits"] - s0["n_hits"]) / looks, "capacity_entries": cap,
             "resident_entries": s1["size"], "evictions": s1["n_evict"] - s0["n_evict"],
             "workload": "BASELINE configs[2]: EvLFU C1 in HBM at %.0f%% of 33.76M rows, Zipf(alpha=%.2f) indices, "

@@ -3342,7 +3342,13 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         a.miss_rec = c->miss_rec; a.list_cnt = c->list_cnt;
         a.list_cap = (int)((B + 8 * (long long)a.g1 - 1) / (8 * (long long)a.g1)) * 8 * T;
         static const bool fold_on = !(getenv("EVS_CACHE_FOLD") && getenv("EVS_CACHE_FOLD")[0] == '0');
-        const bool fold = fold_on && a.row_ids && R && !out && c->sa.ways == 8;   // (the folded probe is compiled for 8-way sets)
+        bool small_tabs = true;   // (tile entries carry a row id in 30 bits)
+        for (int k = 0; k < T; k++) small_tabs = small_tabs && c->backing_rows[k] < (1ll << 30);
+        // a reduced-precision tier (the reference's one-layer 16 / 8 / 4-bit builds): the probe folded into ITS consumer too
+        static const bool foldq_on = !(getenv("EVS_CACHE_FOLDQ") && getenv("EVS_CACHE_FOLDQ")[0] == '0');
+        const bool foldq = fold_on && foldq_on && c->host.codec != 32 && R && !out && c->sa.ways == 8 && c->sa.sub_shift == 0 && small_tabs &&
+                           cap < (1ll << 30) && fused_probe_codec_supported(B, T, c->host.dim, c->host.codec);
+        const bool fold = (fold_on && a.row_ids && R && !out && c->sa.ways == 8) || foldq;   // (the folded probes are compiled for 8-way sets)
         if (fold) {
             ProbeArgs pa;
             pa.slots = nullptr; pa.mask = 0; pa.reusable_tomb = kTomb; pa.eagg = nullptr;
@@ -3353,7 +3359,7 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
             a.list_cap = 16 * T;
             a.g1 = (int)((B + 15) / 16);
             const int rc = fused_probe_interact(B, T, c->host.dim, x, x_stride, pa, c->a.arena,
-                                                reinterpret_cast<const void *const *>(c->backing), c->backing_rows, itself, R, st);
+                                                reinterpret_cast<const void *const *>(c->backing), c->backing_rows, itself, R, st, c->host.codec);
             if (rc) return rc;
         } else {
             hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)a.g1), dim3(256), 0, st, a);

@@ -82,5 +82,7 @@ bool launch_rf_probe(const FusedArgs &a, hipStream_t st);
 // mapping; bag1 == 1 (no offsets) or 2 (the one-index-per-bag leg of the optimistic triple); false = no kernel for the shape
 bool launch_rfq(const FusedArgs &a, int codec, hipStream_t st);
 bool rfq_supported(const FusedArgs &a, int codec);
+bool rfq_probe_supported(int64_t B, int F, int d, int codec);      // evs_fused_rfq.hip: the tier probe folded in (set-associative, 8 ways)
+bool launch_rfq_probe(const FusedArgs &a, int codec, hipStream_t st);
 
 }  // namespace evs

@@ -1343,11 +1343,13 @@ int fused_interact_from_row_ids(int64_t B, int T, int d, const float *x, int64_t
     return EVS_OK;
 }
 
+bool fused_probe_codec_supported(int64_t B, int T, int d, int codec) { return rfq_probe_supported(B, T + 1, d, codec); }
+
 // ... and with the cache probe folded in (evs_fused_rf.hip, PROBE variant): the request rows in, R, hit flags, the miss
 // lists and the hit statistics out.  One block per 16 samples: probe.list_cnt needs ceil(B / 16) entries, probe.miss_rec
 // ceil(B / 16) * probe.list_cap records with list_cap >= 16 * T.
 int fused_probe_interact(int64_t B, int T, int d, const float *x, int64_t x_stride, const ProbeArgs &probe, const void *arena,
-                         const void *const *tables, const long long *table_rows, int itself, float *R, hipStream_t st) {
+                         const void *const *tables, const long long *table_rows, int itself, float *R, hipStream_t st, int codec) {
     FusedArgs a;
     const int F = T + 1;
     for (int f = 0; f < EVS_MAX_FEATURES; f++) {
@@ -1364,6 +1366,12 @@ int fused_probe_interact(int64_t B, int T, int d, const float *x, int64_t x_stri
     a.dummy_i64 = reinterpret_cast<const int64_t *>(a.zeros); a.dummy_f32 = x; a.bag1 = 1; a.enc_lds = 0; a.opt_flag = nullptr; a.opt_id = 0;
     a.w1p = nullptr; a.b1 = nullptr; a.z1 = nullptr; a.n1 = 0; a.kp = 0; a.relu = 0; a.write_r = 1;
     a.row_ids = nullptr; a.arena = arena; a.probe = probe;
+    if (codec != 32) {   // a reduced-precision tier: the rows decoded in the kernel (evs_fused_rfq.hip, PROBE form)
+        a.enc_lds = 1;
+        if (!launch_rfq_probe(a, codec, st)) { set_error("fused_probe_interact: no kernel for B=%lld T=%d d=%d codec=%d", (long long)B, T, d, codec); return EVS_EINVAL; }
+        EVS_HIP_CHECK(hipGetLastError());
+        return EVS_OK;
+    }
     if (!launch_rf_probe(a, st)) { set_error("fused_probe_interact: no kernel for B=%lld T=%d d=%d", (long long)B, T, d); return EVS_EINVAL; }
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;

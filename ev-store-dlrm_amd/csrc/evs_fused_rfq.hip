@@ -121,10 +121,15 @@ __device__ __forceinline__ float dec_elem_q(unsigned w0, unsigned w1, int e, con
 // block that finds anything else pools ITS samples in a slow loop straight from global memory (general semantics: empty
 // bags, several indices summed in index order, bad offsets / indices skipped and flagged -- the arithmetic of the general
 // loop of evs_fused.hip) and feeds the same MFMA + output code.  No flag, no second launch.
-template <int CODEC, int CQ, int REM, int NT, bool CHECK = false>
+// PROBE (round 4; a single reduced-precision tier -- the reference's one-layer evlfu_16 / _8 / _4 builds -- under the
+// set-associative batch policy): the kernel reads the REQUEST rows and probes the tier's set records itself in its head, as
+// emb_interact_rf_kernel<..., PROBE> does for an fp32 tier (evs_fused_rf.hip): hits read the arena (bit 30 of the tile
+// entry), misses the table, hit flags / miss lists / statistics go where cache_batch_probe_gather_kernel would have put them.
+template <int CODEC, int CQ, int REM, int NT, bool CHECK = false, bool PROBE = false>
 __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_kernel(const FusedArgs args) {
+    static_assert(!(CHECK && PROBE), "the offsets check belongs to the plain launch");
     // optimistic launches (offsets given, see offsets_arange_kernel in evs_fused.hip): this is the one-index-per-bag loop
-    if constexpr (!CHECK) {
+    if constexpr (!CHECK && !PROBE) {
         if (args.opt_flag && *args.opt_flag == args.opt_id) return;
     }
     constexpr int NR = NT;
@@ -180,6 +185,92 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
 
     // ---- index tile: thread e (and e + 256) owns element (feature e >> 4, sample e & 15) -------------------------------
     bool bad = false, my_ragged = false, fast_bad = false;
+    if constexpr (PROBE) {
+        // the cache probe folded in (the set-associative form of evs_fused_rf.hip's PROBE head): thread e owns key
+        // (table (e >> 4) - 1, sample e & 15) and its twin e + 256
+        __shared__ int s_agg[16];                 // hits per request of the chunk
+        __shared__ int s_pdelta[kMaxBuckets];     // priority histogram moves
+        __shared__ int s_psum[2];                 // hits / perfect requests
+        __shared__ int s_nlist;                   // misses listed
+        __shared__ unsigned s_nrows[32], s_sa_base[32];
+        const ProbeArgs &pa = args.probe;
+        const int T = pa.T;
+        for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_pdelta[i] = 0;
+        if (threadIdx.x < 16) s_agg[threadIdx.x] = 0;
+        if (threadIdx.x < 2) s_psum[threadIdx.x] = 0;
+        if (threadIdx.x == 0) s_nlist = 0;
+        if (threadIdx.x < 32) {   // per-table facts the probe indexes by LANE: out of LDS, not out of the kernel arguments
+            s_nrows[threadIdx.x] = (unsigned)ka->n_rows[threadIdx.x];                     // feature f's rows (f = table + 1)
+            s_sa_base[threadIdx.x] = ka->probe.sau.row_base[(threadIdx.x + 31) & 31];   // feature f = table f - 1
+        }
+        codec_lut_init<CODEC>(s_lut);
+        if constexpr (PAIR4) s_lut2[threadIdx.x] = make_float2(u4_value(threadIdx.x >> 4), u4_value(threadIdx.x & 15u));
+        __syncthreads();
+        const int64_t bs = blk_first + (threadIdx.x & 15);
+        int prow[2], pe[2], pprio[2];
+        bool pact[2], pok[2];
+        unsigned pset[2], ptag[2], pw0[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            pact[h] = f >= 1 && f < F && bs < blk_end;
+            const int *rp = pact[h] ? pa.requests + bs * (int64_t)T + (f - 1) : reinterpret_cast<const int *>(args.dummy_i64);
+            prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            pok[h] = pact[h] & (prow[h] >= 0) & ((unsigned)prow[h] < s_nrows[f & 31]);
+            sa_split(pa.sa, sa_perm(pa.sau, s_sa_base[f & 31] + (pok[h] ? (unsigned)prow[h] : 0u)), pset[h], ptag[h]);
+            if (!pok[h]) pset[h] = 0u;
+        }
+        SaLine line[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) sa_load<8>(pa.sa, pset[h], line[h]);
+        __builtin_amdgcn_sched_barrier(0);   // both keys' set records in one round trip
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            unsigned w;
+            const int way = sa_find<8>(pa.sa, line[h], ptag[h], w);
+            const bool found = pok[h] && way >= 0;
+            pe[h] = found ? (int)(pset[h] * 8u + (unsigned)way) : -1;
+            pprio[h] = found ? sa_prio(w) : 0x7fffffff;
+            pw0[h] = w;
+            if (found) atomicAdd(&s_agg[threadIdx.x & 15], 1);
+        }
+        __syncthreads();
+        const int agg = s_agg[threadIdx.x & 15];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            if (pe[h] >= 0 && pprio[h] < agg) {   // monotone max like update_agg_hit
+                const int old = sa_prio(atomicMax(sa_ways_ptr(pa.sa, pset[h]) + ((unsigned)pe[h] & 7u), sa_bump(pw0[h], agg)));
+                if (old < agg) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
+            }
+            int v = -1;
+            if (f == 0) v = bs < blk_end ? (int)bs : -1;                 // x: the sample number
+            else if (pact[h]) v = pe[h] >= 0 ? (int)(0x40000000u | (unsigned)pe[h]) : (pok[h] ? prow[h] : -1);
+            s_idx[(int)threadIdx.x + 256 * h] = v;
+            if (pact[h]) {
+                const int64_t m = bs * (int64_t)T + (f - 1);
+                if (pa.hit) pa.hit[m] = pe[h] >= 0;
+                if (!pok[h]) bad = true;
+                if (pok[h] && pe[h] < 0) {
+                    const int at = atomicAdd(&s_nlist, 1);
+                    pa.miss_rec[(int64_t)blockIdx.x * pa.list_cap + at] = make_uint4((unsigned)prow[h], (unsigned)(f - 1) | ((unsigned)agg << 8), pset[h], ptag[h]);
+                }
+            }
+            if (f == 1 && bs < blk_end) { atomicAdd(&s_psum[0], agg); if (agg == T) atomicAdd(&s_psum[1], 1); }
+        }
+        __syncthreads();
+        if (threadIdx.x < 40) {   // the block's totals into one of the replica rows (folded by the cache's close)
+            const int i = threadIdx.x;
+            const int v = i <= T ? s_pdelta[i] : i == 38 ? s_psum[0] : i == 39 ? s_psum[1] : 0;
+            if (v) atomicAdd(&pa.part1[(blockIdx.x % 32) * 40 + i], v);
+        }
+        if (threadIdx.x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
+    } else
     {
         const int64_t bs = blk_first + (threadIdx.x & 15);
         int64_t v[2], o0[2], o1[2];
@@ -455,8 +546,14 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
 #else
             const unsigned neg = (unsigned)(iv >> 31) | phantom;
 #endif
-            const unsigned idx = (unsigned)iv & ~neg;
-            const unsigned long long p = fbase[rr] + (unsigned long long)idx * (unsigned long long)fscale[rr];
+            unsigned idx = (unsigned)iv & ~neg;
+            unsigned long long rbase = fbase[rr];
+            if constexpr (PROBE) {   // bit 30: a row of the tier's arena (bit blend, no select over the LDS reads)
+                const unsigned long long in_arena = 0ull - (unsigned long long)((idx >> 30) & 1u);
+                rbase ^= (rbase ^ (unsigned long long)reinterpret_cast<uintptr_t>(args.arena)) & in_arena;
+                idx &= 0x3fffffffu;
+            }
+            const unsigned long long p = rbase + (unsigned long long)idx * (unsigned long long)fscale[rr];
             const unsigned long long m64 = ((unsigned long long)neg << 32) | neg;
             const unsigned long long pa = p ^ ((p ^ zc_p) & m64);
             if constexpr (FOLD4A) {
@@ -600,6 +697,42 @@ bool rfq_supported(const FusedArgs &a, int codec) {
     if (codec != 16 && codec != 8 && codec != 4) return false;
     if (!rfq_mode() || !a.enc_lds || a.F > kTileMaxF || a.B > rfq_max_batch() || a.B >= (1ll << 31)) return false;
     return a.d == 16 || a.d == 32 || a.d == 36;
+}
+
+// the PROBE form: a single reduced-precision set-associative tier (8-way sets), d in {16, 32, 36}
+template <int CODEC>
+static bool launch_rfq_probe_d(const FusedArgs &a, hipStream_t st) {
+    const unsigned blocks = (unsigned)((a.B + 15) / 16);
+    const bool nt2 = a.F > 16;
+    switch (a.d) {
+    case 16:
+        if (nt2) hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, 1, 0, 2, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, 1, 0, 1, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        return true;
+    case 32:
+        if (nt2) hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, 2, 0, 2, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, 2, 0, 1, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        return true;
+    case 36:
+        if (nt2) hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, 2, 1, 2, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emb_interact_rfq_kernel<CODEC, 2, 1, 1, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        return true;
+    default: return false;
+    }
+}
+bool rfq_probe_supported(int64_t B, int F, int d, int codec) {
+    return (codec == 16 || codec == 8 || codec == 4) && rfq_mode() && F <= kTileMaxF && B < (1ll << 30) && (d == 16 || d == 32 || d == 36);
+}
+bool launch_rfq_probe(const FusedArgs &a, int codec, hipStream_t st) {
+    if (!rfq_probe_supported(a.B, a.F, a.d, codec) || !a.probe.sa.tags || a.probe.sa.ways != 8u || !a.arena) return false;
+    FusedArgs b = a;
+    b.zero_codes = zero_code_page(codec);
+    if (!b.zero_codes) return false;
+    switch (codec) {
+    case 16: return launch_rfq_probe_d<16>(b, st);
+    case 8: return launch_rfq_probe_d<8>(b, st);
+    default: return launch_rfq_probe_d<4>(b, st);
+    }
 }
 
 bool launch_rfq(const FusedArgs &a, int codec, hipStream_t st) {

@@ -286,6 +286,7 @@ struct ProbeArgs {
 // evs_fused.hip: interaction over x + the T rows the cache serves, the probe folded into the kernel (fp32 rows; is there a
 // kernel for the shape: fused_row_ids_supported)
 int fused_probe_interact(int64_t B, int T, int d, const float *x, int64_t x_stride, const ProbeArgs &probe, const void *arena,
-                         const void *const *tables, const long long *table_rows, int itself, float *R, hipStream_t st);
+                         const void *const *tables, const long long *table_rows, int itself, float *R, hipStream_t st, int codec = 32);
+bool fused_probe_codec_supported(int64_t B, int T, int d, int codec);   // a reduced-precision tier: is there a folded kernel
 
 }  // namespace evs

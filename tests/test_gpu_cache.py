@@ -840,13 +840,20 @@ def test_single_tier_reduced_precision_interaction_consumer(E, orc, codec, d, T,
         hot = rs.rand(B, T) < 0.6
         rq = np.where(hot, rs.randint(0, 10, size=(B, T)), np.stack([rs.randint(0, n, size=B) for n in n_rows], 1)).astype(np.int32)
         x = torch.from_numpy(rs.uniform(-1, 1, size=(B, d)).astype(np.float32)).cuda()
+        resident = {(int(t), int(rw)) for _, t, rw in c.batch_dump()} if it else set()
         hit, R = c.lookup_interact(torch.from_numpy(rq).cuda(), x, itself=bool(it & 1))
         want = orc.interact_features(x.cpu().numpy(), [dec[k][rq[:, k]] for k in range(T)], bool(it & 1))
         np.testing.assert_allclose(R.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
         assert torch.equal(R[:, :d], x)
         h = hit.cpu().numpy()
+        # the flags are the snapshot: residency when the batch arrived (the probe folded into the consumer or not)
+        assert np.array_equal(h.astype(bool), np.array([[(k + 1, int(rq[b, k])) in resident for k in range(T)] for b in range(B)]))
         saw_hit |= bool(h.any()); saw_miss |= bool((h == 0).any())
+        st = c.batch_stats()
+        keys = [(int(t), int(rw)) for _, t, rw in c.batch_dump()]
+        assert len(set(keys)) == len(keys) == st["size"] <= 500
     assert saw_hit and saw_miss and c.batch_stats()["size"] <= 500
+    assert c.batch_stats()["n_requests"] == 6 * B
 
 
 @pytest.mark.parametrize("cap", [50, 64, 257])
