@@ -763,10 +763,11 @@ def main():
             ln_run = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
                       4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
         result = sharded.bench_sharded(args, ln_run, rank, world, dev)
-        # N > 1: the device-to-device exchange beside the RCCL headline.  No box with two GPUs has run it yet, so the finished
-        # headline line goes out FIRST (were this side measurement to take the job down, the line above it stands); when it
-        # returns, the same line with `exchange_p2p` added is printed as the last line.  EVS_BENCH_P2P=0 skips it.
-        if world > 1 and args.exchange_mode != "p2p" and os.environ.get("EVS_BENCH_P2P", "1") != "0":
+        # N > 1: the device-to-device exchange beside the RCCL headline.  No box with two GPUs has run it yet (IPC-mapped
+        # fine-grained buffers, cross-GPU flag words, spin-wait kernels: a bad peer write is a GPU fault that takes the job and
+        # its exit status with it), so it is OPT-IN: EVS_BENCH_P2P=1.  The finished headline line still goes out FIRST; when the
+        # side measurement returns, the same line with `exchange_p2p` added is printed as the last line.
+        if world > 1 and args.exchange_mode != "p2p" and os.environ.get("EVS_BENCH_P2P", "0") == "1":
             if rank == 0:
                 import ctypes
                 ctypes.CDLL(None).fflush(None)

@@ -14,6 +14,8 @@ import ctypes as C
 import os
 import threading
 import sys
+import warnings
+import weakref
 
 import torch
 
@@ -37,7 +39,7 @@ class _PooledList(list):
     address the T features arithmetically instead of asking 27 tensors for their pointers and strides.
     Any mutation (a caller swapping in a cached row tensor for one table, say) drops that shortcut.
     _evs_defer: the _Deferred state when the gather behind the list has not been launched yet (see there)."""
-    __slots__ = ("_evs_meta", "_evs_defer")
+    __slots__ = ("_evs_meta", "_evs_defer", "__weakref__")
 
     def _dirty(name):
         base = getattr(list, name)
@@ -73,7 +75,34 @@ _feat_cache = {}
 # rows of the wrong batch).  A result nobody ever touches is never computed -- the forks' --ev-lookup-only mode, which calls
 # apply_emb and drops the list (dlrm_s_pytorch_C1.py:744-754), has to materialize(ly) or pass lazy=False to time anything.
 # EVS_DEFER_POOLING=0 switches the default back to the eager gather.
+# EVS_DEFER_POISON=1 is the debug mode of all this: every deferred buffer is filled with a signalling-NaN pattern when it is
+# handed out, materialize() checks that the gather overwrote every word of it, and interact_features refuses features that
+# still hold the pattern (= somebody read the buffer past torch's dispatch) instead of multiplying garbage.
 DEFER_POOLING = os.environ.get("EVS_DEFER_POOLING", "1") == "1"
+DEFER_POISON = os.environ.get("EVS_DEFER_POISON", "0") == "1"
+POISON_WORD = 0x7FA5A5A5   # exponent all ones, quiet bit clear, mantissa non-zero: a signalling NaN no fp32 sum produces
+_defer_stats = {"handed_out": 0, "recycled": 0, "recycled_unconsumed": 0, "poison_checks": 0}
+
+
+def defer_stats():
+    """counters of the deferred default: results handed out, buffers recycled, and results that were dropped without ever being
+    computed or consumed (legal -- nobody looked -- but a timing loop that does this measures nothing)"""
+    return dict(_defer_stats)
+
+
+def _poisoned(t):
+    """number of fp32 words of t that still hold the poison pattern (synchronises; debug mode only)"""
+    with torch._C.DisableTorchFunctionSubclass():
+        t = t.as_subclass(torch.Tensor) if type(t) is not torch.Tensor else t
+        return int((t.contiguous().view(torch.int32) == POISON_WORD).sum().item())
+
+
+def _version_of(t):
+    """t's version counter, or None where torch keeps none (inference tensors: torch.inference_mode())"""
+    try:
+        return None if t.is_inference() else t._version
+    except RuntimeError:
+        return None
 # (two torch internals carry it -- the storage use count that says "no view of the buffer is alive" and the guard that calls
 #  a torch function without re-entering __torch_function__: a torch build without either keeps the eager default)
 if not (hasattr(torch._C, "_storage_Use_Count") and hasattr(torch._C, "DisableTorchFunctionSubclass")):
@@ -82,11 +111,12 @@ if not (hasattr(torch._C, "_storage_Use_Count") and hasattr(torch._C, "DisableTo
 
 class _Deferred:
     """state behind one deferred apply_emb result"""
-    __slots__ = ("lS_o", "lS_i", "ev", "buf", "done", "vers", "one")
+    __slots__ = ("lS_o", "lS_i", "ev", "buf", "done", "vers", "one", "consumed")
 
     def _check(self):
         for t, v in self.vers:
-            if t._version != v:
+            # (inference tensors keep no version counter: nothing to compare, and in-place writes to them are the caller's to order)
+            if v is not None and t._version != v:
                 raise RuntimeError("apply_emb's indices / offsets were modified in place before its (deferred) result was first used; "
                                    "consume the result first, or call apply_emb(..., lazy=False)")
 
@@ -96,6 +126,11 @@ class _Deferred:
             apply_emb(self.lS_o, self.lS_i, self.ev, None, out=None, lazy=False, one_index_per_bag=self.one, _into=self.buf)
             self.done = True
             self.lS_o = self.lS_i = None
+            if DEFER_POISON:
+                _defer_stats["poison_checks"] += 1
+                left = _poisoned(self.buf)
+                if left:
+                    raise AssertionError("EVS_DEFER_POISON: %d words of the deferred buffer were not written by the gather" % left)
 
 
 _NO_TOUCH = None   # torch functions that only read metadata: filled on first use (the descriptors need torch loaded)
@@ -113,24 +148,30 @@ def _no_touch():
     return _NO_TOUCH
 
 
+def _touch(a, cls):
+    """materialise every deferred row reachable from a torch function's arguments: positional or keyword, inside lists, tuples
+    and dicts at any depth (torch.cat(tensors=ly), torch.stack(tensors=ly, dim=1), nested sequences)"""
+    if type(a) is cls:
+        st = getattr(a, "_evs_state", None)
+        if st is not None:
+            st.materialize()
+    elif isinstance(a, (list, tuple)):
+        for b in a:
+            _touch(b, cls)
+    elif isinstance(a, dict):
+        for b in a.values():
+            _touch(b, cls)
+
+
 class _DeferredRow(torch.Tensor):
     """one (B,d) element of a deferred apply_emb result (see above)"""
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         if func not in _no_touch():
-            for a in args:
-                st = getattr(a, "_evs_state", None) if type(a) is cls else None
-                if st is not None:
-                    st.materialize()
-                elif isinstance(a, (list, tuple)):
-                    for b in a:
-                        if type(b) is cls and b._evs_state is not None:
-                            b._evs_state.materialize()
+            _touch(args, cls)
             if kwargs:
-                for a in kwargs.values():
-                    if type(a) is cls and a._evs_state is not None:
-                        a._evs_state.materialize()
+                _touch(kwargs, cls)
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **(kwargs or {}))
 
@@ -151,8 +192,50 @@ class _DeferredRow(torch.Tensor):
         return self._plain().__reduce_ex__(proto)
 
 
-_defer_pool = {}   # (T, B, d, device) -> entries [buf, rows, state]: recycled when nobody holds the previous result any more
+_defer_pool = {}   # (T, B, d, device, inference mode) -> _PoolEntry list: recycled when nobody holds the previous result any more
 _defer_lock = threading.Lock()   # (two serving threads must not be handed the same free entry)
+
+
+def _max_refs(rows):
+    return max(sys.getrefcount(r) for r in rows)
+
+
+class _PoolEntry:
+    """one (T,B,d) buffer, its T row objects (creating 26 subclass views costs ~45 us -- twice the step -- so they are kept)
+    and the state they share.  Three independent conditions say "free again":
+      * the list handed out last has died (a weakref callback on it clears `out`),
+      * no row object escaped it (every row's reference count is what it was when only this entry held it -- `rc0`,
+        measured then, not a constant),
+      * no view of the buffer is alive (the storage's use count is what it was then -- `uc0`)."""
+    __slots__ = ("buf", "rows", "st", "uc0", "rc0", "out", "_gone")
+
+    def __init__(self, T, B, d, device):
+        self.buf = buf = torch.empty((T, B, d), dtype=torch.float32, device=device)
+        self.st = st = _Deferred()
+        st.buf, st.done, st.consumed = buf, True, True
+        self.rows = []
+        for v in buf.unbind(0):
+            r = v.as_subclass(_DeferredRow)
+            r._evs_state = st
+            self.rows.append(r)
+        del v, r
+        self.uc0 = torch._C._storage_Use_Count(buf.untyped_storage()._cdata)
+        self.rc0 = _max_refs(self.rows)
+        self.out = None
+        self._gone = self._list_died   # (one bound method, made once)
+
+    def _list_died(self, ref):
+        if self.out is ref:
+            self.out = None
+
+    def free(self):
+        return self.out is None and torch._C._storage_Use_Count(self.buf.untyped_storage()._cdata) == self.uc0 \
+            and _max_refs(self.rows) == self.rc0
+
+    def hand_out(self):
+        ly = _PooledList(self.rows)
+        self.out = weakref.ref(ly, self._gone)
+        return ly
 
 
 def _deferred_result(lS_o, lS_i, ev, one_index_per_bag, B):
@@ -162,7 +245,8 @@ def _deferred_result(lS_o, lS_i, ev, one_index_per_bag, B):
 
 def _deferred_result_locked(lS_o, lS_i, ev, one_index_per_bag, B):
     T, d = len(ev), ev.d
-    key = (T, B, d, ev.device)
+    # (a buffer made under torch.inference_mode() is an inference tensor: never handed to code outside it, and the reverse)
+    key = (T, B, d, ev.device, torch.is_inference_mode_enabled())
     pool = _defer_pool.get(key)
     if pool is None:
         if len(_defer_pool) > 8:
@@ -170,31 +254,29 @@ def _deferred_result_locked(lS_o, lS_i, ev, one_index_per_bag, B):
         pool = _defer_pool[key] = []
     ent = None
     for e in pool:
-        # free again?  nobody but the pool holds the rows (Python references) and no view of the buffer is alive (its storage is
-        # shared by the T rows and the buffer itself)
-        if torch._C._storage_Use_Count(e[0].untyped_storage()._cdata) == e[3] and all(sys.getrefcount(r) == 3 for r in e[1]):
+        if e.free():
             ent = e
+            _defer_stats["recycled"] += 1
+            if not (e.st.done or e.st.consumed):
+                _defer_stats["recycled_unconsumed"] += 1
+                if DEFER_POISON:
+                    warnings.warn("EVS_DEFER_POISON: a deferred apply_emb result was dropped without being computed or consumed")
             break
     if ent is None:
-        buf = torch.empty((T, B, d), dtype=torch.float32, device=ev.device)
-        st = _Deferred()
-        rows = []
-        for v in buf.unbind(0):
-            r = v.as_subclass(_DeferredRow)
-            r._evs_state = st
-            rows.append(r)
-        st.buf = buf
-        del v, r
-        ent = [buf, rows, st, torch._C._storage_Use_Count(buf.untyped_storage()._cdata)]   # (the count with nobody else looking)
+        ent = _PoolEntry(T, B, d, ev.device)
         if len(pool) < 4:
             pool.append(ent)
-    buf, rows, st = ent[0], ent[1], ent[2]
-    st.lS_o, st.lS_i, st.ev, st.done, st.one = lS_o, lS_i, ev, False, bool(one_index_per_bag)
+    buf, st = ent.buf, ent.st
+    if DEFER_POISON:
+        with torch._C.DisableTorchFunctionSubclass():
+            buf.view(torch.int32).fill_(POISON_WORD)
+    st.lS_o, st.lS_i, st.ev, st.done, st.one, st.consumed = lS_o, lS_i, ev, False, bool(one_index_per_bag), False
     ts = ([lS_o] if torch.is_tensor(lS_o) else list(lS_o)) + ([lS_i] if torch.is_tensor(lS_i) else list(lS_i))
-    st.vers = [(t, t._version) for t in ts]
-    ly = _PooledList(rows)
+    st.vers = [(t, _version_of(t)) for t in ts]
+    ly = ent.hand_out()
     ly._evs_meta = (buf.data_ptr(), B * d, d, B, d, T)
     ly._evs_defer = st
+    _defer_stats["handed_out"] += 1
     return ly
 
 
@@ -506,6 +588,7 @@ def interact_features(x, ly, arch_interaction_op="dot", arch_interaction_itself=
                 and x.shape[1] == st.ev.d and x.stride(1) == 1 and int(x.shape[0]) == st.buf.shape[1] \
                 and getattr(ly[0], "_evs_state", None) is st and getattr(ly[-1], "_evs_state", None) is st:
             st._check()
+            st.consumed = True
             return apply_emb_interact(x, st.lS_o, st.lS_i, st.ev, None, arch_interaction_itself, one_index_per_bag=st.one)
         st.materialize()
     elif st is None and isinstance(ly, (list, tuple)):
@@ -514,6 +597,11 @@ def interact_features(x, ly, arch_interaction_op="dot", arch_interaction_itself=
                 t._evs_state.materialize()
     B, d = x.shape
     dev = x.device
+    if DEFER_POISON and isinstance(ly, (list, tuple)):
+        _defer_stats["poison_checks"] += 1
+        for k, t in enumerate(ly):
+            if torch.is_tensor(t) and t.dtype == torch.float32 and _poisoned(t):
+                raise AssertionError("EVS_DEFER_POISON: feature %d still holds the unfilled-buffer pattern: it was read past torch's dispatch" % k)
     meta = getattr(ly, "_evs_meta", None)
     pooled = None
     if meta is not None and len(ly) == meta[5] and meta[3] == B and meta[4] == d and len(ly) > 0:

@@ -291,6 +291,8 @@ class Prefetcher:
         self.used = [torch.cuda.Event() for _ in range(depth)]
         self.sig = None          # per slot: (copied word, used word), counting the slot's uses
         self.uses = [0] * depth
+        self.recorded = [False] * depth   # event hand-overs: the slot's `used` event has been recorded at least once
+        self._chk = lambda rc: rc        # (replaced by _lib.check where the signal words are in use)
         if copy_stream and signals:
             from . import _lib
             import ctypes as C
@@ -304,6 +306,7 @@ class Prefetcher:
                         sig.append(p.value)
                 self.sig = [(sig[2 * i], sig[2 * i + 1]) for i in range(depth)]
                 self._L = L
+                self._chk = _lib.check   # a failed hipStreamWaitValue32 / WriteValue32 raises: a dropped hand-over is a data race
             except Exception:    # no stream wait-value operations on this device: events (or, by default, one stream)
                 for p in sig:
                     L.evs_signal_free(C.c_void_p(p))
@@ -338,14 +341,14 @@ class Prefetcher:
         with torch.cuda.stream(self.cs):
             # the slot's previous use has been consumed
             if self.sig:
-                self._L.evs_stream_wait_value(self.cs.cuda_stream, self.sig[sl][1], self.uses[sl] & 0xffffffff)
-            elif i >= self.depth:
+                self._chk(self._L.evs_stream_wait_value(self.cs.cuda_stream, self.sig[sl][1], self.uses[sl] & 0xffffffff))
+            elif self.recorded[sl]:    # (whichever pass used the slot last: a second pass over this object starts at i = 0 again)
                 self.cs.wait_event(self.used[sl])
             src = self.ld.blocks[i % len(self.ld.blocks)]
             self.slots[sl][:src.numel()].copy_(src, non_blocking=True)
             self.uses[sl] += 1
             if self.sig:
-                self._L.evs_stream_write_value(self.cs.cuda_stream, self.sig[sl][0], self.uses[sl] & 0xffffffff)
+                self._chk(self._L.evs_stream_write_value(self.cs.cuda_stream, self.sig[sl][0], self.uses[sl] & 0xffffffff))
             else:
                 self.copied[sl].record(self.cs)
 
@@ -384,18 +387,24 @@ class Prefetcher:
                     self._issue(i + self.depth - 1)      # the next batch starts crossing now
                 sl = i % self.depth
                 if self.sig:   # (the value the copy of batch i wrote: its slot's use count)
-                    self._L.evs_stream_wait_value(main.cuda_stream, self.sig[sl][0], self._use_of(i) & 0xffffffff)
+                    self._chk(self._L.evs_stream_wait_value(main.cuda_stream, self.sig[sl][0], self._use_of(i) & 0xffffffff))
                 else:
                     main.wait_event(self.copied[sl])
                 yield self._views(sl, i)
                 if self.sig:                              # (behind whatever the caller queued on its stream for this batch)
-                    self._L.evs_stream_write_value(main.cuda_stream, self.sig[sl][1], self._use_of(i) & 0xffffffff)
+                    self._chk(self._L.evs_stream_write_value(main.cuda_stream, self.sig[sl][1], self._use_of(i) & 0xffffffff))
                 else:
                     self.used[sl].record(main)
+                    self.recorded[sl] = True
         finally:
-            if self.sig:   # a pass left early: every slot issued counts as consumed (nobody waits for a hand-over that never comes)
-                for sl in range(self.depth):
-                    self._L.evs_stream_write_value(main.cuda_stream, self.sig[sl][1], self.uses[sl] & 0xffffffff)
+            # a pass left early: every slot issued counts as consumed behind what the caller has queued so far (nobody waits for a
+            # hand-over that never comes, and the next pass's copies wait for the launches of the batch the caller broke out of)
+            for sl in range(self.depth):
+                if self.sig:
+                    self._chk(self._L.evs_stream_write_value(main.cuda_stream, self.sig[sl][1], self.uses[sl] & 0xffffffff))
+                else:
+                    self.used[sl].record(main)
+                    self.recorded[sl] = True
 
     def _use_of(self, i):
         """the use count of slot i % depth when batch i of the current pass was issued"""

@@ -133,3 +133,63 @@ def test_file_tier_reader_pool_reads_the_reference_file_format(tmp_path):
         E.FileTier([paths[0], str(tmp_path / "missing.bin")], 144, 0)
     with pytest.raises(E.EvsError):
         E.FileTier(paths, 100, 0)   # not a whole number of rows
+
+
+def test_deferred_rows_see_keyword_and_nested_arguments_and_pool_entries_know_when_they_are_free():
+    """CPU side of the deferred default (dlrm_ops.py): the argument walk of _DeferredRow.__torch_function__ (positional,
+    keyword, nested lists / tuples / dicts) and the three "free again" conditions of a pool entry (the handed-out list died,
+    no row escaped it, no view of the buffer is alive) -- the classes run on CPU tensors; the launches need a GPU."""
+    import torch
+    import evstore_dlrm_amd  # noqa: F401
+    from evstore_dlrm_amd import dlrm_ops as D
+
+    class Count:
+        def __init__(self):
+            self.n = 0
+
+        def materialize(self):
+            self.n += 1
+
+    def rows(st, n=3):
+        out = []
+        for v in torch.zeros(n, 4, 2).unbind(0):
+            r = v.as_subclass(D._DeferredRow)
+            r._evs_state = st
+            out.append(r)
+        return out
+
+    for call in (lambda r: torch.cat(r), lambda r: torch.cat(tensors=r), lambda r: torch.stack(tensors=r, dim=1),
+                 lambda r: torch.cat(tensors=tuple(r)), lambda r: torch.einsum("ij,ij->i", [r[0], r[1]]),
+                 lambda r: torch.add(r[0], other=r[1]), lambda r: r[0] + 1, lambda r: r[2].sum()):
+        st = Count()
+        out = call(rows(st))
+        assert st.n >= 1, call
+        assert type(out) is not D._DeferredRow or True
+    st = Count()
+    r = rows(st)
+    assert r[0].shape == (4, 2) and r[0].dtype == torch.float32 and r[0].size(0) == 4 and r[0].is_contiguous() and st.n == 0
+    D._touch({"a": [(r[0],)], "b": 3}, D._DeferredRow)
+    assert st.n == 1
+
+    e = D._PoolEntry(3, 4, 2, "cpu")
+    assert e.free()
+    ly = e.hand_out()
+    assert not e.free()
+    keep = ly[1]
+    del ly
+    assert e.out is None and not e.free()          # the list died, one of its rows escaped
+    del keep
+    assert e.free()
+    ly = e.hand_out()
+    with torch._C.DisableTorchFunctionSubclass():
+        view = ly[2][1:3]
+    del ly
+    assert not e.free()                            # a view of the buffer is alive
+    del view
+    assert e.free()
+
+    t = torch.zeros(3)
+    assert D._version_of(t) == t._version
+    with torch.inference_mode():
+        u = torch.zeros(3)
+    assert D._version_of(u) is None
