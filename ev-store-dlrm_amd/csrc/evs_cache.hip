@@ -28,6 +28,7 @@
 #include <mutex>
 #include <vector>
 #include <stdlib.h>
+#include <string.h>
 
 #ifndef EVS_X_EXACT_STOP
 #define EVS_X_EXACT_STOP 0
@@ -966,6 +967,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         bool hint_tomb = false;
         int e = -1;
         unsigned sa_w = 0u, sa_tag1 = 0u;
+        int sa_way = -1;
         if (args.sa.tags) {   // set-associative policy: one line, the priority inside the word
             unsigned set = 0u;
             sa_split(args.sa, sa_perm(args.sau, args.sau.row_base[hl] + (ok ? (unsigned)row : 0u)), set, sa_tag1);
@@ -974,8 +976,8 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
             int way;
             if (args.sa.ways == 8u) { sa_load<8>(args.sa, set, line); way = sa_find<8>(args.sa, line, sa_tag1, sa_w); }
             else { sa_load<0>(args.sa, set, line); way = sa_find<0>(args.sa, line, sa_tag1, sa_w); }
-            if (ok && way >= 0) e = (int)(set * args.sa.ways + (unsigned)way);
-            end_slot = set;
+            if (ok && way >= 0) e = (int)sa_entry(args.sa, set, (unsigned)way, sa_w);
+            end_slot = set; sa_way = way;
         } else {
             e = ok ? probe_ro(args.slots, args.mask, key, end_slot, args.tomb_parity == 1 ? kTomb : args.tomb_parity == 0 ? kTomb1 : kTomb, &hint_tomb) : -1;
             if (e == kPending) e = -1;
@@ -985,9 +987,8 @@ __global__ void __launch_bounds__(256) cache_batch_probe_gather_kernel(const Bat
         const int agg = __popc(hmask);
         if (args.sa.tags) {
             if (e >= 0 && sa_prio(sa_w) < agg) {
-                const unsigned es = (unsigned)e / args.sa.ways;
-                const int old = sa_prio(atomicMax(sa_ways_ptr(args.sa, es) + ((unsigned)e - es * args.sa.ways), sa_bump(sa_w, agg)));
-                if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
+                const int old = sa_raise(args.sa, sa_ways_ptr(args.sa, (unsigned)end_slot) + sa_way, sa_w, agg);
+                if (old >= 0) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
             }
         } else {
         // monotone max like update_agg_hit; the plain read first keeps hot entries (thousands of requests of
@@ -1108,6 +1109,7 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         bool ht1 = false, ht2 = false;   // sampled update: is the hinted slot a (re-usable) tombstone
         int e1 = -1, e2 = -1;
         unsigned w1 = 0u, w2 = 0u, tg1 = 0u, tg2 = 0u;
+        int y1 = -1, y2 = -1;
         bool c1_room = !c1_full;
         if (sa) {   // set-associative tiers: both tiers' ways of the key's set (a pair: ONE line) in one round trip; "C1 has room" = the key's C1 set has a free way
             const unsigned px = sa_perm(a1.sau, a1.sau.row_base[hl] + (ok ? (unsigned)row : 0u));
@@ -1116,7 +1118,6 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
             sa_split(a2.sa, px, s2, tg2);
             if (!ok) { s1 = 0u; s2 = 0u; }
             SaLine l1, l2;
-            int y1, y2;
             if (a1.sa.ways == 8u && a2.sa.ways == 8u) {   // (the reference's 1 : 2 pair: way counts known to the compiler)
                 sa_load<8>(a1.sa, s1, l1);
                 sa_load<8>(a2.sa, s2, l2);
@@ -1128,8 +1129,8 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
                 y1 = sa_find<0>(a1.sa, l1, tg1, w1); y2 = sa_find<0>(a2.sa, l2, tg2, w2);
                 c1_room = sa_has_free<0>(a1.sa, l1);
             }
-            if (ok && y1 >= 0) e1 = (int)(s1 * a1.sa.ways + (unsigned)y1);
-            else if (ok && y2 >= 0) e2 = (int)(s2 * a2.sa.ways + (unsigned)y2);
+            if (ok && y1 >= 0) e1 = (int)sa_entry(a1.sa, s1, (unsigned)y1, w1);
+            else if (ok && y2 >= 0) e2 = (int)sa_entry(a2.sa, s2, (unsigned)y2, w2);
             end1 = s1; end2 = s2;
         } else {
             e1 = ok ? probe_ro(a1.slots, a1.mask, key, end1, a1.tomb_parity == 1 ? kTomb : a1.tomb_parity == 0 ? kTomb1 : kTomb, &ht1) : -1;
@@ -1159,12 +1160,12 @@ __global__ void __launch_bounds__(256) cache_batch_probe2_kernel(const BatchArgs
         const int agg = __popc((unsigned)(half ? (hm >> 32) : hm));
         if (sa) {   // the priority rides in the key word: one atomicMax on it
             if (e1 >= 0 && sa_prio(w1) < agg) {
-                const int old = sa_prio(atomicMax(sa_ways_ptr(a1.sa, (unsigned)end1) + ((unsigned)e1 - (unsigned)end1 * a1.sa.ways), sa_bump(w1, agg)));
-                if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
+                const int old = sa_raise(a1.sa, sa_ways_ptr(a1.sa, (unsigned)end1) + y1, w1, agg);
+                if (old >= 0) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
             }
             if (e2 >= 0 && sa_prio(w2) < agg) {
-                const int old = sa_prio(atomicMax(sa_ways_ptr(a2.sa, (unsigned)end2) + ((unsigned)e2 - (unsigned)end2 * a2.sa.ways), sa_bump(w2, agg)));
-                if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
+                const int old = sa_raise(a2.sa, sa_ways_ptr(a2.sa, (unsigned)end2) + y2, w2, agg);
+                if (old >= 0) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
             }
         } else {
         if (e1 >= 0 && a1.a.eagg[e1] < agg) {
@@ -2005,7 +2006,6 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
     __builtin_amdgcn_sched_barrier(0);
     const SaGeom &g = args.sa;
     const unsigned cur = sa_cur_stamp(g, args.stamp);
-    const unsigned neww = sa_word(g, tag1, cur, agg);
     unsigned w[NW];
 #pragma unroll
     for (int j = 0; j < NW; j++) w[j] = sa_way_word(line, j);
@@ -2026,15 +2026,16 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
             best = cand ? j : best; bp = cand ? pj : bp; bw = cand ? w[j] : bw;
         }
         if (dup >= 0) {   // another copy of the key got here first: its priority is the maximum over the copies
-            if (sa_prio(dw) < agg) {
-                const int old = sa_prio(atomicMax(&tags[dup], sa_bump(dw, agg)));
-                if (old < agg) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
+            if (sa_prio(dw) < agg) {   // (a CAS, not a maximum: see sa_raise)
+                const int old = sa_raise(g, &tags[dup], dw, agg);
+                if (old >= 0) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
             }
             done = true;
         } else if (best < 0) {
             done = true;   // every way of the set was filled in this batch: the key is not kept
         } else {
-            const unsigned prev = atomicCAS(&tags[best], bw, neww);
+            // (two-copy arena: the new row goes to the copy the victim's word does NOT name, and the word says so)
+            const unsigned prev = atomicCAS(&tags[best], bw, sa_word(g, tag1, cur, agg, sa_sel(g, bw) ^ 1u));
             if (prev == bw) { way = best; old_prio = bp; old_word = bw; done = true; }
             else {
 #pragma unroll
@@ -2046,7 +2047,7 @@ __device__ __forceinline__ void sa_insert_one(const BatchArgs &args, const unsig
     if (old_prio >= 0) { atomicSub(&s_delta[old_prio], 1); atomicAdd(&s_stat[1], 1); }
     else atomicAdd(&s_stat[0], 1);
     atomicAdd(&s_delta[agg], 1);
-    unsigned char *drow = args.a.arena + ((long long)set * g.ways + way) * args.row_bytes;
+    unsigned char *drow = args.a.arena + (long long)sa_entry(g, set, (unsigned)way, (sa_sel(g, old_word) ^ 1u) << kSaSelShift) * args.row_bytes;
     if constexpr (PIECES > 0) {
         if constexpr (PIECES > 0) reinterpret_cast<NU *>(drow)[0] = r0;
         if constexpr (PIECES > 1) reinterpret_cast<NU *>(drow)[1] = r1;
@@ -2562,6 +2563,8 @@ struct evs_cache {
     evs::SaGeom sa{};
     evs::SaUniverse sau{};
     struct SaShared { unsigned *tags = nullptr; size_t bytes = 0; int refs = 0; } *sa_mem = nullptr;
+    unsigned char *sa_arena = nullptr;   // two-copy arena of a dual geometry (a.arena points here then)
+    int inline_mode = -1;          // the update inside the probe launch (evs_fused_rf.hip): -1 not decided (EVS_CACHE_INLINE, default on), 0 / 1
 };
 
 // ---- set-associative geometry (host) ----
@@ -2582,7 +2585,7 @@ bool sa_make_universe(const long long *rows1, const long long *rows2, int T, evs
     u.n_tables = T;
     return true;
 }
-bool sa_make_geom(evs::SaGeom &g, unsigned nset, unsigned ways, unsigned w_off, unsigned line_words, const evs::SaUniverse &u, unsigned sub_shift = 0) {
+bool sa_make_geom(evs::SaGeom &g, unsigned nset, unsigned ways, unsigned w_off, unsigned line_words, const evs::SaUniverse &u, unsigned sub_shift = 0, unsigned dual = 0) {
     if (nset < 1 || ways < 1 || ways > (unsigned)evs::kSaMaxWays || (w_off & 3u) || (sub_shift && (ways & 3u))) return false;
     g.tags = nullptr; g.nset = nset; g.ways = ways; g.w_off = w_off; g.line_words = line_words; g.sub_shift = sub_shift;
     unsigned l = 0;
@@ -2593,7 +2596,9 @@ bool sa_make_geom(evs::SaGeom &g, unsigned nset, unsigned ways, unsigned w_off, 
     unsigned tb = 1;
     while (tb < 32 && (max_tag1 >> tb)) tb++;
     if (tb > 22) return false;   // (at least 4 stamp bits)
+    if (tb > 21) dual = 0;       // (... also beside the copy-select bit: such a tier keeps one arena row per way and the two-launch update)
     g.tag_bits = tb; g.tag_mask = (1u << tb) - 1u;
+    g.dual = dual; g.stamp_mask = (1u << (26u - dual - tb)) - 1u;
     return true;
 }
 unsigned sa_single_ways() {
@@ -2607,7 +2612,9 @@ bool sa_single_feasible(const evs_cache *c, evs::SaUniverse *u_out = nullptr, ev
     const unsigned ways = sa_single_ways();
     if (!c->has_backing || c->host.cap < (long long)ways) return false;
     if (!sa_make_universe(c->backing_rows, nullptr, c->host.n_tables, u)) return false;
-    if (!sa_make_geom(g, (unsigned)(c->host.cap / ways), ways, 0, ways, u)) return false;
+    // a tier alone keeps two arena rows per way (evs_hash.h: the two-copy arena; EVS_SA_DUAL=0: one, developer A/B)
+    static const unsigned dual_on = (getenv("EVS_SA_DUAL") && getenv("EVS_SA_DUAL")[0] == '0') ? 0u : 1u;
+    if (!sa_make_geom(g, (unsigned)(c->host.cap / ways), ways, 0, ways, u, 0, dual_on)) return false;
     if (u_out) *u_out = u;
     if (g_out) *g_out = g;
     return true;
@@ -2638,6 +2645,16 @@ int sa_alloc(evs_cache *c, evs_cache *partner, hipStream_t st) {   // the set re
     const size_t alloc = std::max<size_t>(m->bytes, (size_t)pad_mb << 20);
     if (hipMalloc(&m->tags, alloc) != hipSuccess) { (void)hipGetLastError(); delete m; return EVS_ENOMEM; }
     if (hipMemsetAsync(m->tags, 0, m->bytes, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(m->tags); delete m; return EVS_EHIP; }
+    for (evs_cache *t : {c, partner}) {   // two-copy arenas (nothing is resident yet: the batched path starts here)
+        if (!t || !t->sa.dual) continue;
+        const size_t ab = ((size_t)t->sa.nset << t->sa.sub_shift) * t->sa.ways * 2u * (size_t)t->host.row_bytes;
+        if (hipMalloc(&t->sa_arena, ab) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(m->tags); delete m;
+            if (c->sa_arena) { (void)hipFree(c->sa_arena); c->sa_arena = nullptr; }
+            return EVS_ENOMEM;
+        }
+        t->a.arena = t->sa_arena;
+    }
     m->refs = partner ? 2 : 1;
     c->sa_mem = m; c->sa.tags = m->tags;
     if (partner) { partner->sa_mem = m; partner->sa.tags = m->tags; }
@@ -2663,7 +2680,7 @@ unsigned long long sa_key_of_host(const evs::SaUniverse &u, const evs::SaGeom &g
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
-    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage, c->evicted_keys, c->vict_keys, c->vict_cnt, c->route_filter};
+    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage, c->evicted_keys, c->vict_keys, c->vict_cnt, c->route_filter, c->sa_arena};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->host_tomb) (void)hipHostFree(c->host_tomb);
@@ -3347,8 +3364,12 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         // a reduced-precision tier (the reference's one-layer 16 / 8 / 4-bit builds): the probe folded into ITS consumer too
         static const bool foldq_on = !(getenv("EVS_CACHE_FOLDQ") && getenv("EVS_CACHE_FOLDQ")[0] == '0');
         const bool foldq = fold_on && foldq_on && c->host.codec != 32 && R && !out && c->sa.ways == 8 && c->sa.sub_shift == 0 && small_tabs &&
-                           cap < (1ll << 30) && fused_probe_codec_supported(B, T, c->host.dim, c->host.codec);
-        const bool fold = (fold_on && a.row_ids && R && !out && c->sa.ways == 8) || foldq;   // (the folded probes are compiled for 8-way sets)
+                           (cap << c->sa.dual) < (1ll << 30) && fused_probe_codec_supported(B, T, c->host.dim, c->host.codec);
+        const bool fold = (fold_on && a.row_ids && R && !out && c->sa.ways == 8 && (cap << c->sa.dual) < (1ll << 30)) || foldq;   // (the folded probes are compiled for 8-way sets; tile entries carry an arena row in 30 bits)
+        // the update inside the probe launch too: fp32 rows, the folded fp32 launch, a two-copy arena (EVS_CACHE_INLINE=0: every
+        // batch updated by a launch of its own behind it -- the round-4 chain, strict snapshot flags)
+        if (c->inline_mode < 0) c->inline_mode = (getenv("EVS_CACHE_INLINE") && getenv("EVS_CACHE_INLINE")[0] == '0') ? 0 : 1;
+        const bool inl = fold && !foldq && c->inline_mode == 1 && c->sa.dual && c->host.codec == 32 && (c->host.row_bytes & 15) == 0;
         if (fold) {
             ProbeArgs pa;
             pa.slots = nullptr; pa.mask = 0; pa.reusable_tomb = kTomb; pa.eagg = nullptr;
@@ -3358,9 +3379,22 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
             pa.sa = c->sa; pa.sau = c->sau;
             a.list_cap = 16 * T;
             a.g1 = (int)((B + 15) / 16);
+            if (inl) {
+                pa.miss_rec = nullptr; pa.list_cnt = nullptr;
+                pa.pend_stamp = (unsigned)a.stamp & c->sa.stamp_mask;
+                pa.arena_w = c->a.arena; pa.row_bytes = c->host.row_bytes; pa.part2 = a.part2;
+                static const int xf = getenv("EVS_X_INL") ? atoi(getenv("EVS_X_INL")) : 0;
+                pa.xflags = xf;
+            }
             const int rc = fused_probe_interact(B, T, c->host.dim, x, x_stride, pa, c->a.arena,
                                                 reinterpret_cast<const void *const *>(c->backing), c->backing_rows, itself, R, st, c->host.codec);
             if (rc) return rc;
+            if (inl) {   // nothing is left to do behind the launch
+                c->pending_batches++; c->pending_requests += B;
+                if (c->pending_batches >= kCloseEvery) sampled_close_pending(c, 0, st);
+                EVS_HIP_CHECK(hipGetLastError());
+                return EVS_OK;
+            }
         } else {
             hipLaunchKernelGGL(cache_batch_probe_gather_kernel, dim3((unsigned)a.g1), dim3(256), 0, st, a);
             const int rc = consumers(); if (rc) return rc;
@@ -3652,6 +3686,13 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     // kernel per tier, lazy closes) over set lines instead of hashes; no tombstones, no housekeeping
     const bool sa2 = resolved_batch_policy(c1) == 2 && resolved_batch_policy(c2) == 2;
     const bool sampled2 = sa2 || (resolved_batch_policy(c1) == 1 && resolved_batch_policy(c2) == 1);
+    // the pair's probe permutes a key ONCE, with C1's universe, for both tiers (a1.sau); C2's inserts, evictions and alt-key
+    // look-ups use its own.  Tiers that did not start out together (each built its universe alone) must have built the same one
+    // -- same row bases, same width -- or C2's (set, tag) would not map back to the key: refused instead of served wrong.
+    if (sa2 && memcmp(&c1->sau, &c2->sau, sizeof(SaUniverse)) != 0) {
+        set_error("evs_cache_lookup_batch_c1c2: the tiers were built over different key universes (table row counts differ); make both over the same tables");
+        return EVS_ESTATE;
+    }
     constexpr unsigned kRouteWords = 1u << 20;
     static const bool route_on_env = !(getenv("EVS_CACHE_ROUTEFILTER") && getenv("EVS_CACHE_ROUTEFILTER")[0] == '0');
     const bool route_on = route_on_env || sa2;   // (the set-associative update has no cross-tier hash look-up to fall back on)
@@ -3706,7 +3747,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     }
     static const bool fold2_on = !(getenv("EVS_CACHE_FOLD2") && getenv("EVS_CACHE_FOLD2")[0] == '0');
     const bool fold2 = fold2_on && sampled2 && !host2 && a1.miss_rec && R && !out && B <= 65536 && T <= 32 &&
-                       (!sa2 || (c1->sa.ways == 8 && c2->sa.ways == 8)) &&   // (the folded probe is compiled for 8-way sets)
+                       (!sa2 || (c1->sa.ways == 8 && c2->sa.ways == 8 && !c1->sa.dual && !c2->sa.dual)) &&   // (the folded probe is compiled for 8-way sets with one arena row per way)
                        mixed84_supported(T, c1->host.dim, c1->host.codec, c2->host.codec);
     if (fold2) {
         Probe2Args pa;

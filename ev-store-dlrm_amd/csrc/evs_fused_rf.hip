@@ -86,6 +86,9 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
     __shared__ unsigned long long s_feat_base[32];                        // per feature: first row / bytes between rows -- read per
     __shared__ unsigned s_feat_scale[32];                                 // load instead of living in 12 VGPRs per lane
     __shared__ unsigned s_sa_base[PROBE ? 32 : 1];                        // PROBE, set-associative cache: dense row number of row 0 of feature f's table
+    // PROBE, the update folded in as well (ProbeArgs::arena_w): totals of the inserts this block makes
+    __shared__ int s_udelta[PROBE ? kMaxBuckets : 1];
+    __shared__ int s_ustat[PROBE ? 2 : 1];
     __shared__ const int64_t *s_tile_o[CHECK ? 32 : 1];                   // CHECK: offsets arrays, their readable entries, nnz
     __shared__ int64_t s_tile_ol[CHECK ? 32 : 1], s_tile_nz[CHECK ? 32 : 1];
     constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
@@ -515,11 +518,24 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         if (threadIdx.x < 2) s_psum[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_nlist = 0;
         __syncthreads();
-        int pe[2], prow[2], pprio[2];
+        int pe[2], prow[2], pprio[2], pway[2];
         unsigned phint[2], ptag[2];
         bool pok[2], ptomb[2], pact[2];
         unsigned long long pkey[2], phome[2], pw0[2];
         const int64_t bs = blk_first + (threadIdx.x & 15);
+        // ---- the policy update folded in too (round 5; ProbeArgs::arena_w != nullptr: a set-associative fp32 tier alone with a
+        // two-copy arena, evs_hash.h).  A thread that misses a key claims a way of the key's set right here -- it holds the
+        // set's ways already: rank, ONE CAS, beside the priority raises -- and the lanes that gather the key's row from its
+        // table for the interaction store it into the arena on the way (s_idx's second tile buffer carries the arena row to
+        // the consume loop).  No miss lists, no update launch, no second read of anything.  What makes it legal inside the
+        // launch that is still probing: the new word carries THIS batch's stamp (= pa.pend_stamp: a miss for every prober of
+        // this launch -- the row may not be there yet) and names the arena copy the retired word does not, so a prober that
+        // read the old word reads a row nobody is writing.
+        const bool ins = pa.arena_w != nullptr;   // block-uniform
+        if (ins) {
+            for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_udelta[i] = 0;
+            if (threadIdx.x < 2) s_ustat[threadIdx.x] = 0;
+        }
         // the thread's two keys side by side, one round trip per step for both: request rows, home slots, priorities
         // (a key whose home slot holds neither it nor nothing walks its chain with probe_ro: rare at load <= 0.25)
 #pragma unroll
@@ -529,6 +545,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             const int *rp = pact[h] ? pa.requests + bs * (int64_t)T + (f - 1) : reinterpret_cast<const int *>(dummy_i);
             prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
         }
+        unsigned lw[2][8];   // the two keys' set ways (kept for the claim of a missed key)
         const bool sa = pa.sa.tags != nullptr;   // set-associative cache (evs_hash.h): one line per key, the priority inside the way word
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -554,11 +571,14 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 unsigned w;
-                const int way = sa_find<8>(pa.sa, line[h], ptag[h], w);
+                const int way = sa_find<8>(pa.sa, line[h], ptag[h], w, pa.pend_stamp);
                 const bool found = pok[h] && way >= 0;
-                pe[h] = found ? (int)(pset[h] * 8u + (unsigned)way) : -1;
+                pe[h] = found ? (int)sa_entry(pa.sa, pset[h], (unsigned)way, w) : -1;
+                pway[h] = way;
                 pprio[h] = found ? sa_prio(w) : 0x7fffffff;
                 pw0[h] = w; phint[h] = pset[h]; ptomb[h] = false;
+#pragma unroll
+                for (int j = 0; j < 8; j++) lw[h][j] = sa_way_word(line[h], j);
                 if (found) atomicAdd(&s_agg[threadIdx.x & 15], 1);
             }
         } else {
@@ -594,24 +614,38 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         }
         __syncthreads();
         const int agg = s_agg[threadIdx.x & 15];
+        // a missed key's claim: duplicate / victim / the CAS sent here, looked at behind the raises below (one round trip for both)
+        int uwon[2] = {-1, -1};
+        unsigned uprev[2] = {0u, 0u};
+        SaPick upk[2] = {{-1, 0, -1, 0u, 0u}, {-1, 0, -1, 0u, 0u}};
+        bool uwait[2] = {false, false};
+        if (ins) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (pok[h] && pe[h] < 0 && !(pa.xflags & 2)) uwait[h] = sa_claim_issue(pa.sa, pa.pend_stamp, phint[h], ptag[h], agg, lw[h], upk[h], uprev[h], s_udelta);
+        }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
             // monotone max like update_agg_hit; the plain read first keeps hot entries from serialising on one address
             if (pe[h] >= 0 && pprio[h] < agg) {
                 int old;
-                if (sa) old = sa_prio(atomicMax(sa_ways_ptr(pa.sa, phint[h]) + ((unsigned)pe[h] & 7u), sa_bump((unsigned)pw0[h], agg)));
-                else old = atomicMax(&pa.eagg[pe[h]], agg);
-                if (old < agg) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
+                if (sa) old = sa_raise(pa.sa, sa_ways_ptr(pa.sa, phint[h]) + pway[h], (unsigned)pw0[h], agg);
+                else { old = atomicMax(&pa.eagg[pe[h]], agg); old = old < agg ? old : -1; }
+                if (old >= 0) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
             }
             int v = -1;
             if (f == 0) v = bs < blk_end ? (int)bs : -1;                 // x: the sample number
             else if (pact[h]) v = pe[h] >= 0 ? (int)(0x40000000u | (unsigned)pe[h]) : (pok[h] ? prow[h] : -1);
             s_idx[(int)threadIdx.x + 256 * h] = v;
+            if (ins) {   // where the gathered row of a missed key goes (-1: nowhere)
+                if (uwait[h]) uwon[h] = sa_claim_finish(pa.sa, pa.pend_stamp, phint[h], ptag[h], agg, lw[h], upk[h], uprev[h], s_udelta, s_ustat);
+                s_idx[512 + (int)threadIdx.x + 256 * h] = uwon[h];
+            }
             if (pact[h]) {
                 const int64_t m = bs * (int64_t)T + (f - 1);
                 if (pa.hit) pa.hit[m] = pe[h] >= 0;
-                if (pok[h] && pe[h] < 0) {
+                if (pa.miss_rec != nullptr && pok[h] && pe[h] < 0) {
                     const int at = atomicAdd(&s_nlist, 1);
                     pa.miss_rec[(int64_t)blockIdx.x * pa.list_cap + at] =
                         make_uint4((unsigned)prow[h], (unsigned)(f - 1) | ((unsigned)agg << 8) | (ptomb[h] ? 0x10000u : 0u), phint[h], sa ? ptag[h] : (unsigned)m);
@@ -625,7 +659,12 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             const int v = i <= T ? s_pdelta[i] : i == 38 ? s_psum[0] : i == 39 ? s_psum[1] : 0;
             if (v) atomicAdd(&pa.part1[(blockIdx.x % 32) * 40 + i], v);
         }
-        if (threadIdx.x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
+        if (ins && threadIdx.x < 40) {   // the inserts' totals, as the update kernels leave them (folded by the cache's close)
+            const int i = threadIdx.x;
+            const int v = i <= T ? s_udelta[i] : i == 33 ? s_ustat[0] : i == 34 ? s_ustat[1] : 0;
+            if (v) atomicAdd(&pa.part2[(blockIdx.x % 32) * 40 + i], v);
+        }
+        if (pa.list_cnt != nullptr && threadIdx.x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
     } else {
         tile_load(0);
         tile_store(0);
@@ -656,12 +695,23 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
     // (16 waves per CU start in step: every instruction in front of the first load is paid by all of them at once)
     fill_stage();
     fill_flush();
+    const bool ins_blk = PROBE && args.probe.arena_w != nullptr && !(args.probe.xflags & 1);   // block-uniform: missed keys' rows go into the cache arena on the way
 #pragma unroll
     for (int u = 0; u < D; u++) {
         const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;   // wave-uniform
         // the image of sample u: what the row DMA of the LDS loop would have left in the slot
 #pragma unroll
         for (int j = 0; j < NJ; j++) *reinterpret_cast<f32x4 *>(my_lds + j * 1024 + lane * 16) = ring[u][j];
+        if constexpr (PROBE) {
+            if (ins_blk) {   // the rows of the ways this block claimed: from the registers that gathered them into the arena
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    const int e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(s_idx) + 2048 + idx_lds[j] + 16 * u);
+                    if (e >= 0)
+                        *reinterpret_cast<f32x4 *>(args.probe.arena_w + (unsigned long long)(unsigned)e * (unsigned)row_bytes + (unsigned)dma_piece16) = ring[u][j];
+                }
+            }
+        }
         float4 a[NR][CQ > 0 ? CQ : 1];
         float ar[NR][REM > 0 ? REM : 1];
 #pragma unroll
@@ -962,3 +1012,17 @@ bool launch_rf(const FusedArgs &a, hipStream_t st) {
 }
 
 }  // namespace evs
+
+#ifdef EVS_X_LOG
+// developer tool (tools/dbg_inline.py): the event log of the folded update -- (type, word address, old word, new word)
+extern "C" __attribute__((visibility("default"))) long long evs_x_log_fetch(unsigned long long *out, long long max_events, int reset) {
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(evs::g_xlog_n), 4) != hipSuccess) return -2;
+    long long m = n < (1u << 18) ? n : (1u << 18);
+    if (m > max_events) m = max_events;
+    if (out && m && hipMemcpyFromSymbol(out, HIP_SYMBOL(evs::g_xlog), (size_t)m * 32) != hipSuccess) return -3;
+    if (reset) { n = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(evs::g_xlog_n), &n, 4) != hipSuccess) return -4; }
+    return m;
+}
+#endif

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
         if constexpr (PAIR4) s_lut2[threadIdx.x] = make_float2(u4_value(threadIdx.x >> 4), u4_value(threadIdx.x & 15u));
         __syncthreads();
         const int64_t bs = blk_first + (threadIdx.x & 15);
-        int prow[2], pe[2], pprio[2];
+        int prow[2], pe[2], pprio[2], pway[2];
         bool pact[2], pok[2];
         unsigned pset[2], ptag[2], pw0[2];
 #pragma unroll
@@ -234,7 +234,8 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
             unsigned w;
             const int way = sa_find<8>(pa.sa, line[h], ptag[h], w);
             const bool found = pok[h] && way >= 0;
-            pe[h] = found ? (int)(pset[h] * 8u + (unsigned)way) : -1;
+            pe[h] = found ? (int)sa_entry(pa.sa, pset[h], (unsigned)way, w) : -1;
+            pway[h] = way;
             pprio[h] = found ? sa_prio(w) : 0x7fffffff;
             pw0[h] = w;
             if (found) atomicAdd(&s_agg[threadIdx.x & 15], 1);
@@ -245,8 +246,8 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
             if (pe[h] >= 0 && pprio[h] < agg) {   // monotone max like update_agg_hit
-                const int old = sa_prio(atomicMax(sa_ways_ptr(pa.sa, pset[h]) + ((unsigned)pe[h] & 7u), sa_bump(pw0[h], agg)));
-                if (old < agg) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
+                const int old = sa_raise(pa.sa, sa_ways_ptr(pa.sa, pset[h]) + pway[h], pw0[h], agg);
+                if (old >= 0) { atomicSub(&s_pdelta[old], 1); atomicAdd(&s_pdelta[agg], 1); }
             }
             int v = -1;
             if (f == 0) v = bs < blk_end ? (int)bs : -1;                 // x: the sample number

@@ -79,6 +79,13 @@ __device__ __forceinline__ int probe_ro(const unsigned long long *slots, unsigne
 //                  still searches 8 ways.
 // A probe is one line, an insert is that line + one CAS + the row; nothing ever moves: no tombstones, sweeps, rebuilds.
 // The victim of a new key is the lowest priority of ITS OWN set (free ways first), ways filled in the running batch excepted.
+//   two-copy arena (round 5, `dual` = 1: a tier alone): every way owns TWO arena rows and bit 25 of its word (`sel`, taken from
+//                  the stamp field) says which one is live.  A replacement writes the new row into the OTHER copy and flips
+//                  the bit with the CAS that installs the word, so the row a reader found through the old word is never
+//                  overwritten by the replacement that retires it -- what lets a batch's policy update run INSIDE the launch
+//                  that is still probing (evs_fused_rf.hip: the thread that misses a key inserts it): a prober that read the
+//                  old word reads the old copy, intact; one that reads the new word sees the running batch's stamp, treats
+//                  the way as a miss (the row may not be there yet) and serves the key from its table.
 constexpr int kSaMaxWays = 16;          // per tier (4 x 16-byte pieces)
 constexpr int kSaPrioShift = 26;
 constexpr unsigned kSaLowMask = (1u << kSaPrioShift) - 1u;
@@ -99,7 +106,11 @@ struct SaGeom {                         // one tier's view of the set records
     unsigned tag_bits;
     unsigned line_words, w_off, ways;
     unsigned sub_shift;                 // log2 of the sub-sets per record (0: one)
+    unsigned dual;                      // 1: two arena rows per way, bit 25 of the word selects the live one (see above); else 0
+    unsigned stamp_mask;                // (1 << stamp bits) - 1, stamp bits = 26 - dual - tag_bits
 };
+constexpr unsigned kSaSelShift = 25;
+constexpr unsigned kSaNoStamp = 0xffffffffu;   // "no update in flight" (a stamp field never holds it)
 // gid = row_base[table] + row.  (The kernels keep row_base in an LDS table: a per-lane index into the kernel arguments is a
 // vector-memory round trip in front of the set loads.)
 __device__ __forceinline__ unsigned sa_perm(const SaUniverse &u, unsigned gid) {
@@ -133,13 +144,42 @@ __device__ __forceinline__ void sa_split(const SaGeom &g, unsigned x, unsigned &
     sa_divmod(g, x, set, q);
     sa_place(g, set, q, es, tag1);
 }
-__device__ __forceinline__ unsigned sa_word(const SaGeom &g, unsigned tag1, unsigned stamp, int prio) {
-    return tag1 | ((stamp << g.tag_bits) & kSaLowMask) | ((unsigned)prio << kSaPrioShift);
+// sel: which arena copy the word's row lives in (dual geometries; always 0 otherwise)
+__device__ __forceinline__ unsigned sa_word(const SaGeom &g, unsigned tag1, unsigned stamp, int prio, unsigned sel = 0u) {
+    return tag1 | ((stamp & g.stamp_mask) << g.tag_bits) | ((sel & g.dual) << kSaSelShift) | ((unsigned)prio << kSaPrioShift);
 }
 __device__ __forceinline__ int sa_prio(unsigned w) { return (int)(w >> kSaPrioShift); }
-__device__ __forceinline__ unsigned sa_stamp(const SaGeom &g, unsigned w) { return (w & kSaLowMask) >> g.tag_bits; }
-__device__ __forceinline__ unsigned sa_cur_stamp(const SaGeom &g, int stamp) { return ((unsigned)stamp << g.tag_bits & kSaLowMask) >> g.tag_bits; }
+__device__ __forceinline__ unsigned sa_stamp(const SaGeom &g, unsigned w) { return (w >> g.tag_bits) & g.stamp_mask; }
+__device__ __forceinline__ unsigned sa_cur_stamp(const SaGeom &g, int stamp) { return (unsigned)stamp & g.stamp_mask; }
 __device__ __forceinline__ unsigned sa_bump(unsigned w, int agg) { return (w & kSaLowMask) | ((unsigned)agg << kSaPrioShift); }
+__device__ __forceinline__ unsigned sa_sel(const SaGeom &g, unsigned w) { return (w >> kSaSelShift) & g.dual; }
+// arena row of (effective set, way) as the word w describes it
+__device__ __forceinline__ unsigned sa_entry(const SaGeom &g, unsigned es, unsigned way, unsigned w) {
+    return ((es * g.ways + way) << g.dual) | sa_sel(g, w);
+}
+// raise the priority of the way that held word w when the prober looked, to agg: a compare-and-swap, not a maximum -- a
+// replacement that got there first must not be undone by the bumped OLD word winning a numeric comparison (with the update
+// of the batch before running in the same launch that is a live race; without it the CAS succeeds first time).
+// Returns the priority the raise replaced, or -1 when it changed nothing (the way was raised past agg, or replaced).
+#ifdef EVS_X_LOG
+static __device__ unsigned long long g_xlog[1 << 20];
+static __device__ unsigned g_xlog_n;
+__device__ __forceinline__ void xlog(unsigned type, unsigned *wp, unsigned oldw, unsigned neww) {
+    const unsigned i = atomicAdd(&g_xlog_n, 1u);
+    if (i < (1u << 18)) { g_xlog[4 * i] = type; g_xlog[4 * i + 1] = (unsigned long long)wp; g_xlog[4 * i + 2] = oldw; g_xlog[4 * i + 3] = neww; }
+}
+#else
+__device__ __forceinline__ void xlog(unsigned, unsigned *, unsigned, unsigned) {}
+#endif
+__device__ __forceinline__ int sa_raise(const SaGeom &g, unsigned *wp, unsigned w, int agg) {
+    for (int spin = 0; spin < 64; spin++) {
+        const unsigned prev = atomicCAS(wp, w, sa_bump(w, agg));
+        if (prev == w) { xlog(1, wp, w, sa_bump(w, agg)); return sa_prio(w); }
+        if (((prev ^ w) & kSaLowMask) != 0u || sa_prio(prev) >= agg) return -1;   // another key's word, or high enough already
+        w = prev;   // the same key, raised by somebody else but still below agg
+    }
+    return -1;
+}
 // a tier's ways of one set: 16-byte loads that all go out before the first one is looked at.
 // W (template): the tier's way count when the caller knows it at compile time (8 or 16: the one-tier form, the 8 + 16 pair) --
 // exactly W / 4 loads and W-way loops; W = 0: any geometry (kSaMaxWays-way loops masked by g.ways; the pieces past the tier's
@@ -177,15 +217,16 @@ __device__ __forceinline__ bool sa_has_free(const SaGeom &g, const SaLine &l) {
     for (int j = 0; j < (W > 0 ? W : kSaMaxWays); j++) f = f || ((W > 0 || (unsigned)j < g.ways) && sa_way_word(l, j) == 0u);
     return f;
 }
-// way holding tag1 (-1: none) and its word
+// way holding tag1 (-1: none) and its word.  pend: the stamp of an update in flight (kSaNoStamp: none) -- a way it has
+// filled is not there yet for this reader
 template <int W = 0>
-__device__ __forceinline__ int sa_find(const SaGeom &g, const SaLine &l, unsigned tag1, unsigned &word) {
+__device__ __forceinline__ int sa_find(const SaGeom &g, const SaLine &l, unsigned tag1, unsigned &word, unsigned pend = kSaNoStamp) {
     int way = -1;
     word = 0u;
 #pragma unroll
     for (int j = 0; j < (W > 0 ? W : kSaMaxWays); j++) {
         const unsigned w = sa_way_word(l, j);
-        const bool m = (W > 0 || (unsigned)j < g.ways) && (w & g.tag_mask) == tag1;   // (tag1 >= 1: an empty way never matches)
+        const bool m = (W > 0 || (unsigned)j < g.ways) && (w & g.tag_mask) == tag1 && sa_stamp(g, w) != pend;   // (tag1 >= 1: an empty way never matches)
         way = m ? j : way;
         word = m ? w : word;
     }
@@ -201,7 +242,7 @@ __device__ __forceinline__ int sa_lookup(const SaUniverse &u, const SaGeom &g, i
     if constexpr (W > 0) { sa_load<W>(g, set, l); way = sa_find<W>(g, l, tag1, w); }
     else if (g.ways == 8u) { sa_load<8>(g, set, l); way = sa_find<8>(g, l, tag1, w); }
     else { sa_load<0>(g, set, l); way = sa_find<0>(g, l, tag1, w); }
-    return way >= 0 ? (int)(set * g.ways + (unsigned)way) : -1;
+    return way >= 0 ? (int)sa_entry(g, set, (unsigned)way, w) : -1;
 }
 // the key (table_1based << 32 | row) a way word of set `set` stands for
 __device__ __forceinline__ unsigned long long sa_key_of(const SaUniverse &u, const SaGeom &g, unsigned es, unsigned w) {
@@ -281,7 +322,80 @@ struct ProbeArgs {
     int *part1;                           // replica rows of the hit / histogram totals
     int hint_shift, T;
     SaGeom sa; SaUniverse sau;            // set-associative form (sa.tags != nullptr): the set records instead of slots / eagg
+    // The policy update folded in too (round 5; a set-associative fp32 tier alone with a two-copy arena): arena_w != nullptr --
+    // a thread that misses a key claims a way of the key's set itself (stamp pend_stamp = this batch's) and the lanes that
+    // gather the key's row store it into the arena; miss_rec / list_cnt may then be NULL (no lists, no update launch).
+    // pend_stamp: ways carrying it are misses for this launch's probe (kSaNoStamp: none are).
+    unsigned pend_stamp = kSaNoStamp;
+    unsigned char *arena_w = nullptr; int row_bytes = 0;
+    int *part2 = nullptr;                 // replica rows of the inserts' totals (as the update kernels write them)
+    int xflags = 0;                       // developer A/B (timing only): 1 = no arena stores, 2 = no claims
 };
+
+// One missed key into its set (the per-record step of cache_batch_sa_list_kernel restated for callers that hold the source
+// row's address; 8-way sets): the set's ways, a duplicate folds its priority, else ONE CAS on the way of the lowest priority
+// (free ways first, lowest index among equals, ways filled with stamp `cur` excepted; a lost CAS refreshes that way from what
+// it returned and ranks again).  The new row belongs in the copy the victim's word does not name; the CALLER copies it (the
+// folded launch does that at its end).  s_delta: priority histogram moves; s_stat: [0] free ways taken, [1] evictions.
+// Split in two so that the first CAS can travel under other work: sa_claim_issue ranks and sends it (false: nothing is on
+// its way -- a duplicate, or no way to take), sa_claim_finish looks at what came back and carries on from there.
+struct SaPick { int best, bp, dup; unsigned bw, dw; };
+__device__ __forceinline__ SaPick sa_pick8(const SaGeom &g, unsigned cur, const unsigned (&w)[8], unsigned tag1) {
+    SaPick p{-1, 0x7fffffff, -1, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const bool is_dup = (w[j] & g.tag_mask) == tag1;
+        p.dup = is_dup ? j : p.dup; p.dw = is_dup ? w[j] : p.dw;
+        const int pj = w[j] == 0u ? -1 : sa_prio(w[j]);
+        const bool cand = (w[j] == 0u || sa_stamp(g, w[j]) != cur) && pj < p.bp;
+        p.best = cand ? j : p.best; p.bp = cand ? pj : p.bp; p.bw = cand ? w[j] : p.bw;
+    }
+    return p;
+}
+__device__ __forceinline__ bool sa_claim_issue(const SaGeom &g, unsigned cur, unsigned set, unsigned tag1, int agg, const unsigned (&w)[8],
+                                               SaPick &pk, unsigned &prev, int *s_delta) {
+    unsigned *tags = sa_ways_ptr(g, set);
+    pk = sa_pick8(g, cur, w, tag1);
+    if (pk.dup >= 0) {
+        if (sa_prio(pk.dw) < agg) {
+            const int old = sa_raise(g, &tags[pk.dup], pk.dw, agg);
+            if (old >= 0) { atomicSub(&s_delta[old], 1); atomicAdd(&s_delta[agg], 1); }
+        }
+        return false;
+    }
+    if (pk.best < 0) return false;   // every way of the set was filled by this very update: the key is not kept
+    prev = atomicCAS(&tags[pk.best], pk.bw, sa_word(g, tag1, cur, agg, sa_sel(g, pk.bw) ^ 1u));
+    return true;
+}
+// -> the arena entry to fill, or -1 (a duplicate folded, or the key turned away)
+__device__ __forceinline__ int sa_claim_finish(const SaGeom &g, unsigned cur, unsigned set, unsigned tag1, int agg, unsigned (&w)[8],
+                                               SaPick pk, unsigned prev, int *s_delta, int *s_stat) {
+    // (every CAS sent is looked at: the loop ends on a success, on "nothing to take", or -- a set under heavy fire: lost CASes
+    //  to raises do not use up ways -- after 24 lost ones with the last answer checked)
+#pragma unroll 1
+    for (int attempt = 0; ; attempt++) {
+        if (prev == pk.bw) {
+            xlog(2, sa_ways_ptr(g, set) + pk.best, pk.bw, sa_word(g, tag1, cur, agg, sa_sel(g, pk.bw) ^ 1u));
+            if (pk.bp >= 0) { atomicSub(&s_delta[pk.bp], 1); atomicAdd(&s_stat[1], 1); }
+            else atomicAdd(&s_stat[0], 1);
+            atomicAdd(&s_delta[agg], 1);
+            return (int)sa_entry(g, set, (unsigned)pk.best, (sa_sel(g, pk.bw) ^ 1u) << kSaSelShift);
+        }
+        if (attempt == 24) return -1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = j == pk.best ? prev : w[j];
+        if (!sa_claim_issue(g, cur, set, tag1, agg, w, pk, prev, s_delta)) return -1;
+    }
+}
+__device__ __forceinline__ int sa_claim_way(const SaGeom &g, unsigned cur, unsigned set, unsigned tag1, int agg, const SaLine &line,
+                                            int *s_delta, int *s_stat) {
+    unsigned w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = sa_way_word(line, j);
+    SaPick pk; unsigned prev = 0u;
+    if (!sa_claim_issue(g, cur, set, tag1, agg, w, pk, prev, s_delta)) return -1;
+    return sa_claim_finish(g, cur, set, tag1, agg, w, pk, prev, s_delta, s_stat);
+}
 
 // evs_fused.hip: interaction over x + the T rows the cache serves, the probe folded into the kernel (fp32 rows; is there a
 // kernel for the shape: fused_row_ids_supported)

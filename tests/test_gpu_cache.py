@@ -398,6 +398,81 @@ def _sa_sets(keys_tr, nset, n_rows, bits):
     return (x % np.uint64(nset)).astype(np.int64)
 
 
+@pytest.mark.parametrize("cap_frac,batch", [(0.10, 512), (0.02, 160), (0.3, 4100)])
+def test_update_inside_the_probe_launch_of_the_set_associative_tier(E, orc, cap_frac, batch):
+    """Round 5: evs_cache_lookup_interact on a set-associative fp32 tier makes the batch's policy update INSIDE the probe +
+    interaction launch (csrc/evs_fused_rf.hip, ProbeArgs::arena_w: the thread that misses a key claims a way of its set, the
+    lanes that gather the row store it into the arena; two arena rows per way, evs_hash.h).  Lookups back to back: R of every
+    batch = the interaction over the TRUE table rows whatever is being replaced underneath (rtol 1e-5 vs the oracle).  A hit
+    flag says the row came from the cache: flag => the key was resident when the batch arrived; a resident key flagged as a
+    miss was retired by this very batch's inserts (at most as many as it evicted).  Behind every batch: no duplicate keys,
+    every key in its own set, no set above its ways, size and histogram = the statistics, hits counted = flags seen;
+    missed keys are resident afterwards unless their set is full.  EVS_CACHE_INLINE=0 (the update as a launch of its own,
+    strict snapshot flags) is what the other tests of this file pin through lookup_batch."""
+    n_rows = [3000, 40, 20000, 700, 5, 9000, 1500, 12, 26000, 300, 8000, 64, 2200, 17000, 3, 450, 5000, 90, 13000,
+              2, 7000, 30, 1000, 11000, 150, 4000]
+    tabs = orc.kaggle_tables(n_rows, 21)
+    dev_tabs = [torch.from_numpy(t).cuda() for t in tabs]
+    cap = int(cap_frac * sum(n_rows))
+    reqs = _zipf_requests(n_rows, 9 * batch, 5)
+    rs = np.random.RandomState(6)
+    x_np = rs.uniform(-1, 1, size=(batch, 36)).astype(np.float32)
+    x = torch.from_numpy(x_np).cuda()
+    c = E.GpuCache("evlfu", cap, 26, 36, 32, "python").set_batch_policy("setassoc")
+    c.set_backing(dev_tabs)
+    r = torch.from_numpy(reqs).cuda()
+    nset, ways, _, bits = _sa_geom(cap, n_rows)
+
+    def residents():
+        d = c.batch_dump()
+        keys = [(int(t), int(rw)) for _, t, rw in d]
+        st = c.batch_stats()
+        assert len(set(keys)) == len(keys) and len(keys) == st["size"] <= cap
+        assert np.array_equal(np.bincount(d[:, 0], minlength=27), np.array(st["hist"]))
+        if keys:
+            assert np.bincount(_sa_sets(keys, nset, n_rows, bits), minlength=nset).max() <= ways
+        return {(int(t), int(rw)): int(p) for p, t, rw in d}, st
+
+    flags_seen = 0
+    res, st0 = {}, {"n_evict": 0}      # (nothing resident, nothing counted: the batched path has not run yet)
+    k = 0
+    for run in (1, 3, 1, 2, 2):       # lookups back to back, the state looked at between the runs
+        before, evict0 = res, st0["n_evict"]
+        Rs, hits = [], []
+        for j in range(run):
+            rq = r[(k + j) * batch:(k + j + 1) * batch].contiguous()
+            hit, R = c.lookup_interact(rq, x)
+            Rs.append(R.clone()); hits.append(hit.clone())
+        res, st0 = residents()
+        asked = set()                  # keys the earlier batches of the run asked for: what can be new for the later ones
+        lost = set()
+        for j in range(run):
+            rq = reqs[(k + j) * batch:(k + j + 1) * batch]
+            hit = hits[j].cpu().numpy().astype(bool)
+            flags_seen += int(hit.sum())
+            ly = [tabs[t][rq[:, t]] for t in range(26)]
+            np.testing.assert_allclose(Rs[j].cpu().numpy(), orc.interact_features(x_np, ly), rtol=1e-5, atol=2e-6)
+            keys = [[(t + 1, int(rq[b, t])) for t in range(26)] for b in range(batch)]
+            was = np.array([[key in before for key in row] for row in keys])
+            new = np.array([[key in asked for key in row] for row in keys])
+            assert not (hit & ~was & ~new).any()                  # a hit was resident when the batch arrived
+            if j == 0:
+                lost |= {keys[b][t] for b in range(batch) for t in range(26) if was[b, t] and not hit[b, t]}
+            asked |= {key for row in keys for key in row}
+        # resident keys reported as misses: retired by the batch's own inserts (each such insert is an eviction)
+        assert len(lost) <= st0["n_evict"] - evict0
+        if run == 1:                   # a missed key is resident afterwards unless its set is full
+            rq = reqs[k * batch:(k + 1) * batch]
+            hit = hits[0].cpu().numpy().astype(bool)
+            missed = sorted({(t + 1, int(rq[b, t])) for b in range(batch) for t in range(26) if not hit[b, t]})
+            gone = [key for key in missed if key not in res]
+            if gone:
+                per_set = np.bincount(_sa_sets(list(res), nset, n_rows, bits), minlength=nset)
+                assert (per_set[_sa_sets(gone, nset, n_rows, bits)] == ways).all()
+        k += run
+    assert st0["n_hits"] == flags_seen and st0["n_requests"] == k * batch
+
+
 @pytest.mark.parametrize("policy", POLICIES1)
 @pytest.mark.parametrize("cap_frac,batch", [(0.10, 256), (0.02, 64), (0.5, 1024)])
 def test_batched_cache_invariants_and_hit_rate(E, orc, cap_frac, batch, policy):
