@@ -516,7 +516,10 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
     # (probe, consumer, policy update), so `achieved` is bytes over the whole batch's device time (HIP events)
     tier_bytes = B * (T * (4 * d + 8) + 4 * d + 4 * (d + F * (F - 1) // 2) + T * 12)
     pol = policy or os.environ.get("EVS_CACHE_POLICY", "setassoc")   # (the library's default for a single tier over HBM tables)
-    chain = {"setassoc": "emb_interact_rf_kernel<..., PROBE> (set probe + gather + interaction, one launch) + cache_batch_sa_list_kernel (policy update), counter folds amortised",
+    inline = pol == "setassoc" and os.environ.get("EVS_CACHE_INLINE", "1") != "0" and os.environ.get("EVS_SA_DUAL", "1") != "0"
+    chain = {"setassoc": ("emb_interact_rf_kernel<..., PROBE> alone: set probe + gather + interaction + the policy update (the thread that misses a key claims a way, "
+                          "the gathering lanes store the row into the two-copy arena), counter folds amortised") if inline else
+                         "emb_interact_rf_kernel<..., PROBE> (set probe + gather + interaction, one launch) + cache_batch_sa_list_kernel (policy update), counter folds amortised",
              "sampled": "emb_interact_rf_kernel<..., PROBE> (hash probe + gather + interaction, one launch) + cache_batch_sampled_list_kernel (policy update), closes / sweeps amortised",
              "plan": "probe, consumer, insert / plan / evict / assign / close"}.get(pol, pol)
     tier_roof = {"bound": "hbm", "kernel": "the batch's launch chain: " + chain,

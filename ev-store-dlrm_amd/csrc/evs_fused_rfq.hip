@@ -56,6 +56,10 @@ constexpr int rfq_min_blocks(int codec) { return codec == 16 ? EVS_RFQ_LB16 : co
 #ifndef EVS_OUT_CPOL
 #define EVS_OUT_CPOL 2   // nt: R is written once and streams out (see evs_fused.hip)
 #endif
+#ifndef EVS_RFQ_I8
+#define EVS_RFQ_I8 1     // u8, d = 36, F > 16: the row x row dot products on the INTEGER matrix pipe (see the I8 path below); 0 = fp32 chains
+#endif
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // N raw bytes at p (global address space: a flat load would force every later wait to vmcnt(0)) -> w[0 .. max(1, N/4))
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
@@ -151,6 +155,19 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     constexpr bool FOLD = REM == 1 && CQ == 2 && (CODEC == 8 || (CODEC == 4 && (EVS_RFQ_FOLD4 || CHECK || NT == 1))) && EVS_RFQ_FOLD;
     constexpr int kLoadDw = FOLD ? kMainDw + 1 : kMainDw;
     static_assert(d <= 64, "x travels one float per lane");
+    // I8 (round 5; u8 rows, d = 36, F > 16): the u8 decoder is affine up to its roundings -- dec(u) = fl(fl(fl(u / 254) * 2) - 1),
+    // within 6e-8 of (u - 127) / 127 = (s + 1) / 127 with s = u - 128 -- so for two u8 rows
+    //     f_i . f_j = (P_ij + S_i + S_j + d) / 127^2,   P_ij = sum_k s_ik s_jk,  S_i = sum_k s_ik     (all exact in int32)
+    // and P is ONE v_mfma_i32_16x16x64_i8 per 16 x 16 tile of pairs (the raw bytes XOR 0x80 are the operand: no decode at all;
+    // k-slot q carries bytes [8 q, 8 q + 8), slot 3 the tail too), S_i rides along as the product with a row of ones (tile row
+    // F, free for F <= 28).  Three integer MFMAs per sample replace 27 fp32 ones (1/32 of their matrix time each) and the
+    // table look-ups of 18 elements per lane.  The 26 pairs with x (fp32) stay fp32: on the vector units, x . f_j =
+    // sum_k (x_k / 127) (s_jk + 1) as packed fp32 fmas over this lane's 12 bytes per row, summed over the four k-slots.
+    // One rounding for N / 127^2 (N < 2^24 converts exactly) against ~36 of the fp32 chain: closer to the exact value of the
+    // reference's own arithmetic than the chain (worst case over 800 k random pairs 0.27 of rtol 1e-5 + atol 2e-6, the chain
+    // 0.30: tests/test_gpu_parity.py, the bound in DESIGN.md 3.3).
+    constexpr bool I8 = CODEC == 8 && FOLD && NT == 2 && EVS_RFQ_I8 != 0;
+    __shared__ int s_S[I8 ? 4 : 1][32];            // I8: the rows' byte sums S_i of the sample in hand, per wave
     __shared__ int s_idx[512];                    // [32 features][16 samples]: row id, sample id (x), -1 = no row
     __shared__ __attribute__((aligned(16))) float s_x[4][64];
     __shared__ float s_lut[CodecLut<CODEC>::kEntries];
@@ -587,6 +604,109 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     for (int u = 0; u < D; u++) {
         const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;   // wave-uniform
         my_x[lane] = rx[u];
+        if constexpr (I8) {
+            flush_out(b - 4, u > 0 && u - 1 < n_samples);    // sample u-1 leaves under this sample's work
+            // (three phases kept apart by scheduling barriers -- the x pairs, the integer products, the output row -- so that
+            //  the twelve scaled x values, the operands and the accumulators are never all alive at once: the launch wants six
+            //  blocks per CU = 80 registers, and a spill costs more than the fp32 chains did)
+            // -- phase 1: the pairs with x, on the vector units: x' = x / 127 over this lane's bytes
+            {
+                float zx[2], xx = 0.f;
+                float xs[12];
+                const float4 xa = *reinterpret_cast<const float4 *>(my_x + 8 * q), xb = *reinterpret_cast<const float4 *>(my_x + 8 * q + 4);
+                const float4 xt = *reinterpret_cast<const float4 *>(my_x + 32);
+                const float r127 = 1.0f / 127.0f, rt = q == 3 ? r127 : 0.f;   // (the tail belongs to k-slot 3)
+                xs[0] = xa.x * r127; xs[1] = xa.y * r127; xs[2] = xa.z * r127; xs[3] = xa.w * r127;
+                xs[4] = xb.x * r127; xs[5] = xb.y * r127; xs[6] = xb.z * r127; xs[7] = xb.w * r127;
+                xs[8] = xt.x * rt; xs[9] = xt.y * rt; xs[10] = xt.z * rt; xs[11] = xt.w * rt;
+                if (itself) {   // x . x (the diagonal, when it is kept) = 127^2 * sum x' x'
+                    float t = xs[0] * xs[0];
+#pragma unroll
+                    for (int e = 1; e < 12; e++) t = __builtin_fmaf(xs[e], xs[e], t);
+                    t += __shfl_xor(t, 16);
+                    t += __shfl_xor(t, 32);
+                    xx = t * 16129.0f;
+                }
+                float x1 = 0.f;   // sum of this lane's x' (the "+ 1" of every s + 1)
+#pragma unroll
+                for (int e = 0; e < 12; e++) x1 += xs[e];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    f32x2 acc = {x1, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const unsigned w = rmain[u][rr][k] ^ 0x80808080u;   // s = u - 128 as signed bytes
+                        const f32x2 s01 = {(float)(signed char)(w & 0xffu), (float)(signed char)((w >> 8) & 0xffu)};
+                        const f32x2 s23 = {(float)(signed char)((w >> 16) & 0xffu), (float)(signed char)(w >> 24)};
+                        acc = __builtin_elementwise_fma(s01, (f32x2){xs[4 * k], xs[4 * k + 1]}, acc);
+                        acc = __builtin_elementwise_fma(s23, (f32x2){xs[4 * k + 2], xs[4 * k + 3]}, acc);
+                    }
+                    float t = acc[0] + acc[1];
+                    t += __shfl_xor(t, 16);
+                    t += __shfl_xor(t, 32);
+                    zx[rr] = t;   // x . f_row for rows r16 (rr = 0) and 16 + r16
+                }
+                // ... staged at once (the x column of the output row; k-slot 0 writes): nothing of phase 1 lives on
+                const int dump = 4 * (OUT_MAX + r16);
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + (lane < d ? 4 * lane : dump)) = rx[u];
+                const int i0 = r16, i1 = 16 + r16;
+                const int zo0 = (q == 0 && i0 < F && 0 < i0 + itself) ? 4 * (d + (i0 * (i0 - 1 + 2 * itself)) / 2) : dump;
+                const int zo1 = (q == 0 && i1 < F) ? 4 * (d + (i1 * (i1 - 1 + 2 * itself)) / 2) : dump;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo0) = i0 == 0 ? xx : zx[0];
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo1) = zx[1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // -- phase 2: the integer operands (this lane's 8 -- k-slot 3: 12 -- bytes of rows r16 and 16 + r16 as signed bytes;
+            // tile row F is a row of ones: S_i = its products) and the three products
+            i32x4 c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+            {
+                i32x4 op[2];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const bool ones = (r16 + 16 * rr) == F;
+                    const unsigned w0 = ones ? 0x01010101u : rmain[u][rr][0] ^ 0x80808080u;
+                    const unsigned w1 = ones ? 0x01010101u : rmain[u][rr][1] ^ 0x80808080u;
+                    const unsigned w2 = q == 3 ? (ones ? 0x01010101u : rmain[u][rr][2] ^ 0x80808080u) : 0u;
+                    op[rr] = (i32x4){(int)w0, (int)w1, (int)w2, 0};
+                }
+                c00 = __builtin_amdgcn_mfma_i32_16x16x64_i8(op[0], op[0], c00, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_i32_16x16x64_i8(op[1], op[0], c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_i32_16x16x64_i8(op[1], op[1], c11, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // -- phase 3: S_i = row F of the products (tile row F - 16 of c10 / c11) -> the wave's LDS slot -> every lane's rows
+            // and column; then the output row: x, the x column (phase 1), the packed lower triangle (integer products)
+            {
+                const int fr = F - 16, fq = fr >> 2, fv = fr & 3;   // wave-uniform
+                const int s0 = fv == 0 ? c10[0] : fv == 1 ? c10[1] : fv == 2 ? c10[2] : c10[3];
+                const int s1 = fv == 0 ? c11[0] : fv == 1 ? c11[1] : fv == 2 ? c11[2] : c11[3];
+                if (q == fq) { s_S[wave_in_block][r16] = s0 + d; s_S[wave_in_block][16 + r16] = s1 + d; }   // (d folded into the column's share)
+            }
+            // the other lanes' reads below are ordered behind these lanes' writes by the hardware (one wave, LDS in order) but NOT
+            // by the language: without a fence the compiler reads s_S first in the lanes that did not write it (it did, for the
+            // first sample of every wave)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float rz = 1.0f / 16129.0f;
+            const int dump = 4 * (OUT_MAX + r16);
+            const int sc0 = s_S[wave_in_block][r16], sc1 = s_S[wave_in_block][16 + r16];   // S_col + d
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int i = 4 * q + v;
+                const int si0 = s_S[wave_in_block][i] - d, si1 = s_S[wave_in_block][16 + i] - d;   // S_row
+                // (column 0 and row 0 are x's: written above)
+                const int zo00 = (i < F && r16 < i + itself && r16 > 0) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = (float)(c00[v] + si0 + sc0) * rz;
+                const int gi = 16 + i;
+                const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+                const int zo10 = (gi < F && r16 > 0) ? 4 * (d + base + r16) : dump;
+                const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = (float)(c10[v] + si1 + sc0) * rz;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = (float)(c11[v] + si1 + sc1) * rz;
+            }
+            continue;
+        }
         // operands: a[rr][c] = the 4 elements of chunk c (c < CQ: this k-slot's own chunks); of the REM trailing chunks
         // k-slot q feeds only element q to the matrix core: a[rr][CQ + t].x holds it, nothing else is decoded
         float4 a[NR][NC];

@@ -344,7 +344,22 @@ EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows,
  *     A probe reads that record; the update kernel's thread that inserts a new key takes the lowest priority OF THE KEY'S
  *     OWN SET (free ways first) with one CAS and writes the row.  No hash chains, tombstones, sweeps or entry arrays.
  *     capacity / 8 sets (up to 7 entries of the capacity unused); fewer than 2^32 rows over all tables; tables in HBM
- *     (host-memory / file-backed tables: EVS_ESTATE).  A C1 + C2 pair that starts out together SHARES its set records: one
+ *     (host-memory / file-backed tables: EVS_ESTATE).
+ *     A tier ALONE keeps TWO arena rows per way (round 5; bit 25 of the way word names the live one, a replacement writes the
+ *     other and flips the bit with the CAS that installs the key), and on such a tier evs_cache_lookup_interact with fp32
+ *     rows makes the policy update INSIDE its one launch: the thread that misses a key claims a way of the key's set right
+ *     there (one CAS beside the priority raises) and the lanes that gather the key's row for the interaction store it into
+ *     the arena -- no miss lists, no update launch (37-38 -> 32-33 us per 16 384-batch at the 10 % Kaggle cache).  What that
+ *     changes: a way filled by the running batch carries the batch's stamp and is a MISS for every prober of the same launch
+ *     (its row may not be there yet: the key is served from its table), and a key that was resident when the batch arrived
+ *     can be retired by one of the batch's own inserts before a later block looks for it.  So under this form a hit flag
+ *     says "served from the cache": flag = 1 => the key was resident when the batch arrived (always); flag = 0 => it was not,
+ *     OR one of this batch's inserts retired it first (at most as many keys as the batch evicted; the row is then served from
+ *     the table, exact as ever, and the key is inserted again like any other miss).  Keys inserted by batch k are hits from
+ *     batch k + 1 on.  Everything listed under "WHAT IS THE SAME" below holds unchanged.  EVS_CACHE_INLINE=0 (environment)
+ *     keeps the update as a launch of its own behind the probe: strict snapshot flags, as evs_cache_lookup_batch and the
+ *     reduced-precision tiers always have.
+ *     A C1 + C2 pair that starts out together SHARES its set records: one
  *     128-byte line per set index holds C1's 8 ways and C2's ways (two 8-way sub-sets, picked by one more bit of the
  *     quotient, for the reference's 1 : 2 capacity split, evlfu_8.cpp:63-78), so a key's two tier probes are ONE line
  *     request; the routing rule's "while C1 is not full" (evlfu_8.cpp:570-601) is read PER KEY: a double miss goes to C1
@@ -355,7 +370,7 @@ EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows,
  *   0 "plan": insert -> plan -> evict -> assign -> close, the lowest priorities of a clock-hand window go, exactly as
  *     many as the batch needs (the file-backed miss tier always takes this form).
  * WHAT IS THE SAME under all three, and tested: served rows are exactly the table rows; hit flags are residency when the
- * batch arrives (snapshot); no duplicate keys; size <= capacity; priorities only rise (monotone max of agg_hit,
+ * batch arrives (snapshot; the one-launch form of policy 2: see there); no duplicate keys; size <= capacity; priorities only rise (monotone max of agg_hit,
  * cache_algo/EvLFU_C1.py:65-79); the EvLFU flush fires when the top bucket reaches max_perfect (:36-44).
  * WHAT DIFFERS from the reference's sequential EvLFU (:97-166 evicts the FIFO-oldest entry of the globally lowest
  * bucket): 0 evicts the lowest priorities of a window, 1 the lowest of 8 sampled entries, 2 the lowest of the key's set --

@@ -12,6 +12,18 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5  # BASELINE.json north_star tolerance for fp32 pooled outputs
 
 
+def _same_bits(a, b, codec=32):
+    """Every path of one precision gives the same BITS -- except u8 at d = 36, F > 16 since round 5: the rows-in-registers
+    kernel takes its row x row products from the integer matrix pipe (exact int32 sums, one rounding: csrc/evs_fused_rfq.hip,
+    I8), every other u8 path (the two-call path, the general loop, blocks with ragged bags) runs the fp32 chains.  Both are
+    within the tolerance of the oracle; between them the same tolerance is what can be asked."""
+    if codec == 8:
+        torch.testing.assert_close(a, b, rtol=RTOL, atol=2e-6)
+        return True
+    return torch.equal(a, b)
+
+
+
 @pytest.fixture(scope="module")
 def E():
     import evstore_dlrm_amd as E
@@ -209,7 +221,7 @@ def test_fused_tiny_batches(E, orc, codec):
         b = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True)
         c = E.apply_emb_interact(x, [o for o in off], [i for i in idx], ev)
         e = E.interact_features(x, E.apply_emb(off, idx, ev, lazy=False))
-        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, e)
+        assert _same_bits(a, b, codec) and _same_bits(a, c, codec) and _same_bits(a, e, codec)
         ly = orc.apply_emb([np.arange(B, dtype=np.int64)] * 26, list(idx_np), tabs if codec == 32 else raws, None, codec, d)
         np.testing.assert_allclose(a.cpu().numpy(), orc.interact_features(x_np, ly), rtol=RTOL, atol=2e-6)
 
@@ -626,7 +638,7 @@ def test_fused_codec_26_tables_one_index_per_bag(E, orc, codec):
     a = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
     b = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True, check_indices=True)
     c = E.interact_features(x, E.apply_emb(off, idx, ev, None, lazy=False))
-    assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(a, b) and _same_bits(a, c, codec)
     ly = orc.apply_emb([np.arange(B, dtype=np.int64)] * 26, list(idx_np), raws, None, codec, d)
     np.testing.assert_allclose(a.cpu().numpy(), orc.interact_features(x_np, ly), rtol=RTOL, atol=2e-6)
     # the x passthrough and an out-of-range index (row skipped, flag raised)
@@ -655,7 +667,7 @@ def test_fused_codec_large_batch(E, orc, codec, d, B):
     b = E.apply_emb_interact(x, off, idx, ev, check_indices=True)
     assert torch.equal(a, b)
     c = E.interact_features(x, E.apply_emb(off, idx, ev, None, lazy=False))
-    assert torch.equal(a, c) and torch.equal(a[:, :d], x)
+    assert _same_bits(a, c, codec if d == 36 else 32) and torch.equal(a[:, :d], x)
     # an out-of-range index in the last chunk and one in the first: rows skipped, flag raised
     idx[3, B - 1] = ln[3]
     idx[20, 5] = -1
@@ -844,7 +856,7 @@ def test_fused_optimistic_offsets_pair(E, orc, codec, B):
         i = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in idxs]
         a = E.apply_emb_interact(x, o, i, ev, check_indices=True)
         b = E.interact_features(x, E.apply_emb(o, i, ev, None, lazy=False))
-        assert torch.equal(a, b)
+        assert _same_bits(a, b, codec)
         return a
 
     def run1(offs, idxs):   # include_last_offset form against the two-call path on its B-entry equivalent
@@ -852,7 +864,7 @@ def test_fused_optimistic_offsets_pair(E, orc, codec, B):
         i = [torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for v in idxs]
         a = E.apply_emb_interact(x, o, i, ev, check_indices=True)
         b = E.interact_features(x, E.apply_emb([v[:B] for v in o], [v[:int(w[B])] for v, w in zip(i, offs)], ev, None, lazy=False))
-        assert torch.equal(a, b)
+        assert _same_bits(a, b, codec)
         return a
 
     idx = [rs.randint(0, n, size=B) for n in ln]
@@ -898,7 +910,7 @@ def test_fused_optimistic_offsets_pair(E, orc, codec, B):
     b7 = E.interact_features(x, E.apply_emb(o, i, ev, None, lazy=False))
     with pytest.raises(E.EvsError):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
-    assert torch.equal(a7, b7)
+    assert _same_bits(a7, b7, codec)
     # arange offsets but a longer last bag (nnz = B + 3): not eligible for the bet
     idx4 = list(idx)
     idx4[3] = rs.randint(0, ln[3], size=B + 3)
@@ -923,7 +935,7 @@ def test_fused_optimistic_offsets_pair(E, orc, codec, B):
     b = E.interact_features(x, E.apply_emb(o, i, ev, None, lazy=False))
     with pytest.raises(E.EvsError):
         E._lib.check(E._lib.lib().evs_check_index_errors(None))
-    assert torch.equal(a, b)
+    assert _same_bits(a, b, codec)
 
 
 def test_sharded_hip_backend_two_virtual_ranks(E, orc):
