@@ -3642,6 +3642,12 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
             if (arc) { c1->sa = SaGeom{}; c2->sa = SaGeom{}; set_error("evs_cache_lookup_batch_c1c2: allocating the set records failed"); return arc; }
         }
     }
+    // (The pair's update folded into the probe launch as well -- the thread that routes a double miss claims a way of the
+    //  destination tier, whose ways it has to read AGAIN once the request's agg_hit has decided the destination, a look at the
+    //  other tier's set behind the claim so that a key routed both ways ends up in one tier, the rows copied table -> arena at
+    //  the end of the block -- was built and measured in round 5: 48.5-49.3 us per batch against 43.0-44.2 for probe launch +
+    //  update launch on the same box (three tiers 60.4-61.7 against 57.2).  A single tier has the missed row in the registers
+    //  of the lanes that gather it and its set's ways at hand; a pair has neither.  The pair keeps its update launch.)
     BatchArgs a1, a2;
     int rc = batch_prepare(c1, B, rows, st, a1, "evs_cache_lookup_batch_c1c2");
     if (rc) return rc;
@@ -3747,7 +3753,7 @@ static int batch_c1c2_impl(evs_cache *c1, evs_cache *c2, evs_aprx *c3, int64_t B
     }
     static const bool fold2_on = !(getenv("EVS_CACHE_FOLD2") && getenv("EVS_CACHE_FOLD2")[0] == '0');
     const bool fold2 = fold2_on && sampled2 && !host2 && a1.miss_rec && R && !out && B <= 65536 && T <= 32 &&
-                       (!sa2 || (c1->sa.ways == 8 && c2->sa.ways == 8 && !c1->sa.dual && !c2->sa.dual)) &&   // (the folded probe is compiled for 8-way sets with one arena row per way)
+                       (!sa2 || (c1->sa.ways == 8 && c2->sa.ways == 8 && (c1->host.cap << c1->sa.dual) < (1ll << 30) && (c2->host.cap << c2->sa.dual) < (1ll << 30))) &&   // (the folded probe is compiled for 8-way sets)
                        mixed84_supported(T, c1->host.dim, c1->host.codec, c2->host.codec);
     if (fold2) {
         Probe2Args pa;

@@ -294,6 +294,7 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
         bool act[2], ok[2], ht1[2], ht2[2], c1_room[2];
         unsigned long long key[2], end1[2], end2[2], w1[2], w2[2];
         unsigned tg1[2] = {0u, 0u}, tg2[2] = {0u, 0u};
+        int yw[2] = {-1, -1};                       // set-associative tiers: the way of the hit (in the tier that holds the key)
         const bool sa = pa.t1.sa.tags != nullptr;   // set-associative tiers (evs_hash.h): both tiers or neither
 #pragma unroll
         for (int h = 0; h < 2; h++) {   // the thread's two request rows side by side
@@ -340,10 +341,10 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 unsigned x1, x2;
-                const int y1 = sa_find<8>(pa.t1.sa, l1[h], tg1[h], x1), y2 = sa_find<8>(pa.t2.sa, l2[h], tg2[h], x2);
+                const int y1 = sa_find<8>(pa.t1.sa, l1[h], tg1[h], x1), y2 = sa_find<8>(pa.t2.sa, l2[h], tg2[h], x2);   // (a pair's update is a launch of its own: no stamp is in flight here)
                 w1[h] = x1; w2[h] = x2;
-                if (ok[h] && y1 >= 0) e1[h] = (int)((unsigned)end1[h] * 8u + (unsigned)y1);
-                else if (ok[h] && y2 >= 0) e2[h] = (int)((unsigned)end2[h] * 8u + (unsigned)y2);
+                if (ok[h] && y1 >= 0) { e1[h] = (int)sa_entry(pa.t1.sa, (unsigned)end1[h], (unsigned)y1, x1); yw[h] = y1; }
+                else if (ok[h] && y2 >= 0) { e2[h] = (int)sa_entry(pa.t2.sa, (unsigned)end2[h], (unsigned)y2, x2); yw[h] = y2; }
                 c1_room[h] = sa_has_free<8>(pa.t1.sa, l1[h]);
             }
         } else {
@@ -411,10 +412,10 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    unsigned xw;
-                    const int y1 = sa_find<8>(pa.t1.sa, la1[h], ag1[h], xw), y2 = sa_find<8>(pa.t2.sa, la2[h], ag2[h], xw);
-                    if (va[h] && y1 >= 0) { ea[h] = (int)(a1[h] * 8u + (unsigned)y1); alt_tier[h] = 1; }
-                    else if (va[h] && y2 >= 0) { ea[h] = (int)(a2[h] * 8u + (unsigned)y2); alt_tier[h] = 2; }
+                    unsigned xw, xw2;
+                    const int y1 = sa_find<8>(pa.t1.sa, la1[h], ag1[h], xw), y2 = sa_find<8>(pa.t2.sa, la2[h], ag2[h], xw2);
+                    if (va[h] && y1 >= 0) { ea[h] = (int)sa_entry(pa.t1.sa, a1[h], (unsigned)y1, xw); alt_tier[h] = 1; }
+                    else if (va[h] && y2 >= 0) { ea[h] = (int)sa_entry(pa.t2.sa, a2[h], (unsigned)y2, xw2); alt_tier[h] = 2; }
                 }
             } else {
 #pragma unroll
@@ -442,12 +443,12 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
             const int f = ((int)threadIdx.x >> 4) + 16 * h, k = f >= 1 ? f - 1 : 0;
             if (sa) {
                 if (e1[h] >= 0 && sa_prio((unsigned)w1[h]) < agg) {
-                    const int old = sa_prio(atomicMax(sa_ways_ptr(pa.t1.sa, (unsigned)end1[h]) + ((unsigned)e1[h] & 7u), sa_bump((unsigned)w1[h], agg)));
-                    if (old < agg) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
+                    const int old = sa_raise(pa.t1.sa, sa_ways_ptr(pa.t1.sa, (unsigned)end1[h]) + yw[h], (unsigned)w1[h], agg);
+                    if (old >= 0) { atomicSub(&s_d1[old], 1); atomicAdd(&s_d1[agg], 1); }
                 }
                 if (e2[h] >= 0 && sa_prio((unsigned)w2[h]) < agg) {
-                    const int old = sa_prio(atomicMax(sa_ways_ptr(pa.t2.sa, (unsigned)end2[h]) + ((unsigned)e2[h] & 7u), sa_bump((unsigned)w2[h], agg)));
-                    if (old < agg) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
+                    const int old = sa_raise(pa.t2.sa, sa_ways_ptr(pa.t2.sa, (unsigned)end2[h]) + yw[h], (unsigned)w2[h], agg);
+                    if (old >= 0) { atomicSub(&s_d2[old], 1); atomicAdd(&s_d2[agg], 1); }
                 }
             } else {
             if (e1[h] >= 0 && pa.t1.eagg[e1[h]] < agg) {
