@@ -5,8 +5,9 @@ Two engines behind the same surface, picked when the first request binds the sto
   host  the exact policy on the host (csrc/evs_hostcache.hip): a few microseconds per request, rows read from
         host-readable tables (EmbStorage.DUMMY / PINNED tensors, or the .bin files of FILEPY / MMAPFILEPY mapped
         read-only) -- the reference's batch-1 loop belongs here (docs/HISTORY.md 3.3);
-  gpu   the GPU tier's exact kernel (csrc/evs_cache.hip): one launch + one synchronise per request, for tables that
-        live in HBM only (EmbStorage.HBM), or when asked for (engine="gpu": one cache shared with batched lookups).
+  gpu   the GPU tier's exact kernel (csrc/evs_cache.hip) for tables that live in HBM only (EmbStorage.HBM), or when asked
+        for (engine="gpu"): as a RESIDENT SERVER fed through a pinned-host mailbox when the rows are wanted on the device
+        (use_gpu=True: ~25 us per request, rows never leave HBM), one launch + one synchronise per request otherwise.
 Both give the same hit flags, rows and list order (tests/test_hostcache.py, tests/test_gpu_cache.py)."""
 import numpy as np
 import torch
@@ -40,6 +41,7 @@ class _ModuleCache:
         self._dev_out = torch.empty((1, self.n_tables, self.dim), dtype=torch.float32, device=device)
         self._device = torch.device(device)
         self.cache.set_backing(tabs)
+        self._serving = None      # approx_thres the resident server was armed with (None: not armed)
         self.engine = "gpu"
 
     def _make_host(self, tabs):
@@ -93,6 +95,14 @@ class _ModuleCache:
             self._rows[0] = group_row_ids
             self.cache.request(self._rows, approx_thres, out=self._out, hit=self._hit)
             return self._hit[0].astype(bool).tolist(), torch.from_numpy(self._out[0])
+        if want_device_rows and self.n_tables <= 30:
+            # the resident server (round 5; gpu_cache.GpuCache.serve_*): the ids go out and the hit flags come back through a
+            # mailbox in pinned host memory, the rows stay in a ring in HBM -- no launch, no copy, no synchronise per request
+            if self._serving != approx_thres:
+                self.cache.serve_start(approx_thres, n_slots=4, idle_us=200)
+                self._serving = approx_thres
+            hit, rows = self.cache.serve_request(group_row_ids)
+            return hit.astype(bool).tolist(), rows
         self._host_rows[0] = torch.as_tensor(group_row_ids, dtype=torch.int32)
         out = self._dev_out if want_device_rows else self._host_out
         self.cache.request(self._host_rows, approx_thres, out=out, hit=self._host_hit)

@@ -217,8 +217,32 @@ __device__ int evlfu_set(const CacheState &cs, const CacheArrays &a, Hot &h, uns
     return e;
 }
 
+// The same kernel as a SERVER (round 5; evs_cache_serve_*): it stays resident and takes one request at a time from a
+// mailbox in pinned host memory -- the reference's operating point is batch 1 (cache_algo/EvLFU_C1.py:97-166,
+// dlrm_s_pytorch_C1.py:227-275), where a launch and a synchronise per request cost twice what the request does.
+//   request line  (host -> device, 128 bytes): the T row ids in words 0..14 and 16..30, a sequence number in word 15 AND in
+//                 word 31 -- the host writes the ids, then both guards; the device reads the line as one 32-lane load (two
+//                 64-byte bus reads that may be taken at different times) and accepts it when both guards hold the number
+//                 it waits for: each half was then read after its guard, hence after every id, was written;
+//   control line  (host -> device): word 0 = stop;
+//   answer line   (device -> host): the T hit flags in bytes 0..63, `done` (the sequence number served) in word 16, `alive`
+//                 in word 17 -- flags first, a system-scope fence, then `done`.
+// The rows go to slot (sequence % n_slots) of a ring in HBM: the caller gets DEVICE rows with no launch, copy or synchronise.
+// An idle server leaves by itself after idle_ticks of the 100 MHz wall clock (a device-wide synchronise elsewhere in the
+// process waits no longer than that); the host starts it again with the next request.
+#ifndef EVS_X_SERVE_FENCE
+#define EVS_X_SERVE_FENCE 0
+#endif
+struct ServeArgs {
+    volatile unsigned *req;     // request line (device address of the mapped host block)
+    volatile unsigned *ctl;     // control line
+    volatile unsigned *ans;     // answer line
+    float *ring; int n_slots;
+    long long idle_ticks;
+};
 // One wavefront, requests strictly in order.
-__global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
+template <bool SERVE>
+__device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const ServeArgs &sv) {
     __shared__ Hot h;
     __shared__ int s_src[kMaxTables];    // >=0: arena entry to read the row from; -1: backing store; -2: copy of table s_from
     __shared__ int s_fill[kMaxTables];   // >=0: arena entry to fill from the backing row after the request
@@ -242,8 +266,43 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
     return;
 #endif
 
-    for (long long rq = 0; rq < args.B; rq++) {
-        const int row = lane < T ? args.requests[rq * T + lane] : 0;   // the only read of the ids (they may live in host memory)
+    unsigned serve_seq = 0;            // SERVE: the last sequence number served
+    long long served = 0;
+    if constexpr (SERVE) {
+        serve_seq = __hip_atomic_load(const_cast<unsigned *>(sv.ans) + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 17, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // alive
+    }
+    for (long long rq = 0; SERVE || rq < args.B; rq++) {
+        int row;
+        float *out;
+        unsigned char *hitp;
+        if constexpr (SERVE) {
+            // ---- wait for the next request: the whole line in one load (lane = word), both guards = the number awaited ----
+            const unsigned want = serve_seq + 1u;
+            const long long t0 = (long long)wall_clock64();
+            unsigned word = 0u;
+            bool leave = false;
+            for (;;) {
+                word = __hip_atomic_load(const_cast<unsigned *>(sv.req) + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned ga = (unsigned)__shfl((int)word, 15), gb = (unsigned)__shfl((int)word, 31);
+                if (ga == want && gb == want) break;
+                const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (stop != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) { leave = true; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (leave) break;
+            // id of table t: word t (t < 15) or t + 1
+            const int src_lane = lane < 15 ? lane : lane + 1;
+            row = __shfl((int)word, src_lane & 31);
+            if (lane >= T) row = 0;
+            out = sv.ring + (long long)(want % (unsigned)sv.n_slots) * T * d;
+            hitp = nullptr;   // (flags go to the answer line, below)
+        } else {
+            row = lane < T ? args.requests[rq * T + lane] : 0;   // the only read of the ids (they may live in host memory)
+            out = args.out + rq * (long long)T * d;
+            hitp = args.hit + rq * T;
+        }
+        unsigned char my_flag = 0;      // this lane's table: the hit flag of the request in hand
         if (lane < T) s_req[lane] = row;
         const unsigned long long key = ((unsigned long long)(lane + 1) << 32) | (unsigned)row;
         const bool row_ok = lane < T && row >= 0 && row < args.backing_rows[lane < T ? lane : 0];
@@ -304,7 +363,7 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
             }
             if (lane == 0 && agg_hit == T) h.n_perfect = h.len[T];  // :163-165
             if (pick_random) my_hit = lane < T;                       // misses are reported as hits (:152)
-            if (lane < T) args.hit[rq * T + lane] = my_hit ? 1 : 0;
+            my_flag = my_hit ? 1 : 0;
             int nh = __popcll(__ballot(my_hit && lane < T));
             n_hits += nh;
             n_perfect_hits += (nh == T);
@@ -338,7 +397,7 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
                     }
                 }
                 hit_i = __shfl(hit_i, 0);
-                if (lane == i) args.hit[rq * T + i] = (unsigned char)hit_i;
+                if (lane == i) my_flag = (unsigned char)hit_i;
                 nh += hit_i;
                 // the fill must land before a later key of this request can evict/reuse the entry:
                 // rows are moved after the loop from the BACKING store for every miss, so order is moot
@@ -386,19 +445,19 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
                     }
                 }
                 hit_i = __shfl(hit_i, 0);
-                if (lane == i) args.hit[rq * T + i] = (unsigned char)hit_i;
+                if (lane == i) my_flag = (unsigned char)hit_i;
                 nh += hit_i;
             }
             n_hits += nh;
             n_perfect_hits += (nh == T);
         }
+        if constexpr (!SERVE) { if (lane < T) hitp[lane] = my_flag; }
         __syncthreads();
 
         // ---- rows: hits from the arena, misses from the backing store; then fill inserted entries ----
 #if EVS_X_EXACT_STOP == 3
         return;
 #endif
-        float *out = args.out + rq * (long long)T * d;
         if (lane < T) {   // lane i resolves where row i comes from ...
             const int i = lane;
             int src = s_src[i];
@@ -440,17 +499,37 @@ __global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) {
         }
         __threadfence_block();   // (the rows are read back by this block only: a workgroup-scope fence; an agent-scope one is an L2 write-back per request, tools/atomic_probe.hip)
         __syncthreads();
+        if constexpr (SERVE) {
+            // ---- the answer: hit flags, then (behind a fence that also puts the ring rows where every later launch sees
+            // them) the sequence number the host is polling for ----
+            served++;
+            serve_seq++;
+            if (lane < T) const_cast<volatile unsigned char *>(reinterpret_cast<volatile unsigned char *>(sv.ans))[lane] = my_flag;
+#if EVS_X_SERVE_FENCE == 1      // developer A/B (timing only): no fence at all
+#elif EVS_X_SERVE_FENCE == 2    // agent-scope fence
+            __threadfence();
+#else
+            __threadfence_system();
+#endif
+            if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 16, serve_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 
     if (lane == 0) {
         gs->min_c1 = h.min_c1; gs->n_perfect = h.n_perfect; gs->count = h.count; gs->n_free = h.n_free;
         gs->n_flush = h.n_flush; gs->n_evict = h.n_evict; gs->least_freq = h.least_freq; gs->error = h.error;
-        gs->n_requests = cs.n_requests + args.B;
+        gs->n_requests = cs.n_requests + (SERVE ? served : args.B);
         gs->n_hits = cs.n_hits + n_hits;
         gs->n_perfect_hits = cs.n_perfect_hits + n_perfect_hits;
     }
     for (int b = lane; b < kMaxBuckets; b += 64) { gs->head[b] = h.head[b]; gs->tail[b] = h.tail[b]; gs->len[b] = h.len[b]; }
+    if constexpr (SERVE) {   // the state is back in HBM: only now may the host start another server (or anything else) on it
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 17, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
+__global__ void __launch_bounds__(64) cache_exact_kernel(const CacheArgs args) { cache_exact_body<false>(args, ServeArgs{}); }
+__global__ void __launch_bounds__(64) cache_serve_kernel(const CacheArgs args, const ServeArgs sv) { cache_exact_body<true>(args, sv); }
 
 
 // ------------------------------------------------------------------------------------------
@@ -2564,6 +2643,13 @@ struct evs_cache {
     evs::SaUniverse sau{};
     struct SaShared { unsigned *tags = nullptr; size_t bytes = 0; int refs = 0; } *sa_mem = nullptr;
     unsigned char *sa_arena = nullptr;   // two-copy arena of a dual geometry (a.arena points here then)
+    // the exact policy as a resident server (evs_cache_serve_*): a mailbox in mapped host memory, its own stream
+    unsigned *mbox = nullptr, *mbox_dev = nullptr;   // 3 lines of 128 bytes: request, control, answer
+    hipStream_t serve_stream = nullptr;
+    bool serving = false;
+    unsigned serve_seq = 0;
+    float *serve_ring = nullptr; int serve_slots = 0, serve_thres = -1;
+    long long serve_idle_ticks = 0;
     int inline_mode = -1;          // the update inside the probe launch (evs_fused_rf.hip): -1 not decided (EVS_CACHE_INLINE, default on), 0 / 1
 };
 
@@ -2689,6 +2775,11 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->mbox) {
+        c->mbox[32] = 1u;   // stop
+        if (c->serve_stream) { (void)hipStreamSynchronize(c->serve_stream); (void)hipStreamDestroy(c->serve_stream); }
+        (void)hipHostFree(c->mbox);
+    }
     sa_release(c);
     delete c;
     return EVS_OK;
@@ -2828,6 +2919,7 @@ extern "C" int evs_cache_set_batch_policy(evs_cache *c, int policy) {
     return EVS_OK;
 }
 
+static int serve_pause(evs_cache *c);
 extern "C" int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, float *out, uint8_t *hit,
                                  int approx_thres, void *stream) {
     using namespace evs;
@@ -2842,15 +2934,103 @@ extern "C" int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, f
     args.requests = rows; args.out = out; args.hit = hit; args.B = B; args.approx_thres = approx_thres;
     if (c->used == 2) { set_error("evs_cache_request: this cache is used through the batched path"); return EVS_ESTATE; }
     c->used = 1;
+    { const int prc = serve_pause(c); if (prc) return prc; }
     hipLaunchKernelGGL(cache_exact_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), args);
     EVS_HIP_CHECK(hipGetLastError());
     return EVS_OK;
+}
+
+// ---- the exact policy as a resident server (cache_serve_kernel) ------------------------------------------------------------
+static void serve_launch(evs_cache *c) {
+    using namespace evs;
+    CacheArgs args;
+    args.st = c->st; args.a = c->a;
+    for (int k = 0; k < kMaxTables; k++) { args.backing[k] = c->backing[k]; args.backing_rows[k] = c->backing_rows[k]; }
+    args.requests = nullptr; args.out = nullptr; args.hit = nullptr; args.B = 0; args.approx_thres = c->serve_thres;
+    ServeArgs sv;
+    sv.req = c->mbox_dev; sv.ctl = c->mbox_dev + 32; sv.ans = c->mbox_dev + 64;
+    sv.ring = c->serve_ring; sv.n_slots = c->serve_slots; sv.idle_ticks = c->serve_idle_ticks;
+    hipLaunchKernelGGL(cache_serve_kernel, dim3(1), dim3(64), 0, c->serve_stream, args, sv);
+}
+// anything else that reads or writes the exact state first sends the server home (it writes the state back on its way out);
+// the next evs_cache_serve_request starts it again
+static int serve_pause(evs_cache *c) {
+    if (!c || !c->mbox || !c->serve_stream) return EVS_OK;
+    if (hipStreamQuery(c->serve_stream) == hipSuccess) return EVS_OK;   // nothing running
+    (void)hipGetLastError();
+    reinterpret_cast<volatile unsigned *>(c->mbox)[32] = 1u;
+    const hipError_t e = hipStreamSynchronize(c->serve_stream);
+    reinterpret_cast<volatile unsigned *>(c->mbox)[32] = 0u;
+    return e == hipSuccess ? EVS_OK : EVS_EHIP;
+}
+extern "C" int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring, int n_slots, int64_t idle_us) {
+    using namespace evs;
+    EVS_REQUIRE(c && ring && n_slots >= 1 && idle_us >= 1, "evs_cache_serve_start: bad argument");
+    if (!c->has_backing) { set_error("evs_cache_serve_start: call evs_cache_set_backing first"); return EVS_ESTATE; }
+    if (c->staged_mask) { set_error("evs_cache_serve_start: a file-backed tier with staged tables serves batched lookups only"); return EVS_ESTATE; }
+    if (c->used == 2) { set_error("evs_cache_serve_start: this cache is used through the batched path"); return EVS_ESTATE; }
+    EVS_REQUIRE(c->host.n_tables <= 30, "evs_cache_serve_start: at most 30 tables (the request line holds 30 ids)");
+    c->used = 1;
+    if (!c->mbox) {
+        EVS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->mbox), 3 * 128, hipHostMallocMapped));
+        memset(c->mbox, 0, 3 * 128);
+        EVS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->mbox_dev), c->mbox, 0));
+        EVS_HIP_CHECK(hipStreamCreateWithFlags(&c->serve_stream, hipStreamNonBlocking));
+        c->serve_seq = 0;
+    } else {
+        const int rc = serve_pause(c);
+        if (rc) return rc;
+    }
+    c->serve_ring = ring; c->serve_slots = n_slots; c->serve_thres = approx_thres;
+    c->serve_idle_ticks = idle_us * 100;   // wall_clock64(): 100 MHz
+    c->serving = true;
+    EVS_HIP_CHECK(hipDeviceSynchronize());   // (the ring and the tables' contents are in place before the server's first read)
+    return EVS_OK;
+}
+// one request (T row ids on the host) -> T hit flags on the host, the T x d fp32 rows in slot *slot_out of the ring (device).
+// Blocks until the server has answered (no launch, no copy, no synchronise: two cache-line hand-overs over the bus).
+extern "C" int evs_cache_serve_request(evs_cache *c, const int32_t *rows, uint8_t *hit, int *slot_out) {
+    using namespace evs;
+    EVS_REQUIRE(c && rows && hit && slot_out, "evs_cache_serve_request: NULL argument");
+    if (!c->serving) { set_error("evs_cache_serve_request: call evs_cache_serve_start first"); return EVS_ESTATE; }
+    volatile unsigned *req = c->mbox, *ans = c->mbox + 64;
+    const int T = c->host.n_tables;
+    const unsigned want = ++c->serve_seq;
+    for (int t = 0; t < T; t++) req[t < 15 ? t : t + 1] = (unsigned)rows[t];
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    req[15] = want;
+    req[31] = want;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    long long spins = 0;
+    while (ans[16] != want) {
+        if ((spins & 63) == 0 && ans[17] == 0u) {   // no server (never started, went home idle, or was paused): start one
+            const hipError_t q = hipStreamQuery(c->serve_stream);
+            if (q == hipSuccess) { serve_launch(c); EVS_HIP_CHECK(hipGetLastError()); }
+            else if (q != hipErrorNotReady) { (void)hipGetLastError(); c->serve_seq--; return EVS_EHIP; }
+            else (void)hipGetLastError();
+        }
+        if (++spins > (1ll << 31)) { set_error("evs_cache_serve_request: the server did not answer"); return EVS_EHIP; }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const volatile unsigned char *fl = reinterpret_cast<const volatile unsigned char *>(ans);
+    for (int t = 0; t < T; t++) hit[t] = fl[t];
+    *slot_out = (int)(want % (unsigned)c->serve_slots);
+    return EVS_OK;
+}
+extern "C" int evs_cache_serve_stop(evs_cache *c) {
+    using namespace evs;
+    EVS_REQUIRE(c, "evs_cache_serve_stop: NULL cache");
+    const int rc = serve_pause(c);
+    c->serving = false;
+    return rc;
 }
 
 // out8: [min_C1, n_perfect, size, n_flush, n_evict, n_requests, n_perfect_hits, n_hits]; returns the sticky error
 extern "C" int evs_cache_stats(evs_cache *c, int64_t *out8, void *stream) {
     using namespace evs;
     EVS_REQUIRE(c && out8, "evs_cache_stats: NULL argument");
+    { const int prc = serve_pause(c); if (prc) return prc; }
     CacheState h;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     EVS_HIP_CHECK(hipMemcpyAsync(&h, c->st, sizeof h, hipMemcpyDeviceToHost, st));
@@ -2867,6 +3047,7 @@ extern "C" int evs_cache_stats(evs_cache *c, int64_t *out8, void *stream) {
 extern "C" int evs_cache_reset_counters(evs_cache *c, void *stream) {
     using namespace evs;
     EVS_REQUIRE(c, "evs_cache_reset_counters: NULL cache");
+    { const int prc = serve_pause(c); if (prc) return prc; }
     CacheState h;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     EVS_HIP_CHECK(hipMemcpyAsync(&h, c->st, sizeof h, hipMemcpyDeviceToHost, st));
@@ -2881,6 +3062,7 @@ extern "C" int evs_cache_reset_counters(evs_cache *c, void *stream) {
 extern "C" int64_t evs_cache_dump(evs_cache *c, int64_t *triples, int64_t max_triples, void *stream) {
     using namespace evs;
     if (!c) return EVS_EINVAL;
+    if (serve_pause(c)) return EVS_EHIP;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (hipStreamSynchronize(st) != hipSuccess) return EVS_EHIP;
     CacheState h;
@@ -4074,6 +4256,7 @@ extern "C" int evs_cache_request_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *
     if (B == 0) return EVS_OK;
     EVS_REQUIRE(B > 0 && rows && out && tier, "evs_cache_request_c1c2c3: NULL argument");
     if (c1->used == 2 || c2->used == 2) { set_error("evs_cache_request_c1c2c3: a tier is used through the batched path"); return EVS_ESTATE; }
+    { const int p1 = serve_pause(c1), p2 = serve_pause(c2); if (p1 || p2) return EVS_EHIP; }
     c1->used = c2->used = 1;
     C1C2Args args;
     evs_cache *cs[2] = {c1, c2};

@@ -157,6 +157,34 @@ class GpuCache:
                                                 int(approx_thres), torch.cuda.current_stream(self.device).cuda_stream))
         return hit, out
 
+    # ---- the exact policy as a resident server (include/evstore_hip.h: evs_cache_serve_*) ----
+    def serve_start(self, approx_thres=-1, n_slots=4, idle_us=200):
+        """Arm the mailbox server: batch-1 requests then cost two cache-line hand-overs over the bus instead of a launch and a
+        synchronise each.  The rows of request i land in self.serve_ring[slot] on the DEVICE."""
+        import ctypes as C
+        import numpy as np
+        self.serve_ring = torch.empty((n_slots, self.n_tables, self.dim), dtype=torch.float32, device=self.device)
+        self._srv_rows = np.zeros(self.n_tables, np.int32)
+        self._srv_hit = np.zeros(self.n_tables, np.uint8)
+        self._srv_slot = C.c_int(0)
+        self._srv_call = (_lib.lib().evs_cache_serve_request, self._h, self._srv_rows.ctypes.data, self._srv_hit.ctypes.data, C.byref(self._srv_slot))
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().evs_cache_serve_start(self._h, int(approx_thres), self.serve_ring.data_ptr(), int(n_slots), int(idle_us)))
+        return self
+
+    def serve_request(self, row_ids):
+        """row_ids: n_tables ints (host).  -> (hit flags: a numpy uint8 view valid until the next request, the (T, dim) fp32
+        rows as a DEVICE tensor view valid until n_slots - 1 more requests).  Same results as request() one at a time."""
+        self._srv_rows[:] = row_ids
+        fn, h, rp, hp, sp = self._srv_call
+        rc = fn(h, rp, hp, sp)
+        if rc:
+            _lib.check(rc)
+        return self._srv_hit, self.serve_ring[self._srv_slot.value]
+
+    def serve_stop(self):
+        _lib.check(_lib.lib().evs_cache_serve_stop(self._h))
+
     def lookup_batch(self, rows, out=None, hit=None):
         """Batched EvLFU lookup, snapshot semantics (see include/evstore_hip.h: evs_cache_lookup_batch)."""
         B = _check_batch(self, rows, out, hit)

@@ -325,6 +325,21 @@ EVS_API int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, floa
  * unordered_set order); perfect requests are counted in c1's n_perfect_hits. */
 EVS_API int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, const int32_t *rows, float *out,
                                    uint8_t *tier, int high_agghit_threshold, void *stream);
+/* The exact policy as a RESIDENT SERVER on the GPU (round 5) -- the reference serves one request at a time
+ * (cache_algo/EvLFU_C1.py:97-166, dlrm_s_pytorch_C1.py:227-275, cpp_socket_client.py:129-157), where evs_cache_request
+ * costs a launch and a synchronise per request on top of the request itself.  evs_cache_serve_start arms a one-wavefront
+ * kernel (the same code as evs_cache_request's: same hit flags, rows, list order) that stays on the device and takes requests
+ * from a mailbox in pinned host memory: the host writes the T ids and a sequence number into one 128-byte line, the server
+ * polls that line over the bus, runs the request, writes the T x dim fp32 rows into slot (sequence % n_slots) of `ring`
+ * (DEVICE memory, n_slots x T x dim floats: the caller gets device rows without a launch, a copy or a synchronise) and the
+ * hit flags + the sequence number into a host line the caller spins on.  evs_cache_serve_request blocks until the answer is
+ * there (hit: T bytes on the host; *slot_out: which ring slot holds the rows -- valid until n_slots - 1 more requests).
+ * An idle server leaves by itself after idle_us (a device-wide synchronise elsewhere waits no longer than that) and is
+ * started again by the next request; evs_cache_stats / _dump / _request / _reset_counters / _destroy send it home first (it
+ * writes the policy state back on its way out).  At most 30 tables; EVS_ESTATE for a cache on the batched path. */
+EVS_API int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring, int n_slots, int64_t idle_us);
+EVS_API int evs_cache_serve_request(evs_cache *c, const int32_t *rows_host, uint8_t *hit_host, int *slot_out);
+EVS_API int evs_cache_serve_stop(evs_cache *c);
 /* Batched EvLFU lookup with snapshot semantics (the throughput path; no reference counterpart --
  * the reference is batch-1): all B requests are probed against the cache as it is when the call
  * starts, rows are served at once (arena for hits, backing for misses: always exactly the table

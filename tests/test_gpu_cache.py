@@ -85,6 +85,59 @@ def test_evlfu_trace_matches_reference(E, orc, cap, chunk):
     assert st["n_perfect_hits"] == int(want.all(1).sum())
 
 
+@pytest.mark.parametrize("policy,cap,key", [("evlfu", 64, "evlfu_cap64"), ("evlfu", 768, "evlfu_cap768"), ("evlfu", 80, "evlfu_cap80"),
+                                            ("lru", 64, "lru_cap64"), ("lfu", 768, "lfu_cap768")])
+def test_resident_server_gives_the_golden_traces(E, orc, policy, cap, key):
+    """Round 5: the exact policy as a RESIDENT SERVER (evs_cache_serve_*: a one-wavefront kernel that stays on the device and
+    takes one request at a time from a mailbox in pinned host memory; rows into a ring in HBM, hit flags back through a host
+    line) against the traces of the imported reference (cache_algo/EvLFU_C1.py, LRU.py, LFU.py): hit flags, rows and final
+    list order bit-exact -- through stops in the middle (stats / dump send the server home, the next request starts it
+    again), an idle time-out, and a plain launch-per-request call mixed in."""
+    import time
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    reqs = t["requests_flush"] if cap == 80 else t["requests"]
+    want = _unpack(t[key + "_hits"], len(reqs))
+    c = E.GpuCache(policy, cap, 26, 36, 32, "python")
+    c.set_backing([torch.from_numpy(x).cuda() for x in tabs])
+    c.serve_start(n_slots=3, idle_us=300)
+    pin_rows = torch.empty((1, 26), dtype=torch.int32).pin_memory()
+    pin_out = torch.empty((1, 26, 36), dtype=torch.float32).pin_memory()
+    pin_hit = torch.empty((1, 26), dtype=torch.uint8).pin_memory()
+    held = []
+    for i, rq in enumerate(reqs):
+        if i == 400:                       # anything else on the exact state sends the server home first ...
+            st = c.stats()
+            assert st["n_requests"] == 400 and st["n_hits"] == int(want[:400].sum())
+        if i == 700:
+            time.sleep(0.01)               # ... it leaves by itself when idle ...
+        if i == 900:                       # ... and a launch-per-request call on the same cache fits in between
+            pin_rows[0] = torch.from_numpy(rq.astype(np.int32))
+            c.request(pin_rows, out=pin_out, hit=pin_hit)
+            torch.cuda.synchronize()
+            assert np.array_equal(pin_hit[0].numpy().astype(bool), want[i]), i
+            continue
+        hit, rows = c.serve_request(rq)
+        assert np.array_equal(hit.astype(bool), want[i]), i
+        if i % 97 == 0 or i < 8:           # rows: device tensors, the table rows bit for bit
+            got = rows.cpu().numpy()
+            for k in range(26):
+                assert np.array_equal(got[k], tabs[k][rq[k]]), (i, k)
+        held.append((rows, rq))
+        if len(held) == 2:                 # a slot stays valid for n_slots - 1 more requests
+            r0, q0 = held.pop(0)
+            assert np.array_equal(r0[3].cpu().numpy(), tabs[3][q0[3]])
+    c.serve_stop()
+    if policy == "evlfu":
+        np.testing.assert_array_equal(c.dump(), t[key + "_final_buckets"])
+    elif policy == "lru":
+        np.testing.assert_array_equal(c.dump()[:, 1:], t[key + "_final_order"])
+    else:
+        np.testing.assert_array_equal(c.dump(), t[key + "_final_freq"])
+    st = c.stats()
+    assert st["n_requests"] == len(reqs) and st["n_hits"] == int(want.sum())
+
+
 def test_evlfu_approx_mode(E, orc):
     t = load_golden("cache_traces")
     tabs = _tables(orc, t)
