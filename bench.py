@@ -755,10 +755,11 @@ def main():
     ap.add_argument("--cdf-dir", default=os.path.join(ROOT, "gpurun_out", "cdf"), help="where the B=1 latency CDF CSV goes")
     ap.add_argument("--replicate-gb", type=float, default=64.0, help="per-GPU HBM budget for replicated tables (hbm placement)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one process")
-    ap.add_argument("--exchange-mode", default="inline", choices=["inline", "async", "p2p"],
+    ap.add_argument("--exchange-mode", default="inline", choices=["inline", "async", "p2p", "auto"],
                     help="N>1: all_to_all_single(async_op=False) in stream order (default), async_op=True with the handle waited on in front of the "
                          "interaction, or p2p: no collective call -- the pooling kernel writes every peer's block straight into that peer's "
-                         "IPC-mapped receive buffer, two flag words per (peer, slot) hand it over (csrc/evs_p2p.hip)")
+                         "IPC-mapped receive buffer, two flag words per (peer, slot) hand it over (csrc/evs_p2p.hip); auto: p2p when ONE batch through both "
+                         "exchanges gave bit-equal receive buffers on every rank (sharded.verify_p2p_against_collective), the RCCL collective otherwise")
     ap.add_argument("--force-exchange", action="store_true", help="with --force-sharded on one rank: issue the RCCL all_to_all_single anyway "
                                                                   "(a self-exchange into a separate receive buffer: what the collective call itself costs per step)")
     ap.add_argument("--shape", default="kaggle", choices=["kaggle", "terabyte"],

@@ -692,6 +692,11 @@ class ShardedEmbeddingInteract:
     #   "async":  async_op=True, the handle waited on in front of the interaction: the exchange of batch i + 1 runs on
     #             RCCL's stream under the interaction of batch i -- at the price of the dearer call.
     # One rank with the exchange forced (bench.py --force-sharded --force-exchange): 52-58 us per step inline, 63 us async.
+    # Round 5: pool(i + 1) + the collective on a stream of their own under the interaction of batch i, the two hand-overs per
+    # step as signal words (evs_stream_write_value / _wait_value) instead of events, was built and measured: 69-75 us against
+    # 52-57 inline on the same box -- the step is bound by the HOST cost of the collective's call path (14-38 us per call),
+    # and two more stream operations per step add to it; what takes the collective off the step is exchange_mode "p2p"
+    # (29.5 us; picked by "auto" -- bench.py -- once one batch through both exchanges gave bit-equal receive buffers).
     exchange_mode = "inline"
 
     def _exchange(self, recv, send, out_splits, in_splits):
@@ -770,22 +775,55 @@ class ShardedEmbeddingInteract:
 
 
 # ----------------------------------------------------------------------------- bench (N > 1)
+def _bench_weights(ln_emb, d, rank, world, dev, owner):
+    """the bench's tables of one rank: same values on every rank that holds table t (a row-split table: this rank's row range)"""
+    g = torch.Generator(device=dev)
+    weights = {}
+    for t in [t for t in range(len(ln_emb)) if owner[t] in (rank, -1, -2)]:
+        g.manual_seed(1000 + t)
+        a = float(np.sqrt(1.0 / ln_emb[t]))
+        lo, hi = row_range(ln_emb[t], rank, world) if owner[t] == -2 else (0, ln_emb[t])
+        weights[t] = torch.empty((hi - lo, d), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
+    return weights
+
+
+def _verify_for_bench(args, ln_emb, rank, world, dev, policy, budget_rows):
+    """verify_p2p_against_collective on the bench's own placement and one of its batches"""
+    d, Bg = args.dim, args.batch * world
+    owner = plan_placement(ln_emb, world, policy, replicate_budget_rows=budget_rows)
+    weights = _bench_weights(ln_emb, d, rank, world, dev, owner)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    off = torch.arange(Bg, device=dev, dtype=torch.int64)
+    lS_i = [torch.randint(0, n, (Bg,), device=dev, generator=g, dtype=torch.int64) for n in ln_emb]
+    ok = verify_p2p_against_collective(ln_emb, d, rank, world, weights, HipBackend(dev), policy, [off] * len(ln_emb), lS_i,
+                                       force_exchange=bool(getattr(args, "force_exchange", False)), one_index_per_bag=True,
+                                       replicate_budget_rows=budget_rows)
+    del weights
+    torch.cuda.empty_cache()
+    return ok
+
+
 def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roofline):
     """Time args.steps steps of one placement policy (all ranks in lockstep); returns a dict."""
+    if getattr(args, "exchange_mode", "inline") == "auto":
+        # "auto": the device-to-device exchange only when one batch through both exchanges gave bit-equal receive buffers on
+        # every rank; the RCCL collective otherwise
+        import copy
+        args = copy.copy(args)
+        verified = (world > 1 or bool(getattr(args, "force_exchange", False))) and _verify_for_bench(args, ln_emb, rank, world, dev, policy, budget_rows)
+        args.exchange_mode = "p2p" if verified else "inline"
+        r = _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roofline)
+        r["exchange_auto"] = {"picked": args.exchange_mode, "p2p_verified": bool(verified)}
+        return r
     d = args.dim
     T = len(ln_emb)
     Bl = args.batch
     Bg = Bl * world
     backend = HipBackend(dev)
     owner = plan_placement(ln_emb, world, policy, replicate_budget_rows=budget_rows)
-    held = [t for t in range(T) if owner[t] in (rank, -1, -2)]
     g = torch.Generator(device=dev)
-    weights = {}
-    for t in held:  # same values on every rank that holds table t (a row-split table: this rank's row range of it)
-        g.manual_seed(1000 + t)
-        a = float(np.sqrt(1.0 / ln_emb[t]))
-        lo, hi = row_range(ln_emb[t], rank, world) if owner[t] == -2 else (0, ln_emb[t])
-        weights[t] = torch.empty((hi - lo, d), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
+    weights = _bench_weights(ln_emb, d, rank, world, dev, owner)
     op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy, one_index_per_bag=True,
                                   replicate_budget_rows=budget_rows)
     op.force_exchange = bool(getattr(args, "force_exchange", False))
@@ -912,6 +950,50 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     return res
 
 
+def verify_p2p_against_collective(ln_emb, d, rank, world, weights, backend, policy, lS_o, lS_i, force_exchange=False, **op_kw):
+    """Before anybody trusts (or times) the device-to-device exchange on hardware no test has seen: ONE batch through both
+    exchanges -- the RCCL all_to_all_single and exchange_mode "p2p" -- and every rank's receive buffer compared bit for bit;
+    the verdict is agreed on over the process group (all ranks return the same bool, none raises).  Cost: two ops' buffers
+    and one step each."""
+    ok = 1
+    try:
+        recvs = []
+        for mode in ("inline", "p2p"):
+            op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy, **op_kw)
+            op.force_exchange = bool(force_exchange)
+            op.exchange_mode = mode
+            if not op.any_sharded:
+                del op
+                return True   # nothing is exchanged under this placement
+            work, recv, Bg, Bl, out_splits = op.start(lS_o, lS_i)
+            if work is not None:
+                work.wait()
+            st_, slot = op._p2p_slot_of(recv, Bg) if mode == "p2p" else (None, None)
+            if slot is not None:
+                st_.begin_consume(slot)      # every source's block has arrived
+                st_.end_consume(slot)
+                op.p2p_flush()
+            torch.cuda.synchronize(backend.device)
+            n = sum(out_splits)
+            recvs.append(recv.view(-1)[:n].clone())
+            if mode == "p2p":
+                if _lib.lib().evs_check_index_errors(None) != 0:
+                    ok = 0               # a hand-over that did not arrive
+                for st2 in op._p2p.values():
+                    st2.close()
+            del op
+        if ok and not torch.equal(recvs[0], recvs[1]):
+            ok = 0
+    except Exception:
+        ok = 0
+    t = torch.tensor([ok], device=backend.device, dtype=torch.int32)
+    try:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    except Exception:
+        return False
+    return bool(int(t.item()))
+
+
 def bench_p2p_side(args, ln_emb, rank, world, dev):
     """The same placement and steps with exchange_mode "p2p" (no collective call in the step), as a side line of the N > 1
     bench: never raises, and every rank returns from it (set-up failures and hand-overs that do not arrive are agreed on over
@@ -922,11 +1004,15 @@ def bench_p2p_side(args, ln_emb, rank, world, dev):
         a.exchange_mode = "p2p"
         policy = getattr(args, "placement", "rows+replicate")
         budget_rows = int(getattr(args, "replicate_gb", 64.0) * 1e9 / (4 * args.dim))
+        verified = _verify_for_bench(args, ln_emb, rank, world, dev, policy, budget_rows)
+        if not verified:
+            return {"verified": False, "skipped": "one batch through both exchanges: the p2p receive buffers differ from the RCCL ones (or a "
+                                                  "hand-over did not arrive) on some rank -- not timed; the RCCL line above stands"}
         e = _bench_policy(a, ln_emb, rank, world, dev, policy, budget_rows, True)
         if e["n_sharded"] == 0 and not e["n_rowsplit"]:
             return {"skipped": "nothing is exchanged under this placement"}
         T, Bg = len(ln_emb), args.batch * world
-        return {"value": T * Bg * args.steps / e["dt"], "unit": "lookups/s", "ms_per_step": e["dt"] / args.steps * 1e3, "roofline": e["roofline"],
+        return {"verified": True, "value": T * Bg * args.steps / e["dt"], "unit": "lookups/s", "ms_per_step": e["dt"] / args.steps * 1e3, "roofline": e["roofline"],
                 "note": "the same step without a collective call: the pooling launch writes every peer's block into that peer's IPC-mapped "
                         "receive buffer over xGMI, two flag words per (peer, slot) hand it over (csrc/evs_p2p.hip)"}
     except Exception as ex:
@@ -987,7 +1073,8 @@ def bench_sharded(args, ln_emb, rank, world, dev):
                    "batch_per_gpu": Bl, "global_batch": Bg, "tables": T, "dim": d, "parallelism": par,
                    "placement": policy, "owner": main["owner"], "step_mode": main["mode"],
                    "observed_world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                   "exchange_mode": getattr(args, "exchange_mode", "inline"),
+                   "exchange_mode": (main.get("exchange_auto") or {}).get("picked", getattr(args, "exchange_mode", "inline")),
+                   "exchange_auto": main.get("exchange_auto"),
                    "a2a_bytes_per_step_per_rank": main["a2a_bytes_per_rank"],
                    "a2a_bytes_per_step_all_links": main["a2a_bytes"]},
         "roofline": main["roofline"], "cpu_baseline": None, "replicated_all": extra,

@@ -50,6 +50,12 @@ def main():
         assert torch.equal(out, want), policy + " (pipelined)"
         assert not op.any_sharded or pl["recv"].data_ptr() != pl["send"].data_ptr(), "the exchange must have its own receive buffer"
         del op
+    # round 5: the check that gates the device-to-device exchange (bench.py --exchange-mode auto, EVS_BENCH_P2P=1): one batch
+    # through the RCCL collective and through exchange_mode "p2p", receive buffers bit-equal, the verdict agreed on over the group
+    lo, li = [off[t] for t in range(T)], [idx[t] for t in range(T)]
+    for policy in ("rows+replicate", "rowsplit"):
+        assert sharded.verify_p2p_against_collective(ln, d, 0, 1, {t: ws[t] for t in range(T)}, sharded.HipBackend(dev), policy, lo, li,
+                                                     force_exchange=True, one_index_per_bag=True, replicate_max_rows=2000), policy
     dist.barrier()
     dist.destroy_process_group()
     print("NCCL_WORLD1_OK")
