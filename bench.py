@@ -212,7 +212,26 @@ def long_bags_section(dev, B=2048, bag=100, d=64, T=8, rows=1000000, iters=200):
     by_f = by + B * (4 * d * (1 + T) + 4 * d + 4 * (d + F * (F - 1) // 2))
     del ev
     torch.cuda.empty_cache()
-    return {"workload": "bench/dlrm_s_benchmark.sh shape: %d tables x %d rows x d=%d fp32, %d indices per bag (fixed), B=%d, uniform" % (T, rows, d, bag, B),
+    # the same shape at the row widths that are NOT whole 128-byte lines (d = 36: the Kaggle model's 144-byte rows, d = 16: half
+    # a line per row): `frac` counts the bytes asked for, `line_terms_frac` the bytes of the LINES those rows touch (what the
+    # memory system moves: a 144-byte row at a 144-byte stride touches 2.125 lines on average, a 64-byte row one) -- the
+    # second figure is the one to hold against the d = 64 line's
+    other = {}
+    for dw in ((36, 16) if d == 64 else ()):
+        try:
+            evw = make_tables([rows] * T, dw, seed=4, device=dev)
+            ms_w = timed(lambda i: E.apply_emb(off, idxs[i % nb], evw, None, lazy=False))
+            rb = 4 * dw
+            lines = sum((r * rb + rb - 1) // 128 - (r * rb) // 128 + 1 for r in range(32)) / 32.0   # lines per row (the pattern repeats within 32 rows)
+            by_w = looks * (rb + 8) + T * B * (8 + rb)
+            by_l = looks * (lines * 128 + 8) + T * B * (8 + rb)
+            other["d=%d" % dw] = {"ms_per_step": ms_w, "value": looks / ms_w * 1e3, "bytes_per_launch": by_w, "frac": by_w / ms_w / 1e6 / HBM_PEAK_GBPS,
+                                  "lines_per_row": lines, "line_terms_frac": by_l / ms_w / 1e6 / HBM_PEAK_GBPS}
+            del evw
+            torch.cuda.empty_cache()
+        except Exception as e:
+            other["d=%d" % dw] = {"error": repr(e)}
+    return {"other_row_widths": other, "workload": "bench/dlrm_s_benchmark.sh shape: %d tables x %d rows x d=%d fp32, %d indices per bag (fixed), B=%d, uniform" % (T, rows, d, bag, B),
             "unit": "lookups/s",
             "apply_emb": {"ms_per_step": ms_g, "value": looks / ms_g * 1e3, "achieved": by / ms_g / 1e6, "peak": HBM_PEAK_GBPS,
                           "frac": by / ms_g / 1e6 / HBM_PEAK_GBPS, "bytes_per_launch": by, "kernel": "bag_sum_long_kernel<%d, ...>" % (d // 4)},
@@ -263,15 +282,36 @@ def cpu_baseline(ev, ln_emb, d, B, seconds=12.0):
         lS_o = torch.arange(B).repeat(len(ln_emb), 1)
         batches.append((lS_o, lS_i, torch.rand(B, d, generator=g)))
     model.step(*batches[0])  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        model.step(*batches[n % len(batches)])
-        n += 1
-    dt = time.perf_counter() - t0
+    # taken TWICE (two windows of seconds / 2 each): the figure moved 2x between boxes of this pool in earlier rounds, and a
+    # baseline that does that needs its spread and its placement stated with it
+    runs, n_tot, dt_tot = [], 0, 0.0
+    for _ in range(2):
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / 2:
+            model.step(*batches[n % len(batches)])
+            n += 1
+        dt = time.perf_counter() - t0
+        runs.append(len(ln_emb) * B * n / dt)
+        n_tot += n
+        dt_tot += dt
+    n, dt = n_tot, dt_tot
+    # where the threads and the tables are: nothing is pinned (torch's intra-op pool, OS scheduling); the tables are first-touched
+    # by the thread that copies them from HBM, i.e. on ONE NUMA node of a multi-socket host -- the other sockets' threads read
+    # them over the inter-socket links
+    try:
+        nodes = sorted(x for x in os.listdir("/sys/devices/system/node") if x.startswith("node") and x[4:].isdigit())
+        numa = {"nodes": len(nodes), "cpus_per_node": [open("/sys/devices/system/node/%s/cpulist" % x).read().strip() for x in nodes][:8]}
+    except OSError:
+        numa = {"nodes": None}
+    try:
+        numa["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    numa["binding"] = "none: %d torch intra-op threads, unpinned; tables first-touched by the copying thread (one NUMA node)" % cores
     return {"value": len(ln_emb) * B * n / dt, "unit": "lookups/s", "cores": cores, "logical_cpus": logical,
-            "kind": "port", "ms_per_batch": dt / n * 1e3,
+            "kind": "port", "ms_per_batch": dt / n * 1e3, "runs": runs, "spread": (max(runs) - min(runs)) / max(runs), "placement": numa,
             "sample": "%d batches of B=%d (the GPU's batch size) over the same 26 Kaggle-shaped fp32 tables (copied from HBM), "
-                      "torch %s CPU EmbeddingBag+bmm loop, %d threads = physical cores, %.1f s" % (n, B, torch.__version__, cores, dt)}
+                      "torch %s CPU EmbeddingBag+bmm loop, %d threads = physical cores, two windows of %.1f s" % (n, B, torch.__version__, cores, dt / 2)}
 
 
 def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
@@ -1002,7 +1042,11 @@ def main():
                      "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "bytes_per_launch": kernel_bytes, "avg_launch_ms": kernel_ms,
-                     "mfma": mfma_line(B, F, d, kernel_ms)},
+                     "mfma": mfma_line(B, F, d, kernel_ms),
+                     # (the other half of BASELINE's metric, kept inside an object the driver's parsed record keeps: p50 of one batch
+                     #  launched and waited for -- blocking synchronise / the host spinning on an end event)
+                     "latency": {"p50_batch_latency_ms": float(np.percentile(lat, 50)), "p95_batch_latency_ms": float(np.percentile(lat, 95)),
+                                 "p50_batch_latency_polled_ms": float(np.percentile(lat_poll, 50))}},
         "declared_one_index": {"value": lookups * args.steps / dtg, "unit": "lookups/s",
                                "ms_per_step": dtg / args.steps * 1e3,
                                "frac": B * bytes_per_sample_declared / (dtg / args.steps) / 1e9 / HBM_PEAK_GBPS,
@@ -1096,6 +1140,7 @@ def main():
                                              "of a launch on this stack is ~6 us); multi_8_per_call = apply_emb_interact_multi, 8 queued batches as ONE launch"}
         except Exception as e:
             result["small_batch"] = {"error": repr(e)}
+        result["roofline"]["small_batch_B2048"] = {k: result["small_batch"].get(k) for k in ("single_launch", "multi_8_per_call", "error") if k in result["small_batch"]}
     result["declared_one_index"]["note"] = ("apply_emb_interact(..., one_index_per_bag=True): the caller states lS_o == arange, the launch "
                                             "does not read it (5 644 algorithmic bytes per sample; frac = those bytes over the wall-clock step)")
     # ---- the same launch at a larger batch (fixed launch / pipeline-fill cost amortised), and reduced precision ----
