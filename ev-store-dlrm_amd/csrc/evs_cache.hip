@@ -90,12 +90,12 @@ __device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOM
 template <typename T>
 __device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, EVS_EXACT_SCOPE); }
 
-__device__ int map_find(const CacheArrays &a, unsigned long long mask, unsigned long long key) {
+__device__ int map_find(const CacheArrays &a, unsigned long long mask, unsigned long long key, long long *empty_slot = nullptr) {
     unsigned long long i = mix64(key) & mask;
     for (;;) {
         const unsigned long long k = ld(&a.keys[i]);
         if (k == key) return ld(&a.slot_entry[i]);
-        if (k == kEmpty) return -1;
+        if (k == kEmpty) { if (empty_slot) *empty_slot = (long long)i; return -1; }   // (where an insert of this key would land)
         i = (i + 1) & mask;
     }
 }
@@ -310,7 +310,8 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
 
         if (cs.policy == kEvLFU) {
             // ---- probe all T keys at once; agg_hit = popcount(ballot)  (EvLFU_C1.py:105-120) ----
-            int e = (lane < T && row_ok) ? map_find(a, mask, key) : -1;
+            long long ins_slot = -1;   // a missing key: the empty slot its probe walk ended on
+            int e = (lane < T && row_ok) ? map_find(a, mask, key, &ins_slot) : -1;
             const unsigned long long hit_mask = __ballot(e >= 0);
             const int agg_hit = __popcll(hit_mask);
             const bool pick_random = args.approx_thres > 0 && agg_hit >= args.approx_thres;  // :122-125
@@ -319,7 +320,29 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             // loop below re-reads them only after an insert of THIS request may have evicted / reused an entry
             const unsigned long long pre_key = e >= 0 ? ld(&a.ekey[e]) : 0ull;
             const int pre_agg = e >= 0 ? ld(&a.eagg[e]) : 0;
+            // Round 5, the same idea for everything else lane 0's serial loop used to fetch one dependent access at a time
+            // (a request with six misses was ~15 round trips of one lane): every lane fetches NOW what its key will need --
+            // a hit whose priority will rise: its list neighbours; a miss: the free entry it will be given (the stack is
+            // popped in table order: the r-th miss of the request gets free_stack[n_free - 1 - r]) -- and knows the map slot
+            // its insert lands in (the empty slot its probe ended on; two new keys that ended on the SAME slot: the later
+            // one probes again).  The loop then only stores -- until something it cannot have foreseen happens (an eviction
+            // or a flush rewrites the map, the stack and the lists: from there on the request takes the old path).
+            const bool my_miss = lane < T && row_ok && e < 0 && !pick_random;
+            const unsigned long long miss_mask = __ballot(my_miss);
+            const int my_rank = __popcll(miss_mask & ((1ull << lane) - 1ull));
+            const int n_free0 = h.n_free;
+            const int pre_free = (my_miss && n_free0 - 1 - my_rank >= 0) ? a.free_stack[n_free0 - 1 - my_rank] : -1;
+            const int pre_prev = (e >= 0 && pre_agg < agg_hit) ? ld(&a.prev[e]) : -1;
+            const int pre_next = (e >= 0 && pre_agg < agg_hit) ? ld(&a.next[e]) : -1;
+            bool slot_clash = false;   // an earlier miss of this request ended on the same empty slot
+            for (int j = 0; j < T; j++) {
+                const long long sj = __shfl((int)(ins_slot & 0xffffffffll), j) | ((long long)__shfl((int)(ins_slot >> 32), j) << 32);
+                const bool mj = (miss_mask >> j) & 1ull;
+                slot_clash |= my_miss && mj && j < lane && sj == ins_slot;
+            }
             bool dirty = false;
+            bool fast_ok = !pick_random;   // nothing unforeseen has happened to the map / the stack yet
+            bool lists_touched = false;    // an unlink of this request may have changed a prefetched neighbour
 #if EVS_X_EXACT_STOP == 2
             if (pre_key != 12345ull || pre_agg != -7) return;
 #endif
@@ -332,6 +355,9 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                 const bool hiti = (hit_mask >> i) & 1ull;
                 const unsigned long long pk = __shfl(pre_key, i);
                 const int pa = __shfl(pre_agg, i);
+                const int pfree = __shfl(pre_free, i), pprev = __shfl(pre_prev, i), pnext = __shfl(pre_next, i);
+                const long long pslot = __shfl((int)(ins_slot & 0xffffffffll), i) | ((long long)__shfl((int)(ins_slot >> 32), i) << 32);
+                const bool pclash = __shfl((int)slot_clash, i) != 0;
                 int src = -1, fill = -1, from = -1;
                 if (lane == 0 && oki) {
                     if (hiti) {
@@ -341,20 +367,41 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                         if (alive) {
                             const int old = dirty ? ld(&a.eagg[ei]) : pa;
                             if (old < agg_hit) {
-                                list_unlink(a, bucket(h, old), ei);
+                                if (!dirty && !lists_touched) {   // list_unlink on the neighbours fetched above
+                                    ListRef l = bucket(h, old);
+                                    if (pprev >= 0) st(&a.next[pprev], pnext); else *l.head = pnext;
+                                    if (pnext >= 0) st(&a.prev[pnext], pprev); else *l.tail = pprev;
+                                    *l.len -= 1;
+                                } else list_unlink(a, bucket(h, old), ei);
+                                lists_touched = true;
                                 list_append(a, bucket(h, agg_hit), ei);
                                 st(&a.eagg[ei], agg_hit);
                             }
                             src = ei;
                         } else {
                             fill = evlfu_set(cs, a, h, mask, ki, agg_hit);
-                            dirty = true;
+                            dirty = true; fast_ok = false;
                         }
                         last_hit_table = i;
                     } else if (pick_random) {  // :142-152: the miss reuses the previous hit's vector
                         from = last_hit_table;
                         src = -2;
+                    } else if (fast_ok && !pclash && pfree >= 0 && h.n_perfect < cs.max_perfect && h.count < cs.cap) {
+                        // evlfu_set without an eviction or a flush, on what was fetched above: stores only
+                        h.last_evicted = 0;
+                        --h.n_free;
+                        st(&a.ekey[pfree], ki);
+                        st(&a.eagg[pfree], agg_hit);
+                        st(&a.slot_entry[pslot], pfree);
+                        st(&a.keys[pslot], ki);
+                        list_append(a, bucket(h, agg_hit), pfree);
+                        h.count++;
+                        if (agg_hit < h.min_c1) h.min_c1 = agg_hit;
+                        fill = pfree;   // (nothing was evicted: no later hit's entry can have been reused -- `dirty` stays as it is)
                     } else {
+                        // (an eviction / a flush pushes entries back on the stack and rewrites map slots: what the later keys of
+                        //  this request fetched in advance is void from here on)
+                        fast_ok = false;   // (also behind a slot clash: the key lands wherever ITS probe ends now -- maybe on the slot a later miss fetched)
                         fill = evlfu_set(cs, a, h, mask, ki, agg_hit);
                         dirty = true;
                     }
@@ -487,15 +534,24 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
 #if EVS_X_EXACT_STOP == 4
         return;
 #endif
-        for (int i = 0; i < T; i++) {
-            const int fe = s_fill[i];
-            if (fe < 0) continue;
+        {   // every new entry's row, table -> arena: lane i moves table i's (one round trip for all of them; it was one key
+            // check and one byte-wise row copy after the other)
+            const int i = lane < T ? lane : 0;
+            const int fe = lane < T ? s_fill[i] : -1;
             // the entry may already have been evicted again by a later key of this request
             const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)s_req[i];
-            if (ld(&a.ekey[fe]) != ki) continue;
-            const unsigned char *rowp = args.backing[i] + (long long)s_req[i] * rb;
-            unsigned char *dst = a.arena + (long long)fe * rb;
-            for (int c = lane; c < rb; c += 64) dst[c] = rowp[c];
+            const bool mine = fe >= 0 && ld(&a.ekey[fe >= 0 ? fe : 0]) == ki;
+            if (mine) {
+                const unsigned char *rowp = args.backing[i] + (long long)s_req[i] * rb;
+                unsigned char *dst = a.arena + (long long)fe * rb;
+                if (((rb | (int)(reinterpret_cast<uintptr_t>(rowp) | reinterpret_cast<uintptr_t>(dst))) & 15) == 0) {
+                    for (int c = 0; c < rb; c += 16) *reinterpret_cast<uint4 *>(dst + c) = *reinterpret_cast<const uint4 *>(rowp + c);
+                } else if (((rb | (int)(reinterpret_cast<uintptr_t>(rowp) | reinterpret_cast<uintptr_t>(dst))) & 3) == 0) {
+                    for (int c = 0; c < rb; c += 4) *reinterpret_cast<unsigned *>(dst + c) = *reinterpret_cast<const unsigned *>(rowp + c);
+                } else {
+                    for (int c = 0; c < rb; c++) dst[c] = rowp[c];
+                }
+            }
         }
         __threadfence_block();   // (the rows are read back by this block only: a workgroup-scope fence; an agent-scope one is an L2 write-back per request, tools/atomic_probe.hip)
         __syncthreads();
