@@ -740,7 +740,7 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
             q1 = c8.batch_stats()
             msq = ea.elapsed_time(eb) / nq
             rp_tier = {"bits": 8, "ms_per_step": msq, "value": T * B / msq * 1e3, "hit_rate": (q1["n_hits"] - q0["n_hits"]) / (T * B * nq), "timed_batches": nq,
-                       "note": "GpuCache(evlfu, 10 % of the rows, codec 8) over the u8 tables: set probe + u8 gather + interaction one launch, one update launch"}
+                       "note": "GpuCache(evlfu, 10 % of the rows, codec 8) over the u8 tables: set probe + claims + u8 gather + interaction + the new rows into the arena, ONE launch (as the fp32 tier)"}
             del c8, ev8
         except Exception as e:
             rp_tier = {"error": repr(e)}

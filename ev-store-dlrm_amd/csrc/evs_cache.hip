@@ -3607,7 +3607,8 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         // the update inside the probe launch too: fp32 rows, the folded fp32 launch, a two-copy arena (EVS_CACHE_INLINE=0: every
         // batch updated by a launch of its own behind it -- the round-4 chain, strict snapshot flags)
         if (c->inline_mode < 0) c->inline_mode = (getenv("EVS_CACHE_INLINE") && getenv("EVS_CACHE_INLINE")[0] == '0') ? 0 : 1;
-        const bool inl = fold && !foldq && c->inline_mode == 1 && c->sa.dual && c->host.codec == 32 && (c->host.row_bytes & 15) == 0;
+        // (a reduced-precision tier takes the same form in its own consumer: evs_fused_rfq.hip, PROBE)
+        const bool inl = fold && c->inline_mode == 1 && c->sa.dual && (foldq || (c->host.codec == 32 && (c->host.row_bytes & 15) == 0));
         if (fold) {
             ProbeArgs pa;
             pa.slots = nullptr; pa.mask = 0; pa.reusable_tomb = kTomb; pa.eagg = nullptr;

@@ -39,7 +39,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef EVS_RFQ_LB4
 #define EVS_RFQ_LB4 5   // u4, folded with aligned windows: 84 VGPRs in the lS_o form (6 blocks per CU = 80 would spill four; 5 vs 6 blocks measured equal)
 #endif
-constexpr int rfq_min_blocks(int codec) { return codec == 16 ? EVS_RFQ_LB16 : codec == 4 ? EVS_RFQ_LB4 : EVS_RFQ_LB8; }
+#ifndef EVS_RFQ_LBP8
+#define EVS_RFQ_LBP8 5   // the u8 PROBE form (a cache tier's head in front: set words, claims): at 80 registers it spills five; 5 blocks per
+#endif                   // CU against 6: 31.4 vs 32.7 us per batch at B = 16 384, 94.3 vs 96.8 at 65 536 (4 blocks: 31.5 / 94.5)
+constexpr int rfq_min_blocks(int codec, bool probe = false) {
+    return codec == 16 ? EVS_RFQ_LB16 : codec == 4 ? EVS_RFQ_LB4 : probe ? EVS_RFQ_LBP8 : EVS_RFQ_LB8;
+}
 #ifndef EVS_RFQ_FOLD
 #define EVS_RFQ_FOLD 1   // developer A/B: 0 = the tail chunk of a d = 36 u8 / u4 row as a load of its own
 #endif
@@ -79,6 +84,23 @@ __device__ __forceinline__ void load_raw(unsigned long long p, unsigned (&w)[N >
     } else {
         static_assert(N == 2, "raw pieces of 16, 12, 8, 4 or 2 bytes");
         w[0] = *reinterpret_cast<const __attribute__((address_space(1))) unsigned short *>((uintptr_t)p);
+    }
+}
+
+// the mirror of load_raw: N raw bytes w[...] -> p (the PROBE form copies the rows of missed keys into the tier's arena)
+template <int N>
+__device__ __forceinline__ void store_raw(unsigned long long p, const unsigned (&w)[N >= 4 ? N / 4 : 1]) {
+    if constexpr (N == 12) {
+        *reinterpret_cast<__attribute__((address_space(1), aligned(4))) u32x3 *>((uintptr_t)p) = (u32x3){w[0], w[1], w[2]};
+    } else if constexpr (N == 16) {
+        *reinterpret_cast<__attribute__((address_space(1), aligned(4))) u32x4 *>((uintptr_t)p) = (u32x4){w[0], w[1], w[2], w[3]};
+    } else if constexpr (N == 8) {
+        *reinterpret_cast<__attribute__((address_space(1), aligned(4))) u32x2 *>((uintptr_t)p) = (u32x2){w[0], w[1]};
+    } else if constexpr (N == 4) {
+        *reinterpret_cast<__attribute__((address_space(1), aligned(2))) unsigned *>((uintptr_t)p) = w[0];
+    } else {
+        static_assert(N == 2, "raw pieces of 16, 12, 8, 4 or 2 bytes");
+        *reinterpret_cast<__attribute__((address_space(1))) unsigned short *>((uintptr_t)p) = (unsigned short)w[0];
     }
 }
 
@@ -130,7 +152,7 @@ __device__ __forceinline__ float dec_elem_q(unsigned w0, unsigned w1, int e, con
 // emb_interact_rf_kernel<..., PROBE> does for an fp32 tier (evs_fused_rf.hip): hits read the arena (bit 30 of the tile
 // entry), misses the table, hit flags / miss lists / statistics go where cache_batch_probe_gather_kernel would have put them.
 template <int CODEC, int CQ, int REM, int NT, bool CHECK = false, bool PROBE = false>
-__global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_kernel(const FusedArgs args) {
+__global__ void __launch_bounds__(256, rfq_min_blocks(CODEC, PROBE)) emb_interact_rfq_kernel(const FusedArgs args) {
     static_assert(!(CHECK && PROBE), "the offsets check belongs to the plain launch");
     // optimistic launches (offsets given, see offsets_arange_kernel in evs_fused.hip): this is the one-index-per-bag loop
     if constexpr (!CHECK && !PROBE) {
@@ -168,7 +190,8 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     // 0.30: tests/test_gpu_parity.py, the bound in DESIGN.md 3.3).
     constexpr bool I8 = CODEC == 8 && FOLD && NT == 2 && EVS_RFQ_I8 != 0;
     __shared__ int s_S[I8 ? 4 : 1][32];            // I8: the rows' byte sums S_i of the sample in hand, per wave
-    __shared__ int s_idx[512];                    // [32 features][16 samples]: row id, sample id (x), -1 = no row
+    __shared__ int s_idx[PROBE ? 1024 : 512];     // [32 features][16 samples]: row id, sample id (x), -1 = no row (PROBE: a second plane,
+                                                  // the arena entry a missed key's row is copied into on the way -- the update folded in)
     __shared__ __attribute__((aligned(16))) float s_x[4][64];
     __shared__ float s_lut[CodecLut<CODEC>::kEntries];
     // u4: a BYTE decodes to two elements at once (element 2j = the high nibble): one 8-byte table read and one byte
@@ -210,9 +233,13 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
         __shared__ int s_psum[2];                 // hits / perfect requests
         __shared__ int s_nlist;                   // misses listed
         __shared__ unsigned s_nrows[32], s_sa_base[32];
+        __shared__ int s_udelta[kMaxBuckets];     // the update folded in (ProbeArgs::arena_w, see evs_fused_rf.hip): the inserts' totals
+        __shared__ int s_ustat[2];
         const ProbeArgs &pa = args.probe;
         const int T = pa.T;
-        for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_pdelta[i] = 0;
+        const bool ins = pa.arena_w != nullptr;   // block-uniform
+        for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) { s_pdelta[i] = 0; s_udelta[i] = 0; }
+        if (threadIdx.x < 2) s_ustat[threadIdx.x] = 0;
         if (threadIdx.x < 16) s_agg[threadIdx.x] = 0;
         if (threadIdx.x < 2) s_psum[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_nlist = 0;
@@ -243,22 +270,35 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
             if (!pok[h]) pset[h] = 0u;
         }
         SaLine line[2];
+        unsigned lw[2][8];   // the two keys' set ways (kept for the claim of a missed key)
 #pragma unroll
         for (int h = 0; h < 2; h++) sa_load<8>(pa.sa, pset[h], line[h]);
         __builtin_amdgcn_sched_barrier(0);   // both keys' set records in one round trip
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             unsigned w;
-            const int way = sa_find<8>(pa.sa, line[h], ptag[h], w);
+            const int way = sa_find<8>(pa.sa, line[h], ptag[h], w, pa.pend_stamp);
             const bool found = pok[h] && way >= 0;
             pe[h] = found ? (int)sa_entry(pa.sa, pset[h], (unsigned)way, w) : -1;
             pway[h] = way;
             pprio[h] = found ? sa_prio(w) : 0x7fffffff;
             pw0[h] = w;
+#pragma unroll
+            for (int j = 0; j < 8; j++) lw[h][j] = sa_way_word(line[h], j);
             if (found) atomicAdd(&s_agg[threadIdx.x & 15], 1);
         }
         __syncthreads();
         const int agg = s_agg[threadIdx.x & 15];
+        // a missed key claims a way of its set here (evs_fused_rf.hip's PROBE head has the reasoning): the CAS travels with the raises
+        int uwon[2] = {-1, -1};
+        unsigned uprev[2] = {0u, 0u};
+        SaPick upk[2] = {{-1, 0, -1, 0u, 0u}, {-1, 0, -1, 0u, 0u}};
+        bool uwait[2] = {false, false};
+        if (ins) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (pok[h] && pe[h] < 0) uwait[h] = sa_claim_issue(pa.sa, pa.pend_stamp, pset[h], ptag[h], agg, lw[h], upk[h], uprev[h], s_udelta);
+        }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int f = ((int)threadIdx.x >> 4) + 16 * h;
@@ -270,11 +310,15 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
             if (f == 0) v = bs < blk_end ? (int)bs : -1;                 // x: the sample number
             else if (pact[h]) v = pe[h] >= 0 ? (int)(0x40000000u | (unsigned)pe[h]) : (pok[h] ? prow[h] : -1);
             s_idx[(int)threadIdx.x + 256 * h] = v;
+            if (ins) {   // where the gathered row of a missed key goes (-1: nowhere)
+                if (uwait[h]) uwon[h] = sa_claim_finish(pa.sa, pa.pend_stamp, pset[h], ptag[h], agg, lw[h], upk[h], uprev[h], s_udelta, s_ustat);
+                s_idx[512 + (int)threadIdx.x + 256 * h] = uwon[h];
+            }
             if (pact[h]) {
                 const int64_t m = bs * (int64_t)T + (f - 1);
                 if (pa.hit) pa.hit[m] = pe[h] >= 0;
                 if (!pok[h]) bad = true;
-                if (pok[h] && pe[h] < 0) {
+                if (pa.miss_rec != nullptr && pok[h] && pe[h] < 0) {
                     const int at = atomicAdd(&s_nlist, 1);
                     pa.miss_rec[(int64_t)blockIdx.x * pa.list_cap + at] = make_uint4((unsigned)prow[h], (unsigned)(f - 1) | ((unsigned)agg << 8), pset[h], ptag[h]);
                 }
@@ -287,7 +331,12 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
             const int v = i <= T ? s_pdelta[i] : i == 38 ? s_psum[0] : i == 39 ? s_psum[1] : 0;
             if (v) atomicAdd(&pa.part1[(blockIdx.x % 32) * 40 + i], v);
         }
-        if (threadIdx.x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
+        if (ins && threadIdx.x < 40) {   // the inserts' totals, as the update kernels leave them (folded by the cache's close)
+            const int i = threadIdx.x;
+            const int v = i <= T ? s_udelta[i] : i == 33 ? s_ustat[0] : i == 34 ? s_ustat[1] : 0;
+            if (v) atomicAdd(&pa.part2[(blockIdx.x % 32) * 40 + i], v);
+        }
+        if (pa.list_cnt != nullptr && threadIdx.x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
     } else
     {
         const int64_t bs = blk_first + (threadIdx.x & 15);
@@ -600,9 +649,37 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC)) emb_interact_rfq_k
     __builtin_amdgcn_sched_barrier(0);   // keep every request above the first consume
 
 
+    const bool ins_blk = PROBE && args.probe.arena_w != nullptr;   // block-uniform: missed keys' rows go into the tier's arena on the way
 #pragma unroll
     for (int u = 0; u < D; u++) {
         const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;   // wave-uniform
+        if constexpr (PROBE) {
+            if (ins_blk) {   // the rows of the ways this block claimed (s_idx's second plane): from the registers that gathered them
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) {
+                    const int e = s_idx[512 + (r16 + 16 * rr) * 16 + wave_in_block + 4 * u];
+                    if (e >= 0) {
+                        const unsigned long long dst = (unsigned long long)reinterpret_cast<uintptr_t>(args.probe.arena_w) + (unsigned long long)(unsigned)e * (unsigned)row_bytes;
+                        if constexpr (FOLD && CODEC == 8) {
+                            store_raw<12>(dst + 8u * (unsigned)q, rmain[u][rr]);   // (bytes 8 q .. 8 q + 11: the overlaps carry the same bytes)
+                        } else if constexpr (FOLD) {   // u4: k-slots 0..2 hold bytes 4 q .. 4 q + 3 in a window that starts 2 bytes early on odd rows
+                            const unsigned par = FOLD4A ? (odd_rows >> (u * NR + rr)) & 1u : 0u;
+                            const unsigned long long w01 = ((unsigned long long)rmain[u][rr][1] << 32) | rmain[u][rr][0];
+                            const unsigned v0[1] = {q < 3 ? (unsigned)(w01 >> (16u * par)) : rmain[u][rr][0]};
+                            store_raw<4>(dst + (q < 3 ? 4u * (unsigned)q : 10u), v0);
+                            const unsigned v1[1] = {rmain[u][rr][1]};
+                            if (q == 3) store_raw<4>(dst + 14u, v1);
+                        } else {
+                            store_raw<kMainBytes>(dst + (unsigned)(q * kMainBytes), rmain[u][rr]);
+                            if (q == 3) {
+#pragma unroll
+                                for (int t = 0; t < REM; t++) store_raw<kChunkBytes>(dst + 4 * kMainBytes + t * kChunkBytes, rrem[u][rr][t]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
         my_x[lane] = rx[u];
         if constexpr (I8) {
             flush_out(b - 4, u > 0 && u - 1 < n_samples);    // sample u-1 leaves under this sample's work

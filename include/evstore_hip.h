@@ -372,8 +372,8 @@ EVS_API int evs_cache_lookup_batch(evs_cache *c, int64_t B, const int32_t *rows,
  *     OR one of this batch's inserts retired it first (at most as many keys as the batch evicted; the row is then served from
  *     the table, exact as ever, and the key is inserted again like any other miss).  Keys inserted by batch k are hits from
  *     batch k + 1 on.  Everything listed under "WHAT IS THE SAME" below holds unchanged.  EVS_CACHE_INLINE=0 (environment)
- *     keeps the update as a launch of its own behind the probe: strict snapshot flags, as evs_cache_lookup_batch and the
- *     reduced-precision tiers always have.
+ *     keeps the update as a launch of its own behind the probe: strict snapshot flags, as evs_cache_lookup_batch always has.
+ *     (A single reduced-precision tier -- codec 16 / 8 / 4, d in {16, 32, 36} -- takes the same one-launch form.)
  *     A C1 + C2 pair that starts out together SHARES its set records: one
  *     128-byte line per set index holds C1's 8 ways and C2's ways (two 8-way sub-sets, picked by one more bit of the
  *     quotient, for the reference's 1 : 2 capacity split, evlfu_8.cpp:63-78), so a key's two tier probes are ONE line

@@ -451,11 +451,13 @@ def _sa_sets(keys_tr, nset, n_rows, bits):
     return (x % np.uint64(nset)).astype(np.int64)
 
 
-@pytest.mark.parametrize("cap_frac,batch", [(0.10, 512), (0.02, 160), (0.3, 4100)])
-def test_update_inside_the_probe_launch_of_the_set_associative_tier(E, orc, cap_frac, batch):
-    """Round 5: evs_cache_lookup_interact on a set-associative fp32 tier makes the batch's policy update INSIDE the probe +
+@pytest.mark.parametrize("cap_frac,batch,codec", [(0.10, 512, 32), (0.02, 160, 32), (0.3, 4100, 32),
+                                                  (0.10, 512, 8), (0.02, 160, 4), (0.3, 1300, 16), (0.05, 700, 4)])
+def test_update_inside_the_probe_launch_of_the_set_associative_tier(E, orc, cap_frac, batch, codec):
+    """Round 5: evs_cache_lookup_interact on a set-associative tier makes the batch's policy update INSIDE the probe +
     interaction launch (csrc/evs_fused_rf.hip, ProbeArgs::arena_w: the thread that misses a key claims a way of its set, the
-    lanes that gather the row store it into the arena; two arena rows per way, evs_hash.h).  Lookups back to back: R of every
+    lanes that gather the row store it into the arena; two arena rows per way, evs_hash.h; a reduced-precision tier does the
+    same in its consumer, csrc/evs_fused_rfq.hip -- its lanes hold the raw bytes).  Lookups back to back: R of every
     batch = the interaction over the TRUE table rows whatever is being replaced underneath (rtol 1e-5 vs the oracle).  A hit
     flag says the row came from the cache: flag => the key was resident when the batch arrived; a resident key flagged as a
     miss was retired by this very batch's inserts (at most as many as it evicted).  Behind every batch: no duplicate keys,
@@ -465,13 +467,18 @@ def test_update_inside_the_probe_launch_of_the_set_associative_tier(E, orc, cap_
     n_rows = [3000, 40, 20000, 700, 5, 9000, 1500, 12, 26000, 300, 8000, 64, 2200, 17000, 3, 450, 5000, 90, 13000,
               2, 7000, 30, 1000, 11000, 150, 4000]
     tabs = orc.kaggle_tables(n_rows, 21)
-    dev_tabs = [torch.from_numpy(t).cuda() for t in tabs]
+    if codec == 32:
+        dev_tabs = [torch.from_numpy(t).cuda() for t in tabs]
+    else:   # (the rows the interaction sees: the decoded ones; spread over the codec's range so that rows differ)
+        raws = [orc.encode_table(np.clip(t * np.sqrt(len(t)), -1, 1), codec) for t in tabs]
+        dev_tabs = [torch.from_numpy(a).cuda() for a in raws]
+        tabs = [orc.decode(a, codec, 36) for a in raws]
     cap = int(cap_frac * sum(n_rows))
     reqs = _zipf_requests(n_rows, 9 * batch, 5)
     rs = np.random.RandomState(6)
     x_np = rs.uniform(-1, 1, size=(batch, 36)).astype(np.float32)
     x = torch.from_numpy(x_np).cuda()
-    c = E.GpuCache("evlfu", cap, 26, 36, 32, "python").set_batch_policy("setassoc")
+    c = E.GpuCache("evlfu", cap, 26, 36, codec, "python").set_batch_policy("setassoc")
     c.set_backing(dev_tabs)
     r = torch.from_numpy(reqs).cuda()
     nset, ways, _, bits = _sa_geom(cap, n_rows)
@@ -524,6 +531,16 @@ def test_update_inside_the_probe_launch_of_the_set_associative_tier(E, orc, cap_
                 assert (per_set[_sa_sets(gone, nset, n_rows, bits)] == ways).all()
         k += run
     assert st0["n_hits"] == flags_seen and st0["n_requests"] == k * batch
+    # what the launches left in the arena, bit for bit: the last batches again through the rows-out path (the update as a launch
+    # of its own: snapshot flags) -- every resident key is served from the arena
+    for j in (k - 2, k - 1):
+        rq = reqs[j * batch:(j + 1) * batch]
+        hit, out = c.lookup_batch(r[j * batch:(j + 1) * batch].contiguous())
+        hit, out = hit.cpu().numpy().astype(bool), out.cpu().numpy()
+        assert np.array_equal(hit, np.array([[(t + 1, int(rq[b, t])) in res for t in range(26)] for b in range(batch)])) and hit.any()
+        for t in range(26):
+            assert np.array_equal(out[:, t, :].view(np.uint32), tabs[t][rq[:, t]].view(np.uint32))
+        res, _ = residents()
 
 
 @pytest.mark.parametrize("policy", POLICIES1)
@@ -974,10 +991,19 @@ def test_single_tier_reduced_precision_interaction_consumer(E, orc, codec, d, T,
         np.testing.assert_allclose(R.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
         assert torch.equal(R[:, :d], x)
         h = hit.cpu().numpy()
-        # the flags are the snapshot: residency when the batch arrived (the probe folded into the consumer or not)
-        assert np.array_equal(h.astype(bool), np.array([[(k + 1, int(rq[b, k])) in resident for k in range(T)] for b in range(B)]))
-        saw_hit |= bool(h.any()); saw_miss |= bool((h == 0).any())
+        was = np.array([[(k + 1, int(rq[b, k])) in resident for k in range(T)] for b in range(B)])
+        ev0 = ev1 if it else 0
         st = c.batch_stats()
+        ev1 = st["n_evict"]
+        if policy == "setassoc":
+            # the update inside the launch (test_update_inside_the_probe_launch...): a flag says the row came from the cache, so the
+            # key was resident when the batch arrived; a resident key read from its table was retired by this batch's own inserts
+            assert not (h.astype(bool) & ~was).any()
+            assert len({(k, int(rq[b, k])) for b, k in zip(*np.nonzero(was & ~h.astype(bool)))}) <= ev1 - ev0
+        else:
+            # the flags are the snapshot: residency when the batch arrived (the probe folded into the consumer or not)
+            assert np.array_equal(h.astype(bool), was)
+        saw_hit |= bool(h.any()); saw_miss |= bool((h == 0).any())
         keys = [(int(t), int(rw)) for _, t, rw in c.batch_dump()]
         assert len(set(keys)) == len(keys) == st["size"] <= 500
     assert saw_hit and saw_miss and c.batch_stats()["size"] <= 500

@@ -8,7 +8,7 @@ import evstore_dlrm_amd as E
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-T, d, B = 26, 36, 16384
+T, d, B = 26, 36, int(os.environ.get("B", 16384))
 ev = bench.make_tables(bench.KAGGLE_LN, d, seed=0, device=dev)
 rq = [b[1].t().contiguous().to(torch.int32) for b in bench.make_batches(bench.KAGGLE_LN, B, 60 + 200, seed=3, device=dev, dist="zipf", alpha=0.75)]
 x = torch.rand((B, d), device=dev)

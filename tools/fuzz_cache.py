@@ -231,7 +231,7 @@ def batched_case(rs, case):
         hits_total += int(hit.sum())
         ev_before = st_prev["n_evict"] if st_prev else 0
         dmp, st = c.batch_dump(), c.batch_stats()
-        if was_interact and policy == "setassoc" and codec == 32 and os.environ.get("EVS_CACHE_INLINE", "1") != "0" and os.environ.get("EVS_SA_DUAL", "1") != "0":
+        if was_interact and policy == "setassoc" and os.environ.get("EVS_CACHE_INLINE", "1") != "0" and os.environ.get("EVS_SA_DUAL", "1") != "0":
             # round 5: the update runs inside the probe + interaction launch -- a flag says "served from the cache": never for a key
             # that was not resident when the batch arrived; a resident key reported as a miss was retired by this batch's own inserts
             assert not (hit & ~want_hit).any(), tag + ": a hit flag for a key that was not resident"
