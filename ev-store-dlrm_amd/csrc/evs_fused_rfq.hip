@@ -426,7 +426,11 @@ __global__ void __launch_bounds__(256, rfq_min_blocks(CODEC, PROBE)) emb_interac
         // (row 0 -- x, fp32, spread from LDS below -- and the rows past F read the zero-code page like an absent row)
         const bool on = f >= 1 && f < F;
         fbase[rr] = on ? (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]) : zc_p;
+#ifdef EVS_X_STRIDE     // developer probe (tools/stride_probe.py; timing only): rows every EVS_X_STRIDE bytes
+        fscale[rr] = on ? (unsigned)EVS_X_STRIDE : 0u;
+#else
         fscale[rr] = on ? (unsigned)row_bytes : 0u;
+#endif
     }
     const unsigned long long xbase = (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[0]);
     const unsigned xscale = (unsigned)(ka->stride[0] * 4);
