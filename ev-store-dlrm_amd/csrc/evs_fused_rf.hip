@@ -617,7 +617,10 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         // a missed key's claim: duplicate / victim / the CAS sent here, looked at behind the raises below (one round trip for both).
         // (Looked at behind the ROW requests instead -- the claim kept across them, block barriers that order LDS only -- was
         // built and measured on one box: 34.4 against 32.5 us per batch, the kernel sits at its 128 registers; the new rows as
-        // predicated buffer stores instead of stores under an exec mask: 33.3.  tools/cache_lib_ab.sh)
+        // predicated buffer stores instead of stores under an exec mask: 33.3.  The lean form of the first -- only the CAS's answer,
+        // the victim's word and the way carried across the requests, a lost CAS re-reading its set: 128 registers, no spill --
+        // measured EQUAL, 34.8-35.2 against 34.8-35.5 on its box: the CAS's round trip is not what the launch waits for.
+        // tools/cache_lib_ab.sh)
         int uwon[2] = {-1, -1};
         unsigned uprev[2] = {0u, 0u};
         SaPick upk[2] = {{-1, 0, -1, 0u, 0u}, {-1, 0, -1, 0u, 0u}};
