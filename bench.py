@@ -30,6 +30,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import evstore_dlrm_amd  # noqa: E402,F401  (before the first call into the runtime: the package's hardware-queue default, __init__.py)
 
 KAGGLE_LN = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593,
              3194, 27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
