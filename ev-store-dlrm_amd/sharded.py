@@ -956,6 +956,7 @@ def verify_p2p_against_collective(ln_emb, d, rank, world, weights, backend, poli
     the verdict is agreed on over the process group (all ranks return the same bool, none raises).  Cost: two ops' buffers
     and one step each."""
     ok = 1
+    verify_p2p_against_collective.last_error = None   # this rank's reason when the verdict is False because something raised
     try:
         recvs = []
         for mode in ("inline", "p2p"):
@@ -984,8 +985,9 @@ def verify_p2p_against_collective(ln_emb, d, rank, world, weights, backend, poli
             del op
         if ok and not torch.equal(recvs[0], recvs[1]):
             ok = 0
-    except Exception:
+    except Exception as ex:
         ok = 0
+        verify_p2p_against_collective.last_error = repr(ex)
     t = torch.tensor([ok], device=backend.device, dtype=torch.int32)
     try:
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -1006,6 +1008,9 @@ def bench_p2p_side(args, ln_emb, rank, world, dev):
         budget_rows = int(getattr(args, "replicate_gb", 64.0) * 1e9 / (4 * args.dim))
         verified = _verify_for_bench(args, ln_emb, rank, world, dev, policy, budget_rows)
         if not verified:
+            why = getattr(verify_p2p_against_collective, "last_error", None)
+            if why:   # the exchange could not even be set up / run on this rank (or a peer said so in the hand-shake)
+                return {"verified": False, "error": why}
             return {"verified": False, "skipped": "one batch through both exchanges: the p2p receive buffers differ from the RCCL ones (or a "
                                                   "hand-over did not arrive) on some rank -- not timed; the RCCL line above stands"}
         e = _bench_policy(a, ln_emb, rank, world, dev, policy, budget_rows, True)

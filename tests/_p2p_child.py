@@ -27,7 +27,7 @@ def main():
         res = sharded.bench_p2p_side(args, [5000, 7, 2600, 40, 9000, 3, 12000] + [100] * 19, rank, world, dev)
         dist.barrier()
         dist.destroy_process_group()
-        print("P2P_BENCH %s" % ("error: " + res["error"] if "error" in res else "ok %.3f ms" % res["ms_per_step"]))
+        print("P2P_BENCH %s" % ("error: " + res["error"] if "error" in res else ("ok %.3f ms" % res["ms_per_step"] if "ms_per_step" in res else "other: %r" % (res,))))
         return
     rs = np.random.RandomState(3)                      # (the same model and batches in every process)
     ln = [5000, 7, 2600, 40, 9000, 3, 12000] + [100] * 19
