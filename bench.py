@@ -458,6 +458,31 @@ def batch1_plugin_section(ev, ln_emb, d, dev, n_req=4000, cap=200000, cdf_dir=No
     return res
 
 
+def memory_calibration(dev, mb=980, reps=10):
+    """Measured on the box the bench runs on: a device-to-device copy (read + write streams, what the headline launch's mix of
+    70 MB read / 26 MB written resembles) and a fill (write only) of buffers far beyond the 256 MiB Infinity Cache.  The
+    datasheet's 8 TB/s stays `peak`; these say what plain streams reach (r05: copy 5.1-5.6 TB/s, fill 6.7-7.0)."""
+    n = mb * 1000 * 1000 // 4
+    a = torch.empty(n, device=dev, dtype=torch.float32).fill_(1.0)
+    b = torch.empty(n, device=dev, dtype=torch.float32)
+    out = {}
+    for name, fn, vol in (("device_copy_GBps", lambda: b.copy_(a), 2 * mb), ("fill_GBps", lambda: b.fill_(2.0), mb)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = vol * 1e6 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+    out["buffer_MB"] = mb
+    out["note"] = "torch copy_ / fill_ of %d MB fp32 buffers, HIP events over %d calls; copy counts bytes read + bytes written" % (mb, reps)
+    del a, b
+    return out
+
+
 def _tier_traffic(B, d, frac, alpha, policy):
     """HBM bytes per batch of the cache tier's launch chain from the committed PMC passes (profiles/traffic.json), for the
     configuration they were taken on; None otherwise."""
@@ -1110,6 +1135,15 @@ def main():
                                              "last blocks drain under the next batch's first ones; bit-identical to K single launches"}
         except Exception as e:
             result["multi_batch"] = {"error": repr(e)}
+    # ---- what this part's memory system gives plain streams of the same size class (a calibration beside the datasheet peak) ----
+    if not args.no_extras:
+        try:
+            result["roofline"]["calibration"] = memory_calibration(dev)
+            cp = result["roofline"]["calibration"].get("device_copy_GBps")
+            if cp:
+                result["roofline"]["frac_of_device_copy"] = result["roofline"]["achieved"] / cp
+        except Exception as e:
+            result["roofline"]["calibration"] = {"error": repr(e)}
     # ---- small batches (B = 2 048: a single launch is mostly its fixed part; a serving loop with a queue hands K batches per call) ----
     if not args.no_extras:
         try:
