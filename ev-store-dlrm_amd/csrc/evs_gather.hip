@@ -444,6 +444,53 @@ __global__ void __launch_bounds__(256, (NJ > 5 ? 2 : 4)) gather_rows_kernel(cons
     } else {
         __syncthreads();
     }
+#ifndef EVS_GR_FLAT
+#define EVS_GR_FLAT 1
+#endif
+    // ---- table-major output (consecutive bags of a table are consecutive rows: the reference's list of T (B, d) tensors, the
+    // blocks of the all-to-all send buffer): the FLAT mapping (round 5).  The block's 16 rows of one table are one aligned run
+    // of 16 LPRD 16-byte pieces; piece P of the block = (table P / (16 LPRD), bag (P % (16 LPRD)) / LPRD, piece P % LPRD), and
+    // instruction i of wave w takes pieces [256 i + 64 w, + 64): every store instruction is 1 024 contiguous bytes that start on a
+    // line -- whole lines only.  The sample-major mapping below writes a table-major output as 144-byte runs, two partial lines
+    // each, and the launch is priced by its line requests, loads and stores alike (tools/gather_ablate.sh: u8 at B = 65 536,
+    // loads only 33 us, stores only 58, both 109).
+    if (EVS_GR_FLAT && args.out_bstride == 4 * LPRD) {   // kernel-uniform
+        constexpr int PT = 16 * LPRD;
+        const int n_pieces = T * PT;
+        const int blk_n = (int)(blk_end - blk_first);
+        piece_t fring[4 * NJ];
+#pragma unroll
+        for (int i = 0; i < 4 * NJ; i++) {
+            const int P = 256 * i + 64 * wave + lane;
+            const int Pc = P < n_pieces ? P : 0;
+            const int t = Pc / PT, q = Pc - t * PT, sm = q / LPRD, piece = q - sm * LPRD;
+            const int iv = (P < n_pieces && sm < blk_n) ? s_idx[t * 16 + sm] : -1;
+            const unsigned long long neg = 0ull - (unsigned long long)((unsigned)iv >> 31);
+            const unsigned long long p = s_base[t] + (unsigned long long)(piece * PB) + (unsigned long long)((unsigned)iv & 0x7fffffffu) * (unsigned long long)row_bytes;
+            const unsigned long long zp = (unsigned long long)reinterpret_cast<uintptr_t>(args.zeros) + (unsigned long long)(piece * PB);
+            fring[i] = *reinterpret_cast<gpiece_t>((uintptr_t)(p ^ ((p ^ zp) & neg)));
+            if ((i + 1) % NJ == 0) __builtin_amdgcn_sched_barrier(0);   // (address temporaries of NJ requests alive at a time, not of all 4 NJ)
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * NJ; i++) {
+            int P = 256 * i + 64 * wave + lane;
+            asm volatile("" : "+v"(P));   // (computed again, not carried from the request loop: 4 NJ x {table, bag, piece} in registers spill the fp32 forms)
+            const int Pc = P < n_pieces ? P : 0;
+            const int t = Pc / PT, q = Pc - t * PT, sm = q / LPRD, piece = q - sm * LPRD;
+            gr_f32x4 o;
+            if constexpr (CODEC == 32) o = fring[i];
+            else {
+                float4 f;
+                if constexpr (CODEC == 16) f = dec_chunk<16>(fring[i].x, fring[i].y, s_lut);
+                else f = dec_chunk<CODEC>((unsigned)fring[i], 0u, s_lut);
+                o.x = f.x; o.y = f.y; o.z = f.z; o.w = f.w;
+            }
+            if (P < n_pieces && sm < blk_n)
+                *reinterpret_cast<gr_f32x4 *>((uintptr_t)(s_obase[t] + (unsigned long long)(out_off(blk_first + sm) * 4) + (unsigned long long)(piece * 16))) = o;
+        }
+        if (bad) atomicOr(args.err, 1);
+        return;
+    }
     // ---- the rows of this wave's samples wave, wave + 4, wave + 8, wave + 12 ----------------------------------------------
     const int r0 = lane / LPRD, piece16 = (lane - r0 * LPRD) * 16, piece_in = (lane - r0 * LPRD) * PB;
     const bool lane_on = r0 < RPI;
