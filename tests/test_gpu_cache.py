@@ -1008,6 +1008,14 @@ def test_single_tier_reduced_precision_interaction_consumer(E, orc, codec, d, T,
         assert len(set(keys)) == len(keys) == st["size"] <= 500
     assert saw_hit and saw_miss and c.batch_stats()["size"] <= 500
     assert c.batch_stats()["n_requests"] == 6 * B
+    # what the launches left in the arena (the one-launch form copies the gathered rows' raw bytes there), bit for bit: the last
+    # requests again through the rows-out path -- every resident key is served from the arena
+    resident = {(int(t), int(rw)) for _, t, rw in c.batch_dump()}
+    hit, out = c.lookup_batch(torch.from_numpy(rq).cuda())
+    hit, out = hit.cpu().numpy().astype(bool), out.cpu().numpy()
+    assert np.array_equal(hit, np.array([[(k + 1, int(rq[b, k])) in resident for k in range(T)] for b in range(B)])) and hit.any()
+    for k in range(T):
+        assert np.array_equal(out[:, k, :].view(np.uint32), dec[k][rq[:, k]].view(np.uint32))
 
 
 @pytest.mark.parametrize("cap", [50, 64, 257])
