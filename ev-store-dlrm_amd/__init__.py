@@ -11,7 +11,8 @@ import os as _os
 # of the caller's that is folded onto the same one waits until the server goes home idle (measured through the plug-in loop in
 # a process with six streams: 299 us per request against 102 with eight queues).  A default, never an override; it counts only
 # when the package is imported before the first call into the runtime.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if _os.environ.get("EVS_KEEP_HW_QUEUES", "0") != "1":   # (EVS_KEEP_HW_QUEUES=1: leave the runtime's own default alone)
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _lib, dlrm_ops, gpu_cache  # noqa: E402
 from ._lib import EvsError, build  # noqa: E402
