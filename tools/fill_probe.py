@@ -1,3 +1,5 @@
+"""Yardstick: what plain streams reach on this part -- torch fill_ (write only) and copy_ (read + write) of 61 MB .. 2 GB buffers
+(r05: fill 6.7-7.0 TB/s, copy 5.1-5.6 TB/s beyond the Infinity Cache); bench.py measures the same each run (roofline.calibration)."""
 import torch, time
 dev = torch.device("cuda", 0)
 def t(fn, n=50):

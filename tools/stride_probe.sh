@@ -1,3 +1,5 @@
+# On the GPU box: tools/stride_probe.py for u8 / u16 / u4 at the tight stride (shipped library) and at 64 / 128 / 32 bytes
+# (libraries built by tools/variants.sh s64@evs_fused_rfq:"-DEVS_X_STRIDE=64" ...)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 V=$R/ev-store-dlrm_amd/lib/var
 for rep in 1 2; do
