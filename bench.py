@@ -915,6 +915,7 @@ def main():
 
     # ---- timed region: exactly K steps, nothing but the launches between the two syncs ----
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()   # (torch creates the HIP event at an Event's FIRST record: tens of microseconds each, which a 20-step region shows)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e0.record()
