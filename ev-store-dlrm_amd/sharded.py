@@ -886,19 +886,20 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     run(args.warmup)
     run(1500)   # clock settle: a FIXED number of untimed steps (every rank must issue the same collectives)
     op.p2p_flush()
+    e_end = torch.cuda.Event()
+    e_end.record()             # (torch creates the HIP event at the first record: tens of microseconds that do not belong in a 20-step region)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps)
     op.p2p_flush()
-    e_end = torch.cuda.Event()
     e_end.record()
     while not e_end.query():   # (poll, then the closing synchronise: a blocking one wakes up tens of microseconds late)
         pass
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0   # this rank's K steps, from the common start to its own completion; the job's time is the MAX below
     dist.barrier()
-    dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
