@@ -75,17 +75,21 @@ def _query_keys(rows_np):
     return (t << 32) | rows_np.astype(np.int64)
 
 
-@pytest.mark.parametrize("policy", ["sampled", "plan", "setassoc", "setassoc-two-launches"])
+@pytest.mark.parametrize("policy", ["sampled", "plan", "setassoc", "setassoc-two-launches", "setassoc-u8"])
 def test_bench_cache_tier_workload_at_full_size(E, orc, kaggle, oracle_rates, policy, monkeypatch):
     """"setassoc" = the library's default for this workload: the policy update inside the probe + interaction launch (round 5);
-    "setassoc-two-launches" = EVS_CACHE_INLINE=0, the update as a launch of its own (strict snapshot flags)."""
+    "setassoc-two-launches" = EVS_CACHE_INLINE=0, the update as a launch of its own (strict snapshot flags); "setassoc-u8" = the
+    same one-launch form of a single u8 tier over the tables encoded to 8 bits (the reference's one-layer evlfu_8 build)."""
     ev, ln, cap = kaggle["ev"], kaggle["ln"], kaggle["cap"]
     T = len(ln)
     assert cap == 3376257
-    inline = policy == "setassoc"
+    inline = policy in ("setassoc", "setassoc-u8")
+    codec = 8 if policy.endswith("-u8") else 32
+    if codec != 32:
+        ev = ev.encode(codec)
     monkeypatch.setenv("EVS_CACHE_INLINE", "1" if inline else "0")   # (read when the cache takes its first batch)
     policy = policy.split("-")[0]
-    cache = E.GpuCache("evlfu", cap, T, D, 32, "python", "cuda").set_batch_policy(policy)
+    cache = E.GpuCache("evlfu", cap, T, D, codec, "python", "cuda").set_batch_policy(policy)
     cache.set_backing(ev)
     g = torch.Generator(device="cuda").manual_seed(17)
     x = torch.rand((B, D), device="cuda", generator=g)
@@ -126,7 +130,8 @@ def test_bench_cache_tier_workload_at_full_size(E, orc, kaggle, oracle_rates, po
         # ... and sampled samples against the oracle
         sel = np.sort(rs.choice(B, 48, replace=False))
         sel_t = torch.from_numpy(sel).cuda()
-        ly = [ev.fp32_view(k)[idx[k][sel_t]].cpu().numpy() for k in range(T)]
+        ly = [ev.fp32_view(k)[idx[k][sel_t]].cpu().numpy() if codec == 32 else
+              orc.decode(ev.raw[k][idx[k][sel_t]].cpu().numpy(), codec, D) for k in range(T)]
         want = orc.interact_features(x[sel_t].cpu().numpy(), ly)
         np.testing.assert_allclose(R[sel_t].cpu().numpy(), want, rtol=RTOL, atol=2e-6)
         st = cache.batch_stats()
