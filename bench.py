@@ -469,16 +469,20 @@ def memory_calibration(dev, mb=980, reps=10):
     for name, fn, vol in (("device_copy_GBps", lambda: b.copy_(a), 2 * mb), ("fill_GBps", lambda: b.fill_(2.0), mb)):
         for _ in range(3):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        out[name] = vol * 1e6 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+        best = None
+        for _ in range(3):   # (three windows, the fastest: a yardstick should not read low because of a hiccup)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            best = ms if best is None or ms < best else best
+        out[name] = vol * 1e6 / (best * 1e-3) / 1e9
     out["buffer_MB"] = mb
-    out["note"] = "torch copy_ / fill_ of %d MB fp32 buffers, HIP events over %d calls; copy counts bytes read + bytes written" % (mb, reps)
+    out["note"] = "torch copy_ / fill_ of %d MB fp32 buffers, HIP events over %d calls, the fastest of three windows; copy counts bytes read + bytes written" % (mb, reps)
     del a, b
     return out
 
