@@ -120,7 +120,7 @@ class _ModuleCache:
         when this request has to take the generic path."""
         if not getattr(self, "_bound", False):
             self._bind()
-        if self.engine != "host" or not torch.is_tensor(lS_i) or lS_i.dtype not in (torch.int64, torch.int32) \
+        if not torch.is_tensor(lS_i) or lS_i.dtype not in (torch.int64, torch.int32) \
                 or lS_i.dim() < 1 or lS_i.shape[0] != self.n_tables or lS_i.numel() < self.n_tables \
                 or (lS_i.is_cuda and (lS_i.dtype != torch.int64 or not use_gpu)):
             return None
@@ -128,6 +128,15 @@ class _ModuleCache:
         X = _ext.ext()
         if X is None:
             return None
+        if self.engine != "host":
+            # the GPU engine's resident server (see _run): the same one-call body -- ids through pinned staging, the request
+            # through the mailbox, the 26 tensors over one copy of the answer's ring slot
+            if not use_gpu or self.n_tables > 30 or not hasattr(X, "serve_request_list"):
+                return None
+            if self._serving != approx_thres:
+                self.cache.serve_start(approx_thres, n_slots=4, idle_us=200)
+                self._serving = approx_thres
+            return X.serve_request_list(self.cache._h.value, lS_i, self.cache.serve_ring, self.n_tables, self.dim)
         return X.hostcache_request_list(self.cache._h.value, lS_i, self.n_tables, self.dim, int(approx_thres), bool(use_gpu),
                                         self._device.index or 0)
 

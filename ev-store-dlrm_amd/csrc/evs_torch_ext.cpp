@@ -294,9 +294,8 @@ std::vector<at::Tensor> slices(const at::Tensor &block, bool requires_grad) {
 // asynchronous copy + one stream synchronise), and with use_gpu the rows go back through pinned staging too (asynchronous:
 // the consumers are stream-ordered behind it; a staging slot is re-used four requests later, and every request
 // synchronises the stream first).
-py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i_in, int T, int d, int approx_thres, bool use_gpu, int device_index) {
+static void first_ids(const at::Tensor &lS_i_in, int T, int32_t (&ids)[64]) {
     TORCH_CHECK(lS_i_in.dim() >= 1 && lS_i_in.size(0) == T && lS_i_in.numel() >= T, "lS_i must have one non-empty row per table");
-    int32_t ids[64];
     TORCH_CHECK(T <= 64, "at most 64 tables");
     at::Tensor lS_i = lS_i_in;
     if (lS_i_in.is_cuda()) {
@@ -318,6 +317,28 @@ py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i_in, int 
         const int64_t s0 = lS_i.stride(0);
         for (int k = 0; k < T; k++) ids[k] = p[k * s0];
     }
+}
+
+// the same body for the GPU engine's resident server (evs_cache_serve_*): the ids as above, the request through the mailbox, the
+// rows of the answer's ring slot (HBM) copied once into a fresh block and handed out as its 26 views
+py::tuple serve_request_list(int64_t handle, const at::Tensor &lS_i_in, const at::Tensor &ring, int T, int d) {
+    int32_t ids[64];
+    first_ids(lS_i_in, T, ids);
+    uint8_t hit[64];
+    int slot = 0;
+    check(evs_cache_serve_request(reinterpret_cast<evs_cache *>(handle), ids, hit, &slot));
+    TORCH_CHECK(ring.dim() == 3 && slot >= 0 && slot < ring.size(0) && ring.size(1) == T && ring.size(2) == d, "ring slot out of range");
+    c10::hip::HIPGuard guard(ring.device().index());
+    at::Tensor block = ring.select(0, slot).clone().unsqueeze(1);
+    py::list flags;
+    bool all = true;
+    for (int k = 0; k < T; k++) { flags.append(py::bool_(hit[k] != 0)); all = all && hit[k]; }
+    return py::make_tuple(flags, slices(block, true), all);
+}
+
+py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i_in, int T, int d, int approx_thres, bool use_gpu, int device_index) {
+    int32_t ids[64];
+    first_ids(lS_i_in, T, ids);
     at::Tensor block;
     uint8_t hit[64];
     if (use_gpu) {
@@ -379,5 +400,6 @@ PYBIND11_MODULE(_evs_torch_ext, m) {
     m.def("cache_request", &cache_request);
     m.def("cache_lookup_interact", &cache_lookup_interact);
     m.def("hostcache_request_list", &hostcache_request_list);
+    m.def("serve_request_list", &serve_request_list);
     m.def("slices", &slices);
 }

@@ -248,6 +248,19 @@ def test_plugin_surface_evstore(E, orc, tmp_path):
                     assert np.array_equal(ly[k].detach().numpy()[0], tabs[k][t["requests"][i][k]])
         assert evstore_ops.perfect_hit == int(want[:n].all(1).sum())
         assert EvLFU_C1.stats()["n_hits"] == int(want[:n].sum())
+        # ... and on with use_gpu=True as dlrm_wrap hands the ids over (on the device): with the tables in HBM the GPU engine's
+        # resident server answers (one extension call: ids through pinned staging, the mailbox, 26 views over one copy of the
+        # answer's ring slot); same trace, rows on the device
+        m = 120
+        for i in range(n, n + m):
+            lS_i = torch.from_numpy(t["requests"][i].astype(np.int64)).reshape(26, 1).cuda()
+            ly = evstore_ops.apply_emb_evstore(None, lS_i, None, None, use_gpu=True, use_emb_cache=True)
+            assert len(ly) == 26 and ly[0].shape == (1, 36) and ly[0].requires_grad and ly[0].is_cuda
+            if i % 7 == 0:
+                got = torch.cat([v.detach() for v in ly]).cpu().numpy()
+                assert np.array_equal(got, np.stack([tabs[k][t["requests"][i][k]] for k in range(26)]))
+        assert evstore_ops.perfect_hit == int(want[:n + m].all(1).sum())
+        assert EvLFU_C1.stats()["n_hits"] == int(want[:n + m].sum())
         _, ly = sm.request_to_emb_storage([int(v) for v in t["requests"][0]])
         assert np.array_equal(ly[3].detach().numpy()[0], tabs[3][t["requests"][0][3]])
         sm.close_any_db_conn()
