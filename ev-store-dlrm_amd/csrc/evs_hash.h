@@ -339,6 +339,9 @@ struct ProbeArgs {
 // folded launch does that at its end).  s_delta: priority histogram moves; s_stat: [0] free ways taken, [1] evictions.
 // Split in two so that the first CAS can travel under other work: sa_claim_issue ranks and sends it (false: nothing is on
 // its way -- a duplicate, or no way to take), sa_claim_finish looks at what came back and carries on from there.
+// (Ways of equal priority: the lowest index goes.  The way filled longest ago instead -- the stamp field as an age, the reference's
+//  FIFO inside a bucket at batch granularity -- was built and measured: the same hit rate at full size (0.8785 against the sequential
+//  oracle's 0.8839 either way) and 41 us per batch instead of 34, the folded launch's head sits at its 128 registers.)
 struct SaPick { int best, bp, dup; unsigned bw, dw; };
 __device__ __forceinline__ SaPick sa_pick8(const SaGeom &g, unsigned cur, const unsigned (&w)[8], unsigned tag1) {
     SaPick p{-1, 0x7fffffff, -1, 0u, 0u};
