@@ -30,7 +30,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-import evstore_dlrm_amd  # noqa: E402,F401  (before the first call into the runtime: the package's hardware-queue default, __init__.py)
+import evstore_dlrm_amd  # noqa: E402
+evstore_dlrm_amd.configure_runtime()   # before the first GPU call: a hardware queue of its own for the resident cache server
 
 KAGGLE_LN = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593,
              3194, 27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
@@ -792,6 +793,90 @@ def cache_tier_section(ev, ln_emb, d, B, dev, steps=200, warmup=60, frac=0.10, a
                         "B=%d, batched snapshot-semantics lookup + interact_features" % (frac * 100, alpha, B)}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python3 bench.py --gpus N` called plainly (no WORLD_SIZE in the environment): start the N ranks as a child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>`, relay its output, print rank 0's JSON record as this process's LAST stdout line and return the child's
+    exit code.  This process never initialises the GPU (torch imported, no device call) and nothing is exec'd: the child
+    is a new process group, ended as a whole when --launch-timeout runs out.  A rank that raises exits non-zero at once
+    (main()'s handler); torch.distributed.run then ends its peers, so the job fails within seconds, not at a collective's
+    time-out."""
+    import signal
+    import subprocess
+    import threading
+    n = max(1, int(args.gpus))
+    child_args = [a for a in argv if a not in ("--self-launch", "--dry-launch")]
+    port = int(os.environ.get("EVS_BENCH_MASTER_PORT", "0")) or _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + child_args
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # (dmabuf IPC: RCCL and the p2p exchange's mapped buffers need it on this pool)
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
+        env.pop(k, None)
+    if args.dry_launch:
+        keys = ("HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES", "WORLD_SIZE", "RANK")
+        print(json.dumps({"dry_launch": True, "cmd": cmd, "env": {k: env.get(k) for k in keys}, "n_ranks": n,
+                          "launch_timeout_s": args.launch_timeout}))
+        return 0
+    t0 = time.time()
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, start_new_session=True, text=True, bufsize=1)
+    last_json = [None]
+    last_line = [None]
+
+    def relay():
+        for line in proc.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            st = line.strip()
+            last_line[0] = st
+            if st.startswith("{") and '"metric"' in st:
+                last_json[0] = st
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc = None
+    try:
+        rc = proc.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py: the rank group did not finish within %.0f s: ending it\n" % args.launch_timeout)
+        rc = 124
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        if proc.poll() is None:      # the whole group (the launcher and every rank), by its own process-group id only
+            for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+                try:
+                    os.killpg(proc.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    proc.wait(timeout=wait)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+    th.join(timeout=10.0)
+    if last_json[0] is not None and rc == 0:
+        try:
+            rec = json.loads(last_json[0])
+            rec["launcher"] = {"self_launched": True, "n_ranks": n, "master_port": port, "child_rc": rc, "wall_s": time.time() - t0}
+            print(json.dumps(rec), flush=True)
+        except ValueError:
+            if last_line[0] != last_json[0]:
+                print(last_json[0], flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the rank group returned 0 without a record\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -837,51 +922,89 @@ def main():
                          "(external to the reference tree; --dim 64 or 128): with the default placement the tables above 1 M rows "
                          "(7 of 26, 97 %% of the rows) shard by rows at either width")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks from this process even at --gpus 1 (with --force-sharded: the N>1 code path through the same "
+                         "launcher the plain `python3 bench.py --gpus N` call uses)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="print the child command line and the environment the self-launch would use as one JSON line and exit (no GPU, no child)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launch: seconds after which the parent ends the whole rank group and returns 124")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank raises behind the set-up
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch or args.dry_launch):
+        # called as the driver calls it (`python3 bench.py --gpus N ...`): nothing here has touched the GPU yet (torch is
+        # imported, no device call was made), so the ranks are started as a CHILD process group and this process only relays
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d inside a rank group of WORLD_SIZE %d: launch with --nproc-per-node %d (or call "
+                 "`python3 bench.py --gpus %d` plainly: it starts its own ranks)" % (args.gpus, world, args.gpus, args.gpus))
+    if world > 1 or args.force_sharded:
+        try:
+            return main_sharded(args, rank, world, local_rank)
+        except BaseException:
+            # a rank that fails must not leave its peers inside a collective: the traceback, then a hard exit -- no atexit
+            # handler or destructor may block on the process group; torch.distributed.run ends the other ranks when it
+            # sees this one's exit code, and a self-launching parent ends the whole group after --launch-timeout
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            sys.stdout.flush()
+            os._exit(1)
+    return main_single(args, local_rank)
+
+
+def main_sharded(args, rank, world, local_rank):
+    """one rank of the N > 1 path (or --force-sharded on one rank): RCCL process group, sharded.bench_sharded"""
+    import datetime
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import evstore_dlrm_amd as E
     E._lib.lib()  # fail loudly if the HIP library is missing
-
-    if world > 1 or args.force_sharded:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        from evstore_dlrm_amd import sharded
-        ln_run = KAGGLE_LN
-        if args.shape == "terabyte":
-            ln_run = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
-                      4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
-        result = sharded.bench_sharded(args, ln_run, rank, world, dev)
-        # N > 1: the device-to-device exchange beside the RCCL headline.  No box with two GPUs has run it yet (IPC-mapped
-        # fine-grained buffers, cross-GPU flag words, spin-wait kernels: a bad peer write is a GPU fault that takes the job and
-        # its exit status with it), so it is OPT-IN: EVS_BENCH_P2P=1.  The finished headline line still goes out FIRST; when the
-        # side measurement returns, the same line with `exchange_p2p` added is printed as the last line.
-        if world > 1 and args.exchange_mode != "p2p" and os.environ.get("EVS_BENCH_P2P", "0") == "1":
-            if rank == 0:
-                import ctypes
-                ctypes.CDLL(None).fflush(None)
-                print(json.dumps(result), flush=True)
-            result["exchange_p2p"] = sharded.bench_p2p_side(args, ln_run, rank, world, dev)
-        dist.barrier()
-        dist.destroy_process_group()
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    # (a collective a peer never joins ends in an error after this long instead of a hang)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=240))
+    from evstore_dlrm_amd import sharded
+    ln_run = KAGGLE_LN
+    if args.shape == "terabyte":
+        ln_run = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
+                  4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+    if args.fail_rank == rank:   # (tests: a rank that throws behind the set-up must take the whole job down, bounded)
+        raise RuntimeError("bench.py --fail-rank %d: injected failure" % rank)
+    result = sharded.bench_sharded(args, ln_run, rank, world, dev)
+    # N > 1: the device-to-device exchange beside the RCCL headline.  No box with two GPUs has run it yet (IPC-mapped
+    # fine-grained buffers, cross-GPU flag words, spin-wait kernels: a bad peer write is a GPU fault that takes the job and
+    # its exit status with it), so it is OPT-IN: EVS_BENCH_P2P=1.  The finished headline line still goes out FIRST; when the
+    # side measurement returns, the same line with `exchange_p2p` added is printed as the last line.
+    if world > 1 and args.exchange_mode != "p2p" and os.environ.get("EVS_BENCH_P2P", "0") == "1":
         if rank == 0:
-            # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line
             import ctypes
             ctypes.CDLL(None).fflush(None)
-            sys.stdout.flush()
             print(json.dumps(result), flush=True)
-        return
+        result["exchange_p2p"] = sharded.bench_p2p_side(args, ln_run, rank, world, dev)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
+    return
 
+
+def main_single(args, local_rank):
+    """N = 1: the headline launch and its side lines on one GPU"""
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import evstore_dlrm_amd as E
+    E._lib.lib()  # fail loudly if the HIP library is missing
     B, d, T = args.batch, args.dim, len(KAGGLE_LN)
     F = T + 1
     P = F * (F - 1) // 2

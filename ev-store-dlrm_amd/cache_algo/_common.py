@@ -95,13 +95,14 @@ class _ModuleCache:
             self._rows[0] = group_row_ids
             self.cache.request(self._rows, approx_thres, out=self._out, hit=self._hit)
             return self._hit[0].astype(bool).tolist(), torch.from_numpy(self._out[0])
-        if want_device_rows and self.n_tables <= 30:
+        if want_device_rows and self.n_tables <= 28:
             # the resident server (round 5; gpu_cache.GpuCache.serve_*): the ids go out and the hit flags come back through a
             # mailbox in pinned host memory, the rows stay in a ring in HBM -- no launch, no copy, no synchronise per request
             if self._serving != approx_thres:
                 self.cache.serve_start(approx_thres, n_slots=4, idle_us=200)
                 self._serving = approx_thres
             hit, rows = self.cache.serve_request(group_row_ids)
+            self._ring_rows = True     # (request() says when its copy of the slot has been enqueued: serve_consumed)
             return hit.astype(bool).tolist(), rows
         self._host_rows[0] = torch.as_tensor(group_row_ids, dtype=torch.int32)
         out = self._dev_out if want_device_rows else self._host_out
@@ -131,7 +132,7 @@ class _ModuleCache:
         if self.engine != "host":
             # the GPU engine's resident server (see _run): the same one-call body -- ids through pinned staging, the request
             # through the mailbox, the 26 tensors over one copy of the answer's ring slot
-            if not use_gpu or self.n_tables > 30 or not hasattr(X, "serve_request_list"):
+            if not use_gpu or self.n_tables > 28 or not hasattr(X, "serve_request_list"):
                 return None
             if self._serving != approx_thres:
                 self.cache.serve_start(approx_thres, n_slots=4, idle_us=200)
@@ -148,6 +149,9 @@ class _ModuleCache:
             block = rows.to(self._device, copy=True)   # ONE host-to-device copy instead of 26 (EvLFU_C1.py:157-161)
         else:
             block = rows.detach().clone()
+            if getattr(self, "_ring_rows", False):   # the clone of a ring slot is only enqueued: the slot is reused after it has run
+                self.cache.serve_consumed()
+                self._ring_rows = False
         from .. import _ext
         X = _ext.ext()
         if X is not None:

@@ -220,10 +220,11 @@ __device__ int evlfu_set(const CacheState &cs, const CacheArrays &a, Hot &h, uns
 // The same kernel as a SERVER (round 5; evs_cache_serve_*): it stays resident and takes one request at a time from a
 // mailbox in pinned host memory -- the reference's operating point is batch 1 (cache_algo/EvLFU_C1.py:97-166,
 // dlrm_s_pytorch_C1.py:227-275), where a launch and a synchronise per request cost twice what the request does.
-//   request line  (host -> device, 128 bytes): the T row ids in words 0..14 and 16..30, a sequence number in word 15 AND in
-//                 word 31 -- the host writes the ids, then both guards; the device reads the line as one 32-lane load (two
-//                 64-byte bus reads that may be taken at different times) and accepts it when both guards hold the number
-//                 it waits for: each half was then read after its guard, hence after every id, was written;
+//   request line  (host -> device, 128 bytes): four 32-byte sectors of seven row ids and a guard word (words 7, 15, 23, 31 =
+//                 the sequence number) -- the host writes the ids, then the four guards; the device reads the line as one
+//                 32-lane load (bus reads of 32 or 64 bytes that may be taken at different times) and accepts it when ALL
+//                 guards hold the number it waits for: every sector was then read after its guard, hence after its ids,
+//                 was written -- whatever the granularity the fabric delivers the line in;
 //   control line  (host -> device): word 0 = stop;
 //   answer line   (device -> host): the T hit flags in bytes 0..63, `done` (the sequence number served) in word 16, `alive`
 //                 in word 17 -- flags first, a system-scope fence, then `done`.
@@ -284,15 +285,15 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             bool leave = false;
             for (;;) {
                 word = __hip_atomic_load(const_cast<unsigned *>(sv.req) + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned ga = (unsigned)__shfl((int)word, 15), gb = (unsigned)__shfl((int)word, 31);
-                if (ga == want && gb == want) break;
+                // words 7, 15, 23, 31: one guard per 32-byte sector
+                if ((__ballot(word == want) & 0x80808080ull) == 0x80808080ull) break;
                 const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (stop != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) { leave = true; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
             if (leave) break;
-            // id of table t: word t (t < 15) or t + 1
-            const int src_lane = lane < 15 ? lane : lane + 1;
+            // id of table t: word t + t / 7 (seven ids, then the sector's guard)
+            const int src_lane = lane + lane / 7;
             row = __shfl((int)word, src_lane & 31);
             if (lane >= T) row = 0;
             out = sv.ring + (long long)(want % (unsigned)sv.n_slots) * T * d;
@@ -2706,6 +2707,13 @@ struct evs_cache {
     unsigned serve_seq = 0;
     float *serve_ring = nullptr; int serve_slots = 0, serve_thres = -1;
     long long serve_idle_ticks = 0;
+    // ordering of the server against everything else that touches the exact state or reads the ring:
+    //   exact_done: recorded behind every exact-path launch on the CALLER's stream; a server started afterwards waits for it
+    //               on its own stream (two kernels must never mutate the lists / the map / the free stack at once);
+    //   slot_done[s]: recorded by evs_cache_serve_consumed on the stream that READS ring slot s; the request that is about
+    //               to hand slot s out again waits for it on the host (the server overwrites the slot in host order).
+    hipEvent_t exact_done = nullptr; bool exact_pending = false;
+    std::vector<hipEvent_t> slot_done; std::vector<char> slot_busy;
     int inline_mode = -1;          // the update inside the probe launch (evs_fused_rf.hip): -1 not decided (EVS_CACHE_INLINE, default on), 0 / 1
 };
 
@@ -2836,6 +2844,8 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
         if (c->serve_stream) { (void)hipStreamSynchronize(c->serve_stream); (void)hipStreamDestroy(c->serve_stream); }
         (void)hipHostFree(c->mbox);
     }
+    if (c->exact_done) (void)hipEventDestroy(c->exact_done);
+    for (hipEvent_t e : c->slot_done) if (e) (void)hipEventDestroy(e);
     sa_release(c);
     delete c;
     return EVS_OK;
@@ -2923,9 +2933,12 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
     return EVS_OK;
 }
 
+static int serve_pause(evs_cache *c);
+static int exact_launched(evs_cache *c, hipStream_t st);
 extern "C" int evs_cache_set_backing(evs_cache *c, const void *const *tables, const int64_t *n_rows) {
     using namespace evs;
     EVS_REQUIRE(c && tables && n_rows, "evs_cache_set_backing: NULL argument");
+    { const int prc = serve_pause(c); if (prc) return prc; }   // (a server inside its idle window holds the OLD table pointers)
     for (int k = 0; k < c->host.n_tables; k++) {
         EVS_REQUIRE(tables[k] || n_rows[k] == 0, "evs_cache_set_backing: table %d is NULL", k);
         c->backing[k] = reinterpret_cast<const unsigned char *>(tables[k]);
@@ -2948,6 +2961,7 @@ extern "C" int evs_cache_set_backing(evs_cache *c, const void *const *tables, co
 extern "C" int evs_cache_set_file_backing(evs_cache *c, evs_filetier *ft) {
     using namespace evs;
     EVS_REQUIRE(c && ft, "evs_cache_set_file_backing: NULL argument");
+    { const int prc = serve_pause(c); if (prc) return prc; }
     EVS_REQUIRE(filetier_tables(ft) == c->host.n_tables, "evs_cache_set_file_backing: the tier has %d tables, the cache %d",
                 filetier_tables(ft), c->host.n_tables);
     EVS_REQUIRE(filetier_row_bytes(ft) == c->host.row_bytes, "evs_cache_set_file_backing: row size %lld, the cache's rows have %d bytes",
@@ -2993,7 +3007,7 @@ extern "C" int evs_cache_request(evs_cache *c, int64_t B, const int32_t *rows, f
     { const int prc = serve_pause(c); if (prc) return prc; }
     hipLaunchKernelGGL(cache_exact_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), args);
     EVS_HIP_CHECK(hipGetLastError());
-    return EVS_OK;
+    return exact_launched(c, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- the exact policy as a resident server (cache_serve_kernel) ------------------------------------------------------------
@@ -3006,7 +3020,18 @@ static void serve_launch(evs_cache *c) {
     ServeArgs sv;
     sv.req = c->mbox_dev; sv.ctl = c->mbox_dev + 32; sv.ans = c->mbox_dev + 64;
     sv.ring = c->serve_ring; sv.n_slots = c->serve_slots; sv.idle_ticks = c->serve_idle_ticks;
+    // an exact-path launch of the caller's (evs_cache_request, evs_cache_request_c1c2[c3]) may still be running on ITS stream:
+    // the server starts behind it
+    if (c->exact_pending) { (void)hipStreamWaitEvent(c->serve_stream, c->exact_done, 0); c->exact_pending = false; }
     hipLaunchKernelGGL(cache_serve_kernel, dim3(1), dim3(64), 0, c->serve_stream, args, sv);
+}
+// behind every exact-path launch: where a server started later has to wait (only caches that have a server pay the record)
+static int exact_launched(evs_cache *c, hipStream_t st) {
+    if (!c->serve_stream) return EVS_OK;
+    if (!c->exact_done) EVS_HIP_CHECK(hipEventCreateWithFlags(&c->exact_done, hipEventDisableTiming));
+    EVS_HIP_CHECK(hipEventRecord(c->exact_done, st));
+    c->exact_pending = true;
+    return EVS_OK;
 }
 // anything else that reads or writes the exact state first sends the server home (it writes the state back on its way out);
 // the next evs_cache_serve_request starts it again
@@ -3025,7 +3050,7 @@ extern "C" int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring
     if (!c->has_backing) { set_error("evs_cache_serve_start: call evs_cache_set_backing first"); return EVS_ESTATE; }
     if (c->staged_mask) { set_error("evs_cache_serve_start: a file-backed tier with staged tables serves batched lookups only"); return EVS_ESTATE; }
     if (c->used == 2) { set_error("evs_cache_serve_start: this cache is used through the batched path"); return EVS_ESTATE; }
-    EVS_REQUIRE(c->host.n_tables <= 30, "evs_cache_serve_start: at most 30 tables (the request line holds 30 ids)");
+    EVS_REQUIRE(c->host.n_tables <= 28, "evs_cache_serve_start: at most 28 tables (the request line holds 4 x 7 ids)");
     c->used = 1;
     if (!c->mbox) {
         EVS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->mbox), 3 * 128, hipHostMallocMapped));
@@ -3043,6 +3068,9 @@ extern "C" int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring
         const int rc = serve_pause(c);
         if (rc) return rc;
     }
+    for (size_t k = 0; k < c->slot_busy.size(); k++)      // (a new ring: whoever still reads the old one finishes first)
+        if (c->slot_busy[k]) { (void)hipEventSynchronize(c->slot_done[k]); c->slot_busy[k] = 0; }
+    c->slot_done.resize((size_t)n_slots, nullptr); c->slot_busy.assign((size_t)n_slots, 0);
     c->serve_ring = ring; c->serve_slots = n_slots; c->serve_thres = approx_thres;
     c->serve_idle_ticks = idle_us * 100;   // wall_clock64(): 100 MHz
     c->serving = true;
@@ -3057,27 +3085,57 @@ extern "C" int evs_cache_serve_request(evs_cache *c, const int32_t *rows, uint8_
     if (!c->serving) { set_error("evs_cache_serve_request: call evs_cache_serve_start first"); return EVS_ESTATE; }
     volatile unsigned *req = c->mbox, *ans = c->mbox + 64;
     const int T = c->host.n_tables;
-    const unsigned want = ++c->serve_seq;
-    for (int t = 0; t < T; t++) req[t < 15 ? t : t + 1] = (unsigned)rows[t];
+    const unsigned want = c->serve_seq + 1u;
+    // the ring slot this request's rows go to: whoever still READS it (evs_cache_serve_consumed) finishes first
+    const int slot = (int)(want % (unsigned)c->serve_slots);
+    if (c->slot_busy[(size_t)slot]) {
+        EVS_HIP_CHECK(hipEventSynchronize(c->slot_done[(size_t)slot]));
+        c->slot_busy[(size_t)slot] = 0;
+    }
+    c->serve_seq = want;
+    // seven ids and a guard per 32-byte sector: whatever granularity the bus delivers the line in, ids are accepted only from
+    // a sector whose guard (written after them) holds the number awaited
+    for (int t = 0; t < T; t++) req[t + t / 7] = (unsigned)rows[t];
     __atomic_thread_fence(__ATOMIC_RELEASE);
-    req[15] = want;
-    req[31] = want;
+    req[7] = want; req[15] = want; req[23] = want; req[31] = want;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     long long spins = 0;
+    // a request that fails leaves host and device agreeing on the sequence number: the one the device last ANSWERED
+    auto fail = [&](int rc) { c->serve_seq = ans[16]; return rc; };
     while (ans[16] != want) {
         if ((spins & 63) == 0 && ans[17] == 0u) {   // no server (never started, went home idle, or was paused): start one
             const hipError_t q = hipStreamQuery(c->serve_stream);
-            if (q == hipSuccess) { serve_launch(c); EVS_HIP_CHECK(hipGetLastError()); }
-            else if (q != hipErrorNotReady) { (void)hipGetLastError(); c->serve_seq--; return EVS_EHIP; }
+            if (q == hipSuccess) {
+                serve_launch(c);
+                if (hipGetLastError() != hipSuccess) { set_error("evs_cache_serve_request: the server could not be started"); return fail(EVS_EHIP); }
+            }
+            else if (q != hipErrorNotReady) { (void)hipGetLastError(); return fail(EVS_EHIP); }
             else (void)hipGetLastError();
         }
-        if (++spins > (1ll << 31)) { set_error("evs_cache_serve_request: the server did not answer"); return EVS_EHIP; }
+        if (++spins > (1ll << 31)) {
+            // send a server that may still be there home (it re-reads the answer line's number when it starts again), then agree
+            (void)serve_pause(c);
+            set_error("evs_cache_serve_request: the server did not answer");
+            return fail(EVS_EHIP);
+        }
         __builtin_ia32_pause();
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const volatile unsigned char *fl = reinterpret_cast<const volatile unsigned char *>(ans);
     for (int t = 0; t < T; t++) hit[t] = fl[t];
-    *slot_out = (int)(want % (unsigned)c->serve_slots);
+    *slot_out = slot;
+    return EVS_OK;
+}
+// The caller has ENQUEUED its reads of ring slot `slot` (a copy, a kernel) on `stream`: the slot is handed out again only
+// after they have finished.  Without this call the contract is stream order, not host order: the rows of a slot are valid
+// until n_slots - 1 more requests have been POSTED, whatever the caller's stream has executed by then.
+extern "C" int evs_cache_serve_consumed(evs_cache *c, int slot, void *stream) {
+    using namespace evs;
+    EVS_REQUIRE(c && c->serving && slot >= 0 && slot < c->serve_slots, "evs_cache_serve_consumed: bad argument");
+    hipEvent_t &e = c->slot_done[(size_t)slot];
+    if (!e) EVS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    EVS_HIP_CHECK(hipEventRecord(e, reinterpret_cast<hipStream_t>(stream)));
+    c->slot_busy[(size_t)slot] = 1;
     return EVS_OK;
 }
 extern "C" int evs_cache_serve_stop(evs_cache *c) {
@@ -4332,5 +4390,6 @@ extern "C" int evs_cache_request_c1c2c3(evs_cache *c1, evs_cache *c2, evs_aprx *
     args.requests = rows; args.out = out; args.tier_out = tier; args.B = B; args.threshold = high_agghit_threshold;
     hipLaunchKernelGGL(cache_c1c2_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), args);
     EVS_HIP_CHECK(hipGetLastError());
+    { const int r1 = exact_launched(c1, reinterpret_cast<hipStream_t>(stream)), r2 = exact_launched(c2, reinterpret_cast<hipStream_t>(stream)); if (r1 || r2) return EVS_EHIP; }
     return EVS_OK;
 }

@@ -330,6 +330,8 @@ py::tuple serve_request_list(int64_t handle, const at::Tensor &lS_i_in, const at
     TORCH_CHECK(ring.dim() == 3 && slot >= 0 && slot < ring.size(0) && ring.size(1) == T && ring.size(2) == d, "ring slot out of range");
     c10::hip::HIPGuard guard(ring.device().index());
     at::Tensor block = ring.select(0, slot).clone().unsqueeze(1);
+    // the copy above is only ENQUEUED: the slot is handed out again (and overwritten by the server, in host order) only after it has run
+    check(evs_cache_serve_consumed(reinterpret_cast<evs_cache *>(handle), slot, c10::hip::getCurrentHIPStream(ring.device().index()).stream()));
     py::list flags;
     bool all = true;
     for (int k = 0; k < T; k++) { flags.append(py::bool_(hit[k] != 0)); all = all && hit[k]; }

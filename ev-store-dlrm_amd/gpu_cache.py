@@ -87,6 +87,28 @@ class FileTier:
             pass
 
 
+_hwq_warned = False
+
+
+def _warn_hw_queues():
+    """the resident server wants a hardware queue nothing else is folded onto (evstore_dlrm_amd.configure_runtime): say so ONCE
+    when the process runs on the runtime's default of four -- the package no longer sets the knob at import"""
+    global _hwq_warned
+    if _hwq_warned:
+        return
+    _hwq_warned = True
+    import os
+    try:
+        n = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        n = 4
+    if n < 8:
+        import warnings
+        warnings.warn("GpuCache.serve_start: GPU_MAX_HW_QUEUES=%d -- a copy or kernel of the caller's that HIP folds onto the resident "
+                      "server's hardware queue waits until the server goes home idle (up to idle_us per request); call "
+                      "evstore_dlrm_amd.configure_runtime() before the first GPU call, or export GPU_MAX_HW_QUEUES=8" % n)
+
+
 class GpuCache:
     def __init__(self, policy, capacity, n_tables=26, dim=36, codec=32, variant="python", device="cuda"):
         self.policy, self.capacity, self.n_tables, self.dim, self.codec = policy, int(capacity), n_tables, dim, codec
@@ -163,6 +185,7 @@ class GpuCache:
         synchronise each.  The rows of request i land in self.serve_ring[slot] on the DEVICE."""
         import ctypes as C
         import numpy as np
+        _warn_hw_queues()
         self.serve_ring = torch.empty((n_slots, self.n_tables, self.dim), dtype=torch.float32, device=self.device)
         self._srv_rows = np.zeros(self.n_tables, np.int32)
         self._srv_hit = np.zeros(self.n_tables, np.uint8)
@@ -174,13 +197,21 @@ class GpuCache:
 
     def serve_request(self, row_ids):
         """row_ids: n_tables ints (host).  -> (hit flags: a numpy uint8 view valid until the next request, the (T, dim) fp32
-        rows as a DEVICE tensor view valid until n_slots - 1 more requests).  Same results as request() one at a time."""
+        rows as a DEVICE tensor view of a ring slot).  Same results as request() one at a time.
+        The server overwrites a slot when the request n_slots later is POSTED (host order): a caller that only ENQUEUES its
+        reads of the view (a clone, a kernel) calls serve_consumed() behind them -- the slot is then handed out again only
+        after they have run; otherwise the rows must have been read before n_slots - 1 more requests are posted."""
         self._srv_rows[:] = row_ids
         fn, h, rp, hp, sp = self._srv_call
         rc = fn(h, rp, hp, sp)
         if rc:
             _lib.check(rc)
         return self._srv_hit, self.serve_ring[self._srv_slot.value]
+
+    def serve_consumed(self, slot=None, stream=None):
+        """the reads of ring slot `slot` (default: the last request's) have been enqueued on `stream` (default: the current one)"""
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        _lib.check(_lib.lib().evs_cache_serve_consumed(self._h, int(self._srv_slot.value if slot is None else slot), st.cuda_stream))
 
     def serve_stop(self):
         _lib.check(_lib.lib().evs_cache_serve_stop(self._h))

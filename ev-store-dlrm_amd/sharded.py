@@ -900,13 +900,21 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0   # this rank's K steps, from the common start to its own completion; the job's time is the MAX below
     dist.barrier()
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    # every rank's own time for the K steps (the job's time is their MAX; the spread shows a placement's imbalance)
+    mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    dt_per_rank = [float(t.item()) for t in every]
+    dt = max(dt_per_rank)
     n_sh = sum(1 for t in range(T) if owner[t] >= 0)
     n_split = sum(1 for t in range(T) if owner[t] == -2)
     n_rep = T - n_sh - n_split
-    res = {"dt": dt, "owner": owner, "n_sharded": n_sh, "n_rowsplit": n_split, "n_replicated": n_rep, "mode": mode,
+    # what the placement asks of each rank per step: lookups pooled for the GLOBAL batch (its own sharded tables, its row range
+    # of every row-split table) and lookups gathered inside its interaction launch for its LOCAL batch (the replicated tables)
+    pool_lookups = [Bg * (len(op.own[r]) + n_split) for r in range(world)]
+    local_lookups = [Bl * n_rep for _ in range(world)]
+    res = {"dt": dt, "dt_per_rank": dt_per_rank, "pool_lookups_per_rank": pool_lookups, "local_lookups_per_rank": local_lookups,
+           "owner": owner, "n_sharded": n_sh, "n_rowsplit": n_split, "n_replicated": n_rep, "mode": mode,
            # bytes that leave a rank per step (its pooled vectors -- and its partials of the row-split tables -- for the
            # other ranks' batch slices), and over all ranks
            "a2a_bytes_per_rank": 4 * d * Bl * (len(op.my_own) + n_split) * (world - 1),
@@ -1055,6 +1063,23 @@ def bench_sharded(args, ln_emb, rank, world, dev):
             extra = {"error": repr(ex)}
     dt = main["dt"]
     lookups = T * Bg
+    per_rank = {"step_ms": [t / args.steps * 1e3 for t in main["dt_per_rank"]],
+                "pool_lookups_per_step": main["pool_lookups_per_rank"],           # own sharded tables (+ row ranges) x the GLOBAL batch
+                "local_lookups_per_step": main["local_lookups_per_rank"],         # replicated tables x the LOCAL batch, inside the interaction launch
+                "tables_owned": [sum(1 for o in main["owner"] if o == r) for r in range(world)],
+                "note": "a rank's step = pool launch over its own tables for the global batch (nothing when it owns none), the exchange, "
+                        "the interaction over its local batch; value uses the MAX of step_ms"}
+    pl_ = per_rank["pool_lookups_per_step"]
+    per_rank["pool_imbalance_max_over_mean"] = (max(pl_) / (sum(pl_) / len(pl_))) if sum(pl_) else None
+    single = None
+    if world == 1:
+        # the same launcher on ONE rank beside the plain single-process step (one fused launch, every table local): the sharded
+        # code path must stay within 25 % of it
+        try:
+            single = _single_process_line(args, ln_emb, dev)
+            single["sharded_over_single"] = (lookups * args.steps / dt) / single["value"]
+        except Exception as ex:
+            single = {"error": repr(ex)}
     shape = "Criteo-Kaggle" if sum(ln_emb) < 100_000_000 else "Criteo-Terabyte-shaped"
     if main.get("n_rowsplit"):
         what = ("%d tables split ROW-WISE over the %d ranks (each rank pools its row range for the global batch; the receiver "
@@ -1083,5 +1108,43 @@ def bench_sharded(args, ln_emb, rank, world, dev):
                    "exchange_auto": main.get("exchange_auto"),
                    "a2a_bytes_per_step_per_rank": main["a2a_bytes_per_rank"],
                    "a2a_bytes_per_step_all_links": main["a2a_bytes"]},
-        "roofline": main["roofline"], "cpu_baseline": None, "replicated_all": extra,
+        "roofline": main["roofline"], "cpu_baseline": None, "replicated_all": extra, "per_rank": per_rank,
+        "single_process": single,
     }
+
+
+def _single_process_line(args, ln_emb, dev):
+    """the plain N = 1 step (bench.py's headline: ONE fused launch over local tables, one index per bag declared as the sharded
+    step declares it) timed in this process, for the line a one-rank sharded run prints beside its own"""
+    from . import dlrm_ops
+    d, B, T = args.dim, args.batch, len(ln_emb)
+    owner = [0] * T
+    w = _bench_weights(ln_emb, d, 0, 1, dev, owner)
+    ev = dlrm_ops.EVTables.from_fp32([w[t] for t in range(T)], device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    off = torch.arange(B, device=dev, dtype=torch.int64).repeat(T, 1)
+    bs = [torch.stack([torch.randint(0, n, (B,), device=dev, generator=g, dtype=torch.int64) for n in ln_emb]) for _ in range(4)]
+    x = torch.rand((B, d), device=dev)
+    F = T + 1
+    out = [torch.empty((B, d + F * (F - 1) // 2), device=dev) for _ in range(2)]
+
+    def run(n):
+        for i in range(n):
+            dlrm_ops.apply_emb_interact(x, off, bs[i % 4], ev, None, out=out[i % 2], one_index_per_bag=True)
+
+    run(args.warmup + 1500)
+    e = torch.cuda.Event()
+    e.record()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    e.record()
+    while not e.query():
+        pass
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del ev, w
+    torch.cuda.empty_cache()
+    return {"value": T * B * args.steps / dt, "unit": "lookups/s", "ms_per_step": dt / args.steps * 1e3,
+            "note": "one fused launch per step in this process (no placement, no exchange): what `bench.py --gpus 1` times"}

@@ -333,12 +333,24 @@ EVS_API int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, cons
  * polls that line over the bus, runs the request, writes the T x dim fp32 rows into slot (sequence % n_slots) of `ring`
  * (DEVICE memory, n_slots x T x dim floats: the caller gets device rows without a launch, a copy or a synchronise) and the
  * hit flags + the sequence number into a host line the caller spins on.  evs_cache_serve_request blocks until the answer is
- * there (hit: T bytes on the host; *slot_out: which ring slot holds the rows -- valid until n_slots - 1 more requests).
- * An idle server leaves by itself after idle_us (a device-wide synchronise elsewhere waits no longer than that) and is
- * started again by the next request; evs_cache_stats / _dump / _request / _reset_counters / _destroy send it home first (it
- * writes the policy state back on its way out).  At most 30 tables; EVS_ESTATE for a cache on the batched path. */
+ * there (hit: T bytes on the host; *slot_out: which ring slot holds the rows).
+ * HOW LONG A SLOT'S ROWS STAY VALID: the server overwrites slot s when the request n_slots later is POSTED -- host order,
+ * not the order of the caller's stream.  A caller that enqueues its reads of the slot (a copy, a kernel) on a stream and does
+ * not synchronise must say so: evs_cache_serve_consumed(c, slot, stream) records an event behind those reads, and the request
+ * that is about to hand the slot out again waits for it on the host.  Without that call the caller has to have FINISHED
+ * reading a slot before it posts the (n_slots - 1)-th request after it.
+ * An idle server leaves by itself after idle_us (a device-wide synchronise elsewhere -- hipDeviceSynchronize,
+ * torch.cuda.synchronize -- waits for it, i.e. up to idle_us longer than it otherwise would) and is
+ * started again by the next request; evs_cache_stats / _dump / _request / _request_c1c2 / _set_backing / _reset_counters /
+ * _destroy send it home first (it writes the policy state back on its way out), and a server started after an exact-path
+ * launch waits for that launch on its own stream.  A request that fails (EVS_EHIP: the server did not answer / could not be
+ * started) leaves host and device agreeing on the sequence number, so the next request is a fresh one.
+ * At most 28 tables (the 128-byte request line: four 32-byte sectors of seven ids and a guard word each -- ids are accepted
+ * only from a sector whose guard holds the number awaited, whatever granularity the bus delivers the line in);
+ * EVS_ESTATE for a cache on the batched path. */
 EVS_API int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring, int n_slots, int64_t idle_us);
 EVS_API int evs_cache_serve_request(evs_cache *c, const int32_t *rows_host, uint8_t *hit_host, int *slot_out);
+EVS_API int evs_cache_serve_consumed(evs_cache *c, int slot, void *stream);
 EVS_API int evs_cache_serve_stop(evs_cache *c);
 /* Batched EvLFU lookup with snapshot semantics (the throughput path; no reference counterpart --
  * the reference is batch-1): all B requests are probed against the cache as it is when the call

@@ -1,0 +1,88 @@
+"""bench.py starts its own ranks: `python3 bench.py --gpus N` called plainly (as the round-end driver calls it; no WORLD_SIZE
+in the environment) launches `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a
+CHILD process group before anything has touched the GPU, relays its output, ends with rank 0's record and returns the child's
+exit code.  CPU: the command line / environment (--dry-launch) and that a rank group whose ranks fail brings the parent back
+non-zero within a bounded time.  GPU: the self-launch at world size 1 through the N > 1 code path, beside the plain step."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_dry_launch_shows_the_child_command_line():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-launch"], capture_output=True, text=True,
+                       timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = j["cmd"]
+    assert j["dry_launch"] is True and j["n_ranks"] == 2
+    assert cmd[0] == sys.executable or os.path.basename(cmd[0]).startswith("python")
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(BENCH)
+    assert cmd[k + 1:] == ["--gpus", "2", "--steps", "20", "--warmup", "5"], "the child gets the same arguments, the launch switches apart"
+    assert j["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and j["env"]["WORLD_SIZE"] is None and j["env"]["RANK"] is None
+
+
+def test_dry_launch_at_one_rank_keeps_the_forced_sharded_path():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--self-launch", "--force-sharded", "--force-exchange", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["cmd"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "1"
+    assert cmd[cmd.index(BENCH) + 1:] == ["--gpus", "1", "--force-sharded", "--force-exchange"]
+
+
+def test_inside_a_rank_group_the_bench_does_not_launch_again():
+    # WORLD_SIZE in the environment = already a rank: a --gpus that disagrees is an error, never a second launcher
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-launch"], capture_output=True, text=True, timeout=300,
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE 2" in r.stderr
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="the CPU form of the failure test: every rank fails at its first device call")
+def test_failing_ranks_bring_the_parent_back_nonzero_in_bounded_time():
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--launch-timeout", "240"], capture_output=True,
+                       text=True, timeout=400, env=_env(), cwd=ROOT)
+    assert r.returncode != 0, "ranks without a GPU must fail the job"
+    assert time.time() - t0 < 240, "bounded: the failing ranks end the job, not the launcher's time-out"
+    assert not any(ln.startswith("{") and '"metric"' in ln for ln in r.stdout.splitlines()), "no record from a failed job"
+
+
+@pytest.mark.gpu
+def test_self_launch_at_world_1_agrees_with_the_plain_step():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--self-launch", "--force-sharded", "--steps", "200", "--warmup", "20"],
+                       capture_output=True, text=True, timeout=900, env=_env(HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["launcher"]["self_launched"] is True and j["launcher"]["n_ranks"] == 1 and j["launcher"]["child_rc"] == 0
+    assert j["n_gpus"] == 1 and j["config"]["observed_world_size"] == 1 and j["config"]["backend"] == "nccl"
+    pr = j["per_rank"]
+    assert len(pr["step_ms"]) == 1 and abs(pr["step_ms"][0] - j["ms_per_step"]) < 1e-9
+    assert pr["pool_lookups_per_step"] == [16384 * 5] and pr["local_lookups_per_step"] == [16384 * 21] and pr["tables_owned"] == [5]
+    sp = j["single_process"]
+    assert sp["value"] > 0 and 0.75 <= sp["sharded_over_single"] <= 1.25, sp
+
+
+@pytest.mark.gpu
+def test_self_launch_returns_the_failing_ranks_code_quickly():
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--self-launch", "--force-sharded", "--steps", "20", "--warmup", "5", "--fail-rank", "0"],
+                       capture_output=True, text=True, timeout=600, env=_env(HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert r.returncode != 0 and "injected failure" in r.stderr
+    assert time.time() - t0 < 180
+    assert not any(ln.startswith("{") and '"metric"' in ln for ln in r.stdout.splitlines())

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 import bench
 import evstore_dlrm_amd as E
+E.configure_runtime()
 from evstore_dlrm_amd import evstore_ops
 from evstore_dlrm_amd import inference_loop as IL
 from evstore_dlrm_amd.cache_algo import EvLFU_C1
