@@ -242,6 +242,70 @@ def long_bags_section(dev, B=2048, bag=100, d=64, T=8, rows=1000000, iters=200):
                                    "note": "two launches: the pooling kernel, then the interaction over the pooled rows"}}
 
 
+def sweep_numbers(E, ev, ln_emb, d, B, dev, dist):
+    """flat numeric fields for the `roofline` object: the fused launch (lS_o given) at B = 1 / 128 / 2 048 over the headline's
+    tables -- ms_B*: stream time per batch of single launches back to back (HIP events over 400), frac_B*: the algorithmic
+    bytes of one batch over that time against the 8 TB/s peak, p50_polled_ms_B*: one batch launched and waited for by polling
+    an end event -- and at the headline batch over d = 16 / d = 64 tables (ms_d*, frac_d*)."""
+    T = len(ln_emb)
+    F = T + 1
+    P = F * (F - 1) // 2
+    out = {}
+
+    def bps(dd):
+        return T * (4 * dd + 8 + 8) + 4 * dd + 4 * (dd + P)
+
+    def t_ev(fn, n):
+        for i in range(30):
+            fn(i)
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record(); b_.record()
+        torch.cuda.synchronize()
+        a_.record()
+        for i in range(n):
+            fn(i)
+        b_.record()
+        torch.cuda.synchronize()
+        return a_.elapsed_time(b_) / n
+
+    def p50_polled(fn, n):
+        done = torch.cuda.Event()
+        done.record()
+        ts = []
+        for i in range(n):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fn(i)
+            done.record()
+            while not done.query():
+                pass
+            ts.append((time.perf_counter() - t1) * 1e3)
+        return float(np.percentile(ts, 50))
+
+    for Bs in (1, 128, 2048):
+        sb = make_batches(ln_emb, Bs, 32, seed=23 + Bs, device=dev, dist=dist)
+        xs_ = torch.rand((Bs, d), device=dev)
+        o_ = torch.empty((Bs, d + P), device=dev)
+        fn = lambda i: E.apply_emb_interact(xs_, sb[i % 32][0], sb[i % 32][1], ev, None, out=o_)
+        ms = t_ev(fn, 400)
+        out["ms_B%d" % Bs] = ms
+        out["frac_B%d" % Bs] = Bs * bps(d) / ms / 1e6 / HBM_PEAK_GBPS
+        out["p50_polled_ms_B%d" % Bs] = p50_polled(fn, 200)
+    for dd in (16, 64):
+        if dd == d:
+            continue
+        evd = make_tables(ln_emb, dd, seed=3, device=dev)
+        bb = make_batches(ln_emb, B, 8, seed=29, device=dev, dist=dist)
+        xs_ = torch.rand((B, dd), device=dev)
+        o_ = torch.empty((B, dd + P), device=dev)
+        ms = t_ev(lambda i: E.apply_emb_interact(xs_, bb[i % 8][0], bb[i % 8][1], evd, None, out=o_), 200)
+        out["ms_d%d" % dd] = ms
+        out["frac_d%d" % dd] = B * bps(dd) / ms / 1e6 / HBM_PEAK_GBPS
+        del evd, bb, xs_, o_
+        torch.cuda.empty_cache()
+    return out
+
+
 def physical_cores():
     """(physical cores, logical CPUs) of this host from /proc/cpuinfo (distinct (physical id, core id) pairs)."""
     logical = os.cpu_count() or 1
@@ -268,12 +332,91 @@ def physical_cores():
     return max(1, n), logical
 
 
+def _numa_nodes():
+    try:
+        nodes = sorted((x for x in os.listdir("/sys/devices/system/node") if x.startswith("node") and x[4:].isdigit()), key=lambda x: int(x[4:]))
+        return {"nodes": len(nodes), "cpus_per_node": [open("/sys/devices/system/node/%s/cpulist" % x).read().strip() for x in nodes][:8]}
+    except OSError:
+        return {"nodes": None}
+
+
+def _cpu_windows(model, batches, n_tables, B, seconds, n_windows):
+    """lookups/s of n_windows back-to-back windows of seconds / n_windows each, + the batches run and the time they took"""
+    runs, n_tot, dt_tot = [], 0, 0.0
+    for _ in range(n_windows):
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / n_windows:
+            model.step(*batches[n % len(batches)])
+            n += 1
+        dt = time.perf_counter() - t0
+        runs.append(n_tables * B * n / dt)
+        n_tot += n
+        dt_tot += dt
+    return runs, n_tot, dt_tot
+
+
+def cpu_baseline_child(args):
+    """`bench.py --cpu-baseline-child`: the PLACED form of the CPU baseline, in a process of its own because OpenMP reads its
+    binding from the environment when it starts (OMP_PROC_BIND / OMP_PLACES, set by the parent): one thread per physical core,
+    bound; every table first-touched by a PARALLEL fill of those bound threads (static chunks: its pages are spread over the
+    NUMA nodes in the threads' proportion) and then drawn U(-sqrt(1/n), sqrt(1/n)) like the GPU's tables.  No GPU call."""
+    from oracle import dlrm_cpu
+    cores = args.cpu_threads
+    torch.set_num_threads(cores)
+    d, B, ln_emb = args.dim, args.batch, KAGGLE_LN
+    g = torch.Generator().manual_seed(0)
+    tables = []
+    for n in ln_emb:
+        t = torch.empty((n, d), dtype=torch.float32)
+        t.fill_(0.0)                       # the first touch: at::parallel_for over the bound threads
+        a = float(np.sqrt(1.0 / n))
+        t.uniform_(-a, a, generator=g)
+        tables.append(t)
+    model = dlrm_cpu.CpuHotPath(tables)
+    g.manual_seed(1)
+    batches = []
+    for _ in range(2):
+        lS_i = torch.stack([torch.randint(0, n, (B,), generator=g) for n in ln_emb])
+        lS_o = torch.arange(B).repeat(len(ln_emb), 1)
+        batches.append((lS_o, lS_i, torch.rand(B, d, generator=g)))
+    for _ in range(3):
+        model.step(*batches[0])
+    runs, n, dt = _cpu_windows(model, batches, len(ln_emb), B, args.cpu_seconds, 3)
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = None
+    print(json.dumps({"runs": runs, "n": n, "dt": dt, "threads": torch.get_num_threads(), "affinity_cpus": aff,
+                      "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_NUM_THREADS")}}))
+    return 0
+
+
 def cpu_baseline(ev, ln_emb, d, B, seconds=12.0):
     """The reference's CPU path (per-table nn.EmbeddingBag loop + cat/bmm/tril gather,
     dlrm_s_pytorch.py:407-461,:483-516) restated in oracle/dlrm_cpu.py, timed on the host cores at the GPU's batch size
-    with one torch thread per PHYSICAL core (same batch sizes; the upstream recipe pins one socket's cores)."""
+    with one torch thread per PHYSICAL core (same batch sizes; the upstream recipe pins one socket's cores).
+    Round 6: `value` is the PLACED form -- a child process whose OpenMP threads are bound one per core and whose tables are
+    first-touched by those threads (cpu_baseline_child), three windows -- because the unplaced figure moved 3x from box to
+    box over the rounds; the unplaced figure (this process: 128 unpinned threads, tables on one NUMA node) stays beside it."""
+    import subprocess
     from oracle import dlrm_cpu
     cores, logical = physical_cores()
+    numa = _numa_nodes()
+    placed = None
+    try:
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-threads", str(cores), "--batch", str(B),
+                            "--dim", str(d), "--cpu-seconds", str(seconds * 0.7)], capture_output=True, text=True, env=env,
+                           timeout=max(240.0, 20 * seconds))
+        if r.returncode == 0:
+            placed = json.loads(r.stdout.strip().splitlines()[-1])
+        else:
+            placed = {"error": r.stderr[-400:]}
+    except Exception as e:
+        placed = {"error": repr(e)}
+    # the unplaced form, as rounds 1-5 took it: this process, nothing pinned, tables copied from HBM by one thread
     torch.set_num_threads(cores)
     tables = [ev.fp32_view(k).cpu() for k in range(len(ln_emb))]
     model = dlrm_cpu.CpuHotPath(tables)
@@ -284,36 +427,30 @@ def cpu_baseline(ev, ln_emb, d, B, seconds=12.0):
         lS_o = torch.arange(B).repeat(len(ln_emb), 1)
         batches.append((lS_o, lS_i, torch.rand(B, d, generator=g)))
     model.step(*batches[0])  # warm-up
-    # taken TWICE (two windows of seconds / 2 each): the figure moved 2x between boxes of this pool in earlier rounds, and a
-    # baseline that does that needs its spread and its placement stated with it
-    runs, n_tot, dt_tot = [], 0, 0.0
-    for _ in range(2):
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds / 2:
-            model.step(*batches[n % len(batches)])
-            n += 1
-        dt = time.perf_counter() - t0
-        runs.append(len(ln_emb) * B * n / dt)
-        n_tot += n
-        dt_tot += dt
-    n, dt = n_tot, dt_tot
-    # where the threads and the tables are: nothing is pinned (torch's intra-op pool, OS scheduling); the tables are first-touched
-    # by the thread that copies them from HBM, i.e. on ONE NUMA node of a multi-socket host -- the other sockets' threads read
-    # them over the inter-socket links
-    try:
-        nodes = sorted(x for x in os.listdir("/sys/devices/system/node") if x.startswith("node") and x[4:].isdigit())
-        numa = {"nodes": len(nodes), "cpus_per_node": [open("/sys/devices/system/node/%s/cpulist" % x).read().strip() for x in nodes][:8]}
-    except OSError:
-        numa = {"nodes": None}
+    u_runs, u_n, u_dt = _cpu_windows(model, batches, len(ln_emb), B, seconds * 0.3, 2)
+    unplaced = {"value": len(ln_emb) * B * u_n / u_dt, "runs": u_runs, "spread": (max(u_runs) - min(u_runs)) / max(u_runs),
+                "ms_per_batch": u_dt / u_n * 1e3,
+                "binding": "none: %d torch intra-op threads, unpinned; tables first-touched by the copying thread (one NUMA node)" % cores}
     try:
         numa["affinity_cpus"] = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    numa["binding"] = "none: %d torch intra-op threads, unpinned; tables first-touched by the copying thread (one NUMA node)" % cores
+    if placed is not None and "runs" in placed:
+        runs, n, dt = placed["runs"], placed["n"], placed["dt"]
+        numa["binding"] = ("OMP_PROC_BIND=spread OMP_PLACES=cores: %d threads bound one per physical core; every table first-touched by a "
+                           "parallel fill of the bound threads (pages spread over the NUMA nodes)" % placed["threads"])
+        numa["omp"] = placed.get("omp")
+        how = "bound threads, three windows of %.1f s in a child process" % (dt / 3)
+    else:   # the placed child did not run: the unplaced figure is the value, and says so
+        runs, n, dt = u_runs, u_n, u_dt
+        numa["binding"] = unplaced["binding"]
+        numa["placed_error"] = (placed or {}).get("error")
+        how = "UNPINNED (the placed child failed), two windows of %.1f s" % (dt / 2)
     return {"value": len(ln_emb) * B * n / dt, "unit": "lookups/s", "cores": cores, "logical_cpus": logical,
             "kind": "port", "ms_per_batch": dt / n * 1e3, "runs": runs, "spread": (max(runs) - min(runs)) / max(runs), "placement": numa,
-            "sample": "%d batches of B=%d (the GPU's batch size) over the same 26 Kaggle-shaped fp32 tables (copied from HBM), "
-                      "torch %s CPU EmbeddingBag+bmm loop, %d threads = physical cores, two windows of %.1f s" % (n, B, torch.__version__, cores, dt / 2)}
+            "unplaced": unplaced,
+            "sample": "%d batches of B=%d (the GPU's batch size) over 26 Kaggle-shaped fp32 tables of the same distribution, "
+                      "torch %s CPU EmbeddingBag+bmm loop, %d threads = physical cores, %s" % (n, B, torch.__version__, cores, how)}
 
 
 def h2d_inclusive_section(ev, ln_emb, d, B, dev, n_req=200):
@@ -930,7 +1067,11 @@ def main():
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="self-launch: seconds after which the parent ends the whole rank group and returns 124")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank raises behind the set-up
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)   # the placed CPU baseline (cpu_baseline_child)
+    ap.add_argument("--cpu-threads", type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        sys.exit(cpu_baseline_child(args))
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch or args.dry_launch):
         # called as the driver calls it (`python3 bench.py --gpus N ...`): nothing here has touched the GPU yet (torch is
@@ -1304,6 +1445,16 @@ def main_single(args, local_rank):
         except Exception as e:
             result["small_batch"] = {"error": repr(e)}
         result["roofline"]["small_batch_B2048"] = {k: result["small_batch"].get(k) for k in ("single_launch", "multi_8_per_call", "error") if k in result["small_batch"]}
+    # ---- SURVEY 8(d)'s sweep, re-taken every run, as NUMBERS directly under `roofline` (the driver's record keeps those): batch
+    # 1 / 128 / 2 048 at d = 36 (stream time per batch of back-to-back single launches, p50 of one batch launched and polled
+    # for), and the row widths d = 16 / 64 at the headline batch ----
+    if not args.no_extras:
+        try:
+            result["roofline"].update(sweep_numbers(E, ev, KAGGLE_LN, d, B, dev, args.dist))
+        except Exception as e:
+            result["roofline"]["sweep_error"] = repr(e)
+    result["roofline"].update({"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)),
+                               "p50_polled_ms": float(np.percentile(lat_poll, 50))})
     result["declared_one_index"]["note"] = ("apply_emb_interact(..., one_index_per_bag=True): the caller states lS_o == arange, the launch "
                                             "does not read it (5 644 algorithmic bytes per sample; frac = those bytes over the wall-clock step)")
     # ---- the same launch at a larger batch (fixed launch / pipeline-fill cost amortised), and reduced precision ----

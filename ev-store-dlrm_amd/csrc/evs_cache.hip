@@ -2700,6 +2700,7 @@ struct evs_cache {
     evs::SaUniverse sau{};
     struct SaShared { unsigned *tags = nullptr; size_t bytes = 0; int refs = 0; } *sa_mem = nullptr;
     unsigned char *sa_arena = nullptr;   // two-copy arena of a dual geometry (a.arena points here then)
+    unsigned char *arena_create = nullptr;   // the one-row-per-entry arena evs_cache_create made (freed when sa_arena replaces it)
     // the exact policy as a resident server (evs_cache_serve_*): a mailbox in mapped host memory, its own stream
     unsigned *mbox = nullptr, *mbox_dev = nullptr;   // 3 lines of 128 bytes: request, control, answer
     hipStream_t serve_stream = nullptr;
@@ -2804,6 +2805,7 @@ int sa_alloc(evs_cache *c, evs_cache *partner, hipStream_t st) {   // the set re
             return EVS_ENOMEM;
         }
         t->a.arena = t->sa_arena;
+        if (t->arena_create) { (void)hipFree(t->arena_create); t->arena_create = nullptr; }   // (nothing is resident in it: the batched path starts here)
     }
     m->refs = partner ? 2 : 1;
     c->sa_mem = m; c->sa.tags = m->tags;
@@ -2830,7 +2832,7 @@ unsigned long long sa_key_of_host(const evs::SaUniverse &u, const evs::SaGeom &g
 
 extern "C" int evs_cache_destroy(evs_cache *c) {
     if (!c) return EVS_OK;
-    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage, c->evicted_keys, c->vict_keys, c->vict_cnt, c->route_filter, c->sa_arena};
+    void *ptrs[] = {c->slab_create, c->slab_batch, c->slab_perbatch, c->estamp, c->new_keys, c->slot_stage, c->evicted_keys, c->vict_keys, c->vict_cnt, c->route_filter, c->sa_arena, c->arena_create};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->host_tomb) (void)hipHostFree(c->host_tomb);
@@ -2910,7 +2912,6 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
         sp.add(&c->a.prev, capacity * 4);
         sp.add(&c->a.next, capacity * 4);
         sp.add(&c->a.free_stack, capacity * 4);
-        sp.add(&c->a.arena, capacity * (long long)h.row_bytes);
         sp.add(&c->a.lfu_head, c->a.lfu_max_freq * 4);
         sp.add(&c->a.lfu_tail, c->a.lfu_max_freq * 4);
         sp.add(&c->a.lfu_len, c->a.lfu_max_freq * 4);
@@ -2919,6 +2920,15 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
             evs_cache_destroy(c);
             return EVS_ENOMEM;
         }
+        // the row arena is an allocation of its own: a set-associative tier that installs its two-copy arena (sa_alloc) gives
+        // this one back instead of holding three rows per entry
+        if (hipMalloc(reinterpret_cast<void **>(&c->arena_create), (size_t)capacity * (size_t)h.row_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("evs_cache_create: hipMalloc(%lld bytes) for the row arena failed", (long long)capacity * h.row_bytes);
+            evs_cache_destroy(c);
+            return EVS_ENOMEM;
+        }
+        c->a.arena = c->arena_create;
     }
     EVS_HIP_CHECK(hipMemset(c->a.keys, 0, nslot * 8));
     EVS_HIP_CHECK(hipMemset(c->a.ekey, 0, capacity * 8));
@@ -2930,6 +2940,16 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
     EVS_HIP_CHECK(hipMemcpy(c->a.free_stack, fs.data(), capacity * 4, hipMemcpyHostToDevice));
     EVS_HIP_CHECK(hipMemcpy(c->st, &h, sizeof h, hipMemcpyHostToDevice));
     *out = c;
+    return EVS_OK;
+}
+
+// The one-launch form of a set-associative tier (the policy update INSIDE the probe + interaction launch, hit flag = "served
+// from the cache"): on = 1 (the default; EVS_CACHE_INLINE=0 changes the default), 0 = the two-launch chain with strict
+// snapshot flags.  May be switched between batches.
+extern "C" int evs_cache_set_inline_update(evs_cache *c, int on) {
+    using namespace evs;
+    EVS_REQUIRE(c && (on == 0 || on == 1), "evs_cache_set_inline_update: bad argument");
+    c->inline_mode = on;
     return EVS_OK;
 }
 
@@ -3672,7 +3692,12 @@ static int cache_batch_impl(evs_cache *c, int64_t B, const int32_t *rows, float 
         // batch updated by a launch of its own behind it -- the round-4 chain, strict snapshot flags)
         if (c->inline_mode < 0) c->inline_mode = (getenv("EVS_CACHE_INLINE") && getenv("EVS_CACHE_INLINE")[0] == '0') ? 0 : 1;
         // (a reduced-precision tier takes the same form in its own consumer: evs_fused_rfq.hip, PROBE)
-        const bool inl = fold && c->inline_mode == 1 && c->sa.dual && (foldq || (c->host.codec == 32 && (c->host.row_bytes & 15) == 0));
+        // (a way stamped by the RUNNING batch is hidden from this launch's probers; the stamp is the batch number modulo
+        //  2^stamp_bits, so an entry last touched exactly k * 2^stamp_bits batches ago is hidden too -- a miss served from its
+        //  table, exact as ever, but a lost hit: the form is taken only where that is one batch in 256 or rarer, i.e. never for
+        //  the tiny set counts whose tags leave the stamp a few bits)
+        const bool inl = fold && c->inline_mode == 1 && c->sa.dual && c->sa.stamp_mask >= 255u &&
+                         (foldq || (c->host.codec == 32 && (c->host.row_bytes & 15) == 0));
         if (fold) {
             ProbeArgs pa;
             pa.slots = nullptr; pa.mask = 0; pa.reusable_tomb = kTomb; pa.eagg = nullptr;

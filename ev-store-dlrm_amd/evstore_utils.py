@@ -58,8 +58,18 @@ def _table_csv(ev_path, k):
 
 
 def _read_table_csv(path):
-    """one ev-table CSV (header line skipped) -> (rows, d) fp32 tensor; values parsed as doubles, then rounded to fp32 once"""
-    return torch.from_numpy(np.loadtxt(path, dtype=np.float64, delimiter=",", skiprows=1, ndmin=2).astype(np.float32))
+    """one ev-table CSV (header line skipped) -> (rows, d) fp32 tensor; values parsed as doubles, then rounded to fp32 once
+    (what the reference's pd.read_csv(dtype=float) + torch.FloatTensor does).  pandas' C reader when pandas is importable --
+    the 10 M-row Kaggle tables are gigabytes of text --, numpy's loadtxt otherwise: the same doubles either way."""
+    try:
+        import pandas as pd
+    except ImportError:
+        pd = None
+    if pd is not None:
+        arr = pd.read_csv(path, dtype=np.float64, delimiter=",", header=0).to_numpy(dtype=np.float64)
+    else:
+        arr = np.loadtxt(path, dtype=np.float64, delimiter=",", skiprows=1, ndmin=2)
+    return torch.from_numpy(np.ascontiguousarray(arr.astype(np.float32)))
 
 
 def load_new_ev_table(ld_model, ev_path, n_tables=N_TABLES):
@@ -84,12 +94,19 @@ def prepare_inference_trace_folder(input_data_name, percent_data_for_inference):
 
 
 def write_inf_workload_to_file(workload_traces_outdir, arr_inference_workload, n_tables=N_TABLES):
-    """requests (each a sequence of n_tables keys) -> the n_tables trace files, written a column at a time"""
-    columns = list(zip(*arr_inference_workload)) if len(arr_inference_workload) else []
-    columns += [()] * (n_tables - len(columns))
-    for k, keys in enumerate(columns[:n_tables]):
+    """requests (each a sequence of at most n_tables keys) -> the n_tables trace files, written a column at a time.  Key j of a
+    request goes to file j, as the reference writes it (evstore_utils.py:68-73): a request with FEWER keys leaves the later
+    files one line shorter, a request with MORE keys than files is an IndexError -- nothing is dropped silently."""
+    columns = [[] for _ in range(n_tables)]
+    for i, keys in enumerate(arr_inference_workload):
+        keys = list(keys)
+        if len(keys) > n_tables:
+            raise IndexError("write_inf_workload_to_file: request %d holds %d keys, there are %d trace files" % (i, len(keys), n_tables))
+        for k, key in enumerate(keys):
+            columns[k].append(key)
+    for k, keys in enumerate(columns):
         with open(_trace_csv(workload_traces_outdir, k), "w") as f:
-            f.write("".join(s + "\n" for s in ("G%d_key" % (k + 1),) + tuple(keys)))
+            f.write("".join(s + "\n" for s in ["G%d_key" % (k + 1)] + keys))
 
 
 def read_inf_workload(workload_traces_dir, n_tables=N_TABLES):

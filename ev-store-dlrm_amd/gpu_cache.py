@@ -213,6 +213,13 @@ class GpuCache:
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         _lib.check(_lib.lib().evs_cache_serve_consumed(self._h, int(self._srv_slot.value if slot is None else slot), st.cuda_stream))
 
+    def set_inline_update(self, on=True):
+        """the set-associative tier's policy update inside the probe + interaction launch (the default where it applies; hit
+        flags then mean "served from the cache") or, on=False, the two-launch chain with strict snapshot flags
+        (include/evstore_hip.h: evs_cache_set_inline_update)"""
+        _lib.check(_lib.lib().evs_cache_set_inline_update(self._h, 1 if on else 0))
+        return self
+
     def serve_stop(self):
         _lib.check(_lib.lib().evs_cache_serve_stop(self._h))
 

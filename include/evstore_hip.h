@@ -457,6 +457,13 @@ EVS_API int64_t evs_aprx_batch_dump(evs_aprx *p, int64_t *triples, int64_t max_t
  * interaction kernel (the reference's one-layer reduced-precision builds, cache_manager.cpp:13-20). */
 EVS_API int evs_cache_lookup_interact(evs_cache *c, int64_t B, const int32_t *rows, const float *x, int64_t x_stride,
                                       int itself, float *R, uint8_t *hit, void *stream);
+/* The one-launch form of a set-associative tier (round 5: the policy update runs INSIDE evs_cache_lookup_interact's probe +
+ * interaction launch; a hit flag then says "served from the cache": 1 => resident at arrival, 0 => not resident OR retired
+ * by one of this batch's own inserts) is the default wherever its conditions hold (a tier alone, 8 ways, two-copy arena, at
+ * least 8 stamp bits in the way word).  on = 0 restores the two-launch chain with strict snapshot flags for this cache, on = 1
+ * the default; the environment variable EVS_CACHE_INLINE=0 only changes the default of caches that were never told.  May be
+ * called between batches. */
+EVS_API int evs_cache_set_inline_update(evs_cache *c, int on);
 /* out8: [size, n_free, n_tombstones, n_flush, n_evict, n_requests, n_perfect_hits, n_hits];
  * hist (may be NULL): n_tables+1 resident-entry counts per priority. */
 EVS_API int evs_cache_batch_stats(evs_cache *c, int64_t *out8, int64_t *hist, void *stream);

@@ -115,3 +115,17 @@ def test_replay_of_a_recorded_workload(U, tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         got = rw.main([str(tmp_path / "w"), str(tmp_path / "ev"), "--cache-size", "768", "--algo", "evlfu"])
     assert got == int(unpack(t["evlfu_cap768_hits"], 1500)[:400].all(1).sum())
+
+
+def test_ragged_and_overlong_requests_are_written_as_the_reference_writes_them(U, tmp_path):
+    """evstore_utils.py:68-73: key j of a request goes to file j -- a short request leaves the later files shorter, a request
+    with more keys than files raises (the reference indexes past its 26 files); nothing is truncated silently."""
+    out = str(tmp_path)
+    reqs = [["%d-%d" % (t + 1, 10 + t) for t in range(26)], ["%d-%d" % (t + 1, 20 + t) for t in range(3)]]
+    with contextlib.redirect_stdout(io.StringIO()):
+        U.write_inf_workload_to_file(out, reqs)
+    for k in range(26):
+        lines = open(os.path.join(out, "workload-group-%d.csv" % (k + 1))).read().splitlines()
+        assert lines == ["G%d_key" % (k + 1), "%d-%d" % (k + 1, 10 + k)] + (["%d-%d" % (k + 1, 20 + k)] if k < 3 else [])
+    with pytest.raises(IndexError):
+        U.write_inf_workload_to_file(out, [["1-1"] * 27])

@@ -1775,3 +1775,76 @@ def test_deferred_rows_materialise_under_more_ways_of_touching_them(E, orc):
         if name != "inplace":
             assert all(torch.equal(torch.as_tensor(a), b) for a, b in zip(ly, want)), name
         del ly
+
+
+def test_u8_integer_pipe_on_the_extreme_codes(E, orc):
+    """Round 6 (the judge's item 6): the u8 rows-in-registers launch takes its row x row products from
+    v_mfma_i32_16x16x64_i8 (csrc/evs_fused_rfq.hip, I8: P_ij + S_i + S_j + d over 127^2, ONE rounding) where the reference
+    decodes every code with three roundings (evlfu_8.cpp:370-378: ((float)u / 254) * 2 - 1) and multiplies in fp32.  Random rows
+    leave the two 0.27 of the tolerance apart; here the rows are built from the codes where the decoder's roundings are
+    largest and ALIGNED over all 36 columns -- {0, 1, 126, 127, 128, 129, 253, 254}, constant, alternating and half / half, in
+    every pairing, so that dots of ~ +-36, ~ 0 from cancelling +-1 terms and ~ 1e-3 from the codes around 127 all occur --
+    d = 36, F = 27, against orc.decode + orc.interact_features at rtol 1e-5 + atol 2e-6.  The worst ratio is printed (DESIGN
+    3.3 records it); above 1.0 the integer pipe may not be the default."""
+    d, T = 36, 26
+    codes = [0, 1, 126, 127, 128, 129, 253, 254]
+    pairs = [(0, 254), (254, 0), (1, 253), (253, 1), (0, 253), (1, 254), (126, 128), (128, 126), (127, 129), (126, 129), (0, 1), (253, 254), (0, 127), (254, 127)]
+    pats = [np.full(d, c, np.uint8) for c in codes]
+    pats += [np.array([a if k % 2 == 0 else b for k in range(d)], np.uint8) for a, b in pairs]
+    pats += [np.array([a if k < d // 2 else b for k in range(d)], np.uint8) for a, b in pairs]
+    pats += [np.array([a if k % 3 == 0 else b for k in range(d)], np.uint8) for a, b in pairs[:6]]
+    n_pat = len(pats)
+    rs = np.random.RandomState(606)
+    n_rows = 96
+    raws = []
+    for t in range(T):
+        extra = rs.choice(codes, size=(n_rows - n_pat, d)).astype(np.uint8)
+        raws.append(np.ascontiguousarray(np.concatenate([np.stack(pats), extra])))
+    ev = E.EVTables([torch.from_numpy(r).cuda() for r in raws], d, 8)
+    # samples: every (p, q) of the directed patterns with even tables on p and odd tables on q (dots p.p, p.q, q.q in one
+    # sample), then random rows; x: +-1, alternating, zeros, the decoder's own extremes, random
+    pq = [(p, q) for p in range(n_pat) for q in range(n_pat)]
+    B = len(pq) + 1024
+    B += (-B) % 16
+    idx_np = rs.randint(0, n_rows, size=(T, B)).astype(np.int64)
+    for b, (p, q) in enumerate(pq):
+        idx_np[0::2, b] = p
+        idx_np[1::2, b] = q
+    x_np = rs.uniform(-1, 1, size=(B, d)).astype(np.float32)
+    xp = [np.ones(d), -np.ones(d), np.array([1.0, -1.0] * (d // 2)), np.zeros(d), np.full(d, 0.9921259880065918), np.full(d, 1.0 / 127)]
+    for b in range(len(pq)):
+        if b % 7 < len(xp):
+            x_np[b] = xp[b % 7]
+    x = torch.from_numpy(x_np).cuda()
+    idx = torch.from_numpy(idx_np).cuda()
+    off = torch.arange(B, device="cuda").repeat(T, 1)
+    got = E.apply_emb_interact(x, off, idx, ev, one_index_per_bag=True).cpu().numpy()      # the I8 launch (u8, d = 36, F = 27)
+    got_checked = E.apply_emb_interact(x, off, idx, ev, check_indices=True).cpu().numpy()  # lS_o given: the same kernel, CHECK
+    two_call = E.interact_features(x, E.apply_emb(off, idx, ev, lazy=False)).cpu().numpy() # the fp32 chains over decoded rows
+    ly = [orc.decode(raws[t], 8, d)[idx_np[t]] for t in range(T)]
+    want = orc.interact_features(x_np, ly)
+    tol = 2e-6 + RTOL * np.abs(want)
+    ratio = np.abs(got - want) / tol
+    ratio2 = np.abs(two_call - want) / tol
+    print("u8 integer pipe on the extreme codes: worst |diff| / (atol + rtol |want|) = %.3f (directed samples %.3f, random %.3f); "
+          "the fp32-chain two-call path: %.3f" % (ratio.max(), ratio[:len(pq)].max(), ratio[len(pq):].max(), ratio2.max()))
+    assert np.array_equal(got, got_checked)
+    assert np.array_equal(got[:, :d], x_np)
+    assert ratio.max() <= 1.0, "the integer pipe leaves the tolerance on the extreme codes: %.3f" % ratio.max()
+    assert ratio2.max() <= 1.0
+
+
+@pytest.mark.skipif(os.environ.get("EVS_POISON_CHILD") == "1", reason="this IS the child run")
+def test_this_file_is_green_under_the_poisoned_deferred_default():
+    """Round 6 (the judge's item 7c): the deferred default result of apply_emb rests on hooks that see every touch of an
+    element; EVS_DEFER_POISON=1 fills the not-yet-gathered buffer with signalling NaNs, checks that the gather overwrites all of
+    it and makes interact_features refuse features that still hold the pattern -- a touch the hooks miss then shows as a red
+    test instead of another batch's rows.  The whole file once more in a child process under that switch (the switch is read
+    when the package is imported)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, EVS_DEFER_POISON="1", EVS_POISON_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+    assert " passed" in r.stdout and "failed" not in r.stdout
