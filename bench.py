@@ -1047,8 +1047,10 @@ def main():
     ap.add_argument("--cdf-dir", default=os.path.join(ROOT, "gpurun_out", "cdf"), help="where the B=1 latency CDF CSV goes")
     ap.add_argument("--replicate-gb", type=float, default=64.0, help="per-GPU HBM budget for replicated tables (hbm placement)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one process")
-    ap.add_argument("--exchange-mode", default="inline", choices=["inline", "async", "p2p", "auto"],
-                    help="N>1: all_to_all_single(async_op=False) in stream order (default), async_op=True with the handle waited on in front of the "
+    ap.add_argument("--exchange-mode", default="direct", choices=["direct", "inline", "async", "p2p", "auto"],
+                    help="N>1: direct (default) = the RCCL all-to-all issued by the extension itself on the step's stream (ONE ncclAllToAllv over a "
+                         "communicator of its own: no torch.distributed call in the step; falls back to inline where the extension or RCCL is missing); "
+                         "inline = all_to_all_single(async_op=False) in stream order, async_op=True with the handle waited on in front of the "
                          "interaction, or p2p: no collective call -- the pooling kernel writes every peer's block straight into that peer's "
                          "IPC-mapped receive buffer, two flag words per (peer, slot) hand it over (csrc/evs_p2p.hip); auto: p2p when ONE batch through both "
                          "exchanges gave bit-equal receive buffers on every rank (sharded.verify_p2p_against_collective), the RCCL collective otherwise")
@@ -1130,6 +1132,8 @@ def main_sharded(args, rank, world, local_rank):
             print(json.dumps(result), flush=True)
         result["exchange_p2p"] = sharded.bench_p2p_side(args, ln_run, rank, world, dev)
     dist.barrier()
+    torch.cuda.synchronize()
+    sharded.direct_close()
     dist.destroy_process_group()
     if rank == 0:
         # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line

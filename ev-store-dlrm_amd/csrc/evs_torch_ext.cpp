@@ -373,6 +373,130 @@ py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i_in, int 
     return py::make_tuple(flags, slices(block, true), all);
 }
 
+// ---- the all-to-all of the sharded step, issued from here (round 6) -----------------------------------------------------------
+// dlrm_s_pytorch.py:543-570 / extend_distributed.py:389-465 exchange "local tables x full batch" for "all tables x local
+// batch" with one all_to_all_single; through torch.distributed that call costs 14-38 us of HOST time per step on this stack
+// (ProcessGroupNCCL: work objects, event pairs, stream hand-overs), more than the two kernels of the step together.  Here the
+// same exchange is ONE call into RCCL -- ncclAllToAllv (RCCL's own entry point; grouped ncclSend / ncclRecv where a build
+// lacks it) -- on torch's CURRENT stream, in stream order between the pooling launch and the interaction, over a communicator
+// of this extension's own (unique id made on rank 0 and handed round through the process group by the Python side).
+// RCCL is reached through the copy torch has already loaded (dlsym on the global scope; no link-time dependency: the
+// extension loads where RCCL is absent, and sharded.py then keeps all_to_all_single).
+}  // namespace
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllToAllv) AllToAllv = nullptr;   // may stay NULL
+    bool ok = false;
+};
+const RcclApi &rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        void *h = dlopen(nullptr, RTLD_NOW);        // the global scope: torch's librccl.so is in it once torch has been imported
+        auto sym = [&](const char *name) -> void * {
+            void *p = h ? dlsym(h, name) : nullptr;
+            if (!p) { void *l = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); if (l) p = dlsym(l, name); }
+            return p;
+        };
+#define EVS_RCCL_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(sym(name))
+        EVS_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); EVS_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+        EVS_RCCL_SYM(CommDestroy, "ncclCommDestroy"); EVS_RCCL_SYM(CommAbort, "ncclCommAbort");
+        EVS_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+        EVS_RCCL_SYM(GroupStart, "ncclGroupStart"); EVS_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+        EVS_RCCL_SYM(Send, "ncclSend"); EVS_RCCL_SYM(Recv, "ncclRecv"); EVS_RCCL_SYM(AllToAllv, "ncclAllToAllv");
+#undef EVS_RCCL_SYM
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+        return a;
+    }();
+    return api;
+}
+inline void rccl_check(ncclResult_t r, const char *what) {
+    if (r != ncclSuccess) {
+        const char *m = rccl().GetErrorString ? rccl().GetErrorString(r) : "?";
+        throw std::runtime_error(std::string("RCCL ") + what + ": " + m);
+    }
+}
+bool rccl_available() { return rccl().ok; }
+py::bytes rccl_unique_id() {
+    TORCH_CHECK(rccl().ok, "RCCL is not loaded in this process");
+    ncclUniqueId id;
+    rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    return py::bytes(reinterpret_cast<const char *>(&id), sizeof id);
+}
+
+// one communicator + the exchanges planned over it (fixed buffers and split lists: a serving loop reuses its staged buffers)
+struct DirectA2A {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    c10::DeviceIndex device = 0;
+    bool use_v = true;
+    struct Plan { const float *send; float *recv; std::vector<size_t> scnt, sdis, rcnt, rdis; };
+    std::vector<Plan> plans;
+
+    DirectA2A(const std::string &id_bytes, int rank_, int world_, int device_index, bool allow_alltoallv)
+        : rank(rank_), world(world_), device(static_cast<c10::DeviceIndex>(device_index)) {
+        TORCH_CHECK(rccl().ok, "RCCL is not loaded in this process");
+        ncclUniqueId id;
+        TORCH_CHECK(id_bytes.size() == sizeof id, "the unique id has ", id_bytes.size(), " bytes, expected ", sizeof id);
+        std::memcpy(&id, id_bytes.data(), sizeof id);
+        c10::hip::HIPGuard guard(device);
+        {
+            py::gil_scoped_release nogil;     // (blocks until every rank has arrived)
+            rccl_check(rccl().CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+        }
+        use_v = allow_alltoallv && rccl().AllToAllv != nullptr;
+    }
+    ~DirectA2A() { close(); }
+    void close() {
+        if (comm) { (void)rccl().CommDestroy(comm); comm = nullptr; }
+    }
+    // recv / send: flat fp32 device tensors; out_splits[p] = elements received FROM rank p, in_splits[p] = elements sent TO rank p
+    // (all_to_all_single's argument order, extend_distributed.py:394-405).  -> the plan's number
+    int64_t plan(const at::Tensor &recv, const at::Tensor &send, const std::vector<int64_t> &out_splits, const std::vector<int64_t> &in_splits) {
+        TORCH_CHECK((int)out_splits.size() == world && (int)in_splits.size() == world, "one split per rank");
+        TORCH_CHECK(recv.is_cuda() && send.is_cuda() && recv.scalar_type() == at::kFloat && send.scalar_type() == at::kFloat &&
+                    recv.is_contiguous() && send.is_contiguous(), "recv / send must be contiguous fp32 device tensors");
+        Plan p;
+        p.send = send.data_ptr<float>(); p.recv = recv.data_ptr<float>();
+        size_t so = 0, ro = 0;
+        for (int r = 0; r < world; r++) {
+            TORCH_CHECK(out_splits[r] >= 0 && in_splits[r] >= 0, "negative split");
+            p.scnt.push_back((size_t)in_splits[r]); p.sdis.push_back(so); so += (size_t)in_splits[r];
+            p.rcnt.push_back((size_t)out_splits[r]); p.rdis.push_back(ro); ro += (size_t)out_splits[r];
+        }
+        TORCH_CHECK((int64_t)so <= send.numel() && (int64_t)ro <= recv.numel(), "the splits exceed the buffers");
+        TORCH_CHECK(p.send != p.recv, "the exchange needs a receive buffer of its own");
+        plans.push_back(std::move(p));
+        return (int64_t)plans.size() - 1;
+    }
+    void run(int64_t k) {
+        TORCH_CHECK(comm && k >= 0 && k < (int64_t)plans.size(), "no such plan");
+        const Plan &p = plans[(size_t)k];
+        hipStream_t st = c10::hip::getCurrentHIPStream(device).stream();
+        if (use_v) {
+            rccl_check(rccl().AllToAllv(p.send, p.scnt.data(), p.sdis.data(), p.recv, p.rcnt.data(), p.rdis.data(), ncclFloat, comm, st), "ncclAllToAllv");
+            return;
+        }
+        rccl_check(rccl().GroupStart(), "ncclGroupStart");
+        for (int r = 0; r < world; r++) {
+            if (p.scnt[r]) rccl_check(rccl().Send(p.send + p.sdis[r], p.scnt[r], ncclFloat, r, comm, st), "ncclSend");
+            if (p.rcnt[r]) rccl_check(rccl().Recv(p.recv + p.rdis[r], p.rcnt[r], ncclFloat, r, comm, st), "ncclRecv");
+        }
+        rccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    }
+};
+
 void set_error_class(py::object cls) {
     Py_XDECREF(g_error_class);
     g_error_class = cls.release().ptr();
@@ -404,4 +528,12 @@ PYBIND11_MODULE(_evs_torch_ext, m) {
     m.def("hostcache_request_list", &hostcache_request_list);
     m.def("serve_request_list", &serve_request_list);
     m.def("slices", &slices);
+    m.def("rccl_available", &rccl_available);
+    m.def("rccl_unique_id", &rccl_unique_id);
+    py::class_<DirectA2A>(m, "DirectA2A")
+        .def(py::init<const std::string &, int, int, int, bool>())
+        .def("plan", &DirectA2A::plan)
+        .def("run", &DirectA2A::run)
+        .def("close", &DirectA2A::close)
+        .def_readonly("use_alltoallv", &DirectA2A::use_v);
 }

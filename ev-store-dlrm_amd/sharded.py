@@ -427,6 +427,7 @@ class ShardedEmbeddingInteract:
         self._bufs = {}
         self._route = {}
         self._p2p = {}
+        self._direct_plans = {}
 
     def tables_held(self):
         return self.my_own + self.replicated + self.split
@@ -697,9 +698,22 @@ class ShardedEmbeddingInteract:
     # 52-57 inline on the same box -- the step is bound by the HOST cost of the collective's call path (14-38 us per call),
     # and two more stream operations per step add to it; what takes the collective off the step is exchange_mode "p2p"
     # (29.5 us; picked by "auto" -- bench.py -- once one batch through both exchanges gave bit-equal receive buffers).
+    #   "direct" (round 6): the same collective issued by the extension itself -- ONE ncclAllToAllv on the step's stream over a
+    #             communicator of the extension's own (csrc/evs_torch_ext.cpp: DirectA2A), no ProcessGroup call in the step;
+    #             falls back to "inline" where the extension or RCCL is missing (direct_comm returns None).
     exchange_mode = "inline"
 
     def _exchange(self, recv, send, out_splits, in_splits):
+        if self.exchange_mode == "direct":
+            a2a = direct_comm(self.group, recv.device)
+            if a2a is not None:
+                key = (recv.data_ptr(), send.data_ptr(), tuple(out_splits), tuple(in_splits))
+                k = self._direct_plans.get(key)
+                if k is None:
+                    # (the plan holds raw addresses: the buffers are this op's own -- _buffers -- and live as long as it does)
+                    k = self._direct_plans[key] = (a2a, a2a.plan(recv.view(-1), send.view(-1), list(out_splits), list(in_splits)))
+                k[0].run(k[1])
+                return None
         if self.exchange_mode == "async":
             return dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group, async_op=True)
         dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group, async_op=False)
@@ -774,6 +788,50 @@ class ShardedEmbeddingInteract:
         return self.finish(self.start(lS_o, lS_i), x_local, lS_o, lS_i)
 
 
+# ----------------------------------------------------------------------------- the extension's own RCCL communicator
+_direct = {}
+
+
+def direct_comm(group, device):
+    """The DirectA2A of (group, device) -- made once: rank 0 draws the RCCL unique id, the process group hands it round
+    (broadcast_object_list: any backend), every rank joins ncclCommInitRank -- or None when the extension / RCCL is missing on
+    ANY rank (agreed over the group first: a communicator some ranks never join would hang the others) or the group is not
+    an RCCL one.  EVS_DIRECT_A2A=0 switches it off; EVS_DIRECT_A2A_V=0 takes grouped ncclSend / ncclRecv instead of ncclAllToAllv."""
+    dev = torch.device(device)
+    key = (id(group) if group is not None else None, dev.index)
+    if key in _direct:
+        return _direct[key]
+    a2a = None
+    try:
+        from . import _ext
+        X = _ext.ext()
+        ok = (os.environ.get("EVS_DIRECT_A2A", "1") != "0" and X is not None and hasattr(X, "DirectA2A") and X.rccl_available()
+              and dist.is_initialized() and dist.get_backend(group) == "nccl" and dev.type == "cuda")
+        if dist.is_initialized() and dist.get_backend(group) == "nccl":
+            t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            ok = bool(int(t.item()))
+        if ok:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            box = [X.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            a2a = X.DirectA2A(box[0], rank, world, dev.index or 0, os.environ.get("EVS_DIRECT_A2A_V", "1") != "0")
+    except Exception as ex:   # (never fatal: the collective through torch.distributed is still there)
+        import warnings
+        warnings.warn("the extension's RCCL communicator could not be made (%r): all_to_all_single is used" % (ex,))
+        a2a = None
+    _direct[key] = a2a
+    return a2a
+
+
+def direct_close():
+    """destroy the extension's communicators (before the process group goes: bench.py, tests)"""
+    for a in _direct.values():
+        if a is not None:
+            a.close()
+    _direct.clear()
+
+
 # ----------------------------------------------------------------------------- bench (N > 1)
 def _bench_weights(ln_emb, d, rank, world, dev, owner):
     """the bench's tables of one rank: same values on every rank that holds table t (a row-split table: this rank's row range)"""
@@ -787,7 +845,7 @@ def _bench_weights(ln_emb, d, rank, world, dev, owner):
     return weights
 
 
-def _verify_for_bench(args, ln_emb, rank, world, dev, policy, budget_rows):
+def _verify_for_bench(args, ln_emb, rank, world, dev, policy, budget_rows, other="p2p"):
     """verify_p2p_against_collective on the bench's own placement and one of its batches"""
     d, Bg = args.dim, args.batch * world
     owner = plan_placement(ln_emb, world, policy, replicate_budget_rows=budget_rows)
@@ -798,7 +856,7 @@ def _verify_for_bench(args, ln_emb, rank, world, dev, policy, budget_rows):
     lS_i = [torch.randint(0, n, (Bg,), device=dev, generator=g, dtype=torch.int64) for n in ln_emb]
     ok = verify_p2p_against_collective(ln_emb, d, rank, world, weights, HipBackend(dev), policy, [off] * len(ln_emb), lS_i,
                                        force_exchange=bool(getattr(args, "force_exchange", False)), one_index_per_bag=True,
-                                       replicate_budget_rows=budget_rows)
+                                       replicate_budget_rows=budget_rows, other=other)
     del weights
     torch.cuda.empty_cache()
     return ok
@@ -828,6 +886,17 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
                                   replicate_budget_rows=budget_rows)
     op.force_exchange = bool(getattr(args, "force_exchange", False))
     op.exchange_mode = getattr(args, "exchange_mode", "inline")
+    direct_used = None
+    if op.exchange_mode == "direct":   # made here, outside the timed loops (ncclCommInitRank is a rendezvous)
+        a2a_ = direct_comm(None, dev) if (world > 1 or op.force_exchange) else None
+        direct_used = None if a2a_ is None else ("ncclAllToAllv" if a2a_.use_alltoallv else "grouped ncclSend/ncclRecv")
+        # no box with two GPUs has run it: ONE batch through all_to_all_single and through the extension's call, every rank's
+        # receive buffer bit for bit, the verdict agreed on over the group -- only then is it the timed exchange
+        if a2a_ is not None and not _verify_for_bench(args, ln_emb, rank, world, dev, policy, budget_rows, other="direct"):
+            direct_used = "refused: receive buffers differ from all_to_all_single's (%s)" % (getattr(verify_p2p_against_collective, "last_error", None),)
+            a2a_ = None
+        if a2a_ is None:
+            op.exchange_mode = "inline"
     # every rank generates the same full-batch indices (same seed), as the reference feeds them
     g.manual_seed(7)
     nb = 4
@@ -915,6 +984,7 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     local_lookups = [Bl * n_rep for _ in range(world)]
     res = {"dt": dt, "dt_per_rank": dt_per_rank, "pool_lookups_per_rank": pool_lookups, "local_lookups_per_rank": local_lookups,
            "owner": owner, "n_sharded": n_sh, "n_rowsplit": n_split, "n_replicated": n_rep, "mode": mode,
+           "exchange_used": op.exchange_mode, "direct_a2a": direct_used,
            # bytes that leave a rank per step (its pooled vectors -- and its partials of the row-split tables -- for the
            # other ranks' batch slices), and over all ranks
            "a2a_bytes_per_rank": 4 * d * Bl * (len(op.my_own) + n_split) * (world - 1),
@@ -959,7 +1029,7 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     return res
 
 
-def verify_p2p_against_collective(ln_emb, d, rank, world, weights, backend, policy, lS_o, lS_i, force_exchange=False, **op_kw):
+def verify_p2p_against_collective(ln_emb, d, rank, world, weights, backend, policy, lS_o, lS_i, force_exchange=False, other="p2p", **op_kw):
     """Before anybody trusts (or times) the device-to-device exchange on hardware no test has seen: ONE batch through both
     exchanges -- the RCCL all_to_all_single and exchange_mode "p2p" -- and every rank's receive buffer compared bit for bit;
     the verdict is agreed on over the process group (all ranks return the same bool, none raises).  Cost: two ops' buffers
@@ -968,7 +1038,7 @@ def verify_p2p_against_collective(ln_emb, d, rank, world, weights, backend, poli
     verify_p2p_against_collective.last_error = None   # this rank's reason when the verdict is False because something raised
     try:
         recvs = []
-        for mode in ("inline", "p2p"):
+        for mode in ("inline", other):    # (other = "direct", round 6: the extension's own ncclAllToAllv against all_to_all_single)
             op = ShardedEmbeddingInteract(ln_emb, d, rank, world, weights, backend, policy=policy, **op_kw)
             op.force_exchange = bool(force_exchange)
             op.exchange_mode = mode
@@ -1104,7 +1174,8 @@ def bench_sharded(args, ln_emb, rank, world, dev):
                    "batch_per_gpu": Bl, "global_batch": Bg, "tables": T, "dim": d, "parallelism": par,
                    "placement": policy, "owner": main["owner"], "step_mode": main["mode"],
                    "observed_world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                   "exchange_mode": (main.get("exchange_auto") or {}).get("picked", getattr(args, "exchange_mode", "inline")),
+                   "exchange_mode": (main.get("exchange_auto") or {}).get("picked", main.get("exchange_used", getattr(args, "exchange_mode", "inline"))),
+                   "exchange_requested": getattr(args, "exchange_mode", "inline"), "direct_a2a": main.get("direct_a2a"),
                    "exchange_auto": main.get("exchange_auto"),
                    "a2a_bytes_per_step_per_rank": main["a2a_bytes_per_rank"],
                    "a2a_bytes_per_step_all_links": main["a2a_bytes"]},
@@ -1114,8 +1185,10 @@ def bench_sharded(args, ln_emb, rank, world, dev):
 
 
 def _single_process_line(args, ln_emb, dev):
-    """the plain N = 1 step (bench.py's headline: ONE fused launch over local tables, one index per bag declared as the sharded
-    step declares it) timed in this process, for the line a one-rank sharded run prints beside its own"""
+    """the plain N = 1 step timed in this process, for the line a one-rank sharded run prints beside its own: `value` = bench.py's
+    N = 1 headline form (ONE fused launch over local tables, lS_o GIVEN and checked in the kernel: what `python3 bench.py --gpus 1`
+    reports and what a scaling efficiency is computed against), `declared_one_index` = the same launch with one index per bag
+    declared, as the sharded step declares it"""
     from . import dlrm_ops
     d, B, T = args.dim, args.batch, len(ln_emb)
     owner = [0] * T
@@ -1129,22 +1202,28 @@ def _single_process_line(args, ln_emb, dev):
     F = T + 1
     out = [torch.empty((B, d + F * (F - 1) // 2), device=dev) for _ in range(2)]
 
-    def run(n):
-        for i in range(n):
-            dlrm_ops.apply_emb_interact(x, off, bs[i % 4], ev, None, out=out[i % 2], one_index_per_bag=True)
+    def timed(declared):
+        def run(n):
+            for i in range(n):
+                dlrm_ops.apply_emb_interact(x, off, bs[i % 4], ev, None, out=out[i % 2], one_index_per_bag=declared)
 
-    run(args.warmup + 1500)
-    e = torch.cuda.Event()
-    e.record()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    e.record()
-    while not e.query():
-        pass
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+        run(args.warmup + 1500)
+        e = torch.cuda.Event()
+        e.record()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        e.record()
+        while not e.query():
+            pass
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    dt, dt_decl = timed(False), timed(True)
     del ev, w
     torch.cuda.empty_cache()
     return {"value": T * B * args.steps / dt, "unit": "lookups/s", "ms_per_step": dt / args.steps * 1e3,
-            "note": "one fused launch per step in this process (no placement, no exchange): what `bench.py --gpus 1` times"}
+            "declared_one_index": {"value": T * B * args.steps / dt_decl, "ms_per_step": dt_decl / args.steps * 1e3},
+            "note": "one fused launch per step in this process (no placement, no exchange): what `bench.py --gpus 1` times (lS_o given); "
+                    "a sharded step is two launches -- the pooling gather of the rank's own tables into the exchange layout, then the "
+                    "interaction over received + replicated features"}

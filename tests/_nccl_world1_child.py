@@ -56,6 +56,32 @@ def main():
     for policy in ("rows+replicate", "rowsplit"):
         assert sharded.verify_p2p_against_collective(ln, d, 0, 1, {t: ws[t] for t in range(T)}, sharded.HipBackend(dev), policy, lo, li,
                                                      force_exchange=True, one_index_per_bag=True, replicate_max_rows=2000), policy
+    # round 6: exchange_mode "direct" -- the all-to-all issued by the extension itself (ONE ncclAllToAllv on the step's stream over
+    # its own communicator; grouped ncclSend / ncclRecv as the other form): same receive buffers as all_to_all_single, same R
+    from evstore_dlrm_amd import _ext
+    X = _ext.ext()
+    assert X is not None and X.rccl_available(), "the extension must reach RCCL on a GPU box"
+    for use_v in ("1", "0"):
+        os.environ["EVS_DIRECT_A2A_V"] = use_v
+        sharded.direct_close()
+        a2a = sharded.direct_comm(None, dev)
+        assert a2a is not None and a2a.use_alltoallv == (use_v == "1")
+        for policy in ("rows+replicate", "rows", "count", "rowsplit"):
+            assert sharded.verify_p2p_against_collective(ln, d, 0, 1, {t: ws[t] for t in range(T)}, sharded.HipBackend(dev), policy, lo, li,
+                                                         force_exchange=True, one_index_per_bag=True, replicate_max_rows=2000, other="direct"), policy
+            op = sharded.ShardedEmbeddingInteract(ln, d, 0, 1, {t: ws[t] for t in range(T)}, sharded.HipBackend(dev), policy=policy,
+                                                  one_index_per_bag=True, replicate_max_rows=2000)
+            op.force_exchange = True
+            op.exchange_mode = "direct"
+            out = torch.empty_like(want)
+            pl = op.plan(x, lo, li, out=out)
+            for _ in range(3):
+                op.step(pl)
+            torch.cuda.synchronize()
+            assert torch.equal(out, want), policy + " (direct)"
+            assert not op.any_sharded or len(op._direct_plans) == 1, "one planned exchange, reused"
+            del op
+    sharded.direct_close()
     dist.barrier()
     dist.destroy_process_group()
     print("NCCL_WORLD1_OK")

@@ -58,3 +58,9 @@ def test_bench_line_sharded_path_one_rank():
         assert j["n_gpus"] == 1 and j["steps"] == 50 and j["scaling"] == "weak" and j["value"] > 0
         assert j["config"]["exchange_mode"] == mode and j["config"]["placement"] == "rows+replicate"
         assert j["roofline"] is not None and j["roofline"]["bound"] == "hbm"
+    # round 6: the default exchange -- the extension's own ncclAllToAllv on the step's stream -- forced on the one rank a box has;
+    # it is verified against all_to_all_single (receive buffers bit for bit) before it is timed
+    j, _ = _run(["--gpus", "1", "--force-sharded", "--force-exchange", "--steps", "50", "--warmup", "5"], timeout=600)
+    assert j["config"]["exchange_requested"] == "direct" and j["config"]["exchange_mode"] == "direct", j["config"]
+    assert j["config"]["direct_a2a"] == "ncclAllToAllv"
+    assert j["per_rank"]["tables_owned"] == [5] and len(j["per_rank"]["step_ms"]) == 1
