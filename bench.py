@@ -1054,6 +1054,9 @@ def main():
                          "interaction, or p2p: no collective call -- the pooling kernel writes every peer's block straight into that peer's "
                          "IPC-mapped receive buffer, two flag words per (peer, slot) hand it over (csrc/evs_p2p.hip); auto: p2p when ONE batch through both "
                          "exchanges gave bit-equal receive buffers on every rank (sharded.verify_p2p_against_collective), the RCCL collective otherwise")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="N>1: keep pool, exchange and interaction of a step on one stream (default: pool(i + 1) + its exchange on a side stream "
+                         "under the interaction of batch i, two event hand-overs per step; direct exchange / no exchange only)")
     ap.add_argument("--force-exchange", action="store_true", help="with --force-sharded on one rank: issue the RCCL all_to_all_single anyway "
                                                                   "(a self-exchange into a separate receive buffer: what the collective call itself costs per step)")
     ap.add_argument("--shape", default="kaggle", choices=["kaggle", "terabyte"],

@@ -9,7 +9,7 @@ import sys as _sys
 
 from . import _lib, dlrm_ops, gpu_cache  # noqa: E402
 from ._lib import EvsError, build  # noqa: E402
-from .dlrm_ops import (EVTables, LazyPooled, apply_emb, apply_emb_interact, apply_emb_interact_mlp1, apply_emb_interact_multi, fused_supported,
+from .dlrm_ops import (EVTables, InteractServer, LazyPooled, apply_emb, apply_emb_interact, apply_emb_interact_mlp1, apply_emb_interact_multi, fused_supported,
                        interact_features, materialize)
 from .gpu_cache import (FileTier, GpuAltKeyTier, GpuCache, lookup_batch_c1c2, lookup_batch_c1c2c3, lookup_interact_c1c2,
                         lookup_interact_c1c2c3, request_c1c2, request_c1c2c3)
@@ -45,6 +45,6 @@ def configure_runtime(hw_queues=8):
     return int(hw_queues)
 
 
-__all__ = ["EvsError", "build", "configure_runtime", "runtime_started", "EVTables", "LazyPooled", "apply_emb", "apply_emb_interact", "apply_emb_interact_multi", "apply_emb_interact_mlp1", "interact_features", "materialize", "fused_supported",
+__all__ = ["EvsError", "build", "configure_runtime", "runtime_started", "EVTables", "InteractServer", "LazyPooled", "apply_emb", "apply_emb_interact", "apply_emb_interact_multi", "apply_emb_interact_mlp1", "interact_features", "materialize", "fused_supported",
            "GpuCache", "FileTier", "GpuAltKeyTier", "request_c1c2", "request_c1c2c3", "lookup_batch_c1c2", "lookup_interact_c1c2",
            "lookup_batch_c1c2c3", "lookup_interact_c1c2c3"]

@@ -89,6 +89,11 @@ _PROTOS = {
     "evs_emb_interact_dot": (_int, [_i64, _int, _int, _int, C.POINTER(EvsFeature), _int, _vp, _vp]),
     "evs_emb_interact_dot_stacked": (_int, [_i64, _int, _int, _int, _pp, _i64p, _vp, _i64, _vp, _i64, _i64, _vp, _i64,
                                             _pp, _int, _vp, _vp]),
+    "evs_emb_interact_serve_start": (_int, [C.POINTER(_vp), _int, _int, _pp, _i64p, _int, _int, _i64]),
+    "evs_emb_interact_serve_post": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, C.POINTER(C.c_uint64)]),
+    "evs_emb_interact_serve_wait": (_int, [_vp, C.c_uint64]),
+    "evs_emb_interact_serve_stop": (_int, [_vp]),
+    "evs_emb_interact_serve_destroy": (_int, [_vp]),
     "evs_emb_interact_dot_stacked_multi": (_int, [_int, _i64, _int, _int, _int, _pp, _i64p, _pp, _i64, _pp, _i64, _i64, _pp, _i64, _int, _pp, _vp]),
     "evs_emb_interact_mlp1_stacked": (_int, [_i64, _int, _int, _pp, _i64p, _vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _int, _int, _vp, _vp, _vp]),
     "evs_cache_create": (_int, [_pp, _int, _i64, _int, _int, _int, C.c_double, C.c_double, _int, _int]),

@@ -26,6 +26,7 @@
 #include "evs_fused.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace evs {
 
@@ -65,9 +66,20 @@ constexpr int kMlpRowStride = 452;   // floats per staged row: kp <= 448 (F <= 2
 // samples in a slow loop straight from global memory (general semantics: empty bags, several indices summed in index
 // order, bad offsets / indices skipped and flagged -- the arithmetic of evs_fused.hip's general loop) and feeds the same
 // MFMA + output code: no flag, no second launch, as in the index-tile loop of evs_fused.hip and in evs_fused_rfq.hip.
-template <int CQ, int REM, int NT, int D, bool MLP = false, bool IDS = false, bool PROBE = false, bool CHECK = false>
-__global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) emb_interact_rf_kernel(const FusedArgs args) {
+// SERVE (round 6; evs_emb_interact_serve_*): the same body run by a RESIDENT grid, once per (descriptor, chunk) -- what varies
+// from batch to batch (x, the (T, B) index / offsets arrays, R, B) comes from the descriptor `sd`, everything else (tables,
+// shapes) from a FusedArgs the server keeps in device memory (`ka` points at it, `args` is a copy of its scalar fields); R is
+// stored with agent-scope write-through stores (sc1): a resident kernel has no end-of-kernel release that would write its L2
+// back for the launches (on other XCDs) that read R afterwards.
+struct RfServeDesc {
+    const float *x; const int64_t *idx; const int64_t *off; float *R;
+    int64_t B, x_stride, idx_stride, off_stride;
+};
+template <int CQ, int REM, int NT, int D, bool MLP, bool IDS, bool PROBE, bool CHECK, bool SERVE>
+__device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *ka, const RfServeDesc &sd, const int blk_in) {
     static_assert(!CHECK || (!MLP && !IDS && !PROBE), "the offsets check belongs to the plain launch");
+    static_assert(!SERVE || (CHECK && !MLP && !IDS && !PROBE), "the resident form serves the drop-in call (lS_o given)");
+    constexpr int kCpol = SERVE ? (EVS_OUT_CPOL | 16) : EVS_OUT_CPOL;   // (aux bit 4 = sc1 on gfx940+: agent scope, write-through)
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
     constexpr int d = 4 * (4 * CQ + REM);
@@ -98,14 +110,19 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
     __shared__ __attribute__((aligned(16))) float s_out[kOutRows][kOutStride];
     __shared__ float s_dump[MLP ? 4 * 16 : 1];   // MLP: where the never-stored accumulator elements go
 
-    const int lane = threadIdx.x & (kWave - 1);
+    // (SERVE: the resident grid runs this body in a loop; every lane-invariant table below -- staging offsets, flush offsets,
+    //  operand addresses -- derives from the thread index, and left alone the compiler hoists all of them out of the loop and
+    //  keeps them alive across the head: 128 VGPRs and 65 spilled.  An opaque copy of the index per call keeps them where the
+    //  launch form has them.)
+    unsigned tid_x = threadIdx.x;
+    if constexpr (SERVE) asm volatile("" : "+v"(tid_x));
+    const int lane = tid_x & (kWave - 1);
     const int r16 = lane & 15;
     const int q = lane >> 4;
     const int F = args.F, itself = args.itself;
     const int out_row = d + args.P;
-    const int64_t B = args.B;
-    const FusedArgs *ka = (const FusedArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t B = SERVE ? sd.B : args.B;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(tid_x >> 6));
     char *my_lds = s_rows[wave_in_block];
     float *my_out = s_out[wave_in_block];   // (MLP: re-pointed per sample)
     const char *zeros_l = reinterpret_cast<const char *>(args.zeros);
@@ -114,24 +131,24 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
     // K batches in one launch (multi_n > 0; plain and CHECK launches): block i = chunk i % multi_cpb of batch i / multi_cpb;
     // sample numbers below are the batch's own, x / indices / offsets / R come from the batch's entries
     const int64_t per = args.tile_per;
-    int blk_id = (int)blockIdx.x, batch_k = 0;
+    int blk_id = blk_in, batch_k = 0;
     if constexpr (!MLP && !IDS && !PROBE) {
         if (args.multi_n > 0) { batch_k = blk_id / args.multi_cpb; blk_id -= batch_k * args.multi_cpb; }
     }
-    const bool multi = !MLP && !IDS && !PROBE && args.multi_n > 0;
-    float *const R_base = multi ? ka->multi_R[batch_k] : args.R;
+    const bool multi = SERVE || (!MLP && !IDS && !PROBE && args.multi_n > 0);
+    float *const R_base = SERVE ? sd.R : (multi ? ka->multi_R[batch_k] : args.R);
     const int64_t blk_first = (int64_t)blk_id * per;
     const int64_t blk_end = blk_first + per < B ? blk_first + per : B;
     if (blk_first >= blk_end) return;       // block-uniform
     const int blk_n = (int)(blk_end - blk_first);
     const int n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
-    if (threadIdx.x < 32) {
+    if (tid_x < 32) {
         // branch-free on purpose: every FusedArgs array has EVS_MAX_FEATURES = 32 entries (those past F are NULL / 0), so
         // lane f reads entry f of each of them UNCONDITIONALLY -- all the loads leave together, one round trip -- and the
         // tests below are selects on the values.  (Written as `f < F ? ka->x[f] : 0` the compiler puts each load behind
         // its own branch and wait: three to six DEPENDENT round trips to the kernel arguments in front of the first index
         // load, in every block of every launch -- the larger part of the launch's fixed cost.)
-        const int f = (int)threadIdx.x;
+        const int f = (int)tid_x;
         const bool on = f < F;
         const int64_t *ip = ka->indices[f];
         const unsigned long long src = (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]);
@@ -139,26 +156,29 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         const int64_t stride = ka->stride[f];
         const int64_t *op = nullptr;
         int64_t ol = 0, nz = 0;
-        if constexpr (CHECK) { op = ka->offsets[f]; ol = ka->off_len[f]; nz = ka->nnz[f]; }
+        if constexpr (CHECK) { op = ka->offsets[f]; ol = SERVE ? sd.B : ka->off_len[f]; nz = SERVE ? sd.B : ka->nnz[f]; }
         unsigned long long mx = 0ull;
         const int64_t *mi = nullptr, *mo = nullptr;
-        if constexpr (!MLP && !IDS && !PROBE) {
+        if constexpr (SERVE) {
+            mx = (unsigned long long)reinterpret_cast<uintptr_t>(sd.x); mi = sd.idx; mo = sd.off;
+        } else if constexpr (!MLP && !IDS && !PROBE) {
             const int kk = multi ? batch_k : 0;   // (entry 0 is always readable)
             mx = (unsigned long long)reinterpret_cast<uintptr_t>(ka->multi_x[kk]);
             mi = ka->multi_idx[kk];
             if constexpr (CHECK) mo = ka->multi_off[kk];
         }
-        if (multi) ip = (f >= 1 && on) ? mi + (int64_t)(f - 1) * args.multi_idx_stride : nullptr;
+        const int64_t m_istride = SERVE ? sd.idx_stride : args.multi_idx_stride, m_ostride = SERVE ? sd.off_stride : args.multi_off_stride;
+        if (multi) ip = (f >= 1 && on) ? mi + (int64_t)(f - 1) * m_istride : nullptr;
         if (!on) ip = nullptr;
         const bool table = (IDS || PROBE) ? (f >= 1 && on) : ip != nullptr;
         s_tile_p[f] = ip;
         s_tile_nr[f] = on ? (unsigned)nr : 0u;
         s_tile_kind[f] = !on ? 0 : (table ? 2 : 1);
         s_feat_base[f] = !on ? 0ull : ((multi && f == 0) ? mx : src);
-        s_feat_scale[f] = !on ? 0u : (table ? (unsigned)row_bytes : (unsigned)(stride * 4));
+        s_feat_scale[f] = !on ? 0u : (table ? (unsigned)row_bytes : (unsigned)(((SERVE && f == 0) ? sd.x_stride : stride) * 4));
         if constexpr (PROBE) s_sa_base[f] = ka->probe.sau.row_base[(f + 31) & 31];   // (feature f = table f - 1; unconditional read, as above)
         if constexpr (CHECK) {
-            s_tile_o[f] = table ? (multi ? mo + (int64_t)(f - 1) * args.multi_off_stride : op) : nullptr;
+            s_tile_o[f] = table ? (multi ? mo + (int64_t)(f - 1) * m_ostride : op) : nullptr;
             s_tile_ol[f] = table ? ol : 0;
             s_tile_nz[f] = table ? nz : 0;
         }
@@ -214,10 +234,10 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         for (int h = 0; h < NFL; h++) {
             const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(my_out) + fl_lds[h]);
             u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(u, rs, fl_off[h], 0, EVS_OUT_CPOL);
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, fl_off[h], 0, kCpol);
         }
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(*reinterpret_cast<const float *>(reinterpret_cast<const char *>(my_out) + fl_tail_lds)),
-                                              rs, fl_tail_off, 0, EVS_OUT_CPOL);
+                                              rs, fl_tail_off, 0, kCpol);
     };
 #else
     auto flush_out = [&](int64_t bp, bool on) {
@@ -232,11 +252,11 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             const int e4 = lane + 64 * h;
             const float4 v = reinterpret_cast<const float4 *>(my_out)[e4 < n4 ? e4 : 0];
             u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, EVS_OUT_CPOL);
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, kCpol);
         }
         {
             const int e = 4 * n4 + (lane & 3);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, EVS_OUT_CPOL);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, kCpol);
         }
     };
 
@@ -249,10 +269,10 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
     int64_t tile_o0[2] = {0, 0}, tile_o1[2] = {0, 0};   // CHECK: offsets[b] and where bag b ends
     const int64_t *dummy_i = args.dummy_i64;   // any readable int64 (lanes with nothing to load read it)
     auto tile_load = [&](int c) {       // chunk c of the block -> registers; no branch, no use of the value before tile_store
-        const int64_t bs = blk_first + 16 * (int64_t)c + (threadIdx.x & 15);
+        const int64_t bs = blk_first + 16 * (int64_t)c + (tid_x & 15);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            const int f = ((int)tid_x >> 4) + 16 * h;
             const bool table = s_tile_kind[f] == 2 && bs < blk_end;
             if constexpr (IDS) {
                 const int *ap = table ? args.row_ids + bs * (int64_t)(F - 1) + (f - 1) : reinterpret_cast<const int *>(dummy_i);
@@ -264,7 +284,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             }
             if constexpr (CHECK) {
                 const int64_t *op = s_tile_o[f];
-                const bool own = table && ((threadIdx.x & 15) == 15 || bs + 1 >= blk_end);
+                const bool own = table && ((tid_x & 15) == 15 || bs + 1 >= blk_end);
                 const int64_t *p0 = table ? op + bs : dummy_i;
                 const int64_t *p1 = (own && bs + 1 < s_tile_ol[f]) ? op + bs + 1 : dummy_i;
                 tile_o0[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(p0));
@@ -273,17 +293,17 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         }
     };
     auto tile_store = [&](int c) {      // registers -> tile buffer c & 1
-        const int64_t bs = blk_first + 16 * (int64_t)c + (threadIdx.x & 15);
+        const int64_t bs = blk_first + 16 * (int64_t)c + (tid_x & 15);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            const int f = ((int)tid_x >> 4) + 16 * h;
             const int kind = s_tile_kind[f];
             const bool live = kind != 0 && bs < blk_end && c >= 0;
             const int64_t v = kind == 2 ? tile_v[h] : bs;       // dense features (x, received pooled vectors): the sample number
             const bool in_range = kind == 1 || (IDS ? v >= 0 : (uint64_t)v < (uint64_t)s_tile_nr[f]);   // (IDS: the probe kernel checked the row ids)
             if constexpr (CHECK) oob[h] = live & !in_range;   // (whether it counts is verify()'s call: see there)
             else bad |= live & !in_range;
-            s_idx[(c & 1) * 512 + (int)threadIdx.x + 256 * h] = (live & in_range) ? (int)v : -1;
+            s_idx[(c & 1) * 512 + (int)tid_x + 256 * h] = (live & in_range) ? (int)v : -1;
         }
     };
 
@@ -297,14 +317,14 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
     // sample in front of the row requests).
     bool fast_bad = false;   // out-of-range indices seen by the one-index code; they count only if the block stays on it
     auto verify = [&]() {
-        const int64_t bs = blk_first + (threadIdx.x & 15);
+        const int64_t bs = blk_first + (tid_x & 15);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            const int f = ((int)tid_x >> 4) + 16 * h;
             // (an index whose own bag is not {idx[b]} may sit at a position no bag refers to: the slow loop, which this
             //  block then runs, has the verdict on it)
             const bool table = s_tile_kind[f] == 2 && bs < blk_end;
-            const bool own = table && ((threadIdx.x & 15) == 15 || bs + 1 >= blk_end);
+            const bool own = table && ((tid_x & 15) == 15 || bs + 1 >= blk_end);
             int64_t o1 = tile_o1[h];
             if (!(bs + 1 < s_tile_ol[f])) o1 = s_tile_nz[f];   // the last bag ends at nnz
             const bool ok = (tile_o0[h] == bs) & (!own | (o1 == bs + 1));
@@ -410,10 +430,10 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             const int e4 = lane + 64 * h;
             const float4 v = reinterpret_cast<const float4 *>(my_out)[e4 < n4 ? e4 : 0];
             u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, EVS_OUT_CPOL);
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, kCpol);
         }
         const int e = 4 * n4 + (lane & 3);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, EVS_OUT_CPOL);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, kCpol);
     };
     // ---- CHECK, rare: a block that finds a bag other than {idx[b]} pools ITS samples with the general semantics --------
     auto slow_block = [&]() {
@@ -433,15 +453,15 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
                 const int64_t *ip = s_tile_p[f];                                            // (multi: this batch's arrays)
                 const char *src = reinterpret_cast<const char *>((uintptr_t)s_feat_base[f]);
                 if (!ip) {   // dense feature (x, received pooled vectors)
-                    const char *row = src + (uint64_t)b * (uint64_t)(ka->stride[f] * 4);
+                    const char *row = src + (uint64_t)b * (uint64_t)(((SERVE && f == 0) ? sd.x_stride : ka->stride[f]) * 4);
 #pragma unroll
                     for (int c = 0; c < NC; c++) a[rr][c] = chunk_at(row, c);
                     continue;
                 }
                 const int64_t *op = s_tile_o[f];
-                const int64_t nnz = ka->nnz[f];
+                const int64_t nnz = SERVE ? sd.B : ka->nnz[f];
                 int64_t s0 = op[b];
-                int64_t e0 = (b + 1 < ka->off_len[f]) ? op[b + 1] : nnz;
+                int64_t e0 = (b + 1 < (SERVE ? sd.B : ka->off_len[f])) ? op[b + 1] : nnz;
                 if (!((s0 >= 0) & (e0 >= s0) & (e0 <= nnz))) { bad = true; s0 = e0 = 0; }
                 const uint64_t n_rows = (uint64_t)ka->n_rows[f];
                 for (int64_t j = s0; j < e0; j++) {
@@ -461,7 +481,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
 #pragma unroll
             for (int h = 0; h < (d + 63) / 64; h++) {
                 const int e = lane + 64 * h;
-                xv[h] = reinterpret_cast<const float *>(reinterpret_cast<const char *>((uintptr_t)s_feat_base[0]) + (uint64_t)b * (uint64_t)(ka->stride[0] * 4))[e < d ? e : 0];
+                xv[h] = reinterpret_cast<const float *>(reinterpret_cast<const char *>((uintptr_t)s_feat_base[0]) + (uint64_t)b * (uint64_t)((SERVE ? sd.x_stride : ka->stride[0]) * 4))[e < d ? e : 0];
             }
             f32x4 c00, c10, c11;
             {
@@ -513,16 +533,16 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         __shared__ int s_nlist;                   // misses listed
         const ProbeArgs &pa = args.probe;
         const int T = pa.T;
-        for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_pdelta[i] = 0;
-        if (threadIdx.x < 16) s_agg[threadIdx.x] = 0;
-        if (threadIdx.x < 2) s_psum[threadIdx.x] = 0;
-        if (threadIdx.x == 0) s_nlist = 0;
+        for (int i = tid_x; i < kMaxBuckets; i += blockDim.x) s_pdelta[i] = 0;
+        if (tid_x < 16) s_agg[tid_x] = 0;
+        if (tid_x < 2) s_psum[tid_x] = 0;
+        if (tid_x == 0) s_nlist = 0;
         __syncthreads();
         int pe[2], prow[2], pprio[2], pway[2];
         unsigned phint[2], ptag[2];
         bool pok[2], ptomb[2], pact[2];
         unsigned long long pkey[2], phome[2], pw0[2];
-        const int64_t bs = blk_first + (threadIdx.x & 15);
+        const int64_t bs = blk_first + (tid_x & 15);
         // ---- the policy update folded in too (round 5; ProbeArgs::arena_w != nullptr: a set-associative fp32 tier alone with a
         // two-copy arena, evs_hash.h).  A thread that misses a key claims a way of the key's set right here -- it holds the
         // set's ways already: rank, ONE CAS, beside the priority raises -- and the lanes that gather the key's row from its
@@ -533,14 +553,14 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         // read the old word reads a row nobody is writing.
         const bool ins = pa.arena_w != nullptr;   // block-uniform
         if (ins) {
-            for (int i = threadIdx.x; i < kMaxBuckets; i += blockDim.x) s_udelta[i] = 0;
-            if (threadIdx.x < 2) s_ustat[threadIdx.x] = 0;
+            for (int i = tid_x; i < kMaxBuckets; i += blockDim.x) s_udelta[i] = 0;
+            if (tid_x < 2) s_ustat[tid_x] = 0;
         }
         // the thread's two keys side by side, one round trip per step for both: request rows, home slots, priorities
         // (a key whose home slot holds neither it nor nothing walks its chain with probe_ro: rare at load <= 0.25)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            const int f = ((int)tid_x >> 4) + 16 * h;
             pact[h] = f >= 1 && f < F && bs < blk_end;
             const int *rp = pact[h] ? pa.requests + bs * (int64_t)T + (f - 1) : reinterpret_cast<const int *>(dummy_i);
             prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
@@ -549,7 +569,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         const bool sa = pa.sa.tags != nullptr;   // set-associative cache (evs_hash.h): one line per key, the priority inside the way word
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            const int f = ((int)tid_x >> 4) + 16 * h;
             const unsigned nrf = s_tile_nr[f & 31];
             pok[h] = pact[h] & (prow[h] >= 0) & ((unsigned)prow[h] < nrf);
             pkey[h] = ((unsigned long long)f << 32) | (unsigned)prow[h];   // table_1based = f
@@ -558,7 +578,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             unsigned pset[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int f = ((int)threadIdx.x >> 4) + 16 * h;
+                const int f = ((int)tid_x >> 4) + 16 * h;
                 sa_split(pa.sa, sa_perm(pa.sau, s_sa_base[f & 31] + (pok[h] ? (unsigned)prow[h] : 0u)), pset[h], ptag[h]);
                 if (!pok[h]) pset[h] = 0u;
             }
@@ -579,7 +599,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
                 pw0[h] = w; phint[h] = pset[h]; ptomb[h] = false;
 #pragma unroll
                 for (int j = 0; j < 8; j++) lw[h][j] = sa_way_word(line[h], j);
-                if (found) atomicAdd(&s_agg[threadIdx.x & 15], 1);
+                if (found) atomicAdd(&s_agg[tid_x & 15], 1);
             }
         } else {
 #pragma unroll
@@ -607,13 +627,13 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (pe[h] >= 0) {
-                atomicAdd(&s_agg[threadIdx.x & 15], 1);
+                atomicAdd(&s_agg[tid_x & 15], 1);
                 pprio[h] = pa.eagg[pe[h]];   // asked for now: it travels while the block meets
             }
         }
         }
         __syncthreads();
-        const int agg = s_agg[threadIdx.x & 15];
+        const int agg = s_agg[tid_x & 15];
         // a missed key's claim: duplicate / victim / the CAS sent here, looked at behind the raises below (one round trip for both).
         // (Looked at behind the ROW requests instead -- the claim kept across them, block barriers that order LDS only -- was
         // built and measured on one box: 34.4 against 32.5 us per batch, the kernel sits at its 128 registers; the new rows as
@@ -632,7 +652,7 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int f = ((int)threadIdx.x >> 4) + 16 * h;
+            const int f = ((int)tid_x >> 4) + 16 * h;
             // monotone max like update_agg_hit; the plain read first keeps hot entries from serialising on one address
             if (pe[h] >= 0 && pprio[h] < agg) {
                 int old;
@@ -643,10 +663,10 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             int v = -1;
             if (f == 0) v = bs < blk_end ? (int)bs : -1;                 // x: the sample number
             else if (pact[h]) v = pe[h] >= 0 ? (int)(0x40000000u | (unsigned)pe[h]) : (pok[h] ? prow[h] : -1);
-            s_idx[(int)threadIdx.x + 256 * h] = v;
+            s_idx[(int)tid_x + 256 * h] = v;
             if (ins) {   // where the gathered row of a missed key goes (-1: nowhere)
                 if (uwait[h]) uwon[h] = sa_claim_finish(pa.sa, pa.pend_stamp, phint[h], ptag[h], agg, lw[h], upk[h], uprev[h], s_udelta, s_ustat);
-                s_idx[512 + (int)threadIdx.x + 256 * h] = uwon[h];
+                s_idx[512 + (int)tid_x + 256 * h] = uwon[h];
             }
             if (pact[h]) {
                 const int64_t m = bs * (int64_t)T + (f - 1);
@@ -660,17 +680,17 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             if (f == 1 && bs < blk_end) { atomicAdd(&s_psum[0], agg); if (agg == T) atomicAdd(&s_psum[1], 1); }
         }
         __syncthreads();
-        if (threadIdx.x < 40) {   // the block's totals into one of the replica rows (folded by the cache's close)
-            const int i = threadIdx.x;
+        if (tid_x < 40) {   // the block's totals into one of the replica rows (folded by the cache's close)
+            const int i = tid_x;
             const int v = i <= T ? s_pdelta[i] : i == 38 ? s_psum[0] : i == 39 ? s_psum[1] : 0;
             if (v) atomicAdd(&pa.part1[(blockIdx.x % 32) * 40 + i], v);
         }
-        if (ins && threadIdx.x < 40) {   // the inserts' totals, as the update kernels leave them (folded by the cache's close)
-            const int i = threadIdx.x;
+        if (ins && tid_x < 40) {   // the inserts' totals, as the update kernels leave them (folded by the cache's close)
+            const int i = tid_x;
             const int v = i <= T ? s_udelta[i] : i == 33 ? s_ustat[0] : i == 34 ? s_ustat[1] : 0;
             if (v) atomicAdd(&pa.part2[(blockIdx.x % 32) * 40 + i], v);
         }
-        if (pa.list_cnt != nullptr && threadIdx.x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
+        if (pa.list_cnt != nullptr && tid_x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
     } else {
         tile_load(0);
         tile_store(0);
@@ -835,6 +855,11 @@ __global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) em
             }
         }
     }
+}
+
+template <int CQ, int REM, int NT, int D, bool MLP = false, bool IDS = false, bool PROBE = false, bool CHECK = false>
+__global__ void __launch_bounds__(256, (MLP ? 3 : (CQ >= 4 ? 2 : EVS_RF_LB))) emb_interact_rf_kernel(const FusedArgs args) {
+    rf_body<CQ, REM, NT, D, MLP, IDS, PROBE, CHECK, false>(args, (const FusedArgs *)__builtin_amdgcn_kernarg_segment_ptr(), RfServeDesc{}, (int)blockIdx.x);
 }
 
 static int rf_mode() {
@@ -1017,7 +1042,342 @@ bool launch_rf(const FusedArgs &a, hipStream_t st) {
     }
 }
 
+
+// ======================================================================================================================
+// The fused launch as a RESIDENT DISPATCHER (round 6; evs_emb_interact_serve_*).  BASELINE's metric is "lookups/sec + p50 batch
+// latency", and a launch that is waited for spends 12 of its 31 us (B = 16 384) outside the kernel: ~6 us of host time in the
+// launch call, ~3 us until the command processor has dispatched 1 024 blocks, ~3 us until the completion signal is visible;
+// below ~4 000 samples a launch IS that floor (7-8 us per batch whatever B).  Here the grid stays on the device and takes
+// batches from a mailbox in pinned host memory (the reference's loop calls the pair once per batch: dlrm_s_pytorch.py:596-601,
+// the inference loop :801-836):
+//   request ring   (host -> device) kSrvSlots descriptors of 64 bytes: x, (T, B) indices, (T, B) offsets, R, B, strides, the block the
+//                  batch's first chunk goes to; each 32-byte sector closed by the sequence number (written last: a sector is
+//                  accepted only when its guard holds the number awaited, whatever granularity the bus delivers it in);
+//   leader         block 0, one wavefront: polls the next FOUR ring slots as one 64-lane system-scope load, copies every
+//                  descriptor that has arrived into device memory (agent-scope write-through stores) and publishes its number
+//                  in kSrvReplicas replica lines (a thousand blocks polling ONE word cost more than the work: r04_atomic_probe);
+//   workers        blocks 1 .. G-1: lane 0 polls its replica line; a new number -> an agent-scope acquire (inputs written by
+//                  other launches), the descriptor, then rf_body<..., SERVE> for every chunk c of the batch with
+//                  (first_block + c) % (G - 1) == this worker -- consecutive small batches land on different blocks and overlap;
+//                  R leaves as agent-scope write-through stores (a resident kernel has no end-of-kernel release), every wave
+//                  waits for its stores (vmcnt(0)), then ONE arrival atomic per block; the block that completes the batch
+//                  writes the batch's number into the ANSWER ring in host memory, which the caller spins on;
+//   leaving        the leader publishes "stop" after idle_ticks without a request (or when the host's control word says so):
+//                  every block returns; the next post starts the grid again.  While it is resident the grid holds its CUs
+//                  (G = 4 blocks per CU by default): kernels of other streams run when it has left.
+// Same bits as the launch form (the same rf_body).  Rules for the caller: the inputs of a batch are complete when it is posted
+// (post on the host after the producer's stream has been synchronised), and R may be read by anything started after evs_emb_interact_serve_wait has returned.
+constexpr int kSrvSlots = 64;
+constexpr int kSrvReplicas = 32;
+struct SrvDesc { unsigned w[16]; };   // w0-1 x, w2-3 idx, w4-5 off, w6 B, w7 seq | w8-9 R, w10 x_stride, w11 first block, w12 idx stride, w13 off stride, w14 -, w15 seq
+struct SrvState {
+    unsigned pub[kSrvReplicas][32];       // line r: word 0 = the last published sequence number, word 1 = the generation (launch number) of the grid that has LEFT behind it
+    SrvDesc desc[kSrvSlots];              // the leader's copies of the descriptors
+    unsigned arrived[kSrvSlots][32];      // per slot (a line each): chunks finished
+};
+struct SrvArgs {
+    const FusedArgs *tmpl;                // tables, shapes (device memory; written before the grid starts, never while it runs)
+    SrvState *st;
+    volatile unsigned *req;               // request ring (device address of the mapped host block)
+    volatile unsigned *ctl;               // word 0: stop
+    volatile unsigned *ans;               // answer ring: kSrvSlots lines of 16 words (word 0 = sequence number done); line kSrvSlots: word 0 = alive, word 1 = the last published number
+    unsigned start_seq;                   // the last number published by an earlier run of the grid
+    unsigned gen;                         // this launch's number (>= 1): "stop" is the leader writing it into word 1 of the replica lines --
+                                          // what an earlier launch left there never matches, so nothing has to be cleared between launches
+    long long idle_ticks;
+};
+
+template <int CQ, int REM, int NT>
+__global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_rf_serve_kernel(const SrvArgs sv) {
+    SrvState *st = sv.st;
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0) {
+        // ---------------- the leader ----------------
+        if (threadIdx.x >= 64) return;
+        unsigned seq = sv.start_seq;
+        if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // alive
+        long long t0 = (long long)wall_clock64();
+        for (;;) {
+            // the next four ring slots in one load: lane = 16 * (slot in the group) + word
+            const unsigned slot0 = (seq + 1u) % (unsigned)kSrvSlots;
+            const unsigned sl = (slot0 + (unsigned)(lane >> 4)) % (unsigned)kSrvSlots;
+            const unsigned word = __hip_atomic_load(const_cast<unsigned *>(sv.req) + sl * 16u + (unsigned)(lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // group g holds descriptor seq + 1 + g when both its guards say so
+            const unsigned want = seq + 1u + (unsigned)(lane >> 4);
+            const unsigned long long gm = __ballot(((lane & 7) == 7) && word == want);   // lanes 7, 15 of every group
+            int n_new = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const bool okg = ((gm >> (16 * g + 7)) & 1ull) && ((gm >> (16 * g + 15)) & 1ull);
+                if (okg && n_new == g) n_new = g + 1;    // consecutive ones only
+            }
+            if (n_new > 0) {
+                if ((lane >> 4) < n_new) __hip_atomic_store(&st->desc[sl].w[lane & 15], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the copies are in memory before their number is
+                seq += (unsigned)n_new;
+                if (lane < kSrvReplicas) __hip_atomic_store(&st->pub[lane][0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t0 = (long long)wall_clock64();
+                continue;
+            }
+            const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (stop != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        // leaving: every worker sees the stop word behind the last number; the host learns how far the grid got
+        if (lane < kSrvReplicas) __hip_atomic_store(&st->pub[lane][1], sv.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16 + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    // ---------------- a worker ----------------
+    __shared__ unsigned s_pub[2];
+    const unsigned n_workers = gridDim.x - 1u, me = blockIdx.x - 1u;
+    const unsigned long long *my_line = reinterpret_cast<const unsigned long long *>(&st->pub[me % (unsigned)kSrvReplicas][0]);
+    // the scalar fields of the template (constant address space: scalar loads; the template is not written while the grid runs)
+    typedef const __attribute__((address_space(4))) FusedArgs *tmpl4_t;
+    const tmpl4_t t4 = reinterpret_cast<tmpl4_t>(reinterpret_cast<uintptr_t>(sv.tmpl));
+    FusedArgs la;
+    la.F = t4->F; la.d = t4->d; la.itself = t4->itself; la.P = t4->P; la.err = t4->err; la.zeros = t4->zeros;
+    la.dummy_i64 = t4->dummy_i64; la.dummy_f32 = t4->dummy_f32; la.tile_per = 16; la.multi_n = 0; la.multi_cpb = 0;
+    la.multi_idx_stride = 0; la.multi_off_stride = 0; la.R = nullptr; la.B = 0; la.bag1 = 3;
+    unsigned my = sv.start_seq;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            unsigned long long v;
+            for (;;) {
+                v = __hip_atomic_load(my_line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)v != my || (unsigned)(v >> 32) == sv.gen) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_pub[0] = (unsigned)v; s_pub[1] = (unsigned)(v >> 32) == sv.gen ? 1u : 0u;
+        }
+        __syncthreads();
+        const unsigned seq = s_pub[0], stop = s_pub[1];
+        __syncthreads();
+        if (seq != my) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // what other launches wrote (x, indices, offsets) before the post
+        for (unsigned k = my + 1u; k != seq + 1u; k++) {
+            const unsigned slot = k % (unsigned)kSrvSlots;
+            const unsigned *dw = st->desc[slot].w;
+            unsigned w[14];
+#pragma unroll
+            for (int i = 0; i < 14; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            RfServeDesc sd;
+            sd.x = reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)w[1] << 32) | w[0]));
+            sd.idx = reinterpret_cast<const int64_t *>((uintptr_t)(((unsigned long long)w[3] << 32) | w[2]));
+            sd.off = reinterpret_cast<const int64_t *>((uintptr_t)(((unsigned long long)w[5] << 32) | w[4]));
+            sd.R = reinterpret_cast<float *>((uintptr_t)(((unsigned long long)w[9] << 32) | w[8]));
+            sd.B = (int64_t)w[6]; sd.x_stride = (int64_t)w[10]; sd.idx_stride = (int64_t)w[12]; sd.off_stride = (int64_t)w[13];
+            const unsigned n_chunks = (w[6] + 15u) >> 4;
+            const unsigned first = w[11] % n_workers;
+            unsigned mine = 0u;
+            for (unsigned c = (me + n_workers - first) % n_workers; c < n_chunks; c += n_workers) {
+                rf_body<CQ, REM, NT, EVS_RF_DEPTH, false, false, false, true, true>(la, sv.tmpl, sd, (int)c);
+                mine++;
+                __syncthreads();
+            }
+            if (mine) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of R have been written through
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const unsigned before = __hip_atomic_fetch_add(&st->arrived[slot][0], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (before + mine == n_chunks) {   // the batch is complete: the counter back to zero for the slot's next use, then the answer
+                        __hip_atomic_store(&st->arrived[slot][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(const_cast<unsigned *>(sv.ans) + slot * 16u, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+        }
+        my = seq;
+        if (stop != 0u) break;
+    }
+}
+
 }  // namespace evs
+
+struct evs_rf_server {
+    evs::FusedArgs tmpl{};
+    evs::FusedArgs *tmpl_dev = nullptr;
+    evs::SrvState *st_dev = nullptr;
+    unsigned *mbox = nullptr, *mbox_dev = nullptr;   // host block: request ring | control line | answer ring + status line
+    hipStream_t stream = nullptr;
+    unsigned posted = 0;            // the last sequence number posted
+    unsigned gen = 0;               // launches of the grid so far
+    unsigned next_first = 0;        // the worker the next batch's first chunk goes to
+    int n_blocks = 0, T = 0, d = 0;
+    long long idle_ticks = 0;
+    bool nt2 = false;
+};
+namespace {
+constexpr size_t kSrvReqWords = (size_t)evs::kSrvSlots * 16, kSrvCtlWords = 32, kSrvAnsWords = ((size_t)evs::kSrvSlots + 1) * 16;
+inline volatile unsigned *srv_req(evs_rf_server *s) { return s->mbox; }
+inline volatile unsigned *srv_ctl(evs_rf_server *s) { return s->mbox + kSrvReqWords; }
+inline volatile unsigned *srv_ans(evs_rf_server *s) { return s->mbox + kSrvReqWords + kSrvCtlWords; }
+void srv_launch(evs_rf_server *s) {
+    using namespace evs;
+    SrvArgs a;
+    a.tmpl = s->tmpl_dev; a.st = s->st_dev;
+    a.req = s->mbox_dev; a.ctl = s->mbox_dev + kSrvReqWords; a.ans = s->mbox_dev + kSrvReqWords + kSrvCtlWords;
+    a.start_seq = srv_ans(s)[kSrvSlots * 16 + 1];   // how far the last run got (0 at first)
+    a.idle_ticks = s->idle_ticks;
+    a.gen = ++s->gen;
+    const dim3 grid((unsigned)s->n_blocks), block(256);
+    const bool nt2 = s->nt2;
+    switch (s->d) {
+    case 16: if (nt2) hipLaunchKernelGGL((emb_interact_rf_serve_kernel<1, 0, 2>), grid, block, 0, s->stream, a); else hipLaunchKernelGGL((emb_interact_rf_serve_kernel<1, 0, 1>), grid, block, 0, s->stream, a); break;
+    case 32: if (nt2) hipLaunchKernelGGL((emb_interact_rf_serve_kernel<2, 0, 2>), grid, block, 0, s->stream, a); else hipLaunchKernelGGL((emb_interact_rf_serve_kernel<2, 0, 1>), grid, block, 0, s->stream, a); break;
+    case 36: if (nt2) hipLaunchKernelGGL((emb_interact_rf_serve_kernel<2, 1, 2>), grid, block, 0, s->stream, a); else hipLaunchKernelGGL((emb_interact_rf_serve_kernel<2, 1, 1>), grid, block, 0, s->stream, a); break;
+    default: if (nt2) hipLaunchKernelGGL((emb_interact_rf_serve_kernel<4, 0, 2>), grid, block, 0, s->stream, a); else hipLaunchKernelGGL((emb_interact_rf_serve_kernel<4, 0, 1>), grid, block, 0, s->stream, a); break;
+    }
+}
+// send the grid home (it leaves by itself when idle) and wait until it has gone
+int srv_pause(evs_rf_server *s) {
+    if (!s->stream) return EVS_OK;
+    if (hipStreamQuery(s->stream) == hipSuccess) return EVS_OK;
+    (void)hipGetLastError();
+    srv_ctl(s)[0] = 1u;
+    const hipError_t e = hipStreamSynchronize(s->stream);
+    srv_ctl(s)[0] = 0u;
+    return e == hipSuccess ? EVS_OK : EVS_EHIP;
+}
+}  // namespace
+
+extern "C" int evs_emb_interact_serve_start(evs_rf_server **out, int T, int d, const void *const *tables, const int64_t *n_rows,
+                                            int itself, int n_blocks, int64_t idle_us) {
+    using namespace evs;
+    EVS_REQUIRE(out && tables && n_rows, "evs_emb_interact_serve_start: NULL argument");
+    EVS_REQUIRE(T >= 1 && T + 1 <= kTileMaxF, "evs_emb_interact_serve_start: T=%d (the rows-in-registers kernel takes x + at most %d tables)", T, kTileMaxF - 1);
+    EVS_REQUIRE(d == 16 || d == 32 || d == 36 || d == 64, "evs_emb_interact_serve_start: d=%d (16, 32, 36 or 64; fp32 tables)", d);
+    EVS_REQUIRE(idle_us >= 1 && n_blocks >= 0, "evs_emb_interact_serve_start: bad argument");
+    for (int t = 0; t < T; t++)
+        EVS_REQUIRE(n_rows[t] >= 0 && n_rows[t] < (1ll << 31) && (n_rows[t] == 0 || (tables[t] && reinterpret_cast<uintptr_t>(tables[t]) % 16 == 0)),
+                    "evs_emb_interact_serve_start: table %d (16-byte aligned, fewer than 2^31 rows)", t);
+    evs_rf_server *s = new evs_rf_server();
+    s->T = T; s->d = d; s->nt2 = T + 1 > 16;
+    const int per_cu = d == 64 ? 2 : EVS_RF_LB;
+    s->n_blocks = n_blocks > 0 ? n_blocks : kNumCu * per_cu;
+    if (s->n_blocks < 2) s->n_blocks = 2;
+    s->idle_ticks = idle_us * 100;   // wall_clock64(): 100 MHz
+    FusedArgs &a = s->tmpl;
+    const int F = T + 1;
+    for (int f = 0; f < EVS_MAX_FEATURES; f++) {
+        a.src[f] = nullptr; a.stride[f] = 0; a.indices[f] = nullptr; a.offsets[f] = nullptr; a.nnz[f] = 0;
+        a.n_rows[f] = 0; a.row_w[f] = nullptr; a.off_len[f] = 0;
+    }
+    a.zeros = zero_page();
+    a.err = index_error_flag();
+    if (!a.zeros || !a.err) { delete s; return EVS_EHIP; }
+    const int64_t *any_i64 = reinterpret_cast<const int64_t *>(a.zeros);
+    for (int t = 0; t < T; t++) {
+        a.src[t + 1] = n_rows[t] == 0 ? a.zeros : tables[t];
+        a.indices[t + 1] = any_i64;       // (non-NULL marks a table: the kernel reads the descriptor's arrays)
+        a.offsets[t + 1] = any_i64;
+        a.n_rows[t + 1] = n_rows[t];
+    }
+    a.src[0] = a.zeros;
+    a.B = 0; a.F = F; a.d = d; a.itself = itself ? 1 : 0; a.P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    a.dummy_i64 = any_i64; a.dummy_f32 = reinterpret_cast<const float *>(a.zeros); a.bag1 = 3; a.enc_lds = 0; a.opt_flag = nullptr; a.opt_id = 0;
+    a.tile_per = 16; a.row_ids = nullptr; a.arena = nullptr; a.w1p = nullptr; a.b1 = nullptr; a.z1 = nullptr; a.n1 = 0; a.kp = 0; a.relu = 0; a.write_r = 1;
+    a.zero_codes = nullptr; a.multi_n = 0; a.multi_cpb = 0; a.multi_idx_stride = 0; a.multi_off_stride = 0; a.R = nullptr;
+    auto fail = [&](int rc) { (void)evs_emb_interact_serve_destroy(s); return rc; };
+    if (hipMalloc(reinterpret_cast<void **>(&s->tmpl_dev), sizeof(FusedArgs)) != hipSuccess) return fail(EVS_ENOMEM);
+    if (hipMalloc(reinterpret_cast<void **>(&s->st_dev), sizeof(SrvState)) != hipSuccess) return fail(EVS_ENOMEM);
+    if (hipMemcpy(s->tmpl_dev, &a, sizeof(FusedArgs), hipMemcpyHostToDevice) != hipSuccess) return fail(EVS_EHIP);
+    if (hipMemset(s->st_dev, 0, sizeof(SrvState)) != hipSuccess) return fail(EVS_EHIP);
+    const size_t words = kSrvReqWords + kSrvCtlWords + kSrvAnsWords;
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->mbox), words * 4, hipHostMallocMapped) != hipSuccess) return fail(EVS_ENOMEM);
+    memset(s->mbox, 0, words * 4);
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&s->mbox_dev), s->mbox, 0) != hipSuccess) return fail(EVS_EHIP);
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) return fail(EVS_EHIP);
+    if (hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return fail(EVS_EHIP);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(EVS_EHIP);   // (the template and the state are in place before the grid's first read)
+    *out = s;
+    return EVS_OK;
+}
+
+// Post one batch: R = interact_features(x, apply_emb(lS_o, lS_i, tables)), lS_o given and checked per 16-sample block exactly as
+// evs_emb_interact_dot_stacked does.  Returns at once; *ticket names the batch for evs_emb_interact_serve_wait.
+extern "C" int evs_emb_interact_serve_post(evs_rf_server *s, int64_t B, const float *x, int64_t x_stride, const int64_t *indices_base,
+                                           int64_t indices_row_stride, const int64_t *offsets_base, int64_t offsets_row_stride,
+                                           float *R, uint64_t *ticket) {
+    using namespace evs;
+    EVS_REQUIRE(s && x && indices_base && offsets_base && R && ticket, "evs_emb_interact_serve_post: NULL argument");
+    EVS_REQUIRE(B >= 1 && B < (1ll << 31), "evs_emb_interact_serve_post: B=%lld", (long long)B);
+    EVS_REQUIRE(x_stride >= 0 && x_stride % 4 == 0 && x_stride < (1ll << 31) && reinterpret_cast<uintptr_t>(x) % 16 == 0,
+                "evs_emb_interact_serve_post: x must be 16-byte aligned with a row stride that is a multiple of 4 floats");
+    EVS_REQUIRE(indices_row_stride >= 0 && indices_row_stride < (1ll << 31) && offsets_row_stride >= 0 && offsets_row_stride < (1ll << 31),
+                "evs_emb_interact_serve_post: row strides of the (T, B) arrays must fit 31 bits");
+    const unsigned k = s->posted + 1u;
+    const unsigned slot = k % (unsigned)kSrvSlots;
+    volatile unsigned *ans = srv_ans(s), *req = srv_req(s) + (size_t)slot * 16;
+    // the ring holds kSrvSlots batches in flight: the slot's previous user (k - kSrvSlots) must have been answered
+    if (k > (unsigned)kSrvSlots) {
+        const unsigned prev = k - (unsigned)kSrvSlots;
+        uint64_t t = prev;
+        if (ans[slot * 16] != prev) { const int rc = evs_emb_interact_serve_wait(s, t); if (rc) return rc; }
+    }
+    const unsigned long long px = (unsigned long long)reinterpret_cast<uintptr_t>(x), pi = (unsigned long long)reinterpret_cast<uintptr_t>(indices_base),
+                             po = (unsigned long long)reinterpret_cast<uintptr_t>(offsets_base), pr = (unsigned long long)reinterpret_cast<uintptr_t>(R);
+    req[0] = (unsigned)px; req[1] = (unsigned)(px >> 32); req[2] = (unsigned)pi; req[3] = (unsigned)(pi >> 32);
+    req[4] = (unsigned)po; req[5] = (unsigned)(po >> 32); req[6] = (unsigned)B;
+    req[8] = (unsigned)pr; req[9] = (unsigned)(pr >> 32); req[10] = (unsigned)x_stride; req[11] = s->next_first;
+    req[12] = (unsigned)indices_row_stride; req[13] = (unsigned)offsets_row_stride; req[14] = 0u;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    req[7] = k; req[15] = k;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    s->posted = k;
+    s->next_first = (unsigned)(((uint64_t)s->next_first + (uint64_t)((B + 15) / 16)) % (uint64_t)(s->n_blocks - 1));
+    *ticket = k;
+    if (ans[kSrvSlots * 16] == 0u) {   // nobody there (never started, or gone home idle): start the grid
+        const hipError_t q = hipStreamQuery(s->stream);
+        if (q == hipSuccess) { srv_launch(s); if (hipGetLastError() != hipSuccess) { set_error("evs_emb_interact_serve_post: the grid could not be started"); return EVS_EHIP; } }
+        else if (q != hipErrorNotReady) { (void)hipGetLastError(); return EVS_EHIP; }
+        else (void)hipGetLastError();
+    }
+    return EVS_OK;
+}
+
+// Spin until batch `ticket` has been answered (R complete: anything started afterwards may read it)
+extern "C" int evs_emb_interact_serve_wait(evs_rf_server *s, uint64_t ticket) {
+    using namespace evs;
+    EVS_REQUIRE(s && ticket >= 1 && ticket <= s->posted, "evs_emb_interact_serve_wait: no such batch");
+    // (only the last kSrvSlots batches have an answer word of their own: an older one was answered when its slot was re-posted)
+    if ((uint64_t)s->posted - ticket >= (uint64_t)kSrvSlots) return EVS_OK;
+    volatile unsigned *ans = srv_ans(s);
+    const unsigned slot = (unsigned)(ticket % (unsigned)kSrvSlots);
+    long long spins = 0;
+    while (ans[slot * 16] != (unsigned)ticket) {
+        if ((++spins & 255) == 0 && ans[kSrvSlots * 16] == 0u) {   // the grid has left (idle) with this batch still in the ring: start it again
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q == hipSuccess) { if (ans[slot * 16] == (unsigned)ticket) break; srv_launch(s); if (hipGetLastError() != hipSuccess) return EVS_EHIP; }
+            else if (q != hipErrorNotReady) { (void)hipGetLastError(); return EVS_EHIP; }
+            else (void)hipGetLastError();
+        }
+        if (spins > (1ll << 31)) { (void)srv_pause(s); set_error("evs_emb_interact_serve_wait: the grid did not answer"); return EVS_EHIP; }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return EVS_OK;
+}
+
+extern "C" int evs_emb_interact_serve_stop(evs_rf_server *s) {
+    EVS_REQUIRE(s, "evs_emb_interact_serve_stop: NULL server");
+    if (s->posted) { const int rc = evs_emb_interact_serve_wait(s, s->posted); if (rc) return rc; }
+    return srv_pause(s);
+}
+
+extern "C" int evs_emb_interact_serve_destroy(evs_rf_server *s) {
+    if (!s) return EVS_OK;
+    if (s->mbox && s->stream) (void)srv_pause(s);
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    if (s->mbox) (void)hipHostFree(s->mbox);
+    if (s->tmpl_dev) (void)hipFree(s->tmpl_dev);
+    if (s->st_dev) (void)hipFree(s->st_dev);
+    delete s;
+    return EVS_OK;
+}
 
 #ifdef EVS_X_LOG
 // developer tool (tools/dbg_inline.py): the event log of the folded update -- (type, word address, old word, new word)

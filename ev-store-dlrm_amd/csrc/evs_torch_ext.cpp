@@ -373,6 +373,27 @@ py::tuple hostcache_request_list(int64_t handle, const at::Tensor &lS_i_in, int 
     return py::make_tuple(flags, slices(block, true), all);
 }
 
+// ---- the resident dispatcher of the fused launch (evs_emb_interact_serve_*): post one batch / wait for a ticket ----------------
+// (checks and the descriptor write without Python in between: a post is ~1 us of host time)
+uint64_t serve_post(int64_t handle, const at::Tensor &x, const at::Tensor &lS_o, const at::Tensor &lS_i, const at::Tensor &R, int T, int d, int64_t K) {
+    const int64_t B = x.size(0);
+    check_x(x, B, d);
+    check_idx(lS_i, "lS_i");
+    check_idx(lS_o, "lS_o");
+    TORCH_CHECK(lS_i.size(0) == T && lS_i.size(1) == B && lS_o.size(0) == T && lS_o.size(1) == B, "lS_o / lS_i must be (T, B)");
+    TORCH_CHECK(R.is_cuda() && R.scalar_type() == at::kFloat && R.dim() == 2 && R.size(0) == B && R.size(1) == K && R.is_contiguous(),
+                "out must be a contiguous (B, d + P) fp32 device tensor");
+    uint64_t ticket = 0;
+    check(evs_emb_interact_serve_post(reinterpret_cast<evs_rf_server *>(handle), B, x.data_ptr<float>(), B > 1 ? x.stride(0) : d,
+                                      lS_i.data_ptr<int64_t>(), lS_i.stride(0), lS_o.data_ptr<int64_t>(), lS_o.stride(0), R.data_ptr<float>(), &ticket));
+    return ticket;
+}
+void serve_wait(int64_t handle, uint64_t ticket) {
+    py::gil_scoped_release nogil;
+    const int rc = evs_emb_interact_serve_wait(reinterpret_cast<evs_rf_server *>(handle), ticket);
+    if (rc) { py::gil_scoped_acquire gil; raise_evs(rc); }
+}
+
 // ---- the all-to-all of the sharded step, issued from here (round 6) -----------------------------------------------------------
 // dlrm_s_pytorch.py:543-570 / extend_distributed.py:389-465 exchange "local tables x full batch" for "all tables x local
 // batch" with one all_to_all_single; through torch.distributed that call costs 14-38 us of HOST time per step on this stack
@@ -528,6 +549,8 @@ PYBIND11_MODULE(_evs_torch_ext, m) {
     m.def("hostcache_request_list", &hostcache_request_list);
     m.def("serve_request_list", &serve_request_list);
     m.def("slices", &slices);
+    m.def("serve_post", &serve_post);
+    m.def("serve_wait", &serve_wait);
     m.def("rccl_available", &rccl_available);
     m.def("rccl_unique_id", &rccl_unique_id);
     py::class_<DirectA2A>(m, "DirectA2A")

@@ -654,6 +654,82 @@ def fused_supported(F, d):
     return F <= 32 and d in (16, 32, 36, 48, 64, 128)
 
 
+class InteractServer:
+    """The fused call R = interact_features(x, apply_emb(lS_o, lS_i, emb_l)) through a RESIDENT grid (round 6;
+    include/evstore_hip.h: evs_emb_interact_serve_*): post() writes one 64-byte descriptor into a pinned-host ring and returns a
+    ticket -- no launch --, the grid (started by the first post, gone after idle_us without one) runs the batch with the body
+    of the launched kernel (same bits), wait() spins on the answer word.  For the latency half of the metric: one
+    16 384-batch posted and waited for, and small batches back to back, without the ~12 us a launch spends outside its kernel.
+
+    Opt-in, and with rules (the header spells them out): fp32 tables, d in {16, 32, 36, 64}, T <= 27, stacked (T, B) int64
+    lS_o / lS_i on the device; the inputs of a batch are COMPLETE when it is posted (synchronise the producer's stream first);
+    R may be read by anything started after wait() returned; while the grid is resident it holds the compute units, so other
+    launches run when it has left (idle_us, or stop())."""
+
+    def __init__(self, emb_l, arch_interaction_itself=False, n_blocks=0, idle_us=200):
+        ev = _as_evtables(emb_l)
+        assert ev.codec == 32, "the resident dispatcher serves fp32 tables"
+        self.ev, self.T, self.d = ev, len(ev), ev.d
+        F = self.T + 1
+        self.K = self.d + (F * (F + 1) // 2 if arch_interaction_itself else F * (F - 1) // 2)
+        self._h = C.c_void_p()
+        with torch.cuda.device(ev.device):
+            _lib.check(_lib.lib().evs_emb_interact_serve_start(C.byref(self._h), self.T, self.d, ev._tables_c, ev._n_rows_c,
+                                                               int(bool(arch_interaction_itself)), int(n_blocks), int(idle_us)))
+        self._keep = {}       # ticket -> the tensors of a batch in flight (kept alive until it has been waited for)
+        self._x = _ext.ext()
+
+    def post(self, x, lS_o, lS_i, out=None):
+        """-> (ticket, R).  The inputs must be complete (no stream orders a post)."""
+        B = int(x.shape[0])
+        R = out if out is not None else torch.empty((B, self.K), dtype=torch.float32, device=self.ev.device)
+        if self._x is not None:
+            t = self._x.serve_post(self._h.value, x, lS_o, lS_i, R, self.T, self.d, self.K)
+        else:
+            assert x.is_cuda and x.dtype == torch.float32 and x.shape == (B, self.d) and x.stride(1) == 1
+            assert lS_i.dtype == torch.int64 and lS_o.dtype == torch.int64 and lS_i.is_cuda and lS_o.is_cuda
+            assert tuple(lS_i.shape) == (self.T, B) and tuple(lS_o.shape) == (self.T, B) and lS_i.stride(1) == 1 and lS_o.stride(1) == 1
+            assert R.shape == (B, self.K) and R.is_contiguous() and R.dtype == torch.float32
+            tk = C.c_uint64(0)
+            _lib.check(_lib.lib().evs_emb_interact_serve_post(self._h, B, x.data_ptr(), int(x.stride(0)) if B > 1 else self.d, lS_i.data_ptr(),
+                                                              int(lS_i.stride(0)), lS_o.data_ptr(), int(lS_o.stride(0)), R.data_ptr(), C.byref(tk)))
+            t = tk.value
+        self._keep[t] = (x, lS_o, lS_i, R)
+        if len(self._keep) > 128:
+            for k in [k for k in self._keep if k + 64 <= t]:
+                del self._keep[k]
+        return t, R
+
+    def wait(self, ticket):
+        if self._x is not None:
+            self._x.serve_wait(self._h.value, int(ticket))
+        else:
+            _lib.check(_lib.lib().evs_emb_interact_serve_wait(self._h, int(ticket)))
+        self._keep.pop(ticket, None)
+
+    def __call__(self, x, lS_o, lS_i, out=None):
+        t, R = self.post(x, lS_o, lS_i, out)
+        self.wait(t)
+        return R
+
+    def stop(self):
+        """wait for every posted batch, then send the grid home (the next post starts it again)"""
+        _lib.check(_lib.lib().evs_emb_interact_serve_stop(self._h))
+        self._keep.clear()
+
+    def close(self):
+        if self._h:
+            _lib.lib().evs_emb_interact_serve_destroy(self._h)
+            self._h = C.c_void_p()
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def apply_emb_interact(x, lS_o, lS_i, emb_l, v_W_l=None, arch_interaction_itself=False, check_indices=False,
                        out=None, one_index_per_bag=False):
     """R = interact_features(x, apply_emb(lS_o, lS_i, emb_l, v_W_l)) in ONE kernel.

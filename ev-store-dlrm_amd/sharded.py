@@ -115,6 +115,10 @@ class HipBackend:
     def __init__(self, device):
         self.device = torch.device(device)
         self._cache = {}
+        self.stream = None      # a raw HIP stream handle the launches go to instead of torch's current stream (the overlapped step)
+
+    def _sp(self):
+        return self.stream if self.stream is not None else _stream_ptr(self.device)
 
     def make_tables(self, weights, d):
         return EVTables([w.to(self.device) for w in weights], d, 32)
@@ -155,17 +159,17 @@ class HipBackend:
         L = _lib.lib()
         if layout is None and row_lo is None and peer_delta is None:
             _lib.check(L.evs_embedding_bag_sum(n, B, d, ev.codec, ent[0], ent[1], ent[2], ent[3], ent[4], None,
-                                               send.data_ptr(), d, n_own * d, _stream_ptr(self.device)))
+                                               send.data_ptr(), d, n_own * d, self._sp()))
             return
         _, foff, tstride, bstride, pstride, bpp = layout if layout is not None else (B, 0, d, n_own * d, 0, 0)
         if peer_delta is not None and bpp < B:
             _lib.check(L.evs_embedding_bag_sum_p2p(n, B, d, ev.codec, ent[0], ent[1], ent[7], ent[8], ent[2], ent[3], ent[4], None,
                                                    send.data_ptr() + 4 * foff, tstride, bstride, pstride, bpp, peer_delta.data_ptr(),
-                                                   _stream_ptr(self.device)))
+                                                   self._sp()))
             return
         _lib.check(L.evs_embedding_bag_sum_sharded(n, B, d, ev.codec, ent[0], ent[1], ent[7], ent[8], ent[2], ent[3], ent[4], None,
                                                    send.data_ptr() + 4 * foff, tstride, bstride, pstride, bpp,
-                                                   _stream_ptr(self.device)))
+                                                   self._sp()))
 
     def route(self, src_rows, n_rows, world, row_off, dst_rows, key=None):
         """row-split tables, receiver side: dst[k][b] = row_off[owner(src[k][b])] + b in ONE launch (evs_rowsplit_route)"""
@@ -179,7 +183,7 @@ class HipBackend:
                     self._cache.clear()
                 self._cache[key] = ent
         _lib.check(_lib.lib().evs_rowsplit_route(n, int(src_rows[0].numel()), world, ent[0], ent[1], ent[2], ent[3],
-                                                 _stream_ptr(self.device)))
+                                                 self._sp()))
 
     def interact_mixed(self, x, specs, ev, d, itself, out=None, planned=False):
         """specs[t]: ("dense", tensor(B,d) view) | ("indirect", local_table_id, idx, off, nnz, off_len) |
@@ -216,7 +220,7 @@ class HipBackend:
                     self._cache.clear()
                 self._cache[fast] = ent
         _lib.check(_lib.lib().evs_emb_interact_dot(B, F, d, ev.codec if ev is not None else 32, ent[0],
-                                                   int(bool(itself)), R.data_ptr(), _stream_ptr(self.device)))
+                                                   int(bool(itself)), R.data_ptr(), self._sp()))
         return R
 
 
@@ -675,6 +679,23 @@ class ShardedEmbeddingInteract:
         if self.exchange_mode == "p2p":   # the wait for the peers' release in front of the stamped interval, not inside it
             self._p2p_state(pl["Bg"]).begin_pool(pl["slot"])
             self._p2p_begun = True
+        ov = self._overlap_state() if (self.overlap and self.exchange_mode in ("direct", "inline") and self.trace is None) else None
+        if ov is not None and not (self._exchanges() and self.exchange_mode == "inline"):
+            # round 6, the reference's overlap (dlrm_s_pytorch.py:564-569 hides its all-to-all under the bottom MLP): pool(i + 1) and
+            # its exchange on a stream of their own under the interaction of batch i.  Two hand-overs per step: this slot's
+            # buffers are free once the interaction that read them last has run; the interaction waits for this exchange.
+            side, slot = ov["side"], pl["slot"]
+            side.wait_event(ov["free"][slot])
+            self.backend.stream = side.cuda_stream
+            try:
+                self._pool_into(pl["send"], pl["Bg"], pl["lo"], pl["li"], planned=True, lo_split=pl["lo_split"], li_split=pl["li_split"])
+                if self._exchanges():
+                    with torch.cuda.stream(side):   # (DirectA2A.run takes torch's current stream)
+                        self._exchange(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"])
+            finally:
+                self.backend.stream = None
+            ov["ready"][slot].record(side)
+            return ("overlap", slot)
         if tr is not None:
             tr["pool"].append(self._stamp())
         self._pool_into(pl["send"], pl["Bg"], pl["lo"], pl["li"], planned=True, lo_split=pl["lo_split"], li_split=pl["li_split"])
@@ -746,9 +767,29 @@ class ShardedEmbeddingInteract:
             self.step(pl)
         return g
 
+    overlap = False    # the planned step's pool + exchange on a side stream under the previous batch's interaction (run_start)
+    _ov = None
+
+    def _overlap_state(self):
+        if self._ov is None:
+            dev = self.backend.device
+            side = torch.cuda.Stream(device=dev)
+            cur = torch.cuda.current_stream(dev)
+            ev = {"side": side, "ready": [torch.cuda.Event() for _ in range(2)], "free": [torch.cuda.Event() for _ in range(2)]}
+            for e in ev["ready"]:
+                e.record(side)     # (torch creates the HIP event at the first record: here, not inside a timed step)
+            for e in ev["free"]:
+                e.record(cur)
+            self._ov = ev
+        return self._ov
+
     def run_finish(self, pl, work):
         if "route_dst" in pl:
             self._reroute(pl)
+        ov_slot = None
+        if isinstance(work, tuple) and work and work[0] == "overlap":
+            ov_slot, work = work[1], None
+            torch.cuda.current_stream(self.backend.device).wait_event(self._ov["ready"][ov_slot])
         if work is not None:
             work.wait()
         tr = self.trace
@@ -764,6 +805,8 @@ class ShardedEmbeddingInteract:
             tr["interact"].append(self._stamp())
         if p2p:
             self._p2p_state(pl["Bg"]).end_consume(pl["slot"])
+        if ov_slot is not None:
+            self._ov["free"][ov_slot].record(torch.cuda.current_stream(self.backend.device))
         return R
 
     # bench: {"pool": [], "interact": [], "n": 0, "every": 4} -> HIP events around the two launches of every 4th step (start,
@@ -886,6 +929,7 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
                                   replicate_budget_rows=budget_rows)
     op.force_exchange = bool(getattr(args, "force_exchange", False))
     op.exchange_mode = getattr(args, "exchange_mode", "inline")
+    op.overlap = bool(getattr(args, "overlap", True))
     direct_used = None
     if op.exchange_mode == "direct":   # made here, outside the timed loops (ncclCommInitRank is a rendezvous)
         a2a_ = direct_comm(None, dev) if (world > 1 or op.force_exchange) else None
@@ -984,7 +1028,7 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
     local_lookups = [Bl * n_rep for _ in range(world)]
     res = {"dt": dt, "dt_per_rank": dt_per_rank, "pool_lookups_per_rank": pool_lookups, "local_lookups_per_rank": local_lookups,
            "owner": owner, "n_sharded": n_sh, "n_rowsplit": n_split, "n_replicated": n_rep, "mode": mode,
-           "exchange_used": op.exchange_mode, "direct_a2a": direct_used,
+           "exchange_used": op.exchange_mode, "direct_a2a": direct_used, "overlap": bool(op.overlap and op._ov is not None),
            # bytes that leave a rank per step (its pooled vectors -- and its partials of the row-split tables -- for the
            # other ranks' batch slices), and over all ranks
            "a2a_bytes_per_rank": 4 * d * Bl * (len(op.my_own) + n_split) * (world - 1),
@@ -1176,6 +1220,7 @@ def bench_sharded(args, ln_emb, rank, world, dev):
                    "observed_world_size": dist.get_world_size(), "backend": dist.get_backend(),
                    "exchange_mode": (main.get("exchange_auto") or {}).get("picked", main.get("exchange_used", getattr(args, "exchange_mode", "inline"))),
                    "exchange_requested": getattr(args, "exchange_mode", "inline"), "direct_a2a": main.get("direct_a2a"),
+                   "overlap": main.get("overlap"),
                    "exchange_auto": main.get("exchange_auto"),
                    "a2a_bytes_per_step_per_rank": main["a2a_bytes_per_rank"],
                    "a2a_bytes_per_step_all_links": main["a2a_bytes"]},

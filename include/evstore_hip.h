@@ -270,6 +270,31 @@ EVS_API int evs_emb_interact_dot_stacked_multi(int K, int64_t B, int T, int d, i
                                                const int64_t *const *indices_base, int64_t indices_row_stride,
                                                int64_t nnz_per_table, const int64_t *const *offsets_base,
                                                int64_t offsets_row_stride, int itself, float *const *R, void *stream);
+/* The same call -- R = interact_features(x, apply_emb(lS_o, lS_i, emb_l, v_W_l)), lS_o given and checked per 16-sample block
+ * (dlrm_s_pytorch.py:596-601; the inference loop calls it once per batch, :801-836) -- through a RESIDENT DISPATCHER (round 6):
+ * the latency half of the metric.  A launched-and-waited-for batch spends ~12 us outside its kernel (the launch call, the
+ * dispatch of a thousand blocks, the completion signal), and below ~4 000 samples a launch IS that floor.  serve_start keeps
+ * the tables (fp32, d in {16, 32, 36, 64}, T <= 27; HBM addresses as evs_emb_interact_dot_stacked takes them) and arms a grid
+ * of n_blocks blocks (0 = 4 per CU) that starts with the first post and STAYS on the device: serve_post writes one 64-byte
+ * descriptor into a ring in pinned host memory (no launch: ~1 us of host time) and returns a ticket, the grid's leader
+ * wavefront republishes it on the device, every block runs the chunks that fall to it with the very body of the launched
+ * kernel (same bits), R is written through to memory, the block that completes the batch writes the ticket into an answer
+ * ring in host memory and serve_wait spins on that word.  Up to 64 batches may be in flight (a post blocks on the batch 64
+ * tickets back); consecutive small batches land on different blocks and overlap.
+ *   WHAT THE CALLER GUARANTEES: x / lS_i / lS_o of a batch are complete when it is posted (no stream orders a post), R may be
+ *   read by anything STARTED after serve_wait has returned, and nothing else needs the GPU urgently while the grid is
+ *   resident -- it holds its compute units; it leaves by itself after idle_us without a post (the next post starts it again;
+ *   a device-wide synchronise elsewhere waits that long), and serve_stop sends it home at once.
+ * Out-of-range indices / bad offsets: skipped and flagged exactly as the launch form does (evs_check_index_errors). */
+typedef struct evs_rf_server evs_rf_server;
+EVS_API int evs_emb_interact_serve_start(evs_rf_server **out, int T, int d, const void *const *tables, const int64_t *n_rows,
+                                         int itself, int n_blocks, int64_t idle_us);
+EVS_API int evs_emb_interact_serve_post(evs_rf_server *s, int64_t B, const float *x, int64_t x_stride,
+                                        const int64_t *indices_base, int64_t indices_row_stride,
+                                        const int64_t *offsets_base, int64_t offsets_row_stride, float *R, uint64_t *ticket);
+EVS_API int evs_emb_interact_serve_wait(evs_rf_server *s, uint64_t ticket);
+EVS_API int evs_emb_interact_serve_stop(evs_rf_server *s);
+EVS_API int evs_emb_interact_serve_destroy(evs_rf_server *s);
 /* SURVEY 8(f).3, second half: the apply_emb -> interact_features -> FIRST top-MLP layer chain of
  * DLRM_Net.sequential_forward (dlrm_s_pytorch.py:596-605) in one launch: Z1 = act(R W1^T + b1), act = ReLU when relu != 0
  * (create_mlp, dlrm_s_pytorch.py:205-245: nn.Linear + nn.ReLU).  The interaction rows of 16 samples stay in LDS and feed

@@ -80,6 +80,26 @@ def main():
             torch.cuda.synchronize()
             assert torch.equal(out, want), policy + " (direct)"
             assert not op.any_sharded or len(op._direct_plans) == 1, "one planned exchange, reused"
+            # ... and the overlapped step: pool(i + 1) + its exchange on a side stream under the interaction of batch i, two pipeline
+            # slots, event hand-overs -- eight batches in flight order, every R against the unsharded launch
+            if use_v == "1":
+                op.overlap = True
+                xs2 = [torch.rand(B, d, device=dev) for _ in range(4)]
+                idx2 = [torch.stack([torch.from_numpy(rs.randint(0, n, size=B)) for n in ln]).to(dev) for _ in range(4)]
+                wants = [E.apply_emb_interact(xs2[j], off, idx2[j], ev, one_index_per_bag=True) for j in range(4)]
+                outs = [torch.empty_like(want) for _ in range(2)]
+                pls = {(j, sl): op.plan(xs2[j], lo, [idx2[j][t] for t in range(T)], out=outs[sl], slot=sl) for j in range(4) for sl in (0, 1)}
+                got = []
+                h = op.run_start(pls[(0, 0)])
+                for i in range(8):
+                    nxt = op.run_start(pls[((i + 1) % 4, (i + 1) % 2)]) if i + 1 < 8 else None
+                    op.run_finish(pls[(i % 4, i % 2)], h)
+                    got.append(outs[i % 2].clone())
+                    h = nxt
+                torch.cuda.synchronize()
+                for i in range(8):
+                    assert torch.equal(got[i], wants[i % 4]), "%s (overlapped step %d)" % (policy, i)
+                assert not op.any_sharded or op._ov is not None
             del op
     sharded.direct_close()
     dist.barrier()
