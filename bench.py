@@ -291,6 +291,39 @@ def sweep_numbers(E, ev, ln_emb, d, B, dev, dist):
         out["ms_B%d" % Bs] = ms
         out["frac_B%d" % Bs] = Bs * bps(d) / ms / 1e6 / HBM_PEAK_GBPS
         out["p50_polled_ms_B%d" % Bs] = p50_polled(fn, 200)
+    # the same call through the RESIDENT dispatcher (E.InteractServer, round 6: no launch per batch): p50 of one batch posted and
+    # waited for (p50_resident_ms_B*), and wall-clock time per batch of 2 000 batches posted back to back (ms_B*_resident)
+    try:
+        srv = E.InteractServer(ev, idle_us=200)
+        for Bs in (1, 128, 2048, B):
+            sb = make_batches(ln_emb, Bs, 32, seed=23 + Bs, device=dev, dist=dist)
+            xs_ = torch.rand((Bs, d), device=dev)
+            os_ = [torch.empty((Bs, d + P), device=dev) for _ in range(64)]
+            want = E.apply_emb_interact(xs_, sb[0][0], sb[0][1], ev, None)
+            torch.cuda.synchronize()
+            if not torch.equal(srv(xs_, sb[0][0], sb[0][1]), want):
+                raise RuntimeError("the resident dispatcher's R differs from the launched kernel's at B = %d" % Bs)
+            ts = []
+            for i in range(300):
+                t1 = time.perf_counter()
+                srv(xs_, sb[i % 32][0], sb[i % 32][1], out=os_[0])
+                ts.append((time.perf_counter() - t1) * 1e3)
+            out["p50_resident_ms_B%d" % Bs] = float(np.percentile(ts, 50))
+            per = None
+            for _rep in range(2):
+                t1 = time.perf_counter()
+                tk = None
+                for i in range(2000):
+                    tk = srv.post(xs_, sb[i % 32][0], sb[i % 32][1], out=os_[i % 64])[0]
+                srv.wait(tk)
+                per = (time.perf_counter() - t1) / 2000 * 1e3
+            out["ms_B%d_resident" % Bs] = per
+            out["frac_B%d_resident" % Bs] = Bs * bps(d) / per / 1e6 / HBM_PEAK_GBPS
+        srv.stop()
+        srv.close()
+        torch.cuda.synchronize()
+    except Exception as e:
+        out["resident_error"] = repr(e)
     for dd in (16, 64):
         if dd == d:
             continue
@@ -1054,9 +1087,11 @@ def main():
                          "interaction, or p2p: no collective call -- the pooling kernel writes every peer's block straight into that peer's "
                          "IPC-mapped receive buffer, two flag words per (peer, slot) hand it over (csrc/evs_p2p.hip); auto: p2p when ONE batch through both "
                          "exchanges gave bit-equal receive buffers on every rank (sharded.verify_p2p_against_collective), the RCCL collective otherwise")
-    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
-                    help="N>1: keep pool, exchange and interaction of a step on one stream (default: pool(i + 1) + its exchange on a side stream "
-                         "under the interaction of batch i, two event hand-overs per step; direct exchange / no exchange only)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N>1: pool(i + 1) + its exchange on a side stream under the interaction of batch i, two event hand-overs per step "
+                         "(direct exchange / no exchange only).  OFF by default: measured on one rank with the exchange forced, 149 us per step "
+                         "against 40.5 in stream order (33.6 against 24.7 without an exchange) -- a cross-stream event wait costs tens of "
+                         "microseconds on this stack, far more than the 13 us of exchange it could hide")
     ap.add_argument("--force-exchange", action="store_true", help="with --force-sharded on one rank: issue the RCCL all_to_all_single anyway "
                                                                   "(a self-exchange into a separate receive buffer: what the collective call itself costs per step)")
     ap.add_argument("--shape", default="kaggle", choices=["kaggle", "terabyte"],
@@ -1462,6 +1497,9 @@ def main_single(args, local_rank):
             result["roofline"]["sweep_error"] = repr(e)
     result["roofline"].update({"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)),
                                "p50_polled_ms": float(np.percentile(lat_poll, 50))})
+    if ("p50_resident_ms_B%d" % B) in result["roofline"]:   # the other half of BASELINE's metric through the resident dispatcher
+        result["p50_batch_latency_resident_ms"] = result["roofline"]["p50_resident_ms_B%d" % B]
+        result["roofline"]["p50_resident_ms"] = result["roofline"]["p50_resident_ms_B%d" % B]
     result["declared_one_index"]["note"] = ("apply_emb_interact(..., one_index_per_bag=True): the caller states lS_o == arange, the launch "
                                             "does not read it (5 644 algorithmic bytes per sample; frac = those bytes over the wall-clock step)")
     # ---- the same launch at a larger batch (fixed launch / pipeline-fill cost amortised), and reduced precision ----

@@ -71,15 +71,33 @@ constexpr int kMlpRowStride = 452;   // floats per staged row: kp <= 448 (F <= 2
 // shapes) from a FusedArgs the server keeps in device memory (`ka` points at it, `args` is a copy of its scalar fields); R is
 // stored with agent-scope write-through stores (sc1): a resident kernel has no end-of-kernel release that would write its L2
 // back for the launches (on other XCDs) that read R afterwards.
+// what a RESIDENT grid reads of a batch's inputs (indices, offsets, x) goes through agent-scope loads: the grid never passes a
+// kernel boundary, so nothing invalidates its L1 / L2 between two batches that reuse the same addresses (an acquire fence per
+// descriptor does -- buffer_inv sc1 by a thousand blocks: measured, +27 us per batch)
+template <bool COHERENT>
+__device__ __forceinline__ int64_t rf_ld_i64(const int64_t *p) {
+    typedef const __attribute__((address_space(1))) int64_t *g_t;
+    if constexpr (COHERENT) return __hip_atomic_load(reinterpret_cast<g_t>(reinterpret_cast<uintptr_t>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *reinterpret_cast<g_t>(reinterpret_cast<uintptr_t>(p));
+}
+template <bool COHERENT>
+__device__ __forceinline__ float rf_ld_f32(const float *p) {
+    typedef const __attribute__((address_space(1))) float *g_t;
+    if constexpr (COHERENT) return __hip_atomic_load(reinterpret_cast<g_t>(reinterpret_cast<uintptr_t>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *reinterpret_cast<g_t>(reinterpret_cast<uintptr_t>(p));
+}
 struct RfServeDesc {
     const float *x; const int64_t *idx; const int64_t *off; float *R;
     int64_t B, x_stride, idx_stride, off_stride;
 };
 template <int CQ, int REM, int NT, int D, bool MLP, bool IDS, bool PROBE, bool CHECK, bool SERVE>
-__device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *ka, const RfServeDesc &sd, const int blk_in) {
+__device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *ka, const RfServeDesc &sd, const int blk_in, const bool srv_first = false) {
     static_assert(!CHECK || (!MLP && !IDS && !PROBE), "the offsets check belongs to the plain launch");
     static_assert(!SERVE || (CHECK && !MLP && !IDS && !PROBE), "the resident form serves the drop-in call (lS_o given)");
-    constexpr int kCpol = SERVE ? (EVS_OUT_CPOL | 16) : EVS_OUT_CPOL;   // (aux bit 4 = sc1 on gfx940+: agent scope, write-through)
+#ifndef EVS_X_SRV
+#define EVS_X_SRV 0     // developer A/B of the resident form (timing only): 2 = R stores without sc1, 4 = workers sleep longer between polls
+#endif
+    constexpr int kCpol = (SERVE && !(EVS_X_SRV & 2)) ? (EVS_OUT_CPOL | 16) : EVS_OUT_CPOL;   // (aux bit 4 = sc1 on gfx940+: agent scope, write-through)
     constexpr int NR = NT;
     constexpr int NC = CQ + REM;
     constexpr int d = 4 * (4 * CQ + REM);
@@ -101,6 +119,8 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
     // PROBE, the update folded in as well (ProbeArgs::arena_w): totals of the inserts this block makes
     __shared__ int s_udelta[PROBE ? kMaxBuckets : 1];
     __shared__ int s_ustat[PROBE ? 2 : 1];
+    __shared__ unsigned long long s_srv_src[SERVE ? 32 : 1];              // SERVE: the tables' addresses and row counts, read from the template ONCE per
+    __shared__ unsigned s_srv_nr[SERVE ? 32 : 1];                         // block (srv_first) -- the launch form pays that round trip per chunk
     __shared__ const int64_t *s_tile_o[CHECK ? 32 : 1];                   // CHECK: offsets arrays, their readable entries, nnz
     __shared__ int64_t s_tile_ol[CHECK ? 32 : 1], s_tile_nz[CHECK ? 32 : 1];
     constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
@@ -150,13 +170,25 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
         // load, in every block of every launch -- the larger part of the launch's fixed cost.)
         const int f = (int)tid_x;
         const bool on = f < F;
-        const int64_t *ip = ka->indices[f];
-        const unsigned long long src = (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]);
-        const int64_t nr = ka->n_rows[f];
-        const int64_t stride = ka->stride[f];
+        const int64_t *ip = nullptr;
+        unsigned long long src = 0ull;
+        int64_t nr = 0, stride = 0;
         const int64_t *op = nullptr;
         int64_t ol = 0, nz = 0;
-        if constexpr (CHECK) { op = ka->offsets[f]; ol = SERVE ? sd.B : ka->off_len[f]; nz = SERVE ? sd.B : ka->nnz[f]; }
+        if constexpr (SERVE) {
+            if (srv_first) {   // (block-uniform) the one round trip to the template this block ever makes
+                s_srv_src[f] = (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]);
+                s_srv_nr[f] = (unsigned)ka->n_rows[f];
+            }
+            src = s_srv_src[f]; nr = (int64_t)s_srv_nr[f];
+            ol = sd.B; nz = sd.B;
+        } else {
+            ip = ka->indices[f];
+            src = (unsigned long long)reinterpret_cast<uintptr_t>(ka->src[f]);
+            nr = ka->n_rows[f];
+            stride = ka->stride[f];
+            if constexpr (CHECK) { op = ka->offsets[f]; ol = ka->off_len[f]; nz = ka->nnz[f]; }
+        }
         unsigned long long mx = 0ull;
         const int64_t *mi = nullptr, *mo = nullptr;
         if constexpr (SERVE) {
@@ -280,15 +312,15 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
             } else {
                 const int64_t *ap = table ? s_tile_p[f] + bs : dummy_i;
                 // (explicitly global: a flat load would force every later wait to vmcnt(0))
-                tile_v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(ap));
+                tile_v[h] = rf_ld_i64<SERVE>(ap);
             }
             if constexpr (CHECK) {
                 const int64_t *op = s_tile_o[f];
                 const bool own = table && ((tid_x & 15) == 15 || bs + 1 >= blk_end);
                 const int64_t *p0 = table ? op + bs : dummy_i;
                 const int64_t *p1 = (own && bs + 1 < s_tile_ol[f]) ? op + bs + 1 : dummy_i;
-                tile_o0[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(p0));
-                tile_o1[h] = *reinterpret_cast<const __attribute__((address_space(1))) int64_t *>(reinterpret_cast<uintptr_t>(p1));
+                tile_o0[h] = rf_ld_i64<SERVE>(p0);
+                tile_o1[h] = rf_ld_i64<SERVE>(p1);
             }
         }
     };
@@ -455,17 +487,22 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
                 if (!ip) {   // dense feature (x, received pooled vectors)
                     const char *row = src + (uint64_t)b * (uint64_t)(((SERVE && f == 0) ? sd.x_stride : ka->stride[f]) * 4);
 #pragma unroll
-                    for (int c = 0; c < NC; c++) a[rr][c] = chunk_at(row, c);
+                    for (int c = 0; c < NC; c++) {
+                        if constexpr (SERVE) {   // (x: fresh from memory, see rf_ld_*)
+                            const float *fp = reinterpret_cast<const float *>(row + (c < CQ ? (q * CQ + c) * 16 : kRemOff + (c - CQ) * 16));
+                            a[rr][c] = make_float4(rf_ld_f32<true>(fp), rf_ld_f32<true>(fp + 1), rf_ld_f32<true>(fp + 2), rf_ld_f32<true>(fp + 3));
+                        } else a[rr][c] = chunk_at(row, c);
+                    }
                     continue;
                 }
                 const int64_t *op = s_tile_o[f];
                 const int64_t nnz = SERVE ? sd.B : ka->nnz[f];
-                int64_t s0 = op[b];
-                int64_t e0 = (b + 1 < (SERVE ? sd.B : ka->off_len[f])) ? op[b + 1] : nnz;
+                int64_t s0 = rf_ld_i64<SERVE>(op + b);
+                int64_t e0 = (b + 1 < (SERVE ? sd.B : ka->off_len[f])) ? rf_ld_i64<SERVE>(op + b + 1) : nnz;
                 if (!((s0 >= 0) & (e0 >= s0) & (e0 <= nnz))) { bad = true; s0 = e0 = 0; }
-                const uint64_t n_rows = (uint64_t)ka->n_rows[f];
+                const uint64_t n_rows = SERVE ? (uint64_t)s_srv_nr[f] : (uint64_t)ka->n_rows[f];
                 for (int64_t j = s0; j < e0; j++) {
-                    const int64_t r = ip[j];
+                    const int64_t r = rf_ld_i64<SERVE>(ip + j);
                     if ((uint64_t)r >= n_rows) { bad = true; continue; }   // skipped; a skipped FIRST row counts as zeros
                     const char *row = src + (uint64_t)r * (uint64_t)row_bytes;
 #pragma unroll
@@ -481,7 +518,7 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
 #pragma unroll
             for (int h = 0; h < (d + 63) / 64; h++) {
                 const int e = lane + 64 * h;
-                xv[h] = reinterpret_cast<const float *>(reinterpret_cast<const char *>((uintptr_t)s_feat_base[0]) + (uint64_t)b * (uint64_t)((SERVE ? sd.x_stride : ka->stride[0]) * 4))[e < d ? e : 0];
+                xv[h] = rf_ld_f32<SERVE>(reinterpret_cast<const float *>(reinterpret_cast<const char *>((uintptr_t)s_feat_base[0]) + (uint64_t)b * (uint64_t)((SERVE ? sd.x_stride : ka->stride[0]) * 4)) + (e < d ? e : 0));
             }
             f32x4 c00, c10, c11;
             {
@@ -716,6 +753,19 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
         issue(u, ring[u]);      // (samples past the block's end: every lane reads the zero page)
         if constexpr ((EVS_RF_SB & 2) != 0) __builtin_amdgcn_sched_barrier(0);
     }
+    float x_srv[SERVE ? D : 1][SERVE ? (d + 63) / 64 : 1];   // SERVE: x[b] once more, fresh from memory (rf_ld_*), asked for with the row requests
+    if constexpr (SERVE) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            const int64_t b = blk_first + wave_in_block + 4 * (int64_t)u;
+#pragma unroll
+            for (int h = 0; h < (d + 63) / 64; h++) {
+                const int e = lane + 64 * h;
+                const float *xp = (u < n_samples && e < d) ? sd.x + b * sd.x_stride + e : reinterpret_cast<const float *>(zeros_l);
+                x_srv[u][h] = rf_ld_f32<true>(xp);
+            }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink three of the four requests below the first consume
     // the lane-invariant staging / flush offsets: computed here, under the row requests' round trip, not in front of them
     // (16 waves per CU start in step: every instruction in front of the first load is paid by all of them at once)
@@ -728,6 +778,13 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
         // the image of sample u: what the row DMA of the LDS loop would have left in the slot
 #pragma unroll
         for (int j = 0; j < NJ; j++) *reinterpret_cast<f32x4 *>(my_lds + j * 1024 + lane * 16) = ring[u][j];
+        if constexpr (SERVE) {   // row 0 of the image = x[b]: the copy that came through the agent-scope loads
+#pragma unroll
+            for (int h = 0; h < (d + 63) / 64; h++) {
+                const int e = lane + 64 * h;
+                if (e < d) reinterpret_cast<float *>(my_lds)[e] = x_srv[u][h];
+            }
+        }
         if constexpr (PROBE) {
             if (ins_blk) {   // the rows of the ways this block claimed: from the registers that gathered them into the arena
 #pragma unroll
@@ -1073,7 +1130,10 @@ struct SrvDesc { unsigned w[16]; };   // w0-1 x, w2-3 idx, w4-5 off, w6 B, w7 se
 struct SrvState {
     unsigned pub[kSrvReplicas][32];       // line r: word 0 = the last published sequence number, word 1 = the generation (launch number) of the grid that has LEFT behind it
     SrvDesc desc[kSrvSlots];              // the leader's copies of the descriptors
-    unsigned arrived[kSrvSlots][32];      // per slot (a line each): chunks finished
+    // per slot: chunks finished -- two levels (a thousand arrivals on ONE word serialise at the memory-side atomic unit: ~6 us,
+    // r04_atomic_probe, and the blocks of a full batch all finish together): chunk c arrives at sub-counter c % 32 (a line each),
+    // whoever completes a sub-counter arrives at the top one (line 32)
+    unsigned arrived[kSrvSlots][33][32];
 };
 struct SrvArgs {
     const FusedArgs *tmpl;                // tables, shapes (device memory; written before the grid starts, never while it runs)
@@ -1087,54 +1147,64 @@ struct SrvArgs {
     long long idle_ticks;
 };
 
+// which block runs chunk c of a batch (the same rule on both sides).  A batch with fewer chunks than the grid has blocks goes to the
+// WORKERS only (blocks 1 .. G-1, starting at the batch's `first`: consecutive small batches land on different blocks), so the
+// leader stays at its mailbox; a batch with at least G chunks uses every block, the leader's too (at B = 16 384 = 1 024 chunks a
+// grid of 1 024 blocks would otherwise hand one worker two chunks: the batch's tail)
+__device__ __forceinline__ unsigned srv_block_of(unsigned c, unsigned n_chunks, unsigned first, unsigned G) {
+    return n_chunks >= G ? (first + c) % G : 1u + (first + c) % (G - 1u);
+}
+// the chunks of one batch that fall to block `me`, then the arrival: every wave waits for its stores of R (written through),
+// ONE atomic per block, and the block that completes the batch writes its number into the answer ring in host memory
+template <int CQ, int REM, int NT>
+__device__ __forceinline__ void srv_run_batch(const SrvArgs &sv, const FusedArgs &la, const unsigned (&w)[16], unsigned k, unsigned me, unsigned G, bool &first) {
+    RfServeDesc sd;
+    sd.x = reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)w[1] << 32) | w[0]));
+    sd.idx = reinterpret_cast<const int64_t *>((uintptr_t)(((unsigned long long)w[3] << 32) | w[2]));
+    sd.off = reinterpret_cast<const int64_t *>((uintptr_t)(((unsigned long long)w[5] << 32) | w[4]));
+    sd.R = reinterpret_cast<float *>((uintptr_t)(((unsigned long long)w[9] << 32) | w[8]));
+    sd.B = (int64_t)w[6]; sd.x_stride = (int64_t)w[10]; sd.idx_stride = (int64_t)w[12]; sd.off_stride = (int64_t)w[13];
+    const unsigned n_chunks = (w[6] + 15u) >> 4;
+    const unsigned slot = k % (unsigned)kSrvSlots;
+    unsigned c0, step;
+    if (n_chunks >= G) { c0 = (me + G - w[11] % G) % G; step = G; }
+    else { if (me == 0u) return; c0 = (me - 1u + (G - 1u) - w[11] % (G - 1u)) % (G - 1u); step = G - 1u; }
+    unsigned mine = 0u;
+    for (unsigned c = c0; c < n_chunks; c += step) {
+        rf_body<CQ, REM, NT, EVS_RF_DEPTH, false, false, false, true, true>(la, sv.tmpl, sd, (int)c, first);
+        first = false;
+        mine++;
+        __syncthreads();
+    }
+    if (mine) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of R have been written through
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            bool last = n_chunks == 1u;       // (a batch of one chunk: nobody else to wait for)
+            if (!last) {
+                unsigned tops = 0u;           // sub-counters this block completed
+                for (unsigned c = c0; c < n_chunks; c += step) {
+                    const unsigned r = c & 31u, expect = (n_chunks >> 5) + (r < (n_chunks & 31u) ? 1u : 0u);
+                    const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][r][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (before + 1u == expect) { tops++; __hip_atomic_store(&sv.st->arrived[slot][r][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // back to zero for the slot's next use
+                }
+                if (tops) {
+                    const unsigned n_sub = n_chunks < 32u ? n_chunks : 32u;
+                    const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][32][0], tops, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = before + tops == n_sub;
+                    if (last) __hip_atomic_store(&sv.st->arrived[slot][32][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (last) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + slot * 16u, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <int CQ, int REM, int NT>
 __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_rf_serve_kernel(const SrvArgs sv) {
     SrvState *st = sv.st;
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == 0) {
-        // ---------------- the leader ----------------
-        if (threadIdx.x >= 64) return;
-        unsigned seq = sv.start_seq;
-        if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // alive
-        long long t0 = (long long)wall_clock64();
-        for (;;) {
-            // the next four ring slots in one load: lane = 16 * (slot in the group) + word
-            const unsigned slot0 = (seq + 1u) % (unsigned)kSrvSlots;
-            const unsigned sl = (slot0 + (unsigned)(lane >> 4)) % (unsigned)kSrvSlots;
-            const unsigned word = __hip_atomic_load(const_cast<unsigned *>(sv.req) + sl * 16u + (unsigned)(lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            // group g holds descriptor seq + 1 + g when both its guards say so
-            const unsigned want = seq + 1u + (unsigned)(lane >> 4);
-            const unsigned long long gm = __ballot(((lane & 7) == 7) && word == want);   // lanes 7, 15 of every group
-            int n_new = 0;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const bool okg = ((gm >> (16 * g + 7)) & 1ull) && ((gm >> (16 * g + 15)) & 1ull);
-                if (okg && n_new == g) n_new = g + 1;    // consecutive ones only
-            }
-            if (n_new > 0) {
-                if ((lane >> 4) < n_new) __hip_atomic_store(&st->desc[sl].w[lane & 15], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the copies are in memory before their number is
-                seq += (unsigned)n_new;
-                if (lane < kSrvReplicas) __hip_atomic_store(&st->pub[lane][0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t0 = (long long)wall_clock64();
-                continue;
-            }
-            const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (stop != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        // leaving: every worker sees the stop word behind the last number; the host learns how far the grid got
-        if (lane < kSrvReplicas) __hip_atomic_store(&st->pub[lane][1], sv.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) {
-            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16 + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return;
-    }
-    // ---------------- a worker ----------------
-    __shared__ unsigned s_pub[2];
-    const unsigned n_workers = gridDim.x - 1u, me = blockIdx.x - 1u;
-    const unsigned long long *my_line = reinterpret_cast<const unsigned long long *>(&st->pub[me % (unsigned)kSrvReplicas][0]);
+    const unsigned G = gridDim.x, me = blockIdx.x;
     // the scalar fields of the template (constant address space: scalar loads; the template is not written while the grid runs)
     typedef const __attribute__((address_space(4))) FusedArgs *tmpl4_t;
     const tmpl4_t t4 = reinterpret_cast<tmpl4_t>(reinterpret_cast<uintptr_t>(sv.tmpl));
@@ -1142,55 +1212,104 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
     la.F = t4->F; la.d = t4->d; la.itself = t4->itself; la.P = t4->P; la.err = t4->err; la.zeros = t4->zeros;
     la.dummy_i64 = t4->dummy_i64; la.dummy_f32 = t4->dummy_f32; la.tile_per = 16; la.multi_n = 0; la.multi_cpb = 0;
     la.multi_idx_stride = 0; la.multi_off_stride = 0; la.R = nullptr; la.B = 0; la.bag1 = 3;
-    unsigned my = sv.start_seq;
+    bool first = true;     // (block-uniform) this block has not run a chunk yet: the body's one read of the template
+    // what the block's wave 0 brought back from its poll: [0..63] descriptor words (leader: up to four new batches; worker: its
+    // replica line -- number, stop word, the descriptor of batch `number`), [64] = batches to look at, [65] = leave afterwards
+    __shared__ unsigned s_line[66];
+    const unsigned *my_line = &st->pub[me % (unsigned)kSrvReplicas][0];
+    unsigned my = sv.start_seq;      // the last batch this block has looked at
+    if (me == 0u && threadIdx.x == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // alive
     for (;;) {
-        if (threadIdx.x == 0) {
-            unsigned long long v;
-            for (;;) {
-                v = __hip_atomic_load(my_line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)v != my || (unsigned)(v >> 32) == sv.gen) break;
-                __builtin_amdgcn_s_sleep(1);
+        if (threadIdx.x < 64) {
+            if (me == 0u) {
+                // ---------------- the leader: wave 0 at the mailbox ----------------
+                const long long t0 = (long long)wall_clock64();
+                int n_new = 0;
+                unsigned word = 0u;
+                for (;;) {
+                    // the next four ring slots in one load: lane = 16 * (slot in the group) + word
+                    const unsigned slot0 = (my + 1u) % (unsigned)kSrvSlots;
+                    const unsigned sl = (slot0 + (unsigned)(lane >> 4)) % (unsigned)kSrvSlots;
+                    word = __hip_atomic_load(const_cast<unsigned *>(sv.req) + sl * 16u + (unsigned)(lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // group g holds descriptor my + 1 + g when both its guards say so
+                    const unsigned want = my + 1u + (unsigned)(lane >> 4);
+                    const unsigned long long gm = __ballot(((lane & 7) == 7) && word == want);   // lanes 7, 15 of every group
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const bool okg = ((gm >> (16 * g + 7)) & 1ull) && ((gm >> (16 * g + 15)) & 1ull);
+                        if (okg && n_new == g) n_new = g + 1;    // consecutive ones only
+                    }
+                    if (n_new > 0) {
+                        // the descriptors into the ring in device memory (what a worker reads when a poll brought it more than one
+                        // new number), the LAST of them into every replica line behind the line's number (a worker's poll brings the
+                        // descriptor with the number: one round trip less per batch) -- all without a wait in between: a reader checks
+                        // the guards of what it reads against the number it is after (older: not there yet, read again)
+                        if ((lane >> 4) < n_new) __hip_atomic_store(&st->desc[sl].w[lane & 15], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned wl = (unsigned)__shfl((int)word, 16 * (n_new - 1) + (lane & 15));
+#pragma unroll 4
+                        for (int r = 0; r < kSrvReplicas; r += 4)
+                            __hip_atomic_store(&st->pub[r + (lane >> 4)][2 + (lane & 15)], wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane < kSrvReplicas) __hip_atomic_store(&st->pub[lane][0], my + (unsigned)n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (stop != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                s_line[lane] = word;
+                if (lane == 0) { s_line[64] = (unsigned)n_new; s_line[65] = n_new == 0 ? 1u : 0u; }
+            } else {
+                // ---------------- a worker: the whole replica line in one 32-lane load ----------------
+                unsigned v, sq, gn;
+                for (;;) {
+                    v = __hip_atomic_load(my_line + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sq = (unsigned)__shfl((int)v, 0); gn = (unsigned)__shfl((int)v, 1);
+                    if (sq != my || gn == sv.gen) break;
+                    __builtin_amdgcn_s_sleep((EVS_X_SRV & 4) ? 16 : 1);
+                }
+                if (lane >= 2 && lane < 18) s_line[lane - 2] = v;
+                if (lane == 0) { s_line[64] = sq - my; s_line[65] = gn == sv.gen ? 1u : 0u; }
             }
-            s_pub[0] = (unsigned)v; s_pub[1] = (unsigned)(v >> 32) == sv.gen ? 1u : 0u;
         }
         __syncthreads();
-        const unsigned seq = s_pub[0], stop = s_pub[1];
-        __syncthreads();
-        if (seq != my) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // what other launches wrote (x, indices, offsets) before the post
-        for (unsigned k = my + 1u; k != seq + 1u; k++) {
-            const unsigned slot = k % (unsigned)kSrvSlots;
-            const unsigned *dw = st->desc[slot].w;
-            unsigned w[14];
+        const unsigned n_look = s_line[64], leave = s_line[65];
+        for (unsigned g = 0; g < n_look; g++) {
+            const unsigned k = my + 1u + g;
+            unsigned w[16];
+            bool have;
+            if (me == 0u || g + 1u == n_look) {     // the leader's own copies / the descriptor that came with the worker's line
 #pragma unroll
-            for (int i = 0; i < 14; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            RfServeDesc sd;
-            sd.x = reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)w[1] << 32) | w[0]));
-            sd.idx = reinterpret_cast<const int64_t *>((uintptr_t)(((unsigned long long)w[3] << 32) | w[2]));
-            sd.off = reinterpret_cast<const int64_t *>((uintptr_t)(((unsigned long long)w[5] << 32) | w[4]));
-            sd.R = reinterpret_cast<float *>((uintptr_t)(((unsigned long long)w[9] << 32) | w[8]));
-            sd.B = (int64_t)w[6]; sd.x_stride = (int64_t)w[10]; sd.idx_stride = (int64_t)w[12]; sd.off_stride = (int64_t)w[13];
-            const unsigned n_chunks = (w[6] + 15u) >> 4;
-            const unsigned first = w[11] % n_workers;
-            unsigned mine = 0u;
-            for (unsigned c = (me + n_workers - first) % n_workers; c < n_chunks; c += n_workers) {
-                rf_body<CQ, REM, NT, EVS_RF_DEPTH, false, false, false, true, true>(la, sv.tmpl, sd, (int)c);
-                mine++;
-                __syncthreads();
-            }
-            if (mine) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of R have been written through
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    const unsigned before = __hip_atomic_fetch_add(&st->arrived[slot][0], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (before + mine == n_chunks) {   // the batch is complete: the counter back to zero for the slot's next use, then the answer
-                        __hip_atomic_store(&st->arrived[slot][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(const_cast<unsigned *>(sv.ans) + slot * 16u, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
+                for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)s_line[(me == 0u ? 16 * g : 0) + i]);
+                have = w[7] == k && w[15] == k;
+            } else have = false;
+            if (!have && me != 0u) {
+                // an earlier batch of a burst (or a line caught between its words and its number): the ring in device memory.  Its
+                // guards say which batch the slot holds: k -- take it (both guards, and the first again after the words: the loads
+                // return in order); an OLDER number -- the leader's copy is still on its way: read again; a LATER one -- this worker
+                // lags, batch k completed without it and the ring has come round: k owed it nothing (a batch is only answered,
+                // and its slot only reused, when every chunk of it has arrived).
+                const unsigned *dw = st->desc[k % (unsigned)kSrvSlots].w;
+                for (int tries = 0; tries < (1 << 20); tries++) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const unsigned g2 = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (w[7] == k && w[15] == k && g2 == k) { have = true; break; }
+                    if ((int)(w[7] - k) > 0 || (int)(w[15] - k) > 0 || (int)(g2 - k) > 0) break;    // overwritten by a later batch
                 }
             }
+            if (have) srv_run_batch<CQ, REM, NT>(sv, la, w, k, me, G, first);
         }
-        my = seq;
-        if (stop != 0u) break;
+        my += n_look;
+        __syncthreads();
+        if (leave) break;
+    }
+    if (me == 0u) {
+        // leaving: every worker sees the stop word behind the last number; the host learns how far the grid got
+        if (threadIdx.x < kSrvReplicas) __hip_atomic_store(&st->pub[threadIdx.x][1], sv.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16 + 1, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1328,7 +1447,7 @@ extern "C" int evs_emb_interact_serve_post(evs_rf_server *s, int64_t B, const fl
     req[7] = k; req[15] = k;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     s->posted = k;
-    s->next_first = (unsigned)(((uint64_t)s->next_first + (uint64_t)((B + 15) / 16)) % (uint64_t)(s->n_blocks - 1));
+    s->next_first = (unsigned)(((uint64_t)s->next_first + (uint64_t)((B + 15) / 16)) % (uint64_t)(1u << 30));
     *ticket = k;
     if (ans[kSrvSlots * 16] == 0u) {   // nobody there (never started, or gone home idle): start the grid
         const hipError_t q = hipStreamQuery(s->stream);

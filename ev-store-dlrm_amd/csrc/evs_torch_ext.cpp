@@ -388,6 +388,13 @@ uint64_t serve_post(int64_t handle, const at::Tensor &x, const at::Tensor &lS_o,
                                       lS_i.data_ptr<int64_t>(), lS_i.stride(0), lS_o.data_ptr<int64_t>(), lS_o.stride(0), R.data_ptr<float>(), &ticket));
     return ticket;
 }
+// post + wait in one call (the latency path: one batch posted and waited for)
+void serve_run(int64_t handle, const at::Tensor &x, const at::Tensor &lS_o, const at::Tensor &lS_i, const at::Tensor &R, int T, int d, int64_t K) {
+    const uint64_t ticket = serve_post(handle, x, lS_o, lS_i, R, T, d, K);
+    py::gil_scoped_release nogil;
+    const int rc = evs_emb_interact_serve_wait(reinterpret_cast<evs_rf_server *>(handle), ticket);
+    if (rc) { py::gil_scoped_acquire gil; raise_evs(rc); }
+}
 void serve_wait(int64_t handle, uint64_t ticket) {
     py::gil_scoped_release nogil;
     const int rc = evs_emb_interact_serve_wait(reinterpret_cast<evs_rf_server *>(handle), ticket);
@@ -551,6 +558,7 @@ PYBIND11_MODULE(_evs_torch_ext, m) {
     m.def("slices", &slices);
     m.def("serve_post", &serve_post);
     m.def("serve_wait", &serve_wait);
+    m.def("serve_run", &serve_run);
     m.def("rccl_available", &rccl_available);
     m.def("rccl_unique_id", &rccl_unique_id);
     py::class_<DirectA2A>(m, "DirectA2A")

@@ -767,7 +767,11 @@ class ShardedEmbeddingInteract:
             self.step(pl)
         return g
 
-    overlap = False    # the planned step's pool + exchange on a side stream under the previous batch's interaction (run_start)
+    # the planned step's pool + exchange on a side stream under the previous batch's interaction (run_start).  Built for the
+    # reference's overlap (dlrm_s_pytorch.py:564-569) once the exchange had left the host path (exchange_mode "direct"); measured
+    # on one rank with the exchange forced: 149 us per step against 40.5 in stream order, 33.6 against 24.7 without an exchange --
+    # the two cross-stream event waits per step cost far more than the 13.7 us exchange kernel they could hide.  Off.
+    overlap = False
     _ov = None
 
     def _overlap_state(self):
@@ -929,7 +933,7 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
                                   replicate_budget_rows=budget_rows)
     op.force_exchange = bool(getattr(args, "force_exchange", False))
     op.exchange_mode = getattr(args, "exchange_mode", "inline")
-    op.overlap = bool(getattr(args, "overlap", True))
+    op.overlap = bool(getattr(args, "overlap", False))
     direct_used = None
     if op.exchange_mode == "direct":   # made here, outside the timed loops (ncclCommInitRank is a rendezvous)
         a2a_ = direct_comm(None, dev) if (world > 1 or op.force_exchange) else None

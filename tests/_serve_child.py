@@ -53,6 +53,15 @@ def main():
         torch.cuda.synchronize()
         for i in range(100):
             assert torch.equal(outs[i], wants[i]), ("pipelined", order, i)
+    # ---- inputs REWRITTEN IN PLACE between posts while the grid stays resident (no kernel boundary invalidates its caches: the
+    # body reads x / indices / offsets through agent-scope loads): every batch must see the new contents
+    xr, ir, orr = torch.empty(B, d, device=dev), torch.empty((T, B), dtype=torch.int64, device=dev), torch.empty((T, B), dtype=torch.int64, device=dev)
+    outr = torch.empty_like(wants[0])
+    for i in range(40):
+        xr.copy_(xs[i]); ir.copy_(idxs[i]); orr.copy_(off)
+        torch.cuda.synchronize()
+        got = srv(xr, orr, ir, out=outr)
+        assert torch.equal(got, wants[i]), ("inputs rewritten in place", i)
     # ---- the grid leaves idle (150 us) and the next post brings it back; stop() in between
     for pause in (0.002, 0.0, 0.01):
         time.sleep(pause)
