@@ -235,7 +235,16 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
     __shared__ unsigned long long s_ptr[512];       // [32 features][16 samples]: row address (feature 0 = x: unused)
     __shared__ unsigned char s_cls[512];
     __shared__ __attribute__((aligned(16))) float s_x[4][64];
-    __shared__ float s_lut[256 + 16];
+    // the decode table: the 256 u8 values, the sixteen u4 values behind them.  (Round 6: sixteen copies side by side, lane l
+    // reading copy l & 15 -- at most a 2-way bank conflict where 32 lanes reading a 256-entry table at RANDOM indices collide ~3.5
+    // ways -- was built and measured: SQ_LDS_BANK_CONFLICT 2.92 M -> 3.42 M per launch, the same 39.2 us.  The codes of real
+    // tables are not random: embeddings sit around zero, i.e. around code 127 / nibble 7, a dozen distinct entries per
+    // instruction, which the single table serves conflict-free and with broadcasts; the copies turn equal indices in different
+    // lanes into different addresses.  The table is not where this kernel's LDS conflicts come from.)
+    constexpr int kLutCopies = 1;
+    constexpr unsigned kU4Base = 256u * kLutCopies * 4u;       // byte offset of the u4 entries
+    constexpr int kLutShift = 2;                               // log2 of the bytes between two entries
+    __shared__ float s_lut[(256 + 16) * kLutCopies];
     constexpr int OUT_MAX = ((d + NROWS * (NROWS + 1) / 2 + 63) / 64) * 64;
     __shared__ __attribute__((aligned(16))) float s_out[4][OUT_MAX + 16];
 
@@ -255,10 +264,16 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
     if (blk_first >= blk_end) return;
     const int blk_n = (int)(blk_end - blk_first);
     const int n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
+    // (Round 6: the four blocks that share a CU started 1 / 2 / 3 us apart -- do their probe heads, which wait for memory, and
+    //  their consume loops, which issue, overlap better than in lock-step?  39.2 -> 40.1 / 41.3 / 43.4 us per batch: every
+    //  microsecond of stagger is a microsecond added.  A block's own chain -- head, then its four samples per wave -- is what the
+    //  launch waits for; tools/variants.sh st100@evs_mixed.)
 
     // ---- the tile: the block's 16 x T (address, class) pairs are one contiguous run of each array ----------------------
     for (int i = threadIdx.x; i < 512; i += blockDim.x) { s_ptr[i] = zc_p; s_cls[i] = 1; }
-    for (int i = threadIdx.x; i < 256 + 16; i += blockDim.x) s_lut[i] = i < 256 ? dec_u8((unsigned)i) : u4_value((unsigned)(i - 256));   // (no read of the __constant__ table: a memory round trip in the head)
+    for (int i = threadIdx.x; i < 256 + 16; i += blockDim.x) {   // (no read of the __constant__ table: a memory round trip in the head)
+        s_lut[i] = i < 256 ? dec_u8((unsigned)i) : u4_value((unsigned)(i - 256));
+    }
     // PROBE: per-table facts the probe indexes by LANE (a per-lane index into the kernel arguments is a vector-memory round
     // trip, and two of them behind a short-circuit && are two DEPENDENT ones in front of the set loads): rows both tiers'
     // tables have, dense row number of row 0 (set-associative tiers)
@@ -465,12 +480,12 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
             const int dest = c1_room[h] ? 1 : (agg < pa.threshold ? ((k & 1) ? 1 : 2) : 2);
             const unsigned char *src = nullptr;
             int codec_of = 0;
-            if (e1[h] >= 0) { src = pa.t1.arena + (long long)e1[h] * pa.t1.row_bytes; codec_of = 1; }
-            else if (e2[h] >= 0) { src = pa.t2.arena + (long long)e2[h] * pa.t2.row_bytes; codec_of = 2; }
-            else if (alt_tier[h] == 1) { src = pa.t1.arena + (long long)ea[h] * pa.t1.row_bytes; codec_of = 1; }
-            else if (alt_tier[h] == 2) { src = pa.t2.arena + (long long)ea[h] * pa.t2.row_bytes; codec_of = 2; }
-            else if (miss && dest == 1) { src = reinterpret_cast<const unsigned char *>((uintptr_t)s_back[k & 31]) + (long long)prow[h] * pa.t1.row_bytes; codec_of = 1; }
-            else if (miss) { src = reinterpret_cast<const unsigned char *>((uintptr_t)s_back[32 + (k & 31)]) + (long long)prow[h] * pa.t2.row_bytes; codec_of = 2; }
+            if (e1[h] >= 0) { src = pa.t1.arena + (long long)((unsigned long long)(unsigned)e1[h] * (unsigned long long)d); codec_of = 1; }
+            else if (e2[h] >= 0) { src = pa.t2.arena + (long long)((unsigned long long)(unsigned)e2[h] * (unsigned long long)RB2); codec_of = 2; }
+            else if (alt_tier[h] == 1) { src = pa.t1.arena + (long long)((unsigned long long)(unsigned)ea[h] * (unsigned long long)d); codec_of = 1; }
+            else if (alt_tier[h] == 2) { src = pa.t2.arena + (long long)((unsigned long long)(unsigned)ea[h] * (unsigned long long)RB2); codec_of = 2; }
+            else if (miss && dest == 1) { src = reinterpret_cast<const unsigned char *>((uintptr_t)s_back[k & 31]) + (long long)prow[h] * d; codec_of = 1; }
+            else if (miss) { src = reinterpret_cast<const unsigned char *>((uintptr_t)s_back[32 + (k & 31)]) + (long long)prow[h] * RB2; codec_of = 2; }
             if (pa.route_filter && miss && dest == 1 && (k & 1)) pa.route_filter[mix64(key[h]) & pa.route_mask] = pa.route_stamp;
             if (act[h]) {
                 const long long m = bs * (long long)T + k;
@@ -524,21 +539,51 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
     }
 
     constexpr int kOob = 0x7ffffff0;
+    // lane-invariant pieces of the flush and of the staging, computed ONCE (round 6, as evs_fused_rf.hip has had them since round
+    // 3: left to itself the compiler re-derives the flush offsets and the twelve accumulator offsets -- multiplies, compares,
+    // exec-mask regions, ~120 vector instructions -- for every sample: two thirds of this loop's vector work)
+    constexpr int NFL = (OUT_MAX + 255) / 256;
+    int fl_lds[NFL], fl_off[NFL], fl_tail_lds, fl_tail_off;
+    {
+        const int n4 = out_row >> 2;
+#pragma unroll
+        for (int h = 0; h < NFL; h++) {
+            const int e4 = lane + 64 * h;
+            fl_lds[h] = 16 * (e4 < n4 ? e4 : 0);
+            fl_off[h] = e4 < n4 ? 16 * e4 : kOob;
+            asm volatile("" : "+v"(fl_lds[h]), "+v"(fl_off[h]));
+        }
+        fl_tail_lds = 4 * (4 * n4 + (lane & 3));
+        fl_tail_off = lane < (out_row & 3) ? fl_tail_lds : kOob;
+        asm volatile("" : "+v"(fl_tail_lds), "+v"(fl_tail_off));
+    }
+    int zo00h[4], zo10h[4], zo11h[4], xv_offh;
+    {
+        const int dump0 = 4 * (OUT_MAX + r16);
+#pragma unroll
+        for (int vv = 0; vv < 4; vv++) {
+            const int i = 4 * q + vv;
+            zo00h[vv] = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump0;
+            const int gi = 16 + i;
+            const int base = (gi * (gi - 1 + 2 * itself)) / 2;
+            zo10h[vv] = (NT == 2 && gi < F) ? 4 * (d + base + r16) : dump0;
+            zo11h[vv] = (NT == 2 && gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump0;
+            asm volatile("" : "+v"(zo00h[vv]), "+v"(zo10h[vv]), "+v"(zo11h[vv]));
+        }
+        xv_offh = lane < d ? 4 * lane : dump0;
+        asm volatile("" : "+v"(xv_offh));
+    }
     auto flush_out = [&](long long bp, bool on) {
         float *Rb = args.R + (on ? bp : 0) * (long long)out_row;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Rb, 0, on ? out_row * 4 : 0, 0x00020000);
-        const int n4 = out_row >> 2;
 #pragma unroll
-        for (int h = 0; h < (OUT_MAX + 255) / 256; h++) {
-            const int e4 = lane + 64 * h;
-            const float4 v = reinterpret_cast<const float4 *>(my_out)[e4 < n4 ? e4 : 0];
+        for (int h = 0; h < NFL; h++) {
+            const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(my_out) + fl_lds[h]);
             u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(u, rs, e4 < n4 ? 16 * e4 : kOob, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, fl_off[h], 0, 2);
         }
-        {
-            const int e = 4 * n4 + (lane & 3);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(my_out[e]), rs, lane < (out_row & 3) ? 4 * e : kOob, 0, 2);
-        }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(*reinterpret_cast<const float *>(reinterpret_cast<const char *>(my_out) + fl_tail_lds)),
+                                              rs, fl_tail_off, 0, 2);
     };
 
     // ---- request the rows of all D samples of this wave -----------------------------------------------------------------
@@ -586,13 +631,23 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // one 4-element chunk: u8 -> bytes of w8, u4 -> nibbles of the low 16 bits of w4 (element 2j = the HIGH nibble of byte j)
-    auto dec = [&](unsigned w8, unsigned w4, bool c2) -> float4 {
-        const unsigned i0 = c2 ? 256u + ((w4 >> 4) & 15u) : (w8 & 255u);
-        const unsigned i1 = c2 ? 256u + (w4 & 15u) : ((w8 >> 8) & 255u);
-        const unsigned i2 = c2 ? 256u + ((w4 >> 12) & 15u) : ((w8 >> 16) & 255u);
-        const unsigned i3 = c2 ? 256u + ((w4 >> 8) & 15u) : (w8 >> 24);
-        return make_float4(s_lut[i0], s_lut[i1], s_lut[i2], s_lut[i3]);
+    // one 4-element chunk: u8 -> bytes of w8, u4 -> nibbles of the low 16 bits of w4 (element 2j = the HIGH nibble of byte j).
+    // Branch-free (round 6): written as `c2 ? index4 : index8` per element the compiler put every select behind an exec-mask
+    // region -- branches, s_and_saveexec / s_or pairs: 3.0 M scalar and 6.4 M vector wave-instructions per launch.  Here the
+    // four nibbles are spread into the four bytes of a word (two masks and a byte permute), the class picks the word by a
+    // bit mask (m: all ones for class 2) and the table base by the same mask, and an element is one bit-field extract and one
+    // shift-add.
+    constexpr unsigned lut_lane = 0u;
+    auto dec = [&](unsigned w8, unsigned w4, unsigned m) -> float4 {
+        const unsigned t0 = w4 & 0x0F0Fu, t1 = (w4 >> 4) & 0x0F0Fu;
+        const unsigned b4 = __builtin_amdgcn_perm(t0, t1, 0x05010400u);   // bytes: e0 = t1.b0, e1 = t0.b0, e2 = t1.b1, e3 = t0.b1
+        const unsigned w = (b4 & m) | (w8 & ~m);
+        const unsigned base = lut_lane + (m & kU4Base);
+        const char *lut = reinterpret_cast<const char *>(s_lut);
+        return make_float4(*reinterpret_cast<const float *>(lut + ((w & 255u) << kLutShift) + base),
+                           *reinterpret_cast<const float *>(lut + (((w >> 8) & 255u) << kLutShift) + base),
+                           *reinterpret_cast<const float *>(lut + (((w >> 16) & 255u) << kLutShift) + base),
+                           *reinterpret_cast<const float *>(lut + ((w >> 24) << kLutShift) + base));
     };
 
 #pragma unroll
@@ -602,7 +657,7 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
         float4 a[NR][NC];
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) {
-            const bool c2 = (cls2 >> (u * NR + rr)) & 1u;
+            const unsigned m2 = 0u - ((cls2 >> (u * NR + rr)) & 1u);   // all ones: the row is of class 2
             // class 2: the wanted W2 bytes, shifted down to bit 0 of a 32-bit word
             unsigned lo4;
             if constexpr (FOLD) {
@@ -610,20 +665,21 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
                 const unsigned w0 = rmain[u][rr][0], w1 = rmain[u][rr][1], w2 = rmain[u][rr][2];
                 lo4 = q < 2 ? w0 : __builtin_amdgcn_alignbit(q == 2 ? w1 : w2, q == 2 ? w0 : w1, 16);
                 // the tail: k-slot 3 holds it -- u8 bytes 32..35 = its third word, u4 bytes 16..17 = the top half of it
-                rrem[u][rr][0] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (48 + r16), (int)(c2 ? w2 >> 16 : w2));
+                rrem[u][rr][0] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (48 + r16), (int)(((w2 >> 16) & m2) | (w2 & ~m2)));
             } else
             if constexpr (WMdw == 2) lo4 = (unsigned)((((unsigned long long)rmain[u][rr][1] << 32) | rmain[u][rr][0]) >> sh2);
             else lo4 = rmain[u][rr][0] >> sh2;
 #pragma unroll
             for (int c = 0; c < CQ; c++) {
                 const unsigned w8 = rmain[u][rr][WMdw == 2 ? c : 0];
-                a[rr][c] = dec(w8, lo4 >> (16 * c), c2);
+                a[rr][c] = dec(w8, lo4 >> (16 * c), m2);
             }
             if constexpr (REM > 0) {   // k-slot q feeds only element q of the REM chunk to the matrix core
                 const unsigned w8 = rrem[u][rr][0], w4 = FOLD ? rrem[u][rr][0] : rrem[u][rr][0] >> rsh2;
                 const unsigned i8 = (w8 >> (8 * q)) & 255u;
-                const unsigned i4 = 256u + ((w4 >> (8 * (q >> 1) + ((q & 1) ? 0 : 4))) & 15u);
-                a[rr][CQ] = make_float4(s_lut[c2 ? i4 : i8], 0.f, 0.f, 0.f);
+                const unsigned i4 = (w4 >> (8 * (q >> 1) + ((q & 1) ? 0 : 4))) & 15u;
+                const unsigned ix = (i4 & m2) | (i8 & ~m2);
+                a[rr][CQ] = make_float4(*reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_lut) + (ix << kLutShift) + lut_lane + (m2 & kU4Base)), 0.f, 0.f, 0.f);
             }
         }
         {   // row 0 is x: plain fp32 chunks, spread through the wave's LDS slot
@@ -662,20 +718,13 @@ __global__ void __launch_bounds__(256, PROBE ? EVS_MIXED_LB_PROBE : 5) interact_
                 }
             }
         }
-        const int dump = 4 * (OUT_MAX + r16);
-        *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + (lane < d ? 4 * lane : dump)) = xv;
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + xv_offh) = xv;
 #pragma unroll
         for (int vv = 0; vv < 4; vv++) {
-            const int i = 4 * q + vv;
-            const int zo00 = (i < F && r16 < i + itself) ? 4 * (d + (i * (i - 1 + 2 * itself)) / 2 + r16) : dump;
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00) = c00[vv];
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo00h[vv]) = c00[vv];
             if constexpr (NT == 2) {
-                const int gi = 16 + i;
-                const int base = (gi * (gi - 1 + 2 * itself)) / 2;
-                const int zo10 = gi < F ? 4 * (d + base + r16) : dump;
-                const int zo11 = (gi < F && 16 + r16 < gi + itself) ? 4 * (d + base + 16 + r16) : dump;
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10) = c10[vv];
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11) = c11[vv];
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo10h[vv]) = c10[vv];
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(my_out) + zo11h[vv]) = c11[vv];
             }
         }
     }
