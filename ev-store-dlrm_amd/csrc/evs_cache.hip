@@ -52,8 +52,11 @@ struct CacheState {
 };
 
 struct CacheArrays {
+    // the map: open addressing, keys[slot] = key | entry << kMapEntryShift when the capacity fits 25 bits (`packed`: a probe is
+    // ONE dependent access instead of two -- round 6), the entry also in slot_entry[slot] (larger caches read it from there)
     unsigned long long *keys;
     int *slot_entry;
+    int packed;
     unsigned long long *ekey;
     int *eagg;        // EvLFU: priority bucket; LFU: unused (efreq used); LRU: 0
     long long *efreq; // LFU frequency
@@ -90,11 +93,18 @@ __device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOM
 template <typename T>
 __device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, EVS_EXACT_SCOPE); }
 
+// keys are (table_1based << 32) | row with table_1based <= kMaxTables = 64: 39 bits; an entry index of at most 25 bits rides above
+constexpr int kMapEntryShift = 39;
+constexpr unsigned long long kMapKeyMask = (1ull << kMapEntryShift) - 1ull;
+__device__ __forceinline__ unsigned long long map_word(const CacheArrays &a, unsigned long long key, int e) {
+    return a.packed ? (key | ((unsigned long long)(unsigned)e << kMapEntryShift)) : key;
+}
+__device__ __forceinline__ unsigned long long map_key(const CacheArrays &a, unsigned long long w) { return a.packed ? (w & kMapKeyMask) : w; }
 __device__ int map_find(const CacheArrays &a, unsigned long long mask, unsigned long long key, long long *empty_slot = nullptr) {
     unsigned long long i = mix64(key) & mask;
     for (;;) {
         const unsigned long long k = ld(&a.keys[i]);
-        if (k == key) return ld(&a.slot_entry[i]);
+        if (map_key(a, k) == key) return a.packed ? (int)(k >> kMapEntryShift) : ld(&a.slot_entry[i]);
         if (k == kEmpty) { if (empty_slot) *empty_slot = (long long)i; return -1; }   // (where an insert of this key would land)
         i = (i + 1) & mask;
     }
@@ -103,27 +113,27 @@ __device__ void map_put(const CacheArrays &a, unsigned long long mask, unsigned 
     unsigned long long i = mix64(key) & mask;
     for (;;) {
         const unsigned long long k = ld(&a.keys[i]);
-        if (k == kEmpty || k == key) break;
+        if (k == kEmpty || map_key(a, k) == key) break;
         i = (i + 1) & mask;
     }
     st(&a.slot_entry[i], e);
-    st(&a.keys[i], key);
+    st(&a.keys[i], map_word(a, key, e));
 }
 // linear-probing delete with backward shift (no tombstones: the table never degrades)
 __device__ void map_del(const CacheArrays &a, unsigned long long mask, unsigned long long key) {
     unsigned long long i = mix64(key) & mask;
     for (;;) {
         const unsigned long long k = ld(&a.keys[i]);
-        if (k == key) break;
+        if (map_key(a, k) == key) break;
         if (k == kEmpty) return;
         i = (i + 1) & mask;
     }
     unsigned long long j = i;
     for (;;) {
         j = (j + 1) & mask;
-        const unsigned long long kj = ld(&a.keys[j]);
+        const unsigned long long kj = ld(&a.keys[j]);   // (a packed word moves with its entry)
         if (kj == kEmpty) break;
-        const unsigned long long h = mix64(kj) & mask;
+        const unsigned long long h = mix64(map_key(a, kj)) & mask;
         const bool between = (i <= j) ? (h > i && h <= j) : (h > i || h <= j);
         if (!between) {
             st(&a.slot_entry[i], ld(&a.slot_entry[j]));
@@ -304,6 +314,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             hitp = args.hit + rq * T;
         }
         unsigned char my_flag = 0;      // this lane's table: the hit flag of the request in hand
+        bool churn = true;              // an insert of this request may have evicted / flushed entries (LRU / LFU: always assumed)
         if (lane < T) s_req[lane] = row;
         const unsigned long long key = ((unsigned long long)(lane + 1) << 32) | (unsigned)row;
         const bool row_ok = lane < T && row >= 0 && row < args.backing_rows[lane < T ? lane : 0];
@@ -333,8 +344,10 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             const int my_rank = __popcll(miss_mask & ((1ull << lane) - 1ull));
             const int n_free0 = h.n_free;
             const int pre_free = (my_miss && n_free0 - 1 - my_rank >= 0) ? a.free_stack[n_free0 - 1 - my_rank] : -1;
-            const int pre_prev = (e >= 0 && pre_agg < agg_hit) ? ld(&a.prev[e]) : -1;
-            const int pre_next = (e >= 0 && pre_agg < agg_hit) ? ld(&a.next[e]) : -1;
+            // (asked for with the key and the priority, not behind them: a hit that does not move has fetched two words for nothing,
+            //  one that moves has saved a dependent round trip -- round 6)
+            const int pre_prev = e >= 0 ? ld(&a.prev[e]) : -1;
+            const int pre_next = e >= 0 ? ld(&a.next[e]) : -1;
             bool slot_clash = false;   // an earlier miss of this request ended on the same empty slot
             for (int j = 0; j < T; j++) {
                 const long long sj = __shfl((int)(ins_slot & 0xffffffffll), j) | ((long long)__shfl((int)(ins_slot >> 32), j) << 32);
@@ -348,8 +361,21 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             if (pre_key != 12345ull || pre_agg != -7) return;
 #endif
             // ---- policy update, table order, one lane (EvLFU_C1.py:135-161) ----
+            // Round 6: lane 0 visits only the tables whose key CHANGES something -- a miss, or a hit whose priority rises.  A hit
+            // that stays where it is needs the loop for one thing only: an insert of this same request may have evicted its entry
+            // (:90-94).  That takes an eviction or a flush, and whether this request can cause one is known now: it inserts
+            // n_miss keys into count entries of cap, with n_perfect against max_perfect.  If it cannot, the hits that do not move
+            // are served by all lanes at once (their source is their entry) and the loop runs over the bits of `work`.
+            const int n_miss = __popcll(miss_mask);
+            const bool calm = !pick_random && (n_miss == 0 || (h.count + n_miss <= cs.cap && h.n_perfect < cs.max_perfect));
+            const bool moves = e >= 0 && pre_agg < agg_hit;
+            unsigned long long work = __ballot(lane < T && row_ok && (e < 0 || moves));
+            if (!calm) work = __ballot(lane < T && row_ok);
+            if (calm && e >= 0 && !moves && lane < T) s_src[lane] = e;
             int last_hit_table = -1;
-            for (int i = 0; i < T; i++) {
+            while (work) {
+                const int i = (int)__builtin_ctzll(work);
+                work &= work - 1ull;
                 const int ei = __shfl(e, i);
                 const unsigned long long ki = __shfl(key, i);
                 const bool oki = __shfl((int)row_ok, i) != 0;
@@ -394,7 +420,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                         st(&a.ekey[pfree], ki);
                         st(&a.eagg[pfree], agg_hit);
                         st(&a.slot_entry[pslot], pfree);
-                        st(&a.keys[pslot], ki);
+                        st(&a.keys[pslot], map_word(a, ki, pfree));
                         list_append(a, bucket(h, agg_hit), pfree);
                         h.count++;
                         if (agg_hit < h.min_c1) h.min_c1 = agg_hit;
@@ -409,6 +435,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                     s_src[i] = src; s_fill[i] = fill; s_from[i] = from;
                 }
             }
+            churn = __shfl((int)dirty, 0) != 0;
             if (lane == 0 && agg_hit == T) h.n_perfect = h.len[T];  // :163-165
             if (pick_random) my_hit = lane < T;                       // misses are reported as hits (:152)
             my_flag = my_hit ? 1 : 0;
@@ -525,11 +552,29 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             s_rowp[i] = rowp;
         }
         __syncthreads();
+        // Round 6: the rows of the NEW entries (table -> arena, below) are asked for here, with the rows that go out -- one round
+        // trip for both; their stores stay behind the out stream (an entry a later key of this request evicted and refilled may
+        // still be the source of an earlier hit's row).  16-byte aligned rows of at most 256 bytes; the rest below as before.
+        const int fill_i = lane < T ? lane : 0;
+        const int fill_e = lane < T ? s_fill[fill_i] : -1;
+        const unsigned char *fill_src = args.backing[fill_i] + (long long)s_req[fill_i] * rb;
+        unsigned char *fill_dst = a.arena + (long long)(fill_e >= 0 ? fill_e : 0) * rb;
+        const bool fill_early = fill_e >= 0 && rb <= 256 && ((rb | (int)(reinterpret_cast<uintptr_t>(fill_src) | reinterpret_cast<uintptr_t>(fill_dst))) & 15) == 0;
+        uint4 fill_r[16];
+        if (fill_early) {
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+                if (c * 16 < rb) fill_r[c] = *reinterpret_cast<const uint4 *>(fill_src + c * 16);
+        }
         // ... and the T*d elements leave as one flat, independent stream (not T dependent row trips)
         for (int idx = lane; idx < T * d; idx += 64) {
             const int i = idx / d, c = idx - i * d;
             const unsigned char *rowp = s_rowp[i];
-            out[idx] = rowp ? decode_elem(rowp, cs.codec, c) : 0.f;
+            const float v = rowp ? decode_elem(rowp, cs.codec, c) : 0.f;
+            // SERVE: written through (agent scope) -- the ring is read by launches that start while this kernel is still resident,
+            // and the alternative is a system-scope fence (an L2 write-back) per request
+            if constexpr (SERVE) __hip_atomic_store(out + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else out[idx] = v;
         }
         __syncthreads();
 #if EVS_X_EXACT_STOP == 4
@@ -537,12 +582,16 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
 #endif
         {   // every new entry's row, table -> arena: lane i moves table i's (one round trip for all of them; it was one key
             // check and one byte-wise row copy after the other)
-            const int i = lane < T ? lane : 0;
-            const int fe = lane < T ? s_fill[i] : -1;
-            // the entry may already have been evicted again by a later key of this request
+            const int i = fill_i;
+            const int fe = fill_e;
+            // the entry may already have been evicted again by a later key of this request (only if this request evicted at all)
             const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)s_req[i];
-            const bool mine = fe >= 0 && ld(&a.ekey[fe >= 0 ? fe : 0]) == ki;
-            if (mine) {
+            const bool mine = fe >= 0 && (!churn || ld(&a.ekey[fe >= 0 ? fe : 0]) == ki);
+            if (mine && fill_early) {
+#pragma unroll
+                for (int c = 0; c < 16; c++)
+                    if (c * 16 < rb) *reinterpret_cast<uint4 *>(fill_dst + c * 16) = fill_r[c];
+            } else if (mine) {
                 const unsigned char *rowp = args.backing[i] + (long long)s_req[i] * rb;
                 unsigned char *dst = a.arena + (long long)fe * rb;
                 if (((rb | (int)(reinterpret_cast<uintptr_t>(rowp) | reinterpret_cast<uintptr_t>(dst))) & 15) == 0) {
@@ -562,13 +611,20 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             served++;
             serve_seq++;
             if (lane < T) const_cast<volatile unsigned char *>(reinterpret_cast<volatile unsigned char *>(sv.ans))[lane] = my_flag;
-#if EVS_X_SERVE_FENCE == 1      // developer A/B (timing only): no fence at all
+            // (round 6: the ring rows were written THROUGH, agent scope; what is left to do before the sequence number goes out is to
+            //  wait for those stores and the flags -- a system-scope fence here was an L2 write-back per request)
+#if EVS_X_SERVE_FENCE == 1      // developer A/B: the round-5 form, a system-scope fence
+            __threadfence_system();
 #elif EVS_X_SERVE_FENCE == 2    // agent-scope fence
             __threadfence();
 #else
-            __threadfence_system();
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 #endif
+#if EVS_X_SERVE_FENCE == 0
+            if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 16, serve_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (behind the wait above; a release here would be the write-back again)
+#else
             if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 16, serve_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
         }
     }
 
@@ -2901,6 +2957,7 @@ extern "C" int evs_cache_create(evs_cache **out, int policy, int64_t capacity, i
     h.n_free = (int)capacity; h.least_freq = 1;
     for (int b = 0; b < kMaxBuckets; b++) { h.head[b] = -1; h.tail[b] = -1; h.len[b] = 0; }
     c->a.lfu_max_freq = policy == kLFU ? (1ll << 22) : 1;
+    c->a.packed = capacity <= (1ll << 25) ? 1 : 0;
     {
         SlabPlan sp;
         sp.add(&c->st, sizeof(CacheState));
