@@ -1156,8 +1156,34 @@ __device__ __forceinline__ unsigned srv_block_of(unsigned c, unsigned n_chunks, 
 }
 // the chunks of one batch that fall to block `me`, then the arrival: every wave waits for its stores of R (written through),
 // ONE atomic per block, and the block that completes the batch writes its number into the answer ring in host memory
+// a batch whose chunks this block has run but not yet reported: the report (srv_arrive) waits until the block's stores of R are
+// known to be complete -- which the worker learns for free from its NEXT poll (vector-memory operations complete in issue
+// order: a load that has returned has every earlier store of its wave behind it), so the drain of a batch's stores runs under
+// the poll for the next one instead of in front of it
+struct SrvPending { unsigned k, c0, step, n_chunks; };
+__device__ __forceinline__ void srv_arrive(const SrvArgs &sv, const SrvPending &p) {
+    const unsigned slot = p.k % (unsigned)kSrvSlots, n_chunks = p.n_chunks;
+    bool last = n_chunks == 1u;       // (a batch of one chunk: nobody else to wait for)
+    if (!last) {
+        unsigned tops = 0u;           // sub-counters this block completed
+        for (unsigned c = p.c0; c < n_chunks; c += p.step) {
+            const unsigned r = c & 31u, expect = (n_chunks >> 5) + (r < (n_chunks & 31u) ? 1u : 0u);
+            const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][r][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1u == expect) { tops++; __hip_atomic_store(&sv.st->arrived[slot][r][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // back to zero for the slot's next use
+        }
+        if (tops) {
+            const unsigned n_sub = n_chunks < 32u ? n_chunks : 32u;
+            const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][32][0], tops, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = before + tops == n_sub;
+            if (last) __hip_atomic_store(&sv.st->arrived[slot][32][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (last) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + slot * 16u, p.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the chunks of one batch that fall to block `me`; -> true: it ran some (pend says which: report them with srv_arrive once the
+// stores are known to be complete)
 template <int CQ, int REM, int NT>
-__device__ __forceinline__ void srv_run_batch(const SrvArgs &sv, const FusedArgs &la, const unsigned (&w)[16], unsigned k, unsigned me, unsigned G, bool &first) {
+__device__ __forceinline__ bool srv_run_batch(const SrvArgs &sv, const FusedArgs &la, const unsigned (&w)[16], unsigned k, unsigned me, unsigned G, bool &first, SrvPending &pend) {
     RfServeDesc sd;
     sd.x = reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)w[1] << 32) | w[0]));
     sd.idx = reinterpret_cast<const int64_t *>((uintptr_t)(((unsigned long long)w[3] << 32) | w[2]));
@@ -1165,10 +1191,9 @@ __device__ __forceinline__ void srv_run_batch(const SrvArgs &sv, const FusedArgs
     sd.R = reinterpret_cast<float *>((uintptr_t)(((unsigned long long)w[9] << 32) | w[8]));
     sd.B = (int64_t)w[6]; sd.x_stride = (int64_t)w[10]; sd.idx_stride = (int64_t)w[12]; sd.off_stride = (int64_t)w[13];
     const unsigned n_chunks = (w[6] + 15u) >> 4;
-    const unsigned slot = k % (unsigned)kSrvSlots;
     unsigned c0, step;
     if (n_chunks >= G) { c0 = (me + G - w[11] % G) % G; step = G; }
-    else { if (me == 0u) return; c0 = (me - 1u + (G - 1u) - w[11] % (G - 1u)) % (G - 1u); step = G - 1u; }
+    else { if (me == 0u) return false; c0 = (me - 1u + (G - 1u) - w[11] % (G - 1u)) % (G - 1u); step = G - 1u; }
     unsigned mine = 0u;
     for (unsigned c = c0; c < n_chunks; c += step) {
         rf_body<CQ, REM, NT, EVS_RF_DEPTH, false, false, false, true, true>(la, sv.tmpl, sd, (int)c, first);
@@ -1176,28 +1201,8 @@ __device__ __forceinline__ void srv_run_batch(const SrvArgs &sv, const FusedArgs
         mine++;
         __syncthreads();
     }
-    if (mine) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores of R have been written through
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            bool last = n_chunks == 1u;       // (a batch of one chunk: nobody else to wait for)
-            if (!last) {
-                unsigned tops = 0u;           // sub-counters this block completed
-                for (unsigned c = c0; c < n_chunks; c += step) {
-                    const unsigned r = c & 31u, expect = (n_chunks >> 5) + (r < (n_chunks & 31u) ? 1u : 0u);
-                    const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][r][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (before + 1u == expect) { tops++; __hip_atomic_store(&sv.st->arrived[slot][r][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // back to zero for the slot's next use
-                }
-                if (tops) {
-                    const unsigned n_sub = n_chunks < 32u ? n_chunks : 32u;
-                    const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][32][0], tops, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    last = before + tops == n_sub;
-                    if (last) __hip_atomic_store(&sv.st->arrived[slot][32][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            if (last) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + slot * 16u, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    pend.k = k; pend.c0 = c0; pend.step = step; pend.n_chunks = n_chunks;
+    return mine != 0u;
 }
 
 template <int CQ, int REM, int NT>
@@ -1218,6 +1223,8 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
     __shared__ unsigned s_line[66];
     const unsigned *my_line = &st->pub[me % (unsigned)kSrvReplicas][0];
     unsigned my = sv.start_seq;      // the last batch this block has looked at
+    SrvPending pend{0u, 0u, 1u, 0u};
+    bool have_pend = false;          // (block-uniform) chunks run, their stores possibly still on their way, not yet reported
     if (me == 0u && threadIdx.x == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // alive
     for (;;) {
         if (threadIdx.x < 64) {
@@ -1226,6 +1233,7 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
                 const long long t0 = (long long)wall_clock64();
                 int n_new = 0;
                 unsigned word = 0u;
+                bool pend_only = false;
                 for (;;) {
                     // the next four ring slots in one load: lane = 16 * (slot in the group) + word
                     const unsigned slot0 = (my + 1u) % (unsigned)kSrvSlots;
@@ -1252,12 +1260,13 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
                         if (lane < kSrvReplicas) __hip_atomic_store(&st->pub[lane][0], my + (unsigned)n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
+                    if (have_pend) { pend_only = true; break; }   // nothing new, but chunks to report: the load above has returned, so have this wave's stores
                     const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (stop != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
                 s_line[lane] = word;
-                if (lane == 0) { s_line[64] = (unsigned)n_new; s_line[65] = n_new == 0 ? 1u : 0u; }
+                if (lane == 0) { s_line[64] = (unsigned)n_new; s_line[65] = (n_new == 0 && !pend_only) ? 1u : 0u; }
             } else {
                 // ---------------- a worker: the whole replica line in one 32-lane load ----------------
                 unsigned v, sq, gn;
@@ -1265,13 +1274,17 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
                     v = __hip_atomic_load(my_line + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sq = (unsigned)__shfl((int)v, 0); gn = (unsigned)__shfl((int)v, 1);
                     if (sq != my || gn == sv.gen) break;
+                    if (have_pend) break;     // nothing new, but chunks to report: the load above has returned, so have this wave's stores
                     __builtin_amdgcn_s_sleep((EVS_X_SRV & 4) ? 16 : 1);
                 }
                 if (lane >= 2 && lane < 18) s_line[lane - 2] = v;
                 if (lane == 0) { s_line[64] = sq - my; s_line[65] = gn == sv.gen ? 1u : 0u; }
             }
         }
+        // (waves 1..3: nothing to poll for, their stores of the batch before drain meanwhile; wave 0's poll has returned: so have its stores)
+        if (have_pend && threadIdx.x >= 64) __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        if (have_pend) { if (threadIdx.x == 0) srv_arrive(sv, pend); have_pend = false; }
         const unsigned n_look = s_line[64], leave = s_line[65];
         for (unsigned g = 0; g < n_look; g++) {
             const unsigned k = my + 1u + g;
@@ -1292,16 +1305,28 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
                 for (int tries = 0; tries < (1 << 20); tries++) {
 #pragma unroll
                     for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    const unsigned g2 = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (w[7] == k && w[15] == k && g2 == k) { have = true; break; }
-                    if ((int)(w[7] - k) > 0 || (int)(w[15] - k) > 0 || (int)(g2 - k) > 0) break;    // overwritten by a later batch
+                    if (w[7] == k && w[15] == k) { have = true; break; }     // (the leader writes a descriptor as ONE 64-byte store)
+                    if ((int)(w[7] - k) > 0 || (int)(w[15] - k) > 0) break;    // overwritten by a later batch
                 }
             }
-            if (have) srv_run_batch<CQ, REM, NT>(sv, la, w, k, me, G, first);
+            if (have) {
+                if (have_pend) {   // a second batch inside one look: the first one's stores are waited for in place (rare: a burst)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    __syncthreads();
+                    if (threadIdx.x == 0) srv_arrive(sv, pend);
+                    have_pend = false;
+                }
+                have_pend = srv_run_batch<CQ, REM, NT>(sv, la, w, k, me, G, first, pend);
+            }
         }
         my += n_look;
         __syncthreads();
         if (leave) break;
+    }
+    if (have_pend) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (threadIdx.x == 0) srv_arrive(sv, pend);
     }
     if (me == 0u) {
         // leaving: every worker sees the stop word behind the last number; the host learns how far the grid got
