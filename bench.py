@@ -133,7 +133,7 @@ def mixed_tiers_section(ev, ln_emb, d, B, dev, fill=180, steps=80, alpha=0.75):
     tier_bytes = B * (T * (d * 3 // 4 + 8 + 2 * 12) + 4 * d + 4 * (d + F * (F - 1) // 2))
     traffic = None
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("mixed_tiers_r04_B%d_d%d" % (B, d), {}).get("per_batch")
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("mixed_tiers_r06_B%d_d%d" % (B, d), {}).get("per_batch")
     except Exception:
         traffic = None
     out["roofline"] = {"bound": "hbm", "kernel": "the two-tier batch's launch chain: interact_mixed84_kernel<2,1,2,true> (both tiers' set probes + mixed-precision "
