@@ -49,6 +49,12 @@ struct FusedArgs {
     // evs_fused_rf.hip, K batches in ONE launch (evs_emb_interact_dot_stacked_multi): block i works on chunk i % multi_cpb of
     // batch i / multi_cpb -- feature 0 (x), the (T, B) index / offsets arrays and R of that batch come from these tables,
     // everything else (tables, shapes) is shared.  multi_n == 0: a plain launch.
+    // evs_fused_rf.hip, the stacked call (x + T tables behind ONE (T, B) index array and, lS_o given, one (T, B) offsets array: what
+    // evs_emb_interact_dot_stacked passes): feature f >= 1 reads indices at stk_idx + (f - 1) * stk_idx_stride -- arithmetic instead
+    // of a read of indices[f] / offsets[f] out of the kernel arguments in front of the first index load.  stk == 0: not that form.
+    int stk = 0;
+    const int64_t *stk_idx = nullptr, *stk_off = nullptr;
+    int64_t stk_idx_stride = 0, stk_off_stride = 0, stk_off_len = 0;
     int multi_n = 0, multi_cpb = 0;
     int64_t multi_idx_stride, multi_off_stride;   // elements between the rows of two tables in a batch's (T, B) arrays
     const float *multi_x[kMultiMax];

@@ -1486,6 +1486,24 @@ extern "C" int evs_emb_interact_dot(int64_t B, int F, int d, int codec, const ev
             a.bag1 = 2;
         }
     }
+    // the stacked form (evs_emb_interact_dot_stacked: x + T tables behind ONE (T, B) index array and, lS_o given, one offsets array):
+    // the rows-in-registers kernel then computes every feature's index / offsets address itself and asks for them before it
+    // reads its feature table out of the kernel arguments (FusedArgs::stk)
+    a.stk = 0;
+    static const bool stk_on = !(getenv("EVS_FUSED_STK") && getenv("EVS_FUSED_STK")[0] == '0');   // developer A/B
+    if (stk_on && indirect && !weighted && codec == 32 && F >= 2 && !feats[0].indices && (a.bag1 == 1 || a.bag1 == 3)) {
+        bool yes = feats[1].indices != nullptr;
+        const int64_t si = F > 2 && feats[2].indices ? feats[2].indices - feats[1].indices : 0;
+        const int64_t so = F > 2 && feats[1].offsets && feats[2].offsets ? feats[2].offsets - feats[1].offsets : 0;
+        for (int f = 1; f < F && yes; f++) {
+            yes = feats[f].indices == feats[1].indices + (int64_t)(f - 1) * si && feats[f].nnz == feats[1].nnz && a.off_len[f] == a.off_len[1] &&
+                  ((a.bag1 == 1 && !feats[f].offsets) || (a.bag1 == 3 && feats[f].offsets && feats[f].offsets == feats[1].offsets + (int64_t)(f - 1) * so));
+        }
+        if (yes) {
+            a.stk = 1; a.stk_idx = feats[1].indices; a.stk_idx_stride = si;
+            a.stk_off = a.bag1 == 3 ? feats[1].offsets : nullptr; a.stk_off_stride = a.bag1 == 3 ? so : 0; a.stk_off_len = a.off_len[1];
+        }
+    }
     bool ok;
     if (!indirect) {
         ok = launch_cpq<32, false, false>(a, st);

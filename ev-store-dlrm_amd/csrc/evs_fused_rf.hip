@@ -162,6 +162,46 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
     if (blk_first >= blk_end) return;       // block-uniform
     const int blk_n = (int)(blk_end - blk_first);
     const int n_samples = blk_n > wave_in_block ? (blk_n - wave_in_block + 3) / 4 : 0;
+    // Round 6: the stacked form of the call (FusedArgs::stk, and every batch of the resident dispatcher) -- its index / offsets
+    // loads need nothing of the feature table below, so they go out FIRST and the table's round trip to the kernel arguments
+    // runs under them: one dependent round trip less in the head of every block.
+    const bool stk = SERVE || (!MLP && !IDS && !PROBE && args.stk != 0 && args.multi_n == 0);
+    const int64_t *const stk_idx = SERVE ? sd.idx : args.stk_idx, *const stk_off = SERVE ? sd.off : args.stk_off;
+    const int64_t stk_istride = SERVE ? sd.idx_stride : args.stk_idx_stride, stk_ostride = SERVE ? sd.off_stride : args.stk_off_stride;
+    const int64_t stk_ol = SERVE ? sd.B : args.stk_off_len;
+    // ---- index tiles: thread e (and e + 256) owns tile element (feature e >> 4, sample-in-chunk e & 15) ----
+    bool bad = false, my_ragged = false;
+    bool oob[2] = {false, false};
+    int64_t tile_v[2] = {-1, -1};
+    int64_t tile_o0[2] = {0, 0}, tile_o1[2] = {0, 0};   // CHECK: offsets[b] and where bag b ends
+    const int64_t *dummy_i = args.dummy_i64;   // any readable int64 (lanes with nothing to load read it)
+    auto tile_load = [&](int c) {       // chunk c of the block -> registers; no branch, no use of the value before tile_store
+        const int64_t bs = blk_first + 16 * (int64_t)c + (tid_x & 15);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = ((int)tid_x >> 4) + 16 * h;
+            // (stk: x + tables behind ONE (T, B) index array -- the Criteo collate's -- whose rows are at a fixed stride: the address is
+            //  arithmetic, nothing of the block's feature table is needed, and the loads leave BEFORE that table is read)
+            const bool table = (stk ? (f >= 1 && f < F) : s_tile_kind[f] == 2) && bs < blk_end;
+            if constexpr (IDS) {
+                const int *ap = table ? args.row_ids + bs * (int64_t)(F - 1) + (f - 1) : reinterpret_cast<const int *>(dummy_i);
+                tile_v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(ap));
+            } else {
+                const int64_t *ap = table ? (stk ? stk_idx + (int64_t)(f - 1) * stk_istride : s_tile_p[f]) + bs : dummy_i;
+                // (explicitly global: a flat load would force every later wait to vmcnt(0))
+                tile_v[h] = rf_ld_i64<SERVE>(ap);
+            }
+            if constexpr (CHECK) {
+                const int64_t *op = stk ? stk_off + (int64_t)(f - 1) * stk_ostride : s_tile_o[f];
+                const bool own = table && ((tid_x & 15) == 15 || bs + 1 >= blk_end);
+                const int64_t *p0 = table ? op + bs : dummy_i;
+                const int64_t *p1 = (own && bs + 1 < (stk ? stk_ol : s_tile_ol[f])) ? op + bs + 1 : dummy_i;
+                tile_o0[h] = rf_ld_i64<SERVE>(p0);
+                tile_o1[h] = rf_ld_i64<SERVE>(p1);
+            }
+        }
+    };
+    if constexpr (!PROBE) { if (stk) tile_load(0); }
     if (tid_x < 32) {
         // branch-free on purpose: every FusedArgs array has EVS_MAX_FEATURES = 32 entries (those past F are NULL / 0), so
         // lane f reads entry f of each of them UNCONDITIONALLY -- all the loads leave together, one round trip -- and the
@@ -294,36 +334,6 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
 
 #endif
 
-    // ---- index tiles: thread e (and e + 256) owns tile element (feature e >> 4, sample-in-chunk e & 15) ----
-    bool bad = false, my_ragged = false;
-    bool oob[2] = {false, false};
-    int64_t tile_v[2] = {-1, -1};
-    int64_t tile_o0[2] = {0, 0}, tile_o1[2] = {0, 0};   // CHECK: offsets[b] and where bag b ends
-    const int64_t *dummy_i = args.dummy_i64;   // any readable int64 (lanes with nothing to load read it)
-    auto tile_load = [&](int c) {       // chunk c of the block -> registers; no branch, no use of the value before tile_store
-        const int64_t bs = blk_first + 16 * (int64_t)c + (tid_x & 15);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int f = ((int)tid_x >> 4) + 16 * h;
-            const bool table = s_tile_kind[f] == 2 && bs < blk_end;
-            if constexpr (IDS) {
-                const int *ap = table ? args.row_ids + bs * (int64_t)(F - 1) + (f - 1) : reinterpret_cast<const int *>(dummy_i);
-                tile_v[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(ap));
-            } else {
-                const int64_t *ap = table ? s_tile_p[f] + bs : dummy_i;
-                // (explicitly global: a flat load would force every later wait to vmcnt(0))
-                tile_v[h] = rf_ld_i64<SERVE>(ap);
-            }
-            if constexpr (CHECK) {
-                const int64_t *op = s_tile_o[f];
-                const bool own = table && ((tid_x & 15) == 15 || bs + 1 >= blk_end);
-                const int64_t *p0 = table ? op + bs : dummy_i;
-                const int64_t *p1 = (own && bs + 1 < s_tile_ol[f]) ? op + bs + 1 : dummy_i;
-                tile_o0[h] = rf_ld_i64<SERVE>(p0);
-                tile_o1[h] = rf_ld_i64<SERVE>(p1);
-            }
-        }
-    };
     auto tile_store = [&](int c) {      // registers -> tile buffer c & 1
         const int64_t bs = blk_first + 16 * (int64_t)c + (tid_x & 15);
 #pragma unroll
@@ -729,7 +739,7 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
         }
         if (pa.list_cnt != nullptr && tid_x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
     } else {
-        tile_load(0);
+        if (!stk) tile_load(0);
         tile_store(0);
         if constexpr (CHECK) {
             verify();
