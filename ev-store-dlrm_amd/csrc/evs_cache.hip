@@ -289,22 +289,31 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
         unsigned char *hitp;
         if constexpr (SERVE) {
             // ---- wait for the next request: the whole line in one load (lane = word), both guards = the number awaited ----
-            const unsigned want = serve_seq + 1u;
+            const unsigned want = (serve_seq + 1u) & 0x7fffffffu;
             const long long t0 = (long long)wall_clock64();
             unsigned word = 0u;
             bool leave = false;
             for (;;) {
                 word = __hip_atomic_load(const_cast<unsigned *>(sv.req) + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                // words 7, 15, 23, 31: one guard per 32-byte sector
-                if ((__ballot(word == want) & 0x80808080ull) == 0x80808080ull) break;
+                // words 7, 15, 23, 31: one guard per 32-byte sector (bit 31 of a guard: the ids are given by ADDRESS, below)
+                if ((__ballot((word & 0x7fffffffu) == want) & 0x80808080ull) == 0x80808080ull) break;
                 const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (stop != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) { leave = true; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
             if (leave) break;
-            // id of table t: word t + t / 7 (seven ids, then the sector's guard)
+            // id of table t: word t + t / 7 (seven ids, then the sector's guard) ...
             const int src_lane = lane + lane / 7;
             row = __shfl((int)word, src_lane & 31);
+            // ... or, round 6 (evs_cache_serve_request_dev: the reference's loop has the ids on the DEVICE -- dlrm_wrap moved lS_i
+            // there -- and fetching them back costs the plug-in a copy and a synchronise per request): words 0..2 = the address of
+            // table 0's first index and the elements between two tables' rows; one agent-scope load per lane
+            if (((unsigned)__shfl((int)word, 7) >> 31) != 0u) {
+                const unsigned long long pa = ((unsigned long long)(unsigned)__shfl((int)word, 1) << 32) | (unsigned)__shfl((int)word, 0);
+                const long long stride = (long long)(unsigned)__shfl((int)word, 2);
+                const long long *ip = reinterpret_cast<const long long *>((uintptr_t)pa) + (long long)(lane < T ? lane : 0) * stride;
+                row = (int)__hip_atomic_load(ip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (lane >= T) row = 0;
             out = sv.ring + (long long)(want % (unsigned)sv.n_slots) * T * d;
             hitp = nullptr;   // (flags go to the answer line, below)
@@ -609,7 +618,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             // ---- the answer: hit flags, then (behind a fence that also puts the ring rows where every later launch sees
             // them) the sequence number the host is polling for ----
             served++;
-            serve_seq++;
+            serve_seq = (serve_seq + 1u) & 0x7fffffffu;
             if (lane < T) const_cast<volatile unsigned char *>(reinterpret_cast<volatile unsigned char *>(sv.ans))[lane] = my_flag;
             // (round 6: the ring rows were written THROUGH, agent scope; what is left to do before the sequence number goes out is to
             //  wait for those stores and the flags -- a system-scope fence here was an L2 write-back per request)
@@ -3156,13 +3165,26 @@ extern "C" int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring
 }
 // one request (T row ids on the host) -> T hit flags on the host, the T x d fp32 rows in slot *slot_out of the ring (device).
 // Blocks until the server has answered (no launch, no copy, no synchronise: two cache-line hand-overs over the bus).
+static int serve_request_impl(evs_cache *c, const int32_t *rows, const int64_t *ids_dev, int64_t ids_stride, uint8_t *hit, int *slot_out);
 extern "C" int evs_cache_serve_request(evs_cache *c, const int32_t *rows, uint8_t *hit, int *slot_out) {
     using namespace evs;
     EVS_REQUIRE(c && rows && hit && slot_out, "evs_cache_serve_request: NULL argument");
+    return serve_request_impl(c, rows, nullptr, 0, hit, slot_out);
+}
+// the same request with the T row ids given by ADDRESS: ids_dev[t * ids_stride] (int64, device memory: the (T, B) lS_i of the
+// reference's loop as dlrm_wrap left it on the device, element 0 of each row, dlrm_s_pytorch_C1.py:236-239) -- the server reads
+// them itself.  The ids must be COMPLETE when this is called (no stream orders the mailbox).
+extern "C" int evs_cache_serve_request_dev(evs_cache *c, const int64_t *ids_dev, int64_t ids_stride, uint8_t *hit, int *slot_out) {
+    using namespace evs;
+    EVS_REQUIRE(c && ids_dev && hit && slot_out && ids_stride >= 0 && ids_stride < (1ll << 32), "evs_cache_serve_request_dev: bad argument");
+    return serve_request_impl(c, nullptr, ids_dev, ids_stride, hit, slot_out);
+}
+static int serve_request_impl(evs_cache *c, const int32_t *rows, const int64_t *ids_dev, int64_t ids_stride, uint8_t *hit, int *slot_out) {
+    using namespace evs;
     if (!c->serving) { set_error("evs_cache_serve_request: call evs_cache_serve_start first"); return EVS_ESTATE; }
     volatile unsigned *req = c->mbox, *ans = c->mbox + 64;
     const int T = c->host.n_tables;
-    const unsigned want = c->serve_seq + 1u;
+    const unsigned want = (c->serve_seq + 1u) & 0x7fffffffu;
     // the ring slot this request's rows go to: whoever still READS it (evs_cache_serve_consumed) finishes first
     const int slot = (int)(want % (unsigned)c->serve_slots);
     if (c->slot_busy[(size_t)slot]) {
@@ -3172,9 +3194,16 @@ extern "C" int evs_cache_serve_request(evs_cache *c, const int32_t *rows, uint8_
     c->serve_seq = want;
     // seven ids and a guard per 32-byte sector: whatever granularity the bus delivers the line in, ids are accepted only from
     // a sector whose guard (written after them) holds the number awaited
-    for (int t = 0; t < T; t++) req[t + t / 7] = (unsigned)rows[t];
+    unsigned guard = want;
+    if (rows) {
+        for (int t = 0; t < T; t++) req[t + t / 7] = (unsigned)rows[t];
+    } else {   // by address: words 0..2, and bit 31 of the guards says so
+        const unsigned long long pa = (unsigned long long)reinterpret_cast<uintptr_t>(ids_dev);
+        req[0] = (unsigned)pa; req[1] = (unsigned)(pa >> 32); req[2] = (unsigned)ids_stride;
+        guard |= 0x80000000u;
+    }
     __atomic_thread_fence(__ATOMIC_RELEASE);
-    req[7] = want; req[15] = want; req[23] = want; req[31] = want;
+    req[7] = guard; req[15] = guard; req[23] = guard; req[31] = guard;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     long long spins = 0;
     // a request that fails leaves host and device agreeing on the sequence number: the one the device last ANSWERED

@@ -322,11 +322,20 @@ static void first_ids(const at::Tensor &lS_i_in, int T, int32_t (&ids)[64]) {
 // the same body for the GPU engine's resident server (evs_cache_serve_*): the ids as above, the request through the mailbox, the
 // rows of the answer's ring slot (HBM) copied once into a fresh block and handed out as its 26 views
 py::tuple serve_request_list(int64_t handle, const at::Tensor &lS_i_in, const at::Tensor &ring, int T, int d) {
-    int32_t ids[64];
-    first_ids(lS_i_in, T, ids);
     uint8_t hit[64];
     int slot = 0;
-    check(evs_cache_serve_request(reinterpret_cast<evs_cache *>(handle), ids, hit, &slot));
+    if (lS_i_in.is_cuda() && lS_i_in.scalar_type() == at::kLong && lS_i_in.dim() >= 1 && lS_i_in.size(0) == T && lS_i_in.numel() >= T &&
+        lS_i_in.device() == ring.device()) {
+        // the ids stay where dlrm_wrap put them: the server reads element 0 of each row by address (no copy back, no staging).
+        // Whatever wrote lS_i ran on this stream: it has to have finished (the reference's own copies from pageable memory have)
+        hipStream_t st = c10::hip::getCurrentHIPStream(lS_i_in.device().index()).stream();
+        if (hipStreamQuery(st) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); }
+        check(evs_cache_serve_request_dev(reinterpret_cast<evs_cache *>(handle), lS_i_in.data_ptr<int64_t>(), lS_i_in.stride(0), hit, &slot));
+    } else {
+        int32_t ids[64];
+        first_ids(lS_i_in, T, ids);
+        check(evs_cache_serve_request(reinterpret_cast<evs_cache *>(handle), ids, hit, &slot));
+    }
     TORCH_CHECK(ring.dim() == 3 && slot >= 0 && slot < ring.size(0) && ring.size(1) == T && ring.size(2) == d, "ring slot out of range");
     c10::hip::HIPGuard guard(ring.device().index());
     at::Tensor block = ring.select(0, slot).clone().unsqueeze(1);

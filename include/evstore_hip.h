@@ -375,6 +375,11 @@ EVS_API int evs_cache_request_c1c2(evs_cache *c1, evs_cache *c2, int64_t B, cons
  * EVS_ESTATE for a cache on the batched path. */
 EVS_API int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring, int n_slots, int64_t idle_us);
 EVS_API int evs_cache_serve_request(evs_cache *c, const int32_t *rows_host, uint8_t *hit_host, int *slot_out);
+/* ... with the T ids given by ADDRESS (round 6): ids_dev[t * ids_stride], int64 in device memory -- element 0 of each row of the
+ * (T, B) lS_i the reference's loop has moved to the GPU (dlrm_wrap, dlrm_s_pytorch.py:131-147; apply_emb_evstore then takes it back
+ * with lS_i.cpu(), dlrm_s_pytorch_C1.py:233-239: a copy and a synchronise per request).  The server reads the ids itself; they
+ * must be complete when the call is made. */
+EVS_API int evs_cache_serve_request_dev(evs_cache *c, const int64_t *ids_dev, int64_t ids_stride, uint8_t *hit_host, int *slot_out);
 EVS_API int evs_cache_serve_consumed(evs_cache *c, int slot, void *stream);
 EVS_API int evs_cache_serve_stop(evs_cache *c);
 /* Batched EvLFU lookup with snapshot semantics (the throughput path; no reference counterpart --
