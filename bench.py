@@ -1087,11 +1087,12 @@ def main():
                          "interaction, or p2p: no collective call -- the pooling kernel writes every peer's block straight into that peer's "
                          "IPC-mapped receive buffer, two flag words per (peer, slot) hand it over (csrc/evs_p2p.hip); auto: p2p when ONE batch through both "
                          "exchanges gave bit-equal receive buffers on every rank (sharded.verify_p2p_against_collective), the RCCL collective otherwise")
-    ap.add_argument("--overlap", action="store_true",
+    ap.add_argument("--overlap", nargs="?", const="events", default=False, choices=["events", "signals"],
                     help="N>1: pool(i + 1) + its exchange on a side stream under the interaction of batch i, two event hand-overs per step "
-                         "(direct exchange / no exchange only).  OFF by default: measured on one rank with the exchange forced, 149 us per step "
-                         "against 40.5 in stream order (33.6 against 24.7 without an exchange) -- a cross-stream event wait costs tens of "
-                         "microseconds on this stack, far more than the 13 us of exchange it could hide")
+                         "(direct exchange / no exchange only); `--overlap signals`: the hand-overs as stream wait-value / write-value words instead of "
+                         "events.  OFF by default: measured on one rank with the exchange forced, 149 us (events) / 160 us (signals) per step "
+                         "against 40.7 in stream order, 33.6 / 28.5 against 24.7 without an exchange -- cross-stream hand-overs cost far more "
+                         "on this stack than the 13 us of exchange they could hide")
     ap.add_argument("--force-exchange", action="store_true", help="with --force-sharded on one rank: issue the RCCL all_to_all_single anyway "
                                                                   "(a self-exchange into a separate receive buffer: what the collective call itself costs per step)")
     ap.add_argument("--shape", default="kaggle", choices=["kaggle", "terabyte"],

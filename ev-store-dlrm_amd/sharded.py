@@ -685,7 +685,12 @@ class ShardedEmbeddingInteract:
             # its exchange on a stream of their own under the interaction of batch i.  Two hand-overs per step: this slot's
             # buffers are free once the interaction that read them last has run; the interaction waits for this exchange.
             side, slot = ov["side"], pl["slot"]
-            side.wait_event(ov["free"][slot])
+            L = _lib.lib()
+            if ov["sig"] is not None:   # hand-overs as signal words of the command processors (evs_stream_wait_value: >=)
+                if ov["n_free"][slot]:
+                    _lib.check(L.evs_stream_wait_value(side.cuda_stream, ov["sig"][slot][1], ov["n_free"][slot]))
+            else:
+                side.wait_event(ov["free"][slot])
             self.backend.stream = side.cuda_stream
             try:
                 self._pool_into(pl["send"], pl["Bg"], pl["lo"], pl["li"], planned=True, lo_split=pl["lo_split"], li_split=pl["li_split"])
@@ -694,7 +699,11 @@ class ShardedEmbeddingInteract:
                         self._exchange(pl["recv"], pl["send"].view(-1), pl["out"], pl["in"])
             finally:
                 self.backend.stream = None
-            ov["ready"][slot].record(side)
+            if ov["sig"] is not None:
+                ov["n_ready"][slot] += 1
+                _lib.check(L.evs_stream_write_value(side.cuda_stream, ov["sig"][slot][0], ov["n_ready"][slot]))
+            else:
+                ov["ready"][slot].record(side)
             return ("overlap", slot)
         if tr is not None:
             tr["pool"].append(self._stamp())
@@ -779,11 +788,25 @@ class ShardedEmbeddingInteract:
             dev = self.backend.device
             side = torch.cuda.Stream(device=dev)
             cur = torch.cuda.current_stream(dev)
-            ev = {"side": side, "ready": [torch.cuda.Event() for _ in range(2)], "free": [torch.cuda.Event() for _ in range(2)]}
+            ev = {"side": side, "ready": [torch.cuda.Event() for _ in range(2)], "free": [torch.cuda.Event() for _ in range(2)],
+                  "sig": None, "n_ready": [0, 0], "n_free": [0, 0]}
             for e in ev["ready"]:
                 e.record(side)     # (torch creates the HIP event at the first record: here, not inside a timed step)
             for e in ev["free"]:
                 e.record(cur)
+            if self.overlap == "signals":   # two signal words per slot: [ready, free] (8 bytes of signal memory each)
+                import ctypes as C_
+                sig = []
+                try:
+                    with torch.cuda.device(dev):
+                        for _ in range(2):
+                            a, b = C_.c_void_p(), C_.c_void_p()
+                            _lib.check(_lib.lib().evs_signal_alloc(C_.byref(a)))
+                            _lib.check(_lib.lib().evs_signal_alloc(C_.byref(b)))
+                            sig.append((a, b))
+                    ev["sig"] = sig
+                except Exception:
+                    ev["sig"] = None   # (no stream wait-value operations on this device: events)
             self._ov = ev
         return self._ov
 
@@ -793,7 +816,10 @@ class ShardedEmbeddingInteract:
         ov_slot = None
         if isinstance(work, tuple) and work and work[0] == "overlap":
             ov_slot, work = work[1], None
-            torch.cuda.current_stream(self.backend.device).wait_event(self._ov["ready"][ov_slot])
+            if self._ov["sig"] is not None:
+                _lib.check(_lib.lib().evs_stream_wait_value(_stream_ptr(self.backend.device), self._ov["sig"][ov_slot][0], self._ov["n_ready"][ov_slot]))
+            else:
+                torch.cuda.current_stream(self.backend.device).wait_event(self._ov["ready"][ov_slot])
         if work is not None:
             work.wait()
         tr = self.trace
@@ -810,7 +836,11 @@ class ShardedEmbeddingInteract:
         if p2p:
             self._p2p_state(pl["Bg"]).end_consume(pl["slot"])
         if ov_slot is not None:
-            self._ov["free"][ov_slot].record(torch.cuda.current_stream(self.backend.device))
+            if self._ov["sig"] is not None:
+                self._ov["n_free"][ov_slot] += 1
+                _lib.check(_lib.lib().evs_stream_write_value(_stream_ptr(self.backend.device), self._ov["sig"][ov_slot][1], self._ov["n_free"][ov_slot]))
+            else:
+                self._ov["free"][ov_slot].record(torch.cuda.current_stream(self.backend.device))
         return R
 
     # bench: {"pool": [], "interact": [], "n": 0, "every": 4} -> HIP events around the two launches of every 4th step (start,
@@ -933,7 +963,7 @@ def _bench_policy(args, ln_emb, rank, world, dev, policy, budget_rows, want_roof
                                   replicate_budget_rows=budget_rows)
     op.force_exchange = bool(getattr(args, "force_exchange", False))
     op.exchange_mode = getattr(args, "exchange_mode", "inline")
-    op.overlap = bool(getattr(args, "overlap", False))
+    op.overlap = getattr(args, "overlap", False) or False
     direct_used = None
     if op.exchange_mode == "direct":   # made here, outside the timed loops (ncclCommInitRank is a rendezvous)
         a2a_ = direct_comm(None, dev) if (world > 1 or op.force_exchange) else None

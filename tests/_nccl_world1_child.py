@@ -82,8 +82,8 @@ def main():
             assert not op.any_sharded or len(op._direct_plans) == 1, "one planned exchange, reused"
             # ... and the overlapped step: pool(i + 1) + its exchange on a side stream under the interaction of batch i, two pipeline
             # slots, event hand-overs -- eight batches in flight order, every R against the unsharded launch
-            if use_v == "1":
-                op.overlap = True
+            for how in (("events", "signals") if use_v == "1" else ()):
+                op.overlap, op._ov = how, None
                 xs2 = [torch.rand(B, d, device=dev) for _ in range(4)]
                 idx2 = [torch.stack([torch.from_numpy(rs.randint(0, n, size=B)) for n in ln]).to(dev) for _ in range(4)]
                 wants = [E.apply_emb_interact(xs2[j], off, idx2[j], ev, one_index_per_bag=True) for j in range(4)]
