@@ -285,7 +285,9 @@ EVS_API int evs_emb_interact_dot_stacked_multi(int K, int64_t B, int T, int d, i
  *   read by anything STARTED after serve_wait has returned, and nothing else needs the GPU urgently while the grid is
  *   resident -- it holds its compute units; it leaves by itself after idle_us without a post (the next post starts it again;
  *   a device-wide synchronise elsewhere waits that long), and serve_stop sends it home at once.
- * Out-of-range indices / bad offsets: skipped and flagged exactly as the launch form does (evs_check_index_errors). */
+ * Out-of-range indices / bad offsets: skipped and flagged exactly as the launch form does (evs_check_index_errors).
+ * x: 16-byte aligned, row stride a multiple of 4 floats; lS_i / lS_o: (T, B) int64 with unit inner stride, given by the address of
+ * row 0 and the elements between two rows; one server is driven by ONE host thread (posts and waits are not locked). */
 typedef struct evs_rf_server evs_rf_server;
 EVS_API int evs_emb_interact_serve_start(evs_rf_server **out, int T, int d, const void *const *tables, const int64_t *n_rows,
                                          int itself, int n_blocks, int64_t idle_us);
