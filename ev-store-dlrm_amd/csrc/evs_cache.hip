@@ -93,6 +93,12 @@ __device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOM
 template <typename T>
 __device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, EVS_EXACT_SCOPE); }
 
+// lane i's value, i wave-uniform: v_readlane_b32 into a scalar register (round 6; __shfl cannot know that its index is
+// uniform and goes through the LDS crossbar: thirteen ds_bpermute per table of a request)
+__device__ __forceinline__ int rl(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
+__device__ __forceinline__ unsigned long long rl64(unsigned long long v, int i) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, i);
+}
 // keys are (table_1based << 32) | row with table_1based <= kMaxTables = 64: 39 bits; an entry index of at most 25 bits rides above
 constexpr int kMapEntryShift = 39;
 constexpr unsigned long long kMapKeyMask = (1ull << kMapEntryShift) - 1ull;
@@ -122,6 +128,10 @@ __device__ void map_put(const CacheArrays &a, unsigned long long mask, unsigned 
 // linear-probing delete with backward shift (no tombstones: the table never degrades)
 __device__ void map_del(const CacheArrays &a, unsigned long long mask, unsigned long long key) {
     unsigned long long i = mix64(key) & mask;
+    {   // the common case in ONE round trip (round 6): the key in its home slot, nothing behind it (load <= 0.5)
+        const unsigned long long k0 = ld(&a.keys[i]), k1 = ld(&a.keys[(i + 1) & mask]);
+        if (map_key(a, k0) == key && k1 == kEmpty) { st(&a.keys[i], kEmpty); return; }
+    }
     for (;;) {
         const unsigned long long k = ld(&a.keys[i]);
         if (map_key(a, k) == key) break;
@@ -152,13 +162,13 @@ __device__ __forceinline__ void list_append(const CacheArrays &a, ListRef l, int
     st(&a.next[e], -1);
     if (t >= 0) st(&a.next[t], e); else *l.head = e;
     *l.tail = e;
-    *l.len += 1;
+    (void)__hip_atomic_fetch_add(l.len, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (ds_add_u32: no read to wait for)
 }
 __device__ __forceinline__ void list_unlink(const CacheArrays &a, ListRef l, int e) {
     const int p = ld(&a.prev[e]), n = ld(&a.next[e]);
     if (p >= 0) st(&a.next[p], n); else *l.head = n;
     if (n >= 0) st(&a.prev[n], p); else *l.tail = p;
-    *l.len -= 1;
+    (void)__hip_atomic_fetch_sub(l.len, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 __device__ __forceinline__ float decode_elem(const unsigned char *row, int codec, int c) {
@@ -190,11 +200,23 @@ __device__ void drop_entry(const CacheArrays &a, Hot &h, unsigned long long mask
     h.count--;
 }
 
+// Round 6, what lane 0's loop over a request's tables may still trust of what the lanes fetched in advance: a 1 024-bit filter
+// (LDS, cleared per request) of the entries whose key or list links an operation of THIS request has changed -- an evicted
+// entry (it carries another key now), the neighbours of an unlinked entry, the old tail of a list that was appended to, the
+// entry moved.  An entry that is not in it (the filter has false positives, never false negatives) still has the key, the
+// priority and the neighbours its lane read before the loop: no dependent access for its liveness check and its unlink,
+// where the first eviction of a request used to send every later hit down two of them.  A flush sets `all`.
+struct TouchMap { unsigned *bits; bool all; };
+// (an LDS atomic whose result nobody reads: one ds_or_b32, nothing to wait for -- a read-modify-write in C is a ds_read the wave stalls on)
+__device__ __forceinline__ void touch(TouchMap &m, int e) { if (m.bits && e >= 0) (void)__hip_atomic_fetch_or(&m.bits[((unsigned)e >> 5) & 31u], 1u << ((unsigned)e & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ bool touched(const TouchMap &m, int e) { return m.all || !m.bits || ((m.bits[((unsigned)e >> 5) & 31u] >> ((unsigned)e & 31u)) & 1u) != 0u; }
+
 // EvLFU_C1.py:32-63 set(key, value, agg_hit); returns the entry id (row is copied later)
 __device__ int evlfu_set(const CacheState &cs, const CacheArrays &a, Hot &h, unsigned long long mask,
-                         unsigned long long key, int agg_hit) {
+                         unsigned long long key, int agg_hit, TouchMap *tm = nullptr) {
     const int top = cs.n_tables;
     h.last_evicted = 0;
+    int reuse = -1;    // the entry an eviction has just freed: handed to the new key without a trip through the free stack
     if (h.n_perfect >= cs.max_perfect) {  // :36-44 flush the oldest of the top bucket
         for (int i = 0; i < cs.flush_n; i++) {
             const int e = h.head[top];
@@ -205,22 +227,40 @@ __device__ int evlfu_set(const CacheState &cs, const CacheArrays &a, Hot &h, uns
         // Python recounts (:43); the C++/Cython variants subtract int(rate*cap) (evlfu_8.cpp:270, EvLFU.cpp:86)
         h.n_perfect = (cs.perfect_mode == 0) ? h.len[top] : h.n_perfect - (cs.flush_n - (cs.perfect_mode == 1 ? 1 : 0));
         h.n_flush++;
+        if (tm) tm->all = true;
     } else if (h.count >= cs.cap) {       // :47-56 evict the FIFO-oldest key of the lowest non-empty bucket
         while (h.len[h.min_c1] == 0) {
             h.min_c1++;
             if (h.min_c1 > top) h.min_c1 = 1;
         }
         const int e = h.head[h.min_c1];
-        list_unlink(a, bucket(h, h.min_c1), e);
-        h.last_evicted = ld(&a.ekey[e]);
-        drop_entry(a, h, mask, e);
+        // the victim's neighbours and its key in ONE round trip (the key waited behind the unlink's stores)
+        const int vp = ld(&a.prev[e]), vn = ld(&a.next[e]);
+        const unsigned long long vk = ld(&a.ekey[e]);
+        {
+            ListRef l = bucket(h, h.min_c1);
+            if (vp >= 0) st(&a.next[vp], vn); else *l.head = vn;
+            if (vn >= 0) st(&a.prev[vn], vp); else *l.tail = vp;
+            *l.len -= 1;
+        }
+        h.last_evicted = vk;
+        map_del(a, mask, vk);
+        st(&a.ekey[e], kEmpty);
+        h.count--;
         h.n_evict++;
+        reuse = e;     // (drop_entry would push it on the free stack and the pop below would take it straight back)
+        if (tm) { touch(*tm, e); touch(*tm, vp); touch(*tm, vn); }
     }
-    if (h.n_free <= 0) { h.error = 2; return -1; }
-    const int e = a.free_stack[--h.n_free];
+    int e;
+    if (reuse >= 0) e = reuse;
+    else {
+        if (h.n_free <= 0) { h.error = 2; return -1; }
+        e = a.free_stack[--h.n_free];
+    }
     st(&a.ekey[e], key);
     st(&a.eagg[e], agg_hit);
     map_put(a, mask, key, e);
+    if (tm) { touch(*tm, *bucket(h, agg_hit).tail); touch(*tm, e); }
     list_append(a, bucket(h, agg_hit), e);
     h.count++;
     if (agg_hit < h.min_c1) h.min_c1 = agg_hit;  // :62-63
@@ -244,6 +284,12 @@ __device__ int evlfu_set(const CacheState &cs, const CacheArrays &a, Hot &h, uns
 #ifndef EVS_X_SERVE_FENCE
 #define EVS_X_SERVE_FENCE 0
 #endif
+#ifdef EVS_X_EXACT_TIMING   // developer build: where a request's time goes (100 MHz ticks per stage, summed over a launch)
+static __device__ long long g_exact_ticks[8];
+#define EVS_TICK(k) do { const long long now_ = (long long)wall_clock64(); if (lane == 0) tick_acc[k] += now_ - tick_t; tick_t = now_; } while (0)
+#else
+#define EVS_TICK(k) do { } while (0)
+#endif
 struct ServeArgs {
     volatile unsigned *req;     // request line (device address of the mapped host block)
     volatile unsigned *ctl;     // control line
@@ -252,6 +298,12 @@ struct ServeArgs {
     long long idle_ticks;
 };
 // One wavefront, requests strictly in order.
+// The exact kernels are ONE wavefront (launched with 64 threads): what its lanes hand each other through LDS, and what lane 0
+// writes to the entry arrays for the lanes of the next request to read, is ordered by the wave's own in-order issue -- a
+// wavefront-scope fence (no cache action, no wait) and a scheduling barrier say so to the compiler.  __syncthreads() here was a
+// workgroup-scope release: s_waitcnt vmcnt(0) in front of every one of them, i.e. the wave waited for its own STORES to be
+// acknowledged three to four times per request (round 6: ~2.5 of a request's 10 us).
+#define EVS_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 template <bool SERVE>
 __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const ServeArgs &sv) {
     __shared__ Hot h;
@@ -260,6 +312,11 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
     __shared__ int s_from[kMaxTables];   // approximate mode: table whose vector is reused
     __shared__ const unsigned char *s_rowp[kMaxTables];
     __shared__ int s_req[kMaxTables];
+    __shared__ unsigned s_touch[32];     // TouchMap::bits of the request in hand (EvLFU)
+    // the tables' addresses and row counts out of LDS (round 6): indexed by a lane's table they were reads of the kernel arguments
+    // -- a vector-memory round trip -- inside every request's row stage
+    __shared__ const unsigned char *s_back[kMaxTables];
+    __shared__ long long s_brows[kMaxTables];
     const int lane = threadIdx.x;
     CacheState *gs = args.st;
     const CacheArrays a = args.a;
@@ -271,14 +328,19 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
         h.n_flush = cs.n_flush; h.n_evict = cs.n_evict; h.least_freq = cs.least_freq; h.error = cs.error;
     }
     for (int b = lane; b < kMaxBuckets; b += 64) { h.head[b] = gs->head[b]; h.tail[b] = gs->tail[b]; h.len[b] = gs->len[b]; }
-    __syncthreads();
+    for (int k = lane; k < kMaxTables; k += 64) { s_back[k] = args.backing[k]; s_brows[k] = args.backing_rows[k]; }
+    EVS_WSYNC();
     long long n_hits = 0, n_perfect_hits = 0;
+    unsigned warm_acc = 0u;            // (what the row warm-up loads return: kept alive to the kernel's end, never meaningful)
 #if EVS_X_EXACT_STOP == 1
     return;
 #endif
 
     unsigned serve_seq = 0;            // SERVE: the last sequence number served
     long long served = 0;
+#ifdef EVS_X_EXACT_TIMING
+    long long tick_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tick_t = (long long)wall_clock64();
+#endif
     if constexpr (SERVE) {
         serve_seq = __hip_atomic_load(const_cast<unsigned *>(sv.ans) + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 17, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // alive
@@ -322,11 +384,12 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             out = args.out + rq * (long long)T * d;
             hitp = args.hit + rq * T;
         }
+        EVS_TICK(0);                    // (waiting for / reading the request)
         unsigned char my_flag = 0;      // this lane's table: the hit flag of the request in hand
         bool churn = true;              // an insert of this request may have evicted / flushed entries (LRU / LFU: always assumed)
         if (lane < T) s_req[lane] = row;
         const unsigned long long key = ((unsigned long long)(lane + 1) << 32) | (unsigned)row;
-        const bool row_ok = lane < T && row >= 0 && row < args.backing_rows[lane < T ? lane : 0];
+        const bool row_ok = lane < T && row >= 0 && row < s_brows[lane < T ? lane : 0];
         if (lane < T) { s_src[lane] = -1; s_fill[lane] = -1; s_from[lane] = -1; }
 
         if (cs.policy == kEvLFU) {
@@ -334,6 +397,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             long long ins_slot = -1;   // a missing key: the empty slot its probe walk ended on
             int e = (lane < T && row_ok) ? map_find(a, mask, key, &ins_slot) : -1;
             const unsigned long long hit_mask = __ballot(e >= 0);
+            EVS_TICK(1);                // (the probe)
             const int agg_hit = __popcll(hit_mask);
             const bool pick_random = args.approx_thres > 0 && agg_hit >= args.approx_thres;  // :122-125
             bool my_hit = e >= 0;
@@ -357,6 +421,12 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             //  one that moves has saved a dependent round trip -- round 6)
             const int pre_prev = e >= 0 ? ld(&a.prev[e]) : -1;
             const int pre_next = e >= 0 ? ld(&a.next[e]) : -1;
+            // ... and the first and the last word of the row this lane's table will be served from (arena row of a hit, table row
+            // of a miss: a random line of a multi-GB table, i.e. a TLB miss on top of the DRAM access): asked for HERE, behind the
+            // fetches above (vector-memory operations complete in issue order: in front of them they would hold them up), their
+            // latency runs under those fetches and the policy step instead of in front of the row stage
+            const unsigned char *warm_p = (lane < T && row_ok) ? (e >= 0 ? a.arena + (long long)e * rb : s_back[lane] + (long long)row * rb) : a.arena;
+            warm_acc ^= *reinterpret_cast<const volatile unsigned char *>(warm_p) ^ *reinterpret_cast<const volatile unsigned char *>(warm_p + (rb > 0 ? rb - 1 : 0));
             bool slot_clash = false;   // an earlier miss of this request ended on the same empty slot
             for (int j = 0; j < T; j++) {
                 const long long sj = __shfl((int)(ins_slot & 0xffffffffll), j) | ((long long)__shfl((int)(ins_slot >> 32), j) << 32);
@@ -365,10 +435,15 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             }
             bool dirty = false;
             bool fast_ok = !pick_random;   // nothing unforeseen has happened to the map / the stack yet
-            bool lists_touched = false;    // an unlink of this request may have changed a prefetched neighbour
+            if (lane < 32) s_touch[lane] = 0u;
+            TouchMap tm{s_touch, false};   // (lane 0's: which entries an operation of this request has changed)
 #if EVS_X_EXACT_STOP == 2
             if (pre_key != 12345ull || pre_agg != -7) return;
 #endif
+#ifdef EVS_X_EXACT_TIMING
+            if (pre_key == 1ull && pre_agg == -77 && pre_free == -77 && pre_prev == -77 && pre_next == -77) h.error = 9;   // (the timing build waits for the fetches HERE)
+#endif
+            EVS_TICK(2);                // (what the lanes fetch in advance)
             // ---- policy update, table order, one lane (EvLFU_C1.py:135-161) ----
             // Round 6: lane 0 visits only the tables whose key CHANGES something -- a miss, or a hit whose priority rises.  A hit
             // that stays where it is needs the loop for one thing only: an insert of this same request may have evicted its entry
@@ -381,69 +456,133 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             unsigned long long work = __ballot(lane < T && row_ok && (e < 0 || moves));
             if (!calm) work = __ballot(lane < T && row_ok);
             if (calm && e >= 0 && !moves && lane < T) s_src[lane] = e;
+            // Round 6, the calm request with ALL LANES AT ONCE.  Lane 0's loop costs a lone wave ~0.5 us per table it visits
+            // (~100 dependent instructions each: 6 of a request's 16 us, tools/exact_stage_probe.py).  When nothing can be evicted,
+            // every miss has the free entry and the map slot it fetched in advance, and no two hits that move are neighbours in
+            // their list, the request's operations commute except for ONE thing, the order of the appends to bucket agg_hit --
+            // table order, i.e. lane order: lane l's entry goes behind the entry of the appending lane before it.  So: every mover
+            // unlinks itself (its neighbours were fetched before anything changed; non-adjacent unlinks touch different words),
+            // every miss fills its entry and its map slot, every appender links itself between its neighbours in lane order, the
+            // first one behind the bucket's old tail, and the counters move by LDS atomics.  Anything else: the loop below.
+            const unsigned long long mover_mask = __ballot(lane < T && row_ok && moves);
+            bool par_ok = calm && __ballot(my_miss && (slot_clash || pre_free < 0)) == 0ull;
+            if (par_ok) {
+                bool adj = false;
+                for (unsigned long long mm = mover_mask; mm; mm &= mm - 1ull) {
+                    const int j = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mm));
+                    const int ej = rl(e, j);
+                    adj |= moves && j != lane && (pre_prev == ej || pre_next == ej);
+                }
+                par_ok = __ballot(lane < T && adj) == 0ull;
+            }
+            if (par_ok) {
+                const bool mover = lane < T && row_ok && moves;
+                const unsigned long long app_mask = mover_mask | miss_mask;    // who appends to bucket agg_hit, in lane order
+                const int n_app = __popcll(app_mask);
+                const int x = mover ? e : pre_free;                              // the entry this lane appends
+                const int tail0 = h.tail[agg_hit];
+                const unsigned long long below = app_mask & ((1ull << lane) - 1ull), above = lane < 63 ? (app_mask >> (lane + 1)) : 0ull;
+                const int lane_prev = below ? 63 - (int)__builtin_clzll(below) : 0, lane_next = above ? lane + 1 + (int)__builtin_ctzll(above) : 0;
+                const int x_prev = __shfl(x, lane_prev), x_next = __shfl(x, lane_next);
+                if (mover) {   // out of its list (update_agg_hit, :65-78) ...
+                    ListRef l = bucket(h, pre_agg);
+                    if (pre_prev >= 0) st(&a.next[pre_prev], pre_next); else *l.head = pre_next;
+                    if (pre_next >= 0) st(&a.prev[pre_next], pre_prev); else *l.tail = pre_prev;
+                    (void)__hip_atomic_fetch_sub(l.len, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    st(&a.eagg[e], agg_hit);
+                }
+                if (my_miss) {   // ... or set() without an eviction (:57-63): the entry and the map slot fetched in advance
+                    st(&a.ekey[pre_free], key);
+                    st(&a.eagg[pre_free], agg_hit);
+                    st(&a.slot_entry[ins_slot], pre_free);
+                    st(&a.keys[ins_slot], map_word(a, key, pre_free));
+                    s_fill[lane] = pre_free;
+                }
+                if (mover || my_miss) {   // ... and behind the appender before it
+                    st(&a.prev[x], below ? x_prev : tail0);
+                    st(&a.next[x], above ? x_next : -1);
+                    if (!below) { if (tail0 >= 0) st(&a.next[tail0], x); else h.head[agg_hit] = x; }
+                    if (!above) h.tail[agg_hit] = x;
+                    if (mover) s_src[lane] = e;
+                }
+                if (lane == 0) {
+                    h.last_evicted = 0;
+                    if (n_app) h.len[agg_hit] += n_app;
+                    if (n_miss) { h.n_free -= n_miss; h.count += n_miss; if (agg_hit < h.min_c1) h.min_c1 = agg_hit; }
+                }
+                work = 0ull;
+            }
             int last_hit_table = -1;
             while (work) {
-                const int i = (int)__builtin_ctzll(work);
+                const int i = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(work));   // (said to be uniform: a readlane whose index the compiler takes for divergent becomes a loop)
                 work &= work - 1ull;
-                const int ei = __shfl(e, i);
-                const unsigned long long ki = __shfl(key, i);
-                const bool oki = __shfl((int)row_ok, i) != 0;
+                const int ei = rl(e, i);
+                const unsigned long long ki = rl64(key, i);
+                const bool oki = rl((int)row_ok, i) != 0;
                 const bool hiti = (hit_mask >> i) & 1ull;
-                const unsigned long long pk = __shfl(pre_key, i);
-                const int pa = __shfl(pre_agg, i);
-                const int pfree = __shfl(pre_free, i), pprev = __shfl(pre_prev, i), pnext = __shfl(pre_next, i);
-                const long long pslot = __shfl((int)(ins_slot & 0xffffffffll), i) | ((long long)__shfl((int)(ins_slot >> 32), i) << 32);
-                const bool pclash = __shfl((int)slot_clash, i) != 0;
+                const unsigned long long pk = rl64(pre_key, i);
+                const int pa = rl(pre_agg, i);
+                const int pfree = rl(pre_free, i), pprev = rl(pre_prev, i), pnext = rl(pre_next, i);
+                const long long pslot = (long long)rl64((unsigned long long)ins_slot, i);
+                const bool pclash = rl((int)slot_clash, i) != 0;
                 int src = -1, fill = -1, from = -1;
                 if (lane == 0 && oki) {
                     if (hiti) {
                         // update() -> update_agg_hit (:65-78); the entry may have been evicted by an
-                        // earlier insert of this same request (:90-94): then re-fetch and set()
-                        const bool alive = (dirty ? ld(&a.ekey[ei]) : pk) == ki;
+                        // earlier insert of this same request (:90-94): then re-fetch and set().  What the lanes fetched
+                        // before the loop -- key, priority, list neighbours -- stands unless an operation of this request
+                        // has touched the entry (TouchMap): no dependent access then
+                        const bool stale = touched(tm, ei);
+                        const bool alive = (stale ? ld(&a.ekey[ei]) : pk) == ki;
                         if (alive) {
-                            const int old = dirty ? ld(&a.eagg[ei]) : pa;
+                            const int old = stale ? ld(&a.eagg[ei]) : pa;
                             if (old < agg_hit) {
-                                if (!dirty && !lists_touched) {   // list_unlink on the neighbours fetched above
-                                    ListRef l = bucket(h, old);
-                                    if (pprev >= 0) st(&a.next[pprev], pnext); else *l.head = pnext;
-                                    if (pnext >= 0) st(&a.prev[pnext], pprev); else *l.tail = pprev;
-                                    *l.len -= 1;
-                                } else list_unlink(a, bucket(h, old), ei);
-                                lists_touched = true;
+                                int up = pprev, un = pnext;
+                                if (stale) { up = ld(&a.prev[ei]); un = ld(&a.next[ei]); }
+                                ListRef l = bucket(h, old);
+                                if (up >= 0) st(&a.next[up], un); else *l.head = un;
+                                if (un >= 0) st(&a.prev[un], up); else *l.tail = up;
+                                (void)__hip_atomic_fetch_sub(l.len, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                touch(tm, up); touch(tm, un); touch(tm, ei); touch(tm, *bucket(h, agg_hit).tail);
                                 list_append(a, bucket(h, agg_hit), ei);
                                 st(&a.eagg[ei], agg_hit);
                             }
                             src = ei;
                         } else {
-                            fill = evlfu_set(cs, a, h, mask, ki, agg_hit);
+                            fill = evlfu_set(cs, a, h, mask, ki, agg_hit, &tm);
                             dirty = true; fast_ok = false;
                         }
                         last_hit_table = i;
                     } else if (pick_random) {  // :142-152: the miss reuses the previous hit's vector
                         from = last_hit_table;
                         src = -2;
-                    } else if (fast_ok && !pclash && pfree >= 0 && h.n_perfect < cs.max_perfect && h.count < cs.cap) {
+                    } else if (fast_ok && !pclash && pfree >= 0 && (calm || (h.n_perfect < cs.max_perfect && h.count < cs.cap))) {
                         // evlfu_set without an eviction or a flush, on what was fetched above: stores only
                         h.last_evicted = 0;
-                        --h.n_free;
+                        (void)__hip_atomic_fetch_sub(&h.n_free, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         st(&a.ekey[pfree], ki);
                         st(&a.eagg[pfree], agg_hit);
                         st(&a.slot_entry[pslot], pfree);
                         st(&a.keys[pslot], map_word(a, ki, pfree));
+                        touch(tm, *bucket(h, agg_hit).tail); touch(tm, pfree);
                         list_append(a, bucket(h, agg_hit), pfree);
-                        h.count++;
-                        if (agg_hit < h.min_c1) h.min_c1 = agg_hit;
+                        (void)__hip_atomic_fetch_add(&h.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        (void)__hip_atomic_fetch_min(&h.min_c1, agg_hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         fill = pfree;   // (nothing was evicted: no later hit's entry can have been reused -- `dirty` stays as it is)
                     } else {
                         // (an eviction / a flush pushes entries back on the stack and rewrites map slots: what the later keys of
                         //  this request fetched in advance is void from here on)
                         fast_ok = false;   // (also behind a slot clash: the key lands wherever ITS probe ends now -- maybe on the slot a later miss fetched)
-                        fill = evlfu_set(cs, a, h, mask, ki, agg_hit);
+                        fill = evlfu_set(cs, a, h, mask, ki, agg_hit, &tm);
                         dirty = true;
                     }
                     s_src[i] = src; s_fill[i] = fill; s_from[i] = from;
                 }
+#ifdef EVS_X_EXACT_TIMING
+                { const long long now_ = (long long)wall_clock64(); if (lane == 0) { tick_acc[hiti ? 6 : 7] += now_ - tick_t; } tick_t = now_; }
+#endif
             }
+            EVS_TICK(3);                // (lane 0's loop: what is left of it beside the per-kind ticks inside)
             churn = __shfl((int)dirty, 0) != 0;
             if (lane == 0 && agg_hit == T) h.n_perfect = h.len[T];  // :163-165
             if (pick_random) my_hit = lane < T;                       // misses are reported as hits (:152)
@@ -536,7 +675,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             n_perfect_hits += (nh == T);
         }
         if constexpr (!SERVE) { if (lane < T) hitp[lane] = my_flag; }
-        __syncthreads();
+        EVS_WSYNC();
 
         // ---- rows: hits from the arena, misses from the backing store; then fill inserted entries ----
 #if EVS_X_EXACT_STOP == 3
@@ -552,21 +691,21 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                 if (tsrc < 0) { zero = true; tsrc = i; } else src = s_src[tsrc];
             }
             const int rrow = s_req[tsrc];
-            const bool ok = rrow >= 0 && rrow < args.backing_rows[tsrc];
+            const bool ok = rrow >= 0 && rrow < s_brows[tsrc];
             const unsigned char *rowp = nullptr;
             if (!zero) {
                 if (src >= 0) rowp = a.arena + (long long)src * rb;
-                else if (ok) rowp = args.backing[tsrc] + (long long)rrow * rb;
+                else if (ok) rowp = s_back[tsrc] + (long long)rrow * rb;
             }
             s_rowp[i] = rowp;
         }
-        __syncthreads();
+        EVS_WSYNC();
         // Round 6: the rows of the NEW entries (table -> arena, below) are asked for here, with the rows that go out -- one round
         // trip for both; their stores stay behind the out stream (an entry a later key of this request evicted and refilled may
         // still be the source of an earlier hit's row).  16-byte aligned rows of at most 256 bytes; the rest below as before.
         const int fill_i = lane < T ? lane : 0;
         const int fill_e = lane < T ? s_fill[fill_i] : -1;
-        const unsigned char *fill_src = args.backing[fill_i] + (long long)s_req[fill_i] * rb;
+        const unsigned char *fill_src = s_back[fill_i] + (long long)s_req[fill_i] * rb;
         unsigned char *fill_dst = a.arena + (long long)(fill_e >= 0 ? fill_e : 0) * rb;
         const bool fill_early = fill_e >= 0 && rb <= 256 && ((rb | (int)(reinterpret_cast<uintptr_t>(fill_src) | reinterpret_cast<uintptr_t>(fill_dst))) & 15) == 0;
         uint4 fill_r[16];
@@ -575,17 +714,71 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             for (int c = 0; c < 16; c++)
                 if (c * 16 < rb) fill_r[c] = *reinterpret_cast<const uint4 *>(fill_src + c * 16);
         }
-        // ... and the T*d elements leave as one flat, independent stream (not T dependent row trips)
-        for (int idx = lane; idx < T * d; idx += 64) {
-            const int i = idx / d, c = idx - i * d;
-            const unsigned char *rowp = s_rowp[i];
-            const float v = rowp ? decode_elem(rowp, cs.codec, c) : 0.f;
-            // SERVE: written through (agent scope) -- the ring is read by launches that start while this kernel is still resident,
-            // and the alternative is a system-scope fence (an L2 write-back) per request
-            if constexpr (SERVE) __hip_atomic_store(out + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else out[idx] = v;
+        // ... and the T*d elements leave as one flat, independent stream (not T dependent row trips).  Round 6: sixteen elements
+        // per lane are asked for before the first is looked at -- the loop over idx was one dependent element load per trip, 15
+        // trips for Kaggle's 936 floats: 7 of a request's 17 us (tools/exact_stage_probe.py)
+        {
+            const int n_el = T * d;
+            auto put = [&](int idx, float v) {
+                // SERVE: written through (agent scope) -- the ring is read by launches that start while this kernel is still
+                // resident, and the alternative is a system-scope fence (an L2 write-back) per request
+                if constexpr (SERVE) __hip_atomic_store(out + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else out[idx] = v;
+            };
+            // branch-free inside (a load behind a divergent branch makes the compiler wait for everything in flight at the branch's
+            // end): a lane past the last element re-reads the last one, an absent row reads the arena's first bytes, both
+            // discarded by the select below; the codec is wave-uniform -- one loop per codec, nothing to decide inside
+            int ti = lane / d, tc = lane - ti * d;     // (table, column) of this lane's first element; + 64 per step
+            const int step_i = 64 / d, step_c = 64 - step_i * d;
+            const int last_i = T - 1, last_c = d - 1;
+            const unsigned char *el_p[16];
+            bool have[16];
+            int col[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const bool in = lane + 64 * k < n_el;
+                const int i_ = in ? ti : last_i, c_ = in ? tc : last_c;
+                const unsigned char *rowp = s_rowp[i_];
+                have[k] = in & (rowp != nullptr);
+                el_p[k] = rowp ? rowp : a.arena;
+                col[k] = c_;
+                ti += step_i; tc += step_c;
+                if (tc >= d) { tc -= d; ti++; }
+            }
+            float val[16];
+            if (cs.codec == 32) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) val[k] = reinterpret_cast<const float *>(el_p[k])[col[k]];
+            } else if (cs.codec == 16) {
+                unsigned short r_[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) r_[k] = reinterpret_cast<const unsigned short *>(el_p[k])[col[k]];
+#pragma unroll
+                for (int k = 0; k < 16; k++) val[k] = dec_u16(r_[k]);
+            } else if (cs.codec == 8) {
+                unsigned char r_[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) r_[k] = el_p[k][col[k]];
+#pragma unroll
+                for (int k = 0; k < 16; k++) val[k] = dec_u8(r_[k]);
+            } else {
+                unsigned char r_[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) r_[k] = el_p[k][col[k] >> 1];
+#pragma unroll
+                for (int k = 0; k < 16; k++) val[k] = kU4Lut[(col[k] & 1) ? (r_[k] & 15u) : (r_[k] >> 4)];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (lane + 64 * k < n_el) put(lane + 64 * k, have[k] ? val[k] : 0.f);
+            for (int idx = lane + 1024; idx < n_el; idx += 64) {   // (more than 1 024 elements: the rest one at a time)
+                const int i = idx / d, c = idx - i * d;
+                const unsigned char *rowp = s_rowp[i];
+                put(idx, rowp ? decode_elem(rowp, cs.codec, c) : 0.f);
+            }
         }
-        __syncthreads();
+        EVS_WSYNC();
+        EVS_TICK(4);                    // (the rows that go out)
 #if EVS_X_EXACT_STOP == 4
         return;
 #endif
@@ -601,7 +794,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                 for (int c = 0; c < 16; c++)
                     if (c * 16 < rb) *reinterpret_cast<uint4 *>(fill_dst + c * 16) = fill_r[c];
             } else if (mine) {
-                const unsigned char *rowp = args.backing[i] + (long long)s_req[i] * rb;
+                const unsigned char *rowp = s_back[i] + (long long)s_req[i] * rb;
                 unsigned char *dst = a.arena + (long long)fe * rb;
                 if (((rb | (int)(reinterpret_cast<uintptr_t>(rowp) | reinterpret_cast<uintptr_t>(dst))) & 15) == 0) {
                     for (int c = 0; c < rb; c += 16) *reinterpret_cast<uint4 *>(dst + c) = *reinterpret_cast<const uint4 *>(rowp + c);
@@ -613,7 +806,8 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             }
         }
         __threadfence_block();   // (the rows are read back by this block only: a workgroup-scope fence; an agent-scope one is an L2 write-back per request, tools/atomic_probe.hip)
-        __syncthreads();
+        EVS_WSYNC();
+        EVS_TICK(5);                    // (the new entries' rows)
         if constexpr (SERVE) {
             // ---- the answer: hit flags, then (behind a fence that also puts the ring rows where every later launch sees
             // them) the sequence number the host is polling for ----
@@ -637,6 +831,10 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
         }
     }
 
+#ifdef EVS_X_EXACT_TIMING
+    if (lane == 0) for (int k = 0; k < 8; k++) g_exact_ticks[k] += tick_acc[k];
+#endif
+    asm volatile("" :: "v"(warm_acc));
     if (lane == 0) {
         gs->min_c1 = h.min_c1; gs->n_perfect = h.n_perfect; gs->count = h.count; gs->n_free = h.n_free;
         gs->n_flush = h.n_flush; gs->n_evict = h.n_evict; gs->least_freq = h.least_freq; gs->error = h.error;
@@ -3244,6 +3442,14 @@ extern "C" int evs_cache_serve_consumed(evs_cache *c, int slot, void *stream) {
     c->slot_busy[(size_t)slot] = 1;
     return EVS_OK;
 }
+#ifdef EVS_X_EXACT_TIMING
+extern "C" __attribute__((visibility("default"))) int evs_x_exact_ticks(long long *out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(evs::g_exact_ticks), 64) != hipSuccess) return -2;
+    if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(evs::g_exact_ticks), z, 64) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
 extern "C" int evs_cache_serve_stop(evs_cache *c) {
     using namespace evs;
     EVS_REQUIRE(c, "evs_cache_serve_stop: NULL cache");
