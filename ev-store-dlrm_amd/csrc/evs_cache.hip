@@ -707,12 +707,16 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
         const int fill_e = lane < T ? s_fill[fill_i] : -1;
         const unsigned char *fill_src = s_back[fill_i] + (long long)s_req[fill_i] * rb;
         unsigned char *fill_dst = a.arena + (long long)(fill_e >= 0 ? fill_e : 0) * rb;
-        const bool fill_early = fill_e >= 0 && rb <= 256 && ((rb | (int)(reinterpret_cast<uintptr_t>(fill_src) | reinterpret_cast<uintptr_t>(fill_dst))) & 15) == 0;
+        // (the wave-uniform half of the condition decides whether there are loads at all, the per-lane half only WHERE a lane
+        // reads: a lane with nothing to move reads the arena's first row and drops it -- no load sits behind a divergent branch)
+        const bool fill_fast = rb <= 256 && ((rb | (int)reinterpret_cast<uintptr_t>(a.arena)) & 15) == 0;
+        const bool fill_early = fill_fast && fill_e >= 0 && (reinterpret_cast<uintptr_t>(fill_src) & 15) == 0;
         uint4 fill_r[16];
-        if (fill_early) {
+        if (fill_fast) {
+            const unsigned char *fp = fill_early ? fill_src : a.arena;
 #pragma unroll
             for (int c = 0; c < 16; c++)
-                if (c * 16 < rb) fill_r[c] = *reinterpret_cast<const uint4 *>(fill_src + c * 16);
+                if (c * 16 < rb) fill_r[c] = *reinterpret_cast<const uint4 *>(fp + c * 16);
         }
         // ... and the T*d elements leave as one flat, independent stream (not T dependent row trips).  Round 6: sixteen elements
         // per lane are asked for before the first is looked at -- the loop over idx was one dependent element load per trip, 15
