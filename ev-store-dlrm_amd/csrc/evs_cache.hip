@@ -356,10 +356,12 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             unsigned word = 0u;
             bool leave = false;
             for (;;) {
-                word = __hip_atomic_load(const_cast<unsigned *>(sv.req) + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // ONE load per poll (round 6: the control word was a second dependent load, and the request waited out both):
+                // lanes 0..31 the request line, lane 32 the control word in the line behind it
+                word = __hip_atomic_load(const_cast<unsigned *>(sv.req) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 // words 7, 15, 23, 31: one guard per 32-byte sector (bit 31 of a guard: the ids are given by ADDRESS, below)
                 if ((__ballot((word & 0x7fffffffu) == want) & 0x80808080ull) == 0x80808080ull) break;
-                const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned stop = (unsigned)__builtin_amdgcn_readlane((int)word, 32);
                 if (stop != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) { leave = true; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
@@ -370,9 +372,9 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             // ... or, round 6 (evs_cache_serve_request_dev: the reference's loop has the ids on the DEVICE -- dlrm_wrap moved lS_i
             // there -- and fetching them back costs the plug-in a copy and a synchronise per request): words 0..2 = the address of
             // table 0's first index and the elements between two tables' rows; one agent-scope load per lane
-            if (((unsigned)__shfl((int)word, 7) >> 31) != 0u) {
-                const unsigned long long pa = ((unsigned long long)(unsigned)__shfl((int)word, 1) << 32) | (unsigned)__shfl((int)word, 0);
-                const long long stride = (long long)(unsigned)__shfl((int)word, 2);
+            if (((unsigned)rl((int)word, 7) >> 31) != 0u) {
+                const unsigned long long pa = ((unsigned long long)(unsigned)rl((int)word, 1) << 32) | (unsigned)rl((int)word, 0);
+                const long long stride = (long long)(unsigned)rl((int)word, 2);
                 const long long *ip = reinterpret_cast<const long long *>((uintptr_t)pa) + (long long)(lane < T ? lane : 0) * stride;
                 row = (int)__hip_atomic_load(ip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -403,8 +405,12 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             bool my_hit = e >= 0;
             // every lane fetches its own entry's key and priority now (one round trip for all T); the serial
             // loop below re-reads them only after an insert of THIS request may have evicted / reused an entry
-            const unsigned long long pre_key = e >= 0 ? ld(&a.ekey[e]) : 0ull;
-            const int pre_agg = e >= 0 ? ld(&a.eagg[e]) : 0;
+            // (round 6: NO load of this block sits behind `e >= 0 ? ... : ...` any more -- a load in a divergent branch is waited
+            //  for at the branch's end, and the seven fetches below were seven round trips one after the other: 1.25 us of a
+            //  10 us request, tools/exact_stage_probe.py; a lane with nothing to fetch reads entry 0 and drops it)
+            const int e0 = e >= 0 ? e : 0;
+            const unsigned long long pre_key_ = ld(&a.ekey[e0]);
+            const int pre_agg_ = ld(&a.eagg[e0]);
             // Round 5, the same idea for everything else lane 0's serial loop used to fetch one dependent access at a time
             // (a request with six misses was ~15 round trips of one lane): every lane fetches NOW what its key will need --
             // a hit whose priority will rise: its list neighbours; a miss: the free entry it will be given (the stack is
@@ -416,23 +422,37 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             const unsigned long long miss_mask = __ballot(my_miss);
             const int my_rank = __popcll(miss_mask & ((1ull << lane) - 1ull));
             const int n_free0 = h.n_free;
-            const int pre_free = (my_miss && n_free0 - 1 - my_rank >= 0) ? a.free_stack[n_free0 - 1 - my_rank] : -1;
+            const bool has_free = my_miss && n_free0 - 1 - my_rank >= 0;
+            const int pre_free_ = a.free_stack[has_free ? n_free0 - 1 - my_rank : 0];
             // (asked for with the key and the priority, not behind them: a hit that does not move has fetched two words for nothing,
             //  one that moves has saved a dependent round trip -- round 6)
-            const int pre_prev = e >= 0 ? ld(&a.prev[e]) : -1;
-            const int pre_next = e >= 0 ? ld(&a.next[e]) : -1;
+            const int pre_prev_ = ld(&a.prev[e0]);
+            const int pre_next_ = ld(&a.next[e0]);
             // ... and the first and the last word of the row this lane's table will be served from (arena row of a hit, table row
             // of a miss: a random line of a multi-GB table, i.e. a TLB miss on top of the DRAM access): asked for HERE, behind the
             // fetches above (vector-memory operations complete in issue order: in front of them they would hold them up), their
             // latency runs under those fetches and the policy step instead of in front of the row stage
             const unsigned char *warm_p = (lane < T && row_ok) ? (e >= 0 ? a.arena + (long long)e * rb : s_back[lane] + (long long)row * rb) : a.arena;
-            warm_acc ^= *reinterpret_cast<const volatile unsigned char *>(warm_p) ^ *reinterpret_cast<const volatile unsigned char *>(warm_p + (rb > 0 ? rb - 1 : 0));
+            // (plain loads whose value is looked at when the NEXT request gets here: a volatile load is waited for on the spot)
+            const unsigned warm_now = (unsigned)warm_p[0] ^ (unsigned)warm_p[rb > 0 ? rb - 1 : 0];
+#ifdef EVS_X_PRE_TIMING
+            EVS_TICK(6);
+#endif
+            const unsigned long long pre_key = e >= 0 ? pre_key_ : 0ull;
+            const int pre_agg = e >= 0 ? pre_agg_ : 0, pre_free = has_free ? pre_free_ : -1;
+            const int pre_prev = e >= 0 ? pre_prev_ : -1, pre_next = e >= 0 ? pre_next_ : -1;
             bool slot_clash = false;   // an earlier miss of this request ended on the same empty slot
-            for (int j = 0; j < T; j++) {
-                const long long sj = __shfl((int)(ins_slot & 0xffffffffll), j) | ((long long)__shfl((int)(ins_slot >> 32), j) << 32);
-                const bool mj = (miss_mask >> j) & 1ull;
-                slot_clash |= my_miss && mj && j < lane && sj == ins_slot;
+            // (over the misses only, their slot read with v_readlane: the loop over all T tables with two __shfl -- the LDS
+            //  crossbar, its index not known to be uniform -- was 2.2 us of the request)
+            for (unsigned long long mm = miss_mask; mm; mm &= mm - 1ull) {
+                const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mm));
+                const long long sj = (long long)rl64((unsigned long long)ins_slot, j);
+                slot_clash |= my_miss && j < lane && sj == ins_slot;
             }
+#ifdef EVS_X_PRE_TIMING
+            if (slot_clash && lane == 77) h.error = 9;
+            EVS_TICK(7);
+#endif
             bool dirty = false;
             bool fast_ok = !pick_random;   // nothing unforeseen has happened to the map / the stack yet
             if (lane < 32) s_touch[lane] = 0u;
@@ -579,11 +599,14 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                     s_src[i] = src; s_fill[i] = fill; s_from[i] = from;
                 }
 #ifdef EVS_X_EXACT_TIMING
+#if !defined(EVS_X_ROWS_TIMING) && !defined(EVS_X_PRE_TIMING)
                 { const long long now_ = (long long)wall_clock64(); if (lane == 0) { tick_acc[hiti ? 6 : 7] += now_ - tick_t; } tick_t = now_; }
+#endif
 #endif
             }
             EVS_TICK(3);                // (lane 0's loop: what is left of it beside the per-kind ticks inside)
-            churn = __shfl((int)dirty, 0) != 0;
+            churn = rl((int)dirty, 0) != 0;
+            warm_acc ^= warm_now;   // (the warm-up loads are looked at here, with the policy step behind them)
             if (lane == 0 && agg_hit == T) h.n_perfect = h.len[T];  // :163-165
             if (pick_random) my_hit = lane < T;                       // misses are reported as hits (:152)
             my_flag = my_hit ? 1 : 0;
@@ -700,6 +723,9 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             s_rowp[i] = rowp;
         }
         EVS_WSYNC();
+#ifdef EVS_X_ROWS_TIMING
+        EVS_TICK(6);
+#endif
         // Round 6: the rows of the NEW entries (table -> arena, below) are asked for here, with the rows that go out -- one round
         // trip for both; their stores stay behind the out stream (an entry a later key of this request evicted and refilled may
         // still be the source of an earlier hit's row).  16-byte aligned rows of at most 256 bytes; the rest below as before.
@@ -772,6 +798,10 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
 #pragma unroll
                 for (int k = 0; k < 16; k++) val[k] = kU4Lut[(col[k] & 1) ? (r_[k] & 15u) : (r_[k] >> 4)];
             }
+#ifdef EVS_X_ROWS_TIMING
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            EVS_TICK(7);
+#endif
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 if (lane + 64 * k < n_el) put(lane + 64 * k, have[k] ? val[k] : 0.f);
@@ -786,6 +816,29 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
 #if EVS_X_EXACT_STOP == 4
         return;
 #endif
+        if constexpr (SERVE) {
+            // ---- the answer: hit flags, then (behind a wait that also puts the ring rows where every later launch sees
+            // them) the sequence number the host is polling for.  Round 6: BEFORE the new entries' rows are moved into the
+            // arena (below) -- that is this server's own bookkeeping, in program order in front of its next request, and it
+            // now runs while the answer travels ----
+            served++;
+            serve_seq = (serve_seq + 1u) & 0x7fffffffu;
+            if (lane < T) const_cast<volatile unsigned char *>(reinterpret_cast<volatile unsigned char *>(sv.ans))[lane] = my_flag;
+            // (round 6: the ring rows were written THROUGH, agent scope; what is left to do before the sequence number goes out is to
+            //  wait for those stores and the flags -- a system-scope fence here was an L2 write-back per request)
+#if EVS_X_SERVE_FENCE == 1      // developer A/B: the round-5 form, a system-scope fence
+            __threadfence_system();
+#elif EVS_X_SERVE_FENCE == 2    // agent-scope fence
+            __threadfence();
+#else
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#endif
+#if EVS_X_SERVE_FENCE == 0
+            if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 16, serve_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (behind the wait above; a release here would be the write-back again)
+#else
+            if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 16, serve_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+        }
         {   // every new entry's row, table -> arena: lane i moves table i's (one round trip for all of them; it was one key
             // check and one byte-wise row copy after the other)
             const int i = fill_i;
@@ -812,27 +865,6 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
         __threadfence_block();   // (the rows are read back by this block only: a workgroup-scope fence; an agent-scope one is an L2 write-back per request, tools/atomic_probe.hip)
         EVS_WSYNC();
         EVS_TICK(5);                    // (the new entries' rows)
-        if constexpr (SERVE) {
-            // ---- the answer: hit flags, then (behind a fence that also puts the ring rows where every later launch sees
-            // them) the sequence number the host is polling for ----
-            served++;
-            serve_seq = (serve_seq + 1u) & 0x7fffffffu;
-            if (lane < T) const_cast<volatile unsigned char *>(reinterpret_cast<volatile unsigned char *>(sv.ans))[lane] = my_flag;
-            // (round 6: the ring rows were written THROUGH, agent scope; what is left to do before the sequence number goes out is to
-            //  wait for those stores and the flags -- a system-scope fence here was an L2 write-back per request)
-#if EVS_X_SERVE_FENCE == 1      // developer A/B: the round-5 form, a system-scope fence
-            __threadfence_system();
-#elif EVS_X_SERVE_FENCE == 2    // agent-scope fence
-            __threadfence();
-#else
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-#endif
-#if EVS_X_SERVE_FENCE == 0
-            if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 16, serve_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (behind the wait above; a release here would be the write-back again)
-#else
-            if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 16, serve_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
-        }
     }
 
 #ifdef EVS_X_EXACT_TIMING
@@ -2970,6 +3002,11 @@ struct evs_cache {
     unsigned char *arena_create = nullptr;   // the one-row-per-entry arena evs_cache_create made (freed when sa_arena replaces it)
     // the exact policy as a resident server (evs_cache_serve_*): a mailbox in mapped host memory, its own stream
     unsigned *mbox = nullptr, *mbox_dev = nullptr;   // 3 lines of 128 bytes: request, control, answer
+    // (Round 6 tried the request + control lines in DEVICE memory, written by the host through the large-BAR aperture:
+    //  tools/mailbox_probe.hip's bare echo makes a round trip in 1.8 us against 2.4, the server's p50 did not move -- 14.3-14.9
+    //  against 14.4-14.8 us over four runs each --, so the lines stay where an ordinary store reaches them.)
+    volatile unsigned *req_host = nullptr;           // the host's view of the request + control lines
+    unsigned *req_dev = nullptr;                     // the device's
     hipStream_t serve_stream = nullptr;
     bool serving = false;
     unsigned serve_seq = 0;
@@ -3109,7 +3146,8 @@ extern "C" int evs_cache_destroy(evs_cache *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->mbox) {
-        c->mbox[32] = 1u;   // stop
+        c->req_host[32] = 1u;   // stop
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
         if (c->serve_stream) { (void)hipStreamSynchronize(c->serve_stream); (void)hipStreamDestroy(c->serve_stream); }
         (void)hipHostFree(c->mbox);
     }
@@ -3306,7 +3344,7 @@ static void serve_launch(evs_cache *c) {
     for (int k = 0; k < kMaxTables; k++) { args.backing[k] = c->backing[k]; args.backing_rows[k] = c->backing_rows[k]; }
     args.requests = nullptr; args.out = nullptr; args.hit = nullptr; args.B = 0; args.approx_thres = c->serve_thres;
     ServeArgs sv;
-    sv.req = c->mbox_dev; sv.ctl = c->mbox_dev + 32; sv.ans = c->mbox_dev + 64;
+    sv.req = c->req_dev; sv.ctl = c->req_dev + 32; sv.ans = c->mbox_dev + 64;
     sv.ring = c->serve_ring; sv.n_slots = c->serve_slots; sv.idle_ticks = c->serve_idle_ticks;
     // an exact-path launch of the caller's (evs_cache_request, evs_cache_request_c1c2[c3]) may still be running on ITS stream:
     // the server starts behind it
@@ -3327,9 +3365,11 @@ static int serve_pause(evs_cache *c) {
     if (!c || !c->mbox || !c->serve_stream) return EVS_OK;
     if (hipStreamQuery(c->serve_stream) == hipSuccess) return EVS_OK;   // nothing running
     (void)hipGetLastError();
-    reinterpret_cast<volatile unsigned *>(c->mbox)[32] = 1u;
+    c->req_host[32] = 1u;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
     const hipError_t e = hipStreamSynchronize(c->serve_stream);
-    reinterpret_cast<volatile unsigned *>(c->mbox)[32] = 0u;
+    c->req_host[32] = 0u;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
     return e == hipSuccess ? EVS_OK : EVS_EHIP;
 }
 extern "C" int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring, int n_slots, int64_t idle_us) {
@@ -3344,6 +3384,7 @@ extern "C" int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring
         EVS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->mbox), 3 * 128, hipHostMallocMapped));
         memset(c->mbox, 0, 3 * 128);
         EVS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->mbox_dev), c->mbox, 0));
+        c->req_host = c->mbox; c->req_dev = c->mbox_dev;
         // a stream of the highest priority: streams share a handful of hardware queues, round-robin per priority level, and a
         // queue runs its commands in order -- a copy or a kernel of the caller's that lands on the queue of the resident server
         // waits until the server goes home idle (measured through the plug-in loop: 299 us per request instead of 104 once a
@@ -3384,7 +3425,7 @@ extern "C" int evs_cache_serve_request_dev(evs_cache *c, const int64_t *ids_dev,
 static int serve_request_impl(evs_cache *c, const int32_t *rows, const int64_t *ids_dev, int64_t ids_stride, uint8_t *hit, int *slot_out) {
     using namespace evs;
     if (!c->serving) { set_error("evs_cache_serve_request: call evs_cache_serve_start first"); return EVS_ESTATE; }
-    volatile unsigned *req = c->mbox, *ans = c->mbox + 64;
+    volatile unsigned *req = c->req_host, *ans = c->mbox + 64;
     const int T = c->host.n_tables;
     const unsigned want = (c->serve_seq + 1u) & 0x7fffffffu;
     // the ring slot this request's rows go to: whoever still READS it (evs_cache_serve_consumed) finishes first
