@@ -315,6 +315,8 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
     __shared__ unsigned s_touch[32];     // TouchMap::bits of the request in hand (EvLFU)
     // the tables' addresses and row counts out of LDS (round 6): indexed by a lane's table they were reads of the kernel arguments
     // -- a vector-memory round trip -- inside every request's row stage
+    __shared__ const unsigned char *s_fsrc[kMaxTables];   // the request's new entries in table order: where their row comes from ...
+    __shared__ unsigned char *s_fdst[kMaxTables];         // ... and where it goes (nullptr: evicted again within the request)
     __shared__ const unsigned char *s_back[kMaxTables];
     __shared__ long long s_brows[kMaxTables];
     const int lane = threadIdx.x;
@@ -330,6 +332,14 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
     for (int b = lane; b < kMaxBuckets; b += 64) { h.head[b] = gs->head[b]; h.tail[b] = gs->tail[b]; h.len[b] = gs->len[b]; }
     for (int k = lane; k < kMaxTables; k += 64) { s_back[k] = args.backing[k]; s_brows[k] = args.backing_rows[k]; }
     EVS_WSYNC();
+    // the chunk new entries' rows are moved in (table -> arena): 16 bytes when the row length, the arena and every table's base
+    // are multiples of 16, else 4, else 0 = byte by byte
+    static_assert(kMaxTables <= 64, "one lane per table");
+    const unsigned long long align_bits = (unsigned long long)(unsigned)rb | (unsigned long long)reinterpret_cast<uintptr_t>(a.arena) |
+                                          (lane < T ? (unsigned long long)reinterpret_cast<uintptr_t>(s_back[lane]) : 0ull);
+    const int fill_cs = __ballot((align_bits & 15ull) != 0ull) == 0ull ? 16 : (__ballot((align_bits & 3ull) != 0ull) == 0ull ? 4 : 0);
+    const int fill_cpr = fill_cs ? rb / fill_cs : 1;            // chunks per row
+    const float fill_inv_cpr = 1.0f / (float)fill_cpr;          // (chunk index -> row of the list: exact for the 256 chunks it is used on)
     long long n_hits = 0, n_perfect_hits = 0;
     unsigned warm_acc = 0u;            // (what the row warm-up loads return: kept alive to the kernel's end, never meaningful)
 #if EVS_X_EXACT_STOP == 1
@@ -728,21 +738,41 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
 #endif
         // Round 6: the rows of the NEW entries (table -> arena, below) are asked for here, with the rows that go out -- one round
         // trip for both; their stores stay behind the out stream (an entry a later key of this request evicted and refilled may
-        // still be the source of an earlier hit's row).  16-byte aligned rows of at most 256 bytes; the rest below as before.
-        const int fill_i = lane < T ? lane : 0;
-        const int fill_e = lane < T ? s_fill[fill_i] : -1;
-        const unsigned char *fill_src = s_back[fill_i] + (long long)s_req[fill_i] * rb;
-        unsigned char *fill_dst = a.arena + (long long)(fill_e >= 0 ? fill_e : 0) * rb;
-        // (the wave-uniform half of the condition decides whether there are loads at all, the per-lane half only WHERE a lane
-        // reads: a lane with nothing to move reads the arena's first row and drops it -- no load sits behind a divergent branch)
-        const bool fill_fast = rb <= 256 && ((rb | (int)reinterpret_cast<uintptr_t>(a.arena)) & 15) == 0;
-        const bool fill_early = fill_fast && fill_e >= 0 && (reinterpret_cast<uintptr_t>(fill_src) & 15) == 0;
-        uint4 fill_r[16];
-        if (fill_fast) {
-            const unsigned char *fp = fill_early ? fill_src : a.arena;
+        // still be the source of an earlier hit's row).  ALL lanes move them, a chunk (16 or 4 bytes, what rows and bases are
+        // aligned to) each: the new entries are listed (source, destination) in table order, chunk c of the list's j-th row is
+        // lane (j * chunks_per_row + c) mod 64's.  (The first form -- lane t moved table t's row, nine 16-byte loads each -- kept
+        // its registers in scratch and waited for every load before the next: ~2 of a request's 8 us.)
+        const int fe_t = lane < T ? s_fill[lane] : -1;
+        const unsigned long long fill_mask = __ballot(fe_t >= 0);
+        const int n_fill = __popcll(fill_mask);
+        const int fill_rank = __popcll(fill_mask & ((1ull << lane) - 1ull));
+        if (fe_t >= 0) {
+            s_fsrc[fill_rank] = s_back[lane] + (long long)s_req[lane] * rb;
+            s_fdst[fill_rank] = a.arena + (long long)fe_t * rb;
+        }
+        EVS_WSYNC();
+        const int n_chunks = fill_cs ? n_fill * fill_cpr : 0;
+        uint4 fill_q[2];
+        unsigned fill_w[4];
+        const unsigned char *const fill_dummy = a.arena;   // (what a lane with no chunk reads: 16 valid, aligned bytes)
+        if (fill_cs == 16) {
 #pragma unroll
-            for (int c = 0; c < 16; c++)
-                if (c * 16 < rb) fill_r[c] = *reinterpret_cast<const uint4 *>(fp + c * 16);
+            for (int k = 0; k < 2; k++) {
+                const int idx = lane + 64 * k;
+                const int j = __float2int_rz(((float)idx + 0.5f) * fill_inv_cpr);
+                const bool on = idx < n_chunks;
+                const unsigned char *sp = on ? s_fsrc[on ? j : 0] + (idx - j * fill_cpr) * 16 : fill_dummy;
+                fill_q[k] = *reinterpret_cast<const uint4 *>(sp);
+            }
+        } else if (fill_cs == 4) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int idx = lane + 64 * k;
+                const int j = __float2int_rz(((float)idx + 0.5f) * fill_inv_cpr);
+                const bool on = idx < n_chunks;
+                const unsigned char *sp = on ? s_fsrc[on ? j : 0] + (idx - j * fill_cpr) * 4 : fill_dummy;
+                fill_w[k] = *reinterpret_cast<const unsigned *>(sp);
+            }
         }
         // ... and the T*d elements leave as one flat, independent stream (not T dependent row trips).  Round 6: sixteen elements
         // per lane are asked for before the first is looked at -- the loop over idx was one dependent element load per trip, 15
@@ -839,27 +869,44 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
             if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + 16, serve_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
         }
-        {   // every new entry's row, table -> arena: lane i moves table i's (one round trip for all of them; it was one key
-            // check and one byte-wise row copy after the other)
-            const int i = fill_i;
-            const int fe = fill_e;
-            // the entry may already have been evicted again by a later key of this request (only if this request evicted at all)
-            const unsigned long long ki = ((unsigned long long)(i + 1) << 32) | (unsigned)s_req[i];
-            const bool mine = fe >= 0 && (!churn || ld(&a.ekey[fe >= 0 ? fe : 0]) == ki);
-            if (mine && fill_early) {
+        {   // every new entry's row, table -> arena
+            // the entry may already have been evicted again by a later key of this request (only if this request evicted at all):
+            // its row is not written then
+            if (churn) {
+                const unsigned long long ki = ((unsigned long long)(lane + 1) << 32) | (unsigned)s_req[lane < T ? lane : 0];
+                if (fe_t >= 0 && ld(&a.ekey[fe_t]) != ki) s_fdst[fill_rank] = nullptr;
+                EVS_WSYNC();
+            }
+            if (fill_cs == 16) {
 #pragma unroll
-                for (int c = 0; c < 16; c++)
-                    if (c * 16 < rb) *reinterpret_cast<uint4 *>(fill_dst + c * 16) = fill_r[c];
-            } else if (mine) {
-                const unsigned char *rowp = s_back[i] + (long long)s_req[i] * rb;
-                unsigned char *dst = a.arena + (long long)fe * rb;
-                if (((rb | (int)(reinterpret_cast<uintptr_t>(rowp) | reinterpret_cast<uintptr_t>(dst))) & 15) == 0) {
-                    for (int c = 0; c < rb; c += 16) *reinterpret_cast<uint4 *>(dst + c) = *reinterpret_cast<const uint4 *>(rowp + c);
-                } else if (((rb | (int)(reinterpret_cast<uintptr_t>(rowp) | reinterpret_cast<uintptr_t>(dst))) & 3) == 0) {
-                    for (int c = 0; c < rb; c += 4) *reinterpret_cast<unsigned *>(dst + c) = *reinterpret_cast<const unsigned *>(rowp + c);
-                } else {
-                    for (int c = 0; c < rb; c++) dst[c] = rowp[c];
+                for (int k = 0; k < 2; k++) {
+                    const int idx = lane + 64 * k;
+                    const int j = __float2int_rz(((float)idx + 0.5f) * fill_inv_cpr);
+                    unsigned char *dp = idx < n_chunks ? s_fdst[idx < n_chunks ? j : 0] : nullptr;
+                    if (dp) *reinterpret_cast<uint4 *>(dp + (idx - j * fill_cpr) * 16) = fill_q[k];
                 }
+                for (int idx = lane + 128; idx < n_chunks; idx += 64) {    // (more than 128 chunks: the rest one at a time)
+                    const int j = idx / fill_cpr, c = idx - j * fill_cpr;
+                    unsigned char *dp = s_fdst[j];
+                    if (dp) *reinterpret_cast<uint4 *>(dp + c * 16) = *reinterpret_cast<const uint4 *>(s_fsrc[j] + c * 16);
+                }
+            } else if (fill_cs == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int idx = lane + 64 * k;
+                    const int j = __float2int_rz(((float)idx + 0.5f) * fill_inv_cpr);
+                    unsigned char *dp = idx < n_chunks ? s_fdst[idx < n_chunks ? j : 0] : nullptr;
+                    if (dp) *reinterpret_cast<unsigned *>(dp + (idx - j * fill_cpr) * 4) = fill_w[k];
+                }
+                for (int idx = lane + 256; idx < n_chunks; idx += 64) {
+                    const int j = idx / fill_cpr, c = idx - j * fill_cpr;
+                    unsigned char *dp = s_fdst[j];
+                    if (dp) *reinterpret_cast<unsigned *>(dp + c * 4) = *reinterpret_cast<const unsigned *>(s_fsrc[j] + c * 4);
+                }
+            } else if (fe_t >= 0 && s_fdst[fill_rank]) {   // rows or bases not even 4-byte aligned: lane t moves table t's, a byte at a time
+                const unsigned char *rowp = s_fsrc[fill_rank];
+                unsigned char *dst = s_fdst[fill_rank];
+                for (int c = 0; c < rb; c++) dst[c] = rowp[c];
             }
         }
         __threadfence_block();   // (the rows are read back by this block only: a workgroup-scope fence; an agent-scope one is an L2 write-back per request, tools/atomic_probe.hip)
