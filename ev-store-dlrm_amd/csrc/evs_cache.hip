@@ -828,8 +828,10 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
 #pragma unroll
                 for (int k = 0; k < 16; k++) val[k] = kU4Lut[(col[k] & 1) ? (r_[k] & 15u) : (r_[k] >> 4)];
             }
-#ifdef EVS_X_ROWS_TIMING
+#ifndef EVS_X_NO_ROWS_WAIT
             __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+#ifdef EVS_X_ROWS_TIMING
             EVS_TICK(7);
 #endif
 #pragma unroll
