@@ -110,6 +110,7 @@ _PROTOS = {
     "evs_cache_serve_start": (_int, [_vp, _int, _vp, _int, _i64]),
     "evs_cache_serve_request": (_int, [_vp, _vp, _vp, C.POINTER(C.c_int)]),
     "evs_cache_serve_request_dev": (_int, [_vp, _vp, _i64, _vp, C.POINTER(C.c_int)]),
+    "evs_cache_serve_request_to": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "evs_cache_serve_consumed": (_int, [_vp, _int, _vp]),
     "evs_cache_set_inline_update": (_int, [_vp, _int]),
     "evs_cache_serve_stop": (_int, [_vp]),

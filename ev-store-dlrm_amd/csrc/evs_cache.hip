@@ -304,6 +304,7 @@ struct ServeArgs {
 // workgroup-scope release: s_waitcnt vmcnt(0) in front of every one of them, i.e. the wave waited for its own STORES to be
 // acknowledged three to four times per request (round 6: ~2.5 of a request's 10 us).
 #define EVS_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <bool SERVE>
 __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const ServeArgs &sv) {
     __shared__ Hot h;
@@ -388,8 +389,13 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                 const long long *ip = reinterpret_cast<const long long *>((uintptr_t)pa) + (long long)(lane < T ? lane : 0) * stride;
                 row = (int)__hip_atomic_load(ip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // ... and, round 6 (evs_cache_serve_request_to), where the rows go: a DEVICE address of the caller's (words 3, 4 beside
+            // an id address; words 29, 30 -- the ids of tables 26, 27 -- beside ids when T <= 26), 0 = this request's ring slot
+            unsigned long long out_a = 0ull;
+            if (((unsigned)rl((int)word, 7) >> 31) != 0u) out_a = ((unsigned long long)(unsigned)rl((int)word, 4) << 32) | (unsigned)rl((int)word, 3);
+            else if (T <= 26) out_a = ((unsigned long long)(unsigned)rl((int)word, 30) << 32) | (unsigned)rl((int)word, 29);
             if (lane >= T) row = 0;
-            out = sv.ring + (long long)(want % (unsigned)sv.n_slots) * T * d;
+            out = out_a ? reinterpret_cast<float *>((uintptr_t)out_a) : sv.ring + (long long)(want % (unsigned)sv.n_slots) * T * d;
             hitp = nullptr;   // (flags go to the answer line, below)
         } else {
             row = lane < T ? args.requests[rq * T + lane] : 0;   // the only read of the ids (they may live in host memory)
@@ -752,7 +758,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
         }
         EVS_WSYNC();
         const int n_chunks = fill_cs ? n_fill * fill_cpr : 0;
-        uint4 fill_q[2];
+        u32x4_t fill_q[2];   // (a plain vector type: an array of HIP's uint4 -- a struct of unions -- is kept in scratch, with a wait per load)
         unsigned fill_w[4];
         const unsigned char *const fill_dummy = a.arena;   // (what a lane with no chunk reads: 16 valid, aligned bytes)
         if (fill_cs == 16) {
@@ -762,7 +768,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                 const int j = __float2int_rz(((float)idx + 0.5f) * fill_inv_cpr);
                 const bool on = idx < n_chunks;
                 const unsigned char *sp = on ? s_fsrc[on ? j : 0] + (idx - j * fill_cpr) * 16 : fill_dummy;
-                fill_q[k] = *reinterpret_cast<const uint4 *>(sp);
+                fill_q[k] = *reinterpret_cast<const u32x4_t *>(sp);
             }
         } else if (fill_cs == 4) {
 #pragma unroll
@@ -885,12 +891,12 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                     const int idx = lane + 64 * k;
                     const int j = __float2int_rz(((float)idx + 0.5f) * fill_inv_cpr);
                     unsigned char *dp = idx < n_chunks ? s_fdst[idx < n_chunks ? j : 0] : nullptr;
-                    if (dp) *reinterpret_cast<uint4 *>(dp + (idx - j * fill_cpr) * 16) = fill_q[k];
+                    if (dp) *reinterpret_cast<u32x4_t *>(dp + (idx - j * fill_cpr) * 16) = fill_q[k];
                 }
                 for (int idx = lane + 128; idx < n_chunks; idx += 64) {    // (more than 128 chunks: the rest one at a time)
                     const int j = idx / fill_cpr, c = idx - j * fill_cpr;
                     unsigned char *dp = s_fdst[j];
-                    if (dp) *reinterpret_cast<uint4 *>(dp + c * 16) = *reinterpret_cast<const uint4 *>(s_fsrc[j] + c * 16);
+                    if (dp) *reinterpret_cast<u32x4_t *>(dp + c * 16) = *reinterpret_cast<const u32x4_t *>(s_fsrc[j] + c * 16);
                 }
             } else if (fill_cs == 4) {
 #pragma unroll
@@ -3457,11 +3463,24 @@ extern "C" int evs_cache_serve_start(evs_cache *c, int approx_thres, float *ring
 }
 // one request (T row ids on the host) -> T hit flags on the host, the T x d fp32 rows in slot *slot_out of the ring (device).
 // Blocks until the server has answered (no launch, no copy, no synchronise: two cache-line hand-overs over the bus).
-static int serve_request_impl(evs_cache *c, const int32_t *rows, const int64_t *ids_dev, int64_t ids_stride, uint8_t *hit, int *slot_out);
+static int serve_request_impl(evs_cache *c, const int32_t *rows, const int64_t *ids_dev, int64_t ids_stride, float *out_dev, uint8_t *hit, int *slot_out);
 extern "C" int evs_cache_serve_request(evs_cache *c, const int32_t *rows, uint8_t *hit, int *slot_out) {
     using namespace evs;
     EVS_REQUIRE(c && rows && hit && slot_out, "evs_cache_serve_request: NULL argument");
-    return serve_request_impl(c, rows, nullptr, 0, hit, slot_out);
+    return serve_request_impl(c, rows, nullptr, 0, nullptr, hit, slot_out);
+}
+// the same request with the rows delivered to a DEVICE buffer of the caller's (T x d floats) instead of a ring slot: no copy out
+// of the ring, nothing to hand back (evs_cache_serve_consumed).  Exactly one of rows (host) / ids_dev (device, as
+// evs_cache_serve_request_dev) is given; at most 26 tables.  Nothing orders the server's stores against the caller's streams:
+// out_dev must not be in use by work still pending when this is called (a freshly allocated block of a stream-ordered
+// allocator counts as in use until that stream is idle), and is complete when the call returns.
+extern "C" int evs_cache_serve_request_to(evs_cache *c, const int32_t *rows, const int64_t *ids_dev, int64_t ids_stride, float *out_dev, uint8_t *hit) {
+    using namespace evs;
+    EVS_REQUIRE(c && out_dev && hit && ((rows != nullptr) != (ids_dev != nullptr)) && ids_stride >= 0 && ids_stride < (1ll << 32),
+                "evs_cache_serve_request_to: bad argument");
+    EVS_REQUIRE(c->host.n_tables <= 26, "evs_cache_serve_request_to: at most 26 tables (the line's last two id words carry the address)");
+    int slot = 0;
+    return serve_request_impl(c, rows, ids_dev, ids_stride, out_dev, hit, &slot);
 }
 // the same request with the T row ids given by ADDRESS: ids_dev[t * ids_stride] (int64, device memory: the (T, B) lS_i of the
 // reference's loop as dlrm_wrap left it on the device, element 0 of each row, dlrm_s_pytorch_C1.py:236-239) -- the server reads
@@ -3469,9 +3488,9 @@ extern "C" int evs_cache_serve_request(evs_cache *c, const int32_t *rows, uint8_
 extern "C" int evs_cache_serve_request_dev(evs_cache *c, const int64_t *ids_dev, int64_t ids_stride, uint8_t *hit, int *slot_out) {
     using namespace evs;
     EVS_REQUIRE(c && ids_dev && hit && slot_out && ids_stride >= 0 && ids_stride < (1ll << 32), "evs_cache_serve_request_dev: bad argument");
-    return serve_request_impl(c, nullptr, ids_dev, ids_stride, hit, slot_out);
+    return serve_request_impl(c, nullptr, ids_dev, ids_stride, nullptr, hit, slot_out);
 }
-static int serve_request_impl(evs_cache *c, const int32_t *rows, const int64_t *ids_dev, int64_t ids_stride, uint8_t *hit, int *slot_out) {
+static int serve_request_impl(evs_cache *c, const int32_t *rows, const int64_t *ids_dev, int64_t ids_stride, float *out_dev, uint8_t *hit, int *slot_out) {
     using namespace evs;
     if (!c->serving) { set_error("evs_cache_serve_request: call evs_cache_serve_start first"); return EVS_ESTATE; }
     volatile unsigned *req = c->req_host, *ans = c->mbox + 64;
@@ -3479,19 +3498,22 @@ static int serve_request_impl(evs_cache *c, const int32_t *rows, const int64_t *
     const unsigned want = (c->serve_seq + 1u) & 0x7fffffffu;
     // the ring slot this request's rows go to: whoever still READS it (evs_cache_serve_consumed) finishes first
     const int slot = (int)(want % (unsigned)c->serve_slots);
-    if (c->slot_busy[(size_t)slot]) {
+    if (!out_dev && c->slot_busy[(size_t)slot]) {
         EVS_HIP_CHECK(hipEventSynchronize(c->slot_done[(size_t)slot]));
         c->slot_busy[(size_t)slot] = 0;
     }
     c->serve_seq = want;
+    const unsigned long long oa = (unsigned long long)reinterpret_cast<uintptr_t>(out_dev);
     // seven ids and a guard per 32-byte sector: whatever granularity the bus delivers the line in, ids are accepted only from
     // a sector whose guard (written after them) holds the number awaited
     unsigned guard = want;
     if (rows) {
         for (int t = 0; t < T; t++) req[t + t / 7] = (unsigned)rows[t];
-    } else {   // by address: words 0..2, and bit 31 of the guards says so
+        if (T <= 26) { req[29] = (unsigned)oa; req[30] = (unsigned)(oa >> 32); }   // (the id words of tables 26, 27: where the rows go, 0 = the ring)
+    } else {   // by address: words 0..2 (3, 4: where the rows go), and bit 31 of the guards says so
         const unsigned long long pa = (unsigned long long)reinterpret_cast<uintptr_t>(ids_dev);
         req[0] = (unsigned)pa; req[1] = (unsigned)(pa >> 32); req[2] = (unsigned)ids_stride;
+        req[3] = (unsigned)oa; req[4] = (unsigned)(oa >> 32);
         guard |= 0x80000000u;
     }
     __atomic_thread_fence(__ATOMIC_RELEASE);
@@ -3521,7 +3543,7 @@ static int serve_request_impl(evs_cache *c, const int32_t *rows, const int64_t *
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const volatile unsigned char *fl = reinterpret_cast<const volatile unsigned char *>(ans);
     for (int t = 0; t < T; t++) hit[t] = fl[t];
-    *slot_out = slot;
+    *slot_out = out_dev ? -1 : slot;
     return EVS_OK;
 }
 // The caller has ENQUEUED its reads of ring slot `slot` (a copy, a kernel) on `stream`: the slot is handed out again only

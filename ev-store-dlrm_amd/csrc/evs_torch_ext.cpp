@@ -324,23 +324,35 @@ static void first_ids(const at::Tensor &lS_i_in, int T, int32_t (&ids)[64]) {
 py::tuple serve_request_list(int64_t handle, const at::Tensor &lS_i_in, const at::Tensor &ring, int T, int d) {
     uint8_t hit[64];
     int slot = 0;
-    if (lS_i_in.is_cuda() && lS_i_in.scalar_type() == at::kLong && lS_i_in.dim() >= 1 && lS_i_in.size(0) == T && lS_i_in.numel() >= T &&
-        lS_i_in.device() == ring.device()) {
-        // the ids stay where dlrm_wrap put them: the server reads element 0 of each row by address (no copy back, no staging).
-        // Whatever wrote lS_i ran on this stream: it has to have finished (the reference's own copies from pageable memory have)
-        hipStream_t st = c10::hip::getCurrentHIPStream(lS_i_in.device().index()).stream();
-        if (hipStreamQuery(st) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); }
-        check(evs_cache_serve_request_dev(reinterpret_cast<evs_cache *>(handle), lS_i_in.data_ptr<int64_t>(), lS_i_in.stride(0), hit, &slot));
-    } else {
-        int32_t ids[64];
-        first_ids(lS_i_in, T, ids);
-        check(evs_cache_serve_request(reinterpret_cast<evs_cache *>(handle), ids, hit, &slot));
-    }
-    TORCH_CHECK(ring.dim() == 3 && slot >= 0 && slot < ring.size(0) && ring.size(1) == T && ring.size(2) == d, "ring slot out of range");
+    evs_cache *c = reinterpret_cast<evs_cache *>(handle);
+    const bool by_address = lS_i_in.is_cuda() && lS_i_in.scalar_type() == at::kLong && lS_i_in.dim() >= 1 && lS_i_in.size(0) == T &&
+                            lS_i_in.numel() >= T && lS_i_in.device() == ring.device();
     c10::hip::HIPGuard guard(ring.device().index());
-    at::Tensor block = ring.select(0, slot).clone().unsqueeze(1);
-    // the copy above is only ENQUEUED: the slot is handed out again (and overwritten by the server, in host order) only after it has run
-    check(evs_cache_serve_consumed(reinterpret_cast<evs_cache *>(handle), slot, c10::hip::getCurrentHIPStream(ring.device().index()).stream()));
+    hipStream_t st = c10::hip::getCurrentHIPStream(ring.device().index()).stream();
+    // Whatever wrote lS_i ran on this stream, and whatever last used the block allocated below was ordered on it: both have to
+    // have finished before the server -- on a stream of its own, ordered by nothing -- reads the one and writes the other
+    // (the reference's own copies from pageable memory have)
+    int32_t ids[64];
+    if (!by_address) first_ids(lS_i_in, T, ids);
+    bool idle = hipStreamQuery(st) == hipSuccess;
+    if (!idle) {
+        (void)hipGetLastError();
+        if (by_address) { (void)hipStreamSynchronize(st); idle = true; }
+    }
+    at::Tensor block;
+    if (T <= 26 && idle) {
+        // round 6: the server writes the rows INTO the fresh block (no copy out of a ring slot, no event behind it)
+        block = at::empty({T, 1, d}, ring.options());
+        check(evs_cache_serve_request_to(c, by_address ? nullptr : ids, by_address ? lS_i_in.data_ptr<int64_t>() : nullptr,
+                                         by_address ? lS_i_in.stride(0) : 0, block.data_ptr<float>(), hit));
+    } else {
+        if (by_address) check(evs_cache_serve_request_dev(c, lS_i_in.data_ptr<int64_t>(), lS_i_in.stride(0), hit, &slot));
+        else check(evs_cache_serve_request(c, ids, hit, &slot));
+        TORCH_CHECK(ring.dim() == 3 && slot >= 0 && slot < ring.size(0) && ring.size(1) == T && ring.size(2) == d, "ring slot out of range");
+        block = ring.select(0, slot).clone().unsqueeze(1);
+        // the copy above is only ENQUEUED: the slot is handed out again (and overwritten by the server, in host order) only after it has run
+        check(evs_cache_serve_consumed(c, slot, st));
+    }
     py::list flags;
     bool all = true;
     for (int k = 0; k < T; k++) { flags.append(py::bool_(hit[k] != 0)); all = all && hit[k]; }

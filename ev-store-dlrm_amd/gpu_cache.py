@@ -209,6 +209,22 @@ class GpuCache:
             _lib.check(rc)
         return self._srv_hit, self._srv_views[self._srv_slot.value]
 
+    def serve_request_to(self, row_ids, out):
+        """the same request with the rows written by the server into `out` (a contiguous (T, dim) fp32 DEVICE tensor of the
+        caller's, not in use by pending work) instead of a ring slot; row_ids: n_tables ints on the host, or a (T, ...) int64
+        device tensor whose element 0 of each row is the id (the reference's lS_i on the GPU).  -> hit flags (numpy uint8 view)"""
+        if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.n_tables * self.dim):
+            raise ValueError("out must be a contiguous fp32 device tensor of %d elements" % (self.n_tables * self.dim))
+        L = _lib.lib()
+        if torch.is_tensor(row_ids) and row_ids.is_cuda:
+            if row_ids.dtype != torch.int64 or row_ids.shape[0] != self.n_tables:
+                raise ValueError("device ids: a (T, ...) int64 tensor")
+            _lib.check(L.evs_cache_serve_request_to(self._h, None, row_ids.data_ptr(), int(row_ids.stride(0)), out.data_ptr(), self._srv_hit.ctypes.data))
+        else:
+            self._srv_rows[:] = row_ids
+            _lib.check(L.evs_cache_serve_request_to(self._h, self._srv_rows.ctypes.data, None, 0, out.data_ptr(), self._srv_hit.ctypes.data))
+        return self._srv_hit
+
     def serve_consumed(self, slot=None, stream=None):
         """the reads of ring slot `slot` (default: the last request's) have been enqueued on `stream` (default: the current one)"""
         st = torch.cuda.current_stream(self.device) if stream is None else stream

@@ -382,6 +382,13 @@ EVS_API int evs_cache_serve_request(evs_cache *c, const int32_t *rows_host, uint
  * with lS_i.cpu(), dlrm_s_pytorch_C1.py:233-239: a copy and a synchronise per request).  The server reads the ids itself; they
  * must be complete when the call is made. */
 EVS_API int evs_cache_serve_request_dev(evs_cache *c, const int64_t *ids_dev, int64_t ids_stride, uint8_t *hit_host, int *slot_out);
+/* ... with the rows delivered to a DEVICE buffer of the caller's (out_dev: T x dim floats) instead of a ring slot (round 6): what
+ * the reference's loop wants is a fresh tensor per request (EvLFU_C1.py:157-161 builds 26 of them), and copying the slot into
+ * one was a launch and an event per request.  Exactly one of rows_host / ids_dev (+ ids_stride, as above) is given; at most 26
+ * tables (the address rides in the line's last two id words).  Nothing orders the server's stores against the caller's
+ * streams: out_dev must not be in use by work still pending when the call is made (a block a stream-ordered allocator has just
+ * handed out counts as in use until that stream is idle), and holds the rows when the call returns. */
+EVS_API int evs_cache_serve_request_to(evs_cache *c, const int32_t *rows_host, const int64_t *ids_dev, int64_t ids_stride, float *out_dev, uint8_t *hit_host);
 EVS_API int evs_cache_serve_consumed(evs_cache *c, int slot, void *stream);
 EVS_API int evs_cache_serve_stop(evs_cache *c);
 /* Batched EvLFU lookup with snapshot semantics (the throughput path; no reference counterpart --

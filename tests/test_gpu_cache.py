@@ -138,6 +138,48 @@ def test_resident_server_gives_the_golden_traces(E, orc, policy, cap, key):
     assert st["n_requests"] == len(reqs) and st["n_hits"] == int(want.sum())
 
 
+@pytest.mark.parametrize("policy,cap,key", [("evlfu", 768, "evlfu_cap768"), ("evlfu", 80, "evlfu_cap80"), ("lru", 64, "lru_cap64")])
+def test_resident_server_rows_into_the_callers_buffer(E, orc, policy, cap, key):
+    """Round 6: evs_cache_serve_request_to -- the server writes a request's rows into a device buffer of the caller's instead of
+    a ring slot (what the plug-in loop wants: a fresh tensor per request, no copy out of the ring), ids by value or by address
+    (an int64 device tensor, element 0 of each row).  Mixed with ring requests on one cache over the imported reference's
+    traces: hit flags and rows bit-exact whichever way a request is posted."""
+    t = load_golden("cache_traces")
+    tabs = _tables(orc, t)
+    reqs = t["requests_flush"] if cap == 80 else t["requests"]
+    want = _unpack(t[key + "_hits"], len(reqs))
+    c = E.GpuCache(policy, cap, 26, 36, 32, "python")
+    c.set_backing([torch.from_numpy(x).cuda() for x in tabs])
+    c.serve_start(n_slots=3, idle_us=300)
+    for i, rq in enumerate(reqs):
+        way = i % 3
+        if way == 0:
+            hit, rows = c.serve_request(rq)
+        elif way == 1:
+            rows = torch.full((26, 36), -7.0, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            hit = c.serve_request_to(rq, rows)
+        else:
+            ids = torch.from_numpy(np.stack([rq.astype(np.int64), np.full(26, -1, np.int64)], 1)).cuda()   # (T, 2): element 0 is the id
+            rows = torch.full((26, 1, 36), -7.0, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            hit = c.serve_request_to(ids, rows)
+        assert np.array_equal(hit.astype(bool), want[i]), (i, way)
+        if i % 31 < 3 or i < 9:
+            got = rows.reshape(26, 36).cpu().numpy()
+            for k in range(26):
+                assert np.array_equal(got[k], tabs[k][rq[k]]), (i, way, k)
+    c.serve_stop()
+    st = c.stats()
+    assert st["n_requests"] == len(reqs) and st["n_hits"] == int(want.sum())
+    c27 = E.GpuCache(policy, cap, 27, 36, 32, "python")     # the address rides in the id words of tables 26 and 27
+    c27.set_backing([torch.from_numpy(tabs[k % 26]).cuda() for k in range(27)])
+    c27.serve_start(n_slots=2, idle_us=100)
+    with pytest.raises(E.EvsError):
+        c27.serve_request_to(np.zeros(27, np.int32), torch.zeros((27, 36), dtype=torch.float32, device="cuda"))
+    c27.serve_stop()
+
+
 def test_evlfu_approx_mode(E, orc):
     t = load_golden("cache_traces")
     tabs = _tables(orc, t)
