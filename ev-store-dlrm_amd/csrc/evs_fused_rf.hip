@@ -1136,21 +1136,25 @@ bool launch_rf(const FusedArgs &a, hipStream_t st) {
 // (post on the host after the producer's stream has been synchronised), and R may be read by anything started after evs_emb_interact_serve_wait has returned.
 constexpr int kSrvSlots = 64;
 constexpr int kSrvReplicas = 32;
+constexpr unsigned kSrvAnsLine = 32;      // words per slot of the answer ring: one per sub-counter of the batch's arrivals
 struct SrvDesc { unsigned w[16]; };   // w0-1 x, w2-3 idx, w4-5 off, w6 B, w7 seq | w8-9 R, w10 x_stride, w11 first block, w12 idx stride, w13 off stride, w14 -, w15 seq
 struct SrvState {
     unsigned pub[kSrvReplicas][32];       // line r: word 0 = the last published sequence number, word 1 = the generation (launch number) of the grid that has LEFT behind it
     SrvDesc desc[kSrvSlots];              // the leader's copies of the descriptors
-    // per slot: chunks finished -- two levels (a thousand arrivals on ONE word serialise at the memory-side atomic unit: ~6 us,
-    // r04_atomic_probe, and the blocks of a full batch all finish together): chunk c arrives at sub-counter c % 32 (a line each),
-    // whoever completes a sub-counter arrives at the top one (line 32)
-    unsigned arrived[kSrvSlots][33][32];
+    // per slot: chunks finished (a thousand arrivals on ONE word serialise at the memory-side atomic unit: ~6 us,
+    // r04_atomic_probe, and the blocks of a full batch all finish together): chunk c arrives at sub-counter c % 32 (a line each);
+    // whoever completes sub-counter r writes the batch's number into word r of the slot's ANSWER line in host memory, and the
+    // host takes the batch as answered when all of them hold it (the first form had a top counter the 32 completers arrived at:
+    // one more dependent atomic round trip, ~1 us, in front of every answer)
+    unsigned arrived[kSrvSlots][32][32];
 };
 struct SrvArgs {
     const FusedArgs *tmpl;                // tables, shapes (device memory; written before the grid starts, never while it runs)
     SrvState *st;
     volatile unsigned *req;               // request ring (device address of the mapped host block)
     volatile unsigned *ctl;               // word 0: stop
-    volatile unsigned *ans;               // answer ring: kSrvSlots lines of 16 words (word 0 = sequence number done); line kSrvSlots: word 0 = alive, word 1 = the last published number
+    volatile unsigned *ans;               // answer ring: kSrvSlots lines of kSrvAnsLine words (word r = the number of the batch whose sub-counter r is complete);
+                                          // behind them the status line: word 0 = alive, word 1 = the last published number
     unsigned start_seq;                   // the last number published by an earlier run of the grid
     unsigned gen;                         // this launch's number (>= 1): "stop" is the leader writing it into word 1 of the replica lines --
                                           // what an earlier launch left there never matches, so nothing has to be cleared between launches
@@ -1173,22 +1177,19 @@ __device__ __forceinline__ unsigned srv_block_of(unsigned c, unsigned n_chunks, 
 struct SrvPending { unsigned k, c0, step, n_chunks; };
 __device__ __forceinline__ void srv_arrive(const SrvArgs &sv, const SrvPending &p) {
     const unsigned slot = p.k % (unsigned)kSrvSlots, n_chunks = p.n_chunks;
-    bool last = n_chunks == 1u;       // (a batch of one chunk: nobody else to wait for)
-    if (!last) {
-        unsigned tops = 0u;           // sub-counters this block completed
-        for (unsigned c = p.c0; c < n_chunks; c += p.step) {
-            const unsigned r = c & 31u, expect = (n_chunks >> 5) + (r < (n_chunks & 31u) ? 1u : 0u);
-            const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][r][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (before + 1u == expect) { tops++; __hip_atomic_store(&sv.st->arrived[slot][r][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // back to zero for the slot's next use
-        }
-        if (tops) {
-            const unsigned n_sub = n_chunks < 32u ? n_chunks : 32u;
-            const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][32][0], tops, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = before + tops == n_sub;
-            if (last) __hip_atomic_store(&sv.st->arrived[slot][32][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned *ans = const_cast<unsigned *>(sv.ans) + slot * kSrvAnsLine;
+    if (n_chunks == 1u) {             // (a batch of one chunk: nobody else to wait for)
+        __hip_atomic_store(ans, p.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    for (unsigned c = p.c0; c < n_chunks; c += p.step) {
+        const unsigned r = c & 31u, expect = (n_chunks >> 5) + (r < (n_chunks & 31u) ? 1u : 0u);
+        const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][r][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1u == expect) {
+            __hip_atomic_store(&sv.st->arrived[slot][r][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // back to zero for the slot's next use
+            __hip_atomic_store(ans + r, p.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (last) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + slot * 16u, p.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the chunks of one batch that fall to block `me`; -> true: it ran some (pend says which: report them with srv_arrive once the
 // stores are known to be complete)
@@ -1235,7 +1236,7 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
     unsigned my = sv.start_seq;      // the last batch this block has looked at
     SrvPending pend{0u, 0u, 1u, 0u};
     bool have_pend = false;          // (block-uniform) chunks run, their stores possibly still on their way, not yet reported
-    if (me == 0u && threadIdx.x == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // alive
+    if (me == 0u && threadIdx.x == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * kSrvAnsLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // alive
     for (;;) {
         if (threadIdx.x < 64) {
             if (me == 0u) {
@@ -1249,6 +1250,8 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
                     const unsigned slot0 = (my + 1u) % (unsigned)kSrvSlots;
                     const unsigned sl = (slot0 + (unsigned)(lane >> 4)) % (unsigned)kSrvSlots;
                     word = __hip_atomic_load(const_cast<unsigned *>(sv.req) + sl * 16u + (unsigned)(lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // (the control word asked for WITH the ring, not behind it: it was a second round trip over the bus per poll)
+                    const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     // group g holds descriptor my + 1 + g when both its guards say so
                     const unsigned want = my + 1u + (unsigned)(lane >> 4);
                     const unsigned long long gm = __ballot(((lane & 7) == 7) && word == want);   // lanes 7, 15 of every group
@@ -1271,7 +1274,6 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
                         break;
                     }
                     if (have_pend) { pend_only = true; break; }   // nothing new, but chunks to report: the load above has returned, so have this wave's stores
-                    const unsigned stop = __hip_atomic_load(const_cast<unsigned *>(sv.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (stop != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
@@ -1282,7 +1284,7 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
                 unsigned v, sq, gn;
                 for (;;) {
                     v = __hip_atomic_load(my_line + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sq = (unsigned)__shfl((int)v, 0); gn = (unsigned)__shfl((int)v, 1);
+                    sq = (unsigned)__builtin_amdgcn_readlane((int)v, 0); gn = (unsigned)__builtin_amdgcn_readlane((int)v, 1);   // (not __shfl: that is the LDS crossbar)
                     if (sq != my || gn == sv.gen) break;
                     if (have_pend) break;     // nothing new, but chunks to report: the load above has returned, so have this wave's stores
                     __builtin_amdgcn_s_sleep((EVS_X_SRV & 4) ? 16 : 1);
@@ -1342,8 +1344,8 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
         // leaving: every worker sees the stop word behind the last number; the host learns how far the grid got
         if (threadIdx.x < kSrvReplicas) __hip_atomic_store(&st->pub[threadIdx.x][1], sv.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (threadIdx.x == 0) {
-            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16 + 1, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * 16, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * kSrvAnsLine + 1, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * kSrvAnsLine, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -1359,12 +1361,21 @@ struct evs_rf_server {
     unsigned posted = 0;            // the last sequence number posted
     unsigned gen = 0;               // launches of the grid so far
     unsigned next_first = 0;        // the worker the next batch's first chunk goes to
+    unsigned slot_words[evs::kSrvSlots] = {};   // answer words the slot's batch in flight is answered through (min(chunks, 32))
     int n_blocks = 0, T = 0, d = 0;
     long long idle_ticks = 0;
     bool nt2 = false;
 };
 namespace {
-constexpr size_t kSrvReqWords = (size_t)evs::kSrvSlots * 16, kSrvCtlWords = 32, kSrvAnsWords = ((size_t)evs::kSrvSlots + 1) * 16;
+constexpr size_t kSrvReqWords = (size_t)evs::kSrvSlots * 16, kSrvCtlWords = 32, kSrvAnsWords = (size_t)evs::kSrvSlots * evs::kSrvAnsLine + 16;
+constexpr size_t kSrvStatus = (size_t)evs::kSrvSlots * evs::kSrvAnsLine;   // the status line behind the answer ring
+// batch k of ring slot `slot` has been answered: every sub-counter's completer has written its number
+inline bool srv_answered(evs_rf_server *s, unsigned slot, unsigned k) {
+    volatile unsigned *a = s->mbox + kSrvReqWords + kSrvCtlWords + (size_t)slot * evs::kSrvAnsLine;
+    const unsigned n = s->slot_words[slot] ? s->slot_words[slot] : 1u;
+    for (unsigned r = 0; r < n; r++) if (a[r] != k) return false;
+    return true;
+}
 inline volatile unsigned *srv_req(evs_rf_server *s) { return s->mbox; }
 inline volatile unsigned *srv_ctl(evs_rf_server *s) { return s->mbox + kSrvReqWords; }
 inline volatile unsigned *srv_ans(evs_rf_server *s) { return s->mbox + kSrvReqWords + kSrvCtlWords; }
@@ -1373,7 +1384,7 @@ void srv_launch(evs_rf_server *s) {
     SrvArgs a;
     a.tmpl = s->tmpl_dev; a.st = s->st_dev;
     a.req = s->mbox_dev; a.ctl = s->mbox_dev + kSrvReqWords; a.ans = s->mbox_dev + kSrvReqWords + kSrvCtlWords;
-    a.start_seq = srv_ans(s)[kSrvSlots * 16 + 1];   // how far the last run got (0 at first)
+    a.start_seq = srv_ans(s)[kSrvStatus + 1];   // how far the last run got (0 at first)
     a.idle_ticks = s->idle_ticks;
     a.gen = ++s->gen;
     const dim3 grid((unsigned)s->n_blocks), block(256);
@@ -1470,8 +1481,10 @@ extern "C" int evs_emb_interact_serve_post(evs_rf_server *s, int64_t B, const fl
     if (k > (unsigned)kSrvSlots) {
         const unsigned prev = k - (unsigned)kSrvSlots;
         uint64_t t = prev;
-        if (ans[slot * 16] != prev) { const int rc = evs_emb_interact_serve_wait(s, t); if (rc) return rc; }
+        if (!srv_answered(s, slot, prev)) { const int rc = evs_emb_interact_serve_wait(s, t); if (rc) return rc; }
     }
+    {   const uint64_t n_chunks = (uint64_t)((B + 15) / 16);
+        s->slot_words[slot] = (unsigned)(n_chunks < 32 ? n_chunks : 32); }
     const unsigned long long px = (unsigned long long)reinterpret_cast<uintptr_t>(x), pi = (unsigned long long)reinterpret_cast<uintptr_t>(indices_base),
                              po = (unsigned long long)reinterpret_cast<uintptr_t>(offsets_base), pr = (unsigned long long)reinterpret_cast<uintptr_t>(R);
     req[0] = (unsigned)px; req[1] = (unsigned)(px >> 32); req[2] = (unsigned)pi; req[3] = (unsigned)(pi >> 32);
@@ -1484,7 +1497,7 @@ extern "C" int evs_emb_interact_serve_post(evs_rf_server *s, int64_t B, const fl
     s->posted = k;
     s->next_first = (unsigned)(((uint64_t)s->next_first + (uint64_t)((B + 15) / 16)) % (uint64_t)(1u << 30));
     *ticket = k;
-    if (ans[kSrvSlots * 16] == 0u) {   // nobody there (never started, or gone home idle): start the grid
+    if (ans[kSrvStatus] == 0u) {   // nobody there (never started, or gone home idle): start the grid
         const hipError_t q = hipStreamQuery(s->stream);
         if (q == hipSuccess) { srv_launch(s); if (hipGetLastError() != hipSuccess) { set_error("evs_emb_interact_serve_post: the grid could not be started"); return EVS_EHIP; } }
         else if (q != hipErrorNotReady) { (void)hipGetLastError(); return EVS_EHIP; }
@@ -1502,10 +1515,10 @@ extern "C" int evs_emb_interact_serve_wait(evs_rf_server *s, uint64_t ticket) {
     volatile unsigned *ans = srv_ans(s);
     const unsigned slot = (unsigned)(ticket % (unsigned)kSrvSlots);
     long long spins = 0;
-    while (ans[slot * 16] != (unsigned)ticket) {
-        if ((++spins & 255) == 0 && ans[kSrvSlots * 16] == 0u) {   // the grid has left (idle) with this batch still in the ring: start it again
+    while (!srv_answered(s, slot, (unsigned)ticket)) {
+        if ((++spins & 255) == 0 && ans[kSrvStatus] == 0u) {   // the grid has left (idle) with this batch still in the ring: start it again
             const hipError_t q = hipStreamQuery(s->stream);
-            if (q == hipSuccess) { if (ans[slot * 16] == (unsigned)ticket) break; srv_launch(s); if (hipGetLastError() != hipSuccess) return EVS_EHIP; }
+            if (q == hipSuccess) { if (srv_answered(s, slot, (unsigned)ticket)) break; srv_launch(s); if (hipGetLastError() != hipSuccess) return EVS_EHIP; }
             else if (q != hipErrorNotReady) { (void)hipGetLastError(); return EVS_EHIP; }
             else (void)hipGetLastError();
         }
