@@ -35,6 +35,15 @@ __global__ void __launch_bounds__(64) chase_wide_kernel(const unsigned *next, in
     if (i == 0xffffffffu) res[3] = 1;
     if (threadIdx.x == 0) res[0] = w1 - w0;
 }
+// what reading the 100 MHz clock itself costs (the stage probes read it ten times per request / batch)
+__global__ void __launch_bounds__(64) clock_cost_kernel(long long *res) {
+    const long long c0 = (long long)clock64();
+    long long acc = 0;
+    const long long w0 = (long long)wall_clock64();
+    for (int i = 0; i < 1000; i++) acc += (long long)wall_clock64();
+    const long long w1 = (long long)wall_clock64();
+    if (threadIdx.x == 0) { res[0] = w1 - w0; res[1] = (long long)clock64() - c0; res[2] = acc; }
+}
 __global__ void __launch_bounds__(256) heater_kernel(float *sink, const int *stop, long long max_ticks) {
     float a = (float)threadIdx.x, b = 1.0001f;
     const long long t0 = (long long)wall_clock64();
@@ -52,6 +61,9 @@ int main() {
     float *sink; CK(hipMalloc((void **)&sink, 64));
     hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     const char *scopes[] = {"plain load", "agent-scope load", "system-scope load"};
+    hipLaunchKernelGGL(clock_cost_kernel, dim3(1), dim3(64), 0, s1, res);
+    CK(hipStreamSynchronize(s1));
+    printf("one read of wall_clock64() (s_memrealtime + the wait for it): %.0f ns\n", res[0] * 10.0 / 1000);
     for (int heat = 0; heat < 2; heat++) {
         *stop = 0;
         if (heat) { hipLaunchKernelGGL(heater_kernel, dim3(255 * 4), dim3(256), 0, s2, sink, stop, 100000000ll * 20); CK(hipGetLastError()); }
