@@ -1147,10 +1147,27 @@ struct SrvState {
     // host takes the batch as answered when all of them hold it (the first form had a top counter the 32 completers arrived at:
     // one more dependent atomic round trip, ~1 us, in front of every answer)
     unsigned arrived[kSrvSlots][32][32];
+    unsigned prog[4096];                  // host-published front end: the last batch block b has looked at (kept across launches)
+};
+// HOST-PUBLISHED front end (round 6; parts whose device memory the host can address -- large BAR): the host writes a batch's
+// descriptor straight into device memory through the PCIe aperture -- into its slot of a descriptor ring and into the first half
+// of every replica line -- and every block's poll of its line is the whole way in: no leader reading the mailbox over the bus
+// and republishing (tools/mailbox_probe.hip: post -> 32 pollers -> arrival counter -> answer 3.0 us; the leader's hop alone
+// was ~3).  Fine-grained device memory (a poll of plain device memory is served by the polling XCD's L2 once the line is in it).
+//   line r, words 0..15   the descriptor of the LATEST batch posted; its guards (words 7, 15) are its number    [host, through the aperture]
+//           word 16       the launch number of a grid that is leaving                                           [the leader]
+//   line 0, word 18       the host's request to leave                                                           [host]
+// Nobody publishes "up to here" when the grid leaves -- the host posts whenever it likes, a block may have seen a batch the
+// leader has not --: every block keeps ITS OWN count of batches looked at (SrvState::prog), stores it on its way out, and its
+// successor in the next launch goes on from there; a batch is answered when every chunk has arrived, whichever launch ran it.
+struct SrvFront {
+    unsigned line[kSrvReplicas][32];
+    SrvDesc desc[kSrvSlots];
 };
 struct SrvArgs {
     const FusedArgs *tmpl;                // tables, shapes (device memory; written before the grid starts, never while it runs)
     SrvState *st;
+    SrvFront *front;                      // the host-published front end, or nullptr: the leader reads the mailbox in host memory
     volatile unsigned *req;               // request ring (device address of the mapped host block)
     volatile unsigned *ctl;               // word 0: stop
     volatile unsigned *ans;               // answer ring: kSrvSlots lines of kSrvAnsLine words (word r = the number of the batch whose sub-counter r is complete);
@@ -1232,13 +1249,41 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
     // what the block's wave 0 brought back from its poll: [0..63] descriptor words (leader: up to four new batches; worker: its
     // replica line -- number, stop word, the descriptor of batch `number`), [64] = batches to look at, [65] = leave afterwards
     __shared__ unsigned s_line[66];
-    const unsigned *my_line = &st->pub[me % (unsigned)kSrvReplicas][0];
-    unsigned my = sv.start_seq;      // the last batch this block has looked at
+    const bool hostpub = sv.front != nullptr;      // (grid-uniform)
+    const unsigned *my_line = hostpub ? &sv.front->line[me % (unsigned)kSrvReplicas][0] : &st->pub[me % (unsigned)kSrvReplicas][0];
+    // the last batch this block has looked at (host-published lines: its own count, kept in device memory across launches)
+    unsigned my = hostpub ? __hip_atomic_load(&st->prog[me & 4095u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : sv.start_seq;
     SrvPending pend{0u, 0u, 1u, 0u};
     bool have_pend = false;          // (block-uniform) chunks run, their stores possibly still on their way, not yet reported
     if (me == 0u && threadIdx.x == 0) __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * kSrvAnsLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // alive
     for (;;) {
-        if (threadIdx.x < 64) {
+        if (threadIdx.x < 64 && hostpub) {
+            // ---------------- host-published lines: every block's wave 0 at its line (the leader's too) ----------------
+            const long long t0 = (long long)wall_clock64();
+            unsigned v = 0u, n_new = 0u;
+            bool leave_now = false;
+            for (;;) {
+                v = __hip_atomic_load(my_line + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned g7 = (unsigned)__builtin_amdgcn_readlane((int)v, 7), g15 = (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+                const unsigned gn = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+                // the line's number: both guards (a line caught between its two halves' arrival shows nothing new yet)
+                const unsigned sq = (g7 == g15 && (int)(g7 - my) > 0) ? g7 : my;
+                if (sq != my) { n_new = sq - my; break; }
+                if (have_pend) break;     // nothing new, but chunks to report: the load above has returned, so have this wave's stores
+                if (gn == sv.gen) { leave_now = true; break; }       // the leader has gone (idle, or asked to): so does this block
+                if (me == 0u) {
+                    const unsigned stopreq = (unsigned)__builtin_amdgcn_readlane((int)v, 18);
+                    if (stopreq != 0u || (long long)wall_clock64() - t0 > sv.idle_ticks) {
+                        if (lane < kSrvReplicas) __hip_atomic_store(&sv.front->line[lane][16], sv.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        leave_now = true;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane < 16) s_line[lane] = v;       // the latest descriptor (the look below checks whose it is)
+            if (lane == 0) { s_line[64] = n_new; s_line[65] = leave_now ? 1u : 0u; }
+        } else if (threadIdx.x < 64) {
             if (me == 0u) {
                 // ---------------- the leader: wave 0 at the mailbox ----------------
                 const long long t0 = (long long)wall_clock64();
@@ -1302,19 +1347,23 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
             const unsigned k = my + 1u + g;
             unsigned w[16];
             bool have;
-            if (me == 0u || g + 1u == n_look) {     // the leader's own copies / the descriptor that came with the worker's line
+            if ((me == 0u && !hostpub) || g + 1u == n_look) {     // the leader's own copies / the descriptor that came with the line
 #pragma unroll
-                for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)s_line[(me == 0u ? 16 * g : 0) + i]);
+                for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)s_line[((me == 0u && !hostpub) ? 16 * g : 0) + i]);
                 have = w[7] == k && w[15] == k;
             } else have = false;
-            if (!have && me != 0u) {
+            if (!have && (me != 0u || hostpub)) {
                 // an earlier batch of a burst (or a line caught between its words and its number): the ring in device memory.  Its
                 // guards say which batch the slot holds: k -- take it (both guards, and the first again after the words: the loads
                 // return in order); an OLDER number -- the leader's copy is still on its way: read again; a LATER one -- this worker
                 // lags, batch k completed without it and the ring has come round: k owed it nothing (a batch is only answered,
                 // and its slot only reused, when every chunk of it has arrived).
-                const unsigned *dw = st->desc[k % (unsigned)kSrvSlots].w;
+                const unsigned *dw = hostpub ? sv.front->desc[k % (unsigned)kSrvSlots].w : st->desc[k % (unsigned)kSrvSlots].w;
                 for (int tries = 0; tries < (1 << 20); tries++) {
+                    if (hostpub) {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                    } else
 #pragma unroll
                     for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     if (w[7] == k && w[15] == k) { have = true; break; }     // (the leader writes a descriptor as ONE 64-byte store)
@@ -1340,9 +1389,10 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
         __syncthreads();
         if (threadIdx.x == 0) srv_arrive(sv, pend);
     }
+    if (hostpub && threadIdx.x == 0) __hip_atomic_store(&st->prog[me & 4095u], my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (me == 0u) {
         // leaving: every worker sees the stop word behind the last number; the host learns how far the grid got
-        if (threadIdx.x < kSrvReplicas) __hip_atomic_store(&st->pub[threadIdx.x][1], sv.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!hostpub && threadIdx.x < kSrvReplicas) __hip_atomic_store(&st->pub[threadIdx.x][1], sv.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (threadIdx.x == 0) {
             __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * kSrvAnsLine + 1, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(const_cast<unsigned *>(sv.ans) + kSrvSlots * kSrvAnsLine, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1356,6 +1406,7 @@ struct evs_rf_server {
     evs::FusedArgs tmpl{};
     evs::FusedArgs *tmpl_dev = nullptr;
     evs::SrvState *st_dev = nullptr;
+    evs::SrvFront *front = nullptr;  // host-published front end: fine-grained device memory the host writes through the aperture (same address on both sides), or nullptr
     unsigned *mbox = nullptr, *mbox_dev = nullptr;   // host block: request ring | control line | answer ring + status line
     hipStream_t stream = nullptr;
     unsigned posted = 0;            // the last sequence number posted
@@ -1382,7 +1433,7 @@ inline volatile unsigned *srv_ans(evs_rf_server *s) { return s->mbox + kSrvReqWo
 void srv_launch(evs_rf_server *s) {
     using namespace evs;
     SrvArgs a;
-    a.tmpl = s->tmpl_dev; a.st = s->st_dev;
+    a.tmpl = s->tmpl_dev; a.st = s->st_dev; a.front = s->front;
     a.req = s->mbox_dev; a.ctl = s->mbox_dev + kSrvReqWords; a.ans = s->mbox_dev + kSrvReqWords + kSrvCtlWords;
     a.start_seq = srv_ans(s)[kSrvStatus + 1];   // how far the last run got (0 at first)
     a.idle_ticks = s->idle_ticks;
@@ -1401,9 +1452,13 @@ int srv_pause(evs_rf_server *s) {
     if (!s->stream) return EVS_OK;
     if (hipStreamQuery(s->stream) == hipSuccess) return EVS_OK;
     (void)hipGetLastError();
-    srv_ctl(s)[0] = 1u;
+    // (the host-published front end: the request is a word of line 0, written through the aperture and never read back)
+    volatile unsigned *stop = s->front ? reinterpret_cast<volatile unsigned *>(&s->front->line[0][18]) : srv_ctl(s);
+    *stop = 1u;
+    __builtin_ia32_sfence();
     const hipError_t e = hipStreamSynchronize(s->stream);
-    srv_ctl(s)[0] = 0u;
+    *stop = 0u;
+    __builtin_ia32_sfence();
     return e == hipSuccess ? EVS_OK : EVS_EHIP;
 }
 }  // namespace
@@ -1450,6 +1505,18 @@ extern "C" int evs_emb_interact_serve_start(evs_rf_server **out, int T, int d, c
     if (hipMalloc(reinterpret_cast<void **>(&s->st_dev), sizeof(SrvState)) != hipSuccess) return fail(EVS_ENOMEM);
     if (hipMemcpy(s->tmpl_dev, &a, sizeof(FusedArgs), hipMemcpyHostToDevice) != hipSuccess) return fail(EVS_EHIP);
     if (hipMemset(s->st_dev, 0, sizeof(SrvState)) != hipSuccess) return fail(EVS_EHIP);
+    {   // The host-published front end where the host can address device memory (EVS_SERVE_PUBLISH=leader keeps the leader's
+        // mailbox: developer A/B, and what parts without a large BAR run)
+        const char *how = getenv("EVS_SERVE_PUBLISH");
+        int dev_id = 0, large_bar = 0;
+        if (!(how && !strcmp(how, "leader")) && s->n_blocks <= 4096 && hipGetDevice(&dev_id) == hipSuccess &&
+            hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_id) == hipSuccess && large_bar) {
+            void *p = nullptr;
+            if (hipExtMallocWithFlags(&p, sizeof(SrvFront), hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, sizeof(SrvFront)) == hipSuccess)
+                s->front = reinterpret_cast<SrvFront *>(p);
+            else { if (p) (void)hipFree(p); (void)hipGetLastError(); }
+        } else (void)hipGetLastError();
+    }
     const size_t words = kSrvReqWords + kSrvCtlWords + kSrvAnsWords;
     if (hipHostMalloc(reinterpret_cast<void **>(&s->mbox), words * 4, hipHostMallocMapped) != hipSuccess) return fail(EVS_ENOMEM);
     memset(s->mbox, 0, words * 4);
@@ -1487,6 +1554,21 @@ extern "C" int evs_emb_interact_serve_post(evs_rf_server *s, int64_t B, const fl
         s->slot_words[slot] = (unsigned)(n_chunks < 32 ? n_chunks : 32); }
     const unsigned long long px = (unsigned long long)reinterpret_cast<uintptr_t>(x), pi = (unsigned long long)reinterpret_cast<uintptr_t>(indices_base),
                              po = (unsigned long long)reinterpret_cast<uintptr_t>(offsets_base), pr = (unsigned long long)reinterpret_cast<uintptr_t>(R);
+    if (s->front) {
+        // host-published: the descriptor into its ring slot in DEVICE memory, then into the first half of every replica line --
+        // 64-byte lines written whole through the write-combining aperture (one bus write each), a store fence between the ring
+        // and the lines (a block that finds a number in its line reads the ring for the batches before it), nothing read back
+        const unsigned dsc[16] = {(unsigned)px, (unsigned)(px >> 32), (unsigned)pi, (unsigned)(pi >> 32), (unsigned)po, (unsigned)(po >> 32), (unsigned)B, k,
+                                  (unsigned)pr, (unsigned)(pr >> 32), (unsigned)x_stride, s->next_first, (unsigned)indices_row_stride, (unsigned)offsets_row_stride, 0u, k};
+        volatile unsigned *ring = reinterpret_cast<volatile unsigned *>(s->front->desc[slot].w);
+        for (int i = 0; i < 16; i++) ring[i] = dsc[i];
+        __builtin_ia32_sfence();
+        for (int r = 0; r < kSrvReplicas; r++) {
+            volatile unsigned *l = reinterpret_cast<volatile unsigned *>(s->front->line[r]);
+            for (int i = 0; i < 16; i++) l[i] = dsc[i];
+        }
+        __builtin_ia32_sfence();
+    } else {
     req[0] = (unsigned)px; req[1] = (unsigned)(px >> 32); req[2] = (unsigned)pi; req[3] = (unsigned)(pi >> 32);
     req[4] = (unsigned)po; req[5] = (unsigned)(po >> 32); req[6] = (unsigned)B;
     req[8] = (unsigned)pr; req[9] = (unsigned)(pr >> 32); req[10] = (unsigned)x_stride; req[11] = s->next_first;
@@ -1494,6 +1576,7 @@ extern "C" int evs_emb_interact_serve_post(evs_rf_server *s, int64_t B, const fl
     __atomic_thread_fence(__ATOMIC_RELEASE);
     req[7] = k; req[15] = k;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    }
     s->posted = k;
     s->next_first = (unsigned)(((uint64_t)s->next_first + (uint64_t)((B + 15) / 16)) % (uint64_t)(1u << 30));
     *ticket = k;
@@ -1542,6 +1625,7 @@ extern "C" int evs_emb_interact_serve_destroy(evs_rf_server *s) {
     if (s->mbox) (void)hipHostFree(s->mbox);
     if (s->tmpl_dev) (void)hipFree(s->tmpl_dev);
     if (s->st_dev) (void)hipFree(s->st_dev);
+    if (s->front) (void)hipFree(s->front);
     delete s;
     return EVS_OK;
 }

@@ -59,6 +59,60 @@ static double run(const char *name, volatile unsigned *req_host_view, const unsi
     return us[us.size() / 2];
 }
 
+// the dispatcher's case: a post = one 64-byte descriptor written into R lines of device memory (a replica line per group of
+// polling blocks) through the aperture; R blocks poll a line each and the LAST of them to see number k answers (an arrival counter)
+__global__ void __launch_bounds__(64) echo_lines_kernel(const unsigned *lines, unsigned *ctr, unsigned *ans, unsigned last, long long max_ticks) {
+    const unsigned *my = lines + (size_t)blockIdx.x * 32;     // 128-byte stride
+    const long long t0 = (long long)wall_clock64();
+    for (unsigned want = 1; want <= last; want++) {
+        unsigned v;
+        for (;;) {
+            v = __hip_atomic_load(my + (threadIdx.x & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((__ballot(v == want) & 0x8080ull) == 0x8080ull) break;         // both guards (words 7 and 15)
+            if ((long long)wall_clock64() - t0 > max_ticks) return;
+        }
+        if (threadIdx.x == 0) {
+            const unsigned before = atomicAdd(ctr + (want & 63u) * 32, 1u);
+            if (before + 1u == gridDim.x) { __hip_atomic_store(ctr + (want & 63u) * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* (a plain store stays in this XCD's L2) */ __hip_atomic_store(ans, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
+    }
+}
+static void run_lines(int R, int n) {
+    unsigned *lines = nullptr, *ctr = nullptr, *ans = nullptr;
+    // (fine-grained: a poll of plain hipMalloc memory is served by the polling XCD's L2 once the line is in it -- eight blocks on
+    //  eight XCDs never saw the second post)
+    CK(hipExtMallocWithFlags((void **)&lines, (size_t)R * 128, hipDeviceMallocFinegrained)); CK(hipMemset(lines, 0, (size_t)R * 128));
+    CK(hipMalloc((void **)&ctr, 64 * 128)); CK(hipMemset(ctr, 0, 64 * 128));
+    CK(hipHostMalloc((void **)&ans, 64, hipHostMallocMapped)); *ans = 0;
+    CK(hipDeviceSynchronize());
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipLaunchKernelGGL(echo_lines_kernel, dim3(R), dim3(64), 0, s, lines, ctr, ans, (unsigned)n, 100000000ll * 3);
+    CK(hipGetLastError());
+    std::vector<double> us((size_t)n), wr((size_t)n);
+    volatile unsigned *va = ans;
+    for (int k = 1; k <= n; k++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < R; r++) {
+            volatile unsigned *l = lines + (size_t)r * 32;
+            for (int w = 0; w < 16; w++) if (w != 7 && w != 15) l[w] = 0x1000u + (unsigned)w;
+            l[7] = (unsigned)k; l[15] = (unsigned)k;
+        }
+        __builtin_ia32_sfence();
+        const auto t1 = std::chrono::steady_clock::now();
+        bool lost = false;
+        while (*va != (unsigned)k) { if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1.0) { lost = true; break; } }
+        if (lost) { printf("%3d lines: post %d was never answered (the pollers do not see it)\n", R, k); break; }
+        us[(size_t)k - 1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        wr[(size_t)k - 1] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    }
+    CK(hipStreamSynchronize(s)); CK(hipStreamDestroy(s));
+    std::sort(us.begin(), us.end()); std::sort(wr.begin(), wr.end());
+    printf("%3d lines of 64 bytes written through the aperture per post: the writes p50 %.2f us; post -> all %d pollers arrived -> answer p50 %.2f us (p95 %.2f)\n",
+           R, wr[wr.size() / 2], R, us[us.size() / 2], us[us.size() * 95 / 100]);
+    fflush(stdout);
+    CK(hipFree(lines)); CK(hipFree(ctr)); CK(hipHostFree(ans));
+}
+
 static sigjmp_buf g_jmp;
 static void on_fault(int) { siglongjmp(g_jmp, 1); }
 static bool host_can_write(void *p) {     // a fault is an answer (the driver's mappings are not inherited by a child: probed in place)
@@ -92,6 +146,9 @@ int main(int argc, char **argv) {
         run(k.name, (volatile unsigned *)d, (const unsigned *)d, n);
         CK(hipFree(d));
     }
+    {   void *d = nullptr; CK(hipMalloc(&d, 4096));
+        if (host_can_write(d)) for (int R : {1, 8, 32, 33}) run_lines(R, n / 8);
+        CK(hipFree(d)); }
     CK(hipHostFree(h));
     return 0;
 }
