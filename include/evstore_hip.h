@@ -275,11 +275,13 @@ EVS_API int evs_emb_interact_dot_stacked_multi(int K, int64_t B, int T, int d, i
  * the latency half of the metric.  A launched-and-waited-for batch spends ~12 us outside its kernel (the launch call, the
  * dispatch of a thousand blocks, the completion signal), and below ~4 000 samples a launch IS that floor.  serve_start keeps
  * the tables (fp32, d in {16, 32, 36, 64}, T <= 27; HBM addresses as evs_emb_interact_dot_stacked takes them) and arms a grid
- * of n_blocks blocks (0 = 4 per CU) that starts with the first post and STAYS on the device: serve_post writes one 64-byte
- * descriptor into a ring in pinned host memory (no launch: ~1 us of host time) and returns a ticket, the grid's leader
- * wavefront republishes it on the device, every block runs the chunks that fall to it with the very body of the launched
- * kernel (same bits), R is written through to memory, the block that completes the batch writes the ticket into an answer
- * ring in host memory and serve_wait spins on that word.  Up to 64 batches may be in flight (a post blocks on the batch 64
+ * of n_blocks blocks (0 = 4 per CU, at most 4 096) that starts with the first post and STAYS on the device: serve_post writes
+ * one 64-byte descriptor (no launch: ~1 us of host time) and returns a ticket -- where the host can address device memory
+ * (large BAR) straight into the lines in device memory the blocks poll, through the PCIe aperture; elsewhere
+ * (or EVS_SERVE_PUBLISH=leader) into a ring in pinned host memory that the grid's leader wavefront reads over the bus and
+ * republishes on the device --, every block runs the chunks that fall to it with the very body of the launched kernel (same
+ * bits), R is written through to memory, the blocks that complete the batch's arrival counters write the ticket into an
+ * answer line in host memory and serve_wait spins on that.  Up to 64 batches may be in flight (a post blocks on the batch 64
  * tickets back); consecutive small batches land on different blocks and overlap.
  *   WHAT THE CALLER GUARANTEES: x / lS_i / lS_o of a batch are complete when it is posted (no stream orders a post), R may be
  *   read by anything STARTED after serve_wait has returned, and nothing else needs the GPU urgently while the grid is
