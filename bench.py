@@ -295,6 +295,7 @@ def sweep_numbers(E, ev, ln_emb, d, B, dev, dist):
     # waited for (p50_resident_ms_B*), and wall-clock time per batch of 2 000 batches posted back to back (ms_B*_resident)
     try:
         srv = E.InteractServer(ev, idle_us=200)
+        out["resident_host_published"] = 1 if srv.host_published else 0   # (1: descriptors through the PCIe aperture; 0: the leader's mailbox)
         for Bs in (1, 128, 2048, B):
             sb = make_batches(ln_emb, Bs, 32, seed=23 + Bs, device=dev, dist=dist)
             xs_ = torch.rand((Bs, d), device=dev)

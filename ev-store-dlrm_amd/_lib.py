@@ -92,6 +92,7 @@ _PROTOS = {
     "evs_emb_interact_serve_start": (_int, [C.POINTER(_vp), _int, _int, _pp, _i64p, _int, _int, _i64]),
     "evs_emb_interact_serve_post": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, C.POINTER(C.c_uint64)]),
     "evs_emb_interact_serve_wait": (_int, [_vp, C.c_uint64]),
+    "evs_emb_interact_serve_mode": (_int, [_vp]),
     "evs_emb_interact_serve_stop": (_int, [_vp]),
     "evs_emb_interact_serve_destroy": (_int, [_vp]),
     "evs_emb_interact_dot_stacked_multi": (_int, [_int, _i64, _int, _int, _int, _pp, _i64p, _pp, _i64, _pp, _i64, _i64, _pp, _i64, _int, _pp, _vp]),

@@ -23,6 +23,8 @@
 //
 // Row addresses need no cross-lane traffic here: the index tile in LDS has one row PER FEATURE (x and dense features
 // carry the sample number as their "index"), and a lane of the DMA mapping reads the tile entry of the row it fetches.
+#include <fcntl.h>
+#include <unistd.h>
 #include "evs_fused.h"
 
 #include <stdlib.h>
@@ -1447,6 +1449,16 @@ void srv_launch(evs_rf_server *s) {
     default: if (nt2) hipLaunchKernelGGL((emb_interact_rf_serve_kernel<4, 0, 2>), grid, block, 0, s->stream, a); else hipLaunchKernelGGL((emb_interact_rf_serve_kernel<4, 0, 1>), grid, block, 0, s->stream, a); break;
     }
 }
+// Can this process STORE to p?  The attribute says the part has a large BAR; whether this allocation is mapped writable here is
+// asked of the kernel, not found out by a fault: read(2) from /dev/zero INTO p copies four zero bytes to it, or fails with
+// EFAULT -- no signal either way (the block has just been zeroed: nothing changes).
+bool host_can_store(void *p) {
+    const int fd = open("/dev/zero", O_RDONLY);
+    if (fd < 0) return false;
+    const ssize_t n = read(fd, p, 4);
+    (void)close(fd);
+    return n == 4;
+}
 // send the grid home (it leaves by itself when idle) and wait until it has gone
 int srv_pause(evs_rf_server *s) {
     if (!s->stream) return EVS_OK;
@@ -1512,7 +1524,8 @@ extern "C" int evs_emb_interact_serve_start(evs_rf_server **out, int T, int d, c
         if (!(how && !strcmp(how, "leader")) && s->n_blocks <= 4096 && hipGetDevice(&dev_id) == hipSuccess &&
             hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_id) == hipSuccess && large_bar) {
             void *p = nullptr;
-            if (hipExtMallocWithFlags(&p, sizeof(SrvFront), hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, sizeof(SrvFront)) == hipSuccess)
+            if (hipExtMallocWithFlags(&p, sizeof(SrvFront), hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, sizeof(SrvFront)) == hipSuccess &&
+                hipDeviceSynchronize() == hipSuccess && host_can_store(p))
                 s->front = reinterpret_cast<SrvFront *>(p);
             else { if (p) (void)hipFree(p); (void)hipGetLastError(); }
         } else (void)hipGetLastError();
@@ -1611,6 +1624,9 @@ extern "C" int evs_emb_interact_serve_wait(evs_rf_server *s, uint64_t ticket) {
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return EVS_OK;
 }
+
+// 1: the host publishes descriptors through the PCIe aperture (large BAR); 0: the leader reads a mailbox in host memory
+extern "C" int evs_emb_interact_serve_mode(evs_rf_server *s) { return s && s->front ? 1 : 0; }
 
 extern "C" int evs_emb_interact_serve_stop(evs_rf_server *s) {
     EVS_REQUIRE(s, "evs_emb_interact_serve_stop: NULL server");

@@ -676,6 +676,9 @@ class InteractServer:
         with torch.cuda.device(ev.device):
             _lib.check(_lib.lib().evs_emb_interact_serve_start(C.byref(self._h), self.T, self.d, ev._tables_c, ev._n_rows_c,
                                                                int(bool(arch_interaction_itself)), int(n_blocks), int(idle_us)))
+        # True: the host writes descriptors through the PCIe aperture into the lines the blocks poll (large BAR); False: block 0
+        # reads a mailbox in pinned host memory and republishes (EVS_SERVE_PUBLISH=leader, or no large BAR)
+        self.host_published = bool(_lib.lib().evs_emb_interact_serve_mode(self._h))
         self._keep = {}       # ticket -> the tensors of a batch in flight (kept alive until it has been waited for)
         self._x = _ext.ext()
 

@@ -297,6 +297,8 @@ EVS_API int evs_emb_interact_serve_post(evs_rf_server *s, int64_t B, const float
                                         const int64_t *indices_base, int64_t indices_row_stride,
                                         const int64_t *offsets_base, int64_t offsets_row_stride, float *R, uint64_t *ticket);
 EVS_API int evs_emb_interact_serve_wait(evs_rf_server *s, uint64_t ticket);
+/* which front end this server runs: 1 = host-published (descriptors through the PCIe aperture), 0 = the leader's mailbox */
+EVS_API int evs_emb_interact_serve_mode(evs_rf_server *s);
 EVS_API int evs_emb_interact_serve_stop(evs_rf_server *s);
 EVS_API int evs_emb_interact_serve_destroy(evs_rf_server *s);
 /* SURVEY 8(f).3, second half: the apply_emb -> interact_features -> FIRST top-MLP layer chain of
