@@ -1138,7 +1138,13 @@ bool launch_rf(const FusedArgs &a, hipStream_t st) {
 // (post on the host after the producer's stream has been synchronised), and R may be read by anything started after evs_emb_interact_serve_wait has returned.
 constexpr int kSrvSlots = 64;
 constexpr int kSrvReplicas = 32;
-constexpr unsigned kSrvAnsLine = 32;      // words per slot of the answer ring: one per sub-counter of the batch's arrivals
+#ifndef EVS_SRV_SUB
+#define EVS_SRV_SUB 32
+#endif
+constexpr unsigned kSrvSub = EVS_SRV_SUB;         // sub-counters a batch's arrivals are spread over (a power of two; developer A/B: 128 -- a quarter of
+                                                  // the arrivals per counter, but 128 answer words written by 128 blocks for the host to collect -- 31.2 us
+                                                  // waited for at B = 16 384 against 26.0, 19.6 against 14.2 at B = 2 048; 8: 26.9 / 14.7)
+constexpr unsigned kSrvAnsLine = kSrvSub;  // words per slot of the answer ring: one per sub-counter of the batch's arrivals
 struct SrvDesc { unsigned w[16]; };   // w0-1 x, w2-3 idx, w4-5 off, w6 B, w7 seq | w8-9 R, w10 x_stride, w11 first block, w12 idx stride, w13 off stride, w14 -, w15 seq
 struct SrvState {
     unsigned pub[kSrvReplicas][32];       // line r: word 0 = the last published sequence number, word 1 = the generation (launch number) of the grid that has LEFT behind it
@@ -1148,7 +1154,7 @@ struct SrvState {
     // whoever completes sub-counter r writes the batch's number into word r of the slot's ANSWER line in host memory, and the
     // host takes the batch as answered when all of them hold it (the first form had a top counter the 32 completers arrived at:
     // one more dependent atomic round trip, ~1 us, in front of every answer)
-    unsigned arrived[kSrvSlots][32][32];
+    unsigned arrived[kSrvSlots][kSrvSub][32];
     unsigned prog[4096];                  // host-published front end: the last batch block b has looked at (kept across launches)
 };
 // HOST-PUBLISHED front end (round 6; parts whose device memory the host can address -- large BAR): the host writes a batch's
@@ -1202,7 +1208,7 @@ __device__ __forceinline__ void srv_arrive(const SrvArgs &sv, const SrvPending &
         return;
     }
     for (unsigned c = p.c0; c < n_chunks; c += p.step) {
-        const unsigned r = c & 31u, expect = (n_chunks >> 5) + (r < (n_chunks & 31u) ? 1u : 0u);
+        const unsigned r = c & (kSrvSub - 1u), expect = n_chunks / kSrvSub + (r < (n_chunks & (kSrvSub - 1u)) ? 1u : 0u);
         const unsigned before = __hip_atomic_fetch_add(&sv.st->arrived[slot][r][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (before + 1u == expect) {
             __hip_atomic_store(&sv.st->arrived[slot][r][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // back to zero for the slot's next use
@@ -1564,7 +1570,7 @@ extern "C" int evs_emb_interact_serve_post(evs_rf_server *s, int64_t B, const fl
         if (!srv_answered(s, slot, prev)) { const int rc = evs_emb_interact_serve_wait(s, t); if (rc) return rc; }
     }
     {   const uint64_t n_chunks = (uint64_t)((B + 15) / 16);
-        s->slot_words[slot] = (unsigned)(n_chunks < 32 ? n_chunks : 32); }
+        s->slot_words[slot] = (unsigned)(n_chunks < kSrvSub ? n_chunks : kSrvSub); }
     const unsigned long long px = (unsigned long long)reinterpret_cast<uintptr_t>(x), pi = (unsigned long long)reinterpret_cast<uintptr_t>(indices_base),
                              po = (unsigned long long)reinterpret_cast<uintptr_t>(offsets_base), pr = (unsigned long long)reinterpret_cast<uintptr_t>(R);
     if (s->front) {
