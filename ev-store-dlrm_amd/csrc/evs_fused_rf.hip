@@ -1362,18 +1362,18 @@ __global__ void __launch_bounds__(256, (CQ >= 4 ? 2 : EVS_RF_LB)) emb_interact_r
             } else have = false;
             if (!have && (me != 0u || hostpub)) {
                 // an earlier batch of a burst (or a line caught between its words and its number): the ring in device memory.  Its
-                // guards say which batch the slot holds: k -- take it (both guards, and the first again after the words: the loads
-                // return in order); an OLDER number -- the leader's copy is still on its way: read again; a LATER one -- this worker
+                // guards say which batch the slot holds: k -- take it (both guards); an OLDER number -- the leader's copy is still on its way: read again; a LATER one -- this worker
                 // lags, batch k completed without it and the ring has come round: k owed it nothing (a batch is only answered,
                 // and its slot only reused, when every chunk of it has arrived).
                 const unsigned *dw = hostpub ? sv.front->desc[k % (unsigned)kSrvSlots].w : st->desc[k % (unsigned)kSrvSlots].w;
                 for (int tries = 0; tries < (1 << 20); tries++) {
-                    if (hostpub) {
+                    // ONE load instruction for the sixteen words (lane = word): a 32-byte sector -- seven words and the guard behind
+                    // them -- is sampled at one time, so a guard that holds k vouches for the words in front of it (sixteen separate
+                    // loads could take words 0..6 before a write lands and the guard after it)
+                    const unsigned dv = hostpub ? __hip_atomic_load(dw + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                : __hip_atomic_load(dw + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                        for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-                    } else
-#pragma unroll
-                    for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(dw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    for (int i = 0; i < 16; i++) w[i] = (unsigned)__builtin_amdgcn_readlane((int)dv, i);
                     if (w[7] == k && w[15] == k) { have = true; break; }     // (the leader writes a descriptor as ONE 64-byte store)
                     if ((int)(w[7] - k) > 0 || (int)(w[15] - k) > 0) break;    // overwritten by a later batch
                 }
