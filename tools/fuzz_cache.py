@@ -36,22 +36,28 @@ def _stream(rs, n_rows, n_req):
 
 def exact_case(rs, case):
     T = int(rs.choice([1, 2, 5, 13, 26, 26, 26, 40]))
-    d = int(rs.choice([4, 16, 36, 36, 64]))
+    codec = int(rs.choice([32, 32, 32, 16, 8, 4]))          # (round 6: the one-tier reduced-precision builds too -- rows of 18 .. 256 bytes)
+    d = int(rs.choice([4, 16, 36, 36, 64] if codec == 4 else [4, 5, 9, 16, 36, 36, 64]))   # (5, 9: rows that are no multiple of 16 bytes)
     n_rows = [int(rs.choice([1, 3, 20, 200, 3000])) for _ in range(T)]
     policy = rs.choice(["evlfu", "evlfu", "evlfu", "lru", "lfu"])
     variant = rs.choice(["python", "cpp", "cython"]) if policy == "evlfu" else "python"
     cap = int(rs.choice([1, 2, 7, T, 3 * T, 64, 500, 5000]))
     n_req = int(rs.choice([1, 10, 200, 1200]))
     approx = int(rs.choice([-1, -1, -1, max(1, T // 2), T])) if policy == "evlfu" and variant == "python" else -1
-    tag = "exact case %d: %s/%s T=%d d=%d cap=%d n_req=%d approx=%d rows=%s" % (case, policy, variant, T, d, cap, n_req, approx, n_rows[:6])
-    tabs = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in n_rows]
-    reqs = _stream(rs, n_rows, n_req)
-    if policy == "evlfu":
-        o = orc.EvLFU(cap, tabs, d, variant)
-    elif policy == "lru":
-        o = orc.LRU(cap, tabs, d)
+    tag = "exact case %d: %s/%s T=%d d=%d codec=%d cap=%d n_req=%d approx=%d rows=%s" % (case, policy, variant, T, d, codec, cap, n_req, approx, n_rows[:6])
+    ws = [rs.uniform(-1, 1, size=(n, d)).astype(np.float32) for n in n_rows]
+    if codec == 32:
+        raws, tabs = ws, ws
     else:
-        o = orc.LFU(cap, tabs, d)
+        raws = [orc.encode_table(w, codec) for w in ws]
+        tabs = [orc.decode(r, codec, d) for r in raws]
+    reqs = _stream(rs, n_rows, n_req)
+
+    def oracle():
+        if policy == "evlfu":
+            return orc.EvLFU(cap, tabs, d, variant)
+        return orc.LRU(cap, tabs, d) if policy == "lru" else orc.LFU(cap, tabs, d)
+    o = oracle()
     if approx > 0:
         return tag + " (skipped: approx mode draws random vectors in the reference)"
     want_h, want_o = [], []
@@ -61,8 +67,10 @@ def exact_case(rs, case):
             want_h.append(h.copy()); want_o.append(out.copy())
     except RuntimeError:
         return tag + " (skipped: the reference raises on this stream)"
-    c = E.GpuCache(policy, cap, T, d, 32, variant)
-    c.set_backing([torch.from_numpy(t).cuda() for t in tabs])
+    want_h, want_o = np.stack(want_h), np.stack(want_o)
+    backing = [torch.from_numpy(np.ascontiguousarray(t)).cuda() for t in raws]
+    c = E.GpuCache(policy, cap, T, d, codec, variant)
+    c.set_backing(backing)
     r = torch.from_numpy(reqs).cuda()
     chunk = int(rs.choice([1, 3, 64, 5000]))
     hits, outs = [], []
@@ -70,15 +78,51 @@ def exact_case(rs, case):
         h, out = c.request(r[s:s + chunk].contiguous(), approx)
         hits.append(h.cpu().numpy().astype(bool)); outs.append(out.cpu().numpy())
     hits, outs = np.concatenate(hits), np.concatenate(outs)
-    assert np.array_equal(hits, np.stack(want_h)), tag + ": hit flags"
-    assert np.array_equal(outs.view(np.uint32), np.stack(want_o).view(np.uint32)), tag + ": rows"
-    got = c.dump()
-    if policy == "lru":
-        got = got[:, 1:]   # the GPU dump carries a (constant) priority column for LRU
-    assert np.array_equal(got, o.dump()), tag + ": final lists"
-    if policy == "evlfu":
-        st, so = c.stats(), o.state()
-        assert [st["min_c1"], st["n_perfect"], st["size"], st["n_flush"]] == [so["min_c1"], so["n_perfect"], so["size"], so["n_flush"]], tag + ": state"
+    assert np.array_equal(hits, want_h), tag + ": hit flags"
+    assert np.array_equal(outs.view(np.uint32), want_o.view(np.uint32)), tag + ": rows"
+
+    def final_state(cc, what):
+        got = cc.dump()
+        if policy == "lru":
+            got = got[:, 1:]   # the GPU dump carries a (constant) priority column for LRU
+        assert np.array_equal(got, o.dump()), tag + ": final lists" + what
+        if policy == "evlfu":
+            st, so = cc.stats(), o.state()
+            assert [st["min_c1"], st["n_perfect"], st["size"], st["n_flush"]] == [so["min_c1"], so["n_perfect"], so["size"], so["n_flush"]], tag + ": state" + what
+    final_state(c, "")
+    # round 6: the same stream through the RESIDENT SERVER of a second cache -- rows into a ring slot, into a buffer of the caller's
+    # (evs_cache_serve_request_to), ids by value or by address, a launch-per-request call and an idle gap in between
+    if T <= 28 and n_req <= 200:
+        c2 = E.GpuCache(policy, cap, T, d, codec, variant)
+        c2.set_backing(backing)
+        c2.serve_start(approx, n_slots=int(rs.choice([1, 2, 5])), idle_us=int(rs.choice([30, 300])))
+        for i, rq in enumerate(reqs):
+            way = int(rs.randint(0, 5)) if T <= 26 else int(rs.choice([0, 3, 4]))
+            if way == 0:
+                h, rows = c2.serve_request(rq)
+                rows = rows.clone()
+            elif way == 1:
+                rows = torch.full((T, d), -7.0, dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                h = c2.serve_request_to(rq, rows)
+            elif way == 2:
+                ids = torch.from_numpy(np.stack([rq.astype(np.int64), np.full(T, -3, np.int64)], 1)).cuda()
+                rows = torch.full((T, d), -7.0, dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                h = c2.serve_request_to(ids, rows)
+            elif way == 3:
+                hh, rows = c2.request(r[i:i + 1].contiguous(), approx)      # (sends the server home first)
+                h = hh[0].cpu().numpy()
+                rows = rows[0]
+            else:
+                import time
+                time.sleep(0.0005)
+                h, rows = c2.serve_request(rq)
+                rows = rows.clone()
+            assert np.array_equal(np.asarray(h).astype(bool), want_h[i]), tag + ": server hit flags, request %d way %d" % (i, way)
+            assert np.array_equal(rows.cpu().numpy().view(np.uint32), want_o[i].view(np.uint32)), tag + ": server rows, request %d way %d" % (i, way)
+        c2.serve_stop()
+        final_state(c2, " (server)")
     return tag
 
 
