@@ -405,6 +405,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
         EVS_TICK(0);                    // (waiting for / reading the request)
         unsigned char my_flag = 0;      // this lane's table: the hit flag of the request in hand
         bool churn = true;              // an insert of this request may have evicted / flushed entries (LRU / LFU: always assumed)
+        bool rows_known = false;        // (wave-uniform) s_rowp has been written by the policy step itself: the resolve step below is skipped
         if (lane < T) s_req[lane] = row;
         const unsigned long long key = ((unsigned long long)(lane + 1) << 32) | (unsigned)row;
         const bool row_ok = lane < T && row >= 0 && row < s_brows[lane < T ? lane : 0];
@@ -546,6 +547,11 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
                     if (n_app) h.len[agg_hit] += n_app;
                     if (n_miss) { h.n_free -= n_miss; h.count += n_miss; if (agg_hit < h.min_c1) h.min_c1 = agg_hit; }
                 }
+                // every lane knows where its row comes from -- a hit's entry (moved or not: nothing is evicted on this path), a
+                // miss's table row, nothing for an id out of range: the very address warmed above -- so the resolve step's chain of
+                // dependent LDS reads (source, request row, table base: 0.4 us) is not needed
+                if (lane < T) s_rowp[lane] = row_ok ? warm_p : nullptr;
+                rows_known = true;
                 work = 0ull;
             }
             int last_hit_table = -1;
@@ -720,7 +726,7 @@ __device__ __forceinline__ void cache_exact_body(const CacheArgs &args, const Se
 #if EVS_X_EXACT_STOP == 3
         return;
 #endif
-        if (lane < T) {   // lane i resolves where row i comes from ...
+        if (!rows_known && lane < T) {   // lane i resolves where row i comes from ...
             const int i = lane;
             int src = s_src[i];
             int tsrc = i;
