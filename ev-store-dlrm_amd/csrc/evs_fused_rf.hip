@@ -92,10 +92,22 @@ struct RfServeDesc {
     const float *x; const int64_t *idx; const int64_t *off; float *R;
     int64_t B, x_stride, idx_stride, off_stride;
 };
+#ifdef EVS_X_PT   // developer instrumentation (tools/probe_stage_probe.py): per block, 100 MHz ticks from the block's entry to stage k, summed over launches
+__device__ unsigned long long g_pt[1024][16];     // (a row per block: launches do not overlap, a block adds to its own words)
+#define EVS_PT(k) do { if (threadIdx.x == 0) g_pt[blockIdx.x & 1023][k] += (unsigned long long)((long long)wall_clock64() - pt_t0); } while (0)
+#define EVS_PTW(k) do { __builtin_amdgcn_s_waitcnt(0x0F70); EVS_PT(k); } while (0)     // behind everything this wave has asked for
+#else
+#define EVS_PT(k) do { } while (0)
+#define EVS_PTW(k) do { } while (0)
+#endif
 template <int CQ, int REM, int NT, int D, bool MLP, bool IDS, bool PROBE, bool CHECK, bool SERVE>
 __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *ka, const RfServeDesc &sd, const int blk_in, const bool srv_first = false) {
     static_assert(!CHECK || (!MLP && !IDS && !PROBE), "the offsets check belongs to the plain launch");
     static_assert(!SERVE || (CHECK && !MLP && !IDS && !PROBE), "the resident form serves the drop-in call (lS_o given)");
+#ifdef EVS_X_PT
+    const long long pt_t0 = (long long)wall_clock64();
+    if (threadIdx.x == 0) g_pt[blockIdx.x & 1023][15] += 1ull;
+#endif
 #ifndef EVS_X_SRV
 #define EVS_X_SRV 0     // developer A/B of the resident form (timing only): 2 = R stores without sc1, 4 = workers sleep longer between polls
 #endif
@@ -614,6 +626,7 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
             const int *rp = pact[h] ? pa.requests + bs * (int64_t)T + (f - 1) : reinterpret_cast<const int *>(dummy_i);
             prow[h] = *reinterpret_cast<const __attribute__((address_space(1))) int *>(reinterpret_cast<uintptr_t>(rp));
         }
+        EVS_PTW(1);          // (the request rows are here)
         unsigned lw[2][8];   // the two keys' set ways (kept for the claim of a missed key)
         const bool sa = pa.sa.tags != nullptr;   // set-associative cache (evs_hash.h): one line per key, the priority inside the way word
 #pragma unroll
@@ -637,6 +650,7 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
 #pragma unroll
             for (int h = 0; h < 2; h++) sa_load<8>(pa.sa, pset[h], line[h]);
             __builtin_amdgcn_sched_barrier(0);   // both keys' set lines in one round trip
+            EVS_PTW(2);          // (the set lines are here)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 unsigned w;
@@ -682,6 +696,7 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
         }
         }
         __syncthreads();
+        EVS_PT(3);
         const int agg = s_agg[tid_x & 15];
         // a missed key's claim: duplicate / victim / the CAS sent here, looked at behind the raises below (one round trip for both).
         // (Looked at behind the ROW requests instead -- the claim kept across them, block barriers that order LDS only -- was
@@ -699,6 +714,7 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
             for (int h = 0; h < 2; h++)
                 if (pok[h] && pe[h] < 0 && !(pa.xflags & 2)) uwait[h] = sa_claim_issue(pa.sa, pa.pend_stamp, phint[h], ptag[h], agg, lw[h], upk[h], uprev[h], s_udelta);
         }
+        EVS_PT(10);          // (the claims are ranked and sent)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int f = ((int)tid_x >> 4) + 16 * h;
@@ -728,7 +744,9 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
             }
             if (f == 1 && bs < blk_end) { atomicAdd(&s_psum[0], agg); if (agg == T) atomicAdd(&s_psum[1], 1); }
         }
+        EVS_PT(11);          // (raises done, claims looked at, the tile written)
         __syncthreads();
+        EVS_PT(12);
         if (tid_x < 40) {   // the block's totals into one of the replica rows (folded by the cache's close)
             const int i = tid_x;
             const int v = i <= T ? s_pdelta[i] : i == 38 ? s_psum[0] : i == 39 ? s_psum[1] : 0;
@@ -740,6 +758,7 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
             if (v) atomicAdd(&pa.part2[(blockIdx.x % 32) * 40 + i], v);
         }
         if (pa.list_cnt != nullptr && tid_x == 0) pa.list_cnt[blockIdx.x] = s_nlist;
+        EVS_PTW(5);          // (everything the head has sent is answered; the head is over)
     } else {
         if (!stk) tile_load(0);
         tile_store(0);
@@ -750,6 +769,7 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
                 return;
             }
             bad |= fast_bad;
+            EVS_PT(5);
         } else {
             __syncthreads();
         }
@@ -783,6 +803,7 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
     // (16 waves per CU start in step: every instruction in front of the first load is paid by all of them at once)
     fill_stage();
     fill_flush();
+    EVS_PT(6);               // (the row requests are out)
     const bool ins_blk = PROBE && args.probe.arena_w != nullptr && !(args.probe.xflags & 1);   // block-uniform: missed keys' rows go into the cache arena on the way
 #pragma unroll
     for (int u = 0; u < D; u++) {
@@ -870,6 +891,8 @@ __device__ __forceinline__ void rf_body(const FusedArgs &args, const FusedArgs *
     }
     if constexpr (MLP) my_out = s_out[wave_in_block + 12];
     flush_out(blk_first + wave_in_block + 12, n_samples == 4);
+    EVS_PT(8);               // (wave 0's last stores are out)
+    EVS_PTW(9);              // (... and acknowledged)
     if (bad) atomicOr(args.err, 1);
     if constexpr (MLP) {
         __syncthreads();   // the chunk's 16 staged rows are complete
@@ -1652,6 +1675,16 @@ extern "C" int evs_emb_interact_serve_destroy(evs_rf_server *s) {
     return EVS_OK;
 }
 
+#ifdef EVS_X_PT
+extern "C" __attribute__((visibility("default"))) int evs_x_pt(unsigned long long *out, int reset) {   // out: 16 (summed over the blocks)
+    static unsigned long long h[1024 * 16], z[1024 * 16];
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(evs::g_pt), sizeof h) != hipSuccess) return -2;
+    if (out) for (int k = 0; k < 16; k++) { out[k] = 0; for (int b = 0; b < 1024; b++) out[k] += h[b * 16 + k]; }
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(evs::g_pt), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+#endif
 #ifdef EVS_X_LOG
 // developer tool (tools/dbg_inline.py): the event log of the folded update -- (type, word address, old word, new word)
 extern "C" __attribute__((visibility("default"))) long long evs_x_log_fetch(unsigned long long *out, long long max_events, int reset) {
