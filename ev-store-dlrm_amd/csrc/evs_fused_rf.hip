@@ -967,10 +967,19 @@ static unsigned rf_pad_lds() {
     if (v < 0) { const char *e = getenv("EVS_FUSED_RF_PADLDS"); v = e ? atoi(e) : 0; }
     return (unsigned)v;
 }
+// developer switch: samples per block (16: one generation of co-resident blocks at B = 16 384; 8 / 4: the grid arrives in two / four
+// generations whose heads and bodies can overlap -- the per-block timeline of tools/probe_stage_probe.py asked for the experiment.
+// Measured on the plain launch, B = 16 384: 19.2 us at 16, 28.8 at 8, 48.7 at 4 -- a block's head and its half-empty waves cost
+// far more than the overlap returns.  Plain launches only: the cache tier's per-block buffers are sized for 16.)
+static int rf_tile_per() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("EVS_FUSED_RF_TILE"); v = e ? atoi(e) : 16; if (v != 4 && v != 8 && v != 12) v = 16; }
+    return v;
+}
 template <auto K>
 static void launch_rf_grid(FusedArgs a, hipStream_t st) {
-    a.tile_per = 16;   // one 16-sample chunk per block: 4 samples per wave, all requested at once
-    hipLaunchKernelGGL(K, dim3((unsigned)((a.B + 15) / 16)), dim3(256), rf_pad_lds(), st, a);
+    a.tile_per = rf_tile_per();   // (default 16) one 16-sample chunk per block: 4 samples per wave, all requested at once
+    hipLaunchKernelGGL(K, dim3((unsigned)((a.B + a.tile_per - 1) / a.tile_per)), dim3(256), rf_pad_lds(), st, a);
 }
 
 // the batch sizes this form is for: every block resident at once (4 blocks of 256 threads per CU at 128 VGPRs)
