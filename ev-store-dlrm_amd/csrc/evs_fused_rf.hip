@@ -969,8 +969,10 @@ static unsigned rf_pad_lds() {
 }
 // developer switch: samples per block (16: one generation of co-resident blocks at B = 16 384; 8 / 4: the grid arrives in two / four
 // generations whose heads and bodies can overlap -- the per-block timeline of tools/probe_stage_probe.py asked for the experiment.
-// Measured on the plain launch, B = 16 384: 19.2 us at 16, 28.8 at 8, 48.7 at 4 -- a block's head and its half-empty waves cost
-// far more than the overlap returns.  Plain launches only: the cache tier's per-block buffers are sized for 16.)
+// Measured on the plain launch, B = 16 384: 19.2 us at 16, 28.8 at 8, 48.7 at 4 -- but a wave still issues four samples' worth of
+// requests (the missing ones against the zero page; the body does not build at a depth of 2), so this prices a block's fixed cost,
+// not two generations as such: EVS_FUSED_RF_PADLDS -- the same blocks, fewer per CU -- is the fair form of that question.
+// Plain launches only: the cache tier's per-block buffers are sized for 16.)
 static int rf_tile_per() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("EVS_FUSED_RF_TILE"); v = e ? atoi(e) : 16; if (v != 4 && v != 8 && v != 12) v = 16; }
